@@ -1,0 +1,1848 @@
+/*
+ * hry_oracle.cc -- CPU ORACLE: single-threaded restatement of the reference .hry v0.1 codec.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (harry_amd/) links, loads or calls this file.
+ * It exists so that every HIP kernel and the host-side walk of the product can be checked, bit for bit,
+ * against the behaviour of maxvonbuelow/harry (reference mounted at /root/reference in the build
+ * container).  Pinning: tests/test_oracle_golden.py compares this restatement with .hry files and decoded
+ * meshes produced by the unmodified reference binary (tests/golden/, generator tests/golden/make_golden.py)
+ * and, where /root/reference exists, with oracle/_ref/harry_ref run live.
+ *
+ * Every block cites the reference file:line whose behaviour it restates.  The code is written from the
+ * behavioural description, not transcribed: flat half-edge ids instead of (face,
+ * edge) pairs, explicit typed dispatch instead of the visitor templates, one translation unit.
+ */
+#include "hry_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <list>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace ho {
+
+// ------------------------------------------------------------------------------------------------
+// Component types (structs/mixing.h:18-19)
+// ------------------------------------------------------------------------------------------------
+enum Type : uint8_t { T_FLOAT, T_DOUBLE, T_ULONG, T_LONG, T_UINT, T_INT, T_USHORT, T_SHORT, T_UCHAR, T_CHAR, T_NONE };
+static const int TSIZE[11] = { 4, 8, 8, 8, 4, 4, 2, 2, 1, 1, 0 };
+enum { I_POS = 0, I_NORMAL = 1, I_COLOR = 2, I_COLOR_AMBIENT = 3, I_COLOR_DIFFUSE = 4, I_COLOR_SPECULAR = 5,
+       I_TEX = 16, I_SCALE = 17, I_CONFIDENCE = 18, I_OTHER = 19 };
+enum Target { TG_FACE, TG_VTX, TG_CORNER, TG_NONE };
+
+static Type quant_type(int q)   // structs/mixing.h:101-108
+{
+	if (q <= 8) return T_UCHAR;
+	if (q <= 16) return T_USHORT;
+	if (q <= 32) return T_UINT;
+	if (q <= 64) return T_ULONG;
+	return T_NONE;
+}
+
+// record format: component types, quantisation bits, storage types, slot offsets (structs/mixing.h:41-99).
+// Slot offsets depend on the ORIGINAL type only (mixing.h:60), so a quantised value lives in the low bytes.
+struct Fmt {
+	std::vector<Type> type, stype;
+	std::vector<int> quant, off{0};
+	void add(Type t, int q = 0)
+	{
+		type.push_back(t);
+		quant.push_back(q);
+		stype.push_back(q == 0 ? t : quant_type(q));
+		off.push_back(off.back() + TSIZE[t]);
+	}
+	void setquant(int i, int q) { quant[i] = q; stype[i] = q == 0 ? type[i] : quant_type(q); }
+	int size() const { return (int)type.size(); }
+	int bytes() const { return off.back(); }
+};
+
+struct Interps {   // structs/mixing.h:139-200
+	std::vector<int> off, len;
+	std::vector<std::string> names;
+	void append(int interp, int o)
+	{
+		if (interp >= (int)off.size()) {
+			off.resize(interp + 1, -1);
+			len.resize(interp + 1, 0);
+			if (interp >= I_OTHER) names.resize(interp - I_OTHER + 1, "");
+		}
+		if (off[interp] == -1) off[interp] = o;
+		++len[interp];
+	}
+	void describe(int interp, const std::string &name)
+	{
+		int id = interp - I_OTHER;
+		if (id < 0) return;
+		if (id >= (int)names.size()) names.resize(id + 1, "");
+		names[id] = name;
+	}
+	int size() const { return (int)off.size(); }
+};
+
+struct List {   // structs/attr.h:24-99
+	Fmt fmt;
+	Interps interps;
+	int target = TG_NONE;
+	uint32_t count = 0;
+	std::vector<uint8_t> data;          // count * fmt.bytes()
+	std::vector<uint8_t> bmin, bmax;    // records in the dequantised (original) types
+	uint8_t *rec(uint32_t i) { return data.data() + (size_t)i * fmt.bytes(); }
+	const uint8_t *rec(uint32_t i) const { return data.data() + (size_t)i * fmt.bytes(); }
+};
+
+typedef uint32_t he_t;   // flat half-edge id = face_offset[f] + local edge
+
+struct Mesh {
+	// connectivity (structs/conn.h:72-170, structs/faces.h:18-98)
+	std::vector<uint32_t> foff{0};
+	std::vector<uint32_t> org;
+	std::vector<he_t> twin;
+	std::vector<uint32_t> eface;
+	std::vector<char> have_deg;
+	uint32_t conn_nv = 0;
+	// attributes + bindings (structs/attr.h:101-189); the oracle supports what the PLY reader creates:
+	// one face region bound to list 0, one vertex region bound to list 1, identity element->attribute maps
+	std::vector<List> lists;
+	uint32_t nv = 0, nf = 0;
+
+	uint32_t add_face(int ne)   // conn.h:83-93
+	{
+		uint32_t f = (uint32_t)foff.size() - 1;
+		uint32_t o = foff.back();
+		foff.push_back(o + ne);
+		if (ne >= (int)have_deg.size()) have_deg.resize(ne + 1, 0);
+		have_deg[ne] = 1;
+		org.resize(o + ne, 0);
+		twin.resize(o + ne);
+		eface.resize(o + ne, f);
+		for (int i = 0; i < ne; ++i) twin[o + i] = o + i;
+		return f;
+	}
+	void set_org(he_t e, uint32_t v) { org[e] = v; conn_nv = std::max(conn_nv, v + 1); }
+	int deg(uint32_t f) const { return (int)(foff[f + 1] - foff[f]); }
+	he_t next(he_t e) const { uint32_t f = eface[e]; return e + 1 == foff[f + 1] ? foff[f] : e + 1; }
+	he_t prev(he_t e) const { uint32_t f = eface[e]; return e == foff[f] ? foff[f + 1] - 1 : e - 1; }
+	uint32_t dest(he_t e) const { return org[next(e)]; }
+	void merge(he_t a, he_t b) { twin[a] = b; twin[b] = a; }   // conn.h:161-165 (a==b makes a border)
+	uint32_t num_face() const { return (uint32_t)foff.size() - 1; }
+	uint32_t num_edge() const { return foff.back(); }
+	uint64_t num_tri() const { return (uint64_t)foff.back() - 2ull * num_face(); }
+};
+
+static std::string g_err;
+
+// ------------------------------------------------------------------------------------------------
+// typed scalar helpers: float<->ordered int, residual folding, predictor
+// (formats/hry/transform.h:19-48, formats/hry/prediction.h:21-147)
+// ------------------------------------------------------------------------------------------------
+template <int S> struct ints;
+template <> struct ints<1> { typedef int8_t s; typedef uint8_t u; };
+template <> struct ints<2> { typedef int16_t s; typedef uint16_t u; };
+template <> struct ints<4> { typedef int32_t s; typedef uint32_t u; };
+template <> struct ints<8> { typedef int64_t s; typedef uint64_t u; };
+
+template <typename T, typename U> static inline U bitcast(T v) { U r; static_assert(sizeof(T) == sizeof(U), ""); memcpy(&r, &v, sizeof(U)); return r; }
+
+// transform.h:19-23: i ^ ((-(unsigned(i) >> msb)) >> 1): negative floats get their low bits inverted
+template <int S> static inline typename ints<S>::s flip_float_bits(typename ints<S>::s i)
+{
+	typedef typename ints<S>::u U;
+	U sign = (U)((U)i >> (S * 8 - 1));
+	U m = (U)((U)(0 - sign) >> 1);
+	return (typename ints<S>::s)((U)i ^ m);
+}
+
+// prediction.h:33-44: the sign-flip table is indexed with sizeof(T) instead of sizeof(T)-1, so the mask that is
+// applied to 4-byte types is ZERO.  8-byte types read past the table: unsupported here.
+template <typename T> static inline uint64_t signmask_as_indexed()
+{
+	static const uint64_t tbl[8] = { 0x80ull, 0x8000ull, 0, 0x80000000ull, 0, 0, 0, 0x8000000000000000ull };
+	if (sizeof(T) >= 8) throw std::runtime_error("oracle: lossless residuals of 8-byte floating types are unspecified in the reference (prediction.h:33-44)");
+	return tbl[sizeof(T)];
+}
+
+template <typename T> static inline int bits_of(int q) { return q == 0 ? (int)sizeof(T) * 8 : q; }   // prediction.h:21-25
+template <typename T> static inline T low_mask(int bits)   // prediction.h:27-31
+{
+	return bits == (int)(sizeof(T) << 3) ? T(-1) : T((1 << bits) - 1);
+}
+
+// prediction.h:81-99 (integral form).  The expressions keep the reference's C++ types so that integer
+// promotion/truncation behaves identically for 1-, 2-, 4- and 8-byte T.
+template <typename T> static T fold_residual_int(const T raw, const T pred, int bits)
+{
+	const T max_pos = low_mask<T>(bits) - pred;
+	if (pred == T(0)) return raw;
+	const T balanced_max = std::min(T(pred), max_pos);
+	if (raw < pred) {
+		const T dlt = pred - raw;
+		if (dlt > balanced_max) return dlt + balanced_max;
+		return T(dlt << 1) - 1;
+	} else {
+		const T dlt = raw - pred;
+		if (dlt > balanced_max) return dlt + balanced_max;
+		return T(dlt << 1);
+	}
+}
+// prediction.h:46-64
+template <typename T> static T unfold_residual_int(const T delta, const T pred, int bits)
+{
+	const T sel[2] = { T(0), T(~T(0)) };
+	const T max_pos = low_mask<T>(bits) - pred;
+	if (pred == T(0)) return delta;
+	const T balanced_max = std::min(T(pred - T(1)), max_pos);
+	if ((delta >> 1) > balanced_max) {
+		if (max_pos >= pred) return pred + delta - balanced_max - T(1);
+		else return pred - delta + balanced_max;
+	}
+	return pred + (T(delta >> 1) ^ sel[delta & 1]);
+}
+template <typename T> static T fold_residual(const T raw, const T pred, int q, std::false_type) { return fold_residual_int<T>(raw, pred, bits_of<T>(q)); }
+template <typename T> static T unfold_residual(const T d, const T pred, int q, std::false_type) { return unfold_residual_int<T>(d, pred, bits_of<T>(q)); }
+// prediction.h:101-113 / 65-73: floats are mapped to order-preserving ints first
+template <typename T> static T fold_residual(const T raw, const T pred, int q, std::true_type)
+{
+	typedef typename ints<sizeof(T)>::s S;
+	typedef typename ints<sizeof(T)>::u U;
+	U m = (U)signmask_as_indexed<T>();
+	U p = (U)flip_float_bits<sizeof(T)>(bitcast<T, S>(pred)) ^ m;
+	U r = (U)flip_float_bits<sizeof(T)>(bitcast<T, S>(raw)) ^ m;
+	return bitcast<U, T>(fold_residual_int<U>(r, p, bits_of<T>(q)));
+}
+template <typename T> static T unfold_residual(const T delta, const T pred, int q, std::true_type)
+{
+	typedef typename ints<sizeof(T)>::s S;
+	typedef typename ints<sizeof(T)>::u U;
+	U m = (U)signmask_as_indexed<T>();
+	U p = (U)flip_float_bits<sizeof(T)>(bitcast<T, S>(pred)) ^ m;
+	U v = unfold_residual_int<U>(bitcast<T, U>(delta), p, bits_of<T>(q));
+	S s = (S)v ^ (S)m;
+	return bitcast<S, T>(flip_float_bits<sizeof(T)>(s));
+}
+// prediction.h:121-147 parallelogram predictor: saturating for integers, plain fp for floats
+template <typename T> static T paral_predict(const T v0, const T v1, const T v2, int q, std::false_type)
+{
+	const T max = low_mask<T>(bits_of<T>(q));
+	if (v1 < v2) {
+		const T tmp = v2 - v1;
+		if (tmp > v0) return T(0);
+		else return v0 - tmp;
+	} else {
+		const T tmp = v1 - v2;
+		const T v = v0 + tmp;
+		if ((v > max) || (v < v0)) return max;
+		return v;
+	}
+}
+template <typename T> static T paral_predict(const T v0, const T v1, const T v2, int, std::true_type) { return v0 + (v1 - v2); }
+
+// big accumulator type per storage type (structs/mixing.h:110-127)
+template <typename T> struct big_of { typedef int64_t type; };
+template <> struct big_of<float> { typedef double type; };
+template <> struct big_of<double> { typedef double type; };
+template <> struct big_of<uint64_t> { typedef uint64_t type; };
+// transform.h:90-93
+static inline double div_round(double n, double d) { return n / d; }
+static inline int64_t div_round(int64_t n, int64_t d) { return (n + (d >> 1)) / d; }
+static inline uint64_t div_round(uint64_t n, uint64_t d) { return (n + (d >> 1)) / d; }
+
+// invoke f(T()) with the C++ type of a storage type (mixing.h:272-289 dispatch)
+template <typename F> static void with_type(Type t, F &&f)
+{
+	switch (t) {
+	case T_FLOAT: f(float()); break;
+	case T_DOUBLE: f(double()); break;
+	case T_ULONG: f(uint64_t()); break;
+	case T_LONG: f(int64_t()); break;
+	case T_UINT: f(uint32_t()); break;
+	case T_INT: f(int32_t()); break;
+	case T_USHORT: f(uint16_t()); break;
+	case T_SHORT: f(int16_t()); break;
+	case T_UCHAR: f(uint8_t()); break;
+	case T_CHAR: f(int8_t()); break;
+	default: throw std::runtime_error("oracle: bad component type");
+	}
+}
+template <typename T> static inline T ld(const uint8_t *p) { T v; memcpy(&v, p, sizeof(T)); return v; }
+template <typename T> static inline void st(uint8_t *p, T v) { memcpy(p, &v, sizeof(T)); }
+
+// ------------------------------------------------------------------------------------------------
+// bit I/O (arith/bitstream.h:16-62): MSB first, last byte zero padded, reads past the end give 0xFF bytes
+// ------------------------------------------------------------------------------------------------
+struct BitSink {
+	std::vector<uint8_t> &out;
+	int fill = 0;
+	uint8_t cur = 0;
+	explicit BitSink(std::vector<uint8_t> &o) : out(o) {}
+	void put(unsigned bit)
+	{
+		cur |= (uint8_t)(bit << (7 - fill));
+		if (++fill == 8) pad();
+	}
+	void pad()
+	{
+		if (fill == 0) return;
+		out.push_back(cur);
+		cur = 0; fill = 0;
+	}
+};
+struct BitSource {
+	const uint8_t *p, *end;
+	int used = 8;
+	uint8_t cur = 0;
+	BitSource(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
+	unsigned get()
+	{
+		if (used == 8) {
+			cur = p < end ? *p++ : 0xFF;   // istream::get() == -1 past EOF (bitstream.h:27)
+			used = 0;
+		}
+		return (cur >> (7 - used++)) & 1;
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// Moffat-Neal-Witten range coder, 64-bit registers (arith/coder.h:27-172)
+// ------------------------------------------------------------------------------------------------
+static const uint64_t C_HALF = 1ull << 63, C_QUARTER = 1ull << 62;
+
+struct RangeEncoder {
+	uint64_t low = 0, range = C_HALF, pending = 0;
+	BitSink sink;
+	bool done = false;
+	explicit RangeEncoder(std::vector<uint8_t> &o) : sink(o) {}
+	void emit(unsigned b)   // coder.h:105-112 bit-plus-follow
+	{
+		sink.put(b);
+		for (; pending > 0; --pending) sink.put(!b);
+	}
+	void encode(uint64_t l, uint64_t h, uint64_t t)   // coder.h:69-91
+	{
+		uint64_t r = range / t;
+		low += r * l;
+		range = h < t ? r * (h - l) : range - r * l;
+		while (range <= C_QUARTER) {
+			if (low <= C_HALF && low + range <= C_HALF) emit(0);
+			else if (low >= C_HALF) { emit(1); low -= C_HALF; }
+			else { ++pending; low -= C_QUARTER; }
+			low <<= 1;
+			range <<= 1;
+		}
+	}
+	void finish()   // coder.h:58-67: 64 bits of low, then pad
+	{
+		if (done) return;
+		done = true;
+		for (int i = 63; i >= 0; --i) emit((unsigned)((low >> i) & 1));
+		sink.pad();
+	}
+};
+struct RangeDecoder {
+	uint64_t range = C_HALF, value = 0, r = 0;
+	BitSource src;
+	RangeDecoder(const uint8_t *b, const uint8_t *e) : src(b, e)
+	{
+		for (int i = 0; i < 64; ++i) value = 2 * value + src.get();   // coder.h:124-129
+	}
+	uint64_t target(uint64_t t)   // coder.h:134-138
+	{
+		r = range / t;
+		return std::min(t - 1, value / r);
+	}
+	void consume(uint64_t l, uint64_t h, uint64_t t)   // coder.h:140-153
+	{
+		value -= r * l;
+		range = h < t ? r * (h - l) : range - r * l;
+		while (range <= C_QUARTER) {
+			range <<= 1;
+			value = 2 * value + src.get();
+		}
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// adaptive frequency table: raw counts + Fenwick tree (arith/stat_adaptive.h:26-126)
+// ------------------------------------------------------------------------------------------------
+struct FreqTable {
+	std::vector<uint64_t> tree, cnt;
+	uint32_t n, top;
+	explicit FreqTable(uint32_t n_ = 256) : tree(n_, 0), cnt(n_, 0), n(n_)
+	{
+		top = 1;
+		while ((top << 1) <= n) top <<= 1;   // highest power of two <= n (msb.h:6-13)
+	}
+	uint64_t prefix(uint32_t k) const   // sum of the first k counts
+	{
+		uint64_t s = 0;
+		for (uint32_t i = k; i != 0; i &= i - 1) s += tree[i - 1];
+		return s;
+	}
+	uint64_t total() const { return prefix(n); }
+	void bump(uint32_t s, uint64_t d)
+	{
+		for (uint32_t i = s + 1; i <= n; i += i & (0 - i)) tree[i - 1] += d;
+		cnt[s] += d;
+	}
+	void inc(uint32_t s, uint64_t d = 1)   // stat_adaptive.h:77-82 incl. the (practically dead) halving
+	{
+		bump(s, d);
+		if (total() > (1ull << 62))
+			for (uint32_t i = 0; i < n; ++i) bump(i, 0 - (cnt[i] >> 1));
+	}
+	void set(uint32_t s, uint64_t f) { bump(s, f - cnt[s]); }   // stat_adaptive.h:87-90 (no halving test)
+	void range_of(uint32_t s, uint64_t &l, uint64_t &h) const { h = prefix(s + 1); l = h - cnt[s]; }
+	uint32_t find(uint64_t target, uint64_t &l, uint64_t &h) const   // stat_adaptive.h:55-72
+	{
+		uint32_t s = 0;
+		uint64_t rem = target;
+		for (uint32_t step = top; step > 0; step >>= 1) {
+			if (s + step <= n && tree[s + step - 1] <= rem) {
+				rem -= tree[s + step - 1];
+				s += step;
+			}
+		}
+		l = target - rem;
+		h = l + cnt[s];
+		return s;
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// context inventory of a .hry (formats/hry/models.h:183-237) with a flat numbering for traces
+// ------------------------------------------------------------------------------------------------
+enum { CTX_IOP = 0, CTX_OP = 1, CTX_ELEM = 2, CTX_PART = 6, CTX_VERT = 8, CTX_NUMTRI = 12, CTX_REGFACE = 14, CTX_REGVTX = 16, CTX_ATTR0 = 18 };
+enum { ATTR_TYPE = 0, ATTR_GHIST = 1, ATTR_LHIST = 5, ATTR_DATA = 7 };
+enum InitOp { IOP_INIT, IOP_TRI100, IOP_TRI010, IOP_TRI001, IOP_TRI110, IOP_TRI101, IOP_TRI011, IOP_TRI111, IOP_EOM };   // cbm/base.h:16-22
+enum Op { OP_BORDER, OP_CONNBWD, OP_SPLIT, OP_UNION, OP_NM, OP_NEWVTX, OP_CONNFWD, OP_CLOSE };                            // cbm/base.h:23
+enum { A_DATA = 0, A_HIST = 1, A_LHIST = 2 };
+
+struct Models {
+	std::vector<FreqTable> tab;       // indexed by ctx id
+	std::vector<int> attr_base;       // per list
+	// order-conditioned op model state (models.h:49-120)
+	uint64_t c_all = 2, c_new[8], c_fwd[8];
+	int order = 0;
+
+	explicit Models(const Mesh &m)
+	{
+		tab.reserve(64);
+		tab.emplace_back(IOP_EOM + 1);                       // CTX_IOP: 9 symbols, all 1 (models.h:27-32)
+		for (uint32_t i = 0; i <= IOP_EOM; ++i) tab[CTX_IOP].inc(i);
+		tab.emplace_back(OP_CONNFWD + 1);                    // CTX_OP: 7 symbols, all 1 (models.h:56-60)
+		for (uint32_t i = 0; i <= OP_CONNFWD; ++i) tab[CTX_OP].inc(i);
+		for (int i = 0; i < 8; ++i) c_new[i] = c_fwd[i] = 1;
+		for (int i = 0; i < 4 + 2 + 4; ++i) { tab.emplace_back(256); ones(tab.back()); }   // elem, part, vert (ModelMult init=true)
+		for (int i = 0; i < 2 + 2 + 2; ++i) tab.emplace_back(256);                           // numtri, regface, regvtx (init=false)
+		// models.h:209-217; ModelMult::init(T) walks the bytes of the value as (signed) char (model.h:49-55)
+		for (size_t d = 0; d < m.have_deg.size(); ++d)
+			if (m.have_deg[d]) seed16(CTX_NUMTRI, (uint16_t)(d - 2));
+		seed16(CTX_REGFACE, 0);   // one face region, one vertex region
+		seed16(CTX_REGVTX, 0);
+		for (size_t l = 0; l < m.lists.size(); ++l) {
+			attr_base.push_back((int)tab.size());
+			tab.emplace_back(256);                           // attr_type: DATA, HIST (+LHIST for corner lists) (models.h:201-203)
+			tab.back().inc(A_DATA); tab.back().inc(A_HIST);
+			if (m.lists[l].target == TG_CORNER) tab.back().inc(A_LHIST);
+			for (int i = 0; i < 4 + 2; ++i) { tab.emplace_back(256); ones(tab.back()); }   // ghist, lhist
+			const Fmt &f = m.lists[l].fmt;
+			for (int c = 0; c < f.size(); ++c)
+				for (int b = 0; b < TSIZE[f.stype[c]]; ++b) { tab.emplace_back(256); ones(tab.back()); }   // models.h:126-144
+		}
+	}
+	static void ones(FreqTable &t) { for (uint32_t j = 0; j < 256; ++j) t.inc(j); }
+	void seed16(int ctx, uint16_t v)
+	{
+		signed char b0 = (signed char)(v & 0xff), b1 = (signed char)(v >> 8);
+		if (b0 < 0 || b1 < 0) throw std::runtime_error("oracle: model seed byte >= 128 is out of bounds in the reference (model.h:49-55)");
+		tab[ctx].inc((uint32_t)b0);
+		tab[ctx + 1].inc((uint32_t)b1);
+	}
+	int data_ctx(int l, const Fmt &f, int comp) const
+	{
+		int c = attr_base[l] + ATTR_DATA;
+		for (int i = 0; i < comp; ++i) c += TSIZE[f.stype[i]];
+		return c;
+	}
+	// models.h:91-119
+	int order_class() const { int o = order - 1; return o < 8 ? o : 7; }
+	void op_prepare()
+	{
+		int i = order_class();
+		uint64_t nv = c_new[i] * c_all / (c_new[i] + c_fwd[i]);
+		tab[CTX_OP].set(OP_NEWVTX, nv);
+		tab[CTX_OP].set(OP_CONNFWD, c_all - nv);
+	}
+	void op_update(uint32_t s)
+	{
+		int i = order_class();
+		if (s == OP_NEWVTX) { ++c_all; ++c_new[i]; }
+		else if (s == OP_CONNFWD) { ++c_all; ++c_fwd[i]; }
+		else tab[CTX_OP].inc(s);
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// symbol layer (formats/hry/io.h:19-231)
+// ------------------------------------------------------------------------------------------------
+struct SymWriter {
+	Models &md;
+	RangeEncoder &rc;
+	std::vector<ho_sym> *trace;
+	SymWriter(Models &m, RangeEncoder &r, std::vector<ho_sym> *t) : md(m), rc(r), trace(t) {}
+	void code(int ctx, uint32_t s)
+	{
+		FreqTable &f = md.tab[ctx];
+		uint64_t l, h, t = f.total();
+		f.range_of(s, l, h);
+		if (trace) trace->push_back(ho_sym{ (uint32_t)ctx, s, l, h, t });
+		rc.encode(l, h, t);
+	}
+	void sym(int ctx, uint32_t s) { code(ctx, s); md.tab[ctx].inc(s); }      // model.h:57-66
+	void bytes(int ctx, const uint8_t *p, int n) { for (int i = 0; i < n; ++i) sym(ctx + i, p[i]); }
+	void iop(uint32_t s) { sym(CTX_IOP, s); }
+	void op(uint32_t s) { md.op_prepare(); code(CTX_OP, s); md.op_update(s); }   // models.h:74-80
+	void elem(int i)   // io.h:150-153 + transform.h:25-30 zigzag
+	{
+		uint32_t c = (uint32_t)i, z = (c << 1) ^ ((c >> 31) ? 0xffffffffu : 0u);
+		bytes(CTX_ELEM, (const uint8_t*)&z, 4);
+	}
+	void part(int p) { uint16_t v = (uint16_t)p; bytes(CTX_PART, (const uint8_t*)&v, 2); }
+	void vertid(uint32_t v) { bytes(CTX_VERT, (const uint8_t*)&v, 4); }
+	void numtri(int n) { if (n != 0) { uint16_t v = (uint16_t)n; bytes(CTX_NUMTRI, (const uint8_t*)&v, 2); } }   // io.h:162-165
+	void reg_face(uint16_t r) { bytes(CTX_REGFACE, (const uint8_t*)&r, 2); }
+	void reg_vtx(uint16_t r) { bytes(CTX_REGVTX, (const uint8_t*)&r, 2); }
+	void attr_type(int l, uint8_t t) { sym(md.attr_base[l] + ATTR_TYPE, t); }
+};
+struct SymReader {
+	Models &md;
+	RangeDecoder &rc;
+	SymReader(Models &m, RangeDecoder &r) : md(m), rc(r) {}
+	uint32_t code(int ctx)   // coder.h:154-162
+	{
+		FreqTable &f = md.tab[ctx];
+		uint64_t l, h, t = f.total();
+		uint32_t s = f.find(rc.target(t), l, h);
+		rc.consume(l, h, t);
+		return s;
+	}
+	uint32_t sym(int ctx) { uint32_t s = code(ctx); md.tab[ctx].inc(s); return s; }
+	void bytes(int ctx, uint8_t *p, int n) { for (int i = 0; i < n; ++i) p[i] = (uint8_t)sym(ctx + i); }
+	uint32_t iop() { return sym(CTX_IOP); }
+	uint32_t op() { md.op_prepare(); uint32_t s = code(CTX_OP); md.op_update(s); return s; }
+	int elem() { uint32_t z; bytes(CTX_ELEM, (uint8_t*)&z, 4); return (int)((z >> 1) ^ ((z & 1) ? 0xffffffffu : 0u)); }
+	uint16_t part() { uint16_t v; bytes(CTX_PART, (uint8_t*)&v, 2); return v; }
+	uint32_t vertid() { uint32_t v; bytes(CTX_VERT, (uint8_t*)&v, 4); return v; }
+	uint16_t numtri() { uint16_t v; bytes(CTX_NUMTRI, (uint8_t*)&v, 2); return v; }
+	uint16_t reg_face() { uint16_t v; bytes(CTX_REGFACE, (uint8_t*)&v, 2); return v; }
+	uint16_t reg_vtx() { uint16_t v; bytes(CTX_REGVTX, (uint8_t*)&v, 2); return v; }
+	uint8_t attr_type(int l) { return (uint8_t)sym(md.attr_base[l] + ATTR_TYPE); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// cut-border data structure (cbm/cutborder.h:49-333)
+// ------------------------------------------------------------------------------------------------
+static const uint32_t NOVTX = 0xffffffffu;
+struct Elem { uint32_t v = NOVTX; he_t a = 0; };
+struct Part { std::list<Elem> el; bool edge_begin = true; size_t num_edges() const { return el.size() - (edge_begin ? 0 : 1); } };
+
+struct CutBorder {
+	std::deque<Part> parts;          // top of the stack = back()
+	Elem *first = nullptr, *second = nullptr;
+	std::vector<uint8_t> on_border;  // occurrence counter per vertex (cutborder.h:69,98-112)
+	explicit CutBorder(uint32_t nv) : on_border(nv, 0) {}
+	Part &top() { return parts.back(); }
+	bool empty() const { return parts.empty(); }
+	void act(uint32_t v) { ++on_border[v]; }
+	void deact(uint32_t v) { --on_border[v]; }
+
+	void start(Elem a, Elem b, Elem c)   // cutborder.h:157-164
+	{
+		parts.emplace_back();
+		Part &p = top();
+		p.el.push_back(a); act(a.v);
+		p.el.push_back(b); act(b.v);
+		p.el.push_back(c); act(c.v);
+	}
+	void new_vertex(Elem e)   // :166-172
+	{
+		Part &p = top();
+		first = &p.el.back();
+		p.el.push_back(e); act(e.v);
+		second = &p.el.back();
+	}
+	bool is_tri() { Part &p = top(); return p.num_edges() == 3 && p.el.size() == 3; }
+	Op border()   // :217-248
+	{
+		Part &p = top();
+		if (p.num_edges() == 1) {
+			auto it = p.el.begin();
+			deact((it++)->v);
+			deact((it++)->v);
+			parts.pop_back();
+			return OP_BORDER;
+		}
+		Elem endv = p.el.back();
+		bool rename = !p.edge_begin;
+		deact(p.el.back().v);
+		p.el.pop_back();
+		if (!p.edge_begin) { deact(p.el.front().v); p.el.pop_front(); }
+		p.el.push_front(endv); act(endv.v);
+		p.edge_begin = false;
+		return rename ? OP_CONNFWD : OP_BORDER;
+	}
+	Elem connect_fwd(Op &op)   // :173-195
+	{
+		Part &p = top();
+		Elem d = *std::next(p.el.begin());
+		if (!p.edge_begin) { op = border(); return Elem(); }
+		if (is_tri()) {
+			auto it = p.el.begin();
+			deact((it++)->v); deact((it++)->v); deact((it++)->v);
+			parts.pop_back();
+			op = OP_CLOSE;
+		} else {
+			deact(p.el.front().v);
+			p.el.pop_front();
+			op = OP_CONNFWD;
+			first = &top().el.back();
+		}
+		return d;
+	}
+	Elem connect_bwd(Op &op)   // :196-209
+	{
+		Part &p = top();
+		deact(p.el.back().v);
+		p.el.pop_back();
+		op = OP_CONNBWD;
+		first = &p.el.back();
+		return p.el.back();
+	}
+	std::list<Elem>::iterator at(int i, int p = 0)   // :114-123
+	{
+		Part &pt = parts[parts.size() - 1 - p];
+		if (i > 0) return std::next(pt.el.begin(), i - 1);
+		return std::prev(pt.el.end(), -i + 1);
+	}
+	// :124-155 two-ended search through the stack of parts, front hit tested first
+	std::list<Elem>::iterator locate(uint32_t v, int &i, int &p)
+	{
+		auto part = parts.rbegin();
+		auto fw = part->el.begin();
+		auto bw = std::prev(part->el.end());
+		i = 0; p = 0;
+		for (;;) {
+			if (fw->v == v) { ++i; return fw; }
+			if (bw->v == v) { i = -i; return bw; }
+			if (bw == fw || std::next(bw) == fw) {
+				++p; ++part;
+				fw = part->el.begin();
+				bw = std::prev(part->el.end());
+				i = 0;
+			} else { ++fw; --bw; ++i; }
+		}
+	}
+	Elem split(std::list<Elem>::iterator it)   // :250-268
+	{
+		Part &p = top();
+		Elem gate = p.el.back();
+		deact(gate.v);
+		p.el.pop_back();
+		parts.emplace_back();
+		Part &np = top();
+		Part &old = parts[parts.size() - 2];
+		np.el.splice(np.el.begin(), old.el, old.el.begin(), it);
+		old.el.push_back(gate); act(gate.v);
+		np.el.push_back(*it); act(it->v);
+		std::swap(old.edge_begin, np.edge_begin);
+		second = &np.el.back();
+		first = &old.el.back();
+		return *it;
+	}
+	Elem unite(std::list<Elem>::iterator it, int p)   // :274-297
+	{
+		Part &cur = top();
+		Elem gate = cur.el.back();
+		deact(gate.v);
+		cur.el.pop_back();
+		size_t oi = parts.size() - 1 - p;
+		Part &other = parts[oi];
+		cur.el.push_back(gate); act(gate.v);
+		first = &cur.el.back();
+		cur.el.splice(cur.el.end(), other.el, it, other.el.end());
+		cur.el.splice(cur.el.end(), other.el, other.el.begin(), other.el.end());
+		cur.el.push_back(*it); act(it->v);
+		second = &cur.el.back();
+		Elem hit = *it;
+		// drop the emptied part, keeping the order of the others (the reference bubbles it to the top)
+		for (size_t k = oi; k + 1 < parts.size(); ++k) {
+			parts[k].el.swap(parts[k + 1].el);
+			std::swap(parts[k].edge_begin, parts[k + 1].edge_begin);
+		}
+		parts.pop_back();
+		return hit;
+	}
+	// :303-332 (encoder side classification)
+	bool find_and_update(uint32_t v, int &i, int &p, Op &op)
+	{
+		if (on_border[v] == 0) return false;
+		auto it = locate(v, i, p);
+		if (p > 0) { op = OP_UNION; unite(it, p); }
+		else {
+			Part &pt = top();
+			if (pt.edge_begin && std::next(pt.el.begin())->v == v) connect_fwd(op);
+			else if (std::next(pt.el.rbegin())->v == v) connect_bwd(op);
+			else { op = OP_SPLIT; split(it); }
+		}
+		return true;
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// attribute prediction shared by encoder and decoder (formats/hry/attrcode.h:83-289)
+// ------------------------------------------------------------------------------------------------
+struct Cand { uint32_t v0, v1, vo; };
+
+struct Predictor {
+	Mesh &m;
+	std::vector<bool> vdone;
+	std::vector<Cand> cands;
+	// identity maps for the encoder; for the decoder vertex -> attribute index assigned in decode order
+	std::vector<uint32_t> *vtx_attr = nullptr;
+	explicit Predictor(Mesh &mesh) : m(mesh), vdone(mesh.nv, false) {}
+
+	void offer(uint32_t v0, uint32_t v1, uint32_t vo)   // attrcode.h:117-134 (single region: region test always passes)
+	{
+		if (!vdone[v0] || !vdone[v1] || !vdone[vo]) return;
+		cands.push_back(Cand{ v0, v1, vo });
+	}
+	void face_parallelograms(he_t ein)   // attrcode.h:155-171
+	{
+		he_t e = ein;
+		int d = m.deg(m.eface[e]);
+		if (d == 3) {
+			e = m.next(e);
+			he_t t = m.twin[e];
+			if (t == e) return;
+			e = m.next(m.next(t));
+			offer(m.org[t], m.dest(t), m.org[e]);
+			return;
+		}
+		he_t e0 = m.next(e), e1 = m.prev(e);
+		offer(m.org[e0], m.org[e1], m.dest(e0));
+		if (d > 4) offer(m.org[e0], m.org[e1], m.org[m.prev(e)]);
+	}
+	void fan(he_t ein)   // attrcode.h:83-106 (TFAN_IT): forward until border, then backward sweep
+	{
+		he_t e = ein, t;
+		for (;;) {
+			face_parallelograms(e);
+			t = m.twin[e];
+			if (t == e) break;          // border: go backward
+			e = m.next(t);
+			if (e == ein) return;       // full circle
+		}
+		e = m.prev(ein);
+		t = m.twin[e];
+		if (e == t) return;
+		e = t;
+		do {
+			face_parallelograms(e);
+			e = m.prev(e);
+			t = m.twin[e];
+			if (e == t) break;
+			e = t;
+		} while (e != ein);
+	}
+	void collect_vertex(he_t e)   // attrcode.h:209-218
+	{
+		cands.clear();
+		fan(e);
+		vdone[m.org[e]] = true;
+	}
+	uint32_t attr_of(uint32_t v) const { return vtx_attr ? (*vtx_attr)[v] : v; }
+
+	// attrcode.h:182-208: mean of the candidates, then (floats) the candidate nearest to the mean
+	template <typename T> T predict_component(const List &L, int c, int q) const
+	{
+		typedef typename big_of<T>::type B;
+		size_t n = cands.size();
+		if (n == 0) return T(0);
+		int off = L.fmt.off[c];
+		B acc = 0;
+		std::vector<T> pv(n);
+		for (size_t k = 0; k < n; ++k) {
+			T a = ld<T>(L.rec(attr_of(cands[k].v0)) + off), b = ld<T>(L.rec(attr_of(cands[k].v1)) + off), o = ld<T>(L.rec(attr_of(cands[k].vo)) + off);
+			pv[k] = paral_predict<T>(a, b, o, q, std::is_floating_point<T>());
+			acc = acc + (B)pv[k];
+		}
+		acc = div_round(acc, (B)n);
+		T avg = (T)acc;
+		if (!std::is_floating_point<T>::value) return avg;
+		T res = std::numeric_limits<T>::max();
+		for (size_t k = 0; k < n; ++k) {
+			T rd = avg > res ? avg - res : res - avg;
+			T pd = avg > pv[k] ? avg - pv[k] : pv[k] - avg;
+			res = rd < pd ? res : pv[k];
+		}
+		return res;
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// header (formats/hry/writer.cc:104-198, reader.cc:60-177)
+// ------------------------------------------------------------------------------------------------
+struct ByteWriter {
+	std::vector<uint8_t> &o;
+	template <typename T> void put(T v) { const uint8_t *p = (const uint8_t*)&v; o.insert(o.end(), p, p + sizeof(T)); }
+	void raw(const void *p, size_t n) { o.insert(o.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
+};
+static void write_header(const Mesh &m, std::vector<uint8_t> &out)
+{
+	ByteWriter w{ out };
+	const uint8_t magic[6] = { 0xfa, 0xff, 0xaf, 0xaf, 0, 1 };   // big-endian magic, version 0.1 (common.h:15-16)
+	w.raw(magic, 6);
+	w.put<uint32_t>(m.nv); w.put<uint32_t>(m.nf); w.put<uint32_t>(m.num_edge());
+	w.put<uint16_t>(1); w.put<uint16_t>(1);                 // one face region, one vertex region
+	w.put<uint16_t>(1); w.put<uint16_t>(0); w.put<uint16_t>(0);   // face region: 1 face list (id 0), 0 corner lists
+	w.put<uint16_t>(1); w.put<uint16_t>(1);                 // vertex region: 1 list (id 1)
+	for (size_t i = 0; i < m.lists.size(); ++i) {
+		const List &L = m.lists[i];
+		w.put<uint32_t>(L.count);
+		w.put<uint16_t>((uint16_t)L.fmt.size());
+		for (int j = 0; j < L.fmt.size(); ++j) { w.put<uint8_t>(L.fmt.type[j]); w.put<uint8_t>((uint8_t)L.fmt.quant[j]); }
+		w.put<uint16_t>((uint16_t)L.interps.size());
+		for (int j = 0; j < L.interps.size(); ++j) {
+			w.put<uint16_t>((uint16_t)L.interps.len[j]);
+			if (j >= I_OTHER) {
+				const std::string &nm = L.interps.names[j - I_OTHER];
+				w.put<uint32_t>((uint32_t)nm.size());
+				w.raw(nm.data(), nm.size());
+			}
+		}
+		w.raw(L.bmin.data(), L.bmin.size());
+		w.raw(L.bmax.data(), L.bmax.size());
+	}
+	uint16_t cnt = 0;
+	for (char c : m.have_deg) cnt += c ? 1 : 0;
+	w.put<uint16_t>(cnt);
+	for (size_t d = 0; d < m.have_deg.size(); ++d) if (m.have_deg[d]) w.put<uint16_t>((uint16_t)d);
+}
+
+struct ByteReader {
+	const uint8_t *p, *end;
+	template <typename T> T get() { need(sizeof(T)); T v; memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+	void raw(void *d, size_t n) { need(n); memcpy(d, p, n); p += n; }
+	void need(size_t n) { if ((size_t)(end - p) < n) throw std::runtime_error("oracle: truncated header"); }
+};
+static int dequant_bytes(const Fmt &f) { return f.bytes(); }
+static void read_header(ByteReader &r, Mesh &m)
+{
+	uint8_t magic[6];
+	r.raw(magic, 6);
+	if (magic[0] != 0xfa || magic[1] != 0xff || magic[2] != 0xaf || magic[3] != 0xaf) throw std::runtime_error("Invalid magic number");
+	if (magic[4] != 0 || magic[5] != 1) throw std::runtime_error("File format version incompatible to decoder format version 0.1");
+	m.nv = r.get<uint32_t>(); m.nf = r.get<uint32_t>(); (void)r.get<uint32_t>();
+	uint16_t nrf = r.get<uint16_t>(), nrv = r.get<uint16_t>();
+	std::vector<int> targets;
+	auto mark = [&](uint16_t b, int t) { if (b >= targets.size()) targets.resize(b + 1, TG_NONE); targets[b] = t; };
+	if (nrf != 1 || nrv != 1) throw std::runtime_error("oracle: only single-region meshes (PLY-originated) are supported");
+	for (int i = 0; i < nrf; ++i) {
+		uint16_t nbf = r.get<uint16_t>(), nbc = r.get<uint16_t>();
+		if (nbf != 1 || nbc != 0) throw std::runtime_error("oracle: unsupported face-region bindings");
+		for (int a = 0; a < nbf; ++a) mark(r.get<uint16_t>(), TG_FACE);
+	}
+	for (int i = 0; i < nrv; ++i) {
+		uint16_t nbv = r.get<uint16_t>();
+		if (nbv != 1) throw std::runtime_error("oracle: unsupported vertex-region bindings");
+		for (int a = 0; a < nbv; ++a) mark(r.get<uint16_t>(), TG_VTX);
+	}
+	if (targets.size() != 2 || targets[0] != TG_FACE || targets[1] != TG_VTX) throw std::runtime_error("oracle: unsupported list layout");
+	for (size_t i = 0; i < targets.size(); ++i) {
+		List L;
+		L.target = targets[i];
+		L.count = r.get<uint32_t>();
+		uint16_t nf = r.get<uint16_t>();
+		for (int j = 0; j < nf; ++j) { uint8_t t = r.get<uint8_t>(), q = r.get<uint8_t>(); if (t >= T_NONE) throw std::runtime_error("oracle: bad type"); L.fmt.add((Type)t, q); }
+		uint16_t ni = r.get<uint16_t>();
+		int off = 0;
+		for (int j = 0; j < ni; ++j) {
+			uint16_t len = r.get<uint16_t>();
+			for (int k = 0; k < len; ++k) L.interps.append(j, off + k);
+			off += len;
+			if (j >= I_OTHER) {
+				uint32_t sl = r.get<uint32_t>();
+				std::string nm(sl, '\0');
+				r.raw(&nm[0], sl);
+				L.interps.describe(j, nm);
+			}
+		}
+		L.data.assign((size_t)L.count * L.fmt.bytes(), 0);
+		L.bmin.resize(dequant_bytes(L.fmt)); L.bmax.resize(dequant_bytes(L.fmt));
+		r.raw(L.bmin.data(), L.bmin.size());
+		r.raw(L.bmax.data(), L.bmax.size());
+		m.lists.push_back(std::move(L));
+	}
+	uint16_t cnt = r.get<uint16_t>();
+	for (int i = 0; i < cnt; ++i) {
+		uint16_t d = r.get<uint16_t>();
+		if (d >= m.have_deg.size()) m.have_deg.resize(d + 1, 0);
+		m.have_deg[d] = 1;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder: cut-border walk + attribute pass (cbm/encoder.h:54-217, attrcode.h:291-417, writer.cc:200-214)
+// ------------------------------------------------------------------------------------------------
+struct Result {
+	std::vector<uint8_t> bytes;
+	size_t header_size = 0;
+	std::vector<ho_sym> trace;
+	std::vector<uint32_t> order_v, order_f;
+};
+
+// Start-face choice: face 0 if unvisited, else the first unvisited face in the iteration order of a
+// std::unordered_set<uint32_t> that received 0..F-1 in order (writer.cc:28-46).
+struct FacePool {
+	std::vector<uint32_t> iter_order;
+	std::vector<uint8_t> gone;
+	size_t cursor = 0, left;
+	explicit FacePool(uint32_t nf) : gone(nf, 0), left(nf)
+	{
+		std::unordered_set<uint32_t> s;
+		for (uint32_t i = 0; i < nf; ++i) s.insert(i);
+		iter_order.assign(s.begin(), s.end());
+	}
+	void take(uint32_t f) { gone[f] = 1; --left; }
+	uint32_t choose()
+	{
+		uint32_t f;
+		if (!gone[0]) f = 0;
+		else {
+			while (gone[iter_order[cursor]]) ++cursor;
+			f = iter_order[cursor];
+		}
+		take(f);
+		return f;
+	}
+};
+
+static void cbm_encode(Mesh &m, SymWriter &wr, std::vector<uint32_t> &order_v, std::vector<uint32_t> &order_f)
+{
+	CutBorder cb(m.nv);
+	FacePool pool(m.num_face());
+	std::vector<uint32_t> perm(m.nv, NOVTX);
+	std::vector<uint16_t> seen(m.nv, 0);
+	uint32_t next_id = 0;
+	auto mapped = [&](uint32_t v) { return perm[v] != NOVTX; };
+	auto add_vtx = [&](he_t e) { order_v.push_back(e); perm[m.org[e]] = next_id++; };
+
+	int curtri = 0, ntri = 0;
+	he_t e0 = 0, e1 = 0, e2 = 0;
+	uint32_t f = 0;
+	do {
+		curtri = 0;
+		f = pool.choose();
+		e0 = m.foff[f]; e1 = m.next(e0); e2 = m.next(e1);
+		uint32_t a = m.org[e0], b = m.org[e1], c = m.org[e2];
+		bool m0 = mapped(a), m1 = mapped(b), m2 = mapped(c);
+		ntri = m.deg(f) - 2;
+		// encoder.h:76-123; ids are written as transmitted indices, new vertices recorded in this order
+		if (m0 && m1 && m2) { wr.iop(IOP_TRI111); wr.vertid(perm[a]); wr.vertid(perm[b]); wr.vertid(perm[c]); wr.numtri(ntri); }
+		else if (m0 && m1) { wr.iop(IOP_TRI110); wr.vertid(perm[a]); wr.vertid(perm[b]); wr.numtri(ntri); add_vtx(e2); }
+		else if (m1 && m2) { wr.iop(IOP_TRI011); wr.vertid(perm[b]); wr.vertid(perm[c]); wr.numtri(ntri); add_vtx(e0); }
+		else if (m2 && m0) { wr.iop(IOP_TRI101); wr.vertid(perm[c]); wr.vertid(perm[a]); wr.numtri(ntri); add_vtx(e1); }
+		else if (m0) { wr.iop(IOP_TRI100); wr.vertid(perm[a]); wr.numtri(ntri); add_vtx(e1); add_vtx(e2); }
+		else if (m1) { wr.iop(IOP_TRI010); wr.vertid(perm[b]); wr.numtri(ntri); add_vtx(e2); add_vtx(e0); }
+		else if (m2) { wr.iop(IOP_TRI001); wr.vertid(perm[c]); wr.numtri(ntri); add_vtx(e0); add_vtx(e1); }
+		else { wr.iop(IOP_INIT); wr.numtri(ntri); add_vtx(e0); add_vtx(e1); add_vtx(e2); }
+		order_f.push_back(e0);
+		++seen[a]; ++seen[b]; ++seen[c];
+		cb.start(Elem{ a, e0 }, Elem{ b, e1 }, Elem{ c, e2 });
+		++curtri;
+
+		while (!cb.empty()) {
+			Part &pt = cb.top();
+			Elem g0 = pt.el.back(), g1 = pt.el.front();
+			he_t gate = g0.a;
+			he_t gateprev = std::next(pt.el.rbegin())->a;
+			he_t gatenext = pt.el.front().a;
+			bool seq_first = curtri == ntri;
+			bool valid = true;
+			if (seq_first) {   // writer.cc:48-58: cross the gate unless it is a border or its neighbour is consumed
+				he_t t = m.twin[gate];
+				if (t == gate || pool.gone[m.eface[t]]) valid = false;
+				else { pool.take(m.eface[t]); e0 = t; }
+			}
+			wr.md.order = seen[g1.v];
+			if (seq_first && !valid) {
+				Op bop = cb.border();
+				if (m.twin[gate] != gate) m.merge(gate, gate);   // one-sided: the old twin keeps pointing here (writer.cc:81-84)
+				wr.op(bop);
+				continue;
+			}
+			if (seq_first) {
+				curtri = 0;
+				f = m.eface[e0];
+				ntri = m.deg(f) - 2;
+				e1 = m.next(e0);
+			} else e1 = m.next(e1);
+			e2 = m.next(e1);
+			uint32_t v2 = m.org[e2];
+			bool seq_last = curtri + 1 == ntri;
+			int nt = seq_first ? ntri : 0;
+			if (!mapped(v2)) {
+				cb.new_vertex(Elem{ v2, 0 });
+				cb.first->a = e1; cb.second->a = e2;
+				wr.op(OP_NEWVTX); wr.numtri(nt);
+				add_vtx(e2);
+			} else {
+				int i, p;
+				Op op;
+				if (!cb.find_and_update(v2, i, p, op)) {
+					cb.new_vertex(Elem{ v2, 0 });
+					cb.first->a = e1; cb.second->a = e2;
+					wr.op(OP_NM); wr.vertid(perm[v2]); wr.numtri(nt);
+				} else if (op == OP_UNION) {
+					wr.op(OP_UNION); wr.elem(i); wr.part(p); wr.numtri(nt);
+					cb.first->a = e1; cb.second->a = e2;
+				} else if (op == OP_CONNFWD || op == OP_CLOSE) {
+					if (seq_last && m.twin[gatenext] != e2) m.merge(gatenext, e2);
+					if (op == OP_CLOSE && m.twin[gateprev] != e1) m.merge(gateprev, e1);
+					wr.op(OP_CONNFWD); wr.numtri(nt);
+					if (op == OP_CONNFWD) cb.first->a = e1;
+				} else if (op == OP_CONNBWD) {
+					if (m.twin[gateprev] != e1) m.merge(gateprev, e1);
+					wr.op(OP_CONNBWD); wr.numtri(nt);
+					cb.first->a = e2;
+				} else {
+					wr.op(OP_SPLIT); wr.elem(i); wr.numtri(nt);
+					cb.first->a = e1; cb.second->a = e2;
+				}
+			}
+			++seen[g0.v]; ++seen[g1.v]; ++seen[v2];
+			if (seq_first) order_f.push_back(e0);
+			++curtri;
+		}
+	} while (pool.left != 0);
+	wr.iop(IOP_EOM);
+}
+
+static void encode_attrs(Mesh &m, SymWriter &wr, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &order_f)
+{
+	Predictor pr(m);
+	const int LV = 1, LF = 0;
+	std::vector<uint8_t> resid;
+	// vertices in traversal order (attrcode.h:321-344,398-403)
+	{
+		List &L = m.lists[LV];
+		resid.assign(std::max(L.fmt.bytes(), 1), 0);
+		for (he_t e : order_v) {
+			uint32_t v = m.org[e];
+			pr.collect_vertex(e);
+			wr.reg_vtx(0);
+			int ctx = wr.md.attr_base[LV] + ATTR_DATA;
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				with_type(L.fmt.stype[c], [&](auto tag) {
+					typedef decltype(tag) T;
+					T pred = pr.predict_component<T>(L, c, L.fmt.quant[c]);
+					T raw = ld<T>(L.rec(v) + L.fmt.off[c]);
+					st<T>(resid.data() + L.fmt.off[c], fold_residual<T>(raw, pred, L.fmt.quant[c], std::is_floating_point<T>()));
+				});
+			}
+			wr.attr_type(LV, A_DATA);   // io.h:90-94
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				int nb = TSIZE[L.fmt.stype[c]];
+				wr.bytes(ctx, resid.data() + L.fmt.off[c], nb);
+				ctx += nb;
+			}
+		}
+	}
+	// faces in traversal order; face prediction never has candidates (attrcode.h:227-254)
+	{
+		List &L = m.lists[LF];
+		resid.assign(std::max(L.fmt.bytes(), 1), 0);
+		for (he_t e : order_f) {
+			uint32_t f = m.eface[e];
+			wr.reg_face(0);
+			int ctx = wr.md.attr_base[LF] + ATTR_DATA;
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				with_type(L.fmt.stype[c], [&](auto tag) {
+					typedef decltype(tag) T;
+					T raw = ld<T>(L.rec(f) + L.fmt.off[c]);
+					st<T>(resid.data() + L.fmt.off[c], fold_residual<T>(raw, T(0), L.fmt.quant[c], std::is_floating_point<T>()));
+				});
+			}
+			wr.attr_type(LF, A_DATA);
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				int nb = TSIZE[L.fmt.stype[c]];
+				wr.bytes(ctx, resid.data() + L.fmt.off[c], nb);
+				ctx += nb;
+			}
+		}
+	}
+}
+
+static void check_supported(const Mesh &m)
+{
+	if (m.lists.size() != 2 || m.lists[0].target != TG_FACE || m.lists[1].target != TG_VTX)
+		throw std::runtime_error("oracle: mesh must have list 0 = face attributes and list 1 = vertex attributes");
+	if (m.lists[0].count != m.nf || m.lists[1].count != m.nv) throw std::runtime_error("oracle: list sizes must equal element counts");
+}
+
+static Result *encode(Mesh &m, bool trace)
+{
+	check_supported(m);
+	Result *res = new Result();
+	try {
+		write_header(m, res->bytes);
+		res->header_size = res->bytes.size();
+		RangeEncoder rc(res->bytes);
+		Models md(m);
+		SymWriter wr(md, rc, trace ? &res->trace : nullptr);
+		cbm_encode(m, wr, res->order_v, res->order_f);
+		encode_attrs(m, wr, res->order_v, res->order_f);
+		rc.finish();
+	} catch (...) { delete res; throw; }
+	return res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder (cbm/decoder.h:27-211, attrcode.h:420-551, reader.cc:179-193)
+// ------------------------------------------------------------------------------------------------
+static void cbm_decode(Mesh &m, SymReader &rd, std::vector<uint32_t> &order_v)
+{
+	CutBorder cb(m.nv);
+	std::vector<uint16_t> seen(m.nv, 0);
+	uint32_t next_id = 0;
+	int curtri = 0, ntri = 0;
+	he_t e0 = 0, e1 = 0, e2 = 0;
+	uint32_t f = 0;
+	for (;;) {
+		uint32_t iop = rd.iop();
+		if (iop == IOP_EOM) break;
+		uint32_t a = 0, b = 0, c = 0;
+		curtri = 0;
+		switch (iop) {   // decoder.h:46-77
+		case IOP_INIT: a = next_id++; b = next_id++; c = next_id++; break;
+		case IOP_TRI100: a = rd.vertid(); b = next_id++; c = next_id++; break;
+		case IOP_TRI010: c = next_id++; b = rd.vertid(); a = next_id++; break;
+		case IOP_TRI001: a = next_id++; b = next_id++; c = rd.vertid(); break;
+		case IOP_TRI110: a = rd.vertid(); b = rd.vertid(); c = next_id++; break;
+		case IOP_TRI101: c = rd.vertid(); b = next_id++; a = rd.vertid(); break;
+		case IOP_TRI011: a = next_id++; b = rd.vertid(); c = rd.vertid(); break;
+		case IOP_TRI111: a = rd.vertid(); b = rd.vertid(); c = rd.vertid(); break;
+		default: throw std::runtime_error("oracle: bad init op");
+		}
+		if (a >= m.nv || b >= m.nv || c >= m.nv) throw std::runtime_error("oracle: corrupt stream (vertex id)");
+		ntri = rd.numtri();
+		++seen[a]; ++seen[b]; ++seen[c];
+		f = m.add_face(ntri + 2);
+		e0 = m.foff[f]; e1 = m.next(e0); e2 = m.next(e1);
+		m.set_org(e0, a); m.set_org(e1, b); m.set_org(e2, c);
+		++curtri;
+		switch (iop) {   // decoder.h:86-110
+		case IOP_INIT: order_v.push_back(e0); order_v.push_back(e1); order_v.push_back(e2); break;
+		case IOP_TRI100: order_v.push_back(e1); order_v.push_back(e2); break;
+		case IOP_TRI010: order_v.push_back(e2); order_v.push_back(e0); break;
+		case IOP_TRI001: order_v.push_back(e0); order_v.push_back(e1); break;
+		case IOP_TRI110: order_v.push_back(e2); break;
+		case IOP_TRI101: order_v.push_back(e1); break;
+		case IOP_TRI011: order_v.push_back(e0); break;
+		default: break;
+		}
+		cb.start(Elem{ a, e0 }, Elem{ b, e1 }, Elem{ c, e2 });
+
+		while (!cb.empty()) {
+			Part &pt = cb.top();
+			Elem g0 = pt.el.back(), g1 = pt.el.front();
+			he_t gate = g0.a;
+			he_t gateprev = std::next(pt.el.rbegin())->a;
+			he_t gatenext = pt.el.front().a;
+			rd.md.order = seen[g1.v];
+			Op op = (Op)rd.op(), realop = op;
+			bool seq_first = curtri == ntri;
+			Elem v2;
+			switch (op) {   // decoder.h:133-166
+			case OP_CONNFWD: v2 = cb.connect_fwd(realop); break;
+			case OP_CONNBWD: v2 = cb.connect_bwd(realop); break;
+			case OP_SPLIT: { int i = rd.elem(); v2 = cb.split(cb.at(i)); break; }
+			case OP_UNION: { int i = rd.elem(); int p = rd.part(); v2 = cb.unite(cb.at(i, p), p); break; }
+			case OP_NEWVTX: v2 = Elem{ next_id++, 0 }; cb.new_vertex(v2); break;
+			case OP_NM: v2 = Elem{ rd.vertid(), 0 }; cb.new_vertex(v2); break;
+			case OP_BORDER: cb.border(); v2 = Elem(); break;
+			default: throw std::runtime_error("oracle: bad op");
+			}
+			if (v2.v == NOVTX) continue;
+			if (v2.v >= m.nv) throw std::runtime_error("oracle: corrupt stream (vertex id)");
+			if (seq_first) {
+				ntri = rd.numtri();
+				curtri = 0;
+				f = m.add_face(ntri + 2);
+				e0 = m.foff[f]; e1 = m.next(e0); e2 = m.next(e1);
+				m.set_org(e0, g1.v); m.set_org(e1, g0.v); m.set_org(e2, v2.v);
+			} else {
+				e1 = m.next(e1);
+				e2 = m.next(e1);
+				m.set_org(e2, v2.v);
+			}
+			bool seq_last = curtri + 1 == ntri;
+			switch (realop) {   // decoder.h:182-197
+			case OP_CONNFWD: cb.first->a = e1; break;
+			case OP_CONNBWD: cb.first->a = e2; break;
+			case OP_SPLIT: case OP_UNION: case OP_NEWVTX: case OP_NM: cb.first->a = e1; cb.second->a = e2; break;
+			default: break;
+			}
+			++seen[g0.v]; ++seen[g1.v]; ++seen[v2.v];
+			if (op == OP_NEWVTX) order_v.push_back(m.foff[f] + curtri + 2);
+			++curtri;
+			if (seq_first) m.merge(gate, e0);
+			if (op == OP_CONNFWD) {
+				if (seq_last && realop != OP_BORDER) m.merge(gatenext, e2);
+				if (realop == OP_CLOSE) m.merge(gateprev, e1);
+			} else if (op == OP_CONNBWD) m.merge(gateprev, e1);
+		}
+	}
+}
+
+static void decode_attrs(Mesh &m, SymReader &rd, const std::vector<uint32_t> &order_v)
+{
+	Predictor pr(m);
+	std::vector<uint32_t> vattr(m.nv, 0);
+	pr.vtx_attr = &vattr;
+	const int LV = 1, LF = 0;
+	uint32_t cur = 0;
+	{
+		List &L = m.lists[LV];
+		for (he_t e : order_v) {   // attrcode.h:443-470
+			uint32_t v = m.org[e];
+			(void)rd.reg_vtx();
+			pr.collect_vertex(e);
+			uint8_t ty = rd.attr_type(LV);
+			if (ty != A_DATA) throw std::runtime_error("oracle: shared-attribute history is not supported");
+			if (cur >= L.count) throw std::runtime_error("oracle: corrupt stream (attribute overflow)");
+			uint32_t idx = cur++;
+			int ctx = rd.md.attr_base[LV] + ATTR_DATA;
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				int nb = TSIZE[L.fmt.stype[c]];
+				rd.bytes(ctx, L.rec(idx) + L.fmt.off[c], nb);
+				ctx += nb;
+			}
+			vattr[v] = idx;
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				with_type(L.fmt.stype[c], [&](auto tag) {
+					typedef decltype(tag) T;
+					T pred = pr.predict_component<T>(L, c, L.fmt.quant[c]);
+					T d = ld<T>(L.rec(idx) + L.fmt.off[c]);
+					st<T>(L.rec(idx) + L.fmt.off[c], unfold_residual<T>(d, pred, L.fmt.quant[c], std::is_floating_point<T>()));
+				});
+			}
+		}
+	}
+	{
+		List &L = m.lists[LF];
+		uint32_t curf = 0;
+		for (uint32_t f = 0; f < m.nf; ++f) {   // attrcode.h:476-501, faces in index order
+			(void)rd.reg_face();
+			uint8_t ty = rd.attr_type(LF);
+			if (ty != A_DATA) throw std::runtime_error("oracle: shared-attribute history is not supported");
+			uint32_t idx = curf++;
+			int ctx = rd.md.attr_base[LF] + ATTR_DATA;
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				int nb = TSIZE[L.fmt.stype[c]];
+				rd.bytes(ctx, L.rec(idx) + L.fmt.off[c], nb);
+				ctx += nb;
+			}
+			for (int c = 0; c < L.fmt.size(); ++c) {
+				with_type(L.fmt.stype[c], [&](auto tag) {
+					typedef decltype(tag) T;
+					T d = ld<T>(L.rec(idx) + L.fmt.off[c]);
+					st<T>(L.rec(idx) + L.fmt.off[c], unfold_residual<T>(d, T(0), L.fmt.quant[c], std::is_floating_point<T>()));
+				});
+			}
+		}
+	}
+}
+
+static Mesh *decode(const uint8_t *p, size_t n)
+{
+	Mesh *m = new Mesh();
+	try {
+		ByteReader br{ p, p + n };
+		read_header(br, *m);
+		RangeDecoder rc(br.p, p + n);
+		Models md(*m);
+		SymReader rd(md, rc);
+		std::vector<uint32_t> order_v;
+		m->org.reserve(m->nf * 3); m->twin.reserve(m->nf * 3); m->eface.reserve(m->nf * 3); m->foff.reserve(m->nf + 1);
+		// the models need the degree table from the header, but add_face() also records degrees: keep header's
+		std::vector<char> hdr_deg = m->have_deg;
+		cbm_decode(*m, rd, order_v);
+		m->have_deg = hdr_deg;
+		if (m->num_face() != m->nf) throw std::runtime_error("oracle: face count mismatch");
+		decode_attrs(*m, rd, order_v);
+	} catch (...) { delete m; throw; }
+	return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bounds + requantisation (structs/quant.h:30-242)
+// ------------------------------------------------------------------------------------------------
+static void set_bounds(List &L)   // quant.h:30-38; max starts at numeric_limits<T>::min() (FLT_MIN for floats, App. B-2)
+{
+	Fmt d;
+	for (int c = 0; c < L.fmt.size(); ++c) d.add(L.fmt.type[c]);
+	L.bmin.assign(d.bytes(), 0); L.bmax.assign(d.bytes(), 0);
+	for (int c = 0; c < d.size(); ++c) {
+		with_type(d.type[c], [&](auto tag) {
+			typedef decltype(tag) T;
+			T mn = std::numeric_limits<T>::max(), mx = std::numeric_limits<T>::min();
+			for (uint32_t i = 0; i < L.count; ++i) {
+				T e = ld<T>(L.rec(i) + L.fmt.off[c]);
+				mn = e < mn ? e : mn;
+				mx = e > mx ? e : mx;
+			}
+			st<T>(L.bmin.data() + d.off[c], mn);
+			st<T>(L.bmax.data() + d.off[c], mx);
+		});
+	}
+}
+// read component j of a record as type T with C++ conversion (mixing.h:245-270 get<T>)
+template <typename T> static T get_as(const uint8_t *rec, const Fmt &f, int j)
+{
+	T out = T();
+	with_type(f.type[j], [&](auto tag) { typedef decltype(tag) S; out = (T)ld<S>(rec + f.off[j]); });
+	return out;
+}
+static std::vector<uint8_t> compute_scale(const List &L)   // quant.h:46-96
+{
+	Fmt d;
+	for (int c = 0; c < L.fmt.size(); ++c) d.add(L.fmt.type[c]);
+	std::vector<uint8_t> spre(d.bytes(), 0), s(d.bytes(), 0);
+	int n = d.size();
+	for (int c = 0; c < n; ++c)
+		with_type(d.type[c], [&](auto tag) {
+			typedef decltype(tag) T;
+			st<T>(spre.data() + d.off[c], (T)(ld<T>(L.bmax.data() + d.off[c]) - ld<T>(L.bmin.data() + d.off[c])));
+			st<T>(s.data() + d.off[c], std::numeric_limits<T>::min());
+		});
+	std::vector<int> group(n, 0);   // components not covered by any interpretation fall into group 0 (zero-initialised in the reference)
+	for (int i = 0; i < L.interps.size(); ++i)
+		for (int j = 0; j < L.interps.len[i]; ++j) group[L.interps.off[i] + j] = L.interps.off[i];
+	for (int j = 0; j < n; ++j) {
+		int k = group[j];
+		with_type(d.type[k], [&](auto tag) {
+			typedef decltype(tag) T;
+			T cur = ld<T>(s.data() + d.off[k]), v = get_as<T>(spre.data(), d, j);
+			st<T>(s.data() + d.off[k], std::max(cur, v));
+		});
+	}
+	for (int j = 0; j < n; ++j) {
+		int k = group[j];
+		with_type(d.type[j], [&](auto tag) { typedef decltype(tag) T; st<T>(s.data() + d.off[j], get_as<T>(s.data(), d, k)); });
+	}
+	return s;
+}
+template <typename T> static T rescale(T val, T from, T to, std::true_type) { return val / from * to; }                       // quant.h:98-102
+template <typename T> static T rescale(T val, T from, T to, std::false_type) { return val / from * to + val % from * to / from; }   // quant.h:103-107
+template <typename T> static T rescale(T val, T from, T to) { return rescale<T>(val, from, to, std::is_floating_point<T>()); }
+
+static uint64_t quantise_scalar_f32(float v, float mn, float sc, int q)   // quant.h:134-136
+{
+	return (uint64_t)(rescale<float>(v - mn, sc, (float)((1 << (uint32_t)q) - 1)) + 0.5f);
+}
+
+static void requant_list(List &L, const Fmt &nf)   // quant.h:114-221: in place, record by record
+{
+	std::vector<uint8_t> scale = compute_scale(L);
+	Fmt d;
+	for (int c = 0; c < L.fmt.size(); ++c) d.add(L.fmt.type[c]);
+	const Fmt &of = L.fmt;
+	for (uint32_t i = 0; i < L.count; ++i) {
+		uint8_t *rec = L.rec(i);
+		for (int j = 0; j < of.size(); ++j) {
+			bool sq = of.quant[j] != 0, dq = nf.quant[j] != 0;
+			if (!sq && !dq) continue;   // copy onto itself
+			uint64_t q = 0;
+			uint8_t *slot = rec + of.off[j];
+			const uint8_t *mn = L.bmin.data() + d.off[j], *sc = scale.data() + d.off[j];
+			if (sq) {
+				switch (of.stype[j]) {
+				case T_ULONG: q = ld<uint64_t>(slot); break;
+				case T_UINT: q = ld<uint32_t>(slot); break;
+				case T_USHORT: q = ld<uint16_t>(slot); break;
+				case T_UCHAR: q = ld<uint8_t>(slot); break;
+				default: throw std::runtime_error("Invalid quantization type");
+				}
+			} else {
+				int nq = nf.quant[j];
+				switch (of.stype[j]) {
+				case T_FLOAT: q = (uint64_t)(rescale<float>(ld<float>(slot) - ld<float>(mn), ld<float>(sc), (float)((1 << (uint32_t)nq) - 1)) + 0.5f); break;
+				case T_DOUBLE: q = (uint64_t)(rescale<double>(ld<double>(slot) - ld<double>(mn), ld<double>(sc), (double)((1 << (uint64_t)nq) - 1)) + 0.5); break;
+				case T_ULONG: q = rescale<uint64_t>(ld<uint64_t>(slot) - ld<uint64_t>(mn), ld<uint64_t>(sc), (uint64_t)((1 << (uint64_t)nq) - 1)); break;
+				case T_LONG: q = (uint64_t)rescale<int64_t>(ld<int64_t>(slot) - ld<int64_t>(mn), ld<int64_t>(sc), (int64_t)((1 << (uint64_t)nq) - 1)); break;
+				case T_UINT: q = rescale<uint32_t>(ld<uint32_t>(slot) - ld<uint32_t>(mn), ld<uint32_t>(sc), (uint32_t)((1 << (uint32_t)nq) - 1)); break;
+				case T_INT: q = (uint64_t)rescale<int32_t>(ld<int32_t>(slot) - ld<int32_t>(mn), ld<int32_t>(sc), (int32_t)((1 << (uint32_t)nq) - 1)); break;
+				case T_USHORT: q = rescale<uint16_t>((uint16_t)(ld<uint16_t>(slot) - ld<uint16_t>(mn)), ld<uint16_t>(sc), (uint16_t)((1 << (uint32_t)nq) - 1)); break;
+				case T_SHORT: q = (uint64_t)rescale<int16_t>((int16_t)(ld<int16_t>(slot) - ld<int16_t>(mn)), ld<int16_t>(sc), (int16_t)((1 << (uint32_t)nq) - 1)); break;
+				case T_UCHAR: q = rescale<uint8_t>((uint8_t)(ld<uint8_t>(slot) - ld<uint8_t>(mn)), ld<uint8_t>(sc), (uint8_t)((1 << (uint32_t)nq) - 1)); break;
+				case T_CHAR: q = (uint64_t)rescale<int8_t>((int8_t)(ld<int8_t>(slot) - ld<int8_t>(mn)), ld<int8_t>(sc), (int8_t)((1 << (uint32_t)nq) - 1)); break;
+				default: break;
+				}
+			}
+			if (sq && dq) q = rescale<uint64_t>(q, (uint64_t)((1 << (uint32_t)of.quant[j]) - 1), (uint64_t)((1 << (uint32_t)nf.quant[j]) - 1));
+			if (dq) {
+				switch (nf.stype[j]) {
+				case T_ULONG: st<uint64_t>(slot, q); break;
+				case T_UINT: st<uint32_t>(slot, (uint32_t)q); break;
+				case T_USHORT: st<uint16_t>(slot, (uint16_t)q); break;
+				case T_UCHAR: st<uint8_t>(slot, (uint8_t)q); break;
+				default: throw std::runtime_error("Invalid quantization type");
+				}
+			} else {   // dequantise (quant.h:180-212)
+				int oq = of.quant[j];
+				switch (nf.stype[j]) {
+				case T_FLOAT: st<float>(slot, rescale<float>((float)q, (float)((1 << (uint32_t)oq) - 1), ld<float>(sc)) + ld<float>(mn)); break;
+				case T_DOUBLE: st<double>(slot, rescale<double>((double)q, (double)((1 << (uint64_t)oq) - 1), ld<double>(sc)) + ld<double>(mn)); break;
+				case T_UINT: st<uint32_t>(slot, rescale<uint32_t>((uint32_t)q, (uint32_t)((1 << (uint32_t)oq) - 1), ld<uint32_t>(sc)) + ld<uint32_t>(mn)); break;
+				case T_INT: st<int32_t>(slot, rescale<int32_t>((int32_t)q, (int32_t)((1 << (uint32_t)oq) - 1), ld<int32_t>(sc)) + ld<int32_t>(mn)); break;
+				case T_USHORT: st<uint16_t>(slot, (uint16_t)(rescale<uint16_t>((uint16_t)q, (uint16_t)((1 << (uint32_t)oq) - 1), ld<uint16_t>(sc)) + ld<uint16_t>(mn))); break;
+				case T_SHORT: st<int16_t>(slot, (int16_t)(rescale<int16_t>((int16_t)q, (int16_t)((1 << (uint32_t)oq) - 1), ld<int16_t>(sc)) + ld<int16_t>(mn))); break;
+				case T_UCHAR: st<uint8_t>(slot, (uint8_t)(rescale<uint8_t>((uint8_t)q, (uint8_t)((1 << (uint32_t)oq) - 1), ld<uint8_t>(sc)) + ld<uint8_t>(mn))); break;
+				case T_CHAR: st<int8_t>(slot, (int8_t)(rescale<int8_t>((int8_t)q, (int8_t)((1 << (uint32_t)oq) - 1), ld<int8_t>(sc)) + ld<int8_t>(mn))); break;
+				default: throw std::runtime_error("oracle: dequantisation of 8-byte integer types is not restated");
+				}
+			}
+		}
+	}
+	L.fmt = nf;
+}
+
+static void requant(Mesh &m, const int *tr, int n, bool clear)   // main.cc:74-91 + quant.h:222-242
+{
+	std::vector<Fmt> nf;
+	for (auto &L : m.lists) nf.push_back(L.fmt);
+	struct Q { int l, o, q; };
+	std::vector<Q> qs;
+	for (int i = 0; i < n; ++i) {
+		int l = tr[3 * i], o = tr[3 * i + 1], q = tr[3 * i + 2];
+		if (q < 0) throw std::runtime_error("Invalid quantization bits");
+		if (l < 0 || l >= (int)m.lists.size()) throw std::runtime_error("Invalid list index");
+		const Fmt &f = m.lists[l].fmt;
+		if (o == -1) {
+			for (int c = 0; c < f.size(); ++c) {
+				if (q > TSIZE[f.type[c]] * 8) throw std::runtime_error("Invalid quantization bits");
+				qs.push_back(Q{ l, c, q });
+			}
+		} else {
+			if (o < 0 || o >= f.size()) throw std::runtime_error("Invalid attribute index");
+			if (q > TSIZE[f.type[o]] * 8) throw std::runtime_error("Invalid quantization bits");
+			qs.push_back(Q{ l, o, q });
+		}
+	}
+	if (clear) for (auto &f : nf) for (int c = 0; c < f.size(); ++c) f.setquant(c, 0);
+	for (const Q &q : qs) nf[q.l].setquant(q.o, q.q);
+	for (size_t l = 0; l < m.lists.size(); ++l) requant_list(m.lists[l], nf[l]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PLY subset reader (formats/ply/reader.cc:36-429) + half-edge twin matching (structs/conn.h:172-234)
+// ------------------------------------------------------------------------------------------------
+struct PlyProp { std::string name; Type type; Type len_type; };
+struct PlyElem { std::string name; long len; std::vector<PlyProp> props; };
+
+static Type ply_type(const std::string &s)   // reader.cc:70-81
+{
+	if (s == "float" || s == "float32") return T_FLOAT;
+	if (s == "double" || s == "float64") return T_DOUBLE;
+	if (s == "uint" || s == "uint32") return T_UINT;
+	if (s == "int" || s == "int32") return T_INT;
+	if (s == "ushort" || s == "uint16") return T_USHORT;
+	if (s == "short" || s == "int16") return T_SHORT;
+	if (s == "uchar" || s == "uint8") return T_UCHAR;
+	if (s == "char" || s == "int8") return T_CHAR;
+	throw std::runtime_error("Invalid data type");
+}
+static const std::unordered_map<std::string, int> &well_known()   // reader.cc:36-57: canonical order of well-known names
+{
+	static const std::unordered_map<std::string, int> m = {
+		{ "x", 0 }, { "y", 1 }, { "z", 2 }, { "w", 3 }, { "nx", 4 }, { "ny", 5 }, { "nz", 6 }, { "nw", 7 },
+		{ "red", 8 }, { "green", 9 }, { "blue", 10 }, { "alpha", 11 },
+		{ "ambient_red", 12 }, { "ambient_green", 13 }, { "ambient_blue", 14 }, { "ambient_alpha", 15 }, { "ambient_coeff", 16 },
+		{ "diffuse_red", 17 }, { "diffuse_green", 18 }, { "diffuse_blue", 19 }, { "diffuse_alpha", 20 }, { "diffuse_coeff", 21 },
+		{ "specular_red", 22 }, { "specular_green", 23 }, { "specular_blue", 24 }, { "specular_alpha", 25 }, { "specular_power", 26 }, { "specular_coeff", 27 },
+		{ "u", 28 }, { "tu", 28 }, { "v", 29 }, { "tv", 29 }, { "tw", 30 }, { "value", 31 }, { "scale", 31 }, { "confidence", 32 },
+	};
+	return m;
+}
+static int interp_of_weight(int w)   // reader.cc:58-68
+{
+	if (w < 4) return I_POS;
+	if (w < 8) return I_NORMAL;
+	if (w < 12) return I_COLOR;
+	if (w < 17) return I_COLOR_AMBIENT;
+	if (w < 22) return I_COLOR_DIFFUSE;
+	if (w < 28) return I_COLOR_SPECULAR;
+	if (w < 31) return I_TEX;
+	if (w == 31) return I_SCALE;
+	return I_CONFIDENCE;
+}
+static const int WKEND = 33;
+
+// reader.cc:130-168: attribute properties sorted by canonical weight; unknown names keep file order after them
+static void layout_element(const PlyElem &el, std::vector<int> &perm, Fmt &fmt, Interps &interps)
+{
+	int other = WKEND, valid = 0;
+	std::vector<int> weight(el.props.size(), std::numeric_limits<int>::max());
+	for (size_t i = 0; i < el.props.size(); ++i) {
+		if (el.props[i].len_type != T_NONE) continue;
+		auto it = well_known().find(el.props[i].name);
+		weight[i] = it == well_known().end() ? other++ : it->second;
+		++valid;
+	}
+	std::vector<int> inv(el.props.size());
+	for (size_t i = 0; i < inv.size(); ++i) inv[i] = (int)i;
+	std::stable_sort(inv.begin(), inv.end(), [&](int a, int b) { return weight[a] < weight[b]; });
+	perm.assign(el.props.size(), -1);
+	int oid = 0;
+	for (int i = 0; i < valid; ++i) {
+		int t = inv[i];
+		fmt.add(el.props[t].type);
+		int w = weight[t];
+		int interp = w >= WKEND ? I_OTHER + oid++ : interp_of_weight(w);
+		interps.append(interp, i);
+		if (interp >= I_OTHER) interps.describe(interp, el.props[t].name);
+		perm[t] = i;
+	}
+}
+
+struct Cursor {
+	const uint8_t *p, *end;
+	bool eof() const { return p >= end; }
+	void skip_ws() { while (p < end && isspace(*p)) ++p; }
+	std::string token() { skip_ws(); const uint8_t *b = p; while (p < end && !isspace(*p)) ++p; return std::string((const char*)b, (const char*)p); }
+	void skip_line() { while (p < end && *p != '\n') ++p; if (p < end) ++p; }
+};
+template <typename T> static T bswap(T v) { uint8_t *b = (uint8_t*)&v; std::reverse(b, b + sizeof(T)); return v; }
+
+struct ValueReader {   // reader.cc:245-321
+	int mode;   // 0 ascii, 1 LE, 2 BE
+	Cursor &c;
+	uint64_t read(uint8_t *dst, Type t)
+	{
+		if (t == T_NONE) return 1;
+		if (mode == 0) {
+			std::string tok = c.token();
+			if (tok.empty()) throw std::runtime_error("oracle: truncated PLY");
+			switch (t) {
+			case T_CHAR: { int8_t v = (int8_t)strtoll(tok.c_str(), 0, 10); st(dst, v); return (uint64_t)v; }
+			case T_UCHAR: { uint8_t v = (uint8_t)strtoull(tok.c_str(), 0, 10); st(dst, v); return v; }
+			case T_SHORT: { int16_t v = (int16_t)strtoll(tok.c_str(), 0, 10); st(dst, v); return (uint64_t)v; }
+			case T_USHORT: { uint16_t v = (uint16_t)strtoull(tok.c_str(), 0, 10); st(dst, v); return v; }
+			case T_INT: { int32_t v = (int32_t)strtoll(tok.c_str(), 0, 10); st(dst, v); return (uint64_t)v; }
+			case T_UINT: { uint32_t v = (uint32_t)strtoull(tok.c_str(), 0, 10); st(dst, v); return v; }
+			case T_FLOAT: { float v = (float)strtod(tok.c_str(), 0); st(dst, v); return (uint64_t)v; }
+			case T_DOUBLE: { double v = strtod(tok.c_str(), 0); st(dst, v); return (uint64_t)v; }
+			default: throw std::runtime_error("oracle: bad PLY type");
+			}
+		}
+		int n = TSIZE[t];
+		if ((size_t)(c.end - c.p) < (size_t)n) throw std::runtime_error("oracle: truncated PLY");
+		uint8_t tmp[8];
+		memcpy(tmp, c.p, n);
+		c.p += n;
+		if (mode == 2) std::reverse(tmp, tmp + n);
+		memcpy(dst, tmp, n);
+		switch (t) {
+		case T_CHAR: return (uint64_t)ld<int8_t>(tmp);
+		case T_UCHAR: return ld<uint8_t>(tmp);
+		case T_SHORT: return (uint64_t)ld<int16_t>(tmp);
+		case T_USHORT: return ld<uint16_t>(tmp);
+		case T_INT: return (uint64_t)ld<int32_t>(tmp);
+		case T_UINT: return ld<uint32_t>(tmp);
+		case T_FLOAT: return (uint64_t)ld<float>(tmp);
+		case T_DOUBLE: return (uint64_t)ld<double>(tmp);
+		default: return 0;
+		}
+	}
+};
+
+struct PairHash { size_t operator()(const std::pair<uint32_t, uint32_t> &x) const { return std::hash<uint32_t>()(x.first) * 0x9e3779b97f4a7c15ull + x.second; } };
+
+// conn.h:201-232: a directed edge (a,b) is matched with a pending (b,a); a duplicate pending key is NOT replaced
+struct TwinMatcher {
+	std::unordered_map<std::pair<uint32_t, uint32_t>, he_t, PairHash> pending;
+	Mesh &m;
+	explicit TwinMatcher(Mesh &mm) : m(mm) {}
+	void edge(uint32_t a, uint32_t b, he_t e)
+	{
+		auto it = pending.find(std::make_pair(b, a));
+		if (it != pending.end()) { m.merge(it->second, e); pending.erase(it); }
+		else pending.insert(std::make_pair(std::make_pair(a, b), e));
+	}
+};
+
+static Mesh *read_ply(const uint8_t *buf, size_t n)
+{
+	Cursor c{ buf, buf + n };
+	std::vector<PlyElem> elems;
+	int mode = -1;
+	std::string id;
+	do {   // reader.cc:197-243
+		id = c.token();
+		if (c.eof() && id.empty()) throw std::runtime_error("oracle: PLY header without end_header");
+		if (id == "ply") {}
+		else if (id == "format") {
+			std::string f = c.token();
+			if (f == "ascii") mode = 0; else if (f == "binary_little_endian") mode = 1; else if (f == "binary_big_endian") mode = 2;
+			else throw std::runtime_error("Invlaid format");
+			c.skip_line();
+		} else if (id == "comment") c.skip_line();
+		else if (id == "element") { PlyElem e; e.name = c.token(); e.len = atol(c.token().c_str()); elems.push_back(e); }
+		else if (id == "property") {
+			if (elems.empty()) throw std::runtime_error("Invlaid property");
+			std::string ty = c.token();
+			Type lt = T_NONE;
+			if (ty == "list") { lt = ply_type(c.token()); ty = c.token(); }
+			std::string nm = c.token();
+			elems.back().props.push_back(PlyProp{ nm, ply_type(ty), lt });
+		} else if (id != "end_header") c.skip_line();
+	} while (id != "end_header");
+	c.skip_line();
+	if (mode < 0) throw std::runtime_error("oracle: PLY without format line");
+
+	int fi = -1, vi = -1;
+	for (size_t i = 0; i < elems.size(); ++i) { if (elems[i].name == "face") fi = (int)i; if (elems[i].name == "vertex") vi = (int)i; }
+	if (fi < 0 || vi < 0) throw std::runtime_error("oracle: PLY needs vertex and face elements");
+	Mesh *m = new Mesh();
+	try {
+		std::vector<int> perm[2];
+		int idx[2] = { fi, vi };
+		for (int k = 0; k < 2; ++k) {   // reader.cc:388-400: list 0 = face attributes, list 1 = vertex attributes
+			List L;
+			layout_element(elems[idx[k]], perm[k], L.fmt, L.interps);
+			L.target = k == 0 ? TG_FACE : TG_VTX;
+			L.count = (uint32_t)elems[idx[k]].len;
+			L.data.assign((size_t)L.count * L.fmt.bytes(), 0);
+			m->lists.push_back(std::move(L));
+		}
+		m->nf = (uint32_t)elems[fi].len;
+		m->nv = (uint32_t)elems[vi].len;
+		int vidx = -1;
+		for (size_t k = 0; k < elems[fi].props.size(); ++k) if (elems[fi].props[k].name == "vertex_indices") vidx = (int)k;
+		ValueReader rd{ mode, c };
+		TwinMatcher tm(*m);
+		tm.pending.reserve((size_t)m->nf * 3);
+		uint8_t ign[8];
+		for (size_t ei = 0; ei < elems.size(); ++ei) {   // reader.cc:323-380
+			const PlyElem &el = elems[ei];
+			bool attr_el = (int)ei == fi || (int)ei == vi;
+			int list = (int)ei == fi ? 0 : 1;
+			for (long j = 0; j < el.len; ++j) {
+				for (size_t k = 0; k < el.props.size(); ++k) {
+					const PlyProp &pp = el.props[k];
+					if (!attr_el || perm[list][k] == -1) {
+						uint64_t len = rd.read(ign, pp.len_type);
+						if (attr_el && pp.len_type != T_NONE && (int)ei == fi && (int)k == vidx) {
+							uint32_t f = m->add_face((int)len);
+							uint32_t first = 0, last = NOVTX;
+							for (uint64_t l = 0; l < len; ++l) {
+								uint32_t v = (uint32_t)rd.read(ign, pp.type);
+								he_t e = m->foff[f] + (uint32_t)l;
+								m->set_org(e, v);
+								if (last != NOVTX) tm.edge(last, v, e - 1); else first = v;
+								last = v;
+							}
+							tm.edge(last, first, m->foff[f] + (uint32_t)len - 1);
+						} else for (uint64_t l = 0; l < len; ++l) rd.read(ign, pp.type);
+					} else {
+						List &L = m->lists[list];
+						rd.read(L.rec((uint32_t)j) + L.fmt.off[perm[list][k]], pp.type);
+					}
+				}
+			}
+		}
+		if (m->num_face() != m->nf) throw std::runtime_error("oracle: PLY face element without vertex_indices");
+		for (uint32_t v : m->org) if (v >= m->nv) throw std::runtime_error("oracle: PLY vertex index out of range");
+		for (auto &L : m->lists) set_bounds(L);   // reader.cc:428
+	} catch (...) { delete m; throw; }
+	return m;
+}
+
+}   // namespace ho
+
+// ------------------------------------------------------------------------------------------------
+// C interface
+// ------------------------------------------------------------------------------------------------
+struct ho_mesh { ho::Mesh m; };
+struct ho_result { ho::Result r; };
+
+#define HO_TRY try {
+#define HO_CATCH(ret) } catch (const std::exception &e) { ho::g_err = e.what(); return ret; }
+
+extern "C" {
+
+const char *ho_last_error(void) { return ho::g_err.c_str(); }
+
+ho_mesh *ho_mesh_from_ply(const uint8_t *ply, size_t n)
+{
+	HO_TRY
+	ho::Mesh *m = ho::read_ply(ply, n);
+	ho_mesh *h = new ho_mesh{ std::move(*m) };
+	delete m;
+	return h;
+	HO_CATCH(nullptr)
+}
+ho_mesh *ho_mesh_from_hry(const uint8_t *hry, size_t n)
+{
+	HO_TRY
+	ho::Mesh *m = ho::decode(hry, n);
+	ho_mesh *h = new ho_mesh{ std::move(*m) };
+	delete m;
+	return h;
+	HO_CATCH(nullptr)
+}
+ho_mesh *ho_mesh_clone(const ho_mesh *m) { return new ho_mesh{ m->m }; }
+void ho_mesh_free(ho_mesh *m) { delete m; }
+
+int ho_requant(ho_mesh *m, const int *triples, int n, int clear)
+{
+	HO_TRY
+	ho::requant(m->m, triples, n, clear != 0);
+	return 0;
+	HO_CATCH(-1)
+}
+ho_result *ho_encode(ho_mesh *m, int trace)
+{
+	HO_TRY
+	ho::Result *r = ho::encode(m->m, trace != 0);
+	ho_result *h = new ho_result{ std::move(*r) };
+	delete r;
+	return h;
+	HO_CATCH(nullptr)
+}
+void ho_result_free(ho_result *r) { delete r; }
+size_t ho_result_size(const ho_result *r) { return r->r.bytes.size(); }
+const uint8_t *ho_result_data(const ho_result *r) { return r->r.bytes.data(); }
+size_t ho_result_header_size(const ho_result *r) { return r->r.header_size; }
+size_t ho_result_trace_len(const ho_result *r) { return r->r.trace.size(); }
+const ho_sym *ho_result_trace(const ho_result *r) { return r->r.trace.data(); }
+size_t ho_result_order_vtx(const ho_result *r, const uint32_t **out) { *out = r->r.order_v.data(); return r->r.order_v.size(); }
+size_t ho_result_order_face(const ho_result *r, const uint32_t **out) { *out = r->r.order_f.data(); return r->r.order_f.size(); }
+
+uint32_t ho_mesh_nv(const ho_mesh *m) { return m->m.nv; }
+uint32_t ho_mesh_nf(const ho_mesh *m) { return m->m.nf; }
+uint32_t ho_mesh_ne(const ho_mesh *m) { return m->m.num_edge(); }
+uint64_t ho_mesh_ntri(const ho_mesh *m) { return m->m.num_tri(); }
+const uint32_t *ho_mesh_face_offsets(const ho_mesh *m) { return m->m.foff.data(); }
+const uint32_t *ho_mesh_org(const ho_mesh *m) { return m->m.org.data(); }
+const uint32_t *ho_mesh_twin(const ho_mesh *m) { return m->m.twin.data(); }
+int ho_mesh_nlists(const ho_mesh *m) { return (int)m->m.lists.size(); }
+int ho_list_ncomp(const ho_mesh *m, int l) { return m->m.lists[l].fmt.size(); }
+int ho_list_target(const ho_mesh *m, int l) { return m->m.lists[l].target; }
+uint32_t ho_list_count(const ho_mesh *m, int l) { return m->m.lists[l].count; }
+int ho_list_stride(const ho_mesh *m, int l) { return m->m.lists[l].fmt.bytes(); }
+int ho_list_type(const ho_mesh *m, int l, int c) { return m->m.lists[l].fmt.type[c]; }
+int ho_list_quant(const ho_mesh *m, int l, int c) { return m->m.lists[l].fmt.quant[c]; }
+int ho_list_offset(const ho_mesh *m, int l, int c) { return m->m.lists[l].fmt.off[c]; }
+const uint8_t *ho_list_data(const ho_mesh *m, int l) { return m->m.lists[l].data.data(); }
+const uint8_t *ho_list_min(const ho_mesh *m, int l) { return m->m.lists[l].bmin.data(); }
+const uint8_t *ho_list_max(const ho_mesh *m, int l) { return m->m.lists[l].bmax.data(); }
+
+int ho_ctx_count(const ho_mesh *m) { ho::Models md(m->m); return (int)md.tab.size(); }
+int ho_ctx_attr_base(const ho_mesh *m, int l) { ho::Models md(m->m); return md.attr_base[l]; }
+
+uint32_t ho_kat_encode_delta_f32(uint32_t raw, uint32_t pred)
+{
+	float r = ho::bitcast<uint32_t, float>(raw), p = ho::bitcast<uint32_t, float>(pred);
+	return ho::bitcast<float, uint32_t>(ho::fold_residual<float>(r, p, 0, std::true_type()));
+}
+uint32_t ho_kat_decode_delta_f32(uint32_t d, uint32_t pred)
+{
+	float r = ho::bitcast<uint32_t, float>(d), p = ho::bitcast<uint32_t, float>(pred);
+	return ho::bitcast<float, uint32_t>(ho::unfold_residual<float>(r, p, 0, std::true_type()));
+}
+uint32_t ho_kat_encode_delta_u(uint32_t raw, uint32_t pred, int bytes, int q)
+{
+	switch (bytes) {
+	case 1: return ho::fold_residual<uint8_t>((uint8_t)raw, (uint8_t)pred, q, std::false_type());
+	case 2: return ho::fold_residual<uint16_t>((uint16_t)raw, (uint16_t)pred, q, std::false_type());
+	default: return ho::fold_residual<uint32_t>(raw, pred, q, std::false_type());
+	}
+}
+uint32_t ho_kat_decode_delta_u(uint32_t d, uint32_t pred, int bytes, int q)
+{
+	switch (bytes) {
+	case 1: return ho::unfold_residual<uint8_t>((uint8_t)d, (uint8_t)pred, q, std::false_type());
+	case 2: return ho::unfold_residual<uint16_t>((uint16_t)d, (uint16_t)pred, q, std::false_type());
+	default: return ho::unfold_residual<uint32_t>(d, pred, q, std::false_type());
+	}
+}
+uint32_t ho_kat_predict_u(uint32_t v0, uint32_t v1, uint32_t v2, int bytes, int q)
+{
+	switch (bytes) {
+	case 1: return ho::paral_predict<uint8_t>((uint8_t)v0, (uint8_t)v1, (uint8_t)v2, q, std::false_type());
+	case 2: return ho::paral_predict<uint16_t>((uint16_t)v0, (uint16_t)v1, (uint16_t)v2, q, std::false_type());
+	default: return ho::paral_predict<uint32_t>(v0, v1, v2, q, std::false_type());
+	}
+}
+uint32_t ho_kat_predict_f32(uint32_t v0, uint32_t v1, uint32_t v2)
+{
+	using ho::bitcast;
+	return bitcast<float, uint32_t>(ho::paral_predict<float>(bitcast<uint32_t, float>(v0), bitcast<uint32_t, float>(v1), bitcast<uint32_t, float>(v2), 0, std::true_type()));
+}
+uint64_t ho_kat_requant_f32(uint32_t v, uint32_t mn, uint32_t sc, int q)
+{
+	using ho::bitcast;
+	return ho::quantise_scalar_f32(bitcast<uint32_t, float>(v), bitcast<uint32_t, float>(mn), bitcast<uint32_t, float>(sc), q);
+}
+size_t ho_kat_range_encode_bytes(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
+{
+	std::vector<uint8_t> out;
+	ho::RangeEncoder rc(out);
+	ho::FreqTable f(256);
+	for (uint32_t i = 0; i < 256; ++i) f.inc(i);
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t l, h, t = f.total();
+		f.range_of(src[i], l, h);
+		rc.encode(l, h, t);
+		f.inc(src[i]);
+	}
+	rc.finish();
+	if (out.size() <= cap) memcpy(dst, out.data(), out.size());
+	return out.size();
+}
+size_t ho_kat_range_decode_bytes(const uint8_t *src, size_t nsrc, uint8_t *dst, size_t nsym)
+{
+	ho::RangeDecoder rc(src, src + nsrc);
+	ho::FreqTable f(256);
+	for (uint32_t i = 0; i < 256; ++i) f.inc(i);
+	for (size_t i = 0; i < nsym; ++i) {
+		uint64_t l, h, t = f.total();
+		uint32_t s = f.find(rc.target(t), l, h);
+		rc.consume(l, h, t);
+		f.inc(s);
+		dst[i] = (uint8_t)s;
+	}
+	return nsym;
+}
+size_t ho_kat_range_encode_lht(const uint64_t *lht, size_t n, uint8_t *dst, size_t cap)
+{
+	std::vector<uint8_t> out;
+	ho::RangeEncoder rc(out);
+	for (size_t i = 0; i < n; ++i) rc.encode(lht[3 * i], lht[3 * i + 1], lht[3 * i + 2]);
+	rc.finish();
+	if (out.size() <= cap) memcpy(dst, out.data(), out.size());
+	return out.size();
+}
+
+}   // extern "C"
