@@ -1,0 +1,114 @@
+"""ctypes binding of libharry_amd.so (C ABI: include/harry_amd.h).
+
+The library is built in-tree by `make -C harry_amd/csrc` (driven by __graft_entry__.build()).  There is no Python or
+CPU implementation behind this module: if the shared library is missing, importing fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libharry_amd.so")
+
+
+class HryError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{msg} (code {code})")
+        self.code = code
+        self.msg = msg
+
+
+class Quant(C.Structure):
+    _fields_ = [("list", C.c_int32), ("comp", C.c_int32), ("bits", C.c_int32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("profile", C.c_int32), ("chunk_syms", C.c_int32), ("keep_stages", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("host_walk_ms", C.c_double), ("h2d_ms", C.c_double), ("device_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("total_ms", C.c_double), ("k_rchain_ms", C.c_double), ("k_model_ms", C.c_double), ("k_predict_ms", C.c_double),
+                ("k_entropy_ms", C.c_double), ("n_symbols", C.c_uint64), ("payload_bytes", C.c_uint64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+OK, E_ARG, E_FORMAT, E_UNSUPPORTED, E_NODEVICE, E_NOMEM, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+PROFILE_COMPAT, PROFILE_CHUNKED = 0, 1
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C harry_amd/csrc` (hipcc, gfx950). "
+                          "harry_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u8p, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    L.hry_last_error.restype = C.c_char_p
+    L.hry_abi_version.restype = C.c_int
+    L.hry_ctx_create.restype = C.c_int; L.hry_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.hry_ctx_destroy.argtypes = [vp]
+    L.hry_ctx_timing.restype = C.c_int; L.hry_ctx_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.hry_ctx_stream.restype = vp; L.hry_ctx_stream.argtypes = [vp]
+    L.hry_mesh_from_ply.restype = C.c_int; L.hry_mesh_from_ply.argtypes = [C.c_char_p, sz, C.POINTER(vp)]
+    L.hry_mesh_from_arrays.restype = C.c_int
+    L.hry_mesh_from_arrays.argtypes = [C.c_uint32, vp, C.c_int, vp, C.POINTER(C.c_char_p), C.c_uint32, vp, vp, vp, C.c_int, vp,
+                                       C.POINTER(C.c_char_p), C.POINTER(vp)]
+    L.hry_mesh_to_ply.restype = C.c_int; L.hry_mesh_to_ply.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    L.hry_mesh_free.argtypes = [vp]
+    L.hry_mesh_clone.restype = vp; L.hry_mesh_clone.argtypes = [vp]
+    for n in ("nv", "nf", "ne"):
+        f = getattr(L, "hry_mesh_" + n); f.restype = C.c_uint32; f.argtypes = [vp]
+    L.hry_mesh_ntri.restype = C.c_uint64; L.hry_mesh_ntri.argtypes = [vp]
+    for n in ("face_offsets", "org", "twin"):
+        f = getattr(L, "hry_mesh_" + n); f.restype = u32p; f.argtypes = [vp]
+    L.hry_mesh_nlists.restype = C.c_int; L.hry_mesh_nlists.argtypes = [vp]
+    for n in ("ncomp", "stride"):
+        f = getattr(L, "hry_list_" + n); f.restype = C.c_int; f.argtypes = [vp, C.c_int]
+    L.hry_list_count.restype = C.c_uint32; L.hry_list_count.argtypes = [vp, C.c_int]
+    for n in ("type", "quant", "offset"):
+        f = getattr(L, "hry_list_" + n); f.restype = C.c_int; f.argtypes = [vp, C.c_int, C.c_int]
+    for n in ("data", "min", "max"):
+        f = getattr(L, "hry_list_" + n); f.restype = u8p; f.argtypes = [vp, C.c_int]
+    L.hry_bounds.restype = C.c_int; L.hry_bounds.argtypes = [vp, vp]
+    L.hry_requant.restype = C.c_int; L.hry_requant.argtypes = [vp, vp, C.POINTER(Quant), sz, C.c_int]
+    L.hry_mesh_upload.restype = C.c_int; L.hry_mesh_upload.argtypes = [vp, vp]
+    L.hry_encode.restype = C.c_int; L.hry_encode.argtypes = [vp, vp, C.POINTER(Opts), C.POINTER(vp), C.POINTER(sz)]
+    L.hry_decode.restype = C.c_int; L.hry_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(Opts), C.POINTER(vp)]
+    L.hry_free.argtypes = [vp]
+    L.hry_stage_get.restype = C.c_int; L.hry_stage_get.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
+    L.hry_walk_run.restype = C.c_int; L.hry_walk_run.argtypes = [vp, C.POINTER(vp)]
+    L.hry_walk_get.restype = sz; L.hry_walk_get.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.hry_walk_free.argtypes = [vp]
+    L.hry_range_encode_lht.restype = C.c_int; L.hry_range_encode_lht.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise HryError(rc, load().hry_last_error().decode(errors="replace"))
+
+
+def take_bytes(ptr, n) -> bytes:
+    """Copy a library-allocated buffer and release it."""
+    try:
+        return C.string_at(ptr, n)
+    finally:
+        load().hry_free(ptr)
+
+
+def arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).copy()

@@ -1,0 +1,236 @@
+"""Host-side mirror of the reference's interface for the .hry path, on top of the C ABI (include/harry_amd.h).
+
+Reference seams mirrored here (names and argument meaning follow the reference):
+    unified::reader::read(fn, mesh)      formats/unified_reader.h:78-86   -> read_mesh(path)
+    quant::requant(attrs, quants, clear) structs/quant.h:222-242          -> Codec.requant(mesh, quants, clear)
+    hry::writer::write(os, mesh)         formats/hry/writer.h:19          -> Codec.write_hry(mesh)
+    hry::reader::read(is, mesh)          formats/hry/reader.h:19          -> Codec.read_hry(data)
+    ply::writer::write(os, mesh, ascii)  formats/ply/writer.cc:136-192    -> Mesh.to_ply(ascii)
+
+All computation happens in libharry_amd.so (host C++ for the walk / PLY I/O, HIP kernels for the rest).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from ._native import HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
+
+TYPE_NP = {0: "<f4", 1: "<f8", 2: "<u8", 3: "<i8", 4: "<u4", 5: "<i4", 6: "<u2", 7: "<i2", 8: "u1", 9: "i1"}
+TYPE_SIZE = {0: 4, 1: 8, 2: 8, 3: 8, 4: 4, 5: 4, 6: 2, 7: 2, 8: 1, 9: 1}
+NP_TYPE = {"f4": 0, "f8": 1, "u8": 2, "i8": 3, "u4": 4, "i4": 5, "u2": 6, "i2": 7, "u1": 8, "i1": 9}
+
+
+def storage_type(t: int, q: int) -> int:
+    """structs/mixing.h:101-108"""
+    if q == 0:
+        return t
+    return 8 if q <= 8 else 6 if q <= 16 else 4 if q <= 32 else 2
+
+
+class Mesh:
+    """In-memory mesh (reference: mesh::Mesh, structs/mesh.h:19-40) as flat arrays owned by the native library."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            nat.load().hry_mesh_free(self.h)
+            self.h = None
+
+    # ---- construction
+    @classmethod
+    def from_ply(cls, data: bytes) -> "Mesh":
+        h = C.c_void_p()
+        nat.check(nat.load().hry_mesh_from_ply(data, len(data), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, verts: np.ndarray, degrees: np.ndarray, indices: np.ndarray, face_props: np.ndarray | None = None) -> "Mesh":
+        """verts / face_props: numpy structured arrays (packed), one field per component."""
+        L = nat.load()
+
+        def pack(a):
+            if a is None or a.dtype.names is None or len(a.dtype.names) == 0:
+                return None, 0, None, None, []
+            names = list(a.dtype.names)
+            packed = np.empty(len(a), dtype=np.dtype([(n, a.dtype[n].newbyteorder("<")) for n in names]))
+            for n in names:
+                packed[n] = a[n]
+            types = np.array([NP_TYPE[a.dtype[n].str[1:]] for n in names], np.uint8)
+            cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
+            return packed, len(names), types, cn, names
+
+        vp, vn, vt, vnames, _ = pack(verts)
+        fp, fn, ft, fnames, _ = pack(face_props)
+        degrees = np.ascontiguousarray(degrees, np.uint8)
+        indices = np.ascontiguousarray(indices, np.uint32)
+        h = C.c_void_p()
+        nat.check(L.hry_mesh_from_arrays(
+            len(verts), vp.ctypes.data if vp is not None else None, vn, vt.ctypes.data if vt is not None else None, vnames,
+            len(degrees), degrees.ctypes.data, indices.ctypes.data,
+            fp.ctypes.data if fp is not None else None, fn, ft.ctypes.data if ft is not None else None, fnames, C.byref(h)))
+        return cls(h)
+
+    def clone(self) -> "Mesh":
+        h = nat.load().hry_mesh_clone(self.h)
+        if not h:
+            raise MemoryError("hry_mesh_clone")
+        return Mesh(C.c_void_p(h))
+
+    # ---- accessors
+    nv = property(lambda s: nat.load().hry_mesh_nv(s.h))
+    nf = property(lambda s: nat.load().hry_mesh_nf(s.h))
+    ne = property(lambda s: nat.load().hry_mesh_ne(s.h))
+    ntri = property(lambda s: nat.load().hry_mesh_ntri(s.h))
+
+    def face_offsets(self):
+        return nat.arr(nat.load().hry_mesh_face_offsets(self.h), self.nf + 1, np.uint32)
+
+    def org(self):
+        return nat.arr(nat.load().hry_mesh_org(self.h), self.ne, np.uint32)
+
+    def twin(self):
+        return nat.arr(nat.load().hry_mesh_twin(self.h), self.ne, np.uint32)
+
+    def list_fmt(self, l):
+        L = nat.load()
+        return [(L.hry_list_type(self.h, l, c), L.hry_list_quant(self.h, l, c), L.hry_list_offset(self.h, l, c))
+                for c in range(L.hry_list_ncomp(self.h, l))]
+
+    def list_stride(self, l):
+        return nat.load().hry_list_stride(self.h, l)
+
+    def list_count(self, l):
+        return nat.load().hry_list_count(self.h, l)
+
+    def list_data(self, l) -> np.ndarray:
+        n, s = self.list_count(l), self.list_stride(l)
+        if n * s == 0:
+            return np.zeros((n, s), np.uint8)
+        return nat.arr(nat.load().hry_list_data(self.h, l), n * s, np.uint8).reshape(n, s)
+
+    def list_min(self, l):
+        p = nat.load().hry_list_min(self.h, l)
+        return nat.arr(p, self.list_stride(l), np.uint8) if p else None
+
+    def list_max(self, l):
+        p = nat.load().hry_list_max(self.h, l)
+        return nat.arr(p, self.list_stride(l), np.uint8) if p else None
+
+    def component(self, l, c) -> np.ndarray:
+        t, q, off = self.list_fmt(l)[c]
+        st = storage_type(t, q)
+        return self.list_data(l)[:, off:off + TYPE_SIZE[st]].copy().view(TYPE_NP[st]).reshape(-1)
+
+    def to_ply(self, ascii: bool = False) -> bytes:
+        p, n = C.c_void_p(), C.c_size_t()
+        nat.check(nat.load().hry_mesh_to_ply(self.h, int(ascii), C.byref(p), C.byref(n)))
+        return nat.take_bytes(p, n.value)
+
+    def host_walk(self) -> dict:
+        """Host-only cut-border walk with a recording writer (mutates twins like an encode)."""
+        L = nat.load()
+        w = C.c_void_p()
+        nat.check(L.hry_walk_run(self.h, C.byref(w)))
+        try:
+            out = {}
+            names = [("order_v", np.uint32), ("order_f", np.uint32), ("op_sym", np.uint8), ("op_class", np.uint8), ("op_l", np.uint32),
+                     ("op_h", np.uint32), ("op_t", np.uint32), ("op_pos", np.uint32), ("info", np.uint32)]
+            for g in range(5):
+                names += [(f"grp{g}_val", np.uint32), (f"grp{g}_pos", np.uint32)]
+            for name, dt in names:
+                p = C.c_void_p()
+                n = L.hry_walk_get(w, name.encode(), C.byref(p))
+                out[name] = (np.frombuffer(C.string_at(p, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt))
+            return out
+        finally:
+            L.hry_walk_free(w)
+
+
+class Codec:
+    """Device context (one HIP device, one stream).  Raises HryError(E_NODEVICE) without a GPU: no CPU fallback."""
+
+    def __init__(self, device: int = 0):
+        self.h = C.c_void_p()
+        nat.check(nat.load().hry_ctx_create(device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            nat.load().hry_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def bounds(self, mesh: Mesh):
+        nat.check(nat.load().hry_bounds(self.h, mesh.h))
+
+    def requant(self, mesh: Mesh, quants, clear: bool = False):
+        """quants: iterable of (list, component or -1, bits) as produced by the reference CLI's -l/-a/-q flags."""
+        qs = list(quants)
+        arr = (nat.Quant * max(len(qs), 1))(*[nat.Quant(int(l), int(c), int(b)) for l, c, b in qs])
+        nat.check(nat.load().hry_requant(self.h, mesh.h, arr, len(qs), int(clear)))
+
+    def upload(self, mesh: Mesh):
+        nat.check(nat.load().hry_mesh_upload(self.h, mesh.h))
+
+    def write_hry(self, mesh: Mesh, profile: int = PROFILE_COMPAT, chunk_syms: int = 0, keep_stages: bool = False) -> bytes:
+        o = nat.Opts(profile, chunk_syms, int(keep_stages), 0)
+        p, n = C.c_void_p(), C.c_size_t()
+        nat.check(nat.load().hry_encode(self.h, mesh.h, C.byref(o), C.byref(p), C.byref(n)))
+        return nat.take_bytes(p, n.value)
+
+    def read_hry(self, data: bytes, keep_stages: bool = False) -> Mesh:
+        o = nat.Opts(0, 0, int(keep_stages), 0)
+        h = C.c_void_p()
+        nat.check(nat.load().hry_decode(self.h, data, len(data), C.byref(o), C.byref(h)))
+        return Mesh(h)
+
+    def timing(self) -> dict:
+        t = nat.Timing()
+        nat.check(nat.load().hry_ctx_timing(self.h, C.byref(t)))
+        return t.asdict()
+
+    def stream(self) -> int:
+        return nat.load().hry_ctx_stream(self.h) or 0
+
+    def stage(self, name: str, dtype=np.uint8) -> np.ndarray:
+        p, n = C.c_void_p(), C.c_size_t()
+        nat.check(nat.load().hry_stage_get(self.h, name.encode(), C.byref(p), C.byref(n)))
+        return np.frombuffer(nat.take_bytes(p, n.value), dtype=dtype).copy()
+
+    def range_encode_lht(self, lht: np.ndarray) -> bytes:
+        lht = np.ascontiguousarray(lht, np.uint64).reshape(-1, 3)
+        p, n = C.c_void_p(), C.c_size_t()
+        nat.check(nat.load().hry_range_encode_lht(self.h, lht.ctypes.data, len(lht), C.byref(p), C.byref(n)))
+        return nat.take_bytes(p, n.value)
+
+
+def parse_quant_flags(flags):
+    """The reference CLI's -l/-a/-q/-c state machine (main.cc:47-71) -> ([(list, comp, bits)], clear)."""
+    cur_l, cur_a, out, clear = None, -1, [], False
+    it = iter(flags)
+    for f in it:
+        if f in ("-l", "--list"):
+            cur_l = int(next(it))
+        elif f.startswith("-l") and f[2:].lstrip("-").isdigit():
+            cur_l = int(f[2:])
+        elif f in ("-a", "--attr"):
+            cur_a = int(next(it))
+        elif f.startswith("-a") and f[2:].lstrip("-").isdigit():
+            cur_a = int(f[2:])
+        elif f in ("-q", "--quant"):
+            out.append((cur_l, cur_a, int(next(it)))); cur_a = -1
+        elif f.startswith("-q") and f[2:].lstrip("-").isdigit():
+            out.append((cur_l, cur_a, int(f[2:]))); cur_a = -1
+        elif f in ("-c", "--clear-quant"):
+            clear = True
+        else:
+            raise ValueError(f"unknown flag {f}")
+    for l, _, _ in out:
+        if l is None:
+            raise ValueError("-q without a preceding -l (the reference reads an uninitialised list index here, main.cc:48)")
+    return out, clear

@@ -1,0 +1,210 @@
+// C ABI of libharry_amd.so (include/harry_amd.h).  Thin: argument checks, exception -> status translation.
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "device/context.hpp"
+
+using namespace hry;
+
+struct hry_ctx { Context cx; explicit hry_ctx(int d) : cx(d) {} };
+struct hry_mesh { Mesh m; };
+struct hry_walk { WalkResult w; uint32_t info[2]; };
+
+static thread_local std::string g_last_error;
+
+template <typename F> static int guarded(F &&f)
+{
+	try { f(); return HRY_OK; }
+	catch (const Error &e) { g_last_error = e.what(); return e.code; }
+	catch (const std::bad_alloc &) { g_last_error = "out of memory"; return HRY_E_NOMEM; }
+	catch (const std::exception &e) { g_last_error = e.what(); return HRY_E_INTERNAL; }
+}
+static uint8_t *dup_bytes(const std::vector<uint8_t> &v)
+{
+	uint8_t *p = (uint8_t*)malloc(v.size() ? v.size() : 1);
+	if (!p) throw std::bad_alloc();
+	if (!v.empty()) memcpy(p, v.data(), v.size());
+	return p;
+}
+
+extern "C" {
+
+const char *hry_last_error(void) { return g_last_error.c_str(); }
+int hry_abi_version(void) { return HRY_ABI_VERSION; }
+
+int hry_ctx_create(int device, hry_ctx **out)
+{
+	if (!out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] { *out = new hry_ctx(device); });
+}
+void hry_ctx_destroy(hry_ctx *ctx) { delete ctx; }
+int hry_ctx_timing(const hry_ctx *ctx, hry_timing *out)
+{
+	if (!ctx || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = ctx->cx.timing;
+	return HRY_OK;
+}
+void *hry_ctx_stream(const hry_ctx *ctx) { return ctx ? (void*)ctx->cx.stream : nullptr; }
+
+int hry_mesh_from_ply(const uint8_t *ply, size_t n, hry_mesh **out)
+{
+	if (!ply || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<Mesh> m(mesh_from_ply(ply, n));
+		*out = new hry_mesh{ std::move(*m) };
+	});
+}
+int hry_mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint8_t *v_types, const char *const *v_names,
+                         uint32_t nf, const uint8_t *degrees, const uint32_t *indices,
+                         const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names, hry_mesh **out)
+{
+	if (!out || (nf && (!degrees || !indices)) || (v_ncomp && (!v_types || !v_names || (nv && !vrec))) || (f_ncomp && (!f_types || !f_names || (nf && !frec)))) {
+		g_last_error = "null argument";
+		return HRY_E_ARG;
+	}
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<Mesh> m(mesh_from_arrays(nv, vrec, v_ncomp, v_types, v_names, nf, degrees, indices, frec, f_ncomp, f_types, f_names));
+		*out = new hry_mesh{ std::move(*m) };
+	});
+}
+int hry_mesh_to_ply(const hry_mesh *m, int ascii, uint8_t **out, size_t *out_len)
+{
+	if (!m || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
+	return guarded([&] {
+		std::vector<uint8_t> v;
+		mesh_to_ply(m->m, ascii != 0, v);
+		*out = dup_bytes(v);
+		*out_len = v.size();
+	});
+}
+void hry_mesh_free(hry_mesh *m) { delete m; }
+hry_mesh *hry_mesh_clone(const hry_mesh *m)
+{
+	if (!m) return nullptr;
+	try { hry_mesh *c = new hry_mesh{ m->m }; c->m.device_token = 0; return c; }
+	catch (...) { g_last_error = "out of memory"; return nullptr; }
+}
+
+uint32_t hry_mesh_nv(const hry_mesh *m) { return m->m.nv; }
+uint32_t hry_mesh_nf(const hry_mesh *m) { return m->m.nf; }
+uint32_t hry_mesh_ne(const hry_mesh *m) { return m->m.ne(); }
+uint64_t hry_mesh_ntri(const hry_mesh *m) { return m->m.ntri(); }
+const uint32_t *hry_mesh_face_offsets(const hry_mesh *m) { return m->m.face_off.data(); }
+const uint32_t *hry_mesh_org(const hry_mesh *m) { return m->m.org.data(); }
+const uint32_t *hry_mesh_twin(const hry_mesh *m) { return m->m.twin.data(); }
+int hry_mesh_nlists(const hry_mesh *) { return 2; }
+int hry_list_ncomp(const hry_mesh *m, int l) { return m->m.lists[l].ncomp(); }
+uint32_t hry_list_count(const hry_mesh *m, int l) { return m->m.lists[l].count; }
+int hry_list_stride(const hry_mesh *m, int l) { return m->m.lists[l].stride(); }
+int hry_list_type(const hry_mesh *m, int l, int c) { return m->m.lists[l].type[c]; }
+int hry_list_quant(const hry_mesh *m, int l, int c) { return m->m.lists[l].quant[c]; }
+int hry_list_offset(const hry_mesh *m, int l, int c) { return m->m.lists[l].offset[c]; }
+const uint8_t *hry_list_data(const hry_mesh *m, int l) { return m->m.lists[l].data.data(); }
+const uint8_t *hry_list_min(const hry_mesh *m, int l) { return m->m.lists[l].have_bounds ? m->m.lists[l].bmin.data() : nullptr; }
+const uint8_t *hry_list_max(const hry_mesh *m, int l) { return m->m.lists[l].have_bounds ? m->m.lists[l].bmax.data() : nullptr; }
+
+int hry_bounds(hry_ctx *ctx, hry_mesh *m)
+{
+	if (!ctx || !m) { g_last_error = "null argument"; return HRY_E_ARG; }
+	return guarded([&] { device_bounds(ctx->cx, m->m); });
+}
+int hry_requant(hry_ctx *ctx, hry_mesh *m, const hry_quant *q, size_t nq, int clear)
+{
+	if (!ctx || !m || (nq && !q)) { g_last_error = "null argument"; return HRY_E_ARG; }
+	return guarded([&] { device_requant(ctx->cx, m->m, q, nq, clear != 0); });
+}
+int hry_mesh_upload(hry_ctx *ctx, hry_mesh *m)
+{
+	if (!ctx || !m) { g_last_error = "null argument"; return HRY_E_ARG; }
+	return guarded([&] { ctx->cx.upload_mesh(m->m); });
+}
+int hry_encode(hry_ctx *ctx, hry_mesh *m, const hry_opts *opts, uint8_t **out, size_t *out_len)
+{
+	if (!ctx || !m || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr; *out_len = 0;
+	return guarded([&] {
+		hry_opts o = opts ? *opts : hry_opts{};
+		ctx->cx.keep_stages = o.keep_stages != 0;
+		ctx->cx.stages.clear();
+		std::vector<uint8_t> v;
+		if (o.profile == HRY_PROFILE_COMPAT) encode_compat(ctx->cx, m->m, v);
+		else if (o.profile == HRY_PROFILE_CHUNKED) encode_chunked(ctx->cx, m->m, o.chunk_syms, v);
+		else throw Error(HRY_E_ARG, "unknown profile");
+		*out = dup_bytes(v);
+		*out_len = v.size();
+	});
+}
+int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out)
+{
+	if (!ctx || !hry || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		hry_opts o = opts ? *opts : hry_opts{};
+		ctx->cx.keep_stages = o.keep_stages != 0;
+		ctx->cx.stages.clear();
+		std::unique_ptr<Mesh> m(decode_any(ctx->cx, hry, n));
+		*out = new hry_mesh{ std::move(*m) };
+	});
+}
+void hry_free(void *p) { free(p); }
+
+int hry_stage_get(hry_ctx *ctx, const char *name, void **host_copy, size_t *bytes)
+{
+	if (!ctx || !name || !host_copy || !bytes) { g_last_error = "null argument"; return HRY_E_ARG; }
+	auto it = ctx->cx.stages.find(name);
+	if (it == ctx->cx.stages.end()) { g_last_error = std::string("no such stage: ") + name; return HRY_E_ARG; }
+	return guarded([&] { *host_copy = dup_bytes(it->second); *bytes = it->second.size(); });
+}
+int hry_walk_run(hry_mesh *m, hry_walk **out)
+{
+	if (!m || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<hry_walk> w(new hry_walk());
+		check_codable(m->m);
+		cut_border_walk(m->m, w->w);
+		w->info[0] = w->w.n_conn; w->info[1] = w->w.numtri_coded ? 1 : 0;
+		*out = w.release();
+	});
+}
+size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
+{
+	if (!w || !name || !ptr) return 0;
+	std::string n(name);
+	const WalkResult &r = w->w;
+	auto ret = [&](const auto &v) { *ptr = v.data(); return v.size(); };
+	if (n == "order_v") return ret(r.order_v);
+	if (n == "order_f") return ret(r.order_f);
+	if (n == "op_sym") return ret(r.op_sym);
+	if (n == "op_class") return ret(r.op_class);
+	if (n == "op_l") return ret(r.op_l);
+	if (n == "op_h") return ret(r.op_h);
+	if (n == "op_t") return ret(r.op_t);
+	if (n == "op_pos") return ret(r.op_pos);
+	if (n == "info") { *ptr = w->info; return 2; }
+	if (n.size() == 8 && n.compare(0, 3, "grp") == 0 && n[3] >= '0' && n[3] < '0' + G_COUNT) {
+		int g = n[3] - '0';
+		if (n.compare(4, 4, "_val") == 0) return ret(r.grp_val[g]);
+		if (n.compare(4, 4, "_pos") == 0) return ret(r.grp_pos[g]);
+	}
+	*ptr = nullptr;
+	return 0;
+}
+void hry_walk_free(hry_walk *w) { delete w; }
+
+int hry_range_encode_lht(hry_ctx *ctx, const uint64_t *lht, size_t n, uint8_t **out, size_t *out_len)
+{
+	if (!ctx || (n && !lht) || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
+	return guarded([&] {
+		std::vector<uint8_t> v;
+		range_encode_lht(ctx->cx, lht, n, v);
+		*out = dup_bytes(v);
+		*out_len = v.size();
+	});
+}
+
+}   // extern "C"

@@ -1,0 +1,514 @@
+// Device pipeline of the compat profile (reference-identical .hry v0.1 stream) + bounds / requantisation.
+//
+//   host walk (cbm_walk.cpp)  ->  H2D: order, repaired twins, connectivity symbol planes
+//   k_rank, k_predict_vtx, k_face_planes              prediction + residuals + byte planes
+//   k_split_bytes, k_op_records, k_type_records,
+//   k_model_hist / _scan / _lht                       exact adaptive models by counting  -> (magic(t), x, l) per symbol
+//   k_rchain                                          serial range recurrence           -> r_k, bit position S_k
+//   k_low_accumulate, k_carry_*                       low register as one big number    -> payload bytes
+//
+// Reference: formats/hry/writer.cc:200-214 (compress), attrcode.h:395-416 (encode), arith/coder.h:58-112.
+#include <chrono>
+#include <cstring>
+#include <limits>
+
+#include "codec_math.hpp"
+#include "context.hpp"
+#include "kernels.hpp"
+
+namespace hry {
+
+using namespace dev;
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+// ---------------------------------------------------------------------------------------------------------
+Context::Context(int dev) : device(dev)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(HRY_E_NODEVICE, "no HIP device available: the .hry path has no CPU fallback");
+	if (dev < 0 || dev >= n) throw Error(HRY_E_ARG, "invalid device index");
+	HIP_OK(hipSetDevice(dev));
+	HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+}
+Context::~Context()
+{
+	(void)hipSetDevice(device);
+	if (stream) (void)hipStreamSynchronize(stream);
+	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+	if (stream) (void)hipStreamDestroy(stream);
+}
+void Context::stage_put(const char *name, const void *dptr, size_t bytes)
+{
+	if (!keep_stages) return;
+	std::vector<uint8_t> h(bytes);
+	if (bytes) {
+		HIP_OK(hipStreamSynchronize(stream));
+		HIP_OK(hipMemcpy(h.data(), dptr, bytes, hipMemcpyDeviceToHost));
+	}
+	stages[name] = std::move(h);
+}
+void Context::stage_put_host(const char *name, const void *hptr, size_t bytes)
+{
+	if (!keep_stages) return;
+	stages[name] = std::vector<uint8_t>((const uint8_t*)hptr, (const uint8_t*)hptr + bytes);
+}
+float Context::elapsed(int a, int b)
+{
+	float ms = 0;
+	(void)hipEventElapsedTime(&ms, ev[a], ev[b]);
+	return ms;
+}
+void Context::ensure_magic(uint32_t n)
+{
+	if (n <= magic_n) return;
+	uint32_t want = n + n / 4 + 1024;
+	DevBuf nb;
+	nb.ensure((size_t)want * sizeof(MagicEnt));
+	// the table is a pure function of t: recompute rather than copy
+	launch_magic_table(stream, nb.as<MagicEnt>(), 0, want);
+	HIP_OK(hipStreamSynchronize(stream));
+	std::swap(d_magic.p, nb.p);
+	std::swap(d_magic.cap, nb.cap);
+	magic_n = want;
+}
+void Context::upload_mesh(Mesh &m)
+{
+	HIP_OK(hipSetDevice(device));
+	for (int l = 0; l < 2; ++l) {
+		d_rec[l].ensure(std::max<size_t>(m.lists[l].data.size(), 16));
+		if (!m.lists[l].data.empty()) HIP_OK(hipMemcpyAsync(d_rec[l].p, m.lists[l].data.data(), m.lists[l].data.size(), hipMemcpyHostToDevice, stream));
+	}
+	uint32_t ne = m.ne();
+	d_org.ensure(std::max<size_t>((size_t)ne * 4, 16));
+	d_twin.ensure(std::max<size_t>((size_t)ne * 4, 16));
+	d_foff.ensure(((size_t)m.nf + 1) * 4);
+	HIP_OK(hipMemcpyAsync(d_org.p, m.org.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
+	HIP_OK(hipMemcpyAsync(d_twin.p, m.twin.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
+	HIP_OK(hipMemcpyAsync(d_foff.p, m.face_off.data(), ((size_t)m.nf + 1) * 4, hipMemcpyHostToDevice, stream));
+	int ud = 0;
+	res_has_eface = !m.uniform_degree(ud);
+	res_udeg = (uint32_t)ud;
+	if (res_has_eface) {
+		std::vector<uint32_t> ef(ne);
+		for (uint32_t f = 0; f < m.nf; ++f) for (uint32_t e = m.face_off[f]; e < m.face_off[f + 1]; ++e) ef[e] = f;
+		d_eface.ensure((size_t)ne * 4);
+		HIP_OK(hipMemcpyAsync(d_eface.p, ef.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
+		HIP_OK(hipStreamSynchronize(stream));
+	}
+	HIP_OK(hipStreamSynchronize(stream));
+	res_nv = m.nv; res_nf = m.nf; res_ne = ne;
+	m.device_token = next_token++;
+	resident_token = m.device_token;
+}
+ConnView Context::conn_view() const
+{
+	ConnView cv;
+	cv.org = d_org.as<uint32_t>(); cv.twin = d_twin.as<uint32_t>(); cv.foff = d_foff.as<uint32_t>();
+	cv.eface = res_has_eface ? d_eface.as<uint32_t>() : nullptr;
+	cv.udeg = res_udeg ? res_udeg : 3; cv.nf = res_nf; cv.ne = res_ne;
+	return cv;
+}
+
+ListDesc make_list_desc(const AttrList &L)
+{
+	ListDesc d{};
+	d.ncomp = L.ncomp(); d.stride = L.stride();
+	int p = 0;
+	for (int c = 0; c < L.ncomp(); ++c) {
+		d.stype[c] = L.stype(c); d.otype[c] = L.type[c]; d.quant[c] = L.quant[c];
+		d.off[c] = (uint16_t)L.offset[c]; d.plane[c] = (uint16_t)p;
+		p += kTypeSize[L.stype(c)];
+	}
+	d.nplanes = p;
+	return d;
+}
+
+void check_codable(const Mesh &m)
+{
+	for (int l = 0; l < 2; ++l)
+		for (int c = 0; c < m.lists[l].ncomp(); ++c) {
+			CompType st = m.lists[l].stype(c);
+			if (st == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components: the reference's residual code reads out of bounds for 8-byte floats (prediction.h:33-44); quantise them with -q");
+		}
+	if (m.lists[0].count != m.nf || m.lists[1].count != m.nv) throw Error(HRY_E_UNSUPPORTED, "attribute lists must have one record per element");
+	int dmax = (int)m.have_degree.size() - 1;
+	if (dmax - 2 >= 128) throw Error(HRY_E_UNSUPPORTED, "polygons with more than 129 edges: the reference seeds its numtri model out of bounds (model.h:49-55)");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bounds (a1) and requantisation (a2 on the host, a3 on the device)
+// ---------------------------------------------------------------------------------------------------------
+void device_bounds(Context &cx, Mesh &m)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
+	const int nparts = 512;
+	cx.d_small.ensure((size_t)nparts * (8 + 8 + 8) + 2 * 8 * dev::kMaxComp * 2 + 64);
+	uint8_t *pmin = cx.d_small.as<uint8_t>(), *pmax = pmin + nparts * 8;
+	uint32_t *pidx = (uint32_t*)(pmax + nparts * 8);
+	uint8_t *outs = (uint8_t*)(pidx + 2 * nparts);
+	for (int l = 0; l < 2; ++l) {
+		AttrList &L = m.lists[l];
+		for (int c = 0; c < L.ncomp(); ++c) if (L.quant[c]) throw Error(HRY_E_UNSUPPORTED, "bounds of an already quantised list come from its header");
+		L.bmin.assign(L.stride(), 0); L.bmax.assign(L.stride(), 0);
+		std::vector<uint8_t> res((size_t)L.ncomp() * 16);
+		for (int c = 0; c < L.ncomp(); ++c) {
+			if (L.type[c] == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "double components are outside the supported subset");
+			launch_bounds(cx.stream, cx.d_rec[l].as<uint8_t>(), L.count, L.stride(), L.offset[c], L.type[c], pmin, pmax, pidx, nparts,
+			              outs + (size_t)c * 16, outs + (size_t)c * 16 + 8);
+		}
+		if (L.ncomp()) {
+			HIP_OK(hipMemcpyAsync(res.data(), outs, res.size(), hipMemcpyDeviceToHost, cx.stream));
+			HIP_OK(hipStreamSynchronize(cx.stream));
+		}
+		for (int c = 0; c < L.ncomp(); ++c) {
+			memcpy(L.bmin.data() + L.offset[c], res.data() + (size_t)c * 16, kTypeSize[L.type[c]]);
+			memcpy(L.bmax.data() + L.offset[c], res.data() + (size_t)c * 16 + 8, kTypeSize[L.type[c]]);
+		}
+		L.have_bounds = true;
+	}
+}
+
+namespace {
+template <typename T> T rd(const uint8_t *p) { T v; memcpy(&v, p, sizeof(T)); return v; }
+template <typename T> void wr(uint8_t *p, T v) { memcpy(p, &v, sizeof(T)); }
+template <typename F> void host_with_type(CompType t, F &&f)
+{
+	switch (t) {
+	case C_FLOAT: f(float()); break; case C_DOUBLE: f(double()); break; case C_ULONG: f(uint64_t()); break; case C_LONG: f(int64_t()); break;
+	case C_UINT: f(uint32_t()); break; case C_INT: f(int32_t()); break; case C_USHORT: f(uint16_t()); break; case C_SHORT: f(int16_t()); break;
+	case C_UCHAR: f(uint8_t()); break; case C_CHAR: f(int8_t()); break; default: break;
+	}
+}
+// per-component extent shared inside an interpretation group (structs/quant.h:46-96)
+std::vector<uint8_t> shared_extent(const AttrList &L)
+{
+	int n = L.ncomp();
+	std::vector<uint8_t> ext(L.stride(), 0), s(L.stride(), 0);
+	for (int c = 0; c < n; ++c)
+		host_with_type(L.type[c], [&](auto tag) {
+			typedef decltype(tag) T;
+			wr<T>(ext.data() + L.offset[c], (T)(rd<T>(L.bmax.data() + L.offset[c]) - rd<T>(L.bmin.data() + L.offset[c])));
+			wr<T>(s.data() + L.offset[c], std::numeric_limits<T>::min());
+		});
+	std::vector<int> lead(n, 0);   // components outside every interpretation share group 0, as in the reference
+	for (size_t i = 0; i < L.interp_off.size(); ++i)
+		for (int j = 0; j < L.interp_len[i]; ++j) lead[L.interp_off[i] + j] = L.interp_off[i];
+	auto get_as = [&](const std::vector<uint8_t> &r, int j, auto tag) {
+		typedef decltype(tag) T;
+		T out = T();
+		host_with_type(L.type[j], [&](auto st) { typedef decltype(st) S; out = (T)rd<S>(r.data() + L.offset[j]); });
+		return out;
+	};
+	for (int j = 0; j < n; ++j) {
+		int k = lead[j];
+		host_with_type(L.type[k], [&](auto tag) {
+			typedef decltype(tag) T;
+			T cur = rd<T>(s.data() + L.offset[k]), v = get_as(ext, j, T());
+			wr<T>(s.data() + L.offset[k], std::max(cur, v));
+		});
+	}
+	for (int j = 0; j < n; ++j) {
+		int k = lead[j];
+		host_with_type(L.type[j], [&](auto tag) { typedef decltype(tag) T; wr<T>(s.data() + L.offset[j], get_as(s, k, T())); });
+	}
+	return s;
+}
+}   // namespace
+
+void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	// validation and expansion as the reference CLI does it (main.cc:74-91)
+	std::vector<uint8_t> nquant[2] = { m.lists[0].quant, m.lists[1].quant };
+	struct One { int l, c, q; };
+	std::vector<One> reqs;
+	for (size_t i = 0; i < nq; ++i) {
+		if (q[i].bits < 0) throw Error(HRY_E_ARG, "Invalid quantization bits");
+		if (q[i].list < 0 || q[i].list >= 2) throw Error(HRY_E_ARG, "Invalid list index");
+		const AttrList &L = m.lists[q[i].list];
+		if (q[i].comp == -1) {
+			for (int c = 0; c < L.ncomp(); ++c) {
+				if (q[i].bits > kTypeSize[L.type[c]] * 8) throw Error(HRY_E_ARG, "Invalid quantization bits");
+				reqs.push_back(One{ q[i].list, c, q[i].bits });
+			}
+		} else {
+			if (q[i].comp < 0 || q[i].comp >= L.ncomp()) throw Error(HRY_E_ARG, "Invalid attribute index");
+			if (q[i].bits > kTypeSize[L.type[q[i].comp]] * 8) throw Error(HRY_E_ARG, "Invalid quantization bits");
+			reqs.push_back(One{ q[i].list, q[i].comp, q[i].bits });
+		}
+	}
+	if (clear) for (int l = 0; l < 2; ++l) std::fill(nquant[l].begin(), nquant[l].end(), 0);
+	for (const One &r : reqs) nquant[r.l][r.c] = (uint8_t)r.q;
+
+	bool any = false;
+	for (int l = 0; l < 2; ++l) any |= nquant[l] != m.lists[l].quant;
+	if (!any) return;
+	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
+	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
+
+	for (int l = 0; l < 2; ++l) {
+		AttrList &L = m.lists[l];
+		if (nquant[l] == L.quant) continue;
+		std::vector<uint8_t> scale = shared_extent(L);
+		RequantPlan plan{};
+		for (int c = 0; c < L.ncomp(); ++c) {
+			int sq = L.quant[c], dq = nquant[l][c];
+			if (sq == dq) continue;
+			if (dq == 0) throw Error(HRY_E_UNSUPPORTED, "dequantisation (-c on a quantised list) is not on the device path yet");
+			if (dq > 30) throw Error(HRY_E_UNSUPPORTED, "more than 30 quantisation bits: the reference evaluates 1 << bits in int (quant.h:135)");
+			if (sq == 0 && kTypeSize[L.type[c]] == 8) throw Error(HRY_E_UNSUPPORTED, "quantisation of 8-byte components is not on the device path yet");
+			RequantComp &rc = plan.c[plan.n++];
+			rc.off = L.offset[c];
+			rc.src_type = sq ? storage_type(L.type[c], sq) : L.type[c];
+			rc.src_bits = sq; rc.dst_bits = dq;
+			rc.mn = 0; rc.scale = 0;
+			memcpy(&rc.mn, L.bmin.data() + L.offset[c], kTypeSize[L.type[c]]);
+			memcpy(&rc.scale, scale.data() + L.offset[c], kTypeSize[L.type[c]]);
+			if (sq == 0 && L.type[c] != C_FLOAT && rc.scale == 0) throw Error(HRY_E_UNSUPPORTED, "constant integer component: the reference divides by a zero extent (quant.h:106)");
+		}
+		launch_requant(cx.stream, cx.d_rec[l].as<uint8_t>(), L.count, L.stride(), plan);
+		if (!L.data.empty()) HIP_OK(hipMemcpyAsync(L.data.data(), cx.d_rec[l].p, L.data.size(), hipMemcpyDeviceToHost, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		L.quant = nquant[l];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// range coder back end shared by encode_compat and hry_range_encode_lht:
+// records (device) -> payload bytes (host)
+// ---------------------------------------------------------------------------------------------------------
+static void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload)
+{
+	cx.d_r.ensure(std::max<size_t>((size_t)ns * 8, 16));
+	cx.d_s.ensure(std::max<size_t>((size_t)ns * 4, 16));
+	cx.d_state.ensure(64);
+	uint64_t st[2] = { 1ull << 63, 0 };   // R = HALF, no shifts yet (coder.h:47)
+	HIP_OK(hipMemcpyAsync(cx.d_state.p, st, 16, hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
+	if (ns) launch_rchain(cx.stream, cx.d_rec_sym.as<SymRec>(), ns, cx.d_r.as<uint64_t>(), cx.d_s.as<uint32_t>(), cx.d_state.as<uint64_t>());
+	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	HIP_OK(hipMemcpyAsync(st, cx.d_state.p, 16, hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	uint64_t total_shift = st[1];
+	if (total_shift + 64 >= (1ull << 32)) throw Error(HRY_E_UNSUPPORTED, "compat stream longer than 2^32 bits: use the chunked profile");
+	uint64_t nbits = total_shift + 64;   // flush: the 64 bits of the low register (coder.h:58-67)
+	size_t nbytes = (size_t)((nbits + 7) / 8);
+	uint32_t nw = (uint32_t)((nbits + 31) / 32) + 2;
+	cx.d_acc.ensure((size_t)nw * 8);
+	cx.d_v.ensure((size_t)nw * 8);
+	cx.d_summary.ensure(((size_t)nw / 1024 + 2) * 4);
+	cx.d_bytes.ensure((size_t)nw * 4);
+	HIP_OK(hipMemsetAsync(cx.d_acc.p, 0, (size_t)nw * 8, cx.stream));
+	launch_low_accumulate(cx.stream, cx.d_r.as<uint64_t>(), cx.d_s.as<uint32_t>(), cx.d_sym_l.as<uint32_t>(), ns, cx.d_acc.as<uint64_t>());
+	launch_carry(cx.stream, cx.d_acc.as<uint64_t>(), nw, cx.d_v.as<uint64_t>(), cx.d_summary.as<uint32_t>(), cx.d_bytes.as<uint8_t>());
+	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
+	payload.resize(nbytes);
+	HIP_OK(hipMemcpyAsync(payload.data(), cx.d_bytes.p, nbytes, hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.stage_put("r", cx.d_r.p, (size_t)ns * 8);
+	cx.stage_put("S", cx.d_s.p, (size_t)ns * 4);
+}
+
+void range_encode_lht(Context &cx, const uint64_t *lht, size_t n, std::vector<uint8_t> &out)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	if (n >= (1ull << 31)) throw Error(HRY_E_ARG, "too many symbols");
+	std::vector<SymRec> rec(n);
+	std::vector<uint32_t> ls(n);
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t l = lht[3 * i], h = lht[3 * i + 1], t = lht[3 * i + 2];
+		if (!(l < h && h <= t) || t >= (1ull << 32) || t < 1) throw Error(HRY_E_ARG, "need l < h <= t < 2^32");
+		bool sub = h == t, noop = sub && l == 0;
+		SymRec r{ 0, 0, 0 };
+		uint32_t shift = 0;
+		if (t >= 2) cm::make_magic((uint32_t)t, r.magic, shift);
+		r.x = (uint32_t)(sub ? l : h - l);
+		r.meta = shift | (sub ? kMetaSub : 0u) | (noop ? kMetaNoop : 0u);
+		rec[i] = r;
+		ls[i] = (uint32_t)l;
+	}
+	cx.d_rec_sym.ensure(std::max<size_t>(n * sizeof(SymRec), 16));
+	cx.d_sym_l.ensure(std::max<size_t>(n * 4, 16));
+	if (n) {
+		HIP_OK(hipMemcpyAsync(cx.d_rec_sym.p, rec.data(), n * sizeof(SymRec), hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(cx.d_sym_l.p, ls.data(), n * 4, hipMemcpyHostToDevice, cx.stream));
+	}
+	finish_stream(cx, (uint32_t)n, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compat encode
+// ---------------------------------------------------------------------------------------------------------
+void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	auto t_all = Clock::now();
+	cx.timing = hry_timing{};
+	check_codable(m);
+	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
+	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds) { m.lists[l].bmin.assign(m.lists[l].stride(), 0); m.lists[l].bmax.assign(m.lists[l].stride(), 0); m.lists[l].have_bounds = true; }
+	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
+
+	// ---- host: header + cut-border walk
+	out.clear();
+	write_hry_header(m, 1, out);
+	auto t_walk = Clock::now();
+	WalkResult w;
+	cut_border_walk(m, w);
+	cx.timing.host_walk_ms = ms_since(t_walk);
+
+	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
+	const ListDesc ldv = make_list_desc(m.lists[1]), ldf = make_list_desc(m.lists[0]);
+	const uint32_t sv = 1 + (uint32_t)ldv.nplanes, sf = 1 + (uint32_t)ldf.nplanes;   // symbols per vertex / face (reg_* symbols are exact no-ops)
+	const uint64_t ns64 = (uint64_t)w.n_conn + (uint64_t)vc * sv + (uint64_t)fc * sf;
+	if (ns64 >= (1ull << 31)) throw Error(HRY_E_UNSUPPORTED, "more than 2^31 symbols in one compat stream: use the chunked profile");
+	const uint32_t ns = (uint32_t)ns64;
+	const uint32_t base_v = w.n_conn, base_f = w.n_conn + vc * sv;
+
+	// ---- H2D
+	auto t_h2d = Clock::now();
+	HIP_OK(hipEventRecord(cx.ev[0], cx.stream));
+	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
+	cx.d_order_f.ensure(std::max<size_t>((size_t)fc * 4, 16));
+	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
+	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
+	if (fc) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));   // repaired twins (encoder.h:150,193-198)
+	// connectivity groups: values + positions, packed back to back
+	size_t ngrp = 0;
+	for (int g = 0; g < G_COUNT; ++g) ngrp += w.grp_val[g].size();
+	const size_t nop = w.op_sym.size();
+	cx.d_grp_val.ensure(std::max<size_t>(ngrp * 4, 16));
+	cx.d_grp_pos.ensure(std::max<size_t>(ngrp * 4, 16));
+	cx.d_op.ensure(std::max<size_t>(nop * 16, 16));
+	size_t goff[G_COUNT + 1] = { 0 };
+	for (int g = 0; g < G_COUNT; ++g) {
+		size_t n = w.grp_val[g].size();
+		goff[g + 1] = goff[g] + n;
+		if (!n) continue;
+		HIP_OK(hipMemcpyAsync(cx.d_grp_val.as<uint32_t>() + goff[g], w.grp_val[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(cx.d_grp_pos.as<uint32_t>() + goff[g], w.grp_pos[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
+	}
+	uint32_t *d_opl = cx.d_op.as<uint32_t>(), *d_oph = d_opl + nop, *d_opt = d_oph + nop, *d_opp = d_opt + nop;
+	if (nop) {
+		HIP_OK(hipMemcpyAsync(d_opl, w.op_l.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(d_oph, w.op_h.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(d_opt, w.op_t.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(d_opp, w.op_pos.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+	}
+
+	// ---- model jobs: every byte plane with its initial counts (models.h:197-218, model.h:38-55)
+	std::vector<uint32_t> inits;   // 256-entry tables
+	auto add_init = [&](const std::vector<uint32_t> &t) { uint32_t id = (uint32_t)(inits.size() / 256); inits.insert(inits.end(), t.begin(), t.end()); return id; };
+	std::vector<uint32_t> ones(256, 1), iop_init(256, 0), nt0(256, 0), nt1(256, 0);
+	for (int i = 0; i < 9; ++i) iop_init[i] = 1;
+	for (size_t d = 3; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++nt0[(d - 2) & 0xff]; ++nt1[(d - 2) >> 8]; }
+	const uint32_t id_ones = add_init(ones), id_iop = add_init(iop_init), id_nt0 = add_init(nt0), id_nt1 = add_init(nt1);
+	auto total_of = [&](uint32_t id) { uint32_t s = 0; for (int i = 0; i < 256; ++i) s += inits[(size_t)id * 256 + i]; return s; };
+
+	size_t conn_plane_bytes = 0;
+	for (int g = 0; g < G_COUNT; ++g) conn_plane_bytes += w.grp_val[g].size() * kGroupBytes[g];
+	cx.d_connplanes.ensure(std::max<size_t>(conn_plane_bytes, 16));
+	cx.d_vplanes.ensure(std::max<size_t>((size_t)vc * ldv.nplanes, 16));
+	cx.d_fplanes.ensure(std::max<size_t>((size_t)fc * ldf.nplanes, 16));
+	cx.d_init.ensure(inits.size() * 4);
+	HIP_OK(hipMemcpyAsync(cx.d_init.p, inits.data(), inits.size() * 4, hipMemcpyHostToDevice, cx.stream));
+
+	struct JobH { PlaneJob j; uint32_t init_id; };
+	std::vector<PlaneJob> jobs;
+	std::vector<ChunkRef> chunks;
+	uint32_t max_total = 2 + std::max(vc, fc);
+	auto add_job = [&](const uint8_t *sym, uint32_t n, uint32_t init_id, const uint32_t *pos_tab, uint32_t pos_add, uint32_t pos_base, uint32_t pos_stride) {
+		if (!n) return;
+		PlaneJob j{};
+		j.sym = sym; j.n = n; j.init = cx.d_init.as<uint32_t>() + (size_t)init_id * 256; j.t0 = total_of(init_id);
+		j.pos_tab = pos_tab; j.pos_add = pos_add; j.pos_base = pos_base; j.pos_stride = pos_stride;
+		j.chunk0 = (uint32_t)chunks.size();
+		for (uint32_t f = 0; f < n; f += kChunk) chunks.push_back(ChunkRef{ (uint32_t)jobs.size(), f });
+		jobs.push_back(j);
+		max_total = std::max(max_total, j.t0 + n);
+	};
+	{
+		size_t poff = 0;
+		for (int g = 0; g < G_COUNT; ++g) {
+			uint32_t n = (uint32_t)w.grp_val[g].size();
+			for (int b = 0; b < kGroupBytes[g]; ++b) {
+				uint32_t init_id = g == G_IOP ? id_iop : g == G_NUMTRI ? (b == 0 ? id_nt0 : id_nt1) : id_ones;
+				add_job(cx.d_connplanes.as<uint8_t>() + poff + (size_t)b * n, n, init_id, cx.d_grp_pos.as<uint32_t>() + goff[g], (uint32_t)b, 0, 0);
+			}
+			poff += (size_t)n * kGroupBytes[g];
+		}
+	}
+	for (int p = 0; p < ldv.nplanes; ++p) add_job(cx.d_vplanes.as<uint8_t>() + (size_t)p * vc, vc, id_ones, nullptr, 0, base_v + 1 + p, sv);
+	for (int p = 0; p < ldf.nplanes; ++p) add_job(cx.d_fplanes.as<uint8_t>() + (size_t)p * fc, fc, id_ones, nullptr, 0, base_f + 1 + p, sf);
+	for (size_t i = 0; i < nop; ++i) max_total = std::max(max_total, w.op_t[i] + 1);
+	cx.d_jobs.ensure(std::max<size_t>(jobs.size() * sizeof(PlaneJob), 16));
+	cx.d_chunks.ensure(std::max<size_t>(chunks.size() * sizeof(ChunkRef), 16));
+	cx.d_hist.ensure(std::max<size_t>(chunks.size() * 256 * 4, 16));
+	if (!jobs.empty()) HIP_OK(hipMemcpyAsync(cx.d_jobs.p, jobs.data(), jobs.size() * sizeof(PlaneJob), hipMemcpyHostToDevice, cx.stream));
+	if (!chunks.empty()) HIP_OK(hipMemcpyAsync(cx.d_chunks.p, chunks.data(), chunks.size() * sizeof(ChunkRef), hipMemcpyHostToDevice, cx.stream));
+	cx.ensure_magic(max_total + 1);
+	cx.d_rec_sym.ensure(std::max<size_t>((size_t)ns * sizeof(SymRec), 16));
+	cx.d_sym_l.ensure(std::max<size_t>((size_t)ns * 4, 16));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.h2d_ms = ms_since(t_h2d);
+
+	// ---- device: prediction + residuals + planes
+	ConnView cv = cx.conn_view();
+	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
+	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m.nv * 4, cx.stream));
+	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
+	launch_predict_vtx(cx.stream, cv, cx.d_order_v.as<uint32_t>(), vc, cx.d_rank.as<uint32_t>(), cx.d_rec[1].as<uint8_t>(), ldv, cx.d_vplanes.as<uint8_t>());
+	launch_face_planes(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, cx.d_rec[0].as<uint8_t>(), ldf, cx.d_fplanes.as<uint8_t>());
+	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
+	// ---- device: models -> per-symbol records in global stream order
+	{
+		size_t poff = 0;
+		for (int g = 0; g < G_COUNT; ++g) {
+			uint32_t n = (uint32_t)w.grp_val[g].size();
+			launch_split_bytes(cx.stream, cx.d_grp_val.as<uint32_t>() + goff[g], n, kGroupBytes[g], cx.d_connplanes.as<uint8_t>() + poff);
+			poff += (size_t)n * kGroupBytes[g];
+		}
+	}
+	const MagicEnt *magic = cx.d_magic.as<MagicEnt>();
+	SymRec *rec = cx.d_rec_sym.as<SymRec>();
+	uint32_t *sym_l = cx.d_sym_l.as<uint32_t>();
+	launch_op_records(cx.stream, d_opl, d_oph, d_opt, d_opp, (uint32_t)nop, magic, rec, sym_l);
+	launch_type_records(cx.stream, vc, base_v, sv, magic, rec, sym_l);
+	launch_type_records(cx.stream, fc, base_f, sf, magic, rec, sym_l);
+	launch_model(cx.stream, cx.d_jobs.as<PlaneJob>(), (uint32_t)jobs.size(), cx.d_chunks.as<ChunkRef>(), (uint32_t)chunks.size(), cx.d_hist.as<uint32_t>(), magic, rec, sym_l);
+
+	if (cx.keep_stages) {
+		cx.stage_put_host("order_v", w.order_v.data(), (size_t)vc * 4);
+		cx.stage_put_host("order_f", w.order_f.data(), (size_t)fc * 4);
+		cx.stage_put_host("twin", m.twin.data(), (size_t)m.ne() * 4);
+		cx.stage_put("rank", cx.d_rank.p, (size_t)m.nv * 4);
+		cx.stage_put("vplanes", cx.d_vplanes.p, (size_t)vc * ldv.nplanes);
+		cx.stage_put("fplanes", cx.d_fplanes.p, (size_t)fc * ldf.nplanes);
+		cx.stage_put("rec", cx.d_rec_sym.p, (size_t)ns * sizeof(SymRec));
+		cx.stage_put("sym_l", cx.d_sym_l.p, (size_t)ns * 4);
+		uint32_t lay[8] = { w.n_conn, vc, fc, sv, sf, ns, (uint32_t)w.numtri_coded, 0 };
+		cx.stage_put_host("layout", lay, sizeof lay);
+	}
+
+	// ---- device: serial recurrence, big-number low register, carries; D2H
+	std::vector<uint8_t> payload;
+	auto t_fin = Clock::now();
+	finish_stream(cx, ns, payload);
+	(void)t_fin;
+	out.insert(out.end(), payload.begin(), payload.end());
+	cx.stage_put_host("payload", payload.data(), payload.size());
+
+	cx.timing.k_predict_ms = cx.elapsed(1, 2);
+	cx.timing.k_model_ms = cx.elapsed(2, 3);
+	cx.timing.k_rchain_ms = cx.elapsed(3, 4);
+	cx.timing.device_ms = cx.elapsed(1, 5);
+	cx.timing.n_symbols = ns;
+	cx.timing.payload_bytes = payload.size();
+	cx.timing.total_ms = ms_since(t_all);
+}
+
+}   // namespace hry

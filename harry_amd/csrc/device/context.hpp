@@ -1,0 +1,85 @@
+// Device context of the codec: HIP device, one stream, grow-only workspace buffers, resident mesh.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../host/host.hpp"
+#include "dev_types.hpp"
+
+namespace hry {
+
+inline void hip_check(hipError_t e, const char *what)
+{
+	if (e != hipSuccess) throw Error(HRY_E_NODEVICE, std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+#define HIP_OK(x) ::hry::hip_check((x), #x)
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf &operator=(const DevBuf&) = delete;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	void ensure(size_t n)
+	{
+		if (n <= cap) return;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = n + n / 8 + 256;
+		HIP_OK(hipMalloc(&p, want));
+		cap = want;
+	}
+	template <typename T> T *as() const { return (T*)p; }
+};
+
+struct Context {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[8] = {};
+	hry_timing timing{};
+
+	// resident mesh (hry_mesh_upload): attribute records and connectivity stay in HBM across encodes
+	uint64_t resident_token = 0;
+	uint64_t next_token = 1;
+	DevBuf d_rec[2], d_org, d_twin, d_foff, d_eface;
+	uint32_t res_nv = 0, res_nf = 0, res_ne = 0, res_udeg = 0;
+	bool res_has_eface = false;
+
+	// reciprocal table, valid for totals < magic_n
+	DevBuf d_magic;
+	uint32_t magic_n = 0;
+
+	// workspace
+	DevBuf d_order_v, d_order_f, d_rank, d_vplanes, d_fplanes, d_connplanes, d_grp_val, d_grp_pos, d_op, d_jobs, d_chunks, d_hist, d_init,
+	       d_rec_sym, d_sym_l, d_r, d_s, d_state, d_acc, d_v, d_summary, d_bytes, d_small;
+	// chunked profile
+	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms;
+
+	bool keep_stages = false;
+	std::map<std::string, std::vector<uint8_t>> stages;
+
+	explicit Context(int dev);
+	~Context();
+	void stage_put(const char *name, const void *dptr, size_t bytes);
+	void stage_put_host(const char *name, const void *hptr, size_t bytes);
+	void ensure_magic(uint32_t n);
+	void upload_mesh(Mesh &m);
+	dev::ConnView conn_view() const;
+	float elapsed(int a, int b);
+};
+
+// codec entry points (codec.cpp / chunked.cpp)
+void device_bounds(Context &cx, Mesh &m);
+void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);
+void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
+void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &out);
+Mesh *decode_any(Context &cx, const uint8_t *p, size_t n);
+void range_encode_lht(Context &cx, const uint64_t *lht, size_t n, std::vector<uint8_t> &out);
+
+dev::ListDesc make_list_desc(const AttrList &L);
+void check_codable(const Mesh &m);
+
+}   // namespace hry

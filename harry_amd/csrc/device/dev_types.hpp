@@ -1,0 +1,53 @@
+// Plain structs shared between host launch code and HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace hry {
+namespace dev {
+
+constexpr int kMaxComp = 32;
+constexpr int kChunk = 2048;        // symbols per model-evaluation chunk (one wavefront walks one chunk)
+constexpr uint32_t kNoRank = 0xffffffffu;
+
+// one attribute list as the kernels see it
+struct ListDesc {
+	int32_t ncomp, stride, nplanes;
+	uint8_t stype[kMaxComp];   // storage type (mixing::Type value) of each component
+	uint8_t otype[kMaxComp];   // original type
+	uint8_t quant[kMaxComp];
+	uint16_t off[kMaxComp];    // byte offset of the component's slot in a record
+	uint16_t plane[kMaxComp];  // index of the component's first byte plane
+};
+
+struct ConnView {
+	const uint32_t *org, *twin, *foff, *eface;   // eface == nullptr when every polygon has udeg edges
+	uint32_t udeg, nf, ne;
+};
+
+// per-symbol record consumed by the serial range recurrence (16 bytes, one dwordx4 per lane)
+struct alignas(16) SymRec {
+	uint64_t magic;    // reciprocal of the context total t (round-up method, 65-bit magic with implicit top bit)
+	uint32_t x;        // multiplier: h - l, or l when the symbol is the last one with non-zero count (h == t)
+	uint32_t meta;     // bits 0-5: post-shift, bit 6: h == t form (R' = R - r*x), bit 7: exact no-op (l == 0 && h == t)
+};
+constexpr uint32_t kMetaSub = 1u << 6, kMetaNoop = 1u << 7;
+
+struct alignas(16) MagicEnt { uint64_t magic; uint32_t shift; uint32_t pad; };
+
+// a byte plane whose adaptive model is evaluated by counting
+struct PlaneJob {
+	const uint8_t *sym;        // n symbols
+	const uint32_t *pos_tab;   // global position of symbol j is pos_tab[j] + pos_add, or pos_base + j * pos_stride when null
+	const uint32_t *init;      // 256 initial counts
+	uint32_t n, t0;            // t0 = sum of init
+	uint32_t pos_add, pos_base, pos_stride;
+	uint32_t chunk0;           // index of this job's first chunk in the global chunk list
+};
+struct ChunkRef { uint32_t job, first; };
+
+// one component of an in-place requantisation: mn / scale carry the raw bits of the component's original type
+struct RequantComp { int32_t off, src_type, src_bits, dst_bits; uint64_t mn, scale; };
+struct RequantPlan { int32_t n; int32_t pad; RequantComp c[kMaxComp]; };
+
+}   // namespace dev
+}   // namespace hry

@@ -1,0 +1,678 @@
+// HIP kernels of the .hry hot path for gfx950 (wave64).  All integer / byte work bounded by HBM traffic or by
+// serial dependencies; no MFMA.  See DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Reference behaviour restated by each kernel is cited at its definition.
+#include <hip/hip_runtime.h>
+
+#include "codec_math.hpp"
+#include "dev_types.hpp"
+#include "kernels.hpp"
+
+namespace hry {
+namespace dev {
+
+// ---------------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T ldg(const uint8_t *p)
+{
+	T v;
+	__builtin_memcpy(&v, p, sizeof(T));
+	return v;
+}
+template <typename T> __device__ __forceinline__ void stg(uint8_t *p, T v) { __builtin_memcpy(p, &v, sizeof(T)); }
+
+template <typename F> __device__ __forceinline__ void with_stype(int st, F &&f)
+{
+	switch (st) {
+	case 0: f(float()); break;
+	case 2: f(uint64_t()); break;
+	case 3: f(int64_t()); break;
+	case 4: f(uint32_t()); break;
+	case 5: f(int32_t()); break;
+	case 6: f(uint16_t()); break;
+	case 7: f(int16_t()); break;
+	case 8: f(uint8_t()); break;
+	case 9: f(int8_t()); break;
+	default: break;   // DOUBLE is rejected on the host (prediction.h:33-44 reads out of bounds for 8-byte floats)
+	}
+}
+__constant__ int c_type_size[11] = { 4, 8, 8, 8, 4, 4, 2, 2, 1, 1, 0 };
+
+struct Topo {
+	ConnView c;
+	__device__ __forceinline__ uint32_t face(uint32_t e) const { return c.eface ? c.eface[e] : e / c.udeg; }
+	__device__ __forceinline__ uint32_t next(uint32_t e) const
+	{
+		if (c.eface) { uint32_t f = c.eface[e]; return e + 1 == c.foff[f + 1] ? c.foff[f] : e + 1; }
+		uint32_t k = e % c.udeg;
+		return k + 1 == c.udeg ? e - k : e + 1;
+	}
+	__device__ __forceinline__ uint32_t prev(uint32_t e) const
+	{
+		if (c.eface) { uint32_t f = c.eface[e]; return e == c.foff[f] ? c.foff[f + 1] - 1 : e - 1; }
+		uint32_t k = e % c.udeg;
+		return k == 0 ? e + c.udeg - 1 : e - 1;
+	}
+	__device__ __forceinline__ uint32_t degree(uint32_t e) const
+	{
+		if (c.eface) { uint32_t f = c.eface[e]; return c.foff[f + 1] - c.foff[f]; }
+		return c.udeg;
+	}
+};
+
+// Visit the prediction candidates of the vertex at half-edge `ein` in the reference's fan order
+// (attrcode.h:83-106 TFAN_IT, :155-171 paral, :117-121 use_paral).  A candidate (v0, v1, vo) is kept iff all three
+// vertices were coded before the current one and not before `lo`: rank in [lo, my_rank).
+// The walk is bounded so that a corrupt twin table cannot hang the wave.
+template <typename F>
+__device__ __forceinline__ void fan_candidates(const Topo &tp, const uint32_t *rank, uint32_t ein, uint32_t my_rank, uint32_t lo, F &&f)
+{
+	auto offer = [&](uint32_t v0, uint32_t v1, uint32_t vo) {
+		uint32_t r0 = rank[v0], r1 = rank[v1], r2 = rank[vo];
+		if (r0 < my_rank && r1 < my_rank && r2 < my_rank && r0 >= lo && r1 >= lo && r2 >= lo) f(v0, v1, vo);
+	};
+	auto visit = [&](uint32_t e) {
+		uint32_t d = tp.degree(e);
+		if (d == 3) {
+			uint32_t e1 = tp.next(e), t = tp.c.twin[e1];
+			if (t == e1) return;
+			uint32_t tn = tp.next(t);
+			offer(tp.c.org[t], tp.c.org[tn], tp.c.org[tp.next(tn)]);
+			return;
+		}
+		uint32_t e0 = tp.next(e), e1 = tp.prev(e);
+		uint32_t a = tp.c.org[e0], b = tp.c.org[e1];
+		offer(a, b, tp.c.org[tp.next(e0)]);
+		if (d > 4) offer(a, b, b);
+	};
+	const int kMaxSteps = 1 << 16;
+	uint32_t e = ein, t;
+	int steps = 0;
+	bool border = false;
+	for (;;) {
+		visit(e);
+		t = tp.c.twin[e];
+		if (t == e) { border = true; break; }
+		e = tp.next(t);
+		if (e == ein || ++steps > kMaxSteps) break;
+	}
+	if (!border) return;
+	e = tp.prev(ein);
+	t = tp.c.twin[e];
+	if (e == t) return;
+	e = t;
+	do {
+		visit(e);
+		e = tp.prev(e);
+		t = tp.c.twin[e];
+		if (e == t) break;
+		e = t;
+	} while (e != ein && ++steps <= kMaxSteps);
+}
+
+// prediction of one component (attrcode.h:182-208): mean of candidate predictions in fan order (double / int64),
+// integers take the mean, floats the candidate nearest to the mean (strict <, first wins).
+template <typename T>
+__device__ __forceinline__ T predict_component(const Topo &tp, const uint32_t *rank, const uint8_t *rec, int stride, int off, int q,
+                                               uint32_t e, uint32_t my_rank, uint32_t lo, const uint32_t *attr_of)
+{
+	typedef typename cm::wide<T>::type W;
+	W acc = 0;
+	uint32_t n = 0;
+	auto value = [&](uint32_t v) { return ldg<T>(rec + (size_t)(attr_of ? attr_of[v] : v) * stride + off); };
+	fan_candidates(tp, rank, e, my_rank, lo, [&](uint32_t v0, uint32_t v1, uint32_t vo) {
+		acc = acc + (W)cm::parallelogram<T>(value(v0), value(v1), value(vo), q);
+		++n;
+	});
+	if (n == 0) return T(0);
+	T avg = (T)cm::mean_of(acc, (W)n);
+	if constexpr (!cm::is_fp<T>::value) return avg;
+	else {
+		T best = 3.402823466e+38f;   // numeric_limits<float>::max()
+		fan_candidates(tp, rank, e, my_rank, lo, [&](uint32_t v0, uint32_t v1, uint32_t vo) {
+			T p = cm::parallelogram<T>(value(v0), value(v1), value(vo), q);
+			T db = avg > best ? avg - best : best - avg;
+			T dp = avg > p ? avg - p : p - avg;
+			best = db < dp ? best : p;
+		});
+		return best;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_bounds: per-component min / max with the reference's initial values and first-wins ties
+// (structs/quant.h:30-38: min starts at numeric_limits::max(), max at numeric_limits::min() == FLT_MIN for floats)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Lim;
+template <> struct Lim<float> { static __device__ float hi() { return 3.402823466e+38f; } static __device__ float lo() { return 1.175494351e-38f; } };
+template <> struct Lim<uint64_t> { static __device__ uint64_t hi() { return ~0ull; } static __device__ uint64_t lo() { return 0; } };
+template <> struct Lim<int64_t> { static __device__ int64_t hi() { return 0x7fffffffffffffffll; } static __device__ int64_t lo() { return -0x7fffffffffffffffll - 1; } };
+template <> struct Lim<uint32_t> { static __device__ uint32_t hi() { return ~0u; } static __device__ uint32_t lo() { return 0; } };
+template <> struct Lim<int32_t> { static __device__ int32_t hi() { return 0x7fffffff; } static __device__ int32_t lo() { return -0x7fffffff - 1; } };
+template <> struct Lim<uint16_t> { static __device__ uint16_t hi() { return 0xffff; } static __device__ uint16_t lo() { return 0; } };
+template <> struct Lim<int16_t> { static __device__ int16_t hi() { return 0x7fff; } static __device__ int16_t lo() { return -0x8000; } };
+template <> struct Lim<uint8_t> { static __device__ uint8_t hi() { return 0xff; } static __device__ uint8_t lo() { return 0; } };
+template <> struct Lim<int8_t> { static __device__ int8_t hi() { return 0x7f; } static __device__ int8_t lo() { return -0x80; } };
+
+// (value, first index) pairs make the parallel reduction reproduce the sequential scan bit for bit (+-0.0 ties)
+template <typename T> struct Ext { T v; uint32_t i; };
+template <typename T> __device__ __forceinline__ Ext<T> pick_min(Ext<T> a, Ext<T> b)
+{
+	if (b.v < a.v) return b;
+	if (a.v < b.v) return a;
+	return a.i <= b.i ? a : b;
+}
+template <typename T> __device__ __forceinline__ Ext<T> pick_max(Ext<T> a, Ext<T> b)
+{
+	if (b.v > a.v) return b;
+	if (a.v > b.v) return a;
+	return a.i <= b.i ? a : b;
+}
+
+template <typename T>
+__device__ void bounds_component(const uint8_t *rec, uint32_t count, int stride, int off, uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx)
+{
+	// index 0 is reserved for the initial value so that it wins ties against every element
+	Ext<T> mn{ Lim<T>::hi(), 0 }, mx{ Lim<T>::lo(), 0 };
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+		T e = ldg<T>(rec + (size_t)i * stride + off);
+		if (e == e) {   // NaN never replaces the running value in the reference's comparisons
+			mn = pick_min(mn, Ext<T>{ e, i + 1 });
+			mx = pick_max(mx, Ext<T>{ e, i + 1 });
+		}
+	}
+	__shared__ unsigned char sm_raw[2 * 256 * sizeof(Ext<uint64_t>)];
+	Ext<T> *smn = (Ext<T>*)sm_raw, *smx = smn + 256;
+	smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+	__syncthreads();
+	for (int s = 128; s > 0; s >>= 1) {
+		if ((int)threadIdx.x < s) {
+			smn[threadIdx.x] = pick_min(smn[threadIdx.x], smn[threadIdx.x + s]);
+			smx[threadIdx.x] = pick_max(smx[threadIdx.x], smx[threadIdx.x + s]);
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		stg<T>(part_min + (size_t)blockIdx.x * 8, smn[0].v);
+		stg<T>(part_max + (size_t)blockIdx.x * 8, smx[0].v);
+		part_idx[2 * blockIdx.x] = smn[0].i;
+		part_idx[2 * blockIdx.x + 1] = smx[0].i;
+	}
+}
+__global__ __launch_bounds__(256) void k_bounds_partial(const uint8_t *rec, uint32_t count, int stride, int off, int type,
+                                                        uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx)
+{
+	with_stype(type, [&](auto tag) { bounds_component<decltype(tag)>(rec, count, stride, off, part_min, part_max, part_idx); });
+}
+template <typename T>
+__device__ void bounds_final(const uint8_t *part_min, const uint8_t *part_max, const uint32_t *part_idx, int nparts, uint8_t *out_min, uint8_t *out_max)
+{
+	Ext<T> mn{ Lim<T>::hi(), 0 }, mx{ Lim<T>::lo(), 0 };
+	for (int p = 0; p < nparts; ++p) {
+		mn = pick_min(mn, Ext<T>{ ldg<T>(part_min + (size_t)p * 8), part_idx[2 * p] });
+		mx = pick_max(mx, Ext<T>{ ldg<T>(part_max + (size_t)p * 8), part_idx[2 * p + 1] });
+	}
+	stg<T>(out_min, mn.v);
+	stg<T>(out_max, mx.v);
+}
+__global__ void k_bounds_final(const uint8_t *part_min, const uint8_t *part_max, const uint32_t *part_idx, int nparts, int type,
+                               uint8_t *out_min, uint8_t *out_max)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+		with_stype(type, [&](auto tag) { bounds_final<decltype(tag)>(part_min, part_max, part_idx, nparts, out_min, out_max); });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_requant: in-place requantisation of selected components (structs/quant.h:114-178).  Sources: unquantised
+// float / 1-2-4 byte integers, or an already quantised value (q -> q').  src and dst alias the same slot
+// (attr.h:95-98); the destination is written in its storage type into the low bytes of the slot.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T rescale_int(T val, T from, T to) { return val / from * to + val % from * to / from; }   // quant.h:103-107
+
+__global__ __launch_bounds__(256) void k_requant(uint8_t *rec, uint32_t count, int stride, RequantPlan plan)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+		uint8_t *r = rec + (size_t)i * stride;
+		for (int k = 0; k < plan.n; ++k) {
+			const RequantComp &c = plan.c[k];
+			uint8_t *slot = r + c.off;
+			uint64_t q = 0;
+			const int lv = (1 << (uint32_t)c.dst_bits) - 1;
+			if (c.src_bits) {   // already quantised: read the storage type, rescale levels (quant.h:121-129,169-171)
+				switch (c.src_type) {
+				case 8: q = ldg<uint8_t>(slot); break;
+				case 6: q = ldg<uint16_t>(slot); break;
+				case 4: q = ldg<uint32_t>(slot); break;
+				default: q = ldg<uint64_t>(slot); break;
+				}
+				q = rescale_int<uint64_t>(q, (uint64_t)((1 << (uint32_t)c.src_bits) - 1), (uint64_t)lv);
+			} else {
+				switch (c.src_type) {
+				case 0: q = cm::quantise_f32(ldg<float>(slot), cm::bits<float>((uint32_t)c.mn), cm::bits<float>((uint32_t)c.scale), c.dst_bits); break;
+				case 4: q = rescale_int<uint32_t>(ldg<uint32_t>(slot) - (uint32_t)c.mn, (uint32_t)c.scale, (uint32_t)lv); break;
+				case 5: q = (uint64_t)rescale_int<int32_t>(ldg<int32_t>(slot) - (int32_t)c.mn, (int32_t)c.scale, (int32_t)lv); break;
+				case 6: q = rescale_int<uint16_t>((uint16_t)(ldg<uint16_t>(slot) - (uint16_t)c.mn), (uint16_t)c.scale, (uint16_t)lv); break;
+				case 7: q = (uint64_t)rescale_int<int16_t>((int16_t)(ldg<int16_t>(slot) - (int16_t)c.mn), (int16_t)c.scale, (int16_t)lv); break;
+				case 8: q = rescale_int<uint8_t>((uint8_t)(ldg<uint8_t>(slot) - (uint8_t)c.mn), (uint8_t)c.scale, (uint8_t)lv); break;
+				case 9: q = (uint64_t)rescale_int<int8_t>((int8_t)(ldg<int8_t>(slot) - (int8_t)c.mn), (int8_t)c.scale, (int8_t)lv); break;
+				default: break;
+				}
+			}
+			if (c.dst_bits <= 8) stg<uint8_t>(slot, (uint8_t)q);
+			else if (c.dst_bits <= 16) stg<uint16_t>(slot, (uint16_t)q);
+			else stg<uint32_t>(slot, (uint32_t)q);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// traversal rank: rank[v] = position of v in the coding order, kNoRank for vertices never coded
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rank(const uint32_t *order_v, uint32_t n, const uint32_t *org, uint32_t *rank)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n) rank[org[order_v[k]]] = k;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_predict_vtx: prediction + residual folding + byte symbolisation of vertex attributes, one thread per coded
+// vertex (attrcode.h:209-225 vtx, :321-344 vtx_post; io.h:90-94; models.h:168-173).  Output: SoA byte planes,
+// plane p holds byte p of every vertex' residual record in coding order (coalesced for the model kernels).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_predict_vtx(ConnView cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank,
+                                                     const uint8_t *rec, ListDesc ld, uint8_t *planes, uint32_t chunk_vtx)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	Topo tp{ cv };
+	uint32_t e = order_v[k];
+	uint32_t v = cv.org[e];
+	uint32_t lo = 0;
+	(void)chunk_vtx;
+	for (int c = 0; c < ld.ncomp; ++c) {
+		with_stype(ld.stype[c], [&](auto tag) {
+			typedef decltype(tag) T;
+			T pred = predict_component<T>(tp, rank, rec, ld.stride, ld.off[c], ld.quant[c], e, k, lo, nullptr);
+			T raw = ldg<T>(rec + (size_t)v * ld.stride + ld.off[c]);
+			auto code = cm::residual_bits<T>(raw, pred, ld.quant[c]);
+			for (int b = 0; b < (int)sizeof(T); ++b) planes[(size_t)(ld.plane[c] + b) * n + k] = (uint8_t)(code >> (8 * b));
+		});
+	}
+}
+
+// faces: prediction is always "no candidate" (attrcode.h:227-254) => residual against 0
+__global__ __launch_bounds__(256) void k_face_planes(ConnView cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, ListDesc ld, uint8_t *planes)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	Topo tp{ cv };
+	uint32_t f = tp.face(order_f[j]);
+	for (int c = 0; c < ld.ncomp; ++c) {
+		with_stype(ld.stype[c], [&](auto tag) {
+			typedef decltype(tag) T;
+			T raw = ldg<T>(rec + (size_t)f * ld.stride + ld.off[c]);
+			auto code = cm::residual_bits<T>(raw, T(0), ld.quant[c]);
+			for (int b = 0; b < (int)sizeof(T); ++b) planes[(size_t)(ld.plane[c] + b) * n + j] = (uint8_t)(code >> (8 * b));
+		});
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reciprocal table: magic[t] for every context total that can occur (t = 2 .. n-1)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_magic_table(MagicEnt *tab, uint32_t from, uint32_t to)
+{
+	uint32_t t = from + blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= to) return;
+	MagicEnt m{ 0, 0, 0 };
+	if (t >= 2) cm::make_magic(t, m.magic, m.shift);
+	tab[t] = m;
+}
+
+__device__ __forceinline__ void emit_symbol(SymRec *rec, uint32_t *sym_l, const MagicEnt *magic, uint32_t g, uint32_t l, uint32_t c, uint32_t t)
+{
+	bool sub = l + c == t;
+	bool noop = sub && l == 0;
+	MagicEnt m = magic[t];
+	SymRec r;
+	r.magic = m.magic;
+	r.x = sub ? l : c;
+	r.meta = m.shift | (sub ? kMetaSub : 0u) | (noop ? kMetaNoop : 0u);
+	rec[g] = r;
+	sym_l[g] = l;
+}
+
+// connectivity groups arrive as one 32-bit value per symbol; split them into byte planes
+__global__ __launch_bounds__(256) void k_split_bytes(const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	uint32_t v = val[j];
+	for (int b = 0; b < nbytes; ++b) planes[(size_t)b * n + j] = (uint8_t)(v >> (8 * b));
+}
+
+// cut-border operations: the order-conditioned model was evaluated by the walk (models.h:91-119)
+__global__ __launch_bounds__(256) void k_op_records(const uint32_t *l, const uint32_t *h, const uint32_t *t, const uint32_t *pos, uint32_t n,
+                                                    const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) emit_symbol(rec, sym_l, magic, pos[j], l[j], h[j] - l[j], t[j]);
+}
+
+// attr_type symbols of a list whose elements all carry private data: the j-th symbol is DATA with counts
+// {DATA: 1 + j, HIST: 1} (models.h:201-203) => l = 0, h = 1 + j, t = 2 + j
+__global__ __launch_bounds__(256) void k_type_records(uint32_t n, uint32_t pos_base, uint32_t pos_stride, const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) emit_symbol(rec, sym_l, magic, pos_base + j * pos_stride, 0, 1 + j, 2 + j);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// exact adaptive-model evaluation by counting (arith/stat_adaptive.h:46-54,77-82):
+//   k_model_hist  : 256-bin histogram of every chunk
+//   k_model_scan  : exclusive scan over the chunks of one plane (+ initial counts) -> table at each chunk start
+//   k_model_lht   : one wavefront owns a chunk, keeps its count / cumulative tables in LDS and produces (l, h-l, t)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_model_hist(const PlaneJob *jobs, const ChunkRef *chunks, uint32_t *hist)
+{
+	ChunkRef cr = chunks[blockIdx.x];
+	const PlaneJob &jb = jobs[cr.job];
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	uint32_t end = min(cr.first + (uint32_t)kChunk, jb.n);
+	for (uint32_t j = cr.first + threadIdx.x; j < end; j += 256) atomicAdd(&h[jb.sym[j]], 1u);
+	__syncthreads();
+	hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_model_scan(const PlaneJob *jobs, uint32_t *hist)
+{
+	const PlaneJob &jb = jobs[blockIdx.x];
+	uint32_t nch = (jb.n + kChunk - 1) / kChunk;
+	uint32_t run = jb.init[threadIdx.x];
+	uint32_t *h = hist + (size_t)jb.chunk0 * 256 + threadIdx.x;
+	for (uint32_t c = 0; c < nch; ++c) {
+		uint32_t v = h[(size_t)c * 256];
+		h[(size_t)c * 256] = run;
+		run += v;
+	}
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
+{
+	uint32_t inc = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t o = __shfl_up(inc, d, 64);
+		if ((int)(threadIdx.x & 63) >= d) inc += o;
+	}
+	total = __shfl(inc, 63, 64);
+	return inc - v;
+}
+
+__global__ __launch_bounds__(64) void k_model_lht(const PlaneJob *jobs, const ChunkRef *chunks, const uint32_t *hist, const MagicEnt *magic,
+                                                  SymRec *rec, uint32_t *sym_l)
+{
+	ChunkRef cr = chunks[blockIdx.x];
+	const PlaneJob jb = jobs[cr.job];
+	const int lane = threadIdx.x;
+	__shared__ uint32_t cnt[256], cum[256], bh[256];
+	{   // table at chunk start; cum[s] = sum of counts of symbols < s
+		const uint32_t *st = hist + (size_t)blockIdx.x * 256 + 4 * lane;
+		uint32_t a = st[0], b = st[1], c = st[2], d = st[3], tot;
+		uint32_t ex = wave_excl_scan(a + b + c + d, tot);
+		cnt[4 * lane] = a; cnt[4 * lane + 1] = b; cnt[4 * lane + 2] = c; cnt[4 * lane + 3] = d;
+		cum[4 * lane] = ex; cum[4 * lane + 1] = ex + a; cum[4 * lane + 2] = ex + a + b; cum[4 * lane + 3] = ex + a + b + c;
+	}
+	__syncthreads();
+	const uint32_t end = min(cr.first + (uint32_t)kChunk, jb.n);
+	for (uint32_t base = cr.first; base < end; base += 64) {
+		uint32_t j = base + lane;
+		bool valid = j < end;
+		uint32_t s = valid ? jb.sym[j] : 0x100u;
+		uint32_t l = valid ? cum[s] : 0, c = valid ? cnt[s] : 0;
+		bh[4 * lane] = 0; bh[4 * lane + 1] = 0; bh[4 * lane + 2] = 0; bh[4 * lane + 3] = 0;
+		// symbols of this batch that precede lane: smaller ones raise l, equal ones raise the count
+		uint32_t nb = min(64u, end - base);
+		for (uint32_t i = 0; i < nb; ++i) {
+			uint32_t si = (uint32_t)__builtin_amdgcn_readlane(s, i);
+			if ((int)i < lane) { l += si < s ? 1u : 0u; c += si == s ? 1u : 0u; }
+		}
+		if (valid) {
+			uint32_t g = jb.pos_tab ? jb.pos_tab[j] + jb.pos_add : jb.pos_base + j * jb.pos_stride;
+			emit_symbol(rec, sym_l, magic, g, l, c, jb.t0 + j);
+		}
+		__syncthreads();
+		if (valid) atomicAdd(&bh[s], 1u);
+		__syncthreads();
+		uint32_t a = bh[4 * lane], b = bh[4 * lane + 1], cc = bh[4 * lane + 2], d = bh[4 * lane + 3], tot;
+		uint32_t ex = wave_excl_scan(a + b + cc + d, tot);
+		cnt[4 * lane] += a; cnt[4 * lane + 1] += b; cnt[4 * lane + 2] += cc; cnt[4 * lane + 3] += d;
+		cum[4 * lane] += ex; cum[4 * lane + 1] += ex + a; cum[4 * lane + 2] += ex + a + b; cum[4 * lane + 3] += ex + a + b + cc;
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_rchain: the serial range recurrence of the reference's single stream (arith/coder.h:69-91):
+//     r = R / t;  R' = (h < t) ? r * (h - l) : R - r * l;  while (R' <= 2^62) R' <<= 1
+// R does not depend on the low register L, so this chain is split off: it produces r_k and the bit position S_k
+// (number of shifts before symbol k); the low register is assembled in parallel by k_low_accumulate.
+// One wavefront; the state lives in scalar registers, symbols are fetched 64 at a time (one dwordx4 per lane).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rchain(const SymRec *rec, uint32_t n, uint64_t *r_out, uint32_t *s_out, uint64_t *state)
+{
+	const int lane = threadIdx.x;
+	uint64_t R = state[0];
+	uint64_t S = state[1];
+	const SymRec idle{ 0, 0, kMetaNoop };
+	SymRec cur = lane < (int)n ? rec[lane] : idle;
+	for (uint32_t base = 0; base < n; base += 64) {
+		uint32_t nidx = base + 64 + lane;
+		SymRec nxt = nidx < n ? rec[nidx] : idle;
+		uint32_t mlo = (uint32_t)cur.magic, mhi = (uint32_t)(cur.magic >> 32), mx = cur.x, mm = cur.meta;
+		uint64_t my_r = 0;
+		uint32_t my_s = 0;
+		uint32_t cntb = min(64u, n - base);
+		for (uint32_t i = 0; i < cntb; ++i) {
+			uint32_t meta = (uint32_t)__builtin_amdgcn_readlane(mm, i);
+			uint64_t r = 0;
+			uint32_t s_before = (uint32_t)S;
+			if (!(meta & kMetaNoop)) {
+				uint64_t magic = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, i) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, i);
+				uint32_t x = (uint32_t)__builtin_amdgcn_readlane(mx, i);
+				r = cm::div_by_magic(R, magic, meta & 63u);
+				uint64_t prod = r * x;
+				uint64_t Rn = (meta & kMetaSub) ? R - prod : prod;
+				uint64_t y = Rn - 1;
+				uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
+				R = Rn << sh;
+				S += sh;
+			}
+			if (lane == (int)i) { my_r = r; my_s = s_before; }
+		}
+		if (base + lane < n) { r_out[base + lane] = my_r; s_out[base + lane] = my_s; }
+		cur = nxt;
+	}
+	if (lane == 0) { state[0] = R; state[1] = S; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// low register as one big number: L = sum_k (r_k * l_k) << (stream position), added into 64-bit accumulators
+// per 32-bit output word (word 0 = most significant).  coder.h:71 (L += r * l) and :73-90 (carry handling by
+// bit-plus-follow) are exactly big-number addition with carry propagation; flush (:58-67) appends the 64 bits of L.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_low_accumulate(const uint64_t *r, const uint32_t *s, const uint32_t *sym_l, uint32_t n, unsigned long long *acc)
+{
+	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n) return;
+	uint32_t l = sym_l[g];
+	if (l == 0) return;
+	uint64_t a = r[g] * l;
+	uint32_t pos = s[g], w = pos >> 5, sh = pos & 31;
+	uint64_t hi = a >> (32 + sh);
+	uint64_t low = a << (32 - sh);
+	uint32_t mid = (uint32_t)(low >> 32), lo = (uint32_t)low;
+	if (hi) atomicAdd(&acc[w], (unsigned long long)hi);
+	if (mid) atomicAdd(&acc[w + 1], (unsigned long long)mid);
+	if (lo) atomicAdd(&acc[w + 2], (unsigned long long)lo);
+}
+
+// first normalisation: v[k] = low32(acc[k]) + high32(acc[k+1]) < 2^33, after which carries are single bits
+__global__ __launch_bounds__(256) void k_carry_fold(const unsigned long long *acc, uint32_t nw, unsigned long long *v)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= nw) return;
+	unsigned long long up = k + 1 < nw ? acc[k + 1] >> 32 : 0ull;
+	v[k] = (acc[k] & 0xffffffffull) + up;
+}
+
+// carry-lookahead over words, processed from the least significant word (index nw-1) upwards.
+// pair (g, p): g = the segment generates a carry, p = it propagates an incoming carry.
+__device__ __forceinline__ uint32_t gp_combine(uint32_t hi, uint32_t lo)   // hi = more significant segment
+{
+	uint32_t g = (hi & 1u) | (((hi >> 1) & 1u) & (lo & 1u));
+	uint32_t p = ((hi >> 1) & 1u) & ((lo >> 1) & 1u);
+	return g | (p << 1);
+}
+__device__ __forceinline__ uint32_t gp_of(unsigned long long v) { return (v >> 32 ? 1u : 0u) | ((v == 0xffffffffull) ? 2u : 0u); }
+
+constexpr int kCarryBlock = 1024;   // words per block
+__global__ __launch_bounds__(256) void k_carry_block_summary(const unsigned long long *v, uint32_t nw, uint32_t *summary)
+{
+	// block b covers reversed indices [b*1024, (b+1)*1024): reversed index i <-> word nw-1-i
+	__shared__ uint32_t sm[256];
+	uint32_t i0 = blockIdx.x * kCarryBlock + threadIdx.x * 4;
+	uint32_t acc = 2u;   // identity: no generate, propagate
+	for (int q = 0; q < 4; ++q) {
+		uint32_t i = i0 + q;
+		uint32_t e = i < nw ? gp_of(v[nw - 1 - i]) : 2u;
+		acc = gp_combine(e, acc);
+	}
+	sm[threadIdx.x] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t a = 2u;
+		for (int t = 0; t < 256; ++t) a = gp_combine(sm[t], a);
+		summary[blockIdx.x] = a;
+	}
+}
+__global__ void k_carry_scan_blocks(uint32_t *summary, uint32_t nblocks)
+{
+	// summary[b] becomes the carry INTO block b
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	uint32_t carry = 0;
+	for (uint32_t b = 0; b < nblocks; ++b) {
+		uint32_t gp = summary[b];
+		summary[b] = carry;
+		carry = (gp & 1u) | (((gp >> 1) & 1u) & carry);
+	}
+}
+__global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *v, uint32_t nw, const uint32_t *block_carry, uint8_t *bytes)
+{
+	__shared__ uint32_t sm[256];
+	uint32_t i0 = blockIdx.x * kCarryBlock + threadIdx.x * 4;
+	uint32_t e[4];
+	uint32_t acc = 2u;
+	for (int q = 0; q < 4; ++q) {
+		uint32_t i = i0 + q;
+		e[q] = i < nw ? gp_of(v[nw - 1 - i]) : 2u;
+		acc = gp_combine(e[q], acc);
+	}
+	sm[threadIdx.x] = acc;
+	__syncthreads();
+	// carry into this thread's 4 words = block carry pushed through all lower threads
+	uint32_t carry = block_carry[blockIdx.x];
+	for (uint32_t t = 0; t < threadIdx.x; ++t) {
+		uint32_t gp = sm[t];
+		carry = (gp & 1u) | (((gp >> 1) & 1u) & carry);
+	}
+	for (int q = 0; q < 4; ++q) {
+		uint32_t i = i0 + q;
+		if (i >= nw) break;
+		uint32_t k = nw - 1 - i;
+		uint32_t word = (uint32_t)(v[k] + carry);
+		carry = (e[q] & 1u) | (((e[q] >> 1) & 1u) & carry);
+		bytes[(size_t)4 * k] = (uint8_t)(word >> 24);
+		bytes[(size_t)4 * k + 1] = (uint8_t)(word >> 16);
+		bytes[(size_t)4 * k + 2] = (uint8_t)(word >> 8);
+		bytes[(size_t)4 * k + 3] = (uint8_t)word;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+void launch_bounds(hipStream_t st, const uint8_t *rec, uint32_t count, int stride, int off, int type,
+                   uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx, int nparts, uint8_t *out_min, uint8_t *out_max)
+{
+	hipLaunchKernelGGL(k_bounds_partial, dim3(nparts), dim3(256), 0, st, rec, count, stride, off, type, part_min, part_max, part_idx);
+	hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, st, part_min, part_max, part_idx, nparts, type, out_min, out_max);
+}
+void launch_requant(hipStream_t st, uint8_t *rec, uint32_t count, int stride, const RequantPlan &plan)
+{
+	if (!count || !plan.n) return;
+	unsigned nb = std::min(blocks_for(count, 256), 4096u);
+	hipLaunchKernelGGL(k_requant, dim3(nb), dim3(256), 0, st, rec, count, stride, plan);
+}
+void launch_rank(hipStream_t st, const uint32_t *order_v, uint32_t n, const uint32_t *org, uint32_t *rank)
+{
+	if (n) hipLaunchKernelGGL(k_rank, dim3(blocks_for(n, 256)), dim3(256), 0, st, order_v, n, org, rank);
+}
+void launch_predict_vtx(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank, const uint8_t *rec,
+                        const ListDesc &ld, uint8_t *planes)
+{
+	if (n) hipLaunchKernelGGL(k_predict_vtx, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, order_v, n, rank, rec, ld, planes, 0u);
+}
+void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes)
+{
+	if (n && ld.ncomp) hipLaunchKernelGGL(k_face_planes, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, order_f, n, rec, ld, planes);
+}
+void launch_magic_table(hipStream_t st, MagicEnt *tab, uint32_t from, uint32_t to)
+{
+	if (to > from) hipLaunchKernelGGL(k_magic_table, dim3(blocks_for(to - from, 256)), dim3(256), 0, st, tab, from, to);
+}
+void launch_split_bytes(hipStream_t st, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes)
+{
+	if (n) hipLaunchKernelGGL(k_split_bytes, dim3(blocks_for(n, 256)), dim3(256), 0, st, val, n, nbytes, planes);
+}
+void launch_op_records(hipStream_t st, const uint32_t *l, const uint32_t *h, const uint32_t *t, const uint32_t *pos, uint32_t n,
+                       const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
+{
+	if (n) hipLaunchKernelGGL(k_op_records, dim3(blocks_for(n, 256)), dim3(256), 0, st, l, h, t, pos, n, magic, rec, sym_l);
+}
+void launch_type_records(hipStream_t st, uint32_t n, uint32_t pos_base, uint32_t pos_stride, const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
+{
+	if (n) hipLaunchKernelGGL(k_type_records, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, pos_base, pos_stride, magic, rec, sym_l);
+}
+void launch_model(hipStream_t st, const PlaneJob *jobs, uint32_t njobs, const ChunkRef *chunks, uint32_t nchunks, uint32_t *hist,
+                  const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
+{
+	if (!nchunks) return;
+	hipLaunchKernelGGL(k_model_hist, dim3(nchunks), dim3(256), 0, st, jobs, chunks, hist);
+	hipLaunchKernelGGL(k_model_scan, dim3(njobs), dim3(256), 0, st, jobs, hist);
+	hipLaunchKernelGGL(k_model_lht, dim3(nchunks), dim3(64), 0, st, jobs, chunks, hist, magic, rec, sym_l);
+}
+void launch_rchain(hipStream_t st, const SymRec *rec, uint32_t n, uint64_t *r_out, uint32_t *s_out, uint64_t *state)
+{
+	hipLaunchKernelGGL(k_rchain, dim3(1), dim3(64), 0, st, rec, n, r_out, s_out, state);
+}
+void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s, const uint32_t *sym_l, uint32_t n, uint64_t *acc)
+{
+	if (n) hipLaunchKernelGGL(k_low_accumulate, dim3(blocks_for(n, 256)), dim3(256), 0, st, r, s, sym_l, n, (unsigned long long*)acc);
+}
+void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes)
+{
+	unsigned nb = blocks_for(nw, kCarryBlock);
+	hipLaunchKernelGGL(k_carry_fold, dim3(blocks_for(nw, 256)), dim3(256), 0, st, (const unsigned long long*)acc, nw, (unsigned long long*)v);
+	hipLaunchKernelGGL(k_carry_block_summary, dim3(nb), dim3(256), 0, st, (const unsigned long long*)v, nw, summary);
+	hipLaunchKernelGGL(k_carry_scan_blocks, dim3(1), dim3(64), 0, st, summary, nb);
+	hipLaunchKernelGGL(k_carry_apply, dim3(nb), dim3(256), 0, st, (const unsigned long long*)v, nw, summary, bytes);
+}
+
+}   // namespace dev
+}   // namespace hry

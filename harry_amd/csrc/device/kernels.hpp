@@ -1,0 +1,33 @@
+// Launch wrappers of the HIP kernels (kernels.hip, chunked.hip).  Everything is enqueued on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "dev_types.hpp"
+
+namespace hry {
+namespace dev {
+
+void launch_bounds(hipStream_t st, const uint8_t *rec, uint32_t count, int stride, int off, int type,
+                   uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx, int nparts, uint8_t *out_min, uint8_t *out_max);
+void launch_requant(hipStream_t st, uint8_t *rec, uint32_t count, int stride, const RequantPlan &plan);
+void launch_rank(hipStream_t st, const uint32_t *order_v, uint32_t n, const uint32_t *org, uint32_t *rank);
+void launch_predict_vtx(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank, const uint8_t *rec,
+                        const ListDesc &ld, uint8_t *planes);
+void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
+void launch_magic_table(hipStream_t st, MagicEnt *tab, uint32_t from, uint32_t to);
+void launch_split_bytes(hipStream_t st, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes);
+void launch_op_records(hipStream_t st, const uint32_t *l, const uint32_t *h, const uint32_t *t, const uint32_t *pos, uint32_t n,
+                       const MagicEnt *magic, SymRec *rec, uint32_t *sym_l);
+void launch_type_records(hipStream_t st, uint32_t n, uint32_t pos_base, uint32_t pos_stride, const MagicEnt *magic, SymRec *rec, uint32_t *sym_l);
+void launch_model(hipStream_t st, const PlaneJob *jobs, uint32_t njobs, const ChunkRef *chunks, uint32_t nchunks, uint32_t *hist,
+                  const MagicEnt *magic, SymRec *rec, uint32_t *sym_l);
+void launch_rchain(hipStream_t st, const SymRec *rec, uint32_t n, uint64_t *r_out, uint32_t *s_out, uint64_t *state);
+void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s, const uint32_t *sym_l, uint32_t n, uint64_t *acc);
+void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes);
+
+
+}   // namespace dev
+}   // namespace hry

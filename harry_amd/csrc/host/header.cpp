@@ -1,0 +1,123 @@
+// .hry container header (formats/hry/writer.cc:104-198, reader.cc:60-177, common.h:15-16).
+// All fields are little-endian raw values except the big-endian magic.  v0.1 = reference stream (compat profile);
+// v0.2 = chunked profile of this implementation (the reference reader rejects it by version, reader.cc:74).
+#include "host.hpp"
+
+namespace hry {
+namespace {
+struct Out {
+	std::vector<uint8_t> &o;
+	template <typename T> void v(T x) { const uint8_t *p = (const uint8_t*)&x; o.insert(o.end(), p, p + sizeof(T)); }
+	void raw(const void *p, size_t n) { o.insert(o.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
+};
+struct In {
+	const uint8_t *p, *end;
+	template <typename T> T v() { T x; need(sizeof(T)); memcpy(&x, p, sizeof(T)); p += sizeof(T); return x; }
+	void raw(void *d, size_t n) { need(n); memcpy(d, p, n); p += n; }
+	void need(size_t n) { if ((size_t)(end - p) < n) throw Error(HRY_E_FORMAT, "truncated .hry header"); }
+};
+}   // namespace
+
+void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out)
+{
+	Out w{ out };
+	const uint8_t magic[6] = { 0xfa, 0xff, 0xaf, 0xaf, 0, (uint8_t)ver_minor };
+	w.raw(magic, 6);
+	w.v<uint32_t>(m.nv); w.v<uint32_t>(m.nf); w.v<uint32_t>(m.ne());
+	// region tables: one face region bound to list 0, one vertex region bound to list 1 (ply/reader.cc:399-401)
+	w.v<uint16_t>(1); w.v<uint16_t>(1);
+	w.v<uint16_t>(1); w.v<uint16_t>(0); w.v<uint16_t>(0);
+	w.v<uint16_t>(1); w.v<uint16_t>(1);
+	for (int l = 0; l < 2; ++l) {
+		const AttrList &L = m.lists[l];
+		if (!L.have_bounds && L.ncomp() > 0) throw Error(HRY_E_INTERNAL, "attribute bounds missing");
+		w.v<uint32_t>(L.count);
+		w.v<uint16_t>((uint16_t)L.ncomp());
+		for (int c = 0; c < L.ncomp(); ++c) { w.v<uint8_t>(L.type[c]); w.v<uint8_t>(L.quant[c]); }
+		w.v<uint16_t>((uint16_t)L.interp_off.size());
+		for (size_t j = 0; j < L.interp_off.size(); ++j) {
+			w.v<uint16_t>((uint16_t)L.interp_len[j]);
+			if ((int)j >= kInterpOther) {
+				const std::string &nm = L.interp_name[j - kInterpOther];
+				w.v<uint32_t>((uint32_t)nm.size());
+				w.raw(nm.data(), nm.size());
+			}
+		}
+		w.raw(L.bmin.data(), (size_t)L.stride());
+		w.raw(L.bmax.data(), (size_t)L.stride());
+	}
+	uint16_t cnt = 0;
+	for (uint8_t d : m.have_degree) cnt += d ? 1 : 0;
+	w.v<uint16_t>(cnt);
+	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) w.v<uint16_t>((uint16_t)d);
+}
+
+size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor)
+{
+	In r{ p, p + n };
+	uint8_t magic[6];
+	r.raw(magic, 6);
+	if (magic[0] != 0xfa || magic[1] != 0xff || magic[2] != 0xaf || magic[3] != 0xaf) throw Error(HRY_E_FORMAT, "Invalid magic number");
+	if (magic[4] != 0)
+		throw Error(HRY_E_FORMAT, "File format version " + std::to_string(magic[4]) + "." + std::to_string(magic[5]) + " incompatible to decoder format version 0.1");
+	ver_minor = magic[5];
+	if (ver_minor != 1 && ver_minor != 2)
+		throw Error(HRY_E_FORMAT, "File format version 0." + std::to_string(magic[5]) + " incompatible to decoder format version 0.1 (All 0.x-versions are incompatible to each other)");
+	m.nv = r.v<uint32_t>(); m.nf = r.v<uint32_t>();
+	uint32_t ne = r.v<uint32_t>();
+	(void)ne;
+	uint16_t nrf = r.v<uint16_t>(), nrv = r.v<uint16_t>();
+	if (nrf != 1 || nrv != 1) throw Error(HRY_E_UNSUPPORTED, "multi-region meshes (OBJ material regions) are outside the supported subset");
+	uint16_t nbf = r.v<uint16_t>(), nbc = r.v<uint16_t>();
+	if (nbf != 1 || nbc != 0) throw Error(HRY_E_UNSUPPORTED, "corner attribute lists are outside the supported subset");
+	if (r.v<uint16_t>() != 0) throw Error(HRY_E_UNSUPPORTED, "unexpected face list id");
+	if (r.v<uint16_t>() != 1) throw Error(HRY_E_UNSUPPORTED, "more than one vertex attribute list");
+	if (r.v<uint16_t>() != 1) throw Error(HRY_E_UNSUPPORTED, "unexpected vertex list id");
+	for (int l = 0; l < 2; ++l) {
+		AttrList &L = m.lists[l];
+		L = AttrList();
+		L.target = l;
+		L.count = r.v<uint32_t>();
+		uint16_t nc = r.v<uint16_t>();
+		if (nc > kMaxComp) throw Error(HRY_E_UNSUPPORTED, "too many components in one attribute list");
+		for (int c = 0; c < nc; ++c) {
+			uint8_t t = r.v<uint8_t>(), q = r.v<uint8_t>();
+			if (t >= C_NONE || q > 64) throw Error(HRY_E_FORMAT, "bad component descriptor");
+			L.add_comp((CompType)t, q);
+		}
+		uint16_t ni = r.v<uint16_t>();
+		int off = 0;
+		for (int j = 0; j < ni; ++j) {
+			uint16_t len = r.v<uint16_t>();
+			for (int k = 0; k < len; ++k) L.add_interp(j, off + k);
+			off += len;
+			if (j >= kInterpOther) {
+				uint32_t sl = r.v<uint32_t>();
+				r.need(sl);
+				std::string nm((const char*)r.p, sl);
+				r.p += sl;
+				if (j >= (int)L.interp_off.size()) { L.interp_off.resize(j + 1, -1); L.interp_len.resize(j + 1, 0); }
+				if ((int)L.interp_name.size() < j - kInterpOther + 1) L.interp_name.resize(j - kInterpOther + 1);
+				L.interp_name[j - kInterpOther] = nm;
+			}
+		}
+		if (off > nc) throw Error(HRY_E_FORMAT, "interpretation table exceeds component count");
+		L.data.assign((size_t)L.count * L.stride(), 0);
+		L.bmin.resize(L.stride()); L.bmax.resize(L.stride());
+		r.raw(L.bmin.data(), L.bmin.size());
+		r.raw(L.bmax.data(), L.bmax.size());
+		L.have_bounds = true;
+	}
+	if (m.lists[0].count != m.nf || m.lists[1].count != m.nv) throw Error(HRY_E_UNSUPPORTED, "shared attribute records are outside the supported subset");
+	uint16_t cnt = r.v<uint16_t>();
+	m.have_degree.clear();
+	for (int i = 0; i < cnt; ++i) {
+		uint16_t d = r.v<uint16_t>();
+		if (d < 3 || d > 255) throw Error(HRY_E_UNSUPPORTED, "polygon degree outside 3..255");
+		if (d >= m.have_degree.size()) m.have_degree.resize(d + 1, 0);
+		m.have_degree[d] = 1;
+	}
+	return (size_t)(r.p - p);
+}
+
+}   // namespace hry

@@ -1,0 +1,53 @@
+// Host-side declarations of the product (PLY I/O, cut-border walk, .hry header).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/harry_amd.h"
+#include "mesh.hpp"
+
+namespace hry {
+
+// ---- ply_io.cpp
+Mesh *mesh_from_ply(const uint8_t *buf, size_t n);
+Mesh *mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint8_t *v_types, const char *const *v_names,
+                       uint32_t nf, const uint8_t *degrees, const uint32_t *indices,
+                       const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names);
+void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out);
+void build_twins(Mesh &m);
+
+// ---- context numbering of a .hry stream (formats/hry/models.h:183-237), shared with the device code
+enum {
+	CTX_IOP = 0, CTX_OP = 1, CTX_ELEM = 2, CTX_PART = 6, CTX_VERT = 8, CTX_NUMTRI = 12, CTX_REGFACE = 14, CTX_REGVTX = 16, CTX_ATTR0 = 18,
+	ATTR_TYPE = 0, ATTR_GHIST = 1, ATTR_LHIST = 5, ATTR_DATA = 7
+};
+// connectivity symbol groups the walk emits as byte planes
+enum ConnGroup { G_IOP = 0, G_ELEM, G_PART, G_VERT, G_NUMTRI, G_COUNT };
+static constexpr int kGroupBytes[G_COUNT] = { 1, 4, 2, 4, 2 };
+static constexpr int kGroupCtx[G_COUNT] = { CTX_IOP, CTX_ELEM, CTX_PART, CTX_VERT, CTX_NUMTRI };
+
+// Output of the host-side cut-border walk (the inputs the device path needs)
+struct WalkResult {
+	std::vector<uint32_t> order_v;   // one half-edge per coded vertex, in coding order (attrcode.h:297,310-314)
+	std::vector<uint32_t> order_f;   // one half-edge per face, in coding order (attrcode.h:298,315-319)
+	// connectivity symbols: values (low byte first, one entry per symbol) + position in the global symbol sequence
+	std::vector<uint32_t> grp_val[G_COUNT];
+	std::vector<uint32_t> grp_pos[G_COUNT];
+	// cut-border operations: raw symbol + order class, and the order-conditioned model already evaluated
+	// (models.h:91-119) as cumulative-frequency triples
+	std::vector<uint8_t> op_sym, op_class;
+	std::vector<uint32_t> op_l, op_h, op_t, op_pos;
+	uint32_t n_conn = 0;             // symbols in the connectivity part of the global sequence
+	bool numtri_coded = false;       // false when a single polygon degree makes every numtri symbol an exact no-op
+};
+
+// ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
+void cut_border_walk(Mesh &m, WalkResult &out);
+
+// ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
+void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);
+// parses the header into a mesh skeleton (lists allocated, no connectivity); returns bytes consumed
+size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor);
+
+}   // namespace hry

@@ -1,0 +1,446 @@
+// PLY subset reader/writer of the product (host side).
+// Behavioural contract: formats/ply/reader.cc:36-429 (property canonicalisation, list 0 = face attributes,
+// list 1 = vertex attributes, `vertex_indices` -> polygons) and formats/ply/writer.cc:106-192.
+// Half-edge twins are matched with the reference's sequential rule (structs/conn.h:201-214): a directed edge
+// (a,b) pairs with a pending (b,a); a second pending (a,b) is dropped.  Implemented here with an open-addressing
+// table instead of std::unordered_map.
+#include "host.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <unordered_map>
+
+namespace hry {
+
+namespace {
+
+struct Prop { std::string name; CompType type; CompType len_type; };
+struct Element { std::string name; long count = 0; std::vector<Prop> props; };
+
+CompType parse_type(const std::string &s)
+{
+	static const std::unordered_map<std::string, CompType> m = {
+		{ "float", C_FLOAT }, { "float32", C_FLOAT }, { "double", C_DOUBLE }, { "float64", C_DOUBLE },
+		{ "uint", C_UINT }, { "uint32", C_UINT }, { "int", C_INT }, { "int32", C_INT },
+		{ "ushort", C_USHORT }, { "uint16", C_USHORT }, { "short", C_SHORT }, { "int16", C_SHORT },
+		{ "uchar", C_UCHAR }, { "uint8", C_UCHAR }, { "char", C_CHAR }, { "int8", C_CHAR } };
+	auto it = m.find(s);
+	if (it == m.end()) throw Error(HRY_E_FORMAT, "Invalid data type");
+	return it->second;
+}
+
+// canonical rank of well-known property names and their interpretation group (ply/reader.cc:36-68)
+struct Known { const char *name; int rank; int interp; };
+const Known kKnown[] = {
+	{ "x", 0, 0 }, { "y", 1, 0 }, { "z", 2, 0 }, { "w", 3, 0 }, { "nx", 4, 1 }, { "ny", 5, 1 }, { "nz", 6, 1 }, { "nw", 7, 1 },
+	{ "red", 8, 2 }, { "green", 9, 2 }, { "blue", 10, 2 }, { "alpha", 11, 2 },
+	{ "ambient_red", 12, 3 }, { "ambient_green", 13, 3 }, { "ambient_blue", 14, 3 }, { "ambient_alpha", 15, 3 }, { "ambient_coeff", 16, 3 },
+	{ "diffuse_red", 17, 4 }, { "diffuse_green", 18, 4 }, { "diffuse_blue", 19, 4 }, { "diffuse_alpha", 20, 4 }, { "diffuse_coeff", 21, 4 },
+	{ "specular_red", 22, 5 }, { "specular_green", 23, 5 }, { "specular_blue", 24, 5 }, { "specular_alpha", 25, 5 }, { "specular_power", 26, 5 }, { "specular_coeff", 27, 5 },
+	{ "u", 28, 16 }, { "tu", 28, 16 }, { "v", 29, 16 }, { "tv", 29, 16 }, { "tw", 30, 16 },
+	{ "value", 31, 17 }, { "scale", 31, 17 }, { "confidence", 32, 18 } };
+const int kKnownEnd = 33;
+
+const Known *lookup_known(const std::string &n)
+{
+	for (const Known &k : kKnown) if (n == k.name) return &k;
+	return nullptr;
+}
+
+}   // namespace
+
+// Arrange scalar properties into an attribute list: well-known names first in canonical order, the rest in file
+// order, each unknown name its own named interpretation.  slot_of[i] = component index of property i or -1.
+void layout_attr_list(const std::vector<std::string> &names, const std::vector<CompType> &types, const std::vector<bool> &is_list,
+                      AttrList &L, std::vector<int> &slot_of)
+{
+	size_t n = names.size();
+	std::vector<int> rank(n, std::numeric_limits<int>::max()), interp(n, -1);
+	int next_other = kKnownEnd, scalars = 0;
+	for (size_t i = 0; i < n; ++i) {
+		if (is_list[i]) continue;
+		const Known *k = lookup_known(names[i]);
+		rank[i] = k ? k->rank : next_other++;
+		interp[i] = k ? k->interp : -1;
+		++scalars;
+	}
+	std::vector<int> order(n);
+	for (size_t i = 0; i < n; ++i) order[i] = (int)i;
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+	slot_of.assign(n, -1);
+	int others = 0;
+	for (int c = 0; c < scalars; ++c) {
+		int p = order[c];
+		L.add_comp(types[p]);
+		int id = interp[p] >= 0 ? interp[p] : kInterpOther + others++;
+		L.add_interp(id, c);
+		if (id >= kInterpOther) L.interp_name[id - kInterpOther] = names[p];
+		slot_of[p] = c;
+	}
+	if (L.ncomp() > kMaxComp) throw Error(HRY_E_UNSUPPORTED, "too many components in one attribute list");
+}
+
+// ---- twin matching -------------------------------------------------------------------------------------
+namespace {
+struct EdgeTable {
+	std::vector<uint64_t> key;
+	std::vector<uint32_t> val;
+	uint64_t mask;
+	static constexpr uint64_t EMPTY = ~0ull, DEAD = ~0ull - 1;
+	explicit EdgeTable(size_t expected)
+	{
+		size_t cap = 16;
+		while (cap < expected * 2) cap <<= 1;
+		key.assign(cap, EMPTY);
+		val.assign(cap, 0);
+		mask = cap - 1;
+	}
+	static uint64_t mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
+	// returns slot of k or -1
+	int64_t find(uint64_t k) const
+	{
+		for (uint64_t i = mix(k) & mask;; i = (i + 1) & mask) {
+			if (key[i] == k) return (int64_t)i;
+			if (key[i] == EMPTY) return -1;
+		}
+	}
+	void insert_if_absent(uint64_t k, uint32_t v)
+	{
+		int64_t dead = -1;
+		for (uint64_t i = mix(k) & mask;; i = (i + 1) & mask) {
+			if (key[i] == k) return;
+			if (key[i] == DEAD && dead < 0) dead = (int64_t)i;
+			if (key[i] == EMPTY) {
+				uint64_t s = dead >= 0 ? (uint64_t)dead : i;
+				key[s] = k; val[s] = v;
+				return;
+			}
+		}
+	}
+	void erase(int64_t slot) { key[slot] = DEAD; }
+};
+}   // namespace
+
+void build_twins(Mesh &m)
+{
+	uint32_t ne = m.ne();
+	m.twin.resize(ne);
+	for (uint32_t e = 0; e < ne; ++e) m.twin[e] = e;
+	EdgeTable tab(ne);
+	for (uint32_t f = 0; f < m.nf; ++f) {
+		uint32_t b = m.face_off[f], e = m.face_off[f + 1];
+		for (uint32_t h = b; h < e; ++h) {
+			uint32_t a = m.org[h], c = m.org[h + 1 == e ? b : h + 1];
+			int64_t s = tab.find(((uint64_t)c << 32) | a);
+			if (s >= 0) {
+				uint32_t o = tab.val[s];
+				m.twin[o] = h; m.twin[h] = o;
+				tab.erase(s);
+			} else tab.insert_if_absent(((uint64_t)a << 32) | c, h);
+		}
+	}
+}
+
+// ---- reader ----------------------------------------------------------------------------------------------
+namespace {
+struct Cur {
+	const uint8_t *p, *end;
+	void ws() { while (p < end && isspace(*p)) ++p; }
+	std::string tok() { ws(); const uint8_t *b = p; while (p < end && !isspace(*p)) ++p; return std::string((const char*)b, (const char*)p); }
+	void line() { while (p < end && *p != '\n') ++p; if (p < end) ++p; }
+	void need(size_t n) const { if ((size_t)(end - p) < n) throw Error(HRY_E_FORMAT, "truncated PLY"); }
+};
+
+template <typename T> inline void put(uint8_t *d, T v) { memcpy(d, &v, sizeof(T)); }
+
+// reads one value of type t (mode 0 ascii / 1 LE / 2 BE) into dst (host order), returns it as uint64 (list lengths, indices)
+inline uint64_t read_value(Cur &c, int mode, CompType t, uint8_t *dst)
+{
+	if (t == C_NONE) return 1;
+	if (mode == 0) {
+		c.ws();
+		if (c.p >= c.end) throw Error(HRY_E_FORMAT, "truncated PLY");
+		char *e = nullptr;
+		const char *s = (const char*)c.p;
+		uint64_t ret;
+		switch (t) {
+		case C_CHAR: { long long v = strtoll(s, &e, 10); put<int8_t>(dst, (int8_t)v); ret = (uint64_t)(int8_t)v; break; }
+		case C_UCHAR: { unsigned long long v = strtoull(s, &e, 10); put<uint8_t>(dst, (uint8_t)v); ret = (uint8_t)v; break; }
+		case C_SHORT: { long long v = strtoll(s, &e, 10); put<int16_t>(dst, (int16_t)v); ret = (uint64_t)(int16_t)v; break; }
+		case C_USHORT: { unsigned long long v = strtoull(s, &e, 10); put<uint16_t>(dst, (uint16_t)v); ret = (uint16_t)v; break; }
+		case C_INT: { long long v = strtoll(s, &e, 10); put<int32_t>(dst, (int32_t)v); ret = (uint64_t)(int32_t)v; break; }
+		case C_UINT: { unsigned long long v = strtoull(s, &e, 10); put<uint32_t>(dst, (uint32_t)v); ret = (uint32_t)v; break; }
+		case C_FLOAT: { double v = strtod(s, &e); put<float>(dst, (float)v); ret = (uint64_t)(float)v; break; }
+		case C_DOUBLE: { double v = strtod(s, &e); put<double>(dst, v); ret = (uint64_t)v; break; }
+		default: throw Error(HRY_E_FORMAT, "Invalid data type");
+		}
+		if (e == s) throw Error(HRY_E_FORMAT, "malformed ASCII PLY value");
+		c.p = (const uint8_t*)e;
+		return ret;
+	}
+	int n = kTypeSize[t];
+	c.need(n);
+	uint8_t tmp[8];
+	if (mode == 1) memcpy(tmp, c.p, n);
+	else for (int i = 0; i < n; ++i) tmp[i] = c.p[n - 1 - i];
+	c.p += n;
+	memcpy(dst, tmp, n);
+	switch (t) {
+	case C_CHAR: { int8_t v; memcpy(&v, tmp, 1); return (uint64_t)v; }
+	case C_UCHAR: return tmp[0];
+	case C_SHORT: { int16_t v; memcpy(&v, tmp, 2); return (uint64_t)v; }
+	case C_USHORT: { uint16_t v; memcpy(&v, tmp, 2); return v; }
+	case C_INT: { int32_t v; memcpy(&v, tmp, 4); return (uint64_t)v; }
+	case C_UINT: { uint32_t v; memcpy(&v, tmp, 4); return v; }
+	case C_FLOAT: { float v; memcpy(&v, tmp, 4); return (uint64_t)v; }
+	default: { double v; memcpy(&v, tmp, 8); return (uint64_t)v; }
+	}
+}
+}   // namespace
+
+Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
+{
+	Cur c{ buf, buf + n };
+	std::vector<Element> elems;
+	int mode = -1;
+	for (;;) {
+		std::string id = c.tok();
+		if (id.empty()) throw Error(HRY_E_FORMAT, "PLY header has no end_header");
+		if (id == "end_header") break;
+		if (id == "ply") continue;
+		if (id == "format") {
+			std::string f = c.tok();
+			mode = f == "ascii" ? 0 : f == "binary_little_endian" ? 1 : f == "binary_big_endian" ? 2 : -2;
+			if (mode == -2) throw Error(HRY_E_FORMAT, "Invlaid format");
+			c.line();
+		} else if (id == "element") {
+			Element e;
+			e.name = c.tok();
+			e.count = atol(c.tok().c_str());
+			elems.push_back(std::move(e));
+		} else if (id == "property") {
+			if (elems.empty()) throw Error(HRY_E_FORMAT, "Invlaid property");
+			std::string ty = c.tok();
+			CompType lt = C_NONE;
+			if (ty == "list") { lt = parse_type(c.tok()); ty = c.tok(); }
+			std::string nm = c.tok();
+			elems.back().props.push_back(Prop{ nm, parse_type(ty), lt });
+		} else c.line();   // comment / obj_info / unknown
+	}
+	c.line();
+	if (mode < 0) throw Error(HRY_E_FORMAT, "PLY header has no format line");
+	int fi = -1, vi = -1;
+	for (size_t i = 0; i < elems.size(); ++i) { if (elems[i].name == "face") fi = (int)i; else if (elems[i].name == "vertex") vi = (int)i; }
+	if (fi < 0 || vi < 0) throw Error(HRY_E_FORMAT, "PLY needs a vertex and a face element");
+
+	std::unique_ptr<Mesh> m(new Mesh());
+	std::vector<int> slot[2];
+	const int which[2] = { fi, vi };
+	for (int k = 0; k < 2; ++k) {
+		const Element &el = elems[which[k]];
+		std::vector<std::string> names; std::vector<CompType> types; std::vector<bool> isl;
+		for (const Prop &p : el.props) { names.push_back(p.name); types.push_back(p.type); isl.push_back(p.len_type != C_NONE); }
+		AttrList &L = m->lists[k];
+		L.target = k;
+		layout_attr_list(names, types, isl, L, slot[k]);
+		L.count = (uint32_t)el.count;
+		L.data.assign((size_t)L.count * L.stride(), 0);
+	}
+	m->nf = (uint32_t)elems[fi].count;
+	m->nv = (uint32_t)elems[vi].count;
+	int conn_prop = -1;
+	for (size_t k = 0; k < elems[fi].props.size(); ++k) if (elems[fi].props[k].name == "vertex_indices") conn_prop = (int)k;
+	if (conn_prop < 0 || elems[fi].props[conn_prop].len_type == C_NONE) throw Error(HRY_E_FORMAT, "PLY face element has no vertex_indices list");
+	m->face_off.reserve((size_t)m->nf + 1);
+	m->org.reserve((size_t)m->nf * 3);
+
+	uint8_t scratch[8];
+	for (size_t ei = 0; ei < elems.size(); ++ei) {
+		const Element &el = elems[ei];
+		bool is_attr = (int)ei == fi || (int)ei == vi;
+		int k = (int)ei == fi ? 0 : 1;
+		AttrList *L = is_attr ? &m->lists[k] : nullptr;
+		// fast path: binary little-endian records made of scalar attributes only
+		bool all_scalar = true;
+		for (const Prop &p : el.props) all_scalar &= p.len_type == C_NONE;
+		if (is_attr && mode == 1 && all_scalar) {
+			size_t rec = 0;
+			std::vector<int> src_off;
+			for (const Prop &p : el.props) { src_off.push_back((int)rec); rec += kTypeSize[p.type]; }
+			c.need(rec * (size_t)el.count);
+			bool ident = (int)rec == L->stride();
+			for (size_t i = 0; ident && i < el.props.size(); ++i) ident = L->offset[slot[k][i]] == src_off[i];
+			if (ident) memcpy(L->data.data(), c.p, rec * (size_t)el.count);
+			else
+				for (long j = 0; j < el.count; ++j) {
+					const uint8_t *s = c.p + rec * (size_t)j;
+					uint8_t *d = L->data.data() + (size_t)j * L->stride();
+					for (size_t i = 0; i < el.props.size(); ++i) memcpy(d + L->offset[slot[k][i]], s + src_off[i], kTypeSize[el.props[i].type]);
+				}
+			c.p += rec * (size_t)el.count;
+			continue;
+		}
+		for (long j = 0; j < el.count; ++j) {
+			for (size_t pi = 0; pi < el.props.size(); ++pi) {
+				const Prop &p = el.props[pi];
+				if (is_attr && slot[k][pi] >= 0) {
+					read_value(c, mode, p.type, L->data.data() + (size_t)j * L->stride() + L->offset[slot[k][pi]]);
+					continue;
+				}
+				uint64_t len = read_value(c, mode, p.len_type, scratch);
+				if ((int)ei == fi && (int)pi == conn_prop) {
+					if (len < 3 || len > 255) throw Error(HRY_E_UNSUPPORTED, "polygon degree outside 3..255");
+					if (len >= m->have_degree.size()) m->have_degree.resize(len + 1, 0);
+					m->have_degree[len] = 1;
+					for (uint64_t l = 0; l < len; ++l) m->org.push_back((uint32_t)read_value(c, mode, p.type, scratch));
+					m->face_off.push_back((uint32_t)m->org.size());
+				} else for (uint64_t l = 0; l < len; ++l) read_value(c, mode, p.type, scratch);
+			}
+		}
+	}
+	if (m->face_off.size() != (size_t)m->nf + 1) throw Error(HRY_E_FORMAT, "PLY face count mismatch");
+	for (uint32_t v : m->org) if (v >= m->nv) throw Error(HRY_E_FORMAT, "PLY vertex index out of range");
+	build_twins(*m);
+	return m.release();
+}
+
+Mesh *mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint8_t *v_types, const char *const *v_names,
+                       uint32_t nf, const uint8_t *degrees, const uint32_t *indices,
+                       const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names)
+{
+	std::unique_ptr<Mesh> m(new Mesh());
+	m->nv = nv; m->nf = nf;
+	const uint8_t *recs[2] = { frec, vrec };
+	const int ncomps[2] = { f_ncomp, v_ncomp };
+	const uint8_t *types[2] = { f_types, v_types };
+	const char *const *names[2] = { f_names, v_names };
+	const uint32_t counts[2] = { nf, nv };
+	for (int k = 0; k < 2; ++k) {
+		std::vector<std::string> nm; std::vector<CompType> ty; std::vector<bool> isl;
+		std::vector<int> src_off;
+		int rec = 0;
+		for (int i = 0; i < ncomps[k]; ++i) {
+			if (types[k][i] >= C_NONE) throw Error(HRY_E_ARG, "bad component type");
+			nm.push_back(names[k][i]); ty.push_back((CompType)types[k][i]); isl.push_back(false);
+			src_off.push_back(rec); rec += kTypeSize[types[k][i]];
+		}
+		AttrList &L = m->lists[k];
+		L.target = k;
+		std::vector<int> slot;
+		layout_attr_list(nm, ty, isl, L, slot);
+		L.count = counts[k];
+		L.data.assign((size_t)L.count * L.stride(), 0);
+		for (uint32_t j = 0; j < L.count && rec; ++j)
+			for (int i = 0; i < ncomps[k]; ++i)
+				memcpy(L.data.data() + (size_t)j * L.stride() + L.offset[slot[i]], recs[k] + (size_t)j * rec + src_off[i], kTypeSize[ty[i]]);
+	}
+	m->face_off.reserve((size_t)nf + 1);
+	uint64_t tot = 0;
+	for (uint32_t f = 0; f < nf; ++f) {
+		int d = degrees[f];
+		if (d < 3) throw Error(HRY_E_UNSUPPORTED, "polygon degree outside 3..255");
+		if (d >= (int)m->have_degree.size()) m->have_degree.resize(d + 1, 0);
+		m->have_degree[d] = 1;
+		tot += d;
+		if (tot > 0xffffffffull) throw Error(HRY_E_UNSUPPORTED, "more than 2^32-1 half-edges");
+		m->face_off.push_back((uint32_t)tot);
+	}
+	m->org.assign(indices, indices + tot);
+	for (uint32_t v : m->org) if (v >= nv) throw Error(HRY_E_ARG, "vertex index out of range");
+	build_twins(*m);
+	return m.release();
+}
+
+// ---- writer (formats/ply/writer.cc:106-192) ------------------------------------------------------------------
+namespace {
+const char *type_name(CompType t)
+{
+	switch (t) {
+	case C_FLOAT: return "float"; case C_DOUBLE: return "double"; case C_UINT: return "uint"; case C_INT: return "int";
+	case C_USHORT: return "ushort"; case C_SHORT: return "short"; case C_UCHAR: return "uchar"; case C_CHAR: return "char";
+	default: return "";
+	}
+}
+std::string interp_prop_name(const AttrList &L, int interp, int k)   // writer.cc:43-66
+{
+	static const std::vector<std::vector<const char*>> names = {
+		{ "x", "y", "z", "w" }, { "nx", "ny", "nz", "nw" }, { "red", "green", "blue" }, { "ambient_red", "ambient_green", "ambient_blue" },
+		{ "diffuse_red", "diffuse_green", "diffuse_blue" }, { "specular_red", "specular_green", "specular_blue" }, { "u", "v", "tw" },
+		{ "scale" }, { "confidence" } };
+	static const char *group[] = { "pos", "normal", "color", "ambient", "diffuse", "specular", "tex" };
+	if (interp < kInterpOther) {
+		if (interp < (int)names.size()) {
+			if (k < (int)names[interp].size()) return names[interp][k];
+			return std::string(group[interp]) + "_" + std::to_string(k);
+		}
+		return "unknown_" + std::to_string(interp) + "_" + std::to_string(k);
+	}
+	const std::string &n = L.interp_name[interp - kInterpOther];
+	return L.interp_len[interp] == 1 ? n : n + "_" + std::to_string(k);
+}
+void print_comp(std::string &o, const AttrList &L, const uint8_t *rec, int c)   // mixing.h:340-359
+{
+	char buf[64];
+	const uint8_t *p = rec + L.offset[c];
+	switch (L.stype(c)) {
+	case C_CHAR: snprintf(buf, sizeof buf, "%d", (int)*(const int8_t*)p); break;
+	case C_SHORT: { int16_t v; memcpy(&v, p, 2); snprintf(buf, sizeof buf, "%d", (int)v); break; }
+	case C_INT: { int32_t v; memcpy(&v, p, 4); snprintf(buf, sizeof buf, "%d", v); break; }
+	case C_UCHAR: snprintf(buf, sizeof buf, "%u", (unsigned)*p); break;
+	case C_USHORT: { uint16_t v; memcpy(&v, p, 2); snprintf(buf, sizeof buf, "%u", (unsigned)v); break; }
+	case C_UINT: { uint32_t v; memcpy(&v, p, 4); snprintf(buf, sizeof buf, "%u", v); break; }
+	case C_FLOAT: { float v; memcpy(&v, p, 4); snprintf(buf, sizeof buf, "%g", (double)v); break; }
+	case C_DOUBLE: { double v; memcpy(&v, p, 8); snprintf(buf, sizeof buf, "%g", v); break; }
+	default: buf[0] = 0;
+	}
+	o += buf;
+}
+}   // namespace
+
+void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out)
+{
+	std::string h = std::string("ply\nformat ") + (ascii ? "ascii" : "binary_little_endian") + " 1.0\ncomment decompressed using harry mesh compressor\n";
+	auto props = [&](const AttrList &L) {
+		for (int i = 0; i < (int)L.interp_off.size(); ++i)
+			for (int k = 0; k < L.interp_len[i]; ++k)
+				h += std::string("property ") + type_name(L.stype(L.interp_off[i] + k)) + " " + interp_prop_name(L, i, k) + "\n";
+	};
+	h += "element vertex " + std::to_string(m.nv) + "\n";
+	props(m.lists[1]);
+	h += "element face " + std::to_string(m.nf) + "\nproperty list uchar uint vertex_indices\n";
+	props(m.lists[0]);
+	h += "end_header\n";
+	out.assign(h.begin(), h.end());
+	const AttrList &LV = m.lists[1], &LF = m.lists[0];
+	if (!ascii) {
+		out.insert(out.end(), LV.data.begin(), LV.data.end());   // whole original-width records (writer.cc:72-75)
+		size_t fs = LF.stride();
+		for (uint32_t f = 0; f < m.nf; ++f) {
+			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
+			out.push_back((uint8_t)(e - b));
+			const uint8_t *p = (const uint8_t*)&m.org[b];
+			out.insert(out.end(), p, p + 4 * (size_t)(e - b));
+			if (fs) out.insert(out.end(), LF.data.begin() + (size_t)f * fs, LF.data.begin() + (size_t)(f + 1) * fs);
+		}
+		return;
+	}
+	std::string o;
+	for (uint32_t v = 0; v < m.nv; ++v) {
+		for (int c = 0; c < LV.ncomp(); ++c) { if (c) o += '\t'; print_comp(o, LV, LV.data.data() + (size_t)v * LV.stride(), c); }
+		o += '\n';
+	}
+	for (uint32_t f = 0; f < m.nf; ++f) {
+		uint32_t b = m.face_off[f], e = m.face_off[f + 1];
+		o += std::to_string((int)(uint8_t)(e - b));
+		for (uint32_t x = b; x < e; ++x) { o += '\t'; o += std::to_string(m.org[x]); }
+		for (int c = 0; c < LF.ncomp(); ++c) { o += '\t'; print_comp(o, LF, LF.data.data() + (size_t)f * LF.stride(), c); }
+		o += '\n';
+		if (o.size() > (1u << 20)) { out.insert(out.end(), o.begin(), o.end()); o.clear(); }
+	}
+	out.insert(out.end(), o.begin(), o.end());
+}
+
+}   // namespace hry

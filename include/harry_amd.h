@@ -1,0 +1,155 @@
+/*
+ * harry_amd.h -- C ABI of the MI355X-native .hry codec path (libharry_amd.so).
+ *
+ * Drop-in boundary for the attribute-quantisation + arithmetic-coding hot path of maxvonbuelow/harry.
+ * The reference has no FFI; its seams are C++ free functions.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference tree):
+ *
+ *   hry_mesh_from_ply   <- ply::reader::read(std::istream&, mesh::Mesh&)          formats/ply/reader.cc:382-429
+ *   hry_mesh_to_ply     <- ply::writer::write(std::ostream&, mesh::Mesh&, bool)   formats/ply/writer.cc:136-192
+ *   hry_requant         <- quant::requant(Attrs&, const vector<Quant>&, bool)     structs/quant.h:222-242 (+ main.cc:74-91)
+ *   hry_encode          <- hry::writer::write(std::ostream&, mesh::Mesh&)         formats/hry/writer.h:19, writer.cc:200-218
+ *   hry_decode          <- hry::reader::read(std::istream&, mesh::Mesh&)          formats/hry/reader.h:19, reader.cc:179-193
+ *   hry_bounds          <- quant::set_bounds(Attrs&)                              structs/quant.h:30-44 (called by ply/reader.cc:428)
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All functions return HRY_OK (0) or a negative error
+ * code; hry_last_error() returns the message of the calling thread's last failure (the reference throws
+ * std::runtime_error with the same texts, e.g. "Invalid magic number", formats/hry/reader.cc:70).
+ *
+ * The compute stages run as hand-written HIP kernels on gfx950.  There is no CPU fallback: without a HIP
+ * device hry_ctx_create() fails with HRY_E_NODEVICE and nothing can be encoded or decoded.
+ */
+#ifndef HARRY_AMD_H
+#define HARRY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HRY_ABI_VERSION 1
+
+enum {
+    HRY_OK = 0,
+    HRY_E_ARG = -1,         /* invalid argument */
+    HRY_E_FORMAT = -2,      /* malformed PLY / .hry input */
+    HRY_E_UNSUPPORTED = -3, /* valid input outside the supported subset */
+    HRY_E_NODEVICE = -4,    /* no usable HIP device / HIP runtime error */
+    HRY_E_NOMEM = -5,
+    HRY_E_INTERNAL = -6
+};
+
+/* component types: numeric values of mixing::Type (structs/mixing.h:19), as stored in the .hry header */
+enum { HRY_FLOAT = 0, HRY_DOUBLE, HRY_ULONG, HRY_LONG, HRY_UINT, HRY_INT, HRY_USHORT, HRY_SHORT, HRY_UCHAR, HRY_CHAR };
+
+/* output profiles: COMPAT is byte-identical to the reference's single stream (v0.1);
+ * CHUNKED is the version-tagged (v0.2) parallel container: same symbols, independent coder per chunk. */
+enum { HRY_PROFILE_COMPAT = 0, HRY_PROFILE_CHUNKED = 1 };
+
+typedef struct hry_ctx hry_ctx;   /* device context: HIP device, streams, workspace */
+typedef struct hry_mesh hry_mesh; /* host-side mesh: flat arrays (see accessors) */
+
+/* one -q request: list, component (-1 = every component of the list), bits (0 clears)  (main.cc:23-27,63-65) */
+typedef struct hry_quant {
+    int32_t list;
+    int32_t comp;
+    int32_t bits;
+} hry_quant;
+
+typedef struct hry_opts {
+    int32_t profile;      /* HRY_PROFILE_* */
+    int32_t chunk_syms;   /* CHUNKED: symbols per chunk and plane (0 = default) */
+    int32_t keep_stages;  /* keep intermediate device buffers for hry_stage_get (tests) */
+    int32_t reserved;
+} hry_opts;
+
+/* timings of the last hry_encode / hry_decode on this context, milliseconds */
+typedef struct hry_timing {
+    double host_walk_ms;   /* cut-border walk on the host (cbm/encoder.h:54-217 equivalent) */
+    double h2d_ms;
+    double device_ms;      /* all kernels, measured with HIP events on the codec stream */
+    double d2h_ms;
+    double total_ms;
+    double k_rchain_ms;    /* compat: serial range recurrence kernel */
+    double k_model_ms;     /* adaptive-model evaluation kernels */
+    double k_predict_ms;   /* prediction + residual + symbolisation kernels */
+    double k_entropy_ms;   /* chunked: fused model+coder kernel */
+    uint64_t n_symbols;    /* coder invocations represented in the stream */
+    uint64_t payload_bytes;
+} hry_timing;
+
+const char *hry_last_error(void);
+int hry_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int hry_ctx_create(int device, hry_ctx **out);
+void hry_ctx_destroy(hry_ctx *ctx);
+int hry_ctx_timing(const hry_ctx *ctx, hry_timing *out);
+/* the HIP stream all kernels of this context are launched on (hipStream_t as void*), for external event timing */
+void *hry_ctx_stream(const hry_ctx *ctx);
+
+/* ---- mesh (host) -------------------------------------------------------------------------------- */
+int hry_mesh_from_ply(const uint8_t *ply, size_t n, hry_mesh **out);
+/* Build from flat arrays: vertex records (AoS, one slot per component in its original type), polygon
+ * degrees + flat vertex indices, optional face records.  Component names follow PLY conventions ("x","nx",
+ * "red", ...; unknown names become named "other" interpretations, formats/ply/reader.cc:130-168). */
+int hry_mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint8_t *v_types, const char *const *v_names,
+                         uint32_t nf, const uint8_t *degrees, const uint32_t *indices,
+                         const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names,
+                         hry_mesh **out);
+int hry_mesh_to_ply(const hry_mesh *m, int ascii, uint8_t **out, size_t *out_len);
+void hry_mesh_free(hry_mesh *m);
+hry_mesh *hry_mesh_clone(const hry_mesh *m);
+
+uint32_t hry_mesh_nv(const hry_mesh *m);
+uint32_t hry_mesh_nf(const hry_mesh *m);
+uint32_t hry_mesh_ne(const hry_mesh *m);
+uint64_t hry_mesh_ntri(const hry_mesh *m);              /* sum(ne - 2), structs/conn.h:87 */
+const uint32_t *hry_mesh_face_offsets(const hry_mesh *m); /* nf + 1 */
+const uint32_t *hry_mesh_org(const hry_mesh *m);          /* ne: origin vertex of each half-edge */
+const uint32_t *hry_mesh_twin(const hry_mesh *m);         /* ne: flat id of the opposite half-edge (self = border) */
+int hry_mesh_nlists(const hry_mesh *m);                   /* 2: list 0 = face attributes, list 1 = vertex attributes */
+int hry_list_ncomp(const hry_mesh *m, int l);
+uint32_t hry_list_count(const hry_mesh *m, int l);
+int hry_list_stride(const hry_mesh *m, int l);
+int hry_list_type(const hry_mesh *m, int l, int c);
+int hry_list_quant(const hry_mesh *m, int l, int c);
+int hry_list_offset(const hry_mesh *m, int l, int c);
+const uint8_t *hry_list_data(const hry_mesh *m, int l);
+const uint8_t *hry_list_min(const hry_mesh *m, int l);
+const uint8_t *hry_list_max(const hry_mesh *m, int l);
+
+/* ---- codec (device) ----------------------------------------------------------------------------- */
+/* min/max per component on the GPU (k_bounds); hry_mesh_from_ply leaves bounds unset until first needed */
+int hry_bounds(hry_ctx *ctx, hry_mesh *m);
+int hry_requant(hry_ctx *ctx, hry_mesh *m, const hry_quant *q, size_t nq, int clear);
+/* Keep the mesh's attribute records and connectivity resident in HBM for subsequent hry_encode calls. */
+int hry_mesh_upload(hry_ctx *ctx, hry_mesh *m);
+/* mesh -> .hry.  *out is allocated by the library, release with hry_free.  The mesh's twin array is updated
+ * exactly as the reference's encoder mutates it (cbm/encoder.h:150,193-198). */
+int hry_encode(hry_ctx *ctx, hry_mesh *m, const hry_opts *opts, uint8_t **out, size_t *out_len);
+int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out);
+void hry_free(void *p);
+
+/* ---- stage-level access for parity tests (valid after hry_encode/hry_decode with keep_stages) ----- */
+/* names: "order_v","order_f","twin","vplanes","fplanes","rec","sym_l","r","S","payload", ... */
+int hry_stage_get(hry_ctx *ctx, const char *name, void **host_copy, size_t *bytes);
+
+/* host-only: the sequential cut-border walk of the encoder (cbm::encode, cbm/encoder.h:54-217) with a recording
+ * writer.  Mutates the mesh's twins like hry_encode.  Arrays by name: "order_v", "order_f", "op_sym"(u8), "op_class"(u8),
+ * "op_l", "op_h", "op_t", "op_pos", "grp<k>_val", "grp<k>_pos" with k = 0 iop, 1 elem, 2 part, 3 vertid, 4 numtri
+ * (u32 unless noted), "info" = { n_conn, numtri_coded }.  hry_walk_get returns the element count. */
+typedef struct hry_walk hry_walk;
+int hry_walk_run(hry_mesh *m, hry_walk **out);
+size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr);
+void hry_walk_free(hry_walk *w);
+
+/* raw range-coder back end on explicit (l,h,t) triples (arith/coder.h:69-91 + flush :58-67), compat form */
+int hry_range_encode_lht(hry_ctx *ctx, const uint64_t *lht, size_t n, uint8_t **out, size_t *out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

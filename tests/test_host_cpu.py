@@ -1,0 +1,142 @@
+"""CPU-side tests of the product's host code (no GPU, no compute entry points):
+ - the C-ABI library loads and exports every symbol include/harry_amd.h declares
+ - PLY reader / half-edge twins / PLY writer agree with the oracle
+ - the host cut-border walk (order, repaired twins, connectivity symbols, op model) agrees with the oracle's trace
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from harry_amd import _native as nat
+from harry_amd import codec as hc
+from harry_amd import meshgen as mg
+from oracle import oracle_py as op
+from tests import util
+
+GOLD = os.path.join(util.ROOT, "tests", "golden")
+PLYS = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".ply") and ".dec." not in f)
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(util.ROOT, "include", "harry_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(hry_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 30
+    L = nat.load()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.hry_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    """Without a HIP device the codec must refuse to exist (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hc.HryError) as e:
+        hc.Codec(0)
+    assert e.value.code == nat.E_NODEVICE
+
+
+@pytest.mark.parametrize("name", PLYS)
+def test_ply_reader_matches_oracle(name):
+    data = open(os.path.join(GOLD, name + ".ply"), "rb").read()
+    a = hc.Mesh.from_ply(data)
+    b = op.Mesh.from_ply(data)
+    assert (a.nv, a.nf, a.ne, a.ntri) == (b.nv, b.nf, b.ne, b.ntri)
+    assert np.array_equal(a.face_offsets(), b.face_offsets())
+    assert np.array_equal(a.org(), b.org())
+    assert np.array_equal(a.twin(), b.twin())
+    for l in range(2):
+        assert a.list_fmt(l) == b.list_fmt(l)
+        assert np.array_equal(a.list_data(l), b.list_data(l))
+
+
+def test_ply_writer_roundtrip_and_from_arrays():
+    m = mg.with_face_props(mg.with_colors(mg.torus(9, 8, polys="mixed")))
+    a = hc.Mesh.from_ply(m.to_ply())
+    again = hc.Mesh.from_ply(a.to_ply(ascii=False))
+    assert np.array_equal(a.org(), again.org()) and np.array_equal(a.twin(), again.twin())
+    for l in range(2):
+        assert np.array_equal(a.list_data(l), again.list_data(l))
+    txt = a.to_ply(ascii=True)
+    assert txt.startswith(b"ply\nformat ascii 1.0\n")
+    b = hc.Mesh.from_arrays(m.verts, m.degrees, m.indices, m.face_props)
+    assert np.array_equal(a.org(), b.org()) and np.array_equal(a.twin(), b.twin())
+    for l in range(2):
+        assert a.list_fmt(l) == b.list_fmt(l)
+        assert np.array_equal(a.list_data(l), b.list_data(l))
+
+
+def test_reader_rejects_garbage():
+    with pytest.raises(hc.HryError):
+        hc.Mesh.from_ply(b"not a ply file")
+    with pytest.raises(hc.HryError):
+        hc.Mesh.from_ply(mg.grid(4).to_ply()[:-7])
+
+
+# ---------------------------------------------------------------- the walk
+CTX_IOP, CTX_OP, CTX_ELEM, CTX_PART, CTX_VERT, CTX_NUMTRI, CTX_REGFACE, CTX_REGVTX = 0, 1, 2, 6, 8, 12, 14, 16
+GROUPS = [(CTX_IOP, 1), (CTX_ELEM, 4), (CTX_PART, 2), (CTX_VERT, 4), (CTX_NUMTRI, 2)]
+
+
+def conn_part_of_trace(tr, numtri_coded):
+    """Oracle trace restricted to the connectivity part, with the symbols the product never materialises removed:
+    reg_face/reg_vtx (single region: l = 0, h = t) and, for single-degree meshes, numtri (same reason)."""
+    keep = (tr["ctx"] < CTX_REGFACE) | (tr["ctx"] >= 18)
+    if not numtri_coded:
+        keep &= ~((tr["ctx"] >= CTX_NUMTRI) & (tr["ctx"] < CTX_REGFACE))
+    return tr[keep]
+
+
+def check_walk_against_oracle(ply: bytes):
+    a = hc.Mesh.from_ply(ply)
+    o = op.Mesh.from_ply(ply)
+    res = o.encode(trace=True)
+    w = a.host_walk()
+    assert np.array_equal(w["order_v"], res.order_vtx())
+    assert np.array_equal(w["order_f"], res.order_face())
+    assert np.array_equal(a.twin(), o.twin()), "repaired twins differ"
+    n_conn, numtri_coded = int(w["info"][0]), bool(w["info"][1])
+    tr = conn_part_of_trace(res.trace(), numtri_coded)
+    conn = tr[:n_conn]
+    assert len(tr) >= n_conn and (n_conn == len(tr) or tr["ctx"][n_conn] >= 18)
+    assert np.all(conn["ctx"] < 18)
+    # operations: symbol and evaluated model
+    ops = conn[conn["ctx"] == CTX_OP]
+    assert np.array_equal(w["op_sym"], ops["sym"].astype(np.uint8))
+    assert np.array_equal(w["op_l"], ops["l"]) and np.array_equal(w["op_h"], ops["h"]) and np.array_equal(w["op_t"], ops["t"])
+    assert np.array_equal(np.nonzero(conn["ctx"] == CTX_OP)[0], w["op_pos"])
+    # byte groups
+    for g, (ctx, nb) in enumerate(GROUPS):
+        val, pos = w[f"grp{g}_val"], w[f"grp{g}_pos"]
+        for b in range(nb):
+            sel = np.nonzero(conn["ctx"] == ctx + b)[0]
+            assert np.array_equal(sel, pos + b), (g, b)
+            assert np.array_equal(conn["sym"][sel], (val >> (8 * b)) & 0xff)
+    return a, o, res, w
+
+
+@pytest.mark.parametrize("name", PLYS)
+def test_walk_matches_oracle_on_golden_inputs(name):
+    check_walk_against_oracle(open(os.path.join(GOLD, name + ".ply"), "rb").read())
+
+
+@pytest.mark.parametrize("case", ["multi", "nonmanifold", "mixed_big", "open_quads", "ico"])
+def test_walk_matches_oracle_on_generated(case):
+    m = {"multi": lambda: mg.multi_component(12, 14, 16),
+         "nonmanifold": lambda: mg.with_nonmanifold(mg.concat([mg.torus(20, 22, polys="mixed"), mg.torus(9, 10, polys="mixed", center=(4, 0, 0))]), 12, 6),
+         "mixed_big": lambda: mg.torus(70, 64, polys="mixed"),
+         "open_quads": lambda: mg.grid(23, 17, quads=True),
+         "ico": lambda: mg.icosphere(4)}[case]()
+    check_walk_against_oracle(m.to_ply())
+
+
+def test_parse_quant_flags():
+    assert hc.parse_quant_flags(["-l1", "-q14"]) == ([(1, -1, 14)], False)
+    assert hc.parse_quant_flags(["-l", "1", "-a", "0", "-q", "14", "-a3", "-q10", "-c"]) == ([(1, 0, 14), (1, 3, 10)], True)
+    with pytest.raises(ValueError):
+        hc.parse_quant_flags(["-q14"])
