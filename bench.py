@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the .hry hot path on MI355X (contract: see the task description / DESIGN.md).
+
+One step = one pass of the hot path over one batch of synthetic input: encode the resident mesh to .hry
+(host cut-border walk + every HIP kernel + D2H of the stream) and, where the profile supports it, decode it back.
+Workload at N=1: BASELINE.json configs[1] -- 1 002 528-triangle closed torus, float32 xyz, `-l1 -q14`, one MI355X.
+With N>1 GPUs every rank codes its own connected component of the same size (weak scaling, no data-path
+collective; the compressed streams are gathered to rank 0 for concatenation only).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_workload(n_side: int, seed: int):
+    from harry_amd import meshgen as mg
+    return mg.torus(n_side, n_side, seed=seed, sigma=1e-4)
+
+
+def cpu_baseline(mesh, quant, budget_s=20.0):
+    """The CPU oracle (a restatement pinned byte-for-byte to the reference, kind = "port") timed single-threaded on
+    the same in-memory workload: encode (quantisation + .hry production) and decode, same phase boundaries."""
+    from oracle import oracle_py as op
+    ply = mesh.to_ply()
+    base = op.Mesh.from_ply(ply)
+    reps, t_enc, t_dec = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    hry = b""
+    while reps < 1 or (time.perf_counter() - t_start < budget_s and reps < 8):
+        m = base.clone()
+        t0 = time.perf_counter()
+        m.requant(quant)
+        hry = m.encode().data
+        t1 = time.perf_counter()
+        op.Mesh.from_hry(hry)
+        t2 = time.perf_counter()
+        t_enc += t1 - t0
+        t_dec += t2 - t1
+        reps += 1
+    ntri = mesh.ntri
+    return {"value": round(ntri * reps / (t_enc + t_dec) / 1e6, 4), "unit": "Mtriangles/s", "cores": 1, "kind": "port",
+            "encode_mtri_s": round(ntri * reps / t_enc / 1e6, 4), "decode_mtri_s": round(ntri * reps / t_dec / 1e6, 4),
+            "hry_bytes": len(hry),
+            "sample": f"full workload ({ntri} triangles, -l1 -q14), {reps} encode+decode repetitions, 1 thread"}, hry
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--side", type=int, default=708, help="torus grid side; 708 -> 1 002 528 triangles (configs[1])")
+    ap.add_argument("--profile", default="auto", choices=["auto", "compat", "chunked"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: harry_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from harry_amd import codec as hc
+
+    quant = [(1, -1, 14)]
+    mesh = build_workload(args.side, seed=2 + rank)     # each rank: its own connected component (weak scaling)
+    base = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    cx = hc.Codec(local_rank)
+    cx.requant(base, quant)                              # quantisation is part of "encode" (timed separately below)
+
+    profile = args.profile
+    if profile == "auto":
+        profile = "chunked"
+        try:
+            probe = base.clone()
+            cx.write_hry(probe, profile=hc.PROFILE_CHUNKED)
+        except hc.HryError:
+            profile = "compat"
+    pid = hc.PROFILE_CHUNKED if profile == "chunked" else hc.PROFILE_COMPAT
+    can_decode = True
+    try:
+        cx.read_hry(cx.write_hry(base.clone(), profile=pid))
+    except hc.HryError:
+        can_decode = False
+
+    def one_step():
+        """returns (stream bytes, timing dict); inputs are resident in HBM before the timed region"""
+        m = base.clone()
+        cx.upload(m)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = cx.write_hry(m, profile=pid)
+        t1 = time.perf_counter()
+        tm_e = cx.timing()
+        if can_decode:
+            cx.read_hry(out)
+        t2 = time.perf_counter()
+        return out, t1 - t0, t2 - t1, tm_e
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    enc_s = dec_s = 0.0
+    timings = []
+    out = b""
+    for _ in range(args.steps):
+        out, te, td, tm = one_step()
+        enc_s += te
+        dec_s += td
+        timings.append(tm)
+    barrier()
+    total = torch.tensor([enc_s + dec_s, enc_s, dec_s], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.MAX)
+        # final stream concatenation: gather the per-component streams on rank 0 (RCCL over xGMI)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([len(out)], dtype=torch.int64, device=dev))
+        cap = int(max(int(s.item()) for s in sizes))
+        buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        buf[:len(out)] = torch.frombuffer(bytearray(out), dtype=torch.uint8).to(dev)
+        gathered = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, gathered, dst=0)
+    t_all, t_enc, t_dec = (float(x) for x in total.tolist())
+
+    if rank == 0:
+        ntri = mesh.ntri
+        step_ms = t_all / args.steps * 1e3
+        value = world * ntri * args.steps / t_all / 1e6
+        med = lambda k: float(np.median([t[k] for t in timings]))
+        dom_ms, dom_name = (med("k_entropy_ms"), "k_chunk_encode") if profile == "chunked" and med("k_entropy_ms") > 0 else (med("k_rchain_ms"), "k_rchain")
+        # algorithmic bytes of the encode path per triangle: vertex records + 4 B per half-edge + stream
+        alg_bytes = base.nv * base.list_stride(1) + 4 * base.ne + len(out)
+        roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / (dom_ms * 1e-3) / 1e9, 3) if dom_ms > 0 else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(dom_ms, 4)}
+        roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 6) if roof["achieved"] else None
+        line = {
+            "metric": "Mtriangles/s encode+decode", "value": round(value, 4), "unit": "Mtriangles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/f32 (integer residuals, 64-bit range coder)", "data": "synthetic",
+            "config": {"workload": f"closed torus {args.side}x{args.side}, {ntri} triangles, float32 xyz, -l1 -q14 (BASELINE configs[1])",
+                       "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}"},
+            "encode_mtri_s": round(world * ntri * args.steps / t_enc / 1e6, 4),
+            "decode_mtri_s": round(world * ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
+            "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / base.nv, 4),
+            "stage_ms": {k: round(med(k), 4) for k in ("host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms")},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, ref_hry = cpu_baseline(mesh, quant)
+            line["cpu_baseline"] = cb
+            line["bits_per_vertex_cpu_ref"] = round(8 * len(ref_hry) / base.nv, 4)
+            if profile == "compat":
+                line["byte_identical_to_cpu_ref"] = bool(out == ref_hry)
+        print(json.dumps(line))
+    cx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

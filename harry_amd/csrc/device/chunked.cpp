@@ -1,9 +1,229 @@
-// Chunked profile (.hry v0.2) and decode entry points -- placeholders until the chunked kernels land.
+// Chunked profile (.hry v0.2) pipeline: encode and decode.
+//
+// Container (after the v0.1-compatible header with minor version 2):
+//     u32 chunk_syms, u32 n_planes, n_planes x u32 n_symbols, n_streams x u32 n_bytes, streams back to back
+// Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
+// Every (plane, chunk of chunk_syms symbols) is one stream: fresh adaptive model (the reference's initial counts,
+// models.h:197-218 / model.h:38-55), fresh 64-bit coder, 64-bit flush (arith/coder.h).  Symbols that carry no
+// information are not stored (reg_face / reg_vtx with a single region, attr_type == DATA, numtri with one degree).
+// The symbols themselves are those of the compat stream, so the two profiles transcode losslessly.
+#include <chrono>
+#include <cstring>
+
+#include "codec_math.hpp"
 #include "context.hpp"
+#include "kernels.hpp"
 
 namespace hry {
 
-void encode_chunked(Context &, Mesh &, int, std::vector<uint8_t> &) { throw Error(HRY_E_UNSUPPORTED, "chunked profile: not built yet"); }
-Mesh *decode_any(Context &, const uint8_t *, size_t) { throw Error(HRY_E_UNSUPPORTED, "decode: not built yet"); }
+using namespace dev;
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
+static constexpr int kDefaultChunk = 32768;
+
+static void build_inits(const Mesh &m, std::vector<uint32_t> &tabs, uint32_t totals[INIT_KINDS])
+{
+	tabs.assign((size_t)INIT_KINDS * 256, 0);
+	for (int i = 0; i < 256; ++i) tabs[INIT_ONES * 256 + i] = 1;
+	for (int i = 0; i < 9; ++i) tabs[INIT_IOP * 256 + i] = 1;
+	for (size_t d = 3; d < m.have_degree.size(); ++d)
+		if (m.have_degree[d]) { ++tabs[INIT_NT0 * 256 + ((d - 2) & 0xff)]; ++tabs[INIT_NT1 * 256 + ((d - 2) >> 8)]; }
+	for (int i = 0; i < 7; ++i) tabs[INIT_OP * 256 + i] = 1;
+	for (int k = 0; k < INIT_KINDS; ++k) { totals[k] = 0; for (int i = 0; i < 256; ++i) totals[k] += tabs[(size_t)k * 256 + i]; }
+}
+
+struct PlaneRef { const uint8_t *dptr; uint32_t n; int init; };
+
+// the plane list of a mesh in container order; device pointers are filled by the caller
+static const int kConnPlanes = 1 + 4 + 2 + 4 + 2 + 8;
+static int plane_init_kind(int conn_index)
+{
+	if (conn_index == 0) return INIT_IOP;
+	if (conn_index == 11) return INIT_NT0;
+	if (conn_index == 12) return INIT_NT1;
+	if (conn_index >= 13) return INIT_OP;
+	return INIT_ONES;
+}
+static uint32_t stream_words(uint32_t n, uint32_t t0)
+{
+	uint32_t tmax = t0 + n, lg = 0;
+	while ((2u << lg) <= tmax) ++lg;   // floor(log2(tmax))
+	uint64_t bits = (uint64_t)n * (lg + 2) + 64;
+	return (uint32_t)(bits / 32 + 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &out)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	auto t_all = Clock::now();
+	cx.timing = hry_timing{};
+	check_codable(m);
+	const uint32_t CH = chunk_syms > 0 ? (uint32_t)chunk_syms : (uint32_t)kDefaultChunk;
+	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
+	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds) { m.lists[l].bmin.assign(m.lists[l].stride(), 0); m.lists[l].bmax.assign(m.lists[l].stride(), 0); m.lists[l].have_bounds = true; }
+	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
+
+	out.clear();
+	write_hry_header(m, 2, out);
+	auto t_walk = Clock::now();
+	WalkResult w;
+	cut_border_walk(m, w);
+	cx.timing.host_walk_ms = ms_since(t_walk);
+
+	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
+	const ListDesc ldv = make_list_desc(m.lists[1]), ldf = make_list_desc(m.lists[0]);
+
+	// ---- connectivity planes on the host side: 5 groups (split into bytes on the device) + 8 operation planes
+	auto t_h2d = Clock::now();
+	std::vector<uint8_t> op_planes[8];
+	for (size_t i = 0; i < w.op_sym.size(); ++i) op_planes[w.op_class[i]].push_back(w.op_sym[i]);
+	size_t ngrp = 0, conn_plane_bytes = 0, nopb = w.op_sym.size();
+	for (int g = 0; g < G_COUNT; ++g) { ngrp += w.grp_val[g].size(); conn_plane_bytes += w.grp_val[g].size() * kGroupBytes[g]; }
+	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
+	cx.d_order_f.ensure(std::max<size_t>((size_t)fc * 4, 16));
+	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
+	cx.d_grp_val.ensure(std::max<size_t>(ngrp * 4, 16));
+	cx.d_connplanes.ensure(std::max<size_t>(conn_plane_bytes + nopb, 16));
+	cx.d_vplanes.ensure(std::max<size_t>((size_t)vc * ldv.nplanes, 16));
+	cx.d_fplanes.ensure(std::max<size_t>((size_t)fc * ldf.nplanes, 16));
+	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
+	if (fc) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
+	size_t goff[G_COUNT + 1] = { 0 };
+	for (int g = 0; g < G_COUNT; ++g) {
+		size_t n = w.grp_val[g].size();
+		goff[g + 1] = goff[g] + n;
+		if (n) HIP_OK(hipMemcpyAsync(cx.d_grp_val.as<uint32_t>() + goff[g], w.grp_val[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
+	}
+	uint8_t *d_opplanes = cx.d_connplanes.as<uint8_t>() + conn_plane_bytes;
+	{
+		size_t o = 0;
+		for (int k = 0; k < 8; ++k) {
+			if (!op_planes[k].empty()) HIP_OK(hipMemcpyAsync(d_opplanes + o, op_planes[k].data(), op_planes[k].size(), hipMemcpyHostToDevice, cx.stream));
+			o += op_planes[k].size();
+		}
+	}
+
+	// ---- plane list in container order
+	std::vector<PlaneRef> planes;
+	{
+		size_t poff = 0;
+		int ci = 0;
+		for (int g = 0; g < G_COUNT; ++g) {
+			uint32_t n = (uint32_t)w.grp_val[g].size();
+			for (int b = 0; b < kGroupBytes[g]; ++b, ++ci) planes.push_back(PlaneRef{ cx.d_connplanes.as<uint8_t>() + poff + (size_t)b * n, n, plane_init_kind(ci) });
+			poff += (size_t)n * kGroupBytes[g];
+		}
+		size_t o = 0;
+		for (int k = 0; k < 8; ++k, ++ci) { planes.push_back(PlaneRef{ d_opplanes + o, (uint32_t)op_planes[k].size(), INIT_OP }); o += op_planes[k].size(); }
+		for (int p = 0; p < ldv.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_vplanes.as<uint8_t>() + (size_t)p * vc, vc, INIT_ONES });
+		for (int p = 0; p < ldf.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_fplanes.as<uint8_t>() + (size_t)p * fc, fc, INIT_ONES });
+	}
+	std::vector<uint32_t> inits;
+	uint32_t totals[INIT_KINDS];
+	build_inits(m, inits, totals);
+	std::vector<StreamJob> jobs;
+	uint64_t words = 0;
+	uint64_t nsym_total = 0;
+	for (const PlaneRef &pl : planes) {
+		nsym_total += pl.n;
+		for (uint32_t f = 0; f < pl.n; f += CH) {
+			uint32_t n = std::min(CH, pl.n - f);
+			if (words >= (1ull << 32) - (1u << 24)) throw Error(HRY_E_UNSUPPORTED, "chunked stream accumulator exceeds 2^32 words");
+			jobs.push_back(StreamJob{ pl.dptr + f, n, (uint32_t)pl.init, totals[pl.init], (uint32_t)words });
+			words += stream_words(n, totals[pl.init]);
+		}
+	}
+	const uint32_t ns = (uint32_t)jobs.size();
+	const uint32_t nw = (uint32_t)words + 2;
+	cx.d_init.ensure(inits.size() * 4);
+	HIP_OK(hipMemcpyAsync(cx.d_init.p, inits.data(), inits.size() * 4, hipMemcpyHostToDevice, cx.stream));
+	cx.d_cjobs.ensure(std::max<size_t>((size_t)ns * sizeof(StreamJob), 16));
+	if (ns) HIP_OK(hipMemcpyAsync(cx.d_cjobs.p, jobs.data(), (size_t)ns * sizeof(StreamJob), hipMemcpyHostToDevice, cx.stream));
+	cx.ensure_magic(256 + CH + 16);
+	cx.d_acc.ensure((size_t)nw * 8);
+	cx.d_v.ensure((size_t)nw * 8);
+	cx.d_summary.ensure(((size_t)nw / 1024 + 2) * 4);
+	cx.d_bytes.ensure((size_t)nw * 4);
+	cx.d_csizes.ensure(std::max<size_t>((size_t)ns * 8, 16));   // bits | nbytes
+	cx.d_coffs.ensure(((size_t)ns + 1) * 8);
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.h2d_ms = ms_since(t_h2d);
+
+	// ---- device: prediction + residuals + planes
+	ConnView cv = cx.conn_view();
+	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
+	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m.nv * 4, cx.stream));
+	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
+	launch_predict_vtx(cx.stream, cv, cx.d_order_v.as<uint32_t>(), vc, cx.d_rank.as<uint32_t>(), cx.d_rec[1].as<uint8_t>(), ldv, cx.d_vplanes.as<uint8_t>());
+	launch_face_planes(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, cx.d_rec[0].as<uint8_t>(), ldf, cx.d_fplanes.as<uint8_t>());
+	{
+		size_t poff = 0;
+		for (int g = 0; g < G_COUNT; ++g) {
+			uint32_t n = (uint32_t)w.grp_val[g].size();
+			launch_split_bytes(cx.stream, cx.d_grp_val.as<uint32_t>() + goff[g], n, kGroupBytes[g], cx.d_connplanes.as<uint8_t>() + poff);
+			poff += (size_t)n * kGroupBytes[g];
+		}
+	}
+	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
+	// ---- device: one wavefront per stream
+	HIP_OK(hipMemsetAsync(cx.d_acc.p, 0, (size_t)nw * 8, cx.stream));
+	uint32_t *d_bits = cx.d_csizes.as<uint32_t>(), *d_nbytes = d_bits + ns;
+	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
+	launch_chunk_encode(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_acc.as<uint64_t>(), d_bits);
+	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	launch_carry(cx.stream, cx.d_acc.as<uint64_t>(), nw, cx.d_v.as<uint64_t>(), cx.d_summary.as<uint32_t>(), cx.d_bytes.as<uint8_t>());
+	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, nullptr, d_nbytes, cx.d_coffs.as<uint64_t>(), nullptr, false);
+	uint64_t total_bytes = 0;
+	HIP_OK(hipMemcpyAsync(&total_bytes, cx.d_coffs.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.d_cout.ensure(std::max<size_t>(total_bytes, 16));
+	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, cx.d_bytes.as<uint8_t>(), d_nbytes, cx.d_coffs.as<uint64_t>(), cx.d_cout.as<uint8_t>(), true);
+	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
+
+	// ---- container
+	size_t dir = 8 + 4 * planes.size() + 4 * (size_t)ns;
+	size_t base = out.size();
+	out.resize(base + dir + total_bytes);
+	uint8_t *o = out.data() + base;
+	uint32_t np = (uint32_t)planes.size();
+	memcpy(o, &CH, 4); memcpy(o + 4, &np, 4);
+	for (size_t i = 0; i < planes.size(); ++i) memcpy(o + 8 + 4 * i, &planes[i].n, 4);
+	if (ns) HIP_OK(hipMemcpyAsync(o + 8 + 4 * planes.size(), d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
+	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+
+	if (cx.keep_stages) {
+		cx.stage_put_host("order_v", w.order_v.data(), (size_t)vc * 4);
+		cx.stage_put_host("order_f", w.order_f.data(), (size_t)fc * 4);
+		cx.stage_put("vplanes", cx.d_vplanes.p, (size_t)vc * ldv.nplanes);
+		cx.stage_put("fplanes", cx.d_fplanes.p, (size_t)fc * ldf.nplanes);
+	}
+	cx.timing.k_predict_ms = cx.elapsed(1, 2);
+	cx.timing.k_entropy_ms = cx.elapsed(3, 4);
+	cx.timing.device_ms = cx.elapsed(1, 5);
+	cx.timing.n_symbols = nsym_total;
+	cx.timing.payload_bytes = total_bytes;
+	cx.timing.total_ms = ms_since(t_all);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------------------------
+Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
+
+Mesh *decode_any(Context &cx, const uint8_t *p, size_t n)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	std::unique_ptr<Mesh> m(new Mesh());
+	int minor = 0;
+	size_t hdr = read_hry_header(p, n, *m, minor);
+	if (minor == 2) return decode_chunked(cx, p, n, hdr, std::move(m));
+	throw Error(HRY_E_UNSUPPORTED, "decoding the reference's single-stream format (v0.1) is a strictly serial chain (SURVEY.md App. C-4) and is not on the device path; "
+	                               "transcode with the chunked profile");
+}
 
 }   // namespace hry

@@ -45,6 +45,15 @@ struct PlaneJob {
 };
 struct ChunkRef { uint32_t job, first; };
 
+// chunked profile: one independent stream = one chunk of one context plane
+struct StreamJob {
+	const uint8_t *sym;    // symbols of the chunk (encode: input, decode: output)
+	uint32_t n;            // symbols in the chunk
+	uint32_t init;         // index of the 256-entry initial count table
+	uint32_t t0;           // sum of the initial counts
+	uint32_t word_base;    // first 32-bit word of this stream's big-number accumulator / byte image
+};
+
 // one component of an in-place requantisation: mn / scale carry the raw bits of the component's original type
 struct RequantComp { int32_t off, src_type, src_bits, dst_bits; uint64_t mn, scale; };
 struct RequantPlan { int32_t n; int32_t pad; RequantComp c[kMaxComp]; };

@@ -28,6 +28,13 @@ void launch_rchain(hipStream_t st, const SymRec *rec, uint32_t n, uint64_t *r_ou
 void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s, const uint32_t *sym_l, uint32_t n, uint64_t *acc);
 void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes);
 
+// chunked profile (chunked.hip)
+void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits);
+void launch_stream_pack(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *stream_bits, const uint8_t *bytes,
+                        uint32_t *nbytes, uint64_t *offsets, uint8_t *out, bool pack);
+void launch_scatter_u8(hipStream_t st, const uint8_t *src, const uint32_t *dst_index, uint32_t n, uint8_t *dst);
+void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
+                         const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes);
 
 }   // namespace dev
 }   // namespace hry

@@ -1,0 +1,163 @@
+// Decode pipeline of the chunked profile (.hry v0.2):
+//   H2D payload -> k_chunk_decode (one wavefront per stream) -> symbol planes
+//   D2H connectivity planes -> host cut-border replay (cbm_unwalk.cpp) -> connectivity, decode order
+//   H2D connectivity -> k_candidates, k_residuals_to_rec, k_faces_unfold, k_unpredict -> attribute records -> D2H
+// Reference: formats/hry/reader.cc:179-193, cbm/decoder.h:27-211, attrcode.h:533-550.
+#include <chrono>
+#include <cstring>
+
+#include "context.hpp"
+#include "kernels.hpp"
+
+namespace hry {
+
+using namespace dev;
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+namespace dev {
+void launch_candidates(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand);
+void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, const ListDesc &ld, uint8_t *rec);
+void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
+void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
+                      const ListDesc &ld, uint8_t *rec);
+}
+
+enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
+static const int kConnPlanes = 21;
+
+static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0 : i == 12 ? INIT_NT1 : i >= 13 ? INIT_OP : INIT_ONES; }
+
+Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
+{
+	auto t_all = Clock::now();
+	cx.timing = hry_timing{};
+	const ListDesc ldv = make_list_desc(m->lists[1]), ldf = make_list_desc(m->lists[0]);
+	for (int l = 0; l < 2; ++l)
+		for (int c = 0; c < m->lists[l].ncomp(); ++c)
+			if (m->lists[l].stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
+	// ---- directory
+	auto need = [&](size_t off, size_t k) { if (off + k > n) throw Error(HRY_E_FORMAT, "truncated chunked directory"); };
+	size_t off = hdr;
+	need(off, 8);
+	uint32_t CH, np;
+	memcpy(&CH, p + off, 4); memcpy(&np, p + off + 4, 4);
+	off += 8;
+	const uint32_t expect_planes = (uint32_t)(kConnPlanes + ldv.nplanes + ldf.nplanes);
+	if (CH == 0 || np != expect_planes) throw Error(HRY_E_FORMAT, "chunked directory does not match the header");
+	need(off, 4ull * np);
+	std::vector<uint32_t> nsym(np);
+	memcpy(nsym.data(), p + off, 4ull * np);
+	off += 4ull * np;
+	uint64_t nstreams = 0, total_syms = 0;
+	for (uint32_t x : nsym) { nstreams += (x + (uint64_t)CH - 1) / CH; total_syms += x; }
+	need(off, 4 * nstreams);
+	std::vector<uint32_t> nbytes((size_t)nstreams);
+	if (nstreams) memcpy(nbytes.data(), p + off, 4 * (size_t)nstreams);
+	off += 4 * (size_t)nstreams;
+	std::vector<uint64_t> offs((size_t)nstreams + 1, 0);
+	for (size_t i = 0; i < nstreams; ++i) offs[i + 1] = offs[i] + nbytes[i];
+	if (off + offs[nstreams] > n) throw Error(HRY_E_FORMAT, "truncated chunked payload");
+	const uint8_t *payload = p + off;
+	const uint64_t payload_bytes = offs[nstreams];
+	// plausibility of the plane sizes against the header: at most one vertex / face record per element
+	const uint32_t vc = ldv.nplanes ? nsym[kConnPlanes] : 0;
+	for (int q = 0; q < ldv.nplanes; ++q) if (nsym[kConnPlanes + q] != vc) throw Error(HRY_E_FORMAT, "vertex planes of different length");
+	for (int q = 0; q < ldf.nplanes; ++q) if (nsym[kConnPlanes + ldv.nplanes + q] != m->nf) throw Error(HRY_E_FORMAT, "face planes of wrong length");
+	if (vc > m->nv) throw Error(HRY_E_FORMAT, "more coded vertices than vertices");
+	if (total_syms > (1ull << 33)) throw Error(HRY_E_FORMAT, "implausible symbol count");
+
+	// ---- model tables
+	std::vector<uint32_t> tabs((size_t)INIT_KINDS * 256, 0);
+	uint32_t totals[INIT_KINDS];
+	for (int i = 0; i < 256; ++i) tabs[INIT_ONES * 256 + i] = 1;
+	for (int i = 0; i < 9; ++i) tabs[INIT_IOP * 256 + i] = 1;
+	for (size_t d = 3; d < m->have_degree.size(); ++d)
+		if (m->have_degree[d]) { ++tabs[INIT_NT0 * 256 + ((d - 2) & 0xff)]; ++tabs[INIT_NT1 * 256 + ((d - 2) >> 8)]; }
+	for (int i = 0; i < 7; ++i) tabs[INIT_OP * 256 + i] = 1;
+	for (int k = 0; k < INIT_KINDS; ++k) { totals[k] = 0; for (int i = 0; i < 256; ++i) totals[k] += tabs[(size_t)k * 256 + i]; }
+
+	// ---- device: entropy decode of every stream
+	auto t_h2d = Clock::now();
+	cx.d_csyms.ensure(std::max<size_t>(total_syms + 64, 16));
+	cx.d_cout.ensure(std::max<size_t>(payload_bytes + 16, 16));
+	cx.d_cjobs.ensure(std::max<size_t>((size_t)nstreams * sizeof(StreamJob), 16));
+	cx.d_coffs.ensure(((size_t)nstreams + 1) * 8);
+	cx.d_csizes.ensure(std::max<size_t>((size_t)nstreams * 4, 16));
+	cx.d_init.ensure(tabs.size() * 4);
+	std::vector<StreamJob> jobs;
+	jobs.reserve((size_t)nstreams);
+	std::vector<uint64_t> plane_off(np + 1, 0);
+	for (uint32_t k = 0; k < np; ++k) {
+		int kind = k < (uint32_t)kConnPlanes ? conn_init_kind((int)k) : INIT_ONES;
+		for (uint32_t f = 0; f < nsym[k]; f += CH)
+			jobs.push_back(StreamJob{ cx.d_csyms.as<uint8_t>() + plane_off[k] + f, std::min(CH, nsym[k] - f), (uint32_t)kind, totals[kind], 0 });
+		plane_off[k + 1] = plane_off[k] + nsym[k];
+	}
+	HIP_OK(hipMemcpyAsync(cx.d_init.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice, cx.stream));
+	if (payload_bytes) HIP_OK(hipMemcpyAsync(cx.d_cout.p, payload, payload_bytes, hipMemcpyHostToDevice, cx.stream));
+	if (nstreams) {
+		HIP_OK(hipMemcpyAsync(cx.d_cjobs.p, jobs.data(), jobs.size() * sizeof(StreamJob), hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(cx.d_csizes.p, nbytes.data(), nbytes.size() * 4, hipMemcpyHostToDevice, cx.stream));
+	}
+	HIP_OK(hipMemcpyAsync(cx.d_coffs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, cx.stream));
+	cx.ensure_magic(256 + CH + 16);
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.h2d_ms = ms_since(t_h2d);
+	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
+	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), (uint32_t)nstreams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
+	                    cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>(), cx.d_csizes.as<uint32_t>());
+	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
+
+	// ---- connectivity planes to the host, replay the cut-border machine
+	std::vector<uint8_t> conn[kConnPlanes];
+	for (int k = 0; k < kConnPlanes; ++k) {
+		conn[k].resize(nsym[k]);
+		if (nsym[k]) HIP_OK(hipMemcpyAsync(conn[k].data(), cx.d_csyms.as<uint8_t>() + plane_off[k], nsym[k], hipMemcpyDeviceToHost, cx.stream));
+	}
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	auto t_walk = Clock::now();
+	std::vector<uint32_t> order_v;
+	cut_border_replay(*m, conn, order_v);
+	cx.timing.host_walk_ms = ms_since(t_walk);
+	if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
+	const uint32_t nvc = (uint32_t)order_v.size();
+
+	// ---- device: attribute reconstruction
+	cx.upload_mesh(*m);   // connectivity + (zeroed) records
+	ConnView cv = cx.conn_view();
+	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
+	if (nvc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
+	cx.d_cscratch.ensure(std::max<size_t>((size_t)nvc * (8 * 3 * 4 + 1) + 64, 16));
+	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
+	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nvc * 24);
+	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
+	if (ldv.nplanes) {
+		launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand);
+		launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], nvc, ldv, cx.d_rec[1].as<uint8_t>());
+		launch_unpredict(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv, cx.d_rec[1].as<uint8_t>());
+	}
+	if (ldf.nplanes) {
+		launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], m->nf, ldf, cx.d_rec[0].as<uint8_t>());
+		launch_faces_unfold(cx.stream, m->nf, ldf, cx.d_rec[0].as<uint8_t>());
+	}
+	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	for (int l = 0; l < 2; ++l)
+		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	if (cx.keep_stages) {
+		cx.stage_put("dec_syms", cx.d_csyms.p, total_syms);
+		cx.stage_put_host("dec_nsym", nsym.data(), nsym.size() * 4);
+		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
+	}
+	cx.timing.k_entropy_ms = cx.elapsed(1, 2);
+	cx.timing.k_predict_ms = cx.elapsed(3, 4);
+	cx.timing.device_ms = cx.timing.k_entropy_ms + cx.timing.k_predict_ms;
+	cx.timing.n_symbols = total_syms;
+	cx.timing.payload_bytes = payload_bytes;
+	cx.timing.total_ms = ms_since(t_all);
+	m->device_token = 0;   // the resident copy belongs to this context only until the next upload
+	return m.release();
+}
+
+}   // namespace hry

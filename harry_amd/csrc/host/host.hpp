@@ -45,6 +45,9 @@ struct WalkResult {
 // ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
 void cut_border_walk(Mesh &m, WalkResult &out);
 
+// ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
+void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v);
+
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);
 // parses the header into a mesh skeleton (lists allocated, no connectivity); returns bytes consumed

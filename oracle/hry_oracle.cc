@@ -494,10 +494,12 @@ struct Models {
 // ------------------------------------------------------------------------------------------------
 // symbol layer (formats/hry/io.h:19-231)
 // ------------------------------------------------------------------------------------------------
+enum { REC_OP0 = 200, REC_SLOTS = 208 };   // recording slots: context id, or REC_OP0 + order class for operations
 struct SymWriter {
 	Models &md;
 	RangeEncoder &rc;
 	std::vector<ho_sym> *trace;
+	std::vector<std::vector<uint8_t>> *record = nullptr;   // chunked profile: collect symbols per context instead of coding
 	SymWriter(Models &m, RangeEncoder &r, std::vector<ho_sym> *t) : md(m), rc(r), trace(t) {}
 	void code(int ctx, uint32_t s)
 	{
@@ -507,10 +509,18 @@ struct SymWriter {
 		if (trace) trace->push_back(ho_sym{ (uint32_t)ctx, s, l, h, t });
 		rc.encode(l, h, t);
 	}
-	void sym(int ctx, uint32_t s) { code(ctx, s); md.tab[ctx].inc(s); }      // model.h:57-66
+	void sym(int ctx, uint32_t s)      // model.h:57-66
+	{
+		if (record) { (*record)[ctx].push_back((uint8_t)s); return; }
+		code(ctx, s); md.tab[ctx].inc(s);
+	}
 	void bytes(int ctx, const uint8_t *p, int n) { for (int i = 0; i < n; ++i) sym(ctx + i, p[i]); }
 	void iop(uint32_t s) { sym(CTX_IOP, s); }
-	void op(uint32_t s) { md.op_prepare(); code(CTX_OP, s); md.op_update(s); }   // models.h:74-80
+	void op(uint32_t s)   // models.h:74-80
+	{
+		if (record) { (*record)[REC_OP0 + md.order_class()].push_back((uint8_t)s); return; }
+		md.op_prepare(); code(CTX_OP, s); md.op_update(s);
+	}
 	void elem(int i)   // io.h:150-153 + transform.h:25-30 zigzag
 	{
 		uint32_t c = (uint32_t)i, z = (c << 1) ^ ((c >> 31) ? 0xffffffffu : 0u);
@@ -526,7 +536,17 @@ struct SymWriter {
 struct SymReader {
 	Models &md;
 	RangeDecoder &rc;
+	// chunked profile: symbols were entropy-decoded per context beforehand and are consumed from these planes
+	std::vector<std::vector<uint8_t>> *planes = nullptr;
+	std::vector<size_t> cursor;
+	int fixed_numtri = -1;   // >= 0: numtri is not transmitted (single polygon degree)
 	SymReader(Models &m, RangeDecoder &r) : md(m), rc(r) {}
+	uint32_t pop(int slot)
+	{
+		if (cursor.size() < planes->size()) cursor.resize(planes->size(), 0);
+		if (cursor[slot] >= (*planes)[slot].size()) throw std::runtime_error("oracle: chunked stream exhausted");
+		return (*planes)[slot][cursor[slot]++];
+	}
 	uint32_t code(int ctx)   // coder.h:154-162
 	{
 		FreqTable &f = md.tab[ctx];
@@ -535,17 +555,25 @@ struct SymReader {
 		rc.consume(l, h, t);
 		return s;
 	}
-	uint32_t sym(int ctx) { uint32_t s = code(ctx); md.tab[ctx].inc(s); return s; }
+	uint32_t sym(int ctx)
+	{
+		if (planes) return pop(ctx);
+		uint32_t s = code(ctx); md.tab[ctx].inc(s); return s;
+	}
 	void bytes(int ctx, uint8_t *p, int n) { for (int i = 0; i < n; ++i) p[i] = (uint8_t)sym(ctx + i); }
 	uint32_t iop() { return sym(CTX_IOP); }
-	uint32_t op() { md.op_prepare(); uint32_t s = code(CTX_OP); md.op_update(s); return s; }
+	uint32_t op()
+	{
+		if (planes) return pop(REC_OP0 + md.order_class());
+		md.op_prepare(); uint32_t s = code(CTX_OP); md.op_update(s); return s;
+	}
 	int elem() { uint32_t z; bytes(CTX_ELEM, (uint8_t*)&z, 4); return (int)((z >> 1) ^ ((z & 1) ? 0xffffffffu : 0u)); }
 	uint16_t part() { uint16_t v; bytes(CTX_PART, (uint8_t*)&v, 2); return v; }
 	uint32_t vertid() { uint32_t v; bytes(CTX_VERT, (uint8_t*)&v, 4); return v; }
-	uint16_t numtri() { uint16_t v; bytes(CTX_NUMTRI, (uint8_t*)&v, 2); return v; }
-	uint16_t reg_face() { uint16_t v; bytes(CTX_REGFACE, (uint8_t*)&v, 2); return v; }
-	uint16_t reg_vtx() { uint16_t v; bytes(CTX_REGVTX, (uint8_t*)&v, 2); return v; }
-	uint8_t attr_type(int l) { return (uint8_t)sym(md.attr_base[l] + ATTR_TYPE); }
+	uint16_t numtri() { if (fixed_numtri >= 0) return (uint16_t)fixed_numtri; uint16_t v; bytes(CTX_NUMTRI, (uint8_t*)&v, 2); return v; }
+	uint16_t reg_face() { if (planes) return 0; uint16_t v; bytes(CTX_REGFACE, (uint8_t*)&v, 2); return v; }
+	uint16_t reg_vtx() { if (planes) return 0; uint16_t v; bytes(CTX_REGVTX, (uint8_t*)&v, 2); return v; }
+	uint8_t attr_type(int l) { if (planes) return A_DATA; return (uint8_t)sym(md.attr_base[l] + ATTR_TYPE); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -806,10 +834,10 @@ struct ByteWriter {
 	template <typename T> void put(T v) { const uint8_t *p = (const uint8_t*)&v; o.insert(o.end(), p, p + sizeof(T)); }
 	void raw(const void *p, size_t n) { o.insert(o.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
 };
-static void write_header(const Mesh &m, std::vector<uint8_t> &out)
+static void write_header(const Mesh &m, std::vector<uint8_t> &out, int ver_minor = 1)
 {
 	ByteWriter w{ out };
-	const uint8_t magic[6] = { 0xfa, 0xff, 0xaf, 0xaf, 0, 1 };   // big-endian magic, version 0.1 (common.h:15-16)
+	const uint8_t magic[6] = { 0xfa, 0xff, 0xaf, 0xaf, 0, (uint8_t)ver_minor };   // big-endian magic, version 0.1 (common.h:15-16)
 	w.raw(magic, 6);
 	w.put<uint32_t>(m.nv); w.put<uint32_t>(m.nf); w.put<uint32_t>(m.num_edge());
 	w.put<uint16_t>(1); w.put<uint16_t>(1);                 // one face region, one vertex region
@@ -845,12 +873,12 @@ struct ByteReader {
 	void need(size_t n) { if ((size_t)(end - p) < n) throw std::runtime_error("oracle: truncated header"); }
 };
 static int dequant_bytes(const Fmt &f) { return f.bytes(); }
-static void read_header(ByteReader &r, Mesh &m)
+static void read_header(ByteReader &r, Mesh &m, int want_minor = 1)
 {
 	uint8_t magic[6];
 	r.raw(magic, 6);
 	if (magic[0] != 0xfa || magic[1] != 0xff || magic[2] != 0xaf || magic[3] != 0xaf) throw std::runtime_error("Invalid magic number");
-	if (magic[4] != 0 || magic[5] != 1) throw std::runtime_error("File format version incompatible to decoder format version 0.1");
+	if (magic[4] != 0 || magic[5] != want_minor) throw std::runtime_error("File format version incompatible to decoder format version 0.1");
 	m.nv = r.get<uint32_t>(); m.nf = r.get<uint32_t>(); (void)r.get<uint32_t>();
 	uint16_t nrf = r.get<uint16_t>(), nrv = r.get<uint16_t>();
 	std::vector<int> targets;
@@ -1295,6 +1323,150 @@ static Mesh *decode(const uint8_t *p, size_t n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// chunked profile (.hry v0.2, this implementation's parallel container; NOT a reference format).
+// Same header (minor version 2), same symbols as the v0.1 stream, but every context plane is cut into chunks of
+// `chunk_syms` symbols and every (plane, chunk) is an independent stream: fresh adaptive model + fresh 64-bit
+// coder + 64-bit flush, using exactly the reference's model/coder arithmetic.  Symbols without information are
+// not stored: reg_face/reg_vtx (single region), attr_type (always DATA), numtri for single-degree meshes.
+// Operations are split into one plane per order class (models.h:101-105) with a plain adaptive 7-symbol model.
+//   u32 chunk_syms, u32 n_planes, n_planes x u32 n_symbols, per stream u32 n_bytes, then the streams.
+// Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
+// ------------------------------------------------------------------------------------------------
+struct PlaneDef { int slot; int init_kind; };   // init_kind: 0 = 256 ones, 1 = iop (9 ones), 2/3 = numtri byte 0/1, 4 = op (7 ones)
+
+static std::vector<PlaneDef> chunked_planes(const Mesh &m, const Models &md)
+{
+	std::vector<PlaneDef> p;
+	p.push_back({ CTX_IOP, 1 });
+	for (int i = 0; i < 4; ++i) p.push_back({ CTX_ELEM + i, 0 });
+	for (int i = 0; i < 2; ++i) p.push_back({ CTX_PART + i, 0 });
+	for (int i = 0; i < 4; ++i) p.push_back({ CTX_VERT + i, 0 });
+	p.push_back({ CTX_NUMTRI, 2 }); p.push_back({ CTX_NUMTRI + 1, 3 });
+	for (int i = 0; i < 8; ++i) p.push_back({ REC_OP0 + i, 4 });
+	for (int l : { 1, 0 }) {
+		int n = 0;
+		for (int c = 0; c < m.lists[l].fmt.size(); ++c) n += TSIZE[m.lists[l].fmt.stype[c]];
+		for (int b = 0; b < n; ++b) p.push_back({ md.attr_base[l] + ATTR_DATA + b, 0 });
+	}
+	return p;
+}
+static void seed_table(FreqTable &f, int kind, const Mesh &m)
+{
+	switch (kind) {
+	case 0: for (uint32_t j = 0; j < 256; ++j) f.inc(j); break;
+	case 1: for (uint32_t j = 0; j <= IOP_EOM; ++j) f.inc(j); break;
+	case 2: for (size_t d = 0; d < m.have_deg.size(); ++d) if (m.have_deg[d]) f.inc((uint32_t)((d - 2) & 0xff)); break;
+	case 3: for (size_t d = 0; d < m.have_deg.size(); ++d) if (m.have_deg[d]) f.inc((uint32_t)((d - 2) >> 8)); break;
+	case 4: for (uint32_t j = 0; j <= OP_CONNFWD; ++j) f.inc(j); break;
+	}
+}
+static int count_degrees(const Mesh &m) { int n = 0; for (char c : m.have_deg) n += c ? 1 : 0; return n; }
+
+static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
+{
+	check_supported(m);
+	if (chunk_syms == 0) chunk_syms = 32768;
+	Result *res = new Result();
+	try {
+		write_header(m, res->bytes, 2);
+		res->header_size = res->bytes.size();
+		std::vector<uint8_t> dummy;
+		RangeEncoder rc(dummy);
+		Models md(m);
+		SymWriter wr(md, rc, nullptr);
+		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
+		wr.record = &rec;
+		cbm_encode(m, wr, res->order_v, res->order_f);
+		encode_attrs(m, wr, res->order_v, res->order_f);
+		if (count_degrees(m) <= 1) { rec[CTX_NUMTRI].clear(); rec[CTX_NUMTRI + 1].clear(); }
+		std::vector<PlaneDef> planes = chunked_planes(m, md);
+		ByteWriter w{ res->bytes };
+		w.put<uint32_t>(chunk_syms);
+		w.put<uint32_t>((uint32_t)planes.size());
+		for (const PlaneDef &pd : planes) w.put<uint32_t>((uint32_t)rec[pd.slot].size());
+		std::vector<std::vector<uint8_t>> streams;
+		for (const PlaneDef &pd : planes) {
+			const std::vector<uint8_t> &sy = rec[pd.slot];
+			for (size_t first = 0; first < sy.size(); first += chunk_syms) {
+				size_t end = std::min(sy.size(), first + chunk_syms);
+				std::vector<uint8_t> out;
+				RangeEncoder enc(out);
+				FreqTable f(256);
+				seed_table(f, pd.init_kind, m);
+				for (size_t j = first; j < end; ++j) {
+					uint64_t l, h, t = f.total();
+					f.range_of(sy[j], l, h);
+					enc.encode(l, h, t);
+					f.inc(sy[j]);
+				}
+				enc.finish();
+				streams.push_back(std::move(out));
+			}
+		}
+		for (auto &st : streams) w.put<uint32_t>((uint32_t)st.size());
+		for (auto &st : streams) w.raw(st.data(), st.size());
+	} catch (...) { delete res; throw; }
+	return res;
+}
+
+static Mesh *decode_chunked(const uint8_t *p, size_t n)
+{
+	Mesh *m = new Mesh();
+	try {
+		ByteReader br{ p, p + n };
+		read_header(br, *m, 2);
+		Models md(*m);
+		uint32_t chunk_syms = br.get<uint32_t>(), np = br.get<uint32_t>();
+		std::vector<PlaneDef> planes = chunked_planes(*m, md);
+		if (np != planes.size() || chunk_syms == 0) throw std::runtime_error("oracle: bad chunked directory");
+		std::vector<uint32_t> nsym(np);
+		for (auto &x : nsym) x = br.get<uint32_t>();
+		size_t nstreams = 0;
+		for (uint32_t x : nsym) nstreams += (x + chunk_syms - 1) / chunk_syms;
+		std::vector<uint32_t> nbytes(nstreams);
+		for (auto &x : nbytes) x = br.get<uint32_t>();
+		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
+		size_t si = 0;
+		const uint8_t *q = br.p;
+		for (size_t k = 0; k < planes.size(); ++k) {
+			std::vector<uint8_t> &sy = rec[planes[k].slot];
+			sy.resize(nsym[k]);
+			for (size_t first = 0; first < sy.size(); first += chunk_syms, ++si) {
+				size_t end = std::min(sy.size(), first + chunk_syms);
+				if ((size_t)(p + n - q) < nbytes[si]) throw std::runtime_error("oracle: truncated chunked stream");
+				RangeDecoder dec(q, q + nbytes[si]);
+				FreqTable f(256);
+				seed_table(f, planes[k].init_kind, *m);
+				for (size_t j = first; j < end; ++j) {
+					uint64_t l, h, t = f.total();
+					uint32_t s = f.find(dec.target(t), l, h);
+					dec.consume(l, h, t);
+					f.inc(s);
+					sy[j] = (uint8_t)s;
+				}
+				q += nbytes[si];
+			}
+		}
+		std::vector<uint8_t> none;
+		RangeDecoder rc(none.data(), none.data());
+		SymReader rd(md, rc);
+		rd.planes = &rec;
+		if (count_degrees(*m) <= 1) {
+			int d = 0;
+			for (size_t i = 0; i < m->have_deg.size(); ++i) if (m->have_deg[i]) d = (int)i;
+			rd.fixed_numtri = d - 2;
+		}
+		std::vector<uint32_t> order_v;
+		std::vector<char> hdr_deg = m->have_deg;
+		cbm_decode(*m, rd, order_v);
+		m->have_deg = hdr_deg;
+		if (m->num_face() != m->nf) throw std::runtime_error("oracle: face count mismatch");
+		decode_attrs(*m, rd, order_v);
+	} catch (...) { delete m; throw; }
+	return m;
+}
+
+// ------------------------------------------------------------------------------------------------
 // bounds + requantisation (structs/quant.h:30-242)
 // ------------------------------------------------------------------------------------------------
 static void set_bounds(List &L)   // quant.h:30-38; max starts at numeric_limits<T>::min() (FLT_MIN for floats, App. B-2)
@@ -1727,6 +1899,24 @@ ho_result *ho_encode(ho_mesh *m, int trace)
 	ho::Result *r = ho::encode(m->m, trace != 0);
 	ho_result *h = new ho_result{ std::move(*r) };
 	delete r;
+	return h;
+	HO_CATCH(nullptr)
+}
+ho_result *ho_encode_chunked(ho_mesh *m, uint32_t chunk_syms)
+{
+	HO_TRY
+	ho::Result *r = ho::encode_chunked(m->m, chunk_syms);
+	ho_result *h = new ho_result{ std::move(*r) };
+	delete r;
+	return h;
+	HO_CATCH(nullptr)
+}
+ho_mesh *ho_mesh_from_hry_chunked(const uint8_t *hry, size_t n)
+{
+	HO_TRY
+	ho::Mesh *m = ho::decode_chunked(hry, n);
+	ho_mesh *h = new ho_mesh{ std::move(*m) };
+	delete m;
 	return h;
 	HO_CATCH(nullptr)
 }

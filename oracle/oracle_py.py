@@ -45,6 +45,8 @@ def lib():
     L.ho_requant.restype = C.c_int; L.ho_requant.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int]
     L.ho_encode.restype = vp; L.ho_encode.argtypes = [vp, C.c_int]
     L.ho_result_free.argtypes = [vp]
+    L.ho_encode_chunked.restype = vp; L.ho_encode_chunked.argtypes = [vp, C.c_uint32]
+    L.ho_mesh_from_hry_chunked.restype = vp; L.ho_mesh_from_hry_chunked.argtypes = [C.c_char_p, sz]
     L.ho_result_size.restype = sz; L.ho_result_size.argtypes = [vp]
     L.ho_result_data.restype = u8p; L.ho_result_data.argtypes = [vp]
     L.ho_result_header_size.restype = sz; L.ho_result_header_size.argtypes = [vp]
@@ -115,6 +117,16 @@ class Mesh:
     @classmethod
     def from_hry(cls, data: bytes) -> "Mesh":
         return cls(lib().ho_mesh_from_hry(data, len(data)))
+
+    @classmethod
+    def from_hry_chunked(cls, data: bytes) -> "Mesh":
+        return cls(lib().ho_mesh_from_hry_chunked(data, len(data)))
+
+    def encode_chunked(self, chunk_syms: int = 0) -> "Result":
+        r = lib().ho_encode_chunked(self.h, chunk_syms)
+        if not r:
+            raise _err()
+        return Result(r)
 
     def clone(self) -> "Mesh":
         return Mesh(lib().ho_mesh_clone(self.h))

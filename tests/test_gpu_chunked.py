@@ -1,0 +1,135 @@
+"""GPU parity tests of the chunked profile (.hry v0.2) through the C ABI.
+
+Parity definition: the chunked container produced by the HIP path is byte-identical to the oracle's
+CPU restatement of the same container; it decodes -- on the GPU and on the CPU oracle -- to exactly the mesh the
+REFERENCE decodes from its own v0.1 stream of the same input (committed tests/golden/*.dec.ply)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from harry_amd import codec as hc
+from harry_amd import meshgen as mg
+from oracle import oracle_py as op
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(util.ROOT, "tests", "golden")
+with open(os.path.join(GOLD, "manifest.json")) as _f:
+    MANIFEST = json.load(_f)
+SMALL = [(n, t, v) for n, e in sorted(MANIFEST["small"].items()) for t, v in sorted(e["variants"].items())]
+
+
+@pytest.fixture(scope="module")
+def cx():
+    c = hc.Codec(0)
+    yield c
+    c.close()
+
+
+def same_mesh(a, b):
+    assert (a.nv, a.nf, a.ne) == (b.nv, b.nf, b.ne)
+    assert np.array_equal(a.face_offsets(), b.face_offsets())
+    assert np.array_equal(a.org(), b.org())
+    for l in range(2):
+        assert a.list_fmt(l) == b.list_fmt(l)
+        assert np.array_equal(a.list_data(l), b.list_data(l)), f"list {l} differs"
+
+
+@pytest.mark.parametrize("name,tag,v", SMALL, ids=[f"{n}.{t}" for n, t, _ in SMALL])
+def test_chunked_roundtrip_equals_reference_decode(cx, name, tag, v):
+    ply = open(os.path.join(GOLD, name + ".ply"), "rb").read()
+    dec_ref = open(os.path.join(GOLD, f"{name}.{tag}.dec.ply"), "rb").read()
+    m = hc.Mesh.from_ply(ply)
+    o = op.Mesh.from_ply(ply)
+    quant, clear = util.flags_to_quant(v["flags"])
+    if quant or clear:
+        cx.requant(m, quant, clear)
+        o.requant(quant, clear)
+    for chunk in (0, 257):
+        got = cx.write_hry(m.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=chunk)
+        want = o.clone().encode_chunked(chunk).data
+        assert got == want, "chunked container differs from the oracle's"
+        dec = cx.read_hry(got)
+        vrec, degs, idx, frec = util.parse_ref_decoded_ply(dec_ref, dec.list_stride(1), dec.list_stride(0))
+        assert np.array_equal(np.diff(dec.face_offsets()).astype(np.uint8), degs)
+        assert np.array_equal(dec.org(), idx)
+        assert np.array_equal(dec.list_data(1), vrec)
+        assert np.array_equal(dec.list_data(0), frec)
+
+
+@pytest.mark.parametrize("case", ["torus150_q14", "ico5", "multi40", "nm_big", "grid_quads", "colors_normals"])
+def test_chunked_larger_meshes(cx, case):
+    mesh, quant = {
+        "torus150_q14": (lambda: mg.torus(150, 150, seed=2), [(1, -1, 14)]),
+        "ico5": (lambda: mg.icosphere(5), []),
+        "multi40": (lambda: mg.multi_component(40, 20, 22), []),
+        "nm_big": (lambda: mg.with_nonmanifold(mg.torus(60, 64, polys="mixed"), 30, 12), []),
+        "grid_quads": (lambda: mg.grid(120, 90, quads=True), [(1, -1, 12)]),
+        "colors_normals": (lambda: mg.with_face_props(mg.with_colors(mg.torus(90, 80, normals=True))), [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)]),
+    }[case]
+    ply = mesh().to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    if quant:
+        cx.requant(a, quant)
+        o.requant(quant)
+    compat = o.clone().encode().data
+    ref_dec = op.Mesh.from_hry(compat)
+    for chunk in (0, 4096):
+        got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=chunk)
+        assert got == o.clone().encode_chunked(chunk).data
+        same_mesh(cx.read_hry(got), ref_dec)                  # GPU decode == decode of the reference-format stream
+        same_mesh(op.Mesh.from_hry_chunked(got), ref_dec)     # independent CPU decode of the GPU's container
+
+
+def test_chunked_entropy_decode_planes(cx):
+    """k_chunk_decode inverts k_chunk_encode symbol for symbol (checked before any mesh logic)."""
+    m = mg.torus(64, 60, polys="mixed", normals=True)
+    a = hc.Mesh.from_ply(m.to_ply())
+    got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED, chunk_syms=1000, keep_stages=True)
+    vplanes = cx.stage("vplanes")
+    fplanes = cx.stage("fplanes")
+    cx.read_hry(got, keep_stages=True)
+    syms = cx.stage("dec_syms")
+    nsym = cx.stage("dec_nsym", np.uint32)
+    tail = syms[int(nsym[:21].sum()):]
+    assert np.array_equal(tail[:len(vplanes)], vplanes)
+    assert np.array_equal(tail[len(vplanes):len(vplanes) + len(fplanes)], fplanes)
+
+
+def test_high_valence_vertex_uses_fan_walk(cx):
+    """A cone apex with 40 incident triangles exceeds the candidate table of the reconstruction kernel."""
+    n = 40
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    ring1 = np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], 1)
+    ring2 = np.stack([2 * np.cos(ang + 0.05), 2 * np.sin(ang + 0.05), -np.ones(n)], 1)
+    pts = np.concatenate([[[0, 0, 1]], ring1, ring2]).astype(np.float32)
+    tris = []
+    for i in range(n):
+        j = (i + 1) % n
+        tris += [[0, 1 + i, 1 + j], [1 + i, 1 + n + i, 1 + n + j], [1 + i, 1 + n + j, 1 + j]]
+    verts = np.empty(len(pts), dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+    verts["x"], verts["y"], verts["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    mesh = mg.Mesh(verts, np.full(len(tris), 3, np.uint8), np.array(tris, np.uint32).reshape(-1))
+    # start the traversal away from the apex so that the apex is coded late, with many coded neighbours
+    mesh = mg.Mesh(verts, mesh.degrees, np.roll(np.array(tris, np.uint32), -n, axis=0).reshape(-1))
+    ply = mesh.to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
+    got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+    same_mesh(cx.read_hry(got), ref_dec)
+
+
+def test_decode_rejects_corrupt_input(cx):
+    a = hc.Mesh.from_ply(mg.torus(12, 12).to_ply())
+    good = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+    with pytest.raises(hc.HryError):
+        cx.read_hry(b"\x00" * 40)
+    with pytest.raises(hc.HryError):
+        cx.read_hry(good[:len(good) // 2])
+    bad = bytearray(good)
+    bad[5] = 7   # unknown minor version
+    with pytest.raises(hc.HryError):
+        cx.read_hry(bytes(bad))
