@@ -16,7 +16,7 @@ typedef std::chrono::steady_clock Clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 
 namespace dev {
-void launch_candidates(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand);
+void launch_candidates(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand, const ListDesc &ld);
 void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, const ListDesc &ld, uint8_t *rec);
 void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
 void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
@@ -133,7 +133,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nvc * 24);
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	if (ldv.nplanes) {
-		launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand);
+		launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
 		launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], nvc, ldv, cx.d_rec[1].as<uint8_t>());
 		launch_unpredict(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv, cx.d_rec[1].as<uint8_t>());
 	}

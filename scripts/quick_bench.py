@@ -1,6 +1,6 @@
 """Ad-hoc timing of the compat encode on one GPU (development aid; bench.py is the contract)."""
 import sys, time, json
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from harry_amd import codec as hc, meshgen as mg
 
