@@ -113,9 +113,12 @@ def main():
         out = cx.write_hry(m, profile=pid)
         t1 = time.perf_counter()
         tm_e = cx.timing()
+        tm_d = {}
         if can_decode:
             cx.read_hry(out)
+            tm_d = cx.timing()
         t2 = time.perf_counter()
+        tm_e.update({"dec_" + k: v for k, v in tm_d.items()})
         return out, t1 - t0, t2 - t1, tm_e
 
     def barrier():
@@ -138,23 +141,26 @@ def main():
     total = torch.tensor([enc_s + dec_s, enc_s, dec_s], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.MAX)
-        # final stream concatenation: gather the per-component streams on rank 0 (RCCL over xGMI)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([len(out)], dtype=torch.int64, device=dev))
-        cap = int(max(int(s.item()) for s in sizes))
-        buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        buf[:len(out)] = torch.frombuffer(bytearray(out), dtype=torch.uint8).to(dev)
-        gathered = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, gathered, dst=0)
+        # final stream concatenation: gather the per-component streams on rank 0 (RCCL over xGMI); not a data-path collective
+        from harry_amd import sharding
+        gathered = sharding.gather_streams({rank: out}, world, dev)
+        if rank == 0:
+            blob = sharding.concat_container(gathered)
+            assert len(sharding.split_container(blob)) == world
     t_all, t_enc, t_dec = (float(x) for x in total.tolist())
 
     if rank == 0:
         ntri = mesh.ntri
         step_ms = t_all / args.steps * 1e3
         value = world * ntri * args.steps / t_all / 1e6
-        med = lambda k: float(np.median([t[k] for t in timings]))
-        dom_ms, dom_name = (med("k_entropy_ms"), "k_chunk_encode") if profile == "chunked" and med("k_entropy_ms") > 0 else (med("k_rchain_ms"), "k_rchain")
-        # algorithmic bytes of the encode path per triangle: vertex records + 4 B per half-edge + stream
+        med = lambda k: float(np.median([t.get(k, 0.0) for t in timings]))
+        # the dominant kernel of a step (HIP-event times taken inside the library on the codec stream)
+        cands = {"k_rchain": med("k_rchain_ms"), "k_chunk_encode": med("k_entropy_ms") if profile == "chunked" else 0.0,
+                 "k_predict_vtx": med("k_predict_ms"), "k_chunk_decode": med("dec_k_entropy_ms"), "k_unpredict": med("dec_k_predict_ms")}
+        dom_name = max(cands, key=cands.get)
+        dom_ms = cands[dom_name]
+        # algorithmic bytes per launch: every input array once + the stream once =
+        # vertex records + 4 B per half-edge + |hry|  (same bytes in the opposite direction for decode)
         alg_bytes = base.nv * base.list_stride(1) + 4 * base.ne + len(out)
         roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / (dom_ms * 1e-3) / 1e9, 3) if dom_ms > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
@@ -169,7 +175,9 @@ def main():
             "encode_mtri_s": round(world * ntri * args.steps / t_enc / 1e6, 4),
             "decode_mtri_s": round(world * ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
             "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / base.nv, 4),
-            "stage_ms": {k: round(med(k), 4) for k in ("host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms")},
+            "stage_ms": {k: round(med(k), 4) for k in ("host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms",
+                                                        "dec_host_walk_ms", "dec_k_entropy_ms", "dec_k_predict_ms", "dec_total_ms")},
+            "kernel_ms": {k: round(v, 4) for k, v in cands.items()},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -61,7 +61,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	auto t_all = Clock::now();
 	cx.timing = hry_timing{};
 	check_codable(m);
-	const uint32_t CH = chunk_syms > 0 ? (uint32_t)chunk_syms : (uint32_t)kDefaultChunk;
+	uint32_t CH = chunk_syms > 0 ? (uint32_t)chunk_syms : (uint32_t)kDefaultChunk;
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds) { m.lists[l].bmin.assign(m.lists[l].stride(), 0); m.lists[l].bmax.assign(m.lists[l].stride(), 0); m.lists[l].have_bounds = true; }
 	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
@@ -75,6 +75,12 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	const ListDesc ldv = make_list_desc(m.lists[1]), ldf = make_list_desc(m.lists[0]);
+	if (chunk_syms <= 0) {
+		// default policy: 32 Ki symbols per chunk (about +5 % size on a 1 M-triangle mesh); larger meshes get larger chunks
+		// as long as some thousands of streams remain to fill the 1024 SIMDs
+		uint64_t total = (uint64_t)w.n_conn + (uint64_t)vc * ldv.nplanes + (uint64_t)fc * ldf.nplanes;
+		while (CH < (1u << 18) && total / CH > 8192) CH <<= 1;
+	}
 
 	// ---- connectivity planes on the host side: 5 groups (split into bytes on the device) + 8 operation planes
 	auto t_h2d = Clock::now();

@@ -149,6 +149,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		cx.stage_put("dec_syms", cx.d_csyms.p, total_syms);
 		cx.stage_put_host("dec_nsym", nsym.data(), nsym.size() * 4);
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
+		cx.stage_put("ncand", d_ncand, nvc);
 	}
 	cx.timing.k_entropy_ms = cx.elapsed(1, 2);
 	cx.timing.k_predict_ms = cx.elapsed(3, 4);
