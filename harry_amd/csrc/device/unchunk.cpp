@@ -21,6 +21,9 @@ void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, 
 void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
 void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                       const ListDesc &ld, uint8_t *rec);
+bool unpredict2_applicable(const ListDesc &ld);
+void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec);
 }
 
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
@@ -133,9 +136,14 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nvc * 24);
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	if (ldv.nplanes) {
-		launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
-		launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], nvc, ldv, cx.d_rec[1].as<uint8_t>());
-		launch_unpredict(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv, cx.d_rec[1].as<uint8_t>());
+		if (unpredict2_applicable(ldv)) {
+			// one wavefront per component, residual codes straight from the decoded byte planes
+			launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], ldv, cx.d_rec[1].as<uint8_t>());
+		} else {
+			launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
+			launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], nvc, ldv, cx.d_rec[1].as<uint8_t>());
+			launch_unpredict(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv, cx.d_rec[1].as<uint8_t>());
+		}
 	}
 	if (ldf.nplanes) {
 		launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], m->nf, ldf, cx.d_rec[0].as<uint8_t>());

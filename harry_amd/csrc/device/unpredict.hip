@@ -376,6 +376,265 @@ __global__ __launch_bounds__(64) void k_unpredict(ConnView cv, const uint32_t *o
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_unpredict2: the reconstruction chain, second structure.  Components are independent chains that share only the
+// candidate lists, so every component gets its own wavefront (one block per component, own LDS ring).  Inside a
+// wavefront a batch of 64 vertices is handled in two phases:
+//   prepare (lane i <-> vertex base+i, all lanes in parallel): gather every prediction source that lies BEFORE the
+//           batch (LDS ring, or HBM when older than the ring) and pre-evaluate every parallelogram whose three
+//           sources are ready; the residual code is read straight from the byte planes
+//   chain   (uniform loop over the batch): only sources inside the batch (typically the predecessor vertex) are still
+//           missing; they come out of a register vector with v_readlane.  No LDS or vector-memory access sits on the
+//           dependency chain, the arithmetic of integer components runs on the scalar unit.
+// Exactly the arithmetic of attrcode.h:182-208 / prediction.h:46-78,121-147 per vertex, in coding order.
+// ---------------------------------------------------------------------------------------------------------
+
+// ---- branch-free scalar forms for the chain (uniform values: every taken branch costs an instruction-fetch bubble
+// of a single wavefront, so the common cases are written with selects).  Same results as codec_math.hpp.
+__device__ __forceinline__ uint32_t usel(bool c, uint32_t a, uint32_t b) { return b ^ ((a ^ b) & (0u - (uint32_t)c)); }
+
+// parallelogram of unsigned values of at most 16 bits, computed in 32-bit: prediction.h:121-138
+template <typename T> __device__ __forceinline__ uint32_t paral_small(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t top)
+{
+	int32_t x = (int32_t)v0 + (int32_t)v1 - (int32_t)v2;
+	uint32_t lo = x < 0 ? 0u : (uint32_t)x;                 // v1 < v2: max(0, v0 - (v2 - v1)), never clamped at the top
+	uint32_t hi = (uint32_t)x > top ? top : (uint32_t)x;    // v1 >= v2: saturates at the top (type wrap included)
+	return usel(v1 < v2, lo, hi) & (uint32_t)(T)(~T(0));
+}
+// inverse residual code of unsigned values of at most 16 bits: prediction.h:46-64
+template <typename T> __device__ __forceinline__ uint32_t unfold_small(uint32_t code, uint32_t pred, uint32_t top)
+{
+	const uint32_t M = (uint32_t)(T)(~T(0));
+	uint32_t room = (top - pred) & M;
+	uint32_t pm1 = (pred - 1u) & M;
+	uint32_t bal = pm1 < room ? pm1 : room;
+	uint32_t half = code >> 1;
+	uint32_t far_hi = (pred + code - bal - 1u) & M, far_lo = (pred - code + bal) & M;
+	uint32_t nearv = (pred + (half ^ usel((code & 1u) != 0, M, 0u))) & M;
+	uint32_t r = usel(half > bal, usel(room >= pred, far_hi, far_lo), nearv);
+	return usel(pred == 0, code, r);
+}
+
+
+template <typename T>
+__device__ __forceinline__ T chain_predict(uint32_t ncu, const T *pv)
+{
+	typedef typename cm::wide<T>::type W;
+	if (ncu == 0) return T(0);
+	W acc = 0;
+#pragma unroll
+	for (int k = 0; k < kCandMax; ++k) if ((uint32_t)k < ncu) acc = acc + (W)pv[k];
+	T avg;
+	if constexpr (!cm::is_fp<T>::value && !(T(-1) < T(0))) {
+		// unsigned sums of <= 8 values: (sum + n/2) / n without the 64-bit divide
+		uint64_t sum = (uint64_t)acc + (ncu >> 1);
+		if (ncu == 1) avg = (T)sum;
+		else if (ncu == 2) avg = (T)(sum >> 1);
+		else if (ncu == 4) avg = (T)(sum >> 2);
+		else if (ncu == 8) avg = (T)(sum >> 3);
+		else if (sizeof(T) <= 2) avg = (T)div_small((uint32_t)sum, ncu);
+		else avg = (T)(sum / ncu);
+	} else avg = (T)cm::mean_of(acc, (W)ncu);
+	if constexpr (!cm::is_fp<T>::value) return avg;
+	else {
+		T best = 3.402823466e+38f;
+#pragma unroll
+		for (int k = 0; k < kCandMax; ++k) {
+			if ((uint32_t)k < ncu) {
+				T db = avg > best ? avg - best : best - avg;
+				T dp = avg > pv[k] ? avg - pv[k] : pv[k] - avg;
+				best = db < dp ? best : pv[k];
+			}
+		}
+		return best;
+	}
+}
+
+template <typename T>
+__device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
+                                     const uint8_t *planes, uint8_t *rec, int stride, int off, int q, int plane0,
+                                     typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n)
+{
+	typedef typename cm::word<sizeof(T)>::u U;
+	static_assert(sizeof(T) <= 4, "8-byte components use the generic kernel");
+	const int lane = threadIdx.x;
+	const uint32_t mask = ring_n - 1;
+	uint4 nid[6];
+	uint32_t nnc = 0, ncode = 0;
+	auto prefetch = [&](uint32_t b) {
+		uint32_t v = b + lane;
+		nnc = 0; ncode = 0;
+		if (v < nvtx) {
+			const uint4 *src = (const uint4*)(cand + (size_t)v * (kCandMax * 3));
+#pragma unroll
+			for (int k = 0; k < 6; ++k) nid[k] = src[k];
+			nnc = ncand[v];
+#pragma unroll
+			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) ncode |= (uint32_t)planes[(size_t)(plane0 + b8) * nvtx + v] << (8 * b8);
+		}
+	};
+	// value of an already reconstructed vertex that lies before the current batch
+	auto old_value = [&](uint32_t id, uint32_t base) -> U {
+		if (base - id <= ring_n) return ring[id & mask];
+		U r;
+		__builtin_memcpy(&r, rec + (size_t)id * stride + off, sizeof(U));
+		return r;
+	};
+	prefetch(0);
+	uint32_t base = 0;
+	while (base < nvtx) {
+		uint32_t ids[kCandMax * 3];
+#pragma unroll
+		for (int k = 0; k < 6; ++k) { ids[4 * k] = nid[k].x; ids[4 * k + 1] = nid[k].y; ids[4 * k + 2] = nid[k].z; ids[4 * k + 3] = nid[k].w; }
+		const uint32_t nc = nnc;
+		const uint32_t code = ncode;
+		uint32_t nb = min(64u, nvtx - base);
+		const uint64_t ovf = __ballot(nc == 0xff);
+		if (ovf & 1ull) {
+			// more candidates than the table holds (very high valence), first vertex of the batch: every source is older,
+			// walk the fan right here (uniform work, all lanes compute the same value)
+			typedef typename cm::wide<T>::type W;
+			const uint32_t v = base;
+			W acc = 0;
+			uint32_t n = 0;
+			fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
+				acc = acc + (W)cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
+				++n;
+			});
+			T pred = T(0);
+			if (n) {
+				T avg = (T)cm::mean_of(acc, (W)n);
+				if constexpr (!cm::is_fp<T>::value) pred = avg;
+				else {
+					T best = 3.402823466e+38f;
+					fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
+						T p = cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
+						T db = avg > best ? avg - best : best - avg;
+						T dp = avg > p ? avg - p : p - avg;
+						best = db < dp ? best : p;
+					});
+					pred = best;
+				}
+			}
+			const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)code);
+			T val = cm::value_from_residual<T>((U)c0, pred, q);
+			if (lane == 0) {
+				stq<T>(rec + (size_t)v * stride + off, val);
+				ring[v & mask] = cm::bits<U>(val);
+			}
+			__syncthreads();
+			base += 1;
+			prefetch(base);
+			continue;
+		}
+		if (ovf) nb = min(nb, (uint32_t)__builtin_ctzll(ovf));
+		// ---- prepare: lane i <-> vertex base + i
+		uint32_t src[kCandMax * 3];   // bit patterns; src[3k] holds the finished parallelogram when candidate k is ready
+		uint32_t flags = 0;           // bit 3k+j: source j of candidate k lies inside this batch
+#pragma unroll
+		for (int k = 0; k < kCandMax; ++k) {
+			src[3 * k] = 0; src[3 * k + 1] = 0; src[3 * k + 2] = 0;
+			if ((uint32_t)k < nc && lane < (int)nb) {
+				uint32_t f = 0;
+#pragma unroll
+				for (int j = 0; j < 3; ++j) {
+					uint32_t id = ids[3 * k + j];
+					if (id >= base) f |= 1u << j;
+					else src[3 * k + j] = (uint32_t)old_value(id, base);
+				}
+				if (f == 0) src[3 * k] = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>((U)src[3 * k]), cm::bits<T>((U)src[3 * k + 1]), cm::bits<T>((U)src[3 * k + 2]), q));
+				flags |= f << (3 * k);
+			}
+		}
+		// Every prepare load has landed before the next batch is requested: the memory counters retire in order, so a
+		// prefetch issued earlier would be waited for together with the first prepare load, and the chain below must not
+		// contain a single wait.  The prefetch then overlaps the whole chain.
+		__builtin_amdgcn_s_waitcnt(0);
+		prefetch(base + nb);
+		// ---- chain
+		uint32_t vals = 0;   // lane j: bit pattern of the reconstructed value of vertex base + j
+		constexpr bool kSmallUnsigned = !cm::is_fp<T>::value && sizeof(T) <= 2 && !(T(-1) < T(0));
+		constexpr bool kFast = kSmallUnsigned || cm::is_fp<T>::value;
+		const uint32_t top = (uint32_t)cm::ones<typename std::conditional<kSmallUnsigned, T, uint32_t>::type>(q == 0 ? (int)sizeof(T) * 8 : q);
+		for (uint32_t i = 0; i < nb; ++i) {
+			const uint32_t ncu = rl(nc, i);
+			const uint32_t fl = rl(flags, i);
+			T pred;
+			bool done = false;
+			if constexpr (kFast) {
+				if (ncu <= 2) {
+					// at most two candidates (the rule in a manifold triangle mesh): straight-line code, no branches.
+					// source = prepared value, or the value of a vertex of this batch taken from the register vector
+#define HRY_SRC(j) usel((fl >> (j)) & 1u, rl(vals, (rl(ids[j], i) - base) & 63u), rl(src[j], i))
+					const uint32_t a0 = HRY_SRC(0), b0 = HRY_SRC(1), o0 = HRY_SRC(2), a1 = HRY_SRC(3), b1 = HRY_SRC(4), o1 = HRY_SRC(5);
+#undef HRY_SRC
+					if constexpr (kSmallUnsigned) {
+						uint32_t p0 = usel((fl & 7u) == 0, rl(src[0], i), paral_small<T>(a0, b0, o0, top));
+						uint32_t p1 = usel(((fl >> 3) & 7u) == 0, rl(src[3], i), paral_small<T>(a1, b1, o1, top));
+						uint32_t two = (p0 + p1 + 1u) >> 1;
+						pred = (T)usel(ncu == 2, two, usel(ncu == 1, p0, 0u));
+					} else {
+						float p0 = cm::bits<float>(usel((fl & 7u) == 0, rl(src[0], i), cm::bits<uint32_t>(cm::bits<float>(a0) + (cm::bits<float>(b0) - cm::bits<float>(o0)))));
+						float p1 = cm::bits<float>(usel(((fl >> 3) & 7u) == 0, rl(src[3], i), cm::bits<uint32_t>(cm::bits<float>(a1) + (cm::bits<float>(b1) - cm::bits<float>(o1)))));
+						// n = 2: mean in double, halved (exactly the division by 2.0), nearest candidate with strict <, first wins
+						float avg = (float)(((double)p0 + (double)p1) * 0.5);
+						float best = 3.402823466e+38f;
+						float db = avg > best ? avg - best : best - avg, dp = avg > p0 ? avg - p0 : p0 - avg;
+						best = db < dp ? best : p0;
+						db = avg > best ? avg - best : best - avg; dp = avg > p1 ? avg - p1 : p1 - avg;
+						float two = db < dp ? best : p1;
+						pred = cm::bits<float>(usel(ncu == 2, cm::bits<uint32_t>(two), usel(ncu == 1, cm::bits<uint32_t>(p0), 0u)));
+					}
+					done = true;
+				}
+			}
+			if (!done) {
+				T pv[kCandMax];
+#pragma unroll
+				for (int k = 0; k < kCandMax; ++k) {
+					if ((uint32_t)k < ncu) {
+						const uint32_t f = (fl >> (3 * k)) & 7u;
+						if (f == 0) pv[k] = cm::bits<T>((U)rl(src[3 * k], i));
+						else {
+							U s0 = (f & 1u) ? (U)rl(vals, rl(ids[3 * k], i) - base) : (U)rl(src[3 * k], i);
+							U s1 = (f & 2u) ? (U)rl(vals, rl(ids[3 * k + 1], i) - base) : (U)rl(src[3 * k + 1], i);
+							U s2 = (f & 4u) ? (U)rl(vals, rl(ids[3 * k + 2], i) - base) : (U)rl(src[3 * k + 2], i);
+							pv[k] = cm::parallelogram<T>(cm::bits<T>(s0), cm::bits<T>(s1), cm::bits<T>(s2), q);
+						}
+					}
+				}
+				pred = chain_predict<T>(ncu, pv);
+			}
+			uint32_t vbits;
+			if constexpr (kSmallUnsigned) vbits = unfold_small<T>(rl(code, i), (uint32_t)pred, top);
+			else vbits = (uint32_t)cm::bits<U>(cm::value_from_residual<T>((U)rl(code, i), pred, q));
+			if (lane == (int)i) vals = vbits;
+		}
+		// ---- publish the batch
+		if (lane < (int)nb) {
+			const uint32_t v = base + lane;
+			ring[v & mask] = (U)vals;
+			stq<T>(rec + (size_t)v * stride + off, cm::bits<T>((U)vals));
+		}
+		__syncthreads();
+		base += nb;
+	}
+}
+
+struct CompSel { int32_t n; int32_t comp[kMaxComp]; };
+
+// one kernel per component type (keeps each instantiation's register allocation to itself: no scratch in the chain)
+template <typename T>
+__global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
+                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, uint32_t ring_bytes, CompSel sel)
+{
+	extern __shared__ unsigned long long ring_raw2[];
+	const int c = sel.comp[blockIdx.x];
+	TopoD tp{ cv };
+	unpredict2_component<T>(tp, order_v, nvtx, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
+	                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T));
+}
+
+// ---------------------------------------------------------------------------------------------------------
 static uint32_t ring_elem_bytes(const ListDesc &ld)
 {
 	bool same = true;
@@ -400,6 +659,45 @@ void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, 
 void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec)
 {
 	if (n && ld.ncomp) hipLaunchKernelGGL(k_faces_unfold, dim3((n + 255) / 256), dim3(256), 0, st, n, ld, rec);
+}
+bool unpredict2_applicable(const ListDesc &ld)
+{
+	for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == 1 || ld.stype[c] == 2 || ld.stype[c] == 3) return false;
+	return ld.ncomp > 0;
+}
+// candidate lists with plain vertex ids (k_unpredict2 resolves ring slots itself)
+__global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= n) return;
+	TopoD tp{ cv };
+	uint32_t k = 0;
+	uint32_t ids[kCandMax * 3];
+	fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
+		if (k < (uint32_t)kCandMax) { ids[3 * k] = a; ids[3 * k + 1] = b; ids[3 * k + 2] = o; }
+		++k;
+	});
+	uint32_t *out = cand + (size_t)v * (kCandMax * 3);
+	uint32_t m = k > (uint32_t)kCandMax ? 0 : k;
+	for (uint32_t j = 0; j < (uint32_t)(3 * kCandMax); ++j) out[j] = j < 3 * m ? ids[j] : 0u;
+	ncand[v] = k > (uint32_t)kCandMax ? 0xff : (uint8_t)k;
+}
+void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec)
+{
+	if (!nvtx || !ld.ncomp) return;
+	hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, nvtx, cand, ncand);
+	const uint32_t ring_bytes = 64 * 1024;
+	auto go = [&](auto kern, int stype) {
+		CompSel sel{};
+		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
+		if (!sel.n) return;
+		(void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes);
+		hipLaunchKernelGGL(kern, dim3(sel.n), dim3(64), ring_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel);
+	};
+	// components of different types are independent chains too: their kernels may overlap on the device
+	go(k_unpredict2<float>, 0); go(k_unpredict2<uint32_t>, 4); go(k_unpredict2<int32_t>, 5); go(k_unpredict2<uint16_t>, 6);
+	go(k_unpredict2<int16_t>, 7); go(k_unpredict2<uint8_t>, 8); go(k_unpredict2<int8_t>, 9);
 }
 void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                       const ListDesc &ld, uint8_t *rec)
