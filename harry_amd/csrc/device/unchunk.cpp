@@ -23,7 +23,7 @@ void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_
                       const ListDesc &ld, uint8_t *rec);
 bool unpredict2_applicable(const ListDesc &ld);
 void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
-                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec);
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists, bool first);
 }
 
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
@@ -120,8 +120,9 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	}
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	auto t_walk = Clock::now();
-	std::vector<uint32_t> order_v;
-	cut_border_replay(*m, conn, order_v);
+	std::vector<uint32_t> order_v, seg_start;
+	std::vector<uint8_t> seg_dep;
+	cut_border_replay(*m, conn, order_v, seg_start, seg_dep);
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
 	const uint32_t nvc = (uint32_t)order_v.size();
@@ -137,8 +138,34 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	if (ldv.nplanes) {
 		if (unpredict2_applicable(ldv)) {
-			// one wavefront per component, residual codes straight from the decoded byte planes
-			launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], ldv, cx.d_rec[1].as<uint8_t>());
+			// One wavefront per attribute component and per independent connected component; residual codes come straight
+			// from the decoded byte planes.  Components that read vertices coded before them (shared non-manifold vertices)
+			// run afterwards, in order, in one chain.
+			std::vector<uint32_t> segs, off_a{ 0 }, off_b{ 0 };
+			std::vector<uint32_t> dep_segs;
+			for (size_t k = 0; k + 1 < seg_start.size(); ++k) {
+				if (seg_start[k] == seg_start[k + 1]) continue;
+				if (seg_dep[k]) { dep_segs.push_back(seg_start[k]); dep_segs.push_back(seg_start[k + 1]); }
+				else { segs.push_back(seg_start[k]); segs.push_back(seg_start[k + 1]); off_a.push_back((uint32_t)segs.size() / 2); }
+			}
+			const uint32_t n_indep = (uint32_t)off_a.size() - 1;
+			const uint32_t dep_first = (uint32_t)segs.size() / 2;
+			segs.insert(segs.end(), dep_segs.begin(), dep_segs.end());
+			off_b[0] = dep_first;
+			off_b.push_back((uint32_t)segs.size() / 2);
+			std::vector<uint32_t> table(segs);
+			const size_t o_a = table.size();
+			table.insert(table.end(), off_a.begin(), off_a.end());
+			const size_t o_b = table.size();
+			table.insert(table.end(), off_b.begin(), off_b.end());
+			cx.d_small.ensure(table.size() * 4 + 64);
+			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
+			const uint32_t *d_tab = cx.d_small.as<uint32_t>();
+			const uint8_t *d_vplanes = cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes];
+			launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(), d_tab, d_tab + o_a, n_indep, true);
+			if (!dep_segs.empty())
+				launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(), d_tab, d_tab + o_b, 1, false);
+			HIP_OK(hipStreamSynchronize(cx.stream));   // the table lives in host memory until the copy has been consumed
 		} else {
 			launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
 			launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], nvc, ldv, cx.d_rec[1].as<uint8_t>());

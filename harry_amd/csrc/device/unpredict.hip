@@ -450,10 +450,11 @@ __device__ __forceinline__ T chain_predict(uint32_t ncu, const T *pv)
 }
 
 template <typename T>
-__device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
+__device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                      const uint8_t *planes, uint8_t *rec, int stride, int off, int q, int plane0,
                                      typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n)
 {
+	// this call reconstructs the vertices [seg_begin, nvtx) of one component; the ring holds only vertices >= seg_begin
 	typedef typename cm::word<sizeof(T)>::u U;
 	static_assert(sizeof(T) <= 4, "8-byte components use the generic kernel");
 	const int lane = threadIdx.x;
@@ -469,18 +470,18 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			for (int k = 0; k < 6; ++k) nid[k] = src[k];
 			nnc = ncand[v];
 #pragma unroll
-			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) ncode |= (uint32_t)planes[(size_t)(plane0 + b8) * nvtx + v] << (8 * b8);
+			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) ncode |= (uint32_t)planes[(size_t)(plane0 + b8) * nvtx_total + v] << (8 * b8);
 		}
 	};
 	// value of an already reconstructed vertex that lies before the current batch
 	auto old_value = [&](uint32_t id, uint32_t base) -> U {
-		if (base - id <= ring_n) return ring[id & mask];
+		if (base - id <= ring_n && id >= seg_begin) return ring[id & mask];
 		U r;
 		__builtin_memcpy(&r, rec + (size_t)id * stride + off, sizeof(U));
 		return r;
 	};
-	prefetch(0);
-	uint32_t base = 0;
+	prefetch(seg_begin);
+	uint32_t base = seg_begin;
 	while (base < nvtx) {
 		uint32_t ids[kCandMax * 3];
 #pragma unroll
@@ -621,17 +622,24 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 }
 
 struct CompSel { int32_t n; int32_t comp[kMaxComp]; };
+// work lists: block y reconstructs the segments segs[list_off[y] .. list_off[y+1]) one after the other
 
 // one kernel per component type (keeps each instantiation's register allocation to itself: no scratch in the chain)
 template <typename T>
 __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
-                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, uint32_t ring_bytes, CompSel sel)
+                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, uint32_t ring_bytes, CompSel sel,
+                                                   const uint32_t *segs, const uint32_t *list_off)
 {
 	extern __shared__ unsigned long long ring_raw2[];
 	const int c = sel.comp[blockIdx.x];
 	TopoD tp{ cv };
-	unpredict2_component<T>(tp, order_v, nvtx, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
-	                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T));
+	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
+		const uint32_t b = segs[2 * k], e = segs[2 * k + 1];
+		if (b < e)
+			unpredict2_component<T>(tp, order_v, nvtx, b, e, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
+			                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T));
+		__syncthreads();
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -682,18 +690,22 @@ __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint3
 	for (uint32_t j = 0; j < (uint32_t)(3 * kCandMax); ++j) out[j] = j < 3 * m ? ids[j] : 0u;
 	ncand[v] = k > (uint32_t)kCandMax ? 0xff : (uint8_t)k;
 }
+// segs: pairs (begin, end) of decode ranks; list_off: n_lists + 1 offsets into segs.  Lists run in parallel blocks, the
+// segments of one list one after the other.  Two launches: independent components first, then the dependent ones.
 void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
-                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec)
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists, bool first)
 {
 	if (!nvtx || !ld.ncomp) return;
-	hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, nvtx, cand, ncand);
+	if (first) hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, nvtx, cand, ncand);
+	if (!n_lists) return;
 	const uint32_t ring_bytes = 64 * 1024;
 	auto go = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
 		(void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes);
-		hipLaunchKernelGGL(kern, dim3(sel.n), dim3(64), ring_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel);
+		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64), ring_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel,
+		                   segs, list_off);
 	};
 	// components of different types are independent chains too: their kernels may overlap on the device
 	go(k_unpredict2<float>, 0); go(k_unpredict2<uint32_t>, 4); go(k_unpredict2<int32_t>, 5); go(k_unpredict2<uint16_t>, 6);

@@ -114,7 +114,8 @@ struct Planes {
 
 // planes: 21 connectivity planes in container order.  Fills m.face_off / org / twin and returns the decode order
 // (one half-edge per vertex; vertex ids are assigned in this order, cbm/decoder.h:48-75,145).
-void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v)
+void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
+                       std::vector<uint8_t> &seg_dep)
 {
 	const uint32_t nv = m.nv, nf = m.nf;
 	int ndeg = 0, onlydeg = 0;
@@ -126,6 +127,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 	m.org.reserve((size_t)nf * 3); m.twin.reserve((size_t)nf * 3);
 	order_v.clear();
 	order_v.reserve(nv);
+	seg_start.clear(); seg_dep.clear();
 	std::vector<uint16_t> seen(nv, 0);
 	Ring cb;
 	uint32_t next_id = 0;
@@ -146,6 +148,11 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 		uint32_t iop = rd.iop();
 		if (iop == I_EOM) break;
 		uint32_t a = 0, b = 0, c = 0;
+		// a component is an independent reconstruction chain unless it touches vertices coded before it started
+		// (TRIxxx start, or an NM operation naming an older vertex)
+		const uint32_t seg_first_id = next_id;
+		seg_start.push_back((uint32_t)order_v.size());
+		seg_dep.push_back(iop != I_INIT ? 1 : 0);
 		switch (iop) {   // decoder.h:46-77
 		case I_INIT: a = next_id++; b = next_id++; c = next_id++; break;
 		case I_TRI100: a = rd.vertid(); b = next_id++; c = next_id++; break;
@@ -260,6 +267,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 			case O_NEWVTX: case O_NM: {
 				v2 = op == O_NEWVTX ? next_id++ : rd.vertid();
 				chk(v2);
+				if (op == O_NM && v2 < seg_first_id) seg_dep.back() = 1;
 				Ring::Part &p = cb.top();
 				first = p.tail;
 				second = cb.make(v2, 0);
@@ -301,6 +309,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 			} else if (op == O_CONNBWD) link(gateprev, e1);
 		}
 	}
+	seg_start.push_back((uint32_t)order_v.size());
 	if (m.face_off.size() != (size_t)nf + 1) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
 	if (next_id > nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)");
 }

@@ -10,6 +10,7 @@
 // call into the arithmetic coder.
 #include "host.hpp"
 
+#include <algorithm>
 #include <unordered_set>
 
 namespace hry {
@@ -163,27 +164,60 @@ struct Border {
 	}
 };
 
-// Start faces: face 0, then the first unvisited face in the iteration order of a std::unordered_set<uint32_t>
-// that received 0..F-1 in order (writer.cc:28-46; SURVEY.md App. B-1: the order is a function of F and libstdc++).
+// Start faces: face 0, then the first unvisited face in the iteration order of a std::unordered_set<uint32_t> that
+// received 0..F-1 in order (writer.cc:28-46).  The order is a function of F and of libstdc++'s
+// hashtable only, so it is derived instead of building a 100 M-node table: with the identity hash, load factor <= 1 and
+// keys 0..k-1, every insertion lands in an empty bucket and is linked at the FRONT of the node list, and every rehash
+// walks the list front to back re-linking each node at the front, i.e. reverses it (bits/hashtable.h: _M_insert_bucket_begin,
+// _M_rehash_aux).  Rehash points come from libstdc++'s own policy object, so they follow the installed library.
 struct StartFaces {
+	struct Block { uint32_t first, last; };   // consecutive keys in list order: ascending if first <= last, else descending
 	uint32_t nf;
 	std::vector<uint8_t> gone;
-	std::vector<uint32_t> order;
-	size_t cursor = 0;
+	std::vector<Block> blocks;
+	size_t bi = 0;
+	uint32_t pos = 0;
+	bool have_order = false;
 	uint32_t left;
 	explicit StartFaces(uint32_t n) : nf(n), gone(n, 0), left(n) {}
 	void take(uint32_t f) { gone[f] = 1; --left; }
+	void derive_order()
+	{
+		std::__detail::_Prime_rehash_policy pol;
+		std::size_t nbkt = 1;
+		std::vector<Block> list;   // front ... back
+		for (uint32_t k = 0; k < nf; ++k) {
+			std::pair<bool, std::size_t> rh = pol._M_need_rehash(nbkt, k, 1);
+			if (rh.first) {
+				nbkt = rh.second;
+				std::reverse(list.begin(), list.end());
+				for (Block &b : list) std::swap(b.first, b.last);
+			}
+			if (!list.empty() && list.front().first == k - 1 && list.front().first >= list.front().last) list.front().first = k;   // extend the descending front block
+			else list.insert(list.begin(), Block{ k, k });
+		}
+		blocks.swap(list);
+		have_order = true;
+		bi = 0; pos = 0;
+	}
+	uint32_t at_cursor() const
+	{
+		const Block &b = blocks[bi];
+		return b.first <= b.last ? b.first + pos : b.first - pos;
+	}
+	void advance()
+	{
+		const Block &b = blocks[bi];
+		uint32_t len = (b.first <= b.last ? b.last - b.first : b.first - b.last) + 1;
+		if (++pos == len) { ++bi; pos = 0; }
+	}
 	uint32_t next()
 	{
 		uint32_t f = 0;
 		if (gone[0]) {
-			if (order.empty()) {
-				std::unordered_set<uint32_t> s;
-				for (uint32_t i = 0; i < nf; ++i) s.insert(i);
-				order.assign(s.begin(), s.end());
-			}
-			while (gone[order[cursor]]) ++cursor;
-			f = order[cursor];
+			if (!have_order) derive_order();
+			while (gone[at_cursor()]) advance();
+			f = at_cursor();
 		}
 		take(f);
 		return f;

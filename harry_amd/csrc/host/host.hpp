@@ -46,7 +46,9 @@ struct WalkResult {
 void cut_border_walk(Mesh &m, WalkResult &out);
 
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
-void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v);
+// seg_start: first decode rank of every connected component (+ end sentinel); seg_dep[k] != 0: component k reads vertices coded earlier
+void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
+                       std::vector<uint8_t> &seg_dep);
 
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);

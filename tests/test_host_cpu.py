@@ -140,3 +140,11 @@ def test_parse_quant_flags():
     assert hc.parse_quant_flags(["-l", "1", "-a", "0", "-q", "14", "-a3", "-q10", "-c"]) == ([(1, 0, 14), (1, 3, 10)], True)
     with pytest.raises(ValueError):
         hc.parse_quant_flags(["-q14"])
+
+
+@pytest.mark.parametrize("ncomp,nu", [(3, 4), (40, 6), (300, 4), (1500, 3), (90, 12)])
+def test_start_face_order_many_components(ncomp, nu):
+    """Every component after the first starts at the face std::unordered_set iteration would yield (App. B-1); the
+    product derives that order analytically, the oracle uses the real container.  Crosses several rehash points."""
+    m = mg.multi_component(ncomp, nu, nu + 1, polys="tri")
+    check_walk_against_oracle(m.to_ply())
