@@ -403,17 +403,18 @@ template <typename T> __device__ __forceinline__ uint32_t paral_small(uint32_t v
 // inverse residual code of unsigned values of at most 16 bits: prediction.h:46-64
 template <typename T> __device__ __forceinline__ uint32_t unfold_small(uint32_t code, uint32_t pred, uint32_t top)
 {
+	// prediction.h:46-64 with the two far branches reduced: room >= pred => bal = pred - 1 and pred + code - bal - 1 == code;
+	// room < pred => bal = room and pred - code + bal == top - code
 	const uint32_t M = (uint32_t)(T)(~T(0));
 	uint32_t room = (top - pred) & M;
 	uint32_t pm1 = (pred - 1u) & M;
 	uint32_t bal = pm1 < room ? pm1 : room;
 	uint32_t half = code >> 1;
-	uint32_t far_hi = (pred + code - bal - 1u) & M, far_lo = (pred - code + bal) & M;
-	uint32_t nearv = (pred + (half ^ usel((code & 1u) != 0, M, 0u))) & M;
-	uint32_t r = usel(half > bal, usel(room >= pred, far_hi, far_lo), nearv);
-	return usel(pred == 0, code, r);
+	uint32_t far = room >= pred ? code : (top - code) & M;
+	uint32_t nearv = ((code & 1u) ? pred - half - 1u : pred + half) & M;
+	uint32_t r = half > bal ? far : nearv;
+	return pred == 0 ? code : r;
 }
-
 
 template <typename T>
 __device__ __forceinline__ T chain_predict(uint32_t ncu, const T *pv)
@@ -539,7 +540,7 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 #pragma unroll
 				for (int j = 0; j < 3; ++j) {
 					uint32_t id = ids[3 * k + j];
-					if (id >= base) f |= 1u << j;
+					if (id >= base) { f |= 1u << j; src[3 * k + j] = 0x80000000u | (id - base); }   // inside the batch: keep the lane of its value
 					else src[3 * k + j] = (uint32_t)old_value(id, base);
 				}
 				if (f == 0) src[3 * k] = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>((U)src[3 * k]), cm::bits<T>((U)src[3 * k + 1]), cm::bits<T>((U)src[3 * k + 2]), q));
@@ -565,9 +566,17 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 				if (ncu <= 2) {
 					// at most two candidates (the rule in a manifold triangle mesh): straight-line code, no branches.
 					// source = prepared value, or the value of a vertex of this batch taken from the register vector
-#define HRY_SRC(j) usel((fl >> (j)) & 1u, rl(vals, (rl(ids[j], i) - base) & 63u), rl(src[j], i))
-					const uint32_t a0 = HRY_SRC(0), b0 = HRY_SRC(1), o0 = HRY_SRC(2), a1 = HRY_SRC(3), b1 = HRY_SRC(4), o1 = HRY_SRC(5);
+					uint32_t a0, b0, o0, a1, b1, o1;
+					if constexpr (kSmallUnsigned) {
+						// values are at most 16 bits: bit 31 of the prepared word marks "inside the batch", bits 0-5 the lane
+#define HRY_SRC(dst, j) { const uint32_t w_ = rl(src[j], i); const uint32_t in_ = rl(vals, w_ & 63u); dst = (int32_t)w_ < 0 ? in_ : w_; }
+						HRY_SRC(a0, 0) HRY_SRC(b0, 1) HRY_SRC(o0, 2) HRY_SRC(a1, 3) HRY_SRC(b1, 4) HRY_SRC(o1, 5)
 #undef HRY_SRC
+					} else {
+#define HRY_SRC(j) usel((fl >> (j)) & 1u, rl(vals, (rl(ids[j], i) - base) & 63u), rl(src[j], i))
+						a0 = HRY_SRC(0); b0 = HRY_SRC(1); o0 = HRY_SRC(2); a1 = HRY_SRC(3); b1 = HRY_SRC(4); o1 = HRY_SRC(5);
+#undef HRY_SRC
+					}
 					if constexpr (kSmallUnsigned) {
 						uint32_t p0 = usel((fl & 7u) == 0, rl(src[0], i), paral_small<T>(a0, b0, o0, top));
 						uint32_t p1 = usel(((fl >> 3) & 7u) == 0, rl(src[3], i), paral_small<T>(a1, b1, o1, top));

@@ -229,6 +229,7 @@ struct Emitter {
 	uint32_t n = 0;
 	// order-conditioned operation model (models.h:49-120), evaluated here because it is connectivity-sized
 	uint64_t plain[5] = { 1, 1, 1, 1, 1 }, c_all = 2, c_new[8], c_fwd[8];
+	bool eval_model = true;   // the compat stream needs (l, h, t) of every operation; the chunked planes only symbol + class
 	explicit Emitter(WalkResult &r) : w(r) { for (int i = 0; i < 8; ++i) c_new[i] = c_fwd[i] = 1; }
 	void group(int g, uint32_t v) { w.grp_val[g].push_back(v); w.grp_pos[g].push_back(n); n += kGroupBytes[g]; }
 	void iop(uint32_t s) { group(G_IOP, s); }
@@ -241,6 +242,11 @@ struct Emitter {
 		int k = order - 1;   // models.h:101-105; order >= 1 because the gate's front vertex lies on a coded triangle
 		if (k > 7) k = 7;
 		if (k < 0) k = 0;
+		if (!eval_model) {
+			w.op_sym.push_back((uint8_t)s); w.op_class.push_back((uint8_t)k);
+			++n;
+			return;
+		}
 		uint64_t nv = c_new[k] * c_all / (c_new[k] + c_fwd[k]);
 		uint64_t f[7] = { plain[0], plain[1], plain[2], plain[3], plain[4], nv, c_all - nv };
 		uint64_t l = 0;
@@ -257,7 +263,7 @@ struct Emitter {
 
 }   // namespace
 
-void cut_border_walk(Mesh &m, WalkResult &w)
+void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
 {
 	const uint32_t nv = m.nv, nf = m.nf;
 	if (nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
@@ -282,11 +288,12 @@ void cut_border_walk(Mesh &m, WalkResult &w)
 	w.order_v.reserve(nv);
 	w.order_f.reserve(nf);
 	w.op_sym.reserve(m.ntri() + 16); w.op_class.reserve(m.ntri() + 16);
-	w.op_l.reserve(m.ntri() + 16); w.op_h.reserve(m.ntri() + 16); w.op_t.reserve(m.ntri() + 16); w.op_pos.reserve(m.ntri() + 16);
+	if (eval_op_model) { w.op_l.reserve(m.ntri() + 16); w.op_h.reserve(m.ntri() + 16); w.op_t.reserve(m.ntri() + 16); w.op_pos.reserve(m.ntri() + 16); }
 
 	Border cb(nv);
 	StartFaces pool(nf);
 	Emitter em(w);
+	em.eval_model = eval_op_model;
 	std::vector<uint32_t> sent(nv, NONE32);   // original vertex -> transmitted index (encoder.h:28-52)
 	std::vector<uint16_t> seen(nv, 0);        // triangles seen per vertex (selects the op model class)
 	uint32_t next_id = 0;

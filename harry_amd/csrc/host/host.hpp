@@ -43,7 +43,7 @@ struct WalkResult {
 };
 
 // ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
-void cut_border_walk(Mesh &m, WalkResult &out);
+void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true);
 
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
 // seg_start: first decode rank of every connected component (+ end sentinel); seg_dep[k] != 0: component k reads vertices coded earlier

@@ -1,0 +1,46 @@
+"""The reference's command line on top of the GPU path: `harry in.ply out.hry [-l1 -q14]`, `harry in.hry out.ply`."""
+import os
+
+import numpy as np
+import pytest
+
+from harry_amd import cli
+from harry_amd import codec as hc
+from harry_amd import meshgen as mg
+from oracle import oracle_py as op
+from tests import util
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(util.ROOT, "tests", "golden")
+
+
+def test_cli_encode_is_byte_identical_to_reference(tmp_path, capsys):
+    out = tmp_path / "grid50.hry"
+    assert cli.main([os.path.join(GOLD, "grid50.ply"), str(out), "-l1", "-q14"]) == 0
+    assert out.read_bytes() == open(os.path.join(GOLD, "grid50.q14.hry"), "rb").read()
+    text = capsys.readouterr().out
+    for phrase in ("Reading input...", "Quantization took", "Writing output took", "Total output size:"):   # main.cc:99-120
+        assert phrase in text
+
+
+def test_cli_chunked_roundtrip_to_ply(tmp_path):
+    m = mg.with_colors(mg.torus(20, 22, polys="mixed", normals=True))
+    src = tmp_path / "in.ply"
+    src.write_bytes(m.to_ply())
+    hry, back = tmp_path / "out.hry", tmp_path / "back.ply"
+    assert cli.main([str(src), str(hry), "--profile", "chunked"]) == 0
+    assert cli.main([str(hry), str(back)]) == 0
+    dec = hc.Mesh.from_ply(back.read_bytes())
+    ref = op.Mesh.from_hry(op.Mesh.from_ply(m.to_ply()).encode().data)
+    assert np.array_equal(dec.org(), ref.org())
+    assert np.array_equal(dec.list_data(1), ref.list_data(1))
+    assert cli.main([str(hry), str(tmp_path / "a.ply"), "--ply-ascii"]) == 0
+    assert (tmp_path / "a.ply").read_bytes().startswith(b"ply\nformat ascii 1.0\n")
+
+
+def test_cli_errors(tmp_path):
+    bad = tmp_path / "x.ply"
+    bad.write_bytes(b"garbage")
+    with pytest.raises(RuntimeError):
+        cli.main([str(bad), str(tmp_path / "y.hry")])
+    assert cli.main(["only_one_arg"]) == 1
