@@ -126,8 +126,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather_all(stream_bytes):
+        """final stream concatenation on rank 0 (RCCL over xGMI); the only communication of the job"""
+        if world == 1:
+            return None
+        from harry_amd import sharding
+        got = sharding.gather_streams({rank: stream_bytes}, world, dev)
+        if rank == 0:
+            blob = sharding.concat_container(got)
+            assert len(sharding.split_container(blob)) == world
+        return got
+
     for _ in range(args.warmup):
-        one_step()
+        o, *_ = one_step()
+        gather_all(o)      # also warms the communicator up
     barrier()
     enc_s = dec_s = 0.0
     timings = []
@@ -137,16 +149,13 @@ def main():
         enc_s += te
         dec_s += td
         timings.append(tm)
+    t_g = time.perf_counter()
+    gather_all(out)
+    gather_s = time.perf_counter() - t_g
     barrier()
-    total = torch.tensor([enc_s + dec_s, enc_s, dec_s], dtype=torch.float64, device=dev)
+    total = torch.tensor([enc_s + dec_s + gather_s, enc_s, dec_s], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.MAX)
-        # final stream concatenation: gather the per-component streams on rank 0 (RCCL over xGMI); not a data-path collective
-        from harry_amd import sharding
-        gathered = sharding.gather_streams({rank: out}, world, dev)
-        if rank == 0:
-            blob = sharding.concat_container(gathered)
-            assert len(sharding.split_container(blob)) == world
     t_all, t_enc, t_dec = (float(x) for x in total.tolist())
 
     if rank == 0:

@@ -26,7 +26,7 @@ class Quant(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("profile", C.c_int32), ("chunk_syms", C.c_int32), ("keep_stages", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("profile", C.c_int32), ("chunk_syms", C.c_int32), ("keep_stages", C.c_int32), ("flags", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -40,6 +40,7 @@ class Timing(C.Structure):
 
 OK, E_ARG, E_FORMAT, E_UNSUPPORTED, E_NODEVICE, E_NOMEM, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PROFILE_COMPAT, PROFILE_CHUNKED = 0, 1
+FLAG_HOST_RECURRENCE = 1
 
 _lib = None
 

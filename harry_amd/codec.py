@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nat
-from ._native import HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
+from ._native import FLAG_HOST_RECURRENCE, HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
 
 TYPE_NP = {0: "<f4", 1: "<f8", 2: "<u8", 3: "<i8", 4: "<u4", 5: "<i4", 6: "<u2", 7: "<i2", 8: "u1", 9: "i1"}
 TYPE_SIZE = {0: 4, 1: 8, 2: 8, 3: 8, 4: 4, 5: 4, 6: 2, 7: 2, 8: 1, 9: 1}
@@ -177,8 +177,8 @@ class Codec:
     def upload(self, mesh: Mesh):
         nat.check(nat.load().hry_mesh_upload(self.h, mesh.h))
 
-    def write_hry(self, mesh: Mesh, profile: int = PROFILE_COMPAT, chunk_syms: int = 0, keep_stages: bool = False) -> bytes:
-        o = nat.Opts(profile, chunk_syms, int(keep_stages), 0)
+    def write_hry(self, mesh: Mesh, profile: int = PROFILE_COMPAT, chunk_syms: int = 0, keep_stages: bool = False, flags: int = 0) -> bytes:
+        o = nat.Opts(profile, chunk_syms, int(keep_stages), flags)
         p, n = C.c_void_p(), C.c_size_t()
         nat.check(nat.load().hry_encode(self.h, mesh.h, C.byref(o), C.byref(p), C.byref(n)))
         return nat.take_bytes(p, n.value)

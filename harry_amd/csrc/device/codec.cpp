@@ -288,10 +288,36 @@ static void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payloa
 	uint64_t st[2] = { 1ull << 63, 0 };   // R = HALF, no shifts yet (coder.h:47)
 	HIP_OK(hipMemcpyAsync(cx.d_state.p, st, 16, hipMemcpyHostToDevice, cx.stream));
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
-	if (ns) launch_rchain(cx.stream, cx.d_rec_sym.as<SymRec>(), ns, cx.d_r.as<uint64_t>(), cx.d_s.as<uint32_t>(), cx.d_state.as<uint64_t>());
-	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
-	HIP_OK(hipMemcpyAsync(st, cx.d_state.p, 16, hipMemcpyDeviceToHost, cx.stream));
-	HIP_OK(hipStreamSynchronize(cx.stream));
+	if (cx.host_recurrence && ns) {
+		// opt-in: the serial recurrence on a host core (SURVEY.md App. C-3 allows "host or one-lane"); same arithmetic as k_rchain
+		std::vector<SymRec> rec(ns);
+		std::vector<uint64_t> rr(ns);
+		std::vector<uint32_t> ss(ns);
+		HIP_OK(hipMemcpyAsync(rec.data(), cx.d_rec_sym.p, (size_t)ns * sizeof(SymRec), hipMemcpyDeviceToHost, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		uint64_t R = st[0], S = st[1];
+		for (uint32_t k = 0; k < ns; ++k) {
+			const SymRec &q = rec[k];
+			uint64_t r = cm::div_by_magic(R, q.magic, q.meta & 63u);
+			uint64_t prod = r * q.x;
+			uint64_t Rn = (q.meta & kMetaSub) ? R - prod : prod;
+			uint64_t y = Rn - 1;
+			uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
+			rr[k] = r; ss[k] = (uint32_t)S;
+			R = Rn << sh;
+			S += sh;
+		}
+		st[0] = R; st[1] = S;
+		HIP_OK(hipMemcpyAsync(cx.d_r.p, rr.data(), (size_t)ns * 8, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(cx.d_s.p, ss.data(), (size_t)ns * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	} else {
+		if (ns) launch_rchain(cx.stream, cx.d_rec_sym.as<SymRec>(), ns, cx.d_r.as<uint64_t>(), cx.d_s.as<uint32_t>(), cx.d_state.as<uint64_t>());
+		HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+		HIP_OK(hipMemcpyAsync(st, cx.d_state.p, 16, hipMemcpyDeviceToHost, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+	}
 	uint64_t total_shift = st[1];
 	if (total_shift + 64 >= (1ull << 32)) throw Error(HRY_E_UNSUPPORTED, "compat stream longer than 2^32 bits: use the chunked profile");
 	uint64_t nbits = total_shift + 64;   // flush: the 64 bits of the low register (coder.h:58-67)

@@ -59,6 +59,7 @@ struct Context {
 	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms;
 
 	bool keep_stages = false;
+	bool host_recurrence = false;   // HRY_FLAG_HOST_RECURRENCE
 	std::map<std::string, std::vector<uint8_t>> stages;
 
 	explicit Context(int dev);

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64) void k_rchain(const SymRec *rec, uint32_t n, ui
 	const int lane = threadIdx.x;
 	uint64_t R = state[0];
 	uint64_t S = state[1];
-	const SymRec idle{ 0, 0, kMetaNoop };
+	const SymRec idle{ 0, 0, kMetaSub | kMetaNoop };
 	SymRec cur = lane < (int)n ? rec[lane] : idle;
 	for (uint32_t base = 0; base < n; base += 64) {
 		uint32_t nidx = base + 64 + lane;
@@ -477,20 +477,18 @@ __global__ __launch_bounds__(64) void k_rchain(const SymRec *rec, uint32_t n, ui
 		uint32_t my_s = 0;
 		uint32_t cntb = min(64u, n - base);
 		for (uint32_t i = 0; i < cntb; ++i) {
+			// an exact no-op (l = 0, h = t) is the form R' = R - r * 0: same code path, no branch in the chain
 			uint32_t meta = (uint32_t)__builtin_amdgcn_readlane(mm, i);
-			uint64_t r = 0;
 			uint32_t s_before = (uint32_t)S;
-			if (!(meta & kMetaNoop)) {
-				uint64_t magic = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, i) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, i);
-				uint32_t x = (uint32_t)__builtin_amdgcn_readlane(mx, i);
-				r = cm::div_by_magic(R, magic, meta & 63u);
-				uint64_t prod = r * x;
-				uint64_t Rn = (meta & kMetaSub) ? R - prod : prod;
-				uint64_t y = Rn - 1;
-				uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
-				R = Rn << sh;
-				S += sh;
-			}
+			uint64_t magic = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, i) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, i);
+			uint32_t x = (uint32_t)__builtin_amdgcn_readlane(mx, i);
+			uint64_t r = cm::div_by_magic(R, magic, meta & 63u);
+			uint64_t prod = r * x;
+			uint64_t Rn = (meta & kMetaSub) ? R - prod : prod;
+			uint64_t y = Rn - 1;
+			uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
+			R = Rn << sh;
+			S += sh;
 			if (lane == (int)i) { my_r = r; my_s = s_before; }
 		}
 		if (base + lane < n) { r_out[base + lane] = my_r; s_out[base + lane] = my_s; }
@@ -504,20 +502,43 @@ __global__ __launch_bounds__(64) void k_rchain(const SymRec *rec, uint32_t n, ui
 // per 32-bit output word (word 0 = most significant).  coder.h:71 (L += r * l) and :73-90 (carry handling by
 // bit-plus-follow) are exactly big-number addition with carry propagation; flush (:58-67) appends the 64 bits of L.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kAccWin = 640;   // LDS window in 32-bit words per block of 256 symbols (256 x 63 shifts = 504 words + 3)
+
 __global__ __launch_bounds__(256) void k_low_accumulate(const uint64_t *r, const uint32_t *s, const uint32_t *sym_l, uint32_t n, unsigned long long *acc)
 {
-	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= n) return;
-	uint32_t l = sym_l[g];
-	if (l == 0) return;
-	uint64_t a = r[g] * l;
-	uint32_t pos = s[g], w = pos >> 5, sh = pos & 31;
-	uint64_t hi = a >> (32 + sh);
-	uint64_t low = a << (32 - sh);
+	// symbols of a block touch a narrow window of output words (positions are monotone): sum them in LDS first, then one
+	// global atomic per touched word instead of three contended ones per symbol
+	__shared__ unsigned long long win[kAccWin];
+	__shared__ uint32_t s_lo, s_hi;
+	const uint32_t g0 = blockIdx.x * blockDim.x, g = g0 + threadIdx.x;
+	if (threadIdx.x == 0) { s_lo = s[g0]; s_hi = s[min(g0 + 255u, n - 1)]; }
+	for (int k = threadIdx.x; k < kAccWin; k += 256) win[k] = 0;
+	__syncthreads();
+	const uint32_t w0 = s_lo >> 5, span = (s_hi >> 5) - w0 + 3;
+	uint64_t a = 0;
+	uint32_t w = 0, sh = 0;
+	if (g < n) {
+		uint32_t l = sym_l[g];
+		if (l) { a = r[g] * l; uint32_t pos = s[g]; w = pos >> 5; sh = pos & 31; }
+	}
+	uint64_t hi = a >> (32 + sh), low = a << (32 - sh);
 	uint32_t mid = (uint32_t)(low >> 32), lo = (uint32_t)low;
-	if (hi) atomicAdd(&acc[w], (unsigned long long)hi);
-	if (mid) atomicAdd(&acc[w + 1], (unsigned long long)mid);
-	if (lo) atomicAdd(&acc[w + 2], (unsigned long long)lo);
+	if (span <= (uint32_t)kAccWin) {
+		if (a) {
+			if (hi) atomicAdd(&win[w - w0], (unsigned long long)hi);
+			if (mid) atomicAdd(&win[w - w0 + 1], (unsigned long long)mid);
+			if (lo) atomicAdd(&win[w - w0 + 2], (unsigned long long)lo);
+		}
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < span; k += 256) {
+			unsigned long long v = win[k];
+			if (v) atomicAdd(&acc[w0 + k], v);
+		}
+	} else if (a) {
+		if (hi) atomicAdd(&acc[w], (unsigned long long)hi);
+		if (mid) atomicAdd(&acc[w + 1], (unsigned long long)mid);
+		if (lo) atomicAdd(&acc[w + 2], (unsigned long long)lo);
+	}
 }
 
 // first normalisation: v[k] = low32(acc[k]) + high32(acc[k+1]) < 2^33, after which carries are single bits

@@ -62,8 +62,13 @@ typedef struct hry_opts {
     int32_t profile;      /* HRY_PROFILE_* */
     int32_t chunk_syms;   /* CHUNKED: symbols per chunk and plane (0 = default) */
     int32_t keep_stages;  /* keep intermediate device buffers for hry_stage_get (tests) */
-    int32_t reserved;
+    int32_t flags;        /* HRY_FLAG_* */
 } hry_opts;
+
+/* COMPAT only: run the one strictly serial recurrence of the reference stream (the range register R of arith/coder.h:69-91,
+ * SURVEY.md App. C-3) on a host core instead of a single GPU wavefront.  Every parallel stage stays on the device; the
+ * bytes are identical either way.  Off by default. */
+#define HRY_FLAG_HOST_RECURRENCE 1
 
 /* timings of the last hry_encode / hry_decode on this context, milliseconds */
 typedef struct hry_timing {

@@ -1,21 +1,20 @@
 """Ad-hoc timing of the compat encode on one GPU (development aid; bench.py is the contract)."""
-import sys, time, json
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, time, json, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from harry_amd import codec as hc, meshgen as mg
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 708
+flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 mesh = mg.torus(n, n, seed=2, sigma=1e-4)
-t0 = time.time(); ply = mesh.to_ply(); t1 = time.time()
-m0 = hc.Mesh.from_ply(ply); t2 = time.time()
-print(f"gen {t1-t0:.2f}s  ply parse+twins {t2-t1:.2f}s  tris {m0.ntri}")
+m0 = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
 cx = hc.Codec(0)
 cx.requant(m0, [(1, -1, 14)])
 for it in range(3):
     m = m0.clone()
     cx.upload(m)
     t = time.time()
-    out = cx.write_hry(m)
+    out = cx.write_hry(m, flags=flags)
     dt = time.time() - t
     tm = cx.timing()
-    print(f"iter {it}: {dt*1e3:.1f} ms  {m.ntri/dt/1e6:.2f} Mtri/s  bytes {len(out)}  " + json.dumps({k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()}))
+    print(f"iter {it}: {dt*1e3:.1f} ms  {m.ntri/dt/1e6:.2f} Mtri/s  bytes {len(out)}  " + json.dumps({k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items() if v}))

@@ -219,3 +219,15 @@ def test_empty_face_list_and_tiny_meshes(cx):
         ply = m.to_ply()
         a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
         assert cx.write_hry(a) == o.encode().data
+
+
+def test_host_recurrence_option_gives_identical_bytes(cx):
+    """HRY_FLAG_HOST_RECURRENCE moves only the serial range-register recurrence to a host core; bytes are unchanged."""
+    for mesh, quant in ((mg.torus(60, 64, polys="mixed", normals=True), []), (mg.torus(90, 90), [(1, -1, 14)])):
+        ply = mesh.to_ply()
+        a, b, o = hc.Mesh.from_ply(ply), hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+        if quant:
+            cx.requant(a, quant); cx.requant(b, quant); o.requant(quant)
+        want = o.encode().data
+        assert cx.write_hry(a) == want
+        assert cx.write_hry(b, flags=hc.FLAG_HOST_RECURRENCE) == want
