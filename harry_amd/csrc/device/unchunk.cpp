@@ -3,6 +3,7 @@
 //   D2H connectivity planes -> host cut-border replay (cbm_unwalk.cpp) -> connectivity, decode order
 //   H2D connectivity -> k_candidates, k_residuals_to_rec, k_faces_unfold, k_unpredict -> attribute records -> D2H
 // Reference: formats/hry/reader.cc:179-193, cbm/decoder.h:27-211, attrcode.h:533-550.
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 
@@ -120,9 +121,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	}
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	auto t_walk = Clock::now();
-	std::vector<uint32_t> order_v, seg_start;
-	std::vector<uint8_t> seg_dep;
-	cut_border_replay(*m, conn, order_v, seg_start, seg_dep);
+	std::vector<uint32_t> order_v, seg_start, seg_level;
+	cut_border_replay(*m, conn, order_v, seg_start, seg_level);
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
 	const uint32_t nvc = (uint32_t)order_v.size();
@@ -141,30 +141,35 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 			// One wavefront per attribute component and per independent connected component; residual codes come straight
 			// from the decoded byte planes.  Components that read vertices coded before them (shared non-manifold vertices)
 			// run afterwards, in order, in one chain.
-			std::vector<uint32_t> segs, off_a{ 0 }, off_b{ 0 };
-			std::vector<uint32_t> dep_segs;
-			for (size_t k = 0; k + 1 < seg_start.size(); ++k) {
-				if (seg_start[k] == seg_start[k + 1]) continue;
-				if (seg_dep[k]) { dep_segs.push_back(seg_start[k]); dep_segs.push_back(seg_start[k + 1]); }
-				else { segs.push_back(seg_start[k]); segs.push_back(seg_start[k + 1]); off_a.push_back((uint32_t)segs.size() / 2); }
-			}
-			const uint32_t n_indep = (uint32_t)off_a.size() - 1;
-			const uint32_t dep_first = (uint32_t)segs.size() / 2;
-			segs.insert(segs.end(), dep_segs.begin(), dep_segs.end());
-			off_b[0] = dep_first;
-			off_b.push_back((uint32_t)segs.size() / 2);
-			std::vector<uint32_t> table(segs);
-			const size_t o_a = table.size();
-			table.insert(table.end(), off_a.begin(), off_a.end());
-			const size_t o_b = table.size();
-			table.insert(table.end(), off_b.begin(), off_b.end());
+			// Components whose vertices are all their own are independent chains (level 0).  A component that touches a
+			// vertex coded earlier (shared non-manifold vertex) runs one level after the component owning it.  One launch
+			// per level, every component of a level in its own wavefronts.
+			uint32_t max_level = 0;
+			for (uint32_t lv : seg_level) max_level = std::max(max_level, lv);
+			std::vector<std::vector<uint32_t>> by_level(max_level + 1);
+			for (size_t k = 0; k + 1 < seg_start.size(); ++k)
+				if (seg_start[k] != seg_start[k + 1]) { by_level[seg_level[k]].push_back(seg_start[k]); by_level[seg_level[k]].push_back(seg_start[k + 1]); }
+			std::vector<uint32_t> table;
+			std::vector<size_t> seg_at, off_at;
+			for (auto &lv : by_level) { seg_at.push_back(table.size()); table.insert(table.end(), lv.begin(), lv.end()); }
+			for (auto &lv : by_level) { off_at.push_back(table.size()); for (uint32_t i = 0; i <= lv.size() / 2; ++i) table.push_back(i); }
 			cx.d_small.ensure(table.size() * 4 + 64);
 			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
 			const uint32_t *d_tab = cx.d_small.as<uint32_t>();
 			const uint8_t *d_vplanes = cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes];
-			launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(), d_tab, d_tab + o_a, n_indep, true);
-			if (!dep_segs.empty())
-				launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(), d_tab, d_tab + o_b, 1, false);
+			bool first = true;
+			for (size_t lv = 0; lv < by_level.size(); ++lv) {
+				uint32_t nl = (uint32_t)by_level[lv].size() / 2;
+				if (!nl && !first) continue;
+				// a 2-D grid holds at most 65535 rows: split very wide levels
+				for (uint32_t done = 0; done < std::max(nl, 1u); done += 65535) {
+					uint32_t part = std::min(65535u, nl - std::min(nl, done));
+					launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
+					                  d_tab + seg_at[lv], d_tab + off_at[lv] + done, part, first);
+					first = false;
+					if (!nl) break;
+				}
+			}
 			HIP_OK(hipStreamSynchronize(cx.stream));   // the table lives in host memory until the copy has been consumed
 		} else {
 			launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);

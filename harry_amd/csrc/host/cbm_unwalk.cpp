@@ -3,6 +3,8 @@
 // formats/hry/io.h:168-231.  Same flat node pool as the encoder-side walk (cbm_walk.cpp).
 #include "host.hpp"
 
+#include <algorithm>
+
 namespace hry {
 namespace {
 
@@ -115,8 +117,9 @@ struct Planes {
 // planes: 21 connectivity planes in container order.  Fills m.face_off / org / twin and returns the decode order
 // (one half-edge per vertex; vertex ids are assigned in this order, cbm/decoder.h:48-75,145).
 void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
-                       std::vector<uint8_t> &seg_dep)
+                       std::vector<uint32_t> &seg_level)
 {
+	std::vector<uint32_t> seg_first;   // first vertex id assigned inside each component (ids are handed out in decode order)
 	const uint32_t nv = m.nv, nf = m.nf;
 	int ndeg = 0, onlydeg = 0;
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++ndeg; onlydeg = (int)d; }
@@ -127,7 +130,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 	m.org.reserve((size_t)nf * 3); m.twin.reserve((size_t)nf * 3);
 	order_v.clear();
 	order_v.reserve(nv);
-	seg_start.clear(); seg_dep.clear();
+	seg_start.clear(); seg_level.clear();
 	std::vector<uint16_t> seen(nv, 0);
 	Ring cb;
 	uint32_t next_id = 0;
@@ -152,7 +155,16 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 		// (TRIxxx start, or an NM operation naming an older vertex)
 		const uint32_t seg_first_id = next_id;
 		seg_start.push_back((uint32_t)order_v.size());
-		seg_dep.push_back(iop != I_INIT ? 1 : 0);
+		seg_first.push_back(seg_first_id);
+		seg_level.push_back(0);
+		// level = 1 + the highest level among the components that own an older vertex this component touches
+		auto depends_on = [&](uint32_t vid) {
+			if (vid >= seg_first_id) return;
+			size_t owner = (size_t)(std::upper_bound(seg_first.begin(), seg_first.end(), vid) - seg_first.begin()) - 1;
+			// a component that created no vertex shares seg_first with its successor: upper_bound lands on the last such entry,
+			// which is at least as late as the true owner -- its level is >= the owner's level, so the bound stays valid
+			seg_level.back() = std::max(seg_level.back(), seg_level[owner] + 1);
+		};
 		switch (iop) {   // decoder.h:46-77
 		case I_INIT: a = next_id++; b = next_id++; c = next_id++; break;
 		case I_TRI100: a = rd.vertid(); b = next_id++; c = next_id++; break;
@@ -165,6 +177,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 		default: throw Error(HRY_E_FORMAT, "corrupt stream (init op)");
 		}
 		chk(a); chk(b); chk(c);
+		depends_on(a); depends_on(b); depends_on(c);
 		int ntri = rd.numtri(), curtri = 1;
 		++seen[a]; ++seen[b]; ++seen[c];
 		uint32_t base = new_face(ntri + 2);
@@ -267,7 +280,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
 			case O_NEWVTX: case O_NM: {
 				v2 = op == O_NEWVTX ? next_id++ : rd.vertid();
 				chk(v2);
-				if (op == O_NM && v2 < seg_first_id) seg_dep.back() = 1;
+				if (op == O_NM) depends_on(v2);
 				Ring::Part &p = cb.top();
 				first = p.tail;
 				second = cb.make(v2, 0);

@@ -46,9 +46,10 @@ struct WalkResult {
 void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true);
 
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
-// seg_start: first decode rank of every connected component (+ end sentinel); seg_dep[k] != 0: component k reads vertices coded earlier
+// seg_start: first decode rank of every connected component (+ end sentinel); seg_level[k]: 0 = the component touches no vertex
+// coded before it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
 void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
-                       std::vector<uint8_t> &seg_dep);
+                       std::vector<uint32_t> &seg_level);
 
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);
