@@ -151,6 +151,22 @@ class Mesh:
             L.hry_walk_free(w)
 
 
+def read_stream_host(data: bytes):
+    """Host-only serial half of reading a reference (v0.1) stream: (mesh with connectivity, order_v, vplanes, fplanes)."""
+    L = nat.load()
+    mh, w = C.c_void_p(), C.c_void_p()
+    nat.check(L.hry_stream_read_host(data, len(data), C.byref(mh), C.byref(w)))
+    try:
+        out = []
+        for name, dt in (("order_v", np.uint32), ("vplanes", np.uint8), ("fplanes", np.uint8)):
+            p = C.c_void_p()
+            n = L.hry_walk_get(w, name.encode(), C.byref(p))
+            out.append(np.frombuffer(C.string_at(p, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt))
+        return (Mesh(mh), *out)
+    finally:
+        L.hry_walk_free(w)
+
+
 class Codec:
     """Device context (one HIP device, one stream).  Raises HryError(E_NODEVICE) without a GPU: no CPU fallback."""
 

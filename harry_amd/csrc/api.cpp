@@ -9,7 +9,7 @@ using namespace hry;
 
 struct hry_ctx { Context cx; explicit hry_ctx(int d) : cx(d) {} };
 struct hry_mesh { Mesh m; };
-struct hry_walk { WalkResult w; uint32_t info[2]; };
+struct hry_walk { WalkResult w; uint32_t info[2]; std::vector<uint8_t> vplanes, fplanes; };
 
 static thread_local std::string g_last_error;
 
@@ -187,6 +187,8 @@ size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 	if (n == "op_t") return ret(r.op_t);
 	if (n == "op_pos") return ret(r.op_pos);
 	if (n == "info") { *ptr = w->info; return 2; }
+	if (n == "vplanes") return ret(w->vplanes);
+	if (n == "fplanes") return ret(w->fplanes);
 	if (n.size() == 8 && n.compare(0, 3, "grp") == 0 && n[3] >= '0' && n[3] < '0' + G_COUNT) {
 		int g = n[3] - '0';
 		if (n.compare(4, 4, "_val") == 0) return ret(r.grp_val[g]);
@@ -196,6 +198,24 @@ size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 	return 0;
 }
 void hry_walk_free(hry_walk *w) { delete w; }
+
+int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_walk **out)
+{
+	if (!hry || !mesh || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*mesh = nullptr; *out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<hry_mesh> m(new hry_mesh());
+		std::unique_ptr<hry_walk> w(new hry_walk());
+		int minor = 0;
+		size_t hdr = read_hry_header((const uint8_t*)hry, bytes, m->m, minor);
+		if (minor != 1) throw Error(HRY_E_ARG, "not a single-stream (v0.1) file");
+		std::vector<uint32_t> seg_start, seg_level;
+		read_compat_stream((const uint8_t*)hry + hdr, bytes - hdr, m->m, w->w.order_v, seg_start, seg_level, w->vplanes, w->fplanes);
+		w->info[0] = w->info[1] = 0;
+		*mesh = m.release();
+		*out = w.release();
+	});
+}
 
 int hry_range_encode_lht(hry_ctx *ctx, const uint64_t *lht, size_t n, uint8_t **out, size_t *out_len)
 {

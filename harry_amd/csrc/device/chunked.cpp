@@ -220,6 +220,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 // decode
 // ---------------------------------------------------------------------------------------------------------
 Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
+Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 
 Mesh *decode_any(Context &cx, const uint8_t *p, size_t n)
 {
@@ -228,8 +229,7 @@ Mesh *decode_any(Context &cx, const uint8_t *p, size_t n)
 	int minor = 0;
 	size_t hdr = read_hry_header(p, n, *m, minor);
 	if (minor == 2) return decode_chunked(cx, p, n, hdr, std::move(m));
-	throw Error(HRY_E_UNSUPPORTED, "decoding the reference's single-stream format (v0.1) is a strictly serial chain (SURVEY.md App. C-4) and is not on the device path; "
-	                               "transcode with the chunked profile");
+	return decode_compat(cx, p, n, hdr, std::move(m));
 }
 
 }   // namespace hry

@@ -32,6 +32,76 @@ static const int kConnPlanes = 21;
 
 static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0 : i == 12 ? INIT_NT1 : i >= 13 ? INIT_OP : INIT_ONES; }
 
+// Attribute reconstruction on the device, shared by both formats: connectivity + decode order + residual byte planes
+// (already in HBM) -> attribute records.  Events 3/4 bracket the kernels.
+static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+                                   const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
+                                   const ListDesc &ldv, const ListDesc &ldf)
+{
+	Mesh *m = &mesh;
+	const uint32_t nvc = (uint32_t)order_v.size();
+	cx.upload_mesh(*m);   // connectivity + (zeroed) records
+	ConnView cv = cx.conn_view();
+	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
+	if (nvc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
+	cx.d_cscratch.ensure(std::max<size_t>((size_t)nvc * (8 * 3 * 4 + 1) + 64, 16));
+	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
+	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nvc * 24);
+	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
+	if (ldv.nplanes) {
+		if (unpredict2_applicable(ldv)) {
+			// One wavefront per attribute component and per independent connected component; residual codes come straight
+			// from the decoded byte planes.  Components that read vertices coded before them (shared non-manifold vertices)
+			// run afterwards, in order, in one chain.
+			// Components whose vertices are all their own are independent chains (level 0).  A component that touches a
+			// vertex coded earlier (shared non-manifold vertex) runs one level after the component owning it.  One launch
+			// per level, every component of a level in its own wavefronts.
+			uint32_t max_level = 0;
+			for (uint32_t lv : seg_level) max_level = std::max(max_level, lv);
+			std::vector<std::vector<uint32_t>> by_level(max_level + 1);
+			for (size_t k = 0; k + 1 < seg_start.size(); ++k)
+				if (seg_start[k] != seg_start[k + 1]) { by_level[seg_level[k]].push_back(seg_start[k]); by_level[seg_level[k]].push_back(seg_start[k + 1]); }
+			std::vector<uint32_t> table;
+			std::vector<size_t> seg_at, off_at;
+			for (auto &lv : by_level) { seg_at.push_back(table.size()); table.insert(table.end(), lv.begin(), lv.end()); }
+			for (auto &lv : by_level) { off_at.push_back(table.size()); for (uint32_t i = 0; i <= lv.size() / 2; ++i) table.push_back(i); }
+			cx.d_small.ensure(table.size() * 4 + 64);
+			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
+			const uint32_t *d_tab = cx.d_small.as<uint32_t>();
+						bool first = true;
+			for (size_t lv = 0; lv < by_level.size(); ++lv) {
+				uint32_t nl = (uint32_t)by_level[lv].size() / 2;
+				if (!nl && !first) continue;
+				// a 2-D grid holds at most 65535 rows: split very wide levels
+				for (uint32_t done = 0; done < std::max(nl, 1u); done += 65535) {
+					uint32_t part = std::min(65535u, nl - std::min(nl, done));
+					launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
+					                  d_tab + seg_at[lv], d_tab + off_at[lv] + done, part, first);
+					first = false;
+					if (!nl) break;
+				}
+			}
+			HIP_OK(hipStreamSynchronize(cx.stream));   // the table lives in host memory until the copy has been consumed
+		} else {
+			launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
+			launch_residuals_to_rec(cx.stream, d_vplanes, nvc, ldv, cx.d_rec[1].as<uint8_t>());
+			launch_unpredict(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv, cx.d_rec[1].as<uint8_t>());
+		}
+	}
+	if (ldf.nplanes) {
+		launch_residuals_to_rec(cx.stream, d_fplanes, m->nf, ldf, cx.d_rec[0].as<uint8_t>());
+		launch_faces_unfold(cx.stream, m->nf, ldf, cx.d_rec[0].as<uint8_t>());
+	}
+	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	for (int l = 0; l < 2; ++l)
+		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	if (cx.keep_stages) {
+		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
+		cx.stage_put("ncand", d_ncand, nvc);
+	}
+}
+
 Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
 {
 	auto t_all = Clock::now();
@@ -125,71 +195,11 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	cut_border_replay(*m, conn, order_v, seg_start, seg_level);
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
-	const uint32_t nvc = (uint32_t)order_v.size();
-
-	// ---- device: attribute reconstruction
-	cx.upload_mesh(*m);   // connectivity + (zeroed) records
-	ConnView cv = cx.conn_view();
-	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
-	if (nvc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
-	cx.d_cscratch.ensure(std::max<size_t>((size_t)nvc * (8 * 3 * 4 + 1) + 64, 16));
-	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
-	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nvc * 24);
-	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
-	if (ldv.nplanes) {
-		if (unpredict2_applicable(ldv)) {
-			// One wavefront per attribute component and per independent connected component; residual codes come straight
-			// from the decoded byte planes.  Components that read vertices coded before them (shared non-manifold vertices)
-			// run afterwards, in order, in one chain.
-			// Components whose vertices are all their own are independent chains (level 0).  A component that touches a
-			// vertex coded earlier (shared non-manifold vertex) runs one level after the component owning it.  One launch
-			// per level, every component of a level in its own wavefronts.
-			uint32_t max_level = 0;
-			for (uint32_t lv : seg_level) max_level = std::max(max_level, lv);
-			std::vector<std::vector<uint32_t>> by_level(max_level + 1);
-			for (size_t k = 0; k + 1 < seg_start.size(); ++k)
-				if (seg_start[k] != seg_start[k + 1]) { by_level[seg_level[k]].push_back(seg_start[k]); by_level[seg_level[k]].push_back(seg_start[k + 1]); }
-			std::vector<uint32_t> table;
-			std::vector<size_t> seg_at, off_at;
-			for (auto &lv : by_level) { seg_at.push_back(table.size()); table.insert(table.end(), lv.begin(), lv.end()); }
-			for (auto &lv : by_level) { off_at.push_back(table.size()); for (uint32_t i = 0; i <= lv.size() / 2; ++i) table.push_back(i); }
-			cx.d_small.ensure(table.size() * 4 + 64);
-			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
-			const uint32_t *d_tab = cx.d_small.as<uint32_t>();
-			const uint8_t *d_vplanes = cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes];
-			bool first = true;
-			for (size_t lv = 0; lv < by_level.size(); ++lv) {
-				uint32_t nl = (uint32_t)by_level[lv].size() / 2;
-				if (!nl && !first) continue;
-				// a 2-D grid holds at most 65535 rows: split very wide levels
-				for (uint32_t done = 0; done < std::max(nl, 1u); done += 65535) {
-					uint32_t part = std::min(65535u, nl - std::min(nl, done));
-					launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
-					                  d_tab + seg_at[lv], d_tab + off_at[lv] + done, part, first);
-					first = false;
-					if (!nl) break;
-				}
-			}
-			HIP_OK(hipStreamSynchronize(cx.stream));   // the table lives in host memory until the copy has been consumed
-		} else {
-			launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
-			launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], nvc, ldv, cx.d_rec[1].as<uint8_t>());
-			launch_unpredict(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv, cx.d_rec[1].as<uint8_t>());
-		}
-	}
-	if (ldf.nplanes) {
-		launch_residuals_to_rec(cx.stream, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], m->nf, ldf, cx.d_rec[0].as<uint8_t>());
-		launch_faces_unfold(cx.stream, m->nf, ldf, cx.d_rec[0].as<uint8_t>());
-	}
-	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
-	for (int l = 0; l < 2; ++l)
-		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
-	HIP_OK(hipStreamSynchronize(cx.stream));
+	reconstruct_attributes(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes],
+	                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf);
 	if (cx.keep_stages) {
 		cx.stage_put("dec_syms", cx.d_csyms.p, total_syms);
 		cx.stage_put_host("dec_nsym", nsym.data(), nsym.size() * 4);
-		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
-		cx.stage_put("ncand", d_ncand, nvc);
 	}
 	cx.timing.k_entropy_ms = cx.elapsed(1, 2);
 	cx.timing.k_predict_ms = cx.elapsed(3, 4);
@@ -198,6 +208,38 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	cx.timing.payload_bytes = payload_bytes;
 	cx.timing.total_ms = ms_since(t_all);
 	m->device_token = 0;   // the resident copy belongs to this context only until the next upload
+	return m.release();
+}
+
+// Reference format (.hry v0.1): the single adaptive stream is decoded and replayed on a host core (the format makes
+// both serial, compat_read.cpp); the residual planes then take the same device reconstruction as above.
+Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
+{
+	auto t_all = Clock::now();
+	cx.timing = hry_timing{};
+	const ListDesc ldv = make_list_desc(m->lists[1]), ldf = make_list_desc(m->lists[0]);
+	for (int l = 0; l < 2; ++l)
+		for (int c = 0; c < m->lists[l].ncomp(); ++c)
+			if (m->lists[l].stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
+	auto t_walk = Clock::now();
+	std::vector<uint32_t> order_v, seg_start, seg_level;
+	std::vector<uint8_t> vplanes, fplanes;
+	read_compat_stream(p + hdr, n - hdr, *m, order_v, seg_start, seg_level, vplanes, fplanes);
+	cx.timing.host_walk_ms = ms_since(t_walk);
+	auto t_h2d = Clock::now();
+	cx.d_csyms.ensure(std::max<size_t>(vplanes.size() + fplanes.size() + 64, 16));
+	uint8_t *d_v = cx.d_csyms.as<uint8_t>(), *d_f = d_v + vplanes.size();
+	if (!vplanes.empty()) HIP_OK(hipMemcpyAsync(d_v, vplanes.data(), vplanes.size(), hipMemcpyHostToDevice, cx.stream));
+	if (!fplanes.empty()) HIP_OK(hipMemcpyAsync(d_f, fplanes.data(), fplanes.size(), hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.h2d_ms = ms_since(t_h2d);
+	reconstruct_attributes(cx, *m, order_v, seg_start, seg_level, d_v, d_f, ldv, ldf);
+	cx.timing.k_predict_ms = cx.elapsed(3, 4);
+	cx.timing.device_ms = cx.timing.k_predict_ms;
+	cx.timing.n_symbols = vplanes.size() + fplanes.size();
+	cx.timing.payload_bytes = n - hdr;
+	cx.timing.total_ms = ms_since(t_all);
+	m->device_token = 0;
 	return m.release();
 }
 

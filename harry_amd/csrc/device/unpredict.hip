@@ -376,44 +376,26 @@ __global__ __launch_bounds__(64) void k_unpredict(ConnView cv, const uint32_t *o
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_unpredict2: the reconstruction chain, second structure.  Components are independent chains that share only the
-// candidate lists, so every component gets its own wavefront (one block per component, own LDS ring).  Inside a
-// wavefront a batch of 64 vertices is handled in two phases:
-//   prepare (lane i <-> vertex base+i, all lanes in parallel): gather every prediction source that lies BEFORE the
-//           batch (LDS ring, or HBM when older than the ring) and pre-evaluate every parallelogram whose three
-//           sources are ready; the residual code is read straight from the byte planes
-//   chain   (uniform loop over the batch): only sources inside the batch (typically the predecessor vertex) are still
-//           missing; they come out of a register vector with v_readlane.  No LDS or vector-memory access sits on the
-//           dependency chain, the arithmetic of integer components runs on the scalar unit.
+// k_unpredict2: the reconstruction chain.  Components are independent chains that share only the candidate lists,
+// so every component gets its own wavefront (one block per component, own LDS ring).  A single wavefront issues
+// about one instruction every 5-8 cycles whatever the instruction is, so the chain is organised to need as few
+// instructions per vertex as possible: a batch of 64 vertices is handled "systolically".
+//   prepare (lane j <-> vertex base+j, all lanes in parallel): gather every prediction source that lies BEFORE the
+//           batch (LDS ring, or HBM when older than the ring) into registers; a source inside the batch is recorded
+//           as the lane that will produce it.  The residual code is read straight from the byte planes.
+//   chain   (step i = 0..nb-1, fully unrolled): EVERY lane evaluates its own vertex from the sources it has (~20
+//           vector instructions for 16-bit components); lane i holds all its sources by then, so its value is final.
+//           The value is broadcast (v_readlane) and every lane that waits for lane i picks it up (compare + select per
+//           source).  No memory access, no branch and no scalar<->vector hand-over sits on the dependency chain.
+// Vertices with more than two candidates (0.3 % of a regular triangle mesh) end a batch and are evaluated on their own,
+// candidates across lanes; all their sources are older than the batch by construction.
 // Exactly the arithmetic of attrcode.h:182-208 / prediction.h:46-78,121-147 per vertex, in coding order.
 // ---------------------------------------------------------------------------------------------------------
-
-// ---- branch-free scalar forms for the chain (uniform values: every taken branch costs an instruction-fetch bubble
-// of a single wavefront, so the common cases are written with selects).  Same results as codec_math.hpp.
-__device__ __forceinline__ uint32_t usel(bool c, uint32_t a, uint32_t b) { return b ^ ((a ^ b) & (0u - (uint32_t)c)); }
-
-// parallelogram of unsigned values of at most 16 bits, computed in 32-bit: prediction.h:121-138
-template <typename T> __device__ __forceinline__ uint32_t paral_small(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t top)
+__device__ __forceinline__ uint32_t med3_i32(int32_t x, int32_t lo, int32_t hi)
 {
-	int32_t x = (int32_t)v0 + (int32_t)v1 - (int32_t)v2;
-	uint32_t lo = x < 0 ? 0u : (uint32_t)x;                 // v1 < v2: max(0, v0 - (v2 - v1)), never clamped at the top
-	uint32_t hi = (uint32_t)x > top ? top : (uint32_t)x;    // v1 >= v2: saturates at the top (type wrap included)
-	return usel(v1 < v2, lo, hi) & (uint32_t)(T)(~T(0));
-}
-// inverse residual code of unsigned values of at most 16 bits: prediction.h:46-64
-template <typename T> __device__ __forceinline__ uint32_t unfold_small(uint32_t code, uint32_t pred, uint32_t top)
-{
-	// prediction.h:46-64 with the two far branches reduced: room >= pred => bal = pred - 1 and pred + code - bal - 1 == code;
-	// room < pred => bal = room and pred - code + bal == top - code
-	const uint32_t M = (uint32_t)(T)(~T(0));
-	uint32_t room = (top - pred) & M;
-	uint32_t pm1 = (pred - 1u) & M;
-	uint32_t bal = pm1 < room ? pm1 : room;
-	uint32_t half = code >> 1;
-	uint32_t far = room >= pred ? code : (top - code) & M;
-	uint32_t nearv = ((code & 1u) ? pred - half - 1u : pred + half) & M;
-	uint32_t r = half > bal ? far : nearv;
-	return pred == 0 ? code : r;
+	int32_t r;
+	asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+	return (uint32_t)r;
 }
 
 template <typename T>
@@ -450,6 +432,123 @@ __device__ __forceinline__ T chain_predict(uint32_t ncu, const T *pv)
 	}
 }
 
+// ---- per-lane evaluation of one vertex with at most two candidates: six source bit patterns -> value bit pattern.
+// Three tiers: unsigned components of at most 16 bits (quantised attributes, the headline case) in trimmed 32-bit
+// arithmetic, float / 32-bit unsigned branch-free, every other type through the generic functions of codec_math.hpp.
+template <typename T> struct LaneEval {
+	typedef typename cm::word<sizeof(T)>::u U;
+	int q;
+	uint32_t nc, code;
+	__device__ __forceinline__ void setup(uint32_t nc_, uint32_t code_, int q_) { nc = nc_; code = code_; q = q_; }
+	__device__ __forceinline__ uint32_t eval(const uint32_t (&s)[6]) const
+	{
+		T p0 = cm::parallelogram<T>(cm::bits<T>((U)s[0]), cm::bits<T>((U)s[1]), cm::bits<T>((U)s[2]), q);
+		T p1 = cm::parallelogram<T>(cm::bits<T>((U)s[3]), cm::bits<T>((U)s[4]), cm::bits<T>((U)s[5]), q);
+		typedef typename cm::wide<T>::type W;
+		T two = (T)cm::mean_of((W)p0 + (W)p1, (W)2);
+		T pred = nc == 2 ? two : nc == 1 ? p0 : T(0);
+		return (uint32_t)cm::bits<U>(cm::value_from_residual<T>((U)code, pred, q));
+	}
+};
+
+// prediction.h:46-64 for unsigned words, far branches reduced (room >= pred: bal = pred - 1, pred + code - bal - 1 == code;
+// room < pred: bal = room, pred - code + bal == top - code); everything that does not depend on the prediction is
+// computed once per vertex
+struct UnfoldPre {
+	uint32_t code, half, top_minus_code, delta;
+	__device__ __forceinline__ void setup(uint32_t c, uint32_t top, uint32_t wrap_mask)
+	{
+		code = c;
+		half = c >> 1;
+		top_minus_code = (top - c) & wrap_mask;
+		delta = (c & 1u) ? 0u - half - 1u : half;
+	}
+	__device__ __forceinline__ uint32_t apply(uint32_t pred, uint32_t top) const
+	{
+		uint32_t room = top - pred;
+		uint32_t pm1 = pred - 1u;
+		uint32_t bal = pm1 < room ? pm1 : room;
+		uint32_t far = room >= pred ? code : top_minus_code;
+		uint32_t r = half > bal ? far : pred + delta;
+		return pred == 0 ? code : r;
+	}
+};
+
+template <typename T> struct LaneEvalSmall {   // uint8_t / uint16_t
+	uint32_t top;
+	UnfoldPre uf;
+	__device__ __forceinline__ void setup(uint32_t nc_, uint32_t code_, int q_)
+	{
+		top = (uint32_t)cm::ones<T>(q_ == 0 ? (int)sizeof(T) * 8 : q_);
+		uf.setup(code_, top, (uint32_t)(T)(~T(0)));
+	}
+	// The caller duplicates the single candidate of a vertex with one candidate ((2p + 1) >> 1 == p) and zeroes the
+	// sources of a vertex without candidates, so the mean of two is the prediction in every case.
+	__device__ __forceinline__ uint32_t eval(const uint32_t (&s)[6]) const
+	{
+		// prediction.h:121-138: v1 < v2 -> max(0, v0 - d), else min(top, v0 + d) (type wrap of v0 + d included); with all
+		// three values in [0, top] both are the clamp of v0 + v1 - v2 to [0, top]
+		uint32_t p0 = med3_i32((int32_t)(s[0] + s[1] - s[2]), 0, (int32_t)top);
+		uint32_t p1 = med3_i32((int32_t)(s[3] + s[4] - s[5]), 0, (int32_t)top);
+		return uf.apply((p0 + p1 + 1u) >> 1, top);
+	}
+};
+template <> struct LaneEval<uint8_t> : LaneEvalSmall<uint8_t> {};
+template <> struct LaneEval<uint16_t> : LaneEvalSmall<uint16_t> {};
+
+template <> struct LaneEval<uint32_t> {
+	uint32_t top, nc;
+	UnfoldPre uf;
+	__device__ __forceinline__ void setup(uint32_t nc_, uint32_t code_, int q_)
+	{
+		nc = nc_;
+		top = cm::ones<uint32_t>(q_ == 0 ? 32 : q_);
+		uf.setup(code_, top, 0xffffffffu);
+	}
+	static __device__ __forceinline__ uint32_t paral(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t top)
+	{
+		uint32_t dn = v2 - v1, dp = v1 - v2;
+		uint32_t lo = dn > v0 ? 0u : v0 - dn;
+		uint32_t v = v0 + dp;
+		uint32_t hi = ((v > top) | (v < v0)) ? top : v;
+		return v1 < v2 ? lo : hi;
+	}
+	__device__ __forceinline__ uint32_t eval(const uint32_t (&s)[6]) const
+	{
+		uint32_t p0 = paral(s[0], s[1], s[2], top), p1 = paral(s[3], s[4], s[5], top);
+		uint32_t two = (uint32_t)(((uint64_t)p0 + p1 + 1u) >> 1);
+		uint32_t pred = nc == 2 ? two : nc == 1 ? p0 : 0u;
+		return uf.apply(pred, top);
+	}
+};
+
+template <> struct LaneEval<float> {
+	uint32_t nc;
+	UnfoldPre uf;
+	__device__ __forceinline__ void setup(uint32_t nc_, uint32_t code_, int)
+	{
+		nc = nc_;
+		uf.setup(code_, 0xffffffffu, 0xffffffffu);
+	}
+	__device__ __forceinline__ uint32_t eval(const uint32_t (&s)[6]) const
+	{
+		float p0 = cm::bits<float>(s[0]) + (cm::bits<float>(s[1]) - cm::bits<float>(s[2]));
+		float p1 = cm::bits<float>(s[3]) + (cm::bits<float>(s[4]) - cm::bits<float>(s[5]));
+		// n = 2: mean in double, nearest candidate with strict <, the first one wins (attrcode.h:182-208)
+		float avg = (float)(((double)p0 + (double)p1) / 2.0);
+		float best = 3.402823466e+38f;
+		float db = avg > best ? avg - best : best - avg, dp = avg > p0 ? avg - p0 : p0 - avg;
+		best = db < dp ? best : p0;
+		db = avg > best ? avg - best : best - avg; dp = avg > p1 ? avg - p1 : p1 - avg;
+		float two = db < dp ? best : p1;
+		float pred = nc == 2 ? two : nc == 1 ? p0 : 0.0f;
+		// transform.h:19-23 ordered-int map on both sides, prediction.h:33-44: no sign flip for 4-byte values
+		return cm::bits<uint32_t>(cm::f32_from_ordered(uf.apply(cm::ordered_from_f32(pred), 0xffffffffu)));
+	}
+};
+
+constexpr uint32_t kNoLane = 64;   // tag of a source that is already present
+
 template <typename T>
 __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                      const uint8_t *planes, uint8_t *rec, int stride, int off, int q, int plane0,
@@ -457,18 +556,20 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 {
 	// this call reconstructs the vertices [seg_begin, nvtx) of one component; the ring holds only vertices >= seg_begin
 	typedef typename cm::word<sizeof(T)>::u U;
+	typedef typename cm::wide<T>::type W;
 	static_assert(sizeof(T) <= 4, "8-byte components use the generic kernel");
+	constexpr bool kSmallUnsigned = !cm::is_fp<T>::value && sizeof(T) <= 2 && !(T(-1) < T(0));
 	const int lane = threadIdx.x;
 	const uint32_t mask = ring_n - 1;
-	uint4 nid[6];
+	uint4 nid[2];
 	uint32_t nnc = 0, ncode = 0;
 	auto prefetch = [&](uint32_t b) {
 		uint32_t v = b + lane;
 		nnc = 0; ncode = 0;
+		nid[0] = nid[1] = make_uint4(0, 0, 0, 0);
 		if (v < nvtx) {
 			const uint4 *src = (const uint4*)(cand + (size_t)v * (kCandMax * 3));
-#pragma unroll
-			for (int k = 0; k < 6; ++k) nid[k] = src[k];
+			nid[0] = src[0]; nid[1] = src[1];   // the ids of the first two candidates
 			nnc = ncand[v];
 #pragma unroll
 			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) ncode |= (uint32_t)planes[(size_t)(plane0 + b8) * nvtx_total + v] << (8 * b8);
@@ -484,37 +585,48 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 	prefetch(seg_begin);
 	uint32_t base = seg_begin;
 	while (base < nvtx) {
-		uint32_t ids[kCandMax * 3];
-#pragma unroll
-		for (int k = 0; k < 6; ++k) { ids[4 * k] = nid[k].x; ids[4 * k + 1] = nid[k].y; ids[4 * k + 2] = nid[k].z; ids[4 * k + 3] = nid[k].w; }
+		const uint32_t ids[6] = { nid[0].x, nid[0].y, nid[0].z, nid[0].w, nid[1].x, nid[1].y };
 		const uint32_t nc = nnc;
 		const uint32_t code = ncode;
 		uint32_t nb = min(64u, nvtx - base);
-		const uint64_t ovf = __ballot(nc == 0xff);
-		if (ovf & 1ull) {
-			// more candidates than the table holds (very high valence), first vertex of the batch: every source is older,
-			// walk the fan right here (uniform work, all lanes compute the same value)
-			typedef typename cm::wide<T>::type W;
+		const uint64_t big = __ballot(nc > 2);
+		if (big & 1ull) {
+			// More than two candidates: this vertex is evaluated on its own; every source is older than it.  Up to
+			// kCandMax candidates sit in the table (lane k evaluates candidate k, the mean and the selection run over
+			// them in table order); beyond that the fan is walked right here (uniform work).
 			const uint32_t v = base;
-			W acc = 0;
-			uint32_t n = 0;
-			fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-				acc = acc + (W)cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
-				++n;
-			});
+			const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nc);
 			T pred = T(0);
-			if (n) {
-				T avg = (T)cm::mean_of(acc, (W)n);
-				if constexpr (!cm::is_fp<T>::value) pred = avg;
-				else {
-					T best = 3.402823466e+38f;
-					fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-						T p = cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
-						T db = avg > best ? avg - best : best - avg;
-						T dp = avg > p ? avg - p : p - avg;
-						best = db < dp ? best : p;
-					});
-					pred = best;
+			if (n0 != 0xff) {
+				uint32_t pk = 0;
+				if ((uint32_t)lane < n0) {
+					const uint32_t *cs = cand + (size_t)v * (kCandMax * 3) + 3 * lane;
+					pk = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(old_value(cs[0], v)), cm::bits<T>(old_value(cs[1], v)), cm::bits<T>(old_value(cs[2], v)), q));
+				}
+				T pv[kCandMax];
+#pragma unroll
+				for (int k = 0; k < kCandMax; ++k) pv[k] = cm::bits<T>((U)rl(pk, k));
+				pred = chain_predict<T>(n0, pv);
+			} else {
+				W acc = 0;
+				uint32_t n = 0;
+				fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
+					acc = acc + (W)cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
+					++n;
+				});
+				if (n) {
+					T avg = (T)cm::mean_of(acc, (W)n);
+					if constexpr (!cm::is_fp<T>::value) pred = avg;
+					else {
+						T best = 3.402823466e+38f;
+						fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
+							T p = cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
+							T db = avg > best ? avg - best : best - avg;
+							T dp = avg > p ? avg - p : p - avg;
+							best = db < dp ? best : p;
+						});
+						pred = best;
+					}
 				}
 			}
 			const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)code);
@@ -528,102 +640,115 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			prefetch(base);
 			continue;
 		}
-		if (ovf) nb = min(nb, (uint32_t)__builtin_ctzll(ovf));
-		// ---- prepare: lane i <-> vertex base + i
-		uint32_t src[kCandMax * 3];   // bit patterns; src[3k] holds the finished parallelogram when candidate k is ready
-		uint32_t flags = 0;           // bit 3k+j: source j of candidate k lies inside this batch
+		if (big) nb = min(nb, (uint32_t)__builtin_ctzll(big));
+		// ---- prepare: lane j <-> vertex base + j
+		uint32_t src[6], tag[6];
 #pragma unroll
-		for (int k = 0; k < kCandMax; ++k) {
-			src[3 * k] = 0; src[3 * k + 1] = 0; src[3 * k + 2] = 0;
-			if ((uint32_t)k < nc && lane < (int)nb) {
-				uint32_t f = 0;
+		for (int k = 0; k < 2; ++k) {
 #pragma unroll
-				for (int j = 0; j < 3; ++j) {
-					uint32_t id = ids[3 * k + j];
-					if (id >= base) { f |= 1u << j; src[3 * k + j] = 0x80000000u | (id - base); }   // inside the batch: keep the lane of its value
+			for (int j = 0; j < 3; ++j) {
+				src[3 * k + j] = 0; tag[3 * k + j] = kNoLane;
+				if ((uint32_t)k < nc && lane < (int)nb) {
+					const uint32_t id = ids[3 * k + j];
+					if (id >= base) tag[3 * k + j] = id - base;   // produced inside this batch, by an earlier lane
 					else src[3 * k + j] = (uint32_t)old_value(id, base);
 				}
-				if (f == 0) src[3 * k] = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>((U)src[3 * k]), cm::bits<T>((U)src[3 * k + 1]), cm::bits<T>((U)src[3 * k + 2]), q));
-				flags |= f << (3 * k);
 			}
 		}
+		if constexpr (kSmallUnsigned) {
+			if (nc == 1) {   // LaneEvalSmall: a lone candidate counts twice
+#pragma unroll
+				for (int j = 0; j < 3; ++j) { src[3 + j] = src[j]; tag[3 + j] = tag[j]; }
+			}
+		}
+		LaneEval<T> ev;
+		ev.setup(nc, code, q);
 		// Every prepare load has landed before the next batch is requested: the memory counters retire in order, so a
 		// prefetch issued earlier would be waited for together with the first prepare load, and the chain below must not
 		// contain a single wait.  The prefetch then overlaps the whole chain.
 		__builtin_amdgcn_s_waitcnt(0);
 		prefetch(base + nb);
 		// ---- chain
-		uint32_t vals = 0;   // lane j: bit pattern of the reconstructed value of vertex base + j
-		constexpr bool kSmallUnsigned = !cm::is_fp<T>::value && sizeof(T) <= 2 && !(T(-1) < T(0));
-		constexpr bool kFast = kSmallUnsigned || cm::is_fp<T>::value;
-		const uint32_t top = (uint32_t)cm::ones<typename std::conditional<kSmallUnsigned, T, uint32_t>::type>(q == 0 ? (int)sizeof(T) * 8 : q);
-		for (uint32_t i = 0; i < nb; ++i) {
-			const uint32_t ncu = rl(nc, i);
-			const uint32_t fl = rl(flags, i);
-			T pred;
-			bool done = false;
-			if constexpr (kFast) {
-				if (ncu <= 2) {
-					// at most two candidates (the rule in a manifold triangle mesh): straight-line code, no branches.
-					// source = prepared value, or the value of a vertex of this batch taken from the register vector
-					uint32_t a0, b0, o0, a1, b1, o1;
-					if constexpr (kSmallUnsigned) {
-						// values are at most 16 bits: bit 31 of the prepared word marks "inside the batch", bits 0-5 the lane
-#define HRY_SRC(dst, j) { const uint32_t w_ = rl(src[j], i); const uint32_t in_ = rl(vals, w_ & 63u); dst = (int32_t)w_ < 0 ? in_ : w_; }
-						HRY_SRC(a0, 0) HRY_SRC(b0, 1) HRY_SRC(o0, 2) HRY_SRC(a1, 3) HRY_SRC(b1, 4) HRY_SRC(o1, 5)
-#undef HRY_SRC
-					} else {
-#define HRY_SRC(j) usel((fl >> (j)) & 1u, rl(vals, (rl(ids[j], i) - base) & 63u), rl(src[j], i))
-						a0 = HRY_SRC(0); b0 = HRY_SRC(1); o0 = HRY_SRC(2); a1 = HRY_SRC(3); b1 = HRY_SRC(4); o1 = HRY_SRC(5);
-#undef HRY_SRC
-					}
-					if constexpr (kSmallUnsigned) {
-						uint32_t p0 = usel((fl & 7u) == 0, rl(src[0], i), paral_small<T>(a0, b0, o0, top));
-						uint32_t p1 = usel(((fl >> 3) & 7u) == 0, rl(src[3], i), paral_small<T>(a1, b1, o1, top));
-						uint32_t two = (p0 + p1 + 1u) >> 1;
-						pred = (T)usel(ncu == 2, two, usel(ncu == 1, p0, 0u));
-					} else {
-						float p0 = cm::bits<float>(usel((fl & 7u) == 0, rl(src[0], i), cm::bits<uint32_t>(cm::bits<float>(a0) + (cm::bits<float>(b0) - cm::bits<float>(o0)))));
-						float p1 = cm::bits<float>(usel(((fl >> 3) & 7u) == 0, rl(src[3], i), cm::bits<uint32_t>(cm::bits<float>(a1) + (cm::bits<float>(b1) - cm::bits<float>(o1)))));
-						// n = 2: mean in double, halved (exactly the division by 2.0), nearest candidate with strict <, first wins
-						float avg = (float)(((double)p0 + (double)p1) * 0.5);
-						float best = 3.402823466e+38f;
-						float db = avg > best ? avg - best : best - avg, dp = avg > p0 ? avg - p0 : p0 - avg;
-						best = db < dp ? best : p0;
-						db = avg > best ? avg - best : best - avg; dp = avg > p1 ? avg - p1 : p1 - avg;
-						float two = db < dp ? best : p1;
-						pred = cm::bits<float>(usel(ncu == 2, cm::bits<uint32_t>(two), usel(ncu == 1, cm::bits<uint32_t>(p0), 0u)));
-					}
-					done = true;
-				}
-			}
-			if (!done) {
-				T pv[kCandMax];
+		uint32_t val = 0;
+		if constexpr (kSmallUnsigned) {
+			// One step, hand-scheduled: 33 instructions, every hazard distance of gfx950 (VALU-written SGPR read by a VALU: 2
+			// wait states, VALU-written VGPR read by v_readlane: 1) is covered by independent instructions instead of s_nop,
+			// each of which would cost this lone wavefront a full issue slot.  Same arithmetic as LaneEvalSmall::eval.
+			const uint32_t top = ev.top, c_code = ev.uf.code, c_half = ev.uf.half, c_tmc = ev.uf.top_minus_code, c_delta = ev.uf.delta;
+#define HRY_STEP(I)                                                                                                     \
+			asm("v_add_u32 v100, %[a0], %[b0]\n\t"                                                                      \
+			    "v_add_u32 v101, %[a1], %[b1]\n\t"                                                                      \
+			    "v_sub_u32 v100, v100, %[o0]\n\t"                                                                       \
+			    "v_sub_u32 v101, v101, %[o1]\n\t"                                                                       \
+			    "v_med3_i32 v100, v100, 0, %[top]\n\t"                                                                  \
+			    "v_med3_i32 v101, v101, 0, %[top]\n\t"                                                                  \
+			    "v_add3_u32 v102, v100, v101, 1\n\t"                                                                    \
+			    "v_lshrrev_b32 v103, 1, v102\n\t"                                                                       \
+			    "v_sub_u32 v104, %[top], v103\n\t"                                                                      \
+			    "v_add_u32 v105, -1, v103\n\t"                                                                          \
+			    "v_cmp_lt_u32 s[80:81], v104, v103\n\t"                                                                 \
+			    "v_min_u32 v105, v105, v104\n\t"                                                                        \
+			    "v_add_u32 v106, v103, %[delta]\n\t"                                                                    \
+			    "v_cmp_gt_u32 s[82:83], %[half], v105\n\t"                                                              \
+			    "v_cmp_gt_u32 s[84:85], 2, v102\n\t"                                                                    \
+			    "v_cndmask_b32 v107, %[code], %[tmc], s[80:81]\n\t"                                                     \
+			    "v_cmp_eq_u32 s[86:87], " #I ", %[t0]\n\t"                                                              \
+			    "v_cmp_eq_u32 s[88:89], " #I ", %[t1]\n\t"                                                              \
+			    "v_cndmask_b32 v107, v106, v107, s[82:83]\n\t"                                                          \
+			    "v_cmp_eq_u32 s[90:91], " #I ", %[t2]\n\t"                                                              \
+			    "v_cndmask_b32 %[val], v107, %[code], s[84:85]\n\t"                                                     \
+			    "v_cmp_eq_u32 s[92:93], " #I ", %[t3]\n\t"                                                              \
+			    "v_readlane_b32 s80, %[val], " #I "\n\t"                                                                \
+			    "v_cmp_eq_u32 s[94:95], " #I ", %[t4]\n\t"                                                              \
+			    "v_cmp_eq_u32 s[96:97], " #I ", %[t5]\n\t"                                                            \
+			    "v_mov_b32 v108, s80\n\t"                                                                               \
+			    "v_cndmask_b32 %[a0], %[a0], v108, s[86:87]\n\t"                                                        \
+			    "v_cndmask_b32 %[b0], %[b0], v108, s[88:89]\n\t"                                                        \
+			    "v_cndmask_b32 %[o0], %[o0], v108, s[90:91]\n\t"                                                        \
+			    "v_cndmask_b32 %[a1], %[a1], v108, s[92:93]\n\t"                                                        \
+			    "v_cndmask_b32 %[b1], %[b1], v108, s[94:95]\n\t"                                                        \
+			    "v_cndmask_b32 %[o1], %[o1], v108, s[96:97]"                                                           \
+			    : [a0] "+v"(src[0]), [b0] "+v"(src[1]), [o0] "+v"(src[2]), [a1] "+v"(src[3]), [b1] "+v"(src[4]), [o1] "+v"(src[5]),  \
+			      [val] "=&v"(val)                                                                                     \
+			    : [t0] "v"(tag[0]), [t1] "v"(tag[1]), [t2] "v"(tag[2]), [t3] "v"(tag[3]), [t4] "v"(tag[4]), [t5] "v"(tag[5]),   \
+			      [top] "s"(top), [code] "v"(c_code), [half] "v"(c_half), [tmc] "v"(c_tmc), [delta] "v"(c_delta)         \
+			    : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",  \
+			      "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
+#define HRY_STEP8(A, B, C, D, E, F, G, H) HRY_STEP(A) HRY_STEP(B) HRY_STEP(C) HRY_STEP(D) HRY_STEP(E) HRY_STEP(F) HRY_STEP(G) HRY_STEP(H)
+			do {   // steps past the end of a short batch only produce unused values: leave at multiples of eight
+				HRY_STEP8(0, 1, 2, 3, 4, 5, 6, 7)
+				if (nb <= 8) break;
+				HRY_STEP8(8, 9, 10, 11, 12, 13, 14, 15)
+				if (nb <= 16) break;
+				HRY_STEP8(16, 17, 18, 19, 20, 21, 22, 23)
+				if (nb <= 24) break;
+				HRY_STEP8(24, 25, 26, 27, 28, 29, 30, 31)
+				if (nb <= 32) break;
+				HRY_STEP8(32, 33, 34, 35, 36, 37, 38, 39)
+				if (nb <= 40) break;
+				HRY_STEP8(40, 41, 42, 43, 44, 45, 46, 47)
+				if (nb <= 48) break;
+				HRY_STEP8(48, 49, 50, 51, 52, 53, 54, 55)
+				if (nb <= 56) break;
+				HRY_STEP8(56, 57, 58, 59, 60, 61, 62, 63)
+			} while (0);
+#undef HRY_STEP8
+#undef HRY_STEP
+		} else {
 #pragma unroll
-				for (int k = 0; k < kCandMax; ++k) {
-					if ((uint32_t)k < ncu) {
-						const uint32_t f = (fl >> (3 * k)) & 7u;
-						if (f == 0) pv[k] = cm::bits<T>((U)rl(src[3 * k], i));
-						else {
-							U s0 = (f & 1u) ? (U)rl(vals, rl(ids[3 * k], i) - base) : (U)rl(src[3 * k], i);
-							U s1 = (f & 2u) ? (U)rl(vals, rl(ids[3 * k + 1], i) - base) : (U)rl(src[3 * k + 1], i);
-							U s2 = (f & 4u) ? (U)rl(vals, rl(ids[3 * k + 2], i) - base) : (U)rl(src[3 * k + 2], i);
-							pv[k] = cm::parallelogram<T>(cm::bits<T>(s0), cm::bits<T>(s1), cm::bits<T>(s2), q);
-						}
-					}
-				}
-				pred = chain_predict<T>(ncu, pv);
+			for (uint32_t i = 0; i < 64; ++i) {
+				if ((i & 7u) == 0 && i >= nb) break;   // steps past the end of a short batch only produce unused values
+				val = ev.eval(src);
+				const uint32_t s = rl(val, i);
+#pragma unroll
+				for (int j = 0; j < 6; ++j) src[j] = tag[j] == i ? s : src[j];
 			}
-			uint32_t vbits;
-			if constexpr (kSmallUnsigned) vbits = unfold_small<T>(rl(code, i), (uint32_t)pred, top);
-			else vbits = (uint32_t)cm::bits<U>(cm::value_from_residual<T>((U)rl(code, i), pred, q));
-			if (lane == (int)i) vals = vbits;
 		}
 		// ---- publish the batch
 		if (lane < (int)nb) {
 			const uint32_t v = base + lane;
-			ring[v & mask] = (U)vals;
-			stq<T>(rec + (size_t)v * stride + off, cm::bits<T>((U)vals));
+			ring[v & mask] = (U)val;
+			stq<T>(rec + (size_t)v * stride + off, cm::bits<T>((U)val));
 		}
 		__syncthreads();
 		base += nb;

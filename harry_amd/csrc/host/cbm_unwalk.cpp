@@ -1,98 +1,8 @@
-// Host-side cut-border replay of the decoder: rebuilds the connectivity from the (already entropy-decoded)
-// connectivity symbol planes.  Behavioural contract: cbm/decoder.h:27-211, cbm/cutborder.h:49-333,
-// formats/hry/io.h:168-231.  Same flat node pool as the encoder-side walk (cbm_walk.cpp).
-#include "host.hpp"
-
-#include <algorithm>
+// Cut-border replay from entropy-decoded symbol planes (chunked profile).  See cbm_replay.hpp.
+#include "cbm_replay.hpp"
 
 namespace hry {
 namespace {
-
-constexpr uint32_t NONE32 = 0xffffffffu;
-enum InitOp { I_INIT, I_TRI100, I_TRI010, I_TRI001, I_TRI110, I_TRI101, I_TRI011, I_TRI111, I_EOM };
-enum Op { O_BORDER, O_CONNBWD, O_SPLIT, O_UNION, O_NM, O_NEWVTX, O_CONNFWD, O_CLOSE };
-
-struct Ring {
-	struct Node { uint32_t v, a; int32_t prev, next; };
-	struct Part { int32_t head, tail; uint32_t size; bool edge_begin; };
-	std::vector<Node> pool;
-	std::vector<int32_t> spare;
-	std::vector<Part> parts;
-	Part &top() { return parts.back(); }
-	int32_t make(uint32_t v, uint32_t a)
-	{
-		int32_t i;
-		if (!spare.empty()) { i = spare.back(); spare.pop_back(); }
-		else { i = (int32_t)pool.size(); pool.push_back(Node()); }
-		pool[i] = Node{ v, a, -1, -1 };
-		return i;
-	}
-	void drop(int32_t i) { spare.push_back(i); }
-	void append(Part &p, int32_t i)
-	{
-		pool[i].prev = p.tail; pool[i].next = -1;
-		if (p.tail >= 0) pool[p.tail].next = i; else p.head = i;
-		p.tail = i; ++p.size;
-	}
-	void prepend(Part &p, int32_t i)
-	{
-		pool[i].next = p.head; pool[i].prev = -1;
-		if (p.head >= 0) pool[p.head].prev = i; else p.tail = i;
-		p.head = i; ++p.size;
-	}
-	int32_t unlink_tail(Part &p)
-	{
-		int32_t i = p.tail;
-		p.tail = pool[i].prev;
-		if (p.tail >= 0) pool[p.tail].next = -1; else p.head = -1;
-		--p.size;
-		return i;
-	}
-	int32_t unlink_head(Part &p)
-	{
-		int32_t i = p.head;
-		p.head = pool[i].next;
-		if (p.head >= 0) pool[p.head].prev = -1; else p.tail = -1;
-		--p.size;
-		return i;
-	}
-	void discard_top()
-	{
-		for (int32_t i = top().head; i >= 0;) { int32_t nx = pool[i].next; drop(i); i = nx; }
-		parts.pop_back();
-	}
-	Op border()   // cutborder.h:217-248
-	{
-		Part &p = top();
-		if (p.size - (p.edge_begin ? 0 : 1) == 1) { discard_top(); return O_BORDER; }
-		bool rename = !p.edge_begin;
-		int32_t t = unlink_tail(p);
-		if (!p.edge_begin) drop(unlink_head(p));
-		prepend(p, t);
-		p.edge_begin = false;
-		return rename ? O_CONNFWD : O_BORDER;
-	}
-	// element addressed by a transmitted offset (cutborder.h:114-123): i > 0 from the front (1-based), i <= 0 from the back
-	int32_t at(int i, int p, uint32_t &before)
-	{
-		if ((size_t)p >= parts.size()) throw Error(HRY_E_FORMAT, "corrupt stream (part index)");
-		Part &pt = parts[parts.size() - 1 - (size_t)p];
-		int32_t n;
-		if (i > 0) {
-			if ((uint32_t)i > pt.size) throw Error(HRY_E_FORMAT, "corrupt stream (element offset)");
-			n = pt.head;
-			for (int k = 1; k < i; ++k) n = pool[n].next;
-			before = (uint32_t)(i - 1);
-		} else {
-			if ((uint32_t)(-i) >= pt.size) throw Error(HRY_E_FORMAT, "corrupt stream (element offset)");
-			n = pt.tail;
-			for (int k = 0; k < -i; ++k) n = pool[n].prev;
-			before = pt.size - 1 - (uint32_t)(-i);
-		}
-		return n;
-	}
-};
-
 struct Planes {
 	const std::vector<uint8_t> *pl;   // container order: iop, elem[4], part[2], vertid[4], numtri[2], op[8]
 	size_t cur[21] = { 0 };
@@ -119,212 +29,10 @@ struct Planes {
 void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
                        std::vector<uint32_t> &seg_level)
 {
-	std::vector<uint32_t> seg_first;   // first vertex id assigned inside each component (ids are handed out in decode order)
-	const uint32_t nv = m.nv, nf = m.nf;
 	int ndeg = 0, onlydeg = 0;
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++ndeg; onlydeg = (int)d; }
 	Planes rd{ conn_planes, { 0 }, ndeg <= 1 ? onlydeg - 2 : -1 };
-	m.face_off.assign(1, 0);
-	m.face_off.reserve((size_t)nf + 1);
-	m.org.clear(); m.twin.clear();
-	m.org.reserve((size_t)nf * 3); m.twin.reserve((size_t)nf * 3);
-	order_v.clear();
-	order_v.reserve(nv);
-	seg_start.clear(); seg_level.clear();
-	std::vector<uint16_t> seen(nv, 0);
-	Ring cb;
-	uint32_t next_id = 0;
-	auto new_face = [&](int ne) {
-		if (ne < 3 || ne > 255) throw Error(HRY_E_FORMAT, "corrupt stream (polygon degree)");
-		if (m.face_off.size() > nf) throw Error(HRY_E_FORMAT, "corrupt stream (too many faces)");
-		uint32_t o = m.face_off.back();
-		m.face_off.push_back(o + (uint32_t)ne);
-		m.org.resize(o + ne, 0);
-		m.twin.resize(o + ne);
-		for (int i = 0; i < ne; ++i) m.twin[o + i] = o + i;
-		return o;
-	};
-	auto link = [&](uint32_t a, uint32_t b) { m.twin[a] = b; m.twin[b] = a; };
-	auto chk = [&](uint32_t v) { if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)"); return v; };
-
-	for (;;) {
-		uint32_t iop = rd.iop();
-		if (iop == I_EOM) break;
-		uint32_t a = 0, b = 0, c = 0;
-		// a component is an independent reconstruction chain unless it touches vertices coded before it started
-		// (TRIxxx start, or an NM operation naming an older vertex)
-		const uint32_t seg_first_id = next_id;
-		seg_start.push_back((uint32_t)order_v.size());
-		seg_first.push_back(seg_first_id);
-		seg_level.push_back(0);
-		// level = 1 + the highest level among the components that own an older vertex this component touches
-		auto depends_on = [&](uint32_t vid) {
-			if (vid >= seg_first_id) return;
-			size_t owner = (size_t)(std::upper_bound(seg_first.begin(), seg_first.end(), vid) - seg_first.begin()) - 1;
-			// a component that created no vertex shares seg_first with its successor: upper_bound lands on the last such entry,
-			// which is at least as late as the true owner -- its level is >= the owner's level, so the bound stays valid
-			seg_level.back() = std::max(seg_level.back(), seg_level[owner] + 1);
-		};
-		switch (iop) {   // decoder.h:46-77
-		case I_INIT: a = next_id++; b = next_id++; c = next_id++; break;
-		case I_TRI100: a = rd.vertid(); b = next_id++; c = next_id++; break;
-		case I_TRI010: c = next_id++; b = rd.vertid(); a = next_id++; break;
-		case I_TRI001: a = next_id++; b = next_id++; c = rd.vertid(); break;
-		case I_TRI110: a = rd.vertid(); b = rd.vertid(); c = next_id++; break;
-		case I_TRI101: c = rd.vertid(); b = next_id++; a = rd.vertid(); break;
-		case I_TRI011: a = next_id++; b = rd.vertid(); c = rd.vertid(); break;
-		case I_TRI111: a = rd.vertid(); b = rd.vertid(); c = rd.vertid(); break;
-		default: throw Error(HRY_E_FORMAT, "corrupt stream (init op)");
-		}
-		chk(a); chk(b); chk(c);
-		depends_on(a); depends_on(b); depends_on(c);
-		int ntri = rd.numtri(), curtri = 1;
-		++seen[a]; ++seen[b]; ++seen[c];
-		uint32_t base = new_face(ntri + 2);
-		uint32_t e0 = base, e1 = base + 1, e2 = base + 2, fend = base + (uint32_t)ntri + 2;
-		m.org[e0] = a; m.org[e1] = b; m.org[e2] = c;
-		switch (iop) {   // decoder.h:86-110
-		case I_INIT: order_v.push_back(e0); order_v.push_back(e1); order_v.push_back(e2); break;
-		case I_TRI100: order_v.push_back(e1); order_v.push_back(e2); break;
-		case I_TRI010: order_v.push_back(e2); order_v.push_back(e0); break;
-		case I_TRI001: order_v.push_back(e0); order_v.push_back(e1); break;
-		case I_TRI110: order_v.push_back(e2); break;
-		case I_TRI101: order_v.push_back(e1); break;
-		case I_TRI011: order_v.push_back(e0); break;
-		default: break;
-		}
-		cb.parts.push_back(Ring::Part{ -1, -1, 0, true });
-		cb.append(cb.top(), cb.make(a, e0));
-		cb.append(cb.top(), cb.make(b, e1));
-		cb.append(cb.top(), cb.make(c, e2));
-
-		while (!cb.parts.empty()) {
-			Ring::Part &pt = cb.top();
-			const uint32_t v0 = cb.pool[pt.tail].v, v1 = cb.pool[pt.head].v;
-			const uint32_t gate = cb.pool[pt.tail].a;
-			if (pt.size < 2) throw Error(HRY_E_FORMAT, "corrupt stream (border part)");
-			const uint32_t gateprev = cb.pool[cb.pool[pt.tail].prev].a;
-			const uint32_t gatenext = cb.pool[pt.head].a;
-			const uint32_t op = rd.op(seen[v1]);
-			const bool seq_first = curtri == ntri;
-			uint32_t v2 = NONE32;
-			int32_t first = -1, second = -1;
-			uint32_t realop = op;
-			switch (op) {   // decoder.h:133-166
-			case O_CONNFWD: {
-				Ring::Part &p = cb.top();
-				if (!p.edge_begin) { realop = cb.border(); break; }   // renamed border (cutborder.h:177-179)
-				if (p.size < 2) throw Error(HRY_E_FORMAT, "corrupt stream (connect forward)");
-				v2 = cb.pool[cb.pool[p.head].next].v;
-				if (p.size == 3) { cb.discard_top(); realop = O_CLOSE; }
-				else { cb.drop(cb.unlink_head(p)); first = p.tail; realop = O_CONNFWD; }
-				break;
-			}
-			case O_CONNBWD: {
-				Ring::Part &p = cb.top();
-				if (p.size < 2) throw Error(HRY_E_FORMAT, "corrupt stream (connect backward)");
-				cb.drop(cb.unlink_tail(p));
-				first = p.tail;
-				v2 = cb.pool[p.tail].v;
-				break;
-			}
-			case O_SPLIT: {
-				int i = rd.elem();
-				uint32_t before;
-				int32_t hit = cb.at(i, 0, before);
-				size_t oi = cb.parts.size() - 1;
-				int32_t g = cb.unlink_tail(cb.parts[oi]);
-				if (hit == g) throw Error(HRY_E_FORMAT, "corrupt stream (split at the gate)");
-				Ring::Part np{ -1, -1, 0, true };
-				if (before > 0) {
-					Ring::Part &old = cb.parts[oi];
-					int32_t last = cb.pool[hit].prev;
-					np.head = old.head; np.tail = last; np.size = before;
-					cb.pool[last].next = -1; cb.pool[hit].prev = -1;
-					old.head = hit; old.size -= before;
-				}
-				cb.append(cb.parts[oi], g);
-				second = cb.make(cb.pool[hit].v, cb.pool[hit].a);
-				cb.append(np, second);
-				np.edge_begin = cb.parts[oi].edge_begin;
-				cb.parts[oi].edge_begin = true;
-				cb.parts.push_back(np);
-				first = g;
-				v2 = cb.pool[hit].v;
-				break;
-			}
-			case O_UNION: {
-				int i = rd.elem();
-				int p = rd.part();
-				if (p <= 0) throw Error(HRY_E_FORMAT, "corrupt stream (union with the current part)");
-				uint32_t before;
-				int32_t hit = cb.at(i, p, before);
-				size_t ci = cb.parts.size() - 1, oi = ci - (size_t)p;
-				Ring::Part other = cb.parts[oi];
-				Ring::Part &cur = cb.parts[ci];
-				first = cur.tail;
-				if (hit != other.head) {
-					cb.pool[other.tail].next = other.head; cb.pool[other.head].prev = other.tail;
-					int32_t last = cb.pool[hit].prev;
-					cb.pool[last].next = -1; cb.pool[hit].prev = -1;
-					other.head = hit; other.tail = last;
-				}
-				cb.pool[cur.tail].next = other.head; cb.pool[other.head].prev = cur.tail;
-				cur.tail = other.tail; cur.size += other.size;
-				second = cb.make(cb.pool[hit].v, cb.pool[hit].a);
-				cb.append(cur, second);
-				v2 = cb.pool[hit].v;
-				cb.parts.erase(cb.parts.begin() + (long)oi);
-				break;
-			}
-			case O_NEWVTX: case O_NM: {
-				v2 = op == O_NEWVTX ? next_id++ : rd.vertid();
-				chk(v2);
-				if (op == O_NM) depends_on(v2);
-				Ring::Part &p = cb.top();
-				first = p.tail;
-				second = cb.make(v2, 0);
-				cb.append(p, second);
-				break;
-			}
-			case O_BORDER: cb.border(); break;
-			default: throw Error(HRY_E_FORMAT, "corrupt stream (op)");
-			}
-			if (v2 == NONE32) continue;
-			uint32_t f0;
-			if (seq_first) {
-				ntri = rd.numtri();
-				curtri = 0;
-				base = new_face(ntri + 2);
-				fend = base + (uint32_t)ntri + 2;
-				e0 = base; e1 = base + 1; e2 = base + 2;
-				m.org[e0] = v1; m.org[e1] = v0; m.org[e2] = v2;
-			} else {
-				e1 = e1 + 1 == fend ? base : e1 + 1;
-				e2 = e1 + 1 == fend ? base : e1 + 1;
-				m.org[e2] = v2;
-			}
-			f0 = base;
-			const bool seq_last = curtri + 1 == ntri;
-			switch (realop) {   // decoder.h:182-197
-			case O_CONNFWD: cb.pool[first].a = e1; break;
-			case O_CONNBWD: cb.pool[first].a = e2; break;
-			case O_SPLIT: case O_UNION: case O_NEWVTX: case O_NM: cb.pool[first].a = e1; cb.pool[second].a = e2; break;
-			default: break;
-			}
-			++seen[v0]; ++seen[v1]; ++seen[v2];
-			if (op == O_NEWVTX) order_v.push_back(f0 + (uint32_t)curtri + 2);
-			++curtri;
-			if (seq_first) link(gate, e0);
-			if (op == O_CONNFWD) {
-				if (seq_last && realop != O_BORDER) link(gatenext, e2);
-				if (realop == O_CLOSE) link(gateprev, e1);
-			} else if (op == O_CONNBWD) link(gateprev, e1);
-		}
-	}
-	seg_start.push_back((uint32_t)order_v.size());
-	if (m.face_off.size() != (size_t)nf + 1) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
-	if (next_id > nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)");
+	cut_border_replay_with(m, rd, order_v, seg_start, seg_level);
 }
 
 }   // namespace hry

@@ -1,0 +1,176 @@
+// Reading the reference's single-stream format (.hry v0.1): the host side of the decoder.
+//
+// One adaptive arithmetic-coded stream carries everything (SURVEY.md finding 0-1), and a symbol can only be located
+// after every symbol before it has been decoded with its adapted model: this part is serial by construction of the
+// format, exactly like the cut-border replay it is interleaved with.  The host therefore does what the format forces
+// to be serial - entropy decoding and the replay - and hands the residual byte planes to the same device
+// reconstruction the chunked profile uses (unchunk.cpp).
+//
+// Behavioural contract: arith/coder.h:115-172 (decoder), arith/stat_adaptive.h:26-126 (adaptive tables),
+// formats/hry/models.h:27-237 (context inventory, order-conditioned operation model), formats/hry/io.h:168-231,
+// formats/hry/attrcode.h:443-501 (attribute symbol order), bitstream.h:14-40 (MSB-first bits, ones past the end).
+#include "cbm_replay.hpp"
+
+#include <cstring>
+
+namespace hry {
+namespace {
+
+// MSB-first bit source; past the end of the data every bit reads as 1 (istream::get() == -1, bitstream.h:27).
+struct Bits {
+	const uint8_t *p, *end;
+	uint64_t buf = 0;
+	int have = 0;
+	uint64_t take(int k)   // 0 <= k <= 56
+	{
+		if (k == 0) return 0;
+		while (have < k) { buf = (buf << 8) | (p < end ? *p++ : 0xFFu); have += 8; }
+		uint64_t v = (buf >> (have - k)) & ((k == 64) ? ~0ull : ((1ull << k) - 1));
+		have -= k;
+		return v;
+	}
+};
+
+// arith/coder.h:115-153
+struct Decoder {
+	static constexpr uint64_t kHalf = 1ull << 63, kQuarter = 1ull << 62;
+	uint64_t range = kHalf, value = 0, r = 0;
+	Bits in;
+	Decoder(const uint8_t *b, const uint8_t *e) : in{ b, e }
+	{
+		value = in.take(32) << 32;
+		value |= in.take(32);
+	}
+	uint64_t target(uint64_t t)
+	{
+		r = range / t;
+		uint64_t q = value / r;
+		return q < t - 1 ? q : t - 1;
+	}
+	void consume(uint64_t l, uint64_t h, uint64_t t)
+	{
+		value -= r * l;
+		range = h < t ? r * (h - l) : range - r * l;
+		if (range == 0) throw Error(HRY_E_FORMAT, "corrupt stream (empty coding interval)");
+		if (range <= kQuarter) {
+			// renormalise until range is in (2^62, 2^63]
+			int top = 63 - __builtin_clzll(range);
+			int sh = (range == (1ull << top)) ? 63 - top : 62 - top;
+			while (sh > 0) {
+				int k = sh > 56 ? 56 : sh;
+				range <<= k;
+				value = (value << k) | in.take(k);
+				sh -= k;
+			}
+		}
+	}
+};
+
+// Adaptive frequency table over <= 256 symbols: counts plus sums over blocks of 16 (same cumulative frequencies as
+// the reference's Fenwick tree, stat_adaptive.h:26-126; the halving above 2^62 total cannot trigger below 2^62 symbols).
+struct Table {
+	uint64_t cnt[256];
+	uint64_t blk[16];
+	uint64_t tot = 0;
+	Table() { memset(cnt, 0, sizeof(cnt)); memset(blk, 0, sizeof(blk)); }
+	void add(uint32_t s, uint64_t d) { cnt[s] += d; blk[s >> 4] += d; tot += d; }
+	void set(uint32_t s, uint64_t f) { uint64_t d = f - cnt[s]; cnt[s] += d; blk[s >> 4] += d; tot += d; }
+	void ones() { for (int i = 0; i < 256; ++i) cnt[i] = 1; for (int b = 0; b < 16; ++b) blk[b] = 16; tot = 256; }
+	uint32_t find(uint64_t target, uint64_t &l, uint64_t &h) const
+	{
+		uint64_t rem = target;
+		uint32_t b = 0;
+		while (b < 15 && rem >= blk[b]) rem -= blk[b++];
+		uint32_t s = b << 4;
+		while (s < 255 && rem >= cnt[s]) rem -= cnt[s++];
+		l = target - rem;
+		h = l + cnt[s];
+		return s;
+	}
+};
+
+enum { IOP_SYMS = 9, OP_SYMS = 7, OP_NEWVTX = 5, OP_CONNFWD = 6 };
+
+struct Live {
+	Decoder dc;
+	Table t_iop, t_op, t_elem[4], t_part[2], t_vert[4], t_numtri[2];
+	uint64_t c_all = 2, c_new[8], c_fwd[8];   // models.h:49-120
+
+	Live(const uint8_t *b, const uint8_t *e, const Mesh &m) : dc(b, e)
+	{
+		for (int i = 0; i < IOP_SYMS; ++i) t_iop.add(i, 1);
+		for (int i = 0; i < OP_SYMS; ++i) t_op.add(i, 1);
+		for (int i = 0; i < 8; ++i) c_new[i] = c_fwd[i] = 1;
+		for (auto &t : t_elem) t.ones();
+		for (auto &t : t_part) t.ones();
+		for (auto &t : t_vert) t.ones();
+		for (size_t d = 0; d < m.have_degree.size(); ++d)   // models.h:209-217
+			if (m.have_degree[d]) {
+				uint32_t v = (uint32_t)d - 2;
+				if ((v & 0xff) > 127 || (v >> 8) > 127) throw Error(HRY_E_UNSUPPORTED, "polygon degree outside the reference's model seeding range");
+				t_numtri[0].add(v & 0xff, 1);
+				t_numtri[1].add(v >> 8, 1);
+			}
+	}
+	uint32_t code(Table &t)   // coder.h:154-162 + model.h:57-66
+	{
+		if (t.tot == 0) throw Error(HRY_E_FORMAT, "corrupt stream (symbol from an empty model)");
+		uint64_t l, h;
+		uint32_t s = t.find(dc.target(t.tot), l, h);
+		if (h == l) throw Error(HRY_E_FORMAT, "corrupt stream (symbol with zero frequency)");
+		dc.consume(l, h, t.tot);
+		return s;
+	}
+	uint32_t sym(Table &t) { uint32_t s = code(t); t.add(s, 1); return s; }
+	uint32_t iop() { return sym(t_iop); }
+	uint32_t u32(Table *t) { uint32_t v = sym(t[0]); v |= sym(t[1]) << 8; v |= sym(t[2]) << 16; v |= sym(t[3]) << 24; return v; }
+	int elem() { uint32_t z = u32(t_elem); return (int)((z >> 1) ^ ((z & 1) ? 0xffffffffu : 0u)); }
+	int part() { uint32_t v = sym(t_part[0]); v |= sym(t_part[1]) << 8; return (int)v; }
+	uint32_t vertid() { return u32(t_vert); }
+	int numtri() { uint32_t v = sym(t_numtri[0]); v |= sym(t_numtri[1]) << 8; return (int)v; }
+	uint32_t op(int order)   // models.h:74-119
+	{
+		int i = order - 1;
+		if (i > 7) i = 7;
+		if (i < 0) i = 0;
+		uint64_t nv = c_new[i] * c_all / (c_new[i] + c_fwd[i]);
+		t_op.set(OP_NEWVTX, nv);
+		t_op.set(OP_CONNFWD, c_all - nv);
+		uint32_t s = code(t_op);
+		if (s == OP_NEWVTX) { ++c_all; ++c_new[i]; }
+		else if (s == OP_CONNFWD) { ++c_all; ++c_fwd[i]; }
+		else t_op.add(s, 1);
+		return s;
+	}
+};
+
+// attribute symbols of one list, in stream order (attrcode.h:443-501): region (2 bytes, a single region: symbol 0 with
+// l = 0 and h = t, which leaves the decoder untouched), record type, then the residual bytes of every component
+void read_list(Live &lv, const AttrList &L, bool corner_list, uint32_t count, std::vector<uint8_t> &planes)
+{
+	int nplanes = 0;
+	for (int c = 0; c < L.ncomp(); ++c) nplanes += kTypeSize[L.stype(c)];
+	planes.assign((size_t)nplanes * count, 0);
+	Table t_type;
+	t_type.add(0, 1); t_type.add(1, 1);            // DATA, HIST (models.h:201-203)
+	if (corner_list) t_type.add(2, 1);
+	std::vector<Table> t_data((size_t)nplanes);
+	for (auto &t : t_data) t.ones();
+	for (uint32_t i = 0; i < count; ++i) {
+		if (lv.sym(t_type) != 0) throw Error(HRY_E_UNSUPPORTED, "shared-attribute history records are outside the supported subset");
+		for (int q = 0; q < nplanes; ++q) planes[(size_t)q * count + i] = (uint8_t)lv.sym(t_data[q]);
+	}
+}
+
+}   // namespace
+
+void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
+                        std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes)
+{
+	Live lv(p, p + n, m);
+	cut_border_replay_with(m, lv, order_v, seg_start, seg_level);
+	read_list(lv, m.lists[1], false, (uint32_t)order_v.size(), vplanes);
+	read_list(lv, m.lists[0], false, m.nf, fplanes);
+}
+
+}   // namespace hry

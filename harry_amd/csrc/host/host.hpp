@@ -52,6 +52,11 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::ve
                        std::vector<uint32_t> &seg_level);
 
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
+// reference single-stream format (compat_read.cpp): serial entropy decode + replay on the host; residual byte planes
+// (plane-major, one plane per coded byte) are returned for the device reconstruction
+void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
+                        std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes);
+
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);
 // parses the header into a mesh skeleton (lists allocated, no connectivity); returns bytes consumed
 size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor);

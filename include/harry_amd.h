@@ -151,6 +151,13 @@ int hry_walk_run(hry_mesh *m, hry_walk **out);
 size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr);
 void hry_walk_free(hry_walk *w);
 
+/* host-only: the serial half of reading a reference stream (.hry v0.1): entropy decoding of the single adaptive
+ * stream interleaved with the cut-border replay (hry::reader::read, formats/hry/reader.cc:179-193; cbm::decode,
+ * cbm/decoder.h:27-211; arith/coder.h:115-172).  *mesh gets the connectivity (attribute records still zero); the
+ * result holds "order_v" (u32, decode order as half-edges), "vplanes"/"fplanes" (u8, residual byte planes, plane-major)
+ * for the device reconstruction.  Free with hry_walk_free / hry_mesh_free. */
+int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_walk **out);
+
 /* raw range-coder back end on explicit (l,h,t) triples (arith/coder.h:69-91 + flush :58-67), compat form */
 int hry_range_encode_lht(hry_ctx *ctx, const uint64_t *lht, size_t n, uint8_t **out, size_t *out_len);
 

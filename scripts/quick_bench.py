@@ -18,3 +18,11 @@ for it in range(3):
     dt = time.time() - t
     tm = cx.timing()
     print(f"iter {it}: {dt*1e3:.1f} ms  {m.ntri/dt/1e6:.2f} Mtri/s  bytes {len(out)}  " + json.dumps({k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items() if v}))
+
+# reading the reference-format stream back (serial entropy decode + replay on the host, reconstruction on the device)
+for it in range(2):
+    t = time.time()
+    back = cx.read_hry(out)
+    dt = time.time() - t
+    tm = cx.timing()
+    print(f"read v0.1 {it}: {dt*1e3:.1f} ms  {back.ntri/dt/1e6:.2f} Mtri/s  " + json.dumps({k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items() if v}))

@@ -231,3 +231,46 @@ def test_host_recurrence_option_gives_identical_bytes(cx):
         want = o.encode().data
         assert cx.write_hry(a) == want
         assert cx.write_hry(b, flags=hc.FLAG_HOST_RECURRENCE) == want
+
+
+# ---------------------------------------------------------------- reading files written by the reference binary
+@pytest.mark.parametrize("name,tag,v", SMALL, ids=[f"{n}.{t}" for n, t, _ in SMALL])
+def test_decode_reference_file_identical_to_reference_decode(cx, name, tag, v):
+    """.hry written by the reference -> arrays identical to the PLY the reference itself decoded from it."""
+    hry = open(os.path.join(GOLD, f"{name}.{tag}.hry"), "rb").read()
+    dec = open(os.path.join(GOLD, f"{name}.{tag}.dec.ply"), "rb").read()
+    m = cx.read_hry(hry)
+    vrec, degs, idx, frec = util.parse_ref_decoded_ply(dec, m.list_stride(1), m.list_stride(0))
+    assert m.nv == len(vrec) and m.nf == len(degs)
+    assert np.array_equal(np.diff(m.face_offsets()).astype(np.uint8), degs)
+    assert np.array_equal(m.org(), idx)
+    assert np.array_equal(m.list_data(1), vrec)
+    assert np.array_equal(m.list_data(0), frec)
+
+
+@pytest.mark.parametrize("case", ["torus150_q14", "multi40", "nm_big", "normals_colors"])
+def test_decode_compat_stream_matches_oracle_on_larger_meshes(cx, case):
+    mesh, quant = {
+        "torus150_q14": (lambda: mg.torus(150, 150, seed=2), [(1, -1, 14)]),
+        "multi40": (lambda: mg.multi_component(40, 20, 22), []),
+        "nm_big": (lambda: mg.with_nonmanifold(mg.torus(60, 64, polys="mixed"), 30, 12), []),
+        "normals_colors": (lambda: mg.with_face_props(mg.with_colors(mg.torus(40, 44, normals=True))), [(1, 0, 12), (1, 1, 12), (1, 2, 12), (1, 3, 9), (1, 4, 9), (1, 5, 9)]),
+    }[case]
+    o = op.Mesh.from_ply(mesh().to_ply())
+    if quant:
+        o.requant(quant)
+    data = o.encode().data
+    want = op.Mesh.from_hry(data)
+    got = cx.read_hry(data)
+    assert np.array_equal(got.face_offsets(), want.face_offsets())
+    assert np.array_equal(got.org(), want.org()) and np.array_equal(got.twin(), want.twin())
+    for l in range(2):
+        assert got.list_fmt(l) == want.list_fmt(l)
+        assert np.array_equal(got.list_data(l), want.list_data(l))
+    # and the product's own compat encoder output decodes the same way
+    a = hc.Mesh.from_ply(mesh().to_ply())
+    if quant:
+        cx.requant(a, quant)
+    again = cx.read_hry(cx.write_hry(a))
+    for l in range(2):
+        assert np.array_equal(again.list_data(l), want.list_data(l))

@@ -148,3 +148,60 @@ def test_start_face_order_many_components(ncomp, nu):
     product derives that order analytically, the oracle uses the real container.  Crosses several rehash points."""
     m = mg.multi_component(ncomp, nu, nu + 1, polys="tri")
     check_walk_against_oracle(m.to_ply())
+
+
+# ---------------------------------------------------------------- reading the reference's stream: the serial host half
+def golden_variants(kind="small"):
+    import json
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        man = json.load(f)
+    return [(n, t, e["variants"][t]["flags"]) for n, e in sorted(man[kind].items()) for t in sorted(e["variants"])]
+
+
+@pytest.mark.parametrize("name,tag,flags", golden_variants(), ids=[f"{n}.{t}" for n, t, _ in golden_variants()])
+def test_host_stream_reader_on_reference_files(name, tag, flags):
+    """Entropy decode + cut-border replay of files written by the reference binary: connectivity equals the oracle's
+    decode of the same file (which is pinned to the reference's own decode), and the residual byte planes equal the
+    data symbols of the stream (taken from the oracle's trace when it encodes the source PLY to this very file)."""
+    data = open(os.path.join(GOLD, f"{name}.{tag}.hry"), "rb").read()
+    m, order_v, vpl, fpl = hc.read_stream_host(data)
+    o = op.Mesh.from_hry(data)
+    assert (m.nv, m.nf, m.ne) == (o.nv, o.nf, o.ne)
+    assert np.array_equal(m.face_offsets(), o.face_offsets())
+    assert np.array_equal(m.org(), o.org())
+    assert np.array_equal(m.twin(), o.twin())
+    src = op.Mesh.from_ply(open(os.path.join(GOLD, name + ".ply"), "rb").read())
+    quant, clear = util.flags_to_quant(flags)
+    if quant or clear:
+        src.requant(quant, clear)
+    res = src.encode(trace=True)
+    assert res.data == data
+    tr = res.trace()
+    vc, fc = len(order_v), m.nf
+    data_syms = tr[tr["ctx"] >= 18]
+    # per record: type symbol + data bytes; vertices first, then faces
+    sv = (len(vpl) // vc if vc else 0) + 1
+    sf = (len(fpl) // fc if fc else 0) + 1
+    assert len(data_syms) == vc * sv + fc * sf
+    vt = data_syms[:vc * sv].reshape(vc, sv)["sym"][:, 1:].astype(np.uint8)
+    ft = data_syms[vc * sv:].reshape(fc, sf)["sym"][:, 1:].astype(np.uint8)
+    assert np.array_equal(vpl.reshape(sv - 1, vc).T, vt)
+    assert np.array_equal(fpl.reshape(sf - 1, fc).T, ft)
+
+
+def test_host_stream_reader_rejects_corrupt_input():
+    data = open(os.path.join(GOLD, "torus_tri.q14.hry"), "rb").read() if os.path.exists(os.path.join(GOLD, "torus_tri.q14.hry")) else None
+    if data is None:
+        n, t, _ = golden_variants()[0]
+        data = open(os.path.join(GOLD, f"{n}.{t}.hry"), "rb").read()
+    with pytest.raises(hc.HryError):
+        hc.read_stream_host(data[:20])
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        bad = bytearray(data)
+        for k in rng.integers(len(data) // 2, len(data), 8):
+            bad[k] ^= int(rng.integers(1, 256))
+        try:
+            hc.read_stream_host(bytes(bad))     # must either decode something or fail cleanly, never crash
+        except hc.HryError:
+            pass
