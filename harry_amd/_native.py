@@ -32,7 +32,7 @@ class Opts(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("host_walk_ms", C.c_double), ("h2d_ms", C.c_double), ("device_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("total_ms", C.c_double), ("k_rchain_ms", C.c_double), ("k_model_ms", C.c_double), ("k_predict_ms", C.c_double),
-                ("k_entropy_ms", C.c_double), ("n_symbols", C.c_uint64), ("payload_bytes", C.c_uint64)]
+                ("k_entropy_ms", C.c_double), ("k_chain_ms", C.c_double), ("n_symbols", C.c_uint64), ("payload_bytes", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,10 +1,12 @@
 // Decode pipeline of the chunked profile (.hry v0.2):
-//   H2D payload -> k_chunk_decode (one wavefront per stream) -> symbol planes
-//   D2H connectivity planes -> host cut-border replay (cbm_unwalk.cpp) -> connectivity, decode order
+//   H2D payload -> k_chunk_decode (one wavefront per stream) -> symbol planes; connectivity streams first
+//   D2H connectivity planes -> host cut-border replay (cbm_replay.hpp), overlapping the attribute streams' decode
 //   H2D connectivity -> k_candidates, k_residuals_to_rec, k_faces_unfold, k_unpredict -> attribute records -> D2H
 // Reference: formats/hry/reader.cc:179-193, cbm/decoder.h:27-211, attrcode.h:533-550.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "context.hpp"
@@ -15,6 +17,10 @@ namespace hry {
 using namespace dev;
 typedef std::chrono::steady_clock Clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+// HRY_TRACE=1: wall-clock marks of the decode pipeline on stderr (development aid)
+static bool trace_on() { static const bool on = getenv("HRY_TRACE") != nullptr; return on; }
+static thread_local Clock::time_point g_t0;
+#define HRY_MARK(t0, what) do { if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  %s\n", ms_since(t0), what); } while (0)
 
 namespace dev {
 void launch_candidates(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand, const ListDesc &ld);
@@ -24,7 +30,8 @@ void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_
                       const ListDesc &ld, uint8_t *rec);
 bool unpredict2_applicable(const ListDesc &ld);
 void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
-                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists, bool first);
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists);
+void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand);
 }
 
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
@@ -40,7 +47,10 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 {
 	Mesh *m = &mesh;
 	const uint32_t nvc = (uint32_t)order_v.size();
+	bool chain_timed = false;
+	HRY_MARK(g_t0, "reconstruct: begin");
 	cx.upload_mesh(*m);   // connectivity + (zeroed) records
+	HRY_MARK(g_t0, "connectivity uploaded");
 	ConnView cv = cx.conn_view();
 	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
 	if (nvc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
@@ -68,20 +78,19 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 			cx.d_small.ensure(table.size() * 4 + 64);
 			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
 			const uint32_t *d_tab = cx.d_small.as<uint32_t>();
-						bool first = true;
+						launch_candidates_ids(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand);
+			HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
 			for (size_t lv = 0; lv < by_level.size(); ++lv) {
-				uint32_t nl = (uint32_t)by_level[lv].size() / 2;
-				if (!nl && !first) continue;
+				const uint32_t nl = (uint32_t)by_level[lv].size() / 2;
 				// a 2-D grid holds at most 65535 rows: split very wide levels
-				for (uint32_t done = 0; done < std::max(nl, 1u); done += 65535) {
-					uint32_t part = std::min(65535u, nl - std::min(nl, done));
+				for (uint32_t done = 0; done < nl; done += 65535)
 					launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
-					                  d_tab + seg_at[lv], d_tab + off_at[lv] + done, part, first);
-					first = false;
-					if (!nl) break;
-				}
+					                  d_tab + seg_at[lv], d_tab + off_at[lv] + done, std::min(65535u, nl - done));
 			}
+			HIP_OK(hipEventRecord(cx.ev[0], cx.stream));
+			chain_timed = true;
 			HIP_OK(hipStreamSynchronize(cx.stream));   // the table lives in host memory until the copy has been consumed
+			HRY_MARK(g_t0, "vertex chain done");
 		} else {
 			launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
 			launch_residuals_to_rec(cx.stream, d_vplanes, nvc, ldv, cx.d_rec[1].as<uint8_t>());
@@ -96,6 +105,8 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	for (int l = 0; l < 2; ++l)
 		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	HRY_MARK(g_t0, "records on the host");
+	cx.timing.k_chain_ms = chain_timed ? cx.elapsed(7, 0) : 0.0;
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
 		cx.stage_put("ncand", d_ncand, nvc);
@@ -105,6 +116,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
 {
 	auto t_all = Clock::now();
+	g_t0 = t_all;
 	cx.timing = hry_timing{};
 	const ListDesc ldv = make_list_desc(m->lists[1]), ldf = make_list_desc(m->lists[0]);
 	for (int l = 0; l < 2; ++l)
@@ -178,22 +190,33 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	cx.ensure_magic(256 + CH + 16);
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	cx.timing.h2d_ms = ms_since(t_h2d);
+	HRY_MARK(g_t0, "payload on the device");
+	// The connectivity streams go first: their planes return to the host for the replay, which then runs while the
+	// attribute streams (the bulk of the payload) are still being decoded on the device.
+	uint32_t n_conn_streams = 0;
+	for (int k = 0; k < kConnPlanes; ++k) n_conn_streams += (uint32_t)((nsym[k] + (uint64_t)CH - 1) / CH);
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
-	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), (uint32_t)nstreams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
+	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), n_conn_streams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
 	                    cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>(), cx.d_csizes.as<uint32_t>());
 	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
-
-	// ---- connectivity planes to the host, replay the cut-border machine
 	std::vector<uint8_t> conn[kConnPlanes];
 	for (int k = 0; k < kConnPlanes; ++k) {
 		conn[k].resize(nsym[k]);
 		if (nsym[k]) HIP_OK(hipMemcpyAsync(conn[k].data(), cx.d_csyms.as<uint8_t>() + plane_off[k], nsym[k], hipMemcpyDeviceToHost, cx.stream));
 	}
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
+	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>() + n_conn_streams, (uint32_t)nstreams - n_conn_streams, cx.d_init.as<uint32_t>(),
+	                    cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>() + n_conn_streams, cx.d_csizes.as<uint32_t>() + n_conn_streams);
+	HIP_OK(hipEventRecord(cx.ev[6], cx.stream));
+
+	HRY_MARK(g_t0, "connectivity planes on the host");
+	// ---- replay the cut-border machine on the host
 	auto t_walk = Clock::now();
 	std::vector<uint32_t> order_v, seg_start, seg_level;
 	cut_border_replay(*m, conn, order_v, seg_start, seg_level);
 	cx.timing.host_walk_ms = ms_since(t_walk);
+	HRY_MARK(g_t0, "replay done");
 	if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
 	reconstruct_attributes(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes],
 	                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf);
@@ -201,7 +224,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		cx.stage_put("dec_syms", cx.d_csyms.p, total_syms);
 		cx.stage_put_host("dec_nsym", nsym.data(), nsym.size() * 4);
 	}
-	cx.timing.k_entropy_ms = cx.elapsed(1, 2);
+	cx.timing.k_entropy_ms = cx.elapsed(1, 2) + cx.elapsed(5, 6);
 	cx.timing.k_predict_ms = cx.elapsed(3, 4);
 	cx.timing.device_ms = cx.timing.k_entropy_ms + cx.timing.k_predict_ms;
 	cx.timing.n_symbols = total_syms;
@@ -216,6 +239,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
 {
 	auto t_all = Clock::now();
+	g_t0 = t_all;
 	cx.timing = hry_timing{};
 	const ListDesc ldv = make_list_desc(m->lists[1]), ldf = make_list_desc(m->lists[0]);
 	for (int l = 0; l < 2; ++l)

@@ -671,49 +671,51 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		// ---- chain
 		uint32_t val = 0;
 		if constexpr (kSmallUnsigned) {
-			// One step, hand-scheduled: 33 instructions, every hazard distance of gfx950 (VALU-written SGPR read by a VALU: 2
+			// One step, hand-scheduled: 27 instructions, every hazard distance of gfx950 (VALU-written SGPR read by a VALU: 2
 			// wait states, VALU-written VGPR read by v_readlane: 1) is covered by independent instructions instead of s_nop,
-			// each of which would cost this lone wavefront a full issue slot.  Same arithmetic as LaneEvalSmall::eval.
-			const uint32_t top = ev.top, c_code = ev.uf.code, c_half = ev.uf.half, c_tmc = ev.uf.top_minus_code, c_delta = ev.uf.delta;
+			// each of which would cost this lone wavefront a full issue slot.  Same arithmetic as LaneEvalSmall::eval with
+			// the inverse residual code reduced further (prediction.h:46-64):
+			//   near case   half <= min(pred - 1, top - pred)  <=>  (pred - (half + 1)) <u top - 2 half   (0 when 2 half > top)
+			//   far value   room >= pred  <=>  pred <= top >> 1 ? code : top - code      (pred == 0 lands here and yields code)
+			// The third source of every candidate is kept negated, so that a parallelogram is one three-operand add.
+			const uint32_t top = ev.top, half_top = ev.top >> 1, c_code = ev.uf.code, c_tmc = ev.uf.top_minus_code, c_delta = ev.uf.delta;
+			const uint32_t c_hp1 = ev.uf.half + 1u, c_lim = top >= 2u * ev.uf.half ? top - 2u * ev.uf.half : 0u;
+			src[2] = 0u - src[2]; src[5] = 0u - src[5];
 #define HRY_STEP(I)                                                                                                     \
-			asm("v_add_u32 v100, %[a0], %[b0]\n\t"                                                                      \
-			    "v_add_u32 v101, %[a1], %[b1]\n\t"                                                                      \
-			    "v_sub_u32 v100, v100, %[o0]\n\t"                                                                       \
-			    "v_sub_u32 v101, v101, %[o1]\n\t"                                                                       \
+			asm("v_add3_u32 v100, %[a0], %[b0], %[o0]\n\t"                                                              \
+			    "v_add3_u32 v101, %[a1], %[b1], %[o1]\n\t"                                                              \
 			    "v_med3_i32 v100, v100, 0, %[top]\n\t"                                                                  \
 			    "v_med3_i32 v101, v101, 0, %[top]\n\t"                                                                  \
 			    "v_add3_u32 v102, v100, v101, 1\n\t"                                                                    \
 			    "v_lshrrev_b32 v103, 1, v102\n\t"                                                                       \
-			    "v_sub_u32 v104, %[top], v103\n\t"                                                                      \
-			    "v_add_u32 v105, -1, v103\n\t"                                                                          \
-			    "v_cmp_lt_u32 s[80:81], v104, v103\n\t"                                                                 \
-			    "v_min_u32 v105, v105, v104\n\t"                                                                        \
+			    "v_sub_u32 v104, v103, %[hp1]\n\t"                                                                      \
+			    "v_cmp_ge_u32 s[80:81], %[htop], v103\n\t"                                                              \
 			    "v_add_u32 v106, v103, %[delta]\n\t"                                                                    \
-			    "v_cmp_gt_u32 s[82:83], %[half], v105\n\t"                                                              \
-			    "v_cmp_gt_u32 s[84:85], 2, v102\n\t"                                                                    \
-			    "v_cndmask_b32 v107, %[code], %[tmc], s[80:81]\n\t"                                                     \
-			    "v_cmp_eq_u32 s[86:87], " #I ", %[t0]\n\t"                                                              \
-			    "v_cmp_eq_u32 s[88:89], " #I ", %[t1]\n\t"                                                              \
-			    "v_cndmask_b32 v107, v106, v107, s[82:83]\n\t"                                                          \
-			    "v_cmp_eq_u32 s[90:91], " #I ", %[t2]\n\t"                                                              \
-			    "v_cndmask_b32 %[val], v107, %[code], s[84:85]\n\t"                                                     \
-			    "v_cmp_eq_u32 s[92:93], " #I ", %[t3]\n\t"                                                              \
-			    "v_readlane_b32 s80, %[val], " #I "\n\t"                                                                \
-			    "v_cmp_eq_u32 s[94:95], " #I ", %[t4]\n\t"                                                              \
-			    "v_cmp_eq_u32 s[96:97], " #I ", %[t5]\n\t"                                                            \
-			    "v_mov_b32 v108, s80\n\t"                                                                               \
-			    "v_cndmask_b32 %[a0], %[a0], v108, s[86:87]\n\t"                                                        \
-			    "v_cndmask_b32 %[b0], %[b0], v108, s[88:89]\n\t"                                                        \
-			    "v_cndmask_b32 %[o0], %[o0], v108, s[90:91]\n\t"                                                        \
-			    "v_cndmask_b32 %[a1], %[a1], v108, s[92:93]\n\t"                                                        \
-			    "v_cndmask_b32 %[b1], %[b1], v108, s[94:95]\n\t"                                                        \
-			    "v_cndmask_b32 %[o1], %[o1], v108, s[96:97]"                                                           \
+			    "v_cmp_lt_u32 s[82:83], v104, %[lim]\n\t"                                                               \
+			    "v_cmp_eq_u32 s[84:85], " #I ", %[t0]\n\t"                                                              \
+			    "v_cmp_eq_u32 s[86:87], " #I ", %[t1]\n\t"                                                              \
+			    "v_cndmask_b32 v107, %[tmc], %[code], s[80:81]\n\t"                                                     \
+			    "v_cmp_eq_u32 s[88:89], " #I ", %[t2]\n\t"                                                              \
+			    "v_cndmask_b32 %[val], v107, v106, s[82:83]\n\t"                                                        \
+			    "v_cmp_eq_u32 s[90:91], " #I ", %[t3]\n\t"                                                              \
+			    "v_readlane_b32 s96, %[val], " #I "\n\t"                                                                \
+			    "v_cmp_eq_u32 s[92:93], " #I ", %[t4]\n\t"                                                              \
+			    "v_cmp_eq_u32 s[94:95], " #I ", %[t5]\n\t"                                                              \
+			    "v_mov_b32 v108, s96\n\t"                                                                               \
+			    "v_sub_u32 v109, 0, v108\n\t"                                                                           \
+			    "v_cndmask_b32 %[a0], %[a0], v108, s[84:85]\n\t"                                                        \
+			    "v_cndmask_b32 %[b0], %[b0], v108, s[86:87]\n\t"                                                        \
+			    "v_cndmask_b32 %[a1], %[a1], v108, s[90:91]\n\t"                                                        \
+			    "v_cndmask_b32 %[b1], %[b1], v108, s[92:93]\n\t"                                                        \
+			    "v_cndmask_b32 %[o0], %[o0], v109, s[88:89]\n\t"                                                        \
+			    "v_cndmask_b32 %[o1], %[o1], v109, s[94:95]"                                                             \
 			    : [a0] "+v"(src[0]), [b0] "+v"(src[1]), [o0] "+v"(src[2]), [a1] "+v"(src[3]), [b1] "+v"(src[4]), [o1] "+v"(src[5]),  \
 			      [val] "=&v"(val)                                                                                     \
 			    : [t0] "v"(tag[0]), [t1] "v"(tag[1]), [t2] "v"(tag[2]), [t3] "v"(tag[3]), [t4] "v"(tag[4]), [t5] "v"(tag[5]),   \
-			      [top] "s"(top), [code] "v"(c_code), [half] "v"(c_half), [tmc] "v"(c_tmc), [delta] "v"(c_delta)         \
-			    : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",  \
-			      "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
+			      [top] "s"(top), [htop] "s"(half_top), [code] "v"(c_code), [tmc] "v"(c_tmc), [delta] "v"(c_delta),       \
+			      [hp1] "v"(c_hp1), [lim] "v"(c_lim)                                                                    \
+			    : "v100", "v101", "v102", "v103", "v104", "v106", "v107", "v108", "v109", "s80", "s81", "s82", "s83", "s84", "s85",  \
+			      "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96");
 #define HRY_STEP8(A, B, C, D, E, F, G, H) HRY_STEP(A) HRY_STEP(B) HRY_STEP(C) HRY_STEP(D) HRY_STEP(E) HRY_STEP(F) HRY_STEP(G) HRY_STEP(H)
 			do {   // steps past the end of a short batch only produce unused values: leave at multiples of eight
 				HRY_STEP8(0, 1, 2, 3, 4, 5, 6, 7)
@@ -824,14 +826,16 @@ __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint3
 	for (uint32_t j = 0; j < (uint32_t)(3 * kCandMax); ++j) out[j] = j < 3 * m ? ids[j] : 0u;
 	ncand[v] = k > (uint32_t)kCandMax ? 0xff : (uint8_t)k;
 }
+void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand)
+{
+	if (nvtx) hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, nvtx, cand, ncand);
+}
 // segs: pairs (begin, end) of decode ranks; list_off: n_lists + 1 offsets into segs.  Lists run in parallel blocks, the
 // segments of one list one after the other.  Two launches: independent components first, then the dependent ones.
 void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
-                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists, bool first)
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists)
 {
-	if (!nvtx || !ld.ncomp) return;
-	if (first) hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, nvtx, cand, ncand);
-	if (!n_lists) return;
+	if (!nvtx || !ld.ncomp || !n_lists) return;
 	const uint32_t ring_bytes = 64 * 1024;
 	auto go = [&](auto kern, int stype) {
 		CompSel sel{};

@@ -81,6 +81,7 @@ typedef struct hry_timing {
     double k_model_ms;     /* adaptive-model evaluation kernels */
     double k_predict_ms;   /* prediction + residual + symbolisation kernels */
     double k_entropy_ms;   /* chunked: fused model+coder kernel */
+    double k_chain_ms;     /* decode: the reconstruction chain kernels alone (k_unpredict2), part of k_predict_ms */
     uint64_t n_symbols;    /* coder invocations represented in the stream */
     uint64_t payload_bytes;
 } hry_timing;
