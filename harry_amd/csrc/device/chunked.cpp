@@ -134,10 +134,15 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	std::vector<StreamJob> jobs;
 	uint64_t words = 0;
 	uint64_t nsym_total = 0;
-	for (const PlaneRef &pl : planes) {
+	// connectivity planes are cut shorter: the decoder needs them first and a stream is a serial chain (container
+	// description: oracle/hry_oracle.cc "chunked profile")
+	const uint32_t CHC = std::min(CH, std::max(CH / 8, 512u));
+	for (size_t pi = 0; pi < planes.size(); ++pi) {
+		const PlaneRef &pl = planes[pi];
+		const uint32_t step = pi < (size_t)kConnPlanes ? CHC : CH;
 		nsym_total += pl.n;
-		for (uint32_t f = 0; f < pl.n; f += CH) {
-			uint32_t n = std::min(CH, pl.n - f);
+		for (uint32_t f = 0; f < pl.n; f += step) {
+			uint32_t n = std::min(step, pl.n - f);
 			if (words >= (1ull << 32) - (1u << 24)) throw Error(HRY_E_UNSUPPORTED, "chunked stream accumulator exceeds 2^32 words");
 			jobs.push_back(StreamJob{ pl.dptr + f, n, (uint32_t)pl.init, totals[pl.init], (uint32_t)words });
 			words += stream_words(n, totals[pl.init]);
@@ -191,14 +196,14 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
 
 	// ---- container
-	size_t dir = 8 + 4 * planes.size() + 4 * (size_t)ns;
+	size_t dir = 12 + 4 * planes.size() + 4 * (size_t)ns;
 	size_t base = out.size();
 	out.resize(base + dir + total_bytes);
 	uint8_t *o = out.data() + base;
 	uint32_t np = (uint32_t)planes.size();
-	memcpy(o, &CH, 4); memcpy(o + 4, &np, 4);
-	for (size_t i = 0; i < planes.size(); ++i) memcpy(o + 8 + 4 * i, &planes[i].n, 4);
-	if (ns) HIP_OK(hipMemcpyAsync(o + 8 + 4 * planes.size(), d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
+	memcpy(o, &CH, 4); memcpy(o + 4, &CHC, 4); memcpy(o + 8, &np, 4);
+	for (size_t i = 0; i < planes.size(); ++i) memcpy(o + 12 + 4 * i, &planes[i].n, 4);
+	if (ns) HIP_OK(hipMemcpyAsync(o + 12 + 4 * planes.size(), d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
 	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 

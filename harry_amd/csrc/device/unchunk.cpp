@@ -125,18 +125,19 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// ---- directory
 	auto need = [&](size_t off, size_t k) { if (off + k > n) throw Error(HRY_E_FORMAT, "truncated chunked directory"); };
 	size_t off = hdr;
-	need(off, 8);
-	uint32_t CH, np;
-	memcpy(&CH, p + off, 4); memcpy(&np, p + off + 4, 4);
-	off += 8;
+	need(off, 12);
+	uint32_t CH, CHC, np;
+	memcpy(&CH, p + off, 4); memcpy(&CHC, p + off + 4, 4); memcpy(&np, p + off + 8, 4);
+	off += 12;
 	const uint32_t expect_planes = (uint32_t)(kConnPlanes + ldv.nplanes + ldf.nplanes);
-	if (CH == 0 || np != expect_planes) throw Error(HRY_E_FORMAT, "chunked directory does not match the header");
+	if (CH == 0 || CHC == 0 || np != expect_planes) throw Error(HRY_E_FORMAT, "chunked directory does not match the header");
 	need(off, 4ull * np);
 	std::vector<uint32_t> nsym(np);
 	memcpy(nsym.data(), p + off, 4ull * np);
 	off += 4ull * np;
 	uint64_t nstreams = 0, total_syms = 0;
-	for (uint32_t x : nsym) { nstreams += (x + (uint64_t)CH - 1) / CH; total_syms += x; }
+	auto step_of = [&](uint32_t k) { return k < (uint32_t)kConnPlanes ? CHC : CH; };
+	for (uint32_t k = 0; k < np; ++k) { nstreams += (nsym[k] + (uint64_t)step_of(k) - 1) / step_of(k); total_syms += nsym[k]; }
 	need(off, 4 * nstreams);
 	std::vector<uint32_t> nbytes((size_t)nstreams);
 	if (nstreams) memcpy(nbytes.data(), p + off, 4 * (size_t)nstreams);
@@ -176,8 +177,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	std::vector<uint64_t> plane_off(np + 1, 0);
 	for (uint32_t k = 0; k < np; ++k) {
 		int kind = k < (uint32_t)kConnPlanes ? conn_init_kind((int)k) : INIT_ONES;
-		for (uint32_t f = 0; f < nsym[k]; f += CH)
-			jobs.push_back(StreamJob{ cx.d_csyms.as<uint8_t>() + plane_off[k] + f, std::min(CH, nsym[k] - f), (uint32_t)kind, totals[kind], 0 });
+		for (uint64_t f = 0; f < nsym[k]; f += step_of(k))
+			jobs.push_back(StreamJob{ cx.d_csyms.as<uint8_t>() + plane_off[k] + f, (uint32_t)std::min<uint64_t>(step_of(k), nsym[k] - f), (uint32_t)kind, totals[kind], 0 });
 		plane_off[k + 1] = plane_off[k] + nsym[k];
 	}
 	HIP_OK(hipMemcpyAsync(cx.d_init.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice, cx.stream));
@@ -187,14 +188,14 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		HIP_OK(hipMemcpyAsync(cx.d_csizes.p, nbytes.data(), nbytes.size() * 4, hipMemcpyHostToDevice, cx.stream));
 	}
 	HIP_OK(hipMemcpyAsync(cx.d_coffs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, cx.stream));
-	cx.ensure_magic(256 + CH + 16);
+	cx.ensure_magic(256 + std::max(CH, CHC) + 16);
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	cx.timing.h2d_ms = ms_since(t_h2d);
 	HRY_MARK(g_t0, "payload on the device");
 	// The connectivity streams go first: their planes return to the host for the replay, which then runs while the
 	// attribute streams (the bulk of the payload) are still being decoded on the device.
 	uint32_t n_conn_streams = 0;
-	for (int k = 0; k < kConnPlanes; ++k) n_conn_streams += (uint32_t)((nsym[k] + (uint64_t)CH - 1) / CH);
+	for (int k = 0; k < kConnPlanes; ++k) n_conn_streams += (uint32_t)((nsym[k] + (uint64_t)CHC - 1) / CHC);
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
 	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), n_conn_streams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
 	                    cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>(), cx.d_csizes.as<uint32_t>());

@@ -1329,8 +1329,11 @@ static Mesh *decode(const uint8_t *p, size_t n)
 // coder + 64-bit flush, using exactly the reference's model/coder arithmetic.  Symbols without information are
 // not stored: reg_face/reg_vtx (single region), attr_type (always DATA), numtri for single-degree meshes.
 // Operations are split into one plane per order class (models.h:101-105) with a plain adaptive 7-symbol model.
-//   u32 chunk_syms, u32 n_planes, n_planes x u32 n_symbols, per stream u32 n_bytes, then the streams.
+//   u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols, per stream u32 n_bytes, then the streams.
 // Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
+// The first 21 planes (connectivity) are cut every conn_chunk_syms symbols, the attribute planes every chunk_syms: the
+// decoder needs the connectivity first and a stream is a serial chain, so short connectivity streams shorten its start-up
+// latency; their small alphabets re-adapt within a few symbols, which keeps the size cost below 1 %.
 // ------------------------------------------------------------------------------------------------
 struct PlaneDef { int slot; int init_kind; };   // init_kind: 0 = 256 ones, 1 = iop (9 ones), 2/3 = numtri byte 0/1, 4 = op (7 ones)
 
@@ -1361,6 +1364,8 @@ static void seed_table(FreqTable &f, int kind, const Mesh &m)
 	}
 }
 static int count_degrees(const Mesh &m) { int n = 0; for (char c : m.have_deg) n += c ? 1 : 0; return n; }
+enum { CONN_PLANES = 21 };
+static uint32_t default_conn_chunk(uint32_t chunk_syms) { return std::min(chunk_syms, std::max(chunk_syms / 8, 512u)); }
 
 static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 {
@@ -1381,14 +1386,18 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 		if (count_degrees(m) <= 1) { rec[CTX_NUMTRI].clear(); rec[CTX_NUMTRI + 1].clear(); }
 		std::vector<PlaneDef> planes = chunked_planes(m, md);
 		ByteWriter w{ res->bytes };
+		const uint32_t conn_chunk = default_conn_chunk(chunk_syms);
 		w.put<uint32_t>(chunk_syms);
+		w.put<uint32_t>(conn_chunk);
 		w.put<uint32_t>((uint32_t)planes.size());
 		for (const PlaneDef &pd : planes) w.put<uint32_t>((uint32_t)rec[pd.slot].size());
 		std::vector<std::vector<uint8_t>> streams;
-		for (const PlaneDef &pd : planes) {
+		for (size_t pi = 0; pi < planes.size(); ++pi) {
+			const PlaneDef &pd = planes[pi];
 			const std::vector<uint8_t> &sy = rec[pd.slot];
-			for (size_t first = 0; first < sy.size(); first += chunk_syms) {
-				size_t end = std::min(sy.size(), first + chunk_syms);
+			const size_t step = pi < CONN_PLANES ? conn_chunk : chunk_syms;
+			for (size_t first = 0; first < sy.size(); first += step) {
+				size_t end = std::min(sy.size(), first + step);
 				std::vector<uint8_t> out;
 				RangeEncoder enc(out);
 				FreqTable f(256);
@@ -1416,13 +1425,13 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 		ByteReader br{ p, p + n };
 		read_header(br, *m, 2);
 		Models md(*m);
-		uint32_t chunk_syms = br.get<uint32_t>(), np = br.get<uint32_t>();
+		uint32_t chunk_syms = br.get<uint32_t>(), conn_chunk = br.get<uint32_t>(), np = br.get<uint32_t>();
 		std::vector<PlaneDef> planes = chunked_planes(*m, md);
-		if (np != planes.size() || chunk_syms == 0) throw std::runtime_error("oracle: bad chunked directory");
+		if (np != planes.size() || chunk_syms == 0 || conn_chunk == 0) throw std::runtime_error("oracle: bad chunked directory");
 		std::vector<uint32_t> nsym(np);
 		for (auto &x : nsym) x = br.get<uint32_t>();
 		size_t nstreams = 0;
-		for (uint32_t x : nsym) nstreams += (x + chunk_syms - 1) / chunk_syms;
+		for (size_t k = 0; k < np; ++k) { uint64_t c = k < CONN_PLANES ? conn_chunk : chunk_syms; nstreams += (size_t)((nsym[k] + c - 1) / c); }
 		std::vector<uint32_t> nbytes(nstreams);
 		for (auto &x : nbytes) x = br.get<uint32_t>();
 		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
@@ -1431,8 +1440,9 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 		for (size_t k = 0; k < planes.size(); ++k) {
 			std::vector<uint8_t> &sy = rec[planes[k].slot];
 			sy.resize(nsym[k]);
-			for (size_t first = 0; first < sy.size(); first += chunk_syms, ++si) {
-				size_t end = std::min(sy.size(), first + chunk_syms);
+			const size_t step = k < CONN_PLANES ? conn_chunk : chunk_syms;
+			for (size_t first = 0; first < sy.size(); first += step, ++si) {
+				size_t end = std::min(sy.size(), first + step);
 				if ((size_t)(p + n - q) < nbytes[si]) throw std::runtime_error("oracle: truncated chunked stream");
 				RangeDecoder dec(q, q + nbytes[si]);
 				FreqTable f(256);
