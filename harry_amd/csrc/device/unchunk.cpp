@@ -110,6 +110,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
 		cx.stage_put("ncand", d_ncand, nvc);
+		cx.stage_put("cand", d_cand, (size_t)nvc * 24 * 4);
 	}
 }
 

@@ -547,33 +547,61 @@ template <> struct LaneEval<float> {
 	}
 };
 
-constexpr uint32_t kNoLane = 64;   // tag of a source that is already present
+template <typename T> __device__ __forceinline__ uint32_t ev_top(int q) { return (uint32_t)cm::ones<T>(q == 0 ? (int)sizeof(T) * 8 : q); }
+constexpr uint32_t kNoLane = 64;
+constexpr uint32_t kQueue = 256;        // vertices in the LDS input queue (4 tiles of 64)
+constexpr uint32_t kQueueCols = 26;     // 24 candidate ids, candidate count, residual code   // tag of a source that is already present
 
 template <typename T>
 __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                      const uint8_t *planes, uint8_t *rec, int stride, int off, int q, int plane0,
-                                     typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n)
+                                     typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n, uint32_t *queue)
 {
-	// this call reconstructs the vertices [seg_begin, nvtx) of one component; the ring holds only vertices >= seg_begin
+	// this call reconstructs the vertices [seg_begin, nvtx) of one component; the ring holds only vertices >= seg_begin.
+	// The workgroup is ONE wavefront: its LDS accesses execute in program order, no barrier is needed anywhere.
 	typedef typename cm::word<sizeof(T)>::u U;
 	typedef typename cm::wide<T>::type W;
 	static_assert(sizeof(T) <= 4, "8-byte components use the generic kernel");
 	constexpr bool kSmallUnsigned = !cm::is_fp<T>::value && sizeof(T) <= 2 && !(T(-1) < T(0));
 	const int lane = threadIdx.x;
 	const uint32_t mask = ring_n - 1;
-	uint4 nid[2];
-	uint32_t nnc = 0, ncode = 0;
-	auto prefetch = [&](uint32_t b) {
-		uint32_t v = b + lane;
-		nnc = 0; ncode = 0;
-		nid[0] = nid[1] = make_uint4(0, 0, 0, 0);
+	// Per-vertex inputs (candidate ids, candidate count, residual code) are staged through an LDS queue of kQueue
+	// vertices, filled in tiles of 64 that are requested from HBM up to four tiles ahead of the batch being reconstructed.
+	// A batch starts wherever the previous one ended (batches are cut at vertices that need special handling) and
+	// reads its 64 entries from the queue, so neither a cut nor the global-memory latency ever stalls the chain.
+	// Queue layout: column-major, column j of vertex slot s at queue[j * kQueue + s]; 24 id columns, count, code.
+	uint4 tid[6];
+	uint32_t tnc = 0, tbyte[sizeof(T)];   // raw loads only: anything computed from them here would wait for the memory
+	uint32_t tiles_committed = 0;             // tiles [0, tiles_committed) are in the queue (subject to its capacity)
+	const uint32_t n_tiles = (nvtx - seg_begin + 63) / 64;
+	auto tile_request = [&](uint32_t t) {     // loads of tile t into registers
+		const uint32_t v = seg_begin + 64 * t + lane;
+		tnc = 0;
+#pragma unroll
+		for (int b8 = 0; b8 < (int)sizeof(T); ++b8) tbyte[b8] = 0;
+#pragma unroll
+		for (int k = 0; k < 6; ++k) tid[k] = make_uint4(0, 0, 0, 0);
 		if (v < nvtx) {
 			const uint4 *src = (const uint4*)(cand + (size_t)v * (kCandMax * 3));
-			nid[0] = src[0]; nid[1] = src[1];   // the ids of the first two candidates
-			nnc = ncand[v];
 #pragma unroll
-			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) ncode |= (uint32_t)planes[(size_t)(plane0 + b8) * nvtx_total + v] << (8 * b8);
+			for (int k = 0; k < 6; ++k) tid[k] = src[k];
+			tnc = ncand[v];
+#pragma unroll
+			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) tbyte[b8] = planes[(size_t)(plane0 + b8) * nvtx_total + v];
 		}
+	};
+	auto tile_commit = [&](uint32_t t) {      // registers -> queue
+		const uint32_t slot = (64 * t + lane) & (kQueue - 1);
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			queue[(4 * k) * kQueue + slot] = tid[k].x; queue[(4 * k + 1) * kQueue + slot] = tid[k].y;
+			queue[(4 * k + 2) * kQueue + slot] = tid[k].z; queue[(4 * k + 3) * kQueue + slot] = tid[k].w;
+		}
+		queue[24 * kQueue + slot] = tnc;
+		uint32_t tcode = 0;
+#pragma unroll
+		for (int b8 = 0; b8 < (int)sizeof(T); ++b8) tcode |= tbyte[b8] << (8 * b8);
+		queue[25 * kQueue + slot] = tcode;
 	};
 	// value of an already reconstructed vertex that lies before the current batch
 	auto old_value = [&](uint32_t id, uint32_t base) -> U {
@@ -582,12 +610,27 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		__builtin_memcpy(&r, rec + (size_t)id * stride + off, sizeof(U));
 		return r;
 	};
-	prefetch(seg_begin);
+	tile_request(0);
 	uint32_t base = seg_begin;
 	while (base < nvtx) {
-		const uint32_t ids[6] = { nid[0].x, nid[0].y, nid[0].z, nid[0].w, nid[1].x, nid[1].y };
-		const uint32_t nc = nnc;
-		const uint32_t code = ncode;
+		// the tiles covering [base, base + 64) must be in the queue; beyond that, commit ahead as far as the queue holds
+		// (tiles tile(base) .. tile(base) + kQueue/64 - 1) so that the request of the next tile is always in flight
+		{
+			const uint32_t t_base = (base - seg_begin) / 64;
+			while (tiles_committed < n_tiles && tiles_committed < t_base + kQueue / 64) {
+				tile_commit(tiles_committed);
+				++tiles_committed;
+				if (tiles_committed < n_tiles) tile_request(tiles_committed);
+				if (tiles_committed >= t_base + 2) break;   // enough for this batch; one more tile per batch keeps the queue ahead
+			}
+		}
+		const uint32_t slot = (base - seg_begin + lane) & (kQueue - 1);
+		const bool in_range = base + lane < nvtx;
+		uint32_t ids[6];
+#pragma unroll
+		for (int j = 0; j < 6; ++j) ids[j] = queue[j * kQueue + slot];
+		const uint32_t nc = in_range ? queue[24 * kQueue + slot] : 0u;
+		const uint32_t code = queue[25 * kQueue + slot];
 		uint32_t nb = min(64u, nvtx - base);
 		const uint64_t big = __ballot(nc > 2);
 		if (big & 1ull) {
@@ -600,8 +643,9 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			if (n0 != 0xff) {
 				uint32_t pk = 0;
 				if ((uint32_t)lane < n0) {
-					const uint32_t *cs = cand + (size_t)v * (kCandMax * 3) + 3 * lane;
-					pk = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(old_value(cs[0], v)), cm::bits<T>(old_value(cs[1], v)), cm::bits<T>(old_value(cs[2], v)), q));
+					const uint32_t s0 = (base - seg_begin) & (kQueue - 1);
+					const uint32_t c0i = queue[(3 * lane) * kQueue + s0], c1i = queue[(3 * lane + 1) * kQueue + s0], c2i = queue[(3 * lane + 2) * kQueue + s0];
+					pk = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(old_value(c0i, v)), cm::bits<T>(old_value(c1i, v)), cm::bits<T>(old_value(c2i, v)), q));
 				}
 				T pv[kCandMax];
 #pragma unroll
@@ -635,42 +679,120 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 				stq<T>(rec + (size_t)v * stride + off, val);
 				ring[v & mask] = cm::bits<U>(val);
 			}
-			__syncthreads();
 			base += 1;
-			prefetch(base);
 			continue;
 		}
 		if (big) nb = min(nb, (uint32_t)__builtin_ctzll(big));
-		// ---- prepare: lane j <-> vertex base + j
+		// ---- shape of the batch and sources, lane j <-> vertex base + j.  Straight-line code on purpose: every branch a lone
+		// wavefront takes costs it an instruction-fetch bubble, so the ring is read unconditionally (the address is always
+		// inside the ring) and the results are selected.  A vertex is "chained" when at most one of its sources lies inside
+		// the batch, that source is the vertex right before it and enters its parallelogram with a plus sign - the rule in a
+		// cut-border traversal (99.5 % of the vertices of a regular triangle mesh).  A run of chained vertices needs no
+		// broadcast at all: the previous lane's value arrives through a DPP wave shift (chain variant "run" below).
+		const uint32_t ncl = lane < (int)nb ? nc : 0u;
 		uint32_t src[6], tag[6];
+		uint32_t npend = 0, ngood = 0, pend_slot = 6, far_any = 0;
 #pragma unroll
-		for (int k = 0; k < 2; ++k) {
+		for (int s6 = 0; s6 < 6; ++s6) {
+			const uint32_t id = ids[s6];
+			const uint32_t ringv = (uint32_t)ring[id & mask];
+			const bool valid = (uint32_t)(s6 / 3) < ncl;
+			const bool inb = valid & (id >= base);
+			const bool old = valid & (id < base);
+			npend += inb ? 1u : 0u;
+			ngood += (inb & (s6 % 3 != 2) & (id + 1u == base + (uint32_t)lane)) ? 1u : 0u;
+			pend_slot = inb ? (uint32_t)s6 : pend_slot;
+			far_any |= (old & ((base - id > ring_n) | (id < seg_begin))) ? 1u : 0u;
+			src[s6] = old ? ringv : 0u;
+			tag[s6] = inb ? id - base : kNoLane;   // produced inside this batch, by an earlier lane
+		}
+		bool run_mode = false;
+		if constexpr (kSmallUnsigned) {
+			const bool chained = (npend == 0) | ((npend == 1) & (ngood == 1));
+			const uint64_t unchained = __ballot(!chained);   // never lane 0: all its sources are older; lanes >= nb count as chained
+			const uint32_t run = unchained ? min(nb, (uint32_t)__builtin_ctzll(unchained)) : nb;
+			if (run == nb || run >= 16) { run_mode = true; nb = run; }
+		}
+		// Only a source older than the ring costs a global round trip, and only then is the vector-memory counter waited
+		// for: neither the stores of the previous batch nor the tile in flight are ever waited for here.
+		if (__ballot(far_any != 0)) {
 #pragma unroll
-			for (int j = 0; j < 3; ++j) {
-				src[3 * k + j] = 0; tag[3 * k + j] = kNoLane;
-				if ((uint32_t)k < nc && lane < (int)nb) {
-					const uint32_t id = ids[3 * k + j];
-					if (id >= base) tag[3 * k + j] = id - base;   // produced inside this batch, by an earlier lane
-					else src[3 * k + j] = (uint32_t)old_value(id, base);
+			for (int s6 = 0; s6 < 6; ++s6) {
+				const uint32_t id = ids[s6];
+				if ((uint32_t)(s6 / 3) < ncl && id < base && ((base - id > ring_n) | (id < seg_begin))) {
+					U r;
+					__builtin_memcpy(&r, rec + (size_t)id * stride + off, sizeof(U));
+					src[s6] = (uint32_t)r;
 				}
 			}
+			__builtin_amdgcn_s_waitcnt(0);   // here, inside the rare branch: nothing after it may wait for vector memory
 		}
 		if constexpr (kSmallUnsigned) {
-			if (nc == 1) {   // LaneEvalSmall: a lone candidate counts twice
+			if (!run_mode) {   // LaneEvalSmall: a lone candidate counts twice
+				const bool lone1 = nc == 1;
 #pragma unroll
-				for (int j = 0; j < 3; ++j) { src[3 + j] = src[j]; tag[3 + j] = tag[j]; }
+				for (int j = 0; j < 3; ++j) { src[3 + j] = lone1 ? src[j] : src[3 + j]; tag[3 + j] = lone1 ? tag[j] : tag[3 + j]; }
 			}
 		}
 		LaneEval<T> ev;
 		ev.setup(nc, code, q);
-		// Every prepare load has landed before the next batch is requested: the memory counters retire in order, so a
-		// prefetch issued earlier would be waited for together with the first prepare load, and the chain below must not
-		// contain a single wait.  The prefetch then overlaps the whole chain.
-		__builtin_amdgcn_s_waitcnt(0);
-		prefetch(base + nb);
 		// ---- chain
 		uint32_t val = 0;
+		bool done_run = false;
 		if constexpr (kSmallUnsigned) {
+			if (run_mode) {
+				// Chain variant "run": lane l waits for lane l-1 only.  What bounds a lone wavefront here is the latency of
+				// DEPENDENT instructions (~10 cycles each), so the step is arranged for depth, not only for count:
+				//   x0   = value[l-1] + bo0        the add reads lane l-1 through a DPP wave shift; bo0 = the other two sources
+				//   p0   = clamp(x0, 0, top)
+				//   sum  = p0 * m + c              two candidates: m = 1, c = p1 + 1; a lone candidate: m = 2, c = 1 ((2p+1)>>1 == p);
+				//                                  a vertex without a source inside the batch: m = 0, c = its finished sum
+				//   pred = sum >> 1, and the inverse residual code is decided on sum directly (prediction.h:46-64):
+				//     near  <=>  (sum - 2(half+1)) <u 2(top - 2 half);  far value = sum <= 2(top>>1)+1 ? code : top - code
+				// 10 instructions + one s_nop (DPP read-after-write distance), 6 of them on the dependency path.
+				const uint32_t top = ev_top<T>(q);
+				const uint32_t kp = pend_slot < 3 ? 0u : pend_slot < 6 ? 1u : 0u;          // candidate holding the chained source
+				const uint32_t sa = kp ? src[3] : src[0], sb = kp ? src[4] : src[1], so = kp ? src[5] : src[2];
+				const uint32_t oa = kp ? src[0] : src[3], ob = kp ? src[1] : src[4], oo = kp ? src[2] : src[5];   // the other candidate
+				const bool pend_is_b = pend_slot == 1 || pend_slot == 4;
+				const uint32_t bo0 = (pend_is_b ? sa : sb) - so;
+				const uint32_t p1c = med3_i32((int32_t)(oa + ob - oo), 0, (int32_t)top);
+				const uint32_t p0c = med3_i32((int32_t)(sa + sb - so), 0, (int32_t)top);   // meaningful when every source is older
+				const bool two = nc == 2, lone = nc == 1, keepl = pend_slot == 6;
+				const uint32_t p1 = two ? p1c : 0u;
+				// every source older than the batch: the sum is a constant (m = 0)
+				const uint32_t m = keepl ? 0u : two ? 1u : 2u;
+				const uint32_t c = keepl ? (two ? p0c + p1 + 1u : lone ? 2u * p0c + 1u : 1u) : (two ? p1 + 1u : 1u);
+				UnfoldPre uf;
+				uf.setup(code, top, (uint32_t)(T)(~T(0)));
+				const uint32_t htop2 = 2u * (top >> 1) + 1u, c_hp2 = 2u * (uf.half + 1u), c_lim2 = top >= 2u * uf.half ? 2u * (top - 2u * uf.half) : 0u;
+#define HRY_RSTEP                                                                                                       \
+				    "v_add_u32_dpp v100, %[val], %[bo0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"            \
+				    "v_med3_i32 v100, v100, 0, %[top]\n\t"                                                                 \
+				    "v_mad_u32_u24 v102, v100, %[m], %[c]\n\t"                                                             \
+				    "v_lshrrev_b32 v103, 1, v102\n\t"                                                                      \
+				    "v_sub_u32 v104, v102, %[hp2]\n\t"                                                                     \
+				    "v_cmp_ge_u32 s[80:81], %[htop2], v102\n\t"                                                            \
+				    "v_cmp_lt_u32 s[82:83], v104, %[lim2]\n\t"                                                             \
+				    "v_add_u32 v106, v103, %[delta]\n\t"                                                                   \
+				    "v_cndmask_b32 v107, %[tmc], %[code], s[80:81]\n\t"                                                    \
+				    "v_cndmask_b32 %[val], v107, v106, s[82:83]\n\t"                                                       \
+				    "s_nop 1\n\t"
+#define HRY_RSTEP8                                                                                                      \
+				asm(HRY_RSTEP HRY_RSTEP HRY_RSTEP HRY_RSTEP HRY_RSTEP HRY_RSTEP HRY_RSTEP HRY_RSTEP                        \
+				    : [val] "+v"(val)                                                                                     \
+				    : [bo0] "v"(bo0), [m] "v"(m), [c] "v"(c), [top] "s"(top), [htop2] "s"(htop2), [code] "v"(uf.code),          \
+				      [tmc] "v"(uf.top_minus_code), [delta] "v"(uf.delta), [hp2] "v"(c_hp2), [lim2] "v"(c_lim2)               \
+				    : "v100", "v102", "v103", "v104", "v106", "v107", "s80", "s81", "s82", "s83");
+				asm volatile("s_nop 1");   // the first DPP read of val
+				for (uint32_t i = 0; i < nb; i += 8) { HRY_RSTEP8 }
+#undef HRY_RSTEP8
+#undef HRY_RSTEP
+				done_run = true;
+			}
+		}
+		if constexpr (kSmallUnsigned) {
+			if (!done_run) {
 			// One step, hand-scheduled: 27 instructions, every hazard distance of gfx950 (VALU-written SGPR read by a VALU: 2
 			// wait states, VALU-written VGPR read by v_readlane: 1) is covered by independent instructions instead of s_nop,
 			// each of which would cost this lone wavefront a full issue slot.  Same arithmetic as LaneEvalSmall::eval with
@@ -736,6 +858,7 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			} while (0);
 #undef HRY_STEP8
 #undef HRY_STEP
+			}
 		} else {
 #pragma unroll
 			for (uint32_t i = 0; i < 64; ++i) {
@@ -752,7 +875,6 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			ring[v & mask] = (U)val;
 			stq<T>(rec + (size_t)v * stride + off, cm::bits<T>((U)val));
 		}
-		__syncthreads();
 		base += nb;
 	}
 }
@@ -773,7 +895,8 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 		const uint32_t b = segs[2 * k], e = segs[2 * k + 1];
 		if (b < e)
 			unpredict2_component<T>(tp, order_v, nvtx, b, e, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
-			                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T));
+			                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T),
+			                        (uint32_t*)((uint8_t*)ring_raw2 + ring_bytes));
 		__syncthreads();
 	}
 }
@@ -836,13 +959,13 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
                        const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists)
 {
 	if (!nvtx || !ld.ncomp || !n_lists) return;
-	const uint32_t ring_bytes = 64 * 1024;
+	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + kQueue * kQueueCols * 4;
 	auto go = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		(void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes);
-		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64), ring_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel,
+		(void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64), lds_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel,
 		                   segs, list_off);
 	};
 	// components of different types are independent chains too: their kernels may overlap on the device
