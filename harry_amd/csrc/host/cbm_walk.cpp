@@ -263,23 +263,27 @@ struct Emitter {
 
 }   // namespace
 
-void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
+// DEG > 0: every polygon has DEG edges and the face of a half-edge is a division by a compile-time constant (the runtime
+// division this replaces was a third of the walk); DEG == 0: mixed degrees, table lookup
+template <int DEG>
+static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 {
 	const uint32_t nv = m.nv, nf = m.nf;
 	if (nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
 	const uint32_t *foff = m.face_off.data();
 	const uint32_t *org = m.org.data();
 	uint32_t *twin = m.twin.data();
-	// face of a half-edge: arithmetic for uniform degree, table otherwise
-	int udeg = 0;
-	const bool uniform = m.uniform_degree(udeg);
 	std::vector<uint32_t> eface_tab;
-	if (!uniform) {
+	if (DEG == 0) {
 		eface_tab.resize(m.ne());
 		for (uint32_t f = 0; f < nf; ++f) for (uint32_t e = foff[f]; e < foff[f + 1]; ++e) eface_tab[e] = f;
 	}
-	auto face_of = [&](uint32_t e) { return uniform ? e / (uint32_t)udeg : eface_tab[e]; };
-	auto nxt = [&](uint32_t e) { uint32_t f = face_of(e); return e + 1 == foff[f + 1] ? foff[f] : e + 1; };
+	auto face_of = [&](uint32_t e) -> uint32_t { return DEG ? e / (uint32_t)(DEG ? DEG : 1) : eface_tab[e]; };
+	auto nxt = [&](uint32_t e) -> uint32_t {
+		if (DEG) { uint32_t k = e % (uint32_t)(DEG ? DEG : 1); return k + 1 == (uint32_t)DEG ? e - k : e + 1; }
+		uint32_t f = eface_tab[e];
+		return e + 1 == foff[f + 1] ? foff[f] : e + 1;
+	};
 	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; };
 
 	int ndeg = 0;
@@ -394,6 +398,17 @@ void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
 	} while (pool.left != 0);
 	em.iop(I_EOM);
 	w.n_conn = em.n;
+}
+
+void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
+{
+	int udeg = 0;
+	if (!m.uniform_degree(udeg)) udeg = 0;
+	switch (udeg) {
+	case 3: walk_impl<3>(m, w, eval_op_model); break;
+	case 4: walk_impl<4>(m, w, eval_op_model); break;
+	default: walk_impl<0>(m, w, eval_op_model); break;   // mixed (or unusual uniform) degrees
+	}
 }
 
 }   // namespace hry
