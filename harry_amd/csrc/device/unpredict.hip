@@ -707,7 +707,7 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			tag[s6] = inb ? id - base : kNoLane;   // produced inside this batch, by an earlier lane
 		}
 		bool run_mode = false;
-		if constexpr (kSmallUnsigned) {
+		{
 			const bool chained = (npend == 0) | ((npend == 1) & (ngood == 1));
 			const uint64_t unchained = __ballot(!chained);   // never lane 0: all its sources are older; lanes >= nb count as chained
 			const uint32_t run = unchained ? min(nb, (uint32_t)__builtin_ctzll(unchained)) : nb;
@@ -858,6 +858,83 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			} while (0);
 #undef HRY_STEP8
 #undef HRY_STEP
+			}
+		} else if (run_mode && cm::is_fp<T>::value) {
+			// Chain variant "run" for float components (lossless meshes), hand-scheduled like the 16-bit one.  Per lane:
+			//   x  = value of the previous vertex (DPP wave shift)
+			//   pp = the parallelogram that waits for it: x + T (x is its first source, T = v1 - v2) or A + (x - O) (second source)
+			//   (p0, p1) = (pp, q) or (q, pp): q is the finished other parallelogram, the order of the candidates is kept because
+			//   the selection below is not symmetric (attrcode.h:182-208: mean in double, candidate nearest to it, strict <,
+			//   starting from FLT_MAX); a lone candidate is the prediction itself
+			//   value = inverse residual code on the ordered-int images (transform.h:19-23, prediction.h:46-64, no sign flip)
+			// 33 instructions + 3 s_nop per vertex; LaneEval<float>::eval is the readable form of the same arithmetic.
+			const uint32_t kp = pend_slot < 3 ? 0u : pend_slot < 6 ? 1u : 0u;
+			const float fa = cm::bits<float>(kp ? src[3] : src[0]), fb = cm::bits<float>(kp ? src[4] : src[1]), fo = cm::bits<float>(kp ? src[5] : src[2]);
+			const float ga = cm::bits<float>(kp ? src[0] : src[3]), gb = cm::bits<float>(kp ? src[1] : src[4]), go = cm::bits<float>(kp ? src[2] : src[5]);
+			const uint32_t cT = cm::bits<uint32_t>(fb - fo), cA = cm::bits<uint32_t>(fa), cO = cm::bits<uint32_t>(fo);
+			const uint32_t cq = cm::bits<uint32_t>(ga + (gb - go));
+			const uint32_t valc = ev.eval(src);                       // the finished value of a vertex without a source inside the batch
+			const uint64_t isB = __ballot(pend_slot == 1 || pend_slot == 4), isK1 = __ballot(kp == 1);
+			const uint64_t lone = __ballot(nc == 1), keep = __ballot(pend_slot == 6);
+			UnfoldPre uf;
+			uf.setup(code, 0xffffffffu, 0xffffffffu);
+			const uint32_t c_hp1 = uf.half + 1u, c_lim = 0xffffffffu - 2u * uf.half, fltmax = 0x7f7fffffu, htop = 0x7fffffffu;
+#define HRY_FSTEP                                                                                                       \
+			    "v_add_f32_dpp v100, %[val], %[T] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                   \
+			    "v_sub_f32_dpp v101, %[val], %[O] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                   \
+			    "v_add_f32 v101, %[A], v101\n\t"                                                                           \
+			    "v_cndmask_b32 v100, v100, v101, %[isB]\n\t"                                                               \
+			    "v_cndmask_b32 v102, v100, %[q], %[isK1]\n\t"                                                              \
+			    "v_cndmask_b32 v103, %[q], v100, %[isK1]\n\t"                                                              \
+			    "v_cvt_f64_f32 v[104:105], v102\n\t"                                                                       \
+			    "v_cvt_f64_f32 v[106:107], v103\n\t"                                                                       \
+			    "v_add_f64 v[104:105], v[104:105], v[106:107]\n\t"                                                         \
+			    "v_mul_f64 v[104:105], v[104:105], 0.5\n\t"                                                                \
+			    "v_cvt_f32_f64 v108, v[104:105]\n\t"                                                                       \
+			    "v_sub_f32 v109, v108, v102\n\t"                                                                           \
+			    "v_sub_f32 v110, v108, %[fmax]\n\t"                                                                        \
+			    "v_cmp_lt_f32 s[80:81], |v110|, |v109|\n\t"                                                                \
+			    "v_sub_f32 v111, v108, v103\n\t"                                                                           \
+			    "s_nop 0\n\t"                                                                                              \
+			    "v_cndmask_b32 v112, v102, %[fmax], s[80:81]\n\t"                                                          \
+			    "v_sub_f32 v114, v108, v112\n\t"                                                                           \
+			    "v_cmp_lt_f32 s[82:83], |v114|, |v111|\n\t"                                                                \
+			    "s_nop 1\n\t"                                                                                              \
+			    "v_cndmask_b32 v115, v103, v112, s[82:83]\n\t"                                                             \
+			    "v_cndmask_b32 v115, v115, v102, %[lone]\n\t"                                                              \
+			    "v_ashrrev_i32 v116, 31, v115\n\t"                                                                         \
+			    "v_lshrrev_b32 v116, 1, v116\n\t"                                                                          \
+			    "v_xor_b32 v116, v116, v115\n\t"                                                                           \
+			    "v_sub_u32 v117, v116, %[hp1]\n\t"                                                                         \
+			    "v_cmp_ge_u32 s[80:81], %[htop], v116\n\t"                                                                 \
+			    "v_cmp_lt_u32 s[82:83], v117, %[lim]\n\t"                                                                  \
+			    "v_add_u32 v118, v116, %[delta]\n\t"                                                                       \
+			    "v_cndmask_b32 v119, %[tmc], %[code], s[80:81]\n\t"                                                        \
+			    "v_cndmask_b32 v119, v119, v118, s[82:83]\n\t"                                                             \
+			    "v_ashrrev_i32 v120, 31, v119\n\t"                                                                         \
+			    "v_lshrrev_b32 v120, 1, v120\n\t"                                                                          \
+			    "v_xor_b32 v119, v120, v119\n\t"                                                                           \
+			    "v_cndmask_b32 %[val], v119, %[valc], %[keep]\n\t"                                                         \
+			    "s_nop 1\n\t"
+			asm volatile("s_nop 1");   // the first DPP read of val, and the ballots above
+			for (uint32_t i = 0; i < nb; i += 4) {
+				asm(HRY_FSTEP HRY_FSTEP HRY_FSTEP HRY_FSTEP
+				    : [val] "+v"(val)
+				    : [T] "v"(cT), [A] "v"(cA), [O] "v"(cO), [q] "v"(cq), [fmax] "v"(fltmax), [valc] "v"(valc), [code] "v"(uf.code),
+				      [tmc] "v"(uf.top_minus_code), [delta] "v"(uf.delta), [hp1] "v"(c_hp1), [lim] "v"(c_lim), [htop] "s"(htop),
+				      [isB] "s"(isB), [isK1] "s"(isK1), [lone] "s"(lone), [keep] "s"(keep)
+				    : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v114", "v115",
+				      "v116", "v117", "v118", "v119", "v120", "s80", "s81", "s82", "s83");
+			}
+#undef HRY_FSTEP
+		} else if (run_mode) {
+			// Chain variant "run" for the other component types (32-bit and signed integers): the same wave shift, the
+			// arithmetic is LaneEval<T>::eval itself with the previous vertex substituted for the one source that waits for it.
+			const bool w0 = pend_slot == 0, w1 = pend_slot == 1, w3 = pend_slot == 3, w4 = pend_slot == 4;
+			for (uint32_t i = 0; i < nb; ++i) {
+				const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)val, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+				const uint32_t s[6] = { w0 ? prev : src[0], w1 ? prev : src[1], src[2], w3 ? prev : src[3], w4 ? prev : src[4], src[5] };
+				val = ev.eval(s);
 			}
 		} else {
 #pragma unroll
