@@ -133,3 +133,44 @@ def test_decode_rejects_corrupt_input(cx):
     bad[5] = 7   # unknown minor version
     with pytest.raises(hc.HryError):
         cx.read_hry(bytes(bad))
+
+
+def with_integer_props(m: mg.Mesh, seed=7) -> mg.Mesh:
+    """Smooth integer-valued vertex properties of every PLY integer type next to the float coordinates."""
+    rng = np.random.default_rng(seed)
+    names = list(m.verts.dtype.names)
+    dt = [(n, m.verts.dtype[n]) for n in names] + [("pi32", "<i4"), ("pu32", "<u4"), ("pi16", "<i2"), ("pu16", "<u2"), ("pi8", "i1"), ("pu8", "u1")]
+    v = np.zeros(m.nv, dtype=dt)
+    for n in names:
+        v[n] = m.verts[n]
+    base = (m.verts["x"].astype(np.float64) * 900 + m.verts["y"].astype(np.float64) * 300)
+    v["pi32"] = (base * 1000).astype(np.int64).astype(np.int32) + rng.integers(-3, 4, m.nv, dtype=np.int32)
+    v["pu32"] = (base * 1000 + 3_000_000_000).astype(np.int64).astype(np.uint32)
+    v["pi16"] = np.clip(base * 10, -32000, 32000).astype(np.int16) + rng.integers(-2, 3, m.nv).astype(np.int16)
+    v["pu16"] = (np.clip(base * 10, -32000, 32000) + 32768).astype(np.uint16)
+    v["pi8"] = np.clip(base / 12, -120, 120).astype(np.int8)
+    v["pu8"] = (np.clip(base / 12, -120, 120) + 128).astype(np.uint8)
+    return mg.Mesh(v, m.degrees, m.indices, m.face_props)
+
+
+@pytest.mark.parametrize("case", ["int_props_tri", "int_props_mixed", "mixed_normals_lossless", "quant_mixed_widths"])
+def test_chunked_component_types_and_chain_variants(cx, case):
+    """Every component type the reference stores (float, (u)int32, (u)int16, (u)int8) through the reconstruction chain,
+    on meshes whose traversal mixes long runs with frequent batch cuts; decode must equal the reference-format decode."""
+    mesh, quant = {
+        "int_props_tri": (lambda: with_integer_props(mg.torus(70, 75, seed=5)), []),
+        "int_props_mixed": (lambda: with_integer_props(mg.with_nonmanifold(mg.torus(50, 56, polys="mixed", seed=6), 20, 8)), []),
+        "mixed_normals_lossless": (lambda: mg.torus(120, 130, polys="mixed", normals=True, seed=8), []),
+        "quant_mixed_widths": (lambda: mg.torus(110, 90, normals=True, seed=9), [(1, 0, 20), (1, 1, 7), (1, 2, 16), (1, 3, 9), (1, 4, 24), (1, 5, 3)]),
+    }[case]
+    ply = mesh().to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    if quant:
+        cx.requant(a, quant)
+        o.requant(quant)
+    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
+    assert got == o.clone().encode_chunked(0).data
+    same_mesh(cx.read_hry(got), ref_dec)
+    # the reference-format stream of the same mesh through the host reader + the same device reconstruction
+    same_mesh(cx.read_hry(cx.write_hry(a.clone())), ref_dec)
