@@ -89,6 +89,7 @@ def load():
     L.hry_free.argtypes = [vp]
     L.hry_stage_get.restype = C.c_int; L.hry_stage_get.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
     L.hry_walk_run.restype = C.c_int; L.hry_walk_run.argtypes = [vp, C.POINTER(vp)]
+    L.hry_walk_run_plain.restype = C.c_int; L.hry_walk_run_plain.argtypes = [vp, C.POINTER(vp)]
     L.hry_walk_get.restype = sz; L.hry_walk_get.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.hry_walk_free.argtypes = [vp]
     L.hry_stream_read_host.restype = C.c_int; L.hry_stream_read_host.argtypes = [C.c_char_p, sz, C.POINTER(vp), C.POINTER(vp)]

@@ -131,11 +131,12 @@ class Mesh:
         nat.check(nat.load().hry_mesh_to_ply(self.h, int(ascii), C.byref(p), C.byref(n)))
         return nat.take_bytes(p, n.value)
 
-    def host_walk(self) -> dict:
-        """Host-only cut-border walk with a recording writer (mutates twins like an encode)."""
+    def host_walk(self, plain: bool = False) -> dict:
+        """Host-only cut-border walk with a recording writer (mutates twins like an encode).  plain: without the operation
+        model (the chunked profile's walk; may use several host threads for multi-component meshes)."""
         L = nat.load()
         w = C.c_void_p()
-        nat.check(L.hry_walk_run(self.h, C.byref(w)))
+        nat.check((L.hry_walk_run_plain if plain else L.hry_walk_run)(self.h, C.byref(w)))
         try:
             out = {}
             names = [("order_v", np.uint32), ("order_f", np.uint32), ("op_sym", np.uint8), ("op_class", np.uint8), ("op_l", np.uint32),

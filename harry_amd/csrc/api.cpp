@@ -172,6 +172,18 @@ int hry_walk_run(hry_mesh *m, hry_walk **out)
 		*out = w.release();
 	});
 }
+int hry_walk_run_plain(hry_mesh *m, hry_walk **out)
+{
+	if (!m || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<hry_walk> w(new hry_walk());
+		check_codable(m->m);
+		cut_border_walk(m->m, w->w, false);
+		w->info[0] = w->w.n_conn; w->info[1] = w->w.numtri_coded ? 1 : 0;
+		*out = w.release();
+	});
+}
 size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 {
 	if (!w || !name || !ptr) return 0;

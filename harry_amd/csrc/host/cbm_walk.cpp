@@ -11,6 +11,14 @@
 #include "host.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <exception>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <unordered_set>
 
 namespace hry {
@@ -26,9 +34,9 @@ struct Border {
 	std::vector<Node> pool;
 	std::vector<int32_t> spare;
 	std::vector<Part> parts;
-	std::vector<uint8_t> on;   // how many border elements reference a vertex (cutborder.h:69)
+	std::vector<uint8_t> &on;  // how many border elements reference a vertex (cutborder.h:69); shared per-vertex array
 
-	explicit Border(uint32_t nv) : on(nv, 0) { pool.reserve(1024); }
+	explicit Border(std::vector<uint8_t> &on_) : on(on_) { pool.reserve(1024); }
 	Part &top() { return parts.back(); }
 	Node &N(int32_t i) { return pool[i]; }
 
@@ -173,14 +181,12 @@ struct Border {
 struct StartFaces {
 	struct Block { uint32_t first, last; };   // consecutive keys in list order: ascending if first <= last, else descending
 	uint32_t nf;
-	std::vector<uint8_t> gone;
+	std::vector<uint8_t> &gone;
 	std::vector<Block> blocks;
 	size_t bi = 0;
 	uint32_t pos = 0;
 	bool have_order = false;
-	uint32_t left;
-	explicit StartFaces(uint32_t n) : nf(n), gone(n, 0), left(n) {}
-	void take(uint32_t f) { gone[f] = 1; --left; }
+	StartFaces(uint32_t n, std::vector<uint8_t> &gone_) : nf(n), gone(gone_) {}
 	void derive_order()
 	{
 		std::__detail::_Prime_rehash_policy pol;
@@ -199,6 +205,28 @@ struct StartFaces {
 		blocks.swap(list);
 		have_order = true;
 		bi = 0; pos = 0;
+	}
+	// position of a face in the sequence (blocks sorted by their smallest key, binary search)
+	struct Span { uint32_t lo, hi, first_pos; bool asc; };
+	std::vector<Span> spans;
+	void index_blocks()
+	{
+		spans.clear();
+		uint32_t pos0 = 0;
+		for (const Block &b : blocks) {
+			bool asc = b.first <= b.last;
+			uint32_t lo = asc ? b.first : b.last, hi = asc ? b.last : b.first;
+			spans.push_back(Span{ lo, hi, pos0, asc });
+			pos0 += hi - lo + 1;
+		}
+		std::sort(spans.begin(), spans.end(), [](const Span &x, const Span &y) { return x.lo < y.lo; });
+	}
+	uint32_t position(uint32_t f) const
+	{
+		size_t a = 0, b = spans.size();
+		while (b - a > 1) { size_t mid = (a + b) / 2; if (spans[mid].lo <= f) a = mid; else b = mid; }
+		const Span &s = spans[a];
+		return s.first_pos + (s.asc ? f - s.lo : s.hi - f);
 	}
 	uint32_t at_cursor() const
 	{
@@ -219,7 +247,6 @@ struct StartFaces {
 			while (gone[at_cursor()]) advance();
 			f = at_cursor();
 		}
-		take(f);
 		return f;
 	}
 };
@@ -261,31 +288,420 @@ struct Emitter {
 	}
 };
 
-}   // namespace
+// Shared state of a walk: per-vertex and per-face marks.  Connected components touch disjoint faces, and disjoint
+// vertices unless they share a (non-manifold) vertex, so several components can be walked at the same time on
+// these arrays as long as components that share a vertex are walked in coding order by one thread.
+struct WalkState {
+	std::vector<uint8_t> gone;      // face consumed
+	std::vector<uint8_t> on;        // how many border elements reference a vertex (cutborder.h:69)
+	std::vector<uint32_t> sent;     // original vertex -> transmitted index (encoder.h:28-52)
+	std::vector<uint16_t> seen;     // triangles seen per vertex (selects the op model class)
+	WalkState(uint32_t nv, uint32_t nf) : gone(nf, 0), on(nv, 0), sent(nv, NONE32), seen(nv, 0) {}
+};
 
-// DEG > 0: every polygon has DEG edges and the face of a half-edge is a division by a compile-time constant (the runtime
-// division this replaces was a third of the walk); DEG == 0: mixed degrees, table lookup
+// One connected component, starting at face f (encoder.h:68-214).  DEG > 0: every polygon has DEG edges and the face of a
+// half-edge is a division by a compile-time constant; DEG == 0: mixed degrees, table lookup.
+template <int DEG>
+static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, uint32_t f, Border &cb, Emitter &em, uint32_t &next_id, uint32_t &consumed)
+{
+	WalkResult &w = em.w;
+	const uint32_t *foff = m.face_off.data();
+	const uint32_t *org = m.org.data();
+	uint32_t *twin = m.twin.data();
+	uint8_t *gone = st.gone.data();
+	uint32_t *sent = st.sent.data();
+	uint16_t *seen = st.seen.data();
+	auto face_of = [&](uint32_t e) -> uint32_t { return DEG ? e / (uint32_t)(DEG ? DEG : 1) : eface_tab[e]; };
+	auto nxt = [&](uint32_t e) -> uint32_t {
+		if (DEG) { uint32_t k = e % (uint32_t)(DEG ? DEG : 1); return k + 1 == (uint32_t)DEG ? e - k : e + 1; }
+		uint32_t fe = eface_tab[e];
+		return e + 1 == foff[fe + 1] ? foff[fe] : e + 1;
+	};
+	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; };
+	auto record_vertex = [&](uint32_t e) { w.order_v.push_back(e); sent[org[e]] = next_id++; };
+	auto take = [&](uint32_t face) { gone[face] = 1; ++consumed; };
+
+	take(f);
+	uint32_t e0 = foff[f], e1 = nxt(e0), e2 = nxt(e1);
+	uint32_t a = org[e0], b = org[e1], c = org[e2];
+	int ntri = (int)(foff[f + 1] - foff[f]) - 2, curtri = 1;
+	unsigned mask = (sent[a] != NONE32 ? 4u : 0u) | (sent[b] != NONE32 ? 2u : 0u) | (sent[c] != NONE32 ? 1u : 0u);
+	switch (mask) {
+	case 7: em.iop(I_TRI111); em.vert(sent[a]); em.vert(sent[b]); em.vert(sent[c]); em.numtri(ntri); break;
+	case 6: em.iop(I_TRI110); em.vert(sent[a]); em.vert(sent[b]); em.numtri(ntri); record_vertex(e2); break;
+	case 3: em.iop(I_TRI011); em.vert(sent[b]); em.vert(sent[c]); em.numtri(ntri); record_vertex(e0); break;
+	case 5: em.iop(I_TRI101); em.vert(sent[c]); em.vert(sent[a]); em.numtri(ntri); record_vertex(e1); break;
+	case 4: em.iop(I_TRI100); em.vert(sent[a]); em.numtri(ntri); record_vertex(e1); record_vertex(e2); break;
+	case 2: em.iop(I_TRI010); em.vert(sent[b]); em.numtri(ntri); record_vertex(e2); record_vertex(e0); break;
+	case 1: em.iop(I_TRI001); em.vert(sent[c]); em.numtri(ntri); record_vertex(e0); record_vertex(e1); break;
+	default: em.iop(I_INIT); em.numtri(ntri); record_vertex(e0); record_vertex(e1); record_vertex(e2); break;
+	}
+	w.order_f.push_back(e0);
+	++seen[a]; ++seen[b]; ++seen[c];
+	cb.start(a, e0, b, e1, c, e2);
+
+	// ---- grow until the border of this component is exhausted (encoder.h:133-214)
+	while (!cb.parts.empty()) {
+		Border::Part &pt = cb.top();
+		const uint32_t v0 = cb.N(pt.tail).v, v1 = cb.N(pt.head).v;
+		const uint32_t gate = cb.N(pt.tail).a;
+		const uint32_t gateprev = cb.N(cb.N(pt.tail).prev).a;
+		const uint32_t gatenext = cb.N(pt.head).a;
+		const bool seq_first = curtri == ntri;
+		const int order = seen[v1];
+		if (seq_first) {
+			uint32_t t = twin[gate];
+			if (t == gate || gone[face_of(t)]) {   // writer.cc:48-58: mesh border or neighbour already consumed
+				Op bop = cb.border();
+				if (t != gate) twin[gate] = gate;       // one-sided split (writer.cc:81-84)
+				em.op(bop, order);
+				continue;
+			}
+			take(face_of(t));
+			e0 = t;
+			f = face_of(e0);
+			ntri = (int)(foff[f + 1] - foff[f]) - 2;
+			curtri = 0;
+			e1 = nxt(e0);
+		} else e1 = nxt(e1);
+		e2 = nxt(e1);
+		const uint32_t v2 = org[e2];
+		const bool seq_last = curtri + 1 == ntri;
+		const int nt = seq_first ? ntri : 0;
+
+		bool fresh = sent[v2] == NONE32;
+		if (fresh || cb.on[v2] == 0) {
+			// NEWVTX, or a vertex that was coded before but left the border (non-manifold): encoder.h:167-181
+			Border::Part &p = cb.top();
+			cb.N(p.tail).a = e1;
+			cb.append(p, cb.make(v2, e2));
+			if (fresh) { em.op(O_NEWVTX, order); em.numtri(nt); record_vertex(e2); }
+			else { em.op(O_NM, order); em.vert(sent[v2]); em.numtri(nt); }
+		} else {
+			int i, p;
+			int32_t hit = cb.locate(v2, i, p);
+			if (p > 0) {
+				int32_t g, cp;
+				cb.unite(hit, p, g, cp);
+				em.op(O_UNION, order); em.elem(i); em.part(p); em.numtri(nt);
+				cb.N(g).a = e1; cb.N(cp).a = e2;
+			} else {
+				Border::Part &tp = cb.top();
+				if (tp.edge_begin && cb.N(cb.N(tp.head).next).v == v2) {
+					bool close = tp.size == 3;   // edge_begin && 3 elements: the part is exactly this triangle
+					if (seq_last && twin[gatenext] != e2) link(gatenext, e2);
+					if (close && twin[gateprev] != e1) link(gateprev, e1);
+					if (close) cb.discard_top();
+					else { cb.drop(cb.unlink_head(tp)); cb.N(tp.tail).a = e1; }
+					em.op(O_CONNFWD, order); em.numtri(nt);
+				} else if (cb.N(cb.N(tp.tail).prev).v == v2) {
+					if (twin[gateprev] != e1) link(gateprev, e1);
+					cb.drop(cb.unlink_tail(tp));
+					cb.N(tp.tail).a = e2;
+					em.op(O_CONNBWD, order); em.numtri(nt);
+				} else {
+					int32_t g, cp;
+					cb.split(hit, i, g, cp);
+					em.op(O_SPLIT, order); em.elem(i); em.numtri(nt);
+					cb.N(g).a = e1; cb.N(cp).a = e2;
+				}
+			}
+		}
+		++seen[v0]; ++seen[v1]; ++seen[v2];
+		if (seq_first) w.order_f.push_back(e0);
+		++curtri;
+	}
+}
+
+static uint32_t parallel_min_faces();
+template <int DEG>
+static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads);
+
+template <int DEG>
+static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, bool eval_op_model, unsigned n_threads)
+{
+	WalkState st(m.nv, m.nf);
+	Border cb(st.on);
+	StartFaces pool(m.nf, st.gone);
+	Emitter em(w);
+	em.eval_model = eval_op_model;
+	uint32_t next_id = 0, consumed = 0;
+	do {
+		uint32_t f = pool.next();
+		walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
+		// The operation model of the reference stream adapts across the whole file (models.h:49-120), so a walk that evaluates
+		// it is one sequence.  Without it (chunked profile: symbol + order class only) the remaining components are walked on
+		// several threads once the first one shows that the mesh has more than one.
+		if (n_threads > 1 && !eval_op_model && m.nf - consumed >= parallel_min_faces()) {
+			walk_rest_parallel<DEG>(m, st, eface_tab, em, next_id, n_threads);
+			break;
+		}
+	} while (consumed != m.nf);
+	em.iop(I_EOM);
+	w.n_conn = em.n;
+}
+
+// ---- several host threads --------------------------------------------------------
+static unsigned host_threads()
+{
+	if (const char *e = getenv("HRY_HOST_THREADS")) { int v = atoi(e); return v > 0 ? (unsigned)v : 1u; }
+	unsigned hw = std::thread::hardware_concurrency();
+	return std::max(1u, std::min(16u, hw ? hw : 1u));
+}
+// below this many remaining faces the analysis passes cost more than they save (HRY_PARALLEL_MIN_FACES overrides, tests)
+static uint32_t parallel_min_faces()
+{
+	if (const char *e = getenv("HRY_PARALLEL_MIN_FACES")) return (uint32_t)strtoul(e, nullptr, 10);
+	return 1u << 16;
+}
+template <typename F> static void parallel_for(unsigned n_threads, F &&body)   // body(thread index), joins before returning
+{
+	std::vector<std::thread> th;
+	std::exception_ptr err;
+	std::mutex mu;
+	for (unsigned t = 1; t < n_threads; ++t)
+		th.emplace_back([&, t] { try { body(t); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); } });
+	try { body(0); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+	for (auto &x : th) x.join();
+	if (err) std::rethrow_exception(err);
+}
+// lock-free union-find on atomics: a root is always the smallest index of its set's links, so links never form a cycle
+struct AtomicSets {
+	std::unique_ptr<std::atomic<uint32_t>[]> parent;
+	explicit AtomicSets(size_t n) : parent(new std::atomic<uint32_t>[n]) {}
+	uint32_t find(uint32_t x)
+	{
+		for (;;) {
+			uint32_t p = parent[x].load(std::memory_order_relaxed);
+			if (p == x) return x;
+			uint32_t g = parent[p].load(std::memory_order_relaxed);
+			if (g != p) parent[x].compare_exchange_weak(p, g, std::memory_order_relaxed);   // path halving
+			x = g;
+		}
+	}
+	void unite(uint32_t a, uint32_t b)
+	{
+		for (;;) {
+			a = find(a); b = find(b);
+			if (a == b) return;
+			if (a > b) std::swap(a, b);
+			uint32_t expect = b;
+			if (parent[b].compare_exchange_weak(expect, a, std::memory_order_relaxed)) return;
+		}
+	}
+};
+static void atomic_min(std::atomic<uint64_t> &a, uint64_t v)
+{
+	uint64_t cur = a.load(std::memory_order_relaxed);
+	while (v < cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+}
+static void atomic_min(std::atomic<uint32_t> &a, uint32_t v)
+{
+	uint32_t cur = a.load(std::memory_order_relaxed);
+	while (v < cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+}
+
+// Everything after the first component, on several threads.  The stream the sequential walk would produce is a
+// function of (a) which faces form a component, (b) the order of the components = the order of their first faces in the
+// start-face sequence, (c) the index the first new vertex of a component gets = the number of vertices the components
+// before it introduce.  All three are computed up front; components that share a vertex with an earlier unfinished one
+// stay in coding order on one thread (their symbols depend on that vertex's index and triangle count).
+template <int DEG>
+static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads)
+{
+	WalkResult &w = em0.w;
+	const uint32_t nf = m.nf, nv = m.nv, ne = m.ne();
+	const uint32_t *org = m.org.data();
+	const uint32_t *twin = m.twin.data();
+	const uint8_t *gone = st.gone.data();
+	auto face_of = [&](uint32_t e) -> uint32_t { return DEG ? e / (uint32_t)(DEG ? DEG : 1) : eface_tab[e]; };
+	auto split = [&](uint32_t n, unsigned t, uint32_t &b, uint32_t &e) { b = (uint32_t)((uint64_t)n * t / n_threads); e = (uint32_t)((uint64_t)n * (t + 1) / n_threads); };
+
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	auto t0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
+	// (a) components of the remaining faces
+	AtomicSets sets(nf);
+	parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nf, t, b, e); for (uint32_t f = b; f < e; ++f) sets.parent[f].store(f, std::memory_order_relaxed); });
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e; split(ne, t, b, e);
+		for (uint32_t h = b; h < e; ++h) {
+			uint32_t o = twin[h];
+			if (o > h) { uint32_t fa = face_of(h), fb = face_of(o); if (!gone[fa] && !gone[fb] && fa != fb) sets.unite(fa, fb); }
+		}
+	});
+	// dense component numbers (roots counted per thread range, then a prefix over the ranges)
+	std::vector<uint32_t> comp(nf, NONE32), range_roots(n_threads + 1, 0);
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e, c = 0; split(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) if (!gone[f] && sets.find(f) == f) ++c;
+		range_roots[t + 1] = c;
+	});
+	for (unsigned t = 0; t < n_threads; ++t) range_roots[t + 1] += range_roots[t];
+	const uint32_t ncomp = range_roots[n_threads];
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e, c = range_roots[t]; split(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) if (!gone[f] && sets.find(f) == f) comp[f] = c++;
+	});
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e; split(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) if (!gone[f]) { uint32_t r = sets.find(f); if (r != f) comp[f] = comp[r]; }
+	});
+	mark("components labelled");
+	// (b) first face of every component in the start-face sequence, and the coding order
+	StartFaces seq(nf, st.gone);
+	seq.derive_order();
+	seq.index_blocks();
+	std::unique_ptr<std::atomic<uint64_t>[]> first_key(new std::atomic<uint64_t>[ncomp]);
+	std::unique_ptr<std::atomic<uint32_t>[]> nfaces(new std::atomic<uint32_t>[ncomp]);
+	for (uint32_t c = 0; c < ncomp; ++c) { first_key[c].store(~0ull, std::memory_order_relaxed); nfaces[c].store(0, std::memory_order_relaxed); }
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e; split(nf, t, b, e);
+		uint32_t run_c = NONE32, run_n = 0;
+		uint64_t run_min = ~0ull;
+		auto flush = [&] { if (run_c != NONE32) { atomic_min(first_key[run_c], run_min); nfaces[run_c].fetch_add(run_n, std::memory_order_relaxed); } };
+		for (uint32_t f = b; f < e; ++f) {
+			if (gone[f]) continue;
+			uint32_t c = comp[f];
+			if (c != run_c) { flush(); run_c = c; run_n = 0; run_min = ~0ull; }
+			++run_n;
+			run_min = std::min(run_min, ((uint64_t)seq.position(f) << 32) | f);
+		}
+		flush();
+	});
+	std::vector<uint32_t> by_rank(ncomp), rank_of(ncomp);
+	for (uint32_t c = 0; c < ncomp; ++c) by_rank[c] = c;
+	std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t x, uint32_t y) { return first_key[x].load(std::memory_order_relaxed) < first_key[y].load(std::memory_order_relaxed); });
+	for (uint32_t k = 0; k < ncomp; ++k) rank_of[by_rank[k]] = k;
+	mark("coding order");
+	// (c) the first remaining component (in coding order) that touches each vertex: it introduces the vertex unless the part
+	// walked before already transmitted it.  Components that touch a common vertex are tied together: the vertex's index,
+	// its triangle count (operation class) and its border count make the later one depend on the earlier one.
+	std::unique_ptr<std::atomic<uint32_t>[]> vfirst(new std::atomic<uint32_t>[nv]);
+	parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nv, t, b, e); for (uint32_t v = b; v < e; ++v) vfirst[v].store(NONE32, std::memory_order_relaxed); });
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e; split(ne, t, b, e);
+		for (uint32_t h = b; h < e; ++h) { uint32_t f = face_of(h); if (!gone[f]) atomic_min(vfirst[org[h]], rank_of[comp[f]]); }
+	});
+	AtomicSets ties(ncomp);
+	for (uint32_t k = 0; k < ncomp; ++k) ties.parent[k].store(k, std::memory_order_relaxed);
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e; split(ne, t, b, e);
+		for (uint32_t h = b; h < e; ++h) {
+			uint32_t f = face_of(h);
+			if (gone[f]) continue;
+			uint32_t k = rank_of[comp[f]], first = vfirst[org[h]].load(std::memory_order_relaxed);
+			if (first != k) ties.unite(first, k);
+		}
+	});
+	std::unique_ptr<std::atomic<uint32_t>[]> fresh(new std::atomic<uint32_t>[ncomp]);
+	for (uint32_t k = 0; k < ncomp; ++k) fresh[k].store(0, std::memory_order_relaxed);
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e; split(nv, t, b, e);
+		uint32_t run_k = NONE32, run_n = 0;
+		for (uint32_t v = b; v < e; ++v) {
+			uint32_t first = vfirst[v].load(std::memory_order_relaxed);
+			if (first == NONE32 || st.sent[v] != NONE32) continue;
+			if (first != run_k) { if (run_k != NONE32) fresh[run_k].fetch_add(run_n, std::memory_order_relaxed); run_k = first; run_n = 0; }
+			++run_n;
+		}
+		if (run_k != NONE32) fresh[run_k].fetch_add(run_n, std::memory_order_relaxed);
+	});
+	std::vector<uint32_t> id_base(ncomp + 1);
+	id_base[0] = first_id;
+	for (uint32_t k = 0; k < ncomp; ++k) id_base[k + 1] = id_base[k] + fresh[k].load(std::memory_order_relaxed);
+	// work items: groups of tied components (ascending rank inside a group), largest groups first
+	std::vector<uint32_t> group_of(ncomp);
+	for (uint32_t k = 0; k < ncomp; ++k) group_of[k] = ties.find(k);
+	std::vector<uint32_t> order(ncomp);
+	for (uint32_t k = 0; k < ncomp; ++k) order[k] = k;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return group_of[x] < group_of[y]; });   // ranks stay ascending inside a group
+	struct Item { uint32_t begin, end; uint64_t faces; };
+	std::vector<Item> items;
+	for (uint32_t i = 0; i < ncomp;) {
+		uint32_t j = i;
+		uint64_t nfc = 0;
+		while (j < ncomp && group_of[order[j]] == group_of[order[i]]) { nfc += nfaces[by_rank[order[j]]].load(std::memory_order_relaxed); ++j; }
+		items.push_back(Item{ i, j, nfc });
+		i = j;
+	}
+	std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.faces > y.faces; });
+	if (trace) fprintf(stderr, "[hry walk] %u components in %zu groups, largest group %llu faces\n", ncomp, items.size(), items.empty() ? 0ull : (unsigned long long)items[0].faces);
+	mark("vertex bases and groups");
+	// the walks
+	std::vector<WalkResult> frag(ncomp);
+	std::vector<uint32_t> frag_syms(ncomp, 0);
+	std::atomic<size_t> next_item{ 0 };
+	parallel_for(n_threads, [&](unsigned) {
+		Border cb(st.on);
+		for (;;) {
+			size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
+			if (it >= items.size()) break;
+			for (uint32_t q = items[it].begin; q < items[it].end; ++q) {
+				const uint32_t k = order[q], c = by_rank[k];
+				WalkResult &fw = frag[k];
+				fw.numtri_coded = w.numtri_coded;
+				const uint32_t nfc = nfaces[c].load(std::memory_order_relaxed);
+				fw.order_f.reserve(nfc); fw.order_v.reserve(fresh[k].load(std::memory_order_relaxed));
+				Emitter em(fw);
+				em.eval_model = false;
+				uint32_t next_id = id_base[k], consumed = 0;
+				walk_component<DEG>(m, st, eface_tab, (uint32_t)first_key[c].load(std::memory_order_relaxed), cb, em, next_id, consumed);
+				if (next_id != id_base[k + 1] || consumed != nfc) throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
+				frag_syms[k] = em.n;
+			}
+		}
+	});
+	mark("walks");
+	// concatenation in coding order
+	std::vector<uint64_t> off_sym(ncomp + 1), off_v(ncomp + 1), off_f(ncomp + 1), off_op(ncomp + 1), off_g[G_COUNT];
+	for (int g = 0; g < G_COUNT; ++g) off_g[g].resize(ncomp + 1);
+	off_sym[0] = em0.n; off_v[0] = w.order_v.size(); off_f[0] = w.order_f.size(); off_op[0] = w.op_sym.size();
+	for (int g = 0; g < G_COUNT; ++g) off_g[g][0] = w.grp_val[g].size();
+	for (uint32_t k = 0; k < ncomp; ++k) {
+		off_sym[k + 1] = off_sym[k] + frag_syms[k];
+		off_v[k + 1] = off_v[k] + frag[k].order_v.size();
+		off_f[k + 1] = off_f[k] + frag[k].order_f.size();
+		off_op[k + 1] = off_op[k] + frag[k].op_sym.size();
+		for (int g = 0; g < G_COUNT; ++g) off_g[g][k + 1] = off_g[g][k] + frag[k].grp_val[g].size();
+	}
+	if (off_sym[ncomp] + 1 >= (1ull << 32)) throw Error(HRY_E_UNSUPPORTED, "more than 2^32 connectivity symbols");
+	w.order_v.resize(off_v[ncomp]); w.order_f.resize(off_f[ncomp]);
+	w.op_sym.resize(off_op[ncomp]); w.op_class.resize(off_op[ncomp]);
+	for (int g = 0; g < G_COUNT; ++g) { w.grp_val[g].resize(off_g[g][ncomp]); w.grp_pos[g].resize(off_g[g][ncomp]); }
+	std::atomic<uint32_t> next_frag{ 0 };
+	parallel_for(n_threads, [&](unsigned) {
+		for (;;) {
+			uint32_t k = next_frag.fetch_add(1, std::memory_order_relaxed);
+			if (k >= ncomp) break;
+			WalkResult &fw = frag[k];
+			std::copy(fw.order_v.begin(), fw.order_v.end(), w.order_v.begin() + (long)off_v[k]);
+			std::copy(fw.order_f.begin(), fw.order_f.end(), w.order_f.begin() + (long)off_f[k]);
+			std::copy(fw.op_sym.begin(), fw.op_sym.end(), w.op_sym.begin() + (long)off_op[k]);
+			std::copy(fw.op_class.begin(), fw.op_class.end(), w.op_class.begin() + (long)off_op[k]);
+			for (int g = 0; g < G_COUNT; ++g) {
+				std::copy(fw.grp_val[g].begin(), fw.grp_val[g].end(), w.grp_val[g].begin() + (long)off_g[g][k]);
+				uint32_t *dst = w.grp_pos[g].data() + off_g[g][k];
+				const uint32_t add = (uint32_t)off_sym[k];
+				for (size_t i = 0; i < fw.grp_pos[g].size(); ++i) dst[i] = fw.grp_pos[g][i] + add;
+			}
+			WalkResult().order_v.swap(fw.order_v);   // release early
+		}
+	});
+	em0.n = (uint32_t)off_sym[ncomp];
+	mark("concatenated");
+}
+
 template <int DEG>
 static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 {
 	const uint32_t nv = m.nv, nf = m.nf;
 	if (nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
-	const uint32_t *foff = m.face_off.data();
-	const uint32_t *org = m.org.data();
-	uint32_t *twin = m.twin.data();
 	std::vector<uint32_t> eface_tab;
 	if (DEG == 0) {
 		eface_tab.resize(m.ne());
-		for (uint32_t f = 0; f < nf; ++f) for (uint32_t e = foff[f]; e < foff[f + 1]; ++e) eface_tab[e] = f;
+		for (uint32_t f = 0; f < nf; ++f) for (uint32_t e = m.face_off[f]; e < m.face_off[f + 1]; ++e) eface_tab[e] = f;
 	}
-	auto face_of = [&](uint32_t e) -> uint32_t { return DEG ? e / (uint32_t)(DEG ? DEG : 1) : eface_tab[e]; };
-	auto nxt = [&](uint32_t e) -> uint32_t {
-		if (DEG) { uint32_t k = e % (uint32_t)(DEG ? DEG : 1); return k + 1 == (uint32_t)DEG ? e - k : e + 1; }
-		uint32_t f = eface_tab[e];
-		return e + 1 == foff[f + 1] ? foff[f] : e + 1;
-	};
-	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; };
-
 	int ndeg = 0;
 	for (uint8_t d : m.have_degree) ndeg += d ? 1 : 0;
 	w.numtri_coded = ndeg > 1;   // one degree => conn_numtri holds a single symbol of count == total: l = 0, h = t, coder state unchanged
@@ -293,112 +709,10 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 	w.order_f.reserve(nf);
 	w.op_sym.reserve(m.ntri() + 16); w.op_class.reserve(m.ntri() + 16);
 	if (eval_op_model) { w.op_l.reserve(m.ntri() + 16); w.op_h.reserve(m.ntri() + 16); w.op_t.reserve(m.ntri() + 16); w.op_pos.reserve(m.ntri() + 16); }
-
-	Border cb(nv);
-	StartFaces pool(nf);
-	Emitter em(w);
-	em.eval_model = eval_op_model;
-	std::vector<uint32_t> sent(nv, NONE32);   // original vertex -> transmitted index (encoder.h:28-52)
-	std::vector<uint16_t> seen(nv, 0);        // triangles seen per vertex (selects the op model class)
-	uint32_t next_id = 0;
-	auto record_vertex = [&](uint32_t e) { w.order_v.push_back(e); sent[org[e]] = next_id++; };
-
-	do {
-		// ---- start a component (encoder.h:68-131)
-		uint32_t f = pool.next();
-		uint32_t e0 = foff[f], e1 = nxt(e0), e2 = nxt(e1);
-		uint32_t a = org[e0], b = org[e1], c = org[e2];
-		int ntri = (int)(foff[f + 1] - foff[f]) - 2, curtri = 1;
-		unsigned mask = (sent[a] != NONE32 ? 4u : 0u) | (sent[b] != NONE32 ? 2u : 0u) | (sent[c] != NONE32 ? 1u : 0u);
-		switch (mask) {
-		case 7: em.iop(I_TRI111); em.vert(sent[a]); em.vert(sent[b]); em.vert(sent[c]); em.numtri(ntri); break;
-		case 6: em.iop(I_TRI110); em.vert(sent[a]); em.vert(sent[b]); em.numtri(ntri); record_vertex(e2); break;
-		case 3: em.iop(I_TRI011); em.vert(sent[b]); em.vert(sent[c]); em.numtri(ntri); record_vertex(e0); break;
-		case 5: em.iop(I_TRI101); em.vert(sent[c]); em.vert(sent[a]); em.numtri(ntri); record_vertex(e1); break;
-		case 4: em.iop(I_TRI100); em.vert(sent[a]); em.numtri(ntri); record_vertex(e1); record_vertex(e2); break;
-		case 2: em.iop(I_TRI010); em.vert(sent[b]); em.numtri(ntri); record_vertex(e2); record_vertex(e0); break;
-		case 1: em.iop(I_TRI001); em.vert(sent[c]); em.numtri(ntri); record_vertex(e0); record_vertex(e1); break;
-		default: em.iop(I_INIT); em.numtri(ntri); record_vertex(e0); record_vertex(e1); record_vertex(e2); break;
-		}
-		w.order_f.push_back(e0);
-		++seen[a]; ++seen[b]; ++seen[c];
-		cb.start(a, e0, b, e1, c, e2);
-
-		// ---- grow until the border of this component is exhausted (encoder.h:133-214)
-		while (!cb.parts.empty()) {
-			Border::Part &pt = cb.top();
-			const uint32_t v0 = cb.N(pt.tail).v, v1 = cb.N(pt.head).v;
-			const uint32_t gate = cb.N(pt.tail).a;
-			const uint32_t gateprev = cb.N(cb.N(pt.tail).prev).a;
-			const uint32_t gatenext = cb.N(pt.head).a;
-			const bool seq_first = curtri == ntri;
-			const int order = seen[v1];
-			if (seq_first) {
-				uint32_t t = twin[gate];
-				if (t == gate || pool.gone[face_of(t)]) {   // writer.cc:48-58: mesh border or neighbour already consumed
-					Op bop = cb.border();
-					if (t != gate) twin[gate] = gate;       // one-sided split (writer.cc:81-84)
-					em.op(bop, order);
-					continue;
-				}
-				pool.take(face_of(t));
-				e0 = t;
-				f = face_of(e0);
-				ntri = (int)(foff[f + 1] - foff[f]) - 2;
-				curtri = 0;
-				e1 = nxt(e0);
-			} else e1 = nxt(e1);
-			e2 = nxt(e1);
-			const uint32_t v2 = org[e2];
-			const bool seq_last = curtri + 1 == ntri;
-			const int nt = seq_first ? ntri : 0;
-
-			bool fresh = sent[v2] == NONE32;
-			if (fresh || cb.on[v2] == 0) {
-				// NEWVTX, or a vertex that was coded before but left the border (non-manifold): encoder.h:167-181
-				Border::Part &p = cb.top();
-				cb.N(p.tail).a = e1;
-				cb.append(p, cb.make(v2, e2));
-				if (fresh) { em.op(O_NEWVTX, order); em.numtri(nt); record_vertex(e2); }
-				else { em.op(O_NM, order); em.vert(sent[v2]); em.numtri(nt); }
-			} else {
-				int i, p;
-				int32_t hit = cb.locate(v2, i, p);
-				if (p > 0) {
-					int32_t g, cp;
-					cb.unite(hit, p, g, cp);
-					em.op(O_UNION, order); em.elem(i); em.part(p); em.numtri(nt);
-					cb.N(g).a = e1; cb.N(cp).a = e2;
-				} else {
-					Border::Part &tp = cb.top();
-					if (tp.edge_begin && cb.N(cb.N(tp.head).next).v == v2) {
-						bool close = tp.size == 3;   // edge_begin && 3 elements: the part is exactly this triangle
-						if (seq_last && twin[gatenext] != e2) link(gatenext, e2);
-						if (close && twin[gateprev] != e1) link(gateprev, e1);
-						if (close) cb.discard_top();
-						else { cb.drop(cb.unlink_head(tp)); cb.N(tp.tail).a = e1; }
-						em.op(O_CONNFWD, order); em.numtri(nt);
-					} else if (cb.N(cb.N(tp.tail).prev).v == v2) {
-						if (twin[gateprev] != e1) link(gateprev, e1);
-						cb.drop(cb.unlink_tail(tp));
-						cb.N(tp.tail).a = e2;
-						em.op(O_CONNBWD, order); em.numtri(nt);
-					} else {
-						int32_t g, cp;
-						cb.split(hit, i, g, cp);
-						em.op(O_SPLIT, order); em.elem(i); em.numtri(nt);
-						cb.N(g).a = e1; cb.N(cp).a = e2;
-					}
-				}
-			}
-			++seen[v0]; ++seen[v1]; ++seen[v2];
-			if (seq_first) w.order_f.push_back(e0);
-			++curtri;
-		}
-	} while (pool.left != 0);
-	em.iop(I_EOM);
-	w.n_conn = em.n;
+	walk_sequential<DEG>(m, w, eface_tab.data(), eval_op_model, eval_op_model ? 1u : host_threads());
 }
+
+}   // namespace
 
 void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
 {

@@ -149,6 +149,9 @@ int hry_stage_get(hry_ctx *ctx, const char *name, void **host_copy, size_t *byte
  * (u32 unless noted), "info" = { n_conn, numtri_coded }.  hry_walk_get returns the element count. */
 typedef struct hry_walk hry_walk;
 int hry_walk_run(hry_mesh *m, hry_walk **out);
+/* same walk without evaluating the operation model (what the chunked profile uses; then "op_l/op_h/op_t/op_pos" are empty and
+ * components after the first may be walked on several host threads: HRY_HOST_THREADS, default min(16, cores)) */
+int hry_walk_run_plain(hry_mesh *m, hry_walk **out);
 size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr);
 void hry_walk_free(hry_walk *w);
 

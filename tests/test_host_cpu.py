@@ -205,3 +205,36 @@ def test_host_stream_reader_rejects_corrupt_input():
             hc.read_stream_host(bytes(bad))     # must either decode something or fail cleanly, never crash
         except hc.HryError:
             pass
+
+
+# ---------------------------------------------------------------- several host threads (components after the first)
+def walk_plain(ply: bytes, threads: int, min_faces: int = 0):
+    os.environ["HRY_HOST_THREADS"] = str(threads)
+    os.environ["HRY_PARALLEL_MIN_FACES"] = str(min_faces)
+    try:
+        m = hc.Mesh.from_ply(ply)
+        return m.host_walk(plain=True), m.twin().copy()
+    finally:
+        del os.environ["HRY_HOST_THREADS"], os.environ["HRY_PARALLEL_MIN_FACES"]
+
+
+@pytest.mark.parametrize("case", ["multi_tri", "multi_mixed_nm", "tied_by_vertices", "many_small", "single"])
+def test_threaded_walk_equals_sequential_walk(case):
+    """The walk of the components after the first on several threads (component discovery, start-face order, vertex index
+    bases computed up front) must reproduce the sequential walk array for array, including the repaired twins."""
+    m = {"multi_tri": lambda: mg.multi_component(23, 14, 16, polys="tri"),
+         "multi_mixed_nm": lambda: mg.with_nonmanifold(mg.multi_component(17, 12, 13, polys="mixed", seed=3), 40, 25),
+         "tied_by_vertices": lambda: mg.with_nonmanifold(mg.concat([mg.torus(9, 10, center=(3.0 * i, 0, 0), seed=i) for i in range(12)]), 30, 60),
+         "many_small": lambda: mg.multi_component(700, 3, 4, polys="tri"),
+         "single": lambda: mg.torus(40, 44)}[case]()
+    ply = m.to_ply()
+    seq, twin_seq = walk_plain(ply, 1)
+    for threads in (2, 5):
+        par, twin_par = walk_plain(ply, threads)
+        assert np.array_equal(twin_seq, twin_par)
+        for k in seq:
+            assert np.array_equal(seq[k], par[k]), (k, threads)
+    # and the plain walk agrees with the modelled one on everything both produce
+    full = hc.Mesh.from_ply(ply).host_walk()
+    for k in ("order_v", "order_f", "op_sym", "op_class", "grp0_val", "grp1_val", "grp2_val", "grp3_val", "grp4_val", "grp3_pos"):
+        assert np.array_equal(full[k], seq[k]), k
