@@ -700,7 +700,11 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 	std::vector<uint32_t> eface_tab;
 	if (DEG == 0) {
 		eface_tab.resize(m.ne());
-		for (uint32_t f = 0; f < nf; ++f) for (uint32_t e = m.face_off[f]; e < m.face_off[f + 1]; ++e) eface_tab[e] = f;
+		const unsigned nt = nf >= (1u << 20) ? host_threads() : 1u;
+		parallel_for(nt, [&](unsigned t) {
+			const uint32_t b = (uint32_t)((uint64_t)nf * t / nt), e = (uint32_t)((uint64_t)nf * (t + 1) / nt);
+			for (uint32_t f = b; f < e; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface_tab[h] = f;
+		});
 	}
 	int ndeg = 0;
 	for (uint8_t d : m.have_degree) ndeg += d ? 1 : 0;
