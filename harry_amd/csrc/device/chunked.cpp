@@ -196,14 +196,22 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
 
 	// ---- container
-	size_t dir = 12 + 4 * planes.size() + 4 * (size_t)ns;
+	// directory: chunk sizes, plane lengths, restart points of the connectivity replay, stream lengths
+	const std::vector<RestartPoint> restarts = select_restart_points(w.marks);
+	const uint32_t nrs = (uint32_t)restarts.size();
+	static_assert(sizeof(RestartPoint) == kRestartWords * 4, "restart points are written as they lie in memory");
+	const size_t dir_restart = 12 + 4 * planes.size();
+	const size_t dir_streams = dir_restart + 4 + sizeof(RestartPoint) * (size_t)nrs;
+	size_t dir = dir_streams + 4 * (size_t)ns;
 	size_t base = out.size();
 	out.resize(base + dir + total_bytes);
 	uint8_t *o = out.data() + base;
 	uint32_t np = (uint32_t)planes.size();
 	memcpy(o, &CH, 4); memcpy(o + 4, &CHC, 4); memcpy(o + 8, &np, 4);
 	for (size_t i = 0; i < planes.size(); ++i) memcpy(o + 12 + 4 * i, &planes[i].n, 4);
-	if (ns) HIP_OK(hipMemcpyAsync(o + 12 + 4 * planes.size(), d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
+	memcpy(o + dir_restart, &nrs, 4);
+	if (nrs) memcpy(o + dir_restart + 4, restarts.data(), sizeof(RestartPoint) * (size_t)nrs);
+	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
 	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 

@@ -139,6 +139,15 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	uint64_t nstreams = 0, total_syms = 0;
 	auto step_of = [&](uint32_t k) { return k < (uint32_t)kConnPlanes ? CHC : CH; };
 	for (uint32_t k = 0; k < np; ++k) { nstreams += (nsym[k] + (uint64_t)step_of(k) - 1) / step_of(k); total_syms += nsym[k]; }
+	need(off, 4);
+	uint32_t nrs;
+	memcpy(&nrs, p + off, 4);
+	off += 4;
+	if ((uint64_t)nrs * sizeof(RestartPoint) > n) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+	need(off, sizeof(RestartPoint) * (size_t)nrs);
+	std::vector<RestartPoint> restarts(nrs);
+	if (nrs) memcpy(restarts.data(), p + off, sizeof(RestartPoint) * (size_t)nrs);
+	off += sizeof(RestartPoint) * (size_t)nrs;
 	need(off, 4 * nstreams);
 	std::vector<uint32_t> nbytes((size_t)nstreams);
 	if (nstreams) memcpy(nbytes.data(), p + off, 4 * (size_t)nstreams);
@@ -216,7 +225,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// ---- replay the cut-border machine on the host
 	auto t_walk = Clock::now();
 	std::vector<uint32_t> order_v, seg_start, seg_level;
-	cut_border_replay(*m, conn, order_v, seg_start, seg_level);
+	cut_border_replay(*m, conn, restarts, order_v, seg_start, seg_level);
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	HRY_MARK(g_t0, "replay done");
 	if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");

@@ -26,9 +26,10 @@ struct Planes {
 
 // planes: 21 connectivity planes in container order.  Fills m.face_off / org / twin and returns the decode order
 // (one half-edge per vertex; vertex ids are assigned in this order, cbm/decoder.h:48-75,145).
-void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
-                       std::vector<uint32_t> &seg_level)
+void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const std::vector<RestartPoint> &restarts,
+                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
 {
+	(void)restarts;
 	int ndeg = 0, onlydeg = 0;
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++ndeg; onlydeg = (int)d; }
 	Planes rd{ conn_planes, { 0 }, ndeg <= 1 ? onlydeg - 2 : -1 };

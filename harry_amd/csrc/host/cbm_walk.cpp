@@ -257,10 +257,25 @@ struct Emitter {
 	// order-conditioned operation model (models.h:49-120), evaluated here because it is connectivity-sized
 	uint64_t plain[5] = { 1, 1, 1, 1, 1 }, c_all = 2, c_new[8], c_fwd[8];
 	bool eval_model = true;   // the compat stream needs (l, h, t) of every operation; the chunked planes only symbol + class
+	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // operations per order class so far
+	uint32_t min_ref = NONE32;                        // smallest vertex index named explicitly since the last mark
+	uint32_t halfedges = 0;                           // half-edges of the faces coded so far
 	explicit Emitter(WalkResult &r) : w(r) { for (int i = 0; i < 8; ++i) c_new[i] = c_fwd[i] = 1; }
+	void mark_component(uint32_t next_id)
+	{
+		if (!w.marks.empty()) w.marks.back().min_ref = min_ref;
+		ComponentMark k;
+		for (int g = 0; g < G_COUNT; ++g) k.n_grp[g] = (uint32_t)w.grp_val[g].size();
+		for (int i = 0; i < 8; ++i) k.n_op[i] = n_op[i];
+		k.first_vertex = next_id; k.first_face = (uint32_t)w.order_f.size(); k.first_halfedge = halfedges;
+		k.min_ref = NONE32;
+		w.marks.push_back(k);
+		min_ref = NONE32;
+	}
+	void finish_marks() { if (!w.marks.empty()) w.marks.back().min_ref = min_ref; }
 	void group(int g, uint32_t v) { w.grp_val[g].push_back(v); w.grp_pos[g].push_back(n); n += kGroupBytes[g]; }
 	void iop(uint32_t s) { group(G_IOP, s); }
-	void vert(uint32_t v) { group(G_VERT, v); }
+	void vert(uint32_t v) { group(G_VERT, v); if (v < min_ref) min_ref = v; }
 	void elem(int i) { uint32_t c = (uint32_t)i; group(G_ELEM, (c << 1) ^ ((c >> 31) ? 0xffffffffu : 0u)); }   // transform.h:25-30
 	void part(int p) { group(G_PART, (uint32_t)(uint16_t)p); }
 	void numtri(int nt) { if (nt != 0 && w.numtri_coded) group(G_NUMTRI, (uint32_t)(uint16_t)nt); }          // io.h:162-165
@@ -269,6 +284,7 @@ struct Emitter {
 		int k = order - 1;   // models.h:101-105; order >= 1 because the gate's front vertex lies on a coded triangle
 		if (k > 7) k = 7;
 		if (k < 0) k = 0;
+		++n_op[k];
 		if (!eval_model) {
 			w.op_sym.push_back((uint8_t)s); w.op_class.push_back((uint8_t)k);
 			++n;
@@ -319,8 +335,9 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 	};
 	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; };
 	auto record_vertex = [&](uint32_t e) { w.order_v.push_back(e); sent[org[e]] = next_id++; };
-	auto take = [&](uint32_t face) { gone[face] = 1; ++consumed; };
+	auto take = [&](uint32_t face) { gone[face] = 1; ++consumed; em.halfedges += foff[face + 1] - foff[face]; };
 
+	em.mark_component(next_id);
 	take(f);
 	uint32_t e0 = foff[f], e1 = nxt(e0), e2 = nxt(e1);
 	uint32_t a = org[e0], b = org[e1], c = org[e2];
@@ -413,7 +430,6 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 	}
 }
 
-static uint32_t parallel_min_faces();
 template <int DEG>
 static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads);
 
@@ -437,23 +453,26 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 			break;
 		}
 	} while (consumed != m.nf);
+	em.finish_marks();
 	em.iop(I_EOM);
 	w.n_conn = em.n;
 }
 
 // ---- several host threads --------------------------------------------------------
-static unsigned host_threads()
+}   // namespace
+unsigned host_threads()
 {
 	if (const char *e = getenv("HRY_HOST_THREADS")) { int v = atoi(e); return v > 0 ? (unsigned)v : 1u; }
 	unsigned hw = std::thread::hardware_concurrency();
 	return std::max(1u, std::min(16u, hw ? hw : 1u));
 }
 // below this many remaining faces the analysis passes cost more than they save (HRY_PARALLEL_MIN_FACES overrides, tests)
-static uint32_t parallel_min_faces()
+uint32_t parallel_min_faces()
 {
 	if (const char *e = getenv("HRY_PARALLEL_MIN_FACES")) return (uint32_t)strtoul(e, nullptr, 10);
 	return 1u << 16;
 }
+namespace {
 template <typename F> static void parallel_for(unsigned n_threads, F &&body)   // body(thread index), joins before returning
 {
 	std::vector<std::thread> th;
@@ -630,7 +649,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	mark("vertex bases and groups");
 	// the walks
 	std::vector<WalkResult> frag(ncomp);
-	std::vector<uint32_t> frag_syms(ncomp, 0);
+	std::vector<uint32_t> frag_syms(ncomp, 0), frag_he(ncomp, 0), frag_op((size_t)ncomp * 8, 0);
 	std::atomic<size_t> next_item{ 0 };
 	parallel_for(n_threads, [&](unsigned) {
 		Border cb(st.on);
@@ -648,7 +667,10 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 				uint32_t next_id = id_base[k], consumed = 0;
 				walk_component<DEG>(m, st, eface_tab, (uint32_t)first_key[c].load(std::memory_order_relaxed), cb, em, next_id, consumed);
 				if (next_id != id_base[k + 1] || consumed != nfc) throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
+				em.finish_marks();
 				frag_syms[k] = em.n;
+				frag_he[k] = em.halfedges;
+				for (int i = 0; i < 8; ++i) frag_op[k * 8 + i] = em.n_op[i];
 			}
 		}
 	});
@@ -688,7 +710,26 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 			WalkResult().order_v.swap(fw.order_v);   // release early
 		}
 	});
+	// marks: every fragment holds exactly one (its component), relative to the fragment; make it absolute
+	em0.finish_marks();
+	{
+		uint32_t he = em0.halfedges, nop[8];
+		for (int i = 0; i < 8; ++i) nop[i] = em0.n_op[i];
+		w.marks.reserve(w.marks.size() + ncomp);
+		for (uint32_t k = 0; k < ncomp; ++k) {
+			ComponentMark mk = frag[k].marks.at(0);
+			for (int g = 0; g < G_COUNT; ++g) mk.n_grp[g] = (uint32_t)off_g[g][k];
+			for (int i = 0; i < 8; ++i) { mk.n_op[i] = nop[i]; nop[i] += frag_op[(size_t)k * 8 + i]; }
+			mk.first_face = (uint32_t)off_f[k];
+			mk.first_halfedge = he;
+			he += frag_he[k];
+			w.marks.push_back(mk);
+		}
+		em0.halfedges = he;
+		for (int i = 0; i < 8; ++i) em0.n_op[i] = nop[i];
+	}
 	em0.n = (uint32_t)off_sym[ncomp];
+	em0.min_ref = NONE32;
 	mark("concatenated");
 }
 
@@ -717,6 +758,26 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 }
 
 }   // namespace
+
+std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks)
+{
+	std::vector<RestartPoint> out;
+	uint32_t last_face = 0;
+	for (size_t k = 1; k < marks.size(); ++k) {
+		if (marks[k].first_face - last_face < kRestartFaces) {
+			if (!out.empty() && marks[k].min_ref < out.back().first_vertex) out.back().flags |= 1u;
+			continue;
+		}
+		RestartPoint r;
+		for (int g = 0; g < G_COUNT; ++g) r.n_grp[g] = marks[k].n_grp[g];
+		for (int i = 0; i < 8; ++i) r.n_op[i] = marks[k].n_op[i];
+		r.first_vertex = marks[k].first_vertex; r.first_face = marks[k].first_face; r.first_halfedge = marks[k].first_halfedge;
+		r.flags = marks[k].min_ref < marks[k].first_vertex ? 1u : 0u;
+		out.push_back(r);
+		last_face = marks[k].first_face;
+	}
+	return out;
+}
 
 void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
 {

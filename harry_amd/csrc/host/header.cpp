@@ -64,8 +64,7 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor)
 	if (ver_minor != 1 && ver_minor != 2)
 		throw Error(HRY_E_FORMAT, "File format version 0." + std::to_string(magic[5]) + " incompatible to decoder format version 0.1 (All 0.x-versions are incompatible to each other)");
 	m.nv = r.v<uint32_t>(); m.nf = r.v<uint32_t>();
-	uint32_t ne = r.v<uint32_t>();
-	(void)ne;
+	m.declared_ne = r.v<uint32_t>();
 	uint16_t nrf = r.v<uint16_t>(), nrv = r.v<uint16_t>();
 	if (nrf != 1 || nrv != 1) throw Error(HRY_E_UNSUPPORTED, "multi-region meshes (OBJ material regions) are outside the supported subset");
 	uint16_t nbf = r.v<uint16_t>(), nbc = r.v<uint16_t>();

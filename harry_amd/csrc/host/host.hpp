@@ -28,6 +28,27 @@ static constexpr int kGroupBytes[G_COUNT] = { 1, 4, 2, 4, 2 };
 static constexpr int kGroupCtx[G_COUNT] = { CTX_IOP, CTX_ELEM, CTX_PART, CTX_VERT, CTX_NUMTRI };
 
 // Output of the host-side cut-border walk (the inputs the device path needs)
+// State of the connectivity coding at the start of a connected component: how many symbols of every connectivity plane group
+// and of every operation class precede it, and the first vertex index / face / half-edge it will create.
+struct ComponentMark {
+	uint32_t n_grp[G_COUNT];
+	uint32_t n_op[8];
+	uint32_t first_vertex, first_face, first_halfedge;
+	uint32_t min_ref;   // smallest vertex index the component names explicitly (TRIxxx start, NM operation); 0xffffffff = none
+};
+// A restart point of the chunked container (v0.2 directory): a ComponentMark at which a decoder may start replaying
+// independently.  flags bit 0: some component between this point and the next names a vertex created before this point.
+struct RestartPoint {
+	uint32_t n_grp[G_COUNT];
+	uint32_t n_op[8];
+	uint32_t first_vertex, first_face, first_halfedge;
+	uint32_t flags;
+};
+constexpr uint32_t kRestartFaces = 8192;   // a restart point at the first component start >= this many faces after the previous one
+constexpr uint32_t kRestartWords = G_COUNT + 8 + 4;
+// canonical selection, shared by every writer of the container (the oracle restates it)
+std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks);
+
 struct WalkResult {
 	std::vector<uint32_t> order_v;   // one half-edge per coded vertex, in coding order (attrcode.h:297,310-314)
 	std::vector<uint32_t> order_f;   // one half-edge per face, in coding order (attrcode.h:298,315-319)
@@ -38,6 +59,7 @@ struct WalkResult {
 	// (models.h:91-119) as cumulative-frequency triples
 	std::vector<uint8_t> op_sym, op_class;
 	std::vector<uint32_t> op_l, op_h, op_t, op_pos;
+	std::vector<ComponentMark> marks; // one per connected component, in coding order
 	uint32_t n_conn = 0;             // symbols in the connectivity part of the global sequence
 	bool numtri_coded = false;       // false when a single polygon degree makes every numtri symbol an exact no-op
 };
@@ -48,8 +70,10 @@ void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true);
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
 // seg_start: first decode rank of every connected component (+ end sentinel); seg_level[k]: 0 = the component touches no vertex
 // coded before it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
-void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
-                       std::vector<uint32_t> &seg_level);
+void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const std::vector<RestartPoint> &restarts,
+                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level);
+unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
+uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
 
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 // reference single-stream format (compat_read.cpp): serial entropy decode + replay on the host; residual byte planes

@@ -69,6 +69,7 @@ struct Mesh {
 	std::vector<uint8_t> have_degree;    // have_degree[d] != 0 iff a polygon with d edges exists (faces.h:44-56)
 	AttrList lists[2];                   // [0] face attributes, [1] vertex attributes (formats/ply/reader.cc:388-400)
 	uint64_t device_token = 0;           // identity of the HBM-resident copy, 0 = none
+	uint32_t declared_ne = 0;            // half-edge count announced by a .hry header (the connectivity follows later)
 
 	uint32_t ne() const { return face_off.back(); }
 	uint64_t ntri() const { return (uint64_t)ne() - 2ull * nf; }

@@ -500,6 +500,24 @@ struct SymWriter {
 	RangeEncoder &rc;
 	std::vector<ho_sym> *trace;
 	std::vector<std::vector<uint8_t>> *record = nullptr;   // chunked profile: collect symbols per context instead of coding
+	// chunked profile: state at the start of every connected component (restart points of the container directory)
+	struct Mark { uint32_t n_grp[5], n_op[8], first_vertex, first_face, min_ref; };
+	std::vector<Mark> marks;
+	uint32_t min_ref = 0xffffffffu;
+	void mark_component(uint32_t next_id, uint32_t nfaces)
+	{
+		if (!record) return;
+		if (!marks.empty()) marks.back().min_ref = min_ref;
+		Mark k;
+		k.n_grp[0] = (uint32_t)(*record)[CTX_IOP].size(); k.n_grp[1] = (uint32_t)(*record)[CTX_ELEM].size();
+		k.n_grp[2] = (uint32_t)(*record)[CTX_PART].size(); k.n_grp[3] = (uint32_t)(*record)[CTX_VERT].size();
+		k.n_grp[4] = (uint32_t)(*record)[CTX_NUMTRI].size();
+		for (int i = 0; i < 8; ++i) k.n_op[i] = (uint32_t)(*record)[REC_OP0 + i].size();
+		k.first_vertex = next_id; k.first_face = nfaces; k.min_ref = 0xffffffffu;
+		marks.push_back(k);
+		min_ref = 0xffffffffu;
+	}
+	void finish_marks() { if (!marks.empty()) marks.back().min_ref = min_ref; }
 	SymWriter(Models &m, RangeEncoder &r, std::vector<ho_sym> *t) : md(m), rc(r), trace(t) {}
 	void code(int ctx, uint32_t s)
 	{
@@ -527,7 +545,7 @@ struct SymWriter {
 		bytes(CTX_ELEM, (const uint8_t*)&z, 4);
 	}
 	void part(int p) { uint16_t v = (uint16_t)p; bytes(CTX_PART, (const uint8_t*)&v, 2); }
-	void vertid(uint32_t v) { bytes(CTX_VERT, (const uint8_t*)&v, 4); }
+	void vertid(uint32_t v) { if (v < min_ref) min_ref = v; bytes(CTX_VERT, (const uint8_t*)&v, 4); }
 	void numtri(int n) { if (n != 0) { uint16_t v = (uint16_t)n; bytes(CTX_NUMTRI, (const uint8_t*)&v, 2); } }   // io.h:162-165
 	void reg_face(uint16_t r) { bytes(CTX_REGFACE, (const uint8_t*)&r, 2); }
 	void reg_vtx(uint16_t r) { bytes(CTX_REGVTX, (const uint8_t*)&r, 2); }
@@ -979,6 +997,7 @@ static void cbm_encode(Mesh &m, SymWriter &wr, std::vector<uint32_t> &order_v, s
 	uint32_t f = 0;
 	do {
 		curtri = 0;
+		wr.mark_component(next_id, (uint32_t)order_f.size());
 		f = pool.choose();
 		e0 = m.foff[f]; e1 = m.next(e0); e2 = m.next(e1);
 		uint32_t a = m.org[e0], b = m.org[e1], c = m.org[e2];
@@ -1329,7 +1348,8 @@ static Mesh *decode(const uint8_t *p, size_t n)
 // coder + 64-bit flush, using exactly the reference's model/coder arithmetic.  Symbols without information are
 // not stored: reg_face/reg_vtx (single region), attr_type (always DATA), numtri for single-degree meshes.
 // Operations are split into one plane per order class (models.h:101-105) with a plain adaptive 7-symbol model.
-//   u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols, per stream u32 n_bytes, then the streams.
+//   u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols,
+//   u32 n_restart, n_restart x 17 u32 (restart points, see encode_chunked), per stream u32 n_bytes, then the streams.
 // Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
 // The first 21 planes (connectivity) are cut every conn_chunk_syms symbols, the attribute planes every chunk_syms: the
 // decoder needs the connectivity first and a stream is a serial chain, so short connectivity streams shorten its start-up
@@ -1364,7 +1384,7 @@ static void seed_table(FreqTable &f, int kind, const Mesh &m)
 	}
 }
 static int count_degrees(const Mesh &m) { int n = 0; for (char c : m.have_deg) n += c ? 1 : 0; return n; }
-enum { CONN_PLANES = 21 };
+enum { CONN_PLANES = 21, RESTART_FACES = 8192 };
 static uint32_t default_conn_chunk(uint32_t chunk_syms) { return std::min(chunk_syms, std::max(chunk_syms / 8, 512u)); }
 
 static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
@@ -1391,6 +1411,35 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 		w.put<uint32_t>(conn_chunk);
 		w.put<uint32_t>((uint32_t)planes.size());
 		for (const PlaneDef &pd : planes) w.put<uint32_t>((uint32_t)rec[pd.slot].size());
+		// restart points of the connectivity replay: the coder state at the first component start that lies at least
+		// RESTART_FACES faces after the previous point: symbols consumed per plane group (iop, elem, part, vertid, numtri)
+		// and per operation class, first vertex index / face / half-edge, flags (bit 0: a component up to the next point
+		// names a vertex created before this point).  A decoder may replay from several points at once.
+		{
+			wr.finish_marks();
+			const bool numtri_coded = count_degrees(m) > 1;
+			std::vector<uint32_t> he_before(res->order_f.size() + 1, 0);
+			for (size_t i = 0; i < res->order_f.size(); ++i) he_before[i + 1] = he_before[i] + (uint32_t)m.deg(m.eface[res->order_f[i]]);
+			std::vector<std::vector<uint32_t>> pts;
+			uint32_t last_face = 0;
+			for (size_t k = 1; k < wr.marks.size(); ++k) {
+				const SymWriter::Mark &mk = wr.marks[k];
+				if (mk.first_face - last_face < RESTART_FACES) {
+					if (!pts.empty() && mk.min_ref < pts.back()[13]) pts.back()[16] |= 1u;
+					continue;
+				}
+				std::vector<uint32_t> r(17);
+				for (int g = 0; g < 5; ++g) r[g] = mk.n_grp[g];
+				if (!numtri_coded) r[4] = 0;
+				for (int i = 0; i < 8; ++i) r[5 + i] = mk.n_op[i];
+				r[13] = mk.first_vertex; r[14] = mk.first_face; r[15] = he_before[mk.first_face];
+				r[16] = mk.min_ref < mk.first_vertex ? 1u : 0u;
+				pts.push_back(r);
+				last_face = mk.first_face;
+			}
+			w.put<uint32_t>((uint32_t)pts.size());
+			for (auto &r : pts) for (uint32_t x : r) w.put<uint32_t>(x);
+		}
 		std::vector<std::vector<uint8_t>> streams;
 		for (size_t pi = 0; pi < planes.size(); ++pi) {
 			const PlaneDef &pd = planes[pi];
@@ -1432,6 +1481,8 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 		for (auto &x : nsym) x = br.get<uint32_t>();
 		size_t nstreams = 0;
 		for (size_t k = 0; k < np; ++k) { uint64_t c = k < CONN_PLANES ? conn_chunk : chunk_syms; nstreams += (size_t)((nsym[k] + c - 1) / c); }
+		uint32_t n_restart = br.get<uint32_t>();   // restart points: an aid for parallel decoders, not needed here
+		for (uint64_t i = 0; i < (uint64_t)n_restart * 17; ++i) (void)br.get<uint32_t>();
 		std::vector<uint32_t> nbytes(nstreams);
 		for (auto &x : nbytes) x = br.get<uint32_t>();
 		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
