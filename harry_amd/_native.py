@@ -93,6 +93,7 @@ def load():
     L.hry_walk_get.restype = sz; L.hry_walk_get.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.hry_walk_free.argtypes = [vp]
     L.hry_stream_read_host.restype = C.c_int; L.hry_stream_read_host.argtypes = [C.c_char_p, sz, C.POINTER(vp), C.POINTER(vp)]
+    L.hry_walk_replay.restype = C.c_int; L.hry_walk_replay.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.hry_range_encode_lht.restype = C.c_int; L.hry_range_encode_lht.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]
     _lib = L
     return L

@@ -152,6 +152,28 @@ class Mesh:
             L.hry_walk_free(w)
 
 
+def walk_and_replay(mesh: "Mesh", use_restart_points: bool):
+    """Host-only: plain cut-border walk of `mesh` (mutates its twins), then the decoder-side replay of the recorded
+    connectivity planes.  Returns (mesh with the rebuilt connectivity, order_v, seg_start, seg_level, n_restart_points)."""
+    L = nat.load()
+    w = C.c_void_p()
+    nat.check(L.hry_walk_run_plain(mesh.h, C.byref(w)))
+    try:
+        mh, r = C.c_void_p(), C.c_void_p()
+        nat.check(L.hry_walk_replay(mesh.h, w, 1 if use_restart_points else 0, C.byref(mh), C.byref(r)))
+        try:
+            out = []
+            for name in ("order_v", "seg_start", "seg_level", "info"):
+                p = C.c_void_p()
+                n = L.hry_walk_get(r, name.encode(), C.byref(p))
+                out.append(np.frombuffer(C.string_at(p, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32))
+            return (Mesh(mh), out[0], out[1], out[2], int(out[3][0]))
+        finally:
+            L.hry_walk_free(r)
+    finally:
+        L.hry_walk_free(w)
+
+
 def read_stream_host(data: bytes):
     """Host-only serial half of reading a reference (v0.1) stream: (mesh with connectivity, order_v, vplanes, fplanes)."""
     L = nat.load()

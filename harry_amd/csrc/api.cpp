@@ -9,7 +9,7 @@ using namespace hry;
 
 struct hry_ctx { Context cx; explicit hry_ctx(int d) : cx(d) {} };
 struct hry_mesh { Mesh m; };
-struct hry_walk { WalkResult w; uint32_t info[2]; std::vector<uint8_t> vplanes, fplanes; };
+struct hry_walk { WalkResult w; uint32_t info[2]; std::vector<uint8_t> vplanes, fplanes; std::vector<uint32_t> seg_start, seg_level; };
 
 static thread_local std::string g_last_error;
 
@@ -199,6 +199,8 @@ size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 	if (n == "op_t") return ret(r.op_t);
 	if (n == "op_pos") return ret(r.op_pos);
 	if (n == "info") { *ptr = w->info; return 2; }
+	if (n == "seg_start") return ret(w->seg_start);
+	if (n == "seg_level") return ret(w->seg_level);
 	if (n == "vplanes") return ret(w->vplanes);
 	if (n == "fplanes") return ret(w->fplanes);
 	if (n.size() == 8 && n.compare(0, 3, "grp") == 0 && n[3] >= '0' && n[3] < '0' + G_COUNT) {
@@ -224,6 +226,35 @@ int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_wal
 		std::vector<uint32_t> seg_start, seg_level;
 		read_compat_stream((const uint8_t*)hry + hdr, bytes - hdr, m->m, w->w.order_v, seg_start, seg_level, w->vplanes, w->fplanes);
 		w->info[0] = w->info[1] = 0;
+		*mesh = m.release();
+		*out = w.release();
+	});
+}
+
+int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_points, hry_mesh **mesh, hry_walk **out)
+{
+	if (!src || !walk || !mesh || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*mesh = nullptr; *out = nullptr;
+	return guarded([&] {
+		const WalkResult &r = walk->w;
+		// the 21 connectivity planes of the chunked container, built on the host: groups split into little-endian bytes,
+		// operations split by order class
+		std::vector<uint8_t> planes[21];
+		static const int first_plane[G_COUNT] = { 0, 1, 5, 7, 11 };
+		for (int g = 0; g < G_COUNT; ++g)
+			for (int b = 0; b < kGroupBytes[g]; ++b) {
+				std::vector<uint8_t> &pl = planes[first_plane[g] + b];
+				pl.resize(r.grp_val[g].size());
+				for (size_t i = 0; i < pl.size(); ++i) pl[i] = (uint8_t)(r.grp_val[g][i] >> (8 * b));
+			}
+		for (size_t i = 0; i < r.op_sym.size(); ++i) planes[13 + r.op_class[i]].push_back(r.op_sym[i]);
+		std::unique_ptr<hry_mesh> m(new hry_mesh());
+		std::unique_ptr<hry_walk> w(new hry_walk());
+		m->m.nv = src->m.nv; m->m.nf = src->m.nf; m->m.declared_ne = src->m.ne(); m->m.have_degree = src->m.have_degree;
+		std::vector<RestartPoint> restarts;
+		if (use_restart_points) restarts = select_restart_points(r.marks);
+		cut_border_replay(m->m, planes, restarts, w->w.order_v, w->seg_start, w->seg_level);
+		w->info[0] = (uint32_t)restarts.size(); w->info[1] = 0;
 		*mesh = m.release();
 		*out = w.release();
 	});

@@ -97,62 +97,78 @@ struct Ring {
 
 }   // namespace replay_detail
 
+// One span of the replay: components from the state (next_id, face, he) up to the component that would start at face
+// stop_face (NONE32: up to the end-of-mesh symbol).  The connectivity arrays, order_v and seen are preallocated and shared
+// between spans; a span writes only the faces / half-edges / vertices it creates (every index is checked against the sizes
+// announced by the header, so a corrupt stream or directory cannot write outside them).
+//   min_id        : smallest vertex id this span may name (its own first id for a span that starts at an unflagged restart point)
+//   g_first/level : components replayed before this span (first vertex id, level), for the owner lookup of older vertices
+//   comp_first/level : out, one entry per component of this span.  level = 0: the component touches no vertex coded before
+//                   it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
 // RD provides: iop(), vertid(), elem(), part(), numtri(), op(order)
+struct ReplayCursor { uint32_t next_id = 0, face = 0, he = 0; };
 template <class RD>
-void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
+bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCursor &cur, uint32_t stop_face, uint32_t min_id,
+                 const std::vector<uint32_t> &g_first, const std::vector<uint32_t> &g_level,
+                 std::vector<uint32_t> &comp_first, std::vector<uint32_t> &comp_level)
 {
 	using namespace replay_detail;
-	std::vector<uint32_t> seg_first;   // first vertex id assigned inside each component (ids are handed out in decode order)
-	const uint32_t nv = m.nv, nf = m.nf;
-	m.face_off.assign(1, 0);
-	m.face_off.reserve((size_t)nf + 1);
-	m.org.clear(); m.twin.clear();
-	m.org.reserve((size_t)nf * 3); m.twin.reserve((size_t)nf * 3);
-	order_v.clear();
-	order_v.reserve(nv);
-	seg_start.clear(); seg_level.clear();
-	std::vector<uint16_t> seen(nv, 0);
+	const uint32_t nv = m.nv, nf = m.nf, ne_max = (uint32_t)m.org.size();
 	Ring cb;
-	uint32_t next_id = 0;
+	uint32_t next_id = cur.next_id, face = cur.face, he = cur.he;
 	auto new_face = [&](int ne) {
 		if (ne < 3 || ne > 255) throw Error(HRY_E_FORMAT, "corrupt stream (polygon degree)");
-		if (m.face_off.size() > nf) throw Error(HRY_E_FORMAT, "corrupt stream (too many faces)");
-		uint32_t o = m.face_off.back();
-		m.face_off.push_back(o + (uint32_t)ne);
-		m.org.resize(o + ne, 0);
-		m.twin.resize(o + ne);
-		for (int i = 0; i < ne; ++i) m.twin[o + i] = o + i;
+		if (face >= nf) throw Error(HRY_E_FORMAT, "corrupt stream (too many faces)");
+		if ((uint64_t)he + (uint32_t)ne > ne_max) throw Error(HRY_E_FORMAT, "corrupt stream (too many polygon edges)");
+		uint32_t o = he;
+		he += (uint32_t)ne;
+		m.face_off[++face] = he;
+		for (int i = 0; i < ne; ++i) { m.org[o + i] = 0; m.twin[o + i] = o + i; }
 		return o;
 	};
 	auto link = [&](uint32_t a, uint32_t b) { m.twin[a] = b; m.twin[b] = a; };
-	auto chk = [&](uint32_t v) { if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)"); return v; };
+	auto chk = [&](uint32_t v) {
+		if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
+		if (v < min_id) throw Error(HRY_E_FORMAT, "corrupt stream (restart point names an older vertex)");
+		return v;
+	};
+	auto fresh = [&]() { if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)"); return next_id++; };
+	bool eom = false;
 
 	for (;;) {
+		if (stop_face != NONE32 && face >= stop_face) break;
 		uint32_t iop = rd.iop();
-		if (iop == I_EOM) break;
+		if (iop == I_EOM) { eom = true; break; }
 		uint32_t a = 0, b = 0, c = 0;
 		// a component is an independent reconstruction chain unless it touches vertices coded before it started
 		// (TRIxxx start, or an NM operation naming an older vertex)
 		const uint32_t seg_first_id = next_id;
-		seg_start.push_back((uint32_t)order_v.size());
-		seg_first.push_back(seg_first_id);
-		seg_level.push_back(0);
+		comp_first.push_back(seg_first_id);
+		comp_level.push_back(0);
 		// level = 1 + the highest level among the components that own an older vertex this component touches
 		auto depends_on = [&](uint32_t vid) {
 			if (vid >= seg_first_id) return;
-			size_t owner = (size_t)(std::upper_bound(seg_first.begin(), seg_first.end(), vid) - seg_first.begin()) - 1;
-			// a component that created no vertex shares seg_first with its successor: upper_bound lands on the last such entry,
+			// a component that created no vertex shares its first id with its successor: upper_bound lands on the last such entry,
 			// which is at least as late as the true owner -- its level is >= the owner's level, so the bound stays valid
-			seg_level.back() = std::max(seg_level.back(), seg_level[owner] + 1);
+			uint32_t lv;
+			if (!comp_first.empty() && vid >= comp_first.front()) {
+				size_t owner = (size_t)(std::upper_bound(comp_first.begin(), comp_first.end(), vid) - comp_first.begin()) - 1;
+				lv = comp_level[owner];
+			} else {
+				size_t owner = (size_t)(std::upper_bound(g_first.begin(), g_first.end(), vid) - g_first.begin());
+				if (owner == 0) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
+				lv = g_level[owner - 1];
+			}
+			comp_level.back() = std::max(comp_level.back(), lv + 1);
 		};
 		switch (iop) {   // decoder.h:46-77
-		case I_INIT: a = next_id++; b = next_id++; c = next_id++; break;
-		case I_TRI100: a = rd.vertid(); b = next_id++; c = next_id++; break;
-		case I_TRI010: c = next_id++; b = rd.vertid(); a = next_id++; break;
-		case I_TRI001: a = next_id++; b = next_id++; c = rd.vertid(); break;
-		case I_TRI110: a = rd.vertid(); b = rd.vertid(); c = next_id++; break;
-		case I_TRI101: c = rd.vertid(); b = next_id++; a = rd.vertid(); break;
-		case I_TRI011: a = next_id++; b = rd.vertid(); c = rd.vertid(); break;
+		case I_INIT: a = fresh(); b = fresh(); c = fresh(); break;
+		case I_TRI100: a = rd.vertid(); b = fresh(); c = fresh(); break;
+		case I_TRI010: c = fresh(); b = rd.vertid(); a = fresh(); break;
+		case I_TRI001: a = fresh(); b = fresh(); c = rd.vertid(); break;
+		case I_TRI110: a = rd.vertid(); b = rd.vertid(); c = fresh(); break;
+		case I_TRI101: c = rd.vertid(); b = fresh(); a = rd.vertid(); break;
+		case I_TRI011: a = fresh(); b = rd.vertid(); c = rd.vertid(); break;
 		case I_TRI111: a = rd.vertid(); b = rd.vertid(); c = rd.vertid(); break;
 		default: throw Error(HRY_E_FORMAT, "corrupt stream (init op)");
 		}
@@ -163,14 +179,15 @@ void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std
 		uint32_t base = new_face(ntri + 2);
 		uint32_t e0 = base, e1 = base + 1, e2 = base + 2, fend = base + (uint32_t)ntri + 2;
 		m.org[e0] = a; m.org[e1] = b; m.org[e2] = c;
-		switch (iop) {   // decoder.h:86-110
-		case I_INIT: order_v.push_back(e0); order_v.push_back(e1); order_v.push_back(e2); break;
-		case I_TRI100: order_v.push_back(e1); order_v.push_back(e2); break;
-		case I_TRI010: order_v.push_back(e2); order_v.push_back(e0); break;
-		case I_TRI001: order_v.push_back(e0); order_v.push_back(e1); break;
-		case I_TRI110: order_v.push_back(e2); break;
-		case I_TRI101: order_v.push_back(e1); break;
-		case I_TRI011: order_v.push_back(e0); break;
+		// vertex ids are handed out in decode order, so order_v is indexed by the id (decoder.h:86-110)
+		switch (iop) {
+		case I_INIT: order_v[a] = e0; order_v[b] = e1; order_v[c] = e2; break;
+		case I_TRI100: order_v[b] = e1; order_v[c] = e2; break;
+		case I_TRI010: order_v[c] = e2; order_v[a] = e0; break;
+		case I_TRI001: order_v[a] = e0; order_v[b] = e1; break;
+		case I_TRI110: order_v[c] = e2; break;
+		case I_TRI101: order_v[b] = e1; break;
+		case I_TRI011: order_v[a] = e0; break;
 		default: break;
 		}
 		cb.parts.push_back(Ring::Part{ -1, -1, 0, true });
@@ -258,7 +275,7 @@ void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std
 				break;
 			}
 			case O_NEWVTX: case O_NM: {
-				v2 = op == O_NEWVTX ? next_id++ : rd.vertid();
+				v2 = op == O_NEWVTX ? fresh() : rd.vertid();
 				chk(v2);
 				if (op == O_NM) depends_on(v2);
 				Ring::Part &p = cb.top();
@@ -293,7 +310,7 @@ void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std
 			default: break;
 			}
 			++seen[v0]; ++seen[v1]; ++seen[v2];
-			if (op == O_NEWVTX) order_v.push_back(f0 + (uint32_t)curtri + 2);
+			if (op == O_NEWVTX) order_v[v2] = f0 + (uint32_t)curtri + 2;
 			++curtri;
 			if (seq_first) link(gate, e0);
 			if (op == O_CONNFWD) {
@@ -302,9 +319,27 @@ void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std
 			} else if (op == O_CONNBWD) link(gateprev, e1);
 		}
 	}
-	seg_start.push_back((uint32_t)order_v.size());
-	if (m.face_off.size() != (size_t)nf + 1) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
-	if (next_id > nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)");
+	cur.next_id = next_id; cur.face = face; cur.he = he;
+	return eom;
+}
+
+// the whole connectivity as one span (reference v0.1 streams, and v0.2 containers without restart points)
+template <class RD>
+void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
+{
+	m.face_off.assign((size_t)m.nf + 1, 0);
+	m.org.assign(m.declared_ne, 0);
+	m.twin.assign(m.declared_ne, 0);
+	order_v.assign(m.nv, 0);
+	std::vector<uint16_t> seen(m.nv, 0);
+	ReplayCursor cur;
+	const std::vector<uint32_t> none;
+	seg_start.clear(); seg_level.clear();
+	replay_span(m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, none, seg_start, seg_level);
+	if (cur.face != m.nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
+	if (cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
+	order_v.resize(cur.next_id);
+	seg_start.push_back(cur.next_id);
 }
 
 }   // namespace hry

@@ -1,6 +1,8 @@
 // Cut-border replay from entropy-decoded symbol planes (chunked profile).  See cbm_replay.hpp.
 #include "cbm_replay.hpp"
 
+#include <atomic>
+
 namespace hry {
 namespace {
 struct Planes {
@@ -26,14 +28,95 @@ struct Planes {
 
 // planes: 21 connectivity planes in container order.  Fills m.face_off / org / twin and returns the decode order
 // (one half-edge per vertex; vertex ids are assigned in this order, cbm/decoder.h:48-75,145).
+//
+// Restart points of the container directory cut the replay into spans that start at a component boundary with a known
+// state (plane cursors, next vertex id / face / half-edge).  A span whose components name no vertex older than its restart
+// point (flag bit 0 clear) touches nothing another span touches and runs on its own host thread; the flagged ones (shared
+// non-manifold vertices across the cut: the order counters of those vertices continue) are replayed afterwards, in order.
 void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const std::vector<RestartPoint> &restarts,
                        std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
 {
-	(void)restarts;
+	using replay_detail::NONE32;
 	int ndeg = 0, onlydeg = 0;
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++ndeg; onlydeg = (int)d; }
-	Planes rd{ conn_planes, { 0 }, ndeg <= 1 ? onlydeg - 2 : -1 };
-	cut_border_replay_with(m, rd, order_v, seg_start, seg_level);
+	const int fixed_numtri = ndeg <= 1 ? onlydeg - 2 : -1;
+	const unsigned n_threads = host_threads();
+	if (restarts.empty() || n_threads < 2 || m.nf < parallel_min_faces()) {
+		Planes rd{ conn_planes, { 0 }, fixed_numtri };
+		cut_border_replay_with(m, rd, order_v, seg_start, seg_level);
+		return;
+	}
+	// spans: [start state, stop face); the directory must be strictly increasing in faces and consistent in every counter
+	const size_t ns = restarts.size() + 1;
+	struct Span { ReplayCursor cur; uint32_t stop_face; bool flagged; Planes rd; std::vector<uint32_t> first, level; bool eom = false; };
+	std::vector<Span> spans(ns);
+	for (size_t k = 0; k < ns; ++k) {
+		Span &sp = spans[k];
+		sp.rd = Planes{ conn_planes, { 0 }, fixed_numtri };
+		sp.flagged = false;
+		if (k > 0) {
+			const RestartPoint &r = restarts[k - 1];
+			const uint32_t prev_face = k > 1 ? restarts[k - 2].first_face : 0u;
+			if (r.first_face <= prev_face || r.first_face >= m.nf || r.first_vertex > m.nv || r.first_halfedge > m.declared_ne)
+				throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart points)");
+			sp.cur.next_id = r.first_vertex; sp.cur.face = r.first_face; sp.cur.he = r.first_halfedge;
+			sp.flagged = (r.flags & 1u) != 0;
+			static const int first_plane[G_COUNT] = { 0, 1, 5, 7, 11 };
+			for (int g = 0; g < G_COUNT; ++g) for (int b = 0; b < kGroupBytes[g]; ++b) sp.rd.cur[first_plane[g] + b] = r.n_grp[g];
+			for (int i = 0; i < 8; ++i) sp.rd.cur[13 + i] = r.n_op[i];
+		}
+		sp.stop_face = k + 1 < ns ? restarts[k].first_face : NONE32;
+	}
+	m.face_off.assign((size_t)m.nf + 1, 0);
+	m.org.assign(m.declared_ne, 0);
+	m.twin.assign(m.declared_ne, 0);
+	order_v.assign(m.nv, 0);
+	std::vector<uint16_t> seen(m.nv, 0);
+	const std::vector<uint32_t> none;
+	// a span must end exactly where the next one starts, in every counter
+	auto check_end = [&](size_t k) {
+		const Span &sp = spans[k];
+		if (k + 1 == ns) {
+			if (!sp.eom || sp.cur.face != m.nf || sp.cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
+			return;
+		}
+		const Span &nx = spans[k + 1];
+		const RestartPoint &r = restarts[k];
+		bool ok = !sp.eom && sp.cur.face == r.first_face && sp.cur.next_id == r.first_vertex && sp.cur.he == r.first_halfedge;
+		for (int p = 0; p < 21 && ok; ++p) {
+			// nx.rd.cur was the start state of the next span unless that span has already run; compare against the directory
+			(void)nx;
+			size_t want = p == 0 ? r.n_grp[0] : p < 5 ? r.n_grp[1] : p < 7 ? r.n_grp[2] : p < 11 ? r.n_grp[3] : p < 13 ? r.n_grp[4] : r.n_op[p - 13];
+			if (fixed_numtri >= 0 && (p == 11 || p == 12)) continue;   // numtri is not stored for a single polygon degree
+			ok = sp.rd.cur[p] == want;
+		}
+		if (!ok) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart point does not match the stream)");
+	};
+	std::atomic<size_t> next{ 0 };
+	parallel_for((unsigned)std::min<size_t>(n_threads, ns), [&](unsigned) {
+		for (;;) {
+			size_t k = next.fetch_add(1, std::memory_order_relaxed);
+			if (k >= ns) break;
+			Span &sp = spans[k];
+			if (sp.flagged) continue;
+			sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, none, none, sp.first, sp.level);
+			check_end(k);
+		}
+	});
+	// flagged spans in order, with the components before them known; then the global component table
+	seg_start.clear(); seg_level.clear();
+	for (size_t k = 0; k < ns; ++k) {
+		Span &sp = spans[k];
+		if (sp.flagged) {
+			sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, 0u, seg_start, seg_level, sp.first, sp.level);
+			check_end(k);
+		}
+		seg_start.insert(seg_start.end(), sp.first.begin(), sp.first.end());
+		seg_level.insert(seg_level.end(), sp.level.begin(), sp.level.end());
+	}
+	const uint32_t n_ids = spans.back().cur.next_id;
+	order_v.resize(n_ids);
+	seg_start.push_back(n_ids);
 }
 
 }   // namespace hry

@@ -473,17 +473,6 @@ uint32_t parallel_min_faces()
 	return 1u << 16;
 }
 namespace {
-template <typename F> static void parallel_for(unsigned n_threads, F &&body)   // body(thread index), joins before returning
-{
-	std::vector<std::thread> th;
-	std::exception_ptr err;
-	std::mutex mu;
-	for (unsigned t = 1; t < n_threads; ++t)
-		th.emplace_back([&, t] { try { body(t); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); } });
-	try { body(0); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
-	for (auto &x : th) x.join();
-	if (err) std::rethrow_exception(err);
-}
 // lock-free union-find on atomics: a root is always the smallest index of its set's links, so links never form a cycle
 struct AtomicSets {
 	std::unique_ptr<std::atomic<uint32_t>[]> parent;

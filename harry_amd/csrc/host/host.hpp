@@ -1,7 +1,10 @@
 // Host-side declarations of the product (PLY I/O, cut-border walk, .hry header).
 #pragma once
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/harry_amd.h"
@@ -74,6 +77,17 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
                        std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level);
 unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
 uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
+template <typename F> inline void parallel_for(unsigned n_threads, F &&body)   // body(thread index), joins before returning
+{
+	std::vector<std::thread> th;
+	std::exception_ptr err;
+	std::mutex mu;
+	for (unsigned t = 1; t < n_threads; ++t)
+		th.emplace_back([&, t] { try { body(t); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); } });
+	try { body(0); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+	for (auto &x : th) x.join();
+	if (err) std::rethrow_exception(err);
+}
 
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 // reference single-stream format (compat_read.cpp): serial entropy decode + replay on the host; residual byte planes

@@ -162,6 +162,13 @@ void hry_walk_free(hry_walk *w);
  * for the device reconstruction.  Free with hry_walk_free / hry_mesh_free. */
 int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_walk **out);
 
+/* host-only: the decoder-side cut-border replay (cbm::decode, cbm/decoder.h:27-211) of the connectivity symbols a plain
+ * walk recorded, as the chunked container carries them (21 byte planes).  use_restart_points != 0: cut the replay at the
+ * restart points the container directory would hold and replay the spans on several host threads (HRY_HOST_THREADS,
+ * HRY_PARALLEL_MIN_FACES).  *mesh gets nv/nf and the rebuilt connectivity; the result holds "order_v", "seg_start",
+ * "seg_level" (u32) and "info" = { number of restart points, 0 }. */
+int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_points, hry_mesh **mesh, hry_walk **out);
+
 /* raw range-coder back end on explicit (l,h,t) triples (arith/coder.h:69-91 + flush :58-67), compat form */
 int hry_range_encode_lht(hry_ctx *ctx, const uint64_t *lht, size_t n, uint8_t **out, size_t *out_len);
 

@@ -84,6 +84,22 @@ def test_chunked_larger_meshes(cx, case):
         same_mesh(op.Mesh.from_hry_chunked(got), ref_dec)     # independent CPU decode of the GPU's container
 
 
+@pytest.mark.parametrize("case", ["multi_tri", "shared_vertices"])
+def test_chunked_decode_from_restart_points(cx, case, monkeypatch):
+    """Encode with the threaded walk, decode with the replay cut at the directory's restart points on several host threads:
+    same container as the oracle's, same mesh as the reference-format decode."""
+    monkeypatch.setenv("HRY_HOST_THREADS", "4")
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "0")
+    mesh = {"multi_tri": lambda: mg.multi_component(60, 30, 32, polys="tri"),
+            "shared_vertices": lambda: mg.with_nonmanifold(mg.concat([mg.torus(40, 41, center=(3.0 * i, 0, 0), seed=i) for i in range(20)]), 30, 200)}[case]()
+    ply = mesh.to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
+    assert got == o.clone().encode_chunked(0).data
+    same_mesh(cx.read_hry(got), ref_dec)
+
+
 def test_chunked_entropy_decode_planes(cx):
     """k_chunk_decode inverts k_chunk_encode symbol for symbol (checked before any mesh logic)."""
     m = mg.torus(64, 60, polys="mixed", normals=True)

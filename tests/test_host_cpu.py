@@ -238,3 +238,39 @@ def test_threaded_walk_equals_sequential_walk(case):
     full = hc.Mesh.from_ply(ply).host_walk()
     for k in ("order_v", "order_f", "op_sym", "op_class", "grp0_val", "grp1_val", "grp2_val", "grp3_val", "grp4_val", "grp3_pos"):
         assert np.array_equal(full[k], seq[k]), k
+
+
+# ---------------------------------------------------------------- decoder-side replay, cut at the directory's restart points
+def replay(ply: bytes, threads: int, restarts: bool, min_faces: int = 0):
+    os.environ["HRY_HOST_THREADS"] = str(threads)
+    os.environ["HRY_PARALLEL_MIN_FACES"] = str(min_faces)
+    try:
+        m = hc.Mesh.from_ply(ply)
+        dec, order_v, seg_start, seg_level, nrs = hc.walk_and_replay(m, restarts)
+        return m, dec, order_v, seg_start, seg_level, nrs
+    finally:
+        del os.environ["HRY_HOST_THREADS"], os.environ["HRY_PARALLEL_MIN_FACES"]
+
+
+@pytest.mark.parametrize("case", ["multi_tri", "multi_mixed", "shared_vertices", "many_small", "single"])
+def test_replay_from_restart_points_equals_sequential_replay(case):
+    """The replay of the connectivity planes started independently at every restart point of the chunked directory (spans on
+    several host threads; spans that name older vertices afterwards, in order) rebuilds exactly what one sequential replay
+    rebuilds: face offsets, origins, twins, decode order, component table and levels."""
+    m = {"multi_tri": lambda: mg.multi_component(60, 30, 32, polys="tri"),
+         "multi_mixed": lambda: mg.with_nonmanifold(mg.multi_component(40, 24, 26, polys="mixed", seed=3), 40, 25),
+         "shared_vertices": lambda: mg.with_nonmanifold(mg.concat([mg.torus(40, 41, center=(3.0 * i, 0, 0), seed=i) for i in range(20)]), 30, 200),
+         "many_small": lambda: mg.multi_component(3000, 3, 4, polys="tri"),
+         "single": lambda: mg.torus(80, 84)}[case]()
+    ply = m.to_ply()
+    src, ref, ov, ss, sl, _ = replay(ply, 1, False)
+    # the sequential replay inverts the walk: same polygon degrees in coding order, same vertex count
+    assert ref.nf == src.nf and ref.ne == src.ne and len(ov) == src.nv
+    for threads in (2, 5):
+        _, dec, ov2, ss2, sl2, nrs = replay(ply, threads, True)
+        if case != "single":
+            assert nrs > 0, "the case must exercise restart points"
+        assert np.array_equal(ref.face_offsets(), dec.face_offsets())
+        assert np.array_equal(ref.org(), dec.org())
+        assert np.array_equal(ref.twin(), dec.twin())
+        assert np.array_equal(ov, ov2) and np.array_equal(ss, ss2) and np.array_equal(sl, sl2)
