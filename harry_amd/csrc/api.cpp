@@ -199,6 +199,7 @@ size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 	if (n == "op_t") return ret(r.op_t);
 	if (n == "op_pos") return ret(r.op_pos);
 	if (n == "info") { *ptr = w->info; return 2; }
+	if (n == "marks") { *ptr = r.marks.data(); return r.marks.size() * (sizeof(ComponentMark) / 4); }
 	if (n == "seg_start") return ret(w->seg_start);
 	if (n == "seg_level") return ret(w->seg_level);
 	if (n == "vplanes") return ret(w->vplanes);

@@ -718,7 +718,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 		for (int i = 0; i < 8; ++i) em0.n_op[i] = nop[i];
 	}
 	em0.n = (uint32_t)off_sym[ncomp];
-	em0.min_ref = NONE32;
+	em0.min_ref = w.marks.empty() ? NONE32 : w.marks.back().min_ref;   // the caller's finish_marks() writes it back into the last mark
 	mark("concatenated");
 }
 
