@@ -29,7 +29,9 @@ void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t
 void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                       const ListDesc &ld, uint8_t *rec);
 bool unpredict2_applicable(const ListDesc &ld);
-void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
+void launch_chain_records(hipStream_t st, const uint32_t *cand, const uint8_t *ncand, uint32_t nvtx, const uint32_t *seg_start, uint32_t nseg, void *crec);
+bool unpredict3_wanted(const ListDesc &ld);
+void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand, const void *crec,
                        const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists);
 void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand);
 }
@@ -54,9 +56,11 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	ConnView cv = cx.conn_view();
 	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
 	if (nvc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
-	cx.d_cscratch.ensure(std::max<size_t>((size_t)nvc * (8 * 3 * 4 + 1) + 64, 16));
+	const size_t ncand_bytes = ((size_t)nvc + 63) & ~(size_t)63;
+	cx.d_cscratch.ensure(std::max<size_t>((size_t)nvc * (8 * 3 * 4 + 16) + ncand_bytes + 64, 16));
 	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
 	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nvc * 24);
+	void *d_crec = d_ncand + ncand_bytes;   // 16-byte chain records (k_unpredict3), 16-byte aligned
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	if (ldv.nplanes) {
 		if (unpredict2_applicable(ldv)) {
@@ -75,16 +79,20 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 			std::vector<size_t> seg_at, off_at;
 			for (auto &lv : by_level) { seg_at.push_back(table.size()); table.insert(table.end(), lv.begin(), lv.end()); }
 			for (auto &lv : by_level) { off_at.push_back(table.size()); for (uint32_t i = 0; i <= lv.size() / 2; ++i) table.push_back(i); }
+			const size_t segstart_at = table.size();
+			table.insert(table.end(), seg_start.begin(), seg_start.end());
+			const bool scan_chain = unpredict3_wanted(ldv) && seg_start.size() >= 2;
 			cx.d_small.ensure(table.size() * 4 + 64);
 			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
 			const uint32_t *d_tab = cx.d_small.as<uint32_t>();
 						launch_candidates_ids(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand);
+			if (scan_chain) launch_chain_records(cx.stream, d_cand, d_ncand, nvc, d_tab + segstart_at, (uint32_t)seg_start.size() - 1, d_crec);
 			HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
 			for (size_t lv = 0; lv < by_level.size(); ++lv) {
 				const uint32_t nl = (uint32_t)by_level[lv].size() / 2;
 				// a 2-D grid holds at most 65535 rows: split very wide levels
 				for (uint32_t done = 0; done < nl; done += 65535)
-					launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
+					launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, scan_chain ? d_crec : nullptr, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
 					                  d_tab + seg_at[lv], d_tab + off_at[lv] + done, std::min(65535u, nl - done));
 			}
 			HIP_OK(hipEventRecord(cx.ev[0], cx.stream));

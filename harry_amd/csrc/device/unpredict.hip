@@ -979,6 +979,265 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_unpredict3: the chain for unsigned components of at most 16 bits (every quantised attribute), evaluated as a
+// PREFIX SCAN instead of vertex by vertex.
+//
+// Everything that depends only on the connectivity is computed beforehand, in parallel, by k_chain_records: per vertex a
+// 16-byte record with the LDS ring slots of its (at most two) candidates' sources, which source is "the vertex right
+// before it" (the chained source), and the earliest batch start the vertex tolerates (every other source must be final
+// before its batch starts).  The chain kernel walks 64-aligned tiles (record + residual code of a tile prefetched one tile
+// ahead, one coalesced load each) and cuts a tile into runs at those marks; inside a run every vertex depends on the run
+// only through its predecessor.
+//
+// A run is a composition of per-vertex maps x -> value (x = the predecessor's value).  With the parallelogram unclamped
+// and the residual code in its "near" form (prediction.h:58-63) the map is
+//     lone candidate : x -> x + (b - o) + delta
+//     two candidates : x -> floor((x + (b - o) + p1 + 1) / 2) + delta          (mean of two, transform.h:91)
+//     no source inside the run : x -> constant                                    (evaluated exactly, not speculated)
+// i.e. x -> floor((x + A) / 2^k) + D with 0 <= A < 2^k.  These maps are closed under composition
+//     g(f(x)) = floor((x + A1 + 2^k1 ((D1 + A2) mod 2^k2)) / 2^(k1+k2)) + D2 + floor((D1 + A2) / 2^k2),
+// and on the value range 0 <= x < 2^16 a map with k > 16 is a step function D + [x >= theta], which is again of the form
+// floor((x + A') / 2^16) + D: the representation never grows.  A wavefront inclusive scan (4 DPP row shifts + 2 row
+// broadcasts) composes the maps of a run; lane l then holds the value of its vertex -- provided no lane left the speculated
+// form (clamped parallelogram, "far" or raw residual code: rare).  That is verified exactly: every lane evaluates its true
+// arithmetic (attrcode.h:182-208, prediction.h:46-64,121-138) on its predecessor's scanned value; by induction all values
+// are right iff every lane agrees.  The first disagreeing lane is replaced by its true value (a constant map) and the
+// scan is repeated once; a second disagreement finishes the run vertex by vertex.  Results are bit-identical to the
+// sequential evaluation in every case; only the speed depends on the data.
+// Reconstructed values live in an LDS ring of kRing3 entries and are flushed to the records every 4096 vertices, so the
+// chain never waits for a store.
+// ---------------------------------------------------------------------------------------------------------
+struct alignas(16) ChainRec { uint16_t slot[6]; uint16_t flags; uint16_t pad; };
+constexpr uint32_t kRing3 = 16384;          // ring entries (32 KB of LDS for 16-bit values)
+constexpr uint32_t kRing3Near = kRing3 - 64;   // a source this close to its vertex is still in the ring when the run is prepared
+constexpr uint32_t kFlush3 = 4096;
+enum { CR_NC = 3, CR_BIG = 3, CR_POS_SHIFT = 2, CR_POS_NONE = 7, CR_FAR = 1 << 5, CR_NEED_SHIFT = 6 };
+
+// cand / ncand as written by k_candidates_ids; seg_start: first decode rank of every component + end sentinel
+__global__ __launch_bounds__(256) void k_chain_records(const uint32_t *cand, const uint8_t *ncand, uint32_t n, const uint32_t *seg_start, uint32_t nseg, ChainRec *out)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= n) return;
+	uint32_t lo = 0, hi = nseg;   // component of v: the last one that starts at or before v
+	while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= v) lo = mid; else hi = mid; }
+	const uint32_t seg_begin = seg_start[lo];
+	const uint32_t nc = ncand[v];
+	ChainRec r;
+#pragma unroll
+	for (int j = 0; j < 6; ++j) r.slot[j] = 0;
+	r.pad = 0;
+	if (nc > 2) { r.flags = (uint16_t)(CR_BIG | (CR_POS_NONE << CR_POS_SHIFT)); out[v] = r; return; }
+	const uint32_t *row = cand + (size_t)v * (kCandMax * 3);
+	uint32_t pos = CR_POS_NONE, need = 0, far = 0;
+	for (uint32_t j = 0; j < 3 * nc; ++j) {
+		const uint32_t id = row[j];
+		if (id + 1u == v && j % 3 != 2 && pos == CR_POS_NONE && v > seg_begin) pos = j;   // the chained source: predecessor, plus sign, once
+		else need = max(need, id + 1u);
+		far |= (v - id > kRing3Near || id < seg_begin) ? 1u : 0u;
+		r.slot[j] = (uint16_t)(id & (kRing3 - 1));
+	}
+	if (nc == 1) { r.slot[3] = r.slot[0]; r.slot[4] = r.slot[1]; r.slot[5] = r.slot[2]; }   // (2 p + 1) >> 1 == p
+	const uint32_t tile = v & ~63u;
+	const uint32_t need_rel = need > tile ? need - tile : 0u;   // <= v - tile <= 63
+	r.flags = (uint16_t)(nc | (pos << CR_POS_SHIFT) | (far ? CR_FAR : 0) | (need_rel << CR_NEED_SHIFT));
+	out[v] = r;
+}
+
+struct Map3 { int32_t k, A, D; };   // x -> floor((x + A) / 2^k) + D, 0 <= A < 2^k, k <= 16
+// g after f, exact for 0 <= x < 2^16
+__device__ __forceinline__ Map3 compose3(const Map3 &f, const Map3 &g)
+{
+	const int32_t T = f.D + g.A;
+	const int32_t rT = T & ((1 << g.k) - 1), q = T >> g.k;
+	const int32_t K = f.k + g.k;
+	const int32_t A_small = f.A + (rT << f.k);
+	// K > 16: step function with threshold theta = (2^k2 - rT) 2^k1 - A1 (>= 1); at or above 2^16 it never fires
+	const uint32_t u = (uint32_t)((1 << g.k) - rT);
+	const bool sat = (u >> (17 - f.k)) != 0u;            // u 2^k1 >= 2^17  (f.k == 0: u <= 2^16, never)
+	const uint32_t theta = (u << f.k) - (uint32_t)f.A;   // meaningful when !sat: < 2^17
+	const int32_t A_big = (sat || theta >= 65536u) ? 0 : (int32_t)(65536u - theta);
+	Map3 h;
+	h.k = K <= 16 ? K : 16;
+	h.A = K <= 16 ? A_small : A_big;
+	h.D = g.D + q;
+	return h;
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ Map3 dpp3(const Map3 &m)
+{
+	Map3 r;   // lanes without a source (row start, masked rows) receive the identity map (0, 0, 0)
+	r.k = __builtin_amdgcn_update_dpp(0, m.k, CTRL, ROWMASK, 0xf, false);
+	r.A = __builtin_amdgcn_update_dpp(0, m.A, CTRL, ROWMASK, 0xf, false);
+	r.D = __builtin_amdgcn_update_dpp(0, m.D, CTRL, ROWMASK, 0xf, false);
+	return r;
+}
+// inclusive scan over the wavefront: lane l gets m_l o m_(l-1) o ... o m_0
+__device__ __forceinline__ Map3 scan3(Map3 m)
+{
+	m = compose3(dpp3<0x111, 0xf>(m), m);   // row_shr:1
+	m = compose3(dpp3<0x112, 0xf>(m), m);   // row_shr:2
+	m = compose3(dpp3<0x114, 0xf>(m), m);   // row_shr:4
+	m = compose3(dpp3<0x118, 0xf>(m), m);   // row_shr:8
+	m = compose3(dpp3<0x142, 0xa>(m), m);   // row_bcast:15 into rows 1 and 3
+	m = compose3(dpp3<0x143, 0xc>(m), m);   // row_bcast:31 into rows 2 and 3
+	return m;
+}
+
+template <typename T>
+__device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t seg_end,
+                                   const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec, const uint8_t *planes, uint8_t *rec,
+                                   int stride, int off, int q, int plane0, T *ring)
+{
+	static_assert(sizeof(T) <= 2 && !(T(-1) < T(0)), "unsigned components of at most 16 bits");
+	const int lane = threadIdx.x;
+	constexpr uint32_t mask = kRing3 - 1;
+	const uint32_t top = ev_top<T>(q), wrap = (uint32_t)(T)(~T(0));
+	uint32_t flushed = seg_begin;   // [seg_begin, flushed) have reached the records in global memory
+	auto flush_to = [&](uint32_t upto) {
+		for (uint32_t b = flushed; b < upto; b += 64) { const uint32_t v = b + lane; if (v < upto) stq<T>(rec + (size_t)v * stride + off, ring[v & mask]); }
+		flushed = upto;
+	};
+	// value of a vertex that is final before the current run, wherever it lives
+	auto old_value = [&](uint32_t id, uint32_t cur) -> uint32_t {
+		if (id >= seg_begin && cur - id <= kRing3Near) return (uint32_t)ring[id & mask];
+		return (uint32_t)__hip_atomic_load((const T*)(rec + (size_t)id * stride + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	uint4 nx_rec = make_uint4(0, 0, 0, 0);
+	uint32_t nx_b0 = 0, nx_b1 = 0;
+	auto request = [&](uint32_t tb) {
+		const uint32_t v = tb + lane;
+		nx_rec = make_uint4(0, 0, 0, 0); nx_b0 = nx_b1 = 0;
+		if (v >= seg_begin && v < seg_end) {
+			nx_rec = *(const uint4*)(crec + v);
+			nx_b0 = planes[(size_t)plane0 * nvtx_total + v];
+			if (sizeof(T) == 2) nx_b1 = planes[(size_t)(plane0 + 1) * nvtx_total + v];
+		}
+	};
+	const uint32_t t_first = seg_begin & ~63u;
+	request(t_first);
+	for (uint32_t tb = t_first; tb < seg_end; tb += 64) {
+		const uint4 cr = nx_rec;
+		const uint32_t code = nx_b0 | (nx_b1 << 8);
+		if (tb - flushed >= kFlush3 && tb > flushed) flush_to(tb);
+		if (tb + 64 < seg_end) request(tb + 64);
+		const uint32_t v = tb + lane;
+		const uint32_t lo = seg_begin > tb ? seg_begin - tb : 0u, hi = min(64u, seg_end - tb);
+		const bool valid = (uint32_t)lane >= lo && (uint32_t)lane < hi;
+		const uint32_t slot0 = cr.x & 0xffffu, slot1 = cr.x >> 16, slot2 = cr.y & 0xffffu, slot3 = cr.y >> 16, slot4 = cr.z & 0xffffu, slot5 = cr.z >> 16;
+		const uint32_t flags = cr.w & 0xffffu;
+		const uint32_t nc = flags & CR_NC, pos = (flags >> CR_POS_SHIFT) & 7u, need_rel = flags >> CR_NEED_SHIFT;
+		const bool far = (flags & CR_FAR) != 0, big = valid && nc == CR_BIG;
+		const uint64_t bigmask = __ballot(big);
+		UnfoldPre uf;
+		uf.setup(code, top, wrap);
+		uint32_t s = lo;
+		while (s < hi) {
+			if ((bigmask >> s) & 1ull) {
+				// more than two candidates: evaluated on its own, candidate k on lane k (table order), or by walking the fan
+				const uint32_t vb = tb + s;
+				const uint32_t n0 = ncand[vb];
+				T pred = T(0);
+				if (n0 != 0xff) {
+					uint32_t pk = 0;
+					if ((uint32_t)lane < n0) {
+						const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
+						pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
+					}
+					T pv[kCandMax];
+#pragma unroll
+					for (int k = 0; k < kCandMax; ++k) pv[k] = (T)rl(pk, k);
+					pred = chain_predict<T>(n0, pv);
+				} else {
+					int64_t acc = 0;
+					uint32_t n = 0;
+					fan_ids(tp, order_v[vb], vb, [&](uint32_t a, uint32_t b, uint32_t o) {
+						acc += (int64_t)cm::parallelogram<T>((T)old_value(a, vb), (T)old_value(b, vb), (T)old_value(o, vb), q);
+						++n;
+					});
+					if (n) pred = (T)cm::mean_of(acc, (int64_t)n);
+				}
+				const uint32_t c0 = rl(code, s);
+				const T val = cm::value_from_residual<T>((typename cm::word<sizeof(T)>::u)c0, pred, q);
+				if (lane == 0) ring[vb & mask] = val;
+				s += 1;
+				continue;
+			}
+			// the run [s, e): cut before the first vertex that needs a later batch start, or a vertex with more than two candidates
+			const uint64_t above = s >= 63u ? 0ull : ~((2ull << s) - 1ull);
+			const uint64_t cut = __ballot(valid && (need_rel > s || big)) & above;
+			const uint32_t e = cut ? (uint32_t)__builtin_ctzll(cut) : hi;
+			const bool active = (uint32_t)lane >= s && (uint32_t)lane < e;
+			uint32_t sv0 = ring[slot0], sv1 = ring[slot1], sv2 = ring[slot2], sv3 = ring[slot3], sv4 = ring[slot4], sv5 = ring[slot5];
+			if (__ballot(active && far)) {
+				if (active && far) {   // some source is older than the ring or belongs to an earlier component: by vertex id
+					const uint32_t *row = cand + (size_t)v * (kCandMax * 3);
+					const uint32_t a0 = old_value(row[0], tb + s), a1 = old_value(row[1], tb + s), a2 = old_value(row[2], tb + s);
+					uint32_t a3 = a0, a4 = a1, a5 = a2;
+					if (nc == 2) { a3 = old_value(row[3], tb + s); a4 = old_value(row[4], tb + s); a5 = old_value(row[5], tb + s); }
+					// the chained source is not final yet unless this vertex starts the run; its slot value is ignored below
+					sv0 = a0; sv1 = a1; sv2 = a2; sv3 = a3; sv4 = a4; sv5 = a5;
+				}
+			}
+			if (nc == 0) { sv0 = sv1 = sv2 = sv3 = sv4 = sv5 = 0; }
+			bool keepl = pos == CR_POS_NONE || (uint32_t)lane == s;
+			// exact value of a vertex without a source inside the run
+			const uint32_t p0e = med3_i32((int32_t)(sv0 + sv1 - sv2), 0, (int32_t)top), p1e = med3_i32((int32_t)(sv3 + sv4 - sv5), 0, (int32_t)top);
+			uint32_t v0 = uf.apply((p0e + p1e + 1u) >> 1, top) & wrap;
+			// chained form: candidate kp holds the predecessor as source a or b
+			const bool kp = pos >= 3u, isb = pos == 1u || pos == 4u;
+			const uint32_t sa = kp ? sv3 : sv0, sb = kp ? sv4 : sv1, so = kp ? sv5 : sv2;
+			const int32_t bo0 = (int32_t)((isb ? sa : sb) - so);
+			const uint32_t p1c = kp ? p0e : p1e;
+			const bool two = nc == 2;
+			const int32_t tsum = bo0 + (int32_t)p1c + 1;
+			Map3 g;
+			g.k = keepl ? 16 : two ? 1 : 0;
+			g.A = keepl ? 0 : two ? (tsum & 1) : 0;
+			g.D = keepl ? (int32_t)v0 : two ? (tsum >> 1) + (int32_t)uf.delta : bo0 + (int32_t)uf.delta;
+			uint32_t xh = 0;
+			for (int attempt = 0;; ++attempt) {
+				xh = (uint32_t)scan3(g).D;
+				const uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xh, 0x138, 0xf, 0xf, false);   // wave_shr:1
+				const uint32_t p0 = med3_i32((int32_t)(xp + (uint32_t)bo0), 0, (int32_t)top);
+				const uint32_t pred = two ? (p0 + p1c + 1u) >> 1 : p0;
+				const uint32_t tv = keepl ? v0 : (uf.apply(pred, top) & wrap);
+				const uint64_t bad = __ballot(active && tv != xh);
+				if (!bad) break;
+				const uint32_t j = (uint32_t)__builtin_ctzll(bad);
+				if ((uint32_t)lane == j) { keepl = true; v0 = tv; g.k = 16; g.A = 0; g.D = (int32_t)tv; xh = tv; }
+				if (attempt == 1) {
+					// the data keeps leaving the speculated form: finish the run vertex by vertex
+					for (uint32_t i = j + 1; i < e; ++i) {
+						const uint32_t xq = rl(xh, i - 1);
+						const uint32_t q0 = med3_i32((int32_t)(xq + (uint32_t)bo0), 0, (int32_t)top);
+						const uint32_t pr = two ? (q0 + p1c + 1u) >> 1 : q0;
+						const uint32_t t2 = keepl ? v0 : (uf.apply(pr, top) & wrap);
+						if ((uint32_t)lane == i) xh = t2;
+					}
+					break;
+				}
+			}
+			if (active) ring[v & mask] = (T)xh;
+			s = e;
+		}
+	}
+	flush_to(seg_end);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_unpredict3(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
+                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, const uint32_t *segs, const uint32_t *list_off)
+{
+	__shared__ T ring3[kRing3];
+	const int c = sel.comp[blockIdx.x];
+	TopoD tp{ cv };
+	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
+		const uint32_t b = segs[2 * k], e = segs[2 * k + 1];
+		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3);
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
 static uint32_t ring_elem_bytes(const ListDesc &ld)
 {
 	bool same = true;
@@ -1032,10 +1291,26 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 }
 // segs: pairs (begin, end) of decode ranks; list_off: n_lists + 1 offsets into segs.  Lists run in parallel blocks, the
 // segments of one list one after the other.  Two launches: independent components first, then the dependent ones.
-void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand,
+void launch_chain_records(hipStream_t st, const uint32_t *cand, const uint8_t *ncand, uint32_t nvtx, const uint32_t *seg_start, uint32_t nseg, void *crec)
+{
+	if (nvtx && nseg) hipLaunchKernelGGL(k_chain_records, dim3((nvtx + 255) / 256), dim3(256), 0, st, cand, ncand, nvtx, seg_start, nseg, (ChainRec*)crec);
+}
+bool unpredict3_wanted(const ListDesc &ld)
+{
+	for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == 6 || ld.stype[c] == 8) return true;
+	return false;
+}
+void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand, const void *crec,
                        const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists)
 {
 	if (!nvtx || !ld.ncomp || !n_lists) return;
+	auto go3 = [&](auto kern, int stype) {
+		CompSel sel{};
+		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
+		if (!sel.n) return;
+		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
+		                   segs, list_off);
+	};
 	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + kQueue * kQueueCols * 4;
 	auto go = [&](auto kern, int stype) {
 		CompSel sel{};
@@ -1046,8 +1321,10 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		                   segs, list_off);
 	};
 	// components of different types are independent chains too: their kernels may overlap on the device
-	go(k_unpredict2<float>, 0); go(k_unpredict2<uint32_t>, 4); go(k_unpredict2<int32_t>, 5); go(k_unpredict2<uint16_t>, 6);
-	go(k_unpredict2<int16_t>, 7); go(k_unpredict2<uint8_t>, 8); go(k_unpredict2<int8_t>, 9);
+	go(k_unpredict2<float>, 0); go(k_unpredict2<uint32_t>, 4); go(k_unpredict2<int32_t>, 5);
+	go(k_unpredict2<int16_t>, 7); go(k_unpredict2<int8_t>, 9);
+	if (crec) { go3(k_unpredict3<uint16_t>, 6); go3(k_unpredict3<uint8_t>, 8); }
+	else { go(k_unpredict2<uint16_t>, 6); go(k_unpredict2<uint8_t>, 8); }
 }
 void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                       const ListDesc &ld, uint8_t *rec)

@@ -2,6 +2,9 @@
 #include "cbm_replay.hpp"
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace hry {
 namespace {
@@ -67,12 +70,18 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 		}
 		sp.stop_face = k + 1 < ns ? restarts[k].first_face : NONE32;
 	}
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry replay] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
+	if (trace) { size_t nfl = 0; uint64_t ffl = 0; for (size_t k = 0; k < ns; ++k) if (spans[k].flagged) { ++nfl; ffl += (k + 1 < ns ? restarts[k].first_face : m.nf) - spans[k].cur.face; }
+		fprintf(stderr, "[hry replay] %zu spans, %zu flagged holding %llu of %u faces\n", ns, nfl, (unsigned long long)ffl, m.nf); }
 	m.face_off.assign((size_t)m.nf + 1, 0);
 	m.org.assign(m.declared_ne, 0);
 	m.twin.assign(m.declared_ne, 0);
 	order_v.assign(m.nv, 0);
 	std::vector<uint16_t> seen(m.nv, 0);
 	const std::vector<uint32_t> none;
+	mark("allocated");
 	// a span must end exactly where the next one starts, in every counter
 	auto check_end = [&](size_t k) {
 		const Span &sp = spans[k];
@@ -103,6 +112,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 			check_end(k);
 		}
 	});
+	mark("independent spans");
 	// flagged spans in order, with the components before them known; then the global component table
 	seg_start.clear(); seg_level.clear();
 	for (size_t k = 0; k < ns; ++k) {
@@ -114,6 +124,7 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 		seg_start.insert(seg_start.end(), sp.first.begin(), sp.first.end());
 		seg_level.insert(seg_level.end(), sp.level.begin(), sp.level.end());
 	}
+	mark("flagged spans");
 	const uint32_t n_ids = spans.back().cur.next_id;
 	order_v.resize(n_ids);
 	seg_start.push_back(n_ids);
