@@ -4,7 +4,7 @@
 //     u32 chunk_syms, u32 n_planes, n_planes x u32 n_symbols, n_streams x u32 n_bytes, streams back to back
 // Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
 // Every (plane, chunk of chunk_syms symbols) is one stream: fresh adaptive model (the reference's initial counts,
-// models.h:197-218 / model.h:38-55), fresh 64-bit coder, 64-bit flush (arith/coder.h).  Symbols that carry no
+// models.h:197-218 / model.h:38-55), fresh coder with 32-bit registers (arith::Encoder<uint32_t>), 32-bit flush (arith/coder.h).  Symbols that carry no
 // information are not stored (reg_face / reg_vtx with a single region, attr_type == DATA, numtri with one degree).
 // The symbols themselves are those of the compat stream, so the two profiles transcode losslessly.
 #include <chrono>
@@ -22,6 +22,7 @@ static double ms_since(Clock::time_point t0) { return std::chrono::duration<doub
 
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
 static constexpr int kDefaultChunk = 32768;
+static constexpr uint32_t kMaxChunk = 1u << 20;   // totals stay below 2^21: far inside the 32-bit coder's t <= 2^30 (oracle: same clamp)
 
 static void build_inits(const Mesh &m, std::vector<uint32_t> &tabs, uint32_t totals[INIT_KINDS])
 {
@@ -61,7 +62,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	auto t_all = Clock::now();
 	cx.timing = hry_timing{};
 	check_codable(m);
-	uint32_t CH = chunk_syms > 0 ? (uint32_t)chunk_syms : (uint32_t)kDefaultChunk;
+	uint32_t CH = chunk_syms > 0 ? std::min<uint32_t>((uint32_t)chunk_syms, kMaxChunk) : (uint32_t)kDefaultChunk;
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds) { m.lists[l].bmin.assign(m.lists[l].stride(), 0); m.lists[l].bmax.assign(m.lists[l].stride(), 0); m.lists[l].have_bounds = true; }
 	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);

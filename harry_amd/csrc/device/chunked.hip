@@ -1,6 +1,8 @@
 // HIP kernels of the chunked profile (.hry v0.2): every (context plane, chunk) is an independent stream with a
-// fresh adaptive model and a fresh 64-bit Moffat-Neal-Witten coder -- the reference's arithmetic
-// (arith/coder.h:58-162, arith/stat_adaptive.h:46-90) instantiated once per chunk.
+// fresh adaptive model and a fresh Moffat-Neal-Witten coder with 32-bit registers -- the reference's templates
+// arith::Encoder<uint32_t> / arith::Decoder<uint32_t> (arith/coder.h:27-162) and arith/stat_adaptive.h:46-90 instantiated
+// once per chunk.  32-bit registers are what the scalar unit multiplies in one instruction; a chunk holds at most 2^20
+// symbols, so totals stay below 2^21 and the interval keeps >= 10 bits per count (size effect < 0.01 %).
 //
 //   k_chunk_encode : one wavefront owns one stream: count / cumulative tables in LDS, 64 symbols per step evaluated
 //                    by counting, range recurrence in scalar registers, low register accumulated through an LDS
@@ -29,14 +31,24 @@ __device__ __forceinline__ uint32_t wscan_excl(uint32_t v, uint32_t &total)
 	return inc - v;
 }
 
-constexpr int kWin = 192;   // LDS accumulation window in 32-bit words (64 symbols x <= 63 shifts = 126 words + 3)
+constexpr int kWin = 72;   // LDS accumulation window in 32-bit words (64 symbols x <= 31 shifts = 62 words + 2)
 
+// One wavefront owns one stream (arith::Encoder<uint32_t>, arith/coder.h:58-91, with an adaptive table of
+// arith/stat_adaptive.h).  Per batch of 64 symbols:
+//   * the model is evaluated by counting: symbol j of the batch sees the table at the batch start plus the symbols before it
+//     inside the batch -- how many are smaller / equal comes from nine ballots (one per symbol bit, MSB first), no loop over lanes;
+//   * the range register follows its serial recurrence on the scalar unit: r = floor(R / t) through the reciprocal of t
+//     (t = t0 + position is known in advance: one s_mul_hi + shift), R' = r x or R - r x, renormalised with one
+//     count-leading-zeros; about a dozen scalar instructions per symbol;
+//   * the low register is a sum: L = sum r_k l_k 2^(-S_k).  Every lane adds its term into an LDS window at its bit position,
+//     the window goes to the stream's accumulator words (one 64-bit counter per 32-bit output word, folded and carried by
+//     k_carry_*): bit-plus-follow is carry propagation.
 __global__ __launch_bounds__(64) void k_chunk_encode(const StreamJob *jobs, const uint32_t *inits, const MagicEnt *magic,
                                                      unsigned long long *acc, uint32_t *stream_bits)
 {
 	const StreamJob jb = jobs[blockIdx.x];
 	const int lane = threadIdx.x;
-	__shared__ uint32_t cnt[256], cum[256], bh[256];
+	__shared__ uint32_t cnt[257], cum[257], bh[256];
 	__shared__ unsigned long long win[kWin];
 	{
 		const uint32_t *st = inits + (size_t)jb.init * 256 + 4 * lane;
@@ -44,80 +56,66 @@ __global__ __launch_bounds__(64) void k_chunk_encode(const StreamJob *jobs, cons
 		uint32_t ex = wscan_excl(a + b + c + d, tot);
 		cnt[4 * lane] = a; cnt[4 * lane + 1] = b; cnt[4 * lane + 2] = c; cnt[4 * lane + 3] = d;
 		cum[4 * lane] = ex; cum[4 * lane + 1] = ex + a; cum[4 * lane + 2] = ex + a + b; cum[4 * lane + 3] = ex + a + b + c;
+		if (lane == 0) { cnt[256] = 0; cum[256] = 0; }
 	}
 	__syncthreads();
-	uint64_t R = 1ull << 63;   // coder.h:47
+	uint32_t R = 1u << 31;   // coder.h:47 with b = 32
 	uint32_t S = 0;
+	const uint64_t earlier = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 	for (uint32_t base = 0; base < jb.n; base += 64) {
 		const uint32_t j = base + lane;
 		const bool valid = j < jb.n;
 		const uint32_t nb = min(64u, jb.n - base);
-		uint32_t s = valid ? jb.sym[j] : 0x100u;
-		uint32_t l = valid ? cum[s] : 0, c = valid ? cnt[s] : 0;
-		for (uint32_t i = 0; i < nb; ++i) {
-			uint32_t si = (uint32_t)__builtin_amdgcn_readlane(s, i);
-			if ((int)i < lane) { l += si < s ? 1u : 0u; c += si == s ? 1u : 0u; }
+		const uint32_t s = valid ? jb.sym[j] : 0x100u;   // the marker is larger than every symbol: never counted below a valid lane
+		// lanes of the batch with a smaller / an equal symbol, bit by bit from the top
+		uint64_t eq = ~0ull, lt = 0;
+#pragma unroll
+		for (int b = 8; b >= 0; --b) {
+			const bool mine = (s >> b) & 1u;
+			const uint64_t m = __ballot(mine);
+			lt |= mine ? (eq & ~m) : 0ull;
+			eq &= mine ? m : ~m;
 		}
+		const uint32_t l = cum[s] + (uint32_t)__popcll(lt & earlier), c = cnt[s] + (uint32_t)__popcll(eq & earlier);
 		// per-symbol constants of the recurrence
-		uint32_t t = jb.t0 + j;
-		bool sub = valid && (l + c == t);
-		bool noop = !valid || (sub && l == 0);
+		const uint32_t t = jb.t0 + j;
+		const bool sub = l + c == t;   // the last symbol with a non-zero count: R' = R - r l (coder.h:74-77)
 		MagicEnt me = valid ? magic[t] : MagicEnt{ 0, 0, 0 };
-		uint32_t mlo = (uint32_t)me.magic, mhi = (uint32_t)(me.magic >> 32), mx = sub ? l : c;
-		uint32_t mm = me.shift | (sub ? kMetaSub : 0u) | (noop ? kMetaNoop : 0u);
-		// serial recurrence over the batch (arith/coder.h:69-91 without the low register)
-		uint64_t my_r = 0;
-		uint32_t my_s = 0;
+		const uint32_t mx = valid ? (sub ? l : c) : 0u;
+		const uint32_t mm = ((me.shift >> kMagicSh32Shift) & 31u) | (sub || !valid ? 0x80u : 0u);
+		// serial recurrence over the batch (coder.h:69-91 without the low register), uniform: lives in scalar registers
+		uint32_t my_r = 0, my_s = 0;
 		const uint32_t s_first = S;
 		for (uint32_t i = 0; i < nb; ++i) {
-			uint32_t meta = (uint32_t)__builtin_amdgcn_readlane(mm, i);
-			uint64_t r = 0;
-			uint32_t s_before = S;
-			if (!(meta & kMetaNoop)) {
-				uint64_t mg = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, i) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, i);
-				uint32_t x = (uint32_t)__builtin_amdgcn_readlane(mx, i);
-				r = cm::div_by_magic(R, mg, meta & 63u);
-				uint64_t prod = r * x;
-				uint64_t Rn = (meta & kMetaSub) ? R - prod : prod;
-				uint64_t y = Rn - 1;
-				uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
-				R = Rn << sh;
-				S += sh;
-			}
-			if (lane == (int)i) { my_r = r; my_s = s_before; }
+			const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)me.m32, (int)i);
+			const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)mx, (int)i);
+			const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)mm, (int)i);
+			const uint32_t r = __umulhi(R, M) >> (meta & 31u);
+			const uint32_t prod = r * x;
+			const uint32_t Rn = (meta & 0x80u) ? R - prod : prod;
+			const uint32_t y = Rn - 1u;
+			const uint32_t sh = y ? (uint32_t)__builtin_clz(y) - 1u : 31u;
+			my_r = lane == (int)i ? r : my_r;
+			my_s = lane == (int)i ? S : my_s;
+			R = Rn << sh;
+			S += sh;
 		}
-		// low register: L += r * l at bit position my_s (coder.h:71), gathered in an LDS window first
-		const uint32_t w0 = s_first >> 5, span = ((S + 95) >> 5) - w0 + 1;
-		uint64_t a = (valid && l) ? my_r * l : 0;
-		uint32_t w = my_s >> 5, shb = my_s & 31;
-		uint64_t hi = a >> (32 + shb), low = a << (32 - shb);
-		uint32_t mid = (uint32_t)(low >> 32), lo = (uint32_t)low;
+		// low register: L += r * l at bit position my_s (coder.h:71); r l <= R fits 32 bits
+		const uint32_t w0 = s_first >> 5, span = ((S + 63) >> 5) - w0 + 1;   // <= 64 words
+		const uint32_t a = (valid && l) ? my_r * l : 0u;
+		const uint32_t w = my_s >> 5, shb = my_s & 31;
+		const uint32_t hi = a >> shb, lo = shb ? a << (32 - shb) : 0u;
 		unsigned long long *dst = acc + jb.word_base;
-		if (span <= (uint32_t)kWin) {
-			for (uint32_t k = lane; k < span; k += 64) win[k] = 0;
-			bh[4 * lane] = 0; bh[4 * lane + 1] = 0; bh[4 * lane + 2] = 0; bh[4 * lane + 3] = 0;
-			__syncthreads();
-			if (a) {
-				if (hi) atomicAdd(&win[w - w0], (unsigned long long)hi);
-				if (mid) atomicAdd(&win[w - w0 + 1], (unsigned long long)mid);
-				if (lo) atomicAdd(&win[w - w0 + 2], (unsigned long long)lo);
-			}
-			if (valid) atomicAdd(&bh[s], 1u);
-			__syncthreads();
-			for (uint32_t k = lane; k < span; k += 64) {
-				unsigned long long v = win[k];
-				if (v) atomicAdd(&dst[w0 + k], v);
-			}
-		} else {
-			bh[4 * lane] = 0; bh[4 * lane + 1] = 0; bh[4 * lane + 2] = 0; bh[4 * lane + 3] = 0;
-			__syncthreads();
-			if (a) {
-				if (hi) atomicAdd(&dst[w], (unsigned long long)hi);
-				if (mid) atomicAdd(&dst[w + 1], (unsigned long long)mid);
-				if (lo) atomicAdd(&dst[w + 2], (unsigned long long)lo);
-			}
-			if (valid) atomicAdd(&bh[s], 1u);
-			__syncthreads();
+		for (uint32_t k = lane; k < span; k += 64) win[k] = 0;
+		bh[4 * lane] = 0; bh[4 * lane + 1] = 0; bh[4 * lane + 2] = 0; bh[4 * lane + 3] = 0;
+		__syncthreads();
+		if (hi) atomicAdd(&win[w - w0], (unsigned long long)hi);
+		if (lo) atomicAdd(&win[w - w0 + 1], (unsigned long long)lo);
+		if (valid) atomicAdd(&bh[s], 1u);
+		__syncthreads();
+		for (uint32_t k = lane; k < span; k += 64) {
+			unsigned long long v = win[k];
+			if (v) atomicAdd(&dst[w0 + k], v);
 		}
 		// adaptive update of the tables by the whole batch (stat_adaptive.h:77-82)
 		uint32_t a0 = bh[4 * lane], a1 = bh[4 * lane + 1], a2 = bh[4 * lane + 2], a3 = bh[4 * lane + 3], tot;
@@ -126,7 +124,7 @@ __global__ __launch_bounds__(64) void k_chunk_encode(const StreamJob *jobs, cons
 		cum[4 * lane] += ex; cum[4 * lane + 1] += ex + a0; cum[4 * lane + 2] += ex + a0 + a1; cum[4 * lane + 3] += ex + a0 + a1 + a2;
 		__syncthreads();
 	}
-	if (lane == 0) stream_bits[blockIdx.x] = S + 64;   // flush: the 64 bits of the low register (coder.h:58-67)
+	if (lane == 0) stream_bits[blockIdx.x] = S + 32;   // flush: the 32 bits of the low register (coder.h:58-67)
 }
 
 // byte length of every stream and exclusive prefix (one workgroup; wave scans + LDS for the wave totals)
@@ -174,21 +172,14 @@ __global__ __launch_bounds__(256) void k_scatter_u8(const uint8_t *src, const ui
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// decode: coder.h:124-162 + stat_adaptive.h:55-72.  target = min(t - 1, D / r) and the Fenwick descent are
-// replaced by their definition: the symbol is the number of table entries whose inclusive cumulative count I
-// satisfies I <= target  <=>  I * r <= D and I < t.  Each lane holds 4 consecutive entries.
+// decode: arith::Decoder<uint32_t> (coder.h:115-162) + stat_adaptive.h:55-72.  target = min(t - 1, D / r) and the Fenwick
+// descent are replaced by their definition: the symbol is the number of table entries whose inclusive cumulative count I
+// satisfies I <= target  <=>  I * r <= D and I < t.  Each lane holds 4 consecutive entries in registers; I * r <= R <= 2^31
+// never overflows.  Entries with I == t are exactly those from the last symbol with a non-zero count on (a count never
+// becomes non-zero later), so "and I < t" is a clamp to that symbol, fixed per stream.  The stream's bits reach the
+// wavefront 2048 at a time: lane k holds big-endian word k of the window that starts at the batch's byte position (a batch
+// consumes at most 64 x 31 bits), and the bits a renormalisation shifts in are cut out of two neighbouring words.
 // ---------------------------------------------------------------------------------------------------------
-struct BitFeed {
-	const uint8_t *p;
-	uint32_t nbytes, pos;   // pos = next byte
-	__device__ __forceinline__ uint64_t take64()   // next 8 bytes, big-endian, 0xFF past the end (bitstream.h:27)
-	{
-		uint64_t v = 0;
-		for (int k = 0; k < 8; ++k) { uint32_t b = pos < nbytes ? p[pos] : 0xffu; ++pos; v = (v << 8) | b; }
-		return v;
-	}
-};
-
 __global__ __launch_bounds__(64) void k_chunk_decode(const StreamJob *jobs, const uint32_t *inits, const MagicEnt *magic,
                                                      const uint8_t *payload, const unsigned long long *offsets, const uint32_t *nbytes, uint8_t *sym_out_base)
 {
@@ -196,64 +187,74 @@ __global__ __launch_bounds__(64) void k_chunk_decode(const StreamJob *jobs, cons
 	const int lane = threadIdx.x;
 	uint8_t *out = const_cast<uint8_t*>(jb.sym);
 	(void)sym_out_base;
-	// inclusive cumulative counts and counts of entries 4*lane .. 4*lane+3
-	uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+	// inclusive cumulative counts of entries 4*lane .. 4*lane+3
+	uint32_t i0, i1, i2, i3, sym_last;
 	{
 		const uint32_t *st = inits + (size_t)jb.init * 256 + 4 * lane;
-		c0 = st[0]; c1 = st[1]; c2 = st[2]; c3 = st[3];
+		const uint32_t c0 = st[0], c1 = st[1], c2 = st[2], c3 = st[3];
 		uint32_t tot, ex = wscan_excl(c0 + c1 + c2 + c3, tot);
 		i0 = ex + c0; i1 = i0 + c1; i2 = i1 + c2; i3 = i2 + c3;
+		const uint32_t top = c3 ? 4 * lane + 3 : c2 ? 4 * lane + 2 : c1 ? 4 * lane + 1 : c0 ? 4 * lane : 0u;
+		uint32_t mx = top;   // largest symbol with a non-zero count
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+		sym_last = mx;
 	}
-	BitFeed bf{ payload + offsets[blockIdx.x], nbytes[blockIdx.x], 0 };
-	uint64_t D = bf.take64();          // coder.h:124-129
-	uint64_t buf = bf.take64();        // look-ahead bits, consumed from the top
-	uint32_t buf_bits = 64;
-	uint64_t R = 1ull << 63;
+	const uint8_t *src = payload + offsets[blockIdx.x];
+	const uint32_t nby = nbytes[blockIdx.x];
+	auto byte_at = [&](uint32_t k) -> uint32_t { return k < nby ? src[k] : 0xffu; };   // reads past the end give 0xFF (bitstream.h:27)
+	uint32_t D = (byte_at(0) << 24) | (byte_at(1) << 16) | (byte_at(2) << 8) | byte_at(3);   // coder.h:124-129
+	D = (uint32_t)__builtin_amdgcn_readfirstlane((int)D);
+	uint32_t pos = 32;   // stream bits consumed so far
+	uint32_t R = 1u << 31;
 	for (uint32_t base = 0; base < jb.n; base += 64) {
 		const uint32_t nb = min(64u, jb.n - base);
 		// reciprocals of the totals of the next 64 symbols: t is known in advance (t0 + position)
-		MagicEnt me = base + lane < jb.n ? magic[jb.t0 + base + lane] : MagicEnt{ 0, 0, 0 };
-		const uint32_t mlo = (uint32_t)me.magic, mhi = (uint32_t)(me.magic >> 32), msh = me.shift;
+		const MagicEnt me = base + lane < jb.n ? magic[jb.t0 + base + lane] : MagicEnt{ 0, 0, 0 };
+		const uint32_t msh = (me.shift >> kMagicSh32Shift) & 31u;
+		// bit window of this batch
+		const uint32_t wbyte = pos >> 3;
+		const uint32_t kb = wbyte + 4 * lane;
+		uint32_t wword;
+		if (kb + 4 <= nby) { uint32_t raw; __builtin_memcpy(&raw, src + kb, 4); wword = __builtin_bswap32(raw); }
+		else wword = (byte_at(kb) << 24) | (byte_at(kb + 1) << 16) | (byte_at(kb + 2) << 8) | byte_at(kb + 3);
+		uint32_t wo = pos & 7u;   // bit offset of the next unread bit inside the window
 		uint32_t mysym = 0;
 		for (uint32_t i = 0; i < nb; ++i) {
 			const uint32_t t = jb.t0 + base + i;
-			uint64_t mg = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, i) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, i);
-			uint32_t shf = (uint32_t)__builtin_amdgcn_readlane(msh, i);
-			uint64_t r = t >= 2 ? cm::div_by_magic(R, mg, shf) : R;
-			// symbol = #{ entries : I * r <= D and I < t }; I * r cannot overflow: I < t, r = floor(R / t) => I * r < R <= 2^63
-			bool b0 = i0 < t && (uint64_t)i0 * r <= D, b1 = i1 < t && (uint64_t)i1 * r <= D, b2 = i2 < t && (uint64_t)i2 * r <= D, b3 = i3 < t && (uint64_t)i3 * r <= D;
-			uint32_t below = (b0 ? 1u : 0u) + (b1 ? 1u : 0u) + (b2 ? 1u : 0u) + (b3 ? 1u : 0u);
-			uint64_t full = __ballot(below == 4);
-			uint32_t lanes_full = (uint32_t)__popcll(full);          // entries are non-decreasing: full lanes form a prefix
-			uint32_t part = (uint32_t)__builtin_amdgcn_readlane(below, lanes_full < 64 ? lanes_full : 63);
-			uint32_t s = lanes_full < 64 ? lanes_full * 4 + part : 255u;
-			// l = inclusive count of entry s-1, h = inclusive count of entry s
-			uint32_t src_lane = s >> 2, k = s & 3;
-			uint32_t incl = k == 0 ? i0 : k == 1 ? i1 : k == 2 ? i2 : i3;
-			uint32_t cn = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
-			uint32_t h = (uint32_t)__builtin_amdgcn_readlane(incl, src_lane);
-			uint32_t l = h - (uint32_t)__builtin_amdgcn_readlane(cn, src_lane);
+			const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)me.m32, (int)i);
+			const uint32_t shf = (uint32_t)__builtin_amdgcn_readlane((int)msh, (int)i);
+			const uint32_t r = __umulhi(R, M) >> shf;
+			// symbol = min(#{ entries : I * r <= D }, last symbol with a non-zero count)
+			const uint64_t b0 = __ballot(i0 * r <= D), b1 = __ballot(i1 * r <= D), b2 = __ballot(i2 * r <= D), b3 = __ballot(i3 * r <= D);
+			const uint32_t below = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+			const uint32_t s = min(below, sym_last);
+			// l = inclusive count of entry s - 1, h = inclusive count of entry s
+			const uint32_t ls = s >> 2, k = s & 3u;
+			const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, (int)ls), e1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, (int)ls);
+			const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)i2, (int)ls), e3 = (uint32_t)__builtin_amdgcn_readlane((int)i3, (int)ls);
+			const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)i3, (int)(ls ? ls - 1 : 0));
+			const uint32_t h = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
+			const uint32_t l = k == 0 ? (ls ? pv : 0u) : k == 1 ? e0 : k == 2 ? e1 : e2;
 			// coder.h:140-153
-			D -= r * l;
-			uint64_t Rn = h < t ? r * (uint64_t)(h - l) : R - r * l;
-			uint64_t y = Rn - 1;
-			uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
+			const uint32_t rl = r * l;
+			const uint32_t Rn = h < t ? r * (h - l) : R - rl;
+			const uint32_t y = Rn - 1u;
+			const uint32_t sh = y ? (uint32_t)__builtin_clz(y) - 1u : 31u;
 			R = Rn << sh;
-			uint32_t take = sh;
-			while (take) {   // shift in the next bits of the stream
-				if (buf_bits == 0) { buf = bf.take64(); buf_bits = 64; }
-				uint32_t n = take < buf_bits ? take : buf_bits;
-				D = n == 64 ? buf : (D << n) | (buf >> (64 - n));
-				buf = n == 64 ? 0 : buf << n;
-				buf_bits -= n;
-				take -= n;
-			}
-			// adaptive update (stat_adaptive.h:77-82): count of s, inclusive counts of every entry >= s
+			// shift in the next sh bits of the stream
+			const uint32_t wk = wo >> 5, wb = wo & 31u;
+			const uint64_t two = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wword, (int)wk) << 32) |
+			                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wword, (int)min(wk + 1u, 63u));
+			const uint32_t bits = (uint32_t)(((two << wb) >> 1) >> (63u - sh));
+			D = ((D - rl) << sh) | bits;
+			wo += sh;
+			// adaptive update (stat_adaptive.h:77-82): inclusive counts of every entry >= s
 			const uint32_t e = 4 * lane;
-			c0 += (e == s); c1 += (e + 1 == s); c2 += (e + 2 == s); c3 += (e + 3 == s);
 			i0 += (e >= s); i1 += (e + 1 >= s); i2 += (e + 2 >= s); i3 += (e + 3 >= s);
-			if (lane == (int)i) mysym = s;
+			mysym = lane == (int)i ? s : mysym;
 		}
+		pos = 8 * wbyte + wo;
 		if (base + lane < jb.n) out[base + lane] = (uint8_t)mysym;
 	}
 }

@@ -163,5 +163,28 @@ HRY_HD void make_magic(uint32_t t, uint64_t &magic, uint32_t &shift)
 	shift = k;
 }
 
+// ---- the same for 32-bit coder registers (arith::Encoder<uint32_t>, the streams of the chunked container) ----
+// r = floor(R / t) == mulhi32(R, m) >> sh for every R <= 2^31 and 2 <= t < 2^31:
+//   t not a power of two: s = floor(log2 t), m = floor(2^(32+s) / t) + 1 = 2^(32+s)/t + e with 0 < e <= 1; the product
+//   overshoots R/t by R e / 2^(32+s) < 1/t because R <= 2^31 < 2^(32+s)/t, so the floor is unchanged;
+//   t = 2^s: m = 2^31 is the exact reciprocal at shift s - 1.
+// t == 1 gets m = 0 (r = 0): the only codable symbol then has l = 0 and h = t, for which r is never used.
+HRY_HD void make_magic32(uint32_t t, uint32_t &m, uint32_t &sh)
+{
+	if (t < 2) { m = 0; sh = 0; return; }
+	uint32_t s = 31u - (uint32_t)__builtin_clz(t);
+	if ((t & (t - 1)) == 0) { m = 1u << 31; sh = s - 1; return; }
+	m = (uint32_t)((1ull << (32 + s)) / t) + 1u;
+	sh = s;
+}
+HRY_HD uint32_t div_by_magic32(uint32_t n, uint32_t m, uint32_t sh)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	return __umulhi(n, m) >> sh;
+#else
+	return (uint32_t)(((uint64_t)n * m) >> 32) >> sh;
+#endif
+}
+
 }   // namespace cm
 }   // namespace hry

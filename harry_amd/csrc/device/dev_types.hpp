@@ -32,7 +32,10 @@ struct alignas(16) SymRec {
 };
 constexpr uint32_t kMetaSub = 1u << 6, kMetaNoop = 1u << 7;
 
-struct alignas(16) MagicEnt { uint64_t magic; uint32_t shift; uint32_t pad; };
+// reciprocals of a context total t: 65-bit magic + shift for 64-bit coder registers (reference stream), and m32 / sh32
+// (cm::make_magic32) for the 32-bit registers of the chunked container's streams
+struct alignas(16) MagicEnt { uint64_t magic; uint32_t shift; uint32_t m32; };
+constexpr uint32_t kMagicSh32Shift = 8;   // MagicEnt::shift bits 8..15 hold sh32
 
 // a byte plane whose adaptive model is evaluated by counting
 struct PlaneJob {

@@ -327,6 +327,9 @@ __global__ __launch_bounds__(256) void k_magic_table(MagicEnt *tab, uint32_t fro
 	if (t >= to) return;
 	MagicEnt m{ 0, 0, 0 };
 	if (t >= 2) cm::make_magic(t, m.magic, m.shift);
+	uint32_t sh32 = 0;
+	cm::make_magic32(t, m.m32, sh32);
+	m.shift |= sh32 << kMagicSh32Shift;
 	tab[t] = m;
 }
 
@@ -338,7 +341,7 @@ __device__ __forceinline__ void emit_symbol(SymRec *rec, uint32_t *sym_l, const 
 	SymRec r;
 	r.magic = m.magic;
 	r.x = sub ? l : c;
-	r.meta = m.shift | (sub ? kMetaSub : 0u) | (noop ? kMetaNoop : 0u);
+	r.meta = (m.shift & 63u) | (sub ? kMetaSub : 0u) | (noop ? kMetaNoop : 0u);
 	rec[g] = r;
 	sym_l[g] = l;
 }

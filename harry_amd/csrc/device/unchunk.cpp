@@ -139,7 +139,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	memcpy(&CH, p + off, 4); memcpy(&CHC, p + off + 4, 4); memcpy(&np, p + off + 8, 4);
 	off += 12;
 	const uint32_t expect_planes = (uint32_t)(kConnPlanes + ldv.nplanes + ldf.nplanes);
-	if (CH == 0 || CHC == 0 || np != expect_planes) throw Error(HRY_E_FORMAT, "chunked directory does not match the header");
+	if (CH == 0 || CHC == 0 || CH > (1u << 20) || CHC > CH || np != expect_planes) throw Error(HRY_E_FORMAT, "chunked directory does not match the header");
 	need(off, 4ull * np);
 	std::vector<uint32_t> nsym(np);
 	memcpy(nsym.data(), p + off, 4ull * np);

@@ -312,63 +312,72 @@ struct BitSource {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Moffat-Neal-Witten range coder, 64-bit registers (arith/coder.h:27-172)
+// Moffat-Neal-Witten range coder (arith/coder.h:27-172), templated on the register type like the reference's
+// arith::Encoder<TF> / arith::Decoder<TF>: 64-bit registers for the reference stream (the default instantiation,
+// which formats/hry uses), 32-bit registers for the streams of the chunked container.
 // ------------------------------------------------------------------------------------------------
-static const uint64_t C_HALF = 1ull << 63, C_QUARTER = 1ull << 62;
-
-struct RangeEncoder {
-	uint64_t low = 0, range = C_HALF, pending = 0;
+template <typename TF> struct RangeEncoderT {
+	static constexpr int B = (int)sizeof(TF) * 8;
+	static constexpr TF HALF = TF(1) << (B - 1), QUARTER = TF(1) << (B - 2);
+	TF low = 0, range = HALF;
+	uint64_t pending = 0;
 	BitSink sink;
 	bool done = false;
-	explicit RangeEncoder(std::vector<uint8_t> &o) : sink(o) {}
+	explicit RangeEncoderT(std::vector<uint8_t> &o) : sink(o) {}
 	void emit(unsigned b)   // coder.h:105-112 bit-plus-follow
 	{
 		sink.put(b);
 		for (; pending > 0; --pending) sink.put(!b);
 	}
-	void encode(uint64_t l, uint64_t h, uint64_t t)   // coder.h:69-91
+	void encode(TF l, TF h, TF t)   // coder.h:69-91
 	{
-		uint64_t r = range / t;
-		low += r * l;
-		range = h < t ? r * (h - l) : range - r * l;
-		while (range <= C_QUARTER) {
-			if (low <= C_HALF && low + range <= C_HALF) emit(0);
-			else if (low >= C_HALF) { emit(1); low -= C_HALF; }
-			else { ++pending; low -= C_QUARTER; }
-			low <<= 1;
-			range <<= 1;
+		TF r = range / t;
+		low = (TF)(low + r * l);
+		range = h < t ? (TF)(r * (h - l)) : (TF)(range - r * l);
+		while (range <= QUARTER) {
+			if (low <= HALF && (TF)(low + range) <= HALF) emit(0);
+			else if (low >= HALF) { emit(1); low -= HALF; }
+			else { ++pending; low -= QUARTER; }
+			low = (TF)(low << 1);
+			range = (TF)(range << 1);
 		}
 	}
-	void finish()   // coder.h:58-67: 64 bits of low, then pad
+	void finish()   // coder.h:58-67: the B bits of low, then pad
 	{
 		if (done) return;
 		done = true;
-		for (int i = 63; i >= 0; --i) emit((unsigned)((low >> i) & 1));
+		for (int i = B - 1; i >= 0; --i) emit((unsigned)((low >> i) & 1));
 		sink.pad();
 	}
 };
-struct RangeDecoder {
-	uint64_t range = C_HALF, value = 0, r = 0;
+template <typename TF> struct RangeDecoderT {
+	static constexpr int B = (int)sizeof(TF) * 8;
+	static constexpr TF HALF = TF(1) << (B - 1), QUARTER = TF(1) << (B - 2);
+	TF range = HALF, value = 0, r = 0;
 	BitSource src;
-	RangeDecoder(const uint8_t *b, const uint8_t *e) : src(b, e)
+	RangeDecoderT(const uint8_t *b, const uint8_t *e) : src(b, e)
 	{
-		for (int i = 0; i < 64; ++i) value = 2 * value + src.get();   // coder.h:124-129
+		for (int i = 0; i < B; ++i) value = (TF)(2 * value + src.get());   // coder.h:124-129
 	}
-	uint64_t target(uint64_t t)   // coder.h:134-138
+	TF target(TF t)   // coder.h:134-138
 	{
 		r = range / t;
-		return std::min(t - 1, value / r);
+		return std::min<TF>(t - 1, value / r);
 	}
-	void consume(uint64_t l, uint64_t h, uint64_t t)   // coder.h:140-153
+	void consume(TF l, TF h, TF t)   // coder.h:140-153
 	{
-		value -= r * l;
-		range = h < t ? r * (h - l) : range - r * l;
-		while (range <= C_QUARTER) {
-			range <<= 1;
-			value = 2 * value + src.get();
+		value = (TF)(value - r * l);
+		range = h < t ? (TF)(r * (h - l)) : (TF)(range - r * l);
+		while (range <= QUARTER) {
+			range = (TF)(range << 1);
+			value = (TF)(2 * value + src.get());
 		}
 	}
 };
+typedef RangeEncoderT<uint64_t> RangeEncoder;
+typedef RangeDecoderT<uint64_t> RangeDecoder;
+typedef RangeEncoderT<uint32_t> ChunkEncoder;   // arith::Encoder<uint32_t>
+typedef RangeDecoderT<uint32_t> ChunkDecoder;   // arith::Decoder<uint32_t>
 
 // ------------------------------------------------------------------------------------------------
 // adaptive frequency table: raw counts + Fenwick tree (arith/stat_adaptive.h:26-126)
@@ -1344,8 +1353,10 @@ static Mesh *decode(const uint8_t *p, size_t n)
 // ------------------------------------------------------------------------------------------------
 // chunked profile (.hry v0.2, this implementation's parallel container; NOT a reference format).
 // Same header (minor version 2), same symbols as the v0.1 stream, but every context plane is cut into chunks of
-// `chunk_syms` symbols and every (plane, chunk) is an independent stream: fresh adaptive model + fresh 64-bit
-// coder + 64-bit flush, using exactly the reference's model/coder arithmetic.  Symbols without information are
+// `chunk_syms` symbols and every (plane, chunk) is an independent stream: fresh adaptive model + fresh coder with
+// 32-bit registers (arith::Encoder<uint32_t>: the reference's coder template instantiated on uint32_t) + 32-bit flush,
+// using exactly the reference's model/coder arithmetic.  A chunk holds at most 2^20 symbols, so every total stays far
+// below 2^30 = QUARTER (the coder's requirement) and the interval keeps >= 10 bits of resolution per count.  Symbols without information are
 // not stored: reg_face/reg_vtx (single region), attr_type (always DATA), numtri for single-degree meshes.
 // Operations are split into one plane per order class (models.h:101-105) with a plain adaptive 7-symbol model.
 //   u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols,
@@ -1391,6 +1402,7 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 {
 	check_supported(m);
 	if (chunk_syms == 0) chunk_syms = 32768;
+	chunk_syms = std::min(chunk_syms, 1u << 20);
 	Result *res = new Result();
 	try {
 		write_header(m, res->bytes, 2);
@@ -1448,13 +1460,13 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 			for (size_t first = 0; first < sy.size(); first += step) {
 				size_t end = std::min(sy.size(), first + step);
 				std::vector<uint8_t> out;
-				RangeEncoder enc(out);
+				ChunkEncoder enc(out);
 				FreqTable f(256);
 				seed_table(f, pd.init_kind, m);
 				for (size_t j = first; j < end; ++j) {
 					uint64_t l, h, t = f.total();
 					f.range_of(sy[j], l, h);
-					enc.encode(l, h, t);
+					enc.encode((uint32_t)l, (uint32_t)h, (uint32_t)t);
 					f.inc(sy[j]);
 				}
 				enc.finish();
@@ -1495,13 +1507,13 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 			for (size_t first = 0; first < sy.size(); first += step, ++si) {
 				size_t end = std::min(sy.size(), first + step);
 				if ((size_t)(p + n - q) < nbytes[si]) throw std::runtime_error("oracle: truncated chunked stream");
-				RangeDecoder dec(q, q + nbytes[si]);
+				ChunkDecoder dec(q, q + nbytes[si]);
 				FreqTable f(256);
 				seed_table(f, planes[k].init_kind, *m);
 				for (size_t j = first; j < end; ++j) {
 					uint64_t l, h, t = f.total();
-					uint32_t s = f.find(dec.target(t), l, h);
-					dec.consume(l, h, t);
+					uint32_t s = f.find(dec.target((uint32_t)t), l, h);
+					dec.consume((uint32_t)l, (uint32_t)h, (uint32_t)t);
 					f.inc(s);
 					sy[j] = (uint8_t)s;
 				}
@@ -2085,6 +2097,46 @@ size_t ho_kat_range_decode_bytes(const uint8_t *src, size_t nsrc, uint8_t *dst, 
 		dst[i] = (uint8_t)s;
 	}
 	return nsym;
+}
+// the same with the 32-bit instantiation (the streams of the chunked container)
+size_t ho_kat_range_encode_bytes32(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
+{
+	std::vector<uint8_t> out;
+	ho::ChunkEncoder rc(out);
+	ho::FreqTable f(256);
+	for (uint32_t i = 0; i < 256; ++i) f.inc(i);
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t l, h, t = f.total();
+		f.range_of(src[i], l, h);
+		rc.encode((uint32_t)l, (uint32_t)h, (uint32_t)t);
+		f.inc(src[i]);
+	}
+	rc.finish();
+	if (out.size() <= cap) memcpy(dst, out.data(), out.size());
+	return out.size();
+}
+size_t ho_kat_range_decode_bytes32(const uint8_t *src, size_t nsrc, uint8_t *dst, size_t nsym)
+{
+	ho::ChunkDecoder rc(src, src + nsrc);
+	ho::FreqTable f(256);
+	for (uint32_t i = 0; i < 256; ++i) f.inc(i);
+	for (size_t i = 0; i < nsym; ++i) {
+		uint64_t l, h, t = f.total();
+		uint32_t s = f.find(rc.target((uint32_t)t), l, h);
+		rc.consume((uint32_t)l, (uint32_t)h, (uint32_t)t);
+		f.inc(s);
+		dst[i] = (uint8_t)s;
+	}
+	return nsym;
+}
+size_t ho_kat_range_encode_lht32(const uint64_t *lht, size_t n, uint8_t *dst, size_t cap)
+{
+	std::vector<uint8_t> out;
+	ho::ChunkEncoder rc(out);
+	for (size_t i = 0; i < n; ++i) rc.encode((uint32_t)lht[3 * i], (uint32_t)lht[3 * i + 1], (uint32_t)lht[3 * i + 2]);
+	rc.finish();
+	if (out.size() <= cap) memcpy(dst, out.data(), out.size());
+	return out.size();
 }
 size_t ho_kat_range_encode_lht(const uint64_t *lht, size_t n, uint8_t *dst, size_t cap)
 {

@@ -80,6 +80,9 @@ def lib():
     L.ho_kat_range_encode_bytes.restype = sz; L.ho_kat_range_encode_bytes.argtypes = [C.c_char_p, sz, C.c_char_p, sz]
     L.ho_kat_range_decode_bytes.restype = sz; L.ho_kat_range_decode_bytes.argtypes = [C.c_char_p, sz, C.c_char_p, sz]
     L.ho_kat_range_encode_lht.restype = sz; L.ho_kat_range_encode_lht.argtypes = [C.POINTER(C.c_uint64), sz, C.c_char_p, sz]
+    L.ho_kat_range_encode_bytes32.restype = sz; L.ho_kat_range_encode_bytes32.argtypes = [C.c_char_p, sz, C.c_char_p, sz]
+    L.ho_kat_range_decode_bytes32.restype = sz; L.ho_kat_range_decode_bytes32.argtypes = [C.c_char_p, sz, C.c_char_p, sz]
+    L.ho_kat_range_encode_lht32.restype = sz; L.ho_kat_range_encode_lht32.argtypes = [C.POINTER(C.c_uint64), sz, C.c_char_p, sz]
     _lib = L
     return L
 
@@ -247,22 +250,26 @@ def encode_ply(ply: bytes, quant=(), clear=False, trace=False):
     return m, m.encode(trace)
 
 
-def range_encode_bytes(data: bytes) -> bytes:
+def range_encode_bytes(data: bytes, bits: int = 64) -> bytes:
+    """adaptive 256-ary model + range coder with `bits`-bit registers (64: the reference stream, 32: chunked container)"""
     cap = len(data) * 2 + 64
     buf = C.create_string_buffer(cap)
-    n = lib().ho_kat_range_encode_bytes(data, len(data), buf, cap)
+    f = lib().ho_kat_range_encode_bytes if bits == 64 else lib().ho_kat_range_encode_bytes32
+    n = f(data, len(data), buf, cap)
     return buf.raw[:n]
 
 
-def range_decode_bytes(code: bytes, nsym: int) -> bytes:
+def range_decode_bytes(code: bytes, nsym: int, bits: int = 64) -> bytes:
     buf = C.create_string_buffer(max(nsym, 1))
-    lib().ho_kat_range_decode_bytes(code, len(code), buf, nsym)
+    f = lib().ho_kat_range_decode_bytes if bits == 64 else lib().ho_kat_range_decode_bytes32
+    f(code, len(code), buf, nsym)
     return buf.raw[:nsym]
 
 
-def range_encode_lht(lht: np.ndarray) -> bytes:
+def range_encode_lht(lht: np.ndarray, bits: int = 64) -> bytes:
     lht = np.ascontiguousarray(lht, dtype=np.uint64).reshape(-1, 3)
     cap = len(lht) * 9 + 64
     buf = C.create_string_buffer(cap)
-    n = lib().ho_kat_range_encode_lht(lht.ctypes.data_as(C.POINTER(C.c_uint64)), len(lht), buf, cap)
+    f = lib().ho_kat_range_encode_lht if bits == 64 else lib().ho_kat_range_encode_lht32
+    n = f(lht.ctypes.data_as(C.POINTER(C.c_uint64)), len(lht), buf, cap)
     return buf.raw[:n]

@@ -127,6 +127,47 @@ int main()
 		for (size_t i = 0; i < tr.size(); ++i) printf("%llu%s", (unsigned long long)tr[i], i + 1 < tr.size() ? "," : "");
 		printf("], \"%s\"]%s\n", hex(os.str()).c_str(), k < 5 ? "," : "");
 	}
+	printf(" ],\n \"range_bytes32\": [\n");
+	// the same coder and model templates instantiated with 32-bit registers (arith::Encoder<uint32_t>): what every stream of
+	// the chunked container uses
+	{ std::string s; for (int i = 0; i < 40000; ++i) s += (char)(rng() % 5 == 0 ? rng() % 256 : rng() % 3); strs.push_back(s); }
+	for (size_t k = 0; k < strs.size(); ++k) {
+		std::ostringstream os;
+		{
+			arith::Encoder<uint32_t> coder(os);
+			arith::ModelMult<uint8_t, arith::AdaptiveStatisticsModule<uint32_t>, uint32_t> model;
+			for (unsigned char c : strs[k]) model.encode<uint8_t>(coder, c);
+			coder.flush();
+		}
+		// the decoder of the same instantiation must invert it (checked here so that the fixture is known to be decodable)
+		{
+			std::istringstream is(os.str());
+			arith::Decoder<uint32_t> dec(is);
+			arith::ModelMult<uint8_t, arith::AdaptiveStatisticsModule<uint32_t>, uint32_t> model;
+			for (unsigned char c : strs[k]) if (model.decode<uint8_t>(dec) != c) { fprintf(stderr, "32-bit coder does not round-trip\n"); return 1; }
+		}
+		printf("  [\"%s\", \"%s\"]%s\n", hex(strs[k]).c_str(), hex(os.str()).c_str(), k + 1 < strs.size() ? "," : "");
+	}
+	printf(" ],\n \"range_lht32\": [\n");
+	for (int k = 0; k < 6; ++k) {
+		std::ostringstream os;
+		std::vector<uint64_t> tr;
+		{
+			arith::Encoder<uint32_t> coder(os);
+			int n = 50 + 200 * k;
+			for (int i = 0; i < n; ++i) {
+				uint32_t t = k == 0 ? 2 : (k == 1 ? (1u << 30) - 5 : 1 + (uint32_t)(rng() % (1ull << (4 + 4 * k))));
+				uint32_t l = (uint32_t)(rng() % t), h = l + 1 + (uint32_t)(rng() % (t - l));
+				if (i % 5 == 0) h = t;
+				coder(l, h, t);
+				tr.push_back(l); tr.push_back(h); tr.push_back(t);
+			}
+			coder.flush();
+		}
+		printf("  [[");
+		for (size_t i = 0; i < tr.size(); ++i) printf("%llu%s", (unsigned long long)tr[i], i + 1 < tr.size() ? "," : "");
+		printf("], \"%s\"]%s\n", hex(os.str()).c_str(), k < 5 ? "," : "");
+	}
 	printf(" ]\n}\n");
 	return 0;
 }

@@ -151,6 +151,17 @@ def test_kat_range_coder(kat):
         assert op.range_encode_lht(np.array(triples, dtype=np.uint64)) == bytes.fromhex(code)
 
 
+def test_kat_range_coder_32bit_registers(kat):
+    """arith::Encoder<uint32_t> / Decoder<uint32_t> of the reference (the instantiation every stream of the chunked
+    container uses): outputs produced by the reference's own headers (oracle/ref_kat.cc)."""
+    for src, code in kat["range_bytes32"]:
+        s, c = bytes.fromhex(src), bytes.fromhex(code)
+        assert op.range_encode_bytes(s, bits=32) == c
+        assert op.range_decode_bytes(c, len(s), bits=32) == s
+    for triples, code in kat["range_lht32"]:
+        assert op.range_encode_lht(np.array(triples, dtype=np.uint64), bits=32) == bytes.fromhex(code)
+
+
 # ---------------------------------------------------------------- live reference (where its binary exists)
 @pytest.mark.skipif(not os.path.exists(util.REF_BIN), reason="reference binary not built (oracle/_ref)")
 @pytest.mark.parametrize("seed", range(4))
