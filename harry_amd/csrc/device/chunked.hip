@@ -12,6 +12,8 @@
 //                    symbol search by wave-wide compare + ballot (no division by the data-dependent r)
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "codec_math.hpp"
 #include "dev_types.hpp"
 #include "kernels.hpp"
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64) void k_chunk_decode(const StreamJob *jobs, cons
 		uint32_t mx = top;   // largest symbol with a non-zero count
 #pragma unroll
 		for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-		sym_last = mx;
+		sym_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
 	}
 	const uint8_t *src = payload + offsets[blockIdx.x];
 	const uint32_t nby = nbytes[blockIdx.x];
@@ -220,46 +222,66 @@ __global__ __launch_bounds__(64) void k_chunk_decode(const StreamJob *jobs, cons
 		else wword = (byte_at(kb) << 24) | (byte_at(kb + 1) << 16) | (byte_at(kb + 2) << 8) | byte_at(kb + 3);
 		uint32_t wo = pos & 7u;   // bit offset of the next unread bit inside the window
 		uint32_t mysym = 0;
-		for (uint32_t i = 0; i < nb; ++i) {
-			const uint32_t t = jb.t0 + base + i;
-			const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)me.m32, (int)i);
-			const uint32_t shf = (uint32_t)__builtin_amdgcn_readlane((int)msh, (int)i);
-			const uint32_t r = __umulhi(R, M) >> shf;
-			// symbol = min(#{ entries : I * r <= D }, last symbol with a non-zero count)
-			const uint64_t b0 = __ballot(i0 * r <= D), b1 = __ballot(i1 * r <= D), b2 = __ballot(i2 * r <= D), b3 = __ballot(i3 * r <= D);
-			const uint32_t below = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-			const uint32_t s = min(below, sym_last);
-			// l = inclusive count of entry s - 1, h = inclusive count of entry s
-			const uint32_t ls = s >> 2, k = s & 3u;
-			const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, (int)ls), e1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, (int)ls);
-			const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)i2, (int)ls), e3 = (uint32_t)__builtin_amdgcn_readlane((int)i3, (int)ls);
-			const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)i3, (int)(ls ? ls - 1 : 0));
-			const uint32_t h = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
-			const uint32_t l = k == 0 ? (ls ? pv : 0u) : k == 1 ? e0 : k == 2 ? e1 : e2;
-			// coder.h:140-153
-			const uint32_t rl = r * l;
-			const uint32_t Rn = h < t ? r * (h - l) : R - rl;
-			const uint32_t y = Rn - 1u;
-			const uint32_t sh = y ? (uint32_t)__builtin_clz(y) - 1u : 31u;
-			R = Rn << sh;
-			// shift in the next sh bits of the stream
-			const uint32_t wk = wo >> 5, wb = wo & 31u;
-			const uint64_t two = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wword, (int)wk) << 32) |
-			                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wword, (int)min(wk + 1u, 63u));
-			const uint32_t bits = (uint32_t)(((two << wb) >> 1) >> (63u - sh));
-			D = ((D - rl) << sh) | bits;
-			wo += sh;
-			// adaptive update (stat_adaptive.h:77-82): inclusive counts of every entry >= s
-			const uint32_t e = 4 * lane;
-			i0 += (e >= s); i1 += (e + 1 >= s); i2 += (e + 2 >= s); i3 += (e + 3 >= s);
-			mysym = lane == (int)i ? s : mysym;
-		}
+		// I * r <= R <= 2^31 always; once t > 128, r = floor(R / t) < 2^24 and I <= t < 2^24: the 24-bit multiplier (full rate)
+		// gives the exact product
+		auto run = [&](auto use24) {
+			for (uint32_t i = 0; i < nb; ++i) {
+				const uint32_t t = jb.t0 + base + i;
+				const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)me.m32, (int)i);
+				const uint32_t shf = (uint32_t)__builtin_amdgcn_readlane((int)msh, (int)i);
+				const uint32_t r = __umulhi(R, M) >> shf;
+				// symbol = min(#{ entries : I * r <= D }, last symbol with a non-zero count)
+				uint32_t p0, p1, p2, p3;
+				if constexpr (decltype(use24)::value) { p0 = __umul24(i0, r); p1 = __umul24(i1, r); p2 = __umul24(i2, r); p3 = __umul24(i3, r); }
+				else { p0 = i0 * r; p1 = i1 * r; p2 = i2 * r; p3 = i3 * r; }
+				const uint64_t b0 = __ballot(p0 <= D), b1 = __ballot(p1 <= D), b2 = __ballot(p2 <= D), b3 = __ballot(p3 <= D);
+				const uint32_t below = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+				const uint32_t s = min(below, sym_last);
+				// r l and r h are the products of the entries s - 1 and s
+				const uint32_t ls = s >> 2, k = s & 3u;
+				const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, (int)ls), e1 = (uint32_t)__builtin_amdgcn_readlane((int)p1, (int)ls);
+				const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)p2, (int)ls), e3 = (uint32_t)__builtin_amdgcn_readlane((int)p3, (int)ls);
+				const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)p3, (int)(ls ? ls - 1 : 0));
+				const uint32_t rh = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
+				const uint32_t rl = k == 0 ? (ls ? pv : 0u) : k == 1 ? e0 : k == 2 ? e1 : e2;
+				// coder.h:140-153; h < t  <=>  s is not the last symbol with a non-zero count
+				const uint32_t Rn = s < sym_last ? rh - rl : R - rl;
+				const uint32_t y = Rn - 1u;
+				const uint32_t sh = y ? (uint32_t)__builtin_clz(y) - 1u : 31u;
+				R = Rn << sh;
+				// shift in the next sh bits of the stream
+				const uint32_t wk = wo >> 5, wb = wo & 31u;
+				const uint64_t two = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wword, (int)wk) << 32) |
+				                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wword, (int)min(wk + 1u, 63u));
+				const uint32_t bits = (uint32_t)(((two << wb) >> 1) >> (63u - sh));
+				D = ((D - rl) << sh) | bits;
+				wo += sh;
+				// adaptive update (stat_adaptive.h:77-82): inclusive counts of every entry >= s
+				const uint32_t e = 4 * lane;
+				i0 += (e >= s); i1 += (e + 1 >= s); i2 += (e + 2 >= s); i3 += (e + 3 >= s);
+				mysym = lane == (int)i ? s : mysym;
+				(void)t;
+			}
+		};
+		if (jb.t0 + base > 128u) run(std::true_type()); else run(std::false_type());
 		pos = 8 * wbyte + wo;
 		if (base + lane < jb.n) out[base + lane] = (uint8_t)mysym;
 	}
 }
 
+// (index, value) pairs -> dst[index] = value (late twin links of the pipelined decode; the pairs are applied in order of
+// appearance only across launches -- inside one list an index occurs at most once per link, later pairs repeat the final value)
+__global__ __launch_bounds__(256) void k_scatter_u32(const uint32_t *pairs, uint32_t n, uint32_t *dst)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[pairs[2 * i]] = pairs[2 * i + 1];
+}
+
 // ---------------------------------------------------------------------------------------------------------
+void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst)
+{
+	if (n) hipLaunchKernelGGL(k_scatter_u32, dim3((n + 255) / 256), dim3(256), 0, st, pairs, n, dst);
+}
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits)
 {
 	if (nstreams) hipLaunchKernelGGL(k_chunk_encode, dim3(nstreams), dim3(64), 0, st, jobs, inits, magic, (unsigned long long*)acc, stream_bits);

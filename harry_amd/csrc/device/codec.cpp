@@ -38,6 +38,8 @@ Context::~Context()
 	if (stream) (void)hipStreamSynchronize(stream);
 	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 	if (stream) (void)hipStreamDestroy(stream);
+	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+	if (h_stage) (void)hipHostFree(h_stage);
 }
 void Context::stage_put(const char *name, const void *dptr, size_t bytes)
 {

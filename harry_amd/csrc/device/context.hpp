@@ -38,6 +38,9 @@ struct DevBuf {
 struct Context {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr;   // uploads and connectivity-only kernels of the pipelined decode (created on first use)
+	void *h_stage = nullptr;         // pinned staging memory for uploads that run next to a busy host thread (copies from
+	size_t h_stage_cap = 0;          // pageable memory make the runtime pin and unpin pages: TLB shootdowns for every thread)
 	hipEvent_t ev[8] = {};
 	hry_timing timing{};
 

@@ -9,6 +9,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <deque>
+#include <thread>
+
+#include "../host/cbm_replay.hpp"
 #include "context.hpp"
 #include "kernels.hpp"
 
@@ -34,6 +38,11 @@ bool unpredict3_wanted(const ListDesc &ld);
 void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand, const void *crec,
                        const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists);
 void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand);
+bool unpredict3_covers(const ListDesc &ld);
+void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t v_begin, uint32_t v_end, uint32_t *cand, uint8_t *ncand, void *crec);
+void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,
+                        const void *crec, const uint8_t *planes, const ListDesc &ld, uint8_t *rec);
+void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst);
 }
 
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
@@ -119,6 +128,217 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
 		cx.stage_put("ncand", d_ncand, nvc);
 		cx.stage_put("cand", d_cand, (size_t)nvc * 24 * 4);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined decode (one large component, no explicitly named vertices, every vertex component quantised): the replay
+// publishes its progress (ReplayLive, cbm_replay.hpp) and a consumer thread keeps the device busy behind it --
+//   stream2: finished faces' origins / twins / offsets -> HBM as they appear, late twin links as patches, then for every
+//            slice of vertices that can no longer change: candidates + chain records (connectivity only);
+//   stream : the reconstruction chain of that slice (k_unpredict3_range), which continues the previous slice's chain.
+// When the replay ends only the last slice is left.  Results are those of the sequential pipeline: the candidates of a
+// complete vertex are final, and the chain is evaluated in the same order with the same arithmetic.
+// ---------------------------------------------------------------------------------------------------------
+struct SliceClock { hipEvent_t a, b; };
+// host -> device through the context's pinned staging buffer (one stream; flush() = everything has left the buffer)
+struct Stager {
+	Context &cx;
+	hipStream_t st;
+	size_t used = 0;
+	Stager(Context &c, hipStream_t s) : cx(c), st(s)
+	{
+		const size_t want = 16u << 20;
+		if (cx.h_stage_cap < want) {
+			if (cx.h_stage) { (void)hipHostFree(cx.h_stage); cx.h_stage = nullptr; cx.h_stage_cap = 0; }
+			HIP_OK(hipHostMalloc(&cx.h_stage, want, hipHostMallocDefault));
+			cx.h_stage_cap = want;
+		}
+	}
+	void flush() { HIP_OK(hipStreamSynchronize(st)); used = 0; }
+	void put(void *dst, const void *src, size_t n)
+	{
+		const uint8_t *s = (const uint8_t*)src;
+		uint8_t *d = (uint8_t*)dst;
+		while (n) {
+			if (used == cx.h_stage_cap) flush();
+			const size_t k = std::min(n, cx.h_stage_cap - used);
+			memcpy((uint8_t*)cx.h_stage + used, s, k);
+			HIP_OK(hipMemcpyAsync(d, (uint8_t*)cx.h_stage + used, k, hipMemcpyHostToDevice, st));
+			used += k; s += k; d += k; n -= k;
+		}
+	}
+};
+static bool pipelined_decode_applicable(const Mesh &m, const std::vector<RestartPoint> &restarts, const std::vector<uint8_t> *conn,
+                                        const ListDesc &ldv, uint32_t vc)
+{
+	if (getenv("HRY_NO_PIPELINE")) return false;
+	int ud = 0;
+	uint32_t min_nv = 1u << 17;
+	if (const char *e = getenv("HRY_PIPELINE_MIN_VERTICES")) min_nv = (uint32_t)strtoul(e, nullptr, 10);
+	return restarts.empty() && conn[7].empty() && m.uniform_degree(ud) && unpredict3_covers(ldv) && vc == m.nv && m.nv >= min_nv && m.declared_ne != 0;
+}
+
+static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t> *conn, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
+                             const ListDesc &ldv, const ListDesc &ldf, std::vector<uint32_t> &order_v)
+{
+	Mesh *m = &mesh;
+	const uint32_t nv = m->nv, nf = m->nf, ne = m->declared_ne;
+	if (!cx.stream2) HIP_OK(hipStreamCreateWithFlags(&cx.stream2, hipStreamNonBlocking));
+	// device arrays at their final size; records start as zeros (host records are zero-filled by the header reader)
+	for (int l = 0; l < 2; ++l) {
+		cx.d_rec[l].ensure(std::max<size_t>(m->lists[l].data.size(), 16));
+		if (!m->lists[l].data.empty()) HIP_OK(hipMemsetAsync(cx.d_rec[l].p, 0, m->lists[l].data.size(), cx.stream2));
+	}
+	cx.d_org.ensure(std::max<size_t>((size_t)ne * 4, 16));
+	cx.d_twin.ensure(std::max<size_t>((size_t)ne * 4, 16));
+	cx.d_foff.ensure(((size_t)nf + 1) * 4);
+	cx.d_order_v.ensure(std::max<size_t>((size_t)nv * 4, 16));
+	const size_t ncand_bytes = ((size_t)nv + 63) & ~(size_t)63;
+	cx.d_cscratch.ensure(std::max<size_t>((size_t)nv * (8 * 3 * 4 + 16) + ncand_bytes + 64, 16));
+	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
+	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nv * 24);
+	void *d_crec = d_ncand + ncand_bytes;
+	int ud = 0;
+	m->uniform_degree(ud);
+	cx.res_has_eface = false; cx.res_udeg = (uint32_t)ud; cx.res_nv = nv; cx.res_nf = nf; cx.res_ne = ne;
+	const ConnView cv = cx.conn_view();
+
+	m->face_off.assign((size_t)nf + 1, 0);
+	m->org.assign(ne, 0);
+	m->twin.assign(ne, 0);
+	order_v.assign(nv, 0);
+	std::vector<uint16_t> seen(nv, 0);
+	ReplayLive live;
+	live.on_border.assign(nv, 0);
+	live.pending.reserve(1 << 16);
+	if (const char *e = getenv("HRY_PIPELINE_FACES")) live.interval = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+
+	std::exception_ptr consumer_error;
+	std::vector<SliceClock> clocks;
+	uint32_t min_slice = 1u << 15;
+	if (const char *e = getenv("HRY_PIPELINE_SLICE")) min_slice = std::max(64u, (uint32_t)strtoul(e, nullptr, 10));
+	std::thread consumer([&] {
+		try {
+			HIP_OK(hipSetDevice(cx.device));
+			uint32_t f_up = 0, he_up = 0, v_done = 0;
+			uint64_t seen_seq = 0;
+			std::vector<uint32_t> patches;
+			DevBuf d_patch;
+			Stager up(cx, cx.stream2);
+			hipEvent_t prepared;
+			HIP_OK(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
+			// The consumer acts on a publication only when `lag` newer ones exist: the newest part of the arrays is still hot
+			// in the replay thread's cache (twins of the last ring keep changing), copying it there would slow the replay down.
+			std::deque<ReplayLive::Pub> hist;
+			uint32_t lag = 2;
+			if (const char *e = getenv("HRY_PIPELINE_LAG")) lag = (uint32_t)strtoul(e, nullptr, 10);
+			for (;;) {
+				ReplayLive::Pub newest;
+				{
+					std::unique_lock<std::mutex> lk(live.mu);
+					live.cv.wait(lk, [&] { return live.pub.seq != seen_seq; });
+					newest = live.pub;
+					patches.insert(patches.end(), live.patches.begin(), live.patches.end());
+					live.patches.clear();
+					seen_seq = newest.seq;
+				}
+				if (newest.failed) break;
+				hist.push_back(newest);
+				if (!newest.done && hist.size() <= lag) continue;
+				const ReplayLive::Pub P = newest.done ? newest : hist.front();
+				while (!hist.empty() && hist.front().seq <= P.seq) hist.pop_front();
+				// finished part of the connectivity
+				if (P.faces > f_up) {
+					up.put(cx.d_foff.as<uint32_t>() + f_up, m->face_off.data() + f_up, ((size_t)P.faces - f_up + 1) * 4);
+					up.put(cx.d_org.as<uint32_t>() + he_up, m->org.data() + he_up, ((size_t)P.he - he_up) * 4);
+					up.put(cx.d_twin.as<uint32_t>() + he_up, m->twin.data() + he_up, ((size_t)P.he - he_up) * 4);
+					f_up = P.faces; he_up = P.he;
+				}
+				// vertices that can no longer change: whole tiles, slices of a useful size
+				const uint32_t v_hi = P.done ? nv : (P.upto & ~63u);
+				if (v_hi > v_done && (P.done || v_hi - v_done >= min_slice)) {
+					// late links of edges that were copied before (a patch of an edge that is copied later is harmless: the copy
+					// carries the final value too)
+					if (!patches.empty()) {
+						d_patch.ensure(patches.size() * 4);
+						up.put(d_patch.p, patches.data(), patches.size() * 4);
+						launch_scatter_u32(cx.stream2, d_patch.as<uint32_t>(), (uint32_t)(patches.size() / 2), cx.d_twin.as<uint32_t>());
+						patches.clear();
+					}
+					up.put(cx.d_order_v.as<uint32_t>() + v_done, order_v.data() + v_done, ((size_t)v_hi - v_done) * 4);
+					launch_slice_prepare(cx.stream2, cv, cx.d_order_v.as<uint32_t>(), v_done, v_hi, d_cand, d_ncand, d_crec);
+					HIP_OK(hipEventRecord(prepared, cx.stream2));
+					HIP_OK(hipStreamWaitEvent(cx.stream, prepared, 0));
+					SliceClock ck;
+					HIP_OK(hipEventCreate(&ck.a)); HIP_OK(hipEventCreate(&ck.b));
+					HIP_OK(hipEventRecord(ck.a, cx.stream));
+					launch_slice_chain(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>());
+					HIP_OK(hipEventRecord(ck.b, cx.stream));
+					clocks.push_back(ck);
+					v_done = v_hi;
+				}
+				if (P.done) break;
+			}
+			up.flush();
+			(void)hipEventDestroy(prepared);
+		} catch (...) { consumer_error = std::current_exception(); }
+	});
+
+	// ---- the replay itself (this thread)
+	std::exception_ptr replay_error;
+	ReplayCursor cur;
+	try {
+		int onlydeg = ud;
+		struct PlanesRd {
+			const std::vector<uint8_t> *pl; size_t cur[21]; int fixed_numtri;
+			uint32_t byte(int plane) { const std::vector<uint8_t> &v = pl[plane]; if (cur[plane] >= v.size()) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)"); return v[cur[plane]++]; }
+			uint32_t iop() { return byte(0); }
+			uint32_t u32(int first) { uint32_t v = byte(first); v |= byte(first + 1) << 8; v |= byte(first + 2) << 16; v |= byte(first + 3) << 24; return v; }
+			int elem() { uint32_t z = u32(1); return (int)((z >> 1) ^ ((z & 1) ? 0xffffffffu : 0u)); }
+			int part() { uint32_t v = byte(5); v |= byte(6) << 8; return (int)v; }
+			uint32_t vertid() { return u32(7); }
+			int numtri() { return fixed_numtri; }
+			uint32_t op(int order) { int k = order - 1; if (k > 7) k = 7; if (k < 0) k = 0; return byte(13 + k); }
+		} rd{ conn, { 0 }, onlydeg - 2 };
+		const std::vector<uint32_t> none;
+		std::vector<uint32_t> comp_first, comp_level;
+		replay_span(*m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, none, comp_first, comp_level, &live);
+		if (cur.face != nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
+		if (cur.he != ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
+		if (cur.next_id != nv) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
+		live.publish(cur.face, cur.he, cur.next_id, true);
+	} catch (...) {
+		replay_error = std::current_exception();
+		live.publish(cur.face, cur.he, cur.next_id, true, true);
+	}
+	cx.timing.host_walk_ms = ms_since(g_t0) ;
+	HRY_MARK(g_t0, "replay done");
+	if (trace_on()) fprintf(stderr, "[hry] %u publications, %.3f ms inside publish()\n", live.n_publish, live.t_publish_ms);
+	consumer.join();
+	auto drop_clocks = [&] { for (auto &c : clocks) { (void)hipEventDestroy(c.a); (void)hipEventDestroy(c.b); } };
+	if (replay_error || consumer_error) {
+		(void)hipStreamSynchronize(cx.stream); (void)hipStreamSynchronize(cx.stream2);
+		drop_clocks();
+		std::rethrow_exception(replay_error ? replay_error : consumer_error);
+	}
+	order_v.resize(cur.next_id);
+	if (ldf.nplanes) {
+		launch_residuals_to_rec(cx.stream, d_fplanes, nf, ldf, cx.d_rec[0].as<uint8_t>());
+		launch_faces_unfold(cx.stream, nf, ldf, cx.d_rec[0].as<uint8_t>());
+	}
+	for (int l = 0; l < 2; ++l)
+		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	HRY_MARK(g_t0, "records on the host");
+	double chain_ms = 0;
+	for (auto &c : clocks) { float t = 0; if (hipEventElapsedTime(&t, c.a, c.b) == hipSuccess) chain_ms += t; }
+	drop_clocks();
+	cx.timing.k_chain_ms = chain_ms;
+	if (cx.keep_stages) {
+		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
+		cx.stage_put("ncand", d_ncand, nv);
+		cx.stage_put("cand", d_cand, (size_t)nv * 24 * 4);
 	}
 }
 
@@ -233,18 +453,25 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// ---- replay the cut-border machine on the host
 	auto t_walk = Clock::now();
 	std::vector<uint32_t> order_v, seg_start, seg_level;
-	cut_border_replay(*m, conn, restarts, order_v, seg_start, seg_level);
-	cx.timing.host_walk_ms = ms_since(t_walk);
-	HRY_MARK(g_t0, "replay done");
-	if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
-	reconstruct_attributes(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes],
-	                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf);
+	bool pipelined = false;
+	if (pipelined_decode_applicable(*m, restarts, conn, ldv, vc)) {
+		pipelined = true;
+		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v);
+		cx.timing.host_walk_ms = cx.timing.host_walk_ms - std::chrono::duration<double, std::milli>(t_walk - g_t0).count();
+	} else {
+		cut_border_replay(*m, conn, restarts, order_v, seg_start, seg_level);
+		cx.timing.host_walk_ms = ms_since(t_walk);
+		HRY_MARK(g_t0, "replay done");
+		if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
+		reconstruct_attributes(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes],
+		                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf);
+	}
 	if (cx.keep_stages) {
 		cx.stage_put("dec_syms", cx.d_csyms.p, total_syms);
 		cx.stage_put_host("dec_nsym", nsym.data(), nsym.size() * 4);
 	}
 	cx.timing.k_entropy_ms = cx.elapsed(1, 2) + cx.elapsed(5, 6);
-	cx.timing.k_predict_ms = cx.elapsed(3, 4);
+	cx.timing.k_predict_ms = pipelined ? cx.timing.k_chain_ms : cx.elapsed(3, 4);
 	cx.timing.device_ms = cx.timing.k_entropy_ms + cx.timing.k_predict_ms;
 	cx.timing.n_symbols = total_syms;
 	cx.timing.payload_bytes = payload_bytes;

@@ -1013,6 +1013,31 @@ constexpr uint32_t kRing3Near = kRing3 - 64;   // a source this close to its ver
 constexpr uint32_t kFlush3 = 4096;
 enum { CR_NC = 3, CR_BIG = 3, CR_POS_SHIFT = 2, CR_POS_NONE = 7, CR_FAR = 1 << 5, CR_NEED_SHIFT = 6 };
 
+// ring_floor: ids below it are not in the LDS ring when the vertex is reconstructed (they belong to an earlier component, or
+// to an earlier slice beyond the part of the ring that is reloaded): such sources are read by vertex id ("far")
+__device__ __forceinline__ ChainRec make_chain_rec(const uint32_t *cand, const uint8_t *ncand, uint32_t v, uint32_t seg_begin, uint32_t ring_floor)
+{
+	const uint32_t nc = ncand[v];
+	ChainRec r;
+#pragma unroll
+	for (int j = 0; j < 6; ++j) r.slot[j] = 0;
+	r.pad = 0;
+	if (nc > 2) { r.flags = (uint16_t)(CR_BIG | (CR_POS_NONE << CR_POS_SHIFT)); return r; }
+	const uint32_t *row = cand + (size_t)v * (kCandMax * 3);
+	uint32_t pos = CR_POS_NONE, need = 0, far = 0;
+	for (uint32_t j = 0; j < 3 * nc; ++j) {
+		const uint32_t id = row[j];
+		if (id + 1u == v && j % 3 != 2 && pos == CR_POS_NONE && v > seg_begin) pos = j;   // the chained source: predecessor, plus sign, once
+		else need = max(need, id + 1u);
+		far |= (v - id > kRing3Near || id < ring_floor) ? 1u : 0u;
+		r.slot[j] = (uint16_t)(id & (kRing3 - 1));
+	}
+	if (nc == 1) { r.slot[3] = r.slot[0]; r.slot[4] = r.slot[1]; r.slot[5] = r.slot[2]; }   // (2 p + 1) >> 1 == p
+	const uint32_t tile = v & ~63u;
+	const uint32_t need_rel = need > tile ? need - tile : 0u;   // <= v - tile <= 63
+	r.flags = (uint16_t)(nc | (pos << CR_POS_SHIFT) | (far ? CR_FAR : 0) | (need_rel << CR_NEED_SHIFT));
+	return r;
+}
 // cand / ncand as written by k_candidates_ids; seg_start: first decode rank of every component + end sentinel
 __global__ __launch_bounds__(256) void k_chain_records(const uint32_t *cand, const uint8_t *ncand, uint32_t n, const uint32_t *seg_start, uint32_t nseg, ChainRec *out)
 {
@@ -1021,26 +1046,13 @@ __global__ __launch_bounds__(256) void k_chain_records(const uint32_t *cand, con
 	uint32_t lo = 0, hi = nseg;   // component of v: the last one that starts at or before v
 	while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= v) lo = mid; else hi = mid; }
 	const uint32_t seg_begin = seg_start[lo];
-	const uint32_t nc = ncand[v];
-	ChainRec r;
-#pragma unroll
-	for (int j = 0; j < 6; ++j) r.slot[j] = 0;
-	r.pad = 0;
-	if (nc > 2) { r.flags = (uint16_t)(CR_BIG | (CR_POS_NONE << CR_POS_SHIFT)); out[v] = r; return; }
-	const uint32_t *row = cand + (size_t)v * (kCandMax * 3);
-	uint32_t pos = CR_POS_NONE, need = 0, far = 0;
-	for (uint32_t j = 0; j < 3 * nc; ++j) {
-		const uint32_t id = row[j];
-		if (id + 1u == v && j % 3 != 2 && pos == CR_POS_NONE && v > seg_begin) pos = j;   // the chained source: predecessor, plus sign, once
-		else need = max(need, id + 1u);
-		far |= (v - id > kRing3Near || id < seg_begin) ? 1u : 0u;
-		r.slot[j] = (uint16_t)(id & (kRing3 - 1));
-	}
-	if (nc == 1) { r.slot[3] = r.slot[0]; r.slot[4] = r.slot[1]; r.slot[5] = r.slot[2]; }   // (2 p + 1) >> 1 == p
-	const uint32_t tile = v & ~63u;
-	const uint32_t need_rel = need > tile ? need - tile : 0u;   // <= v - tile <= 63
-	r.flags = (uint16_t)(nc | (pos << CR_POS_SHIFT) | (far ? CR_FAR : 0) | (need_rel << CR_NEED_SHIFT));
-	out[v] = r;
+	out[v] = make_chain_rec(cand, ncand, v, seg_begin, seg_begin);
+}
+// one slice [v_begin, v_end) of a chain that continues an earlier slice (pipelined decode)
+__global__ __launch_bounds__(256) void k_chain_records_range(const uint32_t *cand, const uint8_t *ncand, uint32_t v_begin, uint32_t v_end, uint32_t ring_floor, ChainRec *out)
+{
+	const uint32_t v = v_begin + blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < v_end) out[v] = make_chain_rec(cand, ncand, v, v_begin, ring_floor);
 }
 
 struct Map3 { int32_t k, A, D; };   // x -> floor((x + A) / 2^k) + D, 0 <= A < 2^k, k <= 16
@@ -1085,7 +1097,7 @@ __device__ __forceinline__ Map3 scan3(Map3 m)
 template <typename T>
 __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t seg_end,
                                    const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec, const uint8_t *planes, uint8_t *rec,
-                                   int stride, int off, int q, int plane0, T *ring)
+                                   int stride, int off, int q, int plane0, T *ring, uint32_t ring_floor)
 {
 	static_assert(sizeof(T) <= 2 && !(T(-1) < T(0)), "unsigned components of at most 16 bits");
 	const int lane = threadIdx.x;
@@ -1098,7 +1110,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	};
 	// value of a vertex that is final before the current run, wherever it lives
 	auto old_value = [&](uint32_t id, uint32_t cur) -> uint32_t {
-		if (id >= seg_begin && cur - id <= kRing3Near) return (uint32_t)ring[id & mask];
+		if (id >= ring_floor && cur - id <= kRing3Near) return (uint32_t)ring[id & mask];
 		return (uint32_t)__hip_atomic_load((const T*)(rec + (size_t)id * stride + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	};
 	uint4 nx_rec = make_uint4(0, 0, 0, 0);
@@ -1112,6 +1124,8 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if (sizeof(T) == 2) nx_b1 = planes[(size_t)(plane0 + 1) * nvtx_total + v];
 		}
 	};
+	// a slice that continues a chain finds the end of the previous slice in the ring again
+	for (uint32_t b = ring_floor; b < seg_begin; b += 64) { const uint32_t v = b + lane; if (v < seg_begin) ring[v & mask] = ldq<T>(rec + (size_t)v * stride + off); }
 	const uint32_t t_first = seg_begin & ~63u;
 	request(t_first);
 	for (uint32_t tb = t_first; tb < seg_end; tb += 64) {
@@ -1232,9 +1246,18 @@ __global__ __launch_bounds__(64) void k_unpredict3(ConnView cv, const uint32_t *
 	TopoD tp{ cv };
 	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
 		const uint32_t b = segs[2 * k], e = segs[2 * k + 1];
-		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3);
+		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, b);
 		__syncthreads();
 	}
+}
+template <typename T>
+__global__ __launch_bounds__(64) void k_unpredict3_range(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
+                                                         const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, uint32_t v_begin, uint32_t v_end, uint32_t ring_floor)
+{
+	__shared__ T ring3[kRing3];
+	const int c = sel.comp[blockIdx.x];
+	TopoD tp{ cv };
+	unpredict3_segment<T>(tp, order_v, nvtx, v_begin, v_end, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, ring_floor);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1269,9 +1292,9 @@ bool unpredict2_applicable(const ListDesc &ld)
 	return ld.ncomp > 0;
 }
 // candidate lists with plain vertex ids (k_unpredict2 resolves ring slots itself)
-__global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand)
+__global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t v0, uint32_t n, uint32_t *cand, uint8_t *ncand)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = v0 + blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= n) return;
 	TopoD tp{ cv };
 	uint32_t k = 0;
@@ -1287,7 +1310,33 @@ __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint3
 }
 void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand)
 {
-	if (nvtx) hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, nvtx, cand, ncand);
+	if (nvtx) hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand);
+}
+// ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
+uint32_t chain_ring_floor(uint32_t v_begin) { return v_begin > kRing3Near ? v_begin - kRing3Near : 0u; }
+bool unpredict3_covers(const ListDesc &ld)
+{
+	for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] != 6 && ld.stype[c] != 8) return false;
+	return ld.ncomp > 0;
+}
+void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t v_begin, uint32_t v_end, uint32_t *cand, uint8_t *ncand, void *crec)
+{
+	if (v_end <= v_begin) return;
+	const uint32_t n = v_end - v_begin;
+	hipLaunchKernelGGL(k_candidates_ids, dim3((n + 255) / 256), dim3(256), 0, st, cv, order_v, v_begin, v_end, cand, ncand);
+	hipLaunchKernelGGL(k_chain_records_range, dim3((n + 255) / 256), dim3(256), 0, st, (const uint32_t*)cand, (const uint8_t*)ncand, v_begin, v_end, chain_ring_floor(v_begin), (ChainRec*)crec);
+}
+void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,
+                        const void *crec, const uint8_t *planes, const ListDesc &ld, uint8_t *rec)
+{
+	if (v_end <= v_begin) return;
+	auto go3 = [&](auto kern, int stype) {
+		CompSel sel{};
+		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
+		if (!sel.n) return;
+		hipLaunchKernelGGL(kern, dim3(sel.n), dim3(64), 0, st, cv, order_v, nvtx, cand, ncand, (const ChainRec*)crec, planes, ld, rec, sel, v_begin, v_end, chain_ring_floor(v_begin));
+	};
+	go3(k_unpredict3_range<uint16_t>, 6); go3(k_unpredict3_range<uint8_t>, 8);
 }
 // segs: pairs (begin, end) of decode ranks; list_off: n_lists + 1 offsets into segs.  Lists run in parallel blocks, the
 // segments of one list one after the other.  Two launches: independent components first, then the dependent ones.

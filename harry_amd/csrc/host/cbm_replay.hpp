@@ -6,6 +6,8 @@
 #include "host.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 
 namespace hry {
 namespace replay_detail {
@@ -20,16 +22,18 @@ struct Ring {
 	std::vector<Node> pool;
 	std::vector<int32_t> spare;
 	std::vector<Part> parts;
+	uint16_t *on_border = nullptr;   // optional: how often every vertex currently occurs on the border (ReplayLive)
 	Part &top() { return parts.back(); }
 	int32_t make(uint32_t v, uint32_t a)
 	{
+		if (on_border) ++on_border[v];
 		int32_t i;
 		if (!spare.empty()) { i = spare.back(); spare.pop_back(); }
 		else { i = (int32_t)pool.size(); pool.push_back(Node()); }
 		pool[i] = Node{ v, a, -1, -1 };
 		return i;
 	}
-	void drop(int32_t i) { spare.push_back(i); }
+	void drop(int32_t i) { if (on_border) --on_border[pool[i].v]; spare.push_back(i); }
 	void append(Part &p, int32_t i)
 	{
 		pool[i].prev = p.tail; pool[i].next = -1;
@@ -107,14 +111,56 @@ struct Ring {
 //                   it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
 // RD provides: iop(), vertid(), elem(), part(), numtri(), op(order)
 struct ReplayCursor { uint32_t next_id = 0, face = 0, he = 0; };
+
+// Progress of a running replay, published for a consumer thread that uploads the finished part of the connectivity and
+// starts the attribute reconstruction of the vertices that can no longer change (unchunk.cpp, pipelined decode).
+// A vertex is COMPLETE when it has left the cut-border for good: every face around it exists, and so does every face around
+// its older neighbours once all smaller ids are complete too.  Without explicitly named vertices (NM operations, TRIxxx
+// starts: the vertid planes are empty) a vertex never returns to the border, so "all ids < upto are complete" is simply the
+// smallest id still on the border.  Twins of edges that lie below the last published half-edge count may already have been
+// copied by the consumer: later links of such edges are recorded as patches (idempotent index/value pairs).
+struct ReplayLive {
+	struct Pub { uint64_t seq = 0; uint32_t faces = 0, he = 0, upto = 0; bool done = false, failed = false; };
+	std::mutex mu;
+	std::condition_variable cv;
+	Pub pub;                                   // guarded by mu
+	std::vector<uint32_t> patches;             // guarded by mu: (half-edge, twin) pairs since the consumer last took them
+	// producer side
+	std::vector<uint16_t> on_border;
+	std::vector<uint32_t> pending;             // patches since the last publication
+	uint32_t interval = 8192, face_pub = 0, he_pub = 0, min_open = 0;
+	void link(uint32_t a, uint32_t b)
+	{
+		if (a < he_pub) { pending.push_back(a); pending.push_back(b); }
+		if (b < he_pub) { pending.push_back(b); pending.push_back(a); }
+	}
+	double t_publish_ms = 0, t_lock_ms = 0; uint32_t n_publish = 0;
+	void publish(uint32_t face, uint32_t he, uint32_t next_id, bool done, bool failed = false)
+	{
+		auto t0 = std::chrono::steady_clock::now();
+		++n_publish;
+		struct Fin { ReplayLive &l; std::chrono::steady_clock::time_point t0; ~Fin() { l.t_publish_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } fin{ *this, t0 };
+		while (min_open < next_id && on_border[min_open] == 0) ++min_open;
+		{
+			std::lock_guard<std::mutex> g(mu);
+			++pub.seq; pub.faces = face; pub.he = he; pub.upto = done ? next_id : min_open; pub.done = done; pub.failed = failed;
+			patches.insert(patches.end(), pending.begin(), pending.end());
+		}
+		cv.notify_one();
+		pending.clear();
+		face_pub = face; he_pub = he;
+	}
+};
+
 template <class RD>
 bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCursor &cur, uint32_t stop_face, uint32_t min_id,
                  const std::vector<uint32_t> &g_first, const std::vector<uint32_t> &g_level,
-                 std::vector<uint32_t> &comp_first, std::vector<uint32_t> &comp_level)
+                 std::vector<uint32_t> &comp_first, std::vector<uint32_t> &comp_level, ReplayLive *live = nullptr)
 {
 	using namespace replay_detail;
 	const uint32_t nv = m.nv, nf = m.nf, ne_max = (uint32_t)m.org.size();
 	Ring cb;
+	if (live) cb.on_border = live->on_border.data();
 	uint32_t next_id = cur.next_id, face = cur.face, he = cur.he;
 	auto new_face = [&](int ne) {
 		if (ne < 3 || ne > 255) throw Error(HRY_E_FORMAT, "corrupt stream (polygon degree)");
@@ -126,7 +172,8 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCurso
 		for (int i = 0; i < ne; ++i) { m.org[o + i] = 0; m.twin[o + i] = o + i; }
 		return o;
 	};
-	auto link = [&](uint32_t a, uint32_t b) { m.twin[a] = b; m.twin[b] = a; };
+
+	auto link = [&](uint32_t a, uint32_t b) { m.twin[a] = b; m.twin[b] = a; if (live) live->link(a, b); };
 	auto chk = [&](uint32_t v) {
 		if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
 		if (v < min_id) throw Error(HRY_E_FORMAT, "corrupt stream (restart point names an older vertex)");
@@ -196,6 +243,8 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCurso
 		cb.append(cb.top(), cb.make(c, e2));
 
 		while (!cb.parts.empty()) {
+			// between two operations the border and the faces agree; publish when the current polygon is complete as well
+			if (live && curtri == ntri && face - live->face_pub >= live->interval) live->publish(face, he, next_id, false);
 			Ring::Part &pt = cb.top();
 			const uint32_t v0 = cb.pool[pt.tail].v, v1 = cb.pool[pt.head].v;
 			const uint32_t gate = cb.pool[pt.tail].a;

@@ -100,6 +100,38 @@ def test_chunked_decode_from_restart_points(cx, case, monkeypatch):
     same_mesh(cx.read_hry(got), ref_dec)
 
 
+@pytest.mark.parametrize("case", ["torus150_q14", "grid_quads_q12", "ico5_q10", "colors_normals", "open_grid_q8"])
+@pytest.mark.parametrize("faces,slice_", [(64, 64), (1000, 4096)])
+def test_chunked_pipelined_decode(cx, case, faces, slice_, monkeypatch):
+    """The pipelined decode (replay publishes its progress; uploads, candidates and the reconstruction chain of every
+    finished slice of vertices run behind it) gives exactly the mesh of the sequential pipeline and of the reference-format
+    decode.  Forced onto small meshes here with tiny publication intervals / slices so that many slices, patches of late twin
+    links and ring reloads are exercised."""
+    mesh, quant = {
+        "torus150_q14": (lambda: mg.torus(150, 150, seed=2), [(1, -1, 14)]),
+        "grid_quads_q12": (lambda: mg.grid(120, 90, quads=True), [(1, -1, 12)]),
+        "ico5_q10": (lambda: mg.icosphere(5), [(1, -1, 10)]),
+        "colors_normals": (lambda: mg.with_colors(mg.torus(90, 80, normals=True)), [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)]),
+        "open_grid_q8": (lambda: mg.grid(200, 150), [(1, -1, 8)]),
+    }[case]
+    ply = mesh().to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    cx.requant(a, quant)
+    o.requant(quant)
+    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
+    monkeypatch.setenv("HRY_NO_PIPELINE", "1")
+    plain = cx.read_hry(got)
+    monkeypatch.delenv("HRY_NO_PIPELINE")
+    monkeypatch.setenv("HRY_PIPELINE_MIN_VERTICES", "0")
+    monkeypatch.setenv("HRY_PIPELINE_FACES", str(faces))
+    monkeypatch.setenv("HRY_PIPELINE_SLICE", str(slice_))
+    piped = cx.read_hry(got)
+    same_mesh(piped, plain)
+    same_mesh(piped, ref_dec)
+    assert np.array_equal(piped.twin(), plain.twin())
+
+
 def test_chunked_entropy_decode_planes(cx):
     """k_chunk_decode inverts k_chunk_encode symbol for symbol (checked before any mesh logic)."""
     m = mg.torus(64, 60, polys="mixed", normals=True)
