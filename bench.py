@@ -85,9 +85,10 @@ def main():
 
     quant = [(1, -1, 14)]
     mesh = build_workload(args.side, seed=2 + rank)     # each rank: its own connected component (weak scaling)
-    base = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    raw = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)   # float32 positions, not yet quantised
     cx = hc.Codec(local_rank)
-    cx.requant(base, quant)                              # quantisation is part of "encode" (timed separately below)
+    base = raw.clone()
+    cx.requant(base, quant)                              # used for the profile probe only; every timed step quantises itself
 
     profile = args.profile
     if profile == "auto":
@@ -106,13 +107,16 @@ def main():
 
     def one_step():
         """returns (stream bytes, timing dict); inputs are resident in HBM before the timed region"""
-        m = base.clone()
-        cx.upload(m)
+        m = raw.clone()
+        cx.upload(m)                                     # float records + connectivity resident in HBM
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        cx.requant(m, quant)                             # encode = quantisation (bounds, float -> uint14) + .hry production
+        t_q = time.perf_counter()
         out = cx.write_hry(m, profile=pid)
         t1 = time.perf_counter()
         tm_e = cx.timing()
+        tm_e["requant_ms"] = (t_q - t0) * 1e3
         tm_d = {}
         if can_decode:
             cx.read_hry(out)
@@ -165,7 +169,7 @@ def main():
         med = lambda k: float(np.median([t.get(k, 0.0) for t in timings]))
         # the dominant kernel of a step (HIP-event times taken inside the library on the codec stream)
         cands = {"k_rchain": med("k_rchain_ms"), "k_chunk_encode": med("k_entropy_ms") if profile == "chunked" else 0.0,
-                 "k_predict_vtx": med("k_predict_ms"), "k_chunk_decode": med("dec_k_entropy_ms"), "k_unpredict2": med("dec_k_chain_ms")}
+                 "k_predict_vtx": med("k_predict_ms"), "k_chunk_decode": med("dec_k_entropy_ms"), "k_unpredict3": med("dec_k_chain_ms")}
         dom_name = max(cands, key=cands.get)
         dom_ms = cands[dom_name]
         # algorithmic bytes per launch: every input array once + the stream once =
@@ -180,22 +184,25 @@ def main():
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "traffic.json")) as f:
                 tr = json.load(f)["kernels"]
-            hit = [v for k, v in tr.items() if k.split("<")[0] == dom_name]
+            hit = [v for k, v in tr.items() if k.split("<")[0].split("_range")[0] == dom_name]
             if hit and args.side == 708 and profile == "chunked":
-                roof["traffic"] = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
-                roof["traffic_source"] = "profiles/r1/traffic.json (PMC, uncorrected)"
+                # MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled;
+                # WRITE_SIZE is exact.  Per decode of the workload (all launches of the kernel together).
+                roof["traffic"] = 2 * hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
+                roof["traffic_raw"] = {"FETCH_SIZE_bytes": hit[0]["fetch_bytes"], "WRITE_SIZE_bytes": hit[0]["write_bytes"]}
+                roof["traffic_source"] = "profiles/r1/traffic.json (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 per the gfx950 note)"
         except (OSError, KeyError, ValueError):
             pass
         line = {
             "metric": "Mtriangles/s encode+decode", "value": round(value, 4), "unit": "Mtriangles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/f32 (integer residuals, 64-bit range coder)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 residual bytes, u32 range-coder registers (compat profile: u64)", "data": "synthetic",
             "config": {"workload": f"closed torus {args.side}x{args.side}, {ntri} triangles, float32 xyz, -l1 -q14 (BASELINE configs[1])",
                        "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}"},
             "encode_mtri_s": round(world * ntri * args.steps / t_enc / 1e6, 4),
             "decode_mtri_s": round(world * ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
             "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / base.nv, 4),
-            "stage_ms": {k: round(med(k), 4) for k in ("host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms",
+            "stage_ms": {k: round(med(k), 4) for k in ("requant_ms", "host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms",
                                                         "dec_host_walk_ms", "dec_k_entropy_ms", "dec_k_predict_ms", "dec_k_chain_ms", "dec_total_ms")},
             "kernel_ms": {k: round(v, 4) for k, v in cands.items()},
             "roofline": roof,

@@ -16,5 +16,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROO
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/scripts/quick_chunked.py 708 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/scripts/quick_chunked.py 708 > $OUT/pmc_sq.log 2>&1
 cd $ROOT
-python3 scripts/summarise_profiles.py $OUT > $OUT/summary.txt 2>&1
+python3 scripts/summarise_profiles.py $OUT 3 > $OUT/summary.txt 2>&1
 tail -40 $OUT/summary.txt

@@ -46,6 +46,17 @@ for k, cs in sorted(traffic.items()):
     summary[k] = {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()}
 with open(os.path.join(out, "pmc_summary.json"), "w") as o:
     json.dump(summary, o, indent=1, sort_keys=True)
+# HBM-side bytes per PASS of the workload (one encode + one decode; a kernel that is launched once per slice or per level is
+# summed over its launches): FETCH_SIZE / WRITE_SIZE are reported in KiB.  Raw counter values: the gfx950 correction (FETCH_SIZE
+# tallies 128-byte requests at 64 bytes -> x2) is applied by the reader (bench.py), not here.
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3   # passes of scripts/quick_chunked.py
+tj = {"passes": iters, "unit": "bytes per pass (KiB x 1024, uncorrected)", "kernels": {}}
+for k, cs in sorted(traffic.items()):
+    if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
+        tj["kernels"][k] = {"fetch_bytes": int(sum(cs.get("FETCH_SIZE", [])) * 1024 / iters), "write_bytes": int(sum(cs.get("WRITE_SIZE", [])) * 1024 / iters),
+                            "launches_per_pass": len(cs.get("FETCH_SIZE", cs.get("WRITE_SIZE", []))) / iters}
+with open(os.path.join(out, "traffic.json"), "w") as o:
+    json.dump(tj, o, indent=1, sort_keys=True)
 print("== PMC means per launch (FETCH_SIZE / WRITE_SIZE in KiB as reported; gfx950: double FETCH_SIZE for wide streaming reads)")
 for k, cs in summary.items():
     print(f"  {k[:50]:50s} " + "  ".join(f"{c}={v['mean']:.4g}" for c, v in sorted(cs.items())))
