@@ -39,7 +39,10 @@ Context::~Context()
 	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 	if (stream) (void)hipStreamDestroy(stream);
 	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+	if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }
+	for (auto &e : ev_x) if (e) (void)hipEventDestroy(e);
 	if (h_stage) (void)hipHostFree(h_stage);
+	if (h_down) (void)hipHostFree(h_down);
 }
 void Context::stage_put(const char *name, const void *dptr, size_t bytes)
 {

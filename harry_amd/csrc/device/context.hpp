@@ -39,6 +39,10 @@ struct Context {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;   // uploads and connectivity-only kernels of the pipelined decode (created on first use)
+	hipStream_t stream3 = nullptr;   // attribute streams' entropy decode, next to the connectivity streams' (created on first use)
+	hipEvent_t ev_x[2] = {};         // cross-stream ordering events (created with stream3)
+	void *h_down = nullptr;          // pinned landing buffer for the vertex records of the pipelined decode (device -> host per slice)
+	size_t h_down_cap = 0;
 	void *h_stage = nullptr;         // pinned staging memory for uploads that run next to a busy host thread (copies from
 	size_t h_stage_cap = 0;          // pageable memory make the runtime pin and unpin pages: TLB shootdowns for every thread)
 	hipEvent_t ev[8] = {};

@@ -185,6 +185,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	Mesh *m = &mesh;
 	const uint32_t nv = m->nv, nf = m->nf, ne = m->declared_ne;
 	if (!cx.stream2) HIP_OK(hipStreamCreateWithFlags(&cx.stream2, hipStreamNonBlocking));
+	HRY_MARK(g_t0, "pipelined decode: begin");
 	// device arrays at their final size; records start as zeros (host records are zero-filled by the header reader)
 	for (int l = 0; l < 2; ++l) {
 		cx.d_rec[l].ensure(std::max<size_t>(m->lists[l].data.size(), 16));
@@ -212,12 +213,24 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	ReplayLive live;
 	live.on_border.assign(nv, 0);
 	live.pending.reserve(1 << 16);
+	HRY_MARK(g_t0, "host arrays allocated");
 	if (const char *e = getenv("HRY_PIPELINE_FACES")) live.interval = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
 
 	std::exception_ptr consumer_error;
 	std::vector<SliceClock> clocks;
 	uint32_t min_slice = 1u << 15;
 	if (const char *e = getenv("HRY_PIPELINE_SLICE")) min_slice = std::max(64u, (uint32_t)strtoul(e, nullptr, 10));
+	const Clock::time_point t_begin = g_t0;
+	// vertex records come back slice by slice into pinned memory and are copied into the mesh by the consumer as they land
+	const size_t vrec_bytes = m->lists[1].data.size();
+	if (cx.h_down_cap < vrec_bytes) {
+		if (cx.h_down) { (void)hipHostFree(cx.h_down); cx.h_down = nullptr; cx.h_down_cap = 0; }
+		HIP_OK(hipHostMalloc(&cx.h_down, vrec_bytes + (vrec_bytes >> 3) + 4096, hipHostMallocDefault));
+		cx.h_down_cap = vrec_bytes + (vrec_bytes >> 3) + 4096;
+	}
+	struct Landing { hipEvent_t ev; size_t off, len; };
+	std::deque<Landing> landing;
+	const int vstride = ldv.stride;
 	std::thread consumer([&] {
 		try {
 			HIP_OK(hipSetDevice(cx.device));
@@ -233,8 +246,20 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 			std::deque<ReplayLive::Pub> hist;
 			uint32_t lag = 2;
 			if (const char *e = getenv("HRY_PIPELINE_LAG")) lag = (uint32_t)strtoul(e, nullptr, 10);
+			auto drain = [&](bool wait) {
+				while (!landing.empty()) {
+					Landing &L = landing.front();
+					if (wait) HIP_OK(hipEventSynchronize(L.ev));
+					else if (hipEventQuery(L.ev) != hipSuccess) break;
+					memcpy(m->lists[1].data.data() + L.off, (const uint8_t*)cx.h_down + L.off, L.len);
+					if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  records of vertices [%zu, %zu) landed\n", ms_since(t_begin), L.off / vstride, (L.off + L.len) / vstride);
+					(void)hipEventDestroy(L.ev);
+					landing.pop_front();
+				}
+			};
 			for (;;) {
 				ReplayLive::Pub newest;
+				drain(false);
 				{
 					std::unique_lock<std::mutex> lk(live.mu);
 					live.cv.wait(lk, [&] { return live.pub.seq != seen_seq; });
@@ -276,11 +301,21 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 					launch_slice_chain(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>());
 					HIP_OK(hipEventRecord(ck.b, cx.stream));
 					clocks.push_back(ck);
+					{
+						Landing L;
+						L.off = (size_t)v_done * vstride; L.len = ((size_t)v_hi - v_done) * vstride;
+						HIP_OK(hipMemcpyAsync((uint8_t*)cx.h_down + L.off, cx.d_rec[1].as<uint8_t>() + L.off, L.len, hipMemcpyDeviceToHost, cx.stream));
+						HIP_OK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+						HIP_OK(hipEventRecord(L.ev, cx.stream));
+						landing.push_back(L);
+					}
+					if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  slice [%u, %u) enqueued (replay at face %u)\n", ms_since(t_begin), v_done, v_hi, newest.faces);
 					v_done = v_hi;
 				}
 				if (P.done) break;
 			}
 			up.flush();
+			drain(true);
 			(void)hipEventDestroy(prepared);
 		} catch (...) { consumer_error = std::current_exception(); }
 	});
@@ -320,6 +355,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	if (replay_error || consumer_error) {
 		(void)hipStreamSynchronize(cx.stream); (void)hipStreamSynchronize(cx.stream2);
 		drop_clocks();
+		for (auto &L : landing) (void)hipEventDestroy(L.ev);
 		std::rethrow_exception(replay_error ? replay_error : consumer_error);
 	}
 	order_v.resize(cur.next_id);
@@ -327,8 +363,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 		launch_residuals_to_rec(cx.stream, d_fplanes, nf, ldf, cx.d_rec[0].as<uint8_t>());
 		launch_faces_unfold(cx.stream, nf, ldf, cx.d_rec[0].as<uint8_t>());
 	}
-	for (int l = 0; l < 2; ++l)
-		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
+	if (!m->lists[0].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[0].data.data(), cx.d_rec[0].p, m->lists[0].data.size(), hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	HRY_MARK(g_t0, "records on the host");
 	double chain_ms = 0;
@@ -434,20 +469,30 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// attribute streams (the bulk of the payload) are still being decoded on the device.
 	uint32_t n_conn_streams = 0;
 	for (int k = 0; k < kConnPlanes; ++k) n_conn_streams += (uint32_t)((nsym[k] + (uint64_t)CHC - 1) / CHC);
+	// ... and the attribute streams start at the same time on a stream of their own (every stream is one wavefront: the two
+	// launches share the device without noticing each other); everything later on the main stream waits for them.
+	if (!cx.stream3) {
+		HIP_OK(hipStreamCreateWithFlags(&cx.stream3, hipStreamNonBlocking));
+		for (auto &e : cx.ev_x) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	}
+	HIP_OK(hipEventRecord(cx.ev_x[0], cx.stream));          // payload, jobs and tables are on the device
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
 	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), n_conn_streams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
 	                    cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>(), cx.d_csizes.as<uint32_t>());
 	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
+	HIP_OK(hipStreamWaitEvent(cx.stream3, cx.ev_x[0], 0));
+	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
+	launch_chunk_decode(cx.stream3, cx.d_cjobs.as<StreamJob>() + n_conn_streams, (uint32_t)nstreams - n_conn_streams, cx.d_init.as<uint32_t>(),
+	                    cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>() + n_conn_streams, cx.d_csizes.as<uint32_t>() + n_conn_streams);
+	HIP_OK(hipEventRecord(cx.ev[6], cx.stream3));
+	HIP_OK(hipEventRecord(cx.ev_x[1], cx.stream3));
 	std::vector<uint8_t> conn[kConnPlanes];
 	for (int k = 0; k < kConnPlanes; ++k) {
 		conn[k].resize(nsym[k]);
 		if (nsym[k]) HIP_OK(hipMemcpyAsync(conn[k].data(), cx.d_csyms.as<uint8_t>() + plane_off[k], nsym[k], hipMemcpyDeviceToHost, cx.stream));
 	}
 	HIP_OK(hipStreamSynchronize(cx.stream));
-	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
-	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>() + n_conn_streams, (uint32_t)nstreams - n_conn_streams, cx.d_init.as<uint32_t>(),
-	                    cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>() + n_conn_streams, cx.d_csizes.as<uint32_t>() + n_conn_streams);
-	HIP_OK(hipEventRecord(cx.ev[6], cx.stream));
+	HIP_OK(hipStreamWaitEvent(cx.stream, cx.ev_x[1], 0));   // attribute planes before anything that reads them
 
 	HRY_MARK(g_t0, "connectivity planes on the host");
 	// ---- replay the cut-border machine on the host
