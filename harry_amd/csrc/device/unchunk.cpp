@@ -43,6 +43,7 @@ void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *or
 void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,
                         const void *crec, const uint8_t *planes, const ListDesc &ld, uint8_t *rec);
 void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst);
+uint32_t chain_timeout_flags(hipStream_t st);
 }
 
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
@@ -123,6 +124,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	HRY_MARK(g_t0, "records on the host");
+	if (uint32_t tf = chain_timeout_flags(cx.stream)) throw Error(HRY_E_INTERNAL, "reconstruction chain: hand-over between wavefronts timed out (flags " + std::to_string(tf) + ")");
 	cx.timing.k_chain_ms = chain_timed ? cx.elapsed(7, 0) : 0.0;
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
@@ -366,6 +368,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	if (!m->lists[0].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[0].data.data(), cx.d_rec[0].p, m->lists[0].data.size(), hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	HRY_MARK(g_t0, "records on the host");
+	if (uint32_t tf = chain_timeout_flags(cx.stream)) { drop_clocks(); throw Error(HRY_E_INTERNAL, "reconstruction chain: hand-over between wavefronts timed out (flags " + std::to_string(tf) + ")"); }
 	double chain_ms = 0;
 	for (auto &c : clocks) { float t = 0; if (hipEventElapsedTime(&t, c.a, c.b) == hipSuccess) chain_ms += t; }
 	drop_clocks();

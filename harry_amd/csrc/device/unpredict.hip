@@ -11,6 +11,7 @@
 //                        sharing the candidate list); reconstructed values of the last N vertices live in LDS.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <stdexcept>
 #include <type_traits>
 
@@ -1010,7 +1011,6 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 struct alignas(16) ChainRec { uint16_t slot[6]; uint16_t flags; uint16_t pad; };
 constexpr uint32_t kRing3 = 16384;          // ring entries (32 KB of LDS for 16-bit values)
 constexpr uint32_t kRing3Near = kRing3 - 64;   // a source this close to its vertex is still in the ring when the run is prepared
-constexpr uint32_t kFlush3 = 4096;
 enum { CR_NC = 3, CR_BIG = 3, CR_POS_SHIFT = 2, CR_POS_NONE = 7, CR_FAR = 1 << 5, CR_NEED_SHIFT = 6 };
 
 // ring_floor: ids below it are not in the LDS ring when the vertex is reconstructed (they belong to an earlier component, or
@@ -1028,7 +1028,7 @@ __device__ __forceinline__ ChainRec make_chain_rec(const uint32_t *cand, const u
 	for (uint32_t j = 0; j < 3 * nc; ++j) {
 		const uint32_t id = row[j];
 		if (id + 1u == v && j % 3 != 2 && pos == CR_POS_NONE && v > seg_begin) pos = j;   // the chained source: predecessor, plus sign, once
-		else need = max(need, id + 1u);
+		else { need = max(need, id + 1u); }
 		far |= (v - id > kRing3Near || id < ring_floor) ? 1u : 0u;
 		r.slot[j] = (uint16_t)(id & (kRing3 - 1));
 	}
@@ -1036,6 +1036,7 @@ __device__ __forceinline__ ChainRec make_chain_rec(const uint32_t *cand, const u
 	const uint32_t tile = v & ~63u;
 	const uint32_t need_rel = need > tile ? need - tile : 0u;   // <= v - tile <= 63
 	r.flags = (uint16_t)(nc | (pos << CR_POS_SHIFT) | (far ? CR_FAR : 0) | (need_rel << CR_NEED_SHIFT));
+	r.pad = (uint16_t)min(65535u, need ? v + 1u - need : 65535u);   // distance to the most recent source other than the chained one
 	return r;
 }
 // cand / ncand as written by k_candidates_ids; seg_start: first decode rank of every component + end sentinel
@@ -1053,6 +1054,27 @@ __global__ __launch_bounds__(256) void k_chain_records_range(const uint32_t *can
 {
 	const uint32_t v = v_begin + blockIdx.x * blockDim.x + threadIdx.x;
 	if (v < v_end) out[v] = make_chain_rec(cand, ncand, v, v_begin, ring_floor);
+}
+
+// Set when a wavefront gave up waiting for another one (a hand-over that takes longer than ~a second is a bug, not load):
+// the grid still drains, and the host turns the flag into an error instead of returning a wrong mesh.
+__device__ uint32_t g_chain_timeout;
+constexpr uint32_t kSpinLimit = 1u << 22;
+
+// rare: a source older than the LDS ring (or of an earlier launch), read from the records by vertex id.  Out of line on purpose:
+// the chain's hot loop has to stay small enough for the instruction cache.
+template <typename T>
+__device__ __attribute__((noinline)) uint32_t chain_far_value(const uint8_t *addr, uint32_t id, uint32_t seg_begin, uint32_t *sync)
+{
+	if (id >= seg_begin) {   // this launch's own output: wait for its flush
+		uint32_t spins = 0;
+#pragma nounroll
+		while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= id) {
+			__builtin_amdgcn_s_sleep(2);
+			if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 2u); __hip_atomic_store(&sync[1], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+		}
+	}
+	return (uint32_t)__hip_atomic_load((const T*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct Map3 { int32_t k, A, D; };   // x -> floor((x + A) / 2^k) + D, 0 <= A < 2^k, k <= 16
@@ -1094,24 +1116,32 @@ __device__ __forceinline__ Map3 scan3(Map3 m)
 	return m;
 }
 
+// Several wavefronts share one chain (blockDim.x / 64 of them): wavefront w owns the tiles t = w (mod W).  A tile whose
+// first run depends on the tiles before it only through its predecessor's value is PREPARED (gathers, maps, scan) while
+// the tiles before it are still being finished by the other wavefronts; only "take the predecessor's value, apply the
+// composed maps, verify, publish" is serial.  Hand-over through LDS: sync[0] = number of finished tiles (tiles finish in
+// order), sync[1] = vertices below it have reached global memory.  Every wait is for an earlier tile, whose owner never
+// waits for a later one, so the chain always advances.
 template <typename T>
 __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t seg_end,
                                    const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec, const uint8_t *planes, uint8_t *rec,
-                                   int stride, int off, int q, int plane0, T *ring, uint32_t ring_floor)
+                                   int stride, int off, int q, int plane0, T *ring, uint32_t ring_floor, uint32_t *sync)
 {
 	static_assert(sizeof(T) <= 2 && !(T(-1) < T(0)), "unsigned components of at most 16 bits");
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const uint32_t wv = threadIdx.x >> 6, W = blockDim.x >> 6;
 	constexpr uint32_t mask = kRing3 - 1;
 	const uint32_t top = ev_top<T>(q), wrap = (uint32_t)(T)(~T(0));
-	uint32_t flushed = seg_begin;   // [seg_begin, flushed) have reached the records in global memory
-	auto flush_to = [&](uint32_t upto) {
-		for (uint32_t b = flushed; b < upto; b += 64) { const uint32_t v = b + lane; if (v < upto) stq<T>(rec + (size_t)v * stride + off, ring[v & mask]); }
-		flushed = upto;
-	};
+	const uint32_t t_first = seg_begin & ~63u;
+	// LDS executes a wavefront's accesses in order, so "values, then counter" on one side and "counter, then values" on the
+	// other need no fence -- and must not get one: acquire / release would also wait for vector memory, i.e. for the prefetch
+	// of the next tile, on every hand-over.  Relaxed atomics keep the compiler from caching or reordering the counters.
+	auto tiles_done = [&]() -> uint32_t { uint32_t x = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return x; };
 	// value of a vertex that is final before the current run, wherever it lives
 	auto old_value = [&](uint32_t id, uint32_t cur) -> uint32_t {
+		if (id >= cur) return 0u;   // the chained source of a vertex inside the run: not final yet, and never used from here
 		if (id >= ring_floor && cur - id <= kRing3Near) return (uint32_t)ring[id & mask];
-		return (uint32_t)__hip_atomic_load((const T*)(rec + (size_t)id * stride + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return chain_far_value<T>(rec + (size_t)id * stride + off, id, seg_begin, sync);
 	};
 	uint4 nx_rec = make_uint4(0, 0, 0, 0);
 	uint32_t nx_b0 = 0, nx_b1 = 0;
@@ -1125,28 +1155,41 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		}
 	};
 	// a slice that continues a chain finds the end of the previous slice in the ring again
-	for (uint32_t b = ring_floor; b < seg_begin; b += 64) { const uint32_t v = b + lane; if (v < seg_begin) ring[v & mask] = ldq<T>(rec + (size_t)v * stride + off); }
-	const uint32_t t_first = seg_begin & ~63u;
-	request(t_first);
-	for (uint32_t tb = t_first; tb < seg_end; tb += 64) {
+	for (uint32_t b = ring_floor + 64 * wv; b < seg_begin; b += 64 * W) { const uint32_t v = b + lane; if (v < seg_begin) ring[v & mask] = ldq<T>(rec + (size_t)v * stride + off); }
+	if (threadIdx.x == 0) { sync[0] = 0; sync[1] = seg_begin; }
+	__syncthreads();
+	request(t_first + 64 * wv);
+	for (uint32_t tb = t_first + 64 * wv; tb < seg_end; tb += 64 * W) {
 		const uint4 cr = nx_rec;
 		const uint32_t code = nx_b0 | (nx_b1 << 8);
-		if (tb - flushed >= kFlush3 && tb > flushed) flush_to(tb);
-		if (tb + 64 < seg_end) request(tb + 64);
+		if (tb + 64 * W < seg_end) request(tb + 64 * W);
+		const uint32_t tile_idx = (tb - t_first) >> 6;
+		bool waited = false;
+		auto wait_prev = [&]() {
+			if (waited) return;
+			uint32_t spins = 0;
+#pragma nounroll
+			while (tiles_done() < tile_idx) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } }
+			waited = true;
+		};
 		const uint32_t v = tb + lane;
 		const uint32_t lo = seg_begin > tb ? seg_begin - tb : 0u, hi = min(64u, seg_end - tb);
 		const bool valid = (uint32_t)lane >= lo && (uint32_t)lane < hi;
 		const uint32_t slot0 = cr.x & 0xffffu, slot1 = cr.x >> 16, slot2 = cr.y & 0xffffu, slot3 = cr.y >> 16, slot4 = cr.z & 0xffffu, slot5 = cr.z >> 16;
-		const uint32_t flags = cr.w & 0xffffu;
+		const uint32_t flags = cr.w & 0xffffu, gap = cr.w >> 16;
 		const uint32_t nc = flags & CR_NC, pos = (flags >> CR_POS_SHIFT) & 7u, need_rel = flags >> CR_NEED_SHIFT;
 		const bool far = (flags & CR_FAR) != 0, big = valid && nc == CR_BIG;
+		// every source other than the predecessor lies in a tile this wavefront has already seen finished (<= t - W)
+		const bool settled = gap > (uint32_t)lane + 64u * (W - 1u);
 		const uint64_t bigmask = __ballot(big);
 		UnfoldPre uf;
 		uf.setup(code, top, wrap);
 		uint32_t s = lo;
+		bool first_run = true;
 		while (s < hi) {
 			if ((bigmask >> s) & 1ull) {
 				// more than two candidates: evaluated on its own, candidate k on lane k (table order), or by walking the fan
+				wait_prev();
 				const uint32_t vb = tb + s;
 				const uint32_t n0 = ncand[vb];
 				T pred = T(0);
@@ -1173,6 +1216,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				const T val = cm::value_from_residual<T>((typename cm::word<sizeof(T)>::u)c0, pred, q);
 				if (lane == 0) ring[vb & mask] = val;
 				s += 1;
+				first_run = false;
 				continue;
 			}
 			// the run [s, e): cut before the first vertex that needs a later batch start, or a vertex with more than two candidates
@@ -1180,6 +1224,10 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			const uint64_t cut = __ballot(valid && (need_rel > s || big)) & above;
 			const uint32_t e = cut ? (uint32_t)__builtin_ctzll(cut) : hi;
 			const bool active = (uint32_t)lane >= s && (uint32_t)lane < e;
+			// early: the run can be prepared before the tile before it is finished -- it is the tile's first run, its first
+			// vertex takes its predecessor through the chained source, and no other source of the run is recent
+			const bool early = first_run && !waited && __ballot(active && !settled) == 0ull;
+			if (!early) wait_prev();
 			uint32_t sv0 = ring[slot0], sv1 = ring[slot1], sv2 = ring[slot2], sv3 = ring[slot3], sv4 = ring[slot4], sv5 = ring[slot5];
 			if (__ballot(active && far)) {
 				if (active && far) {   // some source is older than the ring or belongs to an earlier component: by vertex id
@@ -1192,7 +1240,9 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				}
 			}
 			if (nc == 0) { sv0 = sv1 = sv2 = sv3 = sv4 = sv5 = 0; }
-			bool keepl = pos == CR_POS_NONE || (uint32_t)lane == s;
+			// the first vertex of a run reads its predecessor like any older source -- unless the run is prepared early: then
+			// it keeps its map and the predecessor's value enters below
+			bool keepl = pos == CR_POS_NONE || ((uint32_t)lane == s && !early);
 			// exact value of a vertex without a source inside the run
 			const uint32_t p0e = med3_i32((int32_t)(sv0 + sv1 - sv2), 0, (int32_t)top), p1e = med3_i32((int32_t)(sv3 + sv4 - sv5), 0, (int32_t)top);
 			uint32_t v0 = uf.apply((p0e + p1e + 1u) >> 1, top) & wrap;
@@ -1207,10 +1257,14 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			g.k = keepl ? 16 : two ? 1 : 0;
 			g.A = keepl ? 0 : two ? (tsum & 1) : 0;
 			g.D = keepl ? (int32_t)v0 : two ? (tsum >> 1) + (int32_t)uf.delta : bo0 + (int32_t)uf.delta;
-			uint32_t xh = 0;
+			if ((uint32_t)lane < s) { g.k = 0; g.A = 0; g.D = 0; }   // identity below the run
+			uint32_t xh = 0, x_in = 0;
 			for (int attempt = 0;; ++attempt) {
-				xh = (uint32_t)scan3(g).D;
-				const uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xh, 0x138, 0xf, 0xf, false);   // wave_shr:1
+				const Map3 F = scan3(g);
+				if (early && !waited) { wait_prev(); x_in = (uint32_t)ring[(tb + s - 1u) & mask]; }
+				xh = (uint32_t)((((int32_t)x_in + F.A) >> F.k) + F.D);
+				uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xh, 0x138, 0xf, 0xf, false);   // wave_shr:1
+				xp = (uint32_t)lane == s ? x_in : xp;
 				const uint32_t p0 = med3_i32((int32_t)(xp + (uint32_t)bo0), 0, (int32_t)top);
 				const uint32_t pred = two ? (p0 + p1c + 1u) >> 1 : p0;
 				const uint32_t tv = keepl ? v0 : (uf.apply(pred, top) & wrap);
@@ -1232,32 +1286,47 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			}
 			if (active) ring[v & mask] = (T)xh;
 			s = e;
+			first_run = false;
+		}
+		// the tile is finished: its values are in the ring before the counter moves (release)
+		wait_prev();
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring writes of this tile have executed
+		if (lane == 0) __hip_atomic_fetch_max(&sync[0], tile_idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // max: an aborted chain keeps its "everything done" mark
+		// every 64 tiles, and at the end, the owner of the tile sends the finished values to the records
+		const bool last_tile = tb + 64 >= seg_end;
+		if (((tile_idx + 1u) & 63u) == 0u || last_tile) {
+			const uint32_t upto = min(tb + 64u, seg_end);
+			const uint32_t from = max(seg_begin, t_first + ((tile_idx + 1u - 1u) & ~63u) * 64u);
+			for (uint32_t b = from; b < upto; b += 64) { const uint32_t u = b + lane; if (u < upto) stq<T>(rec + (size_t)u * stride + off, ring[u & mask]); }
+			__threadfence();   // the stores have reached the device's coherence point (far readers load past their L1)
+			if (lane == 0) __hip_atomic_fetch_max(&sync[1], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // flushes of different wavefronts may finish out of order
 		}
 	}
-	flush_to(seg_end);
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void k_unpredict3(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
+__global__ __launch_bounds__(512) void k_unpredict3(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
                                                    const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, const uint32_t *segs, const uint32_t *list_off)
 {
 	__shared__ T ring3[kRing3];
+	__shared__ uint32_t sync3[2];
 	const int c = sel.comp[blockIdx.x];
 	TopoD tp{ cv };
 	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
 		const uint32_t b = segs[2 * k], e = segs[2 * k + 1];
-		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, b);
+		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, b, sync3);
 		__syncthreads();
 	}
 }
 template <typename T>
-__global__ __launch_bounds__(64) void k_unpredict3_range(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
+__global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
                                                          const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, uint32_t v_begin, uint32_t v_end, uint32_t ring_floor)
 {
 	__shared__ T ring3[kRing3];
+	__shared__ uint32_t sync3[2];
 	const int c = sel.comp[blockIdx.x];
 	TopoD tp{ cv };
-	unpredict3_segment<T>(tp, order_v, nvtx, v_begin, v_end, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, ring_floor);
+	unpredict3_segment<T>(tp, order_v, nvtx, v_begin, v_end, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, ring_floor, sync3);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1312,7 +1381,21 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 {
 	if (nvtx) hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand);
 }
+// wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8, default 4
+static uint32_t chain_waves()
+{
+	static const uint32_t w = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
+	return w;
+}
 // ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
+uint32_t chain_timeout_flags(hipStream_t st)
+{
+	uint32_t f = 0, zero = 0;
+	if (hipMemcpyFromSymbolAsync(&f, HIP_SYMBOL(g_chain_timeout), 4, 0, hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
+	(void)hipStreamSynchronize(st);
+	if (f) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chain_timeout), &zero, 4, 0, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
+	return f;
+}
 uint32_t chain_ring_floor(uint32_t v_begin) { return v_begin > kRing3Near ? v_begin - kRing3Near : 0u; }
 bool unpredict3_covers(const ListDesc &ld)
 {
@@ -1334,7 +1417,7 @@ void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *orde
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		hipLaunchKernelGGL(kern, dim3(sel.n), dim3(64), 0, st, cv, order_v, nvtx, cand, ncand, (const ChainRec*)crec, planes, ld, rec, sel, v_begin, v_end, chain_ring_floor(v_begin));
+		hipLaunchKernelGGL(kern, dim3(sel.n), dim3(64 * chain_waves()), 0, st, cv, order_v, nvtx, cand, ncand, (const ChainRec*)crec, planes, ld, rec, sel, v_begin, v_end, chain_ring_floor(v_begin));
 	};
 	go3(k_unpredict3_range<uint16_t>, 6); go3(k_unpredict3_range<uint8_t>, 8);
 }
@@ -1357,7 +1440,7 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
+		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64 * chain_waves()), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
 		                   segs, list_off);
 	};
 	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + kQueue * kQueueCols * 4;
