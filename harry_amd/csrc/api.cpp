@@ -225,7 +225,9 @@ int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_wal
 		size_t hdr = read_hry_header((const uint8_t*)hry, bytes, m->m, minor);
 		if (minor != 1) throw Error(HRY_E_ARG, "not a single-stream (v0.1) file");
 		std::vector<uint32_t> seg_start, seg_level;
-		read_compat_stream((const uint8_t*)hry + hdr, bytes - hdr, m->m, w->w.order_v, seg_start, seg_level, w->vplanes, w->fplanes);
+		std::vector<uint32_t> order_v;
+		read_compat_stream((const uint8_t*)hry + hdr, bytes - hdr, m->m, order_v, seg_start, seg_level, w->vplanes, w->fplanes);
+		w->w.order_v.assign(order_v.begin(), order_v.end());
 		w->info[0] = w->info[1] = 0;
 		*mesh = m.release();
 		*out = w.release();
@@ -254,7 +256,9 @@ int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_p
 		m->m.nv = src->m.nv; m->m.nf = src->m.nf; m->m.declared_ne = src->m.ne(); m->m.have_degree = src->m.have_degree;
 		std::vector<RestartPoint> restarts;
 		if (use_restart_points) restarts = select_restart_points(r.marks);
-		cut_border_replay(m->m, planes, restarts, w->w.order_v, w->seg_start, w->seg_level);
+		std::vector<uint32_t> order_v;
+		cut_border_replay(m->m, planes, restarts, order_v, w->seg_start, w->seg_level);
+		w->w.order_v.assign(order_v.begin(), order_v.end());
 		w->info[0] = (uint32_t)restarts.size(); w->info[1] = 0;
 		*mesh = m.release();
 		*out = w.release();

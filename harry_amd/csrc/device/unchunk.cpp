@@ -207,11 +207,11 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	cx.res_has_eface = false; cx.res_udeg = (uint32_t)ud; cx.res_nv = nv; cx.res_nf = nf; cx.res_ne = ne;
 	const ConnView cv = cx.conn_view();
 
-	m->face_off.assign((size_t)nf + 1, 0);
-	m->org.assign(ne, 0);
-	m->twin.assign(ne, 0);
+	m->face_off.resize((size_t)nf + 1); m->face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
+	m->org.resize(ne);
+	m->twin.resize(ne);
 	order_v.assign(nv, 0);
-	std::vector<uint16_t> seen(nv, 0);
+	BigVec<uint16_t> seen(nv, 0);
 	ReplayLive live;
 	live.on_border.assign(nv, 0);
 	live.pending.reserve(1 << 16);

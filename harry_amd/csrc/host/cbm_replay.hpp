@@ -126,7 +126,7 @@ struct ReplayLive {
 	Pub pub;                                   // guarded by mu
 	std::vector<uint32_t> patches;             // guarded by mu: (half-edge, twin) pairs since the consumer last took them
 	// producer side
-	std::vector<uint16_t> on_border;
+	BigVec<uint16_t> on_border;
 	std::vector<uint32_t> pending;             // patches since the last publication
 	uint32_t interval = 8192, face_pub = 0, he_pub = 0, min_open = 0;
 	void link(uint32_t a, uint32_t b)
@@ -376,11 +376,11 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCurso
 template <class RD>
 void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
 {
-	m.face_off.assign((size_t)m.nf + 1, 0);
-	m.org.assign(m.declared_ne, 0);
-	m.twin.assign(m.declared_ne, 0);
+	m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
+	m.org.resize(m.declared_ne);
+	m.twin.resize(m.declared_ne);
 	order_v.assign(m.nv, 0);
-	std::vector<uint16_t> seen(m.nv, 0);
+	BigVec<uint16_t> seen(m.nv, 0);
 	ReplayCursor cur;
 	const std::vector<uint32_t> none;
 	seg_start.clear(); seg_level.clear();

@@ -75,11 +75,11 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry replay] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	if (trace) { size_t nfl = 0; uint64_t ffl = 0; for (size_t k = 0; k < ns; ++k) if (spans[k].flagged) { ++nfl; ffl += (k + 1 < ns ? restarts[k].first_face : m.nf) - spans[k].cur.face; }
 		fprintf(stderr, "[hry replay] %zu spans, %zu flagged holding %llu of %u faces\n", ns, nfl, (unsigned long long)ffl, m.nf); }
-	m.face_off.assign((size_t)m.nf + 1, 0);
-	m.org.assign(m.declared_ne, 0);
-	m.twin.assign(m.declared_ne, 0);
+	m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
+	m.org.resize(m.declared_ne);
+	m.twin.resize(m.declared_ne);
 	order_v.assign(m.nv, 0);
-	std::vector<uint16_t> seen(m.nv, 0);
+	BigVec<uint16_t> seen(m.nv, 0);
 	const std::vector<uint32_t> none;
 	mark("allocated");
 	// a span must end exactly where the next one starts, in every counter

@@ -34,9 +34,9 @@ struct Border {
 	std::vector<Node> pool;
 	std::vector<int32_t> spare;
 	std::vector<Part> parts;
-	std::vector<uint8_t> &on;  // how many border elements reference a vertex (cutborder.h:69); shared per-vertex array
+	BigVec<uint8_t> &on;  // how many border elements reference a vertex (cutborder.h:69); shared per-vertex array
 
-	explicit Border(std::vector<uint8_t> &on_) : on(on_) { pool.reserve(1024); }
+	explicit Border(BigVec<uint8_t> &on_) : on(on_) { pool.reserve(1024); }
 	Part &top() { return parts.back(); }
 	Node &N(int32_t i) { return pool[i]; }
 
@@ -181,12 +181,12 @@ struct Border {
 struct StartFaces {
 	struct Block { uint32_t first, last; };   // consecutive keys in list order: ascending if first <= last, else descending
 	uint32_t nf;
-	std::vector<uint8_t> &gone;
+	BigVec<uint8_t> &gone;
 	std::vector<Block> blocks;
 	size_t bi = 0;
 	uint32_t pos = 0;
 	bool have_order = false;
-	StartFaces(uint32_t n, std::vector<uint8_t> &gone_) : nf(n), gone(gone_) {}
+	StartFaces(uint32_t n, BigVec<uint8_t> &gone_) : nf(n), gone(gone_) {}
 	void derive_order()
 	{
 		std::__detail::_Prime_rehash_policy pol;
@@ -308,10 +308,10 @@ struct Emitter {
 // vertices unless they share a (non-manifold) vertex, so several components can be walked at the same time on
 // these arrays as long as components that share a vertex are walked in coding order by one thread.
 struct WalkState {
-	std::vector<uint8_t> gone;      // face consumed
-	std::vector<uint8_t> on;        // how many border elements reference a vertex (cutborder.h:69)
-	std::vector<uint32_t> sent;     // original vertex -> transmitted index (encoder.h:28-52)
-	std::vector<uint16_t> seen;     // triangles seen per vertex (selects the op model class)
+	BigVec<uint8_t> gone;      // face consumed
+	BigVec<uint8_t> on;        // how many border elements reference a vertex (cutborder.h:69)
+	BigVec<uint32_t> sent;     // original vertex -> transmitted index (encoder.h:28-52)
+	BigVec<uint16_t> seen;     // triangles seen per vertex (selects the op model class)
 	WalkState(uint32_t nv, uint32_t nf) : gone(nf, 0), on(nv, 0), sent(nv, NONE32), seen(nv, 0) {}
 };
 

@@ -53,15 +53,15 @@ constexpr uint32_t kRestartWords = G_COUNT + 8 + 4;
 std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks);
 
 struct WalkResult {
-	std::vector<uint32_t> order_v;   // one half-edge per coded vertex, in coding order (attrcode.h:297,310-314)
-	std::vector<uint32_t> order_f;   // one half-edge per face, in coding order (attrcode.h:298,315-319)
+	BigVec<uint32_t> order_v;   // one half-edge per coded vertex, in coding order (attrcode.h:297,310-314)
+	BigVec<uint32_t> order_f;   // one half-edge per face, in coding order (attrcode.h:298,315-319)
 	// connectivity symbols: values (low byte first, one entry per symbol) + position in the global symbol sequence
-	std::vector<uint32_t> grp_val[G_COUNT];
-	std::vector<uint32_t> grp_pos[G_COUNT];
+	BigVec<uint32_t> grp_val[G_COUNT];
+	BigVec<uint32_t> grp_pos[G_COUNT];
 	// cut-border operations: raw symbol + order class, and the order-conditioned model already evaluated
 	// (models.h:91-119) as cumulative-frequency triples
-	std::vector<uint8_t> op_sym, op_class;
-	std::vector<uint32_t> op_l, op_h, op_t, op_pos;
+	BigVec<uint8_t> op_sym, op_class;
+	BigVec<uint32_t> op_l, op_h, op_t, op_pos;
 	std::vector<ComponentMark> marks; // one per connected component, in coding order
 	uint32_t n_conn = 0;             // symbols in the connectivity part of the global sequence
 	bool numtri_coded = false;       // false when a single polygon degree makes every numtri symbol an exact no-op

@@ -5,9 +5,42 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace hry {
+
+// ---- big host arrays -------------------------------------------------------------------------------------------------
+// The connectivity, the attribute records and the walk's outputs are tens of megabytes per million triangles and are
+// allocated by every call.  From the C library such blocks are mmap'ed fresh each time: one page fault per 4 KiB on first
+// touch (4.5 ms of a 20 ms decode went there).  They come from a small recycling pool instead -- a freed block keeps its
+// pages and serves the next request of a similar size -- and vectors of them do not value-initialise on resize (every
+// element is written before it is read; callers that need zeros say assign(n, 0)).
+struct BlockPool {
+	static void *take(size_t bytes);            // 64-byte aligned, capacity >= bytes
+	static void give(void *p) noexcept;         // back to the pool (or to the C library when the pool is full)
+	static constexpr size_t kMinBytes = 256u << 10;   // smaller requests bypass the pool
+};
+template <typename T> struct PoolAlloc {
+	typedef T value_type;
+	PoolAlloc() noexcept {}
+	template <typename U> PoolAlloc(const PoolAlloc<U>&) noexcept {}
+	T *allocate(size_t n)
+	{
+		const size_t bytes = n * sizeof(T);
+		void *p = bytes >= BlockPool::kMinBytes ? BlockPool::take(bytes) : ::operator new(bytes);
+		return (T*)p;
+	}
+	void deallocate(T *p, size_t n) noexcept
+	{
+		if (n * sizeof(T) >= BlockPool::kMinBytes) BlockPool::give(p); else ::operator delete(p);
+	}
+	template <typename U> void construct(U *p) noexcept { ::new ((void*)p) U; }   // default-init: no fill on resize()
+	template <typename U, typename A0, typename... As> void construct(U *p, A0 &&a0, As &&... as) { ::new ((void*)p) U(std::forward<A0>(a0), std::forward<As>(as)...); }
+	template <typename U> bool operator==(const PoolAlloc<U>&) const noexcept { return true; }
+	template <typename U> bool operator!=(const PoolAlloc<U>&) const noexcept { return false; }
+};
+template <typename T> using BigVec = std::vector<T, PoolAlloc<T>>;
 
 struct Error : std::runtime_error {
 	int code;
@@ -35,7 +68,7 @@ struct AttrList {
 	std::vector<int> interp_off, interp_len;   // indexed by interpretation id
 	std::vector<std::string> interp_name;      // id - kInterpOther
 	uint32_t count = 0;
-	std::vector<uint8_t> data;
+	BigVec<uint8_t> data;
 	std::vector<uint8_t> bmin, bmax;       // records in original types; empty until computed
 	bool have_bounds = false;
 
@@ -63,9 +96,9 @@ struct AttrList {
 
 struct Mesh {
 	uint32_t nv = 0, nf = 0;
-	std::vector<uint32_t> face_off{0};   // nf + 1
-	std::vector<uint32_t> org;           // per half-edge
-	std::vector<uint32_t> twin;          // per half-edge, flat id; self = border
+	BigVec<uint32_t> face_off{0};        // nf + 1
+	BigVec<uint32_t> org;                // per half-edge
+	BigVec<uint32_t> twin;               // per half-edge, flat id; self = border
 	std::vector<uint8_t> have_degree;    // have_degree[d] != 0 iff a polygon with d edges exists (faces.h:44-56)
 	AttrList lists[2];                   // [0] face attributes, [1] vertex attributes (formats/ply/reader.cc:388-400)
 	uint64_t device_token = 0;           // identity of the HBM-resident copy, 0 = none
