@@ -85,8 +85,17 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 
 	// ---- connectivity planes on the host side: 5 groups (split into bytes on the device) + 8 operation planes
 	auto t_h2d = Clock::now();
-	std::vector<uint8_t> op_planes[8];
-	for (size_t i = 0; i < w.op_sym.size(); ++i) op_planes[w.op_class[i]].push_back(w.op_sym[i]);
+	BigVec<uint8_t> op_planes[8];
+	{
+		// one plane per order class: sizes first, then one pass through bare pointers (a million push_backs cost 2 ms)
+		size_t cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		const size_t nop = w.op_sym.size();
+		const uint8_t *cls = w.op_class.data(), *sym = w.op_sym.data();
+		for (size_t i = 0; i < nop; ++i) ++cnt[cls[i] & 7];
+		uint8_t *dst[8];
+		for (int k = 0; k < 8; ++k) { op_planes[k].resize(cnt[k]); dst[k] = op_planes[k].data(); }
+		for (size_t i = 0; i < nop; ++i) *dst[cls[i] & 7]++ = sym[i];
+	}
 	size_t ngrp = 0, conn_plane_bytes = 0, nopb = w.op_sym.size();
 	for (int g = 0; g < G_COUNT; ++g) { ngrp += w.grp_val[g].size(); conn_plane_bytes += w.grp_val[g].size() * kGroupBytes[g]; }
 	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
@@ -97,8 +106,9 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	cx.d_vplanes.ensure(std::max<size_t>((size_t)vc * ldv.nplanes, 16));
 	cx.d_fplanes.ensure(std::max<size_t>((size_t)fc * ldf.nplanes, 16));
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
-	if (fc) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));
-	HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
+	if (fc && ldf.nplanes) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));   // only the face planes read it
+	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
+	if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
 	size_t goff[G_COUNT + 1] = { 0 };
 	for (int g = 0; g < G_COUNT; ++g) {
 		size_t n = w.grp_val[g].size();

@@ -407,7 +407,8 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
 	if (fc) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));
-	HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));   // repaired twins (encoder.h:150,193-198)
+	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
+	if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));   // repaired twins (encoder.h:150,193-198)
 	// connectivity groups: values + positions, packed back to back
 	size_t ngrp = 0;
 	for (int g = 0; g < G_COUNT; ++g) ngrp += w.grp_val[g].size();

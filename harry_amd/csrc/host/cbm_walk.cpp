@@ -333,7 +333,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 		uint32_t fe = eface_tab[e];
 		return e + 1 == foff[fe + 1] ? foff[fe] : e + 1;
 	};
-	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; };
+	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; w.twins_changed = true; };
 	auto record_vertex = [&](uint32_t e) { w.order_v.push_back(e); sent[org[e]] = next_id++; };
 	auto take = [&](uint32_t face) { gone[face] = 1; ++consumed; em.halfedges += foff[face + 1] - foff[face]; };
 
@@ -370,7 +370,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 			uint32_t t = twin[gate];
 			if (t == gate || gone[face_of(t)]) {   // writer.cc:48-58: mesh border or neighbour already consumed
 				Op bop = cb.border();
-				if (t != gate) twin[gate] = gate;       // one-sided split (writer.cc:81-84)
+				if (t != gate) { twin[gate] = gate; w.twins_changed = true; }   // one-sided split (writer.cc:81-84)
 				em.op(bop, order);
 				continue;
 			}
@@ -681,6 +681,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	w.op_sym.resize(off_op[ncomp]); w.op_class.resize(off_op[ncomp]);
 	for (int g = 0; g < G_COUNT; ++g) { w.grp_val[g].resize(off_g[g][ncomp]); w.grp_pos[g].resize(off_g[g][ncomp]); }
 	std::atomic<uint32_t> next_frag{ 0 };
+	std::atomic<bool> changed_any{ false };
 	parallel_for(n_threads, [&](unsigned) {
 		for (;;) {
 			uint32_t k = next_frag.fetch_add(1, std::memory_order_relaxed);
@@ -697,8 +698,10 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 				for (size_t i = 0; i < fw.grp_pos[g].size(); ++i) dst[i] = fw.grp_pos[g][i] + add;
 			}
 			WalkResult().order_v.swap(fw.order_v);   // release early
+			if (fw.twins_changed) changed_any.store(true, std::memory_order_relaxed);
 		}
 	});
+	if (changed_any.load()) w.twins_changed = true;
 	// marks: every fragment holds exactly one (its component), relative to the fragment; make it absolute
 	em0.finish_marks();
 	{

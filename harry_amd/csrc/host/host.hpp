@@ -65,6 +65,7 @@ struct WalkResult {
 	std::vector<ComponentMark> marks; // one per connected component, in coding order
 	uint32_t n_conn = 0;             // symbols in the connectivity part of the global sequence
 	bool numtri_coded = false;       // false when a single polygon degree makes every numtri symbol an exact no-op
+	bool twins_changed = false;      // the walk repaired at least one twin (cbm/encoder.h:150,193-198): the device copy is stale
 };
 
 // ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
