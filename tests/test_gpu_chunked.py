@@ -132,6 +132,33 @@ def test_chunked_pipelined_decode(cx, case, faces, slice_, monkeypatch):
     assert np.array_equal(piped.twin(), plain.twin())
 
 
+def test_headline_workload_full_size(cx):
+    """BASELINE configs[1] at its full size (closed torus 708 x 708 = 1 002 528 triangles, -l1 -q14), every default of the
+    product path: threaded walk, pipelined decode, wavefront team on the reconstruction chain.
+    * compat profile: the .hry bytes equal the CPU oracle's (= the reference's, byte-pinned on the committed fixtures);
+    * chunked profile: the container equals the oracle's restatement of it, and the GPU decode equals the oracle's decode of
+      the reference-format stream array for array;
+    * size-independent property: the multiset of decoded vertex records equals the multiset of quantised input records."""
+    mesh = mg.torus(708, 708, seed=2, sigma=1e-4)
+    ply = mesh.to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    quant = [(1, -1, 14)]
+    cx.requant(a, quant)
+    o.requant(quant)
+    q_in = a.list_data(1).reshape(a.nv, -1).view(np.uint16)[:, ::2].astype(np.uint64)   # quantised values, low half of each slot
+    compat_ref = o.clone().encode().data
+    assert cx.write_hry(a.clone(), profile=hc.PROFILE_COMPAT, flags=hc.FLAG_HOST_RECURRENCE) == compat_ref
+    ref_dec = op.Mesh.from_hry(compat_ref)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
+    assert got == o.clone().encode_chunked(0).data
+    dec = cx.read_hry(got)
+    same_mesh(dec, ref_dec)
+    same_mesh(cx.read_hry(compat_ref), ref_dec)     # the reference-format stream through the device reconstruction
+    q_out = dec.list_data(1).reshape(dec.nv, -1).view(np.uint16)[:, ::2].astype(np.uint64)
+    key = lambda q: np.sort((q[:, 0] << 28) | (q[:, 1] << 14) | q[:, 2])
+    assert np.array_equal(key(q_in), key(q_out))
+
+
 def test_chunked_entropy_decode_planes(cx):
     """k_chunk_decode inverts k_chunk_encode symbol for symbol (checked before any mesh logic)."""
     m = mg.torus(64, 60, polys="mixed", normals=True)
