@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void k_chunk_encode(const StreamJob *jobs, cons
 		// serial recurrence over the batch (coder.h:69-91 without the low register), uniform: lives in scalar registers
 		uint32_t my_r = 0, my_s = 0;
 		const uint32_t s_first = S;
-		for (uint32_t i = 0; i < nb; ++i) {
+		auto step = [&](uint32_t i) {
 			const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)me.m32, (int)i);
 			const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)mx, (int)i);
 			const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)mm, (int)i);
@@ -101,7 +101,12 @@ __global__ __launch_bounds__(64) void k_chunk_encode(const StreamJob *jobs, cons
 			my_s = lane == (int)i ? S : my_s;
 			R = Rn << sh;
 			S += sh;
-		}
+		};
+		// unrolled by hand: a taken branch costs a lone wavefront more than the few instructions of a step (the decoder's
+		// step is four times as long: unrolling it measured slower)
+		uint32_t i = 0;
+		for (; i + 4 <= nb; i += 4) { step(i); step(i + 1); step(i + 2); step(i + 3); }
+		for (; i < nb; ++i) step(i);
 		// low register: L += r * l at bit position my_s (coder.h:71); r l <= R fits 32 bits
 		const uint32_t w0 = s_first >> 5, span = ((S + 63) >> 5) - w0 + 1;   // <= 64 words
 		const uint32_t a = (valid && l) ? my_r * l : 0u;
