@@ -1182,6 +1182,14 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		// every source other than the predecessor lies in a tile this wavefront has already seen finished (<= t - W)
 		const bool settled = gap > (uint32_t)lane + 64u * (W - 1u);
 		const uint64_t bigmask = __ballot(big);
+		// the candidate rows of the tile's first vertex with more than two candidates are fetched now, ahead of the chain: a
+		// global load on the serial path otherwise (0.18 such vertices per tile)
+		const uint32_t big0 = bigmask ? (uint32_t)__builtin_ctzll(bigmask) : 64u;
+		uint32_t pf_n = 0, pf_a = 0, pf_b = 0, pf_o = 0;
+		if (big0 < 64u) {
+			pf_n = ncand[tb + big0];
+			if (lane < kCandMax) { const uint32_t *row = cand + (size_t)(tb + big0) * (kCandMax * 3) + 3 * lane; pf_a = row[0]; pf_b = row[1]; pf_o = row[2]; }
+		}
 		UnfoldPre uf;
 		uf.setup(code, top, wrap);
 		uint32_t s = lo;
@@ -1191,13 +1199,14 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				// more than two candidates: evaluated on its own, candidate k on lane k (table order), or by walking the fan
 				wait_prev();
 				const uint32_t vb = tb + s;
-				const uint32_t n0 = ncand[vb];
+				const uint32_t n0 = s == big0 ? pf_n : (uint32_t)ncand[vb];
 				T pred = T(0);
 				if (n0 != 0xff) {
 					uint32_t pk = 0;
 					if ((uint32_t)lane < n0) {
-						const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
-						pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
+						uint32_t ia = pf_a, ib = pf_b, io = pf_o;
+						if (s != big0) { const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane; ia = row[0]; ib = row[1]; io = row[2]; }
+						pk = (uint32_t)cm::parallelogram<T>((T)old_value(ia, vb), (T)old_value(ib, vb), (T)old_value(io, vb), q);
 					}
 					T pv[kCandMax];
 #pragma unroll
