@@ -210,6 +210,38 @@ def test_decode_rejects_corrupt_input(cx):
         cx.read_hry(bytes(bad))
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_decode_survives_damaged_payload(cx, pipelined, monkeypatch):
+    """Flipped bytes anywhere behind the header: the decoder either reports an error or returns some mesh -- it must neither
+    crash, nor hang (the wavefront hand-overs of the chain are bounded), nor leave the context unusable.  Both pipelines."""
+    mesh = mg.torus(70, 64, seed=5)
+    a = hc.Mesh.from_ply(mesh.to_ply())
+    cx.requant(a, [(1, -1, 12)])
+    good = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=2048)
+    if pipelined:
+        monkeypatch.setenv("HRY_PIPELINE_MIN_VERTICES", "0")
+        monkeypatch.setenv("HRY_PIPELINE_FACES", "256")
+        monkeypatch.setenv("HRY_PIPELINE_SLICE", "512")
+    else:
+        monkeypatch.setenv("HRY_NO_PIPELINE", "1")
+    ref = cx.read_hry(good)
+    rng = np.random.default_rng(11)
+    hdr = 200   # well inside the directory for this mesh; the header itself is covered by test_decode_rejects_corrupt_input
+    outcomes = {"error": 0, "mesh": 0}
+    for trial in range(24):
+        bad = bytearray(good)
+        for _ in range(1 + trial % 4):
+            k = int(rng.integers(hdr, len(bad)))
+            bad[k] ^= int(rng.integers(1, 256))
+        try:
+            cx.read_hry(bytes(bad))
+            outcomes["mesh"] += 1
+        except hc.HryError:
+            outcomes["error"] += 1
+    assert outcomes["error"] + outcomes["mesh"] == 24
+    same_mesh(cx.read_hry(good), ref)   # the context still decodes the intact stream
+
+
 def with_integer_props(m: mg.Mesh, seed=7) -> mg.Mesh:
     """Smooth integer-valued vertex properties of every PLY integer type next to the float coordinates."""
     rng = np.random.default_rng(seed)
