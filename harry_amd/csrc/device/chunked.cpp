@@ -1,7 +1,8 @@
 // Chunked profile (.hry v0.2) pipeline: encode and decode.
 //
 // Container (after the v0.1-compatible header with minor version 2):
-//     u32 chunk_syms, u32 n_planes, n_planes x u32 n_symbols, n_streams x u32 n_bytes, streams back to back
+//     u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols, n_planes x static prior, restart points,
+//     n_streams x u32 n_bytes, streams back to back
 // Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
 // Every (plane, chunk of chunk_syms symbols) is one stream: fresh adaptive model (the reference's initial counts,
 // models.h:197-218 / model.h:38-55), fresh coder with 32-bit registers (arith::Encoder<uint32_t>), 32-bit flush (arith/coder.h).  Symbols that carry no
@@ -21,7 +22,7 @@ typedef std::chrono::steady_clock Clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
-static constexpr int kDefaultChunk = 32768;
+static constexpr int kDefaultChunk = 8192;   // with static priors a fresh table per chunk costs little: short chunks = short serial chains
 static constexpr uint32_t kMaxChunk = 1u << 20;   // totals stay below 2^21: far inside the 32-bit coder's t <= 2^30 (oracle: same clamp)
 
 static void build_inits(const Mesh &m, std::vector<uint32_t> &tabs, uint32_t totals[INIT_KINDS])
@@ -139,43 +140,24 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 		for (int p = 0; p < ldv.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_vplanes.as<uint8_t>() + (size_t)p * vc, vc, INIT_ONES });
 		for (int p = 0; p < ldf.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_fplanes.as<uint8_t>() + (size_t)p * fc, fc, INIT_ONES });
 	}
-	std::vector<uint32_t> inits;
-	uint32_t totals[INIT_KINDS];
-	build_inits(m, inits, totals);
-	std::vector<StreamJob> jobs;
-	uint64_t words = 0;
-	uint64_t nsym_total = 0;
-	// connectivity planes are cut shorter: the decoder needs them first and a stream is a serial chain (container
-	// description: oracle/hry_oracle.cc "chunked profile", DESIGN.md section 3)
+	std::vector<uint32_t> kind_tabs;
+	uint32_t kind_totals[INIT_KINDS];
+	build_inits(m, kind_tabs, kind_totals);
 	const uint32_t CHC = std::min(CH, std::max(CH / 8, 512u));
-	for (size_t pi = 0; pi < planes.size(); ++pi) {
-		const PlaneRef &pl = planes[pi];
-		const uint32_t step = pi < (size_t)kConnPlanes ? CHC : CH;
-		nsym_total += pl.n;
-		for (uint32_t f = 0; f < pl.n; f += step) {
-			uint32_t n = std::min(step, pl.n - f);
-			if (words >= (1ull << 32) - (1u << 24)) throw Error(HRY_E_UNSUPPORTED, "chunked stream accumulator exceeds 2^32 words");
-			jobs.push_back(StreamJob{ pl.dptr + f, n, (uint32_t)pl.init, totals[pl.init], (uint32_t)words });
-			words += stream_words(n, totals[pl.init]);
-		}
-	}
-	const uint32_t ns = (uint32_t)jobs.size();
-	const uint32_t nw = (uint32_t)words + 2;
-	cx.d_init.ensure(inits.size() * 4);
-	HIP_OK(hipMemcpyAsync(cx.d_init.p, inits.data(), inits.size() * 4, hipMemcpyHostToDevice, cx.stream));
-	cx.d_cjobs.ensure(std::max<size_t>((size_t)ns * sizeof(StreamJob), 16));
-	if (ns) HIP_OK(hipMemcpyAsync(cx.d_cjobs.p, jobs.data(), (size_t)ns * sizeof(StreamJob), hipMemcpyHostToDevice, cx.stream));
-	cx.ensure_magic(256 + CH + 16);
-	cx.d_acc.ensure((size_t)nw * 8);
-	cx.d_v.ensure((size_t)nw * 8);
-	cx.d_summary.ensure(((size_t)nw / 1024 + 2) * 4);
-	cx.d_bytes.ensure((size_t)nw * 4);
-	cx.d_csizes.ensure(std::max<size_t>((size_t)ns * 8, 16));   // bits | nbytes
-	cx.d_coffs.ensure(((size_t)ns + 1) * 8);
+	const uint32_t npl = (uint32_t)planes.size();
+	// slices of the planes for the histogram pass
+	std::vector<HistSlice> slices;
+	for (uint32_t pi = 0; pi < npl; ++pi)
+		for (uint32_t f = 0; f < planes[pi].n; f += 16384) slices.push_back(HistSlice{ planes[pi].dptr + f, std::min(16384u, planes[pi].n - f), pi });
+	cx.d_small.ensure(std::max<size_t>(slices.size() * sizeof(HistSlice) + (size_t)npl * 1024 + 64, 64));
+	uint32_t *d_hist = cx.d_small.as<uint32_t>();
+	HistSlice *d_slices = (HistSlice*)(cx.d_small.as<uint8_t>() + (size_t)npl * 1024);
+	if (!slices.empty()) HIP_OK(hipMemcpyAsync(d_slices, slices.data(), slices.size() * sizeof(HistSlice), hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipMemsetAsync(d_hist, 0, (size_t)npl * 1024, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	cx.timing.h2d_ms = ms_since(t_h2d);
 
-	// ---- device: prediction + residuals + planes
+	// ---- device: prediction + residuals + planes, then the planes' histograms
 	ConnView cv = cx.conn_view();
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
 	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m.nv * 4, cx.stream));
@@ -190,7 +172,54 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 			poff += (size_t)n * kGroupBytes[g];
 		}
 	}
+	launch_plane_hist(cx.stream, d_slices, (uint32_t)slices.size(), d_hist);
 	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
+	std::vector<uint32_t> hist((size_t)npl * 256);
+	if (npl) HIP_OK(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+
+	// ---- initial table of every plane: its static prior, or the reference's initial counts for short planes
+	std::vector<uint32_t> inits((size_t)npl * 256);
+	std::vector<uint32_t> totals(npl, 0);
+	std::vector<uint8_t> prior_dir;
+	for (uint32_t pi = 0; pi < npl; ++pi) {
+		uint32_t *tab = inits.data() + (size_t)pi * 256;
+		const bool use = plane_prior_from_hist(hist.data() + (size_t)pi * 256, planes[pi].n, tab);
+		if (!use) memcpy(tab, kind_tabs.data() + (size_t)planes[pi].init * 256, 1024);
+		for (int i = 0; i < 256; ++i) totals[pi] += tab[i];
+		write_prior(prior_dir, use, tab);
+	}
+	std::vector<StreamJob> jobs;
+	uint64_t words = 0;
+	uint64_t nsym_total = 0;
+	uint32_t max_t0 = 256;
+	// connectivity planes are cut shorter: the decoder needs them first and a stream is a serial chain (container
+	// description: oracle/hry_oracle.cc "chunked profile", DESIGN.md section 3)
+	for (uint32_t pi = 0; pi < npl; ++pi) {
+		const PlaneRef &pl = planes[pi];
+		const uint32_t step = pi < (uint32_t)kConnPlanes ? CHC : CH;
+		nsym_total += pl.n;
+		max_t0 = std::max(max_t0, totals[pi]);
+		for (uint32_t f = 0; f < pl.n; f += step) {
+			uint32_t n = std::min(step, pl.n - f);
+			if (words >= (1ull << 32) - (1u << 24)) throw Error(HRY_E_UNSUPPORTED, "chunked stream accumulator exceeds 2^32 words");
+			jobs.push_back(StreamJob{ pl.dptr + f, n, pi, totals[pi], (uint32_t)words });
+			words += stream_words(n, totals[pi]);
+		}
+	}
+	const uint32_t ns = (uint32_t)jobs.size();
+	const uint32_t nw = (uint32_t)words + 2;
+	cx.d_init.ensure(std::max<size_t>(inits.size() * 4, 16));
+	if (!inits.empty()) HIP_OK(hipMemcpyAsync(cx.d_init.p, inits.data(), inits.size() * 4, hipMemcpyHostToDevice, cx.stream));
+	cx.d_cjobs.ensure(std::max<size_t>((size_t)ns * sizeof(StreamJob), 16));
+	if (ns) HIP_OK(hipMemcpyAsync(cx.d_cjobs.p, jobs.data(), (size_t)ns * sizeof(StreamJob), hipMemcpyHostToDevice, cx.stream));
+	cx.ensure_magic(max_t0 + CH + 16);
+	cx.d_acc.ensure((size_t)nw * 8);
+	cx.d_v.ensure((size_t)nw * 8);
+	cx.d_summary.ensure(((size_t)nw / 1024 + 2) * 4);
+	cx.d_bytes.ensure((size_t)nw * 4);
+	cx.d_csizes.ensure(std::max<size_t>((size_t)ns * 8, 16));   // bits | nbytes
+	cx.d_coffs.ensure(((size_t)ns + 1) * 8);
 	// ---- device: one wavefront per stream
 	HIP_OK(hipMemsetAsync(cx.d_acc.p, 0, (size_t)nw * 8, cx.stream));
 	uint32_t *d_bits = cx.d_csizes.as<uint32_t>(), *d_nbytes = d_bits + ns;
@@ -211,7 +240,8 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	const std::vector<RestartPoint> restarts = select_restart_points(w.marks);
 	const uint32_t nrs = (uint32_t)restarts.size();
 	static_assert(sizeof(RestartPoint) == kRestartWords * 4, "restart points are written as they lie in memory");
-	const size_t dir_restart = 12 + 4 * planes.size();
+	const size_t dir_prior = 12 + 4 * planes.size();
+	const size_t dir_restart = dir_prior + prior_dir.size();
 	const size_t dir_streams = dir_restart + 4 + sizeof(RestartPoint) * (size_t)nrs;
 	size_t dir = dir_streams + 4 * (size_t)ns;
 	size_t base = out.size();
@@ -220,6 +250,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	uint32_t np = (uint32_t)planes.size();
 	memcpy(o, &CH, 4); memcpy(o + 4, &CHC, 4); memcpy(o + 8, &np, 4);
 	for (size_t i = 0; i < planes.size(); ++i) memcpy(o + 12 + 4 * i, &planes[i].n, 4);
+	if (!prior_dir.empty()) memcpy(o + dir_prior, prior_dir.data(), prior_dir.size());
 	memcpy(o + dir_restart, &nrs, 4);
 	if (nrs) memcpy(o + dir_restart + 4, restarts.data(), sizeof(RestartPoint) * (size_t)nrs);
 	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));

@@ -282,7 +282,23 @@ __global__ __launch_bounds__(256) void k_scatter_u32(const uint32_t *pairs, uint
 	if (i < n) dst[pairs[2 * i]] = pairs[2 * i + 1];
 }
 
+// 256-bin histogram of every plane (static priors): one workgroup per 16 Ki-symbol slice, LDS bins, one global add per bin
+__global__ __launch_bounds__(256) void k_plane_hist(const HistSlice *slices, uint32_t *hist)
+{
+	const HistSlice sl = slices[blockIdx.x];
+	__shared__ uint32_t bins[256];
+	bins[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < sl.n; i += 256) atomicAdd(&bins[sl.sym[i]], 1u);
+	__syncthreads();
+	if (bins[threadIdx.x]) atomicAdd(&hist[(size_t)sl.plane * 256 + threadIdx.x], bins[threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
+void launch_plane_hist(hipStream_t st, const HistSlice *slices, uint32_t nslices, uint32_t *hist)
+{
+	if (nslices) hipLaunchKernelGGL(k_plane_hist, dim3(nslices), dim3(256), 0, st, slices, hist);
+}
 void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst)
 {
 	if (n) hipLaunchKernelGGL(k_scatter_u32, dim3((n + 255) / 256), dim3(256), 0, st, pairs, n, dst);

@@ -57,6 +57,9 @@ struct StreamJob {
 	uint32_t word_base;    // first 32-bit word of this stream's big-number accumulator / byte image
 };
 
+// a slice of a plane for the histogram pass (static priors)
+struct HistSlice { const uint8_t *sym; uint32_t n, plane; };
+
 // one component of an in-place requantisation: mn / scale carry the raw bits of the component's original type
 struct RequantComp { int32_t off, src_type, src_bits, dst_bits; uint64_t mn, scale; };
 struct RequantPlan { int32_t n; int32_t pad; RequantComp c[kMaxComp]; };

@@ -32,6 +32,7 @@ void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v,
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits);
 void launch_stream_pack(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *stream_bits, const uint8_t *bytes,
                         uint32_t *nbytes, uint64_t *offsets, uint8_t *out, bool pack);
+void launch_plane_hist(hipStream_t st, const HistSlice *slices, uint32_t nslices, uint32_t *hist);
 void launch_scatter_u8(hipStream_t st, const uint8_t *src, const uint32_t *dst_index, uint32_t n, uint8_t *dst);
 void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
                          const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes);

@@ -405,6 +405,14 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	uint64_t nstreams = 0, total_syms = 0;
 	auto step_of = [&](uint32_t k) { return k < (uint32_t)kConnPlanes ? CHC : CH; };
 	for (uint32_t k = 0; k < np; ++k) { nstreams += (nsym[k] + (uint64_t)step_of(k) - 1) / step_of(k); total_syms += nsym[k]; }
+	// static prior of every plane (or none: the reference's initial counts)
+	std::vector<uint32_t> prior((size_t)np * 256, 0);
+	std::vector<uint8_t> has_prior(np, 0);
+	for (uint32_t k = 0; k < np; ++k) {
+		bool use = false;
+		off += read_prior(p + off, n - off, use, prior.data() + (size_t)k * 256);
+		has_prior[k] = use ? 1 : 0;
+	}
 	need(off, 4);
 	uint32_t nrs;
 	memcpy(&nrs, p + off, 4);
@@ -430,15 +438,26 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	if (vc > m->nv) throw Error(HRY_E_FORMAT, "more coded vertices than vertices");
 	if (total_syms > (1ull << 33)) throw Error(HRY_E_FORMAT, "implausible symbol count");
 
-	// ---- model tables
-	std::vector<uint32_t> tabs((size_t)INIT_KINDS * 256, 0);
-	uint32_t totals[INIT_KINDS];
-	for (int i = 0; i < 256; ++i) tabs[INIT_ONES * 256 + i] = 1;
-	for (int i = 0; i < 9; ++i) tabs[INIT_IOP * 256 + i] = 1;
+	// ---- model tables: one per plane (its prior, or the reference's initial counts of its kind)
+	std::vector<uint32_t> kind_tabs((size_t)INIT_KINDS * 256, 0);
+	for (int i = 0; i < 256; ++i) kind_tabs[INIT_ONES * 256 + i] = 1;
+	for (int i = 0; i < 9; ++i) kind_tabs[INIT_IOP * 256 + i] = 1;
 	for (size_t d = 3; d < m->have_degree.size(); ++d)
-		if (m->have_degree[d]) { ++tabs[INIT_NT0 * 256 + ((d - 2) & 0xff)]; ++tabs[INIT_NT1 * 256 + ((d - 2) >> 8)]; }
-	for (int i = 0; i < 7; ++i) tabs[INIT_OP * 256 + i] = 1;
-	for (int k = 0; k < INIT_KINDS; ++k) { totals[k] = 0; for (int i = 0; i < 256; ++i) totals[k] += tabs[(size_t)k * 256 + i]; }
+		if (m->have_degree[d]) { ++kind_tabs[INIT_NT0 * 256 + ((d - 2) & 0xff)]; ++kind_tabs[INIT_NT1 * 256 + ((d - 2) >> 8)]; }
+	for (int i = 0; i < 7; ++i) kind_tabs[INIT_OP * 256 + i] = 1;
+	std::vector<uint32_t> tabs((size_t)np * 256, 0);
+	std::vector<uint32_t> totals(np, 0);
+	uint32_t max_t0 = 256;
+	for (uint32_t k = 0; k < np; ++k) {
+		const int kind = k < (uint32_t)kConnPlanes ? conn_init_kind((int)k) : INIT_ONES;
+		memcpy(tabs.data() + (size_t)k * 256, has_prior[k] ? prior.data() + (size_t)k * 256 : kind_tabs.data() + (size_t)kind * 256, 1024);
+		uint64_t t = 0;
+		for (int i = 0; i < 256; ++i) t += tabs[(size_t)k * 256 + i];
+		if (t == 0 && nsym[k]) throw Error(HRY_E_FORMAT, "corrupt chunked directory (empty model)");
+		if (t > (1u << 24)) throw Error(HRY_E_FORMAT, "corrupt chunked directory (prior total)");
+		totals[k] = (uint32_t)t;
+		max_t0 = std::max(max_t0, totals[k]);
+	}
 
 	// ---- device: entropy decode of every stream
 	auto t_h2d = Clock::now();
@@ -452,9 +471,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	jobs.reserve((size_t)nstreams);
 	std::vector<uint64_t> plane_off(np + 1, 0);
 	for (uint32_t k = 0; k < np; ++k) {
-		int kind = k < (uint32_t)kConnPlanes ? conn_init_kind((int)k) : INIT_ONES;
 		for (uint64_t f = 0; f < nsym[k]; f += step_of(k))
-			jobs.push_back(StreamJob{ cx.d_csyms.as<uint8_t>() + plane_off[k] + f, (uint32_t)std::min<uint64_t>(step_of(k), nsym[k] - f), (uint32_t)kind, totals[kind], 0 });
+			jobs.push_back(StreamJob{ cx.d_csyms.as<uint8_t>() + plane_off[k] + f, (uint32_t)std::min<uint64_t>(step_of(k), nsym[k] - f), k, totals[k], 0 });
 		plane_off[k + 1] = plane_off[k] + nsym[k];
 	}
 	HIP_OK(hipMemcpyAsync(cx.d_init.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice, cx.stream));
@@ -464,7 +482,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		HIP_OK(hipMemcpyAsync(cx.d_csizes.p, nbytes.data(), nbytes.size() * 4, hipMemcpyHostToDevice, cx.stream));
 	}
 	HIP_OK(hipMemcpyAsync(cx.d_coffs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, cx.stream));
-	cx.ensure_magic(256 + std::max(CH, CHC) + 16);
+	cx.ensure_magic(max_t0 + std::max(CH, CHC) + 16);
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	cx.timing.h2d_ms = ms_since(t_h2d);
 	HRY_MARK(g_t0, "payload on the device");

@@ -3,6 +3,8 @@
 // v0.2 = chunked profile of this implementation (the reference reader rejects it by version, reader.cc:74).
 #include "host.hpp"
 
+#include <algorithm>
+
 namespace hry {
 namespace {
 struct Out {
@@ -117,6 +119,54 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor)
 		m.have_degree[d] = 1;
 	}
 	return (size_t)(r.p - p);
+}
+
+// ---- static priors (chunked container) ----------------------------------------------------------------------------
+bool plane_prior_from_hist(const uint32_t hist[256], uint64_t n, uint32_t table[256])
+{
+	for (int s = 0; s < 256; ++s) table[s] = 0;
+	if (n < kPriorMinSyms) return false;
+	for (int s = 0; s < 256; ++s)
+		if (hist[s]) table[s] = (uint32_t)std::max<uint64_t>(1, ((uint64_t)hist[s] * kPriorK + n / 2) / n);
+	return true;
+}
+// u8 mode (0 = reference initial counts, 1 = prior); prior: 32-byte bitmap of the symbols present (bit s & 7 of byte s >> 3),
+// then one value per present symbol in symbol order: u8 if < 255, else 255 followed by u16
+void write_prior(std::vector<uint8_t> &out, bool use, const uint32_t table[256])
+{
+	out.push_back(use ? 1 : 0);
+	if (!use) return;
+	uint8_t bm[32] = { 0 };
+	for (int s = 0; s < 256; ++s) if (table[s]) bm[s >> 3] |= (uint8_t)(1u << (s & 7));
+	out.insert(out.end(), bm, bm + 32);
+	for (int s = 0; s < 256; ++s) {
+		if (!table[s]) continue;
+		if (table[s] < 255) out.push_back((uint8_t)table[s]);
+		else { out.push_back(255); out.push_back((uint8_t)(table[s] & 0xff)); out.push_back((uint8_t)(table[s] >> 8)); }
+	}
+}
+size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256])
+{
+	for (int s = 0; s < 256; ++s) table[s] = 0;
+	size_t k = 0;
+	auto need = [&](size_t n) { if (k + n > avail) throw Error(HRY_E_FORMAT, "truncated chunked directory"); };
+	need(1);
+	const uint8_t mode = p[k++];
+	use = mode == 1;
+	if (mode == 0) return k;
+	if (mode != 1) throw Error(HRY_E_FORMAT, "corrupt chunked directory (prior mode)");
+	need(32);
+	const uint8_t *bm = p + k;
+	k += 32;
+	for (int s = 0; s < 256; ++s) {
+		if (!(bm[s >> 3] & (1u << (s & 7)))) continue;
+		need(1);
+		uint32_t v = p[k++];
+		if (v == 255) { need(2); v = (uint32_t)p[k] | ((uint32_t)p[k + 1] << 8); k += 2; }
+		if (v == 0) throw Error(HRY_E_FORMAT, "corrupt chunked directory (prior count)");
+		table[s] = v;
+	}
+	return k;
 }
 
 }   // namespace hry

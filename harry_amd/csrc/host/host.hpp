@@ -90,6 +90,14 @@ template <typename F> inline void parallel_for(unsigned n_threads, F &&body)   /
 	if (err) std::rethrow_exception(err);
 }
 
+// ---- static priors of the chunked container's planes (header.cpp; the oracle restates the rule and the directory form)
+// Every chunk of a plane starts its adaptive table from the plane's histogram scaled to about kPriorK counts (symbols that
+// do not occur get 0) instead of the reference's flat initial counts; planes shorter than kPriorMinSyms keep those.
+constexpr uint32_t kPriorK = 1024, kPriorMinSyms = 1024;
+bool plane_prior_from_hist(const uint32_t hist[256], uint64_t n, uint32_t table[256]);
+void write_prior(std::vector<uint8_t> &out, bool use, const uint32_t table[256]);
+size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256]);   // returns bytes consumed; throws on damage
+
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 // reference single-stream format (compat_read.cpp): serial entropy decode + replay on the host; residual byte planes
 // (plane-major, one plane per coded byte) are returned for the device reconstruction

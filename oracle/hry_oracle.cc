@@ -15,6 +15,7 @@
 #include "hry_oracle.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1359,7 +1360,7 @@ static Mesh *decode(const uint8_t *p, size_t n)
 // below 2^30 = QUARTER (the coder's requirement) and the interval keeps >= 10 bits of resolution per count.  Symbols without information are
 // not stored: reg_face/reg_vtx (single region), attr_type (always DATA), numtri for single-degree meshes.
 // Operations are split into one plane per order class (models.h:101-105) with a plain adaptive 7-symbol model.
-//   u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols,
+//   u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols, n_planes x prior (see plane_prior / write_prior),
 //   u32 n_restart, n_restart x 17 u32 (restart points, see encode_chunked), per stream u32 n_bytes, then the streams.
 // Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
 // The first 21 planes (connectivity) are cut every conn_chunk_syms symbols, the attribute planes every chunk_syms: the
@@ -1394,6 +1395,54 @@ static void seed_table(FreqTable &f, int kind, const Mesh &m)
 	case 4: for (uint32_t j = 0; j <= OP_CONNFWD; ++j) f.inc(j); break;
 	}
 }
+// Static prior of a plane (chunked container): every chunk of the plane starts its adaptive table from the plane's own
+// histogram scaled to about PRIOR_K counts instead of the reference's flat initial counts -- a fresh table per chunk costs
+// ~250 bytes of learning on a 256-symbol plane, which is what made short chunks expensive.  Planes with fewer than
+// PRIOR_MIN_SYMS symbols keep the reference's initial counts.  table[s] = 0 for symbols that do not occur in the plane.
+enum { PRIOR_K = 1024, PRIOR_MIN_SYMS = 1024 };
+static bool plane_prior(const std::vector<uint8_t> &sy, uint32_t table[256])
+{
+	for (int s = 0; s < 256; ++s) table[s] = 0;
+	if (sy.size() < PRIOR_MIN_SYMS) return false;
+	uint64_t hist[256] = { 0 };
+	for (uint8_t b : sy) ++hist[b];
+	const uint64_t n = sy.size();
+	for (int s = 0; s < 256; ++s)
+		if (hist[s]) table[s] = (uint32_t)std::max<uint64_t>(1, (hist[s] * PRIOR_K + n / 2) / n);
+	return true;
+}
+// directory form: u8 mode (0 = reference initial counts, 1 = prior); prior: 32-byte bitmap of the symbols present (bit s & 7
+// of byte s >> 3), then one value per present symbol in symbol order: u8 if < 255, else 255 followed by u16
+static void write_prior(ByteWriter &w, bool use, const uint32_t table[256])
+{
+	w.put<uint8_t>(use ? 1 : 0);
+	if (!use) return;
+	uint8_t bm[32] = { 0 };
+	for (int s = 0; s < 256; ++s) if (table[s]) bm[s >> 3] |= (uint8_t)(1u << (s & 7));
+	w.raw(bm, 32);
+	for (int s = 0; s < 256; ++s) {
+		if (!table[s]) continue;
+		if (table[s] < 255) w.put<uint8_t>((uint8_t)table[s]);
+		else { w.put<uint8_t>(255); w.put<uint16_t>((uint16_t)table[s]); }
+	}
+}
+static bool read_prior(ByteReader &br, uint32_t table[256])
+{
+	for (int s = 0; s < 256; ++s) table[s] = 0;
+	uint8_t mode = br.get<uint8_t>();
+	if (mode == 0) return false;
+	if (mode != 1) throw std::runtime_error("oracle: bad prior mode");
+	uint8_t bm[32];
+	for (int i = 0; i < 32; ++i) bm[i] = br.get<uint8_t>();
+	for (int s = 0; s < 256; ++s) {
+		if (!(bm[s >> 3] & (1u << (s & 7)))) continue;
+		uint32_t v = br.get<uint8_t>();
+		if (v == 255) v = br.get<uint16_t>();
+		if (v == 0) throw std::runtime_error("oracle: zero count in a prior");
+		table[s] = v;
+	}
+	return true;
+}
 static int count_degrees(const Mesh &m) { int n = 0; for (char c : m.have_deg) n += c ? 1 : 0; return n; }
 enum { CONN_PLANES = 21, RESTART_FACES = 8192 };
 static uint32_t default_conn_chunk(uint32_t chunk_syms) { return std::min(chunk_syms, std::max(chunk_syms / 8, 512u)); }
@@ -1401,7 +1450,7 @@ static uint32_t default_conn_chunk(uint32_t chunk_syms) { return std::min(chunk_
 static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 {
 	check_supported(m);
-	if (chunk_syms == 0) chunk_syms = 32768;
+	if (chunk_syms == 0) chunk_syms = 8192;
 	chunk_syms = std::min(chunk_syms, 1u << 20);
 	Result *res = new Result();
 	try {
@@ -1423,6 +1472,12 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 		w.put<uint32_t>(conn_chunk);
 		w.put<uint32_t>((uint32_t)planes.size());
 		for (const PlaneDef &pd : planes) w.put<uint32_t>((uint32_t)rec[pd.slot].size());
+		std::vector<std::array<uint32_t, 256>> prior(planes.size());
+		std::vector<char> has_prior(planes.size(), 0);
+		for (size_t pi = 0; pi < planes.size(); ++pi) {
+			has_prior[pi] = plane_prior(rec[planes[pi].slot], prior[pi].data()) ? 1 : 0;
+			write_prior(w, has_prior[pi] != 0, prior[pi].data());
+		}
 		// restart points of the connectivity replay: the coder state at the first component start that lies at least
 		// RESTART_FACES faces after the previous point: symbols consumed per plane group (iop, elem, part, vertid, numtri)
 		// and per operation class, first vertex index / face / half-edge, flags (bit 0: a component up to the next point
@@ -1462,7 +1517,8 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 				std::vector<uint8_t> out;
 				ChunkEncoder enc(out);
 				FreqTable f(256);
-				seed_table(f, pd.init_kind, m);
+				if (has_prior[pi]) { for (uint32_t j = 0; j < 256; ++j) if (prior[pi][j]) f.inc(j, prior[pi][j]); }
+				else seed_table(f, pd.init_kind, m);
 				for (size_t j = first; j < end; ++j) {
 					uint64_t l, h, t = f.total();
 					f.range_of(sy[j], l, h);
@@ -1493,6 +1549,9 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 		for (auto &x : nsym) x = br.get<uint32_t>();
 		size_t nstreams = 0;
 		for (size_t k = 0; k < np; ++k) { uint64_t c = k < CONN_PLANES ? conn_chunk : chunk_syms; nstreams += (size_t)((nsym[k] + c - 1) / c); }
+		std::vector<std::array<uint32_t, 256>> prior(np);
+		std::vector<char> has_prior(np, 0);
+		for (size_t k = 0; k < np; ++k) has_prior[k] = read_prior(br, prior[k].data()) ? 1 : 0;
 		uint32_t n_restart = br.get<uint32_t>();   // restart points: an aid for parallel decoders, not needed here
 		for (uint64_t i = 0; i < (uint64_t)n_restart * 17; ++i) (void)br.get<uint32_t>();
 		std::vector<uint32_t> nbytes(nstreams);
@@ -1509,7 +1568,8 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 				if ((size_t)(p + n - q) < nbytes[si]) throw std::runtime_error("oracle: truncated chunked stream");
 				ChunkDecoder dec(q, q + nbytes[si]);
 				FreqTable f(256);
-				seed_table(f, planes[k].init_kind, *m);
+				if (has_prior[k]) { for (uint32_t j = 0; j < 256; ++j) if (prior[k][j]) f.inc(j, prior[k][j]); }
+				else seed_table(f, planes[k].init_kind, *m);
 				for (size_t j = first; j < end; ++j) {
 					uint64_t l, h, t = f.total();
 					uint32_t s = f.find(dec.target((uint32_t)t), l, h);
