@@ -255,9 +255,10 @@ int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_p
 		std::unique_ptr<hry_walk> w(new hry_walk());
 		m->m.nv = src->m.nv; m->m.nf = src->m.nf; m->m.declared_ne = src->m.ne(); m->m.have_degree = src->m.have_degree;
 		std::vector<RestartPoint> restarts;
-		if (use_restart_points) restarts = select_restart_points(r.marks);
+		std::vector<RestartCounters> rcounters;
+		if (use_restart_points) restarts = select_restart_points(r.marks, r.named, rcounters);
 		std::vector<uint32_t> order_v;
-		cut_border_replay(m->m, planes, restarts, order_v, w->seg_start, w->seg_level);
+		cut_border_replay(m->m, planes, restarts, rcounters, order_v, w->seg_start, w->seg_level);
 		w->w.order_v.assign(order_v.begin(), order_v.end());
 		w->info[0] = (uint32_t)restarts.size(); w->info[1] = 0;
 		*mesh = m.release();

@@ -237,12 +237,19 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 
 	// ---- container
 	// directory: chunk sizes, plane lengths, restart points of the connectivity replay, stream lengths
-	const std::vector<RestartPoint> restarts = select_restart_points(w.marks);
+	std::vector<RestartCounters> rcounters;
+	const std::vector<RestartPoint> restarts = select_restart_points(w.marks, w.named, rcounters);
 	const uint32_t nrs = (uint32_t)restarts.size();
+	std::vector<uint32_t> counter_dir;   // per restart point: n, then n x (vertex, counter)
+	for (const RestartCounters &cs : rcounters) {
+		counter_dir.push_back((uint32_t)cs.size());
+		for (const auto &c : cs) { counter_dir.push_back(c.first); counter_dir.push_back(c.second); }
+	}
 	static_assert(sizeof(RestartPoint) == kRestartWords * 4, "restart points are written as they lie in memory");
 	const size_t dir_prior = 12 + 4 * planes.size();
 	const size_t dir_restart = dir_prior + prior_dir.size();
-	const size_t dir_streams = dir_restart + 4 + sizeof(RestartPoint) * (size_t)nrs;
+	const size_t dir_counters = dir_restart + 4 + sizeof(RestartPoint) * (size_t)nrs;
+	const size_t dir_streams = dir_counters + 4 * counter_dir.size();
 	size_t dir = dir_streams + 4 * (size_t)ns;
 	size_t base = out.size();
 	out.resize(base + dir + total_bytes);
@@ -253,6 +260,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	if (!prior_dir.empty()) memcpy(o + dir_prior, prior_dir.data(), prior_dir.size());
 	memcpy(o + dir_restart, &nrs, 4);
 	if (nrs) memcpy(o + dir_restart + 4, restarts.data(), sizeof(RestartPoint) * (size_t)nrs);
+	if (!counter_dir.empty()) memcpy(o + dir_counters, counter_dir.data(), 4 * counter_dir.size());
 	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
 	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));

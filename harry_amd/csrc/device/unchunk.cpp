@@ -338,9 +338,10 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 			int numtri() { return fixed_numtri; }
 			uint32_t op(int order) { int k = order - 1; if (k > 7) k = 7; if (k < 0) k = 0; return byte(13 + k); }
 		} rd{ conn, { 0 }, onlydeg - 2 };
-		const std::vector<uint32_t> none;
-		std::vector<uint32_t> comp_first, comp_level;
-		replay_span(*m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, none, comp_first, comp_level, &live);
+		const RestartCounters none;
+		std::vector<uint32_t> comp_first;
+		std::vector<std::pair<uint32_t, uint32_t>> refs;
+		replay_span(*m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, comp_first, refs, &live);
 		if (cur.face != nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
 		if (cur.he != ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
 		if (cur.next_id != nv) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
@@ -422,6 +423,18 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	std::vector<RestartPoint> restarts(nrs);
 	if (nrs) memcpy(restarts.data(), p + off, sizeof(RestartPoint) * (size_t)nrs);
 	off += sizeof(RestartPoint) * (size_t)nrs;
+	std::vector<RestartCounters> rcounters(nrs);
+	for (uint32_t k = 0; k < nrs; ++k) {
+		need(off, 4);
+		uint32_t nc;
+		memcpy(&nc, p + off, 4);
+		off += 4;
+		if ((uint64_t)nc * 8 > n) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+		need(off, 8ull * nc);
+		rcounters[k].resize(nc);
+		for (uint32_t j = 0; j < nc; ++j) { uint32_t v[2]; memcpy(v, p + off + 8ull * j, 8); rcounters[k][j] = { v[0], v[1] }; }
+		off += 8ull * nc;
+	}
 	need(off, 4 * nstreams);
 	std::vector<uint32_t> nbytes((size_t)nstreams);
 	if (nstreams) memcpy(nbytes.data(), p + off, 4 * (size_t)nstreams);
@@ -525,7 +538,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v);
 		cx.timing.host_walk_ms = cx.timing.host_walk_ms - std::chrono::duration<double, std::milli>(t_walk - g_t0).count();
 	} else {
-		cut_border_replay(*m, conn, restarts, order_v, seg_start, seg_level);
+		cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
 		cx.timing.host_walk_ms = ms_since(t_walk);
 		HRY_MARK(g_t0, "replay done");
 		if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");

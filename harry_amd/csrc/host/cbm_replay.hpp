@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <unordered_map>
 
 namespace hry {
 namespace replay_detail {
@@ -105,10 +106,12 @@ struct Ring {
 // stop_face (NONE32: up to the end-of-mesh symbol).  The connectivity arrays, order_v and seen are preallocated and shared
 // between spans; a span writes only the faces / half-edges / vertices it creates (every index is checked against the sizes
 // announced by the header, so a corrupt stream or directory cannot write outside them).
-//   min_id        : smallest vertex id this span may name (its own first id for a span that starts at an unflagged restart point)
-//   g_first/level : components replayed before this span (first vertex id, level), for the owner lookup of older vertices
-//   comp_first/level : out, one entry per component of this span.  level = 0: the component touches no vertex coded before
-//                   it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
+//   own_first     : first vertex id of the span.  Older vertices may be named only if the span brings their order counters
+//                   along (old_counts: the restart point's snapshot); the span then counts on its private copy, so that spans
+//                   never touch each other's counters
+//   comp_first    : out, first vertex id of every component of this span
+//   refs          : out, (component of this span, older vertex it names) pairs -- the caller derives the dependency levels of
+//                   the reconstruction from them (replay_levels) once every span is known
 // RD provides: iop(), vertid(), elem(), part(), numtri(), op(order)
 struct ReplayCursor { uint32_t next_id = 0, face = 0, he = 0; };
 
@@ -153,9 +156,9 @@ struct ReplayLive {
 };
 
 template <class RD>
-bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCursor &cur, uint32_t stop_face, uint32_t min_id,
-                 const std::vector<uint32_t> &g_first, const std::vector<uint32_t> &g_level,
-                 std::vector<uint32_t> &comp_first, std::vector<uint32_t> &comp_level, ReplayLive *live = nullptr)
+bool replay_span(Mesh &m, RD &rd, uint16_t *seen_shared, uint32_t *order_v, ReplayCursor &cur, uint32_t stop_face, uint32_t own_first,
+                 const RestartCounters &old_counts, std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs,
+                 ReplayLive *live = nullptr)
 {
 	using namespace replay_detail;
 	const uint32_t nv = m.nv, nf = m.nf, ne_max = (uint32_t)m.org.size();
@@ -174,9 +177,16 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCurso
 	};
 
 	auto link = [&](uint32_t a, uint32_t b) { m.twin[a] = b; m.twin[b] = a; if (live) live->link(a, b); };
+	// order counters: the span's own vertices in the shared array, older ones in a private map seeded by the restart point
+	std::unordered_map<uint32_t, uint16_t> old_seen;
+	for (const auto &c : old_counts) old_seen.emplace(c.first, (uint16_t)c.second);
+	struct Seen {
+		uint16_t *shared; std::unordered_map<uint32_t, uint16_t> &old; uint32_t own_first;
+		uint16_t &operator[](uint32_t v) { return v >= own_first ? shared[v] : old.find(v)->second; }
+	} seen{ seen_shared, old_seen, own_first };
 	auto chk = [&](uint32_t v) {
 		if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
-		if (v < min_id) throw Error(HRY_E_FORMAT, "corrupt stream (restart point names an older vertex)");
+		if (v < own_first && !old_seen.count(v)) throw Error(HRY_E_FORMAT, "corrupt stream (restart point names an older vertex without its counter)");
 		return v;
 	};
 	auto fresh = [&]() { if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)"); return next_id++; };
@@ -191,23 +201,8 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCurso
 		// (TRIxxx start, or an NM operation naming an older vertex)
 		const uint32_t seg_first_id = next_id;
 		comp_first.push_back(seg_first_id);
-		comp_level.push_back(0);
-		// level = 1 + the highest level among the components that own an older vertex this component touches
-		auto depends_on = [&](uint32_t vid) {
-			if (vid >= seg_first_id) return;
-			// a component that created no vertex shares its first id with its successor: upper_bound lands on the last such entry,
-			// which is at least as late as the true owner -- its level is >= the owner's level, so the bound stays valid
-			uint32_t lv;
-			if (!comp_first.empty() && vid >= comp_first.front()) {
-				size_t owner = (size_t)(std::upper_bound(comp_first.begin(), comp_first.end(), vid) - comp_first.begin()) - 1;
-				lv = comp_level[owner];
-			} else {
-				size_t owner = (size_t)(std::upper_bound(g_first.begin(), g_first.end(), vid) - g_first.begin());
-				if (owner == 0) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
-				lv = g_level[owner - 1];
-			}
-			comp_level.back() = std::max(comp_level.back(), lv + 1);
-		};
+		const uint32_t comp_idx = (uint32_t)comp_first.size() - 1;
+		auto depends_on = [&](uint32_t vid) { if (vid < seg_first_id) refs.push_back({ comp_idx, vid }); };
 		switch (iop) {   // decoder.h:46-77
 		case I_INIT: a = fresh(); b = fresh(); c = fresh(); break;
 		case I_TRI100: a = rd.vertid(); b = fresh(); c = fresh(); break;
@@ -372,6 +367,23 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen, uint32_t *order_v, ReplayCurso
 	return eom;
 }
 
+// Dependency levels of the attribute reconstruction: level 0 = the component names no older vertex; else 1 + the highest
+// level among the components that own a vertex it names.  seg_start: first vertex id of every component (ascending).
+// A component that created no vertex shares its first id with its successor: upper_bound then lands on the last such entry,
+// which is at least as late as the true owner -- its level is >= the owner's, so the bound stays valid.
+inline void replay_levels(const std::vector<uint32_t> &seg_start, const std::vector<std::pair<uint32_t, uint32_t>> &refs, std::vector<uint32_t> &seg_level)
+{
+	seg_level.assign(seg_start.size(), 0);
+	for (const auto &r : refs) {   // refs are in component order
+		const uint32_t comp = r.first, vid = r.second;
+		size_t owner = (size_t)(std::upper_bound(seg_start.begin(), seg_start.begin() + comp + 1, vid) - seg_start.begin());
+		if (owner == 0) continue;
+		--owner;
+		if (owner >= comp) owner = comp ? comp - 1 : 0;
+		if (comp) seg_level[comp] = std::max(seg_level[comp], seg_level[owner] + 1);
+	}
+}
+
 // the whole connectivity as one span (reference v0.1 streams, and v0.2 containers without restart points)
 template <class RD>
 void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
@@ -382,12 +394,14 @@ void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std
 	order_v.assign(m.nv, 0);
 	BigVec<uint16_t> seen(m.nv, 0);
 	ReplayCursor cur;
-	const std::vector<uint32_t> none;
-	seg_start.clear(); seg_level.clear();
-	replay_span(m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, none, seg_start, seg_level);
+	const RestartCounters none;
+	std::vector<std::pair<uint32_t, uint32_t>> refs;
+	seg_start.clear();
+	replay_span(m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, seg_start, refs);
 	if (cur.face != m.nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
 	if (cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
 	order_v.resize(cur.next_id);
+	replay_levels(seg_start, refs, seg_level);
 	seg_start.push_back(cur.next_id);
 }
 

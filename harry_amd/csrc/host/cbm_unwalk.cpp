@@ -33,10 +33,11 @@ struct Planes {
 // (one half-edge per vertex; vertex ids are assigned in this order, cbm/decoder.h:48-75,145).
 //
 // Restart points of the container directory cut the replay into spans that start at a component boundary with a known
-// state (plane cursors, next vertex id / face / half-edge).  A span whose components name no vertex older than its restart
-// point (flag bit 0 clear) touches nothing another span touches and runs on its own host thread; the flagged ones (shared
-// non-manifold vertices across the cut: the order counters of those vertices continue) are replayed afterwards, in order.
+// state: plane cursors, next vertex id / face / half-edge, and the order counters of the older vertices the span names
+// (shared non-manifold vertices across the cut).  A span writes only the faces, half-edges and vertices it creates and counts
+// older vertices on its private copy of their counters, so every span runs on its own host thread.
 void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const std::vector<RestartPoint> &restarts,
+                       const std::vector<RestartCounters> &counters,
                        std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
 {
 	using replay_detail::NONE32;
@@ -44,26 +45,25 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++ndeg; onlydeg = (int)d; }
 	const int fixed_numtri = ndeg <= 1 ? onlydeg - 2 : -1;
 	const unsigned n_threads = host_threads();
-	if (restarts.empty() || n_threads < 2 || m.nf < parallel_min_faces()) {
+	if (restarts.empty() || n_threads < 2 || m.nf < parallel_min_faces() || counters.size() != restarts.size()) {
 		Planes rd{ conn_planes, { 0 }, fixed_numtri };
 		cut_border_replay_with(m, rd, order_v, seg_start, seg_level);
 		return;
 	}
 	// spans: [start state, stop face); the directory must be strictly increasing in faces and consistent in every counter
 	const size_t ns = restarts.size() + 1;
-	struct Span { ReplayCursor cur; uint32_t stop_face; bool flagged; Planes rd; std::vector<uint32_t> first, level; bool eom = false; };
+	struct Span { ReplayCursor cur; uint32_t stop_face; Planes rd; std::vector<uint32_t> first; std::vector<std::pair<uint32_t, uint32_t>> refs; bool eom = false; };
 	std::vector<Span> spans(ns);
 	for (size_t k = 0; k < ns; ++k) {
 		Span &sp = spans[k];
 		sp.rd = Planes{ conn_planes, { 0 }, fixed_numtri };
-		sp.flagged = false;
 		if (k > 0) {
 			const RestartPoint &r = restarts[k - 1];
 			const uint32_t prev_face = k > 1 ? restarts[k - 2].first_face : 0u;
 			if (r.first_face <= prev_face || r.first_face >= m.nf || r.first_vertex > m.nv || r.first_halfedge > m.declared_ne)
 				throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart points)");
+			for (const auto &c : counters[k - 1]) if (c.first >= r.first_vertex) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart counters)");
 			sp.cur.next_id = r.first_vertex; sp.cur.face = r.first_face; sp.cur.he = r.first_halfedge;
-			sp.flagged = (r.flags & 1u) != 0;
 			static const int first_plane[G_COUNT] = { 0, 1, 5, 7, 11 };
 			for (int g = 0; g < G_COUNT; ++g) for (int b = 0; b < kGroupBytes[g]; ++b) sp.rd.cur[first_plane[g] + b] = r.n_grp[g];
 			for (int i = 0; i < 8; ++i) sp.rd.cur[13 + i] = r.n_op[i];
@@ -73,14 +73,13 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 	const bool trace = getenv("HRY_TRACE") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry replay] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
-	if (trace) { size_t nfl = 0; uint64_t ffl = 0; for (size_t k = 0; k < ns; ++k) if (spans[k].flagged) { ++nfl; ffl += (k + 1 < ns ? restarts[k].first_face : m.nf) - spans[k].cur.face; }
-		fprintf(stderr, "[hry replay] %zu spans, %zu flagged holding %llu of %u faces\n", ns, nfl, (unsigned long long)ffl, m.nf); }
+	if (trace) fprintf(stderr, "[hry replay] %zu spans\n", ns);
 	m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
 	m.org.resize(m.declared_ne);
 	m.twin.resize(m.declared_ne);
 	order_v.assign(m.nv, 0);
 	BigVec<uint16_t> seen(m.nv, 0);
-	const std::vector<uint32_t> none;
+	const RestartCounters none;
 	mark("allocated");
 	// a span must end exactly where the next one starts, in every counter
 	auto check_end = [&](size_t k) {
@@ -89,12 +88,9 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 			if (!sp.eom || sp.cur.face != m.nf || sp.cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
 			return;
 		}
-		const Span &nx = spans[k + 1];
 		const RestartPoint &r = restarts[k];
 		bool ok = !sp.eom && sp.cur.face == r.first_face && sp.cur.next_id == r.first_vertex && sp.cur.he == r.first_halfedge;
 		for (int p = 0; p < 21 && ok; ++p) {
-			// nx.rd.cur was the start state of the next span unless that span has already run; compare against the directory
-			(void)nx;
 			size_t want = p == 0 ? r.n_grp[0] : p < 5 ? r.n_grp[1] : p < 7 ? r.n_grp[2] : p < 11 ? r.n_grp[3] : p < 13 ? r.n_grp[4] : r.n_op[p - 13];
 			if (fixed_numtri >= 0 && (p == 11 || p == 12)) continue;   // numtri is not stored for a single polygon degree
 			ok = sp.rd.cur[p] == want;
@@ -107,24 +103,20 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 			size_t k = next.fetch_add(1, std::memory_order_relaxed);
 			if (k >= ns) break;
 			Span &sp = spans[k];
-			if (sp.flagged) continue;
-			sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, none, none, sp.first, sp.level);
+			sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
 			check_end(k);
 		}
 	});
-	mark("independent spans");
-	// flagged spans in order, with the components before them known; then the global component table
-	seg_start.clear(); seg_level.clear();
+	mark("spans replayed");
+	// the component table and the dependency levels of the reconstruction
+	seg_start.clear();
+	std::vector<std::pair<uint32_t, uint32_t>> refs;
 	for (size_t k = 0; k < ns; ++k) {
-		Span &sp = spans[k];
-		if (sp.flagged) {
-			sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, 0u, seg_start, seg_level, sp.first, sp.level);
-			check_end(k);
-		}
-		seg_start.insert(seg_start.end(), sp.first.begin(), sp.first.end());
-		seg_level.insert(seg_level.end(), sp.level.begin(), sp.level.end());
+		const uint32_t base = (uint32_t)seg_start.size();
+		seg_start.insert(seg_start.end(), spans[k].first.begin(), spans[k].first.end());
+		for (const auto &r : spans[k].refs) refs.push_back({ base + r.first, r.second });
 	}
-	mark("flagged spans");
+	replay_levels(seg_start, refs, seg_level);
 	const uint32_t n_ids = spans.back().cur.next_id;
 	order_v.resize(n_ids);
 	seg_start.push_back(n_ids);

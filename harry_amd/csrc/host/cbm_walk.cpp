@@ -275,7 +275,12 @@ struct Emitter {
 	void finish_marks() { if (!w.marks.empty()) w.marks.back().min_ref = min_ref; }
 	void group(int g, uint32_t v) { w.grp_val[g].push_back(v); w.grp_pos[g].push_back(n); n += kGroupBytes[g]; }
 	void iop(uint32_t s) { group(G_IOP, s); }
-	void vert(uint32_t v) { group(G_VERT, v); if (v < min_ref) min_ref = v; }
+	void vert(uint32_t v, uint32_t count)
+	{
+		group(G_VERT, v);
+		if (v < min_ref) min_ref = v;
+		if (!w.marks.empty()) w.named.push_back(NamedVertex{ (uint32_t)w.marks.size() - 1, v, count });
+	}
 	void elem(int i) { uint32_t c = (uint32_t)i; group(G_ELEM, (c << 1) ^ ((c >> 31) ? 0xffffffffu : 0u)); }   // transform.h:25-30
 	void part(int p) { group(G_PART, (uint32_t)(uint16_t)p); }
 	void numtri(int nt) { if (nt != 0 && w.numtri_coded) group(G_NUMTRI, (uint32_t)(uint16_t)nt); }          // io.h:162-165
@@ -344,13 +349,13 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 	int ntri = (int)(foff[f + 1] - foff[f]) - 2, curtri = 1;
 	unsigned mask = (sent[a] != NONE32 ? 4u : 0u) | (sent[b] != NONE32 ? 2u : 0u) | (sent[c] != NONE32 ? 1u : 0u);
 	switch (mask) {
-	case 7: em.iop(I_TRI111); em.vert(sent[a]); em.vert(sent[b]); em.vert(sent[c]); em.numtri(ntri); break;
-	case 6: em.iop(I_TRI110); em.vert(sent[a]); em.vert(sent[b]); em.numtri(ntri); record_vertex(e2); break;
-	case 3: em.iop(I_TRI011); em.vert(sent[b]); em.vert(sent[c]); em.numtri(ntri); record_vertex(e0); break;
-	case 5: em.iop(I_TRI101); em.vert(sent[c]); em.vert(sent[a]); em.numtri(ntri); record_vertex(e1); break;
-	case 4: em.iop(I_TRI100); em.vert(sent[a]); em.numtri(ntri); record_vertex(e1); record_vertex(e2); break;
-	case 2: em.iop(I_TRI010); em.vert(sent[b]); em.numtri(ntri); record_vertex(e2); record_vertex(e0); break;
-	case 1: em.iop(I_TRI001); em.vert(sent[c]); em.numtri(ntri); record_vertex(e0); record_vertex(e1); break;
+	case 7: em.iop(I_TRI111); em.vert(sent[a], seen[a]); em.vert(sent[b], seen[b]); em.vert(sent[c], seen[c]); em.numtri(ntri); break;
+	case 6: em.iop(I_TRI110); em.vert(sent[a], seen[a]); em.vert(sent[b], seen[b]); em.numtri(ntri); record_vertex(e2); break;
+	case 3: em.iop(I_TRI011); em.vert(sent[b], seen[b]); em.vert(sent[c], seen[c]); em.numtri(ntri); record_vertex(e0); break;
+	case 5: em.iop(I_TRI101); em.vert(sent[c], seen[c]); em.vert(sent[a], seen[a]); em.numtri(ntri); record_vertex(e1); break;
+	case 4: em.iop(I_TRI100); em.vert(sent[a], seen[a]); em.numtri(ntri); record_vertex(e1); record_vertex(e2); break;
+	case 2: em.iop(I_TRI010); em.vert(sent[b], seen[b]); em.numtri(ntri); record_vertex(e2); record_vertex(e0); break;
+	case 1: em.iop(I_TRI001); em.vert(sent[c], seen[c]); em.numtri(ntri); record_vertex(e0); record_vertex(e1); break;
 	default: em.iop(I_INIT); em.numtri(ntri); record_vertex(e0); record_vertex(e1); record_vertex(e2); break;
 	}
 	w.order_f.push_back(e0);
@@ -393,7 +398,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 			cb.N(p.tail).a = e1;
 			cb.append(p, cb.make(v2, e2));
 			if (fresh) { em.op(O_NEWVTX, order); em.numtri(nt); record_vertex(e2); }
-			else { em.op(O_NM, order); em.vert(sent[v2]); em.numtri(nt); }
+			else { em.op(O_NM, order); em.vert(sent[v2], seen[v2]); em.numtri(nt); }
 		} else {
 			int i, p;
 			int32_t hit = cb.locate(v2, i, p);
@@ -709,6 +714,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 		for (int i = 0; i < 8; ++i) nop[i] = em0.n_op[i];
 		w.marks.reserve(w.marks.size() + ncomp);
 		for (uint32_t k = 0; k < ncomp; ++k) {
+			for (NamedVertex ev : frag[k].named) { ev.mark = (uint32_t)w.marks.size(); w.named.push_back(ev); }   // fragment-local mark 0 -> its place in the sequence
 			ComponentMark mk = frag[k].marks.at(0);
 			for (int g = 0; g < G_COUNT; ++g) mk.n_grp[g] = (uint32_t)off_g[g][k];
 			for (int i = 0; i < 8; ++i) { mk.n_op[i] = nop[i]; nop[i] += frag_op[(size_t)k * 8 + i]; }
@@ -751,13 +757,16 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 
 }   // namespace
 
-std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks)
+std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks, const std::vector<NamedVertex> &named,
+                                                std::vector<RestartCounters> &counters)
 {
 	std::vector<RestartPoint> out;
+	std::vector<uint32_t> span_of_mark(marks.size(), NONE32);   // restart span of every component (none: before the first point)
 	uint32_t last_face = 0;
 	for (size_t k = 1; k < marks.size(); ++k) {
 		if (marks[k].first_face - last_face < kRestartFaces) {
 			if (!out.empty() && marks[k].min_ref < out.back().first_vertex) out.back().flags |= 1u;
+			if (!out.empty()) span_of_mark[k] = (uint32_t)out.size() - 1;
 			continue;
 		}
 		RestartPoint r;
@@ -766,7 +775,18 @@ std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark>
 		r.first_vertex = marks[k].first_vertex; r.first_face = marks[k].first_face; r.first_halfedge = marks[k].first_halfedge;
 		r.flags = marks[k].min_ref < marks[k].first_vertex ? 1u : 0u;
 		out.push_back(r);
+		span_of_mark[k] = (uint32_t)out.size() - 1;
 		last_face = marks[k].first_face;
+	}
+	// the older vertices a span names, with their counters at the first naming inside the span = at the start of the span (a
+	// vertex is touched only after the component at hand has named it)
+	counters.assign(out.size(), RestartCounters());
+	std::unordered_set<uint64_t> taken;
+	for (const NamedVertex &ev : named) {
+		if (ev.mark >= marks.size()) continue;
+		const uint32_t sp = span_of_mark[ev.mark];
+		if (sp == NONE32 || ev.id >= out[sp].first_vertex) continue;
+		if (taken.insert(((uint64_t)sp << 32) | ev.id).second) counters[sp].push_back({ ev.id, ev.count });
 	}
 	return out;
 }

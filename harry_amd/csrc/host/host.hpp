@@ -5,6 +5,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../../include/harry_amd.h"
@@ -47,10 +48,16 @@ struct RestartPoint {
 	uint32_t first_vertex, first_face, first_halfedge;
 	uint32_t flags;
 };
+// An explicit naming of a vertex (TRIxxx start, NM operation) with the number of triangles seen at it so far (the "order"
+// the operation planes are split by, models.h:69-72) and the component (index into marks) that names it.
+struct NamedVertex { uint32_t mark, id, count; };
+// counters a restart point carries: (vertex, order counter at the start of the span) for every older vertex its span names
+typedef std::vector<std::pair<uint32_t, uint32_t>> RestartCounters;
 constexpr uint32_t kRestartFaces = 8192;   // a restart point at the first component start >= this many faces after the previous one
 constexpr uint32_t kRestartWords = G_COUNT + 8 + 4;
 // canonical selection, shared by every writer of the container (the oracle restates it)
-std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks);
+std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks, const std::vector<NamedVertex> &named,
+                                                std::vector<RestartCounters> &counters);
 
 struct WalkResult {
 	BigVec<uint32_t> order_v;   // one half-edge per coded vertex, in coding order (attrcode.h:297,310-314)
@@ -63,6 +70,7 @@ struct WalkResult {
 	BigVec<uint8_t> op_sym, op_class;
 	BigVec<uint32_t> op_l, op_h, op_t, op_pos;
 	std::vector<ComponentMark> marks; // one per connected component, in coding order
+	std::vector<NamedVertex> named;   // every explicit naming of a vertex, in coding order
 	uint32_t n_conn = 0;             // symbols in the connectivity part of the global sequence
 	bool numtri_coded = false;       // false when a single polygon degree makes every numtri symbol an exact no-op
 	bool twins_changed = false;      // the walk repaired at least one twin (cbm/encoder.h:150,193-198): the device copy is stale
@@ -75,6 +83,7 @@ void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true);
 // seg_start: first decode rank of every connected component (+ end sentinel); seg_level[k]: 0 = the component touches no vertex
 // coded before it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
 void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const std::vector<RestartPoint> &restarts,
+                       const std::vector<RestartCounters> &counters,
                        std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level);
 unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
 uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536

@@ -556,6 +556,12 @@ struct SymWriter {
 	}
 	void part(int p) { uint16_t v = (uint16_t)p; bytes(CTX_PART, (const uint8_t*)&v, 2); }
 	void vertid(uint32_t v) { if (v < min_ref) min_ref = v; bytes(CTX_VERT, (const uint8_t*)&v, 4); }
+	// chunked profile: every explicit naming of a vertex with the number of triangles seen at it so far (the "order" the
+	// operation model conditions on, models.h:69-72), per component -- restart points carry the counters of the older
+	// vertices their span names, so that a decoder can start there without the components before it
+	struct Named { uint32_t mark, id, count; };
+	std::vector<Named> named;
+	void name(uint32_t v, uint32_t count) { if (record && !marks.empty()) named.push_back(Named{ (uint32_t)marks.size() - 1, v, count }); vertid(v); }
 	void numtri(int n) { if (n != 0) { uint16_t v = (uint16_t)n; bytes(CTX_NUMTRI, (const uint8_t*)&v, 2); } }   // io.h:162-165
 	void reg_face(uint16_t r) { bytes(CTX_REGFACE, (const uint8_t*)&r, 2); }
 	void reg_vtx(uint16_t r) { bytes(CTX_REGVTX, (const uint8_t*)&r, 2); }
@@ -1014,13 +1020,13 @@ static void cbm_encode(Mesh &m, SymWriter &wr, std::vector<uint32_t> &order_v, s
 		bool m0 = mapped(a), m1 = mapped(b), m2 = mapped(c);
 		ntri = m.deg(f) - 2;
 		// encoder.h:76-123; ids are written as transmitted indices, new vertices recorded in this order
-		if (m0 && m1 && m2) { wr.iop(IOP_TRI111); wr.vertid(perm[a]); wr.vertid(perm[b]); wr.vertid(perm[c]); wr.numtri(ntri); }
-		else if (m0 && m1) { wr.iop(IOP_TRI110); wr.vertid(perm[a]); wr.vertid(perm[b]); wr.numtri(ntri); add_vtx(e2); }
-		else if (m1 && m2) { wr.iop(IOP_TRI011); wr.vertid(perm[b]); wr.vertid(perm[c]); wr.numtri(ntri); add_vtx(e0); }
-		else if (m2 && m0) { wr.iop(IOP_TRI101); wr.vertid(perm[c]); wr.vertid(perm[a]); wr.numtri(ntri); add_vtx(e1); }
-		else if (m0) { wr.iop(IOP_TRI100); wr.vertid(perm[a]); wr.numtri(ntri); add_vtx(e1); add_vtx(e2); }
-		else if (m1) { wr.iop(IOP_TRI010); wr.vertid(perm[b]); wr.numtri(ntri); add_vtx(e2); add_vtx(e0); }
-		else if (m2) { wr.iop(IOP_TRI001); wr.vertid(perm[c]); wr.numtri(ntri); add_vtx(e0); add_vtx(e1); }
+		if (m0 && m1 && m2) { wr.iop(IOP_TRI111); wr.name(perm[a], seen[a]); wr.name(perm[b], seen[b]); wr.name(perm[c], seen[c]); wr.numtri(ntri); }
+		else if (m0 && m1) { wr.iop(IOP_TRI110); wr.name(perm[a], seen[a]); wr.name(perm[b], seen[b]); wr.numtri(ntri); add_vtx(e2); }
+		else if (m1 && m2) { wr.iop(IOP_TRI011); wr.name(perm[b], seen[b]); wr.name(perm[c], seen[c]); wr.numtri(ntri); add_vtx(e0); }
+		else if (m2 && m0) { wr.iop(IOP_TRI101); wr.name(perm[c], seen[c]); wr.name(perm[a], seen[a]); wr.numtri(ntri); add_vtx(e1); }
+		else if (m0) { wr.iop(IOP_TRI100); wr.name(perm[a], seen[a]); wr.numtri(ntri); add_vtx(e1); add_vtx(e2); }
+		else if (m1) { wr.iop(IOP_TRI010); wr.name(perm[b], seen[b]); wr.numtri(ntri); add_vtx(e2); add_vtx(e0); }
+		else if (m2) { wr.iop(IOP_TRI001); wr.name(perm[c], seen[c]); wr.numtri(ntri); add_vtx(e0); add_vtx(e1); }
 		else { wr.iop(IOP_INIT); wr.numtri(ntri); add_vtx(e0); add_vtx(e1); add_vtx(e2); }
 		order_f.push_back(e0);
 		++seen[a]; ++seen[b]; ++seen[c];
@@ -1068,7 +1074,7 @@ static void cbm_encode(Mesh &m, SymWriter &wr, std::vector<uint32_t> &order_v, s
 				if (!cb.find_and_update(v2, i, p, op)) {
 					cb.new_vertex(Elem{ v2, 0 });
 					cb.first->a = e1; cb.second->a = e2;
-					wr.op(OP_NM); wr.vertid(perm[v2]); wr.numtri(nt);
+					wr.op(OP_NM); wr.name(perm[v2], seen[v2]); wr.numtri(nt);
 				} else if (op == OP_UNION) {
 					wr.op(OP_UNION); wr.elem(i); wr.part(p); wr.numtri(nt);
 					cb.first->a = e1; cb.second->a = e2;
@@ -1361,7 +1367,8 @@ static Mesh *decode(const uint8_t *p, size_t n)
 // not stored: reg_face/reg_vtx (single region), attr_type (always DATA), numtri for single-degree meshes.
 // Operations are split into one plane per order class (models.h:101-105) with a plain adaptive 7-symbol model.
 //   u32 chunk_syms, u32 conn_chunk_syms, u32 n_planes, n_planes x u32 n_symbols, n_planes x prior (see plane_prior / write_prior),
-//   u32 n_restart, n_restart x 17 u32 (restart points, see encode_chunked), per stream u32 n_bytes, then the streams.
+//   u32 n_restart, n_restart x 17 u32 (restart points, see encode_chunked), per restart point u32 n + n x (u32 vertex, u32 counter),
+//   per stream u32 n_bytes, then the streams.
 // Plane order: iop, elem[4], part[2], vertid[4], numtri[2], op class[8], vertex data bytes, face data bytes.
 // The first 21 planes (connectivity) are cut every conn_chunk_syms symbols, the attribute planes every chunk_syms: the
 // decoder needs the connectivity first and a stream is a serial chain, so short connectivity streams shorten its start-up
@@ -1506,6 +1513,29 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 			}
 			w.put<uint32_t>((uint32_t)pts.size());
 			for (auto &r : pts) for (uint32_t x : r) w.put<uint32_t>(x);
+			// per restart point: the older vertices its span names (first naming in the span) with their counters at that moment
+			// = at the start of the span (a vertex is only touched after it has been named in the component at hand)
+			std::vector<uint32_t> span_of_mark(wr.marks.size(), 0xffffffffu);   // mark -> index of its restart span, or none (span before the first point)
+			{
+				for (size_t k = 1; k < wr.marks.size(); ++k) {
+					if (pts.empty() || wr.marks[k].first_face < pts[0][14]) continue;
+					size_t q = 0;
+					while (q + 1 < pts.size() && wr.marks[k].first_face >= pts[q + 1][14]) ++q;
+					span_of_mark[k] = (uint32_t)q;
+				}
+			}
+			std::vector<std::vector<std::pair<uint32_t, uint32_t>>> counters(pts.size());
+			for (const SymWriter::Named &ev : wr.named) {
+				const uint32_t sp = span_of_mark[ev.mark];
+				if (sp == 0xffffffffu || ev.id >= pts[sp][13]) continue;
+				bool dup = false;
+				for (auto &c : counters[sp]) if (c.first == ev.id) { dup = true; break; }
+				if (!dup) counters[sp].push_back({ ev.id, ev.count });
+			}
+			for (auto &cs : counters) {
+				w.put<uint32_t>((uint32_t)cs.size());
+				for (auto &c : cs) { w.put<uint32_t>(c.first); w.put<uint32_t>(c.second); }
+			}
 		}
 		std::vector<std::vector<uint8_t>> streams;
 		for (size_t pi = 0; pi < planes.size(); ++pi) {
@@ -1554,6 +1584,7 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 		for (size_t k = 0; k < np; ++k) has_prior[k] = read_prior(br, prior[k].data()) ? 1 : 0;
 		uint32_t n_restart = br.get<uint32_t>();   // restart points: an aid for parallel decoders, not needed here
 		for (uint64_t i = 0; i < (uint64_t)n_restart * 17; ++i) (void)br.get<uint32_t>();
+		for (uint32_t i = 0; i < n_restart; ++i) { uint32_t nc = br.get<uint32_t>(); for (uint64_t j = 0; j < 2ull * nc; ++j) (void)br.get<uint32_t>(); }
 		std::vector<uint32_t> nbytes(nstreams);
 		for (auto &x : nbytes) x = br.get<uint32_t>();
 		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
