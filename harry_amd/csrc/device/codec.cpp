@@ -29,7 +29,11 @@ Context::Context(int dev) : device(dev)
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(HRY_E_NODEVICE, "no HIP device available: the .hry path has no CPU fallback");
 	if (dev < 0 || dev >= n) throw Error(HRY_E_ARG, "invalid device index");
 	HIP_OK(hipSetDevice(dev));
-	HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	// the codec's main stream outranks the helper streams: its launches (connectivity streams of a decode, the reconstruction
+	// chain) must not queue behind the tens of thousands of attribute-stream workgroups on stream3
+	int prio_lo = 0, prio_hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+	HIP_OK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_hi));
 	for (auto &e : ev) HIP_OK(hipEventCreate(&e));
 }
 Context::~Context()
@@ -95,12 +99,9 @@ void Context::upload_mesh(Mesh &m)
 	int ud = 0;
 	res_has_eface = !m.uniform_degree(ud);
 	res_udeg = (uint32_t)ud;
-	if (res_has_eface) {
-		std::vector<uint32_t> ef(ne);
-		for (uint32_t f = 0; f < m.nf; ++f) for (uint32_t e = m.face_off[f]; e < m.face_off[f + 1]; ++e) ef[e] = f;
-		d_eface.ensure((size_t)ne * 4);
-		HIP_OK(hipMemcpyAsync(d_eface.p, ef.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
-		HIP_OK(hipStreamSynchronize(stream));
+	if (res_has_eface) {   // mixed polygon degrees: face of every half-edge, derived on the device from the offsets
+		d_eface.ensure(std::max<size_t>((size_t)ne * 4, 16));
+		dev::launch_edge_faces(stream, d_foff.as<uint32_t>(), m.nf, d_eface.as<uint32_t>());
 	}
 	HIP_OK(hipStreamSynchronize(stream));
 	res_nv = m.nv; res_nf = m.nf; res_ne = ne;
