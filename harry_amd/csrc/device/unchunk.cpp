@@ -327,9 +327,9 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	ReplayCursor cur;
 	try {
 		int onlydeg = ud;
-		struct PlanesRd {
-			const std::vector<uint8_t> *pl; size_t cur[21]; int fixed_numtri;
-			uint32_t byte(int plane) { const std::vector<uint8_t> &v = pl[plane]; if (cur[plane] >= v.size()) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)"); return v[cur[plane]++]; }
+		struct PlanesRd {   // bare cursors: the replay reads a byte or two per operation
+			const uint8_t *cur[21], *end[21]; int fixed_numtri;
+			uint32_t byte(int plane) { if (cur[plane] == end[plane]) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)"); return *cur[plane]++; }
 			uint32_t iop() { return byte(0); }
 			uint32_t u32(int first) { uint32_t v = byte(first); v |= byte(first + 1) << 8; v |= byte(first + 2) << 16; v |= byte(first + 3) << 24; return v; }
 			int elem() { uint32_t z = u32(1); return (int)((z >> 1) ^ ((z & 1) ? 0xffffffffu : 0u)); }
@@ -337,7 +337,9 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 			uint32_t vertid() { return u32(7); }
 			int numtri() { return fixed_numtri; }
 			uint32_t op(int order) { int k = order - 1; if (k > 7) k = 7; if (k < 0) k = 0; return byte(13 + k); }
-		} rd{ conn, { 0 }, onlydeg - 2 };
+		} rd;
+		for (int k = 0; k < 21; ++k) { rd.cur[k] = conn[k].data(); rd.end[k] = conn[k].data() + conn[k].size(); }
+		rd.fixed_numtri = onlydeg - 2;
 		const RestartCounters none;
 		std::vector<uint32_t> comp_first;
 		std::vector<std::pair<uint32_t, uint32_t>> refs;

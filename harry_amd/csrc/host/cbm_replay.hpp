@@ -21,20 +21,20 @@ struct Ring {
 	struct Node { uint32_t v, a; int32_t prev, next; };
 	struct Part { int32_t head, tail; uint32_t size; bool edge_begin; };
 	std::vector<Node> pool;
-	std::vector<int32_t> spare;
+	int32_t free_head = -1;          // dropped nodes, chained through .next
 	std::vector<Part> parts;
 	uint16_t *on_border = nullptr;   // optional: how often every vertex currently occurs on the border (ReplayLive)
 	Part &top() { return parts.back(); }
 	int32_t make(uint32_t v, uint32_t a)
 	{
 		if (on_border) ++on_border[v];
-		int32_t i;
-		if (!spare.empty()) { i = spare.back(); spare.pop_back(); }
+		int32_t i = free_head;
+		if (i >= 0) free_head = pool[i].next;
 		else { i = (int32_t)pool.size(); pool.push_back(Node()); }
 		pool[i] = Node{ v, a, -1, -1 };
 		return i;
 	}
-	void drop(int32_t i) { if (on_border) --on_border[pool[i].v]; spare.push_back(i); }
+	void drop(int32_t i) { if (on_border) --on_border[pool[i].v]; pool[i].next = free_head; free_head = i; }
 	void append(Part &p, int32_t i)
 	{
 		pool[i].prev = p.tail; pool[i].next = -1;
@@ -65,7 +65,7 @@ struct Ring {
 	}
 	void discard_top()
 	{
-		for (int32_t i = top().head; i >= 0;) { int32_t nx = pool[i].next; drop(i); i = nx; }
+		for (int32_t i = top().head; i >= 0;) { int32_t nx = pool[i].next; drop(i); i = nx; }   // (drop overwrites .next: read it first)
 		parts.pop_back();
 	}
 	Op border()   // cutborder.h:217-248
@@ -172,7 +172,8 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen_shared, uint32_t *order_v, Repl
 		uint32_t o = he;
 		he += (uint32_t)ne;
 		m.face_off[++face] = he;
-		for (int i = 0; i < ne; ++i) { m.org[o + i] = 0; m.twin[o + i] = o + i; }
+		for (int i = 0; i < ne; ++i) m.twin[o + i] = o + i;
+		for (int i = 3; i < ne; ++i) m.org[o + i] = 0;   // the first three origins are assigned by the caller right away
 		return o;
 	};
 
