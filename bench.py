@@ -57,6 +57,43 @@ def cpu_baseline(mesh, quant, budget_s=20.0):
             "sample": f"full workload ({ntri} triangles, -l1 -q14), {reps} encode+decode repetitions, 1 thread"}, hry
 
 
+def cpu_baseline_reference(mesh, budget_s=20.0):
+    """The UNMODIFIED reference binary (oracle/_ref/harry_ref, built from /root/reference by oracle/Makefile; it travels with
+    the snapshot), timed on this box's host cores on the same workload: its own phase clocks (main.cc:99-120) --
+    encode = "Quantization" + "Writing output" of `harry in.ply out.hry -l1 -q14`, decode = "Reading input" of
+    `harry out.hry back.ply`.  Single-threaded, like the reference.  Returns None where the binary is not available."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "harry_ref")
+    if not os.path.exists(exe):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            ply, hry, back = os.path.join(td, "in.ply"), os.path.join(td, "out.hry"), os.path.join(td, "back.ply")
+            with open(ply, "wb") as f:
+                f.write(mesh.to_ply())
+            t_enc = t_dec = 0.0
+            reps = 0
+            t_start = time.perf_counter()
+            ms = lambda text, what: float(re.search(what + r" took (\d+) ms", text).group(1))
+            while reps < 1 or (time.perf_counter() - t_start < budget_s and reps < 8):
+                e = subprocess.run([exe, ply, hry, "-l1", "-q14"], capture_output=True, text=True, timeout=300, check=True).stdout
+                d = subprocess.run([exe, hry, back], capture_output=True, text=True, timeout=300, check=True).stdout
+                t_enc += (ms(e, "Quantization") + ms(e, "Writing output")) * 1e-3
+                t_dec += ms(d, "Reading input") * 1e-3
+                reps += 1
+            nbytes = os.path.getsize(hry)
+        ntri = mesh.ntri
+        return {"value": round(ntri * reps / (t_enc + t_dec) / 1e6, 4), "unit": "Mtriangles/s", "cores": 1, "kind": "reference",
+                "encode_mtri_s": round(ntri * reps / t_enc / 1e6, 4), "decode_mtri_s": round(ntri * reps / t_dec / 1e6, 4), "hry_bytes": nbytes,
+                "sample": f"full workload ({ntri} triangles, -l1 -q14), {reps} runs of the reference binary (encode = its Quantization + "
+                          f"Writing output phases, decode = its Reading input phase of the .hry; 1 ms clock), 1 thread"}
+    except Exception as exc:   # the checker must never take the benchmark down
+        sys.stderr.write(f"reference baseline unavailable: {exc}\n")
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,8 +245,14 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            cb, ref_hry = cpu_baseline(mesh, quant)
-            line["cpu_baseline"] = cb
+            cb, ref_hry = cpu_baseline(mesh, quant, budget_s=8.0)
+            ref = cpu_baseline_reference(mesh, budget_s=12.0)
+            if ref is not None:
+                line["cpu_baseline"] = ref            # the reference itself
+                line["cpu_baseline_port"] = cb        # the oracle (CPU restatement) in memory, same workload
+                line["reference_bytes_equal_port"] = bool(ref["hry_bytes"] == len(ref_hry))
+            else:
+                line["cpu_baseline"] = cb
             line["bits_per_vertex_cpu_ref"] = round(8 * len(ref_hry) / base.nv, 4)
             if profile == "compat":
                 line["byte_identical_to_cpu_ref"] = bool(out == ref_hry)
