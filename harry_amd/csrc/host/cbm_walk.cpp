@@ -32,56 +32,57 @@ struct Border {
 	struct Node { uint32_t v, a; int32_t prev, next; };
 	struct Part { int32_t head, tail; uint32_t size; bool edge_begin; };
 	std::vector<Node> pool;
-	std::vector<int32_t> spare;
+	Node *P = nullptr;               // == pool.data(): the hot loop indexes through it (refreshed when the pool grows)
+	int32_t free_head = -1;          // dropped nodes, chained through .next
 	std::vector<Part> parts;
 	BigVec<uint8_t> &on;  // how many border elements reference a vertex (cutborder.h:69); shared per-vertex array
 
-	explicit Border(BigVec<uint8_t> &on_) : on(on_) { pool.reserve(1024); }
+	explicit Border(BigVec<uint8_t> &on_) : on(on_) { pool.reserve(1 << 16); P = pool.data(); }
 	Part &top() { return parts.back(); }
-	Node &N(int32_t i) { return pool[i]; }
+	Node &N(int32_t i) { return P[i]; }
 
 	int32_t make(uint32_t v, uint32_t a)
 	{
-		int32_t i;
-		if (!spare.empty()) { i = spare.back(); spare.pop_back(); }
-		else { i = (int32_t)pool.size(); pool.push_back(Node()); }
-		pool[i] = Node{ v, a, -1, -1 };
+		int32_t i = free_head;
+		if (i >= 0) free_head = P[i].next;
+		else { i = (int32_t)pool.size(); pool.push_back(Node()); P = pool.data(); }
+		P[i] = Node{ v, a, -1, -1 };
 		++on[v];
 		return i;
 	}
-	void drop(int32_t i) { --on[pool[i].v]; spare.push_back(i); }
+	void drop(int32_t i) { --on[P[i].v]; P[i].next = free_head; free_head = i; }
 	void append(Part &p, int32_t i)
 	{
-		pool[i].prev = p.tail; pool[i].next = -1;
-		if (p.tail >= 0) pool[p.tail].next = i; else p.head = i;
+		P[i].prev = p.tail; P[i].next = -1;
+		if (p.tail >= 0) P[p.tail].next = i; else p.head = i;
 		p.tail = i; ++p.size;
 	}
 	void prepend(Part &p, int32_t i)
 	{
-		pool[i].next = p.head; pool[i].prev = -1;
-		if (p.head >= 0) pool[p.head].prev = i; else p.tail = i;
+		P[i].next = p.head; P[i].prev = -1;
+		if (p.head >= 0) P[p.head].prev = i; else p.tail = i;
 		p.head = i; ++p.size;
 	}
 	int32_t unlink_tail(Part &p)
 	{
 		int32_t i = p.tail;
-		p.tail = pool[i].prev;
-		if (p.tail >= 0) pool[p.tail].next = -1; else p.head = -1;
+		p.tail = P[i].prev;
+		if (p.tail >= 0) P[p.tail].next = -1; else p.head = -1;
 		--p.size;
 		return i;
 	}
 	int32_t unlink_head(Part &p)
 	{
 		int32_t i = p.head;
-		p.head = pool[i].next;
-		if (p.head >= 0) pool[p.head].prev = -1; else p.tail = -1;
+		p.head = P[i].next;
+		if (p.head >= 0) P[p.head].prev = -1; else p.tail = -1;
 		--p.size;
 		return i;
 	}
 	void discard_top()
 	{
 		Part &p = top();
-		for (int32_t i = p.head; i >= 0;) { int32_t nx = pool[i].next; drop(i); i = nx; }
+		for (int32_t i = p.head; i >= 0;) { int32_t nx = P[i].next; drop(i); i = nx; }
 		parts.pop_back();
 	}
 
@@ -113,13 +114,13 @@ struct Border {
 		int32_t fw = parts[pi].head, bw = parts[pi].tail;
 		i = 0; p = 0;
 		for (;;) {
-			if (pool[fw].v == v) { ++i; return fw; }
-			if (pool[bw].v == v) { i = -i; return bw; }
-			if (bw == fw || pool[bw].next == fw) {
+			if (P[fw].v == v) { ++i; return fw; }
+			if (P[bw].v == v) { i = -i; return bw; }
+			if (bw == fw || P[bw].next == fw) {
 				++p; --pi;
 				fw = parts[pi].head; bw = parts[pi].tail;
 				i = 0;
-			} else { fw = pool[fw].next; bw = pool[bw].prev; ++i; }
+			} else { fw = P[fw].next; bw = P[bw].prev; ++i; }
 		}
 	}
 	// cutborder.h:250-268. Returns (gate node, copy-of-hit node): their .a are filled by the caller.
@@ -132,15 +133,15 @@ struct Border {
 		Part np{ -1, -1, 0, true };
 		if (before > 0) {   // move [head, hit) to the new part
 			Part &old = parts[oi];
-			int32_t last = pool[hit].prev;
+			int32_t last = P[hit].prev;
 			np.head = old.head; np.tail = last; np.size = before;
-			pool[last].next = -1;
-			pool[hit].prev = -1;
+			P[last].next = -1;
+			P[hit].prev = -1;
 			old.head = hit;
 			old.size -= before;
 		}
 		append(parts[oi], g);
-		copy_node = make(pool[hit].v, pool[hit].a);
+		copy_node = make(P[hit].v, P[hit].a);
 		append(np, copy_node);
 		np.edge_begin = parts[oi].edge_begin;
 		parts[oi].edge_begin = true;
@@ -155,18 +156,18 @@ struct Border {
 		Part &cur = parts[ci];
 		gate_node = cur.tail;
 		if (hit != other.head) {   // rotate the other part so that it starts at the hit
-			pool[other.tail].next = other.head;
-			pool[other.head].prev = other.tail;
-			int32_t last = pool[hit].prev;
-			pool[last].next = -1;
-			pool[hit].prev = -1;
+			P[other.tail].next = other.head;
+			P[other.head].prev = other.tail;
+			int32_t last = P[hit].prev;
+			P[last].next = -1;
+			P[hit].prev = -1;
 			other.head = hit; other.tail = last;
 		}
-		pool[cur.tail].next = other.head;
-		pool[other.head].prev = cur.tail;
+		P[cur.tail].next = other.head;
+		P[other.head].prev = cur.tail;
 		cur.tail = other.tail;
 		cur.size += other.size;
-		copy_node = make(pool[hit].v, pool[hit].a);
+		copy_node = make(P[hit].v, P[hit].a);
 		append(cur, copy_node);
 		parts.erase(parts.begin() + (long)oi);
 	}
