@@ -244,6 +244,27 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in cands.items()},
             "roofline": roof,
         }
+        # end to end, as the `harry in.ply out.hry -l1 -q14` / `harry out.hry back.ply` command lines see it: PLY bytes ->
+        # parse + twin matching -> upload -> quantisation -> .hry bytes, and .hry bytes -> mesh -> binary PLY bytes.  Outside the timed
+        # region; not part of `value`.
+        try:
+            ply_bytes = mesh.to_ply()
+            e2e_e, e2e_d = [], []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                mm = hc.Mesh.from_ply(ply_bytes)
+                cx.requant(mm, quant)
+                hb = cx.write_hry(mm, profile=pid)
+                t1 = time.perf_counter()
+                back = cx.read_hry(hb).to_ply() if can_decode else b""
+                t2 = time.perf_counter()
+                e2e_e.append(t1 - t0); e2e_d.append(t2 - t1)
+            line["end_to_end"] = {"encode_ms": round(float(np.median(e2e_e)) * 1e3, 3), "decode_ms": round(float(np.median(e2e_d)) * 1e3, 3),
+                                  "encode_mtri_s": round(ntri / float(np.median(e2e_e)) / 1e6, 3),
+                                  "decode_mtri_s": round(ntri / float(np.median(e2e_d)) / 1e6, 3) if can_decode else None,
+                                  "ply_bytes": len(ply_bytes), "what": "PLY bytes -> .hry bytes (parse, twin matching, upload, quantisation, encode); .hry bytes -> PLY bytes"}
+        except Exception as exc:
+            sys.stderr.write(f"end-to-end leg failed: {exc}\n")
         if not args.no_cpu_baseline and world == 1:
             cb, ref_hry = cpu_baseline(mesh, quant, budget_s=8.0)
             ref = cpu_baseline_reference(mesh, budget_s=12.0)

@@ -6,6 +6,8 @@
 // table instead of std::unordered_map.
 #include "host.hpp"
 
+#include <atomic>
+
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -124,24 +126,96 @@ struct EdgeTable {
 };
 }   // namespace
 
+// The reference pairs half-edges greedily in face order (structs/conn.h:201-214): a half-edge a->c takes the waiting half-edge
+// c->a if there is one, else it waits itself unless an earlier a->c is still waiting.  Only half-edges of the same undirected
+// edge ever interact, so the edges can be dealt out to buckets (by their smaller vertex) and every bucket paired
+// independently with the very same rule, each on its own host thread -- as long as a bucket sees its half-edges in face
+// order, which a stable scatter guarantees.  Result: identical twins, ~10 times sooner on 16 threads (the hash-map pass was
+// 100 ms per million triangles: six times the whole encode).
+static void pair_bucket(const uint64_t *pairs, size_t n, uint32_t *twin)
+{
+	// pairs: (directed key a<<32|c, half-edge) as two u64 per entry, in face order
+	EdgeTable tab(n);
+	for (size_t i = 0; i < n; ++i) {
+		const uint64_t k = pairs[2 * i];
+		const uint32_t h = (uint32_t)pairs[2 * i + 1];
+		const uint64_t opp = (k << 32) | (k >> 32);
+		int64_t s = tab.find(opp);
+		if (s >= 0) {
+			uint32_t o = tab.val[s];
+			twin[o] = h; twin[h] = o;
+			tab.erase(s);
+		} else tab.insert_if_absent(k, h);
+	}
+}
+
 void build_twins(Mesh &m)
 {
-	uint32_t ne = m.ne();
+	const uint32_t ne = m.ne(), nf = m.nf;
 	m.twin.resize(ne);
-	for (uint32_t e = 0; e < ne; ++e) m.twin[e] = e;
-	EdgeTable tab(ne);
-	for (uint32_t f = 0; f < m.nf; ++f) {
-		uint32_t b = m.face_off[f], e = m.face_off[f + 1];
-		for (uint32_t h = b; h < e; ++h) {
-			uint32_t a = m.org[h], c = m.org[h + 1 == e ? b : h + 1];
-			int64_t s = tab.find(((uint64_t)c << 32) | a);
-			if (s >= 0) {
-				uint32_t o = tab.val[s];
-				m.twin[o] = h; m.twin[h] = o;
-				tab.erase(s);
-			} else tab.insert_if_absent(((uint64_t)a << 32) | c, h);
+	const unsigned nt = ne >= (1u << 18) ? host_threads() : 1u;
+	if (nt < 2) {
+		for (uint32_t e = 0; e < ne; ++e) m.twin[e] = e;
+		EdgeTable tab(ne);
+		for (uint32_t f = 0; f < nf; ++f) {
+			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
+			for (uint32_t h = b; h < e; ++h) {
+				uint32_t a = m.org[h], c = m.org[h + 1 == e ? b : h + 1];
+				int64_t s = tab.find(((uint64_t)c << 32) | a);
+				if (s >= 0) {
+					uint32_t o = tab.val[s];
+					m.twin[o] = h; m.twin[h] = o;
+					tab.erase(s);
+				} else tab.insert_if_absent(((uint64_t)a << 32) | c, h);
+			}
 		}
+		return;
 	}
+	// buckets by the smaller endpoint: a few per thread so that uneven meshes still balance
+	const uint32_t nb = nt * 8;
+	const uint64_t nvp = (uint64_t)m.nv + 1;
+	auto bucket_of = [&](uint32_t a, uint32_t c) { return (uint32_t)(((uint64_t)std::min(a, c) * nb) / nvp); };
+	auto face_range = [&](unsigned t, uint32_t &fb, uint32_t &fe) { fb = (uint32_t)((uint64_t)nf * t / nt); fe = (uint32_t)((uint64_t)nf * (t + 1) / nt); };
+	std::vector<uint64_t> count((size_t)nt * nb, 0);
+	parallel_for(nt, [&](unsigned t) {
+		uint32_t fb, fe; face_range(t, fb, fe);
+		uint64_t *cnt = count.data() + (size_t)t * nb;
+		for (uint32_t f = fb; f < fe; ++f) {
+			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
+			for (uint32_t h = b; h < e; ++h) { m.twin[h] = h; ++cnt[bucket_of(m.org[h], m.org[h + 1 == e ? b : h + 1])]; }
+		}
+	});
+	// bucket-major, thread-minor offsets: inside a bucket the threads' (= face ranges') entries follow one another in face order
+	std::vector<uint64_t> start((size_t)nt * nb), bucket_begin(nb + 1, 0);
+	uint64_t run = 0;
+	for (uint32_t k = 0; k < nb; ++k) {
+		bucket_begin[k] = run;
+		for (unsigned t = 0; t < nt; ++t) { start[(size_t)t * nb + k] = run; run += count[(size_t)t * nb + k]; }
+	}
+	bucket_begin[nb] = run;
+	BigVec<uint64_t> pairs;
+	pairs.resize(2 * (size_t)ne);
+	parallel_for(nt, [&](unsigned t) {
+		uint32_t fb, fe; face_range(t, fb, fe);
+		uint64_t *pos = start.data() + (size_t)t * nb;
+		for (uint32_t f = fb; f < fe; ++f) {
+			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
+			for (uint32_t h = b; h < e; ++h) {
+				const uint32_t a = m.org[h], c = m.org[h + 1 == e ? b : h + 1];
+				const uint64_t p = pos[bucket_of(a, c)]++;
+				pairs[2 * p] = ((uint64_t)a << 32) | c;
+				pairs[2 * p + 1] = h;
+			}
+		}
+	});
+	std::atomic<uint32_t> next{ 0 };
+	parallel_for(nt, [&](unsigned) {
+		for (;;) {
+			const uint32_t k = next.fetch_add(1, std::memory_order_relaxed);
+			if (k >= nb) break;
+			pair_bucket(pairs.data() + 2 * bucket_begin[k], (size_t)(bucket_begin[k + 1] - bucket_begin[k]), m.twin.data());
+		}
+	});
 }
 
 // ---- reader ----------------------------------------------------------------------------------------------

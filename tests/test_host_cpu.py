@@ -274,3 +274,29 @@ def test_replay_from_restart_points_equals_sequential_replay(case):
         assert np.array_equal(ref.org(), dec.org())
         assert np.array_equal(ref.twin(), dec.twin())
         assert np.array_equal(ov, ov2) and np.array_equal(ss, ss2) and np.array_equal(sl, sl2)
+
+
+# ---------------------------------------------------------------- half-edge twin matching on several threads
+@pytest.mark.parametrize("case", ["torus_tri", "mixed_nonmanifold", "open_grid", "duplicates"])
+def test_threaded_twin_matching_equals_sequential(case):
+    """structs/conn.h:201-214 pairs half-edges greedily in face order; the product deals the edges out to buckets and pairs
+    every bucket with the same rule on its own thread.  Twins must be identical to the one-thread pass, also where an edge
+    carries more than two faces or the same face occurs twice (order-dependent pairing)."""
+    m = {"torus_tri": lambda: mg.torus(310, 300, seed=3),
+         "mixed_nonmanifold": lambda: mg.with_nonmanifold(mg.torus(260, 250, polys="mixed", seed=5), 400, 150),
+         "open_grid": lambda: mg.grid(400, 350),
+         "duplicates": lambda: mg.concat([mg.torus(300, 300, seed=1), mg.torus(20, 20, seed=1)])}[case]()
+    if case == "duplicates":   # the small torus a second time on the SAME vertices: every one of its edges carries four faces
+        small = mg.torus(20, 20, seed=1)
+        idx = np.concatenate([m.indices, small.indices.astype(np.uint32) + np.uint32(300 * 300)])
+        m = mg.Mesh(m.verts, np.concatenate([m.degrees, small.degrees]), idx)
+    def twins(threads):
+        os.environ["HRY_HOST_THREADS"] = str(threads)
+        try:
+            return hc.Mesh.from_arrays(m.verts, m.degrees, m.indices).twin().copy()
+        finally:
+            del os.environ["HRY_HOST_THREADS"]
+    ref = twins(1)
+    assert len(ref) >= 1 << 18, "the case must be large enough for the threaded path"
+    for t in (2, 7):
+        assert np.array_equal(ref, twins(t)), t
