@@ -248,6 +248,8 @@ def main():
         # parse + twin matching -> upload -> quantisation -> .hry bytes, and .hry bytes -> mesh -> binary PLY bytes.  Outside the timed
         # region; not part of `value`.
         try:
+            if world != 1:
+                raise RuntimeError("skipped on multi-GPU runs (rank 0 only work would hold the other ranks at shutdown)")
             ply_bytes = mesh.to_ply()
             e2e_e, e2e_d = [], []
             for _ in range(3):
@@ -264,7 +266,8 @@ def main():
                                   "decode_mtri_s": round(ntri / float(np.median(e2e_d)) / 1e6, 3) if can_decode else None,
                                   "ply_bytes": len(ply_bytes), "what": "PLY bytes -> .hry bytes (parse, twin matching, upload, quantisation, encode); .hry bytes -> PLY bytes"}
         except Exception as exc:
-            sys.stderr.write(f"end-to-end leg failed: {exc}\n")
+            if world == 1:
+                sys.stderr.write(f"end-to-end leg failed: {exc}\n")
         if not args.no_cpu_baseline and world == 1:
             cb, ref_hry = cpu_baseline(mesh, quant, budget_s=8.0)
             ref = cpu_baseline_reference(mesh, budget_s=12.0)
