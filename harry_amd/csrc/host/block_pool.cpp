@@ -1,5 +1,6 @@
 // Recycling pool for the big host arrays (mesh.hpp: BlockPool / BigVec).
 #include <cstdlib>
+#include <sys/mman.h>
 #include <map>
 #include <mutex>
 #include <new>
@@ -22,6 +23,7 @@ struct Pool {
 	}
 	~Pool() { for (auto &kv : free_blocks) free(kv.second); }
 };
+bool huge_pages_wanted() { static const bool on = getenv("HRY_NO_HUGEPAGES") == nullptr; return on; }
 Pool &pool() { static Pool *p = new Pool(); return *p; }   // never destroyed: vectors in static objects may outlive any order
 }   // namespace
 
@@ -38,9 +40,15 @@ void *BlockPool::take(size_t bytes)
 			return p;
 		}
 	}
-	const size_t cap = (bytes + 65535) & ~(size_t)65535;
-	void *p = aligned_alloc(64, cap);
+	// 2 MiB alignment + MADV_HUGEPAGE: the walk and the replay touch these arrays ring by ring, i.e. a few entries on
+	// thousands of different 4 KiB pages per ring -- with transparent huge pages (where the system grants them) the
+	// page-table walks disappear.  Purely advisory: without THP nothing changes.
+	const size_t huge = (size_t)2 << 20;
+	const bool want_huge = bytes >= huge && huge_pages_wanted();
+	const size_t cap = want_huge ? (bytes + huge - 1) & ~(huge - 1) : (bytes + 65535) & ~(size_t)65535;
+	void *p = aligned_alloc(want_huge ? huge : 64, cap);
 	if (!p) throw std::bad_alloc();
+	if (want_huge) (void)madvise(p, cap, MADV_HUGEPAGE);
 	std::lock_guard<std::mutex> g(P.mu);
 	P.capacity[p] = cap;
 	return p;
