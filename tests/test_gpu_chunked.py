@@ -100,7 +100,7 @@ def test_chunked_decode_from_restart_points(cx, case, monkeypatch):
     same_mesh(cx.read_hry(got), ref_dec)
 
 
-@pytest.mark.parametrize("case", ["torus150_q14", "grid_quads_q12", "ico5_q10", "colors_normals", "open_grid_q8"])
+@pytest.mark.parametrize("case", ["torus150_q14", "grid_quads_q12", "ico5_q10", "colors_normals", "open_grid_q8", "face_props"])
 @pytest.mark.parametrize("faces,slice_", [(64, 64), (1000, 4096)])
 def test_chunked_pipelined_decode(cx, case, faces, slice_, monkeypatch):
     """The pipelined decode (replay publishes its progress; uploads, candidates and the reconstruction chain of every
@@ -113,6 +113,7 @@ def test_chunked_pipelined_decode(cx, case, faces, slice_, monkeypatch):
         "ico5_q10": (lambda: mg.icosphere(5), [(1, -1, 10)]),
         "colors_normals": (lambda: mg.with_colors(mg.torus(90, 80, normals=True)), [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)]),
         "open_grid_q8": (lambda: mg.grid(200, 150), [(1, -1, 8)]),
+        "face_props": (lambda: mg.with_face_props(mg.torus(90, 80, seed=4)), [(1, -1, 12)]),   # lossless face attributes next to the quantised vertices
     }[case]
     ply = mesh().to_ply()
     a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
