@@ -516,12 +516,16 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), n_conn_streams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
 	                    cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>(), cx.d_csizes.as<uint32_t>());
 	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
-	HIP_OK(hipStreamWaitEvent(cx.stream3, cx.ev_x[0], 0));
+	// the attribute streams wait for the connectivity streams' kernel: launched side by side, the long attribute waves took
+	// the SIMD slots the short connectivity waves needed (15 ms instead of 1 ms on a 12 M-triangle mesh), and the host replay
+	// -- the critical path -- waits for exactly those
+	HIP_OK(hipStreamWaitEvent(cx.stream3, getenv("HRY_ATTR_SIDE_BY_SIDE") ? cx.ev_x[0] : cx.ev[2], 0));
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
 	launch_chunk_decode(cx.stream3, cx.d_cjobs.as<StreamJob>() + n_conn_streams, (uint32_t)nstreams - n_conn_streams, cx.d_init.as<uint32_t>(),
 	                    cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>() + n_conn_streams, cx.d_csizes.as<uint32_t>() + n_conn_streams);
 	HIP_OK(hipEventRecord(cx.ev[6], cx.stream3));
 	HIP_OK(hipEventRecord(cx.ev_x[1], cx.stream3));
+	if (trace_on()) { HIP_OK(hipEventSynchronize(cx.ev[2])); HRY_MARK(g_t0, "connectivity streams decoded"); }
 	std::vector<uint8_t> conn[kConnPlanes];
 	for (int k = 0; k < kConnPlanes; ++k) {
 		conn[k].resize(nsym[k]);
