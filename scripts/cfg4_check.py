@@ -14,11 +14,12 @@ m0 = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
 print(f"half-edge build {time.time()-t:.1f}s", flush=True)
 cx = hc.Codec(0)
 r = lambda tm: json.dumps({k: round(v, 1) if isinstance(v, float) else v for k, v in tm.items() if v})
-m = m0.clone(); cx.upload(m)
-t = time.time(); out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED); te = time.time() - t
-print(f"encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(out)} bpv {8*len(out)/mesh.nv:.2f} " + r(cx.timing()), flush=True)
-t = time.time(); dec = cx.read_hry(out); td = time.time() - t
-print(f"decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(cx.timing()), flush=True)
+for it in range(2):   # the first pass pays for module loading, stream creation and first-touch of the pools
+    m = m0.clone(); cx.upload(m)
+    t = time.time(); out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED); te = time.time() - t
+    print(f"pass {it}: encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(out)} bpv {8*len(out)/mesh.nv:.2f} " + r(cx.timing()), flush=True)
+    t = time.time(); dec = cx.read_hry(out); td = time.time() - t
+    print(f"pass {it}: decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(cx.timing()), flush=True)
 if "--no-verify" not in sys.argv:
     from oracle import oracle_py as op
     t = time.time()
