@@ -26,7 +26,8 @@ class Quant(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("profile", C.c_int32), ("chunk_syms", C.c_int32), ("keep_stages", C.c_int32), ("flags", C.c_int32)]
+    _fields_ = [("profile", C.c_int32), ("chunk_syms", C.c_int32), ("keep_stages", C.c_int32), ("flags", C.c_int32),
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -95,6 +96,20 @@ def load():
     L.hry_stream_read_host.restype = C.c_int; L.hry_stream_read_host.argtypes = [C.c_char_p, sz, C.POINTER(vp), C.POINTER(vp)]
     L.hry_walk_replay.restype = C.c_int; L.hry_walk_replay.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.hry_range_encode_lht.restype = C.c_int; L.hry_range_encode_lht.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]
+    L.hry_shard_plan.restype = C.c_int; L.hry_shard_plan.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.hry_plan_free.argtypes = [vp]
+    L.hry_plan_ncomponents.restype = C.c_uint32; L.hry_plan_ncomponents.argtypes = [vp]
+    L.hry_plan_ngroups.restype = C.c_uint32; L.hry_plan_ngroups.argtypes = [vp]
+    L.hry_plan_triangles.restype = C.c_uint64; L.hry_plan_triangles.argtypes = [vp, C.c_int]
+    L.hry_shard_extract.restype = C.c_int; L.hry_shard_extract.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.hry_merge.restype = C.c_int; L.hry_merge.argtypes = [C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.POINTER(vp), C.POINTER(sz)]
+    L.hry_mesh_runs.restype = sz; L.hry_mesh_runs.argtypes = [vp, C.POINTER(vp)]
+    L.hry_shard_elements.restype = sz; L.hry_shard_elements.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.hry_list_set_bounds.restype = C.c_int; L.hry_list_set_bounds.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p]
+    for n in ("min_at", "max_at"):
+        f = getattr(L, "hry_list_" + n); f.restype = C.c_uint32; f.argtypes = [vp, C.c_int, C.c_int]
+    if L.hry_abi_version() != 2:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 2: rebuild it")
     _lib = L
     return L
 

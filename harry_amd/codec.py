@@ -126,6 +126,32 @@ class Mesh:
         st = storage_type(t, q)
         return self.list_data(l)[:, off:off + TYPE_SIZE[st]].copy().view(TYPE_NP[st]).reshape(-1)
 
+    def set_bounds(self, l: int, mn: bytes, mx: bytes):
+        """bounds of list l as records in the original component types (the whole mesh's, for a shard)"""
+        nat.check(nat.load().hry_list_set_bounds(self.h, l, bytes(mn), bytes(mx)))
+
+    def bounds_at(self, l: int):
+        """after Codec.bounds: per component (1 + index of the first element holding the minimum, same for the maximum); 0 = the
+        initial value of the reference's scan"""
+        L = nat.load()
+        n = L.hry_list_ncomp(self.h, l)
+        return [(L.hry_list_min_at(self.h, l, c), L.hry_list_max_at(self.h, l, c)) for c in range(n)]
+
+    def runs(self) -> np.ndarray:
+        """(n, 6) u32: first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges in the numbering of the whole mesh.
+        A shard: where its components go.  A mesh decoded from a sharded container: what was decoded."""
+        p = C.c_void_p()
+        n = nat.load().hry_mesh_runs(self.h, C.byref(p))
+        if n == 0:
+            return np.zeros((0, 6), np.uint32)
+        return np.frombuffer(C.string_at(p, n * 24), dtype=np.uint32).reshape(n, 6).copy()
+
+    def shard_elements(self, which: int) -> np.ndarray:
+        """a shard: index in the whole mesh of every vertex (which = 1) / face (which = 0)"""
+        p = C.c_void_p()
+        n = nat.load().hry_shard_elements(self.h, which, C.byref(p))
+        return np.frombuffer(C.string_at(p, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
+
     def to_ply(self, ascii: bool = False) -> bytes:
         p, n = C.c_void_p(), C.c_size_t()
         nat.check(nat.load().hry_mesh_to_ply(self.h, int(ascii), C.byref(p), C.byref(n)))
@@ -150,6 +176,41 @@ class Mesh:
             return out
         finally:
             L.hry_walk_free(w)
+
+
+class ShardPlan:
+    """Distribution of one mesh over n shards by groups of connected components (include/harry_amd.h, hry_shard_plan)."""
+
+    def __init__(self, mesh: Mesh, n_shards: int):
+        self.h = C.c_void_p()
+        self.n_shards = n_shards
+        nat.check(nat.load().hry_shard_plan(mesh.h, n_shards, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            nat.load().hry_plan_free(self.h)
+            self.h = None
+
+    ncomponents = property(lambda s: nat.load().hry_plan_ncomponents(s.h))
+    ngroups = property(lambda s: nat.load().hry_plan_ngroups(s.h))
+
+    def triangles(self, shard: int) -> int:
+        return nat.load().hry_plan_triangles(self.h, shard)
+
+    def extract(self, mesh: Mesh, shard: int) -> Mesh:
+        h = C.c_void_p()
+        nat.check(nat.load().hry_shard_extract(mesh.h, self.h, shard, C.byref(h)))
+        return Mesh(h)
+
+
+def merge(parts) -> bytes:
+    """several sharded containers (.hry v0.3) of the same mesh -> one (hry_merge)"""
+    parts = [bytes(p) for p in parts]
+    arr = (C.c_char_p * len(parts))(*parts)
+    sizes = (C.c_size_t * len(parts))(*[len(p) for p in parts])
+    p, n = C.c_void_p(), C.c_size_t()
+    nat.check(nat.load().hry_merge(arr, sizes, len(parts), C.byref(p), C.byref(n)))
+    return nat.take_bytes(p, n.value)
 
 
 def walk_and_replay(mesh: "Mesh", use_restart_points: bool):
@@ -217,13 +278,14 @@ class Codec:
         nat.check(nat.load().hry_mesh_upload(self.h, mesh.h))
 
     def write_hry(self, mesh: Mesh, profile: int = PROFILE_COMPAT, chunk_syms: int = 0, keep_stages: bool = False, flags: int = 0) -> bytes:
-        o = nat.Opts(profile, chunk_syms, int(keep_stages), flags)
+        o = nat.Opts(profile, chunk_syms, int(keep_stages), flags, 0, 0)
         p, n = C.c_void_p(), C.c_size_t()
         nat.check(nat.load().hry_encode(self.h, mesh.h, C.byref(o), C.byref(p), C.byref(n)))
         return nat.take_bytes(p, n.value)
 
-    def read_hry(self, data: bytes, keep_stages: bool = False) -> Mesh:
-        o = nat.Opts(0, 0, int(keep_stages), 0)
+    def read_hry(self, data: bytes, keep_stages: bool = False, shard=(0, 0)) -> Mesh:
+        """shard = (index, count): of a sharded container decode only the segments i with i % count == index"""
+        o = nat.Opts(0, 0, int(keep_stages), 0, int(shard[0]), int(shard[1]))
         h = C.c_void_p()
         nat.check(nat.load().hry_decode(self.h, data, len(data), C.byref(o), C.byref(h)))
         return Mesh(h)

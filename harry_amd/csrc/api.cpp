@@ -9,6 +9,7 @@ using namespace hry;
 
 struct hry_ctx { Context cx; explicit hry_ctx(int d) : cx(d) {} };
 struct hry_mesh { Mesh m; };
+struct hry_plan { ShardPlan p; };
 struct hry_walk { WalkResult w; uint32_t info[2]; std::vector<uint8_t> vplanes, fplanes; std::vector<uint32_t> seg_start, seg_level; };
 
 static thread_local std::string g_last_error;
@@ -147,11 +148,78 @@ int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts,
 		hry_opts o = opts ? *opts : hry_opts{};
 		ctx->cx.keep_stages = o.keep_stages != 0;
 		ctx->cx.stages.clear();
-		std::unique_ptr<Mesh> m(decode_any(ctx->cx, hry, n));
+		std::unique_ptr<Mesh> m(decode_any(ctx->cx, hry, n, o.shard_index, o.shard_count));
 		*out = new hry_mesh{ std::move(*m) };
 	});
 }
 void hry_free(void *p) { free(p); }
+
+int hry_shard_plan(const hry_mesh *m, int n_shards, hry_plan **out)
+{
+	if (!m || !out || n_shards <= 0) { g_last_error = "invalid argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<hry_plan> p(new hry_plan());
+		shard_plan(m->m, (uint32_t)n_shards, p->p);
+		*out = p.release();
+	});
+}
+void hry_plan_free(hry_plan *p) { delete p; }
+uint32_t hry_plan_ncomponents(const hry_plan *p) { return p ? p->p.A.ncomp : 0; }
+uint32_t hry_plan_ngroups(const hry_plan *p)
+{
+	uint32_t n = 0;
+	if (p) for (uint32_t k = 0; k < p->p.A.ncomp; ++k) n += p->p.A.group[k] == k;
+	return n;
+}
+uint64_t hry_plan_triangles(const hry_plan *p, int shard) { return p && shard >= 0 && (uint32_t)shard < p->p.n_shards ? p->p.shard_triangles[shard] : 0; }
+int hry_shard_extract(const hry_mesh *m, const hry_plan *p, int shard, hry_mesh **out)
+{
+	if (!m || !p || !out || shard < 0) { g_last_error = "invalid argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<Mesh> s(shard_extract(m->m, p->p, (uint32_t)shard));
+		*out = new hry_mesh{ std::move(*s) };
+	});
+}
+int hry_merge(const uint8_t *const *parts, const size_t *sizes, size_t n, uint8_t **out, size_t *out_len)
+{
+	if (!parts || !sizes || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr; *out_len = 0;
+	return guarded([&] {
+		std::vector<uint8_t> v;
+		merge_containers(parts, sizes, n, v);
+		*out = dup_bytes(v);
+		*out_len = v.size();
+	});
+}
+size_t hry_mesh_runs(const hry_mesh *m, const uint32_t **runs)
+{
+	if (!m || !runs) return 0;
+	const std::vector<ShardRun> &r = m->m.shard.active() ? m->m.shard.runs : m->m.covered;
+	*runs = (const uint32_t*)r.data();
+	return r.size();
+}
+size_t hry_shard_elements(const hry_mesh *m, int which, const uint32_t **idx)
+{
+	if (!m || !idx) return 0;
+	const std::vector<uint32_t> &v = which ? m->m.shard.vertex_of : m->m.shard.face_of;
+	*idx = v.data();
+	return v.size();
+}
+int hry_list_set_bounds(hry_mesh *m, int l, const uint8_t *min_rec, const uint8_t *max_rec)
+{
+	if (!m || l < 0 || l > 1 || !min_rec || !max_rec) { g_last_error = "invalid argument"; return HRY_E_ARG; }
+	AttrList &L = m->m.lists[l];
+	for (int c = 0; c < L.ncomp(); ++c) if (L.quant[c]) { g_last_error = "bounds of an already quantised list come from its header"; return HRY_E_ARG; }
+	L.bmin.assign(min_rec, min_rec + L.stride());
+	L.bmax.assign(max_rec, max_rec + L.stride());
+	L.bmin_at.clear(); L.bmax_at.clear();
+	L.have_bounds = true;
+	return HRY_OK;
+}
+uint32_t hry_list_min_at(const hry_mesh *m, int l, int c) { return m && l >= 0 && l < 2 && c >= 0 && (size_t)c < m->m.lists[l].bmin_at.size() ? m->m.lists[l].bmin_at[c] : 0; }
+uint32_t hry_list_max_at(const hry_mesh *m, int l, int c) { return m && l >= 0 && l < 2 && c >= 0 && (size_t)c < m->m.lists[l].bmax_at.size() ? m->m.lists[l].bmax_at[c] : 0; }
 
 int hry_stage_get(hry_ctx *ctx, const char *name, void **host_copy, size_t *bytes)
 {

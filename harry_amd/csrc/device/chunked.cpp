@@ -68,8 +68,29 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds) { m.lists[l].bmin.assign(m.lists[l].stride(), 0); m.lists[l].bmax.assign(m.lists[l].stride(), 0); m.lists[l].have_bounds = true; }
 	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
 
+	// a shard of a larger mesh writes one segment of a sharded container (.hry v0.3, host/shard.cpp): the header of the whole
+	// mesh, then its runs and an ordinary v0.2 body of the shard in its own numbering
+	const bool sharded = m.shard.active();
 	out.clear();
-	write_hry_header(m, 2, out);
+	write_hry_header(m, sharded ? 3 : 2, out);
+	size_t seg_len_at = 0, seg_begin = 0;
+	if (sharded && m.nf == 0) {   // a rank without a group to code contributes no segment
+		const uint32_t none = 0;
+		out.insert(out.end(), (const uint8_t*)&none, (const uint8_t*)&none + 4);
+		cx.timing.total_ms = ms_since(t_all);
+		return;
+	}
+	if (sharded) {
+		auto put32 = [&](uint32_t v) { out.insert(out.end(), (const uint8_t*)&v, (const uint8_t*)&v + 4); };
+		put32(1);
+		seg_len_at = out.size();
+		put32(0); put32(0);
+		seg_begin = out.size();
+		put32((uint32_t)m.shard.runs.size());
+		static_assert(sizeof(ShardRun) == 24, "runs are written as they lie in memory");
+		const uint8_t *rp = (const uint8_t*)m.shard.runs.data();
+		out.insert(out.end(), rp, rp + sizeof(ShardRun) * m.shard.runs.size());
+	}
 	auto t_walk = Clock::now();
 	WalkResult w;
 	cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
@@ -264,6 +285,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
 	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	if (sharded) { const uint64_t seg_len = out.size() - seg_begin; memcpy(out.data() + seg_len_at, &seg_len, 8); }
 
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", w.order_v.data(), (size_t)vc * 4);
@@ -285,12 +307,17 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 
-Mesh *decode_any(Context &cx, const uint8_t *p, size_t n)
+Mesh *decode_sharded(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m, int shard_index, int shard_count);
+
+Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index, int shard_count)
 {
 	HIP_OK(hipSetDevice(cx.device));
 	std::unique_ptr<Mesh> m(new Mesh());
 	int minor = 0;
-	size_t hdr = read_hry_header(p, n, *m, minor);
+	const bool sharded = n >= 6 && p[4] == 0 && p[5] == 3;   // the whole mesh's records are filled segment by segment: no zero fill first
+	size_t hdr = read_hry_header(p, n, *m, minor, !sharded);
+	if (minor == 3) return decode_sharded(cx, p, n, hdr, std::move(m), shard_index, shard_count);
+	if (shard_count > 1) throw Error(HRY_E_ARG, "only a sharded container (.hry v0.3) decodes segment by segment");
 	if (minor == 2) return decode_chunked(cx, p, n, hdr, std::move(m));
 	return decode_compat(cx, p, n, hdr, std::move(m));
 }

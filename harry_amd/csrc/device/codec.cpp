@@ -150,28 +150,33 @@ void device_bounds(Context &cx, Mesh &m)
 {
 	HIP_OK(hipSetDevice(cx.device));
 	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
-	const int nparts = 512;
-	cx.d_small.ensure((size_t)nparts * (8 + 8 + 8) + 2 * 8 * dev::kMaxComp * 2 + 64);
-	uint8_t *pmin = cx.d_small.as<uint8_t>(), *pmax = pmin + nparts * 8;
-	uint32_t *pidx = (uint32_t*)(pmax + nparts * 8);
-	uint8_t *outs = (uint8_t*)(pidx + 2 * nparts);
+	const int nparts = 256;   // one block per compute unit
+	cx.d_small.ensure((size_t)nparts * dev::kMaxComp * (8 + 8 + 8) + 24 * dev::kMaxComp + 64);
+	uint8_t *pmin = cx.d_small.as<uint8_t>(), *pmax = pmin + (size_t)nparts * dev::kMaxComp * 8;
+	uint32_t *pidx = (uint32_t*)(pmax + (size_t)nparts * dev::kMaxComp * 8);
+	uint8_t *outs = (uint8_t*)(pidx + 2 * (size_t)nparts * dev::kMaxComp);
 	for (int l = 0; l < 2; ++l) {
 		AttrList &L = m.lists[l];
 		for (int c = 0; c < L.ncomp(); ++c) if (L.quant[c]) throw Error(HRY_E_UNSUPPORTED, "bounds of an already quantised list come from its header");
 		L.bmin.assign(L.stride(), 0); L.bmax.assign(L.stride(), 0);
-		std::vector<uint8_t> res((size_t)L.ncomp() * 16);
+		L.bmin_at.assign(L.ncomp(), 0); L.bmax_at.assign(L.ncomp(), 0);
+		BoundsPlan plan{};
+		plan.n = L.ncomp(); plan.stride = L.stride();
 		for (int c = 0; c < L.ncomp(); ++c) {
 			if (L.type[c] == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "double components are outside the supported subset");
-			launch_bounds(cx.stream, cx.d_rec[l].as<uint8_t>(), L.count, L.stride(), L.offset[c], L.type[c], pmin, pmax, pidx, nparts,
-			              outs + (size_t)c * 16, outs + (size_t)c * 16 + 8);
+			plan.off[c] = (uint16_t)L.offset[c]; plan.type[c] = (uint8_t)L.type[c];
 		}
+		std::vector<uint8_t> res((size_t)L.ncomp() * 24);
 		if (L.ncomp()) {
+			launch_bounds(cx.stream, cx.d_rec[l].as<uint8_t>(), L.count, plan, pmin, pmax, pidx, nparts, outs);
 			HIP_OK(hipMemcpyAsync(res.data(), outs, res.size(), hipMemcpyDeviceToHost, cx.stream));
 			HIP_OK(hipStreamSynchronize(cx.stream));
 		}
 		for (int c = 0; c < L.ncomp(); ++c) {
-			memcpy(L.bmin.data() + L.offset[c], res.data() + (size_t)c * 16, kTypeSize[L.type[c]]);
-			memcpy(L.bmax.data() + L.offset[c], res.data() + (size_t)c * 16 + 8, kTypeSize[L.type[c]]);
+			memcpy(L.bmin.data() + L.offset[c], res.data() + (size_t)c * 24, kTypeSize[L.type[c]]);
+			memcpy(L.bmax.data() + L.offset[c], res.data() + (size_t)c * 24 + 8, kTypeSize[L.type[c]]);
+			memcpy(&L.bmin_at[c], res.data() + (size_t)c * 24 + 16, 4);
+			memcpy(&L.bmax_at[c], res.data() + (size_t)c * 24 + 20, 4);
 		}
 		L.have_bounds = true;
 	}

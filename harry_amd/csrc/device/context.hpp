@@ -84,7 +84,7 @@ void device_bounds(Context &cx, Mesh &m);
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);
 void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
 void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &out);
-Mesh *decode_any(Context &cx, const uint8_t *p, size_t n);
+Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index = 0, int shard_count = 0);
 void range_encode_lht(Context &cx, const uint64_t *lht, size_t n, std::vector<uint8_t> &out);
 
 dev::ListDesc make_list_desc(const AttrList &L);

@@ -60,6 +60,9 @@ struct StreamJob {
 // a slice of a plane for the histogram pass (static priors)
 struct HistSlice { const uint8_t *sym; uint32_t n, plane; };
 
+// the components of a list for the bounds reduction
+struct BoundsPlan { int32_t n, stride; uint16_t off[kMaxComp]; uint8_t type[kMaxComp]; };
+
 // one component of an in-place requantisation: mn / scale carry the raw bits of the component's original type
 struct RequantComp { int32_t off, src_type, src_bits, dst_bits; uint64_t mn, scale; };
 struct RequantPlan { int32_t n; int32_t pad; RequantComp c[kMaxComp]; };

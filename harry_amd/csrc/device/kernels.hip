@@ -170,6 +170,22 @@ template <typename T> __device__ __forceinline__ Ext<T> pick_max(Ext<T> a, Ext<T
 	return a.i <= b.i ? a : b;
 }
 
+// 64-bit pattern of a value and back (wave shuffles move 32-bit words)
+template <typename T> __device__ __forceinline__ uint64_t to_bits(T v) { uint64_t b = 0; __builtin_memcpy(&b, &v, sizeof(T)); return b; }
+template <typename T> __device__ __forceinline__ T from_bits(uint64_t b) { T v; __builtin_memcpy(&v, &b, sizeof(T)); return v; }
+template <typename T> __device__ __forceinline__ Ext<T> shfl_xor_ext(Ext<T> a, int mask)
+{
+	uint64_t b = to_bits(a.v);
+	uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), mask);
+	return Ext<T>{ from_bits<T>(((uint64_t)hi << 32) | lo), (uint32_t)__shfl_xor((int)a.i, mask) };
+}
+template <typename T> __device__ __forceinline__ void wave_reduce_ext(Ext<T> &mn, Ext<T> &mx)
+{
+	for (int m = 32; m > 0; m >>= 1) { mn = pick_min(mn, shfl_xor_ext(mn, m)); mx = pick_max(mx, shfl_xor_ext(mx, m)); }
+}
+
+// grid (nparts, ncomp): block (p, c) scans its grid-stride share of component c; wavefronts reduce by shuffles, the four
+// wavefronts of a block through LDS
 template <typename T>
 __device__ void bounds_component(const uint8_t *rec, uint32_t count, int stride, int off, uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx)
 {
@@ -182,45 +198,51 @@ __device__ void bounds_component(const uint8_t *rec, uint32_t count, int stride,
 			mx = pick_max(mx, Ext<T>{ e, i + 1 });
 		}
 	}
-	__shared__ unsigned char sm_raw[2 * 256 * sizeof(Ext<uint64_t>)];
-	Ext<T> *smn = (Ext<T>*)sm_raw, *smx = smn + 256;
-	smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+	wave_reduce_ext(mn, mx);
+	__shared__ uint64_t sv[2][4];
+	__shared__ uint32_t si[2][4];
+	const int wave = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) { sv[0][wave] = to_bits(mn.v); si[0][wave] = mn.i; sv[1][wave] = to_bits(mx.v); si[1][wave] = mx.i; }
 	__syncthreads();
-	for (int s = 128; s > 0; s >>= 1) {
-		if ((int)threadIdx.x < s) {
-			smn[threadIdx.x] = pick_min(smn[threadIdx.x], smn[threadIdx.x + s]);
-			smx[threadIdx.x] = pick_max(smx[threadIdx.x], smx[threadIdx.x + s]);
-		}
-		__syncthreads();
-	}
 	if (threadIdx.x == 0) {
-		stg<T>(part_min + (size_t)blockIdx.x * 8, smn[0].v);
-		stg<T>(part_max + (size_t)blockIdx.x * 8, smx[0].v);
-		part_idx[2 * blockIdx.x] = smn[0].i;
-		part_idx[2 * blockIdx.x + 1] = smx[0].i;
+		for (int w = 1; w < 4; ++w) {
+			mn = pick_min(mn, Ext<T>{ from_bits<T>(sv[0][w]), si[0][w] });
+			mx = pick_max(mx, Ext<T>{ from_bits<T>(sv[1][w]), si[1][w] });
+		}
+		const size_t p = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+		stg<uint64_t>(part_min + p * 8, to_bits(mn.v));
+		stg<uint64_t>(part_max + p * 8, to_bits(mx.v));
+		part_idx[2 * p] = mn.i;
+		part_idx[2 * p + 1] = mx.i;
 	}
 }
-__global__ __launch_bounds__(256) void k_bounds_partial(const uint8_t *rec, uint32_t count, int stride, int off, int type,
+__global__ __launch_bounds__(256) void k_bounds_partial(const uint8_t *rec, uint32_t count, BoundsPlan plan,
                                                         uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx)
 {
-	with_stype(type, [&](auto tag) { bounds_component<decltype(tag)>(rec, count, stride, off, part_min, part_max, part_idx); });
+	const int c = blockIdx.y;
+	with_stype(plan.type[c], [&](auto tag) { bounds_component<decltype(tag)>(rec, count, plan.stride, plan.off[c], part_min, part_max, part_idx); });
 }
+// one wavefront per component folds its partials: lanes stride over them, then a shuffle reduction.
+// out: per component { u64 min bits, u64 max bits, u32 first index of the min + 1, u32 of the max + 1 } (24 bytes)
 template <typename T>
-__device__ void bounds_final(const uint8_t *part_min, const uint8_t *part_max, const uint32_t *part_idx, int nparts, uint8_t *out_min, uint8_t *out_max)
+__device__ void bounds_final(const uint8_t *part_min, const uint8_t *part_max, const uint32_t *part_idx, int nparts, uint8_t *out)
 {
 	Ext<T> mn{ Lim<T>::hi(), 0 }, mx{ Lim<T>::lo(), 0 };
-	for (int p = 0; p < nparts; ++p) {
-		mn = pick_min(mn, Ext<T>{ ldg<T>(part_min + (size_t)p * 8), part_idx[2 * p] });
-		mx = pick_max(mx, Ext<T>{ ldg<T>(part_max + (size_t)p * 8), part_idx[2 * p + 1] });
+	const size_t base = (size_t)blockIdx.x * nparts;
+	for (int p = threadIdx.x; p < nparts; p += 64) {
+		mn = pick_min(mn, Ext<T>{ from_bits<T>(ldg<uint64_t>(part_min + (base + p) * 8)), part_idx[2 * (base + p)] });
+		mx = pick_max(mx, Ext<T>{ from_bits<T>(ldg<uint64_t>(part_max + (base + p) * 8)), part_idx[2 * (base + p) + 1] });
 	}
-	stg<T>(out_min, mn.v);
-	stg<T>(out_max, mx.v);
+	wave_reduce_ext(mn, mx);
+	if (threadIdx.x == 0) {
+		uint8_t *o = out + (size_t)blockIdx.x * 24;
+		stg<uint64_t>(o, to_bits(mn.v)); stg<uint64_t>(o + 8, to_bits(mx.v));
+		stg<uint32_t>(o + 16, mn.i); stg<uint32_t>(o + 20, mx.i);
+	}
 }
-__global__ void k_bounds_final(const uint8_t *part_min, const uint8_t *part_max, const uint32_t *part_idx, int nparts, int type,
-                               uint8_t *out_min, uint8_t *out_max)
+__global__ __launch_bounds__(64) void k_bounds_final(const uint8_t *part_min, const uint8_t *part_max, const uint32_t *part_idx, int nparts, BoundsPlan plan, uint8_t *out)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0)
-		with_stype(type, [&](auto tag) { bounds_final<decltype(tag)>(part_min, part_max, part_idx, nparts, out_min, out_max); });
+	with_stype(plan.type[blockIdx.x], [&](auto tag) { bounds_final<decltype(tag)>(part_min, part_max, part_idx, nparts, out); });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -654,11 +676,12 @@ __global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *v
 // ---------------------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_bounds(hipStream_t st, const uint8_t *rec, uint32_t count, int stride, int off, int type,
-                   uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx, int nparts, uint8_t *out_min, uint8_t *out_max)
+void launch_bounds(hipStream_t st, const uint8_t *rec, uint32_t count, const BoundsPlan &plan,
+                   uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx, int nparts, uint8_t *out)
 {
-	hipLaunchKernelGGL(k_bounds_partial, dim3(nparts), dim3(256), 0, st, rec, count, stride, off, type, part_min, part_max, part_idx);
-	hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, st, part_min, part_max, part_idx, nparts, type, out_min, out_max);
+	if (plan.n <= 0) return;
+	hipLaunchKernelGGL(k_bounds_partial, dim3(nparts, plan.n), dim3(256), 0, st, rec, count, plan, part_min, part_max, part_idx);
+	hipLaunchKernelGGL(k_bounds_final, dim3(plan.n), dim3(64), 0, st, part_min, part_max, part_idx, nparts, plan, out);
 }
 void launch_requant(hipStream_t st, uint8_t *rec, uint32_t count, int stride, const RequantPlan &plan)
 {

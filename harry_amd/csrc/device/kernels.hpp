@@ -10,8 +10,9 @@
 namespace hry {
 namespace dev {
 
-void launch_bounds(hipStream_t st, const uint8_t *rec, uint32_t count, int stride, int off, int type,
-                   uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx, int nparts, uint8_t *out_min, uint8_t *out_max);
+// every component of a list in two launches; out: 24 bytes per component { u64 min, u64 max, u32 min_at, u32 max_at }
+void launch_bounds(hipStream_t st, const uint8_t *rec, uint32_t count, const BoundsPlan &plan,
+                   uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx, int nparts, uint8_t *out);
 void launch_requant(hipStream_t st, uint8_t *rec, uint32_t count, int stride, const RequantPlan &plan);
 void launch_rank(hipStream_t st, const uint32_t *order_v, uint32_t n, const uint32_t *org, uint32_t *rank);
 void launch_predict_vtx(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank, const uint8_t *rec,

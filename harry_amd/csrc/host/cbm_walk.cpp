@@ -240,8 +240,15 @@ struct StartFaces {
 		uint32_t len = (b.first <= b.last ? b.last - b.first : b.first - b.last) + 1;
 		if (++pos == len) { ++bi; pos = 0; }
 	}
+	const std::vector<uint32_t> *seeds = nullptr;   // a shard brings its start faces along, in coding order (mesh.hpp ShardInfo)
+	size_t seed_pos = 0;
 	uint32_t next()
 	{
+		if (seeds) {
+			while (seed_pos < seeds->size() && gone[(*seeds)[seed_pos]]) ++seed_pos;
+			if (seed_pos == seeds->size()) throw Error(HRY_E_ARG, "shard: component without a seed face");
+			return (*seeds)[seed_pos];
+		}
 		uint32_t f = 0;
 		if (gone[0]) {
 			if (!have_order) derive_order();
@@ -445,6 +452,10 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	WalkState st(m.nv, m.nf);
 	Border cb(st.on);
 	StartFaces pool(m.nf, st.gone);
+	if (!m.shard.seeds.empty()) {
+		for (uint32_t f : m.shard.seeds) if (f >= m.nf) throw Error(HRY_E_ARG, "shard seed face out of range");
+		pool.seeds = &m.shard.seeds;
+	}
 	Emitter em(w);
 	em.eval_model = eval_op_model;
 	uint32_t next_id = 0, consumed = 0;
@@ -515,22 +526,22 @@ static void atomic_min(std::atomic<uint32_t> &a, uint32_t v)
 	while (v < cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
 }
 
-// Everything after the first component, on several threads.  The stream the sequential walk would produce is a
-// function of (a) which faces form a component, (b) the order of the components = the order of their first faces in the
-// start-face sequence, (c) the index the first new vertex of a component gets = the number of vertices the components
-// before it introduce.  All three are computed up front; components that share a vertex with an earlier unfinished one
-// stay in coding order on one thread (their symbols depend on that vertex's index and triangle count).
+// Component analysis shared by the multi-threaded walk (below) and the shard planner (shard.cpp).  The stream a sequential
+// walk produces is a function of (a) which faces form a component, (b) the order of the components = the order of their
+// first faces in the start-face sequence (or the explicit seed list of a shard), (c) the index the first new vertex of a
+// component gets = the number of vertices the components before it introduce.  All three are computed up front; components
+// that share a vertex are tied into one group (their symbols depend on that vertex's index and triangle count).
+// gone / sent: faces already consumed and vertices already transmitted by the part walked before (nullptr: none).
 template <int DEG>
-static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads)
+static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t *gone, const uint32_t *sent, unsigned n_threads, ComponentAnalysis &A)
 {
-	WalkResult &w = em0.w;
 	const uint32_t nf = m.nf, nv = m.nv, ne = m.ne();
 	const uint32_t *org = m.org.data();
 	const uint32_t *twin = m.twin.data();
-	const uint8_t *gone = st.gone.data();
+	const uint32_t *foff = m.face_off.data();
 	auto face_of = [&](uint32_t e) -> uint32_t { return DEG ? e / (uint32_t)(DEG ? DEG : 1) : eface_tab[e]; };
+	auto is_gone = [&](uint32_t f) -> bool { return gone && gone[f]; };
 	auto split = [&](uint32_t n, unsigned t, uint32_t &b, uint32_t &e) { b = (uint32_t)((uint64_t)n * t / n_threads); e = (uint32_t)((uint64_t)n * (t + 1) / n_threads); };
-
 	const bool trace = getenv("HRY_TRACE") != nullptr;
 	auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
@@ -541,52 +552,82 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 		uint32_t b, e; split(ne, t, b, e);
 		for (uint32_t h = b; h < e; ++h) {
 			uint32_t o = twin[h];
-			if (o > h) { uint32_t fa = face_of(h), fb = face_of(o); if (!gone[fa] && !gone[fb] && fa != fb) sets.unite(fa, fb); }
+			if (o != h && (o > h || twin[o] != h)) { uint32_t fa = face_of(h), fb = face_of(o); if (!is_gone(fa) && !is_gone(fb) && fa != fb) sets.unite(fa, fb); }
 		}
 	});
 	// dense component numbers (roots counted per thread range, then a prefix over the ranges)
-	std::vector<uint32_t> comp(nf, NONE32), range_roots(n_threads + 1, 0);
+	std::vector<uint32_t> &comp = A.comp;
+	comp.assign(nf, NONE32);
+	std::vector<uint32_t> range_roots(n_threads + 1, 0);
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e, c = 0; split(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) if (!gone[f] && sets.find(f) == f) ++c;
+		for (uint32_t f = b; f < e; ++f) if (!is_gone(f) && sets.find(f) == f) ++c;
 		range_roots[t + 1] = c;
 	});
 	for (unsigned t = 0; t < n_threads; ++t) range_roots[t + 1] += range_roots[t];
-	const uint32_t ncomp = range_roots[n_threads];
+	const uint32_t ncomp = A.ncomp = range_roots[n_threads];
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e, c = range_roots[t]; split(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) if (!gone[f] && sets.find(f) == f) comp[f] = c++;
+		for (uint32_t f = b; f < e; ++f) if (!is_gone(f) && sets.find(f) == f) comp[f] = c++;
 	});
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) if (!gone[f]) { uint32_t r = sets.find(f); if (r != f) comp[f] = comp[r]; }
+		for (uint32_t f = b; f < e; ++f) if (!is_gone(f)) { uint32_t r = sets.find(f); if (r != f) comp[f] = comp[r]; }
 	});
 	mark("components labelled");
 	// (b) first face of every component in the start-face sequence, and the coding order
-	StartFaces seq(nf, st.gone);
-	seq.derive_order();
-	seq.index_blocks();
+	const bool seeded = !m.shard.seeds.empty();
+	BigVec<uint8_t> no_gone;   // StartFaces wants a reference; only its order is used here
+	StartFaces seq(nf, no_gone);
+	if (!seeded) { seq.derive_order(); seq.index_blocks(); }
 	std::unique_ptr<std::atomic<uint64_t>[]> first_key(new std::atomic<uint64_t>[ncomp]);
-	std::unique_ptr<std::atomic<uint32_t>[]> nfaces(new std::atomic<uint32_t>[ncomp]);
-	for (uint32_t c = 0; c < ncomp; ++c) { first_key[c].store(~0ull, std::memory_order_relaxed); nfaces[c].store(0, std::memory_order_relaxed); }
+	std::unique_ptr<std::atomic<uint32_t>[]> nfaces(new std::atomic<uint32_t>[ncomp]), nhe(new std::atomic<uint32_t>[ncomp]);
+	for (uint32_t c = 0; c < ncomp; ++c) { first_key[c].store(~0ull, std::memory_order_relaxed); nfaces[c].store(0, std::memory_order_relaxed); nhe[c].store(0, std::memory_order_relaxed); }
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(nf, t, b, e);
-		uint32_t run_c = NONE32, run_n = 0;
+		uint32_t run_c = NONE32, run_n = 0, run_he = 0;
 		uint64_t run_min = ~0ull;
-		auto flush = [&] { if (run_c != NONE32) { atomic_min(first_key[run_c], run_min); nfaces[run_c].fetch_add(run_n, std::memory_order_relaxed); } };
+		auto flush = [&] {
+			if (run_c == NONE32) return;
+			if (!seeded) atomic_min(first_key[run_c], run_min);
+			nfaces[run_c].fetch_add(run_n, std::memory_order_relaxed);
+			nhe[run_c].fetch_add(run_he, std::memory_order_relaxed);
+		};
 		for (uint32_t f = b; f < e; ++f) {
-			if (gone[f]) continue;
+			if (is_gone(f)) continue;
 			uint32_t c = comp[f];
-			if (c != run_c) { flush(); run_c = c; run_n = 0; run_min = ~0ull; }
+			if (c != run_c) { flush(); run_c = c; run_n = 0; run_he = 0; run_min = ~0ull; }
 			++run_n;
-			run_min = std::min(run_min, ((uint64_t)seq.position(f) << 32) | f);
+			run_he += foff[f + 1] - foff[f];
+			// the reference takes face 0 first whatever the set's order (writer.cc:40-46)
+			if (!seeded) run_min = std::min<uint64_t>(run_min, f == 0 ? 0ull : ((((uint64_t)seq.position(f) + 1) << 32) | f));
 		}
 		flush();
 	});
-	std::vector<uint32_t> by_rank(ncomp), rank_of(ncomp);
+	if (seeded) {
+		// a shard brings the coding order of its components along: one start face per component
+		const std::vector<uint32_t> &sd = m.shard.seeds;
+		for (size_t i = 0; i < sd.size(); ++i) {
+			if (sd[i] >= nf) throw Error(HRY_E_ARG, "shard seed face out of range");
+			if (is_gone(sd[i])) continue;
+			const uint32_t c = comp[sd[i]];
+			if (first_key[c].load(std::memory_order_relaxed) != ~0ull) throw Error(HRY_E_ARG, "shard: two seed faces in one component");
+			first_key[c].store(((uint64_t)(i + 1) << 32) | sd[i], std::memory_order_relaxed);
+		}
+		for (uint32_t c = 0; c < ncomp; ++c) if (first_key[c].load(std::memory_order_relaxed) == ~0ull) throw Error(HRY_E_ARG, "shard: component without a seed face");
+	}
+	std::vector<uint32_t> &by_rank = A.by_rank, &rank_of = A.rank_of;
+	by_rank.resize(ncomp); rank_of.resize(ncomp);
 	for (uint32_t c = 0; c < ncomp; ++c) by_rank[c] = c;
 	std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t x, uint32_t y) { return first_key[x].load(std::memory_order_relaxed) < first_key[y].load(std::memory_order_relaxed); });
 	for (uint32_t k = 0; k < ncomp; ++k) rank_of[by_rank[k]] = k;
+	A.seed.resize(ncomp); A.n_faces.resize(ncomp); A.n_halfedges.resize(ncomp);
+	for (uint32_t k = 0; k < ncomp; ++k) {
+		const uint32_t c = by_rank[k];
+		A.seed[k] = (uint32_t)first_key[c].load(std::memory_order_relaxed);
+		A.n_faces[k] = nfaces[c].load(std::memory_order_relaxed);
+		A.n_halfedges[k] = nhe[c].load(std::memory_order_relaxed);
+	}
 	mark("coding order");
 	// (c) the first remaining component (in coding order) that touches each vertex: it introduces the vertex unless the part
 	// walked before already transmitted it.  Components that touch a common vertex are tied together: the vertex's index,
@@ -595,7 +636,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nv, t, b, e); for (uint32_t v = b; v < e; ++v) vfirst[v].store(NONE32, std::memory_order_relaxed); });
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(ne, t, b, e);
-		for (uint32_t h = b; h < e; ++h) { uint32_t f = face_of(h); if (!gone[f]) atomic_min(vfirst[org[h]], rank_of[comp[f]]); }
+		for (uint32_t h = b; h < e; ++h) { uint32_t f = face_of(h); if (!is_gone(f)) atomic_min(vfirst[org[h]], rank_of[comp[f]]); }
 	});
 	AtomicSets ties(ncomp);
 	for (uint32_t k = 0; k < ncomp; ++k) ties.parent[k].store(k, std::memory_order_relaxed);
@@ -603,7 +644,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 		uint32_t b, e; split(ne, t, b, e);
 		for (uint32_t h = b; h < e; ++h) {
 			uint32_t f = face_of(h);
-			if (gone[f]) continue;
+			if (is_gone(f)) continue;
 			uint32_t k = rank_of[comp[f]], first = vfirst[org[h]].load(std::memory_order_relaxed);
 			if (first != k) ties.unite(first, k);
 		}
@@ -615,18 +656,38 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 		uint32_t run_k = NONE32, run_n = 0;
 		for (uint32_t v = b; v < e; ++v) {
 			uint32_t first = vfirst[v].load(std::memory_order_relaxed);
-			if (first == NONE32 || st.sent[v] != NONE32) continue;
+			if (first == NONE32 || (sent && sent[v] != NONE32)) continue;
 			if (first != run_k) { if (run_k != NONE32) fresh[run_k].fetch_add(run_n, std::memory_order_relaxed); run_k = first; run_n = 0; }
 			++run_n;
 		}
 		if (run_k != NONE32) fresh[run_k].fetch_add(run_n, std::memory_order_relaxed);
 	});
+	A.fresh.resize(ncomp); A.group.resize(ncomp);
+	for (uint32_t k = 0; k < ncomp; ++k) { A.fresh[k] = fresh[k].load(std::memory_order_relaxed); A.group[k] = ties.find(k); }   // a root is the smallest rank of its group
+	if (A.want_vertex_owner) {
+		A.vertex_owner.resize(nv);
+		parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nv, t, b, e); for (uint32_t v = b; v < e; ++v) A.vertex_owner[v] = vfirst[v].load(std::memory_order_relaxed); });
+	}
+	mark("vertex bases and groups");
+}
+
+// Everything after the first component, on several threads (see analyse_impl); components of one group stay in coding
+// order on one thread.
+template <int DEG>
+static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads)
+{
+	WalkResult &w = em0.w;
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	auto t0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
+	ComponentAnalysis A;
+	analyse_impl<DEG>(m, eface_tab, st.gone.data(), st.sent.data(), n_threads, A);
+	const uint32_t ncomp = A.ncomp;
+	const std::vector<uint32_t> &group_of = A.group;
 	std::vector<uint32_t> id_base(ncomp + 1);
 	id_base[0] = first_id;
-	for (uint32_t k = 0; k < ncomp; ++k) id_base[k + 1] = id_base[k] + fresh[k].load(std::memory_order_relaxed);
+	for (uint32_t k = 0; k < ncomp; ++k) id_base[k + 1] = id_base[k] + A.fresh[k];
 	// work items: groups of tied components (ascending rank inside a group), largest groups first
-	std::vector<uint32_t> group_of(ncomp);
-	for (uint32_t k = 0; k < ncomp; ++k) group_of[k] = ties.find(k);
 	std::vector<uint32_t> order(ncomp);
 	for (uint32_t k = 0; k < ncomp; ++k) order[k] = k;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return group_of[x] < group_of[y]; });   // ranks stay ascending inside a group
@@ -635,13 +696,12 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	for (uint32_t i = 0; i < ncomp;) {
 		uint32_t j = i;
 		uint64_t nfc = 0;
-		while (j < ncomp && group_of[order[j]] == group_of[order[i]]) { nfc += nfaces[by_rank[order[j]]].load(std::memory_order_relaxed); ++j; }
+		while (j < ncomp && group_of[order[j]] == group_of[order[i]]) { nfc += A.n_faces[order[j]]; ++j; }
 		items.push_back(Item{ i, j, nfc });
 		i = j;
 	}
 	std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.faces > y.faces; });
 	if (trace) fprintf(stderr, "[hry walk] %u components in %zu groups, largest group %llu faces\n", ncomp, items.size(), items.empty() ? 0ull : (unsigned long long)items[0].faces);
-	mark("vertex bases and groups");
 	// the walks
 	std::vector<WalkResult> frag(ncomp);
 	std::vector<uint32_t> frag_syms(ncomp, 0), frag_he(ncomp, 0), frag_op((size_t)ncomp * 8, 0);
@@ -652,15 +712,15 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 			size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
 			if (it >= items.size()) break;
 			for (uint32_t q = items[it].begin; q < items[it].end; ++q) {
-				const uint32_t k = order[q], c = by_rank[k];
+				const uint32_t k = order[q];
 				WalkResult &fw = frag[k];
 				fw.numtri_coded = w.numtri_coded;
-				const uint32_t nfc = nfaces[c].load(std::memory_order_relaxed);
-				fw.order_f.reserve(nfc); fw.order_v.reserve(fresh[k].load(std::memory_order_relaxed));
+				const uint32_t nfc = A.n_faces[k];
+				fw.order_f.reserve(nfc); fw.order_v.reserve(A.fresh[k]);
 				Emitter em(fw);
 				em.eval_model = false;
 				uint32_t next_id = id_base[k], consumed = 0;
-				walk_component<DEG>(m, st, eface_tab, (uint32_t)first_key[c].load(std::memory_order_relaxed), cb, em, next_id, consumed);
+				walk_component<DEG>(m, st, eface_tab, A.seed[k], cb, em, next_id, consumed);
 				if (next_id != id_base[k + 1] || consumed != nfc) throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
 				em.finish_marks();
 				frag_syms[k] = em.n;
@@ -790,6 +850,21 @@ std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark>
 		if (taken.insert(((uint64_t)sp << 32) | ev.id).second) counters[sp].push_back({ ev.id, ev.count });
 	}
 	return out;
+}
+
+void analyse_components(const Mesh &m, ComponentAnalysis &A)
+{
+	int udeg = 0;
+	if (!m.uniform_degree(udeg)) udeg = 0;
+	const unsigned nt = m.nf >= (1u << 16) ? host_threads() : 1u;
+	if (udeg == 3) { analyse_impl<3>(m, nullptr, nullptr, nullptr, nt, A); return; }
+	if (udeg == 4) { analyse_impl<4>(m, nullptr, nullptr, nullptr, nt, A); return; }
+	std::vector<uint32_t> eface_tab(m.ne());
+	parallel_for(nt, [&](unsigned t) {
+		const uint32_t b = (uint32_t)((uint64_t)m.nf * t / nt), e = (uint32_t)((uint64_t)m.nf * (t + 1) / nt);
+		for (uint32_t f = b; f < e; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface_tab[h] = f;
+	});
+	analyse_impl<0>(m, eface_tab.data(), nullptr, nullptr, nt, A);
 }
 
 void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)

@@ -1,6 +1,7 @@
 // .hry container header (formats/hry/writer.cc:104-198, reader.cc:60-177, common.h:15-16).
 // All fields are little-endian raw values except the big-endian magic.  v0.1 = reference stream (compat profile);
-// v0.2 = chunked profile of this implementation (the reference reader rejects it by version, reader.cc:74).
+// v0.2 = chunked profile of this implementation (the reference reader rejects it by version, reader.cc:74);
+// v0.3 = sharded chunked container: the same header for the whole mesh, then one v0.2 body per shard (shard.cpp).
 #include "host.hpp"
 
 #include <algorithm>
@@ -25,7 +26,8 @@ void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out)
 	Out w{ out };
 	const uint8_t magic[6] = { 0xfa, 0xff, 0xaf, 0xaf, 0, (uint8_t)ver_minor };
 	w.raw(magic, 6);
-	w.v<uint32_t>(m.nv); w.v<uint32_t>(m.nf); w.v<uint32_t>(m.ne());
+	const bool sh = m.shard.active();
+	w.v<uint32_t>(sh ? m.shard.g_nv : m.nv); w.v<uint32_t>(sh ? m.shard.g_nf : m.nf); w.v<uint32_t>(sh ? m.shard.g_ne : m.ne());
 	// region tables: one face region bound to list 0, one vertex region bound to list 1 (ply/reader.cc:399-401)
 	w.v<uint16_t>(1); w.v<uint16_t>(1);
 	w.v<uint16_t>(1); w.v<uint16_t>(0); w.v<uint16_t>(0);
@@ -33,7 +35,7 @@ void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out)
 	for (int l = 0; l < 2; ++l) {
 		const AttrList &L = m.lists[l];
 		if (!L.have_bounds && L.ncomp() > 0) throw Error(HRY_E_INTERNAL, "attribute bounds missing");
-		w.v<uint32_t>(L.count);
+		w.v<uint32_t>(sh ? (l == 0 ? m.shard.g_nf : m.shard.g_nv) : L.count);
 		w.v<uint16_t>((uint16_t)L.ncomp());
 		for (int c = 0; c < L.ncomp(); ++c) { w.v<uint8_t>(L.type[c]); w.v<uint8_t>(L.quant[c]); }
 		w.v<uint16_t>((uint16_t)L.interp_off.size());
@@ -54,7 +56,7 @@ void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out)
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) w.v<uint16_t>((uint16_t)d);
 }
 
-size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor)
+size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool alloc_records)
 {
 	In r{ p, p + n };
 	uint8_t magic[6];
@@ -63,7 +65,7 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor)
 	if (magic[4] != 0)
 		throw Error(HRY_E_FORMAT, "File format version " + std::to_string(magic[4]) + "." + std::to_string(magic[5]) + " incompatible to decoder format version 0.1");
 	ver_minor = magic[5];
-	if (ver_minor != 1 && ver_minor != 2)
+	if (ver_minor != 1 && ver_minor != 2 && ver_minor != 3)
 		throw Error(HRY_E_FORMAT, "File format version 0." + std::to_string(magic[5]) + " incompatible to decoder format version 0.1 (All 0.x-versions are incompatible to each other)");
 	m.nv = r.v<uint32_t>(); m.nf = r.v<uint32_t>();
 	m.declared_ne = r.v<uint32_t>();
@@ -103,7 +105,7 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor)
 			}
 		}
 		if (off > nc) throw Error(HRY_E_FORMAT, "interpretation table exceeds component count");
-		L.data.assign((size_t)L.count * L.stride(), 0);
+		if (alloc_records) L.data.assign((size_t)L.count * L.stride(), 0);
 		L.bmin.resize(L.stride()); L.bmax.resize(L.stride());
 		r.raw(L.bmin.data(), L.bmin.size());
 		r.raw(L.bmax.data(), L.bmax.size());

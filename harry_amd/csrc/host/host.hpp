@@ -79,6 +79,34 @@ struct WalkResult {
 // ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
 void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true);
 
+// The connected components of a mesh as the walk will code them, without walking: which faces form a component, the coding
+// order (start-face sequence of the reference, writer.cc:40-46, or the seed list of a shard), how many vertices / faces /
+// half-edges each one introduces (their exclusive scans are the numbering of the decoded mesh, cbm/decoder.h:48,75,145,162),
+// and which components share a vertex (cbm/encoder.h:79-113,187: they name each other's vertices and must stay together).
+struct ComponentAnalysis {
+	uint32_t ncomp = 0;
+	std::vector<uint32_t> comp;                  // per face: component number (arbitrary, dense)
+	std::vector<uint32_t> by_rank, rank_of;      // coding rank <-> component number
+	std::vector<uint32_t> seed, n_faces, n_halfedges, fresh, group;   // per coding rank; group = smallest rank tied to it
+	bool want_vertex_owner = false;
+	std::vector<uint32_t> vertex_owner;          // per vertex: coding rank of the component that introduces it (0xffffffff: unused)
+};
+void analyse_components(const Mesh &m, ComponentAnalysis &A);
+
+// ---- shard.cpp: a mesh shards by groups of connected components
+struct ShardPlan {
+	uint32_t n_shards = 0, g_nv = 0, g_nf = 0, g_ne = 0;
+	ComponentAnalysis A;
+	std::vector<uint32_t> shard_of;               // per coding rank
+	std::vector<uint32_t> base_v, base_f, base_he; // per coding rank (+ end): position in the numbering of the decoded mesh
+	std::vector<uint64_t> shard_triangles;        // per shard
+	std::vector<uint8_t> have_degree;
+};
+void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan);
+Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard);
+// several single- or multi-segment sharded containers (.hry v0.3) of the same mesh -> one
+void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, std::vector<uint8_t> &out);
+
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
 // seg_start: first decode rank of every connected component (+ end sentinel); seg_level[k]: 0 = the component touches no vertex
 // coded before it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
@@ -113,8 +141,9 @@ size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256]
 void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
                         std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes);
 
+// a shard writes the sizes of the full mesh (m.shard.g_*): the header of a sharded container describes the whole
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);
-// parses the header into a mesh skeleton (lists allocated, no connectivity); returns bytes consumed
-size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor);
+// parses the header into a mesh skeleton (lists allocated unless alloc_records is false, no connectivity); returns bytes consumed
+size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool alloc_records = true);
 
 }   // namespace hry

@@ -70,6 +70,7 @@ struct AttrList {
 	uint32_t count = 0;
 	BigVec<uint8_t> data;
 	std::vector<uint8_t> bmin, bmax;       // records in original types; empty until computed
+	std::vector<uint32_t> bmin_at, bmax_at; // 1 + index of the first element that holds the bound, 0 = the initial value (device_bounds)
 	bool have_bounds = false;
 
 	int ncomp() const { return (int)type.size(); }
@@ -94,6 +95,20 @@ struct AttrList {
 	}
 };
 
+// A shard of a larger mesh (host/shard.cpp): whole groups of connected components that share no vertex
+// with the rest, in the numbering of the shard itself.  The vertex / face / half-edge numbering of a decoded mesh follows the
+// coding order across ALL components of the full mesh (cbm/encoder.h:61-68,215; decoder.h:48,75,145,162), so every run of
+// components that are consecutive in that order keeps its place in the full numbering.
+struct ShardRun { uint32_t first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges; };
+struct ShardInfo {
+	uint32_t g_nv = 0, g_nf = 0, g_ne = 0;   // sizes of the full mesh (the merged container's header); g_nf == 0: not a shard
+	std::vector<uint32_t> seeds;             // start face of every component of the shard, in coding order (replaces the
+	                                         // reference's start-face rule, writer.cc:40-46, which depends on the full face count)
+	std::vector<ShardRun> runs;              // in coding order; the shard's own numbering lays them out back to back
+	std::vector<uint32_t> vertex_of, face_of; // input index in the full mesh of every vertex / face of the shard (bounds ties, tests)
+	bool active() const { return g_nf != 0; }
+};
+
 struct Mesh {
 	uint32_t nv = 0, nf = 0;
 	BigVec<uint32_t> face_off{0};        // nf + 1
@@ -103,6 +118,8 @@ struct Mesh {
 	AttrList lists[2];                   // [0] face attributes, [1] vertex attributes (formats/ply/reader.cc:388-400)
 	uint64_t device_token = 0;           // identity of the HBM-resident copy, 0 = none
 	uint32_t declared_ne = 0;            // half-edge count announced by a .hry header (the connectivity follows later)
+	ShardInfo shard;                     // set by shard_extract: this mesh is a shard of a larger one
+	std::vector<ShardRun> covered;       // set by the decoder of a sharded container: the runs of the whole numbering that were decoded
 
 	uint32_t ne() const { return face_off.back(); }
 	uint64_t ntri() const { return (uint64_t)ne() - 2ull * nf; }

@@ -1,0 +1,256 @@
+// Sharding of one mesh over several GPUs (north_star: "meshes shard by independent connected
+// component across the 8 GPUs of one node").
+//
+// What the reference fixes and a split has to honour:
+//   * the numbering of the decoded mesh runs across ALL components in coding order: vertices, faces and half-edges are
+//     numbered as the cut-border machine creates them (cbm/encoder.h:61-68,215; cbm/decoder.h:48,75,145,162);
+//   * the coding order of the components is the start-face sequence (formats/hry/writer.cc:28-46): face 0 first, then the
+//     iteration order of a std::unordered_set that holds the faces of the WHOLE mesh;
+//   * a component that touches a vertex introduced by an earlier one names it by its index (TRIxxx start operations,
+//     NM operations: cbm/encoder.h:79-113,187), and its operation classes depend on that vertex's triangle count.
+// So the unit of distribution is a GROUP: components tied together by shared vertices.  A plan (host analysis of the
+// connectivity only, no walk) labels the components, orders them, ties them, and takes the exclusive scans of the vertices /
+// faces / half-edges each one introduces.  A shard is the sub-mesh of some groups in its own compact numbering, plus the seed
+// face of each of its components (in coding order) and the place of every run of consecutive components in the full
+// numbering.  Shards are coded independently (one v0.2 body each, no data-path collective) and merged into one .hry v0.3:
+//
+//     header of the whole mesh (minor version 3) | u32 n_segments | n_segments x u64 bytes | segments
+//     segment: u32 n_runs | n_runs x { u32 first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges } | v0.2 body
+//
+// A segment decodes on its own (any GPU); its runs say where its vertices, faces and half-edges go in the whole mesh.
+#include "host.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <numeric>
+
+namespace hry {
+namespace {
+constexpr uint32_t NONE32 = 0xffffffffu;
+
+struct Ranges {
+	unsigned nt;
+	explicit Ranges(uint64_t n) : nt(n >= (1u << 16) ? host_threads() : 1u) {}
+	void of(uint32_t n, unsigned t, uint32_t &b, uint32_t &e) const { b = (uint32_t)((uint64_t)n * t / nt); e = (uint32_t)((uint64_t)n * (t + 1) / nt); }
+};
+}   // namespace
+
+void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
+{
+	if (n_shards == 0) throw Error(HRY_E_ARG, "need at least one shard");
+	if (m.nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
+	if (m.shard.active()) throw Error(HRY_E_ARG, "a shard cannot be sharded again");
+	plan = ShardPlan();
+	plan.n_shards = n_shards;
+	plan.g_nv = m.nv; plan.g_nf = m.nf; plan.g_ne = m.ne();
+	plan.have_degree = m.have_degree;
+	ComponentAnalysis &A = plan.A;
+	A.want_vertex_owner = true;
+	analyse_components(m, A);
+	const uint32_t nc = A.ncomp;
+	// numbering of the decoded mesh: exclusive scans in coding order
+	plan.base_v.resize(nc + 1); plan.base_f.resize(nc + 1); plan.base_he.resize(nc + 1);
+	plan.base_v[0] = plan.base_f[0] = plan.base_he[0] = 0;
+	for (uint32_t k = 0; k < nc; ++k) {
+		plan.base_v[k + 1] = plan.base_v[k] + A.fresh[k];
+		plan.base_f[k + 1] = plan.base_f[k] + A.n_faces[k];
+		plan.base_he[k + 1] = plan.base_he[k] + A.n_halfedges[k];
+	}
+	// groups in the order of their first component, with their triangle counts
+	std::vector<uint32_t> groups;          // representative ranks, ascending
+	std::vector<uint64_t> gtri(nc, 0);     // indexed by representative
+	uint64_t total = 0;
+	for (uint32_t k = 0; k < nc; ++k) {
+		const uint64_t tri = (uint64_t)A.n_halfedges[k] - 2ull * A.n_faces[k];
+		if (A.group[k] == k) groups.push_back(k);
+		gtri[A.group[k]] += tri;
+		total += tri;
+	}
+	std::vector<uint32_t> shard_of_group(nc, 0);
+	plan.shard_triangles.assign(n_shards, 0);
+	if (groups.size() >= 8ull * n_shards) {
+		// many groups: cut their sequence where the running triangle count passes k / n of the total (midpoint rule), which
+		// keeps long runs of consecutive components together
+		uint64_t run = 0;
+		for (uint32_t g : groups) {
+			const uint64_t mid = run + gtri[g] / 2;
+			uint32_t s = total ? (uint32_t)std::min<uint64_t>(n_shards - 1, (unsigned __int128)mid * n_shards / total) : 0;
+			shard_of_group[g] = s;
+			run += gtri[g];
+		}
+	} else {
+		// few groups: largest first onto the least loaded shard (ties: lower index) -- the same greedy rule as
+		// harry_amd.sharding.assign_components
+		std::vector<uint32_t> by_size(groups);
+		std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return gtri[a] > gtri[b]; });
+		std::vector<uint64_t> load(n_shards, 0);
+		for (uint32_t g : by_size) {
+			uint32_t s = 0;
+			for (uint32_t j = 1; j < n_shards; ++j) if (load[j] < load[s]) s = j;
+			shard_of_group[g] = s;
+			load[s] += gtri[g];
+		}
+	}
+	plan.shard_of.resize(nc);
+	for (uint32_t k = 0; k < nc; ++k) {
+		plan.shard_of[k] = shard_of_group[A.group[k]];
+		plan.shard_triangles[plan.shard_of[k]] += (uint64_t)A.n_halfedges[k] - 2ull * A.n_faces[k];
+	}
+}
+
+Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
+{
+	if (shard >= plan.n_shards) throw Error(HRY_E_ARG, "shard index out of range");
+	if (plan.g_nv != m.nv || plan.g_nf != m.nf || plan.g_ne != m.ne() || plan.A.comp.size() != m.nf || plan.A.vertex_owner.size() != m.nv)
+		throw Error(HRY_E_ARG, "the plan belongs to another mesh");
+	const ComponentAnalysis &A = plan.A;
+	const uint32_t nf = m.nf, nv = m.nv, nc = A.ncomp;
+	const uint32_t *foff = m.face_off.data();
+	const Ranges R(m.ne());
+	const unsigned nt = R.nt;
+	auto face_sel = [&](uint32_t f) { return plan.shard_of[A.rank_of[A.comp[f]]] == shard; };
+	auto vert_sel = [&](uint32_t v) { const uint32_t o = A.vertex_owner[v]; return o != NONE32 && plan.shard_of[o] == shard; };
+	// compact numbering: ascending input index
+	std::vector<uint32_t> cf(nt + 1, 0), ch(nt + 1, 0), cv(nt + 1, 0);
+	parallel_for(nt, [&](unsigned t) {
+		uint32_t b, e, nfc = 0, nhc = 0, nvc = 0;
+		R.of(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) if (face_sel(f)) { ++nfc; nhc += foff[f + 1] - foff[f]; }
+		R.of(nv, t, b, e);
+		for (uint32_t v = b; v < e; ++v) if (vert_sel(v)) ++nvc;
+		cf[t + 1] = nfc; ch[t + 1] = nhc; cv[t + 1] = nvc;
+	});
+	for (unsigned t = 0; t < nt; ++t) { cf[t + 1] += cf[t]; ch[t + 1] += ch[t]; cv[t + 1] += cv[t]; }
+	const uint32_t lnf = cf[nt], lne = ch[nt], lnv = cv[nt];
+	std::unique_ptr<Mesh> out(new Mesh());
+	Mesh &s = *out;
+	s.nv = lnv; s.nf = lnf;
+	s.have_degree = m.have_degree;   // the tables of the whole mesh: numtri model and its presence follow the container header
+	s.face_off.resize((size_t)lnf + 1); s.face_off[0] = 0;
+	s.org.resize(lne); s.twin.resize(lne);
+	s.shard.g_nv = plan.g_nv; s.shard.g_nf = plan.g_nf; s.shard.g_ne = plan.g_ne;
+	s.shard.vertex_of.resize(lnv); s.shard.face_of.resize(lnf);
+	BigVec<uint32_t> g2l_f, g2l_v, l_off;   // input face -> (shard face, first half-edge of it in the shard); input vertex -> shard vertex
+	g2l_f.resize(nf); g2l_v.resize(nv); l_off.resize(nf);
+	parallel_for(nt, [&](unsigned t) {
+		uint32_t b, e;
+		R.of(nf, t, b, e);
+		uint32_t lf = cf[t], lh = ch[t];
+		for (uint32_t f = b; f < e; ++f) {
+			if (!face_sel(f)) { g2l_f[f] = NONE32; continue; }
+			g2l_f[f] = lf; l_off[f] = lh;
+			s.shard.face_of[lf] = f;
+			lh += foff[f + 1] - foff[f];
+			s.face_off[++lf] = lh;
+		}
+		R.of(nv, t, b, e);
+		uint32_t lv = cv[t];
+		for (uint32_t v = b; v < e; ++v) {
+			if (!vert_sel(v)) { g2l_v[v] = NONE32; continue; }
+			g2l_v[v] = lv;
+			s.shard.vertex_of[lv++] = v;
+		}
+	});
+	// face of a half-edge: uniform degree by division, else by bisection of the offsets
+	int udeg = 0;
+	if (!m.uniform_degree(udeg)) udeg = 0;
+	auto face_of = [&](uint32_t h) -> uint32_t {
+		if (udeg) return h / (uint32_t)udeg;
+		return (uint32_t)(std::upper_bound(foff, foff + nf + 1, h) - foff) - 1;
+	};
+	std::atomic<bool> bad{ false };
+	parallel_for(nt, [&](unsigned t) {
+		uint32_t b, e;
+		R.of(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) {
+			if (g2l_f[f] == NONE32) continue;
+			const uint32_t lo = l_off[f];
+			for (uint32_t h = foff[f]; h < foff[f + 1]; ++h) {
+				const uint32_t lh = lo + (h - foff[f]);
+				const uint32_t lv = g2l_v[m.org[h]];
+				if (lv == NONE32) bad.store(true, std::memory_order_relaxed);
+				s.org[lh] = lv;
+				const uint32_t o = m.twin[h];
+				if (o == h) { s.twin[lh] = lh; continue; }
+				const uint32_t fo = face_of(o);
+				if (g2l_f[fo] == NONE32) { bad.store(true, std::memory_order_relaxed); s.twin[lh] = lh; continue; }
+				s.twin[lh] = l_off[fo] + (o - foff[fo]);
+			}
+		}
+	});
+	if (bad.load()) throw Error(HRY_E_INTERNAL, "shard: a selected face reaches outside its group");
+	// attribute records and list formats
+	for (int l = 0; l < 2; ++l) {
+		const AttrList &L = m.lists[l];
+		AttrList &D = s.lists[l];
+		D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
+		D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
+		D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = L.have_bounds;
+		const std::vector<uint32_t> &src = l == 0 ? s.shard.face_of : s.shard.vertex_of;
+		D.count = (uint32_t)src.size();
+		const size_t st = (size_t)L.stride();
+		D.data.resize(src.size() * st);
+		if (st && L.count != (l == 0 ? nf : nv)) throw Error(HRY_E_UNSUPPORTED, "attribute lists must have one record per element");
+		if (st) parallel_for(nt, [&](unsigned t) {
+			uint32_t b, e;
+			R.of((uint32_t)src.size(), t, b, e);
+			for (uint32_t i = b; i < e; ++i) memcpy(D.data.data() + (size_t)i * st, L.data.data() + (size_t)src[i] * st, st);
+		});
+	}
+	// components of the shard in coding order: seeds and runs
+	bool open = false;
+	for (uint32_t k = 0; k < nc; ++k) {
+		if (plan.shard_of[k] != shard) { open = false; continue; }
+		s.shard.seeds.push_back(g2l_f[A.seed[k]]);
+		if (!open) { s.shard.runs.push_back(ShardRun{ plan.base_v[k], plan.base_f[k], plan.base_he[k], 0, 0, 0 }); open = true; }
+		ShardRun &r = s.shard.runs.back();
+		r.n_vertices += A.fresh[k]; r.n_faces += A.n_faces[k]; r.n_halfedges += A.n_halfedges[k];
+	}
+	return out.release();
+}
+
+// ---- merge ---------------------------------------------------------------------------------------------------------
+namespace {
+struct PartView { size_t hdr; uint32_t nseg; const uint8_t *lens; const uint8_t *segs; size_t seg_bytes; };
+PartView parse_part(const uint8_t *p, size_t n)
+{
+	Mesh tmp;
+	int minor = 0;
+	PartView v{};
+	v.hdr = read_hry_header(p, n, tmp, minor, false);
+	if (minor != 3) throw Error(HRY_E_ARG, "merge: not a sharded (.hry v0.3) container");
+	if (n < v.hdr + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
+	memcpy(&v.nseg, p + v.hdr, 4);
+	if ((uint64_t)v.nseg * 8 > n - v.hdr - 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
+	v.lens = p + v.hdr + 4;
+	v.segs = v.lens + 8ull * v.nseg;
+	uint64_t tot = 0;
+	for (uint32_t i = 0; i < v.nseg; ++i) { uint64_t l; memcpy(&l, v.lens + 8ull * i, 8); if (l > n) throw Error(HRY_E_FORMAT, "truncated sharded container"); tot += l; }
+	if (tot != n - (size_t)(v.segs - p)) throw Error(HRY_E_FORMAT, "sharded container: segment sizes do not add up");
+	v.seg_bytes = (size_t)tot;
+	return v;
+}
+}   // namespace
+
+void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, std::vector<uint8_t> &out)
+{
+	if (n == 0) throw Error(HRY_E_ARG, "merge: nothing to merge");
+	std::vector<PartView> pv(n);
+	uint64_t nseg = 0, bytes = 0;
+	for (size_t i = 0; i < n; ++i) {
+		if (!parts[i]) throw Error(HRY_E_ARG, "null argument");
+		pv[i] = parse_part(parts[i], sizes[i]);
+		if (pv[i].hdr != pv[0].hdr || memcmp(parts[i], parts[0], pv[0].hdr) != 0) throw Error(HRY_E_ARG, "merge: the parts describe different meshes (headers differ)");
+		nseg += pv[i].nseg; bytes += pv[i].seg_bytes;
+	}
+	if (nseg > 0xffffffffull) throw Error(HRY_E_UNSUPPORTED, "too many segments");
+	out.clear();
+	out.reserve(pv[0].hdr + 4 + 8 * (size_t)nseg + (size_t)bytes);
+	out.insert(out.end(), parts[0], parts[0] + pv[0].hdr);
+	const uint32_t ns32 = (uint32_t)nseg;
+	out.insert(out.end(), (const uint8_t*)&ns32, (const uint8_t*)&ns32 + 4);
+	for (size_t i = 0; i < n; ++i) out.insert(out.end(), pv[i].lens, pv[i].lens + 8ull * pv[i].nseg);
+	for (size_t i = 0; i < n; ++i) out.insert(out.end(), pv[i].segs, pv[i].segs + pv[i].seg_bytes);
+}
+
+}   // namespace hry

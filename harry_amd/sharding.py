@@ -1,16 +1,21 @@
-"""Multi-GPU sharding of the .hry path: meshes shard by independent connected component; there is
-no data-path collective.  Ranks exchange only the finished streams, for concatenation on rank 0 (RCCL over xGMI when the
-process group is `nccl`, gloo in the CPU tests)."""
+"""One mesh over N GPUs: the mesh shards by groups of connected components (libharry_amd:
+hry_shard_plan / hry_shard_extract), every rank codes its shard with no data-path collective, and the ranks exchange only
+  * the per-component bounds of their shards (a few hundred bytes, all-gather) -- quantisation and the container header use
+    the bounds of the WHOLE mesh (structs/quant.h:30-96), and
+  * the finished segments, gathered on rank 0 for concatenation into ONE .hry v0.3 container (hry_merge).
+torch.distributed is plumbing here: backend `nccl` = RCCL over xGMI on the GPU box, `gloo` in the CPU tests."""
 from __future__ import annotations
 
-import struct
-
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import codec as hc
+
 
 def assign_components(tri_counts, world: int):
-    """Greedy bin packing by triangle count (largest first, ties by index); identical on every rank."""
+    """Greedy bin packing by triangle count (largest first, ties by index); identical on every rank.  The library applies
+    the same rule to groups of components when there are few of them (host/shard.cpp)."""
     order = sorted(range(len(tri_counts)), key=lambda c: (-tri_counts[c], c))
     parts = [[] for _ in range(world)]
     load = [0] * world
@@ -21,57 +26,87 @@ def assign_components(tri_counts, world: int):
     return [sorted(p) for p in parts]
 
 
-def gather_streams(streams: dict, n_components: int, device: torch.device):
-    """streams: {component index: bytes} produced by this rank.  Returns {component: bytes} on rank 0, None elsewhere.
-    Variable-length gather: all_gather of the per-component sizes, then one padded gather of the payloads."""
+# ---- bounds of the whole mesh from the bounds of its shards ------------------------------------------------------------
+def shard_bounds(cx: "hc.Codec", shard: "hc.Mesh") -> np.ndarray:
+    """k_bounds on the shard's resident records -> int64[n_components_total, 4]: min bits, max bits, and for each the key that
+    breaks ties like ONE sequential scan over the whole mesh would (structs/quant.h:30-44: strict comparisons, first wins):
+    0 for the scan's initial value, else 1 + the element's index in the whole mesh."""
+    cx.bounds(shard)
+    rows = []
+    for l in (0, 1):
+        fmt = shard.list_fmt(l)
+        if not fmt:
+            continue
+        mn, mx = shard.list_min(l), shard.list_max(l)
+        at = shard.bounds_at(l)
+        whole_index = shard.shard_elements(1 if l == 1 else 0)
+        for c, (t, _q, off) in enumerate(fmt):
+            sz = hc.TYPE_SIZE[t]
+            bits = lambda rec: int.from_bytes(bytes(rec[off:off + sz]), "little")
+            key = lambda a: 0 if a == 0 else (int(whole_index[a - 1]) + 1 if len(whole_index) else a)
+            rows.append([bits(mn), bits(mx), key(at[c][0]), key(at[c][1])])
+    return np.array(rows, dtype=np.uint64).reshape(-1, 4).view(np.int64)
+
+
+def combine_bounds(per_shard, shard: "hc.Mesh"):
+    """per_shard: the shard_bounds arrays of every shard (same list formats).  Sets the whole mesh's bounds on `shard`."""
+    tabs = [np.asarray(p).view(np.uint64).reshape(-1, 4) for p in per_shard]
+    row = 0
+    for l in (0, 1):
+        fmt = shard.list_fmt(l)
+        if not fmt:
+            continue
+        stride = shard.list_stride(l)
+        mn, mx = bytearray(stride), bytearray(stride)
+        for t, _q, off in fmt:
+            sz, dt = hc.TYPE_SIZE[t], np.dtype(hc.TYPE_NP[t])
+            val = lambda b: np.frombuffer(int(b).to_bytes(8, "little")[:sz], dtype=dt)[0]
+            best_mn = best_mx = None
+            for tab in tabs:
+                vmn, vmx, kmn, kmx = val(tab[row, 0]), val(tab[row, 1]), int(tab[row, 2]), int(tab[row, 3])
+                if best_mn is None or vmn < best_mn[0] or (not best_mn[0] < vmn and kmn < best_mn[1]):
+                    best_mn = (vmn, kmn, int(tab[row, 0]))
+                if best_mx is None or vmx > best_mx[0] or (not best_mx[0] > vmx and kmx < best_mx[1]):
+                    best_mx = (vmx, kmx, int(tab[row, 1]))
+            mn[off:off + sz] = best_mn[2].to_bytes(8, "little")[:sz]
+            mx[off:off + sz] = best_mx[2].to_bytes(8, "little")[:sz]
+            row += 1
+        shard.set_bounds(l, bytes(mn), bytes(mx))
+
+
+def exchange_bounds(cx: "hc.Codec", shard: "hc.Mesh", device: torch.device):
+    """all-gather of the shards' bounds (RCCL over xGMI under `nccl`), then the same combination on every rank"""
+    mine = torch.from_numpy(shard_bounds(cx, shard).copy()).to(device)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        combine_bounds([mine.cpu().numpy()], shard)
+        return
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    combine_bounds([o.cpu().numpy() for o in out], shard)
+
+
+# ---- the finished segments -> rank 0 -------------------------------------------------------------------------------
+def gather_segments(container: bytes, device: torch.device):
+    """Variable-length gather of every rank's one-segment container on rank 0: all_gather of the sizes, then one padded
+    gather of the payloads.  Returns the list of containers (rank order) on rank 0, None elsewhere."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = torch.zeros(n_components, dtype=torch.int64, device=device)
-    for c, b in streams.items():
-        sizes[c] = len(b)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
-    per_rank = [int(s.sum().item()) for s in all_sizes]
-    cap = max(max(per_rank), 1)
+    size = torch.tensor([len(container)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
     buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    off = 0
-    for c in sorted(streams):
-        b = streams[c]
-        buf[off:off + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(device)
-        off += len(b)
+    buf[:len(container)] = torch.frombuffer(bytearray(container), dtype=torch.uint8).to(device)
     out = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, out, dst=0)
     if rank != 0:
         return None
-    result = {}
-    for r in range(world):
-        raw = out[r].cpu().numpy().tobytes()
-        off = 0
-        for c in range(n_components):
-            n = int(all_sizes[r][c].item())
-            if n:
-                result[c] = raw[off:off + n]
-                off += n
-    return result
+    return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
 
 
-MAGIC = b"HRYS"
-
-
-def concat_container(streams: dict) -> bytes:
-    """Concatenation of per-component .hry streams: magic, u32 count, u64 sizes, payloads in component order."""
-    keys = sorted(streams)
-    head = MAGIC + struct.pack("<I", len(keys)) + b"".join(struct.pack("<Q", len(streams[k])) for k in keys)
-    return head + b"".join(streams[k] for k in keys)
-
-
-def split_container(blob: bytes):
-    if blob[:4] != MAGIC:
-        raise ValueError("not a multi-component container")
-    (n,) = struct.unpack_from("<I", blob, 4)
-    sizes = struct.unpack_from(f"<{n}Q", blob, 8)
-    off = 8 + 8 * n
-    out = []
-    for s in sizes:
-        out.append(blob[off:off + s])
-        off += s
-    return out
+def merge_on_rank0(container: bytes, device: torch.device):
+    """rank 0: ONE .hry v0.3 container holding every rank's segment; other ranks: None"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return hc.merge([container])
+    parts = gather_segments(container, device)
+    return hc.merge(parts) if parts is not None else None

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HRY_ABI_VERSION 1
+#define HRY_ABI_VERSION 2
 
 enum {
     HRY_OK = 0,
@@ -63,6 +63,8 @@ typedef struct hry_opts {
     int32_t chunk_syms;   /* CHUNKED: symbols per chunk and plane (0 = default) */
     int32_t keep_stages;  /* keep intermediate device buffers for hry_stage_get (tests) */
     int32_t flags;        /* HRY_FLAG_* */
+    int32_t shard_index;  /* hry_decode of a sharded container (.hry v0.3): decode only the segments i with */
+    int32_t shard_count;  /*   i % shard_count == shard_index (one process per GPU); 0 or 1 = every segment */
 } hry_opts;
 
 /* COMPAT only: run the one strictly serial recurrence of the reference stream (the range register R of arith/coder.h:69-91,
@@ -138,6 +140,43 @@ int hry_mesh_upload(hry_ctx *ctx, hry_mesh *m);
 int hry_encode(hry_ctx *ctx, hry_mesh *m, const hry_opts *opts, uint8_t **out, size_t *out_len);
 int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out);
 void hry_free(void *p);
+
+/* ---- one mesh over several GPUs ---------------------------------------------------- */
+/* The reference has no multi-device path; what a split must honour is its numbering: vertices, faces and half-edges of the
+ * decoded mesh are numbered in coding order across ALL connected components (cbm/encoder.h:61-68,215; cbm/decoder.h:48,75,
+ * 145,162), components that share a vertex name it by that number (cbm/encoder.h:79-113,187), and the order of the
+ * components is the start-face sequence over the whole mesh (formats/hry/writer.cc:28-46).
+ *   hry_shard_plan     host analysis of the connectivity (no walk): components, their coding order, groups of components tied
+ *                      by shared vertices, exclusive scans of the vertices / faces / half-edges each introduces, and the
+ *                      distribution of the groups over n_shards (balanced by triangle count).  Deterministic: every rank
+ *                      that holds the mesh computes the same plan.
+ *   hry_shard_extract  the sub-mesh of one shard in its own compact numbering; it carries the seed face of each of its
+ *                      components and the place of its runs of components in the whole numbering.  hry_encode (CHUNKED) of
+ *                      a shard writes a one-segment sharded container (.hry v0.3) whose header describes the WHOLE mesh:
+ *                      give the shard the bounds of the whole mesh first (hry_list_set_bounds) -- they are in that header
+ *                      and scale the quantisation (structs/quant.h:30-96).
+ *   hry_merge          concatenates the segments of several such containers into ONE .hry v0.3 (no re-coding).
+ *   hry_decode         reads it on one GPU (all segments) or, with opts->shard_index / shard_count, a share of the segments
+ *                      per process; hry_mesh_runs lists the runs of the whole numbering that the returned mesh holds. */
+typedef struct hry_plan hry_plan;
+int hry_shard_plan(const hry_mesh *m, int n_shards, hry_plan **out);
+void hry_plan_free(hry_plan *p);
+uint32_t hry_plan_ncomponents(const hry_plan *p);
+uint32_t hry_plan_ngroups(const hry_plan *p);
+uint64_t hry_plan_triangles(const hry_plan *p, int shard);
+int hry_shard_extract(const hry_mesh *m, const hry_plan *p, int shard, hry_mesh **out);
+int hry_merge(const uint8_t *const *parts, const size_t *sizes, size_t n, uint8_t **out, size_t *out_len);
+/* runs as 6 x u32 each: first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges (numbering of the whole
+ * mesh).  For a shard: where its components go; for a mesh decoded from a sharded container: what was decoded. */
+size_t hry_mesh_runs(const hry_mesh *m, const uint32_t **runs);
+/* for a shard: index in the whole mesh of every vertex (which = 1) / face (which = 0) of the shard */
+size_t hry_shard_elements(const hry_mesh *m, int which, const uint32_t **idx);
+/* bounds of a list as records in the original component types (what hry_list_min / hry_list_max return) */
+int hry_list_set_bounds(hry_mesh *m, int l, const uint8_t *min_rec, const uint8_t *max_rec);
+/* after hry_bounds: 1 + index of the first element that holds the minimum / maximum of component c, 0 = the initial value of
+ * the reference's scan (structs/quant.h:33) -- what a combination of per-shard bounds needs to break ties (+-0.0) like one scan */
+uint32_t hry_list_min_at(const hry_mesh *m, int l, int c);
+uint32_t hry_list_max_at(const hry_mesh *m, int l, int c);
 
 /* ---- stage-level access for parity tests (valid after hry_encode/hry_decode with keep_stages) ----- */
 /* names: "order_v","order_f","twin","vplanes","fplanes","rec","sym_l","r","S","payload", ... */
