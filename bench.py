@@ -4,8 +4,14 @@
 One step = one pass of the hot path over one batch of synthetic input: encode the resident mesh to .hry
 (host cut-border walk + every HIP kernel + D2H of the stream) and, where the profile supports it, decode it back.
 Workload at N=1: BASELINE.json configs[1] -- 1 002 528-triangle closed torus, float32 xyz, `-l1 -q14`, one MI355X.
-With N>1 GPUs every rank codes its own connected component of the same size (weak scaling, no data-path
-collective; the compressed streams are gathered to rank 0 for concatenation only).
+With N>1 GPUs the workload is ONE mesh of N such components (weak scaling: per-GPU work fixed).  Every rank plans the split
+(hry_shard_plan: components, coding order, global vertex / face / half-edge bases), extracts its shard and keeps it resident;
+a step = all-gather of the shards' bounds (RCCL) + quantisation + encode of the shard (one segment, no data-path collective)
++ gather of the segments on rank 0 and merge into ONE .hry v0.3 container + decode of the rank's own segment.  After the
+timed region rank 0 decodes the merged container and checks it against the single-GPU path on the whole mesh.
+
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks (torch.distributed.run, 127.0.0.1)
+before anything touches a GPU.
 
 Prints ONE JSON line on rank 0.
 """
@@ -94,6 +100,29 @@ def cpu_baseline_reference(mesh, budget_s=20.0):
         return None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) and pass their output through.
+    Nothing in this process has touched a GPU yet."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def build_whole(n_side: int, world: int):
+    """ONE mesh of `world` torus components (seed 2 + k, side by side); world == 1 is BASELINE configs[1] itself"""
+    from harry_amd import meshgen as mg
+    if world == 1:
+        return build_workload(n_side, seed=2)
+    return mg.concat([mg.torus(n_side, n_side, seed=2 + k, sigma=1e-4, center=(3.0 * k, 0.0, 0.0)) for k in range(world)])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,37 +133,67 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: harry_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box (HRY_BENCH_SHARE_GPU=1): every rank on device 0, gloo instead of RCCL (RCCL refuses two ranks
+    # on one device).  Never the measured configuration: the JSON line says so.
+    share_gpu = os.environ.get("HRY_BENCH_SHARE_GPU") == "1"
+    if not share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
+    dev_index = 0 if share_gpu else local_rank
+    backend = "gloo" if share_gpu else "nccl"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = torch.device("cpu") if share_gpu else dev
 
     from harry_amd import codec as hc
+    from harry_amd import sharding
 
     quant = [(1, -1, 14)]
-    mesh = build_workload(args.side, seed=2 + rank)     # each rank: its own connected component (weak scaling)
-    raw = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)   # float32 positions, not yet quantised
-    cx = hc.Codec(local_rank)
+    mesh = build_whole(args.side, world)                 # the WHOLE mesh, identical on every rank
+    whole = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)   # float32 positions, not yet quantised
+    cx = hc.Codec(dev_index)
+    n_groups = 1
+    if world > 1:
+        plan = hc.ShardPlan(whole, world)                # deterministic: the same plan on every rank
+        raw = plan.extract(whole, rank)                  # this rank's shard: whole groups of components, own numbering
+        n_groups = plan.ngroups
+        shard_tris = [plan.triangles(r) for r in range(world)]
+        if rank != 0:
+            del whole
+    else:
+        raw = whole
+        shard_tris = [mesh.ntri]
     base = raw.clone()
+    if world > 1:
+        cx.upload(base)
+        sharding.exchange_bounds(cx, base, comm_dev)
     cx.requant(base, quant)                              # used for the profile probe only; every timed step quantises itself
 
     profile = args.profile
     if profile == "auto":
         profile = "chunked"
         try:
-            probe = base.clone()
-            cx.write_hry(probe, profile=hc.PROFILE_CHUNKED)
+            cx.write_hry(base.clone(), profile=hc.PROFILE_CHUNKED)
         except hc.HryError:
             profile = "compat"
+    if world > 1 and profile != "chunked":
+        raise SystemExit("the reference's single stream (compat) does not shard: replicas only (DESIGN.md section 5)")
     pid = hc.PROFILE_CHUNKED if profile == "chunked" else hc.PROFILE_COMPAT
     can_decode = True
     try:
@@ -143,66 +202,57 @@ def main():
         can_decode = False
 
     def one_step():
-        """returns (stream bytes, timing dict); inputs are resident in HBM before the timed region"""
+        """returns (container bytes, merged container on rank 0, timings); inputs are resident in HBM before the timed region"""
         m = raw.clone()
         cx.upload(m)                                     # float records + connectivity resident in HBM
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if world > 1:
+            sharding.exchange_bounds(cx, m, comm_dev)    # k_bounds on the shard + all-gather (RCCL) -> bounds of the whole mesh
         cx.requant(m, quant)                             # encode = quantisation (bounds, float -> uint14) + .hry production
         t_q = time.perf_counter()
         out = cx.write_hry(m, profile=pid)
         t1 = time.perf_counter()
         tm_e = cx.timing()
         tm_e["requant_ms"] = (t_q - t0) * 1e3
+        merged = sharding.merge_on_rank0(out, comm_dev) if world > 1 else None   # segments -> rank 0 -> ONE container
+        t_g = time.perf_counter()
         tm_d = {}
         if can_decode:
-            cx.read_hry(out)
+            cx.read_hry(out)                             # every rank decodes its own segment
             tm_d = cx.timing()
         t2 = time.perf_counter()
         tm_e.update({"dec_" + k: v for k, v in tm_d.items()})
-        return out, t1 - t0, t2 - t1, tm_e
+        tm_e["gather_merge_ms"] = (t_g - t1) * 1e3
+        return out, merged, t1 - t0, t2 - t_g, t_g - t1, tm_e
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_all(stream_bytes):
-        """final stream concatenation on rank 0 (RCCL over xGMI); the only communication of the job"""
-        if world == 1:
-            return None
-        from harry_amd import sharding
-        got = sharding.gather_streams({rank: stream_bytes}, world, dev)
-        if rank == 0:
-            blob = sharding.concat_container(got)
-            assert len(sharding.split_container(blob)) == world
-        return got
-
     for _ in range(args.warmup):
-        o, *_ = one_step()
-        gather_all(o)      # also warms the communicator up
+        one_step()                                       # also warms the communicator up
     barrier()
-    enc_s = dec_s = 0.0
+    enc_s = dec_s = comm_s = 0.0
     timings = []
-    out = b""
+    out, merged = b"", None
     for _ in range(args.steps):
-        out, te, td, tm = one_step()
+        out, merged, te, td, tg, tm = one_step()
         enc_s += te
         dec_s += td
+        comm_s += tg
         timings.append(tm)
-    t_g = time.perf_counter()
-    gather_all(out)
-    gather_s = time.perf_counter() - t_g
     barrier()
-    total = torch.tensor([enc_s + dec_s + gather_s, enc_s, dec_s], dtype=torch.float64, device=dev)
+    total = torch.tensor([enc_s + dec_s + comm_s, enc_s, dec_s, comm_s], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.MAX)
-    t_all, t_enc, t_dec = (float(x) for x in total.tolist())
+    t_all, t_enc, t_dec, t_comm = (float(x) for x in total.tolist())
 
     if rank == 0:
-        ntri = mesh.ntri
+        ntri = mesh.ntri                                  # the whole mesh
         step_ms = t_all / args.steps * 1e3
-        value = world * ntri * args.steps / t_all / 1e6
+        value = ntri * args.steps / t_all / 1e6
         med = lambda k: float(np.median([t.get(k, 0.0) for t in timings]))
         # the dominant kernel of a step (HIP-event times taken inside the library on the codec stream)
         cands = {"k_rchain": med("k_rchain_ms"), "k_chunk_encode": med("k_entropy_ms") if profile == "chunked" else 0.0,
@@ -210,7 +260,7 @@ def main():
         dom_name = max(cands, key=cands.get)
         dom_ms = cands[dom_name]
         # algorithmic bytes per launch: every input array once + the stream once =
-        # vertex records + 4 B per half-edge + |hry|  (same bytes in the opposite direction for decode)
+        # vertex records + 4 B per half-edge + |hry|  (same bytes in the opposite direction for decode); rank 0's shard
         alg_bytes = base.nv * base.list_stride(1) + 4 * base.ne + len(out)
         roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / (dom_ms * 1e-3) / 1e9, 3) if dom_ms > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
@@ -218,32 +268,58 @@ def main():
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 6) if roof["achieved"] else None
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
         # timed program; scripts/collect_profiles.sh collects FETCH_SIZE and WRITE_SIZE in their own passes on this workload)
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "traffic.json")) as f:
-                tr = json.load(f)["kernels"]
-            hit = [v for k, v in tr.items() if k.split("<")[0].split("_range")[0] == dom_name]
-            if hit and args.side == 708 and profile == "chunked":
-                # MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled;
-                # WRITE_SIZE is exact.  Per decode of the workload (all launches of the kernel together).
-                roof["traffic"] = 2 * hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
-                roof["traffic_raw"] = {"FETCH_SIZE_bytes": hit[0]["fetch_bytes"], "WRITE_SIZE_bytes": hit[0]["write_bytes"]}
-                roof["traffic_source"] = "profiles/r1/traffic.json (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 per the gfx950 note)"
-        except (OSError, KeyError, ValueError):
-            pass
+        for rnd in ("r2", "r1"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
+                    tr = json.load(f)["kernels"]
+                hit = [v for k, v in tr.items() if k.split("<")[0].split("_range")[0] == dom_name]
+                if hit and args.side == 708 and profile == "chunked":
+                    # MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled;
+                    # WRITE_SIZE is exact.  Per decode of the workload (all launches of the kernel together).
+                    roof["traffic"] = 2 * hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
+                    roof["traffic_raw"] = {"FETCH_SIZE_bytes": hit[0]["fetch_bytes"], "WRITE_SIZE_bytes": hit[0]["write_bytes"]}
+                    roof["traffic_source"] = f"profiles/{rnd}/traffic.json (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 per the gfx950 note)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        host_ms = med("host_walk_ms") + med("dec_host_walk_ms")
+        per_gpu = f"closed torus {args.side}x{args.side}, {mesh.ntri // world} triangles, float32 xyz, -l1 -q14 (BASELINE configs[1])"
         line = {
             "metric": "Mtriangles/s encode+decode", "value": round(value, 4), "unit": "Mtriangles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 residual bytes, u32 range-coder registers (compat profile: u64)", "data": "synthetic",
-            "config": {"workload": f"closed torus {args.side}x{args.side}, {ntri} triangles, float32 xyz, -l1 -q14 (BASELINE configs[1])",
-                       "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}"},
-            "encode_mtri_s": round(world * ntri * args.steps / t_enc / 1e6, 4),
-            "decode_mtri_s": round(world * ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
-            "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / base.nv, 4),
+            "config": {"workload": per_gpu if world == 1 else f"ONE mesh of {world} components ({ntri} triangles), each a {per_gpu}; sharded by connected component",
+                       "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}", "inputs_resident": True},
+            "encode_mtri_s": round(ntri * args.steps / t_enc / 1e6, 4),
+            "decode_mtri_s": round(ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
+            "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / max(base.nv, 1), 4),
+            "host_fraction": round(host_ms / step_ms, 4) if step_ms > 0 else None,
             "stage_ms": {k: round(med(k), 4) for k in ("requant_ms", "host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms",
-                                                        "dec_host_walk_ms", "dec_k_entropy_ms", "dec_k_predict_ms", "dec_k_chain_ms", "dec_total_ms")},
+                                                        "gather_merge_ms", "dec_host_walk_ms", "dec_k_entropy_ms", "dec_k_predict_ms", "dec_k_chain_ms", "dec_total_ms")},
             "kernel_ms": {k: round(v, 4) for k, v in cands.items()},
             "roofline": roof,
         }
+        if world > 1:
+            # the merged container: decode it whole on this GPU and compare with the single-GPU path on the whole mesh
+            # (outside the timed region)
+            ok = None
+            try:
+                got = cx.read_hry(merged)
+                one = whole.clone()
+                cx.requant(one, quant)
+                ref = cx.read_hry(cx.write_hry(one, profile=pid))
+                ok = bool(got.nv == ref.nv and np.array_equal(got.face_offsets(), ref.face_offsets()) and np.array_equal(got.org(), ref.org())
+                          and np.array_equal(got.twin(), ref.twin()) and np.array_equal(got.list_data(1), ref.list_data(1)))
+            except Exception as exc:
+                sys.stderr.write(f"merged-container check failed: {exc}\n")
+                ok = False
+            line["sharded"] = {"rccl_ranks": world, "backend": "nccl (RCCL over xGMI)" if backend == "nccl" else "gloo (one-GPU rehearsal, not a measurement)",
+                               "components": world, "groups": n_groups, "triangles_per_rank": shard_tris,
+                               "merged_container_bytes": len(merged), "segments": world,
+                               "merged_decode_equals_single_gpu": ok, "comm_ms_per_step": round(t_comm / args.steps * 1e3, 3),
+                               "collectives": "all_gather(bounds, 96 B/rank) + all_gather(sizes) + gather(segments) per step"}
+            if ok is False:
+                line["error"] = "merged container does not decode to the single-GPU result"
         # end to end, as the `harry in.ply out.hry -l1 -q14` / `harry out.hry back.ply` command lines see it: PLY bytes ->
         # parse + twin matching -> upload -> quantisation -> .hry bytes, and .hry bytes -> mesh -> binary PLY bytes.  Outside the timed
         # region; not part of `value`.
@@ -283,6 +359,7 @@ def main():
         print(json.dumps(line))
     cx.close()
     if world > 1:
+        dist.barrier()          # rank 0 checks the merged container after the timed region; leave together
         dist.destroy_process_group()
 
 
