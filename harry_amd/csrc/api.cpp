@@ -203,7 +203,7 @@ size_t hry_mesh_runs(const hry_mesh *m, const uint32_t **runs)
 size_t hry_shard_elements(const hry_mesh *m, int which, const uint32_t **idx)
 {
 	if (!m || !idx) return 0;
-	const std::vector<uint32_t> &v = which ? m->m.shard.vertex_of : m->m.shard.face_of;
+	const std::vector<uint32_t> &v = which == 2 ? m->m.shard.seeds : which ? m->m.shard.vertex_of : m->m.shard.face_of;
 	*idx = v.data();
 	return v.size();
 }

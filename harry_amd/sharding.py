@@ -75,8 +75,13 @@ def combine_bounds(per_shard, shard: "hc.Mesh"):
 
 
 def exchange_bounds(cx: "hc.Codec", shard: "hc.Mesh", device: torch.device):
-    """all-gather of the shards' bounds (RCCL over xGMI under `nccl`), then the same combination on every rank"""
-    mine = torch.from_numpy(shard_bounds(cx, shard).copy()).to(device)
+    """k_bounds on this rank's shard, all-gather (RCCL over xGMI under `nccl`), the same combination on every rank"""
+    allgather_combine(shard_bounds(cx, shard), shard, device)
+
+
+def allgather_combine(table: np.ndarray, shard: "hc.Mesh", device: torch.device):
+    """table: this rank's shard_bounds array"""
+    mine = torch.from_numpy(np.ascontiguousarray(table).copy()).to(device)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         combine_bounds([mine.cpu().numpy()], shard)
         return

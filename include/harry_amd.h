@@ -169,7 +169,8 @@ int hry_merge(const uint8_t *const *parts, const size_t *sizes, size_t n, uint8_
 /* runs as 6 x u32 each: first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges (numbering of the whole
  * mesh).  For a shard: where its components go; for a mesh decoded from a sharded container: what was decoded. */
 size_t hry_mesh_runs(const hry_mesh *m, const uint32_t **runs);
-/* for a shard: index in the whole mesh of every vertex (which = 1) / face (which = 0) of the shard */
+/* for a shard: index in the whole mesh of every vertex (which = 1) / face (which = 0) of the shard; which = 2: the start face of
+ * each of its components (shard numbering) in coding order */
 size_t hry_shard_elements(const hry_mesh *m, int which, const uint32_t **idx);
 /* bounds of a list as records in the original component types (what hry_list_min / hry_list_max return) */
 int hry_list_set_bounds(hry_mesh *m, int l, const uint8_t *min_rec, const uint8_t *max_rec);

@@ -115,6 +115,13 @@ struct Mesh {
 	// one face region bound to list 0, one vertex region bound to list 1, identity element->attribute maps
 	std::vector<List> lists;
 	uint32_t nv = 0, nf = 0;
+	// a shard of a larger mesh (sharded container .hry v0.3 of this implementation, see "sharded container" below): sizes of
+	// the whole mesh for the header, the start face of every component in coding order, and the place of every run of
+	// consecutive components in the numbering of the whole decoded mesh
+	uint32_t g_nv = 0, g_nf = 0, g_ne = 0;
+	std::vector<uint32_t> seeds;
+	std::vector<std::array<uint32_t, 6>> runs;   // first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges
+	bool is_shard() const { return g_nf != 0; }
 
 	uint32_t add_face(int ne)   // conn.h:83-93
 	{
@@ -873,13 +880,14 @@ static void write_header(const Mesh &m, std::vector<uint8_t> &out, int ver_minor
 	ByteWriter w{ out };
 	const uint8_t magic[6] = { 0xfa, 0xff, 0xaf, 0xaf, 0, (uint8_t)ver_minor };   // big-endian magic, version 0.1 (common.h:15-16)
 	w.raw(magic, 6);
-	w.put<uint32_t>(m.nv); w.put<uint32_t>(m.nf); w.put<uint32_t>(m.num_edge());
+	const bool sh = m.is_shard();   // a shard announces the whole mesh
+	w.put<uint32_t>(sh ? m.g_nv : m.nv); w.put<uint32_t>(sh ? m.g_nf : m.nf); w.put<uint32_t>(sh ? m.g_ne : m.num_edge());
 	w.put<uint16_t>(1); w.put<uint16_t>(1);                 // one face region, one vertex region
 	w.put<uint16_t>(1); w.put<uint16_t>(0); w.put<uint16_t>(0);   // face region: 1 face list (id 0), 0 corner lists
 	w.put<uint16_t>(1); w.put<uint16_t>(1);                 // vertex region: 1 list (id 1)
 	for (size_t i = 0; i < m.lists.size(); ++i) {
 		const List &L = m.lists[i];
-		w.put<uint32_t>(L.count);
+		w.put<uint32_t>(sh ? (L.target == TG_FACE ? m.g_nf : m.g_nv) : L.count);
 		w.put<uint16_t>((uint16_t)L.fmt.size());
 		for (int j = 0; j < L.fmt.size(); ++j) { w.put<uint8_t>(L.fmt.type[j]); w.put<uint8_t>((uint8_t)L.fmt.quant[j]); }
 		w.put<uint16_t>((uint16_t)L.interps.size());
@@ -907,13 +915,14 @@ struct ByteReader {
 	void need(size_t n) { if ((size_t)(end - p) < n) throw std::runtime_error("oracle: truncated header"); }
 };
 static int dequant_bytes(const Fmt &f) { return f.bytes(); }
-static void read_header(ByteReader &r, Mesh &m, int want_minor = 1)
+static void read_header(ByteReader &r, Mesh &m, int want_minor = 1, uint32_t *declared_ne = nullptr)
 {
 	uint8_t magic[6];
 	r.raw(magic, 6);
 	if (magic[0] != 0xfa || magic[1] != 0xff || magic[2] != 0xaf || magic[3] != 0xaf) throw std::runtime_error("Invalid magic number");
 	if (magic[4] != 0 || magic[5] != want_minor) throw std::runtime_error("File format version incompatible to decoder format version 0.1");
-	m.nv = r.get<uint32_t>(); m.nf = r.get<uint32_t>(); (void)r.get<uint32_t>();
+	m.nv = r.get<uint32_t>(); m.nf = r.get<uint32_t>();
+	{ uint32_t ne = r.get<uint32_t>(); if (declared_ne) *declared_ne = ne; }
 	uint16_t nrf = r.get<uint16_t>(), nrv = r.get<uint16_t>();
 	std::vector<int> targets;
 	auto mark = [&](uint16_t b, int t) { if (b >= targets.size()) targets.resize(b + 1, TG_NONE); targets[b] = t; };
@@ -978,8 +987,12 @@ struct FacePool {
 	std::vector<uint32_t> iter_order;
 	std::vector<uint8_t> gone;
 	size_t cursor = 0, left;
-	explicit FacePool(uint32_t nf) : gone(nf, 0), left(nf)
+	bool seeded = false;
+	explicit FacePool(uint32_t nf, const std::vector<uint32_t> &seeds = std::vector<uint32_t>()) : gone(nf, 0), left(nf)
 	{
+		// a shard brings the start faces of its components along, in the coding order they have in the whole mesh (the rule
+		// below depends on the face count of the whole mesh, which a shard does not have)
+		if (!seeds.empty()) { iter_order = seeds; seeded = true; return; }
 		std::unordered_set<uint32_t> s;
 		for (uint32_t i = 0; i < nf; ++i) s.insert(i);
 		iter_order.assign(s.begin(), s.end());
@@ -988,7 +1001,7 @@ struct FacePool {
 	uint32_t choose()
 	{
 		uint32_t f;
-		if (!gone[0]) f = 0;
+		if (!seeded && !gone[0]) f = 0;
 		else {
 			while (gone[iter_order[cursor]]) ++cursor;
 			f = iter_order[cursor];
@@ -1001,7 +1014,7 @@ struct FacePool {
 static void cbm_encode(Mesh &m, SymWriter &wr, std::vector<uint32_t> &order_v, std::vector<uint32_t> &order_f)
 {
 	CutBorder cb(m.nv);
-	FacePool pool(m.num_face());
+	FacePool pool(m.num_face(), m.seeds);
 	std::vector<uint32_t> perm(m.nv, NOVTX);
 	std::vector<uint16_t> seen(m.nv, 0);
 	uint32_t next_id = 0;
@@ -1461,8 +1474,22 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 	chunk_syms = std::min(chunk_syms, 1u << 20);
 	Result *res = new Result();
 	try {
-		write_header(m, res->bytes, 2);
+		// sharded container (.hry v0.3): the header of the WHOLE mesh, u32 n_segments, n_segments x u64 bytes, then per segment
+		// u32 n_runs, the runs (6 x u32), and the v0.2 body of the shard in its own numbering.  A shard writes one segment
+		// (none when it holds no face); segments of different shards are concatenated without re-coding.
+		write_header(m, res->bytes, m.is_shard() ? 3 : 2);
 		res->header_size = res->bytes.size();
+		size_t seg_len_at = 0, seg_begin = 0;
+		if (m.is_shard()) {
+			ByteWriter w0{ res->bytes };
+			if (m.num_face() == 0) { w0.put<uint32_t>(0); return res; }
+			w0.put<uint32_t>(1);
+			seg_len_at = res->bytes.size();
+			w0.put<uint64_t>(0);
+			seg_begin = res->bytes.size();
+			w0.put<uint32_t>((uint32_t)m.runs.size());
+			for (const auto &r : m.runs) for (uint32_t x : r) w0.put<uint32_t>(x);
+		}
 		std::vector<uint8_t> dummy;
 		RangeEncoder rc(dummy);
 		Models md(m);
@@ -1561,16 +1588,16 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 		}
 		for (auto &st : streams) w.put<uint32_t>((uint32_t)st.size());
 		for (auto &st : streams) w.raw(st.data(), st.size());
+		if (m.is_shard()) { const uint64_t len = res->bytes.size() - seg_begin; memcpy(res->bytes.data() + seg_len_at, &len, 8); }
 	} catch (...) { delete res; throw; }
 	return res;
 }
 
-static Mesh *decode_chunked(const uint8_t *p, size_t n)
+// body of a v0.2 container (or of one segment of a v0.3 container) -> *m, whose header fields are set
+static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 {
-	Mesh *m = new Mesh();
-	try {
+	{
 		ByteReader br{ p, p + n };
-		read_header(br, *m, 2);
 		Models md(*m);
 		uint32_t chunk_syms = br.get<uint32_t>(), conn_chunk = br.get<uint32_t>(), np = br.get<uint32_t>();
 		std::vector<PlaneDef> planes = chunked_planes(*m, md);
@@ -1626,6 +1653,83 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 		m->have_deg = hdr_deg;
 		if (m->num_face() != m->nf) throw std::runtime_error("oracle: face count mismatch");
 		decode_attrs(*m, rd, order_v);
+	}
+}
+
+// v0.2: one body.  v0.3 (sharded): every segment is decoded as a mesh of its own -- vertex ids inside a segment are the
+// segment's -- and then placed into the numbering of the whole mesh run by run.
+static Mesh *decode_chunked(const uint8_t *p, size_t n)
+{
+	Mesh *m = new Mesh();
+	try {
+		if (n < 6) throw std::runtime_error("oracle: truncated header");
+		ByteReader br{ p, p + n };
+		if (p[5] != 3) {
+			read_header(br, *m, 2);
+			decode_chunked_body(m, br.p, (size_t)(p + n - br.p));
+			return m;
+		}
+		uint32_t gne = 0;
+		read_header(br, *m, 3, &gne);
+		const uint32_t gnv = m->nv, gnf = m->nf;
+		m->foff.assign((size_t)gnf + 1, 0); m->org.assign(gne, 0); m->twin.assign(gne, 0); m->eface.assign(gne, 0);
+		std::vector<char> face_seen(gnf, 0);
+		const uint32_t nseg = br.get<uint32_t>();
+		std::vector<uint64_t> len(nseg);
+		for (auto &x : len) x = br.get<uint64_t>();
+		const uint8_t *q = br.p;
+		for (uint32_t si = 0; si < nseg; ++si) {
+			if ((uint64_t)(p + n - q) < len[si]) throw std::runtime_error("oracle: truncated segment");
+			ByteReader sr{ q, q + len[si] };
+			const uint32_t nr = sr.get<uint32_t>();
+			std::vector<std::array<uint32_t, 6>> runs(nr);
+			Mesh lm;
+			uint32_t lne = 0;
+			for (auto &r : runs) {
+				for (auto &x : r) x = sr.get<uint32_t>();
+				if ((uint64_t)r[0] + r[3] > gnv || (uint64_t)r[1] + r[4] > gnf || (uint64_t)r[2] + r[5] > gne) throw std::runtime_error("oracle: run outside the mesh");
+				lm.nv += r[3]; lm.nf += r[4]; lne += r[5];
+			}
+			lm.have_deg = m->have_deg;
+			for (const List &L : m->lists) {
+				List D;
+				D.target = L.target; D.fmt = L.fmt; D.interps = L.interps; D.bmin = L.bmin; D.bmax = L.bmax;
+				D.count = L.target == TG_FACE ? lm.nf : lm.nv;
+				D.data.assign((size_t)D.count * D.fmt.bytes(), 0);
+				lm.lists.push_back(std::move(D));
+			}
+			decode_chunked_body(&lm, sr.p, (size_t)(sr.end - sr.p));
+			if (lm.num_edge() != lne) throw std::runtime_error("oracle: segment edge count mismatch");
+			std::vector<uint32_t> l2g(lm.nv);
+			uint32_t cv = 0, cf = 0, ch = 0;
+			for (const auto &r : runs) { for (uint32_t i = 0; i < r[3]; ++i) l2g[cv + i] = r[0] + i; cv += r[3]; }
+			cv = 0;
+			for (const auto &r : runs) {
+				for (uint32_t i = 0; i < r[4]; ++i) {
+					if (face_seen[r[1] + i]) throw std::runtime_error("oracle: overlapping runs");
+					face_seen[r[1] + i] = 1;
+					m->foff[(size_t)r[1] + i + 1] = lm.foff[(size_t)cf + i + 1] - ch + r[2];
+				}
+				m->foff[r[1]] = r[2];
+				for (uint32_t i = 0; i < r[5]; ++i) {
+					m->org[(size_t)r[2] + i] = l2g.at(lm.org[ch + i]);
+					const uint32_t tw = lm.twin[ch + i];
+					if (tw < ch || tw >= ch + r[5]) throw std::runtime_error("oracle: twin outside its run");
+					m->twin[(size_t)r[2] + i] = tw - ch + r[2];
+					m->eface[(size_t)r[2] + i] = lm.eface[ch + i] - cf + r[1];
+				}
+				for (const List &S : lm.lists) {
+					List &D = m->lists[&S - &lm.lists[0]];
+					const size_t st = (size_t)S.fmt.bytes();
+					if (!st) continue;
+					if (S.target == TG_FACE) memcpy(D.data.data() + (size_t)r[1] * st, S.data.data() + (size_t)cf * st, (size_t)r[4] * st);
+					else memcpy(D.data.data() + (size_t)r[0] * st, S.data.data() + (size_t)cv * st, (size_t)r[3] * st);
+				}
+				cv += r[3]; cf += r[4]; ch += r[5];
+			}
+			q += len[si];
+		}
+		m->conn_nv = gnv;
 	} catch (...) { delete m; throw; }
 	return m;
 }
@@ -2048,6 +2152,29 @@ ho_mesh *ho_mesh_from_hry(const uint8_t *hry, size_t n)
 	HO_CATCH(nullptr)
 }
 ho_mesh *ho_mesh_clone(const ho_mesh *m) { return new ho_mesh{ m->m }; }
+void ho_mesh_set_shard(ho_mesh *m, uint32_t g_nv, uint32_t g_nf, uint32_t g_ne, const uint32_t *seeds, size_t nseeds, const uint32_t *runs, size_t nruns)
+{
+	m->m.g_nv = g_nv; m->m.g_nf = g_nf; m->m.g_ne = g_ne;
+	m->m.seeds.assign(seeds, seeds + nseeds);
+	m->m.runs.resize(nruns);
+	for (size_t i = 0; i < nruns; ++i) for (int k = 0; k < 6; ++k) m->m.runs[i][k] = runs[6 * i + k];
+}
+void ho_mesh_set_bounds(ho_mesh *m, int l, const uint8_t *mn, const uint8_t *mx)
+{
+	ho::List &L = m->m.lists[l];
+	L.bmin.assign(mn, mn + L.fmt.bytes()); L.bmax.assign(mx, mx + L.fmt.bytes());
+}
+void ho_mesh_set_degrees(ho_mesh *m, const uint16_t *deg, size_t n)
+{
+	m->m.have_deg.assign(m->m.have_deg.size(), 0);
+	for (size_t i = 0; i < n; ++i) { if (deg[i] >= m->m.have_deg.size()) m->m.have_deg.resize(deg[i] + 1, 0); m->m.have_deg[deg[i]] = 1; }
+}
+size_t ho_mesh_degrees(const ho_mesh *m, uint16_t *out, size_t cap)
+{
+	size_t n = 0;
+	for (size_t d = 0; d < m->m.have_deg.size(); ++d) if (m->m.have_deg[d]) { if (n < cap) out[n] = (uint16_t)d; ++n; }
+	return n;
+}
 void ho_mesh_free(ho_mesh *m) { delete m; }
 
 int ho_requant(ho_mesh *m, const int *triples, int n, int clear)

@@ -42,6 +42,10 @@ def lib():
     L.ho_mesh_from_hry.restype = vp; L.ho_mesh_from_hry.argtypes = [C.c_char_p, sz]
     L.ho_mesh_clone.restype = vp; L.ho_mesh_clone.argtypes = [vp]
     L.ho_mesh_free.argtypes = [vp]
+    L.ho_mesh_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, vp, sz]
+    L.ho_mesh_set_bounds.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p]
+    L.ho_mesh_set_degrees.argtypes = [vp, vp, sz]
+    L.ho_mesh_degrees.restype = sz; L.ho_mesh_degrees.argtypes = [vp, vp, sz]
     L.ho_requant.restype = C.c_int; L.ho_requant.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int]
     L.ho_encode.restype = vp; L.ho_encode.argtypes = [vp, C.c_int]
     L.ho_result_free.argtypes = [vp]
@@ -130,6 +134,23 @@ class Mesh:
         if not r:
             raise _err()
         return Result(r)
+
+    def set_shard(self, g_nv, g_nf, g_ne, seeds, runs):
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        runs = np.ascontiguousarray(runs, np.uint32).reshape(-1, 6)
+        lib().ho_mesh_set_shard(self.h, g_nv, g_nf, g_ne, seeds.ctypes.data, len(seeds), runs.ctypes.data, len(runs))
+
+    def set_bounds(self, l, mn: bytes, mx: bytes):
+        lib().ho_mesh_set_bounds(self.h, l, bytes(mn), bytes(mx))
+
+    def degrees(self):
+        out = np.zeros(256, np.uint16)
+        n = lib().ho_mesh_degrees(self.h, out.ctypes.data, 256)
+        return out[:n].copy()
+
+    def set_degrees(self, deg):
+        deg = np.ascontiguousarray(deg, np.uint16)
+        lib().ho_mesh_set_degrees(self.h, deg.ctypes.data, len(deg))
 
     def clone(self) -> "Mesh":
         return Mesh(lib().ho_mesh_clone(self.h))

@@ -9,6 +9,7 @@ from harry_amd import codec as hc
 from harry_amd import meshgen as mg
 from harry_amd import sharding
 from oracle import oracle_py as op   # checker only
+from tests import util
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +29,12 @@ def _mesh(kind):
     if kind == "faceprops":
         return mg.with_face_props(mg.multi_component(6, 9, 11, seed=9, polys="tri"))
     raise ValueError(kind)
+
+
+def plan_extract_again(gen, n_shards, s):
+    """a fresh, unquantised copy of shard s (the encode mutated the one that was coded)"""
+    whole = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props)
+    return hc.ShardPlan(whole, n_shards).extract(whole, s)
 
 
 def _encode_sharded(cx, gen, n_shards, quant, chunk_syms=0):
@@ -55,6 +62,7 @@ def test_virtual_ranks_merge_decodes_like_the_reference(cx, kind, quant, n_shard
     merged = hc.merge(parts)
     # the pin: the oracle's reference-format encode + decode of the whole mesh
     o = op.Mesh.from_ply(gen.to_ply())
+    o0 = o.clone()                                           # unquantised: bounds and formats of the whole mesh
     if quant:
         o.requant(quant)
     ref = op.Mesh.from_hry(o.encode().data)
@@ -63,6 +71,17 @@ def test_virtual_ranks_merge_decodes_like_the_reference(cx, kind, quant, n_shard
     if quant:
         cx.requant(one, quant)
     single = cx.write_hry(one, profile=hc.PROFILE_CHUNKED, chunk_syms=1024)
+    # every rank's segment is byte-identical to the oracle's restatement of the shard container, and the oracle decodes the
+    # merged container (independent CPU decoder) to the reference's arrays
+    for sh, part in zip(shards, parts):
+        if sh.nf == 0:
+            continue
+        os_ = util.oracle_shard(plan_extract_again(gen, n_shards, shards.index(sh)), o0)
+        if quant:
+            os_.requant(quant)
+        assert part == os_.encode_chunked(1024).data
+    odec = op.Mesh.from_hry_chunked(merged)
+    assert np.array_equal(odec.org(), ref.org()) and np.array_equal(odec.list_data(1), ref.list_data(1)) and np.array_equal(odec.list_data(0), ref.list_data(0))
     dec = cx.read_hry(merged)
     assert dec.nv == ref.nv and dec.nf == ref.nf
     assert np.array_equal(dec.face_offsets(), ref.face_offsets())

@@ -86,3 +86,19 @@ def canonical_faces(vrec: np.ndarray, degs: np.ndarray, idx: np.ndarray):
         out.append(tuple(vs[k:] + vs[:k]))
     out.sort()
     return out
+
+
+def oracle_shard(shard, whole_oracle):
+    """The CPU oracle's copy of a product shard (harry_amd.codec.Mesh from ShardPlan.extract): same elements in the same
+    order (through PLY), the whole mesh's bounds and polygon degrees, the shard's seeds and runs."""
+    from oracle import oracle_py as op
+    if shard.nf == 0:
+        o = whole_oracle.clone()   # formats only; no face is coded
+        raise ValueError("empty shard: nothing to restate")
+    o = op.Mesh.from_ply(shard.to_ply())
+    for l in (0, 1):
+        if whole_oracle.list_fmt(l):
+            o.set_bounds(l, bytes(whole_oracle.list_min(l)), bytes(whole_oracle.list_max(l)))
+    o.set_degrees(whole_oracle.degrees())
+    o.set_shard(whole_oracle.nv, whole_oracle.nf, whole_oracle.ne, shard.shard_elements(2), shard.runs())
+    return o
