@@ -88,6 +88,7 @@ def load():
     L.hry_encode.restype = C.c_int; L.hry_encode.argtypes = [vp, vp, C.POINTER(Opts), C.POINTER(vp), C.POINTER(sz)]
     L.hry_decode.restype = C.c_int; L.hry_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(Opts), C.POINTER(vp)]
     L.hry_free.argtypes = [vp]
+    L.hry_container_info.restype = C.c_int; L.hry_container_info.argtypes = [C.c_char_p, sz, C.POINTER(C.c_uint32)]
     L.hry_stage_get.restype = C.c_int; L.hry_stage_get.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
     L.hry_walk_run.restype = C.c_int; L.hry_walk_run.argtypes = [vp, C.POINTER(vp)]
     L.hry_walk_run_plain.restype = C.c_int; L.hry_walk_run_plain.argtypes = [vp, C.POINTER(vp)]

@@ -203,6 +203,14 @@ class ShardPlan:
         return Mesh(h)
 
 
+def container_info(data: bytes) -> dict:
+    """what a .hry file is, without decoding it (hry_container_info)"""
+    info = (C.c_uint32 * 8)()
+    nat.check(nat.load().hry_container_info(data, len(data), info))
+    keys = ("minor", "header_bytes", "nv", "nf", "ne", "chunk_syms", "conn_chunk_syms", "segments")
+    return dict(zip(keys, (int(x) for x in info)))
+
+
 def merge(parts) -> bytes:
     """several sharded containers (.hry v0.3) of the same mesh -> one (hry_merge)"""
     parts = [bytes(p) for p in parts]

@@ -153,6 +153,32 @@ int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts,
 	});
 }
 void hry_free(void *p) { free(p); }
+int hry_container_info(const uint8_t *hry, size_t n, uint32_t info[8])
+{
+	if (!hry || !info) { g_last_error = "null argument"; return HRY_E_ARG; }
+	return guarded([&] {
+		Mesh m;
+		int minor = 0;
+		const size_t hdr = read_hry_header(hry, n, m, minor, false);
+		for (int i = 0; i < 8; ++i) info[i] = 0;
+		info[0] = (uint32_t)minor; info[1] = (uint32_t)hdr; info[2] = m.nv; info[3] = m.nf; info[4] = m.declared_ne; info[7] = 1;
+		size_t body = hdr;
+		if (minor == 3) {
+			if (n < hdr + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
+			memcpy(&info[7], hry + hdr, 4);
+			if (info[7] == 0) return;
+			body = hdr + 4 + 8ull * info[7];
+			if (n < body + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
+			uint32_t nr;
+			memcpy(&nr, hry + body, 4);
+			body += 4 + 24ull * nr;
+		}
+		if (minor >= 2) {
+			if (n < body + 8) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+			memcpy(&info[5], hry + body, 4); memcpy(&info[6], hry + body + 4, 4);
+		}
+	});
+}
 
 int hry_shard_plan(const hry_mesh *m, int n_shards, hry_plan **out)
 {

@@ -140,6 +140,10 @@ int hry_mesh_upload(hry_ctx *ctx, hry_mesh *m);
 int hry_encode(hry_ctx *ctx, hry_mesh *m, const hry_opts *opts, uint8_t **out, size_t *out_len);
 int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out);
 void hry_free(void *p);
+/* host-only: what a .hry file is, without decoding it.  info[0] minor version (1 reference stream, 2 chunked, 3 sharded chunked),
+ * [1] header bytes, [2] vertices, [3] faces, [4] half-edges, [5] symbols per chunk and plane (first segment; 0 for v0.1),
+ * [6] the same for the connectivity planes, [7] segments (v0.3; else 1) */
+int hry_container_info(const uint8_t *hry, size_t n, uint32_t info[8]);
 
 /* ---- one mesh over several GPUs ---------------------------------------------------- */
 /* The reference has no multi-device path; what a split must honour is its numbering: vertices, faces and half-edges of the

@@ -1,0 +1,167 @@
+"""Every configuration BASELINE.json names, at its full size, against the oracle (SURVEY.md section 8d for the synthetic
+stand-ins: no mesh files exist offline).  configs[1] lives in test_gpu_chunked.py::test_headline_workload_full_size.
+
+  configs[0]  bunny-class ~80 k triangles, lossless round trip (the reference's own CPU-runnable case)
+  configs[2]  Lucy-class 28 M triangles, positions 14 bits + normals 10 bits, one GPU
+  configs[3]  non-manifold polygon mesh, lossless, sharded by connected component: one GPU's share of the 100 M-triangle
+              mesh (128 components, 12.6 M triangles) on one GPU, and the same mesh through the real sharded path as 8
+              virtual ranks (one after the other on this GPU) -> one merged container
+  configs[4]  decode-only of the merged container: whole, and segment by segment as 8 processes would
+The pin is always the oracle's REFERENCE-FORMAT encode + decode of the same input (the oracle is byte-pinned to the
+reference binary on the committed fixtures); the chunked containers are additionally compared byte for byte with the
+oracle's restatement of the container."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from harry_amd import codec as hc
+from harry_amd import meshgen as mg
+from harry_amd import sharding
+from oracle import oracle_py as op   # checker only
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(util.ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def cx():
+    c = hc.Codec(0)
+    yield c
+    c.close()
+
+
+def same_mesh(a, b, twins=True):
+    assert (a.nv, a.nf, a.ne) == (b.nv, b.nf, b.ne)
+    assert np.array_equal(a.face_offsets(), b.face_offsets())
+    assert np.array_equal(a.org(), b.org())
+    if twins:
+        assert np.array_equal(a.twin(), b.twin())
+    for l in range(2):
+        assert a.list_fmt(l) == b.list_fmt(l)
+        assert np.array_equal(a.list_data(l), b.list_data(l)), f"list {l} differs"
+
+
+def _need_memory(gib):
+    try:
+        import psutil
+        free = psutil.virtual_memory().available / 2**30
+    except Exception:
+        return
+    if free < gib:
+        pytest.skip(f"needs about {gib} GiB of host memory for the CPU oracle at this size, {free:.0f} GiB available")
+
+
+def test_cfg0_bunny_class_lossless_roundtrip(cx):
+    """configs[0]: icosphere level 6 with radial noise + confidence / intensity (81 920 triangles), lossless.
+    compat bytes == oracle (== reference); decode == the oracle's decode; chunked container == the oracle's."""
+    mesh = mg.cfg1_bunny_class()
+    ply = mesh.to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    ref_bytes = o.clone().encode().data
+    assert cx.write_hry(a.clone(), profile=hc.PROFILE_COMPAT) == ref_bytes
+    ref_dec = op.Mesh.from_hry(ref_bytes)
+    same_mesh(cx.read_hry(ref_bytes), ref_dec, twins=False)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
+    assert got == o.clone().encode_chunked(0).data
+    same_mesh(cx.read_hry(got), ref_dec, twins=False)
+    # lossless: the decoded records are the input records (as a multiset: the codec renumbers vertices)
+    key = lambda rec: np.sort(np.ascontiguousarray(rec).view([("", rec.dtype)] * rec.shape[1]).reshape(-1), axis=0)
+    assert np.array_equal(key(a.list_data(1)), key(ref_dec.list_data(1)))
+
+
+def test_requant_of_a_quantised_list_matches_reference_golden(cx):
+    """q -> q' on the device (structs/quant.h:121-129,169-171): the reference re-quantised its own 14-bit file to 10 bits
+    (tests/golden/grid50.q14_to_q10.hry); decode -> hry_requant -> compat encode must give those bytes."""
+    src = open(os.path.join(GOLD, "grid50.q14.hry"), "rb").read()
+    want = open(os.path.join(GOLD, "grid50.q14_to_q10.hry"), "rb").read()
+    m = cx.read_hry(src)
+    cx.requant(m, [(1, -1, 10)])
+    assert [q for _t, q, _o in m.list_fmt(1)] == [10, 10, 10]
+    assert cx.write_hry(m, profile=hc.PROFILE_COMPAT) == want
+
+
+def test_cfg2_lucy_class_28m_full_size(cx):
+    """configs[2] at full size: torus 3742 x 3742 = 28 005 128 triangles with analytic normals; positions 14 bits, normals 10
+    (`-l1 -a0 -q14 -a1 -q14 -a2 -q14 -a3 -q10 -a4 -q10 -a5 -q10`: SURVEY 8d flag caveat).  The chunked container equals
+    the oracle's, and its GPU decode equals the oracle's reference-format decode array for array."""
+    _need_memory(40)
+    t0 = time.time()
+    mesh = mg.cfg3_lucy_class()
+    quant = [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)]
+    a = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    cx.requant(a, quant)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
+    dec = cx.read_hry(got)
+    print(f"[cfg2] GPU side done {time.time() - t0:.0f} s", flush=True)
+    o = op.Mesh.from_ply(mesh.to_ply())
+    del mesh
+    o.requant(quant)
+    assert np.array_equal(o.list_data(1), a.list_data(1)), "quantised integers differ from the CPU reference path"
+    print(f"[cfg2] oracle mesh + quantisation {time.time() - t0:.0f} s", flush=True)
+    info = hc.container_info(got)       # larger meshes get larger default chunks: tell the oracle which
+    assert info["minor"] == 2 and info["nf"] == a.nf
+    want = o.clone().encode_chunked(info["chunk_syms"]).data
+    print(f"[cfg2] oracle chunked container ({info['chunk_syms']} symbols per chunk) {time.time() - t0:.0f} s", flush=True)
+    assert len(got) == len(want) and got == want
+    del want
+    ref_dec = op.Mesh.from_hry(o.encode().data)
+    print(f"[cfg2] oracle reference-format encode + decode {time.time() - t0:.0f} s", flush=True)
+    same_mesh(dec, ref_dec)
+
+
+@pytest.fixture(scope="module")
+def cfg4_share():
+    """one GPU's share of configs[3]: 128 components of 221 x 222 mixed polygons, 0.1 % extra faces on existing edges, 0.05 %
+    cones on existing vertices (both become tiny components tied to a large one through shared vertices)"""
+    mesh = mg.multi_component(128, 221, 222, seed=4, polys="mixed")
+    mesh = mg.with_nonmanifold(mesh, n_edges=max(1, mesh.ntri // 1000), n_vtx=max(1, mesh.ntri // 2000))
+    o = op.Mesh.from_ply(mesh.to_ply())
+    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
+    return mesh, o, ref_dec
+
+
+def test_cfg3_share_one_gpu_lossless(cx, cfg4_share):
+    """12.6 M triangles, lossless float: container == the oracle's, decode == the oracle's reference-format decode"""
+    _need_memory(24)
+    mesh, o, ref_dec = cfg4_share
+    a = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+    assert got == o.clone().encode_chunked(hc.container_info(got)["chunk_syms"]).data
+    same_mesh(cx.read_hry(got), ref_dec)
+
+
+def test_cfg3_cfg4_sharded_as_8_virtual_ranks(cx, cfg4_share):
+    """The same mesh through the sharded path: plan -> 8 shards -> per-shard bounds + combination -> 8 segments -> ONE
+    container; decode-only (configs[4]) of that container whole and segment by segment == reference-format decode."""
+    _need_memory(24)
+    mesh, o, ref_dec = cfg4_share
+    whole = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    n = 8
+    plan = hc.ShardPlan(whole, n)
+    loads = [plan.triangles(r) for r in range(n)]
+    assert sum(loads) == whole.ntri and max(loads) <= 1.05 * min(loads), loads
+    shards = [plan.extract(whole, r) for r in range(n)]
+    tabs = [sharding.shard_bounds(cx, sh) for sh in shards]
+    parts = []
+    for sh in shards:
+        sharding.combine_bounds(tabs, sh)
+        assert bytes(sh.list_min(1)) == bytes(o.list_min(1)) and bytes(sh.list_max(1)) == bytes(o.list_max(1))
+        parts.append(cx.write_hry(sh, profile=hc.PROFILE_CHUNKED))
+    merged = hc.merge(parts)
+    same_mesh(cx.read_hry(merged), ref_dec)
+    covered = 0
+    ref_v, ref_org = ref_dec.list_data(1), ref_dec.org()
+    for r in range(n):
+        part = cx.read_hry(merged, shard=(r, n))
+        pv, porg = part.list_data(1), part.org()
+        mask_v, mask_h = np.zeros(len(pv), bool), np.zeros(len(porg), bool)
+        for fv, ff, fh, nv, nf, nh in part.runs():
+            mask_v[fv:fv + nv] = True
+            mask_h[fh:fh + nh] = True
+            covered += int(nf)
+        assert np.array_equal(pv[mask_v], ref_v[mask_v]) and np.array_equal(porg[mask_h], ref_org[mask_h])
+    assert covered == ref_dec.nf

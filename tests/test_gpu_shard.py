@@ -100,18 +100,19 @@ def test_virtual_ranks_merge_decodes_like_the_reference(cx, kind, quant, n_shard
         want = shards[r].runs()
         assert sorted(map(tuple, runs)) == sorted(map(tuple, want))
         fo, fo_ref = part.face_offsets(), ref.face_offsets()
+        pv, porg, ptw, rv, rorg, rtw = part.list_data(1), part.org(), part.twin(), ref.list_data(1), ref.org(), ref.twin()
         for fv, ff, fh, nv, nf, nh in runs:
-            assert np.array_equal(part.list_data(1)[fv:fv + nv], ref.list_data(1)[fv:fv + nv])
-            assert np.array_equal(part.org()[fh:fh + nh], ref.org()[fh:fh + nh])
-            assert np.array_equal(part.twin()[fh:fh + nh], ref.twin()[fh:fh + nh])
+            assert np.array_equal(pv[fv:fv + nv], rv[fv:fv + nv])
+            assert np.array_equal(porg[fh:fh + nh], rorg[fh:fh + nh])
+            assert np.array_equal(ptw[fh:fh + nh], rtw[fh:fh + nh])
             assert np.array_equal(fo[ff:ff + nf + 1], fo_ref[ff:ff + nf + 1])
             assert not seen_f[ff:ff + nf].any()
             seen_f[ff:ff + nf] = True
         # a rank's own one-segment container decodes the same way
         if len(want):
-            own = cx.read_hry(parts[r])
+            own = cx.read_hry(parts[r]).list_data(1)
             for fv, ff, fh, nv, nf, nh in want:
-                assert np.array_equal(own.list_data(1)[fv:fv + nv], ref.list_data(1)[fv:fv + nv])
+                assert np.array_equal(own[fv:fv + nv], rv[fv:fv + nv])
     assert seen_f.all()
 
 
