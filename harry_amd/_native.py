@@ -42,6 +42,7 @@ class Timing(C.Structure):
 OK, E_ARG, E_FORMAT, E_UNSUPPORTED, E_NODEVICE, E_NOMEM, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PROFILE_COMPAT, PROFILE_CHUNKED = 0, 1
 FLAG_HOST_RECURRENCE = 1
+FLAG_DEVICE_RECURRENCE = 2
 
 _lib = None
 

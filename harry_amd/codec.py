@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nat
-from ._native import FLAG_HOST_RECURRENCE, HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
+from ._native import FLAG_DEVICE_RECURRENCE, FLAG_HOST_RECURRENCE, HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
 
 TYPE_NP = {0: "<f4", 1: "<f8", 2: "<u8", 3: "<i8", 4: "<u4", 5: "<i4", 6: "<u2", 7: "<i2", 8: "u1", 9: "i1"}
 TYPE_SIZE = {0: 4, 1: 8, 2: 8, 3: 8, 4: 4, 5: 4, 6: 2, 7: 2, 8: 1, 9: 1}

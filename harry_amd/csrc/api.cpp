@@ -130,7 +130,7 @@ int hry_encode(hry_ctx *ctx, hry_mesh *m, const hry_opts *opts, uint8_t **out, s
 	return guarded([&] {
 		hry_opts o = opts ? *opts : hry_opts{};
 		ctx->cx.keep_stages = o.keep_stages != 0;
-		ctx->cx.host_recurrence = (o.flags & HRY_FLAG_HOST_RECURRENCE) != 0;
+		ctx->cx.device_recurrence = (o.flags & HRY_FLAG_DEVICE_RECURRENCE) != 0;
 		ctx->cx.stages.clear();
 		std::vector<uint8_t> v;
 		if (o.profile == HRY_PROFILE_COMPAT) encode_compat(ctx->cx, m->m, v);

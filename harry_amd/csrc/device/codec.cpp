@@ -299,29 +299,41 @@ static void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payloa
 	uint64_t st[2] = { 1ull << 63, 0 };   // R = HALF, no shifts yet (coder.h:47)
 	HIP_OK(hipMemcpyAsync(cx.d_state.p, st, 16, hipMemcpyHostToDevice, cx.stream));
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
-	if (cx.host_recurrence && ns) {
-		// opt-in: the serial recurrence on a host core (SURVEY.md App. C-3 allows "host or one-lane"); same arithmetic as k_rchain
-		std::vector<SymRec> rec(ns);
-		std::vector<uint64_t> rr(ns);
-		std::vector<uint32_t> ss(ns);
-		HIP_OK(hipMemcpyAsync(rec.data(), cx.d_rec_sym.p, (size_t)ns * sizeof(SymRec), hipMemcpyDeviceToHost, cx.stream));
-		HIP_OK(hipStreamSynchronize(cx.stream));
+	if (!cx.device_recurrence && ns) {
+		// The serial recurrence on a host core ("host or one-lane"; same arithmetic as k_rchain, 8 times
+		// faster than a lone wavefront's scalar unit).  It runs BEHIND the device: the records come down slice by slice into
+		// pinned memory while the core works on the slices before, and (r, S) of a finished slice go back up at once.
+		const uint32_t SL = 1u << 18;
+		const uint32_t nsl = (ns + SL - 1) / SL;
+		cx.h_rec.ensure((size_t)ns * sizeof(SymRec)); cx.h_r.ensure((size_t)ns * 8); cx.h_s.ensure((size_t)ns * 4);
+		while (cx.slice_ev.size() < nsl) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); cx.slice_ev.push_back(e); }
+		SymRec *rec = cx.h_rec.as<SymRec>();
+		uint64_t *rr = cx.h_r.as<uint64_t>();
+		uint32_t *ss = cx.h_s.as<uint32_t>();
+		for (uint32_t i = 0; i < nsl; ++i) {
+			const uint32_t b0 = i * SL, n0 = std::min(SL, ns - b0);
+			HIP_OK(hipMemcpyAsync(rec + b0, cx.d_rec_sym.as<SymRec>() + b0, (size_t)n0 * sizeof(SymRec), hipMemcpyDeviceToHost, cx.stream));
+			HIP_OK(hipEventRecord(cx.slice_ev[i], cx.stream));
+		}
 		uint64_t R = st[0], S = st[1];
-		for (uint32_t k = 0; k < ns; ++k) {
-			const SymRec &q = rec[k];
-			uint64_t r = cm::div_by_magic(R, q.magic, q.meta & 63u);
-			uint64_t prod = r * q.x;
-			uint64_t Rn = (q.meta & kMetaSub) ? R - prod : prod;
-			uint64_t y = Rn - 1;
-			uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
-			rr[k] = r; ss[k] = (uint32_t)S;
-			R = Rn << sh;
-			S += sh;
+		for (uint32_t i = 0; i < nsl; ++i) {
+			const uint32_t b0 = i * SL, e0 = b0 + std::min(SL, ns - b0);
+			HIP_OK(hipEventSynchronize(cx.slice_ev[i]));
+			for (uint32_t k = b0; k < e0; ++k) {
+				const SymRec &q = rec[k];
+				uint64_t r = cm::div_by_magic(R, q.magic, q.meta & 63u);
+				uint64_t prod = r * q.x;
+				uint64_t Rn = (q.meta & kMetaSub) ? R - prod : prod;
+				uint64_t y = Rn - 1;
+				uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
+				rr[k] = r; ss[k] = (uint32_t)S;
+				R = Rn << sh;
+				S += sh;
+			}
+			HIP_OK(hipMemcpyAsync(cx.d_r.as<uint64_t>() + b0, rr + b0, (size_t)(e0 - b0) * 8, hipMemcpyHostToDevice, cx.stream));
+			HIP_OK(hipMemcpyAsync(cx.d_s.as<uint32_t>() + b0, ss + b0, (size_t)(e0 - b0) * 4, hipMemcpyHostToDevice, cx.stream));
 		}
 		st[0] = R; st[1] = S;
-		HIP_OK(hipMemcpyAsync(cx.d_r.p, rr.data(), (size_t)ns * 8, hipMemcpyHostToDevice, cx.stream));
-		HIP_OK(hipMemcpyAsync(cx.d_s.p, ss.data(), (size_t)ns * 4, hipMemcpyHostToDevice, cx.stream));
-		HIP_OK(hipStreamSynchronize(cx.stream));
 		HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
 	} else {
 		if (ns) launch_rchain(cx.stream, cx.d_rec_sym.as<SymRec>(), ns, cx.d_r.as<uint64_t>(), cx.d_s.as<uint32_t>(), cx.d_state.as<uint64_t>());

@@ -35,6 +35,25 @@ struct DevBuf {
 	template <typename T> T *as() const { return (T*)p; }
 };
 
+// pinned host memory, grow-only (persistent across calls: fresh pinned or pageable blocks cost a page fault per 4 KiB)
+struct PinBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	PinBuf() = default;
+	PinBuf(const PinBuf&) = delete;
+	PinBuf &operator=(const PinBuf&) = delete;
+	~PinBuf() { if (p) (void)hipHostFree(p); }
+	void ensure(size_t n)
+	{
+		if (n <= cap) return;
+		if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+		size_t want = n + n / 8 + 4096;
+		HIP_OK(hipHostMalloc(&p, want, hipHostMallocDefault));
+		cap = want;
+	}
+	template <typename T> T *as() const { return (T*)p; }
+};
+
 struct Context {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -66,7 +85,9 @@ struct Context {
 	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms;
 
 	bool keep_stages = false;
-	bool host_recurrence = false;   // HRY_FLAG_HOST_RECURRENCE
+	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
+	PinBuf h_rec, h_r, h_s;         // compat: symbol records down, (r, S) up, slice by slice (codec.cpp finish_stream)
+	std::vector<hipEvent_t> slice_ev;
 	std::map<std::string, std::vector<uint8_t>> stages;
 
 	explicit Context(int dev);

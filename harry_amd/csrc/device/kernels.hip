@@ -302,22 +302,63 @@ __global__ __launch_bounds__(256) void k_rank(const uint32_t *order_v, uint32_t 
 // vertex (attrcode.h:209-225 vtx, :321-344 vtx_post; io.h:90-94; models.h:168-173).  Output: SoA byte planes,
 // plane p holds byte p of every vertex' residual record in coding order (coalesced for the model kernels).
 // ---------------------------------------------------------------------------------------------------------
+// The fan is walked ONCE per vertex: the (at most kEncCand) candidate triples that pass the rank filter are kept as vertex
+// ids in LDS and every component is evaluated from them -- the mean, and for floats the nearest-to-the-mean selection, which
+// the reference evaluates in a second sweep over the same candidates (attrcode.h:182-208).  A fan with more candidates
+// (high-valence vertices) takes predict_component, which walks again per component.
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2: virtual block (b % 8) * per + b / 8 gives every
+// XCD one contiguous range of the coding order, so the connectivity / rank / record lines its wavefronts gather are shared
+// inside one L2 instead of being fetched by all eight.
+constexpr int kEncCand = 8;
 __global__ __launch_bounds__(256) void k_predict_vtx(ConnView cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank,
-                                                     const uint8_t *rec, ListDesc ld, uint8_t *planes, uint32_t chunk_vtx)
+                                                     const uint8_t *rec, ListDesc ld, uint8_t *planes, uint32_t blocks_per_xcd)
 {
-	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t vb = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
+	const uint32_t k = vb * blockDim.x + threadIdx.x;
+	__shared__ uint32_t s_cand[kEncCand * 3][256];
 	if (k >= n) return;
 	Topo tp{ cv };
-	uint32_t e = order_v[k];
-	uint32_t v = cv.org[e];
-	uint32_t lo = 0;
-	(void)chunk_vtx;
+	const uint32_t e = order_v[k];
+	const uint32_t v = cv.org[e];
+	int nc = 0;
+	fan_candidates(tp, rank, e, k, 0, [&](uint32_t v0, uint32_t v1, uint32_t vo) {
+		if (nc < kEncCand) { s_cand[3 * nc][threadIdx.x] = v0; s_cand[3 * nc + 1][threadIdx.x] = v1; s_cand[3 * nc + 2][threadIdx.x] = vo; }
+		++nc;
+	});
 	for (int c = 0; c < ld.ncomp; ++c) {
 		with_stype(ld.stype[c], [&](auto tag) {
 			typedef decltype(tag) T;
-			T pred = predict_component<T>(tp, rank, rec, ld.stride, ld.off[c], ld.quant[c], e, k, lo, nullptr);
-			T raw = ldg<T>(rec + (size_t)v * ld.stride + ld.off[c]);
-			auto code = cm::residual_bits<T>(raw, pred, ld.quant[c]);
+			typedef typename cm::wide<T>::type W;
+			const int off = ld.off[c], q = ld.quant[c];
+			auto value = [&](uint32_t x) { return ldg<T>(rec + (size_t)x * ld.stride + off); };
+			T pred;
+			if (nc > kEncCand) pred = predict_component<T>(tp, rank, rec, ld.stride, off, q, e, k, 0, nullptr);
+			else if (nc == 0) pred = T(0);
+			else {
+				T p[kEncCand];
+				W acc = 0;
+#pragma unroll
+				for (int i = 0; i < kEncCand; ++i)
+					if (i < nc) {
+						p[i] = cm::parallelogram<T>(value(s_cand[3 * i][threadIdx.x]), value(s_cand[3 * i + 1][threadIdx.x]), value(s_cand[3 * i + 2][threadIdx.x]), q);
+						acc = acc + (W)p[i];   // fan order (the float mean is a double sum in candidate order)
+					}
+				const T avg = (T)cm::mean_of(acc, (W)nc);
+				if constexpr (!cm::is_fp<T>::value) pred = avg;
+				else {
+					T best = 3.402823466e+38f;   // numeric_limits<float>::max()
+#pragma unroll
+					for (int i = 0; i < kEncCand; ++i)
+						if (i < nc) {
+							T db = avg > best ? avg - best : best - avg;
+							T dp = avg > p[i] ? avg - p[i] : p[i] - avg;
+							best = db < dp ? best : p[i];
+						}
+					pred = best;
+				}
+			}
+			T raw = value(v);
+			auto code = cm::residual_bits<T>(raw, pred, q);
 			for (int b = 0; b < (int)sizeof(T); ++b) planes[(size_t)(ld.plane[c] + b) * n + k] = (uint8_t)(code >> (8 * b));
 		});
 	}
@@ -696,7 +737,9 @@ void launch_rank(hipStream_t st, const uint32_t *order_v, uint32_t n, const uint
 void launch_predict_vtx(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank, const uint8_t *rec,
                         const ListDesc &ld, uint8_t *planes)
 {
-	if (n) hipLaunchKernelGGL(k_predict_vtx, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, order_v, n, rank, rec, ld, planes, 0u);
+	if (!n) return;
+	const unsigned per = (blocks_for(n, 256) + 7) / 8;   // blocks per XCD; the grid is padded to 8 * per, surplus blocks find k >= n
+	hipLaunchKernelGGL(k_predict_vtx, dim3(per * 8), dim3(256), 0, st, cv, order_v, n, rank, rec, ld, planes, per);
 }
 void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes)
 {

@@ -1370,9 +1370,10 @@ bool unpredict2_applicable(const ListDesc &ld)
 	return ld.ncomp > 0;
 }
 // candidate lists with plain vertex ids (k_unpredict2 resolves ring slots itself)
-__global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t v0, uint32_t n, uint32_t *cand, uint8_t *ncand)
+// (virtual block (b % 8) * per + b / 8: one contiguous range of vertices per XCD and L2, see k_predict_vtx)
+__global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t v0, uint32_t n, uint32_t *cand, uint8_t *ncand, uint32_t blocks_per_xcd)
 {
-	uint32_t v = v0 + blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = v0 + ((blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
 	if (v >= n) return;
 	TopoD tp{ cv };
 	uint32_t k = 0;
@@ -1388,7 +1389,9 @@ __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint3
 }
 void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand)
 {
-	if (nvtx) hipLaunchKernelGGL(k_candidates_ids, dim3((nvtx + 255) / 256), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand);
+	if (!nvtx) return;
+	const uint32_t per = ((nvtx + 255) / 256 + 7) / 8;
+	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand, per);
 }
 // wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8, default 4
 static uint32_t chain_waves()
@@ -1415,7 +1418,8 @@ void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *or
 {
 	if (v_end <= v_begin) return;
 	const uint32_t n = v_end - v_begin;
-	hipLaunchKernelGGL(k_candidates_ids, dim3((n + 255) / 256), dim3(256), 0, st, cv, order_v, v_begin, v_end, cand, ncand);
+	const uint32_t per = ((n + 255) / 256 + 7) / 8;
+	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, v_begin, v_end, cand, ncand, per);
 	hipLaunchKernelGGL(k_chain_records_range, dim3((n + 255) / 256), dim3(256), 0, st, (const uint32_t*)cand, (const uint8_t*)ncand, v_begin, v_end, chain_ring_floor(v_begin), (ChainRec*)crec);
 }
 void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,

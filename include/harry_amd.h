@@ -67,10 +67,12 @@ typedef struct hry_opts {
     int32_t shard_count;  /*   i % shard_count == shard_index (one process per GPU); 0 or 1 = every segment */
 } hry_opts;
 
-/* COMPAT only: run the one strictly serial recurrence of the reference stream (the range register R of arith/coder.h:69-91,
- * SURVEY.md App. C-3) on a host core instead of a single GPU wavefront.  Every parallel stage stays on the device; the
- * bytes are identical either way.  Off by default. */
+/* COMPAT only: the one strictly serial recurrence of the reference stream (the range register R of arith/coder.h:69-91,
+ * SURVEY.md App. C-3) runs on a host core behind the device kernels (records stream down slice by slice); every parallel stage
+ * stays on the device.  HRY_FLAG_DEVICE_RECURRENCE runs it on a single GPU wavefront instead (k_rchain: 8 times slower, same
+ * bytes).  HRY_FLAG_HOST_RECURRENCE is accepted for older callers and changes nothing. */
 #define HRY_FLAG_HOST_RECURRENCE 1
+#define HRY_FLAG_DEVICE_RECURRENCE 2
 
 /* timings of the last hry_encode / hry_decode on this context, milliseconds */
 typedef struct hry_timing {

@@ -148,7 +148,7 @@ def test_headline_workload_full_size(cx):
     o.requant(quant)
     q_in = a.list_data(1).reshape(a.nv, -1).view(np.uint16)[:, ::2].astype(np.uint64)   # quantised values, low half of each slot
     compat_ref = o.clone().encode().data
-    assert cx.write_hry(a.clone(), profile=hc.PROFILE_COMPAT, flags=hc.FLAG_HOST_RECURRENCE) == compat_ref
+    assert cx.write_hry(a.clone(), profile=hc.PROFILE_COMPAT) == compat_ref
     ref_dec = op.Mesh.from_hry(compat_ref)
     got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
     assert got == o.clone().encode_chunked(0).data

@@ -221,8 +221,9 @@ def test_empty_face_list_and_tiny_meshes(cx):
         assert cx.write_hry(a) == o.encode().data
 
 
-def test_host_recurrence_option_gives_identical_bytes(cx):
-    """HRY_FLAG_HOST_RECURRENCE moves only the serial range-register recurrence to a host core; bytes are unchanged."""
+def test_recurrence_on_host_core_or_on_one_wavefront_gives_identical_bytes(cx):
+    """The serial range-register recurrence runs on a host core by default (streamed behind the device kernels) and on a single
+    wavefront (k_rchain) with HRY_FLAG_DEVICE_RECURRENCE; bytes are those of the reference either way."""
     for mesh, quant in ((mg.torus(60, 64, polys="mixed", normals=True), []), (mg.torus(90, 90), [(1, -1, 14)])):
         ply = mesh.to_ply()
         a, b, o = hc.Mesh.from_ply(ply), hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
@@ -230,7 +231,7 @@ def test_host_recurrence_option_gives_identical_bytes(cx):
             cx.requant(a, quant); cx.requant(b, quant); o.requant(quant)
         want = o.encode().data
         assert cx.write_hry(a) == want
-        assert cx.write_hry(b, flags=hc.FLAG_HOST_RECURRENCE) == want
+        assert cx.write_hry(b, flags=hc.FLAG_DEVICE_RECURRENCE) == want
 
 
 # ---------------------------------------------------------------- reading files written by the reference binary
