@@ -10,7 +10,16 @@ using namespace hry;
 struct hry_ctx { Context cx; explicit hry_ctx(int d) : cx(d) {} };
 struct hry_mesh { Mesh m; };
 struct hry_plan { ShardPlan p; };
-struct hry_walk { WalkResult w; uint32_t info[2]; std::vector<uint8_t> vplanes, fplanes; std::vector<uint32_t> seg_start, seg_level; };
+struct hry_walk {
+	WalkResult w; uint32_t info[2]; std::vector<uint8_t> vplanes, fplanes; std::vector<uint32_t> seg_start, seg_level;
+	mutable std::vector<uint8_t> op_sym, op_class;   // unpacked from w.op_sc on first request
+	void unpack_ops() const
+	{
+		if (op_sym.size() == w.op_sc.size()) return;
+		op_sym.resize(w.op_sc.size()); op_class.resize(w.op_sc.size());
+		for (size_t i = 0; i < w.op_sc.size(); ++i) { op_sym[i] = w.op_sc[i] & 7; op_class[i] = w.op_sc[i] >> 3; }
+	}
+};
 
 static thread_local std::string g_last_error;
 
@@ -286,8 +295,8 @@ size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 	auto ret = [&](const auto &v) { *ptr = v.data(); return v.size(); };
 	if (n == "order_v") return ret(r.order_v);
 	if (n == "order_f") return ret(r.order_f);
-	if (n == "op_sym") return ret(r.op_sym);
-	if (n == "op_class") return ret(r.op_class);
+	if (n == "op_sym") { w->unpack_ops(); return ret(w->op_sym); }
+	if (n == "op_class") { w->unpack_ops(); return ret(w->op_class); }
 	if (n == "op_l") return ret(r.op_l);
 	if (n == "op_h") return ret(r.op_h);
 	if (n == "op_t") return ret(r.op_t);
@@ -344,7 +353,7 @@ int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_p
 				pl.resize(r.grp_val[g].size());
 				for (size_t i = 0; i < pl.size(); ++i) pl[i] = (uint8_t)(r.grp_val[g][i] >> (8 * b));
 			}
-		for (size_t i = 0; i < r.op_sym.size(); ++i) planes[13 + r.op_class[i]].push_back(r.op_sym[i]);
+		for (size_t i = 0; i < r.op_sc.size(); ++i) planes[13 + (r.op_sc[i] >> 3)].push_back(r.op_sc[i] & 7);
 		std::unique_ptr<hry_mesh> m(new hry_mesh());
 		std::unique_ptr<hry_walk> w(new hry_walk());
 		m->m.nv = src->m.nv; m->m.nf = src->m.nf; m->m.declared_ne = src->m.ne(); m->m.have_degree = src->m.have_degree;

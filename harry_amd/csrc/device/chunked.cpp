@@ -107,24 +107,17 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 
 	// ---- connectivity planes on the host side: 5 groups (split into bytes on the device) + 8 operation planes
 	auto t_h2d = Clock::now();
-	BigVec<uint8_t> op_planes[8];
-	{
-		// one plane per order class: sizes first, then one pass through bare pointers (a million push_backs cost 2 ms)
-		size_t cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		const size_t nop = w.op_sym.size();
-		const uint8_t *cls = w.op_class.data(), *sym = w.op_sym.data();
-		for (size_t i = 0; i < nop; ++i) ++cnt[cls[i] & 7];
-		uint8_t *dst[8];
-		for (int k = 0; k < 8; ++k) { op_planes[k].resize(cnt[k]); dst[k] = op_planes[k].data(); }
-		for (size_t i = 0; i < nop; ++i) *dst[cls[i] & 7]++ = sym[i];
-	}
-	size_t ngrp = 0, conn_plane_bytes = 0, nopb = w.op_sym.size();
+	// operations arrive as one byte each (symbol | order class << 3); the device sorts them into one plane per class
+	// (k_split_classes: a stable partition), the walk has counted the classes
+	size_t op_plane_n[8];
+	for (int k = 0; k < 8; ++k) op_plane_n[k] = w.n_op_class[k];
+	size_t ngrp = 0, conn_plane_bytes = 0, nopb = w.op_sc.size();
 	for (int g = 0; g < G_COUNT; ++g) { ngrp += w.grp_val[g].size(); conn_plane_bytes += w.grp_val[g].size() * kGroupBytes[g]; }
 	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
 	cx.d_order_f.ensure(std::max<size_t>((size_t)fc * 4, 16));
 	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
 	cx.d_grp_val.ensure(std::max<size_t>(ngrp * 4, 16));
-	cx.d_connplanes.ensure(std::max<size_t>(conn_plane_bytes + nopb, 16));
+	cx.d_connplanes.ensure(std::max<size_t>(conn_plane_bytes + 2 * nopb + 64, 16));   // ... + operation planes + the raw operation bytes
 	cx.d_vplanes.ensure(std::max<size_t>((size_t)vc * ldv.nplanes, 16));
 	cx.d_fplanes.ensure(std::max<size_t>((size_t)fc * ldf.nplanes, 16));
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
@@ -138,13 +131,8 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 		if (n) HIP_OK(hipMemcpyAsync(cx.d_grp_val.as<uint32_t>() + goff[g], w.grp_val[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
 	}
 	uint8_t *d_opplanes = cx.d_connplanes.as<uint8_t>() + conn_plane_bytes;
-	{
-		size_t o = 0;
-		for (int k = 0; k < 8; ++k) {
-			if (!op_planes[k].empty()) HIP_OK(hipMemcpyAsync(d_opplanes + o, op_planes[k].data(), op_planes[k].size(), hipMemcpyHostToDevice, cx.stream));
-			o += op_planes[k].size();
-		}
-	}
+	uint8_t *d_opraw = d_opplanes + nopb;
+	if (nopb) HIP_OK(hipMemcpyAsync(d_opraw, w.op_sc.data(), nopb, hipMemcpyHostToDevice, cx.stream));
 
 	// ---- plane list in container order
 	std::vector<PlaneRef> planes;
@@ -157,7 +145,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 			poff += (size_t)n * kGroupBytes[g];
 		}
 		size_t o = 0;
-		for (int k = 0; k < 8; ++k, ++ci) { planes.push_back(PlaneRef{ d_opplanes + o, (uint32_t)op_planes[k].size(), INIT_OP }); o += op_planes[k].size(); }
+		for (int k = 0; k < 8; ++k, ++ci) { planes.push_back(PlaneRef{ d_opplanes + o, (uint32_t)op_plane_n[k], INIT_OP }); o += op_plane_n[k]; }
 		for (int p = 0; p < ldv.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_vplanes.as<uint8_t>() + (size_t)p * vc, vc, INIT_ONES });
 		for (int p = 0; p < ldf.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_fplanes.as<uint8_t>() + (size_t)p * fc, fc, INIT_ONES });
 	}
@@ -192,6 +180,12 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 			launch_split_bytes(cx.stream, cx.d_grp_val.as<uint32_t>() + goff[g], n, kGroupBytes[g], cx.d_connplanes.as<uint8_t>() + poff);
 			poff += (size_t)n * kGroupBytes[g];
 		}
+	}
+	{
+		uint32_t base[8], o = 0;
+		for (int k = 0; k < 8; ++k) { base[k] = o; o += (uint32_t)op_plane_n[k]; }
+		cx.d_op.ensure(((nopb + kSplitUnit - 1) / kSplitUnit + 1) * 8 * 4 + 64);
+		launch_split_classes(cx.stream, d_opraw, (uint32_t)nopb, base, cx.d_op.as<uint32_t>(), d_opplanes);
 	}
 	launch_plane_hist(cx.stream, d_slices, (uint32_t)slices.size(), d_hist);
 	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));

@@ -295,6 +295,74 @@ __global__ __launch_bounds__(256) void k_plane_hist(const HistSlice *slices, uin
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// operation planes: the walk emits one byte per cut-border operation (symbol | order class << 3, models.h:101-105); the
+// container codes one plane per class.  Stable partition in three small launches: a wavefront counts the classes of its unit
+// of kSplitUnit operations, one wavefront scans the units per class, then every wavefront places its unit: rank inside a
+// 64-operation step = population count of the ballot below the lane.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_split_count(const uint8_t *ops, uint32_t n, uint32_t *cnt)
+{
+	const uint32_t u = blockIdx.x, lane = threadIdx.x;
+	uint32_t c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	for (uint32_t i = u * kSplitUnit + lane; i < min(n, (u + 1) * kSplitUnit); i += 64) {
+		const uint32_t k = ops[i] >> 3;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) c[j] += k == (uint32_t)j;
+	}
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		uint32_t v = c[j];
+		for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+		if (lane == 0) cnt[u * 8 + j] = v;
+	}
+}
+__global__ __launch_bounds__(64) void k_split_scan(uint32_t *cnt, uint32_t nunits, SplitBase base)
+{
+	// one wavefront per class: exclusive scan of the class's counts over the units, 64 units per step
+	const uint32_t j = blockIdx.x, lane = threadIdx.x;
+	uint32_t run = base.b[j];
+	for (uint32_t u0 = 0; u0 < nunits; u0 += 64) {
+		const uint32_t u = u0 + lane;
+		const uint32_t c = u < nunits ? cnt[u * 8 + j] : 0u;
+		uint32_t inc = c;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+		if (u < nunits) cnt[u * 8 + j] = run + inc - c;
+		run += __shfl(inc, 63);
+	}
+}
+__global__ __launch_bounds__(64) void k_split_place(const uint8_t *ops, uint32_t n, const uint32_t *cnt, uint8_t *planes)
+{
+	const uint32_t u = blockIdx.x, lane = threadIdx.x;
+	uint32_t at[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) at[j] = cnt[u * 8 + j];
+	const uint32_t end = min(n, (u + 1) * kSplitUnit);
+	for (uint32_t i0 = u * kSplitUnit; i0 < end; i0 += 64) {
+		const uint32_t i = i0 + lane;
+		const bool live = i < end;
+		const uint32_t b = live ? ops[i] : 0xffu, k = b >> 3;
+		uint32_t dst = 0;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const uint64_t mk = __ballot(live && k == (uint32_t)j);
+			if (live && k == (uint32_t)j) dst = at[j] + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+			at[j] += (uint32_t)__popcll(mk);
+		}
+		if (live) planes[dst] = (uint8_t)(b & 7u);
+	}
+}
+void launch_split_classes(hipStream_t st, const uint8_t *ops, uint32_t n, const uint32_t base[8], uint32_t *scratch, uint8_t *planes)
+{
+	if (!n) return;
+	const uint32_t nunits = (n + kSplitUnit - 1) / kSplitUnit;
+	SplitBase sb;
+	for (int j = 0; j < 8; ++j) sb.b[j] = base[j];
+	hipLaunchKernelGGL(k_split_count, dim3(nunits), dim3(64), 0, st, ops, n, scratch);
+	hipLaunchKernelGGL(k_split_scan, dim3(8), dim3(64), 0, st, scratch, nunits, sb);
+	hipLaunchKernelGGL(k_split_place, dim3(nunits), dim3(64), 0, st, ops, n, scratch, planes);
+}
+
 void launch_plane_hist(hipStream_t st, const HistSlice *slices, uint32_t nslices, uint32_t *hist)
 {
 	if (nslices) hipLaunchKernelGGL(k_plane_hist, dim3(nslices), dim3(256), 0, st, slices, hist);

@@ -430,7 +430,7 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	// connectivity groups: values + positions, packed back to back
 	size_t ngrp = 0;
 	for (int g = 0; g < G_COUNT; ++g) ngrp += w.grp_val[g].size();
-	const size_t nop = w.op_sym.size();
+	const size_t nop = w.op_sc.size();
 	cx.d_grp_val.ensure(std::max<size_t>(ngrp * 4, 16));
 	cx.d_grp_pos.ensure(std::max<size_t>(ngrp * 4, 16));
 	cx.d_op.ensure(std::max<size_t>(nop * 16, 16));

@@ -60,6 +60,8 @@ struct StreamJob {
 // a slice of a plane for the histogram pass (static priors)
 struct HistSlice { const uint8_t *sym; uint32_t n, plane; };
 
+struct SplitBase { uint32_t b[8]; };
+
 // the components of a list for the bounds reduction
 struct BoundsPlan { int32_t n, stride; uint16_t off[kMaxComp]; uint8_t type[kMaxComp]; };
 

@@ -34,6 +34,10 @@ void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v,
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits);
 void launch_stream_pack(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *stream_bits, const uint8_t *bytes,
                         uint32_t *nbytes, uint64_t *offsets, uint8_t *out, bool pack);
+// stable partition of the operation bytes (symbol | class << 3) into one plane of symbols per class; base[c] = first byte of
+// plane c in `planes`, scratch: 8 counters per unit of kSplitUnit operations
+constexpr uint32_t kSplitUnit = 1024;
+void launch_split_classes(hipStream_t st, const uint8_t *ops, uint32_t n, const uint32_t base[8], uint32_t *scratch, uint8_t *planes);
 void launch_plane_hist(hipStream_t st, const HistSlice *slices, uint32_t nslices, uint32_t *hist);
 void launch_scatter_u8(hipStream_t st, const uint8_t *src, const uint32_t *dst_index, uint32_t n, uint8_t *dst);
 void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,

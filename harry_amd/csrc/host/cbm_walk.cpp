@@ -268,14 +268,35 @@ struct Emitter {
 	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // operations per order class so far
 	uint32_t min_ref = NONE32;                        // smallest vertex index named explicitly since the last mark
 	uint32_t halfedges = 0;                           // half-edges of the faces coded so far
+	// The per-triangle outputs go through bare cursors into arrays sized for the worst case up front (a push_back per symbol
+	// re-reads and re-writes the vector's end pointer through memory: the byte stores of the loop may alias anything):
+	// operations (symbol | class << 3, one byte), coded vertices, coded faces.  detach() trims the arrays to what was written.
+	uint8_t *op_cur = nullptr, *op_begin = nullptr;
+	uint32_t *ov_cur = nullptr, *ov_begin = nullptr, *of_cur = nullptr, *of_begin = nullptr;
 	explicit Emitter(WalkResult &r) : w(r) { for (int i = 0; i < 8; ++i) c_new[i] = c_fwd[i] = 1; }
+	// cap_*: upper bounds of what the walk can still emit on top of what the arrays hold
+	void attach(size_t cap_ops, size_t cap_v, size_t cap_f)
+	{
+		const size_t no = w.op_sc.size(), nv = w.order_v.size(), nf = w.order_f.size();
+		w.op_sc.resize(no + cap_ops); w.order_v.resize(nv + cap_v); w.order_f.resize(nf + cap_f);
+		op_begin = w.op_sc.data(); op_cur = op_begin + no;
+		ov_begin = w.order_v.data(); ov_cur = ov_begin + nv;
+		of_begin = w.order_f.data(); of_cur = of_begin + nf;
+	}
+	void detach()
+	{
+		if (!op_begin) return;
+		w.op_sc.resize((size_t)(op_cur - op_begin)); w.order_v.resize((size_t)(ov_cur - ov_begin)); w.order_f.resize((size_t)(of_cur - of_begin));
+		op_begin = op_cur = nullptr;
+	}
+	uint32_t faces_coded() const { return (uint32_t)(of_cur - of_begin); }
 	void mark_component(uint32_t next_id)
 	{
 		if (!w.marks.empty()) w.marks.back().min_ref = min_ref;
 		ComponentMark k;
 		for (int g = 0; g < G_COUNT; ++g) k.n_grp[g] = (uint32_t)w.grp_val[g].size();
 		for (int i = 0; i < 8; ++i) k.n_op[i] = n_op[i];
-		k.first_vertex = next_id; k.first_face = (uint32_t)w.order_f.size(); k.first_halfedge = halfedges;
+		k.first_vertex = next_id; k.first_face = faces_coded(); k.first_halfedge = halfedges;
 		k.min_ref = NONE32;
 		w.marks.push_back(k);
 		min_ref = NONE32;
@@ -298,17 +319,13 @@ struct Emitter {
 		if (k > 7) k = 7;
 		if (k < 0) k = 0;
 		++n_op[k];
-		if (!eval_model) {
-			w.op_sym.push_back((uint8_t)s); w.op_class.push_back((uint8_t)k);
-			++n;
-			return;
-		}
+		*op_cur++ = (uint8_t)(s | ((uint32_t)k << 3));
+		if (!eval_model) { ++n; return; }
 		uint64_t nv = c_new[k] * c_all / (c_new[k] + c_fwd[k]);
 		uint64_t f[7] = { plain[0], plain[1], plain[2], plain[3], plain[4], nv, c_all - nv };
 		uint64_t l = 0;
 		for (uint32_t x = 0; x < s; ++x) l += f[x];
 		uint64_t t = plain[0] + plain[1] + plain[2] + plain[3] + plain[4] + c_all;
-		w.op_sym.push_back((uint8_t)s); w.op_class.push_back((uint8_t)k);
 		w.op_l.push_back((uint32_t)l); w.op_h.push_back((uint32_t)(l + f[s])); w.op_t.push_back((uint32_t)t);
 		w.op_pos.push_back(n++);
 		if (s == O_NEWVTX) { ++c_all; ++c_new[k]; }
@@ -347,7 +364,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 		return e + 1 == foff[fe + 1] ? foff[fe] : e + 1;
 	};
 	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; w.twins_changed = true; };
-	auto record_vertex = [&](uint32_t e) { w.order_v.push_back(e); sent[org[e]] = next_id++; };
+	auto record_vertex = [&](uint32_t e) { *em.ov_cur++ = e; sent[org[e]] = next_id++; };
 	auto take = [&](uint32_t face) { gone[face] = 1; ++consumed; em.halfedges += foff[face + 1] - foff[face]; };
 
 	em.mark_component(next_id);
@@ -366,7 +383,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 	case 1: em.iop(I_TRI001); em.vert(sent[c], seen[c]); em.numtri(ntri); record_vertex(e0); record_vertex(e1); break;
 	default: em.iop(I_INIT); em.numtri(ntri); record_vertex(e0); record_vertex(e1); record_vertex(e2); break;
 	}
-	w.order_f.push_back(e0);
+	*em.of_cur++ = e0;
 	++seen[a]; ++seen[b]; ++seen[c];
 	cb.start(a, e0, b, e1, c, e2);
 
@@ -438,7 +455,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 			}
 		}
 		++seen[v0]; ++seen[v1]; ++seen[v2];
-		if (seq_first) w.order_f.push_back(e0);
+		if (seq_first) *em.of_cur++ = e0;
 		++curtri;
 	}
 }
@@ -458,6 +475,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	}
 	Emitter em(w);
 	em.eval_model = eval_op_model;
+	em.attach((size_t)m.ne() + m.ntri() + 16, m.nv, m.nf);   // every half-edge ends at most one border operation, every triangle one other
 	uint32_t next_id = 0, consumed = 0;
 	do {
 		uint32_t f = pool.next();
@@ -466,13 +484,16 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 		// it is one sequence.  Without it (chunked profile: symbol + order class only) the remaining components are walked on
 		// several threads once the first one shows that the mesh has more than one.
 		if (n_threads > 1 && !eval_op_model && m.nf - consumed >= parallel_min_faces()) {
+			em.detach();
 			walk_rest_parallel<DEG>(m, st, eface_tab, em, next_id, n_threads);
 			break;
 		}
 	} while (consumed != m.nf);
+	em.detach();
 	em.finish_marks();
 	em.iop(I_EOM);
 	w.n_conn = em.n;
+	for (int i = 0; i < 8; ++i) w.n_op_class[i] = em.n_op[i];
 }
 
 // ---- several host threads --------------------------------------------------------
@@ -716,11 +737,12 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 				WalkResult &fw = frag[k];
 				fw.numtri_coded = w.numtri_coded;
 				const uint32_t nfc = A.n_faces[k];
-				fw.order_f.reserve(nfc); fw.order_v.reserve(A.fresh[k]);
 				Emitter em(fw);
 				em.eval_model = false;
+				em.attach((size_t)2 * A.n_halfedges[k] - 2 * (size_t)nfc + 16, A.fresh[k], nfc);
 				uint32_t next_id = id_base[k], consumed = 0;
 				walk_component<DEG>(m, st, eface_tab, A.seed[k], cb, em, next_id, consumed);
+				em.detach();
 				if (next_id != id_base[k + 1] || consumed != nfc) throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
 				em.finish_marks();
 				frag_syms[k] = em.n;
@@ -733,18 +755,18 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	// concatenation in coding order
 	std::vector<uint64_t> off_sym(ncomp + 1), off_v(ncomp + 1), off_f(ncomp + 1), off_op(ncomp + 1), off_g[G_COUNT];
 	for (int g = 0; g < G_COUNT; ++g) off_g[g].resize(ncomp + 1);
-	off_sym[0] = em0.n; off_v[0] = w.order_v.size(); off_f[0] = w.order_f.size(); off_op[0] = w.op_sym.size();
+	off_sym[0] = em0.n; off_v[0] = w.order_v.size(); off_f[0] = w.order_f.size(); off_op[0] = w.op_sc.size();
 	for (int g = 0; g < G_COUNT; ++g) off_g[g][0] = w.grp_val[g].size();
 	for (uint32_t k = 0; k < ncomp; ++k) {
 		off_sym[k + 1] = off_sym[k] + frag_syms[k];
 		off_v[k + 1] = off_v[k] + frag[k].order_v.size();
 		off_f[k + 1] = off_f[k] + frag[k].order_f.size();
-		off_op[k + 1] = off_op[k] + frag[k].op_sym.size();
+		off_op[k + 1] = off_op[k] + frag[k].op_sc.size();
 		for (int g = 0; g < G_COUNT; ++g) off_g[g][k + 1] = off_g[g][k] + frag[k].grp_val[g].size();
 	}
 	if (off_sym[ncomp] + 1 >= (1ull << 32)) throw Error(HRY_E_UNSUPPORTED, "more than 2^32 connectivity symbols");
 	w.order_v.resize(off_v[ncomp]); w.order_f.resize(off_f[ncomp]);
-	w.op_sym.resize(off_op[ncomp]); w.op_class.resize(off_op[ncomp]);
+	w.op_sc.resize(off_op[ncomp]);
 	for (int g = 0; g < G_COUNT; ++g) { w.grp_val[g].resize(off_g[g][ncomp]); w.grp_pos[g].resize(off_g[g][ncomp]); }
 	std::atomic<uint32_t> next_frag{ 0 };
 	std::atomic<bool> changed_any{ false };
@@ -755,8 +777,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 			WalkResult &fw = frag[k];
 			std::copy(fw.order_v.begin(), fw.order_v.end(), w.order_v.begin() + (long)off_v[k]);
 			std::copy(fw.order_f.begin(), fw.order_f.end(), w.order_f.begin() + (long)off_f[k]);
-			std::copy(fw.op_sym.begin(), fw.op_sym.end(), w.op_sym.begin() + (long)off_op[k]);
-			std::copy(fw.op_class.begin(), fw.op_class.end(), w.op_class.begin() + (long)off_op[k]);
+			std::copy(fw.op_sc.begin(), fw.op_sc.end(), w.op_sc.begin() + (long)off_op[k]);
 			for (int g = 0; g < G_COUNT; ++g) {
 				std::copy(fw.grp_val[g].begin(), fw.grp_val[g].end(), w.grp_val[g].begin() + (long)off_g[g][k]);
 				uint32_t *dst = w.grp_pos[g].data() + off_g[g][k];
@@ -809,9 +830,6 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 	int ndeg = 0;
 	for (uint8_t d : m.have_degree) ndeg += d ? 1 : 0;
 	w.numtri_coded = ndeg > 1;   // one degree => conn_numtri holds a single symbol of count == total: l = 0, h = t, coder state unchanged
-	w.order_v.reserve(nv);
-	w.order_f.reserve(nf);
-	w.op_sym.reserve(m.ntri() + 16); w.op_class.reserve(m.ntri() + 16);
 	if (eval_op_model) { w.op_l.reserve(m.ntri() + 16); w.op_h.reserve(m.ntri() + 16); w.op_t.reserve(m.ntri() + 16); w.op_pos.reserve(m.ntri() + 16); }
 	walk_sequential<DEG>(m, w, eface_tab.data(), eval_op_model, eval_op_model ? 1u : host_threads());
 }

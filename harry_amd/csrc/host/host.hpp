@@ -65,9 +65,10 @@ struct WalkResult {
 	// connectivity symbols: values (low byte first, one entry per symbol) + position in the global symbol sequence
 	BigVec<uint32_t> grp_val[G_COUNT];
 	BigVec<uint32_t> grp_pos[G_COUNT];
-	// cut-border operations: raw symbol + order class, and the order-conditioned model already evaluated
-	// (models.h:91-119) as cumulative-frequency triples
-	BigVec<uint8_t> op_sym, op_class;
+	// cut-border operations: raw symbol | order class << 3 (one byte each), and -- for the reference stream -- the
+	// order-conditioned model already evaluated (models.h:91-119) as cumulative-frequency triples
+	BigVec<uint8_t> op_sc;
+	uint32_t n_op_class[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // operations per order class (sizes of the chunked container's operation planes)
 	BigVec<uint32_t> op_l, op_h, op_t, op_pos;
 	std::vector<ComponentMark> marks; // one per connected component, in coding order
 	std::vector<NamedVertex> named;   // every explicit naming of a vertex, in coding order
