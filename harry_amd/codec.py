@@ -152,9 +152,10 @@ class Mesh:
         n = nat.load().hry_shard_elements(self.h, which, C.byref(p))
         return np.frombuffer(C.string_at(p, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
 
-    def to_ply(self, ascii: bool = False) -> bytes:
+    def to_ply(self, ascii: bool = False, packed: bool = False) -> bytes:
+        """packed: quantised components in the width of the storage type the header declares (see HRY_PLY_PACKED)"""
         p, n = C.c_void_p(), C.c_size_t()
-        nat.check(nat.load().hry_mesh_to_ply(self.h, int(ascii), C.byref(p), C.byref(n)))
+        nat.check(nat.load().hry_mesh_to_ply(self.h, int(ascii) | (2 if packed else 0), C.byref(p), C.byref(n)))
         return nat.take_bytes(p, n.value)
 
     def host_walk(self, plain: bool = False) -> dict:

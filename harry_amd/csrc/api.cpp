@@ -86,7 +86,7 @@ int hry_mesh_to_ply(const hry_mesh *m, int ascii, uint8_t **out, size_t *out_len
 	if (!m || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
 	return guarded([&] {
 		std::vector<uint8_t> v;
-		mesh_to_ply(m->m, ascii != 0, v);
+		mesh_to_ply(m->m, (ascii & HRY_PLY_ASCII) != 0, v, (ascii & HRY_PLY_PACKED) != 0);
 		*out = dup_bytes(v);
 		*out_len = v.size();
 	});

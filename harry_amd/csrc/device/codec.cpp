@@ -157,13 +157,15 @@ void device_bounds(Context &cx, Mesh &m)
 	uint8_t *outs = (uint8_t*)(pidx + 2 * (size_t)nparts * dev::kMaxComp);
 	for (int l = 0; l < 2; ++l) {
 		AttrList &L = m.lists[l];
-		for (int c = 0; c < L.ncomp(); ++c) if (L.quant[c]) throw Error(HRY_E_UNSUPPORTED, "bounds of an already quantised list come from its header");
+		bool quantised = false;
+		for (int c = 0; c < L.ncomp(); ++c) quantised |= L.quant[c] != 0;
+		if (quantised && L.have_bounds) continue;   // they came with the quantisation (file header or an earlier hry_requant)
+		if (quantised) throw Error(HRY_E_UNSUPPORTED, "bounds of an already quantised list come from its header");
 		L.bmin.assign(L.stride(), 0); L.bmax.assign(L.stride(), 0);
 		L.bmin_at.assign(L.ncomp(), 0); L.bmax_at.assign(L.ncomp(), 0);
 		BoundsPlan plan{};
 		plan.n = L.ncomp(); plan.stride = L.stride();
 		for (int c = 0; c < L.ncomp(); ++c) {
-			if (L.type[c] == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "double components are outside the supported subset");
 			plan.off[c] = (uint16_t)L.offset[c]; plan.type[c] = (uint8_t)L.type[c];
 		}
 		std::vector<uint8_t> res((size_t)L.ncomp() * 24);
@@ -268,17 +270,15 @@ void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool cl
 		for (int c = 0; c < L.ncomp(); ++c) {
 			int sq = L.quant[c], dq = nquant[l][c];
 			if (sq == dq) continue;
-			if (dq == 0) throw Error(HRY_E_UNSUPPORTED, "dequantisation (-c on a quantised list) is not on the device path yet");
-			if (dq > 30) throw Error(HRY_E_UNSUPPORTED, "more than 30 quantisation bits: the reference evaluates 1 << bits in int (quant.h:135)");
-			if (sq == 0 && kTypeSize[L.type[c]] == 8) throw Error(HRY_E_UNSUPPORTED, "quantisation of 8-byte components is not on the device path yet");
+			if (dq > 30 || sq > 30) throw Error(HRY_E_UNSUPPORTED, "more than 30 quantisation bits: the reference evaluates 1 << bits in int (quant.h:135)");
 			RequantComp &rc = plan.c[plan.n++];
 			rc.off = L.offset[c];
 			rc.src_type = sq ? storage_type(L.type[c], sq) : L.type[c];
-			rc.src_bits = sq; rc.dst_bits = dq;
+			rc.src_bits = sq; rc.dst_bits = dq; rc.dst_type = L.type[c]; rc.pad = 0;
 			rc.mn = 0; rc.scale = 0;
 			memcpy(&rc.mn, L.bmin.data() + L.offset[c], kTypeSize[L.type[c]]);
 			memcpy(&rc.scale, scale.data() + L.offset[c], kTypeSize[L.type[c]]);
-			if (sq == 0 && L.type[c] != C_FLOAT && rc.scale == 0) throw Error(HRY_E_UNSUPPORTED, "constant integer component: the reference divides by a zero extent (quant.h:106)");
+			if (L.type[c] != C_FLOAT && L.type[c] != C_DOUBLE && rc.scale == 0) throw Error(HRY_E_UNSUPPORTED, "constant integer component: the reference divides by a zero extent (quant.h:106)");
 		}
 		launch_requant(cx.stream, cx.d_rec[l].as<uint8_t>(), L.count, L.stride(), plan);
 		if (!L.data.empty()) HIP_OK(hipMemcpyAsync(L.data.data(), cx.d_rec[l].p, L.data.size(), hipMemcpyDeviceToHost, cx.stream));

@@ -66,7 +66,7 @@ struct SplitBase { uint32_t b[8]; };
 struct BoundsPlan { int32_t n, stride; uint16_t off[kMaxComp]; uint8_t type[kMaxComp]; };
 
 // one component of an in-place requantisation: mn / scale carry the raw bits of the component's original type
-struct RequantComp { int32_t off, src_type, src_bits, dst_bits; uint64_t mn, scale; };
+struct RequantComp { int32_t off, src_type, src_bits, dst_bits, dst_type, pad; uint64_t mn, scale; };   // dst_bits 0: dequantise into dst_type
 struct RequantPlan { int32_t n; int32_t pad; RequantComp c[kMaxComp]; };
 
 }   // namespace dev

@@ -146,6 +146,7 @@ __device__ __forceinline__ T predict_component(const Topo &tp, const uint32_t *r
 // ---------------------------------------------------------------------------------------------------------
 template <typename T> struct Lim;
 template <> struct Lim<float> { static __device__ float hi() { return 3.402823466e+38f; } static __device__ float lo() { return 1.175494351e-38f; } };
+template <> struct Lim<double> { static __device__ double hi() { return 1.7976931348623157e+308; } static __device__ double lo() { return 2.2250738585072014e-308; } };
 template <> struct Lim<uint64_t> { static __device__ uint64_t hi() { return ~0ull; } static __device__ uint64_t lo() { return 0; } };
 template <> struct Lim<int64_t> { static __device__ int64_t hi() { return 0x7fffffffffffffffll; } static __device__ int64_t lo() { return -0x7fffffffffffffffll - 1; } };
 template <> struct Lim<uint32_t> { static __device__ uint32_t hi() { return ~0u; } static __device__ uint32_t lo() { return 0; } };
@@ -216,11 +217,16 @@ __device__ void bounds_component(const uint8_t *rec, uint32_t count, int stride,
 		part_idx[2 * p + 1] = mx.i;
 	}
 }
+// every component type, doubles included (they can be quantised, quant.h:137-139; only their lossless residuals are undefined)
+template <typename F> __device__ __forceinline__ void with_any_type(int t, F &&f)
+{
+	if (t == 1) f(double()); else with_stype(t, f);
+}
 __global__ __launch_bounds__(256) void k_bounds_partial(const uint8_t *rec, uint32_t count, BoundsPlan plan,
                                                         uint8_t *part_min, uint8_t *part_max, uint32_t *part_idx)
 {
 	const int c = blockIdx.y;
-	with_stype(plan.type[c], [&](auto tag) { bounds_component<decltype(tag)>(rec, count, plan.stride, plan.off[c], part_min, part_max, part_idx); });
+	with_any_type(plan.type[c], [&](auto tag) { bounds_component<decltype(tag)>(rec, count, plan.stride, plan.off[c], part_min, part_max, part_idx); });
 }
 // one wavefront per component folds its partials: lanes stride over them, then a shuffle reduction.
 // out: per component { u64 min bits, u64 max bits, u32 first index of the min + 1, u32 of the max + 1 } (24 bytes)
@@ -242,7 +248,7 @@ __device__ void bounds_final(const uint8_t *part_min, const uint8_t *part_max, c
 }
 __global__ __launch_bounds__(64) void k_bounds_final(const uint8_t *part_min, const uint8_t *part_max, const uint32_t *part_idx, int nparts, BoundsPlan plan, uint8_t *out)
 {
-	with_stype(plan.type[blockIdx.x], [&](auto tag) { bounds_final<decltype(tag)>(part_min, part_max, part_idx, nparts, out); });
+	with_any_type(plan.type[blockIdx.x], [&](auto tag) { bounds_final<decltype(tag)>(part_min, part_max, part_idx, nparts, out); });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -252,6 +258,8 @@ __global__ __launch_bounds__(64) void k_bounds_final(const uint8_t *part_min, co
 // ---------------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T rescale_int(T val, T from, T to) { return val / from * to + val % from * to / from; }   // quant.h:103-107
 
+template <typename T> __device__ __forceinline__ T rescale_fp(T val, T from, T to) { return val / from * to; }   // quant.h:98-102 (every operation rounded on its own)
+
 __global__ __launch_bounds__(256) void k_requant(uint8_t *rec, uint32_t count, int stride, RequantPlan plan)
 {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -260,18 +268,21 @@ __global__ __launch_bounds__(256) void k_requant(uint8_t *rec, uint32_t count, i
 			const RequantComp &c = plan.c[k];
 			uint8_t *slot = r + c.off;
 			uint64_t q = 0;
-			const int lv = (1 << (uint32_t)c.dst_bits) - 1;
-			if (c.src_bits) {   // already quantised: read the storage type, rescale levels (quant.h:121-129,169-171)
+			const int lv = (1 << (uint32_t)c.dst_bits) - 1;   // levels of the destination; evaluated in int like the reference (quant.h:135)
+			if (c.src_bits) {   // already quantised: read the storage type (quant.h:121-129)
 				switch (c.src_type) {
 				case 8: q = ldg<uint8_t>(slot); break;
 				case 6: q = ldg<uint16_t>(slot); break;
 				case 4: q = ldg<uint32_t>(slot); break;
 				default: q = ldg<uint64_t>(slot); break;
 				}
-				q = rescale_int<uint64_t>(q, (uint64_t)((1 << (uint32_t)c.src_bits) - 1), (uint64_t)lv);
+				if (c.dst_bits) q = rescale_int<uint64_t>(q, (uint64_t)((1 << (uint32_t)c.src_bits) - 1), (uint64_t)lv);   // q -> q' (quant.h:169-171)
 			} else {
-				switch (c.src_type) {
+				switch (c.src_type) {   // quant.h:131-166
 				case 0: q = cm::quantise_f32(ldg<float>(slot), cm::bits<float>((uint32_t)c.mn), cm::bits<float>((uint32_t)c.scale), c.dst_bits); break;
+				case 1: q = (uint64_t)(rescale_fp<double>(ldg<double>(slot) - cm::bits<double>(c.mn), cm::bits<double>(c.scale), (double)lv) + 0.5); break;
+				case 2: q = rescale_int<uint64_t>(ldg<uint64_t>(slot) - c.mn, c.scale, (uint64_t)lv); break;
+				case 3: q = (uint64_t)rescale_int<int64_t>(ldg<int64_t>(slot) - (int64_t)c.mn, (int64_t)c.scale, (int64_t)lv); break;
 				case 4: q = rescale_int<uint32_t>(ldg<uint32_t>(slot) - (uint32_t)c.mn, (uint32_t)c.scale, (uint32_t)lv); break;
 				case 5: q = (uint64_t)rescale_int<int32_t>(ldg<int32_t>(slot) - (int32_t)c.mn, (int32_t)c.scale, (int32_t)lv); break;
 				case 6: q = rescale_int<uint16_t>((uint16_t)(ldg<uint16_t>(slot) - (uint16_t)c.mn), (uint16_t)c.scale, (uint16_t)lv); break;
@@ -281,9 +292,27 @@ __global__ __launch_bounds__(256) void k_requant(uint8_t *rec, uint32_t count, i
 				default: break;
 				}
 			}
-			if (c.dst_bits <= 8) stg<uint8_t>(slot, (uint8_t)q);
-			else if (c.dst_bits <= 16) stg<uint16_t>(slot, (uint16_t)q);
-			else stg<uint32_t>(slot, (uint32_t)q);
+			if (c.dst_bits) {
+				if (c.dst_bits <= 8) stg<uint8_t>(slot, (uint8_t)q);
+				else if (c.dst_bits <= 16) stg<uint16_t>(slot, (uint16_t)q);
+				else stg<uint32_t>(slot, (uint32_t)q);
+				continue;
+			}
+			// dequantisation into the original type (quant.h:180-212): rescale(q, 2^bits - 1, extent) + min, in that type
+			const int sl = (1 << (uint32_t)c.src_bits) - 1;
+			switch (c.dst_type) {
+			case 0: stg<float>(slot, rescale_fp<float>((float)q, (float)sl, cm::bits<float>((uint32_t)c.scale)) + cm::bits<float>((uint32_t)c.mn)); break;
+			case 1: stg<double>(slot, rescale_fp<double>((double)q, (double)sl, cm::bits<double>(c.scale)) + cm::bits<double>(c.mn)); break;
+			case 2: stg<uint64_t>(slot, rescale_int<uint64_t>(q, (uint64_t)sl, c.scale) + c.mn); break;
+			case 3: stg<int64_t>(slot, rescale_int<int64_t>((int64_t)q, (int64_t)sl, (int64_t)c.scale) + (int64_t)c.mn); break;
+			case 4: stg<uint32_t>(slot, rescale_int<uint32_t>((uint32_t)q, (uint32_t)sl, (uint32_t)c.scale) + (uint32_t)c.mn); break;
+			case 5: stg<int32_t>(slot, rescale_int<int32_t>((int32_t)q, (int32_t)sl, (int32_t)c.scale) + (int32_t)c.mn); break;
+			case 6: stg<uint16_t>(slot, (uint16_t)(rescale_int<uint16_t>((uint16_t)q, (uint16_t)sl, (uint16_t)c.scale) + (uint16_t)c.mn)); break;
+			case 7: stg<int16_t>(slot, (int16_t)(rescale_int<int16_t>((int16_t)q, (int16_t)sl, (int16_t)c.scale) + (int16_t)c.mn)); break;
+			case 8: stg<uint8_t>(slot, (uint8_t)(rescale_int<uint8_t>((uint8_t)q, (uint8_t)sl, (uint8_t)c.scale) + (uint8_t)c.mn)); break;
+			case 9: stg<int8_t>(slot, (int8_t)(rescale_int<int8_t>((int8_t)q, (int8_t)sl, (int8_t)c.scale) + (int8_t)c.mn)); break;
+			default: break;
+			}
 		}
 	}
 }

@@ -18,7 +18,7 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n);
 Mesh *mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint8_t *v_types, const char *const *v_names,
                        uint32_t nf, const uint8_t *degrees, const uint32_t *indices,
                        const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names);
-void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out);
+void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed = false);
 void build_twins(Mesh &m);
 
 // ---- context numbering of a .hry stream (formats/hry/models.h:183-237), shared with the device code

@@ -474,7 +474,7 @@ void print_comp(std::string &o, const AttrList &L, const uint8_t *rec, int c)   
 }
 }   // namespace
 
-void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out)
+void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed)
 {
 	std::string h = std::string("ply\nformat ") + (ascii ? "ascii" : "binary_little_endian") + " 1.0\ncomment decompressed using harry mesh compressor\n";
 	auto props = [&](const AttrList &L) {
@@ -489,15 +489,25 @@ void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out)
 	h += "end_header\n";
 	out.assign(h.begin(), h.end());
 	const AttrList &LV = m.lists[1], &LF = m.lists[0];
+	// packed: every value in the width of the type the header declares for it.  The reference dumps the whole original-width
+	// record even when the header announces the narrower storage type of a quantised component (writer.cc:72-75,168; SURVEY
+	// App. B-12), which no PLY reader can parse; without quantised components the two forms are the same bytes.
+	auto any_quant = [](const AttrList &L) { for (int c = 0; c < L.ncomp(); ++c) if (L.quant[c]) return true; return false; };
+	auto put_packed = [&](const AttrList &L, const uint8_t *rec) {
+		for (int c = 0; c < L.ncomp(); ++c) out.insert(out.end(), rec + L.offset[c], rec + L.offset[c] + kTypeSize[L.stype(c)]);
+	};
 	if (!ascii) {
-		out.insert(out.end(), LV.data.begin(), LV.data.end());   // whole original-width records (writer.cc:72-75)
+		const bool pv = packed && any_quant(LV), pf = packed && any_quant(LF);
+		if (pv) { out.reserve(out.size() + LV.data.size()); for (uint32_t v = 0; v < m.nv; ++v) put_packed(LV, LV.data.data() + (size_t)v * LV.stride()); }
+		else out.insert(out.end(), LV.data.begin(), LV.data.end());   // whole original-width records (writer.cc:72-75)
 		size_t fs = LF.stride();
 		for (uint32_t f = 0; f < m.nf; ++f) {
 			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
 			out.push_back((uint8_t)(e - b));
 			const uint8_t *p = (const uint8_t*)&m.org[b];
 			out.insert(out.end(), p, p + 4 * (size_t)(e - b));
-			if (fs) out.insert(out.end(), LF.data.begin() + (size_t)f * fs, LF.data.begin() + (size_t)(f + 1) * fs);
+			if (fs && pf) put_packed(LF, LF.data.data() + (size_t)f * fs);
+			else if (fs) out.insert(out.end(), LF.data.begin() + (size_t)f * fs, LF.data.begin() + (size_t)(f + 1) * fs);
 		}
 		return;
 	}

@@ -339,6 +339,15 @@ def negated(m: Mesh) -> Mesh:
     return Mesh(v, m.degrees, m.indices, m.face_props)
 
 
+def doubles(m: Mesh) -> Mesh:
+    """the same mesh with `double` vertex coordinates (8-byte sources of the quantiser, structs/quant.h:137-139)"""
+    dt = np.dtype([(k, "<f8" if m.verts.dtype[k].kind == "f" else m.verts.dtype[k]) for k in m.verts.dtype.names])
+    v = np.empty(m.nv, dt)
+    for k in m.verts.dtype.names:
+        v[k] = m.verts[k].astype(np.float64) * (1.0 + 1e-9) if m.verts.dtype[k].kind == "f" else m.verts[k]
+    return Mesh(v, m.degrees, m.indices, m.face_props)
+
+
 # the named configurations of BASELINE.json / SURVEY.md 8(d)
 def cfg1_bunny_class() -> Mesh:
     return icosphere(6, seed=1, sigma=1e-3, extra_props=True)          # 81 920 tris

@@ -109,7 +109,13 @@ int hry_mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const ui
                          uint32_t nf, const uint8_t *degrees, const uint32_t *indices,
                          const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names,
                          hry_mesh **out);
-int hry_mesh_to_ply(const hry_mesh *m, int ascii, uint8_t **out, size_t *out_len);
+/* flags: HRY_PLY_ASCII (the reference's --ply-ascii), HRY_PLY_PACKED: binary values of QUANTISED components in the width of the
+ * storage type the header declares (a well-formed PLY).  Without it the binary writer does what the reference does: it announces
+ * the storage type and dumps the whole original-width record (formats/ply/writer.cc:72-75,168) -- readable only by knowing
+ * that.  `-c` (hry_requant with clear) before writing gives dequantised values in the original types instead. */
+#define HRY_PLY_ASCII 1
+#define HRY_PLY_PACKED 2
+int hry_mesh_to_ply(const hry_mesh *m, int flags, uint8_t **out, size_t *out_len);
 void hry_mesh_free(hry_mesh *m);
 hry_mesh *hry_mesh_clone(const hry_mesh *m);
 

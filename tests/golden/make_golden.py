@@ -43,6 +43,21 @@ def small_cases():
         "faceprops": (mg.with_face_props(mg.grid(9, 7)), "binary_little_endian", [("ll", []), ("q", ["-l0", "-q6", "-l1", "-q11"])]),
         "negative": (mg.negated(mg.grid(11)), "binary_little_endian", [("ll", []), ("q14", ["-l1", "-q14"])]),
         "tiny_tri": (mg.grid(2), "ascii", [("ll", []), ("q4", ["-l1", "-q4"])]),
+        # 8-byte sources of the quantiser (quant.h:137-139); lossless doubles are outside the reference's own defined behaviour
+        "grid_double": (mg.doubles(mg.grid(12, 9, seed=3)), "binary_little_endian", [("q14", ["-l1", "-q14"]), ("q30", ["-l1", "-q30"])]),
+    }
+
+
+def requant_cases():
+    """re-quantisation / dequantisation of an already quantised .hry: name -> (source fixture, flags)  (quant.h:169-212, main.cc:44,108)"""
+    return {
+        "grid50.q14_to_q10": ("grid50.q14.hry", ["-l1", "-q10"]),
+        "grid50.q14_c": ("grid50.q14.hry", ["-c"]),
+        "grid50.q14_a1q0": ("grid50.q14.hry", ["-l1", "-a1", "-q0"]),
+        "colors_normals.q6_c": ("colors_normals.q6.hry", ["-c"]),
+        "colors_normals.posnrm_c_q8": ("colors_normals.posnrm.hry", ["-c", "-l1", "-a6", "-q5", "-a3", "-q8"]),
+        "faceprops.q_c": ("faceprops.q.hry", ["-c"]),
+        "grid_double.q14_to_q9": ("grid_double.q14.hry", ["-l1", "-q9"]),
     }
 
 
@@ -86,12 +101,12 @@ def main():
                                           "hry_sha256": sha(open(hry, "rb").read()),
                                           "dec_sha256": sha(open(dec, "rb").read())}
             manifest["small"][name] = entry
-        # re-quantisation of an already quantised .hry (quant.h:169-171 q -> q' path)
-        src = os.path.join(HERE, "grid50.q14.hry")
-        dst = os.path.join(HERE, "grid50.q14_to_q10.hry")
-        run_ref([src, dst, "-l1", "-q10"])
-        manifest["requant_of_hry"]["grid50.q14_to_q10"] = {"src": "grid50.q14.hry", "flags": ["-l1", "-q10"],
-                                                            "hry_sha256": sha(open(dst, "rb").read())}
+        # re-quantisation / dequantisation of an already quantised .hry (quant.h:169-212)
+        for name, (src_name, flags) in requant_cases().items():
+            src = os.path.join(HERE, src_name)
+            dst = os.path.join(HERE, name + ".hry")
+            run_ref([src, dst] + flags)
+            manifest["requant_of_hry"][name] = {"src": src_name, "flags": flags, "hry_sha256": sha(open(dst, "rb").read())}
         for name, (make, variants) in big_cases().items():
             mesh = make()
             p = os.path.join(tmp, name + ".ply")

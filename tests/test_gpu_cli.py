@@ -1,5 +1,7 @@
-"""The reference's command line on top of the GPU path: `harry in.ply out.hry [-l1 -q14]`, `harry in.hry out.ply`."""
+"""The reference's command line on top of the GPU path: `harry in.ply out.hry [-l1 -q14]`, `harry in.hry out.ply` -- the C++
+executable harry_amd/bin/harry (harry_amd/csrc/cli/main.cpp over the C ABI), run as a child process."""
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -14,13 +16,39 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(util.ROOT, "tests", "golden")
 
 
-def test_cli_encode_is_byte_identical_to_reference(tmp_path, capsys):
+def harry(*args):
+    return subprocess.run([cli.HARRY] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+
+
+def test_cli_encode_is_byte_identical_to_reference(tmp_path):
     out = tmp_path / "grid50.hry"
-    assert cli.main([os.path.join(GOLD, "grid50.ply"), str(out), "-l1", "-q14"]) == 0
+    r = harry(os.path.join(GOLD, "grid50.ply"), out, "-l1", "-q14")
+    assert r.returncode == 0, r.stderr
     assert out.read_bytes() == open(os.path.join(GOLD, "grid50.q14.hry"), "rb").read()
-    text = capsys.readouterr().out
     for phrase in ("Reading input...", "Quantization took", "Writing output took", "Total output size:"):   # main.cc:99-120
-        assert phrase in text
+        assert phrase in r.stdout
+    # spelled the long way, component by component (main.cc:63-65: -a applies to the next -q only)
+    out2 = tmp_path / "b.hry"
+    r = harry(os.path.join(GOLD, "grid50.ply"), out2, "--list", "1", "-a", "0", "-q", "14", "--attr=1", "--quant=14", "-a2", "-q14")
+    assert r.returncode == 0 and out2.read_bytes() == out.read_bytes()
+    assert cli.main([os.path.join(GOLD, "grid50.ply"), str(tmp_path / "c.hry")]) == 0       # the Python alias
+    assert (tmp_path / "c.hry").read_bytes() == open(os.path.join(GOLD, "grid50.ll.hry"), "rb").read()
+
+
+def test_cli_sharded_container(tmp_path):
+    """--shards N: one mesh -> N shards -> one .hry v0.3, decoded back by the same executable"""
+    m = mg.with_nonmanifold(mg.multi_component(5, 10, 12, seed=6, polys="mixed"), 5, 3, seed=2)
+    src, hry, back = tmp_path / "in.ply", tmp_path / "out.hry", tmp_path / "back.ply"
+    src.write_bytes(m.to_ply())
+    r = harry(src, hry, "--profile", "chunked", "--shards", "4", "-l1", "-q12")
+    assert r.returncode == 0, r.stderr
+    assert hc.container_info(hry.read_bytes())["minor"] == 3
+    assert harry(hry, back, "--ply-packed").returncode == 0       # (a quantised mesh: the reference's binary form is not parseable)
+    o = op.Mesh.from_ply(m.to_ply())
+    o.requant([(1, -1, 12)])
+    ref = op.Mesh.from_hry(o.encode().data)
+    dec = hc.Mesh.from_ply(back.read_bytes())
+    assert np.array_equal(dec.org(), ref.org())
 
 
 def test_cli_chunked_roundtrip_to_ply(tmp_path):
@@ -28,22 +56,32 @@ def test_cli_chunked_roundtrip_to_ply(tmp_path):
     src = tmp_path / "in.ply"
     src.write_bytes(m.to_ply())
     hry, back = tmp_path / "out.hry", tmp_path / "back.ply"
-    assert cli.main([str(src), str(hry), "--profile", "chunked"]) == 0
-    assert cli.main([str(hry), str(back)]) == 0
+    assert harry(src, hry, "--profile", "chunked").returncode == 0
+    assert harry(hry, back).returncode == 0
     dec = hc.Mesh.from_ply(back.read_bytes())
     ref = op.Mesh.from_hry(op.Mesh.from_ply(m.to_ply()).encode().data)
     assert np.array_equal(dec.org(), ref.org())
     assert np.array_equal(dec.list_data(1), ref.list_data(1))
-    assert cli.main([str(hry), str(tmp_path / "a.ply"), "--ply-ascii"]) == 0
+    assert harry(hry, tmp_path / "a.ply", "--ply-ascii").returncode == 0
     assert (tmp_path / "a.ply").read_bytes().startswith(b"ply\nformat ascii 1.0\n")
 
 
 def test_cli_errors(tmp_path):
     bad = tmp_path / "x.ply"
     bad.write_bytes(b"garbage")
-    with pytest.raises(RuntimeError):
-        cli.main([str(bad), str(tmp_path / "y.hry")])
-    assert cli.main(["only_one_arg"]) == 1
+    r = harry(bad, tmp_path / "y.hry")
+    assert r.returncode == 134 and "what():  Not a mesh file" in r.stderr                 # the reference's uncaught std::runtime_error
+    r = harry(os.path.join(GOLD, "grid50.ply"), tmp_path / "y.hry", "-l1", "-q40")
+    assert r.returncode == 134 and "Invalid quantization bits" in r.stderr               # main.cc:78-87
+    r = harry(os.path.join(GOLD, "grid50.ply"), tmp_path / "y.hry", "-l7", "-q4")
+    assert r.returncode == 134 and "Invalid list index" in r.stderr
+    r = harry(os.path.join(GOLD, "grid50.ply"), tmp_path / "y.xyz")
+    assert r.returncode == 134 and "Unknown file extension" in r.stderr                  # unified_writer.h:46
+    r = harry("only_one_arg")
+    assert r.returncode == 1 and "Too few non-optional arguments" in r.stderr and "Usage:" in r.stdout   # utils/args.h:237-262
+    r = harry("a", "b", "--nonsense")
+    assert r.returncode == 1 and "Invalid option" in r.stderr
+    assert harry("-h").returncode == 0
 
 
 @pytest.mark.parametrize("name,tag", [("grid50", "q14"), ("grid50", "ll")])
@@ -53,7 +91,7 @@ def test_cli_decodes_reference_files(tmp_path, name, tag):
     if not os.path.exists(src):
         pytest.skip("variant not in the golden set")
     out = tmp_path / "out.ply"
-    assert cli.main([src, str(out)]) == 0
+    assert harry(src, out).returncode == 0
     want = open(os.path.join(GOLD, f"{name}.{tag}.dec.ply"), "rb").read()
     got = out.read_bytes()
     m = hc.Mesh.from_ply(got) if tag == "ll" else None

@@ -73,15 +73,46 @@ def test_cfg0_bunny_class_lossless_roundtrip(cx):
     assert np.array_equal(key(a.list_data(1)), key(ref_dec.list_data(1)))
 
 
-def test_requant_of_a_quantised_list_matches_reference_golden(cx):
-    """q -> q' on the device (structs/quant.h:121-129,169-171): the reference re-quantised its own 14-bit file to 10 bits
-    (tests/golden/grid50.q14_to_q10.hry); decode -> hry_requant -> compat encode must give those bytes."""
-    src = open(os.path.join(GOLD, "grid50.q14.hry"), "rb").read()
-    want = open(os.path.join(GOLD, "grid50.q14_to_q10.hry"), "rb").read()
+with open(os.path.join(GOLD, "manifest.json")) as _f:
+    import json as _json
+    REQUANT = sorted(_json.load(_f)["requant_of_hry"].items())
+
+
+@pytest.mark.parametrize("name,e", REQUANT, ids=[n for n, _ in REQUANT])
+def test_requant_of_a_quantised_file_matches_reference_golden(cx, name, e):
+    """`harry q.hry out.hry [-c] [-l L -a A -q Q]` on a file the reference quantised: q -> q' (structs/quant.h:121-129,169-171),
+    dequantisation into the original type for float / double / integer components (:180-212, `-c`: main.cc:44,108) and
+    mixtures of both.  decode -> hry_requant on the device -> compat encode must give the bytes the reference wrote."""
+    src = open(os.path.join(GOLD, e["src"]), "rb").read()
+    want = open(os.path.join(GOLD, name + ".hry"), "rb").read()
+    quant, clear = util.flags_to_quant(e["flags"])
     m = cx.read_hry(src)
-    cx.requant(m, [(1, -1, 10)])
-    assert [q for _t, q, _o in m.list_fmt(1)] == [10, 10, 10]
+    cx.requant(m, quant, clear)
     assert cx.write_hry(m, profile=hc.PROFILE_COMPAT) == want
+    # and the oracle's view of the same records
+    o = op.Mesh.from_hry(src)
+    o.requant(quant, clear)
+    assert np.array_equal(m.list_data(1), o.list_data(1)) and np.array_equal(m.list_data(0), o.list_data(0))
+
+
+def test_ply_of_a_quantised_mesh_packed_and_dequantised(cx):
+    """row f4: the reference's binary PLY of a quantised mesh announces the storage types but dumps original-width records
+    (formats/ply/writer.cc:72-75,168).  HRY_PLY_PACKED writes what the header says; `-c` first gives the original types back."""
+    src = open(os.path.join(GOLD, "colors_normals.posnrm.hry"), "rb").read()
+    m = cx.read_hry(src)
+    packed = hc.Mesh.from_ply(m.to_ply(packed=True))        # a well-formed PLY: our own reader takes it by its header
+    assert [t for t, _q, _o in packed.list_fmt(1)][:6] == [6, 6, 6, 6, 6, 6]       # ushort positions and normals
+    for c in range(len(m.list_fmt(1))):
+        assert np.array_equal(packed.component(1, c), m.component(1, c))
+    assert np.array_equal(packed.org(), m.org())
+    ascii_ = hc.Mesh.from_ply(m.to_ply(ascii=True))
+    for c in range(len(m.list_fmt(1))):
+        assert np.array_equal(ascii_.component(1, c), m.component(1, c))
+    cx.requant(m, [], clear=True)                            # -c
+    o = op.Mesh.from_hry(src)
+    o.requant([], True)
+    back = hc.Mesh.from_ply(m.to_ply())
+    assert [t for t, _q, _o in back.list_fmt(1)][:6] == [0] * 6 and np.array_equal(back.list_data(1), o.list_data(1))
 
 
 def test_cfg2_lucy_class_28m_full_size(cx):
