@@ -28,11 +28,8 @@ static thread_local Clock::time_point g_t0;
 #define HRY_MARK(t0, what) do { if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  %s\n", ms_since(t0), what); } while (0)
 
 namespace dev {
-void launch_candidates(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand, const ListDesc &ld);
 void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, const ListDesc &ld, uint8_t *rec);
 void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
-void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
-                      const ListDesc &ld, uint8_t *rec);
 bool unpredict2_applicable(const ListDesc &ld);
 void launch_chain_records(hipStream_t st, const uint32_t *cand, const uint8_t *ncand, uint32_t nvtx, const uint32_t *seg_start, uint32_t nseg, void *crec);
 bool unpredict3_wanted(const ListDesc &ld);
@@ -110,11 +107,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 			chain_timed = true;
 			HIP_OK(hipStreamSynchronize(cx.stream));   // the table lives in host memory until the copy has been consumed
 			HRY_MARK(g_t0, "vertex chain done");
-		} else {
-			launch_candidates(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv);
-			launch_residuals_to_rec(cx.stream, d_vplanes, nvc, ldv, cx.d_rec[1].as<uint8_t>());
-			launch_unpredict(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, ldv, cx.d_rec[1].as<uint8_t>());
-		}
+		} else throw Error(HRY_E_UNSUPPORTED, "8-byte storage types (more than 32 quantisation bits, lossless 64-bit integers) are outside the supported subset");
 	}
 	if (ldf.nplanes) {
 		launch_residuals_to_rec(cx.stream, d_fplanes, m->nf, ldf, cx.d_rec[0].as<uint8_t>());

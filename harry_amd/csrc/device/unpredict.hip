@@ -91,30 +91,6 @@ template <typename F> __device__ __forceinline__ void fan_ids(const TopoD &tp, u
 
 constexpr int kCandMax = 8;
 
-// ncand[v]: 0..8 = number of candidates, every source vertex within the last ring_n vertices, cand[] holds their RING SLOTS
-//           as byte offsets (id mod ring_n) * ring_stride * 8; 0x80 | n = same but some source is older than the ring, cand[] holds vertex ids;
-//           0xff = more than 8 candidates (the chain walks the fan itself)
-__global__ __launch_bounds__(256) void k_candidates(ConnView cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand,
-                                                    uint32_t ring_n, uint32_t ring_stride, uint32_t elem_bytes)
-{
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= n) return;
-	TopoD tp{ cv };
-	uint32_t k = 0;
-	uint32_t ids[kCandMax * 3];
-	bool far = false;
-	fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-		if (k < (uint32_t)kCandMax) { ids[3 * k] = a; ids[3 * k + 1] = b; ids[3 * k + 2] = o; }
-		far |= (v - a > ring_n) | (v - b > ring_n) | (v - o > ring_n);
-		++k;
-	});
-	uint32_t *out = cand + (size_t)v * (kCandMax * 3);
-	uint32_t m = k > (uint32_t)kCandMax ? 0 : k;
-	for (uint32_t j = 0; j < (uint32_t)(3 * kCandMax); ++j)
-		out[j] = j < 3 * m ? (far ? ids[j] : (ids[j] & (ring_n - 1)) * ring_stride * elem_bytes) : 0u;   // near: byte offset of the ring slot
-	ncand[v] = k > (uint32_t)kCandMax ? 0xff : (uint8_t)(k | (far ? 0x80u : 0u));
-}
-
 __global__ __launch_bounds__(256) void k_residuals_to_rec(const uint8_t *planes, uint32_t n, ListDesc ld, uint8_t *rec)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,218 +139,7 @@ __device__ __forceinline__ uint32_t div_small(uint32_t x, uint32_t n)
 	return n == 1 ? x : __umulhi(x, inv);
 }
 
-constexpr int kRecWords = 32;   // records up to 128 bytes are staged through LDS
-
-// One batch of 64 vertices for one component (= one lane).  Candidate lists, candidate counts and residual records
-// of the batch are already staged in LDS; reconstructed values of the last ring_n vertices live in the LDS ring.
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane_idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane_idx); }
-
-template <typename T, typename RE>
-__device__ __forceinline__ void unpredict_batch(const TopoD &tp, const uint32_t *order_v, uint32_t base, uint32_t nb,
-                                                const uint4 (&cid)[6], uint32_t cnc, const uint32_t *rbuf, int rec_words,
-                                                uint8_t *rec, int stride, int off, int q, RE *ring, uint32_t ring_n, int ring_stride, int lane, bool active)
-{
-	typedef typename cm::wide<T>::type W;
-	typedef typename cm::word<sizeof(T)>::u U;
-	auto fetch = [&](uint32_t id, uint32_t v) -> T {
-		if (v - id <= ring_n) return cm::bits<T>((U)ring[(id & (ring_n - 1)) * (uint32_t)ring_stride + (uint32_t)lane]);
-		return ldq<T>(rec + (size_t)id * stride + off);
-	};
-	// Candidate slots and counts of vertex i sit in lane i's registers (staged by the whole wave) and are broadcast with
-	// v_readlane: no memory access, and they do not depend on reconstructed values.  The residual code comes from LDS
-	// one vertex ahead.  Only the ring reads sit on the dependency chain.
-	U code_next = ldq<U>((const uint8_t*)rbuf + off);
-	for (uint32_t i = 0; i < nb; ++i) {
-		const uint32_t v = base + i;
-		const uint32_t nraw = rl(cnc, i);
-		const uint32_t nc = nraw == 0xff ? 0xffu : (nraw & 0x7fu);
-		const U code_staged = code_next;
-		if (i + 1 < nb) code_next = ldq<U>((const uint8_t*)(rbuf + (i + 1) * rec_words) + off);
-		T pv[kCandMax];
-		T pred = T(0);
-#define HRY_SLOT(j) rl(((j) & 3) == 0 ? cid[(j) >> 2].x : ((j) & 3) == 1 ? cid[(j) >> 2].y : ((j) & 3) == 2 ? cid[(j) >> 2].z : cid[(j) >> 2].w, i)
-		if (nraw == 2) {
-			// two candidates, both inside the ring (94 % of the vertices of a manifold triangle mesh): six ring reads in one
-			// LDS round trip, then attrcode.h:182-208 written out for n = 2
-			const uint8_t *ringb = (const uint8_t*)ring + (uint32_t)sizeof(RE) * (uint32_t)lane;
-			U a0 = (U)*(const RE*)(ringb + HRY_SLOT(0)), b0 = (U)*(const RE*)(ringb + HRY_SLOT(1)), o0 = (U)*(const RE*)(ringb + HRY_SLOT(2));
-			U a1 = (U)*(const RE*)(ringb + HRY_SLOT(3)), b1 = (U)*(const RE*)(ringb + HRY_SLOT(4)), o1 = (U)*(const RE*)(ringb + HRY_SLOT(5));
-			T p0 = cm::parallelogram<T>(cm::bits<T>(a0), cm::bits<T>(b0), cm::bits<T>(o0), q);
-			T p1 = cm::parallelogram<T>(cm::bits<T>(a1), cm::bits<T>(b1), cm::bits<T>(o1), q);
-			W acc = (W)p0;
-			acc = acc + (W)p1;
-			T avg;
-			if constexpr (sizeof(T) <= 4 && !cm::is_fp<T>::value && !(T(-1) < T(0))) avg = (T)((uint64_t)(acc + 1) >> 1);   // (sum + n/2) / n, sum >= 0
-			else avg = (T)cm::mean_of(acc, (W)2);
-			if constexpr (!cm::is_fp<T>::value) pred = avg;
-			else {
-				T best = 3.402823466e+38f;
-				T db = avg > best ? avg - best : best - avg, dp = avg > p0 ? avg - p0 : p0 - avg;
-				best = db < dp ? best : p0;
-				db = avg > best ? avg - best : best - avg; dp = avg > p1 ? avg - p1 : p1 - avg;
-				pred = db < dp ? best : p1;
-			}
-		} else if (nraw == 1) {
-			// The common case of a cut-border traversal: a new vertex sees exactly one coded face, the triangle across the
-			// gate.  Mean and selection of a single candidate are the candidate itself (attrcode.h:182-208 with n = 1):
-			// (p + 0) / 1 == p for integers, double(p) / 1.0 == p and |p - p| = 0 wins the selection for floats.
-			const uint8_t *ringb = (const uint8_t*)ring + (uint32_t)sizeof(RE) * (uint32_t)lane;
-			U a = (U)*(const RE*)(ringb + HRY_SLOT(0)), b = (U)*(const RE*)(ringb + HRY_SLOT(1)),
-			  o = (U)*(const RE*)(ringb + HRY_SLOT(2));
-			pred = cm::parallelogram<T>(cm::bits<T>(a), cm::bits<T>(b), cm::bits<T>(o), q);
-		} else if (nraw != 0xff) {
-			W acc = 0;
-			const bool far = (nraw & 0x80u) != 0;
-			const uint8_t *ringb = (const uint8_t*)ring + (uint32_t)sizeof(RE) * (uint32_t)lane;
-			if (!far) {
-				// all ring reads of up to 4 candidates are issued before the first use (one LDS round trip);
-				// unused slots are zero offsets (valid addresses), candidates 5..8 are rare
-				U ra[4], rb[4], ro[4];
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					if ((uint32_t)k < nc || k < 2) {
-						ra[k] = (U)*(const RE*)(ringb + HRY_SLOT(3 * k));
-						rb[k] = (U)*(const RE*)(ringb + HRY_SLOT(3 * k + 1));
-						ro[k] = (U)*(const RE*)(ringb + HRY_SLOT(3 * k + 2));
-					}
-				}
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					if ((uint32_t)k < nc) {
-						pv[k] = cm::parallelogram<T>(cm::bits<T>(ra[k]), cm::bits<T>(rb[k]), cm::bits<T>(ro[k]), q);
-						acc = acc + (W)pv[k];
-					}
-				}
-#pragma unroll
-				for (int k = 4; k < kCandMax; ++k) {
-					if ((uint32_t)k < nc) {
-						U a = (U)*(const RE*)(ringb + HRY_SLOT(3 * k)), b = (U)*(const RE*)(ringb + HRY_SLOT(3 * k + 1)),
-						  o = (U)*(const RE*)(ringb + HRY_SLOT(3 * k + 2));
-						pv[k] = cm::parallelogram<T>(cm::bits<T>(a), cm::bits<T>(b), cm::bits<T>(o), q);
-						acc = acc + (W)pv[k];
-					}
-				}
-			} else {
-#pragma unroll
-				for (int k = 0; k < kCandMax; ++k) {
-					if ((uint32_t)k < nc) {
-						pv[k] = cm::parallelogram<T>(fetch(HRY_SLOT(3 * k), v), fetch(HRY_SLOT(3 * k + 1), v), fetch(HRY_SLOT(3 * k + 2), v), q);
-						acc = acc + (W)pv[k];
-					}
-				}
-			}
-#undef HRY_SLOT
-			if (nc) {
-				T avg;
-				if constexpr (sizeof(T) <= 2 && !cm::is_fp<T>::value && !(T(-1) < T(0))) avg = (T)div_small((uint32_t)acc + (nc >> 1), nc);
-				else avg = (T)cm::mean_of(acc, (W)nc);
-				if constexpr (!cm::is_fp<T>::value) pred = avg;
-				else {
-					T best = 3.402823466e+38f;
-#pragma unroll
-					for (int k = 0; k < kCandMax; ++k) {
-						if ((uint32_t)k < nc) {
-							T db = avg > best ? avg - best : best - avg;
-							T dp = avg > pv[k] ? avg - pv[k] : pv[k] - avg;
-							best = db < dp ? best : pv[k];
-						}
-					}
-					pred = best;
-				}
-			}
-		} else {
-			// more candidates than the table holds (high-valence vertex): walk the fan here
-			W acc = 0;
-			uint32_t n = 0;
-			fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-				acc = acc + (W)cm::parallelogram<T>(fetch(a, v), fetch(b, v), fetch(o, v), q);
-				++n;
-			});
-			if (n) {
-				T avg = (T)cm::mean_of(acc, (W)n);
-				if constexpr (!cm::is_fp<T>::value) pred = avg;
-				else {
-					T best = 3.402823466e+38f;
-					fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-						T p = cm::parallelogram<T>(fetch(a, v), fetch(b, v), fetch(o, v), q);
-						T db = avg > best ? avg - best : best - avg;
-						T dp = avg > p ? avg - p : p - avg;
-						best = db < dp ? best : p;
-					});
-					pred = best;
-				}
-			}
-		}
-		// no vector-memory load on this path: a pending load would make every store wait for vmcnt(0), i.e. for the previous store
-		U code = code_staged;
-		T val = cm::value_from_residual<T>(code, pred, q);
-		if (active) {
-			stq<T>(rec + (size_t)v * stride + off, val);
-			ring[(v & (ring_n - 1)) * (uint32_t)ring_stride + (uint32_t)lane] = (RE)cm::bits<U>(val);
-		}
-	}
-}
-
-// The chain: one wavefront.  All 64 lanes stage the NEXT batch's candidate lists / counts / residual records from
-// global memory into registers while lanes 0..ncomp-1 reconstruct the current batch out of LDS, so that no global
-// load sits on the dependency chain.
-template <typename FIXED>
-__global__ __launch_bounds__(64) void k_unpredict(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
-                                                  ListDesc ld, uint8_t *rec, uint32_t ring_n)
-{
-	extern __shared__ unsigned long long ring_raw[];
-	typedef typename std::conditional<std::is_same<FIXED, void>::value, unsigned long long, typename cm::word<sizeof(typename std::conditional<std::is_same<FIXED, void>::value, uint64_t, FIXED>::type)>::u>::type RE;
-	RE *ring = (RE*)ring_raw;
-	__shared__ uint32_t rbuf[2][64 * kRecWords];
-	const int lane = threadIdx.x;
-	TopoD tp{ cv };
-	const int rec_words = (ld.stride + 3) / 4;   // <= kRecWords (checked by the launcher); records are over-read by < 4 bytes (buffers carry slack)
-	uint4 cur_id[6], nxt_id[6];
-	uint32_t cur_nc = 0, nxt_nc = 0, rreg[kRecWords];
-#pragma unroll
-	for (int k = 0; k < 6; ++k) nxt_id[k] = make_uint4(0, 0, 0, 0);
-	auto prefetch = [&](uint32_t base) {
-		uint32_t v = base + lane;
-		if (v < nvtx) {
-			const uint4 *src = (const uint4*)(cand + (size_t)v * (kCandMax * 3));
-#pragma unroll
-			for (int k = 0; k < 6; ++k) nxt_id[k] = src[k];
-			nxt_nc = ncand[v];
-			const uint32_t *rs = (const uint32_t*)(rec + (size_t)v * ld.stride);
-#pragma unroll
-			for (int k = 0; k < kRecWords; ++k) if (k < rec_words) rreg[k] = rs[k];
-		}
-	};
-	auto commit = [&](int buf) {
-#pragma unroll
-		for (int k = 0; k < 6; ++k) cur_id[k] = nxt_id[k];
-		cur_nc = nxt_nc;
-#pragma unroll
-		for (int k = 0; k < kRecWords; ++k) if (k < rec_words) rbuf[buf][lane * rec_words + k] = rreg[k];
-	};
-	prefetch(0);
-	commit(0);
-	__syncthreads();
-	int cur = 0;
-	for (uint32_t base = 0; base < nvtx; base += 64) {
-		prefetch(base + 64);
-		const uint32_t nb = min(64u, nvtx - base);
-		// every lane takes part (the broadcasts read all lanes' registers); lanes without a component discard the result
-		const int comp = lane < ld.ncomp ? lane : 0;
-		if constexpr (std::is_same<FIXED, void>::value) {
-			with_st(ld.stype[comp], [&](auto tag) {
-				unpredict_batch<decltype(tag), RE>(tp, order_v, base, nb, cur_id, cur_nc, rbuf[cur], rec_words, rec, ld.stride, ld.off[comp], ld.quant[comp],
-				                               ring, ring_n, ld.ncomp, comp, lane < ld.ncomp);
-			});
-		} else {   // every component has the same storage type: no per-lane dispatch inside the chain
-			unpredict_batch<FIXED, RE>(tp, order_v, base, nb, cur_id, cur_nc, rbuf[cur], rec_words, rec, ld.stride, ld.off[comp], ld.quant[comp],
-			                       ring, ring_n, ld.ncomp, comp, lane < ld.ncomp);
-		}
-		commit(cur ^ 1);
-		__syncthreads();
-		cur ^= 1;
-	}
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // k_unpredict2: the reconstruction chain.  Components are independent chains that share only the candidate lists,
@@ -1339,23 +1104,6 @@ __global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uin
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static uint32_t ring_elem_bytes(const ListDesc &ld)
-{
-	bool same = true;
-	for (int c = 1; c < ld.ncomp; ++c) same &= ld.stype[c] == ld.stype[0];
-	if (!same) return 8;
-	switch (ld.stype[0]) { case 0: case 4: return 4; case 6: return 2; case 8: return 1; default: return 8; }
-}
-static uint32_t ring_size_for(const ListDesc &ld)
-{
-	uint32_t ring_n = 32768, eb = ring_elem_bytes(ld);
-	while ((size_t)ring_n * ld.ncomp * eb > 96 * 1024 && ring_n > 64) ring_n >>= 1;
-	return ring_n;
-}
-void launch_candidates(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, uint32_t *cand, uint8_t *ncand, const ListDesc &ld)
-{
-	if (n) hipLaunchKernelGGL(k_candidates, dim3((n + 255) / 256), dim3(256), 0, st, cv, order_v, n, cand, ncand, ring_size_for(ld), (uint32_t)ld.ncomp, ring_elem_bytes(ld));
-}
 void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, const ListDesc &ld, uint8_t *rec)
 {
 	if (n && ld.ncomp) hipLaunchKernelGGL(k_residuals_to_rec, dim3((n + 255) / 256), dim3(256), 0, st, planes, n, ld, rec);
@@ -1471,25 +1219,5 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 	if (crec) { go3(k_unpredict3<uint16_t>, 6); go3(k_unpredict3<uint8_t>, 8); }
 	else { go(k_unpredict2<uint16_t>, 6); go(k_unpredict2<uint8_t>, 8); }
 }
-void launch_unpredict(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
-                      const ListDesc &ld, uint8_t *rec)
-{
-	if (!nvtx || !ld.ncomp) return;
-	if (ld.stride > kRecWords * 4) throw std::runtime_error("vertex records wider than 128 bytes are not supported by the reconstruction kernel");
-	uint32_t ring_n = ring_size_for(ld);
-	size_t lds = (size_t)ring_n * ld.ncomp * ring_elem_bytes(ld);
-	bool same = true;
-	for (int c = 1; c < ld.ncomp; ++c) same &= ld.stype[c] == ld.stype[0];
-	auto go = [&](auto kern) {
-		(void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds, st, cv, order_v, nvtx, cand, ncand, ld, rec, ring_n);
-	};
-	if (same && ld.stype[0] == 0) go(k_unpredict<float>);
-	else if (same && ld.stype[0] == 6) go(k_unpredict<uint16_t>);
-	else if (same && ld.stype[0] == 8) go(k_unpredict<uint8_t>);
-	else if (same && ld.stype[0] == 4) go(k_unpredict<uint32_t>);
-	else go(k_unpredict<void>);
-}
-
 }   // namespace dev
 }   // namespace hry
