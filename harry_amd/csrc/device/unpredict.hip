@@ -1098,7 +1098,12 @@ __global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uin
 {
 	__shared__ T ring3[kRing3];
 	__shared__ uint32_t sync3[2];
-	const int c = sel.comp[blockIdx.x];
+	// The chains of the attribute components read the same chain records and write into the same vertex records.  Workgroups
+	// go round-robin over the 8 XCDs (each with its own L2): only every eighth workgroup of the launch carries a chain, so
+	// that all of them share ONE L2 -- the records are fetched from memory once, and the components' 2-byte stores into a
+	// 12-byte record meet in one cache instead of three.
+	if (blockIdx.x & 7u) return;
+	const int c = sel.comp[blockIdx.x >> 3];
 	TopoD tp{ cv };
 	unpredict3_segment<T>(tp, order_v, nvtx, v_begin, v_end, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, ring_floor, sync3);
 }
@@ -1178,7 +1183,7 @@ void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *orde
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		hipLaunchKernelGGL(kern, dim3(sel.n), dim3(64 * chain_waves()), 0, st, cv, order_v, nvtx, cand, ncand, (const ChainRec*)crec, planes, ld, rec, sel, v_begin, v_end, chain_ring_floor(v_begin));
+		hipLaunchKernelGGL(kern, dim3((sel.n - 1) * 8 + 1), dim3(64 * chain_waves()), 0, st, cv, order_v, nvtx, cand, ncand, (const ChainRec*)crec, planes, ld, rec, sel, v_begin, v_end, chain_ring_floor(v_begin));
 	};
 	go3(k_unpredict3_range<uint16_t>, 6); go3(k_unpredict3_range<uint8_t>, 8);
 }
