@@ -34,7 +34,8 @@ bool unpredict2_applicable(const ListDesc &ld);
 void launch_chain_records(hipStream_t st, const uint32_t *cand, const uint8_t *ncand, uint32_t nvtx, const uint32_t *seg_start, uint32_t nseg, void *crec);
 bool unpredict3_wanted(const ListDesc &ld);
 void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand, const void *crec,
-                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists);
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists,
+                       const uint32_t *seg_start, uint32_t nseg, uint32_t *done);
 void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand);
 bool unpredict3_covers(const ListDesc &ld);
 void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t v_begin, uint32_t v_end, uint32_t *cand, uint8_t *ncand, void *crec);
@@ -72,37 +73,33 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	if (ldv.nplanes) {
 		if (unpredict2_applicable(ldv)) {
-			// One wavefront per attribute component and per independent connected component; residual codes come straight
-			// from the decoded byte planes.  Components that read vertices coded before them (shared non-manifold vertices)
-			// run afterwards, in order, in one chain.
-			// Components whose vertices are all their own are independent chains (level 0).  A component that touches a
-			// vertex coded earlier (shared non-manifold vertex) runs one level after the component owning it.  One launch
-			// per level, every component of a level in its own wavefronts.
-			uint32_t max_level = 0;
-			for (uint32_t lv : seg_level) max_level = std::max(max_level, lv);
-			std::vector<std::vector<uint32_t>> by_level(max_level + 1);
-			for (size_t k = 0; k + 1 < seg_start.size(); ++k)
-				if (seg_start[k] != seg_start[k + 1]) { by_level[seg_level[k]].push_back(seg_start[k]); by_level[seg_level[k]].push_back(seg_start[k + 1]); }
+			// One chain (a wavefront, or a team of them) per attribute component and per connected component of the mesh, all of
+			// them in ONE launch in coding order; residual codes come straight from the decoded byte planes.  A component that
+			// names vertices coded before it (shared non-manifold vertices) waits for the chain of the component that owns
+			// them -- vertex by vertex, through per-component flags in HBM -- instead of for a whole level of components.
+			(void)seg_level;
+			const uint32_t nseg = (uint32_t)seg_start.size() - 1;
 			std::vector<uint32_t> table;
-			std::vector<size_t> seg_at, off_at;
-			for (auto &lv : by_level) { seg_at.push_back(table.size()); table.insert(table.end(), lv.begin(), lv.end()); }
-			for (auto &lv : by_level) { off_at.push_back(table.size()); for (uint32_t i = 0; i <= lv.size() / 2; ++i) table.push_back(i); }
+			uint32_t n_lists = 0;
+			for (uint32_t k = 0; k < nseg; ++k)
+				if (seg_start[k] != seg_start[k + 1]) { table.push_back(seg_start[k]); table.push_back(seg_start[k + 1]); table.push_back(k); ++n_lists; }
+			const size_t off_at = table.size();
+			for (uint32_t i = 0; i <= n_lists; ++i) table.push_back(i);
 			const size_t segstart_at = table.size();
 			table.insert(table.end(), seg_start.begin(), seg_start.end());
+			const size_t done_at = table.size();
 			const bool scan_chain = unpredict3_wanted(ldv) && seg_start.size() >= 2;
-			cx.d_small.ensure(table.size() * 4 + 64);
+			cx.d_small.ensure((table.size() + (size_t)ldv.ncomp * nseg) * 4 + 64);
 			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
-			const uint32_t *d_tab = cx.d_small.as<uint32_t>();
-						launch_candidates_ids(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand);
-			if (scan_chain) launch_chain_records(cx.stream, d_cand, d_ncand, nvc, d_tab + segstart_at, (uint32_t)seg_start.size() - 1, d_crec);
+			uint32_t *d_tab = cx.d_small.as<uint32_t>();
+			HIP_OK(hipMemsetAsync(d_tab + done_at, 0, (size_t)ldv.ncomp * nseg * 4, cx.stream));
+			launch_candidates_ids(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand);
+			if (scan_chain) launch_chain_records(cx.stream, d_cand, d_ncand, nvc, d_tab + segstart_at, nseg, d_crec);
 			HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
-			for (size_t lv = 0; lv < by_level.size(); ++lv) {
-				const uint32_t nl = (uint32_t)by_level[lv].size() / 2;
-				// a 2-D grid holds at most 65535 rows: split very wide levels
-				for (uint32_t done = 0; done < nl; done += 65535)
-					launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, scan_chain ? d_crec : nullptr, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
-					                  d_tab + seg_at[lv], d_tab + off_at[lv] + done, std::min(65535u, nl - done));
-			}
+			// a 2-D grid holds at most 65535 rows: very many components go in several launches, still in coding order
+			for (uint32_t done = 0; done < n_lists; done += 65535)
+				launch_unpredict2(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, scan_chain ? d_crec : nullptr, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
+				                  d_tab, d_tab + off_at + done, std::min(65535u, n_lists - done), d_tab + segstart_at, nseg, d_tab + done_at);
 			HIP_OK(hipEventRecord(cx.ev[0], cx.stream));
 			chain_timed = true;
 			HIP_OK(hipStreamSynchronize(cx.stream));   // the table lives in host memory until the copy has been consumed

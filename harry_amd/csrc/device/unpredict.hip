@@ -318,10 +318,43 @@ constexpr uint32_t kNoLane = 64;
 constexpr uint32_t kQueue = 256;        // vertices in the LDS input queue (4 tiles of 64)
 constexpr uint32_t kQueueCols = 26;     // 24 candidate ids, candidate count, residual code   // tag of a source that is already present
 
+// Chains of different connected components run in ONE launch.  A component that names vertices of an earlier one (shared
+// non-manifold vertices, cbm/encoder.h:79-113,187) reads their reconstructed values from the records; it waits until the chain
+// of that component -- same attribute component -- has raised its flag.  Workgroups start in the order of their indices and
+// a chain only ever waits for a component before it in coding order (= a lower workgroup index), which is therefore running
+// or finished: the waits cannot deadlock.  Bounded like every other wait of the chains (g_chain_timeout).
+struct CrossSync { const uint32_t *seg_start; uint32_t nseg; uint32_t *done; };   // done[attribute component * nseg + component of the mesh]
+__device__ uint32_t g_chain_timeout;
+constexpr uint32_t kSpinLimit = 1u << 22;
+__device__ __attribute__((noinline)) void wait_owner(const CrossSync &xs, int c, uint32_t id)
+{
+	if (!xs.done) return;
+	uint32_t lo = 0, hi = xs.nseg;   // owner: the last component that starts at or before the vertex
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (xs.seg_start[mid] <= id) lo = mid; else hi = mid; }
+	const uint32_t *flag = xs.done + (size_t)c * xs.nseg + lo;
+	uint32_t spins = 0;
+#pragma nounroll
+	while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+		__builtin_amdgcn_s_sleep(8);
+		if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 4u); break; }
+	}
+}
+// value of a vertex reconstructed by another chain or long ago by this one: past this compute unit's L1 (the line may have been
+// cached while a neighbouring attribute component of the same record was still unwritten)
+template <typename U> __device__ __forceinline__ U far_load(const uint8_t *addr) { return __hip_atomic_load((const U*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void raise_flag(const CrossSync &xs, int c, uint32_t seg_idx)
+{
+	__syncthreads();
+	if (threadIdx.x == 0 && xs.done) {
+		__threadfence();   // the chain's stores into the records are visible device-wide before the flag
+		__hip_atomic_store(xs.done + (size_t)c * xs.nseg + seg_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 template <typename T>
 __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                      const uint8_t *planes, uint8_t *rec, int stride, int off, int q, int plane0,
-                                     typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n, uint32_t *queue)
+                                     typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n, uint32_t *queue, const CrossSync &xs, int comp)
 {
 	// this call reconstructs the vertices [seg_begin, nvtx) of one component; the ring holds only vertices >= seg_begin.
 	// The workgroup is ONE wavefront: its LDS accesses execute in program order, no barrier is needed anywhere.
@@ -372,9 +405,8 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 	// value of an already reconstructed vertex that lies before the current batch
 	auto old_value = [&](uint32_t id, uint32_t base) -> U {
 		if (base - id <= ring_n && id >= seg_begin) return ring[id & mask];
-		U r;
-		__builtin_memcpy(&r, rec + (size_t)id * stride + off, sizeof(U));
-		return r;
+		if (id < seg_begin) wait_owner(xs, comp, id);
+		return far_load<U>(rec + (size_t)id * stride + off);
 	};
 	tile_request(0);
 	uint32_t base = seg_begin;
@@ -486,9 +518,8 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			for (int s6 = 0; s6 < 6; ++s6) {
 				const uint32_t id = ids[s6];
 				if ((uint32_t)(s6 / 3) < ncl && id < base && ((base - id > ring_n) | (id < seg_begin))) {
-					U r;
-					__builtin_memcpy(&r, rec + (size_t)id * stride + off, sizeof(U));
-					src[s6] = (uint32_t)r;
+					if (id < seg_begin) wait_owner(xs, comp, id);
+					src[s6] = (uint32_t)far_load<U>(rec + (size_t)id * stride + off);
 				}
 			}
 			__builtin_amdgcn_s_waitcnt(0);   // here, inside the rare branch: nothing after it may wait for vector memory
@@ -729,18 +760,19 @@ struct CompSel { int32_t n; int32_t comp[kMaxComp]; };
 template <typename T>
 __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                                    const uint8_t *planes, ListDesc ld, uint8_t *rec, uint32_t ring_bytes, CompSel sel,
-                                                   const uint32_t *segs, const uint32_t *list_off)
+                                                   const uint32_t *segs, const uint32_t *list_off, CrossSync xs)
 {
 	extern __shared__ unsigned long long ring_raw2[];
 	const int c = sel.comp[blockIdx.x];
 	TopoD tp{ cv };
+	// segs: triples (first decode rank, end, component of the mesh)
 	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
-		const uint32_t b = segs[2 * k], e = segs[2 * k + 1];
+		const uint32_t b = segs[3 * k], e = segs[3 * k + 1];
 		if (b < e)
 			unpredict2_component<T>(tp, order_v, nvtx, b, e, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
 			                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T),
-			                        (uint32_t*)((uint8_t*)ring_raw2 + ring_bytes));
-		__syncthreads();
+			                        (uint32_t*)((uint8_t*)ring_raw2 + ring_bytes), xs, c);
+		raise_flag(xs, c, segs[3 * k + 2]);
 	}
 }
 
@@ -821,17 +853,16 @@ __global__ __launch_bounds__(256) void k_chain_records_range(const uint32_t *can
 	if (v < v_end) out[v] = make_chain_rec(cand, ncand, v, v_begin, ring_floor);
 }
 
-// Set when a wavefront gave up waiting for another one (a hand-over that takes longer than ~a second is a bug, not load):
-// the grid still drains, and the host turns the flag into an error instead of returning a wrong mesh.
-__device__ uint32_t g_chain_timeout;
-constexpr uint32_t kSpinLimit = 1u << 22;
+// g_chain_timeout (above) is set when a wavefront gave up waiting for another one (a hand-over that takes longer than ~a second
+// is a bug, not load): the grid still drains, and the host turns the flag into an error instead of returning a wrong mesh.
 
 // rare: a source older than the LDS ring (or of an earlier launch), read from the records by vertex id.  Out of line on purpose:
 // the chain's hot loop has to stay small enough for the instruction cache.
 template <typename T>
-__device__ __attribute__((noinline)) uint32_t chain_far_value(const uint8_t *addr, uint32_t id, uint32_t seg_begin, uint32_t *sync)
+__device__ __attribute__((noinline)) uint32_t chain_far_value(const uint8_t *addr, uint32_t id, uint32_t seg_begin, uint32_t *sync, const CrossSync &xs, int comp)
 {
-	if (id >= seg_begin) {   // this launch's own output: wait for its flush
+	if (id < seg_begin) wait_owner(xs, comp, id);   // another component's chain (or an earlier slice: no flags, already final)
+	else {   // this chain's own output: wait for its flush
 		uint32_t spins = 0;
 #pragma nounroll
 		while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= id) {
@@ -890,7 +921,7 @@ __device__ __forceinline__ Map3 scan3(Map3 m)
 template <typename T>
 __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t seg_end,
                                    const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec, const uint8_t *planes, uint8_t *rec,
-                                   int stride, int off, int q, int plane0, T *ring, uint32_t ring_floor, uint32_t *sync)
+                                   int stride, int off, int q, int plane0, T *ring, uint32_t ring_floor, uint32_t *sync, const CrossSync &xs, int comp)
 {
 	static_assert(sizeof(T) <= 2 && !(T(-1) < T(0)), "unsigned components of at most 16 bits");
 	const int lane = threadIdx.x & 63;
@@ -906,7 +937,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	auto old_value = [&](uint32_t id, uint32_t cur) -> uint32_t {
 		if (id >= cur) return 0u;   // the chained source of a vertex inside the run: not final yet, and never used from here
 		if (id >= ring_floor && cur - id <= kRing3Near) return (uint32_t)ring[id & mask];
-		return chain_far_value<T>(rec + (size_t)id * stride + off, id, seg_begin, sync);
+		return chain_far_value<T>(rec + (size_t)id * stride + off, id, seg_begin, sync, xs, comp);
 	};
 	uint4 nx_rec = make_uint4(0, 0, 0, 0);
 	uint32_t nx_b0 = 0, nx_b1 = 0;
@@ -1080,16 +1111,16 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 
 template <typename T>
 __global__ __launch_bounds__(512) void k_unpredict3(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
-                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, const uint32_t *segs, const uint32_t *list_off)
+                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, const uint32_t *segs, const uint32_t *list_off, CrossSync xs)
 {
 	__shared__ T ring3[kRing3];
 	__shared__ uint32_t sync3[2];
 	const int c = sel.comp[blockIdx.x];
 	TopoD tp{ cv };
 	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
-		const uint32_t b = segs[2 * k], e = segs[2 * k + 1];
-		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, b, sync3);
-		__syncthreads();
+		const uint32_t b = segs[3 * k], e = segs[3 * k + 1];
+		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, b, sync3, xs, c);
+		raise_flag(xs, c, segs[3 * k + 2]);
 	}
 }
 template <typename T>
@@ -1105,7 +1136,8 @@ __global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uin
 	if (blockIdx.x & 7u) return;
 	const int c = sel.comp[blockIdx.x >> 3];
 	TopoD tp{ cv };
-	unpredict3_segment<T>(tp, order_v, nvtx, v_begin, v_end, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, ring_floor, sync3);
+	const CrossSync none{ nullptr, 0, nullptr };   // one component: no other chain to wait for
+	unpredict3_segment<T>(tp, order_v, nvtx, v_begin, v_end, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, ring_floor, sync3, none, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1198,16 +1230,21 @@ bool unpredict3_wanted(const ListDesc &ld)
 	for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == 6 || ld.stype[c] == 8) return true;
 	return false;
 }
+// segs: triples (first decode rank, end, component of the mesh); list_off: n_lists + 1 offsets into segs.  Lists run in parallel
+// workgroups, the segments of one list one after the other.  seg_start (every component's first decode rank + end) and done
+// (ld.ncomp x nseg flags, zeroed) let a chain wait for the component that owns an older vertex it reads.
 void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand, const void *crec,
-                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists)
+                       const uint8_t *planes, const ListDesc &ld, uint8_t *rec, const uint32_t *segs, const uint32_t *list_off, uint32_t n_lists,
+                       const uint32_t *seg_start, uint32_t nseg, uint32_t *done)
 {
 	if (!nvtx || !ld.ncomp || !n_lists) return;
+	const CrossSync xs{ seg_start, nseg, done };
 	auto go3 = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
 		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64 * chain_waves()), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
-		                   segs, list_off);
+		                   segs, list_off, xs);
 	};
 	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + kQueue * kQueueCols * 4;
 	auto go = [&](auto kern, int stype) {
@@ -1216,7 +1253,7 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		if (!sel.n) return;
 		(void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64), lds_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel,
-		                   segs, list_off);
+		                   segs, list_off, xs);
 	};
 	// components of different types are independent chains too: their kernels may overlap on the device
 	go(k_unpredict2<float>, 0); go(k_unpredict2<uint32_t>, 4); go(k_unpredict2<int32_t>, 5);

@@ -190,18 +190,25 @@ struct StartFaces {
 	StartFaces(uint32_t n, BigVec<uint8_t> &gone_) : nf(n), gone(gone_) {}
 	void derive_order()
 	{
+		// between two rehash checks every insertion extends the descending block at the front of the list, and the policy only
+		// looks at the count when it passes _M_next_resize: whole runs of keys are handled at once (a handful of steps for 10^8 faces)
 		std::__detail::_Prime_rehash_policy pol;
 		std::size_t nbkt = 1;
 		std::vector<Block> list;   // front ... back
-		for (uint32_t k = 0; k < nf; ++k) {
+		uint32_t k = 0;
+		while (k < nf) {
 			std::pair<bool, std::size_t> rh = pol._M_need_rehash(nbkt, k, 1);
 			if (rh.first) {
 				nbkt = rh.second;
 				std::reverse(list.begin(), list.end());
 				for (Block &b : list) std::swap(b.first, b.last);
 			}
-			if (!list.empty() && list.front().first == k - 1 && list.front().first >= list.front().last) list.front().first = k;   // extend the descending front block
-			else list.insert(list.begin(), Block{ k, k });
+			// keys k .. k_end - 1 arrive without another look at the policy (it compares the count with _M_next_resize first)
+			const uint64_t quiet = (uint64_t)pol._M_next_resize;
+			const uint32_t k_end = (uint32_t)std::min<uint64_t>(nf, std::max<uint64_t>((uint64_t)k + 1, quiet));
+			if (!list.empty() && k > 0 && list.front().first == k - 1 && list.front().first >= list.front().last) list.front().first = k_end - 1;   // extend the descending front block
+			else list.insert(list.begin(), Block{ k_end - 1, k });
+			k = k_end;
 		}
 		blocks.swap(list);
 		have_order = true;
@@ -501,8 +508,10 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 unsigned host_threads()
 {
 	if (const char *e = getenv("HRY_HOST_THREADS")) { int v = atoi(e); return v > 0 ? (unsigned)v : 1u; }
+	// up to 32, and at most an eighth of a large node's cores: eight processes (one per GPU) share the node
 	unsigned hw = std::thread::hardware_concurrency();
-	return std::max(1u, std::min(16u, hw ? hw : 1u));
+	if (!hw) hw = 1;
+	return std::max(1u, std::min(32u, hw >= 128 ? hw / 8 : std::min(16u, hw)));
 }
 // below this many remaining faces the analysis passes cost more than they save (HRY_PARALLEL_MIN_FACES overrides, tests)
 uint32_t parallel_min_faces()
