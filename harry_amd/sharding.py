@@ -91,27 +91,40 @@ def allgather_combine(table: np.ndarray, shard: "hc.Mesh", device: torch.device)
 
 
 # ---- the finished segments -> rank 0 -------------------------------------------------------------------------------
-def gather_segments(container: bytes, device: torch.device):
-    """Variable-length gather of every rank's one-segment container on rank 0: all_gather of the sizes, then one padded
-    gather of the payloads.  Returns the list of containers (rank order) on rank 0, None elsewhere."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    size = torch.tensor([len(container)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(size) for _ in range(world)]
-    dist.all_gather(sizes, size)
-    sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    buf[:len(container)] = torch.frombuffer(bytearray(container), dtype=torch.uint8).to(device)
-    out = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, out, dst=0)
-    if rank != 0:
-        return None
-    return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+class SegmentGather:
+    """Variable-length gather of every rank's one-segment container on rank 0: all_gather of the sizes, then one padded gather
+    of the payloads, started asynchronously so that it overlaps whatever the rank does next (the collective runs on RCCL's
+    own stream); finish() waits for it and, on rank 0, merges the segments into ONE .hry v0.3 (hry_merge)."""
+
+    def __init__(self, container: bytes, device: torch.device):
+        self.single = not dist.is_initialized() or dist.get_world_size() == 1
+        self.container = container
+        if self.single:
+            return
+        world, self.rank = dist.get_world_size(), dist.get_rank()
+        size = torch.tensor([len(container)], dtype=torch.int64, device=device)
+        sizes = [torch.zeros_like(size) for _ in range(world)]
+        dist.all_gather(sizes, size)
+        self.sizes = [int(s.item()) for s in sizes]
+        cap = max(max(self.sizes), 1)
+        self.buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+        self.buf[:len(container)] = torch.frombuffer(bytearray(container), dtype=torch.uint8).to(device)
+        self.out = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)] if self.rank == 0 else None
+        # under RCCL the gather is asynchronous (its own stream, device buffers); gloo would run it on a host thread next to the
+        # rank's own host work (the replay of the decode is host-bound), so there it completes right here
+        self.work = dist.gather(self.buf, self.out, dst=0, async_op=dist.get_backend() == "nccl")
+
+    def finish(self):
+        """rank 0: the merged container; other ranks: None"""
+        if self.single:
+            return hc.merge([self.container])
+        if self.work is not None:
+            self.work.wait()
+        if self.rank != 0:
+            return None
+        return hc.merge([self.out[r][:self.sizes[r]].cpu().numpy().tobytes() for r in range(len(self.sizes))])
 
 
 def merge_on_rank0(container: bytes, device: torch.device):
     """rank 0: ONE .hry v0.3 container holding every rank's segment; other ranks: None"""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return hc.merge([container])
-    parts = gather_segments(container, device)
-    return hc.merge(parts) if parts is not None else None
+    return SegmentGather(container, device).finish()
