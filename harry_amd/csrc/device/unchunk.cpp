@@ -334,7 +334,12 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 		const RestartCounters none;
 		std::vector<uint32_t> comp_first;
 		std::vector<std::pair<uint32_t, uint32_t>> refs;
-		replay_span(*m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, comp_first, refs, &live);
+		const bool count = getenv("HRY_PERF") != nullptr;
+		PerfCounters pc;
+		if (count) pc.start();
+		if (onlydeg == 3 && !getenv("HRY_GENERIC_REPLAY")) replay_triangles<true>(*m, conn, seen.data(), order_v.data(), cur, comp_first, refs, &live);   // the lean loop
+		else replay_span(*m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, comp_first, refs, &live);
+		if (count) { pc.stop(); pc.report("cut-border replay (pipelined decode, publishing)", (double)cur.he - 2.0 * cur.face); }
 		if (cur.face != nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
 		if (cur.he != ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
 		if (cur.next_id != nv) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");

@@ -4,6 +4,7 @@
 // Same flat node pool as the encoder-side walk (cbm_walk.cpp).
 #pragma once
 #include "host.hpp"
+#include "perf_counters.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -368,6 +369,277 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen_shared, uint32_t *order_v, Repl
 	return eom;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same replay for the case that carries the headline workload: every polygon is a triangle, one span from the start of
+// the stream, symbols in planes.  Hardware counters on the generic loop (EPYC 9575F, HRY_PERF=1) showed what bounds it:
+// 274 instructions per triangle at 5.8 instructions per cycle, 0.004 branch misses and 0.03 last-level misses per
+// triangle -- instruction count, nothing else.  So this loop is written for few instructions: a triangle per operation (no
+// fan bookkeeping, the face offsets are 3 f and filled up front), the operation planes end in a sentinel that the switch
+// rejects (no bounds check per symbol), gate neighbours are loaded only by the operations that use them, nodes and the top
+// part through bare pointers, the order counters in the shared array only.  Same checks against a corrupt stream as
+// replay_span, same results (the tests run both on the same inputs).
+// ---------------------------------------------------------------------------------------------------------
+template <bool LIVE>
+bool replay_triangles(Mesh &m, const std::vector<uint8_t> *conn, uint16_t *seen, uint32_t *order_v, ReplayCursor &cur,
+                      std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs, ReplayLive *live)
+{
+	using namespace replay_detail;
+	struct Node { uint32_t v, a; int32_t prev, next; };
+	struct Part { int32_t head, tail; uint32_t size, edge_begin; };
+	const uint32_t nv = m.nv, nf = m.nf;
+	const uint64_t ne_max = m.org.size();
+	uint32_t *const org = m.org.data(), *const twin = m.twin.data();
+	{   // a triangle mesh: face f owns the half-edges 3 f .. 3 f + 2 (the counts are checked against the header at the end)
+		uint32_t *fo = m.face_off.data();
+		const size_t n = std::min<uint64_t>((uint64_t)nf, ne_max / 3) + 1;
+		for (size_t i = 0; i < n; ++i) fo[i] = (uint32_t)(3 * i);
+	}
+	// operation planes with a sentinel behind the last symbol
+	std::vector<uint8_t> opl[8];
+	const uint8_t *opc[8];
+	for (int k = 0; k < 8; ++k) {
+		opl[k].reserve(conn[13 + k].size() + 1);
+		opl[k].assign(conn[13 + k].begin(), conn[13 + k].end());
+		opl[k].push_back(0xff);
+		opc[k] = opl[k].data();
+	}
+	// the other connectivity planes are read a few times per mesh: checked cursors
+	size_t rc[13] = { 0 };
+	auto rbyte = [&](int p) -> uint32_t { if (rc[p] >= conn[p].size()) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)"); return conn[p][rc[p]++]; };
+	auto ru32 = [&](int first) -> uint32_t { uint32_t v = rbyte(first); v |= rbyte(first + 1) << 8; v |= rbyte(first + 2) << 16; v |= rbyte(first + 3) << 24; return v; };
+	auto r_elem = [&]() -> int { uint32_t z = ru32(1); return (int)((z >> 1) ^ ((z & 1) ? 0xffffffffu : 0u)); };
+	auto r_part = [&]() -> int { uint32_t v = rbyte(5); v |= rbyte(6) << 8; return (int)v; };
+	auto r_vertid = [&]() -> uint32_t { return ru32(7); };
+
+	std::vector<Node> pool;
+	pool.reserve(1 << 14);
+	Node *P = pool.data();
+	int32_t free_head = -1;
+	std::vector<Part> parts;
+	uint16_t *const onb = LIVE ? live->on_border.data() : nullptr;
+	auto make = [&](uint32_t v, uint32_t a) -> int32_t {
+		if (LIVE) ++onb[v];
+		int32_t i = free_head;
+		if (i >= 0) free_head = P[i].next;
+		else { i = (int32_t)pool.size(); pool.push_back(Node()); P = pool.data(); }
+		P[i].v = v; P[i].a = a; P[i].prev = -1; P[i].next = -1;
+		return i;
+	};
+	auto drop = [&](int32_t i) { if (LIVE) --onb[P[i].v]; P[i].next = free_head; free_head = i; };
+	auto append = [&](Part &p, int32_t i) { P[i].prev = p.tail; P[i].next = -1; if (p.tail >= 0) P[p.tail].next = i; else p.head = i; p.tail = i; ++p.size; };
+	auto prepend = [&](Part &p, int32_t i) { P[i].next = p.head; P[i].prev = -1; if (p.head >= 0) P[p.head].prev = i; else p.tail = i; p.head = i; ++p.size; };
+	auto unlink_tail = [&](Part &p) -> int32_t { int32_t i = p.tail; p.tail = P[i].prev; if (p.tail >= 0) P[p.tail].next = -1; else p.head = -1; --p.size; return i; };
+	auto unlink_head = [&](Part &p) -> int32_t { int32_t i = p.head; p.head = P[i].next; if (p.head >= 0) P[p.head].prev = -1; else p.tail = -1; --p.size; return i; };
+	auto discard_top = [&]() { for (int32_t i = parts.back().head; i >= 0;) { int32_t nx = P[i].next; drop(i); i = nx; } parts.pop_back(); };
+	auto border = [&]() -> uint32_t {   // cutborder.h:217-248
+		Part &p = parts.back();
+		if (p.size - (p.edge_begin ? 0u : 1u) == 1u) { discard_top(); return O_BORDER; }
+		const bool rename = !p.edge_begin;
+		int32_t t = unlink_tail(p);
+		if (!p.edge_begin) drop(unlink_head(p));
+		prepend(p, t);
+		p.edge_begin = 0;
+		return rename ? O_CONNFWD : O_BORDER;
+	};
+	auto at = [&](int i, int pi, uint32_t &before) -> int32_t {   // cutborder.h:114-123
+		if ((size_t)pi >= parts.size()) throw Error(HRY_E_FORMAT, "corrupt stream (part index)");
+		Part &pt = parts[parts.size() - 1 - (size_t)pi];
+		int32_t n;
+		if (i > 0) {
+			if ((uint32_t)i > pt.size) throw Error(HRY_E_FORMAT, "corrupt stream (element offset)");
+			n = pt.head;
+			for (int k = 1; k < i; ++k) n = P[n].next;
+			before = (uint32_t)(i - 1);
+		} else {
+			if ((uint32_t)(-i) >= pt.size) throw Error(HRY_E_FORMAT, "corrupt stream (element offset)");
+			n = pt.tail;
+			for (int k = 0; k < -i; ++k) n = P[n].prev;
+			before = pt.size - 1 - (uint32_t)(-i);
+		}
+		return n;
+	};
+
+	uint32_t next_id = cur.next_id, face = cur.face, he = cur.he;
+	uint32_t he_pub = LIVE ? live->he_pub : 0u, face_pub = LIVE ? live->face_pub : 0u;
+	const uint32_t interval = LIVE ? live->interval : 0u;
+	bool eom = false;
+	for (;;) {
+		const uint32_t iop = rbyte(0);
+		if (iop == I_EOM) { eom = true; break; }
+		const uint32_t seg_first_id = next_id;
+		comp_first.push_back(seg_first_id);
+		const uint32_t comp_idx = (uint32_t)comp_first.size() - 1;
+		auto depends_on = [&](uint32_t vid) { if (vid < seg_first_id) refs.push_back({ comp_idx, vid }); };
+		auto chk = [&](uint32_t v) { if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)"); return v; };
+		auto fresh = [&]() { if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)"); return next_id++; };
+		uint32_t a = 0, b = 0, c = 0;
+		switch (iop) {   // decoder.h:46-77
+		case I_INIT: a = fresh(); b = fresh(); c = fresh(); break;
+		case I_TRI100: a = r_vertid(); b = fresh(); c = fresh(); break;
+		case I_TRI010: c = fresh(); b = r_vertid(); a = fresh(); break;
+		case I_TRI001: a = fresh(); b = fresh(); c = r_vertid(); break;
+		case I_TRI110: a = r_vertid(); b = r_vertid(); c = fresh(); break;
+		case I_TRI101: c = r_vertid(); b = fresh(); a = r_vertid(); break;
+		case I_TRI011: a = fresh(); b = r_vertid(); c = r_vertid(); break;
+		case I_TRI111: a = r_vertid(); b = r_vertid(); c = r_vertid(); break;
+		default: throw Error(HRY_E_FORMAT, "corrupt stream (init op)");
+		}
+		chk(a); chk(b); chk(c);
+		depends_on(a); depends_on(b); depends_on(c);
+		++seen[a]; ++seen[b]; ++seen[c];
+		if (face >= nf) throw Error(HRY_E_FORMAT, "corrupt stream (too many faces)");
+		if ((uint64_t)he + 3 > ne_max) throw Error(HRY_E_FORMAT, "corrupt stream (too many polygon edges)");
+		{
+			const uint32_t e0 = he, e1 = he + 1, e2 = he + 2;
+			he += 3; ++face;
+			twin[e0] = e0; twin[e1] = e1; twin[e2] = e2;
+			org[e0] = a; org[e1] = b; org[e2] = c;
+			switch (iop) {   // decoder.h:86-110: vertex ids are handed out in decode order, order_v is indexed by the id
+			case I_INIT: order_v[a] = e0; order_v[b] = e1; order_v[c] = e2; break;
+			case I_TRI100: order_v[b] = e1; order_v[c] = e2; break;
+			case I_TRI010: order_v[c] = e2; order_v[a] = e0; break;
+			case I_TRI001: order_v[a] = e0; order_v[b] = e1; break;
+			case I_TRI110: order_v[c] = e2; break;
+			case I_TRI101: order_v[b] = e1; break;
+			case I_TRI011: order_v[a] = e0; break;
+			default: break;
+			}
+			parts.push_back(Part{ -1, -1, 0, 1 });
+			append(parts.back(), make(a, e0));
+			append(parts.back(), make(b, e1));
+			append(parts.back(), make(c, e2));
+		}
+
+		while (!parts.empty()) {
+			if (LIVE && face - face_pub >= interval) { live->publish(face, he, next_id, false); he_pub = live->he_pub; face_pub = live->face_pub; }
+			Part *T = &parts.back();
+			if (T->size < 2) throw Error(HRY_E_FORMAT, "corrupt stream (border part)");
+			const int32_t tn = T->tail, hn = T->head;
+			const uint32_t v0 = P[tn].v, gate = P[tn].a, v1 = P[hn].v;
+			uint32_t k = seen[v1];
+			k = k == 0 ? 0u : k > 8u ? 7u : k - 1u;   // models.h:101-105
+			const uint32_t op = *opc[k];
+			opc[k] += op != 0xffu;                      // (the sentinel is never passed)
+			uint32_t v2, realop = op, lk_next = NONE32, lk_prev = NONE32;   // lk_*: cut-border edges the new triangle closes (decoder.h:182-197)
+			int32_t first = -1, second = -1;
+			switch (op) {   // decoder.h:133-166
+			case O_NEWVTX: {
+				if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)");
+				v2 = next_id++;
+				first = tn;
+				second = make(v2, 0);
+				T = &parts.back();
+				P[second].prev = tn; P[tn].next = second; T->tail = second; ++T->size;   // append
+				break;
+			}
+			case O_CONNFWD: {
+				if (!T->edge_begin) { border(); continue; }   // renamed border (cutborder.h:177-179): no triangle
+				v2 = P[P[hn].next].v;
+				lk_next = P[hn].a;
+				if (T->size == 3) { lk_prev = P[P[tn].prev].a; discard_top(); realop = O_CLOSE; }
+				else { drop(unlink_head(*T)); first = T->tail; }
+				break;
+			}
+			case O_CONNBWD: {
+				lk_prev = P[P[tn].prev].a;
+				drop(unlink_tail(*T));
+				first = T->tail;
+				v2 = P[first].v;
+				break;
+			}
+			case O_NM: {
+				v2 = r_vertid();
+				chk(v2);
+				depends_on(v2);
+				first = tn;
+				second = make(v2, 0);
+				T = &parts.back();
+				P[second].prev = tn; P[tn].next = second; T->tail = second; ++T->size;
+				break;
+			}
+			case O_SPLIT: {
+				const int i = r_elem();
+				uint32_t before;
+				const int32_t hit = at(i, 0, before);
+				const size_t oi = parts.size() - 1;
+				const int32_t g = unlink_tail(parts[oi]);
+				if (hit == g) throw Error(HRY_E_FORMAT, "corrupt stream (split at the gate)");
+				Part np{ -1, -1, 0, 1 };
+				if (before > 0) {
+					Part &old = parts[oi];
+					const int32_t last = P[hit].prev;
+					np.head = old.head; np.tail = last; np.size = before;
+					P[last].next = -1; P[hit].prev = -1;
+					old.head = hit; old.size -= before;
+				}
+				append(parts[oi], g);
+				second = make(P[hit].v, P[hit].a);
+				append(np, second);
+				np.edge_begin = parts[oi].edge_begin;
+				parts[oi].edge_begin = 1;
+				parts.push_back(np);
+				first = g;
+				v2 = P[hit].v;
+				break;
+			}
+			case O_UNION: {
+				const int i = r_elem();
+				const int pp = r_part();
+				if (pp <= 0) throw Error(HRY_E_FORMAT, "corrupt stream (union with the current part)");
+				uint32_t before;
+				const int32_t hit = at(i, pp, before);
+				const size_t ci = parts.size() - 1, oi = ci - (size_t)pp;
+				Part other = parts[oi];
+				Part &cp = parts[ci];
+				first = cp.tail;
+				if (hit != other.head) {
+					P[other.tail].next = other.head; P[other.head].prev = other.tail;
+					const int32_t last = P[hit].prev;
+					P[last].next = -1; P[hit].prev = -1;
+					other.head = hit; other.tail = last;
+				}
+				P[cp.tail].next = other.head; P[other.head].prev = cp.tail;
+				cp.tail = other.tail; cp.size += other.size;
+				second = make(P[hit].v, P[hit].a);
+				append(parts[ci], second);
+				v2 = P[hit].v;
+				parts.erase(parts.begin() + (long)oi);
+				break;
+			}
+			case O_BORDER: border(); continue;
+			default: throw Error(HRY_E_FORMAT, op == 0xffu ? "corrupt stream (connectivity plane exhausted)" : "corrupt stream (op)");
+			}
+			// the new triangle (gate's twin, v1 -> v0 -> v2)
+			if (face >= nf) throw Error(HRY_E_FORMAT, "corrupt stream (too many faces)");
+			if ((uint64_t)he + 3 > ne_max) throw Error(HRY_E_FORMAT, "corrupt stream (too many polygon edges)");
+			const uint32_t e0 = he, e1 = he + 1, e2 = he + 2;
+			he += 3; ++face;
+			org[e0] = v1; org[e1] = v0; org[e2] = v2;
+			twin[e0] = gate; twin[gate] = e0;             // decoder.h:179 merge(gate, e0)
+			twin[e1] = e1; twin[e2] = e2;
+			if (LIVE && gate < he_pub) { live->pending.push_back(gate); live->pending.push_back(e0); }
+			switch (realop) {   // decoder.h:182-197
+			case O_CONNFWD: P[first].a = e1; break;
+			case O_CONNBWD: P[first].a = e2; break;
+			case O_CLOSE: break;
+			default: P[first].a = e1; P[second].a = e2; break;   // SPLIT, UNION, NEWVTX, NM
+			}
+			++seen[v0]; ++seen[v1]; ++seen[v2];
+			if (op == O_NEWVTX) order_v[v2] = e2;
+			if (lk_next != NONE32) {   // CONNFWD / CLOSE: the triangle's last edge meets the next cut-border edge
+				twin[lk_next] = e2; twin[e2] = lk_next;
+				if (LIVE && lk_next < he_pub) { live->pending.push_back(lk_next); live->pending.push_back(e2); }
+			}
+			if (lk_prev != NONE32) {   // CONNBWD / CLOSE: its second edge meets the previous one
+				twin[lk_prev] = e1; twin[e1] = lk_prev;
+				if (LIVE && lk_prev < he_pub) { live->pending.push_back(lk_prev); live->pending.push_back(e1); }
+			}
+		}
+	}
+	cur.next_id = next_id; cur.face = face; cur.he = he;
+	return eom;
+}
+
 // Dependency levels of the attribute reconstruction: level 0 = the component names no older vertex; else 1 + the highest
 // level among the components that own a vertex it names.  seg_start: first vertex id of every component (ascending).
 // A component that created no vertex shares its first id with its successor: upper_bound then lands on the last such entry,
@@ -398,7 +670,13 @@ void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std
 	const RestartCounters none;
 	std::vector<std::pair<uint32_t, uint32_t>> refs;
 	seg_start.clear();
-	replay_span(m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, seg_start, refs);
+	if (getenv("HRY_PERF")) {
+		PerfCounters pc;
+		pc.start();
+		replay_span(m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, seg_start, refs);
+		pc.stop();
+		pc.report("cut-border replay", (double)cur.he - 2.0 * cur.face);
+	} else replay_span(m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, seg_start, refs);
 	if (cur.face != m.nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
 	if (cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
 	order_v.resize(cur.next_id);

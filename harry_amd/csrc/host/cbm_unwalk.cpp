@@ -46,6 +46,28 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
 	const int fixed_numtri = ndeg <= 1 ? onlydeg - 2 : -1;
 	const unsigned n_threads = host_threads();
 	if (restarts.empty() || n_threads < 2 || m.nf < parallel_min_faces() || counters.size() != restarts.size()) {
+		if (fixed_numtri == 1 && !getenv("HRY_GENERIC_REPLAY")) {
+			// triangles only: the lean loop (cbm_replay.hpp: replay_triangles), same results
+			m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;
+			m.org.resize(m.declared_ne);
+			m.twin.resize(m.declared_ne);
+			order_v.assign(m.nv, 0);
+			BigVec<uint16_t> seen(m.nv, 0);
+			ReplayCursor cur;
+			std::vector<std::pair<uint32_t, uint32_t>> refs;
+			seg_start.clear();
+			PerfCounters pc;
+			const bool count = getenv("HRY_PERF") != nullptr;
+			if (count) pc.start();
+			replay_triangles<false>(m, conn_planes, seen.data(), order_v.data(), cur, seg_start, refs, nullptr);
+			if (count) { pc.stop(); pc.report("cut-border replay (triangles)", (double)cur.he - 2.0 * cur.face); }
+			if (cur.face != m.nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
+			if (cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
+			order_v.resize(cur.next_id);
+			replay_levels(seg_start, refs, seg_level);
+			seg_start.push_back(cur.next_id);
+			return;
+		}
 		Planes rd{ conn_planes, { 0 }, fixed_numtri };
 		cut_border_replay_with(m, rd, order_v, seg_start, seg_level);
 		return;

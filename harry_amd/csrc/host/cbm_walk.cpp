@@ -9,6 +9,7 @@
 // with index links for all parts of the border, and symbol planes + global positions instead of an immediate
 // call into the arithmetic coder.
 #include "host.hpp"
+#include "perf_counters.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -484,8 +485,17 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	em.eval_model = eval_op_model;
 	em.attach((size_t)m.ne() + m.ntri() + 16, m.nv, m.nf);   // every half-edge ends at most one border operation, every triangle one other
 	uint32_t next_id = 0, consumed = 0;
+	const bool count = getenv("HRY_PERF") != nullptr;   // hardware counters of this thread around the first component's walk
 	do {
 		uint32_t f = pool.next();
+		if (count && consumed == 0) {
+			PerfCounters pc;
+			pc.start();
+			walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
+			pc.stop();
+			pc.report(eval_op_model ? "cut-border walk (with the operation model)" : "cut-border walk", (double)(em.halfedges - 2.0 * consumed));
+			continue;
+		}
 		walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 		// The operation model of the reference stream adapts across the whole file (models.h:49-120), so a walk that evaluates
 		// it is one sequence.  Without it (chunked profile: symbol + order class only) the remaining components are walked on

@@ -300,3 +300,21 @@ def test_threaded_twin_matching_equals_sequential(case):
     assert len(ref) >= 1 << 18, "the case must be large enough for the threaded path"
     for t in (2, 7):
         assert np.array_equal(ref, twins(t)), t
+
+
+@pytest.mark.parametrize("case", ["torus", "open_grid", "ico", "multi_nm", "tiny"])
+def test_lean_triangle_replay_equals_generic_replay(case, monkeypatch):
+    """cbm_replay.hpp: replay_triangles (few instructions per triangle, the headline decode's loop) against replay_span on the
+    same connectivity planes: borders, splits / unions (torus), several components, shared non-manifold vertices."""
+    mesh = {"torus": lambda: mg.torus(40, 36), "open_grid": lambda: mg.grid(31, 17), "ico": lambda: mg.icosphere(4),
+            "multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 9, 10, polys="tri"), 7, 4), "tiny": lambda: mg.grid(2)}[case]()
+    monkeypatch.setenv("HRY_HOST_THREADS", "1")
+    out = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("HRY_GENERIC_REPLAY", "1")
+        m = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+        dec, order_v, seg_start, seg_level, _ = hc.walk_and_replay(m, False)
+        out.append((dec.face_offsets(), dec.org(), dec.twin(), order_v, seg_start, seg_level))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
