@@ -17,7 +17,7 @@ struct hry_walk {
 	{
 		if (op_sym.size() == w.op_sc.size()) return;
 		op_sym.resize(w.op_sc.size()); op_class.resize(w.op_sc.size());
-		for (size_t i = 0; i < w.op_sc.size(); ++i) { op_sym[i] = w.op_sc[i] & 7; op_class[i] = w.op_sc[i] >> 3; }
+		for (size_t i = 0; i < w.op_sc.size(); ++i) { op_sym[i] = op_u8(w.op_sc[i]) & 7; op_class[i] = op_u8(w.op_sc[i]) >> 3; }
 	}
 };
 
@@ -353,7 +353,7 @@ int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_p
 				pl.resize(r.grp_val[g].size());
 				for (size_t i = 0; i < pl.size(); ++i) pl[i] = (uint8_t)(r.grp_val[g][i] >> (8 * b));
 			}
-		for (size_t i = 0; i < r.op_sc.size(); ++i) planes[13 + (r.op_sc[i] >> 3)].push_back(r.op_sc[i] & 7);
+		for (size_t i = 0; i < r.op_sc.size(); ++i) planes[13 + (op_u8(r.op_sc[i]) >> 3)].push_back(op_u8(r.op_sc[i]) & 7);
 		std::unique_ptr<hry_mesh> m(new hry_mesh());
 		std::unique_ptr<hry_walk> w(new hry_walk());
 		m->m.nv = src->m.nv; m->m.nf = src->m.nf; m->m.declared_ne = src->m.ne(); m->m.have_degree = src->m.have_degree;

@@ -59,6 +59,12 @@ constexpr uint32_t kRestartWords = G_COUNT + 8 + 4;
 std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks, const std::vector<NamedVertex> &named,
                                                 std::vector<RestartCounters> &counters);
 
+// One byte per cut-border operation: symbol | order class << 3.  A distinct type on purpose: stores through a character
+// type may alias anything, so a plain uint8_t stream makes the compiler reload every pointer of the walk's hot loop after each
+// operation it writes; an enumeration with the same representation does not (read it back through uint8_t freely).
+enum class OpByte : uint8_t {};
+inline uint8_t op_u8(OpByte b) { return (uint8_t)b; }
+
 struct WalkResult {
 	BigVec<uint32_t> order_v;   // one half-edge per coded vertex, in coding order (attrcode.h:297,310-314)
 	BigVec<uint32_t> order_f;   // one half-edge per face, in coding order (attrcode.h:298,315-319)
@@ -67,7 +73,7 @@ struct WalkResult {
 	BigVec<uint32_t> grp_pos[G_COUNT];
 	// cut-border operations: raw symbol | order class << 3 (one byte each), and -- for the reference stream -- the
 	// order-conditioned model already evaluated (models.h:91-119) as cumulative-frequency triples
-	BigVec<uint8_t> op_sc;
+	BigVec<OpByte> op_sc;
 	uint32_t n_op_class[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // operations per order class (sizes of the chunked container's operation planes)
 	BigVec<uint32_t> op_l, op_h, op_t, op_pos;
 	std::vector<ComponentMark> marks; // one per connected component, in coding order

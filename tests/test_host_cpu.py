@@ -318,3 +318,24 @@ def test_lean_triangle_replay_equals_generic_replay(case, monkeypatch):
         out.append((dec.face_offsets(), dec.org(), dec.twin(), order_v, seg_start, seg_level))
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["torus", "open_grid", "ico", "multi_nm", "tiny"])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_lean_triangle_walk_equals_generic_walk(case, threads, monkeypatch):
+    """cbm_walk.cpp: walk_component_tri (the headline encode's loop) against the generic walk_component: same order, same
+    symbols, same repaired twins."""
+    mesh = {"torus": lambda: mg.torus(40, 36), "open_grid": lambda: mg.grid(31, 17), "ico": lambda: mg.icosphere(4),
+            "multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 9, 10, polys="tri"), 7, 4), "tiny": lambda: mg.grid(2)}[case]()
+    monkeypatch.setenv("HRY_HOST_THREADS", str(threads))
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
+    out = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("HRY_GENERIC_WALK", "1")
+        m = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+        w = m.host_walk(plain=True)
+        out.append((w, m.twin()))
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
+    assert np.array_equal(out[0][1], out[1][1])
