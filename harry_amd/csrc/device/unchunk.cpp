@@ -515,7 +515,11 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// the attribute streams wait for the connectivity streams' kernel: launched side by side, the long attribute waves took
 	// the SIMD slots the short connectivity waves needed (15 ms instead of 1 ms on a 12 M-triangle mesh), and the host replay
 	// -- the critical path -- waits for exactly those
-	HIP_OK(hipStreamWaitEvent(cx.stream3, getenv("HRY_ATTR_SIDE_BY_SIDE") ? cx.ev_x[0] : cx.ev[2], 0));
+	// ... unless the mesh takes the pipelined decode (one large component, triangles replayed at ~6 ns each): there the device
+	// chain, not the replay, ends the decode, and it can start only when the attribute streams are done -- side by side then
+	const bool chain_bound = restarts.empty() && nsym[7] == 0 && vc == m->nv && unpredict3_covers(ldv);
+	const bool side_by_side = getenv("HRY_ATTR_SIDE_BY_SIDE") ? atoi(getenv("HRY_ATTR_SIDE_BY_SIDE")) != 0 : chain_bound;
+	HIP_OK(hipStreamWaitEvent(cx.stream3, side_by_side ? cx.ev_x[0] : cx.ev[2], 0));
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
 	launch_chunk_decode(cx.stream3, cx.d_cjobs.as<StreamJob>() + n_conn_streams, (uint32_t)nstreams - n_conn_streams, cx.d_init.as<uint32_t>(),
 	                    cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>() + n_conn_streams, cx.d_csizes.as<uint32_t>() + n_conn_streams);
