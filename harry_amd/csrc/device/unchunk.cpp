@@ -211,7 +211,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 
 	std::exception_ptr consumer_error;
 	std::vector<SliceClock> clocks;
-	uint32_t min_slice = 1u << 15;
+	uint32_t min_slice = 1u << 16;   // (the chain is the longer path since the replay became lean: fewer, larger launches)
 	if (const char *e = getenv("HRY_PIPELINE_SLICE")) min_slice = std::max(64u, (uint32_t)strtoul(e, nullptr, 10));
 	const Clock::time_point t_begin = g_t0;
 	// vertex records come back slice by slice into pinned memory and are copied into the mesh by the consumer as they land
