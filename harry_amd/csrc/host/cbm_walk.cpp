@@ -478,6 +478,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 // cursors and counters in locals (the mark arrays and the operation stream are not character types, so their stores do not
 // force reloads), derives the triangle's edges from one division, loads the gate's neighbours only where an operation needs
 // them, tests connect-forward / -backward before searching the border, and writes the Emitter back once per component.
+template <bool MODEL>   // MODEL: the operation model of the reference stream is evaluated per operation (compat profile), through the Emitter
 static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, Emitter &em, uint32_t &next_id_io, uint32_t &consumed_io)
 {
 	WalkResult &w = em.w;
@@ -496,6 +497,7 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 	// (1 M triangles: 7.8 -> 7.4 ms; 28 M, beyond the caches: 293 -> 237 ms)
 	static const int pf_level = [] { const char *e = getenv("HRY_WALK_PREFETCH"); return e ? atoi(e) : 2; }();
 	auto emit = [&](uint32_t s, uint32_t order) {
+		if (MODEL) { em.op(s, (int)order); return; }
 		uint32_t k = order == 0 ? 0u : order > 8u ? 7u : order - 1u;   // models.h:101-105
 		++n_op[k]; ++n_ops;
 		*opc++ = (OpByte)(s | (k << 3));
@@ -597,7 +599,8 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 	sync_n();
 	for (int i = 0; i < 8; ++i) em.n_op[i] += n_op[i];
 	em.halfedges += 3 * (consumed - consumed_io);
-	em.op_cur = opc; em.ov_cur = ovc; em.of_cur = ofc;
+	if (!MODEL) em.op_cur = opc;
+	em.ov_cur = ovc; em.of_cur = ofc;
 	if (changed) w.twins_changed = true;
 	next_id_io = next_id; consumed_io = consumed;
 }
@@ -622,17 +625,19 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	const bool count = getenv("HRY_PERF") != nullptr;   // hardware counters of this thread around the first component's walk
 	do {
 		uint32_t f = pool.next();
-		const bool lean = DEG == 3 && !eval_op_model && !getenv("HRY_GENERIC_WALK");
+		const bool lean = DEG == 3 && !getenv("HRY_GENERIC_WALK");
 		if (count && consumed == 0) {
 			PerfCounters pc;
 			pc.start();
-			if (lean) walk_component_tri(m, st, f, cb, em, next_id, consumed);
+			if (lean && eval_op_model) walk_component_tri<true>(m, st, f, cb, em, next_id, consumed);
+			else if (lean) walk_component_tri<false>(m, st, f, cb, em, next_id, consumed);
 			else walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 			pc.stop();
 			pc.report(eval_op_model ? "cut-border walk (with the operation model)" : "cut-border walk", (double)(em.halfedges - 2.0 * consumed));
 			continue;
 		}
-		if (lean) walk_component_tri(m, st, f, cb, em, next_id, consumed);
+		if (lean && eval_op_model) walk_component_tri<true>(m, st, f, cb, em, next_id, consumed);
+		else if (lean) walk_component_tri<false>(m, st, f, cb, em, next_id, consumed);
 		else walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 		// The operation model of the reference stream adapts across the whole file (models.h:49-120), so a walk that evaluates
 		// it is one sequence.  Without it (chunked profile: symbol + order class only) the remaining components are walked on
@@ -897,7 +902,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 				em.eval_model = false;
 				em.attach((size_t)2 * A.n_halfedges[k] - 2 * (size_t)nfc + 16, A.fresh[k], nfc);
 				uint32_t next_id = id_base[k], consumed = 0;
-				if (DEG == 3 && !getenv("HRY_GENERIC_WALK")) walk_component_tri(m, st, A.seed[k], cb, em, next_id, consumed);
+				if (DEG == 3 && !getenv("HRY_GENERIC_WALK")) walk_component_tri<false>(m, st, A.seed[k], cb, em, next_id, consumed);
 				else walk_component<DEG>(m, st, eface_tab, A.seed[k], cb, em, next_id, consumed);
 				em.detach();
 				if (next_id != id_base[k + 1] || consumed != nfc) throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
