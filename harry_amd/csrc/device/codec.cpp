@@ -397,6 +397,8 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	auto t_all = Clock::now();
 	cx.timing = hry_timing{};
 	check_codable(m);
+	// the reference's single stream carries one coder state and one numbering across the whole file: it does not shard
+	if (m.shard.active()) throw Error(HRY_E_UNSUPPORTED, "a shard of a larger mesh codes into the sharded chunked container only (HRY_PROFILE_CHUNKED)");
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds) { m.lists[l].bmin.assign(m.lists[l].stride(), 0); m.lists[l].bmax.assign(m.lists[l].stride(), 0); m.lists[l].have_bounds = true; }
 	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);

@@ -134,6 +134,15 @@ def test_shard_bounds_combine_to_the_whole_meshs_bounds(cx):
         assert bytes(sh.list_max(1)) == bytes(whole.list_max(1))
 
 
+def test_a_shard_does_not_code_into_the_reference_stream(cx):
+    gen = _mesh("mixed_nm")
+    whole = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices)
+    sh = hc.ShardPlan(whole, 2).extract(whole, 0)
+    with pytest.raises(hc.HryError) as e:
+        cx.write_hry(sh, profile=hc.PROFILE_COMPAT)
+    assert e.value.code == -3
+
+
 def test_merge_checks_headers(cx):
     a = _encode_sharded(cx, _mesh("mixed_nm"), 2, [])[2]
     b = _encode_sharded(cx, _mesh("faceprops"), 2, [])[2]
