@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <fstream>
 #include <limits>
 #include <list>
 #include <stdexcept>
@@ -122,6 +123,47 @@ struct Mesh {
 	std::vector<uint32_t> seeds;
 	std::vector<std::array<uint32_t, 6>> runs;   // first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges
 	bool is_shard() const { return g_nf != 0; }
+	// general bindings (structs/attr.h:101-189): what the OBJ reader creates and what any .hry may announce.  Off = the PLY
+	// layout above (kept implicit: the 28 M-triangle checks would not fit otherwise).
+	struct Bind {
+		bool on = false;
+		std::vector<uint16_t> face_reg, vtx_reg;                            // element -> region
+		int nb_face = 0, nb_vtx = 0, nb_corner = 0;                         // slots per element (max over regions)
+		std::vector<uint32_t> face_attr, vtx_attr, corner_attr;             // element x slot -> record of the bound list
+		std::vector<uint16_t> reg_facelist, reg_vtxlist, reg_cornerlist;    // region x slot -> list
+		std::vector<int> off_facelist{0}, off_vtxlist{0}, off_cornerlist{0};
+		int nregs_face() const { return (int)off_facelist.size() - 1; }
+		int nregs_vtx() const { return (int)off_vtxlist.size() - 1; }
+		int nfacelists(int r) const { return off_facelist[r + 1] - off_facelist[r]; }
+		int nvtxlists(int r) const { return off_vtxlist[r + 1] - off_vtxlist[r]; }
+		int ncornerlists(int r) const { return off_cornerlist[r + 1] - off_cornerlist[r]; }
+		int facelist(int r, int a) const { return reg_facelist[off_facelist[r] + a]; }
+		int vtxlist(int r, int a) const { return reg_vtxlist[off_vtxlist[r] + a]; }
+		int cornerlist(int r, int a) const { return reg_cornerlist[off_cornerlist[r] + a]; }
+		int add_face_region(int nface, int ncorner)   // mesh.h:106-113
+		{
+			off_facelist.push_back(off_facelist.back() + nface); off_cornerlist.push_back(off_cornerlist.back() + ncorner);
+			reg_facelist.resize(off_facelist.back(), 0); reg_cornerlist.resize(off_cornerlist.back(), 0);
+			return nregs_face() - 1;
+		}
+		int add_vtx_region(int n)   // mesh.h:114-119
+		{
+			off_vtxlist.push_back(off_vtxlist.back() + n); reg_vtxlist.resize(off_vtxlist.back(), 0);
+			return nregs_vtx() - 1;
+		}
+	} bind;
+	void make_general()   // the PLY layout spelled out: one face region -> list 0, one vertex region -> list 1, private records
+	{
+		if (bind.on) return;
+		bind.on = true;
+		bind.add_face_region(1, 0); bind.reg_facelist[0] = 0;
+		bind.add_vtx_region(1); bind.reg_vtxlist[0] = 1;
+		bind.nb_face = 1; bind.nb_vtx = 1; bind.nb_corner = 0;
+		bind.face_reg.assign(nf, 0); bind.vtx_reg.assign(nv, 0);
+		bind.face_attr.resize(nf); bind.vtx_attr.resize(nv);
+		for (uint32_t i = 0; i < nf; ++i) bind.face_attr[i] = i;
+		for (uint32_t i = 0; i < nv; ++i) bind.vtx_attr[i] = i;
+	}
 
 	uint32_t add_face(int ne)   // conn.h:83-93
 	{
@@ -463,8 +505,13 @@ struct Models {
 		// models.h:209-217; ModelMult::init(T) walks the bytes of the value as (signed) char (model.h:49-55)
 		for (size_t d = 0; d < m.have_deg.size(); ++d)
 			if (m.have_deg[d]) seed16(CTX_NUMTRI, (uint16_t)(d - 2));
-		seed16(CTX_REGFACE, 0);   // one face region, one vertex region
-		seed16(CTX_REGVTX, 0);
+		if (m.bind.on) {          // models.h:212-217
+			for (int r = 0; r < m.bind.nregs_face(); ++r) seed16(CTX_REGFACE, (uint16_t)r);
+			for (int r = 0; r < m.bind.nregs_vtx(); ++r) seed16(CTX_REGVTX, (uint16_t)r);
+		} else {
+			seed16(CTX_REGFACE, 0);   // one face region, one vertex region
+			seed16(CTX_REGVTX, 0);
+		}
 		for (size_t l = 0; l < m.lists.size(); ++l) {
 			attr_base.push_back((int)tab.size());
 			tab.emplace_back(256);                           // attr_type: DATA, HIST (+LHIST for corner lists) (models.h:201-203)
@@ -573,6 +620,8 @@ struct SymWriter {
 	void reg_face(uint16_t r) { bytes(CTX_REGFACE, (const uint8_t*)&r, 2); }
 	void reg_vtx(uint16_t r) { bytes(CTX_REGVTX, (const uint8_t*)&r, 2); }
 	void attr_type(int l, uint8_t t) { sym(md.attr_base[l] + ATTR_TYPE, t); }
+	void attr_ghist(int l, uint32_t d) { attr_type(l, A_HIST); bytes(md.attr_base[l] + ATTR_GHIST, (const uint8_t*)&d, 4); }    // io.h:99-103
+	void attr_lhist(int l, uint16_t d) { attr_type(l, A_LHIST); bytes(md.attr_base[l] + ATTR_LHIST, (const uint8_t*)&d, 2); }  // io.h:104-108
 };
 struct SymReader {
 	Models &md;
@@ -615,6 +664,8 @@ struct SymReader {
 	uint16_t reg_face() { if (planes) return 0; uint16_t v; bytes(CTX_REGFACE, (uint8_t*)&v, 2); return v; }
 	uint16_t reg_vtx() { if (planes) return 0; uint16_t v; bytes(CTX_REGVTX, (uint8_t*)&v, 2); return v; }
 	uint8_t attr_type(int l) { if (planes) return A_DATA; return (uint8_t)sym(md.attr_base[l] + ATTR_TYPE); }
+	uint32_t attr_ghist(int l) { uint32_t v; bytes(md.attr_base[l] + ATTR_GHIST, (uint8_t*)&v, 4); return v; }
+	uint16_t attr_lhist(int l) { uint16_t v; bytes(md.attr_base[l] + ATTR_LHIST, (uint8_t*)&v, 2); return v; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -882,11 +933,28 @@ static void write_header(const Mesh &m, std::vector<uint8_t> &out, int ver_minor
 	w.raw(magic, 6);
 	const bool sh = m.is_shard();   // a shard announces the whole mesh
 	w.put<uint32_t>(sh ? m.g_nv : m.nv); w.put<uint32_t>(sh ? m.g_nf : m.nf); w.put<uint32_t>(sh ? m.g_ne : m.num_edge());
-	w.put<uint16_t>(1); w.put<uint16_t>(1);                 // one face region, one vertex region
-	w.put<uint16_t>(1); w.put<uint16_t>(0); w.put<uint16_t>(0);   // face region: 1 face list (id 0), 0 corner lists
-	w.put<uint16_t>(1); w.put<uint16_t>(1);                 // vertex region: 1 list (id 1)
+	std::vector<char> seen(m.lists.size(), 1);
+	if (m.bind.on) {   // writer.cc:124-151: regions with the lists bound to them; lists no region names are not written
+		const Mesh::Bind &b = m.bind;
+		seen.assign(m.lists.size(), 0);
+		w.put<uint16_t>((uint16_t)b.nregs_face()); w.put<uint16_t>((uint16_t)b.nregs_vtx());
+		for (int r = 0; r < b.nregs_face(); ++r) {
+			w.put<uint16_t>((uint16_t)b.nfacelists(r)); w.put<uint16_t>((uint16_t)b.ncornerlists(r));
+			for (int a = 0; a < b.nfacelists(r); ++a) { seen[b.facelist(r, a)] = 1; w.put<uint16_t>((uint16_t)b.facelist(r, a)); }
+			for (int a = 0; a < b.ncornerlists(r); ++a) { seen[b.cornerlist(r, a)] = 1; w.put<uint16_t>((uint16_t)b.cornerlist(r, a)); }
+		}
+		for (int r = 0; r < b.nregs_vtx(); ++r) {
+			w.put<uint16_t>((uint16_t)b.nvtxlists(r));
+			for (int a = 0; a < b.nvtxlists(r); ++a) { seen[b.vtxlist(r, a)] = 1; w.put<uint16_t>((uint16_t)b.vtxlist(r, a)); }
+		}
+	} else {
+		w.put<uint16_t>(1); w.put<uint16_t>(1);                 // one face region, one vertex region
+		w.put<uint16_t>(1); w.put<uint16_t>(0); w.put<uint16_t>(0);   // face region: 1 face list (id 0), 0 corner lists
+		w.put<uint16_t>(1); w.put<uint16_t>(1);                 // vertex region: 1 list (id 1)
+	}
 	for (size_t i = 0; i < m.lists.size(); ++i) {
 		const List &L = m.lists[i];
+		if (!seen[i]) continue;
 		w.put<uint32_t>(sh ? (L.target == TG_FACE ? m.g_nf : m.g_nv) : L.count);
 		w.put<uint16_t>((uint16_t)L.fmt.size());
 		for (int j = 0; j < L.fmt.size(); ++j) { w.put<uint8_t>(L.fmt.type[j]); w.put<uint8_t>((uint8_t)L.fmt.quant[j]); }
@@ -925,22 +993,35 @@ static void read_header(ByteReader &r, Mesh &m, int want_minor = 1, uint32_t *de
 	{ uint32_t ne = r.get<uint32_t>(); if (declared_ne) *declared_ne = ne; }
 	uint16_t nrf = r.get<uint16_t>(), nrv = r.get<uint16_t>();
 	std::vector<int> targets;
-	auto mark = [&](uint16_t b, int t) { if (b >= targets.size()) targets.resize(b + 1, TG_NONE); targets[b] = t; };
-	if (nrf != 1 || nrv != 1) throw std::runtime_error("oracle: only single-region meshes (PLY-originated) are supported");
+	auto mark = [&](uint16_t b, int t) { if (b >= targets.size()) targets.resize(b + 1, TG_NONE); targets[b] = t; return b; };
+	Mesh::Bind b;   // reader.cc:86-126
 	for (int i = 0; i < nrf; ++i) {
 		uint16_t nbf = r.get<uint16_t>(), nbc = r.get<uint16_t>();
-		if (nbf != 1 || nbc != 0) throw std::runtime_error("oracle: unsupported face-region bindings");
-		for (int a = 0; a < nbf; ++a) mark(r.get<uint16_t>(), TG_FACE);
+		int reg = b.add_face_region(nbf, nbc);
+		b.nb_face = std::max<int>(b.nb_face, nbf); b.nb_corner = std::max<int>(b.nb_corner, nbc);
+		for (int a = 0; a < nbf; ++a) b.reg_facelist[b.off_facelist[reg] + a] = mark(r.get<uint16_t>(), TG_FACE);
+		for (int a = 0; a < nbc; ++a) b.reg_cornerlist[b.off_cornerlist[reg] + a] = mark(r.get<uint16_t>(), TG_CORNER);
 	}
 	for (int i = 0; i < nrv; ++i) {
 		uint16_t nbv = r.get<uint16_t>();
-		if (nbv != 1) throw std::runtime_error("oracle: unsupported vertex-region bindings");
-		for (int a = 0; a < nbv; ++a) mark(r.get<uint16_t>(), TG_VTX);
+		int reg = b.add_vtx_region(nbv);
+		b.nb_vtx = std::max<int>(b.nb_vtx, nbv);
+		for (int a = 0; a < nbv; ++a) b.reg_vtxlist[b.off_vtxlist[reg] + a] = mark(r.get<uint16_t>(), TG_VTX);
 	}
-	if (targets.size() != 2 || targets[0] != TG_FACE || targets[1] != TG_VTX) throw std::runtime_error("oracle: unsupported list layout");
+	const bool ply_layout = nrf == 1 && nrv == 1 && b.nfacelists(0) == 1 && b.ncornerlists(0) == 0 && b.nvtxlists(0) == 1 &&
+	                        b.facelist(0, 0) == 0 && b.vtxlist(0, 0) == 1;
+	if (!ply_layout) {
+		if (want_minor != 1) throw std::runtime_error("oracle: the chunked container holds the PLY layout only");
+		if (nrf > 128 || nrv > 128) throw std::runtime_error("oracle: more than 128 regions overflow the reference's model seeding (model.h:49-55)");
+		b.on = true;
+		b.face_reg.assign(m.nf, 0); b.vtx_reg.assign(m.nv, 0);
+		b.face_attr.assign((size_t)m.nf * b.nb_face, 0); b.vtx_attr.assign((size_t)m.nv * b.nb_vtx, 0);
+		m.bind = std::move(b);   // corner slots follow the connectivity
+	}
 	for (size_t i = 0; i < targets.size(); ++i) {
 		List L;
 		L.target = targets[i];
+		if (L.target == TG_NONE) { m.lists.push_back(std::move(L)); continue; }   // reader.cc:128-166: nothing stored for it
 		L.count = r.get<uint32_t>();
 		uint16_t nf = r.get<uint16_t>();
 		for (int j = 0; j < nf; ++j) { uint8_t t = r.get<uint8_t>(), q = r.get<uint8_t>(); if (t >= T_NONE) throw std::runtime_error("oracle: bad type"); L.fmt.add((Type)t, q); }
@@ -1168,8 +1249,12 @@ static void encode_attrs(Mesh &m, SymWriter &wr, const std::vector<uint32_t> &or
 	}
 }
 
+static void check_general(const Mesh &m);
+static void encode_attrs_general(Mesh &m, SymWriter &wr, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &order_f);
+
 static void check_supported(const Mesh &m)
 {
+	if (m.bind.on) throw std::runtime_error("oracle: this path takes the PLY layout only (list 0 = face attributes, list 1 = vertex attributes)");
 	if (m.lists.size() != 2 || m.lists[0].target != TG_FACE || m.lists[1].target != TG_VTX)
 		throw std::runtime_error("oracle: mesh must have list 0 = face attributes and list 1 = vertex attributes");
 	if (m.lists[0].count != m.nf || m.lists[1].count != m.nv) throw std::runtime_error("oracle: list sizes must equal element counts");
@@ -1177,7 +1262,7 @@ static void check_supported(const Mesh &m)
 
 static Result *encode(Mesh &m, bool trace)
 {
-	check_supported(m);
+	if (m.bind.on) check_general(m); else check_supported(m);
 	Result *res = new Result();
 	try {
 		write_header(m, res->bytes);
@@ -1186,7 +1271,8 @@ static Result *encode(Mesh &m, bool trace)
 		Models md(m);
 		SymWriter wr(md, rc, trace ? &res->trace : nullptr);
 		cbm_encode(m, wr, res->order_v, res->order_f);
-		encode_attrs(m, wr, res->order_v, res->order_f);
+		if (m.bind.on) encode_attrs_general(m, wr, res->order_v, res->order_f);
+		else encode_attrs(m, wr, res->order_v, res->order_f);
 		rc.finish();
 	} catch (...) { delete res; throw; }
 	return res;
@@ -1349,6 +1435,301 @@ static void decode_attrs(Mesh &m, SymReader &rd, const std::vector<uint32_t> &or
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// general bindings: several regions, records shared between elements (global / per-vertex history) and corner
+// attributes -- what the OBJ reader creates (attrcode.h:23-80 histories, :108-289 prediction, :321-393 encoder,
+// :443-531 decoder).  The PLY layout above is the special case with private records and no corner lists.
+// ------------------------------------------------------------------------------------------------
+static const uint32_t UNSET = 0xffffffffu;
+
+template <typename F> static void fan_each(const Mesh &m, he_t ein, F &&cb)   // attrcode.h:83-106 (TFAN_IT)
+{
+	he_t e = ein, t;
+	for (;;) {
+		cb(e);
+		t = m.twin[e];
+		if (t == e) break;
+		e = m.next(t);
+		if (e == ein) return;
+	}
+	e = m.prev(ein);
+	t = m.twin[e];
+	if (e == t) return;
+	e = t;
+	do {
+		cb(e);
+		e = m.prev(e);
+		t = m.twin[e];
+		if (e == t) break;
+		e = t;
+	} while (e != ein);
+}
+
+// attrcode.h:182-208: mean of the parts (rounded division in the wide type), then for floats the part nearest to the mean
+template <typename T> static T combine_parts(const std::vector<T> &pv)
+{
+	typedef typename big_of<T>::type B;
+	if (pv.empty()) return T(0);
+	B acc = 0;
+	for (T x : pv) acc = acc + (B)x;
+	acc = div_round(acc, (B)pv.size());
+	T avg = (T)acc;
+	if (!std::is_floating_point<T>::value) return avg;
+	T res = std::numeric_limits<T>::max();
+	for (T x : pv) {
+		T rd = avg > res ? avg - res : res - avg;
+		T pd = avg > x ? avg - x : x - avg;
+		res = rd < pd ? res : x;
+	}
+	return res;
+}
+
+struct GenAttr {
+	Mesh &m;
+	Mesh::Bind &b;
+	std::vector<char> vdone, fdone;
+	std::vector<Cand> cands;      // parallelograms around the vertex being coded
+	std::vector<he_t> srcs;       // corners (half-edges) of already coded faces of the same region around the corner's vertex
+	explicit GenAttr(Mesh &mesh) : m(mesh), b(mesh.bind), vdone(mesh.nv, 0), fdone(mesh.nf, 0) {}
+
+	void offer(uint32_t v0, uint32_t v1, uint32_t vo, int r)   // attrcode.h:117-134
+	{
+		if (!vdone[v0] || !vdone[v1] || !vdone[vo]) return;
+		if (b.vtx_reg[v0] != r || b.vtx_reg[v1] != r || b.vtx_reg[vo] != r) return;
+		cands.push_back(Cand{ v0, v1, vo });
+	}
+	void paral(he_t ein, int r)   // attrcode.h:155-171
+	{
+		he_t e = ein;
+		int d = m.deg(m.eface[e]);
+		if (d == 3) {
+			e = m.next(e);
+			he_t t = m.twin[e];
+			if (t == e) return;
+			e = m.next(m.next(t));
+			offer(m.org[t], m.dest(t), m.org[e], r);
+			return;
+		}
+		he_t e0 = m.next(e), e1 = m.prev(e);
+		offer(m.org[e0], m.org[e1], m.dest(e0), r);
+		if (d > 4) offer(m.org[e0], m.org[e1], m.org[m.prev(e)], r);
+	}
+	void vertex(he_t e, int r)   // attrcode.h:209-225
+	{
+		cands.clear();
+		fan_each(m, e, [&](he_t x) { paral(x, r); });
+		vdone[m.org[e]] = 1;
+	}
+	void corner(uint32_t f, he_t e)   // attrcode.h:135-154,272-288: the face itself does not count
+	{
+		int r = b.face_reg[f];
+		srcs.clear();
+		fdone[f] = 0;
+		fan_each(m, e, [&](he_t x) { uint32_t g = m.eface[x]; if (fdone[g] && b.face_reg[g] == r) srcs.push_back(x); });
+		fdone[f] = 1;
+	}
+	template <typename T> T predict_vtx(const List &L, int a, int c) const
+	{
+		std::vector<T> pv;
+		const int off = L.fmt.off[c], q = L.fmt.quant[c];
+		for (const Cand &k : cands) {
+			T x = ld<T>(L.rec(b.vtx_attr[(size_t)k.v0 * b.nb_vtx + a]) + off), y = ld<T>(L.rec(b.vtx_attr[(size_t)k.v1 * b.nb_vtx + a]) + off),
+			  o = ld<T>(L.rec(b.vtx_attr[(size_t)k.vo * b.nb_vtx + a]) + off);
+			pv.push_back(paral_predict<T>(x, y, o, q, std::is_floating_point<T>()));
+		}
+		return combine_parts<T>(pv);
+	}
+	template <typename T> T predict_corner(const List &L, int a, int c) const   // prediction.h:149-164: the value itself
+	{
+		std::vector<T> pv;
+		for (he_t x : srcs) pv.push_back(ld<T>(L.rec(b.corner_attr[(size_t)x * b.nb_corner + a]) + L.fmt.off[c]));
+		return combine_parts<T>(pv);
+	}
+};
+
+struct LocalHist {   // attrcode.h:54-80, one per corner slot
+	std::vector<std::vector<uint32_t>> hist;
+	uint32_t insert(uint32_t v, uint32_t idx)
+	{
+		std::vector<uint32_t> &h = hist[v];
+		for (size_t i = 0; i < h.size(); ++i) if (h[i] == idx) return (uint32_t)(h.size() - 1 - i);
+		h.push_back(idx);
+		return UNSET;
+	}
+	uint32_t find(uint32_t v, uint32_t off) const
+	{
+		const std::vector<uint32_t> &h = hist[v];
+		if (off >= h.size()) throw std::runtime_error("oracle: corrupt stream (per-vertex history)");
+		return h[h.size() - 1 - off];
+	}
+};
+
+static void check_general(const Mesh &m)
+{
+	const Mesh::Bind &b = m.bind;
+	if (m.is_shard()) throw std::runtime_error("oracle: a shard holds the PLY layout only");
+	if (b.nregs_face() > 128 || b.nregs_vtx() > 128) throw std::runtime_error("oracle: more than 128 regions overflow the reference's model seeding (model.h:49-55)");
+	if (b.face_reg.size() != m.nf || b.vtx_reg.size() != m.nv) throw std::runtime_error("oracle: region tables do not match the element counts");
+	if (b.face_attr.size() != (size_t)m.nf * b.nb_face || b.vtx_attr.size() != (size_t)m.nv * b.nb_vtx ||
+	    b.corner_attr.size() != (size_t)m.num_edge() * b.nb_corner) throw std::runtime_error("oracle: binding tables do not match the element counts");
+}
+
+static void encode_attrs_general(Mesh &m, SymWriter &wr, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &order_f)
+{
+	GenAttr g(m);
+	const Mesh::Bind &b = m.bind;
+	std::vector<std::vector<uint32_t>> seen_at(m.lists.size());   // GlobalHistory::tidxlist (attrcode.h:23-53)
+	std::vector<uint32_t> nseen(m.lists.size(), 0);
+	for (size_t l = 0; l < m.lists.size(); ++l) seen_at[l].assign(m.lists[l].count, UNSET);
+	std::vector<LocalHist> lh(b.nb_corner);
+	for (auto &h : lh) h.hist.resize(m.nv);
+	std::vector<uint8_t> resid;
+	auto seen_before = [&](int l, uint32_t idx) -> uint32_t {   // lget_set
+		if (idx >= seen_at[l].size()) throw std::runtime_error("oracle: binding outside its list");
+		uint32_t at = seen_at[l][idx];
+		if (at == UNSET) { seen_at[l][idx] = nseen[l]++; return UNSET; }
+		return nseen[l] - 1 - at;
+	};
+	auto code_data = [&](int l, uint32_t idx, auto &&pred) {   // attrcode.h:340-342 + io.h:90-94
+		List &L = m.lists[l];
+		resid.assign(std::max(L.fmt.bytes(), 1), 0);
+		for (int c = 0; c < L.fmt.size(); ++c)
+			with_type(L.fmt.stype[c], [&](auto tag) {
+				typedef decltype(tag) T;
+				T p = pred(tag, L, c);
+				T raw = ld<T>(L.rec(idx) + L.fmt.off[c]);
+				st<T>(resid.data() + L.fmt.off[c], fold_residual<T>(raw, p, L.fmt.quant[c], std::is_floating_point<T>()));
+			});
+		wr.attr_type(l, A_DATA);
+		int ctx = wr.md.attr_base[l] + ATTR_DATA;
+		for (int c = 0; c < L.fmt.size(); ++c) {
+			int nb = TSIZE[L.fmt.stype[c]];
+			wr.bytes(ctx, resid.data() + L.fmt.off[c], nb);
+			ctx += nb;
+		}
+	};
+	for (he_t e : order_v) {   // attrcode.h:321-344
+		uint32_t v = m.org[e];
+		int r = b.vtx_reg[v];
+		g.vertex(e, r);
+		wr.reg_vtx((uint16_t)r);
+		for (int a = 0; a < b.nvtxlists(r); ++a) {
+			int l = b.vtxlist(r, a);
+			uint32_t idx = b.vtx_attr[(size_t)v * b.nb_vtx + a];
+			uint32_t d = seen_before(l, idx);
+			if (d != UNSET) { wr.attr_ghist(l, d); continue; }
+			code_data(l, idx, [&](auto tag, const List &L, int c) { return g.predict_vtx<decltype(tag)>(L, a, c); });
+		}
+	}
+	for (he_t e : order_f) {   // attrcode.h:345-393,405-414
+		uint32_t f = m.eface[e];
+		int r = b.face_reg[f];
+		g.fdone[f] = 1;          // face prediction never finds a coded neighbour (attrcode.h:245-254 tests the face itself)
+		wr.reg_face((uint16_t)r);
+		for (int a = 0; a < b.nfacelists(r); ++a) {
+			int l = b.facelist(r, a);
+			uint32_t idx = b.face_attr[(size_t)f * b.nb_face + a];
+			uint32_t d = seen_before(l, idx);
+			if (d != UNSET) { wr.attr_ghist(l, d); continue; }
+			code_data(l, idx, [&](auto tag, const List &, int) { return decltype(tag)(0); });
+		}
+		he_t c = e;
+		do {
+			g.corner(f, c);
+			uint32_t v = m.org[c];
+			for (int a = 0; a < b.ncornerlists(r); ++a) {
+				int l = b.cornerlist(r, a);
+				uint32_t idx = b.corner_attr[(size_t)c * b.nb_corner + a];
+				uint32_t ld_ = lh[a].insert(v, idx);
+				if (ld_ != UNSET) { wr.attr_lhist(l, (uint16_t)ld_); continue; }
+				uint32_t d = seen_before(l, idx);
+				if (d != UNSET) { wr.attr_ghist(l, d); continue; }
+				code_data(l, idx, [&](auto tag, const List &L, int cc) { return g.predict_corner<decltype(tag)>(L, a, cc); });
+			}
+			c = m.next(c);
+		} while (c != e);
+	}
+}
+
+static void decode_attrs_general(Mesh &m, SymReader &rd, const std::vector<uint32_t> &order_v)
+{
+	GenAttr g(m);
+	Mesh::Bind &b = m.bind;
+	b.corner_attr.assign((size_t)m.num_edge() * b.nb_corner, 0);
+	std::vector<uint32_t> cur(m.lists.size(), 0);
+	std::vector<LocalHist> lh(b.nb_corner);
+	for (auto &h : lh) h.hist.resize(m.nv);
+	auto read_data = [&](int l, auto &&pred) -> uint32_t {   // attrcode.h:457-462
+		List &L = m.lists[l];
+		if (cur[l] >= L.count) throw std::runtime_error("oracle: corrupt stream (attribute overflow)");
+		uint32_t idx = cur[l]++;
+		int ctx = rd.md.attr_base[l] + ATTR_DATA;
+		for (int c = 0; c < L.fmt.size(); ++c) {
+			int nb = TSIZE[L.fmt.stype[c]];
+			rd.bytes(ctx, L.rec(idx) + L.fmt.off[c], nb);
+			ctx += nb;
+		}
+		for (int c = 0; c < L.fmt.size(); ++c)
+			with_type(L.fmt.stype[c], [&](auto tag) {
+				typedef decltype(tag) T;
+				T p = pred(tag, L, c);
+				T d = ld<T>(L.rec(idx) + L.fmt.off[c]);
+				st<T>(L.rec(idx) + L.fmt.off[c], unfold_residual<T>(d, p, L.fmt.quant[c], std::is_floating_point<T>()));
+			});
+		return idx;
+	};
+	auto read_hist = [&](int l) -> uint32_t {   // attrcode.h:463-465
+		uint32_t d = rd.attr_ghist(l);
+		if (d >= cur[l]) throw std::runtime_error("oracle: corrupt stream (history)");
+		return cur[l] - 1 - d;
+	};
+	for (he_t e : order_v) {   // attrcode.h:443-470
+		uint32_t v = m.org[e];
+		int r = rd.reg_vtx();
+		if (r >= b.nregs_vtx()) throw std::runtime_error("oracle: corrupt stream (vertex region)");
+		b.vtx_reg[v] = (uint16_t)r;
+		g.vertex(e, r);
+		for (int a = 0; a < b.nvtxlists(r); ++a) {
+			int l = b.vtxlist(r, a);
+			uint8_t ty = rd.attr_type(l);
+			uint32_t idx;
+			if (ty == A_DATA) idx = read_data(l, [&](auto tag, const List &L, int c) { return g.predict_vtx<decltype(tag)>(L, a, c); });
+			else if (ty == A_HIST) idx = read_hist(l);
+			else throw std::runtime_error("oracle: corrupt stream (attribute type)");
+			b.vtx_attr[(size_t)v * b.nb_vtx + a] = idx;
+		}
+	}
+	for (uint32_t f = 0; f < m.nf; ++f) {   // attrcode.h:476-531,543-548: faces in index order, corners from 0
+		int r = rd.reg_face();
+		if (r >= b.nregs_face()) throw std::runtime_error("oracle: corrupt stream (face region)");
+		b.face_reg[f] = (uint16_t)r;
+		g.fdone[f] = 1;
+		for (int a = 0; a < b.nfacelists(r); ++a) {
+			int l = b.facelist(r, a);
+			uint8_t ty = rd.attr_type(l);
+			uint32_t idx;
+			if (ty == A_DATA) idx = read_data(l, [&](auto tag, const List &, int) { return decltype(tag)(0); });
+			else if (ty == A_HIST) idx = read_hist(l);
+			else throw std::runtime_error("oracle: corrupt stream (attribute type)");
+			b.face_attr[(size_t)f * b.nb_face + a] = idx;
+		}
+		for (he_t c = m.foff[f]; c < m.foff[f + 1]; ++c) {
+			g.corner(f, c);
+			uint32_t v = m.org[c];
+			for (int a = 0; a < b.ncornerlists(r); ++a) {
+				int l = b.cornerlist(r, a);
+				uint8_t ty = rd.attr_type(l);
+				uint32_t idx;
+				if (ty == A_DATA) { idx = read_data(l, [&](auto tag, const List &L, int cc) { return g.predict_corner<decltype(tag)>(L, a, cc); }); lh[a].insert(v, idx); }
+				else if (ty == A_HIST) { idx = read_hist(l); lh[a].insert(v, idx); }
+				else if (ty == A_LHIST) idx = lh[a].find(v, rd.attr_lhist(l));
+				else throw std::runtime_error("oracle: corrupt stream (attribute type)");
+				b.corner_attr[(size_t)c * b.nb_corner + a] = idx;
+			}
+		}
+	}
+}
+
 static Mesh *decode(const uint8_t *p, size_t n)
 {
 	Mesh *m = new Mesh();
@@ -1365,7 +1746,8 @@ static Mesh *decode(const uint8_t *p, size_t n)
 		cbm_decode(*m, rd, order_v);
 		m->have_deg = hdr_deg;
 		if (m->num_face() != m->nf) throw std::runtime_error("oracle: face count mismatch");
-		decode_attrs(*m, rd, order_v);
+		if (m->bind.on) decode_attrs_general(*m, rd, order_v);
+		else decode_attrs(*m, rd, order_v);
 	} catch (...) { delete m; throw; }
 	return m;
 }
@@ -1652,7 +2034,8 @@ static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 		cbm_decode(*m, rd, order_v);
 		m->have_deg = hdr_deg;
 		if (m->num_face() != m->nf) throw std::runtime_error("oracle: face count mismatch");
-		decode_attrs(*m, rd, order_v);
+		if (m->bind.on) decode_attrs_general(*m, rd, order_v);
+		else decode_attrs(*m, rd, order_v);
 	}
 }
 
@@ -2118,6 +2501,275 @@ static Mesh *read_ply(const uint8_t *buf, size_t n)
 	return m;
 }
 
+// ------------------------------------------------------------------------------------------------
+// OBJ reader (formats/obj/reader.rl:27-80 grammar, :108-299 actions).  The grammar is restated by hand, with its quirks:
+//   * the sign of an exponent is required and then ignored ("1e-2" reads as 100; "1e2" does not parse) -- rl:36-37,44
+//   * "v" takes 3, 4, 6, 7 or 8 numbers; "vt" 2 or 3; "vn" 3; "o s g l p" need at least one blank after the keyword
+//   * anything else, and any stray '\r', is "Unable to parse this OBJ file"; a last line without '\n' is dropped
+//   * material names keep trailing blanks; "usemtl" of an unknown material falls back to material 0
+//   * the face-region lookup key (tex_list << 3) | normal_list with 9 = none collides for some list pairs (rl:229)
+//   * a corner written "v/t" names normal t as well ("n too big" when there are fewer normals); "v/t/" names the texture only
+// Not restated: "nan" / "inf" literals (the sign state of "inf" is undefined in the reference), faces with fewer than 3 corners
+// and faces whose corners do not all carry the same kinds of index (the reference reads past its index arrays there).
+// ------------------------------------------------------------------------------------------------
+struct ObjLine {
+	const uint8_t *p, *end;
+	bool at_end() const { return p == end; }
+	bool blank(uint8_t c) const { return c == ' ' || c == '\t'; }
+	bool sp() { if (p == end || !blank(*p)) return false; while (p != end && blank(*p)) ++p; return true; }
+	void fail() const { throw std::runtime_error("Unable to parse this OBJ file"); }
+	bool digit() const { return p != end && *p >= '0' && *p <= '9'; }
+	float number()   // rl:32-50
+	{
+		double sign = 1, val = 0, fraction = 0, denom = 1, ex = 0, expmul = 1;
+		if (p != end && (*p == 'n' || *p == 'N' || *p == 'i' || *p == 'I')) throw std::runtime_error("oracle: nan / inf literals in an OBJ file are not restated");
+		if (p != end && (*p == '+' || *p == '-')) { sign = *p == '-' ? -1 : 1; ++p; }
+		if (digit()) {
+			while (digit()) { val *= 10; val += *p - '0'; ++p; }
+			if (p != end && *p == '.') { ++p; while (digit()) { fraction *= 10; fraction += *p - '0'; denom *= 10; ++p; } }
+		} else if (p != end && *p == '.') {
+			++p;
+			if (!digit()) fail();
+			while (digit()) { fraction *= 10; fraction += *p - '0'; denom *= 10; ++p; }
+		} else fail();
+		if (p != end && (*p == 'e' || *p == 'E')) {
+			++p;
+			if (p == end || (*p != '+' && *p != '-')) fail();
+			++p;
+			if (!digit()) fail();
+			while (digit()) { ex *= 10; ex += *p - '0'; ++p; }
+			expmul = std::pow(10.0, ex);
+		}
+		val += fraction / denom;
+		val *= sign * expmul;
+		return (float)val;
+	}
+	bool index(int &out)   // rl:52
+	{
+		const uint8_t *q = p;
+		bool neg = false;
+		if (q != end && *q == '-') { neg = true; ++q; }
+		if (q == end || *q < '0' || *q > '9') return false;
+		int v = 0;
+		while (q != end && *q >= '0' && *q <= '9') { v = (int)((unsigned)v * 10u + (unsigned)(*q - '0')); ++q; }
+		p = q;
+		out = neg ? -v : v;
+		return true;
+	}
+};
+
+static int obj_index(int n, int size)   // rl:91-103
+{
+	if (n == 0) throw std::runtime_error("index cannot be 0");
+	if (n > size) throw std::runtime_error("n too big");
+	if (n < 0) {
+		if (size + n < 0) throw std::runtime_error("n too small");
+		return size + n;
+	}
+	return n - 1;
+}
+
+struct ObjBuilder {
+	enum { VERTEX, TEX, NORMAL, IL = 9 };
+	Mesh &m;
+	TwinMatcher tm;
+	int attr_lists[3][9];
+	int vtx_reg[9];
+	std::vector<std::array<int, 256>> face_regs;
+	std::vector<std::pair<int, uint32_t>> tex_loc, normal_loc;
+	std::unordered_map<std::string, int> mtls;
+	int cur_mtl = 0;
+	std::string base;
+	explicit ObjBuilder(Mesh &mesh, const std::string &dir) : m(mesh), tm(mesh), base(dir)
+	{
+		for (auto &row : attr_lists) for (int &x : row) x = IL;
+		for (int &x : vtx_reg) x = -1;
+		face_regs.emplace_back();
+		face_regs[0].fill(-1);
+		m.bind.on = true;
+		m.bind.nb_face = 0; m.bind.nb_vtx = 1; m.bind.nb_corner = 2;   // rl:257
+	}
+	int init_attr(int attr, int n)   // rl:132-148
+	{
+		int &list = attr_lists[attr][n];
+		if (list == IL) {
+			static const int lut[3] = { I_POS, I_TEX, I_NORMAL };
+			List L;
+			for (int i = 0; i < n; ++i) {
+				L.fmt.add(T_FLOAT);
+				int interp = lut[attr];
+				if (attr == VERTEX && n > 4) interp = ((n == 8 && i >= 4) || i >= 3) ? I_COLOR : interp;
+				L.interps.append(interp, i);
+			}
+			L.target = attr == VERTEX ? TG_VTX : TG_CORNER;
+			m.lists.push_back(std::move(L));
+			list = (int)m.lists.size() - 1;
+		}
+		return list;
+	}
+	uint32_t write_attr(int list, const float *c, int n)
+	{
+		List &L = m.lists[list];
+		L.data.resize(L.data.size() + (size_t)n * 4);
+		memcpy(L.rec(L.count), c, (size_t)n * 4);
+		return L.count++;
+	}
+	void usemtl(const std::string &name) { auto it = mtls.find(name); cur_mtl = it == mtls.end() ? 0 : it->second; }   // rl:160-169
+	void mtllib(const std::string &name)   // rl:170-190
+	{
+		std::ifstream is(base + "/" + name);
+		if (!is) return;
+		while (!is.eof()) {
+			std::string id;
+			is >> id;
+			if (id == "newmtl") {
+				std::string nm;
+				is >> nm;
+				mtls[nm] = (int)face_regs.size();
+				face_regs.emplace_back();
+				face_regs.back().fill(-1);
+			} else is.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
+		}
+	}
+	void vertex(const float *c, int n)   // rl:191-204
+	{
+		int list = init_attr(VERTEX, n);
+		uint32_t aidx = write_attr(list, c, n);
+		if (vtx_reg[n] < 0) { vtx_reg[n] = m.bind.add_vtx_region(1); m.bind.reg_vtxlist[m.bind.off_vtxlist[vtx_reg[n]]] = (uint16_t)list; }
+		m.bind.vtx_reg.push_back((uint16_t)vtx_reg[n]);
+		m.bind.vtx_attr.push_back(aidx);
+		++m.nv;
+	}
+	void tex(const float *c, int n) { int l = init_attr(TEX, n); tex_loc.push_back(std::make_pair(l, write_attr(l, c, n))); }
+	void normal(const float *c, int n) { int l = init_attr(NORMAL, n); normal_loc.push_back(std::make_pair(l, write_attr(l, c, n))); }
+	void face(const std::vector<int> &vi, const std::vector<int> &ti, const std::vector<int> &ni)   // rl:217-249
+	{
+		const int corners = (int)vi.size();
+		const bool has_t = !ti.empty(), has_n = !ni.empty();
+		if (corners < 3) throw std::runtime_error("oracle: OBJ faces with fewer than 3 corners are not restated");
+		if ((has_t && (int)ti.size() != corners) || (has_n && (int)ni.size() != corners)) throw std::runtime_error("oracle: OBJ face with unevenly indexed corners is not restated");
+		int tex_l = IL, normal_l = IL;
+		if (has_t) tex_l = tex_loc[ti[0]].first;
+		if (has_n) normal_l = normal_loc[ni[0]].first;
+		for (int c = 1; c < corners; ++c) {
+			if (has_t && tex_loc[ti[c]].first != tex_l) throw std::runtime_error("Inconsistent texture attribute types in face");
+			if (has_n && normal_loc[ni[c]].first != normal_l) throw std::runtime_error("Inconsistent normal attribute types in face");
+		}
+		int key = (tex_l << 3) | normal_l;
+		int r = face_regs[cur_mtl][key];
+		const int tex_a = 0, normal_a = has_t ? 1 : 0;
+		if (r < 0) {
+			r = face_regs[cur_mtl][key] = m.bind.add_face_region(0, (has_t ? 1 : 0) + (has_n ? 1 : 0));
+			if (has_t) m.bind.reg_cornerlist[m.bind.off_cornerlist[r] + tex_a] = (uint16_t)tex_l;
+			if (has_n) m.bind.reg_cornerlist[m.bind.off_cornerlist[r] + normal_a] = (uint16_t)normal_l;
+		}
+		uint32_t f = m.add_face(corners);
+		m.bind.face_reg.push_back((uint16_t)r);
+		m.bind.corner_attr.resize(m.bind.corner_attr.size() + (size_t)corners * 2, 0);
+		uint32_t first = 0, last = NOVTX;
+		for (int i = 0; i < corners; ++i) {
+			he_t e = m.foff[f] + (uint32_t)i;
+			uint32_t v = (uint32_t)vi[i];
+			m.set_org(e, v);
+			if (has_t) m.bind.corner_attr[(size_t)e * 2 + tex_a] = tex_loc[ti[i]].second;
+			if (has_n) m.bind.corner_attr[(size_t)e * 2 + normal_a] = normal_loc[ni[i]].second;
+			if (last != NOVTX) tm.edge(last, v, e - 1); else first = v;
+			last = v;
+		}
+		tm.edge(last, first, m.foff[f] + (uint32_t)corners - 1);
+		++m.nf;
+	}
+};
+
+static Mesh *read_obj(const uint8_t *buf, size_t n, const std::string &dir)
+{
+	Mesh *m = new Mesh();
+	try {
+		ObjBuilder ob(*m, dir);
+		int count[3] = { 0, 0, 0 };
+		std::vector<int> fi[3];
+		float coords[8];
+		const uint8_t *p = buf, *end = buf + n;
+		while (p != end) {
+			const uint8_t *nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+			if (!nl) break;                                   // a last line without '\n' never completes
+			const uint8_t *le = nl;
+			if (le != p && le[-1] == '\r') --le;              // eol = sp? '\r'? '\n'
+			ObjLine L{ p, le };
+			p = nl + 1;
+			for (const uint8_t *q = L.p; q != L.end; ++q) if (*q == '\r') L.fail();
+			auto eol = [&]() { L.sp(); if (!L.at_end()) L.fail(); };
+			auto keyword = [&](const char *kw) {
+				size_t k = strlen(kw);
+				if ((size_t)(L.end - L.p) < k || memcmp(L.p, kw, k) != 0) return false;
+				if ((size_t)(L.end - L.p) > k && !L.blank(L.p[k])) return false;
+				return true;
+			};
+			if (L.at_end()) continue;
+			if (L.blank(*L.p)) { eol(); continue; }           // '' eol with blanks only
+			if (*L.p == '#') continue;
+			if (keyword("usemtl") || keyword("mtllib")) {
+				const bool use = L.p[0] == 'u';
+				L.p += 6;
+				const uint8_t *a = L.p;
+				if (!L.sp()) L.fail();
+				std::string s((const char*)L.p, (const char*)L.end);
+				if (s.empty()) {                               // only blanks followed the keyword: one is sp, the last one is the name
+					if (L.end - a < 2) L.fail();
+					s.assign(1, (char)L.end[-1]);
+				}
+				if (use) ob.usemtl(s); else ob.mtllib(s);
+				continue;
+			}
+			if (keyword("vt") || keyword("vn") || keyword("v")) {
+				int kind = keyword("vt") ? ObjBuilder::TEX : keyword("vn") ? ObjBuilder::NORMAL : ObjBuilder::VERTEX;
+				L.p += kind == ObjBuilder::VERTEX ? 1 : 2;
+				int nc = 0;
+				while (L.sp()) {
+					if (L.at_end()) break;
+					if (nc == 8) L.fail();
+					coords[nc++] = L.number();
+				}
+				if (!L.at_end()) L.fail();
+				if (kind == ObjBuilder::VERTEX) { if (nc != 3 && nc != 4 && nc != 6 && nc != 7 && nc != 8) L.fail(); ++count[0]; ob.vertex(coords, nc); }
+				else if (kind == ObjBuilder::TEX) { if (nc != 2 && nc != 3) L.fail(); ++count[1]; ob.tex(coords, nc); }
+				else { if (nc != 3) L.fail(); ++count[2]; ob.normal(coords, nc); }
+				continue;
+			}
+			if (keyword("f")) {
+				L.p += 1;
+				fi[0].clear(); fi[1].clear(); fi[2].clear();
+				while (L.sp()) {
+					if (L.at_end()) break;
+					int idx;
+					if (!L.index(idx)) L.fail();
+					fi[0].push_back(obj_index(idx, count[0]));
+					int slashes = 0, last_with_index = 0;
+					for (int k = 1; k <= 2; ++k) {
+						if (L.at_end() || *L.p != '/') break;
+						++L.p; ++slashes;
+						if (L.index(idx)) { fi[k].push_back(obj_index(idx, count[k])); last_with_index = k; }
+					}
+					// "v/t" also matches as "v" + no texture + "/n": the generated scanner runs both and so the index lands in the
+					// normals as well (rl:54-56); "v/t/" does not
+					if (slashes == 1 && last_with_index == 1) fi[2].push_back(obj_index(idx, count[2]));
+				}
+				if (!L.at_end() || fi[0].size() < 2) L.fail();
+				ob.face(fi[0], fi[1], fi[2]);
+				continue;
+			}
+			if (keyword("o") || keyword("s") || keyword("g") || keyword("l") || keyword("p")) {
+				if (L.end - L.p < 2) L.fail();                // the keyword needs a blank after it
+				continue;
+			}
+			L.fail();
+		}
+		m->conn_nv = std::max(m->conn_nv, m->nv);
+		for (auto &L : m->lists) set_bounds(L);   // rl:294
+	} catch (...) { delete m; throw; }
+	return m;
+}
+
 }   // namespace ho
 
 // ------------------------------------------------------------------------------------------------
@@ -2151,6 +2803,29 @@ ho_mesh *ho_mesh_from_hry(const uint8_t *hry, size_t n)
 	return h;
 	HO_CATCH(nullptr)
 }
+ho_mesh *ho_mesh_from_obj(const uint8_t *obj, size_t n, const char *dir)
+{
+	HO_TRY
+	ho::Mesh *m = ho::read_obj(obj, n, dir ? dir : "");
+	ho_mesh *h = new ho_mesh{ std::move(*m) };
+	delete m;
+	return h;
+	HO_CATCH(nullptr)
+}
+int ho_mesh_general(const ho_mesh *m) { return m->m.bind.on ? 1 : 0; }
+void ho_mesh_make_general(ho_mesh *m) { m->m.make_general(); }
+int ho_mesh_nregions(const ho_mesh *m, int which) { return !m->m.bind.on ? 1 : which == 0 ? m->m.bind.nregs_face() : m->m.bind.nregs_vtx(); }
+int ho_mesh_region_lists(const ho_mesh *m, int kind, int r, uint16_t *out, int cap)
+{
+	const ho::Mesh::Bind &b = m->m.bind;
+	if (!b.on) { if (kind == 2) return 0; if (cap > 0) out[0] = kind == 0 ? 0 : 1; return 1; }
+	int n = kind == 0 ? b.nfacelists(r) : kind == 1 ? b.nvtxlists(r) : b.ncornerlists(r);
+	for (int a = 0; a < n && a < cap; ++a) out[a] = (uint16_t)(kind == 0 ? b.facelist(r, a) : kind == 1 ? b.vtxlist(r, a) : b.cornerlist(r, a));
+	return n;
+}
+const uint16_t *ho_mesh_regions_of(const ho_mesh *m, int which) { return which == 0 ? m->m.bind.face_reg.data() : m->m.bind.vtx_reg.data(); }
+int ho_mesh_nslots(const ho_mesh *m, int kind) { const ho::Mesh::Bind &b = m->m.bind; return kind == 0 ? b.nb_face : kind == 1 ? b.nb_vtx : b.nb_corner; }
+const uint32_t *ho_mesh_bindings(const ho_mesh *m, int kind) { const ho::Mesh::Bind &b = m->m.bind; return kind == 0 ? b.face_attr.data() : kind == 1 ? b.vtx_attr.data() : b.corner_attr.data(); }
 ho_mesh *ho_mesh_clone(const ho_mesh *m) { return new ho_mesh{ m->m }; }
 void ho_mesh_set_shard(ho_mesh *m, uint32_t g_nv, uint32_t g_nf, uint32_t g_ne, const uint32_t *seeds, size_t nseeds, const uint32_t *runs, size_t nruns)
 {

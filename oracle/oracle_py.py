@@ -41,6 +41,14 @@ def lib():
     L.ho_mesh_from_ply.restype = vp; L.ho_mesh_from_ply.argtypes = [C.c_char_p, sz]
     L.ho_mesh_from_hry.restype = vp; L.ho_mesh_from_hry.argtypes = [C.c_char_p, sz]
     L.ho_mesh_clone.restype = vp; L.ho_mesh_clone.argtypes = [vp]
+    L.ho_mesh_from_obj.restype = vp; L.ho_mesh_from_obj.argtypes = [C.c_char_p, sz, C.c_char_p]
+    L.ho_mesh_general.restype = C.c_int; L.ho_mesh_general.argtypes = [vp]
+    L.ho_mesh_make_general.argtypes = [vp]
+    L.ho_mesh_nregions.restype = C.c_int; L.ho_mesh_nregions.argtypes = [vp, C.c_int]
+    L.ho_mesh_region_lists.restype = C.c_int; L.ho_mesh_region_lists.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.ho_mesh_regions_of.restype = C.POINTER(C.c_uint16); L.ho_mesh_regions_of.argtypes = [vp, C.c_int]
+    L.ho_mesh_nslots.restype = C.c_int; L.ho_mesh_nslots.argtypes = [vp, C.c_int]
+    L.ho_mesh_bindings.restype = u32p; L.ho_mesh_bindings.argtypes = [vp, C.c_int]
     L.ho_mesh_free.argtypes = [vp]
     L.ho_mesh_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, vp, sz]
     L.ho_mesh_set_bounds.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p]
@@ -120,6 +128,37 @@ class Mesh:
     @classmethod
     def from_ply(cls, data: bytes) -> "Mesh":
         return cls(lib().ho_mesh_from_ply(data, len(data)))
+
+    @classmethod
+    def from_obj(cls, data: bytes, directory: str = "") -> "Mesh":
+        return cls(lib().ho_mesh_from_obj(data, len(data), directory.encode()))
+
+    general = property(lambda s: bool(lib().ho_mesh_general(s.h)))
+
+    def make_general(self):
+        lib().ho_mesh_make_general(self.h)
+
+    def nregions(self, which):
+        return lib().ho_mesh_nregions(self.h, which)
+
+    def region_lists(self, kind, r):
+        """lists bound to region r: kind 0 = face lists, 1 = vertex lists, 2 = corner lists (of face region r)"""
+        out = np.zeros(64, np.uint16)
+        n = lib().ho_mesh_region_lists(self.h, kind, r, out.ctypes.data, 64)
+        return [int(x) for x in out[:n]]
+
+    def regions_of(self, which):
+        return _arr(lib().ho_mesh_regions_of(self.h, which), self.nf if which == 0 else self.nv, np.uint16)
+
+    def nslots(self, kind):
+        return lib().ho_mesh_nslots(self.h, kind)
+
+    def bindings(self, kind):
+        n = (self.nf, self.nv, self.ne)[kind] * self.nslots(kind)
+        return _arr(lib().ho_mesh_bindings(self.h, kind), n, np.uint32).reshape(-1, max(self.nslots(kind), 1)) if n else np.zeros((0, self.nslots(kind)), np.uint32)
+
+    def list_target(self, l):
+        return lib().ho_list_target(self.h, l)
 
     @classmethod
     def from_hry(cls, data: bytes) -> "Mesh":

@@ -1,0 +1,130 @@
+"""The CPU oracle's general-bindings path (OBJ reader, regions, shared records with global / per-vertex history, corner
+attributes: attrcode.h:23-80,135-154,367-393,502-531; obj/reader.rl:27-299) pinned to the UNMODIFIED reference binary through
+tests/golden/obj/ (written by tests/golden/make_golden_obj.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from harry_amd import meshgen as mg
+from harry_amd import objgen as og
+from oracle import oracle_py as op   # checker only
+from tests import util
+
+OBJ = os.path.join(util.ROOT, "tests", "golden", "obj")
+with open(os.path.join(OBJ, "manifest.json")) as _f:
+    MAN = json.load(_f)
+SMALL = [(n, t) for n, e in sorted(MAN["small"].items()) for t in sorted(e["variants"])]
+
+
+def _read(name):
+    with open(os.path.join(OBJ, name), "rb") as f:
+        return f.read()
+
+
+def _encode(name, flags):
+    m = op.Mesh.from_obj(_read(name + ".obj"), OBJ)
+    quant, clear = util.flags_to_quant(flags)
+    if quant or clear:
+        m.requant(quant, clear)
+    return m, m.clone().encode().data
+
+
+@pytest.mark.parametrize("name,tag", SMALL, ids=[f"{n}.{t}" for n, t in SMALL])
+def test_obj_encode_is_byte_identical_to_the_reference(name, tag):
+    _m, got = _encode(name, MAN["small"][name]["variants"][tag]["flags"])
+    assert got == _read(f"{name}.{tag}.hry")
+
+
+@pytest.mark.parametrize("name,tag", SMALL, ids=[f"{n}.{t}" for n, t in SMALL])
+def test_obj_decode_gives_the_coded_mesh(name, tag):
+    """decode(reference bytes): connectivity, regions and -- through the bindings -- the record behind every vertex and corner
+    equal the encoder's input in coding order; re-encoding the decoded mesh gives the same bytes again"""
+    flags = MAN["small"][name]["variants"][tag]["flags"]
+    m, _ = _encode(name, flags)
+    ref = _read(f"{name}.{tag}.hry")
+    d = op.Mesh.from_hry(ref)
+    assert d.general and (d.nv, d.nf, d.ne) == (m.nv, m.nf, m.ne)
+    r = m.clone().encode()
+    order_v, order_f = r.order_vtx(), r.order_face()
+    org_m, foff_m = m.org(), m.face_offsets()
+    assert np.array_equal(m.regions_of(1)[org_m[order_v]], d.regions_of(1)[:len(order_v)])
+    f_of = np.searchsorted(foff_m, order_f, side="right") - 1
+    assert np.array_equal(m.regions_of(0)[f_of], d.regions_of(0))
+    # records compare by their coded values (a quantised value only owns the low bytes of its slot)
+    def vals(mesh):
+        return [np.stack([mesh.component(l, c).astype(np.float64) for c in range(len(mesh.list_fmt(l)))], axis=1)
+                if mesh.list_target(l) != 3 and mesh.list_fmt(l) else None for l in range(mesh.nlists)]
+    vm, vd = vals(m), vals(d)
+    bm, bd = m.bindings(1), d.bindings(1)
+    for k, e in enumerate(order_v[:: max(1, len(order_v) // 200)]):
+        k = k * max(1, len(order_v) // 200)
+        v = org_m[e]
+        reg = int(m.regions_of(1)[v])
+        l = m.region_lists(1, reg)[0]
+        assert np.array_equal(vm[l][bm[v, 0]], vd[l][bd[k, 0]])
+    # corner records: decoded face i is coded face order_f[i], its corner 0 the start corner
+    cm, cd = m.bindings(2), d.bindings(2)
+    foff_d = d.face_offsets()
+    for i in range(0, d.nf, max(1, d.nf // 100)):
+        f = int(f_of[i])
+        deg = int(foff_m[f + 1] - foff_m[f])
+        start = int(order_f[i] - foff_m[f])
+        lists = m.region_lists(2, int(m.regions_of(0)[f]))
+        for c in range(deg):
+            em = foff_m[f] + (start + c) % deg
+            ed = foff_d[i] + c
+            for a, l in enumerate(lists):
+                assert np.array_equal(vm[l][cm[em, a]], vd[l][cd[ed, a]])
+    assert d.clone().encode().data == d.clone().encode().data
+
+
+@pytest.mark.parametrize("name", sorted(MAN["requant_of_hry"]))
+def test_requant_of_an_obj_hry(name):
+    e = MAN["requant_of_hry"][name]
+    m = op.Mesh.from_hry(_read(e["src"]))
+    quant, clear = util.flags_to_quant(e["flags"])
+    m.requant(quant, clear)
+    assert m.encode().data == _read(name + ".hry")
+
+
+@pytest.mark.parametrize("name", sorted(MAN["big"]))
+def test_big_scene_hash(name):
+    e = MAN["big"][name]
+    sc = {"torus150": lambda: og.scene(mg.torus(150, 150, seed=2), normals="smooth", tex="atlas", charts=7),
+          "flat_ico5": lambda: og.scene(mg.icosphere(5), normals="flat", tex="corner")}[name]()
+    assert hashlib.sha256(sc.obj).hexdigest() == e["obj_sha256"]
+    for tag, v in e["variants"].items():
+        m = op.Mesh.from_obj(sc.obj, "")
+        quant, clear = util.flags_to_quant(v["flags"])
+        if quant or clear:
+            m.requant(quant, clear)
+        got = m.encode().data
+        assert len(got) == v["hry_bytes"] and hashlib.sha256(got).hexdigest() == v["hry_sha256"]
+
+
+def test_general_coder_on_the_ply_layout_writes_the_same_bytes():
+    """the PLY layout spelled out as general bindings must code to the same stream (the general coder contains the special one)"""
+    for name in ("colors_normals", "faceprops", "nonmanifold", "torus_mixed"):
+        ply = open(os.path.join(util.ROOT, "tests", "golden", name + ".ply"), "rb").read()
+        a = op.Mesh.from_ply(ply)
+        b = a.clone()
+        b.make_general()
+        assert b.general and a.encode().data == b.encode().data
+
+
+def test_obj_grammar_quirks():
+    tri = b"v 0 0 0\nv 1 0 0\nv 0 1 0\n"
+    for bad in (b"v 1e2 0 0\n", b"g\n", b"v 1 2\n", b"v 1 2 3 4 5\n", b"vt 1\n", b"vn 1 2\n", b"x 1\n", b" v 1 2 3\n", b"v 1 2 3\rx\n"):
+        with pytest.raises(RuntimeError, match="Unable to parse"):
+            op.Mesh.from_obj(tri + bad + b"f 1 2 3\n")
+    with pytest.raises(RuntimeError, match="n too big"):
+        op.Mesh.from_obj(tri + b"vt 0 0\nf 1/1 2/1 3/1\n")          # "v/t" names normal t as well
+    with pytest.raises(RuntimeError, match="index cannot be 0"):
+        op.Mesh.from_obj(tri + b"f 0 1 2\n")
+    m = op.Mesh.from_obj(tri + b"f 1 2 3")                            # last line without a line feed: dropped
+    assert (m.nv, m.nf) == (3, 0)
+    m = op.Mesh.from_obj(b"v 1e-1 2e+1 -.5\nv 0 0 0\nv 1 1 1\nf 1 2 3\n")
+    assert m.list_data(0).view("<f4").reshape(-1, 3)[0].tolist() == [10.0, 20.0, -0.5]
