@@ -110,8 +110,16 @@ def load():
     L.hry_list_set_bounds.restype = C.c_int; L.hry_list_set_bounds.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p]
     for n in ("min_at", "max_at"):
         f = getattr(L, "hry_list_" + n); f.restype = C.c_uint32; f.argtypes = [vp, C.c_int, C.c_int]
-    if L.hry_abi_version() != 2:
-        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 2: rebuild it")
+    L.hry_mesh_from_obj.restype = C.c_int; L.hry_mesh_from_obj.argtypes = [C.c_char_p, sz, C.c_char_p, C.POINTER(vp)]
+    L.hry_mesh_to_obj.restype = C.c_int; L.hry_mesh_to_obj.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    L.hry_mesh_general.restype = C.c_int; L.hry_mesh_general.argtypes = [vp]
+    L.hry_list_target.restype = C.c_int; L.hry_list_target.argtypes = [vp, C.c_int]
+    L.hry_mesh_nregions.restype = C.c_int; L.hry_mesh_nregions.argtypes = [vp, C.c_int]
+    L.hry_mesh_region_lists.restype = C.c_int; L.hry_mesh_region_lists.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.hry_mesh_regions_of.restype = sz; L.hry_mesh_regions_of.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.hry_mesh_bindings.restype = sz; L.hry_mesh_bindings.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]
+    if L.hry_abi_version() != 3:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 3: rebuild it")
     _lib = L
     return L
 

@@ -49,6 +49,13 @@ class Mesh:
         return cls(h)
 
     @classmethod
+    def from_obj(cls, data: bytes, directory: str = "") -> "Mesh":
+        """OBJ text -> mesh with general bindings (regions, shared records, corner lists); `directory`: where "mtllib" files are"""
+        h = C.c_void_p()
+        nat.check(nat.load().hry_mesh_from_obj(data, len(data), directory.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def from_arrays(cls, verts: np.ndarray, degrees: np.ndarray, indices: np.ndarray, face_props: np.ndarray | None = None) -> "Mesh":
         """verts / face_props: numpy structured arrays (packed), one field per component."""
         L = nat.load()
@@ -157,6 +164,38 @@ class Mesh:
         p, n = C.c_void_p(), C.c_size_t()
         nat.check(nat.load().hry_mesh_to_ply(self.h, int(ascii) | (2 if packed else 0), C.byref(p), C.byref(n)))
         return nat.take_bytes(p, n.value)
+
+    def to_obj(self) -> bytes:
+        p, n = C.c_void_p(), C.c_size_t()
+        nat.check(nat.load().hry_mesh_to_obj(self.h, 0, C.byref(p), C.byref(n)))
+        return nat.take_bytes(p, n.value)
+
+    # ---- general bindings (structs/attr.h:101-189)
+    general = property(lambda s: bool(nat.load().hry_mesh_general(s.h)))
+    nlists = property(lambda s: nat.load().hry_mesh_nlists(s.h))
+
+    def list_target(self, l) -> int:
+        return nat.load().hry_list_target(self.h, l)
+
+    def nregions(self, which: int) -> int:
+        return nat.load().hry_mesh_nregions(self.h, which)
+
+    def region_lists(self, kind: int, r: int):
+        out = np.zeros(256, np.uint16)
+        n = nat.load().hry_mesh_region_lists(self.h, kind, r, out.ctypes.data, 256)
+        return [int(x) for x in out[:n]]
+
+    def regions_of(self, which: int) -> np.ndarray:
+        p = C.c_void_p()
+        n = nat.load().hry_mesh_regions_of(self.h, which, C.byref(p))
+        return np.frombuffer(C.string_at(p, n * 2), dtype=np.uint16).copy() if n else np.zeros(0, np.uint16)
+
+    def bindings(self, kind: int) -> np.ndarray:
+        p, slots = C.c_void_p(), C.c_int()
+        n = nat.load().hry_mesh_bindings(self.h, kind, C.byref(p), C.byref(slots))
+        if not n or not slots.value:
+            return np.zeros((n, slots.value), np.uint32)
+        return np.frombuffer(C.string_at(p, n * slots.value * 4), dtype=np.uint32).copy().reshape(n, slots.value)
 
     def host_walk(self, plain: bool = False) -> dict:
         """Host-only cut-border walk with a recording writer (mutates twins like an encode).  plain: without the operation

@@ -91,6 +91,59 @@ int hry_mesh_to_ply(const hry_mesh *m, int ascii, uint8_t **out, size_t *out_len
 		*out_len = v.size();
 	});
 }
+int hry_mesh_from_obj(const uint8_t *obj, size_t n, const char *dir, hry_mesh **out)
+{
+	if (!obj || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<Mesh> m(mesh_from_obj(obj, n, dir));
+		*out = new hry_mesh{ std::move(*m) };
+	});
+}
+int hry_mesh_to_obj(const hry_mesh *m, int, uint8_t **out, size_t *out_len)
+{
+	if (!m || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
+	return guarded([&] {
+		std::vector<uint8_t> v;
+		mesh_to_obj(m->m, v);
+		*out = dup_bytes(v);
+		*out_len = v.size();
+	});
+}
+int hry_mesh_general(const hry_mesh *m) { return m && m->m.general ? 1 : 0; }
+int hry_list_target(const hry_mesh *m, int l) { return m && l >= 0 && (size_t)l < m->m.lists.size() ? m->m.lists[l].target : 3; }
+int hry_mesh_nregions(const hry_mesh *m, int which)
+{
+	if (!m) return 0;
+	if (!m->m.general) return 1;
+	return which == 0 ? m->m.bind.nregs_face() : m->m.bind.nregs_vtx();
+}
+int hry_mesh_region_lists(const hry_mesh *m, int kind, int r, uint16_t *out, int cap)
+{
+	if (!m || r < 0) return 0;
+	if (!m->m.general) { if (kind == 2 || r != 0) return 0; if (out && cap > 0) out[0] = kind == 0 ? 0 : 1; return 1; }
+	const Bindings &b = m->m.bind;
+	if (r >= (kind == 1 ? b.nregs_vtx() : b.nregs_face())) return 0;
+	const int n = kind == 0 ? b.nfacelists(r) : kind == 1 ? b.nvtxlists(r) : b.ncornerlists(r);
+	for (int a = 0; a < n && a < cap && out; ++a) out[a] = (uint16_t)(kind == 0 ? b.facelist(r, a) : kind == 1 ? b.vtxlist(r, a) : b.cornerlist(r, a));
+	return n;
+}
+size_t hry_mesh_regions_of(const hry_mesh *m, int which, const uint16_t **out)
+{
+	if (!m || !out || !m->m.general) return 0;
+	const BigVec<uint16_t> &v = which == 0 ? m->m.bind.face_reg : m->m.bind.vtx_reg;
+	*out = v.data();
+	return v.size();
+}
+size_t hry_mesh_bindings(const hry_mesh *m, int kind, const uint32_t **out, int *slots)
+{
+	if (!m || !out || !slots || !m->m.general) return 0;
+	const Bindings &b = m->m.bind;
+	const BigVec<uint32_t> &v = kind == 0 ? b.face_attr : kind == 1 ? b.vtx_attr : b.corner_attr;
+	*slots = kind == 0 ? b.nb_face : kind == 1 ? b.nb_vtx : b.nb_corner;
+	*out = v.data();
+	return kind == 0 ? m->m.nf : kind == 1 ? m->m.nv : m->m.ne();
+}
 void hry_mesh_free(hry_mesh *m) { delete m; }
 hry_mesh *hry_mesh_clone(const hry_mesh *m)
 {
@@ -106,7 +159,7 @@ uint64_t hry_mesh_ntri(const hry_mesh *m) { return m->m.ntri(); }
 const uint32_t *hry_mesh_face_offsets(const hry_mesh *m) { return m->m.face_off.data(); }
 const uint32_t *hry_mesh_org(const hry_mesh *m) { return m->m.org.data(); }
 const uint32_t *hry_mesh_twin(const hry_mesh *m) { return m->m.twin.data(); }
-int hry_mesh_nlists(const hry_mesh *) { return 2; }
+int hry_mesh_nlists(const hry_mesh *m) { return (int)m->m.lists.size(); }
 int hry_list_ncomp(const hry_mesh *m, int l) { return m->m.lists[l].ncomp(); }
 uint32_t hry_list_count(const hry_mesh *m, int l) { return m->m.lists[l].count; }
 int hry_list_stride(const hry_mesh *m, int l) { return m->m.lists[l].stride(); }
@@ -244,7 +297,7 @@ size_t hry_shard_elements(const hry_mesh *m, int which, const uint32_t **idx)
 }
 int hry_list_set_bounds(hry_mesh *m, int l, const uint8_t *min_rec, const uint8_t *max_rec)
 {
-	if (!m || l < 0 || l > 1 || !min_rec || !max_rec) { g_last_error = "invalid argument"; return HRY_E_ARG; }
+	if (!m || l < 0 || (size_t)l >= m->m.lists.size() || !min_rec || !max_rec) { g_last_error = "invalid argument"; return HRY_E_ARG; }
 	AttrList &L = m->m.lists[l];
 	for (int c = 0; c < L.ncomp(); ++c) if (L.quant[c]) { g_last_error = "bounds of an already quantised list come from its header"; return HRY_E_ARG; }
 	L.bmin.assign(min_rec, min_rec + L.stride());
@@ -253,8 +306,8 @@ int hry_list_set_bounds(hry_mesh *m, int l, const uint8_t *min_rec, const uint8_
 	L.have_bounds = true;
 	return HRY_OK;
 }
-uint32_t hry_list_min_at(const hry_mesh *m, int l, int c) { return m && l >= 0 && l < 2 && c >= 0 && (size_t)c < m->m.lists[l].bmin_at.size() ? m->m.lists[l].bmin_at[c] : 0; }
-uint32_t hry_list_max_at(const hry_mesh *m, int l, int c) { return m && l >= 0 && l < 2 && c >= 0 && (size_t)c < m->m.lists[l].bmax_at.size() ? m->m.lists[l].bmax_at[c] : 0; }
+uint32_t hry_list_min_at(const hry_mesh *m, int l, int c) { return m && l >= 0 && (size_t)l < m->m.lists.size() && c >= 0 && (size_t)c < m->m.lists[l].bmin_at.size() ? m->m.lists[l].bmin_at[c] : 0; }
+uint32_t hry_list_max_at(const hry_mesh *m, int l, int c) { return m && l >= 0 && (size_t)l < m->m.lists.size() && c >= 0 && (size_t)c < m->m.lists[l].bmax_at.size() ? m->m.lists[l].bmax_at[c] : 0; }
 
 int hry_stage_get(hry_ctx *ctx, const char *name, void **host_copy, size_t *bytes)
 {
@@ -327,6 +380,7 @@ int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_wal
 		int minor = 0;
 		size_t hdr = read_hry_header((const uint8_t*)hry, bytes, m->m, minor);
 		if (minor != 1) throw Error(HRY_E_ARG, "not a single-stream (v0.1) file");
+		if (m->m.general) throw Error(HRY_E_UNSUPPORTED, "hry_stream_read_host returns the planes of the PLY layout only");
 		std::vector<uint32_t> seg_start, seg_level;
 		std::vector<uint32_t> order_v;
 		read_compat_stream((const uint8_t*)hry + hdr, bytes - hdr, m->m, order_v, seg_start, seg_level, w->vplanes, w->fplanes);

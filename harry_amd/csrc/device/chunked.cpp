@@ -62,6 +62,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	HIP_OK(hipSetDevice(cx.device));
 	auto t_all = Clock::now();
 	cx.timing = hry_timing{};
+	if (m.general) throw Error(HRY_E_UNSUPPORTED, "the chunked container holds the PLY layout only (one face list, one vertex list, one record per element): code general bindings with HRY_PROFILE_COMPAT");
 	check_codable(m);
 	uint32_t CH = chunk_syms > 0 ? std::min<uint32_t>((uint32_t)chunk_syms, kMaxChunk) : (uint32_t)kDefaultChunk;
 	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
@@ -313,6 +314,7 @@ Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index, int s
 	if (minor == 3) return decode_sharded(cx, p, n, hdr, std::move(m), shard_index, shard_count);
 	if (shard_count > 1) throw Error(HRY_E_ARG, "only a sharded container (.hry v0.3) decodes segment by segment");
 	if (minor == 2) return decode_chunked(cx, p, n, hdr, std::move(m));
+	if (m->general) return decode_general(cx, p, n, hdr, std::move(m));
 	return decode_compat(cx, p, n, hdr, std::move(m));
 }
 

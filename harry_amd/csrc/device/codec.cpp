@@ -85,7 +85,8 @@ void Context::ensure_magic(uint32_t n)
 void Context::upload_mesh(Mesh &m)
 {
 	HIP_OK(hipSetDevice(device));
-	for (int l = 0; l < 2; ++l) {
+	if (m.lists.size() > (size_t)kMaxLists) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
+	for (size_t l = 0; l < m.lists.size(); ++l) {
 		d_rec[l].ensure(std::max<size_t>(m.lists[l].data.size(), 16));
 		if (!m.lists[l].data.empty()) HIP_OK(hipMemcpyAsync(d_rec[l].p, m.lists[l].data.data(), m.lists[l].data.size(), hipMemcpyHostToDevice, stream));
 	}
@@ -133,12 +134,13 @@ ListDesc make_list_desc(const AttrList &L)
 
 void check_codable(const Mesh &m)
 {
-	for (int l = 0; l < 2; ++l)
+	for (size_t l = 0; l < m.lists.size(); ++l)
 		for (int c = 0; c < m.lists[l].ncomp(); ++c) {
 			CompType st = m.lists[l].stype(c);
 			if (st == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components: the reference's residual code reads out of bounds for 8-byte floats (prediction.h:33-44); quantise them with -q");
+			if (m.general && kTypeSize[st] == 8) throw Error(HRY_E_UNSUPPORTED, "8-byte storage types (more than 32 quantisation bits, lossless 64-bit integers) are outside the supported subset");
 		}
-	if (m.lists[0].count != m.nf || m.lists[1].count != m.nv) throw Error(HRY_E_UNSUPPORTED, "attribute lists must have one record per element");
+	if (!m.general && (m.lists[0].count != m.nf || m.lists[1].count != m.nv)) throw Error(HRY_E_UNSUPPORTED, "attribute lists must have one record per element");
 	int dmax = (int)m.have_degree.size() - 1;
 	if (dmax - 2 >= 128) throw Error(HRY_E_UNSUPPORTED, "polygons with more than 129 edges: the reference seeds its numtri model out of bounds (model.h:49-55)");
 }
@@ -155,7 +157,7 @@ void device_bounds(Context &cx, Mesh &m)
 	uint8_t *pmin = cx.d_small.as<uint8_t>(), *pmax = pmin + (size_t)nparts * dev::kMaxComp * 8;
 	uint32_t *pidx = (uint32_t*)(pmax + (size_t)nparts * dev::kMaxComp * 8);
 	uint8_t *outs = (uint8_t*)(pidx + 2 * (size_t)nparts * dev::kMaxComp);
-	for (int l = 0; l < 2; ++l) {
+	for (size_t l = 0; l < m.lists.size(); ++l) {
 		AttrList &L = m.lists[l];
 		bool quantised = false;
 		for (int c = 0; c < L.ncomp(); ++c) quantised |= L.quant[c] != 0;
@@ -235,12 +237,14 @@ void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool cl
 {
 	HIP_OK(hipSetDevice(cx.device));
 	// validation and expansion as the reference CLI does it (main.cc:74-91)
-	std::vector<uint8_t> nquant[2] = { m.lists[0].quant, m.lists[1].quant };
+	const int nl = (int)m.lists.size();
+	std::vector<std::vector<uint8_t>> nquant(nl);
+	for (int l = 0; l < nl; ++l) nquant[l] = m.lists[l].quant;
 	struct One { int l, c, q; };
 	std::vector<One> reqs;
 	for (size_t i = 0; i < nq; ++i) {
 		if (q[i].bits < 0) throw Error(HRY_E_ARG, "Invalid quantization bits");
-		if (q[i].list < 0 || q[i].list >= 2) throw Error(HRY_E_ARG, "Invalid list index");
+		if (q[i].list < 0 || q[i].list >= nl) throw Error(HRY_E_ARG, "Invalid list index");
 		const AttrList &L = m.lists[q[i].list];
 		if (q[i].comp == -1) {
 			for (int c = 0; c < L.ncomp(); ++c) {
@@ -253,16 +257,16 @@ void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool cl
 			reqs.push_back(One{ q[i].list, q[i].comp, q[i].bits });
 		}
 	}
-	if (clear) for (int l = 0; l < 2; ++l) std::fill(nquant[l].begin(), nquant[l].end(), 0);
+	if (clear) for (int l = 0; l < nl; ++l) std::fill(nquant[l].begin(), nquant[l].end(), 0);
 	for (const One &r : reqs) nquant[r.l][r.c] = (uint8_t)r.q;
 
 	bool any = false;
-	for (int l = 0; l < 2; ++l) any |= nquant[l] != m.lists[l].quant;
+	for (int l = 0; l < nl; ++l) any |= nquant[l] != m.lists[l].quant;
 	if (!any) return;
-	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
+	for (int l = 0; l < nl; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
 	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
 
-	for (int l = 0; l < 2; ++l) {
+	for (int l = 0; l < nl; ++l) {
 		AttrList &L = m.lists[l];
 		if (nquant[l] == L.quant) continue;
 		std::vector<uint8_t> scale = shared_extent(L);
@@ -291,7 +295,7 @@ void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool cl
 // range coder back end shared by encode_compat and hry_range_encode_lht:
 // records (device) -> payload bytes (host)
 // ---------------------------------------------------------------------------------------------------------
-static void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload)
+void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload)
 {
 	cx.d_r.ensure(std::max<size_t>((size_t)ns * 8, 16));
 	cx.d_s.ensure(std::max<size_t>((size_t)ns * 4, 16));
@@ -395,6 +399,7 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 {
 	HIP_OK(hipSetDevice(cx.device));
 	auto t_all = Clock::now();
+	if (m.general) { encode_general(cx, m, out); return; }
 	cx.timing = hry_timing{};
 	check_codable(m);
 	// the reference's single stream carries one coder state and one numbering across the whole file: it does not shard

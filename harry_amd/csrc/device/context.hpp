@@ -54,6 +54,8 @@ struct PinBuf {
 	template <typename T> T *as() const { return (T*)p; }
 };
 
+constexpr int kMaxLists = 16;   // attribute lists of one mesh kept in HBM (the OBJ reader creates at most 8)
+
 struct Context {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -70,7 +72,8 @@ struct Context {
 	// resident mesh (hry_mesh_upload): attribute records and connectivity stay in HBM across encodes
 	uint64_t resident_token = 0;
 	uint64_t next_token = 1;
-	DevBuf d_rec[2], d_org, d_twin, d_foff, d_eface;
+	DevBuf d_rec[kMaxLists], d_org, d_twin, d_foff, d_eface;
+	DevBuf d_vreg, d_freg, d_vattr, d_cattr, d_gen;   // general bindings (general.cpp): region and record tables, event arena
 	uint32_t res_nv = 0, res_nf = 0, res_ne = 0, res_udeg = 0;
 	bool res_has_eface = false;
 
@@ -105,6 +108,9 @@ void device_bounds(Context &cx, Mesh &m);
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);
 void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
 void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &out);
+void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out);   // general.cpp: regions, shared records, corner lists (reference stream only)
+Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
+void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload);
 Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index = 0, int shard_count = 0);
 void range_encode_lht(Context &cx, const uint64_t *lht, size_t n, std::vector<uint8_t> &out);
 

@@ -24,6 +24,13 @@ struct ConnView {
 	uint32_t udeg, nf, ne;
 };
 
+// general bindings as the kernels see them (mesh.hpp Bindings): element -> region, element x slot -> record of the bound list
+struct GenView {
+	const uint16_t *vtx_reg, *face_reg;
+	const uint32_t *vtx_attr, *corner_attr;
+	int32_t nb_vtx, nb_corner;
+};
+
 // per-symbol record consumed by the serial range recurrence (16 bytes, one dwordx4 per lane)
 struct alignas(16) SymRec {
 	uint64_t magic;    // reciprocal of the context total t (round-up method, 65-bit magic with implicit top bit)

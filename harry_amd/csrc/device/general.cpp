@@ -1,0 +1,468 @@
+// The reference stream (.hry v0.1) of a mesh with GENERAL bindings: several regions, records
+// shared between elements, corner attributes -- what the OBJ reader creates (formats/obj/reader.rl:108-277) and what
+// formats/hry/attrcode.h:23-80,135-154,321-393,443-531 code.  The PLY layout keeps its own faster pipeline (codec.cpp).
+//
+// Division of labour, as everywhere in the compat profile:
+//   host    the cut-border walk; which record every vertex / face / corner names and whether the stream says so with a new
+//           record (DATA), a distance in creation order (HIST) or a distance in the vertex' own list of names (LHIST) --
+//           integer bookkeeping along the coding order; the position of every symbol in the single stream
+//   device  prediction + residuals of every record coded as DATA (general.hip), the adaptive models of every byte plane by
+//           counting, the range coder (kernels.hip: the same kernels as the PLY layout; planes carry explicit positions)
+// and for the decoder: host = serial entropy decode + replay + the same bookkeeping (compat_read.cpp), device = un-prediction.
+#include <chrono>
+#include <cstring>
+
+#include "codec_math.hpp"
+#include "context.hpp"
+#include "kernels.hpp"
+
+namespace hry {
+
+using namespace dev;
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+namespace dev {
+void launch_face_rank(hipStream_t st, const ConnView &cv, const uint32_t *order_f, uint32_t n, uint32_t *frank);
+void launch_gen_vtx_resid(hipStream_t st, const ConnView &cv, const GenView &gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
+                          const uint32_t *ev_idx, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
+void launch_gen_face_resid(hipStream_t st, const uint32_t *ev_idx, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
+void launch_gen_corner_resid(hipStream_t st, const ConnView &cv, const GenView &gv, const uint32_t *frank, const uint32_t *ev_he, const uint8_t *ev_slot,
+                             const uint32_t *ev_idx, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
+void launch_gen_unpredict(hipStream_t st, int kind, const ConnView &cv, const GenView &gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
+                          uint32_t n, uint8_t *rec, const ListDesc &ld, uint32_t *done);
+uint32_t gen_timeout_flags(hipStream_t st);
+void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
+}
+
+void check_general(const Mesh &m)
+{
+	const Bindings &b = m.bind;
+	if (m.shard.active()) throw Error(HRY_E_UNSUPPORTED, "a shard holds the PLY layout only");
+	if (m.lists.size() > (size_t)kMaxLists) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
+	if (b.nregs_face() > 128 || b.nregs_vtx() > 128) throw Error(HRY_E_UNSUPPORTED, "more than 128 regions: the reference seeds its region models out of bounds (model.h:49-55)");
+	if (b.nb_face > 255 || b.nb_vtx > 255 || b.nb_corner > 255) throw Error(HRY_E_UNSUPPORTED, "more than 255 lists bound to one region");
+	if (b.face_reg.size() != m.nf || b.vtx_reg.size() != m.nv || b.face_attr.size() != (size_t)m.nf * b.nb_face ||
+	    b.vtx_attr.size() != (size_t)m.nv * b.nb_vtx || b.corner_attr.size() != (size_t)m.ne() * b.nb_corner)
+		throw Error(HRY_E_ARG, "binding tables do not match the element counts");
+	auto bound = [&](int l, int want) {
+		if (l < 0 || l >= (int)m.lists.size()) throw Error(HRY_E_ARG, "a region binds a list that does not exist");
+		if (m.lists[l].target != want) throw Error(HRY_E_ARG, "a region binds a list of another kind");
+	};
+	for (int r = 0; r < b.nregs_face(); ++r) {
+		for (int a = 0; a < b.nfacelists(r); ++a) bound(b.facelist(r, a), 0);
+		for (int a = 0; a < b.ncornerlists(r); ++a) bound(b.cornerlist(r, a), 2);
+	}
+	for (int r = 0; r < b.nregs_vtx(); ++r) for (int a = 0; a < b.nvtxlists(r); ++a) bound(b.vtxlist(r, a), 1);
+	for (uint32_t f = 0; f < m.nf; ++f) if (b.face_reg[f] >= b.nregs_face()) throw Error(HRY_E_ARG, "face region out of range");
+	for (uint32_t v = 0; v < m.nv; ++v) if (b.vtx_reg[v] >= b.nregs_vtx()) throw Error(HRY_E_ARG, "vertex region out of range");
+}
+
+// connectivity + every list + the binding tables -> HBM
+void upload_general(Context &cx, Mesh &m)
+{
+	cx.upload_mesh(m);
+	const Bindings &b = m.bind;
+	auto put = [&](DevBuf &d, const void *src, size_t bytes) {
+		d.ensure(std::max<size_t>(bytes, 16));
+		if (bytes) HIP_OK(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, cx.stream));
+	};
+	put(cx.d_vreg, b.vtx_reg.data(), b.vtx_reg.size() * 2);
+	put(cx.d_freg, b.face_reg.data(), b.face_reg.size() * 2);
+	put(cx.d_vattr, b.vtx_attr.data(), b.vtx_attr.size() * 4);
+	put(cx.d_cattr, b.corner_attr.data(), b.corner_attr.size() * 4);
+	HIP_OK(hipStreamSynchronize(cx.stream));
+}
+static GenView gen_view(const Context &cx, const Mesh &m)
+{
+	GenView gv;
+	gv.vtx_reg = cx.d_vreg.as<uint16_t>(); gv.face_reg = cx.d_freg.as<uint16_t>();
+	gv.vtx_attr = cx.d_vattr.as<uint32_t>(); gv.corner_attr = cx.d_cattr.as<uint32_t>();
+	gv.nb_vtx = m.bind.nb_vtx; gv.nb_corner = m.bind.nb_corner;
+	return gv;
+}
+
+namespace {
+
+// everything the stream says about one list, as byte planes with the position of every symbol in the stream
+struct ListStream {
+	std::vector<uint8_t> type_sym;
+	std::vector<uint32_t> type_pos;
+	std::vector<uint32_t> gh_val, gh_pos;   // distance in creation order (4 bytes each, io.h:99-103)
+	std::vector<uint32_t> lh_val, lh_pos;   // distance in the vertex' own names (2 bytes each, io.h:104-108)
+	std::vector<uint32_t> d_pos, d_idx, d_he;   // records coded as data: position of the first residual byte, the record, where
+	std::vector<uint8_t> d_slot;
+	uint32_t nbytes = 0;                    // residual bytes per record
+	std::vector<uint32_t> first_at;         // record -> its rank among the records created so far (GlobalHistory::tidxlist)
+	uint32_t created = 0;
+};
+
+struct Events {
+	std::vector<ListStream> ls;
+	std::vector<uint8_t> rv_sym, rf_sym;    // region of every vertex / face (low byte; the high byte never carries information)
+	std::vector<uint32_t> rv_pos, rf_pos;
+	uint32_t end_pos = 0;
+};
+
+// attrcode.h:321-393,395-416 without the values
+void collect_events(const Mesh &m, const WalkResult &w, uint32_t pos0, Events &E)
+{
+	const Bindings &b = m.bind;
+	static constexpr uint32_t NONE = 0xffffffffu;
+	E.ls.assign(m.lists.size(), ListStream());
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		E.ls[l].nbytes = (uint32_t)m.lists[l].coded_bytes();
+		E.ls[l].first_at.assign(m.lists[l].count, NONE);
+	}
+	const bool code_rv = b.nregs_vtx() > 1, code_rf = b.nregs_face() > 1;
+	uint32_t pos = pos0;
+	auto reference = [&](int l, uint32_t idx) -> bool {   // true: already created (HIST written)
+		ListStream &S = E.ls[l];
+		if (idx >= S.first_at.size()) throw Error(HRY_E_ARG, "an element names a record outside its list");
+		if (S.first_at[idx] == NONE) { S.first_at[idx] = S.created++; return false; }
+		S.type_sym.push_back(1); S.type_pos.push_back(pos++);
+		S.gh_val.push_back(S.created - 1 - S.first_at[idx]); S.gh_pos.push_back(pos);
+		pos += 4;
+		return true;
+	};
+	auto data = [&](int l, uint32_t idx, uint32_t he, int slot) {
+		ListStream &S = E.ls[l];
+		S.type_sym.push_back(0); S.type_pos.push_back(pos++);
+		S.d_pos.push_back(pos); S.d_idx.push_back(idx); S.d_he.push_back(he); S.d_slot.push_back((uint8_t)slot);
+		pos += S.nbytes;
+	};
+	for (uint32_t e : w.order_v) {
+		const uint32_t v = m.org[e];
+		const int r = b.vtx_reg[v];
+		if (code_rv) { E.rv_sym.push_back((uint8_t)r); E.rv_pos.push_back(pos++); }
+		for (int a = 0; a < b.nvtxlists(r); ++a) {
+			const int l = b.vtxlist(r, a);
+			const uint32_t idx = b.vtx_attr[(size_t)v * b.nb_vtx + a];
+			if (!reference(l, idx)) data(l, idx, e, a);
+		}
+	}
+	// per corner slot and vertex: the records named there so far, newest first (LocalHistory, attrcode.h:54-80)
+	struct Node { uint32_t idx, next; };
+	std::vector<Node> pool;
+	std::vector<std::vector<uint32_t>> head(b.nb_corner);
+	for (auto &h : head) h.assign(m.nv, NONE);
+	// face of a half-edge
+	std::vector<uint32_t> eface(m.ne());
+	for (uint32_t f = 0; f < m.nf; ++f) for (uint32_t e = m.face_off[f]; e < m.face_off[f + 1]; ++e) eface[e] = f;
+	for (uint32_t e0 : w.order_f) {
+		const uint32_t f = eface[e0];
+		const int r = b.face_reg[f];
+		if (code_rf) { E.rf_sym.push_back((uint8_t)r); E.rf_pos.push_back(pos++); }
+		for (int a = 0; a < b.nfacelists(r); ++a) {
+			const int l = b.facelist(r, a);
+			const uint32_t idx = b.face_attr[(size_t)f * b.nb_face + a];
+			if (!reference(l, idx)) data(l, idx, f, a);
+		}
+		const uint32_t fb = m.face_off[f], fe = m.face_off[f + 1];
+		uint32_t c = e0;
+		do {
+			const uint32_t v = m.org[c];
+			for (int a = 0; a < b.ncornerlists(r); ++a) {
+				const int l = b.cornerlist(r, a);
+				const uint32_t idx = b.corner_attr[(size_t)c * b.nb_corner + a];
+				uint32_t back = 0, k = head[a][v];
+				while (k != NONE && pool[k].idx != idx) { k = pool[k].next; ++back; }
+				if (k != NONE) {
+					if (back > 0xffffu) throw Error(HRY_E_UNSUPPORTED, "more than 65536 different records of one list at one vertex (io.h:104 codes 16 bits)");
+					ListStream &S = E.ls[l];
+					S.type_sym.push_back(2); S.type_pos.push_back(pos++);
+					S.lh_val.push_back(back); S.lh_pos.push_back(pos);
+					pos += 2;
+					continue;
+				}
+				pool.push_back(Node{ idx, head[a][v] });
+				head[a][v] = (uint32_t)pool.size() - 1;
+				if (!reference(l, idx)) data(l, idx, c, a);
+			}
+			c = c + 1 == fe ? fb : c + 1;
+		} while (c != e0);
+	}
+	E.end_pos = pos;
+}
+
+// a device arena filled from host vectors in one go
+struct Arena {
+	std::vector<uint8_t> host;
+	size_t add(const void *p, size_t bytes)
+	{
+		size_t at = (host.size() + 15) & ~(size_t)15;
+		host.resize(at + bytes);
+		if (bytes) memcpy(host.data() + at, p, bytes);
+		return at;
+	}
+	template <typename T> size_t add(const std::vector<T> &v) { return add(v.data(), v.size() * sizeof(T)); }
+};
+
+}   // namespace
+
+void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload);
+
+void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	auto t_all = Clock::now();
+	cx.timing = hry_timing{};
+	check_codable(m);
+	check_general(m);
+	for (auto &L : m.lists) if (!L.have_bounds && L.ncomp()) { device_bounds(cx, m); break; }
+	for (auto &L : m.lists) if (!L.have_bounds) { L.bmin.assign(L.stride(), 0); L.bmax.assign(L.stride(), 0); L.have_bounds = true; }
+	upload_general(cx, m);
+
+	out.clear();
+	write_hry_header(m, 1, out);
+	auto t_walk = Clock::now();
+	WalkResult w;
+	cut_border_walk(m, w);
+	Events E;
+	collect_events(m, w, w.n_conn, E);
+	cx.timing.host_walk_ms = ms_since(t_walk);
+	if ((uint64_t)E.end_pos >= (1ull << 31)) throw Error(HRY_E_UNSUPPORTED, "more than 2^31 symbols in one compat stream");
+	const uint32_t ns = E.end_pos;
+	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
+
+	// ---- H2D: orders, repaired twins, connectivity groups (as codec.cpp), then everything collect_events produced
+	auto t_h2d = Clock::now();
+	HIP_OK(hipEventRecord(cx.ev[0], cx.stream));
+	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
+	cx.d_order_f.ensure(std::max<size_t>((size_t)fc * 4, 16));
+	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4 + (size_t)m.nf * 4, 16));
+	uint32_t *d_rank = cx.d_rank.as<uint32_t>(), *d_frank = d_rank + m.nv;
+	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
+	if (fc) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));
+	if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
+	size_t ngrp = 0;
+	for (int g = 0; g < G_COUNT; ++g) ngrp += w.grp_val[g].size();
+	const size_t nop = w.op_sc.size();
+	cx.d_grp_val.ensure(std::max<size_t>(ngrp * 4, 16));
+	cx.d_grp_pos.ensure(std::max<size_t>(ngrp * 4, 16));
+	cx.d_op.ensure(std::max<size_t>(nop * 16, 16));
+	size_t goff[G_COUNT + 1] = { 0 };
+	for (int g = 0; g < G_COUNT; ++g) {
+		size_t n = w.grp_val[g].size();
+		goff[g + 1] = goff[g] + n;
+		if (!n) continue;
+		HIP_OK(hipMemcpyAsync(cx.d_grp_val.as<uint32_t>() + goff[g], w.grp_val[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(cx.d_grp_pos.as<uint32_t>() + goff[g], w.grp_pos[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
+	}
+	uint32_t *d_opl = cx.d_op.as<uint32_t>(), *d_oph = d_opl + nop, *d_opt = d_oph + nop, *d_opp = d_opt + nop;
+	if (nop) {
+		HIP_OK(hipMemcpyAsync(d_opl, w.op_l.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(d_oph, w.op_h.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(d_opt, w.op_t.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(d_opp, w.op_pos.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+	}
+
+	// initial count tables (models.h:197-218)
+	std::vector<uint32_t> inits;
+	auto add_init = [&](const std::vector<uint32_t> &t) { uint32_t id = (uint32_t)(inits.size() / 256); inits.insert(inits.end(), t.begin(), t.end()); return id; };
+	std::vector<uint32_t> ones(256, 1), iop_init(256, 0), nt0(256, 0), nt1(256, 0), ty2(256, 0), ty3(256, 0), rv(256, 0), rf(256, 0);
+	for (int i = 0; i < 9; ++i) iop_init[i] = 1;
+	for (size_t d = 3; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++nt0[(d - 2) & 0xff]; ++nt1[(d - 2) >> 8]; }
+	ty2[0] = ty2[1] = 1; ty3[0] = ty3[1] = ty3[2] = 1;
+	for (int r = 0; r < m.bind.nregs_vtx(); ++r) ++rv[r];
+	for (int r = 0; r < m.bind.nregs_face(); ++r) ++rf[r];
+	const uint32_t id_ones = add_init(ones), id_iop = add_init(iop_init), id_nt0 = add_init(nt0), id_nt1 = add_init(nt1),
+	               id_ty2 = add_init(ty2), id_ty3 = add_init(ty3), id_rv = add_init(rv), id_rf = add_init(rf);
+	auto total_of = [&](uint32_t id) { uint32_t s = 0; for (int i = 0; i < 256; ++i) s += inits[(size_t)id * 256 + i]; return s; };
+	cx.d_init.ensure(inits.size() * 4);
+	HIP_OK(hipMemcpyAsync(cx.d_init.p, inits.data(), inits.size() * 4, hipMemcpyHostToDevice, cx.stream));
+
+	// the arena: symbol planes the host made, position tables, event tables; then room for the residual planes the kernels make
+	Arena A;
+	struct ListAt { size_t type_sym, type_pos, gh_planes, gh_pos, lh_planes, lh_pos, d_pos, d_idx, d_he, d_slot, planes; };
+	std::vector<ListAt> at(m.lists.size());
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		const ListStream &S = E.ls[l];
+		ListAt &T = at[l];
+		T.type_sym = A.add(S.type_sym); T.type_pos = A.add(S.type_pos);
+		std::vector<uint8_t> pl(S.gh_val.size() * 4);
+		for (size_t i = 0; i < S.gh_val.size(); ++i) for (int k = 0; k < 4; ++k) pl[(size_t)k * S.gh_val.size() + i] = (uint8_t)(S.gh_val[i] >> (8 * k));
+		T.gh_planes = A.add(pl); T.gh_pos = A.add(S.gh_pos);
+		pl.assign(S.lh_val.size() * 2, 0);
+		for (size_t i = 0; i < S.lh_val.size(); ++i) for (int k = 0; k < 2; ++k) pl[(size_t)k * S.lh_val.size() + i] = (uint8_t)(S.lh_val[i] >> (8 * k));
+		T.lh_planes = A.add(pl); T.lh_pos = A.add(S.lh_pos);
+		T.d_pos = A.add(S.d_pos); T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
+	}
+	const size_t rv_sym = A.add(E.rv_sym), rv_pos = A.add(E.rv_pos), rf_sym = A.add(E.rf_sym), rf_pos = A.add(E.rf_pos);
+	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
+	for (size_t l = 0; l < m.lists.size(); ++l) { at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_pos.size() * E.ls[l].nbytes + 15) & ~(size_t)15; }
+	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
+	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
+	uint8_t *arena = cx.d_gen.as<uint8_t>();
+
+	size_t conn_plane_bytes = 0;
+	for (int g = 0; g < G_COUNT; ++g) conn_plane_bytes += w.grp_val[g].size() * kGroupBytes[g];
+	cx.d_connplanes.ensure(std::max<size_t>(conn_plane_bytes, 16));
+
+	// ---- model jobs
+	std::vector<PlaneJob> jobs;
+	std::vector<ChunkRef> chunks;
+	uint32_t max_total = 2;
+	auto add_job = [&](const uint8_t *sym, uint32_t n, uint32_t init_id, const uint32_t *pos_tab, uint32_t pos_add) {
+		if (!n) return;
+		PlaneJob j{};
+		j.sym = sym; j.n = n; j.init = cx.d_init.as<uint32_t>() + (size_t)init_id * 256; j.t0 = total_of(init_id);
+		j.pos_tab = pos_tab; j.pos_add = pos_add; j.pos_base = 0; j.pos_stride = 0;
+		j.chunk0 = (uint32_t)chunks.size();
+		for (uint32_t f = 0; f < n; f += kChunk) chunks.push_back(ChunkRef{ (uint32_t)jobs.size(), f });
+		jobs.push_back(j);
+		max_total = std::max(max_total, j.t0 + n);
+	};
+	{
+		size_t poff = 0;
+		for (int g = 0; g < G_COUNT; ++g) {
+			uint32_t n = (uint32_t)w.grp_val[g].size();
+			for (int k = 0; k < kGroupBytes[g]; ++k) {
+				uint32_t init_id = g == G_IOP ? id_iop : g == G_NUMTRI ? (k == 0 ? id_nt0 : id_nt1) : id_ones;
+				add_job(cx.d_connplanes.as<uint8_t>() + poff + (size_t)k * n, n, init_id, cx.d_grp_pos.as<uint32_t>() + goff[g], (uint32_t)k);
+			}
+			poff += (size_t)n * kGroupBytes[g];
+		}
+	}
+	add_job(arena + rv_sym, (uint32_t)E.rv_sym.size(), id_rv, (const uint32_t*)(arena + rv_pos), 0);
+	add_job(arena + rf_sym, (uint32_t)E.rf_sym.size(), id_rf, (const uint32_t*)(arena + rf_pos), 0);
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		const ListStream &S = E.ls[l];
+		const ListAt &T = at[l];
+		add_job(arena + T.type_sym, (uint32_t)S.type_sym.size(), m.lists[l].target == 2 ? id_ty3 : id_ty2, (const uint32_t*)(arena + T.type_pos), 0);
+		for (int k = 0; k < 4; ++k) add_job(arena + T.gh_planes + (size_t)k * S.gh_val.size(), (uint32_t)S.gh_val.size(), id_ones, (const uint32_t*)(arena + T.gh_pos), (uint32_t)k);
+		for (int k = 0; k < 2; ++k) add_job(arena + T.lh_planes + (size_t)k * S.lh_val.size(), (uint32_t)S.lh_val.size(), id_ones, (const uint32_t*)(arena + T.lh_pos), (uint32_t)k);
+		const uint32_t nd = (uint32_t)S.d_pos.size();
+		for (uint32_t k = 0; k < S.nbytes; ++k) add_job(arena + T.planes + (size_t)k * nd, nd, id_ones, (const uint32_t*)(arena + T.d_pos), k);
+	}
+	for (size_t i = 0; i < nop; ++i) max_total = std::max(max_total, w.op_t[i] + 1);
+	cx.d_jobs.ensure(std::max<size_t>(jobs.size() * sizeof(PlaneJob), 16));
+	cx.d_chunks.ensure(std::max<size_t>(chunks.size() * sizeof(ChunkRef), 16));
+	cx.d_hist.ensure(std::max<size_t>(chunks.size() * 256 * 4, 16));
+	if (!jobs.empty()) HIP_OK(hipMemcpyAsync(cx.d_jobs.p, jobs.data(), jobs.size() * sizeof(PlaneJob), hipMemcpyHostToDevice, cx.stream));
+	if (!chunks.empty()) HIP_OK(hipMemcpyAsync(cx.d_chunks.p, chunks.data(), chunks.size() * sizeof(ChunkRef), hipMemcpyHostToDevice, cx.stream));
+	cx.ensure_magic(max_total + 1);
+	cx.d_rec_sym.ensure(std::max<size_t>((size_t)ns * sizeof(SymRec), 16));
+	cx.d_sym_l.ensure(std::max<size_t>((size_t)ns * 4, 16));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.h2d_ms = ms_since(t_h2d);
+
+	// ---- device: residuals of the records coded as data
+	ConnView cv = cx.conn_view();
+	const GenView gv = gen_view(cx, m);
+	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
+	HIP_OK(hipMemsetAsync(d_rank, 0xff, (size_t)m.nv * 4, cx.stream));
+	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, d_rank);
+	launch_face_rank(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, d_frank);
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		const ListStream &S = E.ls[l];
+		const ListAt &T = at[l];
+		const uint32_t nd = (uint32_t)S.d_pos.size();
+		if (!nd || !S.nbytes) continue;
+		const ListDesc ld = make_list_desc(m.lists[l]);
+		const uint32_t *he = (const uint32_t*)(arena + T.d_he), *idx = (const uint32_t*)(arena + T.d_idx);
+		const uint8_t *slot = arena + T.d_slot;
+		const uint8_t *rec = cx.d_rec[l].as<uint8_t>();
+		if (m.lists[l].target == 1) launch_gen_vtx_resid(cx.stream, cv, gv, d_rank, he, slot, idx, nd, rec, ld, arena + T.planes);
+		else if (m.lists[l].target == 2) launch_gen_corner_resid(cx.stream, cv, gv, d_frank, he, slot, idx, nd, rec, ld, arena + T.planes);
+		else launch_gen_face_resid(cx.stream, idx, nd, rec, ld, arena + T.planes);
+	}
+	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
+	// ---- device: models -> per-symbol records in stream order
+	{
+		size_t poff = 0;
+		for (int g = 0; g < G_COUNT; ++g) {
+			uint32_t n = (uint32_t)w.grp_val[g].size();
+			launch_split_bytes(cx.stream, cx.d_grp_val.as<uint32_t>() + goff[g], n, kGroupBytes[g], cx.d_connplanes.as<uint8_t>() + poff);
+			poff += (size_t)n * kGroupBytes[g];
+		}
+	}
+	const MagicEnt *magic = cx.d_magic.as<MagicEnt>();
+	SymRec *rec = cx.d_rec_sym.as<SymRec>();
+	uint32_t *sym_l = cx.d_sym_l.as<uint32_t>();
+	launch_op_records(cx.stream, d_opl, d_oph, d_opt, d_opp, (uint32_t)nop, magic, rec, sym_l);
+	launch_model(cx.stream, cx.d_jobs.as<PlaneJob>(), (uint32_t)jobs.size(), cx.d_chunks.as<ChunkRef>(), (uint32_t)chunks.size(), cx.d_hist.as<uint32_t>(), magic, rec, sym_l);
+
+	if (cx.keep_stages) {
+		cx.stage_put_host("order_v", w.order_v.data(), (size_t)vc * 4);
+		cx.stage_put_host("order_f", w.order_f.data(), (size_t)fc * 4);
+		cx.stage_put("rec", cx.d_rec_sym.p, (size_t)ns * sizeof(SymRec));
+		cx.stage_put("sym_l", cx.d_sym_l.p, (size_t)ns * 4);
+	}
+	std::vector<uint8_t> payload;
+	finish_stream(cx, ns, payload);
+	out.insert(out.end(), payload.begin(), payload.end());
+
+	cx.timing.k_predict_ms = cx.elapsed(1, 2);
+	cx.timing.k_model_ms = cx.elapsed(2, 3);
+	cx.timing.k_rchain_ms = cx.elapsed(3, 4);
+	cx.timing.device_ms = cx.elapsed(1, 5);
+	cx.timing.n_symbols = ns;
+	cx.timing.payload_bytes = payload.size();
+	cx.timing.total_ms = ms_since(t_all);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	auto t_all = Clock::now();
+	cx.timing = hry_timing{};
+	if (m->lists.size() > (size_t)kMaxLists) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
+	for (const AttrList &L : m->lists)
+		for (int c = 0; c < L.ncomp(); ++c) {
+			if (L.stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
+		}
+	auto t_walk = Clock::now();
+	std::vector<uint32_t> order_v;
+	std::vector<GenRecordEvents> ev;
+	read_general_stream(p + hdr, n - hdr, *m, order_v, ev);
+	cx.timing.host_walk_ms = ms_since(t_walk);
+
+	auto t_h2d = Clock::now();
+	upload_general(cx, *m);   // connectivity, bindings, and the residual codes in record layout
+	const uint32_t vc = (uint32_t)order_v.size();
+	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
+	cx.d_rank.ensure(std::max<size_t>((size_t)m->nv * 4, 16));
+	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
+	Arena A;
+	std::vector<size_t> he_at(m->lists.size()), slot_at(m->lists.size()), done_at(m->lists.size());
+	for (size_t l = 0; l < m->lists.size(); ++l) { he_at[l] = A.add(ev[l].he); slot_at[l] = A.add(ev[l].slot); }
+	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
+	for (size_t l = 0; l < m->lists.size(); ++l) { done_at[l] = arena_bytes; arena_bytes += ((size_t)ev[l].he.size() * 4 + 15) & ~(size_t)15; }
+	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
+	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
+	uint8_t *arena = cx.d_gen.as<uint8_t>();
+	HIP_OK(hipMemsetAsync(arena + ((A.host.size() + 15) & ~(size_t)15), 0, arena_bytes - ((A.host.size() + 15) & ~(size_t)15), cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.h2d_ms = ms_since(t_h2d);
+
+	ConnView cv = cx.conn_view();
+	const GenView gv = gen_view(cx, *m);
+	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
+	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m->nv * 4, cx.stream));
+	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
+	for (size_t l = 0; l < m->lists.size(); ++l) {
+		const AttrList &L = m->lists[l];
+		const uint32_t nd = (uint32_t)ev[l].he.size();
+		if (!nd || !L.ncomp()) continue;
+		const ListDesc ld = make_list_desc(L);
+		uint8_t *rec = cx.d_rec[l].as<uint8_t>();
+		if (L.target == 0) { launch_faces_unfold(cx.stream, nd, ld, rec); continue; }
+		launch_gen_unpredict(cx.stream, L.target == 1 ? 0 : 1, cv, gv, cx.d_rank.as<uint32_t>(), (const uint32_t*)(arena + he_at[l]), arena + slot_at[l], nd, rec, ld,
+		                     (uint32_t*)(arena + done_at[l]));
+	}
+	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	for (size_t l = 0; l < m->lists.size(); ++l)
+		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	if (gen_timeout_flags(cx.stream)) throw Error(HRY_E_INTERNAL, "record reconstruction: a wait for an earlier record timed out");
+	cx.timing.k_predict_ms = cx.elapsed(3, 4);
+	cx.timing.device_ms = cx.timing.k_predict_ms;
+	cx.timing.payload_bytes = n - hdr;
+	cx.timing.total_ms = ms_since(t_all);
+	m->device_token = 0;
+	return m.release();
+}
+
+}   // namespace hry

@@ -162,7 +162,135 @@ void read_list(Live &lv, const AttrList &L, bool corner_list, uint32_t count, st
 	}
 }
 
+// attribute symbols with general bindings (attrcode.h:443-531): per vertex its region and one record reference per list of the
+// region; per face its region, its face lists, then every corner's lists.  A reference is DATA (a new record: its residual bytes
+// follow), HIST (a record created earlier, by distance in creation order) or, at corners, LHIST (a record already named at this
+// vertex, by distance in the vertex' own list of names).  Pure integer bookkeeping next to the serial entropy decoder; the
+// residual bytes go to the device.
+struct GeneralReader {
+	Live &lv;
+	Mesh &m;
+	Bindings &b;
+	struct PerList { Table t_type, t_ghist[4], t_lhist[2]; std::vector<Table> t_data; std::vector<int> byte_at; uint32_t created = 0; };
+	std::vector<PerList> pl;
+	Table t_regface[2], t_regvtx[2];
+	std::vector<GenRecordEvents> &ev;
+	// per corner slot and vertex: the records named there so far, newest first
+	struct Node { uint32_t idx, next; };
+	std::vector<Node> pool;
+	std::vector<std::vector<uint32_t>> head;
+	static constexpr uint32_t NONE = 0xffffffffu;
+
+	GeneralReader(Live &l, Mesh &mesh, std::vector<GenRecordEvents> &events) : lv(l), m(mesh), b(mesh.bind), pl(mesh.lists.size()), ev(events)
+	{
+		ev.assign(m.lists.size(), GenRecordEvents());
+		for (size_t i = 0; i < m.lists.size(); ++i) {
+			const AttrList &L = m.lists[i];
+			PerList &P = pl[i];
+			P.t_type.add(0, 1); P.t_type.add(1, 1);            // models.h:201-203
+			if (L.target == 2) P.t_type.add(2, 1);
+			for (auto &t : P.t_ghist) t.ones();
+			for (auto &t : P.t_lhist) t.ones();
+			for (int c = 0; c < L.ncomp(); ++c)
+				for (int k = 0; k < kTypeSize[L.stype(c)]; ++k) P.byte_at.push_back(L.offset[c] + k);
+			P.t_data.resize(P.byte_at.size());
+			for (auto &t : P.t_data) t.ones();
+		}
+		for (int r = 0; r < b.nregs_face(); ++r) { t_regface[0].add((uint32_t)r & 0xff, 1); t_regface[1].add((uint32_t)r >> 8, 1); }   // models.h:212-217
+		for (int r = 0; r < b.nregs_vtx(); ++r) { t_regvtx[0].add((uint32_t)r & 0xff, 1); t_regvtx[1].add((uint32_t)r >> 8, 1); }
+		head.assign(b.nb_corner, std::vector<uint32_t>());
+		for (auto &h : head) h.assign(m.nv, NONE);
+	}
+	uint32_t region(Table *t, int nregs)
+	{
+		uint32_t r = lv.sym(t[0]);
+		r |= lv.sym(t[1]) << 8;
+		if ((int)r >= nregs) throw Error(HRY_E_FORMAT, "corrupt stream (region)");
+		return r;
+	}
+	uint32_t new_record(int l, uint32_t he, int slot)
+	{
+		AttrList &L = m.lists[l];
+		PerList &P = pl[l];
+		if (P.created >= L.count) throw Error(HRY_E_FORMAT, "corrupt stream (more records than the header announces)");
+		const uint32_t idx = P.created++;
+		uint8_t *rec = L.data.data() + (size_t)idx * L.stride();
+		for (size_t k = 0; k < P.byte_at.size(); ++k) rec[P.byte_at[k]] = (uint8_t)lv.sym(P.t_data[k]);
+		ev[l].he.push_back(he); ev[l].slot.push_back((uint8_t)slot);
+		return idx;
+	}
+	uint32_t earlier_record(int l)   // attrcode.h:463-465
+	{
+		PerList &P = pl[l];
+		uint32_t d = lv.u32(P.t_ghist);
+		if (d >= P.created) throw Error(HRY_E_FORMAT, "corrupt stream (record history)");
+		return P.created - 1 - d;
+	}
+	void remember(int a, uint32_t v, uint32_t idx) { pool.push_back(Node{ idx, head[a][v] }); head[a][v] = (uint32_t)pool.size() - 1; }
+	uint32_t named_here(int a, uint32_t v, uint32_t back)   // attrcode.h:76-79
+	{
+		uint32_t k = head[a][v];
+		while (k != NONE && back) { k = pool[k].next; --back; }
+		if (k == NONE) throw Error(HRY_E_FORMAT, "corrupt stream (per-vertex record history)");
+		return pool[k].idx;
+	}
+	void run(const std::vector<uint32_t> &order_v)
+	{
+		if (b.nb_corner > 255 || b.nb_vtx > 255 || b.nb_face > 255) throw Error(HRY_E_UNSUPPORTED, "more than 255 lists bound to one region");
+		b.corner_attr.assign((size_t)m.ne() * b.nb_corner, 0);
+		for (uint32_t e : order_v) {   // attrcode.h:443-470
+			const uint32_t v = m.org[e];
+			const int r = (int)region(t_regvtx, b.nregs_vtx());
+			b.vtx_reg[v] = (uint16_t)r;
+			for (int a = 0; a < b.nvtxlists(r); ++a) {
+				const int l = b.vtxlist(r, a);
+				const uint32_t ty = lv.sym(pl[l].t_type);
+				uint32_t idx;
+				if (ty == 0) idx = new_record(l, e, a);
+				else if (ty == 1) idx = earlier_record(l);
+				else throw Error(HRY_E_FORMAT, "corrupt stream (record reference type)");
+				b.vtx_attr[(size_t)v * b.nb_vtx + a] = idx;
+			}
+		}
+		for (uint32_t f = 0; f < m.nf; ++f) {   // attrcode.h:476-531,543-548
+			const int r = (int)region(t_regface, b.nregs_face());
+			b.face_reg[f] = (uint16_t)r;
+			for (int a = 0; a < b.nfacelists(r); ++a) {
+				const int l = b.facelist(r, a);
+				const uint32_t ty = lv.sym(pl[l].t_type);
+				uint32_t idx;
+				if (ty == 0) idx = new_record(l, f, a);
+				else if (ty == 1) idx = earlier_record(l);
+				else throw Error(HRY_E_FORMAT, "corrupt stream (record reference type)");
+				b.face_attr[(size_t)f * b.nb_face + a] = idx;
+			}
+			for (uint32_t c = m.face_off[f]; c < m.face_off[f + 1]; ++c) {
+				const uint32_t v = m.org[c];
+				for (int a = 0; a < b.ncornerlists(r); ++a) {
+					const int l = b.cornerlist(r, a);
+					const uint32_t ty = lv.sym(pl[l].t_type);
+					uint32_t idx;
+					if (ty == 0) { idx = new_record(l, c, a); remember(a, v, idx); }
+					else if (ty == 1) { idx = earlier_record(l); remember(a, v, idx); }
+					else if (ty == 2) { uint32_t back = lv.sym(pl[l].t_lhist[0]); back |= lv.sym(pl[l].t_lhist[1]) << 8; idx = named_here(a, v, back); }
+					else throw Error(HRY_E_FORMAT, "corrupt stream (record reference type)");
+					b.corner_attr[(size_t)c * b.nb_corner + a] = idx;
+				}
+			}
+		}
+	}
+};
+
 }   // namespace
+
+void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events)
+{
+	Live lv(p, p + n, m);
+	std::vector<uint32_t> seg_start, seg_level;
+	cut_border_replay_with(m, lv, order_v, seg_start, seg_level);
+	GeneralReader gr(lv, m, events);
+	gr.run(order_v);
+}
 
 void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
                         std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes)

@@ -28,12 +28,29 @@ void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out)
 	w.raw(magic, 6);
 	const bool sh = m.shard.active();
 	w.v<uint32_t>(sh ? m.shard.g_nv : m.nv); w.v<uint32_t>(sh ? m.shard.g_nf : m.nf); w.v<uint32_t>(sh ? m.shard.g_ne : m.ne());
-	// region tables: one face region bound to list 0, one vertex region bound to list 1 (ply/reader.cc:399-401)
-	w.v<uint16_t>(1); w.v<uint16_t>(1);
-	w.v<uint16_t>(1); w.v<uint16_t>(0); w.v<uint16_t>(0);
-	w.v<uint16_t>(1); w.v<uint16_t>(1);
-	for (int l = 0; l < 2; ++l) {
+	std::vector<char> named(m.lists.size(), 1);
+	if (m.general) {   // writer.cc:124-151: the regions with the lists bound to them; a list no region names is not written
+		const Bindings &b = m.bind;
+		std::fill(named.begin(), named.end(), 0);
+		w.v<uint16_t>((uint16_t)b.nregs_face()); w.v<uint16_t>((uint16_t)b.nregs_vtx());
+		for (int r = 0; r < b.nregs_face(); ++r) {
+			w.v<uint16_t>((uint16_t)b.nfacelists(r)); w.v<uint16_t>((uint16_t)b.ncornerlists(r));
+			for (int a = 0; a < b.nfacelists(r); ++a) { named[b.facelist(r, a)] = 1; w.v<uint16_t>((uint16_t)b.facelist(r, a)); }
+			for (int a = 0; a < b.ncornerlists(r); ++a) { named[b.cornerlist(r, a)] = 1; w.v<uint16_t>((uint16_t)b.cornerlist(r, a)); }
+		}
+		for (int r = 0; r < b.nregs_vtx(); ++r) {
+			w.v<uint16_t>((uint16_t)b.nvtxlists(r));
+			for (int a = 0; a < b.nvtxlists(r); ++a) { named[b.vtxlist(r, a)] = 1; w.v<uint16_t>((uint16_t)b.vtxlist(r, a)); }
+		}
+	} else {
+		// region tables: one face region bound to list 0, one vertex region bound to list 1 (ply/reader.cc:399-401)
+		w.v<uint16_t>(1); w.v<uint16_t>(1);
+		w.v<uint16_t>(1); w.v<uint16_t>(0); w.v<uint16_t>(0);
+		w.v<uint16_t>(1); w.v<uint16_t>(1);
+	}
+	for (size_t l = 0; l < m.lists.size(); ++l) {
 		const AttrList &L = m.lists[l];
+		if (!named[l]) continue;
 		if (!L.have_bounds && L.ncomp() > 0) throw Error(HRY_E_INTERNAL, "attribute bounds missing");
 		w.v<uint32_t>(sh ? (l == 0 ? m.shard.g_nf : m.shard.g_nv) : L.count);
 		w.v<uint16_t>((uint16_t)L.ncomp());
@@ -70,16 +87,34 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 	m.nv = r.v<uint32_t>(); m.nf = r.v<uint32_t>();
 	m.declared_ne = r.v<uint32_t>();
 	uint16_t nrf = r.v<uint16_t>(), nrv = r.v<uint16_t>();
-	if (nrf != 1 || nrv != 1) throw Error(HRY_E_UNSUPPORTED, "multi-region meshes (OBJ material regions) are outside the supported subset");
-	uint16_t nbf = r.v<uint16_t>(), nbc = r.v<uint16_t>();
-	if (nbf != 1 || nbc != 0) throw Error(HRY_E_UNSUPPORTED, "corner attribute lists are outside the supported subset");
-	if (r.v<uint16_t>() != 0) throw Error(HRY_E_UNSUPPORTED, "unexpected face list id");
-	if (r.v<uint16_t>() != 1) throw Error(HRY_E_UNSUPPORTED, "more than one vertex attribute list");
-	if (r.v<uint16_t>() != 1) throw Error(HRY_E_UNSUPPORTED, "unexpected vertex list id");
-	for (int l = 0; l < 2; ++l) {
+	// reader.cc:86-126: region tables; a list's target is what the last region naming it binds it as
+	Bindings b;
+	std::vector<int> target;
+	auto name_list = [&](uint16_t l, int t) { if (l >= target.size()) target.resize((size_t)l + 1, 3); target[l] = t; return l; };
+	if (nrf > 128 || nrv > 128) throw Error(HRY_E_UNSUPPORTED, "more than 128 regions: the reference seeds its region models out of bounds (model.h:49-55)");
+	for (int i = 0; i < nrf; ++i) {
+		uint16_t nbf = r.v<uint16_t>(), nbc = r.v<uint16_t>();
+		const int reg = b.add_face_region(nbf, nbc);
+		b.nb_face = std::max<int>(b.nb_face, nbf); b.nb_corner = std::max<int>(b.nb_corner, nbc);
+		for (int a = 0; a < nbf; ++a) b.reg_facelist[b.off_facelist[reg] + a] = name_list(r.v<uint16_t>(), 0);
+		for (int a = 0; a < nbc; ++a) b.reg_cornerlist[b.off_cornerlist[reg] + a] = name_list(r.v<uint16_t>(), 2);
+	}
+	for (int i = 0; i < nrv; ++i) {
+		uint16_t nbv = r.v<uint16_t>();
+		const int reg = b.add_vtx_region(nbv);
+		b.nb_vtx = std::max<int>(b.nb_vtx, nbv);
+		for (int a = 0; a < nbv; ++a) b.reg_vtxlist[b.off_vtxlist[reg] + a] = name_list(r.v<uint16_t>(), 1);
+	}
+	if (target.size() > 4096) throw Error(HRY_E_FORMAT, "implausible number of attribute lists");
+	const bool ply_layout = nrf == 1 && nrv == 1 && b.nfacelists(0) == 1 && b.ncornerlists(0) == 0 && b.nvtxlists(0) == 1 &&
+	                        b.facelist(0, 0) == 0 && b.vtxlist(0, 0) == 1;
+	m.general = !ply_layout;
+	if (m.general && ver_minor != 1) throw Error(HRY_E_UNSUPPORTED, "the chunked container holds the PLY layout only (one face list, one vertex list)");
+	m.lists.assign(ply_layout ? 2 : target.size(), AttrList());
+	for (size_t l = 0; l < m.lists.size(); ++l) {
 		AttrList &L = m.lists[l];
-		L = AttrList();
-		L.target = l;
+		L.target = ply_layout ? (int)l : target[l];
+		if (L.target == 3) { L.have_bounds = true; continue; }   // reader.cc:128-166: a list no region names has nothing in the file
 		L.count = r.v<uint32_t>();
 		uint16_t nc = r.v<uint16_t>();
 		if (nc > kMaxComp) throw Error(HRY_E_UNSUPPORTED, "too many components in one attribute list");
@@ -111,7 +146,15 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 		r.raw(L.bmax.data(), L.bmax.size());
 		L.have_bounds = true;
 	}
-	if (m.lists[0].count != m.nf || m.lists[1].count != m.nv) throw Error(HRY_E_UNSUPPORTED, "shared attribute records are outside the supported subset");
+	if (!m.general && (m.lists[0].count != m.nf || m.lists[1].count != m.nv)) m.general = true;   // shared records: the general decoder
+	if (m.general && ver_minor != 1) throw Error(HRY_E_UNSUPPORTED, "the chunked container holds the PLY layout only (one record per element)");
+	if (m.general) {
+		m.bind = std::move(b);
+		if (alloc_records) {
+			m.bind.face_reg.assign(m.nf, 0); m.bind.vtx_reg.assign(m.nv, 0);
+			m.bind.face_attr.assign((size_t)m.nf * m.bind.nb_face, 0); m.bind.vtx_attr.assign((size_t)m.nv * m.bind.nb_vtx, 0);
+		}
+	}
 	uint16_t cnt = r.v<uint16_t>();
 	m.have_degree.clear();
 	for (int i = 0; i < cnt; ++i) {

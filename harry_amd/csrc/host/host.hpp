@@ -20,6 +20,11 @@ Mesh *mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint
                        const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names);
 void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed = false);
 void build_twins(Mesh &m);
+void print_component(std::string &o, const AttrList &L, const uint8_t *rec, int c);   // one value as the reference prints it (mixing.h:340-359)
+
+// ---- obj_io.cpp (formats/obj/reader.rl:108-299, writer.cc:20-132): meshes with general bindings (mesh.hpp Bindings)
+Mesh *mesh_from_obj(const uint8_t *buf, size_t n, const char *directory);   // directory: where "mtllib" files are looked up
+void mesh_to_obj(const Mesh &m, std::vector<uint8_t> &out);
 
 // ---- context numbering of a .hry stream (formats/hry/models.h:183-237), shared with the device code
 enum {
@@ -147,6 +152,12 @@ size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256]
 // (plane-major, one plane per coded byte) are returned for the device reconstruction
 void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
                         std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes);
+
+// the same for a stream whose header announces general bindings (regions, shared records, corner lists; mesh.hpp Bindings):
+// fills m.bind, leaves in every list the RESIDUAL codes of its records (record layout, in creation order) and says where each
+// record was created: the half-edge of the vertex / the corner (the face index for face lists) and the slot of the list there
+struct GenRecordEvents { std::vector<uint32_t> he; std::vector<uint8_t> slot; };
+void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events);
 
 // a shard writes the sizes of the full mesh (m.shard.g_*): the header of a sharded container describes the whole
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);

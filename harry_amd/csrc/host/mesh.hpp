@@ -61,7 +61,7 @@ inline CompType storage_type(CompType t, int q)   // mixing.h:101-108
 // One attribute list = AoS records; slot offsets follow the ORIGINAL component types (mixing.h:60),
 // a quantised value occupies the low bytes of its slot.
 struct AttrList {
-	int target = 0;                        // 0 face, 1 vertex
+	int target = 0;                        // 0 face, 1 vertex, 2 corner, 3 none (structs/attr.h:22)
 	std::vector<CompType> type;
 	std::vector<uint8_t> quant;
 	std::vector<int> offset{0};            // ncomp + 1
@@ -109,13 +109,47 @@ struct ShardInfo {
 	bool active() const { return g_nf != 0; }
 };
 
+// General attribute bindings (structs/attr.h:101-189): what the OBJ reader creates and what any .hry header may announce.
+// Faces and vertices belong to regions; a region names the lists its elements carry records of (face regions also the lists of
+// their corners); an element has one slot per list of its region, holding the index of ITS record in that list -- records are
+// shared (several corners / vertices may name the same one).  The PLY layout (one face region -> list 0, one vertex region ->
+// list 1, element i owns record i) keeps all of this implicit: Mesh::general == false.
+struct Bindings {
+	std::vector<uint16_t> reg_facelist, reg_vtxlist, reg_cornerlist;   // region x slot -> list
+	std::vector<int> off_facelist{0}, off_vtxlist{0}, off_cornerlist{0};
+	int nb_face = 0, nb_vtx = 0, nb_corner = 0;                        // slots per face / vertex / corner (max over regions)
+	BigVec<uint16_t> face_reg, vtx_reg;                                // element -> region
+	BigVec<uint32_t> face_attr, vtx_attr, corner_attr;                 // element x slot -> record of the bound list
+	int nregs_face() const { return (int)off_facelist.size() - 1; }
+	int nregs_vtx() const { return (int)off_vtxlist.size() - 1; }
+	int nfacelists(int r) const { return off_facelist[r + 1] - off_facelist[r]; }
+	int nvtxlists(int r) const { return off_vtxlist[r + 1] - off_vtxlist[r]; }
+	int ncornerlists(int r) const { return off_cornerlist[r + 1] - off_cornerlist[r]; }
+	int facelist(int r, int a) const { return reg_facelist[off_facelist[r] + a]; }
+	int vtxlist(int r, int a) const { return reg_vtxlist[off_vtxlist[r] + a]; }
+	int cornerlist(int r, int a) const { return reg_cornerlist[off_cornerlist[r] + a]; }
+	int add_face_region(int nface, int ncorner)   // structs/mesh.h:106-113
+	{
+		off_facelist.push_back(off_facelist.back() + nface); off_cornerlist.push_back(off_cornerlist.back() + ncorner);
+		reg_facelist.resize(off_facelist.back(), 0); reg_cornerlist.resize(off_cornerlist.back(), 0);
+		return nregs_face() - 1;
+	}
+	int add_vtx_region(int n)   // structs/mesh.h:114-119
+	{
+		off_vtxlist.push_back(off_vtxlist.back() + n); reg_vtxlist.resize(off_vtxlist.back(), 0);
+		return nregs_vtx() - 1;
+	}
+};
+
 struct Mesh {
 	uint32_t nv = 0, nf = 0;
 	BigVec<uint32_t> face_off{0};        // nf + 1
 	BigVec<uint32_t> org;                // per half-edge
 	BigVec<uint32_t> twin;               // per half-edge, flat id; self = border
 	std::vector<uint8_t> have_degree;    // have_degree[d] != 0 iff a polygon with d edges exists (faces.h:44-56)
-	AttrList lists[2];                   // [0] face attributes, [1] vertex attributes (formats/ply/reader.cc:388-400)
+	std::vector<AttrList> lists = std::vector<AttrList>(2);   // PLY layout: [0] face attributes, [1] vertex attributes (formats/ply/reader.cc:388-400)
+	bool general = false;                // true: `bind` holds regions and element -> record maps, any number of lists
+	Bindings bind;
 	uint64_t device_token = 0;           // identity of the HBM-resident copy, 0 = none
 	uint32_t declared_ne = 0;            // half-edge count announced by a .hry header (the connectivity follows later)
 	ShardInfo shard;                     // set by shard_extract: this mesh is a shard of a larger one

@@ -455,7 +455,8 @@ std::string interp_prop_name(const AttrList &L, int interp, int k)   // writer.c
 	const std::string &n = L.interp_name[interp - kInterpOther];
 	return L.interp_len[interp] == 1 ? n : n + "_" + std::to_string(k);
 }
-void print_comp(std::string &o, const AttrList &L, const uint8_t *rec, int c)   // mixing.h:340-359
+}   // namespace
+void print_component(std::string &o, const AttrList &L, const uint8_t *rec, int c)   // mixing.h:340-359
 {
 	char buf[64];
 	const uint8_t *p = rec + L.offset[c];
@@ -472,10 +473,75 @@ void print_comp(std::string &o, const AttrList &L, const uint8_t *rec, int c)   
 	}
 	o += buf;
 }
+namespace {
+inline void print_comp(std::string &o, const AttrList &L, const uint8_t *rec, int c) { print_component(o, L, rec, c); }
+
+// General bindings (formats/ply/writer.cc:106-192): the vertex element carries the lists that EVERY vertex region binds, the face
+// element those every face region binds as face lists (corner lists have no PLY form); each element writes the records its own
+// region binds, in slot order.
+void general_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed)
+{
+	const Bindings &b = m.bind;
+	auto common = [&](int nregs, auto nlists, auto list_at) {   // writer.cc:141-156: running intersection over the regions that bind anything
+		std::vector<int> cur, last;
+		for (int r = 0; r < nregs; ++r) {
+			for (int a = 0; a < nlists(r); ++a) {
+				int l = list_at(r, a);
+				if (r == 0 || std::find(last.begin(), last.end(), l) != last.end()) if (std::find(cur.begin(), cur.end(), l) == cur.end()) cur.push_back(l);
+			}
+			if (nlists(r)) { std::swap(cur, last); cur.clear(); }
+		}
+		std::sort(last.begin(), last.end());
+		return last;
+	};
+	const std::vector<int> vl = common(b.nregs_vtx(), [&](int r) { return b.nvtxlists(r); }, [&](int r, int a) { return b.vtxlist(r, a); });
+	const std::vector<int> fl = common(b.nregs_face(), [&](int r) { return b.nfacelists(r); }, [&](int r, int a) { return b.facelist(r, a); });
+	std::vector<char> in_v(m.lists.size(), 0), in_f(m.lists.size(), 0);
+	std::string h = std::string("ply\nformat ") + (ascii ? "ascii" : "binary_little_endian") + " 1.0\ncomment decompressed using harry mesh compressor\n";
+	auto props = [&](const AttrList &L) {
+		for (int i = 0; i < (int)L.interp_off.size(); ++i)
+			for (int k = 0; k < L.interp_len[i]; ++k)
+				h += std::string("property ") + type_name(L.stype(L.interp_off[i] + k)) + " " + interp_prop_name(L, i, k) + "\n";
+	};
+	h += "element vertex " + std::to_string(m.nv) + "\n";
+	for (int l : vl) { in_v[l] = 1; props(m.lists[l]); }
+	h += "element face " + std::to_string(m.nf) + "\nproperty list uchar uint vertex_indices\n";
+	for (int l : fl) { in_f[l] = 1; props(m.lists[l]); }
+	h += "end_header\n";
+	out.assign(h.begin(), h.end());
+	std::string o;
+	auto record = [&](int l, uint32_t idx, bool append) {
+		const AttrList &L = m.lists[l];
+		const uint8_t *rec = L.data.data() + (size_t)idx * L.stride();
+		if (ascii) { for (int c = 0; c < L.ncomp(); ++c) { if (c || append) o += '\t'; print_component(o, L, rec, c); } return; }
+		bool q = false;
+		for (int c = 0; c < L.ncomp(); ++c) q |= L.quant[c] != 0;
+		if (packed && q) for (int c = 0; c < L.ncomp(); ++c) o.append((const char*)rec + L.offset[c], (size_t)kTypeSize[L.stype(c)]);
+		else o.append((const char*)rec, (size_t)L.stride());
+	};
+	auto flush = [&]() { out.insert(out.end(), o.begin(), o.end()); o.clear(); };
+	for (uint32_t v = 0; v < m.nv; ++v) {
+		const int r = b.vtx_reg[v];
+		for (int a = 0; a < b.nvtxlists(r); ++a) if (in_v[b.vtxlist(r, a)]) record(b.vtxlist(r, a), b.vtx_attr[(size_t)v * b.nb_vtx + a], a != 0);
+		if (ascii) o += '\n';
+		if (o.size() > (1u << 20)) flush();
+	}
+	for (uint32_t f = 0; f < m.nf; ++f) {
+		const int r = b.face_reg[f];
+		const uint32_t s = m.face_off[f], e = m.face_off[f + 1];
+		if (ascii) { o += std::to_string((int)(uint8_t)(e - s)); for (uint32_t x = s; x < e; ++x) { o += '\t'; o += std::to_string(m.org[x]); } }
+		else { o += (char)(uint8_t)(e - s); o.append((const char*)&m.org[s], 4 * (size_t)(e - s)); }
+		for (int a = 0; a < b.nfacelists(r); ++a) if (in_f[b.facelist(r, a)]) record(b.facelist(r, a), b.face_attr[(size_t)f * b.nb_face + a], true);
+		if (ascii) o += '\n';
+		if (o.size() > (1u << 20)) flush();
+	}
+	flush();
+}
 }   // namespace
 
 void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed)
 {
+	if (m.general) { general_to_ply(m, ascii, out, packed); return; }
 	std::string h = std::string("ply\nformat ") + (ascii ? "ascii" : "binary_little_endian") + " 1.0\ncomment decompressed using harry mesh compressor\n";
 	auto props = [&](const AttrList &L) {
 		for (int i = 0; i < (int)L.interp_off.size(); ++i)

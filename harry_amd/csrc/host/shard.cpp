@@ -37,6 +37,7 @@ struct Ranges {
 
 void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 {
+	if (m.general) throw Error(HRY_E_UNSUPPORTED, "only the PLY layout (one record per element) shards");
 	if (n_shards == 0) throw Error(HRY_E_ARG, "need at least one shard");
 	if (m.nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
 	if (m.shard.active()) throw Error(HRY_E_ARG, "a shard cannot be sharded again");

@@ -7,6 +7,8 @@
  *
  *   hry_mesh_from_ply   <- ply::reader::read(std::istream&, mesh::Mesh&)          formats/ply/reader.cc:382-429
  *   hry_mesh_to_ply     <- ply::writer::write(std::ostream&, mesh::Mesh&, bool)   formats/ply/writer.cc:136-192
+ *   hry_mesh_from_obj   <- obj::reader::read(std::istream&, const std::string&, mesh::Mesh&)  formats/obj/reader.rl:287-299
+ *   hry_mesh_to_obj     <- obj::writer::write(std::ostream&, const std::string&, mesh::Mesh&) formats/obj/writer.cc:20-132
  *   hry_requant         <- quant::requant(Attrs&, const vector<Quant>&, bool)     structs/quant.h:222-242 (+ main.cc:74-91)
  *   hry_encode          <- hry::writer::write(std::ostream&, mesh::Mesh&)         formats/hry/writer.h:19, writer.cc:200-218
  *   hry_decode          <- hry::reader::read(std::istream&, mesh::Mesh&)          formats/hry/reader.h:19, reader.cc:179-193
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HRY_ABI_VERSION 2
+#define HRY_ABI_VERSION 3
 
 enum {
     HRY_OK = 0,
@@ -116,6 +118,25 @@ int hry_mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const ui
 #define HRY_PLY_ASCII 1
 #define HRY_PLY_PACKED 2
 int hry_mesh_to_ply(const hry_mesh *m, int flags, uint8_t **out, size_t *out_len);
+/* OBJ (formats/obj/reader.rl, writer.cc): positions (+ colours) per vertex; texture coordinates and normals per CORNER, shared
+ * between corners; "usemtl" materials become face regions.  Such a mesh has GENERAL bindings (structs/attr.h:101-189): any
+ * number of lists (hry_mesh_nlists / hry_list_target), faces and vertices belong to regions, a region names the lists its
+ * elements (and, for face regions, their corners) carry, and every element holds one record index per list of its region.
+ * The reader follows the reference's scanner where that differs from the OBJ specification (harry_amd/csrc/host/obj_io.cpp).
+ * `dir`: where "mtllib" files are looked up (the reference passes the input path up to its last '/', formats/unified_reader.h:56).
+ * hry_encode codes general bindings into the reference stream (HRY_PROFILE_COMPAT) only. */
+int hry_mesh_from_obj(const uint8_t *obj, size_t n, const char *dir, hry_mesh **out);
+int hry_mesh_to_obj(const hry_mesh *m, int flags, uint8_t **out, size_t *out_len);   /* flags: 0 */
+int hry_mesh_general(const hry_mesh *m);                   /* 0: the PLY layout (list 0 = face, list 1 = vertex attributes, record i of element i) */
+int hry_list_target(const hry_mesh *m, int l);             /* 0 face, 1 vertex, 2 corner, 3 none (structs/attr.h:22) */
+int hry_mesh_nregions(const hry_mesh *m, int which);       /* which: 0 face regions, 1 vertex regions */
+/* lists bound to region r: kind 0 = face lists, 1 = vertex lists, 2 = corner lists of face region r; returns their number */
+int hry_mesh_region_lists(const hry_mesh *m, int kind, int r, uint16_t *out, int cap);
+/* general bindings only: region of every face (which 0) / vertex (which 1); returns the element count */
+size_t hry_mesh_regions_of(const hry_mesh *m, int which, const uint16_t **out);
+/* general bindings only: record index per element and slot (kind 0 faces, 1 vertices, 2 corners = half-edges), row-major with
+ * *slots entries per element; returns the element count */
+size_t hry_mesh_bindings(const hry_mesh *m, int kind, const uint32_t **out, int *slots);
 void hry_mesh_free(hry_mesh *m);
 hry_mesh *hry_mesh_clone(const hry_mesh *m);
 
@@ -126,7 +147,7 @@ uint64_t hry_mesh_ntri(const hry_mesh *m);              /* sum(ne - 2), structs/
 const uint32_t *hry_mesh_face_offsets(const hry_mesh *m); /* nf + 1 */
 const uint32_t *hry_mesh_org(const hry_mesh *m);          /* ne: origin vertex of each half-edge */
 const uint32_t *hry_mesh_twin(const hry_mesh *m);         /* ne: flat id of the opposite half-edge (self = border) */
-int hry_mesh_nlists(const hry_mesh *m);                   /* 2: list 0 = face attributes, list 1 = vertex attributes */
+int hry_mesh_nlists(const hry_mesh *m);                   /* PLY layout: 2 (list 0 = face attributes, list 1 = vertex attributes) */
 int hry_list_ncomp(const hry_mesh *m, int l);
 uint32_t hry_list_count(const hry_mesh *m, int l);
 int hry_list_stride(const hry_mesh *m, int l);

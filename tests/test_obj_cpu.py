@@ -1,0 +1,81 @@
+"""OBJ reader of the product (host side, no GPU): the mesh it builds -- lists, regions, element -> record tables, connectivity,
+bounds formats -- equals the CPU oracle's, which is byte-pinned to the reference binary (tests/test_oracle_obj.py).
+Reference: formats/obj/reader.rl:27-299."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from harry_amd import codec as hc
+from harry_amd import meshgen as mg
+from harry_amd import objgen as og
+from oracle import oracle_py as op   # checker only
+from tests import util
+
+OBJ = os.path.join(util.ROOT, "tests", "golden", "obj")
+with open(os.path.join(OBJ, "manifest.json")) as _f:
+    MAN = json.load(_f)
+
+
+def same_general_mesh(a, o):
+    """a: harry_amd mesh, o: oracle mesh"""
+    assert a.general and o.general
+    assert (a.nv, a.nf, a.ne, a.nlists) == (o.nv, o.nf, o.ne, o.nlists)
+    assert np.array_equal(a.face_offsets(), o.face_offsets()) and np.array_equal(a.org(), o.org()) and np.array_equal(a.twin(), o.twin())
+    for l in range(a.nlists):
+        assert a.list_target(l) == o.list_target(l)
+        if a.list_target(l) == 3:
+            continue
+        assert a.list_fmt(l) == o.list_fmt(l) and a.list_count(l) == o.list_count(l)
+        for c in range(len(a.list_fmt(l))):
+            assert np.array_equal(a.component(l, c), o.component(l, c)), (l, c)
+    for which in (0, 1):
+        assert a.nregions(which) == o.nregions(which)
+        assert np.array_equal(a.regions_of(which), o.regions_of(which))
+    for r in range(a.nregions(0)):
+        assert a.region_lists(0, r) == o.region_lists(0, r) and a.region_lists(2, r) == o.region_lists(2, r)
+    for r in range(a.nregions(1)):
+        assert a.region_lists(1, r) == o.region_lists(1, r)
+    for kind in (1, 2):
+        assert np.array_equal(a.bindings(kind), o.bindings(kind)), kind
+
+
+@pytest.mark.parametrize("name", sorted(MAN["small"]))
+def test_obj_reader_builds_the_oracles_mesh(name):
+    data = open(os.path.join(OBJ, name + ".obj"), "rb").read()
+    same_general_mesh(hc.Mesh.from_obj(data, OBJ), op.Mesh.from_obj(data, OBJ))
+
+
+def test_obj_reader_bigger_scene():
+    sc = og.scene(mg.torus(60, 64, polys="mixed"), normals="smooth", tex="atlas", charts=5, colors="some")
+    same_general_mesh(hc.Mesh.from_obj(sc.obj, ""), op.Mesh.from_obj(sc.obj, ""))
+
+
+def test_obj_grammar_errors_read_like_the_reference():
+    tri = b"v 0 0 0\nv 1 0 0\nv 0 1 0\n"
+    for bad in (b"v 1e2 0 0\n", b"g\n", b"v 1 2\n", b"v 1 2 3 4 5\n", b"vt 1\n", b"vn 1 2\n", b"x 1\n", b" v 1 2 3\n", b"v 1 2 3\rx\n"):
+        with pytest.raises(hc.HryError, match="Unable to parse this OBJ file") as e:
+            hc.Mesh.from_obj(tri + bad + b"f 1 2 3\n")
+        assert e.value.code == -2
+    with pytest.raises(hc.HryError, match="n too big"):
+        hc.Mesh.from_obj(tri + b"vt 0 0\nf 1/1 2/1 3/1\n")
+    with pytest.raises(hc.HryError, match="index cannot be 0"):
+        hc.Mesh.from_obj(tri + b"f 0 1 2\n")
+    with pytest.raises(hc.HryError, match="n too small"):
+        hc.Mesh.from_obj(tri + b"f -4 1 2\n")
+    m = hc.Mesh.from_obj(tri + b"f 1 2 3")      # last line without a line feed: dropped
+    assert (m.nv, m.nf) == (3, 0)
+    m = hc.Mesh.from_obj(b"v 1e-1 2e+1 -.5\nv 0 0 0\nv 1 1 1\nf 1 2 3\n")
+    assert m.list_data(0).view("<f4").reshape(-1, 3)[0].tolist() == [10.0, 20.0, -0.5]
+
+
+def test_obj_writer_roundtrips_what_the_reader_built():
+    """to_obj of an OBJ-read mesh, read again, is the same mesh when normals and texture coordinates do not both occur (the writer
+    numbers normals after ALL texture coordinates, formats/obj/writer.cc:68-93)"""
+    sc = og.scene(mg.torus(9, 11), normals="smooth")
+    a = hc.Mesh.from_obj(sc.obj, "")
+    b = hc.Mesh.from_obj(a.to_obj(), "")
+    assert np.array_equal(a.org(), b.org()) and np.array_equal(a.bindings(2), b.bindings(2))
+    for l in range(a.nlists):
+        assert np.allclose(a.list_data(l).view("<f4"), b.list_data(l).view("<f4"), rtol=1e-5, atol=1e-6)
