@@ -154,8 +154,10 @@ class Mesh:
         return lib().ho_mesh_nslots(self.h, kind)
 
     def bindings(self, kind):
-        n = (self.nf, self.nv, self.ne)[kind] * self.nslots(kind)
-        return _arr(lib().ho_mesh_bindings(self.h, kind), n, np.uint32).reshape(-1, max(self.nslots(kind), 1)) if n else np.zeros((0, self.nslots(kind)), np.uint32)
+        rows, slots = (self.nf, self.nv, self.ne)[kind], self.nslots(kind)
+        if not rows or not slots:
+            return np.zeros((rows, slots), np.uint32)
+        return _arr(lib().ho_mesh_bindings(self.h, kind), rows * slots, np.uint32).reshape(rows, slots)
 
     def list_target(self, l):
         return lib().ho_list_target(self.h, l)

@@ -1,0 +1,113 @@
+"""SURVEY.md section 8 row f3 on the GPU: OBJ input, regions, records shared between elements (global / per-vertex history), corner
+attributes.  The pin is the UNMODIFIED reference binary through tests/golden/obj/ (tests/golden/make_golden_obj.py): the encoder
+must write the reference's bytes, the decoder must give the reference's decoded OBJ / PLY text; beyond the fixtures the CPU oracle
+(pinned to the same fixtures, tests/test_oracle_obj.py) checks larger scenes.
+Reference: formats/obj/reader.rl:108-299, writer.cc:20-132, formats/hry/attrcode.h:23-80,135-154,321-393,443-531."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from harry_amd import codec as hc
+from harry_amd import meshgen as mg
+from harry_amd import objgen as og
+from oracle import oracle_py as op   # checker only
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+OBJ = os.path.join(util.ROOT, "tests", "golden", "obj")
+GOLD = os.path.join(util.ROOT, "tests", "golden")
+with open(os.path.join(OBJ, "manifest.json")) as _f:
+    MAN = json.load(_f)
+SMALL = [(n, t) for n, e in sorted(MAN["small"].items()) for t in sorted(e["variants"])]
+
+
+@pytest.fixture(scope="module")
+def cx():
+    c = hc.Codec(0)
+    yield c
+    c.close()
+
+
+def _read(name, root=OBJ):
+    with open(os.path.join(root, name), "rb") as f:
+        return f.read()
+
+
+def same_decoded(a, o):
+    """a: harry_amd decode, o: oracle decode of the same bytes"""
+    assert a.general == o.general and (a.nv, a.nf, a.ne, a.nlists) == (o.nv, o.nf, o.ne, o.nlists)
+    assert np.array_equal(a.face_offsets(), o.face_offsets()) and np.array_equal(a.org(), o.org()) and np.array_equal(a.twin(), o.twin())
+    for which in (0, 1):
+        assert np.array_equal(a.regions_of(which), o.regions_of(which))
+    for kind in (0, 1, 2):
+        assert np.array_equal(a.bindings(kind), o.bindings(kind)), kind
+    for l in range(a.nlists):
+        assert a.list_target(l) == o.list_target(l)
+        if a.list_target(l) == 3:
+            continue
+        assert a.list_fmt(l) == o.list_fmt(l) and np.array_equal(a.list_data(l), o.list_data(l)), f"list {l} differs"
+
+
+@pytest.mark.parametrize("name,tag", SMALL, ids=[f"{n}.{t}" for n, t in SMALL])
+def test_obj_to_hry_is_byte_identical_to_the_reference(cx, name, tag):
+    m = hc.Mesh.from_obj(_read(name + ".obj"), OBJ)
+    quant, clear = util.flags_to_quant(MAN["small"][name]["variants"][tag]["flags"])
+    if quant or clear:
+        cx.requant(m, quant, clear)
+    assert cx.write_hry(m, profile=hc.PROFILE_COMPAT) == _read(f"{name}.{tag}.hry")
+
+
+@pytest.mark.parametrize("name,tag", SMALL, ids=[f"{n}.{t}" for n, t in SMALL])
+def test_reference_hry_decodes_to_the_reference_obj_and_ply(cx, name, tag):
+    ref = _read(f"{name}.{tag}.hry")
+    d = cx.read_hry(ref)
+    same_decoded(d, op.Mesh.from_hry(ref))
+    assert d.to_obj() == _read(f"{name}.{tag}.dec.obj")
+    assert d.to_ply(ascii=True) == _read(f"{name}.{tag}.dec.ply")
+    assert cx.write_hry(d, profile=hc.PROFILE_COMPAT) == op.Mesh.from_hry(ref).encode().data   # and codes again like the oracle
+
+
+@pytest.mark.parametrize("name", sorted(MAN["requant_of_hry"]))
+def test_requant_of_an_obj_hry_matches_reference_golden(cx, name):
+    e = MAN["requant_of_hry"][name]
+    m = cx.read_hry(_read(e["src"]))
+    quant, clear = util.flags_to_quant(e["flags"])
+    cx.requant(m, quant, clear)
+    out = cx.write_hry(m, profile=hc.PROFILE_COMPAT)
+    assert out == _read(name + ".hry")
+    assert cx.read_hry(out).to_obj() == _read(name + ".dec.obj")
+
+
+@pytest.mark.parametrize("src", sorted(MAN["ply_to_obj"]))
+def test_ply_layout_writes_the_reference_obj(cx, src):
+    assert cx.read_hry(_read(src, GOLD)).to_obj() == _read(src[:-4] + ".dec.obj")
+
+
+@pytest.mark.parametrize("name", sorted(MAN["big"]))
+def test_big_scene_matches_reference_hash_and_oracle_decode(cx, name):
+    e = MAN["big"][name]
+    sc = {"torus150": lambda: og.scene(mg.torus(150, 150, seed=2), normals="smooth", tex="atlas", charts=7),
+          "flat_ico5": lambda: og.scene(mg.icosphere(5), normals="flat", tex="corner")}[name]()
+    for tag, v in e["variants"].items():
+        m = hc.Mesh.from_obj(sc.obj, "")
+        quant, clear = util.flags_to_quant(v["flags"])
+        if quant or clear:
+            cx.requant(m, quant, clear)
+        got = cx.write_hry(m, profile=hc.PROFILE_COMPAT)
+        assert len(got) == v["hry_bytes"] and hashlib.sha256(got).hexdigest() == v["hry_sha256"]
+        d = cx.read_hry(got)
+        same_decoded(d, op.Mesh.from_hry(got))
+        assert hashlib.sha256(d.to_obj()).hexdigest() == v["dec_obj_sha256"]
+
+
+def test_general_bindings_refuse_the_chunked_container(cx):
+    m = hc.Mesh.from_obj(_read("smooth.obj"), OBJ)
+    with pytest.raises(hc.HryError) as e:
+        cx.write_hry(m, profile=hc.PROFILE_CHUNKED)
+    assert e.value.code == -3
+    with pytest.raises(hc.HryError):
+        hc.ShardPlan(m, 2)
