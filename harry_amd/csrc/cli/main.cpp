@@ -1,10 +1,10 @@
 // harry -- the reference's command line (main.cc:23-123) on top of the C ABI of libharry_amd.so (include/harry_amd.h):
-//     harry [OPTIONS] INPUT OUTPUT      -f/--format hry|ply   -l/--list L   -a/--attr A   -q/--quant Q   -c/--clear-quant
+//     harry [OPTIONS] INPUT OUTPUT      -f/--format hry|ply|obj   -l/--list L   -a/--attr A   -q/--quant Q   -c/--clear-quant
 //                                       --ply-ascii   -h/--help
 // Same flag state machine (-l sets the list, -a the component for the next -q only, main.cc:47-71), same phase prints
 // (main.cc:99-120), same error texts; an error ends the program the way the reference's uncaught std::runtime_error does
 // (message of std::terminate on stderr, status 134).  Input kind by magic number, output kind by extension
-// (formats/unified_reader.h:33-56, unified_writer.h:31-47).  OBJ is outside this path ("Currently unimplemented").
+// (formats/unified_reader.h:33-56, unified_writer.h:31-47): .hry, .ply and .obj both ways.
 // Additive options (the reference rejects them as invalid): --profile compat|chunked (default compat = the reference's own
 // v0.1 stream), --chunk N, --device D, --shards N (chunked: code the mesh as N shards, one after the other on this GPU, and
 // merge them into one sharded container -- what N ranks do in parallel, see harry_amd/sharding.py), --ply-packed (binary PLY
@@ -160,7 +160,14 @@ int run(const Args &args)
 	}
 	if (in.size() >= 4 && in[0] == 0xfa && in[1] == 0xff && in[2] == 0xaf && in[3] == 0xaf) ok(hry_decode(h.cx, in.data(), in.size(), nullptr, &h.mesh));
 	else if (in.size() >= 3 && in[0] == 'p' && in[1] == 'l' && in[2] == 'y') ok(hry_mesh_from_ply(in.data(), in.size(), &h.mesh));
-	else if (ext_of(args.in) == ".obj") throw std::runtime_error("Currently unimplemented");
+	else if (ext_of(args.in) == ".obj") {
+		// material libraries are looked up in the input path up to its last separator -- the whole path when there is none, as
+		// the reference computes it (formats/unified_reader.h:56)
+		const std::string dir = args.in.substr(0, args.in.find_last_of("/\\"));
+		ok(hry_mesh_from_obj(in.data(), in.size(), dir.c_str(), &h.mesh));
+		std::cout << "Used face regions: " << hry_mesh_nregions(h.mesh, 0) << std::endl;     // formats/obj/reader.rl:296-297
+		std::cout << "Used vertex regions: " << hry_mesh_nregions(h.mesh, 1) << std::endl;
+	}
 	else throw std::runtime_error("Not a mesh file");
 	Clock::time_point t1 = Clock::now();
 	std::cout << "Reading input took " << ms(t0, t1) << " ms." << std::endl;
@@ -191,7 +198,7 @@ int run(const Args &args)
 			// the sharded path on one GPU: plan, extract, code every shard, merge.  The whole mesh's bounds come from the mesh itself
 			// here (hry_shard_extract copies them); N ranks combine their shards' bounds instead (harry_amd/sharding.py).
 			bool need_bounds = false;
-			for (int l = 0; l < 2; ++l) if (hry_list_ncomp(h.mesh, l) > 0 && !hry_list_min(h.mesh, l)) need_bounds = true;
+			for (int l = 0; l < hry_mesh_nlists(h.mesh); ++l) if (hry_list_ncomp(h.mesh, l) > 0 && !hry_list_min(h.mesh, l)) need_bounds = true;
 			if (need_bounds) ok(hry_bounds(h.cx, h.mesh));
 			ok(hry_shard_plan(h.mesh, args.shards, &h.plan));
 			std::vector<const uint8_t*> parts;
@@ -209,7 +216,7 @@ int run(const Args &args)
 			ok(hry_merge(parts.data(), sizes.data(), parts.size(), &out, &out_len));
 		} else ok(hry_encode(h.cx, h.mesh, &o, &out, &out_len));
 	} else if (type == "ply") ok(hry_mesh_to_ply(h.mesh, (args.ply_ascii ? HRY_PLY_ASCII : 0) | (args.ply_packed ? HRY_PLY_PACKED : 0), &out, &out_len));
-	else throw std::runtime_error("Currently unimplemented");
+	else ok(hry_mesh_to_obj(h.mesh, 0, &out, &out_len));
 	h.bufs.push_back(out);
 	{
 		std::ofstream os(args.out, std::ofstream::binary);

@@ -9,7 +9,9 @@
 //   device  prediction + residuals of every record coded as DATA (general.hip), the adaptive models of every byte plane by
 //           counting, the range coder (kernels.hip: the same kernels as the PLY layout; planes carry explicit positions)
 // and for the decoder: host = serial entropy decode + replay + the same bookkeeping (compat_read.cpp), device = un-prediction.
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "codec_math.hpp"
@@ -29,11 +31,22 @@ void launch_gen_vtx_resid(hipStream_t st, const ConnView &cv, const GenView &gv,
 void launch_gen_face_resid(hipStream_t st, const uint32_t *ev_idx, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
 void launch_gen_corner_resid(hipStream_t st, const ConnView &cv, const GenView &gv, const uint32_t *frank, const uint32_t *ev_he, const uint8_t *ev_slot,
                              const uint32_t *ev_idx, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
-void launch_gen_unpredict(hipStream_t st, int kind, const ConnView &cv, const GenView &gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
-                          uint32_t n, uint8_t *rec, const ListDesc &ld, uint32_t *done);
-uint32_t gen_timeout_flags(hipStream_t st);
+constexpr int kSrcCap = 24;   // general.hip
+struct GenChainJob {
+	int32_t kind, comp;
+	uint32_t n, pad2;
+	uint8_t *rec;
+	const uint32_t *src, *ev_he;
+	const uint8_t *nsrc, *ev_slot;
+	ListDesc ld;
+};
+void launch_gen_sources(hipStream_t st, int kind, const ConnView &cv, const GenView &gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
+                        uint32_t n, uint32_t *src, uint8_t *nsrc);
+void launch_gen_chain(hipStream_t st, int kind, int stype, const ConnView &cv, const GenView &gv, const uint32_t *rank, const GenChainJob *jobs, uint32_t njobs);
 void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
 }
+bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+                                  const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes);   // unchunk.cpp
 
 void check_general(const Mesh &m)
 {
@@ -414,10 +427,18 @@ Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 			if (L.stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
 		}
 	auto t_walk = Clock::now();
-	std::vector<uint32_t> order_v;
+	std::vector<uint32_t> order_v, seg_start, seg_level;
 	std::vector<GenRecordEvents> ev;
-	read_general_stream(p + hdr, n - hdr, *m, order_v, ev);
+	std::vector<uint8_t> vplanes;
+	// one vertex region with one list (every OBJ whose "v" lines have the same number of values): candidate for the vertex chains
+	int fast_l = -1;
+	if (m->bind.nregs_vtx() == 1 && m->bind.nvtxlists(0) == 1 && !getenv("HRY_GENERIC_VERTEX")) fast_l = m->bind.vtxlist(0, 0);
+	read_general_stream(p + hdr, n - hdr, *m, order_v, ev, seg_start, seg_level, fast_l, vplanes);
 	cx.timing.host_walk_ms = ms_since(t_walk);
+	double fast_ms = 0;
+	if (fast_l >= 0 && ev[fast_l].he.size() == order_v.size() && !order_v.empty()) {   // ... and every vertex created its own record
+		if (reconstruct_vertex_list_fast(cx, *m, fast_l, order_v, seg_start, seg_level, vplanes)) { ev[fast_l].he.clear(); ev[fast_l].slot.clear(); fast_ms = cx.elapsed(3, 4); }
+	}
 
 	auto t_h2d = Clock::now();
 	upload_general(cx, *m);   // connectivity, bindings, and the residual codes in record layout
@@ -426,14 +447,40 @@ Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	cx.d_rank.ensure(std::max<size_t>((size_t)m->nv * 4, 16));
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
 	Arena A;
-	std::vector<size_t> he_at(m->lists.size()), slot_at(m->lists.size()), done_at(m->lists.size());
-	for (size_t l = 0; l < m->lists.size(); ++l) { he_at[l] = A.add(ev[l].he); slot_at[l] = A.add(ev[l].slot); }
+	const size_t nl = m->lists.size();
+	std::vector<size_t> he_at(nl), slot_at(nl), src_at(nl), nsrc_at(nl);
+	for (size_t l = 0; l < nl; ++l) { he_at[l] = A.add(ev[l].he); slot_at[l] = A.add(ev[l].slot); }
 	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
-	for (size_t l = 0; l < m->lists.size(); ++l) { done_at[l] = arena_bytes; arena_bytes += ((size_t)ev[l].he.size() * 4 + 15) & ~(size_t)15; }
+	for (size_t l = 0; l < nl; ++l) {
+		if (m->lists[l].target != 1 && m->lists[l].target != 2) continue;
+		const size_t nd = ev[l].he.size();
+		src_at[l] = arena_bytes; arena_bytes += (nd * kSrcCap * 4 + 15) & ~(size_t)15;
+		nsrc_at[l] = arena_bytes; arena_bytes += (nd + 15) & ~(size_t)15;
+	}
+	const size_t jobs_at = arena_bytes;
+	size_t max_jobs = 0;
+	for (const AttrList &L : m->lists) max_jobs += (size_t)L.ncomp();
+	arena_bytes += (max_jobs + 1) * sizeof(GenChainJob);
 	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
 	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
 	uint8_t *arena = cx.d_gen.as<uint8_t>();
-	HIP_OK(hipMemsetAsync(arena + ((A.host.size() + 15) & ~(size_t)15), 0, arena_bytes - ((A.host.size() + 15) & ~(size_t)15), cx.stream));
+	std::vector<GenChainJob> jobs, lead;   // lead: one per list (the source table is per record)
+	for (size_t l = 0; l < nl; ++l) {
+		const AttrList &L = m->lists[l];
+		const uint32_t nd = (uint32_t)ev[l].he.size();
+		if (!nd || !L.ncomp() || (L.target != 1 && L.target != 2)) continue;
+		GenChainJob j{};
+		j.kind = L.target == 1 ? 0 : 1; j.n = nd; j.rec = cx.d_rec[l].as<uint8_t>();
+		j.src = (const uint32_t*)(arena + src_at[l]); j.nsrc = arena + nsrc_at[l];
+		j.ev_he = (const uint32_t*)(arena + he_at[l]); j.ev_slot = arena + slot_at[l];
+		j.ld = make_list_desc(L);
+		lead.push_back(j);
+		for (int c = 0; c < L.ncomp(); ++c) { j.comp = c; jobs.push_back(j); }   // the components of a record are predicted independently
+	}
+	// one launch per kind and storage type (the kernel is instantiated for each); inside a launch every job has its own wavefront
+	std::stable_sort(jobs.begin(), jobs.end(), [](const GenChainJob &a, const GenChainJob &b) {
+		return std::make_pair(a.kind, (int)a.ld.stype[a.comp]) < std::make_pair(b.kind, (int)b.ld.stype[b.comp]); });
+	if (!jobs.empty()) HIP_OK(hipMemcpyAsync(arena + jobs_at, jobs.data(), jobs.size() * sizeof(GenChainJob), hipMemcpyHostToDevice, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	cx.timing.h2d_ms = ms_since(t_h2d);
 
@@ -442,22 +489,26 @@ Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m->nv * 4, cx.stream));
 	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
-	for (size_t l = 0; l < m->lists.size(); ++l) {
+	for (const GenChainJob &j : lead)
+		launch_gen_sources(cx.stream, j.kind, cv, gv, cx.d_rank.as<uint32_t>(), j.ev_he, j.ev_slot, j.n, const_cast<uint32_t*>(j.src), const_cast<uint8_t*>(j.nsrc));
+	for (size_t l = 0; l < nl; ++l) {   // face lists: no prediction (attrcode.h:245-270)
 		const AttrList &L = m->lists[l];
-		const uint32_t nd = (uint32_t)ev[l].he.size();
-		if (!nd || !L.ncomp()) continue;
-		const ListDesc ld = make_list_desc(L);
-		uint8_t *rec = cx.d_rec[l].as<uint8_t>();
-		if (L.target == 0) { launch_faces_unfold(cx.stream, nd, ld, rec); continue; }
-		launch_gen_unpredict(cx.stream, L.target == 1 ? 0 : 1, cv, gv, cx.d_rank.as<uint32_t>(), (const uint32_t*)(arena + he_at[l]), arena + slot_at[l], nd, rec, ld,
-		                     (uint32_t*)(arena + done_at[l]));
+		if (L.target == 0 && L.ncomp() && !ev[l].he.empty()) launch_faces_unfold(cx.stream, (uint32_t)ev[l].he.size(), make_list_desc(L), cx.d_rec[l].as<uint8_t>());
+	}
+	HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
+	for (size_t a = 0; a < jobs.size();) {
+		size_t e = a + 1;
+		while (e < jobs.size() && jobs[e].kind == jobs[a].kind && jobs[e].ld.stype[jobs[e].comp] == jobs[a].ld.stype[jobs[a].comp]) ++e;
+		launch_gen_chain(cx.stream, jobs[a].kind, jobs[a].ld.stype[jobs[a].comp], cv, gv, cx.d_rank.as<uint32_t>(), (const GenChainJob*)(arena + jobs_at) + a, (uint32_t)(e - a));
+		a = e;
 	}
 	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
-	for (size_t l = 0; l < m->lists.size(); ++l)
+	for (size_t l = 0; l < nl; ++l)
 		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
-	if (gen_timeout_flags(cx.stream)) throw Error(HRY_E_INTERNAL, "record reconstruction: a wait for an earlier record timed out");
-	cx.timing.k_predict_ms = cx.elapsed(3, 4);
+	cx.timing.k_chain_ms = cx.elapsed(7, 4);
+	(void)fast_ms;
+	cx.timing.k_predict_ms = cx.elapsed(3, 4) + fast_ms;
 	cx.timing.device_ms = cx.timing.k_predict_ms;
 	cx.timing.payload_bytes = n - hdr;
 	cx.timing.total_ms = ms_since(t_all);

@@ -6,11 +6,11 @@
 //            k_gen_face_resid    residual against 0 (face prediction never finds a neighbour, App. B-16)       attrcode.h:245-270,345-366
 //            k_gen_corner_resid  mean / nearest of the same slot's records at the already coded faces of the
 //                                same region around the corner's vertex + residual bytes                      attrcode.h:135-154,272-288,367-393
-//   decode   k_gen_unpredict     the inverse, record by record in coding order.  A record's prediction reads records coded
-//                                before it (any of them: a corner may name a record that was created at another vertex), so the
-//                                records of one list form a DAG with edges to smaller indices only: one thread per record
-//                                waits for its sources' flags, computes, raises its own.  Workgroups start in index order and
-//                                every wait is for a smaller index, so the waits cannot deadlock; they are bounded anyway.
+//   decode   k_gen_sources       which earlier records every record's prediction reads (connectivity only: all records at once)
+//            k_gen_chain         the inverse of the above, record by record in creation order.  A record's prediction reads records
+//                                created before it (any of them: a corner may name a record that was created at another vertex),
+//                                so the records of one list form a DAG with edges to smaller indices only: one wavefront per list
+//                                takes 64 records at a time and relaxes the batch in LDS until every lane's sources are final.
 // All byte / integer work next to dependent gathers: bounded by memory latency, not by bandwidth.
 #include <hip/hip_runtime.h>
 
@@ -125,9 +125,6 @@ __global__ __launch_bounds__(256) void k_gen_corner_resid(ConnView cv, GenView g
 // ---------------------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------------------
-__device__ uint32_t g_gen_timeout;
-constexpr uint32_t kGenSpinLimit = 1u << 22;   // x s_sleep(4): seconds; a healthy wait is microseconds
-
 // a value another workgroup (possibly on another XCD) wrote during this launch: read past the non-coherent caches
 template <typename T> __device__ __forceinline__ T far_value(const uint8_t *p, bool aligned)
 {
@@ -141,86 +138,175 @@ template <typename T> __device__ __forceinline__ T far_value(const uint8_t *p, b
 	return cm::bits<T>(u);
 }
 
-// KIND 0: vertex records (sources: the three records of every parallelogram), 1: corner records (sources: one record per
-// already decoded face of the region around the vertex).  rec holds the residual codes on entry (record layout), values on exit.
-// Record i of the list was created by the i-th data symbol of the list; ev_he / ev_slot say where.
-constexpr int kGenCap = 24;   // source ids kept per thread; fans with more are walked again whenever they are needed
-template <int KIND>
-__global__ __launch_bounds__(256) void k_gen_unpredict(ConnView cv, GenView gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
-                                                       uint32_t n, uint8_t *rec, ListDesc ld, uint32_t *done)
+// ---- sources: which earlier records the prediction of record i reads -----------------------------------------------
+// KIND 0: vertex records (the three records of every parallelogram, in fan order), 1: corner records (one record per already
+// decoded face of the region around the vertex).  Connectivity only, so every record at once: src[k * n + i] = k-th source id of
+// record i, nsrc[i] = their number, kSrcOverflow when the fan has more than kSrcCap (the chain walks that fan itself).
+constexpr int kSrcCap = 24;                                                 // rows of the table
+template <int KIND> struct SrcCap { static constexpr int value = KIND == 0 ? 24 : 12; };   // 8 parallelograms / 12 faces around a vertex
+constexpr uint8_t kSrcOverflow = 255;
+
+template <int KIND, typename F>
+__device__ __forceinline__ void walk_sources(const Topo &tp, const GenView &gv, const uint32_t *rank, uint32_t e, int a, F &&f)
 {
-	__shared__ uint32_t s_src[kGenCap][256];
+	if constexpr (KIND == 0) {
+		const uint32_t v = tp.c.org[e], my_rank = rank[v], r = gv.vtx_reg[v];
+		fan_candidates(tp, rank, e, my_rank, 0, [&](uint32_t v0, uint32_t v1, uint32_t vo) {
+			if (gv.vtx_reg[v0] != r || gv.vtx_reg[v1] != r || gv.vtx_reg[vo] != r) return;   // attrcode.h:120-121
+			f(gv.vtx_attr[(size_t)v0 * gv.nb_vtx + a]); f(gv.vtx_attr[(size_t)v1 * gv.nb_vtx + a]); f(gv.vtx_attr[(size_t)vo * gv.nb_vtx + a]);
+		});
+	} else {
+		const uint32_t face = tp.face(e), r = gv.face_reg[face];
+		fan_each(tp, e, [&](uint32_t x) {
+			const uint32_t g = tp.face(x);
+			if (g >= face || gv.face_reg[g] != r) return;   // faces are decoded in index order (attrcode.h:543-548); not the face itself
+			f(gv.corner_attr[(size_t)x * gv.nb_corner + a]);
+		});
+	}
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_gen_sources(ConnView cv, GenView gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
+                                                     uint32_t n, uint32_t *src, uint8_t *nsrc)
+{
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	const int t = threadIdx.x;
-	const bool live = i < n;
+	if (i >= n) return;
 	Topo tp{ cv };
-	uint32_t e = 0, my_rank = 0, r = 0;
-	int a = 0, ns = 0;
-	// every source id of this record, in the reference's visiting order: f(id) -- three consecutive calls per parallelogram for KIND 0
-	auto walk = [&](auto &&f) {
-		if constexpr (KIND == 0)
-			fan_candidates(tp, rank, e, my_rank, 0, [&](uint32_t v0, uint32_t v1, uint32_t vo) {
-				if (gv.vtx_reg[v0] != r || gv.vtx_reg[v1] != r || gv.vtx_reg[vo] != r) return;
-				f(gv.vtx_attr[(size_t)v0 * gv.nb_vtx + a]); f(gv.vtx_attr[(size_t)v1 * gv.nb_vtx + a]); f(gv.vtx_attr[(size_t)vo * gv.nb_vtx + a]);
-			});
-		else
-			fan_each(tp, e, [&](uint32_t x) {
-				const uint32_t g = tp.face(x);
-				if (g >= my_rank || gv.face_reg[g] != r) return;   // faces are decoded in index order (attrcode.h:543-548)
-				f(gv.corner_attr[(size_t)x * gv.nb_corner + a]);
-			});
-	};
-	if (live) {
-		e = ev_he[i]; a = ev_slot[i];
-		if constexpr (KIND == 0) { const uint32_t v = cv.org[e]; my_rank = rank[v]; r = gv.vtx_reg[v]; }
-		else { my_rank = tp.face(e); r = gv.face_reg[my_rank]; }
-		walk([&](uint32_t id) { if (ns < kGenCap) s_src[ns][t] = id; ++ns; });
-	}
-	auto sources = [&](auto &&f) {
-		if (ns <= kGenCap) { for (int k = 0; k < ns; ++k) f(s_src[k][t]); }
-		else walk(f);
-	};
-	bool pending = live;
-	uint32_t spins = 0;
-	for (;;) {
-		if (pending) {
-			bool ready = true;
-			sources([&](uint32_t id) { if (id < i && __hip_atomic_load(done + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ready = false; });   // id >= i: damaged input, read as 0
-			if (ready) {
-				uint8_t *mine = rec + (size_t)i * ld.stride;
-				for (int c = 0; c < ld.ncomp; ++c)
-					with_stype(ld.stype[c], [&](auto tag) {
-						typedef decltype(tag) T;
-						typedef typename cm::word<sizeof(T)>::u U;
-						const int off = ld.off[c], q = ld.quant[c];
-						const bool aligned = (ld.stride % (int)sizeof(T)) == 0 && (off % (int)sizeof(T)) == 0;
-						T pred;
-						if constexpr (KIND == 0) {
-							pred = combine_parts<T>([&](auto &&use) {
-								T tri[3];
-								int k = 0;
-								sources([&](uint32_t id) {
-									tri[k++] = id < i ? far_value<T>(rec + (size_t)id * ld.stride + off, aligned) : T(0);
-									if (k == 3) { use(cm::parallelogram<T>(tri[0], tri[1], tri[2], q)); k = 0; }
-								});
-							});
-						} else {
-							pred = combine_parts<T>([&](auto &&use) {
-								sources([&](uint32_t id) { use(id < i ? far_value<T>(rec + (size_t)id * ld.stride + off, aligned) : T(0)); });
-							});
+	int ns = 0;
+	constexpr int CAP = SrcCap<KIND>::value;
+	walk_sources<KIND>(tp, gv, rank, ev_he[i], ev_slot[i], [&](uint32_t id) { if (ns < CAP) src[(size_t)ns * n + i] = id; ++ns; });
+	nsrc[i] = ns <= CAP ? (uint8_t)ns : kSrcOverflow;
+}
+
+// ---- the chain: one wavefront per list walks its records in creation order, 64 at a time -------------------------------------
+// A record reads only records created before it, so inside a batch of 64 the values are found by relaxation: every lane
+// evaluates its record from the current values of the batch (LDS) and the final values of everything before the batch; a lane
+// whose in-batch sources are final becomes final; at most 64 rounds (a batch in which every record reads its predecessor), one
+// round when no record reads inside the batch (texture atlases, smooth normals).  Same arithmetic, same order of the parts as
+// the encoder (combine_parts above).  Records whose fan did not fit the source table are done by their lane alone, walking the fan.
+struct GenChainJob {
+	int32_t kind, comp;        // one job = one component of one list (the components of a record are predicted independently)
+	uint32_t n, pad2;
+	uint8_t *rec;
+	const uint32_t *src, *ev_he;
+	const uint8_t *nsrc, *ev_slot;
+	ListDesc ld;
+};
+
+template <typename T> __device__ __forceinline__ uint32_t as_u32(T v) { typename cm::word<sizeof(T)>::u u = cm::bits<typename cm::word<sizeof(T)>::u>(v); return (uint32_t)u; }
+template <typename T> __device__ __forceinline__ T from_u32(uint32_t x) { return cm::bits<T>((typename cm::word<sizeof(T)>::u)x); }
+
+// val[k] = value of the k-th source
+template <int KIND, typename T, int CAP>
+__device__ __forceinline__ T predict_from(int ns, int q, const T (&val)[CAP])
+{
+	if constexpr (KIND == 0)
+		return combine_parts<T>([&](auto &&use) {
+#pragma unroll
+			for (int k = 0; k + 2 < CAP; k += 3) if (k + 2 < ns) use(cm::parallelogram<T>(val[k], val[k + 1], val[k + 2], q));
+		});
+	else
+		return combine_parts<T>([&](auto &&use) {
+#pragma unroll
+			for (int k = 0; k < CAP; ++k) if (k < ns) use(val[k]);
+		});
+}
+
+template <int KIND, typename T>
+__device__ void chain_component(const ConnView &cv, const GenView &gv, const uint32_t *rank, const GenChainJob &jb, uint32_t *s_val)
+{
+	typedef typename cm::word<sizeof(T)>::u U;
+	constexpr int CAP = SrcCap<KIND>::value;
+	const int lane = threadIdx.x;
+	const ListDesc &ld = jb.ld;
+	const int c = jb.comp, off = ld.off[c], q = ld.quant[c];
+	const bool aligned = (ld.stride % (int)sizeof(T)) == 0 && (off % (int)sizeof(T)) == 0;
+	Topo tp{ cv };
+	for (uint32_t base = 0; base < jb.n; base += 64) {
+		const uint32_t i = base + lane;
+		const bool live = i < jb.n;
+		const int ns_raw = live ? jb.nsrc[i] : 0;
+		const bool heavy = ns_raw == kSrcOverflow;
+		const int ns = heavy ? 0 : ns_raw;
+		uint32_t id[CAP];
+#pragma unroll
+		for (int k = 0; k < CAP; ++k) id[k] = k < ns ? jb.src[(size_t)k * jb.n + i] : 0u;
+		uint8_t *mine = jb.rec + (size_t)i * ld.stride + off;
+		const U code = live ? cm::bits<U>(ldg<T>(mine)) : U(0);
+		const unsigned long long heavy_mask = __ballot(heavy);
+		// the batch in runs of lanes between the heavy ones
+		int lo = 0;
+		while (lo < 64) {
+			const unsigned long long rest = heavy_mask >> lo;
+			const int hi = rest ? lo + __builtin_ctzll(rest) : 64;   // [lo, hi): ordinary lanes; hi: a heavy lane (or the end)
+			const uint32_t first = base + lo;                        // records before `first` are final in memory
+			const bool in_run = live && lane >= lo && lane < hi;
+			if (hi > lo) {
+				T val[CAP];
+				uint32_t slot[CAP];          // LDS slot of a source inside the run, 64 = outside
+				bool inside = false;
+#pragma unroll
+				for (int k = 0; k < CAP; ++k) {
+					val[k] = T(0); slot[k] = 64u;
+					if (in_run && k < ns) {
+						if (id[k] < first) val[k] = far_value<T>(jb.rec + (size_t)id[k] * ld.stride + off, aligned);
+						else if (id[k] < i) { slot[k] = id[k] - base; inside = true; }   // (id >= i: damaged input, reads as 0)
+					}
+				}
+				bool final_ = !inside;
+				T out = T(0);
+				for (int round = 0; round < 65; ++round) {
+					if (inside) {
+#pragma unroll
+						for (int k = 0; k < CAP; ++k) {   // unconditional reads: issued back to back, one wait
+							const uint32_t x = s_val[slot[k] & 63u];
+							val[k] = slot[k] < 64u ? from_u32<T>(x) : val[k];
 						}
-						const U code = cm::bits<U>(ldg<T>(mine + off));
-						stg<T>(mine + off, cm::value_from_residual<T>(code, pred, q));
-					});
-				__threadfence();   // the record is visible device-wide before its flag
-				__hip_atomic_store(done + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				pending = false;
+					}
+					if (in_run) out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP>(ns, q, val), q);
+					__syncthreads();   // (one wavefront: orders the LDS traffic of the rounds)
+					if (in_run) s_val[lane] = as_u32<T>(out);
+					__syncthreads();
+					// final: every source inside the run was final BEFORE this round
+					const unsigned long long fin = __ballot(final_ || !in_run);
+					if (fin == ~0ull) break;
+					if (!final_) {
+						bool now = true;
+#pragma unroll
+						for (int k = 0; k < CAP; ++k) if (slot[k] < 64u && !((fin >> slot[k]) & 1ull)) now = false;
+						final_ = now;
+					}
+				}
+				if (in_run) stg<T>(mine, out);
 			}
+			__threadfence();   // the run's records are in memory before anything later reads them
+			if (hi < 64) {
+				if (lane == hi && live) {   // a fan too large for the table: this lane alone, every source from memory
+					auto value = [&](uint32_t x) { return x < i ? far_value<T>(jb.rec + (size_t)x * ld.stride + off, aligned) : T(0); };
+					const uint32_t e = jb.ev_he[i];
+					const int a = jb.ev_slot[i];
+					const T pred = combine_parts<T>([&](auto &&use) {
+						if constexpr (KIND == 0) {
+							T tri[3];
+							int k = 0;
+							walk_sources<0>(tp, gv, rank, e, a, [&](uint32_t x) { tri[k++] = value(x); if (k == 3) { use(cm::parallelogram<T>(tri[0], tri[1], tri[2], q)); k = 0; } });
+						} else walk_sources<1>(tp, gv, rank, e, a, [&](uint32_t x) { use(value(x)); });
+					});
+					stg<T>(mine, cm::value_from_residual<T>(code, pred, q));
+				}
+				__threadfence();
+			}
+			lo = hi + 1;
 		}
-		if (__ballot(pending) == 0ull) break;
-		__builtin_amdgcn_s_sleep(4);
-		if (++spins > kGenSpinLimit) { atomicOr(&g_gen_timeout, 1u); break; }
 	}
+}
+
+// one instantiation per kind and storage type: the jobs of a launch all have that kind and type (the host groups them)
+template <int KIND, typename T>
+__global__ __launch_bounds__(64) void k_gen_chain(ConnView cv, GenView gv, const uint32_t *rank, const GenChainJob *jobs)
+{
+	__shared__ uint32_t s_val[64];
+	chain_component<KIND, T>(cv, gv, rank, jobs[blockIdx.x], s_val);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -244,20 +330,33 @@ void launch_gen_corner_resid(hipStream_t st, const ConnView &cv, const GenView &
 {
 	if (n) hipLaunchKernelGGL(k_gen_corner_resid, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, gv, frank, ev_he, ev_slot, ev_idx, n, rec, ld, planes);
 }
-void launch_gen_unpredict(hipStream_t st, int kind, const ConnView &cv, const GenView &gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
-                          uint32_t n, uint8_t *rec, const ListDesc &ld, uint32_t *done)
+void launch_gen_sources(hipStream_t st, int kind, const ConnView &cv, const GenView &gv, const uint32_t *rank, const uint32_t *ev_he, const uint8_t *ev_slot,
+                        uint32_t n, uint32_t *src, uint8_t *nsrc)
 {
 	if (!n) return;
-	if (kind == 0) hipLaunchKernelGGL(k_gen_unpredict<0>, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, gv, rank, ev_he, ev_slot, n, rec, ld, done);
-	else hipLaunchKernelGGL(k_gen_unpredict<1>, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, gv, rank, ev_he, ev_slot, n, rec, ld, done);
+	if (kind == 0) hipLaunchKernelGGL(k_gen_sources<0>, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, gv, rank, ev_he, ev_slot, n, src, nsrc);
+	else hipLaunchKernelGGL(k_gen_sources<1>, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, gv, rank, ev_he, ev_slot, n, src, nsrc);
 }
-uint32_t gen_timeout_flags(hipStream_t st)
+template <int KIND>
+static void launch_chain_kind(hipStream_t st, int stype, const ConnView &cv, const GenView &gv, const uint32_t *rank, const GenChainJob *jobs, uint32_t njobs)
 {
-	uint32_t f = 0, zero = 0;
-	if (hipMemcpyFromSymbolAsync(&f, HIP_SYMBOL(g_gen_timeout), 4, 0, hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
-	if (hipStreamSynchronize(st) != hipSuccess) return 0;
-	if (f) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gen_timeout), &zero, 4, 0, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
-	return f;
+	switch (stype) {
+	case 0: hipLaunchKernelGGL((k_gen_chain<KIND, float>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 4: hipLaunchKernelGGL((k_gen_chain<KIND, uint32_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 5: hipLaunchKernelGGL((k_gen_chain<KIND, int32_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 6: hipLaunchKernelGGL((k_gen_chain<KIND, uint16_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 7: hipLaunchKernelGGL((k_gen_chain<KIND, int16_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 8: hipLaunchKernelGGL((k_gen_chain<KIND, uint8_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 9: hipLaunchKernelGGL((k_gen_chain<KIND, int8_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	default: break;   // 8-byte storage types are rejected on the host
+	}
+}
+// jobs: device array of njobs jobs that all have this kind and storage type
+void launch_gen_chain(hipStream_t st, int kind, int stype, const ConnView &cv, const GenView &gv, const uint32_t *rank, const GenChainJob *jobs, uint32_t njobs)
+{
+	if (!njobs) return;
+	if (kind == 0) launch_chain_kind<0>(st, stype, cv, gv, rank, jobs, njobs);
+	else launch_chain_kind<1>(st, stype, cv, gv, rank, jobs, njobs);
 }
 
 }   // namespace dev

@@ -709,6 +709,29 @@ Mesh *decode_sharded(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	return g.release();
 }
 
+// General bindings (general.cpp) whose vertices all carry a private record of ONE list: that list is the vertex list of the PLY
+// layout in everything that matters to the reconstruction chains (record i belongs to the i-th coded vertex, candidates are the
+// parallelograms of the fan), so it takes them.  The mesh lends its connectivity and the list for the duration of the call.
+bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+                                  const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes)
+{
+	const ListDesc ldv = make_list_desc(m.lists[l]);
+	if (!ldv.nplanes || !unpredict2_applicable(ldv) || m.lists[l].count < order_v.size()) return false;
+	Mesh t;
+	t.nv = m.nv; t.nf = m.nf; t.declared_ne = m.declared_ne; t.have_degree = m.have_degree;
+	t.face_off.swap(m.face_off); t.org.swap(m.org); t.twin.swap(m.twin);
+	std::swap(t.lists[1], m.lists[l]);
+	struct Back {   // returned on every path
+		Mesh &m, &t; int l;
+		~Back() { t.face_off.swap(m.face_off); t.org.swap(m.org); t.twin.swap(m.twin); std::swap(t.lists[1], m.lists[l]); }
+	} back{ m, t, l };
+	cx.d_csyms.ensure(std::max<size_t>(vplanes.size() + 64, 16));
+	if (!vplanes.empty()) HIP_OK(hipMemcpyAsync(cx.d_csyms.p, vplanes.data(), vplanes.size(), hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	reconstruct_attributes(cx, t, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>(), nullptr, ldv, make_list_desc(t.lists[0]));
+	return true;
+}
+
 // Reference format (.hry v0.1): the single adaptive stream is decoded and replayed on a host core (the format makes
 // both serial, compat_read.cpp); the residual planes then take the same device reconstruction as above.
 Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)

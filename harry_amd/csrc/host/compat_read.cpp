@@ -181,6 +181,10 @@ struct GeneralReader {
 	std::vector<std::vector<uint32_t>> head;
 	static constexpr uint32_t NONE = 0xffffffffu;
 
+	int plane_list = -1;                 // this list's residual bytes also go to `planes`, plane-major with plane_count records per plane
+	uint32_t plane_count = 0;
+	std::vector<uint8_t> *planes = nullptr;
+
 	GeneralReader(Live &l, Mesh &mesh, std::vector<GenRecordEvents> &events) : lv(l), m(mesh), b(mesh.bind), pl(mesh.lists.size()), ev(events)
 	{
 		ev.assign(m.lists.size(), GenRecordEvents());
@@ -215,7 +219,11 @@ struct GeneralReader {
 		if (P.created >= L.count) throw Error(HRY_E_FORMAT, "corrupt stream (more records than the header announces)");
 		const uint32_t idx = P.created++;
 		uint8_t *rec = L.data.data() + (size_t)idx * L.stride();
-		for (size_t k = 0; k < P.byte_at.size(); ++k) rec[P.byte_at[k]] = (uint8_t)lv.sym(P.t_data[k]);
+		if (l == plane_list && idx < plane_count) {
+			uint8_t *pp = planes->data() + idx;
+			for (size_t k = 0; k < P.byte_at.size(); ++k) { const uint8_t s = (uint8_t)lv.sym(P.t_data[k]); rec[P.byte_at[k]] = s; pp[k * (size_t)plane_count] = s; }
+		} else
+			for (size_t k = 0; k < P.byte_at.size(); ++k) rec[P.byte_at[k]] = (uint8_t)lv.sym(P.t_data[k]);
 		ev[l].he.push_back(he); ev[l].slot.push_back((uint8_t)slot);
 		return idx;
 	}
@@ -283,12 +291,16 @@ struct GeneralReader {
 
 }   // namespace
 
-void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events)
+void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events,
+                         std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, int plane_list, std::vector<uint8_t> &planes)
 {
 	Live lv(p, p + n, m);
-	std::vector<uint32_t> seg_start, seg_level;
 	cut_border_replay_with(m, lv, order_v, seg_start, seg_level);
 	GeneralReader gr(lv, m, events);
+	if (plane_list >= 0 && plane_list < (int)m.lists.size()) {
+		gr.plane_list = plane_list; gr.plane_count = (uint32_t)order_v.size(); gr.planes = &planes;
+		planes.assign((size_t)m.lists[plane_list].coded_bytes() * order_v.size(), 0);
+	}
 	gr.run(order_v);
 }
 

@@ -157,7 +157,9 @@ void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_
 // fills m.bind, leaves in every list the RESIDUAL codes of its records (record layout, in creation order) and says where each
 // record was created: the half-edge of the vertex / the corner (the face index for face lists) and the slot of the list there
 struct GenRecordEvents { std::vector<uint32_t> he; std::vector<uint8_t> slot; };
-void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events);
+// plane_list >= 0: the residual bytes of that list additionally plane-major (one plane per coded byte, order_v.size() records each)
+void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events,
+                         std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, int plane_list, std::vector<uint8_t> &planes);
 
 // a shard writes the sizes of the full mesh (m.shard.g_*): the header of a sharded container describes the whole
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);

@@ -63,9 +63,9 @@ def small_cases():
         "smooth": (og.scene(mg.torus(10, 12), normals="smooth", tex="atlas", charts=3),
                    [("ll", []), ("q", ["-l0", "-q14", "-l1", "-q12", "-l2", "-q10"]), ("qn", ["-l2", "-a1", "-q9"])]),
         "flat": (og.scene(mg.icosphere(2), normals="flat"), [("ll", []), ("q8", ["-l1", "-q8"])]),
-        "mtl": (og.scene(mg.torus(9, 10, polys="mixed"), tex="corner", materials=3, chatter=True), [("ll", [])]),
+        "mtl": (og.scene(mg.torus(9, 10, polys="mixed"), tex="corner", materials=3, chatter=True, mtl_name="mtl.mtl"), [("ll", [])]),
         "mixedfmt": (og.scene(mg.grid(8, 7, seed=4), normals="smooth", tex="atlas", charts=4, colors="some", tex3=True,
-                              interleave=True, negative=True, crlf=True, materials=2), [("ll", []), ("q10", ["-l0", "-q10"])]),
+                              interleave=True, negative=True, crlf=True, materials=2, mtl_name="mixedfmt.mtl"), [("ll", []), ("q10", ["-l0", "-q10"])]),
         "colors": (og.scene(mg.torus(8, 9, polys="quad"), colors="all", normals="flat", tex="atlas", charts=2), [("ll", [])]),
         "nm": (og.scene(mg.with_nonmanifold(mg.multi_component(4, 9, 10, polys="mixed"), 4, 3), normals="smooth", tex="atlas", charts=5),
                [("ll", []), ("q11", ["-l0", "-q11", "-l1", "-q11", "-l2", "-q11"])]),

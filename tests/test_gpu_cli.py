@@ -103,3 +103,30 @@ def test_cli_decodes_reference_files(tmp_path, name, tag):
             assert np.array_equal(x, y)
     if m is not None:
         assert m.nv > 0
+
+
+def test_cli_obj_both_ways(tmp_path):
+    """`harry scene.obj out.hry -l0 -q14 -l1 -q12 -l2 -q10` (the README's OBJ example), `harry out.hry back.obj`, `-f ply`"""
+    import shutil
+    OBJ = os.path.join(GOLD, "obj")
+    for f in ("smooth.obj", "mtl.obj", "mtl.mtl"):
+        shutil.copy(os.path.join(OBJ, f), tmp_path / f)
+    hry = tmp_path / "smooth.hry"
+    r = harry(tmp_path / "smooth.obj", hry, "-l0", "-q14", "-l1", "-q12", "-l2", "-q10")
+    assert r.returncode == 0, r.stderr
+    assert "Used face regions: 1" in r.stdout and "Used vertex regions: 1" in r.stdout       # formats/obj/reader.rl:296-297
+    assert hry.read_bytes() == open(os.path.join(OBJ, "smooth.q.hry"), "rb").read()
+    back = tmp_path / "back.obj"
+    assert harry(hry, back).returncode == 0
+    assert back.read_bytes() == open(os.path.join(OBJ, "smooth.q.dec.obj"), "rb").read()
+    as_ply = tmp_path / "back.xyz"
+    assert harry(hry, as_ply, "-f", "ply", "--ply-ascii").returncode == 0
+    assert as_ply.read_bytes() == open(os.path.join(OBJ, "smooth.q.dec.ply"), "rb").read()
+    # material libraries are found next to the input when its path has a directory part (formats/unified_reader.h:56)
+    r = harry(tmp_path / "mtl.obj", tmp_path / "mtl.hry")
+    assert r.returncode == 0 and "Used face regions: 3" in r.stdout
+    assert (tmp_path / "mtl.hry").read_bytes() == open(os.path.join(OBJ, "mtl.ll.hry"), "rb").read()
+    r = subprocess.run([cli.HARRY, "mtl.obj", "mtl2.hry"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0 and "Used face regions: 1" in r.stdout                           # ... and not when it has none
+    r = harry(tmp_path / "smooth.obj", tmp_path / "c.hry", "--profile", "chunked")
+    assert r.returncode == 134 and "PLY layout only" in r.stderr

@@ -71,6 +71,15 @@ def test_reference_hry_decodes_to_the_reference_obj_and_ply(cx, name, tag):
     assert cx.write_hry(d, profile=hc.PROFILE_COMPAT) == op.Mesh.from_hry(ref).encode().data   # and codes again like the oracle
 
 
+@pytest.mark.parametrize("name,tag", SMALL, ids=[f"{n}.{t}" for n, t in SMALL])
+def test_generic_vertex_chain_gives_the_same_records(cx, name, tag, monkeypatch):
+    """vertex lists normally take the reconstruction chains of the PLY layout when every vertex owns a record of one list; the
+    relaxation chain of the general path (several vertex regions, shared vertex records) must give the same records"""
+    ref = _read(f"{name}.{tag}.hry")
+    monkeypatch.setenv("HRY_GENERIC_VERTEX", "1")
+    same_decoded(cx.read_hry(ref), op.Mesh.from_hry(ref))
+
+
 @pytest.mark.parametrize("name", sorted(MAN["requant_of_hry"]))
 def test_requant_of_an_obj_hry_matches_reference_golden(cx, name):
     e = MAN["requant_of_hry"][name]
