@@ -120,3 +120,71 @@ def test_general_bindings_refuse_the_chunked_container(cx):
     assert e.value.code == -3
     with pytest.raises(hc.HryError):
         hc.ShardPlan(m, 2)
+
+
+def _disk_scene(n=28, colors_every=0):
+    """a disk: centre, inner ring, outer ring; the outer band comes first in the file so that the centre is coded late, with
+    more coded parallelograms (n) and more coded faces around it (n) than the decoder's source table holds per record"""
+    import math
+    rng = np.random.default_rng(5)
+    pts = [(0.0, 0.0, 0.3)]
+    for ring, rad in ((1, 1.0), (2, 2.0)):
+        for i in range(n):
+            a = 2 * math.pi * i / n
+            pts.append((rad * math.cos(a) + 0.01 * rng.random(), rad * math.sin(a) + 0.01 * rng.random(), 0.05 * rng.random()))
+    inner = lambda i: 1 + i % n
+    outer = lambda i: 1 + n + i % n
+    faces = []
+    for i in range(n):
+        faces.append((inner(i), outer(i), outer(i + 1)))
+        faces.append((inner(i), outer(i + 1), inner(i + 1)))
+    for i in range(n):
+        faces.append((0, inner(i), inner(i + 1)))
+    out = []
+    for k, p in enumerate(pts):
+        vals = [f"{x:.6f}" for x in p]
+        if colors_every and k % colors_every == 0:
+            vals += [f"{x:.6f}" for x in rng.random(3)]
+        out.append("v " + " ".join(vals))
+    for p in pts:
+        out.append(f"vt {p[0] * 0.2 + 0.5:.6f} {p[1] * 0.2 + 0.5:.6f}")
+    for k in range(len(faces)):
+        out.append(f"vn {rng.random():.6f} {rng.random():.6f} {rng.random():.6f}")      # one normal per face: every face adds a record at the centre
+    for k, f in enumerate(faces):
+        out.append("f " + " ".join(f"{v + 1}/{v + 1}/{k + 1}" for v in f))
+    return ("\n".join(out) + "\n").encode()
+
+
+@pytest.mark.parametrize("colors_every", [0, 3])
+@pytest.mark.parametrize("quantised", [False, True])
+def test_fans_larger_than_the_source_table(cx, monkeypatch, colors_every, quantised):
+    """high-valence vertex: more candidates than k_gen_sources keeps per record (the chain walks those fans itself), in both
+    vertex paths; colors_every=3 gives two vertex regions (x y z and x y z r g b), which only the general chain handles"""
+    data = _disk_scene(28, colors_every)
+    o = op.Mesh.from_obj(data, "")
+    m = hc.Mesh.from_obj(data, "")
+    if quantised:
+        q = [(l, -1, 9 + l) for l in range(m.nlists)]
+        cx.requant(m, q)
+        o.requant(q)
+    want = o.clone().encode().data
+    got = cx.write_hry(m, profile=hc.PROFILE_COMPAT)
+    assert got == want
+    ref = op.Mesh.from_hry(want)
+    same_decoded(cx.read_hry(want), ref)
+    monkeypatch.setenv("HRY_GENERIC_VERTEX", "1")
+    same_decoded(cx.read_hry(want), ref)
+
+
+def test_larger_random_scenes_against_the_oracle(cx):
+    for sc, quant in ((og.scene(mg.torus(40, 44, polys="mixed"), normals="smooth", tex="atlas", charts=6, colors="some", materials=3), []),
+                      (og.scene(mg.with_nonmanifold(mg.multi_component(6, 14, 15, polys="mixed"), 6, 4), normals="flat", tex="corner"), [(0, -1, 14), (1, -1, 11)]),
+                      (og.scene(mg.icosphere(4), normals="flat", tex="atlas", charts=9, tex3=True), [(2, -1, 10)])):
+        o = op.Mesh.from_obj(sc.obj, "")
+        m = hc.Mesh.from_obj(sc.obj, "")
+        if quant:
+            cx.requant(m, quant)
+            o.requant(quant)
+        want = o.clone().encode().data
+        assert cx.write_hry(m, profile=hc.PROFILE_COMPAT) == want
+        same_decoded(cx.read_hry(want), op.Mesh.from_hry(want))
