@@ -379,11 +379,65 @@ def main():
                                   "what": "quantisation + .hry v0.1 from the resident mesh; k_rchain_ms = the serial recurrence (host core, streamed behind the kernels)"}
             except Exception as exc:
                 sys.stderr.write(f"compat leg failed: {exc}\n")
+            # SURVEY.md section 8 row f3 next to it: an OBJ scene (positions per vertex, texture coordinates and normals per corner,
+            # shared between corners) through the same reference stream; checked against the oracle, timed beside the reference binary
+            try:
+                line["obj"] = obj_leg(cx)
+            except Exception as exc:
+                sys.stderr.write(f"obj leg failed: {exc}\n")
         print(json.dumps(line))
     cx.close()
     if world > 1:
         dist.barrier()          # rank 0 checks the merged container after the timed region; leave together
         dist.destroy_process_group()
+
+
+def obj_leg(cx):
+    import subprocess
+    import tempfile
+    from harry_amd import codec as hc
+    from harry_amd import meshgen as mg
+    from harry_amd import objgen as og
+    from oracle import oracle_py as op   # checker only
+    sc = og.scene(mg.torus(200, 200, seed=2), normals="smooth", tex="atlas", charts=7)
+    t0 = time.perf_counter()
+    m = hc.Mesh.from_obj(sc.obj, "")
+    t_parse = time.perf_counter() - t0
+    ntri = m.ntri
+    enc, dec, data = [], [], b""
+    for _ in range(3):
+        a = m.clone()
+        t0 = time.perf_counter()
+        data = cx.write_hry(a, profile=hc.PROFILE_COMPAT)
+        t1 = time.perf_counter()
+        d = cx.read_hry(data)
+        t2 = time.perf_counter()
+        enc.append(t1 - t0); dec.append(t2 - t1)
+    want = op.Mesh.from_obj(sc.obj, "").encode().data
+    rec = {"workload": "torus 200 x 200 as OBJ: smooth normals + 7-chart texture atlas (v / vt / vn, f v/t/n)", "triangles": int(ntri), "obj_bytes": len(sc.obj),
+           "parse_ms": round(t_parse * 1e3, 2), "encode_ms": round(min(enc[1:]) * 1e3, 2), "decode_ms": round(min(dec[1:]) * 1e3, 2),
+           "encode_mtri_s": round(ntri / min(enc[1:]) / 1e6, 3), "decode_mtri_s": round(ntri / min(dec[1:]) / 1e6, 3),
+           "hry_bytes": len(data), "byte_identical_to_cpu_ref": bool(data == want),
+           "decode_equals_cpu_ref": bool(d.to_obj() is not None and all(np.array_equal(d.list_data(l), x) for l, x in enumerate(_oracle_lists(op, want))))}
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "harry_ref")
+    if os.path.exists(ref_bin):
+        with tempfile.TemporaryDirectory() as tmp:
+            src, hry, back = os.path.join(tmp, "s.obj"), os.path.join(tmp, "s.hry"), os.path.join(tmp, "b.obj")
+            with open(src, "wb") as f:
+                f.write(sc.obj)
+            t0 = time.perf_counter()
+            subprocess.run([ref_bin, src, hry], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            t1 = time.perf_counter()
+            subprocess.run([ref_bin, hry, back], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            t2 = time.perf_counter()
+            rec["reference_binary"] = {"obj_to_hry_ms": round((t1 - t0) * 1e3, 1), "hry_to_obj_ms": round((t2 - t1) * 1e3, 1),
+                                       "bytes_equal": bool(open(hry, "rb").read() == data), "what": "whole process, file to file, one core"}
+    return rec
+
+
+def _oracle_lists(op, data):
+    o = op.Mesh.from_hry(data)
+    return [o.list_data(l) for l in range(o.nlists)]
 
 
 if __name__ == "__main__":
