@@ -106,6 +106,7 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 		for (int a = 0; a < nbv; ++a) b.reg_vtxlist[b.off_vtxlist[reg] + a] = name_list(r.v<uint16_t>(), 1);
 	}
 	if (target.size() > 4096) throw Error(HRY_E_FORMAT, "implausible number of attribute lists");
+	if (b.nb_face > 255 || b.nb_vtx > 255 || b.nb_corner > 255) throw Error(HRY_E_UNSUPPORTED, "more than 255 lists bound to one region");
 	const bool ply_layout = nrf == 1 && nrv == 1 && b.nfacelists(0) == 1 && b.ncornerlists(0) == 0 && b.nvtxlists(0) == 1 &&
 	                        b.facelist(0, 0) == 0 && b.vtxlist(0, 0) == 1;
 	m.general = !ply_layout;

@@ -188,3 +188,28 @@ def test_larger_random_scenes_against_the_oracle(cx):
         want = o.clone().encode().data
         assert cx.write_hry(m, profile=hc.PROFILE_COMPAT) == want
         same_decoded(cx.read_hry(want), op.Mesh.from_hry(want))
+
+
+def test_decode_survives_damaged_payload(cx):
+    """flipped bytes behind the header of an OBJ-made stream: an error or some mesh, never a crash, a hang or an unusable context"""
+    good = _read("mixedfmt.ll.hry")
+    ref = op.Mesh.from_hry(good)
+    hdr = hc.container_info(good)["header_bytes"]
+    rng = np.random.default_rng(17)
+    outcomes = {"error": 0, "mesh": 0}
+    for trial in range(40):
+        bad = bytearray(good)
+        for _ in range(1 + trial % 3):
+            k = int(rng.integers(hdr, len(bad)))
+            bad[k] ^= int(rng.integers(1, 256))
+        try:
+            cx.read_hry(bytes(bad)).to_obj()
+            outcomes["mesh"] += 1
+        except hc.HryError:
+            outcomes["error"] += 1
+    assert outcomes["error"] + outcomes["mesh"] == 40 and outcomes["error"] > 0
+    try:
+        cx.read_hry(good[:hdr + 10])     # a cut stream reads ones past its end (arith/bitstream.h:27): usually a format error
+    except hc.HryError:
+        pass
+    same_decoded(cx.read_hry(good), ref)
