@@ -224,8 +224,10 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	struct Landing { hipEvent_t ev; size_t off, len; };
 	std::deque<Landing> landing;
 	const int vstride = ldv.stride;
-	std::thread consumer([&] {
+	const void *node = callers_node_cpus();
+	std::thread consumer([&, node] {
 		try {
+			stay_on_node(node);
 			HIP_OK(hipSetDevice(cx.device));
 			uint32_t f_up = 0, he_up = 0, v_done = 0;
 			uint64_t seen_seq = 0;

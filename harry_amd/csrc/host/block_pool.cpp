@@ -1,5 +1,8 @@
 // Recycling pool for the big host arrays (mesh.hpp: BlockPool / BigVec).
+#include <cstdio>
 #include <cstdlib>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <map>
 #include <mutex>
@@ -65,6 +68,96 @@ void BlockPool::give(void *p) noexcept
 	if (P.free_bytes + cap > P.limit) { P.capacity.erase(it); free(p); return; }
 	P.free_blocks.emplace(cap, p);
 	P.free_bytes += cap;
+}
+
+// ---- helper threads stay on the caller's memory node ------------------------------------------------------------
+// A helper thread that first touches (or last wrote) a block leaves its pages on the node it ran on, and the recycling pool hands
+// such blocks to the next call: on a two-socket host the sequential walk / replay of that call then works out of the other
+// socket's memory (measured: replay 6.3 -> 35 ms per million triangles after a PLY parse whose twin matching ran on both
+// sockets).  So every helper thread is confined to the CPUs of the node its creator is running on.
+namespace {
+struct NodeTable {
+	std::vector<cpu_set_t> nodes;
+	NodeTable()
+	{
+		if (getenv("HRY_NO_NUMA_BIND")) return;
+		cpu_set_t allowed;
+		CPU_ZERO(&allowed);
+		if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+		for (int n = 0; n < 64; ++n) {
+			char path[96];
+			snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n);
+			FILE *f = fopen(path, "r");
+			if (!f) break;
+			cpu_set_t cs;
+			CPU_ZERO(&cs);
+			int a, b;
+			while (fscanf(f, "%d", &a) == 1) {   // "0-63,128-191"
+				b = a;
+				int c = fgetc(f);
+				if (c == '-') { if (fscanf(f, "%d", &b) != 1) break; c = fgetc(f); }
+				for (int k = a; k <= b && k < CPU_SETSIZE; ++k) if (CPU_ISSET(k, &allowed)) CPU_SET(k, &cs);
+				if (c != ',') break;
+			}
+			fclose(f);
+			nodes.push_back(cs);
+		}
+		if (nodes.size() < 2) nodes.clear();   // one node: nothing to confine
+	}
+};
+}   // namespace
+
+// the CPUs that share the caller's last-level cache (one CCD of an EPYC: 8 cores).  What helper threads of a SHORT parallel phase
+// write stays in their L3; a sequential phase that follows on the caller's core and rewrites those lines (the recycling pool hands
+// the freed temporaries straight to the next call) pays a cache-to-cache transfer between chiplets per line -- as slow as remote
+// memory (measured: the replay after a PLY parse 11 -> 23 ms even with every thread on the caller's memory node).
+const void *callers_cache_cpus(unsigned *n_cpus)
+{
+	static std::mutex mu;
+	static std::unordered_map<int, cpu_set_t> *by_cpu = new std::unordered_map<int, cpu_set_t>();
+	if (n_cpus) *n_cpus = 0;
+	if (getenv("HRY_NO_NUMA_BIND")) return nullptr;
+	const int cpu = sched_getcpu();
+	if (cpu < 0) return nullptr;
+	std::lock_guard<std::mutex> g(mu);
+	auto it = by_cpu->find(cpu);
+	if (it == by_cpu->end()) {
+		cpu_set_t cs, allowed;
+		CPU_ZERO(&cs); CPU_ZERO(&allowed);
+		(void)sched_getaffinity(0, sizeof(allowed), &allowed);
+		char path[128];
+		snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+		if (FILE *f = fopen(path, "r")) {
+			int a, b;
+			while (fscanf(f, "%d", &a) == 1) {
+				b = a;
+				int c = fgetc(f);
+				if (c == '-') { if (fscanf(f, "%d", &b) != 1) break; c = fgetc(f); }
+				for (int k = a; k <= b && k < CPU_SETSIZE; ++k) if (CPU_ISSET(k, &allowed)) CPU_SET(k, &cs);
+				if (c != ',') break;
+			}
+			fclose(f);
+		}
+		it = by_cpu->emplace(cpu, cs).first;
+	}
+	const unsigned n = (unsigned)CPU_COUNT(&it->second);
+	if (n < 2) return nullptr;
+	if (n_cpus) *n_cpus = n;
+	return &it->second;
+}
+
+const void *callers_node_cpus()
+{
+	static const NodeTable *tab = new NodeTable();
+	if (tab->nodes.empty()) return nullptr;
+	const int cpu = sched_getcpu();
+	if (cpu < 0) return nullptr;
+	for (const cpu_set_t &cs : tab->nodes) if (CPU_ISSET(cpu, &cs) && CPU_COUNT(&cs) > 0) return &cs;
+	return nullptr;
+}
+void stay_on_node(const void *cpus)
+{
+	if (cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), (const cpu_set_t*)cpus);
 }
 
 }   // namespace hry

@@ -127,13 +127,18 @@ void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const s
                        std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level);
 unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
 uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
-template <typename F> inline void parallel_for(unsigned n_threads, F &&body)   // body(thread index), joins before returning
+// helper threads run on the CPUs of the memory node their creator is on (block_pool.cpp; HRY_NO_NUMA_BIND switches it off)
+const void *callers_node_cpus();       // nullptr: one node, or unknown
+void stay_on_node(const void *cpus);   // confines the calling thread
+const void *callers_cache_cpus(unsigned *n_cpus);   // CPUs sharing the caller's last-level cache (nullptr: unknown)
+template <typename F> inline void parallel_for(unsigned n_threads, F &&body, const void *cpus = nullptr)   // body(thread index), joins before returning
 {
 	std::vector<std::thread> th;
 	std::exception_ptr err;
 	std::mutex mu;
+	const void *node = n_threads > 1 ? (cpus ? cpus : callers_node_cpus()) : nullptr;
 	for (unsigned t = 1; t < n_threads; ++t)
-		th.emplace_back([&, t] { try { body(t); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); } });
+		th.emplace_back([&, t, node] { stay_on_node(node); try { body(t); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); } });
 	try { body(0); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
 	for (auto &x : th) x.join();
 	if (err) std::rethrow_exception(err);

@@ -153,7 +153,11 @@ void build_twins(Mesh &m)
 {
 	const uint32_t ne = m.ne(), nf = m.nf;
 	m.twin.resize(ne);
-	const unsigned nt = ne >= (1u << 18) ? host_threads() : 1u;
+	// the matching does not scale past a handful of cores, and what its threads write is read next by the caller's core: keep
+	// them inside the caller's last-level cache domain (block_pool.cpp)
+	unsigned n_near = 0;
+	const void *near = callers_cache_cpus(&n_near);
+	const unsigned nt = ne >= (1u << 18) ? (near ? std::min(host_threads(), n_near) : host_threads()) : 1u;
 	if (nt < 2) {
 		for (uint32_t e = 0; e < ne; ++e) m.twin[e] = e;
 		EdgeTable tab(ne);
@@ -184,7 +188,7 @@ void build_twins(Mesh &m)
 			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
 			for (uint32_t h = b; h < e; ++h) { m.twin[h] = h; ++cnt[bucket_of(m.org[h], m.org[h + 1 == e ? b : h + 1])]; }
 		}
-	});
+	}, near);
 	// bucket-major, thread-minor offsets: inside a bucket the threads' (= face ranges') entries follow one another in face order
 	std::vector<uint64_t> start((size_t)nt * nb), bucket_begin(nb + 1, 0);
 	uint64_t run = 0;
@@ -207,7 +211,7 @@ void build_twins(Mesh &m)
 				pairs[2 * p + 1] = h;
 			}
 		}
-	});
+	}, near);
 	std::atomic<uint32_t> next{ 0 };
 	parallel_for(nt, [&](unsigned) {
 		for (;;) {
@@ -215,7 +219,7 @@ void build_twins(Mesh &m)
 			if (k >= nb) break;
 			pair_bucket(pairs.data() + 2 * bucket_begin[k], (size_t)(bucket_begin[k + 1] - bucket_begin[k]), m.twin.data());
 		}
-	});
+	}, near);
 }
 
 // ---- reader ----------------------------------------------------------------------------------------------
