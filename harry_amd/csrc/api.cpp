@@ -158,7 +158,11 @@ uint32_t hry_mesh_ne(const hry_mesh *m) { return m->m.ne(); }
 uint64_t hry_mesh_ntri(const hry_mesh *m) { return m->m.ntri(); }
 const uint32_t *hry_mesh_face_offsets(const hry_mesh *m) { return m->m.face_off.data(); }
 const uint32_t *hry_mesh_org(const hry_mesh *m) { return m->m.org.data(); }
-const uint32_t *hry_mesh_twin(const hry_mesh *m) { return m->m.twin.data(); }
+const uint32_t *hry_mesh_twin(const hry_mesh *m)
+{
+	try { ensure_twins(m->m); } catch (...) { return nullptr; }
+	return m->m.twin.data();
+}
 int hry_mesh_nlists(const hry_mesh *m) { return (int)m->m.lists.size(); }
 int hry_list_ncomp(const hry_mesh *m, int l) { return m->m.lists[l].ncomp(); }
 uint32_t hry_list_count(const hry_mesh *m, int l) { return m->m.lists[l].count; }

@@ -95,7 +95,7 @@ void Context::upload_mesh(Mesh &m)
 	d_twin.ensure(std::max<size_t>((size_t)ne * 4, 16));
 	d_foff.ensure(((size_t)m.nf + 1) * 4);
 	HIP_OK(hipMemcpyAsync(d_org.p, m.org.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
-	HIP_OK(hipMemcpyAsync(d_twin.p, m.twin.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
+	if (!m.twins_pending) HIP_OK(hipMemcpyAsync(d_twin.p, m.twin.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
 	HIP_OK(hipMemcpyAsync(d_foff.p, m.face_off.data(), ((size_t)m.nf + 1) * 4, hipMemcpyHostToDevice, stream));
 	int ud = 0;
 	res_has_eface = !m.uniform_degree(ud);
@@ -104,8 +104,19 @@ void Context::upload_mesh(Mesh &m)
 		d_eface.ensure(std::max<size_t>((size_t)ne * 4, 16));
 		dev::launch_edge_faces(stream, d_foff.as<uint32_t>(), m.nf, d_eface.as<uint32_t>());
 	}
-	HIP_OK(hipStreamSynchronize(stream));
 	res_nv = m.nv; res_nf = m.nf; res_ne = ne;
+	if (m.twins_pending) {   // a freshly read mesh: half-edge twin matching on the device (twins.hip), and down for the host's walk
+		if (ne && m.nv) {
+			for (uint32_t v : m.org) if (v >= m.nv) throw Error(HRY_E_ARG, "vertex index out of range");
+			d_cscratch.ensure(dev::twin_workspace_bytes(m.nv, ne));
+			dev::launch_twins(stream, conn_view(), m.nv, d_twin.as<uint32_t>(), d_cscratch.p);
+		}
+		m.twin.resize(ne);
+		if (ne) HIP_OK(hipMemcpyAsync(m.twin.data(), d_twin.p, (size_t)ne * 4, hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipStreamSynchronize(stream));
+		m.twins_pending = false;
+	}
+	HIP_OK(hipStreamSynchronize(stream));
 	m.device_token = next_token++;
 	resident_token = m.device_token;
 }

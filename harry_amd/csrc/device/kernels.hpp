@@ -30,6 +30,10 @@ void launch_rchain(hipStream_t st, const SymRec *rec, uint32_t n, uint64_t *r_ou
 void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s, const uint32_t *sym_l, uint32_t n, uint64_t *acc);
 void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes);
 
+// half-edge twin matching (twins.hip): conn.org / foff (/ eface) resident, twin = output; ws: twin_workspace_bytes
+size_t twin_workspace_bytes(uint32_t nv, uint32_t ne);
+void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twin, void *ws);
+
 // chunked profile (chunked.hip)
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits);
 void launch_stream_pack(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *stream_bits, const uint8_t *bytes,

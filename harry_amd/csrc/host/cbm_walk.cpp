@@ -1034,6 +1034,7 @@ std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark>
 
 void analyse_components(const Mesh &m, ComponentAnalysis &A)
 {
+	ensure_twins(m);
 	int udeg = 0;
 	if (!m.uniform_degree(udeg)) udeg = 0;
 	const unsigned nt = m.nf >= (1u << 16) ? host_threads() : 1u;
@@ -1049,6 +1050,7 @@ void analyse_components(const Mesh &m, ComponentAnalysis &A)
 
 void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
 {
+	ensure_twins(m);
 	int udeg = 0;
 	if (!m.uniform_degree(udeg)) udeg = 0;
 	switch (udeg) {

@@ -20,6 +20,9 @@ Mesh *mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint
                        const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names);
 void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed = false);
 void build_twins(Mesh &m);
+// the readers leave the twin matching pending (Mesh::twins_pending); a context does it on the device when the mesh is first
+// uploaded (device/twins.hip), host-only entry points do it here
+void ensure_twins(const Mesh &m);
 void print_component(std::string &o, const AttrList &L, const uint8_t *rec, int c);   // one value as the reference prints it (mixing.h:340-359)
 
 // ---- obj_io.cpp (formats/obj/reader.rl:108-299, writer.cc:20-132): meshes with general bindings (mesh.hpp Bindings)

@@ -146,6 +146,8 @@ struct Mesh {
 	BigVec<uint32_t> face_off{0};        // nf + 1
 	BigVec<uint32_t> org;                // per half-edge
 	BigVec<uint32_t> twin;               // per half-edge, flat id; self = border
+	bool twins_pending = false;          // a reader left the matching for later: on the device at the first upload (twins.hip), else
+	                                     // on the host when first asked for (ensure_twins)
 	std::vector<uint8_t> have_degree;    // have_degree[d] != 0 iff a polygon with d edges exists (faces.h:44-56)
 	std::vector<AttrList> lists = std::vector<AttrList>(2);   // PLY layout: [0] face attributes, [1] vertex attributes (formats/ply/reader.cc:388-400)
 	bool general = false;                // true: `bind` holds regions and element -> record maps, any number of lists

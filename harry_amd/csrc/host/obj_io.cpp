@@ -200,7 +200,7 @@ struct Loader {
 		m.bind.vtx_reg.assign(vreg.begin(), vreg.end()); m.bind.face_reg.assign(freg.begin(), freg.end());
 		m.bind.vtx_attr.assign(vattr.begin(), vattr.end()); m.bind.corner_attr.assign(cattr.begin(), cattr.end());
 		for (size_t l = 0; l < m.lists.size(); ++l) m.lists[l].data.assign(rec[l].begin(), rec[l].end());
-		build_twins(m);
+		m.twins_pending = true;
 	}
 };
 

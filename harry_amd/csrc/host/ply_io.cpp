@@ -149,6 +149,14 @@ static void pair_bucket(const uint64_t *pairs, size_t n, uint32_t *twin)
 	}
 }
 
+void ensure_twins(const Mesh &cm)
+{
+	if (!cm.twins_pending) return;
+	Mesh &m = const_cast<Mesh&>(cm);   // logically const: the twins are a function of the connectivity
+	build_twins(m);
+	m.twins_pending = false;
+}
+
 void build_twins(Mesh &m)
 {
 	const uint32_t ne = m.ne(), nf = m.nf;
@@ -315,6 +323,8 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 	if (fi < 0 || vi < 0) throw Error(HRY_E_FORMAT, "PLY needs a vertex and a face element");
 
 	std::unique_ptr<Mesh> m(new Mesh());
+	if (elems[fi].count < 0 || elems[vi].count < 0 || (uint64_t)elems[fi].count > 0xfffffff0ull || (uint64_t)elems[vi].count > 0xfffffff0ull)
+		throw Error(HRY_E_FORMAT, "implausible element count");
 	std::vector<int> slot[2];
 	const int which[2] = { fi, vi };
 	for (int k = 0; k < 2; ++k) {
@@ -361,6 +371,66 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 			c.p += rec * (size_t)el.count;
 			continue;
 		}
+		// fast path: binary little-endian faces that are nothing but the index list, one count byte + 4-byte indices
+		if ((int)ei == fi && mode == 1 && el.props.size() == 1 && kTypeSize[el.props[0].len_type] == 1 && kTypeSize[el.props[0].type] == 4 &&
+		    el.props[0].type != C_FLOAT) {
+			const uint32_t nf = m->nf, nv = m->nv;
+			const uint8_t *p = c.p;
+			const size_t avail = (size_t)(c.end - c.p);
+			m->face_off.resize((size_t)nf + 1);
+			m->face_off[0] = 0;
+			// all triangles (the usual file): fixed 13-byte records, checked and copied by a few threads
+			bool tri = avail >= (size_t)nf * 13 && nf >= (1u << 16);
+			if (tri) {
+				unsigned n_near = 0;
+				const void *near = callers_cache_cpus(&n_near);
+				const unsigned nt = std::max(1u, std::min(near ? n_near : 8u, host_threads()));
+				std::atomic<bool> ok{ true }, range{ true };
+				m->org.resize((size_t)nf * 3);
+				uint32_t *org = m->org.data(), *foff = m->face_off.data();
+				parallel_for(nt, [&](unsigned t) {
+					const uint32_t fb = (uint32_t)((uint64_t)nf * t / nt), fe = (uint32_t)((uint64_t)nf * (t + 1) / nt);
+					bool good = true, inside = true;
+					for (uint32_t f = fb; f < fe; ++f) {
+						const uint8_t *r = p + (size_t)f * 13;
+						good &= r[0] == 3;
+						uint32_t v[3];
+						memcpy(v, r + 1, 12);
+						inside &= (v[0] < nv) & (v[1] < nv) & (v[2] < nv);
+						memcpy(org + (size_t)f * 3, v, 12);
+						foff[f + 1] = (f + 1) * 3;
+					}
+					if (!good) ok.store(false, std::memory_order_relaxed);
+					if (!inside) range.store(false, std::memory_order_relaxed);
+				}, near);
+				tri = ok.load();
+				if (tri && !range.load()) throw Error(HRY_E_FORMAT, "PLY vertex index out of range");
+				if (tri) {
+					if (m->have_degree.size() < 4) m->have_degree.resize(4, 0);
+					m->have_degree[3] = 1;
+					c.p += (size_t)nf * 13;
+					continue;
+				}
+			}
+			m->org.clear();
+			m->org.reserve((size_t)nf * 3);
+			size_t pos = 0;
+			for (uint32_t f = 0; f < nf; ++f) {
+				if (p >= c.end) throw Error(HRY_E_FORMAT, "truncated PLY");
+				const uint32_t len = *p++;
+				if (len < 3) throw Error(HRY_E_UNSUPPORTED, "polygon degree outside 3..255");
+				if ((size_t)(c.end - p) < (size_t)len * 4) throw Error(HRY_E_FORMAT, "truncated PLY");
+				if (len >= m->have_degree.size()) m->have_degree.resize(len + 1, 0);
+				m->have_degree[len] = 1;
+				m->org.resize(pos + len);
+				memcpy(m->org.data() + pos, p, (size_t)len * 4);
+				p += (size_t)len * 4;
+				pos += len;
+				m->face_off[f + 1] = (uint32_t)pos;
+			}
+			c.p = p;
+			continue;
+		}
 		for (long j = 0; j < el.count; ++j) {
 			for (size_t pi = 0; pi < el.props.size(); ++pi) {
 				const Prop &p = el.props[pi];
@@ -381,7 +451,7 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 	}
 	if (m->face_off.size() != (size_t)m->nf + 1) throw Error(HRY_E_FORMAT, "PLY face count mismatch");
 	for (uint32_t v : m->org) if (v >= m->nv) throw Error(HRY_E_FORMAT, "PLY vertex index out of range");
-	build_twins(*m);
+	m->twins_pending = true;   // matched on the device at the first upload, or by ensure_twins
 	return m.release();
 }
 
@@ -428,7 +498,7 @@ Mesh *mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint
 	}
 	m->org.assign(indices, indices + tot);
 	for (uint32_t v : m->org) if (v >= nv) throw Error(HRY_E_ARG, "vertex index out of range");
-	build_twins(*m);
+	m->twins_pending = true;   // matched on the device at the first upload, or by ensure_twins
 	return m.release();
 }
 
@@ -571,6 +641,22 @@ void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool pack
 		if (pv) { out.reserve(out.size() + LV.data.size()); for (uint32_t v = 0; v < m.nv; ++v) put_packed(LV, LV.data.data() + (size_t)v * LV.stride()); }
 		else out.insert(out.end(), LV.data.begin(), LV.data.end());   // whole original-width records (writer.cc:72-75)
 		size_t fs = LF.stride();
+		int tri = 0;
+		if (!fs && m.uniform_degree(tri) && tri == 3 && m.nf >= (1u << 16)) {   // the usual file: 13-byte records, filled by a few threads
+			const size_t at = out.size();
+			out.resize(at + (size_t)m.nf * 13);
+			unsigned n_near = 0;
+			const void *near = callers_cache_cpus(&n_near);
+			const unsigned nt = std::max(1u, std::min(near ? n_near : 8u, host_threads()));
+			uint8_t *dst = out.data() + at;
+			const uint32_t *org = m.org.data();
+			const uint32_t nf = m.nf;
+			parallel_for(nt, [&](unsigned t) {
+				const uint32_t fb = (uint32_t)((uint64_t)nf * t / nt), fe = (uint32_t)((uint64_t)nf * (t + 1) / nt);
+				for (uint32_t f = fb; f < fe; ++f) { uint8_t *r = dst + (size_t)f * 13; r[0] = 3; memcpy(r + 1, org + (size_t)f * 3, 12); }
+			}, near);
+			return;
+		}
 		for (uint32_t f = 0; f < m.nf; ++f) {
 			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
 			out.push_back((uint8_t)(e - b));

@@ -101,6 +101,7 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 {
+	ensure_twins(m);
 	if (shard >= plan.n_shards) throw Error(HRY_E_ARG, "shard index out of range");
 	if (plan.g_nv != m.nv || plan.g_nf != m.nf || plan.g_ne != m.ne() || plan.A.comp.size() != m.nf || plan.A.vertex_owner.size() != m.nv)
 		throw Error(HRY_E_ARG, "the plan belongs to another mesh");
