@@ -123,6 +123,30 @@ def build_whole(n_side: int, world: int):
     return mg.concat([mg.torus(n_side, n_side, seed=2 + k, sigma=1e-4, center=(3.0 * k, 0.0, 0.0)) for k in range(world)])
 
 
+def stay_on_memory_node():
+    """The step is bound by two sequential host loops that work out of recycled buffers: a migration of this process to the other
+    socket in mid-run leaves them in remote memory.  Confine the process to the CPUs of the memory node it is on (what `numactl
+    --cpunodebind` would do); returns the node or None."""
+    try:
+        import ctypes
+        cpu = ctypes.CDLL(None).sched_getcpu()
+        allowed = os.sched_getaffinity(0)
+        for node in range(64):
+            path = f"/sys/devices/system/node/node{node}/cpulist"
+            if not os.path.exists(path):
+                break
+            cpus = set()
+            for part in open(path).read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+            if cpu in cpus and len(cpus & allowed) >= 8:
+                os.sched_setaffinity(0, cpus & allowed)
+                return node
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +159,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    stay_on_memory_node()
 
     import torch
     import torch.distributed as dist
