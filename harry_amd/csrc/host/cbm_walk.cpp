@@ -611,7 +611,11 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 template <int DEG>
 static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, bool eval_op_model, unsigned n_threads)
 {
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	auto t0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	WalkState st(m.nv, m.nf);
+	mark("(sequential part) state allocated");
 	Border cb(st.on);
 	StartFaces pool(m.nf, st.gone);
 	if (!m.shard.seeds.empty()) {
@@ -621,6 +625,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	Emitter em(w);
 	em.eval_model = eval_op_model;
 	em.attach((size_t)m.ne() + m.ntri() + 16, m.nv, m.nf);   // every half-edge ends at most one border operation, every triangle one other
+	mark("(sequential part) start faces and output planes");
 	uint32_t next_id = 0, consumed = 0;
 	const bool count = getenv("HRY_PERF") != nullptr;   // hardware counters of this thread around the first component's walk
 	do {
@@ -644,6 +649,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 		// several threads once the first one shows that the mesh has more than one.
 		if (n_threads > 1 && !eval_op_model && m.nf - consumed >= parallel_min_faces()) {
 			em.detach();
+			mark("(sequential part) first component walked");
 			walk_rest_parallel<DEG>(m, st, eface_tab, em, next_id, n_threads);
 			break;
 		}
@@ -651,6 +657,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	em.detach();
 	em.finish_marks();
 	em.iop(I_EOM);
+	mark("(sequential part) done");
 	w.n_conn = em.n;
 	for (int i = 0; i < 8; ++i) w.n_op_class[i] = em.n_op[i];
 }
@@ -673,9 +680,23 @@ uint32_t parallel_min_faces()
 }
 namespace {
 // lock-free union-find on atomics: a root is always the smallest index of its set's links, so links never form a cycle
+// big arrays of atomics come from the recycling pool like every other per-call array (fresh pages cost a fault per 4 KiB)
+struct AtomicArray {
+	std::atomic<uint32_t> *p;
+	size_t bytes;
+	explicit AtomicArray(size_t n) : bytes(std::max<size_t>(n, 1) * sizeof(std::atomic<uint32_t>))
+	{
+		static_assert(sizeof(std::atomic<uint32_t>) == 4 && std::is_trivially_destructible<std::atomic<uint32_t>>::value, "plain words");
+		p = (std::atomic<uint32_t>*)(bytes >= BlockPool::kMinBytes ? BlockPool::take(bytes) : ::operator new(bytes));
+	}
+	~AtomicArray() { if (bytes >= BlockPool::kMinBytes) BlockPool::give(p); else ::operator delete(p); }
+	AtomicArray(const AtomicArray&) = delete;
+	AtomicArray &operator=(const AtomicArray&) = delete;
+	std::atomic<uint32_t> &operator[](size_t i) const { return p[i]; }
+};
 struct AtomicSets {
-	std::unique_ptr<std::atomic<uint32_t>[]> parent;
-	explicit AtomicSets(size_t n) : parent(new std::atomic<uint32_t>[n]) {}
+	AtomicArray parent;
+	explicit AtomicSets(size_t n) : parent(n) {}
 	uint32_t find(uint32_t x)
 	{
 		for (;;) {
@@ -738,12 +759,12 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 		}
 	});
 	// dense component numbers (roots counted per thread range, then a prefix over the ranges)
-	std::vector<uint32_t> &comp = A.comp;
-	comp.assign(nf, NONE32);
+	BigVec<uint32_t> &comp = A.comp;
+	comp.resize(nf);
 	std::vector<uint32_t> range_roots(n_threads + 1, 0);
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e, c = 0; split(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) if (!is_gone(f) && sets.find(f) == f) ++c;
+		for (uint32_t f = b; f < e; ++f) { comp[f] = NONE32; if (!is_gone(f) && sets.find(f) == f) ++c; }
 		range_roots[t + 1] = c;
 	});
 	for (unsigned t = 0; t < n_threads; ++t) range_roots[t + 1] += range_roots[t];
@@ -814,7 +835,7 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 	// (c) the first remaining component (in coding order) that touches each vertex: it introduces the vertex unless the part
 	// walked before already transmitted it.  Components that touch a common vertex are tied together: the vertex's index,
 	// its triangle count (operation class) and its border count make the later one depend on the earlier one.
-	std::unique_ptr<std::atomic<uint32_t>[]> vfirst(new std::atomic<uint32_t>[nv]);
+	AtomicArray vfirst(nv);
 	parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nv, t, b, e); for (uint32_t v = b; v < e; ++v) vfirst[v].store(NONE32, std::memory_order_relaxed); });
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(ne, t, b, e);
@@ -946,7 +967,9 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 				const uint32_t add = (uint32_t)off_sym[k];
 				for (size_t i = 0; i < fw.grp_pos[g].size(); ++i) dst[i] = fw.grp_pos[g][i] + add;
 			}
-			WalkResult().order_v.swap(fw.order_v);   // release early
+			// release here, on this thread: thousands of small fragments are otherwise freed one by one by the caller
+			BigVec<uint32_t>().swap(fw.order_v); BigVec<uint32_t>().swap(fw.order_f); BigVec<OpByte>().swap(fw.op_sc);
+			for (int g = 0; g < G_COUNT; ++g) { BigVec<uint32_t>().swap(fw.grp_val[g]); BigVec<uint32_t>().swap(fw.grp_pos[g]); }
 			if (fw.twins_changed) changed_any.store(true, std::memory_order_relaxed);
 		}
 	});
@@ -980,7 +1003,7 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 {
 	const uint32_t nv = m.nv, nf = m.nf;
 	if (nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
-	std::vector<uint32_t> eface_tab;
+	BigVec<uint32_t> eface_tab;   // (pooled, not value-initialised: 4 bytes per half-edge, every entry written below)
 	if (DEG == 0) {
 		eface_tab.resize(m.ne());
 		const unsigned nt = nf >= (1u << 20) ? host_threads() : 1u;

@@ -100,11 +100,11 @@ void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true);
 // and which components share a vertex (cbm/encoder.h:79-113,187: they name each other's vertices and must stay together).
 struct ComponentAnalysis {
 	uint32_t ncomp = 0;
-	std::vector<uint32_t> comp;                  // per face: component number (arbitrary, dense)
+	BigVec<uint32_t> comp;                       // per face: component number (arbitrary, dense)
 	std::vector<uint32_t> by_rank, rank_of;      // coding rank <-> component number
 	std::vector<uint32_t> seed, n_faces, n_halfedges, fresh, group;   // per coding rank; group = smallest rank tied to it
 	bool want_vertex_owner = false;
-	std::vector<uint32_t> vertex_owner;          // per vertex: coding rank of the component that introduces it (0xffffffff: unused)
+	BigVec<uint32_t> vertex_owner;               // per vertex: coding rank of the component that introduces it (0xffffffff: unused)
 };
 void analyse_components(const Mesh &m, ComponentAnalysis &A);
 
