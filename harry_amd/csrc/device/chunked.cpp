@@ -21,11 +21,7 @@ using namespace dev;
 typedef std::chrono::steady_clock Clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 
-enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
-static constexpr int kDefaultChunk = 8192;   // with static priors a fresh table per chunk costs little: short chunks = short serial chains
-static constexpr uint32_t kMaxChunk = 1u << 20;   // totals stay below 2^21: far inside the 32-bit coder's t <= 2^30 (oracle: same clamp)
-
-static void build_inits(const Mesh &m, std::vector<uint32_t> &tabs, uint32_t totals[INIT_KINDS])
+void build_init_tables(const Mesh &m, std::vector<uint32_t> &tabs)
 {
 	tabs.assign((size_t)INIT_KINDS * 256, 0);
 	for (int i = 0; i < 256; ++i) tabs[INIT_ONES * 256 + i] = 1;
@@ -33,10 +29,17 @@ static void build_inits(const Mesh &m, std::vector<uint32_t> &tabs, uint32_t tot
 	for (size_t d = 3; d < m.have_degree.size(); ++d)
 		if (m.have_degree[d]) { ++tabs[INIT_NT0 * 256 + ((d - 2) & 0xff)]; ++tabs[INIT_NT1 * 256 + ((d - 2) >> 8)]; }
 	for (int i = 0; i < 7; ++i) tabs[INIT_OP * 256 + i] = 1;
-	for (int k = 0; k < INIT_KINDS; ++k) { totals[k] = 0; for (int i = 0; i < 256; ++i) totals[k] += tabs[(size_t)k * 256 + i]; }
+	if (m.general) {   // models.h:201-203,212-217
+		for (int r = 0; r < m.bind.nregs_vtx() && r < 256; ++r) tabs[INIT_REGV * 256 + r] = 1;
+		for (int r = 0; r < m.bind.nregs_face() && r < 256; ++r) tabs[INIT_REGF * 256 + r] = 1;
+	}
+	tabs[INIT_TYPE2 * 256 + 0] = tabs[INIT_TYPE2 * 256 + 1] = 1;
+	tabs[INIT_TYPE3 * 256 + 0] = tabs[INIT_TYPE3 * 256 + 1] = tabs[INIT_TYPE3 * 256 + 2] = 1;
 }
 
-struct PlaneRef { const uint8_t *dptr; uint32_t n; int init; };
+static constexpr int kDefaultChunk = 8192;   // with static priors a fresh table per chunk costs little: short chunks = short serial chains
+static constexpr uint32_t kMaxChunk = 1u << 20;   // totals stay below 2^21: far inside the 32-bit coder's t <= 2^30 (oracle: same clamp)
+
 
 // the plane list of a mesh in container order; device pointers are filled by the caller
 static const int kConnPlanes = 1 + 4 + 2 + 4 + 2 + 8;
@@ -62,12 +65,14 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	HIP_OK(hipSetDevice(cx.device));
 	auto t_all = Clock::now();
 	cx.timing = hry_timing{};
-	if (m.general) throw Error(HRY_E_UNSUPPORTED, "the chunked container holds the PLY layout only (one face list, one vertex list, one record per element): code general bindings with HRY_PROFILE_COMPAT");
+	if (m.general && m.shard.active()) throw Error(HRY_E_UNSUPPORTED, "only the PLY layout (one record per element) shards");
 	check_codable(m);
+	if (m.general) check_general(m);
 	uint32_t CH = chunk_syms > 0 ? std::min<uint32_t>((uint32_t)chunk_syms, kMaxChunk) : (uint32_t)kDefaultChunk;
-	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds && m.lists[l].ncomp()) { device_bounds(cx, m); break; }
-	for (int l = 0; l < 2; ++l) if (!m.lists[l].have_bounds) { m.lists[l].bmin.assign(m.lists[l].stride(), 0); m.lists[l].bmax.assign(m.lists[l].stride(), 0); m.lists[l].have_bounds = true; }
-	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
+	for (auto &L : m.lists) if (!L.have_bounds && L.ncomp()) { device_bounds(cx, m); break; }
+	for (auto &L : m.lists) if (!L.have_bounds) { L.bmin.assign(L.stride(), 0); L.bmax.assign(L.stride(), 0); L.have_bounds = true; }
+	if (m.general) upload_general(cx, m);
+	else if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
 
 	// a shard of a larger mesh writes one segment of a sharded container (.hry v0.3, host/shard.cpp): the header of the whole
 	// mesh, then its runs and an ordinary v0.2 body of the shard in its own numbering
@@ -98,11 +103,12 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	cx.timing.host_walk_ms = ms_since(t_walk);
 
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
-	const ListDesc ldv = make_list_desc(m.lists[1]), ldf = make_list_desc(m.lists[0]);
+	const ListDesc ldv = m.general ? ListDesc{} : make_list_desc(m.lists[1]), ldf = m.general ? ListDesc{} : make_list_desc(m.lists[0]);   // (general bindings: general_planes_encode)
 	if (chunk_syms <= 0) {
 		// default policy: 32 Ki symbols per chunk (about +5 % size on a 1 M-triangle mesh); larger meshes get larger chunks
 		// as long as some thousands of streams remain to fill the 1024 SIMDs
 		uint64_t total = (uint64_t)w.n_conn + (uint64_t)vc * ldv.nplanes + (uint64_t)fc * ldf.nplanes;
+		if (m.general) for (const AttrList &L : m.lists) total += (uint64_t)L.count * L.coded_bytes();
 		while (CH < (1u << 18) && total / CH > 8192) CH <<= 1;
 	}
 
@@ -122,7 +128,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	cx.d_vplanes.ensure(std::max<size_t>((size_t)vc * ldv.nplanes, 16));
 	cx.d_fplanes.ensure(std::max<size_t>((size_t)fc * ldf.nplanes, 16));
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
-	if (fc && ldf.nplanes) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));   // only the face planes read it
+	if (fc && (ldf.nplanes || m.general)) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));   // only the face planes read it
 	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
 	if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
 	size_t goff[G_COUNT + 1] = { 0 };
@@ -150,9 +156,11 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 		for (int p = 0; p < ldv.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_vplanes.as<uint8_t>() + (size_t)p * vc, vc, INIT_ONES });
 		for (int p = 0; p < ldf.nplanes; ++p) planes.push_back(PlaneRef{ cx.d_fplanes.as<uint8_t>() + (size_t)p * fc, fc, INIT_ONES });
 	}
+	// general bindings: which record every element names is settled on the host, the residuals of the records coded as data are
+	// computed by general.hip; the planes join the list like any other (kernels are enqueued here, behind the uploads above)
+	if (m.general) general_planes_encode(cx, m, w, planes);
 	std::vector<uint32_t> kind_tabs;
-	uint32_t kind_totals[INIT_KINDS];
-	build_inits(m, kind_tabs, kind_totals);
+	build_init_tables(m, kind_tabs);
 	const uint32_t CHC = std::min(CH, std::max(CH / 8, 512u));
 	const uint32_t npl = (uint32_t)planes.size();
 	// slices of the planes for the histogram pass
@@ -170,10 +178,12 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	// ---- device: prediction + residuals + planes, then the planes' histograms
 	ConnView cv = cx.conn_view();
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
-	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m.nv * 4, cx.stream));
-	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
-	launch_predict_vtx(cx.stream, cv, cx.d_order_v.as<uint32_t>(), vc, cx.d_rank.as<uint32_t>(), cx.d_rec[1].as<uint8_t>(), ldv, cx.d_vplanes.as<uint8_t>());
-	launch_face_planes(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, cx.d_rec[0].as<uint8_t>(), ldf, cx.d_fplanes.as<uint8_t>());
+	if (!m.general) {
+		HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m.nv * 4, cx.stream));
+		launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
+		launch_predict_vtx(cx.stream, cv, cx.d_order_v.as<uint32_t>(), vc, cx.d_rank.as<uint32_t>(), cx.d_rec[1].as<uint8_t>(), ldv, cx.d_vplanes.as<uint8_t>());
+		launch_face_planes(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, cx.d_rec[0].as<uint8_t>(), ldf, cx.d_fplanes.as<uint8_t>());
+	}
 	{
 		size_t poff = 0;
 		for (int g = 0; g < G_COUNT; ++g) {

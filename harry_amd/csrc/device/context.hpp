@@ -103,6 +103,30 @@ struct Context {
 	float elapsed(int a, int b);
 };
 
+// ---- planes of the chunked container (chunked.cpp, unchunk.cpp, general.cpp)
+// initial counts of a plane that carries no static prior (the reference's initial model of that context, models.h:197-218)
+enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_REGV = 5, INIT_REGF = 6, INIT_TYPE2 = 7, INIT_TYPE3 = 8, INIT_KINDS = 9 };
+void build_init_tables(const Mesh &m, std::vector<uint32_t> &tabs);   // INIT_KINDS x 256
+struct PlaneRef { const uint8_t *dptr; uint32_t n; int init; };
+// general bindings: the attribute planes that follow the 21 connectivity planes, in container order (the oracle restates it):
+// the region of every vertex / face (low byte; only with more than one region), then per list a region binds, in list order:
+// the kind of every reference, the creation-order distances (4 planes), at corner lists the per-vertex distances (2 planes),
+// the residual bytes of the records coded as data
+enum { GP_REGV = 0, GP_REGF, GP_TYPE, GP_GHIST, GP_LHIST, GP_DATA };
+struct GenPlane { int what, list, byte, init; };
+std::vector<GenPlane> general_plane_layout(const Mesh &m);
+// encode: collects the references on the host, computes the residuals on the device, returns the planes (device pointers into
+// cx.d_gen) in layout order; order_v / order_f / repaired twins must be resident (d_order_v, d_order_f, d_twin)
+void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vector<PlaneRef> &planes);
+// decode: the decoded planes (device, plane k at d_syms + plane_off[k], nsym[k] symbols; first = index of the first attribute
+// plane) -> bindings + records of m
+void general_planes_decode(Context &cx, Mesh &m, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+                           const std::vector<uint32_t> &seg_level, const uint8_t *d_syms, const std::vector<uint64_t> &plane_off,
+                           const std::vector<uint32_t> &nsym, uint32_t first);
+
+void check_general(const Mesh &m);             // general.cpp
+void upload_general(Context &cx, Mesh &m);     // connectivity + every list + the binding tables -> HBM
+
 // codec entry points (codec.cpp / chunked.cpp)
 void device_bounds(Context &cx, Mesh &m);
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);

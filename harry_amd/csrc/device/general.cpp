@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 #include "codec_math.hpp"
 #include "context.hpp"
@@ -46,7 +47,7 @@ void launch_gen_chain(hipStream_t st, int kind, int stype, const ConnView &cv, c
 void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
 }
 bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
-                                  const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes);   // unchunk.cpp
+                                  const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes, const uint8_t *d_vplanes = nullptr);   // unchunk.cpp
 
 void check_general(const Mesh &m)
 {
@@ -415,6 +416,82 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	cx.timing.total_ms = ms_since(t_all);
 }
 
+// Device part of a decode with general bindings: connectivity, bindings and the lists (holding residual codes in record layout,
+// or -- chunked container -- zeros, the codes being scattered from the decoded planes by `fill`) go up; every list with records
+// to reconstruct gets its source table and its chains.  ev[l] empty: the list is final already (vertex fast path) or has no records.
+static void reconstruct_general(Context &cx, Mesh &m, const std::vector<uint32_t> &order_v, const std::vector<GenRecordEvents> &ev,
+                                const std::function<void()> &fill)
+{
+	auto t_h2d = Clock::now();
+	upload_general(cx, m);   // connectivity, bindings, and the residual codes in record layout
+	if (fill) fill();
+	const uint32_t vc = (uint32_t)order_v.size();
+	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
+	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
+	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
+	Arena A;
+	const size_t nl = m.lists.size();
+	std::vector<size_t> he_at(nl), slot_at(nl), src_at(nl), nsrc_at(nl);
+	for (size_t l = 0; l < nl; ++l) { he_at[l] = A.add(ev[l].he); slot_at[l] = A.add(ev[l].slot); }
+	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
+	for (size_t l = 0; l < nl; ++l) {
+		if (m.lists[l].target != 1 && m.lists[l].target != 2) continue;
+		const size_t nd = ev[l].he.size();
+		src_at[l] = arena_bytes; arena_bytes += (nd * kSrcCap * 4 + 15) & ~(size_t)15;
+		nsrc_at[l] = arena_bytes; arena_bytes += (nd + 15) & ~(size_t)15;
+	}
+	const size_t jobs_at = arena_bytes;
+	size_t max_jobs = 0;
+	for (const AttrList &L : m.lists) max_jobs += (size_t)L.ncomp();
+	arena_bytes += (max_jobs + 1) * sizeof(GenChainJob);
+	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
+	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
+	uint8_t *arena = cx.d_gen.as<uint8_t>();
+	std::vector<GenChainJob> jobs, lead;   // lead: one per list (the source table is per record)
+	for (size_t l = 0; l < nl; ++l) {
+		const AttrList &L = m.lists[l];
+		const uint32_t nd = (uint32_t)ev[l].he.size();
+		if (!nd || !L.ncomp() || (L.target != 1 && L.target != 2)) continue;
+		GenChainJob j{};
+		j.kind = L.target == 1 ? 0 : 1; j.n = nd; j.rec = cx.d_rec[l].as<uint8_t>();
+		j.src = (const uint32_t*)(arena + src_at[l]); j.nsrc = arena + nsrc_at[l];
+		j.ev_he = (const uint32_t*)(arena + he_at[l]); j.ev_slot = arena + slot_at[l];
+		j.ld = make_list_desc(L);
+		lead.push_back(j);
+		for (int c = 0; c < L.ncomp(); ++c) { j.comp = c; jobs.push_back(j); }   // the components of a record are predicted independently
+	}
+	// one launch per kind and storage type (the kernel is instantiated for each); inside a launch every job has its own wavefront
+	std::stable_sort(jobs.begin(), jobs.end(), [](const GenChainJob &a, const GenChainJob &b) {
+		return std::make_pair(a.kind, (int)a.ld.stype[a.comp]) < std::make_pair(b.kind, (int)b.ld.stype[b.comp]); });
+	if (!jobs.empty()) HIP_OK(hipMemcpyAsync(arena + jobs_at, jobs.data(), jobs.size() * sizeof(GenChainJob), hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.h2d_ms = ms_since(t_h2d);
+
+	ConnView cv = cx.conn_view();
+	const GenView gv = gen_view(cx, m);
+	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
+	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m.nv * 4, cx.stream));
+	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
+	for (const GenChainJob &j : lead)
+		launch_gen_sources(cx.stream, j.kind, cv, gv, cx.d_rank.as<uint32_t>(), j.ev_he, j.ev_slot, j.n, const_cast<uint32_t*>(j.src), const_cast<uint8_t*>(j.nsrc));
+	for (size_t l = 0; l < nl; ++l) {   // face lists: no prediction (attrcode.h:245-270)
+		const AttrList &L = m.lists[l];
+		if (L.target == 0 && L.ncomp() && !ev[l].he.empty()) launch_faces_unfold(cx.stream, (uint32_t)ev[l].he.size(), make_list_desc(L), cx.d_rec[l].as<uint8_t>());
+	}
+	HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
+	for (size_t a = 0; a < jobs.size();) {
+		size_t e = a + 1;
+		while (e < jobs.size() && jobs[e].kind == jobs[a].kind && jobs[e].ld.stype[jobs[e].comp] == jobs[a].ld.stype[jobs[a].comp]) ++e;
+		launch_gen_chain(cx.stream, jobs[a].kind, jobs[a].ld.stype[jobs[a].comp], cv, gv, cx.d_rank.as<uint32_t>(), (const GenChainJob*)(arena + jobs_at) + a, (uint32_t)(e - a));
+		a = e;
+	}
+	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	for (size_t l = 0; l < nl; ++l)
+		if (!m.lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m.lists[l].data.data(), cx.d_rec[l].p, m.lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.timing.k_chain_ms = cx.elapsed(7, 4);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
 {
@@ -440,80 +517,151 @@ Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		if (reconstruct_vertex_list_fast(cx, *m, fast_l, order_v, seg_start, seg_level, vplanes)) { ev[fast_l].he.clear(); ev[fast_l].slot.clear(); fast_ms = cx.elapsed(3, 4); }
 	}
 
-	auto t_h2d = Clock::now();
-	upload_general(cx, *m);   // connectivity, bindings, and the residual codes in record layout
-	const uint32_t vc = (uint32_t)order_v.size();
-	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
-	cx.d_rank.ensure(std::max<size_t>((size_t)m->nv * 4, 16));
-	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
-	Arena A;
-	const size_t nl = m->lists.size();
-	std::vector<size_t> he_at(nl), slot_at(nl), src_at(nl), nsrc_at(nl);
-	for (size_t l = 0; l < nl; ++l) { he_at[l] = A.add(ev[l].he); slot_at[l] = A.add(ev[l].slot); }
-	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
-	for (size_t l = 0; l < nl; ++l) {
-		if (m->lists[l].target != 1 && m->lists[l].target != 2) continue;
-		const size_t nd = ev[l].he.size();
-		src_at[l] = arena_bytes; arena_bytes += (nd * kSrcCap * 4 + 15) & ~(size_t)15;
-		nsrc_at[l] = arena_bytes; arena_bytes += (nd + 15) & ~(size_t)15;
-	}
-	const size_t jobs_at = arena_bytes;
-	size_t max_jobs = 0;
-	for (const AttrList &L : m->lists) max_jobs += (size_t)L.ncomp();
-	arena_bytes += (max_jobs + 1) * sizeof(GenChainJob);
-	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
-	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
-	uint8_t *arena = cx.d_gen.as<uint8_t>();
-	std::vector<GenChainJob> jobs, lead;   // lead: one per list (the source table is per record)
-	for (size_t l = 0; l < nl; ++l) {
-		const AttrList &L = m->lists[l];
-		const uint32_t nd = (uint32_t)ev[l].he.size();
-		if (!nd || !L.ncomp() || (L.target != 1 && L.target != 2)) continue;
-		GenChainJob j{};
-		j.kind = L.target == 1 ? 0 : 1; j.n = nd; j.rec = cx.d_rec[l].as<uint8_t>();
-		j.src = (const uint32_t*)(arena + src_at[l]); j.nsrc = arena + nsrc_at[l];
-		j.ev_he = (const uint32_t*)(arena + he_at[l]); j.ev_slot = arena + slot_at[l];
-		j.ld = make_list_desc(L);
-		lead.push_back(j);
-		for (int c = 0; c < L.ncomp(); ++c) { j.comp = c; jobs.push_back(j); }   // the components of a record are predicted independently
-	}
-	// one launch per kind and storage type (the kernel is instantiated for each); inside a launch every job has its own wavefront
-	std::stable_sort(jobs.begin(), jobs.end(), [](const GenChainJob &a, const GenChainJob &b) {
-		return std::make_pair(a.kind, (int)a.ld.stype[a.comp]) < std::make_pair(b.kind, (int)b.ld.stype[b.comp]); });
-	if (!jobs.empty()) HIP_OK(hipMemcpyAsync(arena + jobs_at, jobs.data(), jobs.size() * sizeof(GenChainJob), hipMemcpyHostToDevice, cx.stream));
-	HIP_OK(hipStreamSynchronize(cx.stream));
-	cx.timing.h2d_ms = ms_since(t_h2d);
-
-	ConnView cv = cx.conn_view();
-	const GenView gv = gen_view(cx, *m);
-	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
-	HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m->nv * 4, cx.stream));
-	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
-	for (const GenChainJob &j : lead)
-		launch_gen_sources(cx.stream, j.kind, cv, gv, cx.d_rank.as<uint32_t>(), j.ev_he, j.ev_slot, j.n, const_cast<uint32_t*>(j.src), const_cast<uint8_t*>(j.nsrc));
-	for (size_t l = 0; l < nl; ++l) {   // face lists: no prediction (attrcode.h:245-270)
-		const AttrList &L = m->lists[l];
-		if (L.target == 0 && L.ncomp() && !ev[l].he.empty()) launch_faces_unfold(cx.stream, (uint32_t)ev[l].he.size(), make_list_desc(L), cx.d_rec[l].as<uint8_t>());
-	}
-	HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
-	for (size_t a = 0; a < jobs.size();) {
-		size_t e = a + 1;
-		while (e < jobs.size() && jobs[e].kind == jobs[a].kind && jobs[e].ld.stype[jobs[e].comp] == jobs[a].ld.stype[jobs[a].comp]) ++e;
-		launch_gen_chain(cx.stream, jobs[a].kind, jobs[a].ld.stype[jobs[a].comp], cv, gv, cx.d_rank.as<uint32_t>(), (const GenChainJob*)(arena + jobs_at) + a, (uint32_t)(e - a));
-		a = e;
-	}
-	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
-	for (size_t l = 0; l < nl; ++l)
-		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
-	HIP_OK(hipStreamSynchronize(cx.stream));
-	cx.timing.k_chain_ms = cx.elapsed(7, 4);
-	(void)fast_ms;
+	reconstruct_general(cx, *m, order_v, ev, nullptr);
 	cx.timing.k_predict_ms = cx.elapsed(3, 4) + fast_ms;
 	cx.timing.device_ms = cx.timing.k_predict_ms;
 	cx.timing.payload_bytes = n - hdr;
 	cx.timing.total_ms = ms_since(t_all);
 	m->device_token = 0;
 	return m.release();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// chunked container (.hry v0.2) with general bindings
+// ---------------------------------------------------------------------------------------------------------
+std::vector<GenPlane> general_plane_layout(const Mesh &m)
+{
+	std::vector<GenPlane> p;
+	if (m.bind.nregs_vtx() > 1) p.push_back(GenPlane{ GP_REGV, -1, 0, INIT_REGV });
+	if (m.bind.nregs_face() > 1) p.push_back(GenPlane{ GP_REGF, -1, 0, INIT_REGF });
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		const AttrList &L = m.lists[l];
+		if (L.target == 3) continue;
+		p.push_back(GenPlane{ GP_TYPE, (int)l, 0, L.target == 2 ? INIT_TYPE3 : INIT_TYPE2 });
+		for (int k = 0; k < 4; ++k) p.push_back(GenPlane{ GP_GHIST, (int)l, k, INIT_ONES });
+		if (L.target == 2) for (int k = 0; k < 2; ++k) p.push_back(GenPlane{ GP_LHIST, (int)l, k, INIT_ONES });
+		for (int k = 0; k < L.coded_bytes(); ++k) p.push_back(GenPlane{ GP_DATA, (int)l, k, INIT_ONES });
+	}
+	return p;
+}
+
+void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vector<PlaneRef> &planes)
+{
+	Events E;
+	collect_events(m, w, 0, E);
+	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
+	Arena A;
+	struct At { size_t type_sym, gh, lh, d_idx, d_he, d_slot, planes; };
+	std::vector<At> at(m.lists.size());
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		const ListStream &S = E.ls[l];
+		At &T = at[l];
+		T.type_sym = A.add(S.type_sym);
+		std::vector<uint8_t> pl(S.gh_val.size() * 4);
+		for (size_t i = 0; i < S.gh_val.size(); ++i) for (int k = 0; k < 4; ++k) pl[(size_t)k * S.gh_val.size() + i] = (uint8_t)(S.gh_val[i] >> (8 * k));
+		T.gh = A.add(pl);
+		pl.assign(S.lh_val.size() * 2, 0);
+		for (size_t i = 0; i < S.lh_val.size(); ++i) for (int k = 0; k < 2; ++k) pl[(size_t)k * S.lh_val.size() + i] = (uint8_t)(S.lh_val[i] >> (8 * k));
+		T.lh = A.add(pl);
+		T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
+	}
+	const size_t rv = A.add(E.rv_sym), rf = A.add(E.rf_sym);
+	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
+	for (size_t l = 0; l < m.lists.size(); ++l) { at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_idx.size() * E.ls[l].nbytes + 15) & ~(size_t)15; }
+	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
+	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
+	HIP_OK(hipStreamSynchronize(cx.stream));   // (the arena's host copy goes out of scope)
+	uint8_t *arena = cx.d_gen.as<uint8_t>();
+	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4 + (size_t)m.nf * 4, 16));
+	uint32_t *d_rank = cx.d_rank.as<uint32_t>(), *d_frank = d_rank + m.nv;
+	ConnView cv = cx.conn_view();
+	const GenView gv = gen_view(cx, m);
+	HIP_OK(hipMemsetAsync(d_rank, 0xff, (size_t)m.nv * 4, cx.stream));
+	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, d_rank);
+	launch_face_rank(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, d_frank);
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		const ListStream &S = E.ls[l];
+		const At &T = at[l];
+		const uint32_t nd = (uint32_t)S.d_idx.size();
+		if (!nd || !S.nbytes) continue;
+		const ListDesc ld = make_list_desc(m.lists[l]);
+		const uint32_t *he = (const uint32_t*)(arena + T.d_he), *idx = (const uint32_t*)(arena + T.d_idx);
+		const uint8_t *slot = arena + T.d_slot;
+		const uint8_t *rec = cx.d_rec[l].as<uint8_t>();
+		if (m.lists[l].target == 1) launch_gen_vtx_resid(cx.stream, cv, gv, d_rank, he, slot, idx, nd, rec, ld, arena + T.planes);
+		else if (m.lists[l].target == 2) launch_gen_corner_resid(cx.stream, cv, gv, d_frank, he, slot, idx, nd, rec, ld, arena + T.planes);
+		else launch_gen_face_resid(cx.stream, idx, nd, rec, ld, arena + T.planes);
+	}
+	for (const GenPlane &g : general_plane_layout(m)) {
+		const ListStream *S = g.list >= 0 ? &E.ls[g.list] : nullptr;
+		const At *T = g.list >= 0 ? &at[g.list] : nullptr;
+		switch (g.what) {
+		case GP_REGV: planes.push_back(PlaneRef{ arena + rv, (uint32_t)E.rv_sym.size(), g.init }); break;
+		case GP_REGF: planes.push_back(PlaneRef{ arena + rf, (uint32_t)E.rf_sym.size(), g.init }); break;
+		case GP_TYPE: planes.push_back(PlaneRef{ arena + T->type_sym, (uint32_t)S->type_sym.size(), g.init }); break;
+		case GP_GHIST: planes.push_back(PlaneRef{ arena + T->gh + (size_t)g.byte * S->gh_val.size(), (uint32_t)S->gh_val.size(), g.init }); break;
+		case GP_LHIST: planes.push_back(PlaneRef{ arena + T->lh + (size_t)g.byte * S->lh_val.size(), (uint32_t)S->lh_val.size(), g.init }); break;
+		default: planes.push_back(PlaneRef{ arena + T->planes + (size_t)g.byte * S->d_idx.size(), (uint32_t)S->d_idx.size(), g.init }); break;
+		}
+	}
+}
+
+namespace dev { void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, const ListDesc &ld, uint8_t *rec); }
+
+void general_planes_decode(Context &cx, Mesh &m, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+                           const std::vector<uint32_t> &seg_level, const uint8_t *d_syms, const std::vector<uint64_t> &plane_off,
+                           const std::vector<uint32_t> &nsym, uint32_t first)
+{
+	const std::vector<GenPlane> layout = general_plane_layout(m);
+	// the planes that say which record every element names come down; the residual bytes stay where they are
+	std::vector<std::vector<uint8_t>> host(layout.size());
+	for (size_t q = 0; q < layout.size(); ++q) {
+		if (layout[q].what == GP_DATA) continue;
+		host[q].resize(nsym[first + q]);
+		if (!host[q].empty()) HIP_OK(hipMemcpyAsync(host[q].data(), d_syms + plane_off[first + q], host[q].size(), hipMemcpyDeviceToHost, cx.stream));
+	}
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	GenHostPlanes hp;
+	hp.lists.resize(m.lists.size());
+	std::vector<size_t> data_plane0(m.lists.size(), 0);
+	for (size_t q = 0; q < layout.size(); ++q) {
+		const GenPlane &g = layout[q];
+		const uint32_t n = nsym[first + q];
+		switch (g.what) {
+		case GP_REGV: hp.regv = host[q].data(); hp.n_regv = n; if (!hp.regv) hp.regv = (const uint8_t*)""; break;
+		case GP_REGF: hp.regf = host[q].data(); hp.n_regf = n; if (!hp.regf) hp.regf = (const uint8_t*)""; break;
+		case GP_TYPE: hp.lists[g.list].type = host[q].data(); hp.lists[g.list].n_type = n; break;
+		case GP_GHIST:
+			if (g.byte && n != hp.lists[g.list].n_gh) throw Error(HRY_E_FORMAT, "history planes of different length");
+			hp.lists[g.list].gh[g.byte] = host[q].data(); hp.lists[g.list].n_gh = n; break;
+		case GP_LHIST:
+			if (g.byte && n != hp.lists[g.list].n_lh) throw Error(HRY_E_FORMAT, "history planes of different length");
+			hp.lists[g.list].lh[g.byte] = host[q].data(); hp.lists[g.list].n_lh = n; break;
+		default:
+			if (g.byte == 0) { data_plane0[g.list] = first + q; hp.lists[g.list].n_data = n; }
+			else if (n != hp.lists[g.list].n_data) throw Error(HRY_E_FORMAT, "residual planes of different length");
+			break;
+		}
+	}
+	std::vector<GenRecordEvents> ev;
+	read_general_planes(m, order_v, hp, ev);
+	// a list without coded bytes still creates records
+	// vertex lists in which every vertex owns a record take the PLY layout's chains, straight from the decoded planes
+	if (m.bind.nregs_vtx() == 1 && m.bind.nvtxlists(0) == 1 && !getenv("HRY_GENERIC_VERTEX") && !order_v.empty()) {
+		const int l = m.bind.vtxlist(0, 0);
+		if (ev[l].he.size() == order_v.size() && m.lists[l].coded_bytes() > 0 &&
+		    reconstruct_vertex_list_fast(cx, m, l, order_v, seg_start, seg_level, std::vector<uint8_t>(), d_syms + plane_off[data_plane0[l]])) {
+			ev[l].he.clear(); ev[l].slot.clear();
+		}
+	}
+	reconstruct_general(cx, m, order_v, ev, [&] {
+		for (size_t l = 0; l < m.lists.size(); ++l) {
+			const uint32_t nd = (uint32_t)ev[l].he.size();
+			if (!nd || !m.lists[l].coded_bytes()) continue;
+			launch_residuals_to_rec(cx.stream, d_syms + plane_off[data_plane0[l]], nd, make_list_desc(m.lists[l]), cx.d_rec[l].as<uint8_t>());
+		}
+	});
 }
 
 }   // namespace hry

@@ -45,7 +45,6 @@ void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint3
 uint32_t chain_timeout_flags(hipStream_t st);
 }
 
-enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_KINDS = 5 };
 static const int kConnPlanes = 21;
 
 static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0 : i == 12 ? INIT_NT1 : i >= 13 ? INIT_OP : INIT_ONES; }
@@ -386,10 +385,13 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	auto t_all = Clock::now();
 	g_t0 = t_all;
 	cx.timing = hry_timing{};
-	const ListDesc ldv = make_list_desc(m->lists[1]), ldf = make_list_desc(m->lists[0]);
-	for (int l = 0; l < 2; ++l)
-		for (int c = 0; c < m->lists[l].ncomp(); ++c)
-			if (m->lists[l].stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
+	const ListDesc ldv = m->general ? ListDesc{} : make_list_desc(m->lists[1]), ldf = m->general ? ListDesc{} : make_list_desc(m->lists[0]);
+	if (m->lists.size() > (size_t)kMaxLists) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
+	for (const AttrList &L : m->lists)
+		for (int c = 0; c < L.ncomp(); ++c) {
+			if (L.stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
+			if (m->general && kTypeSize[L.stype(c)] == 8) throw Error(HRY_E_UNSUPPORTED, "8-byte storage types are outside the supported subset");
+		}
 	// ---- directory
 	auto need = [&](size_t off, size_t k) { if (off + k > n) throw Error(HRY_E_FORMAT, "truncated chunked directory"); };
 	size_t off = hdr;
@@ -397,7 +399,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	uint32_t CH, CHC, np;
 	memcpy(&CH, p + off, 4); memcpy(&CHC, p + off + 4, 4); memcpy(&np, p + off + 8, 4);
 	off += 12;
-	const uint32_t expect_planes = (uint32_t)(kConnPlanes + ldv.nplanes + ldf.nplanes);
+	const std::vector<GenPlane> gen_layout = m->general ? general_plane_layout(*m) : std::vector<GenPlane>();
+	const uint32_t expect_planes = (uint32_t)(kConnPlanes + (m->general ? (int)gen_layout.size() : ldv.nplanes + ldf.nplanes));
 	if (CH == 0 || CHC == 0 || CH > (1u << 20) || CHC > CH || np != expect_planes) throw Error(HRY_E_FORMAT, "chunked directory does not match the header");
 	need(off, 4ull * np);
 	std::vector<uint32_t> nsym(np);
@@ -445,24 +448,29 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	const uint8_t *payload = p + off;
 	const uint64_t payload_bytes = offs[nstreams];
 	// plausibility of the plane sizes against the header: at most one vertex / face record per element
-	const uint32_t vc = ldv.nplanes ? nsym[kConnPlanes] : 0;
-	for (int q = 0; q < ldv.nplanes; ++q) if (nsym[kConnPlanes + q] != vc) throw Error(HRY_E_FORMAT, "vertex planes of different length");
-	for (int q = 0; q < ldf.nplanes; ++q) if (nsym[kConnPlanes + ldv.nplanes + q] != m->nf) throw Error(HRY_E_FORMAT, "face planes of wrong length");
-	if (vc > m->nv) throw Error(HRY_E_FORMAT, "more coded vertices than vertices");
+	const uint32_t vc = !m->general && ldv.nplanes ? nsym[kConnPlanes] : 0;
+	if (!m->general) {
+		for (int q = 0; q < ldv.nplanes; ++q) if (nsym[kConnPlanes + q] != vc) throw Error(HRY_E_FORMAT, "vertex planes of different length");
+		for (int q = 0; q < ldf.nplanes; ++q) if (nsym[kConnPlanes + ldv.nplanes + q] != m->nf) throw Error(HRY_E_FORMAT, "face planes of wrong length");
+		if (vc > m->nv) throw Error(HRY_E_FORMAT, "more coded vertices than vertices");
+	} else {
+		// at most one reference per vertex / face / corner slot, at most one record per reference
+		const uint64_t most = (uint64_t)m->nv * m->bind.nb_vtx + (uint64_t)m->nf * m->bind.nb_face + (uint64_t)m->declared_ne * m->bind.nb_corner + 16;
+		for (size_t q = 0; q < gen_layout.size(); ++q) {
+			if (nsym[kConnPlanes + q] > most) throw Error(HRY_E_FORMAT, "implausible plane length");
+			if (gen_layout[q].what == GP_DATA && nsym[kConnPlanes + q] > m->lists[gen_layout[q].list].count) throw Error(HRY_E_FORMAT, "more records than the header announces");
+		}
+	}
 	if (total_syms > (1ull << 33)) throw Error(HRY_E_FORMAT, "implausible symbol count");
 
 	// ---- model tables: one per plane (its prior, or the reference's initial counts of its kind)
-	std::vector<uint32_t> kind_tabs((size_t)INIT_KINDS * 256, 0);
-	for (int i = 0; i < 256; ++i) kind_tabs[INIT_ONES * 256 + i] = 1;
-	for (int i = 0; i < 9; ++i) kind_tabs[INIT_IOP * 256 + i] = 1;
-	for (size_t d = 3; d < m->have_degree.size(); ++d)
-		if (m->have_degree[d]) { ++kind_tabs[INIT_NT0 * 256 + ((d - 2) & 0xff)]; ++kind_tabs[INIT_NT1 * 256 + ((d - 2) >> 8)]; }
-	for (int i = 0; i < 7; ++i) kind_tabs[INIT_OP * 256 + i] = 1;
+	std::vector<uint32_t> kind_tabs;
+	build_init_tables(*m, kind_tabs);
 	std::vector<uint32_t> tabs((size_t)np * 256, 0);
 	std::vector<uint32_t> totals(np, 0);
 	uint32_t max_t0 = 256;
 	for (uint32_t k = 0; k < np; ++k) {
-		const int kind = k < (uint32_t)kConnPlanes ? conn_init_kind((int)k) : INIT_ONES;
+		const int kind = k < (uint32_t)kConnPlanes ? conn_init_kind((int)k) : m->general ? gen_layout[k - kConnPlanes].init : INIT_ONES;
 		memcpy(tabs.data() + (size_t)k * 256, has_prior[k] ? prior.data() + (size_t)k * 256 : kind_tabs.data() + (size_t)kind * 256, 1024);
 		uint64_t t = 0;
 		for (int i = 0; i < 256; ++i) t += tabs[(size_t)k * 256 + i];
@@ -519,7 +527,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// -- the critical path -- waits for exactly those
 	// ... unless the mesh takes the pipelined decode (one large component, triangles replayed at ~6 ns each): there the device
 	// chain, not the replay, ends the decode, and it can start only when the attribute streams are done -- side by side then
-	const bool chain_bound = restarts.empty() && nsym[7] == 0 && vc == m->nv && unpredict3_covers(ldv);
+	const bool chain_bound = !m->general && restarts.empty() && nsym[7] == 0 && vc == m->nv && unpredict3_covers(ldv);
 	const bool side_by_side = getenv("HRY_ATTR_SIDE_BY_SIDE") ? atoi(getenv("HRY_ATTR_SIDE_BY_SIDE")) != 0 : chain_bound;
 	HIP_OK(hipStreamWaitEvent(cx.stream3, side_by_side ? cx.ev_x[0] : cx.ev[2], 0));
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
@@ -541,7 +549,12 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	auto t_walk = Clock::now();
 	std::vector<uint32_t> order_v, seg_start, seg_level;
 	bool pipelined = false;
-	if (pipelined_decode_applicable(*m, restarts, conn, ldv, vc)) {
+	if (m->general) {
+		cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
+		cx.timing.host_walk_ms = ms_since(t_walk);
+		HRY_MARK(g_t0, "replay done");
+		general_planes_decode(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>(), plane_off, nsym, (uint32_t)kConnPlanes);
+	} else if (pipelined_decode_applicable(*m, restarts, conn, ldv, vc)) {
 		pipelined = true;
 		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v);
 		cx.timing.host_walk_ms = cx.timing.host_walk_ms - std::chrono::duration<double, std::milli>(t_walk - g_t0).count();
@@ -715,7 +728,7 @@ Mesh *decode_sharded(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 // layout in everything that matters to the reconstruction chains (record i belongs to the i-th coded vertex, candidates are the
 // parallelograms of the fan), so it takes them.  The mesh lends its connectivity and the list for the duration of the call.
 bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
-                                  const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes)
+                                  const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes, const uint8_t *d_vplanes)
 {
 	const ListDesc ldv = make_list_desc(m.lists[l]);
 	if (!ldv.nplanes || !unpredict2_applicable(ldv) || m.lists[l].count < order_v.size()) return false;
@@ -727,10 +740,13 @@ bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector
 		Mesh &m, &t; int l;
 		~Back() { t.face_off.swap(m.face_off); t.org.swap(m.org); t.twin.swap(m.twin); std::swap(t.lists[1], m.lists[l]); }
 	} back{ m, t, l };
-	cx.d_csyms.ensure(std::max<size_t>(vplanes.size() + 64, 16));
-	if (!vplanes.empty()) HIP_OK(hipMemcpyAsync(cx.d_csyms.p, vplanes.data(), vplanes.size(), hipMemcpyHostToDevice, cx.stream));
-	HIP_OK(hipStreamSynchronize(cx.stream));
-	reconstruct_attributes(cx, t, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>(), nullptr, ldv, make_list_desc(t.lists[0]));
+	if (!d_vplanes) {   // planes from the host (reference stream); a chunked container's are in HBM already
+		cx.d_csyms.ensure(std::max<size_t>(vplanes.size() + 64, 16));
+		if (!vplanes.empty()) HIP_OK(hipMemcpyAsync(cx.d_csyms.p, vplanes.data(), vplanes.size(), hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		d_vplanes = cx.d_csyms.as<uint8_t>();
+	}
+	reconstruct_attributes(cx, t, order_v, seg_start, seg_level, d_vplanes, nullptr, ldv, make_list_desc(t.lists[0]));
 	return true;
 }
 

@@ -165,29 +165,21 @@ void read_list(Live &lv, const AttrList &L, bool corner_list, uint32_t count, st
 // attribute symbols with general bindings (attrcode.h:443-531): per vertex its region and one record reference per list of the
 // region; per face its region, its face lists, then every corner's lists.  A reference is DATA (a new record: its residual bytes
 // follow), HIST (a record created earlier, by distance in creation order) or, at corners, LHIST (a record already named at this
-// vertex, by distance in the vertex' own list of names).  Pure integer bookkeeping next to the serial entropy decoder; the
-// residual bytes go to the device.
-struct GeneralReader {
+// vertex, by distance in the vertex' own list of names).  Pure integer bookkeeping along the coding order; the residual bytes
+// go to the device.  SRC says where the symbols come from: the live arithmetic decoder of a reference stream, or the decoded
+// planes of a chunked container.
+struct LiveSource {
 	Live &lv;
 	Mesh &m;
-	Bindings &b;
-	struct PerList { Table t_type, t_ghist[4], t_lhist[2]; std::vector<Table> t_data; std::vector<int> byte_at; uint32_t created = 0; };
+	struct PerList { Table t_type, t_ghist[4], t_lhist[2]; std::vector<Table> t_data; std::vector<int> byte_at; };
 	std::vector<PerList> pl;
 	Table t_regface[2], t_regvtx[2];
-	std::vector<GenRecordEvents> &ev;
-	// per corner slot and vertex: the records named there so far, newest first
-	struct Node { uint32_t idx, next; };
-	std::vector<Node> pool;
-	std::vector<std::vector<uint32_t>> head;
-	static constexpr uint32_t NONE = 0xffffffffu;
-
 	int plane_list = -1;                 // this list's residual bytes also go to `planes`, plane-major with plane_count records per plane
 	uint32_t plane_count = 0;
 	std::vector<uint8_t> *planes = nullptr;
-
-	GeneralReader(Live &l, Mesh &mesh, std::vector<GenRecordEvents> &events) : lv(l), m(mesh), b(mesh.bind), pl(mesh.lists.size()), ev(events)
+	LiveSource(Live &l, Mesh &mesh) : lv(l), m(mesh), pl(mesh.lists.size())
 	{
-		ev.assign(m.lists.size(), GenRecordEvents());
+		const Bindings &b = m.bind;
 		for (size_t i = 0; i < m.lists.size(); ++i) {
 			const AttrList &L = m.lists[i];
 			PerList &P = pl[i];
@@ -202,37 +194,92 @@ struct GeneralReader {
 		}
 		for (int r = 0; r < b.nregs_face(); ++r) { t_regface[0].add((uint32_t)r & 0xff, 1); t_regface[1].add((uint32_t)r >> 8, 1); }   // models.h:212-217
 		for (int r = 0; r < b.nregs_vtx(); ++r) { t_regvtx[0].add((uint32_t)r & 0xff, 1); t_regvtx[1].add((uint32_t)r >> 8, 1); }
-		head.assign(b.nb_corner, std::vector<uint32_t>());
-		for (auto &h : head) h.assign(m.nv, NONE);
 	}
-	uint32_t region(Table *t, int nregs)
-	{
-		uint32_t r = lv.sym(t[0]);
-		r |= lv.sym(t[1]) << 8;
-		if ((int)r >= nregs) throw Error(HRY_E_FORMAT, "corrupt stream (region)");
-		return r;
-	}
-	uint32_t new_record(int l, uint32_t he, int slot)
+	uint32_t region(Table *t) { uint32_t r = lv.sym(t[0]); r |= lv.sym(t[1]) << 8; return r; }
+	uint32_t region_vtx() { return region(t_regvtx); }
+	uint32_t region_face() { return region(t_regface); }
+	uint32_t type(int l) { return lv.sym(pl[l].t_type); }
+	uint32_t ghist(int l) { return lv.u32(pl[l].t_ghist); }
+	uint32_t lhist(int l) { uint32_t v = lv.sym(pl[l].t_lhist[0]); v |= lv.sym(pl[l].t_lhist[1]) << 8; return v; }
+	void data(int l, uint32_t idx)
 	{
 		AttrList &L = m.lists[l];
 		PerList &P = pl[l];
-		if (P.created >= L.count) throw Error(HRY_E_FORMAT, "corrupt stream (more records than the header announces)");
-		const uint32_t idx = P.created++;
 		uint8_t *rec = L.data.data() + (size_t)idx * L.stride();
 		if (l == plane_list && idx < plane_count) {
 			uint8_t *pp = planes->data() + idx;
 			for (size_t k = 0; k < P.byte_at.size(); ++k) { const uint8_t s = (uint8_t)lv.sym(P.t_data[k]); rec[P.byte_at[k]] = s; pp[k * (size_t)plane_count] = s; }
 		} else
 			for (size_t k = 0; k < P.byte_at.size(); ++k) rec[P.byte_at[k]] = (uint8_t)lv.sym(P.t_data[k]);
+	}
+	void finish() {}
+};
+
+struct PlaneSource {
+	const GenHostPlanes &hp;
+	uint32_t c_regv = 0, c_regf = 0;
+	std::vector<uint32_t> c_type, c_gh, c_lh, c_data;
+	explicit PlaneSource(const GenHostPlanes &h) : hp(h), c_type(h.lists.size(), 0), c_gh(h.lists.size(), 0), c_lh(h.lists.size(), 0), c_data(h.lists.size(), 0) {}
+	[[noreturn]] static void short_plane() { throw Error(HRY_E_FORMAT, "corrupt container (a reference plane is shorter than the mesh needs)"); }
+	uint32_t region_vtx() { if (!hp.regv) return 0; if (c_regv >= hp.n_regv) short_plane(); return hp.regv[c_regv++]; }
+	uint32_t region_face() { if (!hp.regf) return 0; if (c_regf >= hp.n_regf) short_plane(); return hp.regf[c_regf++]; }
+	uint32_t type(int l) { const auto &P = hp.lists[l]; if (c_type[l] >= P.n_type) short_plane(); return P.type[c_type[l]++]; }
+	uint32_t ghist(int l)
+	{
+		const auto &P = hp.lists[l];
+		if (c_gh[l] >= P.n_gh) short_plane();
+		const uint32_t i = c_gh[l]++;
+		return (uint32_t)P.gh[0][i] | ((uint32_t)P.gh[1][i] << 8) | ((uint32_t)P.gh[2][i] << 16) | ((uint32_t)P.gh[3][i] << 24);
+	}
+	uint32_t lhist(int l)
+	{
+		const auto &P = hp.lists[l];
+		if (c_lh[l] >= P.n_lh) short_plane();
+		const uint32_t i = c_lh[l]++;
+		return (uint32_t)P.lh[0][i] | ((uint32_t)P.lh[1][i] << 8);
+	}
+	void data(int l, uint32_t) { if (c_data[l] >= hp.lists[l].n_data) short_plane(); ++c_data[l]; }   // the bytes stay on the device
+	void finish()
+	{
+		if (c_regv != hp.n_regv || c_regf != hp.n_regf) throw Error(HRY_E_FORMAT, "corrupt container (region plane longer than the mesh needs)");
+		for (size_t l = 0; l < hp.lists.size(); ++l)
+			if (c_type[l] != hp.lists[l].n_type || c_gh[l] != hp.lists[l].n_gh || c_lh[l] != hp.lists[l].n_lh || c_data[l] != hp.lists[l].n_data)
+				throw Error(HRY_E_FORMAT, "corrupt container (a reference plane is longer than the mesh needs)");
+	}
+};
+
+template <class SRC>
+struct GeneralReader {
+	SRC &src;
+	Mesh &m;
+	Bindings &b;
+	std::vector<uint32_t> created;
+	std::vector<GenRecordEvents> &ev;
+	// per corner slot and vertex: the records named there so far, newest first
+	struct Node { uint32_t idx, next; };
+	std::vector<Node> pool;
+	std::vector<std::vector<uint32_t>> head;
+	static constexpr uint32_t NONE = 0xffffffffu;
+
+	GeneralReader(SRC &s, Mesh &mesh, std::vector<GenRecordEvents> &events) : src(s), m(mesh), b(mesh.bind), created(mesh.lists.size(), 0), ev(events)
+	{
+		ev.assign(m.lists.size(), GenRecordEvents());
+		head.assign(b.nb_corner, std::vector<uint32_t>());
+		for (auto &h : head) h.assign(m.nv, NONE);
+	}
+	uint32_t new_record(int l, uint32_t he, int slot)
+	{
+		if (created[l] >= m.lists[l].count) throw Error(HRY_E_FORMAT, "corrupt stream (more records than the header announces)");
+		const uint32_t idx = created[l]++;
+		src.data(l, idx);
 		ev[l].he.push_back(he); ev[l].slot.push_back((uint8_t)slot);
 		return idx;
 	}
 	uint32_t earlier_record(int l)   // attrcode.h:463-465
 	{
-		PerList &P = pl[l];
-		uint32_t d = lv.u32(P.t_ghist);
-		if (d >= P.created) throw Error(HRY_E_FORMAT, "corrupt stream (record history)");
-		return P.created - 1 - d;
+		const uint32_t d = src.ghist(l);
+		if (d >= created[l]) throw Error(HRY_E_FORMAT, "corrupt stream (record history)");
+		return created[l] - 1 - d;
 	}
 	void remember(int a, uint32_t v, uint32_t idx) { pool.push_back(Node{ idx, head[a][v] }); head[a][v] = (uint32_t)pool.size() - 1; }
 	uint32_t named_here(int a, uint32_t v, uint32_t back)   // attrcode.h:76-79
@@ -248,11 +295,12 @@ struct GeneralReader {
 		b.corner_attr.assign((size_t)m.ne() * b.nb_corner, 0);
 		for (uint32_t e : order_v) {   // attrcode.h:443-470
 			const uint32_t v = m.org[e];
-			const int r = (int)region(t_regvtx, b.nregs_vtx());
+			const int r = (int)src.region_vtx();
+			if (r >= b.nregs_vtx()) throw Error(HRY_E_FORMAT, "corrupt stream (region)");
 			b.vtx_reg[v] = (uint16_t)r;
 			for (int a = 0; a < b.nvtxlists(r); ++a) {
 				const int l = b.vtxlist(r, a);
-				const uint32_t ty = lv.sym(pl[l].t_type);
+				const uint32_t ty = src.type(l);
 				uint32_t idx;
 				if (ty == 0) idx = new_record(l, e, a);
 				else if (ty == 1) idx = earlier_record(l);
@@ -261,11 +309,12 @@ struct GeneralReader {
 			}
 		}
 		for (uint32_t f = 0; f < m.nf; ++f) {   // attrcode.h:476-531,543-548
-			const int r = (int)region(t_regface, b.nregs_face());
+			const int r = (int)src.region_face();
+			if (r >= b.nregs_face()) throw Error(HRY_E_FORMAT, "corrupt stream (region)");
 			b.face_reg[f] = (uint16_t)r;
 			for (int a = 0; a < b.nfacelists(r); ++a) {
 				const int l = b.facelist(r, a);
-				const uint32_t ty = lv.sym(pl[l].t_type);
+				const uint32_t ty = src.type(l);
 				uint32_t idx;
 				if (ty == 0) idx = new_record(l, f, a);
 				else if (ty == 1) idx = earlier_record(l);
@@ -276,16 +325,17 @@ struct GeneralReader {
 				const uint32_t v = m.org[c];
 				for (int a = 0; a < b.ncornerlists(r); ++a) {
 					const int l = b.cornerlist(r, a);
-					const uint32_t ty = lv.sym(pl[l].t_type);
+					const uint32_t ty = src.type(l);
 					uint32_t idx;
 					if (ty == 0) { idx = new_record(l, c, a); remember(a, v, idx); }
 					else if (ty == 1) { idx = earlier_record(l); remember(a, v, idx); }
-					else if (ty == 2) { uint32_t back = lv.sym(pl[l].t_lhist[0]); back |= lv.sym(pl[l].t_lhist[1]) << 8; idx = named_here(a, v, back); }
+					else if (ty == 2) idx = named_here(a, v, src.lhist(l));
 					else throw Error(HRY_E_FORMAT, "corrupt stream (record reference type)");
 					b.corner_attr[(size_t)c * b.nb_corner + a] = idx;
 				}
 			}
 		}
+		src.finish();
 	}
 };
 
@@ -296,11 +346,20 @@ void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32
 {
 	Live lv(p, p + n, m);
 	cut_border_replay_with(m, lv, order_v, seg_start, seg_level);
-	GeneralReader gr(lv, m, events);
+	LiveSource src(lv, m);
 	if (plane_list >= 0 && plane_list < (int)m.lists.size()) {
-		gr.plane_list = plane_list; gr.plane_count = (uint32_t)order_v.size(); gr.planes = &planes;
+		src.plane_list = plane_list; src.plane_count = (uint32_t)order_v.size(); src.planes = &planes;
 		planes.assign((size_t)m.lists[plane_list].coded_bytes() * order_v.size(), 0);
 	}
+	GeneralReader<LiveSource> gr(src, m, events);
+	gr.run(order_v);
+}
+
+void read_general_planes(Mesh &m, const std::vector<uint32_t> &order_v, const GenHostPlanes &hp, std::vector<GenRecordEvents> &events)
+{
+	if (hp.lists.size() != m.lists.size()) throw Error(HRY_E_INTERNAL, "plane table does not match the lists");
+	PlaneSource src(hp);
+	GeneralReader<PlaneSource> gr(src, m, events);
 	gr.run(order_v);
 }
 

@@ -110,7 +110,7 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 	const bool ply_layout = nrf == 1 && nrv == 1 && b.nfacelists(0) == 1 && b.ncornerlists(0) == 0 && b.nvtxlists(0) == 1 &&
 	                        b.facelist(0, 0) == 0 && b.vtxlist(0, 0) == 1;
 	m.general = !ply_layout;
-	if (m.general && ver_minor != 1) throw Error(HRY_E_UNSUPPORTED, "the chunked container holds the PLY layout only (one face list, one vertex list)");
+	if (m.general && ver_minor == 3) throw Error(HRY_E_UNSUPPORTED, "the sharded container holds the PLY layout only (one face list, one vertex list)");
 	m.lists.assign(ply_layout ? 2 : target.size(), AttrList());
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		AttrList &L = m.lists[l];
@@ -148,7 +148,7 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 		L.have_bounds = true;
 	}
 	if (!m.general && (m.lists[0].count != m.nf || m.lists[1].count != m.nv)) m.general = true;   // shared records: the general decoder
-	if (m.general && ver_minor != 1) throw Error(HRY_E_UNSUPPORTED, "the chunked container holds the PLY layout only (one record per element)");
+	if (m.general && ver_minor == 3) throw Error(HRY_E_UNSUPPORTED, "the sharded container holds the PLY layout only (one record per element)");
 	if (m.general) {
 		m.bind = std::move(b);
 		if (alloc_records) {

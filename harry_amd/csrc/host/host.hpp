@@ -169,6 +169,17 @@ struct GenRecordEvents { std::vector<uint32_t> he; std::vector<uint8_t> slot; };
 void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events,
                          std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, int plane_list, std::vector<uint8_t> &planes);
 
+// the same bookkeeping over the decoded planes of a chunked container (host copies): region planes (absent with one region),
+// per list the reference kinds, the creation-order distances (4 byte planes), the per-vertex distances (2 byte planes) and the
+// number of records coded as data (their residual bytes stay on the device)
+struct GenHostPlanes {
+	const uint8_t *regv = nullptr, *regf = nullptr;
+	uint32_t n_regv = 0, n_regf = 0;
+	struct L { const uint8_t *type = nullptr, *gh[4] = { nullptr, nullptr, nullptr, nullptr }, *lh[2] = { nullptr, nullptr }; uint32_t n_type = 0, n_gh = 0, n_lh = 0, n_data = 0; };
+	std::vector<L> lists;
+};
+void read_general_planes(Mesh &m, const std::vector<uint32_t> &order_v, const GenHostPlanes &hp, std::vector<GenRecordEvents> &events);
+
 // a shard writes the sizes of the full mesh (m.shard.g_*): the header of a sharded container describes the whole
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);
 // parses the header into a mesh skeleton (lists allocated unless alloc_records is false, no connectivity); returns bytes consumed

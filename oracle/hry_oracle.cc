@@ -558,7 +558,7 @@ struct Models {
 // ------------------------------------------------------------------------------------------------
 // symbol layer (formats/hry/io.h:19-231)
 // ------------------------------------------------------------------------------------------------
-enum { REC_OP0 = 200, REC_SLOTS = 208 };   // recording slots: context id, or REC_OP0 + order class for operations
+enum { REC_OP0 = 8192, REC_SLOTS = 8200 };   // recording slots: context id, or REC_OP0 + order class for operations (above every context id)
 struct SymWriter {
 	Models &md;
 	RangeEncoder &rc;
@@ -661,9 +661,11 @@ struct SymReader {
 	uint16_t part() { uint16_t v; bytes(CTX_PART, (uint8_t*)&v, 2); return v; }
 	uint32_t vertid() { uint32_t v; bytes(CTX_VERT, (uint8_t*)&v, 4); return v; }
 	uint16_t numtri() { if (fixed_numtri >= 0) return (uint16_t)fixed_numtri; uint16_t v; bytes(CTX_NUMTRI, (uint8_t*)&v, 2); return v; }
-	uint16_t reg_face() { if (planes) return 0; uint16_t v; bytes(CTX_REGFACE, (uint8_t*)&v, 2); return v; }
-	uint16_t reg_vtx() { if (planes) return 0; uint16_t v; bytes(CTX_REGVTX, (uint8_t*)&v, 2); return v; }
-	uint8_t attr_type(int l) { if (planes) return A_DATA; return (uint8_t)sym(md.attr_base[l] + ATTR_TYPE); }
+	// chunked container: planes that carry no information are not stored (one region; the PLY layout's references are all DATA)
+	bool stored(int slot) const { return slot < (int)planes->size() && !(*planes)[slot].empty(); }
+	uint16_t reg_face() { if (planes) return stored(CTX_REGFACE) ? (uint16_t)pop(CTX_REGFACE) : 0; uint16_t v; bytes(CTX_REGFACE, (uint8_t*)&v, 2); return v; }
+	uint16_t reg_vtx() { if (planes) return stored(CTX_REGVTX) ? (uint16_t)pop(CTX_REGVTX) : 0; uint16_t v; bytes(CTX_REGVTX, (uint8_t*)&v, 2); return v; }
+	uint8_t attr_type(int l) { if (planes && !stored(md.attr_base[l] + ATTR_TYPE)) return A_DATA; return (uint8_t)sym(md.attr_base[l] + ATTR_TYPE); }
 	uint32_t attr_ghist(int l) { uint32_t v; bytes(md.attr_base[l] + ATTR_GHIST, (uint8_t*)&v, 4); return v; }
 	uint16_t attr_lhist(int l) { uint16_t v; bytes(md.attr_base[l] + ATTR_LHIST, (uint8_t*)&v, 2); return v; }
 };
@@ -1011,7 +1013,7 @@ static void read_header(ByteReader &r, Mesh &m, int want_minor = 1, uint32_t *de
 	const bool ply_layout = nrf == 1 && nrv == 1 && b.nfacelists(0) == 1 && b.ncornerlists(0) == 0 && b.nvtxlists(0) == 1 &&
 	                        b.facelist(0, 0) == 0 && b.vtxlist(0, 0) == 1;
 	if (!ply_layout) {
-		if (want_minor != 1) throw std::runtime_error("oracle: the chunked container holds the PLY layout only");
+		if (want_minor == 3) throw std::runtime_error("oracle: the sharded container holds the PLY layout only");
 		if (nrf > 128 || nrv > 128) throw std::runtime_error("oracle: more than 128 regions overflow the reference's model seeding (model.h:49-55)");
 		b.on = true;
 		b.face_reg.assign(m.nf, 0); b.vtx_reg.assign(m.nv, 0);
@@ -1780,6 +1782,23 @@ static std::vector<PlaneDef> chunked_planes(const Mesh &m, const Models &md)
 	for (int i = 0; i < 4; ++i) p.push_back({ CTX_VERT + i, 0 });
 	p.push_back({ CTX_NUMTRI, 2 }); p.push_back({ CTX_NUMTRI + 1, 3 });
 	for (int i = 0; i < 8; ++i) p.push_back({ REC_OP0 + i, 4 });
+	if (m.bind.on) {
+		// general bindings: the region of every vertex / face (low byte; only when there is more than one region), then for every
+		// list a region binds, in list order: the kind of every reference, the creation-order distances (4 bytes), at corner
+		// lists the per-vertex distances (2 bytes), and the residual bytes of the records coded as data
+		if (m.bind.nregs_vtx() > 1) p.push_back({ CTX_REGVTX, 5 });
+		if (m.bind.nregs_face() > 1) p.push_back({ CTX_REGFACE, 6 });
+		for (size_t l = 0; l < m.lists.size(); ++l) {
+			if (m.lists[l].target == TG_NONE) continue;
+			p.push_back({ md.attr_base[l] + ATTR_TYPE, m.lists[l].target == TG_CORNER ? 8 : 7 });
+			for (int b = 0; b < 4; ++b) p.push_back({ md.attr_base[l] + ATTR_GHIST + b, 0 });
+			if (m.lists[l].target == TG_CORNER) for (int b = 0; b < 2; ++b) p.push_back({ md.attr_base[l] + ATTR_LHIST + b, 0 });
+			int n = 0;
+			for (int c = 0; c < m.lists[l].fmt.size(); ++c) n += TSIZE[m.lists[l].fmt.stype[c]];
+			for (int b = 0; b < n; ++b) p.push_back({ md.attr_base[l] + ATTR_DATA + b, 0 });
+		}
+		return p;
+	}
 	for (int l : { 1, 0 }) {
 		int n = 0;
 		for (int c = 0; c < m.lists[l].fmt.size(); ++c) n += TSIZE[m.lists[l].fmt.stype[c]];
@@ -1795,6 +1814,10 @@ static void seed_table(FreqTable &f, int kind, const Mesh &m)
 	case 2: for (size_t d = 0; d < m.have_deg.size(); ++d) if (m.have_deg[d]) f.inc((uint32_t)((d - 2) & 0xff)); break;
 	case 3: for (size_t d = 0; d < m.have_deg.size(); ++d) if (m.have_deg[d]) f.inc((uint32_t)((d - 2) >> 8)); break;
 	case 4: for (uint32_t j = 0; j <= OP_CONNFWD; ++j) f.inc(j); break;
+	case 5: for (int r = 0; r < m.bind.nregs_vtx(); ++r) f.inc((uint32_t)r); break;    // models.h:212-217
+	case 6: for (int r = 0; r < m.bind.nregs_face(); ++r) f.inc((uint32_t)r); break;
+	case 7: f.inc(A_DATA); f.inc(A_HIST); break;                                       // models.h:201-203
+	case 8: f.inc(A_DATA); f.inc(A_HIST); f.inc(A_LHIST); break;
 	}
 }
 // Static prior of a plane (chunked container): every chunk of the plane starts its adaptive table from the plane's own
@@ -1851,7 +1874,7 @@ static uint32_t default_conn_chunk(uint32_t chunk_syms) { return std::min(chunk_
 
 static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 {
-	check_supported(m);
+	if (m.bind.on) check_general(m); else check_supported(m);
 	if (chunk_syms == 0) chunk_syms = 8192;
 	chunk_syms = std::min(chunk_syms, 1u << 20);
 	Result *res = new Result();
@@ -1879,7 +1902,8 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
 		wr.record = &rec;
 		cbm_encode(m, wr, res->order_v, res->order_f);
-		encode_attrs(m, wr, res->order_v, res->order_f);
+		if (m.bind.on) encode_attrs_general(m, wr, res->order_v, res->order_f);
+		else encode_attrs(m, wr, res->order_v, res->order_f);
 		if (count_degrees(m) <= 1) { rec[CTX_NUMTRI].clear(); rec[CTX_NUMTRI + 1].clear(); }
 		std::vector<PlaneDef> planes = chunked_planes(m, md);
 		ByteWriter w{ res->bytes };

@@ -128,5 +128,9 @@ def test_cli_obj_both_ways(tmp_path):
     assert (tmp_path / "mtl.hry").read_bytes() == open(os.path.join(OBJ, "mtl.ll.hry"), "rb").read()
     r = subprocess.run([cli.HARRY, "mtl.obj", "mtl2.hry"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert r.returncode == 0 and "Used face regions: 1" in r.stdout                           # ... and not when it has none
-    r = harry(tmp_path / "smooth.obj", tmp_path / "c.hry", "--profile", "chunked")
-    assert r.returncode == 134 and "PLY layout only" in r.stderr
+    r = harry(tmp_path / "smooth.obj", tmp_path / "c.hry", "--profile", "chunked")     # the parallel container holds general bindings too
+    assert r.returncode == 0 and hc.container_info((tmp_path / "c.hry").read_bytes())["minor"] == 2
+    assert harry(tmp_path / "c.hry", tmp_path / "c.obj").returncode == 0
+    assert (tmp_path / "c.obj").read_bytes() == open(os.path.join(OBJ, "smooth.ll.dec.obj"), "rb").read()
+    r = harry(tmp_path / "smooth.obj", tmp_path / "d.hry", "--profile", "chunked", "--shards", "2")
+    assert r.returncode == 134 and "shards" in r.stderr

@@ -113,13 +113,45 @@ def test_big_scene_matches_reference_hash_and_oracle_decode(cx, name):
         assert hashlib.sha256(d.to_obj()).hexdigest() == v["dec_obj_sha256"]
 
 
-def test_general_bindings_refuse_the_chunked_container(cx):
+@pytest.mark.parametrize("name,tag", SMALL, ids=[f"{n}.{t}" for n, t in SMALL])
+@pytest.mark.parametrize("chunk", [0, 256])
+def test_chunked_container_of_general_bindings(cx, name, tag, chunk, monkeypatch):
+    """the parallel container (.hry v0.2) with general bindings: byte-identical to the oracle's restatement, and its GPU decode
+    equals the reference-format decode of the same mesh (bindings and records), through both vertex paths"""
+    m = hc.Mesh.from_obj(_read(name + ".obj"), OBJ)
+    o = op.Mesh.from_obj(_read(name + ".obj"), OBJ)
+    quant, clear = util.flags_to_quant(MAN["small"][name]["variants"][tag]["flags"])
+    if quant or clear:
+        cx.requant(m, quant, clear)
+        o.requant(quant, clear)
+    got = cx.write_hry(m, profile=hc.PROFILE_CHUNKED, chunk_syms=chunk)
+    info = hc.container_info(got)
+    assert info["minor"] == 2
+    assert got == o.clone().encode_chunked(info["chunk_syms"]).data
+    ref = op.Mesh.from_hry(_read(f"{name}.{tag}.hry"))
+    same_decoded(cx.read_hry(got), ref)
+    monkeypatch.setenv("HRY_GENERIC_VERTEX", "1")
+    same_decoded(cx.read_hry(got), ref)
+
+
+def test_chunked_container_larger_scenes(cx):
+    for sc, quant in ((og.scene(mg.torus(60, 64, polys="mixed"), normals="smooth", tex="atlas", charts=6, colors="some", materials=3), []),
+                      (og.scene(mg.icosphere(5), normals="flat", tex="atlas", charts=9), [(0, -1, 14), (1, -1, 11), (2, -1, 10)])):
+        o = op.Mesh.from_obj(sc.obj, "")
+        m = hc.Mesh.from_obj(sc.obj, "")
+        if quant:
+            cx.requant(m, quant)
+            o.requant(quant)
+        got = cx.write_hry(m, profile=hc.PROFILE_CHUNKED)
+        assert got == o.clone().encode_chunked(hc.container_info(got)["chunk_syms"]).data
+        same_decoded(cx.read_hry(got), op.Mesh.from_hry(o.clone().encode().data))
+
+
+def test_general_bindings_do_not_shard(cx):
     m = hc.Mesh.from_obj(_read("smooth.obj"), OBJ)
     with pytest.raises(hc.HryError) as e:
-        cx.write_hry(m, profile=hc.PROFILE_CHUNKED)
-    assert e.value.code == -3
-    with pytest.raises(hc.HryError):
         hc.ShardPlan(m, 2)
+    assert e.value.code == -3
 
 
 def _disk_scene(n=28, colors_every=0):
