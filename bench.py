@@ -439,7 +439,21 @@ def obj_leg(cx):
         t2 = time.perf_counter()
         enc.append(t1 - t0); dec.append(t2 - t1)
     want = op.Mesh.from_obj(sc.obj, "").encode().data
-    rec = {"workload": "torus 200 x 200 as OBJ: smooth normals + 7-chart texture atlas (v / vt / vn, f v/t/n)", "triangles": int(ntri), "obj_bytes": len(sc.obj),
+    # the same scene in the parallel container (.hry v0.2 holds general bindings too)
+    cenc, cdec, cdata = [], [], b""
+    for _ in range(3):
+        a = m.clone()
+        t0 = time.perf_counter()
+        cdata = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+        t1 = time.perf_counter()
+        cd = cx.read_hry(cdata)
+        t2 = time.perf_counter()
+        cenc.append(t1 - t0); cdec.append(t2 - t1)
+    chunked = {"encode_ms": round(min(cenc[1:]) * 1e3, 2), "decode_ms": round(min(cdec[1:]) * 1e3, 2),
+               "encode_mtri_s": round(ntri / min(cenc[1:]) / 1e6, 3), "decode_mtri_s": round(ntri / min(cdec[1:]) / 1e6, 3), "hry_bytes": len(cdata),
+               "container_equals_cpu_port": bool(cdata == op.Mesh.from_obj(sc.obj, "").encode_chunked(hc.container_info(cdata)["chunk_syms"]).data),
+               "decode_equals_reference_format_decode": bool(all(np.array_equal(cd.list_data(l), x) for l, x in enumerate(_oracle_lists(op, want))))}
+    rec = {"workload": "torus 200 x 200 as OBJ: smooth normals + 7-chart texture atlas (v / vt / vn, f v/t/n)", "triangles": int(ntri), "obj_bytes": len(sc.obj), "chunked": chunked,
            "parse_ms": round(t_parse * 1e3, 2), "encode_ms": round(min(enc[1:]) * 1e3, 2), "decode_ms": round(min(dec[1:]) * 1e3, 2),
            "encode_mtri_s": round(ntri / min(enc[1:]) / 1e6, 3), "decode_mtri_s": round(ntri / min(dec[1:]) / 1e6, 3),
            "hry_bytes": len(data), "byte_identical_to_cpu_ref": bool(data == want),

@@ -19,17 +19,18 @@ for label, kw in (("smooth normals + atlas", dict(normals="smooth", tex="atlas",
     m = hc.Mesh.from_obj(sc.obj, "")
     t_parse = time.time() - t
     ntri = m.ntri
-    for rep in range(2):
+    for rep in range(4):
+        prof = hc.PROFILE_COMPAT if rep < 2 else hc.PROFILE_CHUNKED
         a = m.clone()
         t = time.time()
-        data = cx.write_hry(a, profile=hc.PROFILE_COMPAT)
+        data = cx.write_hry(a, profile=prof)
         t_enc = time.time() - t
         te = cx.timing()
         t = time.time()
         d = cx.read_hry(data)
         t_dec = time.time() - t
         td = cx.timing()
-        print(f"[{label}] pass {rep}: {ntri} triangles, parse {t_parse * 1e3:.0f} ms, encode {t_enc * 1e3:.0f} ms ({ntri / t_enc / 1e6:.2f} Mtri/s; host {te['host_walk_ms']:.0f} ms, "
+        print(f"[{label}] {'compat ' if rep < 2 else 'chunked'} pass {rep % 2}: {ntri} triangles, parse {t_parse * 1e3:.0f} ms, encode {t_enc * 1e3:.0f} ms ({ntri / t_enc / 1e6:.2f} Mtri/s; host {te['host_walk_ms']:.0f} ms, "
               f"kernels {te['device_ms']:.0f} ms), decode {t_dec * 1e3:.0f} ms ({ntri / t_dec / 1e6:.2f} Mtri/s; host {td['host_walk_ms']:.0f} ms, kernels {td['device_ms']:.0f} ms), "
               f"{len(data)} bytes = {8 * len(data) / max(m.nv, 1):.1f} bits/vertex", flush=True)
     assert cx.write_hry(d, profile=hc.PROFILE_COMPAT) is not None
