@@ -109,10 +109,22 @@ void Context::upload_mesh(Mesh &m)
 		if (ne && m.nv) {
 			for (uint32_t v : m.org) if (v >= m.nv) throw Error(HRY_E_ARG, "vertex index out of range");
 			d_cscratch.ensure(dev::twin_workspace_bytes(m.nv, ne));
-			dev::launch_twins(stream, conn_view(), m.nv, d_twin.as<uint32_t>(), d_cscratch.p);
-		}
-		m.twin.resize(ne);
-		if (ne) HIP_OK(hipMemcpyAsync(m.twin.data(), d_twin.p, (size_t)ne * 4, hipMemcpyDeviceToHost, stream));
+			const uint32_t *d_over = nullptr;
+			dev::launch_twins(stream, conn_view(), m.nv, d_twin.as<uint32_t>(), d_cscratch.p, &d_over);
+			m.twin.resize(ne);
+			std::vector<uint32_t> over(1 + dev::twin_overflow_capacity(), 0);
+			HIP_OK(hipMemcpyAsync(m.twin.data(), d_twin.p, (size_t)ne * 4, hipMemcpyDeviceToHost, stream));
+			HIP_OK(hipMemcpyAsync(over.data(), d_over, over.size() * 4, hipMemcpyDeviceToHost, stream));
+			HIP_OK(hipStreamSynchronize(stream));
+			if (over[0] > dev::twin_overflow_capacity()) {   // a mesh of hubs: the host's matcher does all of it
+				m.twins_pending = true;
+				ensure_twins(m);
+				HIP_OK(hipMemcpyAsync(d_twin.p, m.twin.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
+			} else if (over[0]) {
+				match_twins_at(m, over.data() + 1, over[0]);   // the few hubs, with the reference's rule, on the host
+				HIP_OK(hipMemcpyAsync(d_twin.p, m.twin.data(), (size_t)ne * 4, hipMemcpyHostToDevice, stream));
+			}
+		} else m.twin.resize(ne);
 		HIP_OK(hipStreamSynchronize(stream));
 		m.twins_pending = false;
 	}

@@ -32,7 +32,9 @@ void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v,
 
 // half-edge twin matching (twins.hip): conn.org / foff (/ eface) resident, twin = output; ws: twin_workspace_bytes
 size_t twin_workspace_bytes(uint32_t nv, uint32_t ne);
-void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twin, void *ws);
+uint32_t twin_overflow_capacity();
+// *over: device pointer (inside ws) of the list of vertices with too many half-edges for the kernel: count, then vertex ids
+void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twin, void *ws, const uint32_t **over);
 
 // chunked profile (chunked.hip)
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits);

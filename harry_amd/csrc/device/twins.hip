@@ -91,12 +91,21 @@ __global__ __launch_bounds__(256) void k_twin_scatter(ConnView cv, const uint32_
 	ent[pos] = ((unsigned long long)hi << 32) | h;
 }
 
-__global__ __launch_bounds__(256) void k_twin_match(ConnView cv, uint32_t nv, const uint32_t *start, unsigned long long *ent, uint32_t *twin)
+// vertices with more than kTwinSegMax half-edges in their segment (the hub of a fan with thousands of spokes) are not for one
+// thread's insertion sort: they are listed in `over` (over[0] = how many, then the vertex ids, at most kTwinOverMax of them) and
+// matched by the host, which has the twins anyway (Context::upload_mesh)
+constexpr uint32_t kTwinSegMax = 48, kTwinOverMax = 4096;
+__global__ __launch_bounds__(256) void k_twin_match(ConnView cv, uint32_t nv, const uint32_t *start, unsigned long long *ent, uint32_t *twin, uint32_t *over)
 {
 	const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
 	if (lo >= nv) return;
 	const uint32_t b = start[lo], e = start[lo + 1];
 	if (e - b < 2) return;
+	if (e - b > kTwinSegMax) {
+		const uint32_t k = atomicAdd(&over[0], 1u);
+		if (k < kTwinOverMax) over[1 + k] = lo;
+		return;
+	}
 	for (uint32_t i = b + 1; i < e; ++i) {   // insertion sort by (larger endpoint, half-edge): segments are a handful of entries
 		const unsigned long long x = ent[i];
 		uint32_t j = i;
@@ -123,13 +132,18 @@ __global__ __launch_bounds__(256) void k_twin_match(ConnView cv, uint32_t nv, co
 
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
-// ws: (2 * nv + 2 + blocks) * 4 bytes of counters + ne * 8 bytes of entries (8-byte aligned first)
-size_t twin_workspace_bytes(uint32_t nv, uint32_t ne) { return (size_t)ne * 8 + ((size_t)2 * nv + 2 + blocks_for(nv, kScanBlock) + 2) * 4; }
-void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twin, void *ws)
+// ws: (2 * nv + 2 + blocks) * 4 bytes of counters + ne * 8 bytes of entries (8-byte aligned first) + the overflow list
+size_t twin_workspace_bytes(uint32_t nv, uint32_t ne) { return (size_t)ne * 8 + ((size_t)2 * nv + 2 + blocks_for(nv, kScanBlock) + 2 + kTwinOverMax + 1) * 4; }
+uint32_t twin_overflow_capacity() { return kTwinOverMax; }
+// over_out: device pointer of the overflow list (count, then vertex ids) inside ws
+void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twin, void *ws, const uint32_t **over_out)
 {
 	if (!cv.ne) return;
 	unsigned long long *ent = (unsigned long long*)ws;
 	uint32_t *count = (uint32_t*)(ent + cv.ne), *start = count + nv, *sums = start + nv + 1;
+	uint32_t *over = sums + blocks_for(nv, kScanBlock) + 2;
+	(void)hipMemsetAsync(over, 0, 4, st);
+	*over_out = over;
 	const unsigned nb = blocks_for(nv, kScanBlock);
 	(void)hipMemsetAsync(count, 0, (size_t)nv * 4, st);
 	hipLaunchKernelGGL(k_twin_count, dim3(blocks_for(cv.ne, 256)), dim3(256), 0, st, cv, twin, count);
@@ -138,7 +152,7 @@ void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twi
 	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanBlock), 0, st, count, nv, sums, start);
 	(void)hipMemsetAsync(count, 0, (size_t)nv * 4, st);   // reused as the fill cursors
 	hipLaunchKernelGGL(k_twin_scatter, dim3(blocks_for(cv.ne, 256)), dim3(256), 0, st, cv, start, count, ent);
-	hipLaunchKernelGGL(k_twin_match, dim3(blocks_for(nv, 256)), dim3(256), 0, st, cv, nv, start, ent, twin);
+	hipLaunchKernelGGL(k_twin_match, dim3(blocks_for(nv, 256)), dim3(256), 0, st, cv, nv, start, ent, twin, over);
 }
 
 }   // namespace dev

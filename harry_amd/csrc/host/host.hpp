@@ -23,6 +23,9 @@ void build_twins(Mesh &m);
 // the readers leave the twin matching pending (Mesh::twins_pending); a context does it on the device when the mesh is first
 // uploaded (device/twins.hip), host-only entry points do it here
 void ensure_twins(const Mesh &m);
+// the half-edges whose smaller endpoint is one of the given vertices, matched on the host (the device leaves hubs with more
+// than a few dozen such half-edges to it); every other entry of m.twin is final already
+void match_twins_at(Mesh &m, const uint32_t *vertices, uint32_t n);
 void print_component(std::string &o, const AttrList &L, const uint8_t *rec, int c);   // one value as the reference prints it (mixing.h:340-359)
 
 // ---- obj_io.cpp (formats/obj/reader.rl:108-299, writer.cc:20-132): meshes with general bindings (mesh.hpp Bindings)

@@ -157,6 +157,39 @@ void ensure_twins(const Mesh &cm)
 	m.twins_pending = false;
 }
 
+void match_twins_at(Mesh &m, const uint32_t *vertices, uint32_t n)
+{
+	std::unordered_map<uint32_t, std::vector<uint64_t>> seg;   // hub -> (larger endpoint << 32 | half-edge)
+	for (uint32_t i = 0; i < n; ++i) seg[vertices[i]];
+	for (uint32_t f = 0; f < m.nf; ++f) {
+		const uint32_t b = m.face_off[f], e = m.face_off[f + 1];
+		for (uint32_t h = b; h < e; ++h) {
+			const uint32_t a = m.org[h], c = m.org[h + 1 == e ? b : h + 1];
+			auto it = seg.find(std::min(a, c));
+			if (it != seg.end()) it->second.push_back(((uint64_t)std::max(a, c) << 32) | h);
+		}
+	}
+	const uint32_t NONE = 0xffffffffu;
+	for (auto &kv : seg) {
+		const uint32_t lo = kv.first;
+		std::vector<uint64_t> &v = kv.second;
+		std::sort(v.begin(), v.end());
+		uint32_t cur_hi = NONE, pend_out = NONE, pend_in = NONE;
+		for (uint64_t x : v) {   // structs/conn.h:201-214, run by run of equal larger endpoints, in half-edge order
+			const uint32_t hi = (uint32_t)(x >> 32), h = (uint32_t)x;
+			if (hi != cur_hi) { cur_hi = hi; pend_out = pend_in = NONE; }
+			if (hi == lo) {
+				if (pend_out != NONE) { m.twin[h] = pend_out; m.twin[pend_out] = h; pend_out = NONE; } else pend_out = h;
+				continue;
+			}
+			const bool out = m.org[h] == lo;
+			uint32_t &opposite = out ? pend_in : pend_out, &same = out ? pend_out : pend_in;
+			if (opposite != NONE) { m.twin[h] = opposite; m.twin[opposite] = h; opposite = NONE; }
+			else if (same == NONE) same = h;
+		}
+	}
+}
+
 void build_twins(Mesh &m)
 {
 	const uint32_t ne = m.ne(), nf = m.nf;

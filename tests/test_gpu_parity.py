@@ -275,3 +275,42 @@ def test_decode_compat_stream_matches_oracle_on_larger_meshes(cx, case):
     again = cx.read_hry(cx.write_hry(a))
     for l in range(2):
         assert np.array_equal(again.list_data(l), want.list_data(l))
+
+
+def _fans(n_fans, spokes, seed=3):
+    """n_fans cones: a hub joined to a closed ring of `spokes` vertices (hub valence = spokes); every third fan shares its ring
+    with a second hub on the other side (two hubs over the same ring edges)"""
+    rng = np.random.default_rng(seed)
+    pts, tris = [], []
+    for k in range(n_fans):
+        base = len(pts)
+        pts.append((3.0 * k, 0.0, 1.0))
+        for i in range(spokes):
+            a = 2 * np.pi * i / spokes
+            pts.append((3.0 * k + np.cos(a), np.sin(a), 0.01 * rng.random()))
+        for i in range(spokes):
+            tris.append((base, base + 1 + i, base + 1 + (i + 1) % spokes))
+        if k % 3 == 0:
+            hub2 = len(pts)
+            pts.append((3.0 * k, 0.0, -1.0))
+            for i in range(spokes):
+                tris.append((hub2, base + 1 + (i + 1) % spokes, base + 1 + i))
+    v = np.zeros(len(pts), dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+    p = np.asarray(pts, np.float32)
+    v["x"], v["y"], v["z"] = p[:, 0], p[:, 1], p[:, 2]
+    t = np.asarray(tris, np.uint32)
+    return mg.Mesh(v, np.full(len(t), 3, np.uint8), t.reshape(-1))
+
+
+@pytest.mark.parametrize("n_fans,spokes", [(3, 300), (40, 60), (4300, 50)])
+def test_device_twin_matching_with_hubs(cx, n_fans, spokes):
+    """twins.hip leaves vertices with more than a few dozen half-edges to the host (a few hubs: patched; thousands: the host's
+    matcher does everything); either way the twins are the sequential matcher's (structs/conn.h:201-214)"""
+    mesh = _fans(n_fans, spokes)
+    ply = mesh.to_ply()
+    a = hc.Mesh.from_ply(ply)
+    cx.upload(a)                                   # twin matching on the device + hubs on the host
+    assert np.array_equal(a.twin(), op.Mesh.from_ply(ply).twin())
+    b = hc.Mesh.from_ply(ply)
+    assert np.array_equal(b.twin(), a.twin())      # host-only matcher (no context)
+    assert cx.write_hry(a) == op.Mesh.from_ply(ply).encode().data
