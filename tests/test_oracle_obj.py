@@ -128,3 +128,44 @@ def test_obj_grammar_quirks():
     assert (m.nv, m.nf) == (3, 0)
     m = op.Mesh.from_obj(b"v 1e-1 2e+1 -.5\nv 0 0 0\nv 1 1 1\nf 1 2 3\n")
     assert m.list_data(0).view("<f4").reshape(-1, 3)[0].tolist() == [10.0, 20.0, -0.5]
+
+
+REF_BIN = os.path.join(util.ROOT, "oracle", "_ref", "harry_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="the reference binary is built only where /root/reference exists (make -C oracle ref)")
+def test_oracle_matches_the_live_reference_binary_on_random_scenes(tmp_path):
+    """beyond the committed fixtures: random OBJ scenes and random PLY meshes, encoded by the unmodified reference binary here and now,
+    against the oracle's bytes; and the reference's decode of its own file against the oracle's decode (as OBJ / PLY text sizes
+    differ in formatting only through the values, compare the re-encoded bytes)"""
+    import subprocess
+    rng = np.random.default_rng(23)
+    for it in range(16):
+        polys = ["tri", "quad", "mixed"][int(rng.integers(0, 3))]
+        base = [lambda: mg.torus(int(rng.integers(5, 22)), int(rng.integers(5, 22)), polys=polys, seed=int(rng.integers(1, 99))),
+                lambda: mg.icosphere(int(rng.integers(1, 4))),
+                lambda: mg.with_nonmanifold(mg.multi_component(int(rng.integers(2, 5)), 8, 9, polys=polys), int(rng.integers(1, 5)), int(rng.integers(1, 3)), seed=int(rng.integers(1, 99)))][int(rng.integers(0, 3))]()
+        flags = []
+        if it % 2 == 0:
+            sc = og.scene(base, normals=[None, "smooth", "flat"][int(rng.integers(0, 3))], tex=[None, "atlas", "corner"][int(rng.integers(0, 3))],
+                          charts=int(rng.integers(1, 7)), colors=[None, "all", "some"][int(rng.integers(0, 3))], tex3=bool(rng.integers(0, 2)),
+                          interleave=bool(rng.integers(0, 2)), negative=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 99)))
+            src = tmp_path / f"s{it}.obj"
+            src.write_bytes(sc.obj)
+            o = op.Mesh.from_obj(sc.obj, str(tmp_path))
+            if rng.integers(0, 2):
+                flags = ["-l0", f"-q{int(rng.integers(6, 17))}"]
+        else:
+            ply = base.to_ply(["binary_little_endian", "binary_big_endian", "ascii"][int(rng.integers(0, 3))])
+            src = tmp_path / f"s{it}.ply"
+            src.write_bytes(ply)
+            o = op.Mesh.from_ply(ply)
+            if rng.integers(0, 2):
+                flags = ["-l1", f"-q{int(rng.integers(6, 17))}"]
+        quant, clear = util.flags_to_quant(flags)
+        if quant:
+            o.requant(quant, clear)
+        hry = tmp_path / f"s{it}.hry"
+        r = subprocess.run([REF_BIN, str(src), str(hry)] + flags, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-300:]
+        assert hry.read_bytes() == o.clone().encode().data, (it, str(src), flags)
