@@ -223,10 +223,10 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	// description: oracle/hry_oracle.cc "chunked profile")
 	for (uint32_t pi = 0; pi < npl; ++pi) {
 		const PlaneRef &pl = planes[pi];
-		const uint32_t step = pi < (uint32_t)kConnPlanes ? CHC : CH;
 		nsym_total += pl.n;
 		max_t0 = std::max(max_t0, totals[pi]);
-		for (uint32_t f = 0; f < pl.n; f += step) {
+		for (uint32_t f = 0, step; f < pl.n; f += step) {
+			step = pi < (uint32_t)kConnPlanes ? CHC : attr_chunk_len(f, CH);
 			uint32_t n = std::min(step, pl.n - f);
 			if (words >= (1ull << 32) - (1u << 24)) throw Error(HRY_E_UNSUPPORTED, "chunked stream accumulator exceeds 2^32 words");
 			jobs.push_back(StreamJob{ pl.dptr + f, n, pi, totals[pi], (uint32_t)words });

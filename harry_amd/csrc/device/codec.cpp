@@ -45,6 +45,8 @@ Context::~Context()
 	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
 	if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }
 	for (auto &e : ev_x) if (e) (void)hipEventDestroy(e);
+	for (auto &e : attr_ev) if (e) (void)hipEventDestroy(e);
+	for (int g = 1; g < kAttrGroups; ++g) if (attr_stream[g]) { (void)hipStreamSynchronize(attr_stream[g]); (void)hipStreamDestroy(attr_stream[g]); }   // [0] is stream3
 	if (h_stage) (void)hipHostFree(h_stage);
 	if (h_down) (void)hipHostFree(h_down);
 }

@@ -62,6 +62,11 @@ struct Context {
 	hipStream_t stream2 = nullptr;   // uploads and connectivity-only kernels of the pipelined decode (created on first use)
 	hipStream_t stream3 = nullptr;   // attribute streams' entropy decode, next to the connectivity streams' (created on first use)
 	hipEvent_t ev_x[2] = {};         // cross-stream ordering events (created with stream3)
+	// chunked decode: the attribute streams are launched in groups by how far into their plane they end (unchunk.cpp); group g
+	// runs on attr_stream[g] and raises attr_ev[g]
+	static constexpr int kAttrGroups = 3;   // (+ the codec's three streams: more streams than hardware queues serialise)
+	hipStream_t attr_stream[kAttrGroups] = {};
+	hipEvent_t attr_ev[kAttrGroups] = {};
 	void *h_down = nullptr;          // pinned landing buffer for the vertex records of the pipelined decode (device -> host per slice)
 	size_t h_down_cap = 0;
 	void *h_stage = nullptr;         // pinned staging memory for uploads that run next to a busy host thread (copies from
@@ -85,7 +90,7 @@ struct Context {
 	DevBuf d_order_v, d_order_f, d_rank, d_vplanes, d_fplanes, d_connplanes, d_grp_val, d_grp_pos, d_op, d_jobs, d_chunks, d_hist, d_init,
 	       d_rec_sym, d_sym_l, d_r, d_s, d_state, d_acc, d_v, d_summary, d_bytes, d_small;
 	// chunked profile
-	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms;
+	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms, d_patch;
 
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
@@ -108,6 +113,17 @@ struct Context {
 enum { INIT_ONES = 0, INIT_IOP = 1, INIT_NT0 = 2, INIT_NT1 = 3, INIT_OP = 4, INIT_REGV = 5, INIT_REGF = 6, INIT_TYPE2 = 7, INIT_TYPE3 = 8, INIT_KINDS = 9 };
 void build_init_tables(const Mesh &m, std::vector<uint32_t> &tabs);   // INIT_KINDS x 256
 struct PlaneRef { const uint8_t *dptr; uint32_t n; int init; };
+// Chunks of an attribute plane grow with their position: 1 Ki symbols each up to symbol 32 Ki, 2 Ki up to 64 Ki, 4 Ki up to 128 Ki
+// ... (length = position / 16 rounded down to a power of two, at least 1 Ki, at most the container's chunk size).  A stream is one
+// serial wavefront, 0.26 us per symbol: the decoder's reconstruction chain walks the vertices in order at 16 ns each and finds
+// every chunk decoded when it gets there, instead of waiting for the first full-size chunk (2.1 ms at 8 Ki symbols).
+// Connectivity planes keep one size (they are needed whole, first).  The oracle restates the same rule.
+inline uint32_t attr_chunk_len(uint64_t pos, uint32_t chunk_syms)
+{
+	uint32_t len = 1024;
+	while (len < chunk_syms && (uint64_t)len * 2 <= pos / 16) len *= 2;
+	return len < chunk_syms ? len : chunk_syms;
+}
 // general bindings: the attribute planes that follow the 21 connectivity planes, in container order (the oracle restates it):
 // the region of every vertex / face (low byte; only with more than one region), then per list a region binds, in list order:
 // the kind of every reference, the creation-order distances (4 planes), at corner lists the per-vertex distances (2 planes),

@@ -171,8 +171,9 @@ static bool pipelined_decode_applicable(const Mesh &m, const std::vector<Restart
 	return restarts.empty() && conn[7].empty() && m.uniform_degree(ud) && unpredict3_covers(ldv) && vc == m.nv && m.nv >= min_nv && m.declared_ne != 0;
 }
 
+// attr_upto[g]: the vertex planes are decoded up to this vertex once cx.attr_ev[g] has fired (the last entry covers everything)
 static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t> *conn, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
-                             const ListDesc &ldv, const ListDesc &ldf, std::vector<uint32_t> &order_v)
+                             const ListDesc &ldv, const ListDesc &ldf, std::vector<uint32_t> &order_v, const uint32_t (&attr_upto)[Context::kAttrGroups])
 {
 	Mesh *m = &mesh;
 	const uint32_t nv = m->nv, nf = m->nf, ne = m->declared_ne;
@@ -212,6 +213,12 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	std::vector<SliceClock> clocks;
 	uint32_t min_slice = 1u << 16;   // (the chain is the longer path since the replay became lean: fewer, larger launches)
 	if (const char *e = getenv("HRY_PIPELINE_SLICE")) min_slice = std::max(64u, (uint32_t)strtoul(e, nullptr, 10));
+	// ... but the first slices are small and double up to that size: the chain is the longer path, what counts is how early it
+	// starts, and the early chunks of the vertex planes are short for exactly that (attr_chunk_len)
+	uint32_t first_slice = 1u << 13;
+	if (const char *e = getenv("HRY_PIPELINE_FIRST_SLICE")) first_slice = std::max(64u, (uint32_t)strtoul(e, nullptr, 10));
+	first_slice = std::min(first_slice, min_slice);
+	int attr_waited = 0;   // groups of attribute streams the chain's stream has been told to wait for
 	const Clock::time_point t_begin = g_t0;
 	// vertex records come back slice by slice into pinned memory and are copied into the mesh by the consumer as they land
 	const size_t vrec_bytes = m->lists[1].data.size();
@@ -220,6 +227,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 		HIP_OK(hipHostMalloc(&cx.h_down, vrec_bytes + (vrec_bytes >> 3) + 4096, hipHostMallocDefault));
 		cx.h_down_cap = vrec_bytes + (vrec_bytes >> 3) + 4096;
 	}
+	cx.d_patch.ensure(std::max<size_t>(4u << 20, (size_t)nv));   // late twin links of a slice: (edge, twin) pairs, a few thousand per slice
 	struct Landing { hipEvent_t ev; size_t off, len; };
 	std::deque<Landing> landing;
 	const int vstride = ldv.stride;
@@ -231,7 +239,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 			uint32_t f_up = 0, he_up = 0, v_done = 0;
 			uint64_t seen_seq = 0;
 			std::vector<uint32_t> patches;
-			DevBuf d_patch;
+			DevBuf &d_patch = cx.d_patch;   // persistent and sized before the pipeline starts: growing it here would synchronise the device (hipFree / hipMalloc) in mid-flight
 			Stager up(cx, cx.stream2);
 			hipEvent_t prepared;
 			HIP_OK(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
@@ -263,6 +271,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 					seen_seq = newest.seq;
 				}
 				if (newest.failed) break;
+				if (trace_on() && getenv("HRY_TRACE_CONSUMER")) fprintf(stderr, "[hry] %8.3f ms    consumer: publication %llu (faces %u, vertices final up to %u)\n", ms_since(t_begin), (unsigned long long)newest.seq, newest.faces, newest.upto);
 				hist.push_back(newest);
 				if (!newest.done && hist.size() <= lag) continue;
 				const ReplayLive::Pub P = newest.done ? newest : hist.front();
@@ -276,7 +285,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 				}
 				// vertices that can no longer change: whole tiles, slices of a useful size
 				const uint32_t v_hi = P.done ? nv : (P.upto & ~63u);
-				if (v_hi > v_done && (P.done || v_hi - v_done >= min_slice)) {
+				if (v_hi > v_done && (P.done || v_hi - v_done >= std::min(min_slice, std::max(first_slice, v_done)))) {
 					// late links of edges that were copied before (a patch of an edge that is copied later is harmless: the copy
 					// carries the final value too)
 					if (!patches.empty()) {
@@ -289,6 +298,8 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 					launch_slice_prepare(cx.stream2, cv, cx.d_order_v.as<uint32_t>(), v_done, v_hi, d_cand, d_ncand, d_crec);
 					HIP_OK(hipEventRecord(prepared, cx.stream2));
 					HIP_OK(hipStreamWaitEvent(cx.stream, prepared, 0));
+					// the residual codes of this slice: the groups of attribute streams that end inside it or before
+					while (attr_waited < Context::kAttrGroups && (attr_waited == 0 || attr_upto[attr_waited - 1] < v_hi)) HIP_OK(hipStreamWaitEvent(cx.stream, cx.attr_ev[attr_waited++], 0));
 					SliceClock ck;
 					HIP_OK(hipEventCreate(&ck.a)); HIP_OK(hipEventCreate(&ck.b));
 					HIP_OK(hipEventRecord(ck.a, cx.stream));
@@ -361,6 +372,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 		std::rethrow_exception(replay_error ? replay_error : consumer_error);
 	}
 	order_v.resize(cur.next_id);
+	for (; attr_waited < Context::kAttrGroups; ++attr_waited) HIP_OK(hipStreamWaitEvent(cx.stream, cx.attr_ev[attr_waited], 0));
 	if (ldf.nplanes) {
 		launch_residuals_to_rec(cx.stream, d_fplanes, nf, ldf, cx.d_rec[0].as<uint8_t>());
 		launch_faces_unfold(cx.stream, nf, ldf, cx.d_rec[0].as<uint8_t>());
@@ -407,8 +419,12 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	memcpy(nsym.data(), p + off, 4ull * np);
 	off += 4ull * np;
 	uint64_t nstreams = 0, total_syms = 0;
-	auto step_of = [&](uint32_t k) { return k < (uint32_t)kConnPlanes ? CHC : CH; };
-	for (uint32_t k = 0; k < np; ++k) { nstreams += (nsym[k] + (uint64_t)step_of(k) - 1) / step_of(k); total_syms += nsym[k]; }
+	auto step_of = [&](uint32_t k, uint64_t pos) { return k < (uint32_t)kConnPlanes ? CHC : attr_chunk_len(pos, CH); };
+	for (uint32_t k = 0; k < np; ++k) {
+		if (k < (uint32_t)kConnPlanes) nstreams += (nsym[k] + (uint64_t)CHC - 1) / CHC;
+		else for (uint64_t f = 0; f < nsym[k]; f += step_of(k, f)) ++nstreams;
+		total_syms += nsym[k];
+	}
 	// static prior of every plane (or none: the reference's initial counts)
 	std::vector<uint32_t> prior((size_t)np * 256, 0);
 	std::vector<uint8_t> has_prior(np, 0);
@@ -492,9 +508,43 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	jobs.reserve((size_t)nstreams);
 	std::vector<uint64_t> plane_off(np + 1, 0);
 	for (uint32_t k = 0; k < np; ++k) {
-		for (uint64_t f = 0; f < nsym[k]; f += step_of(k))
-			jobs.push_back(StreamJob{ cx.d_csyms.as<uint8_t>() + plane_off[k] + f, (uint32_t)std::min<uint64_t>(step_of(k), nsym[k] - f), k, totals[k], 0 });
+		for (uint64_t f = 0, step; f < nsym[k]; f += step) {
+			step = step_of(k, f);
+			jobs.push_back(StreamJob{ cx.d_csyms.as<uint8_t>() + plane_off[k] + f, (uint32_t)std::min<uint64_t>(step, nsym[k] - f), k, totals[k], 0 });
+		}
 		plane_off[k + 1] = plane_off[k] + nsym[k];
+	}
+	// The attribute streams are launched in groups by where in their plane they END (32 Ki, 128 Ki symbols, the rest): the
+	// early chunks are short (attr_chunk_len) and done within a fraction of a millisecond, and the reconstruction chain -- which
+	// walks the vertices in order -- waits only for the groups it has reached.  Jobs, offsets and sizes are permuted alike.
+	uint32_t n_conn_streams = 0;
+	for (int k = 0; k < kConnPlanes; ++k) n_conn_streams += (uint32_t)((nsym[k] + (uint64_t)CHC - 1) / CHC);
+	uint64_t kGroupEnd[Context::kAttrGroups] = { 1u << 15, 1u << 17, ~0ull };
+	if (const char *e = getenv("HRY_ATTR_GROUPS")) {   // 1: one launch for all attribute streams, 2: two groups (measurements)
+		const int ng = atoi(e);
+		if (ng == 1) kGroupEnd[0] = kGroupEnd[1] = ~0ull;
+		else if (ng == 2) { kGroupEnd[0] = 1u << 17; kGroupEnd[1] = ~0ull; }
+	}
+	uint32_t group_n[Context::kAttrGroups] = { 0, 0, 0 };
+	{
+		std::vector<uint32_t> perm(jobs.size());
+		std::vector<uint8_t> grp(jobs.size(), 0);
+		for (size_t j = 0; j < jobs.size(); ++j) {
+			perm[j] = (uint32_t)j;
+			if (j < n_conn_streams) continue;
+			const uint64_t end = (uint64_t)(jobs[j].sym - (cx.d_csyms.as<uint8_t>() + plane_off[jobs[j].init])) + jobs[j].n;   // (init holds the plane index)
+			int g = 0;
+			while (end > kGroupEnd[g]) ++g;
+			grp[j] = (uint8_t)g;
+			++group_n[g];
+		}
+		std::stable_sort(perm.begin() + n_conn_streams, perm.end(), [&](uint32_t a, uint32_t b) { return grp[a] < grp[b]; });
+		std::vector<StreamJob> pj(jobs.size());
+		std::vector<uint32_t> pn(nbytes.size());
+		std::vector<uint64_t> po(offs.size());
+		for (size_t j = 0; j < jobs.size(); ++j) { pj[j] = jobs[perm[j]]; pn[j] = nbytes[perm[j]]; po[j] = offs[perm[j]]; }
+		po[jobs.size()] = offs[jobs.size()];
+		jobs.swap(pj); nbytes.swap(pn); offs.swap(po);
 	}
 	HIP_OK(hipMemcpyAsync(cx.d_init.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice, cx.stream));
 	if (payload_bytes) HIP_OK(hipMemcpyAsync(cx.d_cout.p, payload, payload_bytes, hipMemcpyHostToDevice, cx.stream));
@@ -509,13 +559,14 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	HRY_MARK(g_t0, "payload on the device");
 	// The connectivity streams go first: their planes return to the host for the replay, which then runs while the
 	// attribute streams (the bulk of the payload) are still being decoded on the device.
-	uint32_t n_conn_streams = 0;
-	for (int k = 0; k < kConnPlanes; ++k) n_conn_streams += (uint32_t)((nsym[k] + (uint64_t)CHC - 1) / CHC);
 	// ... and the attribute streams start at the same time on a stream of their own (every stream is one wavefront: the two
 	// launches share the device without noticing each other); everything later on the main stream waits for them.
 	if (!cx.stream3) {
 		HIP_OK(hipStreamCreateWithFlags(&cx.stream3, hipStreamNonBlocking));
 		for (auto &e : cx.ev_x) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		cx.attr_stream[0] = cx.stream3;
+		for (int g = 1; g < Context::kAttrGroups; ++g) HIP_OK(hipStreamCreateWithFlags(&cx.attr_stream[g], hipStreamNonBlocking));
+		for (auto &e : cx.attr_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	}
 	HIP_OK(hipEventRecord(cx.ev_x[0], cx.stream));          // payload, jobs and tables are on the device
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
@@ -531,8 +582,19 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	const bool side_by_side = getenv("HRY_ATTR_SIDE_BY_SIDE") ? atoi(getenv("HRY_ATTR_SIDE_BY_SIDE")) != 0 : chain_bound;
 	HIP_OK(hipStreamWaitEvent(cx.stream3, side_by_side ? cx.ev_x[0] : cx.ev[2], 0));
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
-	launch_chunk_decode(cx.stream3, cx.d_cjobs.as<StreamJob>() + n_conn_streams, (uint32_t)nstreams - n_conn_streams, cx.d_init.as<uint32_t>(),
-	                    cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>() + n_conn_streams, cx.d_csizes.as<uint32_t>() + n_conn_streams);
+	{
+		uint32_t first = n_conn_streams;
+		for (int g = 0; g < Context::kAttrGroups; ++g) {
+			hipStream_t st = cx.attr_stream[g];
+			if (g) HIP_OK(hipStreamWaitEvent(st, side_by_side ? cx.ev_x[0] : cx.ev[2], 0));
+			launch_chunk_decode(st, cx.d_cjobs.as<StreamJob>() + first, group_n[g], cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
+			                    cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first);
+			HIP_OK(hipEventRecord(cx.attr_ev[g], st));
+			first += group_n[g];
+		}
+		// everything joins on stream3: "all attribute planes decoded"
+		for (int g = 1; g < Context::kAttrGroups; ++g) HIP_OK(hipStreamWaitEvent(cx.stream3, cx.attr_ev[g], 0));
+	}
 	HIP_OK(hipEventRecord(cx.ev[6], cx.stream3));
 	HIP_OK(hipEventRecord(cx.ev_x[1], cx.stream3));
 	if (trace_on()) { HIP_OK(hipEventSynchronize(cx.ev[2])); HRY_MARK(g_t0, "connectivity streams decoded"); }
@@ -542,7 +604,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		if (nsym[k]) HIP_OK(hipMemcpyAsync(conn[k].data(), cx.d_csyms.as<uint8_t>() + plane_off[k], nsym[k], hipMemcpyDeviceToHost, cx.stream));
 	}
 	HIP_OK(hipStreamSynchronize(cx.stream));
-	HIP_OK(hipStreamWaitEvent(cx.stream, cx.ev_x[1], 0));   // attribute planes before anything that reads them
+	const bool take_pipeline = !m->general && pipelined_decode_applicable(*m, restarts, conn, ldv, vc);
+	if (!take_pipeline) HIP_OK(hipStreamWaitEvent(cx.stream, cx.ev_x[1], 0));   // attribute planes before anything that reads them (the pipelined decode waits group by group)
 
 	HRY_MARK(g_t0, "connectivity planes on the host");
 	// ---- replay the cut-border machine on the host
@@ -554,9 +617,11 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		cx.timing.host_walk_ms = ms_since(t_walk);
 		HRY_MARK(g_t0, "replay done");
 		general_planes_decode(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>(), plane_off, nsym, (uint32_t)kConnPlanes);
-	} else if (pipelined_decode_applicable(*m, restarts, conn, ldv, vc)) {
+	} else if (take_pipeline) {
 		pipelined = true;
-		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v);
+		uint32_t attr_upto[Context::kAttrGroups];
+		for (int g = 0; g < Context::kAttrGroups; ++g) attr_upto[g] = (uint32_t)std::min<uint64_t>(kGroupEnd[g], 0xffffffffull);
+		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v, attr_upto);
 		cx.timing.host_walk_ms = cx.timing.host_walk_ms - std::chrono::duration<double, std::milli>(t_walk - g_t0).count();
 	} else {
 		cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);

@@ -1871,6 +1871,15 @@ static bool read_prior(ByteReader &br, uint32_t table[256])
 static int count_degrees(const Mesh &m) { int n = 0; for (char c : m.have_deg) n += c ? 1 : 0; return n; }
 enum { CONN_PLANES = 21, RESTART_FACES = 8192 };
 static uint32_t default_conn_chunk(uint32_t chunk_syms) { return std::min(chunk_syms, std::max(chunk_syms / 8, 512u)); }
+// chunks of an attribute plane grow with their position: length = position / 16 rounded down to a power of two, at least 1024,
+// at most the container's chunk size (a decoder walks the vertices in order and should find the early chunks decoded early);
+// connectivity planes keep one size
+static size_t attr_chunk_len(size_t pos, size_t chunk_syms)
+{
+	size_t len = 1024;
+	while (len < chunk_syms && len * 2 <= pos / 16) len *= 2;
+	return std::min(len, chunk_syms);
+}
 
 static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 {
@@ -1974,8 +1983,8 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 		for (size_t pi = 0; pi < planes.size(); ++pi) {
 			const PlaneDef &pd = planes[pi];
 			const std::vector<uint8_t> &sy = rec[pd.slot];
-			const size_t step = pi < CONN_PLANES ? conn_chunk : chunk_syms;
-			for (size_t first = 0; first < sy.size(); first += step) {
+			for (size_t first = 0, step; first < sy.size(); first += step) {
+				step = pi < CONN_PLANES ? conn_chunk : attr_chunk_len(first, chunk_syms);
 				size_t end = std::min(sy.size(), first + step);
 				std::vector<uint8_t> out;
 				ChunkEncoder enc(out);
@@ -2011,7 +2020,10 @@ static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 		std::vector<uint32_t> nsym(np);
 		for (auto &x : nsym) x = br.get<uint32_t>();
 		size_t nstreams = 0;
-		for (size_t k = 0; k < np; ++k) { uint64_t c = k < CONN_PLANES ? conn_chunk : chunk_syms; nstreams += (size_t)((nsym[k] + c - 1) / c); }
+		for (size_t k = 0; k < np; ++k) {
+			if (k < CONN_PLANES) nstreams += (size_t)((nsym[k] + (uint64_t)conn_chunk - 1) / conn_chunk);
+			else for (size_t f = 0; f < nsym[k]; f += attr_chunk_len(f, chunk_syms)) ++nstreams;
+		}
 		std::vector<std::array<uint32_t, 256>> prior(np);
 		std::vector<char> has_prior(np, 0);
 		for (size_t k = 0; k < np; ++k) has_prior[k] = read_prior(br, prior[k].data()) ? 1 : 0;
@@ -2026,8 +2038,8 @@ static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 		for (size_t k = 0; k < planes.size(); ++k) {
 			std::vector<uint8_t> &sy = rec[planes[k].slot];
 			sy.resize(nsym[k]);
-			const size_t step = k < CONN_PLANES ? conn_chunk : chunk_syms;
-			for (size_t first = 0; first < sy.size(); first += step, ++si) {
+			for (size_t first = 0, step; first < sy.size(); first += step, ++si) {
+				step = k < CONN_PLANES ? conn_chunk : attr_chunk_len(first, chunk_syms);
 				size_t end = std::min(sy.size(), first + step);
 				if ((size_t)(p + n - q) < nbytes[si]) throw std::runtime_error("oracle: truncated chunked stream");
 				ChunkDecoder dec(q, q + nbytes[si]);
