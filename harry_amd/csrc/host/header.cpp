@@ -16,7 +16,7 @@ struct Out {
 struct In {
 	const uint8_t *p, *end;
 	template <typename T> T v() { T x; need(sizeof(T)); memcpy(&x, p, sizeof(T)); p += sizeof(T); return x; }
-	void raw(void *d, size_t n) { need(n); memcpy(d, p, n); p += n; }
+	void raw(void *d, size_t n) { need(n); if (n) memcpy(d, p, n); p += n; }
 	void need(size_t n) { if ((size_t)(end - p) < n) throw Error(HRY_E_FORMAT, "truncated .hry header"); }
 };
 }   // namespace
@@ -86,6 +86,7 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 		throw Error(HRY_E_FORMAT, "File format version 0." + std::to_string(magic[5]) + " incompatible to decoder format version 0.1 (All 0.x-versions are incompatible to each other)");
 	m.nv = r.v<uint32_t>(); m.nf = r.v<uint32_t>();
 	m.declared_ne = r.v<uint32_t>();
+	if ((uint64_t)m.declared_ne < 3ull * m.nf || (uint64_t)m.declared_ne > 255ull * m.nf) throw Error(HRY_E_FORMAT, "corrupt header (edge count outside 3..255 per face)");
 	uint16_t nrf = r.v<uint16_t>(), nrv = r.v<uint16_t>();
 	// reader.cc:86-126: region tables; a list's target is what the last region naming it binds it as
 	Bindings b;

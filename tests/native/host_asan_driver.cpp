@@ -1,0 +1,114 @@
+// Host-only pieces of the product under AddressSanitizer / UBSan (CPU build, no HIP): PLY and OBJ readers and writers, twin
+// matching, the cut-border walk, the reference-stream reader with its replay, header parsing of arbitrary bytes, sharding.
+// Built and run by tests/test_host_cpu.py::test_host_code_under_sanitizers.  Usage: driver FILE...  (.ply .obj .hry)
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <fstream>
+#include <iterator>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../harry_amd/csrc/host/host.hpp"
+
+using namespace hry;
+
+static std::vector<uint8_t> slurp(const std::string &fn)
+{
+	std::ifstream is(fn, std::ios::binary);
+	return std::vector<uint8_t>((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char **argv)
+{
+	int done = 0;
+	for (int i = 1; i < argc; ++i) {
+		const std::string fn = argv[i];
+		const std::vector<uint8_t> data = slurp(fn);
+		const std::string ext = fn.size() >= 4 ? fn.substr(fn.size() - 4) : "";
+		try {
+			if (ext == ".ply" || ext == ".obj") {
+				const std::string dir = fn.substr(0, fn.find_last_of('/'));
+				std::unique_ptr<Mesh> m(ext == ".ply" ? mesh_from_ply(data.data(), data.size()) : mesh_from_obj(data.data(), data.size(), dir.c_str()));
+				ensure_twins(*m);
+				std::vector<uint8_t> out;
+				mesh_to_ply(*m, true, out);
+				mesh_to_ply(*m, false, out, true);
+				mesh_to_obj(*m, out);
+				for (auto &L : m->lists) { L.bmin.assign(L.stride(), 0); L.bmax.assign(L.stride(), 0); L.have_bounds = true; }
+				std::vector<uint8_t> hdr;
+				write_hry_header(*m, 1, hdr);
+				Mesh back;
+				int minor = 0;
+				read_hry_header(hdr.data(), hdr.size(), back, minor);
+				if (!m->general && m->nf) {
+					ShardPlan plan;
+					shard_plan(*m, 3, plan);
+					for (uint32_t s = 0; s < 3; ++s) { std::unique_ptr<Mesh> sh(shard_extract(*m, plan, s)); }
+				}
+				if (m->nf) { WalkResult w; cut_border_walk(*m, w); }
+				// the same text, damaged: a clean error or a mesh
+				for (int k = 0; k < 16; ++k) {
+					std::vector<uint8_t> bad = data;
+					for (int j = 0; j < 4; ++j) bad[(size_t)(1103515245u * (unsigned)(k * 4 + j + 1) + 12345u) % bad.size()] = (uint8_t)("0 /-\n9fv"[(k + j) % 9]);
+					try {
+						std::unique_ptr<Mesh> b(ext == ".ply" ? mesh_from_ply(bad.data(), bad.size()) : mesh_from_obj(bad.data(), bad.size(), dir.c_str()));
+						ensure_twins(*b);
+					} catch (const Error &) {
+					} catch (const std::bad_alloc &) {
+					} catch (const std::length_error &) {
+					}
+				}
+			} else if (ext == ".hry") {
+				Mesh m;
+				int minor = 0;
+				const size_t h = read_hry_header(data.data(), data.size(), m, minor);
+				if (minor == 1) {
+					std::vector<uint32_t> order_v, seg_start, seg_level;
+					if (m.general) {
+						std::vector<GenRecordEvents> ev;
+						std::vector<uint8_t> planes;
+						read_general_stream(data.data() + h, data.size() - h, m, order_v, ev, seg_start, seg_level, -1, planes);
+					} else {
+						std::vector<uint8_t> vp, fp;
+						read_compat_stream(data.data() + h, data.size() - h, m, order_v, seg_start, seg_level, vp, fp);
+					}
+				}
+				// the same bytes, damaged: must fail cleanly or decode something
+				for (int k = 0; k < 24; ++k) {
+					if (getenv("HRY_DRIVER_VERBOSE")) fprintf(stderr, "k=%d t=%ld\n", k, (long)clock() / 1000);
+					std::vector<uint8_t> bad = data;
+					for (int j = 0; j < 3; ++j) bad[(size_t)(1103515245u * (unsigned)(k * 3 + j + 1) + 12345u) % bad.size()] ^= (uint8_t)(1 + k + j);
+					try {
+						int mn = 0;
+						{   // a damaged record count is a legal header naming gigabytes: nothing to learn from filling them
+							Mesh probe;
+							read_hry_header(bad.data(), bad.size(), probe, mn, false);
+							uint64_t bytes = ((uint64_t)probe.nv + probe.nf) * 16;
+							for (auto &L : probe.lists) bytes += (uint64_t)L.count * (L.stride() + 1);
+							if (bytes > (64u << 20)) continue;
+						}
+						Mesh b;
+						const size_t hb = read_hry_header(bad.data(), bad.size(), b, mn);
+						if (getenv("HRY_DRIVER_VERBOSE")) fprintf(stderr, "  minor %d nv %u nf %u general %d\n", mn, b.nv, b.nf, (int)b.general);
+						if (mn == 1 && (uint64_t)b.nv + b.nf < (1u << 22)) {
+							std::vector<uint32_t> ov, ss, sl;
+							if (b.general) { std::vector<GenRecordEvents> ev; std::vector<uint8_t> pl; read_general_stream(bad.data() + hb, bad.size() - hb, b, ov, ev, ss, sl, -1, pl); }
+							else { std::vector<uint8_t> vp, fp; read_compat_stream(bad.data() + hb, bad.size() - hb, b, ov, ss, sl, vp, fp); }
+						}
+					} catch (const Error &) {
+					} catch (const std::bad_alloc &) {
+					} catch (const std::length_error &) {
+					}
+				}
+			}
+			++done;
+		} catch (const Error &e) {
+			fprintf(stderr, "%s: %s\n", fn.c_str(), e.what());
+			return 2;
+		}
+	}
+	printf("ok %d files\n", done);
+	return 0;
+}

@@ -1,0 +1,42 @@
+"""The product's host-only code (PLY / OBJ readers and writers, twin matching, the cut-border walk, the reference-stream readers
+with their replay, header parsing, sharding) built with gcc's AddressSanitizer and UBSan and run over every golden input, and over
+damaged copies of them.  The GPU pool has no sanitizer runs; this is the CPU build the task's environment notes ask for."""
+import glob
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "harry_amd", "csrc", "host")
+SOURCES = ["block_pool", "ply_io", "obj_io", "header", "cbm_walk", "cbm_unwalk", "compat_read", "shard"]
+FLAGS = ["-O0", "-g1", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread"]
+
+
+@pytest.mark.timeout(900)
+def test_host_code_under_sanitizers(tmp_path):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    units = [(os.path.join(HOST, s + ".cpp"), str(tmp_path / (s + ".o"))) for s in SOURCES]
+    units.append((os.path.join(ROOT, "tests", "native", "host_asan_driver.cpp"), str(tmp_path / "driver.o")))
+
+    def compile_one(u):
+        return subprocess.run(["g++", *FLAGS, "-c", u[0], "-o", u[1]], capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        for r in ex.map(compile_one, units):
+            assert r.returncode == 0, r.stderr[-3000:]
+    exe = str(tmp_path / "host_asan")
+    r = subprocess.run(["g++", *FLAGS, *[u[1] for u in units], "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+    g = os.path.join(ROOT, "tests", "golden")
+    files = [f for f in sorted(glob.glob(g + "/*.ply") + glob.glob(g + "/obj/*.obj")) if ".dec." not in f]   # the reference's own
+    files += sorted(glob.glob(g + "/*.hry") + glob.glob(g + "/obj/*.hry"))                                   # outputs do not all re-read
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe, *files], capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (r.stdout + r.stderr)[-4000:]
+    assert r.stdout.strip() == "ok %d files" % len(files)
