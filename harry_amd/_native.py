@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libharry_amd.so")
+LIB_PATH = os.environ.get("HRY_LIB") or os.path.join(_HERE, "libharry_amd.so")   # HRY_LIB: a development build (scripts/build_variant.sh)
 
 
 class HryError(RuntimeError):

@@ -808,6 +808,15 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 struct alignas(16) ChainRec { uint16_t slot[6]; uint16_t flags; uint16_t pad; };
 constexpr uint32_t kRing3 = 16384;          // ring entries (32 KB of LDS for 16-bit values)
 constexpr uint32_t kRing3Near = kRing3 - 64;   // a source this close to its vertex is still in the ring when the run is prepared
+#ifndef HRY_CHAIN_POLL_PAUSE_ASM
+#define HRY_CHAIN_POLL_PAUSE_ASM
+#endif
+#ifdef HRY_CHAIN_CLOCKS   // development: where the ticks of a chain go (wavefront 0 of every chain prints its sums)
+#define HRY_CLK(...) __VA_ARGS__
+#else
+#define HRY_CLK(...)
+#endif
+constexpr uint32_t kHand0 = 2, kHand = 64;     // hand-over words of the chain's wavefront team behind its two control words
 enum { CR_NC = 3, CR_BIG = 3, CR_POS_SHIFT = 2, CR_POS_NONE = 7, CR_FAR = 1 << 5, CR_NEED_SHIFT = 6 };
 
 // ring_floor: ids below it are not in the LDS ring when the vertex is reconstructed (they belong to an earlier component, or
@@ -867,7 +876,8 @@ __device__ __attribute__((noinline)) uint32_t chain_far_value(const uint8_t *add
 #pragma nounroll
 		while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= id) {
 			__builtin_amdgcn_s_sleep(2);
-			if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 2u); __hip_atomic_store(&sync[1], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+			if ((++spins & 1023u) == 0u && __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // the chain was given up
+			if (spins > kSpinLimit) { atomicOr(&g_chain_timeout, 2u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
 		}
 	}
 	return (uint32_t)__hip_atomic_load((const T*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -915,9 +925,11 @@ __device__ __forceinline__ Map3 scan3(Map3 m)
 // Several wavefronts share one chain (blockDim.x / 64 of them): wavefront w owns the tiles t = w (mod W).  A tile whose
 // first run depends on the tiles before it only through its predecessor's value is PREPARED (gathers, maps, scan) while
 // the tiles before it are still being finished by the other wavefronts; only "take the predecessor's value, apply the
-// composed maps, verify, publish" is serial.  Hand-over through LDS: sync[0] = number of finished tiles (tiles finish in
-// order), sync[1] = vertices below it have reached global memory.  Every wait is for an earlier tile, whose owner never
-// waits for a later one, so the chain always advances.
+// composed maps, verify, publish" is serial.  Hand-over through LDS, one word per tile: sync[kHand0 + (t & 63)] = (t + 1) << 16 |
+// value of the tile's last vertex, written after the tile's values -- the word is flag and operand at once, so the next
+// tile's owner has its input with the load that ends its wait (no second LDS round trip, no counter, no s_waitcnt on the
+// serial path).  sync[0] = the chain was given up (a wait ran into its bound), sync[1] = vertices below it have reached global
+// memory.  Every wait is for an earlier tile, whose owner never waits for a later one, so the chain always advances.
 template <typename T>
 __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t seg_end,
                                    const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec, const uint8_t *planes, uint8_t *rec,
@@ -925,14 +937,13 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 {
 	static_assert(sizeof(T) <= 2 && !(T(-1) < T(0)), "unsigned components of at most 16 bits");
 	const int lane = threadIdx.x & 63;
-	const uint32_t wv = threadIdx.x >> 6, W = blockDim.x >> 6;
+	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), W = blockDim.x >> 6;   // uniform, and known to be: scalar loop control
 	constexpr uint32_t mask = kRing3 - 1;
 	const uint32_t top = ev_top<T>(q), wrap = (uint32_t)(T)(~T(0));
 	const uint32_t t_first = seg_begin & ~63u;
 	// LDS executes a wavefront's accesses in order, so "values, then counter" on one side and "counter, then values" on the
 	// other need no fence -- and must not get one: acquire / release would also wait for vector memory, i.e. for the prefetch
 	// of the next tile, on every hand-over.  Relaxed atomics keep the compiler from caching or reordering the counters.
-	auto tiles_done = [&]() -> uint32_t { uint32_t x = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return x; };
 	// value of a vertex that is final before the current run, wherever it lives
 	auto old_value = [&](uint32_t id, uint32_t cur) -> uint32_t {
 		if (id >= cur) return 0u;   // the chained source of a vertex inside the run: not final yet, and never used from here
@@ -953,20 +964,50 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	// a slice that continues a chain finds the end of the previous slice in the ring again
 	for (uint32_t b = ring_floor + 64 * wv; b < seg_begin; b += 64 * W) { const uint32_t v = b + lane; if (v < seg_begin) ring[v & mask] = ldq<T>(rec + (size_t)v * stride + off); }
 	if (threadIdx.x == 0) { sync[0] = 0; sync[1] = seg_begin; }
+	if (threadIdx.x < kHand) sync[kHand0 + threadIdx.x] = 0;
 	__syncthreads();
+	bool given_up = false;
+	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
 	request(t_first + 64 * wv);
-	for (uint32_t tb = t_first + 64 * wv; tb < seg_end; tb += 64 * W) {
+	for (uint32_t tb = t_first + 64 * wv; tb < seg_end && !given_up; tb += 64 * W) {
+		if (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // another wavefront's wait ran into its bound
+		HRY_CLK(ck_t0 = __builtin_amdgcn_s_memtime(); ++ck_tiles; ck_is_clean = true; const unsigned long long ck_runs0 = ck_runs;)
 		const uint4 cr = nx_rec;
 		const uint32_t code = nx_b0 | (nx_b1 << 8);
 		if (tb + 64 * W < seg_end) request(tb + 64 * W);
 		const uint32_t tile_idx = (tb - t_first) >> 6;
 		bool waited = false;
+		uint32_t x_prev = 0;    // the value of vertex tb - 1, as handed over by its tile
+		uint32_t x_out = 0;     // the value of this tile's last finished vertex (uniform)
 		auto wait_prev = [&]() {
 			if (waited) return;
-			uint32_t spins = 0;
-#pragma nounroll
-			while (tiles_done() < tile_idx) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } }
 			waited = true;
+			HRY_CLK(const unsigned long long w0 = __builtin_amdgcn_s_memtime(); ck_prep += w0 - ck_t0;)
+			HRY_CLK(struct Stamp { unsigned long long &a, &b, w0; __device__ ~Stamp() { b = __builtin_amdgcn_s_memtime(); a += b - w0; } } stamp{ ck_wait, ck_t1, w0 };)
+			if (tile_idx == 0u) return;
+			// hand-written: the compiler turns this loop into an exec-mask loop with a dozen mask operations per round and on
+			// the way out, all of them on the serial path.  The word is the same for every lane: one SGPR, scalar branches.
+			const uint32_t slot_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&sync[kHand0 + ((tile_idx - 1u) & (kHand - 1u))];   // LDS byte address
+			const uint32_t want = tile_idx & 0xffffu;
+			uint32_t w, left = kSpinLimit, tmp_v, tmp_s;
+			asm volatile("1:\n\t"
+			             "ds_read_b32 %[v], %[addr]\n\t"
+			             "s_waitcnt lgkmcnt(0)\n\t"
+			             "v_readfirstlane_b32 %[w], %[v]\n\t"
+			             "s_lshr_b32 %[t], %[w], 16\n\t"
+			             "s_cmp_eq_u32 %[t], %[want]\n\t"
+			             "s_cbranch_scc1 2f\n\t"
+			             HRY_CHAIN_POLL_PAUSE_ASM
+			             "s_sub_u32 %[left], %[left], 1\n\t"
+			             "s_cmp_lg_u32 %[left], 0\n\t"
+			             "s_cbranch_scc1 1b\n\t"
+			             "2:"
+			             : [w] "=&s"(w), [t] "=&s"(tmp_s), [v] "=&v"(tmp_v), [left] "+s"(left)
+			             : [addr] "v"(slot_addr), [want] "s"(want)
+			             : "memory", "scc");
+			if (left == 0u) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); given_up = true; }
+			asm volatile("" ::: "memory");   // ring reads stay behind the wait
+			x_prev = w & 0xffffu;
 		};
 		const uint32_t v = tb + lane;
 		const uint32_t lo = seg_begin > tb ? seg_begin - tb : 0u, hi = min(64u, seg_end - tb);
@@ -978,13 +1019,27 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		// every source other than the predecessor lies in a tile this wavefront has already seen finished (<= t - W)
 		const bool settled = gap > (uint32_t)lane + 64u * (W - 1u);
 		const uint64_t bigmask = __ballot(big);
-		// the candidate rows of the tile's first vertex with more than two candidates are fetched now, ahead of the chain: a
-		// global load on the serial path otherwise (0.18 such vertices per tile)
-		const uint32_t big0 = bigmask ? (uint32_t)__builtin_ctzll(bigmask) : 64u;
-		uint32_t pf_n = 0, pf_a = 0, pf_b = 0, pf_o = 0;
-		if (big0 < 64u) {
-			pf_n = ncand[tb + big0];
-			if (lane < kCandMax) { const uint32_t *row = cand + (size_t)(tb + big0) * (kCandMax * 3) + 3 * lane; pf_a = row[0]; pf_b = row[1]; pf_o = row[2]; }
+		// The candidate rows of the tile's first eight vertices with more than two candidates are fetched now, ahead of the chain
+		// (0.18 such vertices per tile on average, 0.4 - 0.7 where a cut border closes): lane l holds candidate l & 7 of the
+		// (l >> 3)-th of them.  Sources older than the ring are final in the records by now and are fetched here as well: on the
+		// serial path each of them is a trip to memory (1 - 2 us, as much as two whole tiles).
+		uint32_t pf_pos = 64u, pf_n = 0, pf_a = 0, pf_b = 0, pf_o = 0, pf_va = 0, pf_vb = 0, pf_vo = 0, pf_far = 0;
+		if (bigmask) {
+			uint64_t bm = bigmask;
+#pragma nounroll
+			for (uint32_t j = 0; j < 8u && bm; ++j) { const uint32_t p = (uint32_t)__builtin_ctzll(bm); bm &= bm - 1ull; if ((uint32_t)lane >> 3 == j) pf_pos = p; }
+			if (pf_pos < 64u) {
+				const uint32_t vb = tb + pf_pos;
+				pf_n = ncand[vb];
+				const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * (lane & 7);
+				pf_a = row[0]; pf_b = row[1]; pf_o = row[2];
+				if (pf_n != 0xffu && (uint32_t)(lane & 7) < pf_n) {
+					auto is_far = [&](uint32_t id) { return id < vb && !(id >= ring_floor && vb - id <= kRing3Near); };
+					if (is_far(pf_a)) { pf_va = chain_far_value<T>(rec + (size_t)pf_a * stride + off, pf_a, seg_begin, sync, xs, comp); pf_far |= 1u; }
+					if (is_far(pf_b)) { pf_vb = chain_far_value<T>(rec + (size_t)pf_b * stride + off, pf_b, seg_begin, sync, xs, comp); pf_far |= 2u; }
+					if (is_far(pf_o)) { pf_vo = chain_far_value<T>(rec + (size_t)pf_o * stride + off, pf_o, seg_begin, sync, xs, comp); pf_far |= 4u; }
+				}
+			}
 		}
 		UnfoldPre uf;
 		uf.setup(code, top, wrap);
@@ -994,19 +1049,28 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if ((bigmask >> s) & 1ull) {
 				// more than two candidates: evaluated on its own, candidate k on lane k (table order), or by walking the fan
 				wait_prev();
+				HRY_CLK(++ck_bigs; ck_is_clean = false;)
 				const uint32_t vb = tb + s;
-				const uint32_t n0 = s == big0 ? pf_n : (uint32_t)ncand[vb];
+				const uint32_t bj = (uint32_t)__builtin_popcountll(bigmask & ((1ull << s) - 1ull));   // which of the tile's many-candidate vertices
+				const bool fetched = bj < 8u;
+				const uint32_t l0 = fetched ? 8u * bj : 0u;                                           // lanes l0 .. l0 + 7 hold its candidates
+				const uint32_t n0 = fetched ? rl(pf_n, l0) : (uint32_t)ncand[vb];
 				T pred = T(0);
 				if (n0 != 0xff) {
 					uint32_t pk = 0;
-					if ((uint32_t)lane < n0) {
-						uint32_t ia = pf_a, ib = pf_b, io = pf_o;
-						if (s != big0) { const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane; ia = row[0]; ib = row[1]; io = row[2]; }
-						pk = (uint32_t)cm::parallelogram<T>((T)old_value(ia, vb), (T)old_value(ib, vb), (T)old_value(io, vb), q);
+					if (fetched) {
+						if ((uint32_t)lane >> 3 == bj && (uint32_t)(lane & 7) < n0) {
+							auto near_value = [&](uint32_t id) -> uint32_t { return id >= vb ? 0u : (uint32_t)ring[id & mask]; };   // whatever is not far is in the ring
+							const uint32_t a = (pf_far & 1u) ? pf_va : near_value(pf_a), b = (pf_far & 2u) ? pf_vb : near_value(pf_b), o = (pf_far & 4u) ? pf_vo : near_value(pf_o);
+							pk = (uint32_t)cm::parallelogram<T>((T)a, (T)b, (T)o, q);
+						}
+					} else if ((uint32_t)lane < n0) {
+						const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
+						pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
 					}
 					T pv[kCandMax];
 #pragma unroll
-					for (int k = 0; k < kCandMax; ++k) pv[k] = (T)rl(pk, k);
+					for (int k = 0; k < kCandMax; ++k) pv[k] = (T)rl(pk, l0 + k);
 					pred = chain_predict<T>(n0, pv);
 				} else {
 					int64_t acc = 0;
@@ -1020,6 +1084,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				const uint32_t c0 = rl(code, s);
 				const T val = cm::value_from_residual<T>((typename cm::word<sizeof(T)>::u)c0, pred, q);
 				if (lane == 0) ring[vb & mask] = val;
+				x_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)val);
 				s += 1;
 				first_run = false;
 				continue;
@@ -1033,6 +1098,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			// vertex takes its predecessor through the chained source, and no other source of the run is recent
 			const bool early = first_run && !waited && __ballot(active && !settled) == 0ull;
 			if (!early) wait_prev();
+			HRY_CLK(++ck_runs; if (!early) ck_is_clean = false;)
 			uint32_t sv0 = ring[slot0], sv1 = ring[slot1], sv2 = ring[slot2], sv3 = ring[slot3], sv4 = ring[slot4], sv5 = ring[slot5];
 			if (__ballot(active && far)) {
 				if (active && far) {   // some source is older than the ring or belongs to an earlier component: by vertex id
@@ -1065,8 +1131,9 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if ((uint32_t)lane < s) { g.k = 0; g.A = 0; g.D = 0; }   // identity below the run
 			uint32_t xh = 0, x_in = 0;
 			for (int attempt = 0;; ++attempt) {
-				const Map3 F = scan3(g);
-				if (early && !waited) { wait_prev(); x_in = (uint32_t)ring[(tb + s - 1u) & mask]; }
+				Map3 F = scan3(g);
+				asm volatile("" : "+v"(F.k), "+v"(F.A), "+v"(F.D));   // the whole scan is computed before the wait below, not sunk behind it
+				if (early && !waited) { HRY_CLK(++ck_early;) wait_prev(); x_in = tile_idx ? x_prev : (uint32_t)ring[(tb + s - 1u) & mask]; }
 				xh = (uint32_t)((((int32_t)x_in + F.A) >> F.k) + F.D);
 				uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xh, 0x138, 0xf, 0xf, false);   // wave_shr:1
 				xp = (uint32_t)lane == s ? x_in : xp;
@@ -1075,6 +1142,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				const uint32_t tv = keepl ? v0 : (uf.apply(pred, top) & wrap);
 				const uint64_t bad = __ballot(active && tv != xh);
 				if (!bad) break;
+				HRY_CLK(++ck_retry; ck_is_clean = false;)
 				const uint32_t j = (uint32_t)__builtin_ctzll(bad);
 				if ((uint32_t)lane == j) { keepl = true; v0 = tv; g.k = 16; g.A = 0; g.D = (int32_t)tv; xh = tv; }
 				if (attempt == 1) {
@@ -1090,13 +1158,15 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				}
 			}
 			if (active) ring[v & mask] = (T)xh;
+			x_out = rl(xh, e - 1u);
 			s = e;
 			first_run = false;
 		}
 		// the tile is finished: its values are in the ring before the counter moves (release)
 		wait_prev();
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring writes of this tile have executed
-		if (lane == 0) __hip_atomic_fetch_max(&sync[0], tile_idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // max: an aborted chain keeps its "everything done" mark
+		asm volatile("" ::: "memory");   // the ring writes of this tile are issued before the word that announces them (LDS runs a wavefront's accesses in order)
+		if (lane == 0) __hip_atomic_store(&sync[kHand0 + (tile_idx & (kHand - 1u))], ((tile_idx + 1u) << 16) | (x_out & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		HRY_CLK(const unsigned long long ck_d = __builtin_amdgcn_s_memtime() - ck_t1; ck_serial += ck_d; if (ck_is_clean && ck_runs - ck_runs0 == 1) { ck_clean += ck_d; ++ck_clean_n; })
 		// every 64 tiles, and at the end, the owner of the tile sends the finished values to the records
 		const bool last_tile = tb + 64 >= seg_end;
 		if (((tile_idx + 1u) & 63u) == 0u || last_tile) {
@@ -1107,6 +1177,8 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if (lane == 0) __hip_atomic_fetch_max(&sync[1], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // flushes of different wavefronts may finish out of order
 		}
 	}
+	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu early %llu runs %llu bigs %llu retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_early, ck_runs, ck_bigs, ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
+	                                    ck_prep / ck_tiles, ck_wait / ck_tiles, ck_serial / ck_tiles, (unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin, ((unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin) / (ck_tiles * W));)
 }
 
 template <typename T>
@@ -1114,7 +1186,7 @@ __global__ __launch_bounds__(512) void k_unpredict3(ConnView cv, const uint32_t 
                                                    const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, const uint32_t *segs, const uint32_t *list_off, CrossSync xs)
 {
 	__shared__ T ring3[kRing3];
-	__shared__ uint32_t sync3[2];
+	__shared__ uint32_t sync3[kHand0 + kHand];
 	const int c = sel.comp[blockIdx.x];
 	TopoD tp{ cv };
 	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
@@ -1128,7 +1200,7 @@ __global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uin
                                                          const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, uint32_t v_begin, uint32_t v_end, uint32_t ring_floor)
 {
 	__shared__ T ring3[kRing3];
-	__shared__ uint32_t sync3[2];
+	__shared__ uint32_t sync3[kHand0 + kHand];
 	// The chains of the attribute components read the same chain records and write into the same vertex records.  Workgroups
 	// go round-robin over the 8 XCDs (each with its own L2): only every eighth workgroup of the launch carries a chain, so
 	// that all of them share ONE L2 -- the records are fetched from memory once, and the components' 2-byte stores into a
