@@ -922,6 +922,28 @@ __device__ __forceinline__ Map3 scan3(Map3 m)
 	return m;
 }
 
+// segmented: bit 8 of k marks a lane that starts a run; lane l gets m_l o ... o m_s, s = the last start at or below l
+constexpr int32_t kRunStart = 256;
+__device__ __forceinline__ Map3 scan3_runs(Map3 m)
+{
+	auto step = [&](const Map3 &p) {
+		const bool start = (m.k & kRunStart) != 0;
+		Map3 pm = p, mm = m;
+		pm.k &= kRunStart - 1; mm.k &= kRunStart - 1;
+		Map3 c = compose3(pm, mm);
+		c.k |= p.k & kRunStart;   // a start anywhere in the span
+		m.k = start ? m.k : c.k; m.A = start ? m.A : c.A; m.D = start ? m.D : c.D;
+	};
+	step(dpp3<0x111, 0xf>(m));
+	step(dpp3<0x112, 0xf>(m));
+	step(dpp3<0x114, 0xf>(m));
+	step(dpp3<0x118, 0xf>(m));
+	step(dpp3<0x142, 0xa>(m));
+	step(dpp3<0x143, 0xc>(m));
+	m.k &= kRunStart - 1;
+	return m;
+}
+
 // Several wavefronts share one chain (blockDim.x / 64 of them): wavefront w owns the tiles t = w (mod W).  A tile whose
 // first run depends on the tiles before it only through its predecessor's value is PREPARED (gathers, maps, scan) while
 // the tiles before it are still being finished by the other wavefronts; only "take the predecessor's value, apply the
@@ -967,7 +989,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	if (threadIdx.x < kHand) sync[kHand0 + threadIdx.x] = 0;
 	__syncthreads();
 	bool given_up = false;
-	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
+	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_r2 = 0, ck_r2len = 0, ck_r2_8 = 0, ck_r2_16 = 0, ck_r2_32 = 0, ck_r2_afterbig = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
 	request(t_first + 64 * wv);
 	for (uint32_t tb = t_first + 64 * wv; tb < seg_end && !given_up; tb += 64 * W) {
 		if (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // another wavefront's wait ran into its bound
@@ -1015,17 +1037,25 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		const uint32_t slot0 = cr.x & 0xffffu, slot1 = cr.x >> 16, slot2 = cr.y & 0xffffu, slot3 = cr.y >> 16, slot4 = cr.z & 0xffffu, slot5 = cr.z >> 16;
 		const uint32_t flags = cr.w & 0xffffu, gap = cr.w >> 16;
 		const uint32_t nc = flags & CR_NC, pos = (flags >> CR_POS_SHIFT) & 7u, need_rel = flags >> CR_NEED_SHIFT;
-		const bool far = (flags & CR_FAR) != 0, big = valid && nc == CR_BIG;
+		const bool far = (flags & CR_FAR) != 0;
 		// every source other than the predecessor lies in a tile this wavefront has already seen finished (<= t - W)
 		const bool settled = gap > (uint32_t)lane + 64u * (W - 1u);
-		const uint64_t bigmask = __ballot(big);
-		// The candidate rows of the tile's first eight vertices with more than two candidates are fetched now, ahead of the chain
-		// (0.18 such vertices per tile on average, 0.4 - 0.7 where a cut border closes): lane l holds candidate l & 7 of the
-		// (l >> 3)-th of them.  Sources older than the ring are final in the records by now and are fetched here as well: on the
-		// serial path each of them is a trip to memory (1 - 2 us, as much as two whole tiles).
+		// HEADS: vertices that are evaluated on their own in the serial part, from the ring -- the ones with more than two
+		// candidates (no map of the scan's family) and the ones with a source, other than the predecessor, that is not final yet
+		// when the tile is prepared.  Everything between two heads is a run whose maps are composed NOW: behind a head only
+		// "apply the composed maps to the head's value, verify" is left.
+		const bool head = valid && (nc == CR_BIG || (nc != 0u && !settled));
+		const uint64_t headmask = __ballot(head);
+		const uint32_t nheads = (uint32_t)__builtin_popcountll(headmask);
+		// a head with at most two candidates, all of them in the ring, is evaluated on its own lane from its record's slots;
+		// the others (more candidates, or a source older than the ring) from their candidate rows, which are fetched ahead
+		const uint64_t rowmask = __ballot(head && (nc == CR_BIG || far));
+		// The candidate rows of the tile's first eight heads are fetched now, ahead of the chain (0.2 - 0.7 heads per tile): lane l
+		// holds candidate l & 7 of the (l >> 3)-th of them.  Sources older than the ring are final in the records by now and are
+		// fetched here as well: on the serial path each of them is a trip to memory (1 - 2 us, as much as two whole tiles).
 		uint32_t pf_pos = 64u, pf_n = 0, pf_a = 0, pf_b = 0, pf_o = 0, pf_va = 0, pf_vb = 0, pf_vo = 0, pf_far = 0;
-		if (bigmask) {
-			uint64_t bm = bigmask;
+		if (rowmask && nheads <= 8u) {
+			uint64_t bm = rowmask;
 #pragma nounroll
 			for (uint32_t j = 0; j < 8u && bm; ++j) { const uint32_t p = (uint32_t)__builtin_ctzll(bm); bm &= bm - 1ull; if ((uint32_t)lane >> 3 == j) pf_pos = p; }
 			if (pf_pos < 64u) {
@@ -1043,100 +1073,90 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		}
 		UnfoldPre uf;
 		uf.setup(code, top, wrap);
-		uint32_t s = lo;
-		bool first_run = true;
-		while (s < hi) {
-			if ((bigmask >> s) & 1ull) {
-				// more than two candidates: evaluated on its own, candidate k on lane k (table order), or by walking the fan
-				wait_prev();
-				HRY_CLK(++ck_bigs; ck_is_clean = false;)
-				const uint32_t vb = tb + s;
-				const uint32_t bj = (uint32_t)__builtin_popcountll(bigmask & ((1ull << s) - 1ull));   // which of the tile's many-candidate vertices
-				const bool fetched = bj < 8u;
-				const uint32_t l0 = fetched ? 8u * bj : 0u;                                           // lanes l0 .. l0 + 7 hold its candidates
-				const uint32_t n0 = fetched ? rl(pf_n, l0) : (uint32_t)ncand[vb];
-				T pred = T(0);
-				if (n0 != 0xff) {
-					uint32_t pk = 0;
-					if (fetched) {
-						if ((uint32_t)lane >> 3 == bj && (uint32_t)(lane & 7) < n0) {
-							auto near_value = [&](uint32_t id) -> uint32_t { return id >= vb ? 0u : (uint32_t)ring[id & mask]; };   // whatever is not far is in the ring
-							const uint32_t a = (pf_far & 1u) ? pf_va : near_value(pf_a), b = (pf_far & 2u) ? pf_vb : near_value(pf_b), o = (pf_far & 4u) ? pf_vo : near_value(pf_o);
-							pk = (uint32_t)cm::parallelogram<T>((T)a, (T)b, (T)o, q);
-						}
-					} else if ((uint32_t)lane < n0) {
-						const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
-						pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
-					}
-					T pv[kCandMax];
-#pragma unroll
-					for (int k = 0; k < kCandMax; ++k) pv[k] = (T)rl(pk, l0 + k);
-					pred = chain_predict<T>(n0, pv);
-				} else {
-					int64_t acc = 0;
-					uint32_t n = 0;
-					fan_ids(tp, order_v[vb], vb, [&](uint32_t a, uint32_t b, uint32_t o) {
-						acc += (int64_t)cm::parallelogram<T>((T)old_value(a, vb), (T)old_value(b, vb), (T)old_value(o, vb), q);
-						++n;
-					});
-					if (n) pred = (T)cm::mean_of(acc, (int64_t)n);
-				}
-				const uint32_t c0 = rl(code, s);
-				const T val = cm::value_from_residual<T>((typename cm::word<sizeof(T)>::u)c0, pred, q);
-				if (lane == 0) ring[vb & mask] = val;
-				x_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)val);
-				s += 1;
-				first_run = false;
-				continue;
-			}
-			// the run [s, e): cut before the first vertex that needs a later batch start, or a vertex with more than two candidates
-			const uint64_t above = s >= 63u ? 0ull : ~((2ull << s) - 1ull);
-			const uint64_t cut = __ballot(valid && (need_rel > s || big)) & above;
-			const uint32_t e = cut ? (uint32_t)__builtin_ctzll(cut) : hi;
-			const bool active = (uint32_t)lane >= s && (uint32_t)lane < e;
-			// early: the run can be prepared before the tile before it is finished -- it is the tile's first run, its first
-			// vertex takes its predecessor through the chained source, and no other source of the run is recent
-			const bool early = first_run && !waited && __ballot(active && !settled) == 0ull;
-			if (!early) wait_prev();
-			HRY_CLK(++ck_runs; if (!early) ck_is_clean = false;)
+		// ---- the map of a vertex, from the ring as it is when this is called: x (the predecessor's value) -> value
+		bool keepl = false;
+		uint32_t v0 = 0, p1c = 0;
+		int32_t bo0 = 0;
+		const bool two = nc == 2;
+		Map3 g;
+		auto build_maps = [&](bool sel, uint32_t cur, uint32_t const_lane) {   // cur: sources from here on are not final (only the chained one is)
 			uint32_t sv0 = ring[slot0], sv1 = ring[slot1], sv2 = ring[slot2], sv3 = ring[slot3], sv4 = ring[slot4], sv5 = ring[slot5];
-			if (__ballot(active && far)) {
-				if (active && far) {   // some source is older than the ring or belongs to an earlier component: by vertex id
+			if (__ballot(sel && far)) {
+				if (sel && far) {   // some source is older than the ring or belongs to an earlier component: by vertex id
 					const uint32_t *row = cand + (size_t)v * (kCandMax * 3);
-					const uint32_t a0 = old_value(row[0], tb + s), a1 = old_value(row[1], tb + s), a2 = old_value(row[2], tb + s);
+					const uint32_t a0 = old_value(row[0], cur), a1 = old_value(row[1], cur), a2 = old_value(row[2], cur);
 					uint32_t a3 = a0, a4 = a1, a5 = a2;
-					if (nc == 2) { a3 = old_value(row[3], tb + s); a4 = old_value(row[4], tb + s); a5 = old_value(row[5], tb + s); }
+					if (nc == 2) { a3 = old_value(row[3], cur); a4 = old_value(row[4], cur); a5 = old_value(row[5], cur); }
 					// the chained source is not final yet unless this vertex starts the run; its slot value is ignored below
 					sv0 = a0; sv1 = a1; sv2 = a2; sv3 = a3; sv4 = a4; sv5 = a5;
 				}
 			}
 			if (nc == 0) { sv0 = sv1 = sv2 = sv3 = sv4 = sv5 = 0; }
-			// the first vertex of a run reads its predecessor like any older source -- unless the run is prepared early: then
-			// it keeps its map and the predecessor's value enters below
-			bool keepl = pos == CR_POS_NONE || ((uint32_t)lane == s && !early);
-			// exact value of a vertex without a source inside the run
+			// a vertex without a source inside the run is a constant; const_lane reads its predecessor like any older source
+			keepl = pos == CR_POS_NONE || (uint32_t)lane == const_lane;
 			const uint32_t p0e = med3_i32((int32_t)(sv0 + sv1 - sv2), 0, (int32_t)top), p1e = med3_i32((int32_t)(sv3 + sv4 - sv5), 0, (int32_t)top);
-			uint32_t v0 = uf.apply((p0e + p1e + 1u) >> 1, top) & wrap;
+			v0 = uf.apply((p0e + p1e + 1u) >> 1, top) & wrap;
 			// chained form: candidate kp holds the predecessor as source a or b
 			const bool kp = pos >= 3u, isb = pos == 1u || pos == 4u;
 			const uint32_t sa = kp ? sv3 : sv0, sb = kp ? sv4 : sv1, so = kp ? sv5 : sv2;
-			const int32_t bo0 = (int32_t)((isb ? sa : sb) - so);
-			const uint32_t p1c = kp ? p0e : p1e;
-			const bool two = nc == 2;
+			bo0 = (int32_t)((isb ? sa : sb) - so);
+			p1c = kp ? p0e : p1e;
 			const int32_t tsum = bo0 + (int32_t)p1c + 1;
-			Map3 g;
 			g.k = keepl ? 16 : two ? 1 : 0;
 			g.A = keepl ? 0 : two ? (tsum & 1) : 0;
 			g.D = keepl ? (int32_t)v0 : two ? (tsum >> 1) + (int32_t)uf.delta : bo0 + (int32_t)uf.delta;
-			if ((uint32_t)lane < s) { g.k = 0; g.A = 0; g.D = 0; }   // identity below the run
-			uint32_t xh = 0, x_in = 0;
+		};
+		auto scan_run = [&](uint32_t s, uint32_t e) -> Map3 {   // lane l of [s, e): g_l o ... o g_s
+			Map3 m = g;
+			if ((uint32_t)lane < s || (uint32_t)lane >= e) { m.k = 0; m.A = 0; m.D = 0; }
+			return scan3(m);
+		};
+		// a vertex evaluated on its own from the ring: candidate k on lane l0 + k (table order), or by walking the fan
+		auto eval_alone = [&](uint32_t s, bool fetched, uint32_t bj) -> uint32_t {
+			HRY_CLK(++ck_bigs; ck_is_clean = false;)
+			const uint32_t vb = tb + s;
+			const uint32_t l0 = fetched ? 8u * bj : 0u;   // lanes l0 .. l0 + 7 hold its candidates
+			const uint32_t n0 = fetched ? rl(pf_n, l0) : (uint32_t)ncand[vb];
+			T pred = T(0);
+			if (n0 != 0xff) {
+				uint32_t pk = 0;
+				if (fetched) {
+					if ((uint32_t)lane >> 3 == bj && (uint32_t)(lane & 7) < n0) {
+						auto near_value = [&](uint32_t id) -> uint32_t { return id >= vb ? 0u : (uint32_t)ring[id & mask]; };   // whatever is not far is in the ring
+						const uint32_t a = (pf_far & 1u) ? pf_va : near_value(pf_a), b = (pf_far & 2u) ? pf_vb : near_value(pf_b), o = (pf_far & 4u) ? pf_vo : near_value(pf_o);
+						pk = (uint32_t)cm::parallelogram<T>((T)a, (T)b, (T)o, q);
+					}
+				} else if ((uint32_t)lane < n0) {
+					const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
+					pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
+				}
+				T pv[kCandMax];
+#pragma unroll
+				for (int k = 0; k < kCandMax; ++k) pv[k] = (T)rl(pk, l0 + k);
+				pred = chain_predict<T>(n0, pv);
+			} else {
+				int64_t acc = 0;
+				uint32_t n = 0;
+				fan_ids(tp, order_v[vb], vb, [&](uint32_t a, uint32_t b, uint32_t o) {
+					acc += (int64_t)cm::parallelogram<T>((T)old_value(a, vb), (T)old_value(b, vb), (T)old_value(o, vb), q);
+					++n;
+				});
+				if (n) pred = (T)cm::mean_of(acc, (int64_t)n);
+			}
+			const uint32_t c0 = rl(code, s);
+			const T val = cm::value_from_residual<T>((typename cm::word<sizeof(T)>::u)c0, pred, q);
+			if (lane == 0) ring[vb & mask] = val;
+			return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)val);
+		};
+		// the run [s, e) from the value x before it: apply the composed maps, verify every vertex against its true arithmetic
+		auto finish_run = [&](uint32_t s, uint32_t e, Map3 F, uint32_t x) -> uint32_t {
+			const bool active = (uint32_t)lane >= s && (uint32_t)lane < e;
+			uint32_t xh = 0;
 			for (int attempt = 0;; ++attempt) {
-				Map3 F = scan3(g);
-				asm volatile("" : "+v"(F.k), "+v"(F.A), "+v"(F.D));   // the whole scan is computed before the wait below, not sunk behind it
-				if (early && !waited) { HRY_CLK(++ck_early;) wait_prev(); x_in = tile_idx ? x_prev : (uint32_t)ring[(tb + s - 1u) & mask]; }
-				xh = (uint32_t)((((int32_t)x_in + F.A) >> F.k) + F.D);
+				if (attempt) F = scan_run(s, e);
+				xh = (uint32_t)((((int32_t)x + F.A) >> F.k) + F.D);
 				uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xh, 0x138, 0xf, 0xf, false);   // wave_shr:1
-				xp = (uint32_t)lane == s ? x_in : xp;
+				xp = (uint32_t)lane == s ? x : xp;
 				const uint32_t p0 = med3_i32((int32_t)(xp + (uint32_t)bo0), 0, (int32_t)top);
 				const uint32_t pred = two ? (p0 + p1c + 1u) >> 1 : p0;
 				const uint32_t tv = keepl ? v0 : (uf.apply(pred, top) & wrap);
@@ -1158,10 +1178,63 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				}
 			}
 			if (active) ring[v & mask] = (T)xh;
-			x_out = rl(xh, e - 1u);
-			s = e;
-			first_run = false;
+			return rl(xh, e - 1u);
+		};
+		uint32_t x = 0;   // value of the vertex before the current position (uniform)
+		if (nheads <= 8u) {
+			// ---- prepared tile: the maps of the vertices that are not heads (all their sources but the predecessor are final) and
+			// the scans of the runs between the heads, all of it before the tile before this one is finished
+			build_maps(valid && !head, tb + lo, 64u);
+			Map3 Fm = g;
+			if (!valid || head) { Fm.k = 0; Fm.A = 0; Fm.D = 0; }
+			// ONE segmented scan for all the runs of the tile: a run starts at the tile's first vertex and behind every head
+			if ((uint32_t)lane == lo || head || ((headmask << 1) >> lane) & 1ull) Fm.k |= kRunStart;
+			Fm = scan3_runs(Fm);
+			asm volatile("" : "+v"(Fm.k), "+v"(Fm.A), "+v"(Fm.D));   // the scan is computed before the wait below, not sunk behind it
+			auto run_end = [&](uint32_t s) -> uint32_t {   // the run that starts at s ends before the next head
+				const uint64_t above = headmask & ~((1ull << s) - 1ull);
+				return above ? (uint32_t)__builtin_ctzll(above) : hi;
+			};
+			HRY_CLK(++ck_early;)
+			wait_prev();
+			x = x_prev;   // the first vertex of a slice is never chained
+			for (uint32_t s = lo; s < hi;) {
+				if ((headmask >> s) & 1ull) {
+					if ((rowmask >> s) & 1ull) x = eval_alone(s, true, (uint32_t)__builtin_popcountll(rowmask & ((1ull << s) - 1ull)));
+					else {
+						// on its own lane, every source from the ring (the predecessor included): LaneEvalSmall::eval
+						HRY_CLK(++ck_bigs; ck_is_clean = false;)
+						const uint32_t h0 = ring[slot0], h1 = ring[slot1], h2 = ring[slot2], h3 = ring[slot3], h4 = ring[slot4], h5 = ring[slot5];
+						const uint32_t q0 = med3_i32((int32_t)(h0 + h1 - h2), 0, (int32_t)top), q1 = med3_i32((int32_t)(h3 + h4 - h5), 0, (int32_t)top);
+						const uint32_t val = uf.apply((q0 + q1 + 1u) >> 1, top) & wrap;
+						if ((uint32_t)lane == s) ring[v & mask] = (T)val;
+						x = rl(val, s);
+					}
+					++s;
+					continue;
+				}
+				const uint32_t e = run_end(s);
+				HRY_CLK(++ck_runs; if (s != lo) { ++ck_r2; ck_r2len += e - s; })
+				x = finish_run(s, e, Fm, x);
+				s = e;
+			}
+		} else {
+			// ---- a tile with many recent sources (small or irregular meshes): runs are cut where a vertex needs a source inside
+			// the run, and prepared when the vertices before them are final
+			wait_prev();
+			const uint64_t bigmask = __ballot(valid && nc == CR_BIG);
+			for (uint32_t s = lo; s < hi;) {
+				if ((bigmask >> s) & 1ull) { x = eval_alone(s, false, 0u); ++s; continue; }
+				const uint64_t above = s >= 63u ? 0ull : ~((2ull << s) - 1ull);
+				const uint64_t cut = (__ballot(valid && need_rel > s) | bigmask) & above;
+				const uint32_t e = cut ? (uint32_t)__builtin_ctzll(cut) : hi;
+				HRY_CLK(++ck_runs; ck_is_clean = false;)
+				build_maps((uint32_t)lane >= s && (uint32_t)lane < e, tb + s, s);
+				x = finish_run(s, e, scan_run(s, e), 0u);
+				s = e;
+			}
 		}
+		x_out = x;
 		// the tile is finished: its values are in the ring before the counter moves (release)
 		wait_prev();
 		asm volatile("" ::: "memory");   // the ring writes of this tile are issued before the word that announces them (LDS runs a wavefront's accesses in order)
@@ -1177,7 +1250,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if (lane == 0) __hip_atomic_fetch_max(&sync[1], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // flushes of different wavefronts may finish out of order
 		}
 	}
-	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu early %llu runs %llu bigs %llu retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_early, ck_runs, ck_bigs, ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
+	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu early %llu runs %llu (later runs %llu, mean length %llu, <8 %llu <16 %llu <32 %llu, after a big %llu) bigs %llu retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_early, ck_runs, ck_r2, ck_r2len / (ck_r2 ? ck_r2 : 1), ck_r2_8, ck_r2_16, ck_r2_32, ck_r2_afterbig, ck_bigs, ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
 	                                    ck_prep / ck_tiles, ck_wait / ck_tiles, ck_serial / ck_tiles, (unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin, ((unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin) / (ck_tiles * W));)
 }
 
