@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256) void k_faces_unfold(uint32_t n, ListDesc ld, u
 __device__ __forceinline__ uint32_t div_small(uint32_t x, uint32_t n)
 {
 	// floor(x / n) == (x * ceil(2^32 / n)) >> 32 whenever x * n < 2^32
-	uint32_t inv = n == 1 ? 0u : (uint32_t)(0x100000000ull / n) + 1u;
-	return n == 1 ? x : __umulhi(x, inv);
+	// ceil(2^32 / n) for n = 2 .. 8 spelled out: the 64-bit division that would compute it costs more than a vertex of the chain
+	const uint32_t inv = n == 2 ? 0x80000000u : n == 3 ? 0x55555556u : n == 4 ? 0x40000000u : n == 5 ? 0x33333334u : n == 6 ? 0x2aaaaaabu : n == 7 ? 0x24924925u : n == 8 ? 0x20000000u
+	                     : n <= 1 ? 0u : (uint32_t)(0x100000000ull / n) + 1u;
+	return n <= 1 ? x : __umulhi(x, inv);
 }
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane_idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane_idx); }
@@ -816,6 +818,10 @@ constexpr uint32_t kRing3Near = kRing3 - 64;   // a source this close to its ver
 #else
 #define HRY_CLK(...)
 #endif
+#ifndef HRY_CHAIN_MAX_HEADS
+#define HRY_CHAIN_MAX_HEADS 8
+#endif
+constexpr uint32_t kMaxHeads = HRY_CHAIN_MAX_HEADS;   // heads per prepared tile
 constexpr uint32_t kHand0 = 2, kHand = 64;     // hand-over words of the chain's wavefront team behind its two control words
 enum { CR_NC = 3, CR_BIG = 3, CR_POS_SHIFT = 2, CR_POS_NONE = 7, CR_FAR = 1 << 5, CR_NEED_SHIFT = 6 };
 
@@ -989,7 +995,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	if (threadIdx.x < kHand) sync[kHand0 + threadIdx.x] = 0;
 	__syncthreads();
 	bool given_up = false;
-	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_r2 = 0, ck_r2len = 0, ck_r2_8 = 0, ck_r2_16 = 0, ck_r2_32 = 0, ck_r2_afterbig = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
+	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_r2 = 0, ck_r2len = 0, ck_r2_8 = 0, ck_r2_16 = 0, ck_r2_32 = 0, ck_r2_afterbig = 0, ck_rowt = 0, ck_rown = 0, ck_slott = 0, ck_slotn = 0, ck_runt = 0, ck_dense = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
 	request(t_first + 64 * wv);
 	for (uint32_t tb = t_first + 64 * wv; tb < seg_end && !given_up; tb += 64 * W) {
 		if (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // another wavefront's wait ran into its bound
@@ -1049,12 +1055,16 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		const uint32_t nheads = (uint32_t)__builtin_popcountll(headmask);
 		// a head with at most two candidates, all of them in the ring, is evaluated on its own lane from its record's slots;
 		// the others (more candidates, or a source older than the ring) from their candidate rows, which are fetched ahead
-		const uint64_t rowmask = __ballot(head && (nc == CR_BIG || far));
+		const uint64_t bigmask = __ballot(valid && nc == CR_BIG);
+		const uint64_t rowheads = __ballot(head && (nc == CR_BIG || far));
+		// otherwise: a tile with many recent sources (small or irregular meshes), cut into runs as they come
+		const bool prepared = nheads <= kMaxHeads && (uint32_t)__builtin_popcountll(rowheads) <= 8u;
+		const uint64_t rowmask = prepared ? rowheads : bigmask;
 		// The candidate rows of the tile's first eight heads are fetched now, ahead of the chain (0.2 - 0.7 heads per tile): lane l
 		// holds candidate l & 7 of the (l >> 3)-th of them.  Sources older than the ring are final in the records by now and are
 		// fetched here as well: on the serial path each of them is a trip to memory (1 - 2 us, as much as two whole tiles).
 		uint32_t pf_pos = 64u, pf_n = 0, pf_a = 0, pf_b = 0, pf_o = 0, pf_va = 0, pf_vb = 0, pf_vo = 0, pf_far = 0;
-		if (rowmask && nheads <= 8u) {
+		if (rowmask) {
 			uint64_t bm = rowmask;
 #pragma nounroll
 			for (uint32_t j = 0; j < 8u && bm; ++j) { const uint32_t p = (uint32_t)__builtin_ctzll(bm); bm &= bm - 1ull; if ((uint32_t)lane >> 3 == j) pf_pos = p; }
@@ -1121,11 +1131,11 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if (n0 != 0xff) {
 				uint32_t pk = 0;
 				if (fetched) {
-					if ((uint32_t)lane >> 3 == bj && (uint32_t)(lane & 7) < n0) {
-						auto near_value = [&](uint32_t id) -> uint32_t { return id >= vb ? 0u : (uint32_t)ring[id & mask]; };   // whatever is not far is in the ring
-						const uint32_t a = (pf_far & 1u) ? pf_va : near_value(pf_a), b = (pf_far & 2u) ? pf_vb : near_value(pf_b), o = (pf_far & 4u) ? pf_vo : near_value(pf_o);
-						pk = (uint32_t)cm::parallelogram<T>((T)a, (T)b, (T)o, q);
-					}
+					// branch-free: every lane reads the ring at its own (valid or zero) ids; prediction.h:121-138 as in LaneEvalSmall
+					const uint32_t ra = ring[pf_a & mask], rb = ring[pf_b & mask], ro = ring[pf_o & mask];
+					const uint32_t a = (pf_far & 1u) ? pf_va : ra, b = (pf_far & 2u) ? pf_vb : rb, o = (pf_far & 4u) ? pf_vo : ro;
+					const bool mine = (uint32_t)lane >> 3 == bj && (uint32_t)(lane & 7) < n0;
+					pk = mine ? med3_i32((int32_t)(a + b - o), 0, (int32_t)top) : 0u;
 				} else if ((uint32_t)lane < n0) {
 					const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
 					pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
@@ -1143,10 +1153,10 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				});
 				if (n) pred = (T)cm::mean_of(acc, (int64_t)n);
 			}
-			const uint32_t c0 = rl(code, s);
-			const T val = cm::value_from_residual<T>((typename cm::word<sizeof(T)>::u)c0, pred, q);
-			if (lane == 0) ring[vb & mask] = val;
-			return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)val);
+			// prediction.h:46-64 through the vertex's own lane (uf holds its residual code)
+			const uint32_t val = uf.apply((uint32_t)pred, top) & wrap;
+			if ((uint32_t)lane == s) ring[vb & mask] = (T)val;
+			return rl(val, s);
 		};
 		// the run [s, e) from the value x before it: apply the composed maps, verify every vertex against its true arithmetic
 		auto finish_run = [&](uint32_t s, uint32_t e, Map3 F, uint32_t x) -> uint32_t {
@@ -1181,7 +1191,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			return rl(xh, e - 1u);
 		};
 		uint32_t x = 0;   // value of the vertex before the current position (uniform)
-		if (nheads <= 8u) {
+		if (prepared) {
 			// ---- prepared tile: the maps of the vertices that are not heads (all their sources but the predecessor are final) and
 			// the scans of the runs between the heads, all of it before the tile before this one is finished
 			build_maps(valid && !head, tb + lo, 64u);
@@ -1200,7 +1210,8 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			x = x_prev;   // the first vertex of a slice is never chained
 			for (uint32_t s = lo; s < hi;) {
 				if ((headmask >> s) & 1ull) {
-					if ((rowmask >> s) & 1ull) x = eval_alone(s, true, (uint32_t)__builtin_popcountll(rowmask & ((1ull << s) - 1ull)));
+					HRY_CLK(const unsigned long long h0t = __builtin_amdgcn_s_memtime();)
+					if ((rowmask >> s) & 1ull) { x = eval_alone(s, true, (uint32_t)__builtin_popcountll(rowmask & ((1ull << s) - 1ull))); HRY_CLK(asm volatile("" :: "s"(x)); ck_rowt += __builtin_amdgcn_s_memtime() - h0t; ++ck_rown;) }
 					else {
 						// on its own lane, every source from the ring (the predecessor included): LaneEvalSmall::eval
 						HRY_CLK(++ck_bigs; ck_is_clean = false;)
@@ -1209,22 +1220,30 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 						const uint32_t val = uf.apply((q0 + q1 + 1u) >> 1, top) & wrap;
 						if ((uint32_t)lane == s) ring[v & mask] = (T)val;
 						x = rl(val, s);
+						HRY_CLK(asm volatile("" :: "s"(x)); ck_slott += __builtin_amdgcn_s_memtime() - h0t; ++ck_slotn;)
 					}
 					++s;
 					continue;
 				}
 				const uint32_t e = run_end(s);
 				HRY_CLK(++ck_runs; if (s != lo) { ++ck_r2; ck_r2len += e - s; })
+				HRY_CLK(const unsigned long long r0t = __builtin_amdgcn_s_memtime();)
 				x = finish_run(s, e, Fm, x);
+				HRY_CLK(asm volatile("" :: "s"(x)); ck_runt += __builtin_amdgcn_s_memtime() - r0t;)
 				s = e;
 			}
 		} else {
 			// ---- a tile with many recent sources (small or irregular meshes): runs are cut where a vertex needs a source inside
 			// the run, and prepared when the vertices before them are final
 			wait_prev();
-			const uint64_t bigmask = __ballot(valid && nc == CR_BIG);
+			HRY_CLK(++ck_dense;)
 			for (uint32_t s = lo; s < hi;) {
-				if ((bigmask >> s) & 1ull) { x = eval_alone(s, false, 0u); ++s; continue; }
+				if ((bigmask >> s) & 1ull) {
+					const uint32_t bj = (uint32_t)__builtin_popcountll(bigmask & ((1ull << s) - 1ull));
+					x = eval_alone(s, bj < 8u, bj);
+					++s;
+					continue;
+				}
 				const uint64_t above = s >= 63u ? 0ull : ~((2ull << s) - 1ull);
 				const uint64_t cut = (__ballot(valid && need_rel > s) | bigmask) & above;
 				const uint32_t e = cut ? (uint32_t)__builtin_ctzll(cut) : hi;
@@ -1238,7 +1257,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		// the tile is finished: its values are in the ring before the counter moves (release)
 		wait_prev();
 		asm volatile("" ::: "memory");   // the ring writes of this tile are issued before the word that announces them (LDS runs a wavefront's accesses in order)
-		if (lane == 0) __hip_atomic_store(&sync[kHand0 + (tile_idx & (kHand - 1u))], ((tile_idx + 1u) << 16) | (x_out & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_store(&sync[kHand0 + (tile_idx & (kHand - 1u))], ((tile_idx + 1u) << 16) | (x_out & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // every lane, the same word: no exec juggling
 		HRY_CLK(const unsigned long long ck_d = __builtin_amdgcn_s_memtime() - ck_t1; ck_serial += ck_d; if (ck_is_clean && ck_runs - ck_runs0 == 1) { ck_clean += ck_d; ++ck_clean_n; })
 		// every 64 tiles, and at the end, the owner of the tile sends the finished values to the records
 		const bool last_tile = tb + 64 >= seg_end;
@@ -1250,7 +1269,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if (lane == 0) __hip_atomic_fetch_max(&sync[1], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // flushes of different wavefronts may finish out of order
 		}
 	}
-	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu early %llu runs %llu (later runs %llu, mean length %llu, <8 %llu <16 %llu <32 %llu, after a big %llu) bigs %llu retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_early, ck_runs, ck_r2, ck_r2len / (ck_r2 ? ck_r2 : 1), ck_r2_8, ck_r2_16, ck_r2_32, ck_r2_afterbig, ck_bigs, ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
+	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu (dense %llu) runs %llu at %llu (later runs %llu, mean length %llu), heads from rows %llu at %llu, from slots %llu at %llu, retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_dense, ck_runs, ck_runt / (ck_runs ? ck_runs : 1), ck_r2, ck_r2len / (ck_r2 ? ck_r2 : 1), ck_rown, ck_rowt / (ck_rown ? ck_rown : 1), ck_slotn, ck_slott / (ck_slotn ? ck_slotn : 1), ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
 	                                    ck_prep / ck_tiles, ck_wait / ck_tiles, ck_serial / ck_tiles, (unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin, ((unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin) / (ck_tiles * W));)
 }
 
@@ -1323,11 +1342,12 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 	const uint32_t per = ((nvtx + 255) / 256 + 7) / 8;
 	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand, per);
 }
-// wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8, default 4
-static uint32_t chain_waves()
+// wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8; by default 5 for a large mesh (long rings: more
+// look-ahead for the preparation costs no heads), 4 otherwise
+static uint32_t chain_waves(uint32_t nvtx)
 {
-	static const uint32_t w = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
-	return w;
+	static const uint32_t forced = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }();
+	return forced ? forced : nvtx >= (1u << 18) ? 5u : 4u;
 }
 // ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
 uint32_t chain_timeout_flags(hipStream_t st)
@@ -1360,7 +1380,7 @@ void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *orde
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		hipLaunchKernelGGL(kern, dim3((sel.n - 1) * 8 + 1), dim3(64 * chain_waves()), 0, st, cv, order_v, nvtx, cand, ncand, (const ChainRec*)crec, planes, ld, rec, sel, v_begin, v_end, chain_ring_floor(v_begin));
+		hipLaunchKernelGGL(kern, dim3((sel.n - 1) * 8 + 1), dim3(64 * chain_waves(nvtx)), 0, st, cv, order_v, nvtx, cand, ncand, (const ChainRec*)crec, planes, ld, rec, sel, v_begin, v_end, chain_ring_floor(v_begin));
 	};
 	go3(k_unpredict3_range<uint16_t>, 6); go3(k_unpredict3_range<uint8_t>, 8);
 }
@@ -1388,7 +1408,7 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64 * chain_waves()), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
+		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64 * chain_waves(nvtx)), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
 		                   segs, list_off, xs);
 	};
 	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + kQueue * kQueueCols * 4;
