@@ -211,7 +211,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 
 	std::exception_ptr consumer_error;
 	std::vector<SliceClock> clocks;
-	uint32_t min_slice = 1u << 16;   // (the chain is the longer path since the replay became lean: fewer, larger launches)
+	uint32_t min_slice = 1u << 15;   // replay and chain take about the same time per vertex: what is left behind the replay is the last slice (16 Ki: the consumer's launches become the longer path)
 	if (const char *e = getenv("HRY_PIPELINE_SLICE")) min_slice = std::max(64u, (uint32_t)strtoul(e, nullptr, 10));
 	// ... but the first slices are small and double up to that size: the chain is the longer path, what counts is how early it
 	// starts, and the early chunks of the vertex planes are short for exactly that (attr_chunk_len)
@@ -263,8 +263,12 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 				ReplayLive::Pub newest;
 				drain(false);
 				{
+					// polled: the chain's hand-over of the next slice should not wait for a wake-up either (a decode lasts milliseconds)
+					for (uint32_t spins = 0; live.announced.load(std::memory_order_acquire) == seen_seq; ++spins) {
+						if (spins < 2000) __builtin_ia32_pause();
+						else { drain(false); std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+					}
 					std::unique_lock<std::mutex> lk(live.mu);
-					live.cv.wait(lk, [&] { return live.pub.seq != seen_seq; });
 					newest = live.pub;
 					patches.insert(patches.end(), live.patches.begin(), live.patches.end());
 					live.patches.clear();
