@@ -1132,8 +1132,10 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				uint32_t pk = 0;
 				if (fetched) {
 					// branch-free: every lane reads the ring at its own (valid or zero) ids; prediction.h:121-138 as in LaneEvalSmall
-					const uint32_t ra = ring[pf_a & mask], rb = ring[pf_b & mask], ro = ring[pf_o & mask];
-					const uint32_t a = (pf_far & 1u) ? pf_va : ra, b = (pf_far & 2u) ? pf_vb : rb, o = (pf_far & 4u) ? pf_vo : ro;
+					uint32_t ia = pf_a, ib = pf_b, io = pf_o, fr = pf_far;
+					asm volatile("" : "+v"(ia), "+v"(ib), "+v"(io), "+v"(fr));   // addresses and tests computed here, for a head, not hoisted into every tile's serial part
+					const uint32_t ra = ring[ia & mask], rb = ring[ib & mask], ro = ring[io & mask];
+					const uint32_t a = (fr & 1u) ? pf_va : ra, b = (fr & 2u) ? pf_vb : rb, o = (fr & 4u) ? pf_vo : ro;
 					const bool mine = (uint32_t)lane >> 3 == bj && (uint32_t)(lane & 7) < n0;
 					pk = mine ? med3_i32((int32_t)(a + b - o), 0, (int32_t)top) : 0u;
 				} else if ((uint32_t)lane < n0) {
@@ -1169,7 +1171,9 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				xp = (uint32_t)lane == s ? x : xp;
 				const uint32_t p0 = med3_i32((int32_t)(xp + (uint32_t)bo0), 0, (int32_t)top);
 				const uint32_t pred = two ? (p0 + p1c + 1u) >> 1 : p0;
-				const uint32_t tv = keepl ? v0 : (uf.apply(pred, top) & wrap);
+				uint32_t ap = uf.apply(pred, top) & wrap;
+				asm volatile("" : "+v"(ap));   // straight-line: a branch around ten instructions costs a lone wavefront more than they do
+				const uint32_t tv = keepl ? v0 : ap;
 				const uint64_t bad = __ballot(active && tv != xh);
 				if (!bad) break;
 				HRY_CLK(++ck_retry; ck_is_clean = false;)
