@@ -6,6 +6,7 @@ from harry_amd import codec as hc, meshgen as mg, _native as nat
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 708
 mesh = mg.torus(n, n, seed=2)
 m0 = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+m0.twin()   # twin matching (left pending by the readers) is not part of the walk
 L = nat.load()
 for name, fn in (("plain", L.hry_walk_run_plain), ("model", L.hry_walk_run)):
     best = 1e9
