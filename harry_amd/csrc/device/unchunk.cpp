@@ -299,7 +299,11 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 						patches.clear();
 					}
 					up.put(cx.d_order_v.as<uint32_t>() + v_done, order_v.data() + v_done, ((size_t)v_hi - v_done) * 4);
-					launch_slice_prepare(cx.stream2, cv, cx.d_order_v.as<uint32_t>(), v_done, v_hi, d_cand, d_ncand, d_crec);
+					// what the kernels of this slice may follow: the half-edges that are on the device now (a link into the part
+					// that is not -- made after the publication this slice rests on -- reads as a border, which is what it was then)
+					ConnView cvs = cv;
+					cvs.ne = he_up;
+					launch_slice_prepare(cx.stream2, cvs, cx.d_order_v.as<uint32_t>(), v_done, v_hi, d_cand, d_ncand, d_crec);
 					HIP_OK(hipEventRecord(prepared, cx.stream2));
 					HIP_OK(hipStreamWaitEvent(cx.stream, prepared, 0));
 					// the residual codes of this slice: the groups of attribute streams that end inside it or before
@@ -307,7 +311,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 					SliceClock ck;
 					HIP_OK(hipEventCreate(&ck.a)); HIP_OK(hipEventCreate(&ck.b));
 					HIP_OK(hipEventRecord(ck.a, cx.stream));
-					launch_slice_chain(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>());
+					launch_slice_chain(cx.stream, cvs, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>());
 					HIP_OK(hipEventRecord(ck.b, cx.stream));
 					clocks.push_back(ck);
 					{

@@ -50,10 +50,15 @@ struct TopoD {
 template <typename F> __device__ __forceinline__ void fan_ids(const TopoD &tp, uint32_t ein, uint32_t v, F &&f)
 {
 	auto offer = [&](uint32_t a, uint32_t b, uint32_t o) { if (a < v && b < v && o < v) f(a, b, o); };
+	// A twin at or beyond c.ne is no neighbour: the pipelined decode has uploaded the connectivity up to there only (c.ne = the
+	// half-edges on the device).  Such a link was made after the vertex became final and leads to a face with a younger vertex,
+	// which the rank filter would reject -- but what lies behind it on the device is not that face yet, it is whatever the buffer
+	// held before.  (Elsewhere c.ne is the table's size and this reads a damaged entry as a border.)
+	auto twin_of = [&](uint32_t e) { const uint32_t t = tp.c.twin[e]; return t < tp.c.ne ? t : e; };
 	auto visit = [&](uint32_t e) {
 		uint32_t d = tp.degree(e);
 		if (d == 3) {
-			uint32_t e1 = tp.next(e), t = tp.c.twin[e1];
+			uint32_t e1 = tp.next(e), t = twin_of(e1);
 			if (t == e1) return;
 			uint32_t tn = tp.next(t);
 			offer(tp.c.org[t], tp.c.org[tn], tp.c.org[tp.next(tn)]);
@@ -70,20 +75,20 @@ template <typename F> __device__ __forceinline__ void fan_ids(const TopoD &tp, u
 	bool border = false;
 	for (;;) {
 		visit(e);
-		t = tp.c.twin[e];
+		t = twin_of(e);
 		if (t == e) { border = true; break; }
 		e = tp.next(t);
 		if (e == ein || ++steps > kMaxSteps) break;
 	}
 	if (!border) return;
 	e = tp.prev(ein);
-	t = tp.c.twin[e];
+	t = twin_of(e);
 	if (e == t) return;
 	e = t;
 	do {
 		visit(e);
 		e = tp.prev(e);
-		t = tp.c.twin[e];
+		t = twin_of(e);
 		if (e == t) break;
 		e = t;
 	} while (e != ein && ++steps <= kMaxSteps);

@@ -282,3 +282,28 @@ def test_chunked_component_types_and_chain_variants(cx, case):
     same_mesh(cx.read_hry(got), ref_dec)
     # the reference-format stream of the same mesh through the host reader + the same device reconstruction
     same_mesh(cx.read_hry(cx.write_hry(a.clone())), ref_dec)
+
+
+def test_pipelined_decode_after_another_mesh(cx, monkeypatch):
+    """The slices of the pipelined decode run on connectivity that is uploaded behind the replay.  A twin link made after the
+    publication a slice rests on can point into the part of the device arrays that is not uploaded yet -- which holds whatever
+    the previous decode left there.  Found by scripts/chain_stress.py: the first decode after a different mesh saw extra
+    candidates (a fan walk that continued through the previous mesh's faces); the kernels now stop at the uploaded half-edges."""
+    other = mg.torus(138, 156, polys="quad", seed=25, sigma=3.5e-2).to_ply()
+    a0 = hc.Mesh.from_ply(other)
+    cx.requant(a0, [(1, -1, 4)])
+    first = cx.write_hry(a0, profile=hc.PROFILE_CHUNKED)
+    ply = mg.icosphere(6, seed=52, sigma=1.5e-2).to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    cx.requant(a, [(1, -1, 7)])
+    o.requant([(1, -1, 7)])
+    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
+    monkeypatch.setenv("HRY_PIPELINE_MIN_VERTICES", "0")
+    for faces, slice_ in ((1529, 10752), (700, 4096), (3000, 8192)):
+        monkeypatch.setenv("HRY_NO_PIPELINE", "1")
+        cx.read_hry(first)                       # fills the device's connectivity arrays with another mesh
+        monkeypatch.delenv("HRY_NO_PIPELINE")
+        monkeypatch.setenv("HRY_PIPELINE_FACES", str(faces))
+        monkeypatch.setenv("HRY_PIPELINE_SLICE", str(slice_))
+        same_mesh(cx.read_hry(got), ref_dec)
