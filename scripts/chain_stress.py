@@ -29,12 +29,15 @@ t0 = time.time()
 only = os.environ.get("STRESS_ONLY")
 failed = 0
 for it in range(n_meshes):
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 7 if os.environ.get("STRESS_BIG") else 6))
     sigma = float(10.0 ** rng.uniform(-5, -0.5))
     seed = int(rng.integers(1, 99))
     polys = ["tri", "quad", "mixed"][int(rng.integers(0, 3))]
     dims = [int(x) for x in rng.integers(0, 1 << 30, 4)]
     q = int(rng.integers(2, 17))
+    lossless = bool(rng.integers(0, 4) == 0)
+    from_compat = bool(rng.integers(0, 4) == 0)     # decode the reference-format stream (host entropy decoder + device reconstruction)
+    chunk = [0, 0, 1024, 4096, 20000][int(rng.integers(0, 5))]
     mode = int(rng.integers(0, 3))
     faces, slice_ = int(rng.integers(64, 3000)), 64 * int(rng.integers(1, 200))
     if only is not None and it != int(only):
@@ -50,16 +53,24 @@ for it in range(n_meshes):
         base = mg.multi_component(r(0, 2, 30), r(1, 8, 60), r(2, 8, 60), polys=polys, seed=seed)
     elif kind == 4:
         base = mg.with_nonmanifold(mg.torus(r(0, 30, 120), r(1, 30, 120), polys=polys, seed=seed, sigma=sigma), r(2, 1, 40), r(3, 1, 20), seed=seed)
-    else:
+    elif kind == 5:
         base = mg.with_colors(mg.torus(r(0, 30, 160), r(1, 30, 160), normals=True, seed=seed, sigma=sigma))
+    else:   # large enough for the pipelined decode with its production parameters (STRESS_BIG=1)
+        base = mg.torus(r(0, 370, 520), r(1, 370, 520), polys="tri", seed=seed, sigma=sigma) if dims[2] & 1 else mg.grid(r(0, 370, 520), r(1, 370, 520), seed=seed, sigma=sigma)
+        lossless, mode = False, 2
     ply = base.to_ply()
     a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
-    quant = [(1, -1, q)] if kind != 5 else [(1, c, q) for c in range(6)]   # (the colours are bytes already)
-    cx.requant(a, quant)
-    o.requant(quant)
-    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
-    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED)
-    assert got == o.clone().encode_chunked(0).data, "container"
+    quant = [] if lossless else [(1, -1, q)] if kind != 5 else [(1, c, q) for c in range(6)]   # (the colours are bytes already)
+    if quant:
+        cx.requant(a, quant)
+        o.requant(quant)
+    compat = o.clone().encode().data
+    ref_dec = op.Mesh.from_hry(compat)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=chunk)
+    assert got == o.clone().encode_chunked(chunk).data, "container"
+    if from_compat:
+        assert cx.write_hry(a.clone(), profile=hc.PROFILE_COMPAT) == compat, "reference-format stream"
+        got = compat
     for k in ("HRY_NO_PIPELINE", "HRY_PIPELINE_MIN_VERTICES", "HRY_PIPELINE_FACES", "HRY_PIPELINE_SLICE"):
         os.environ.pop(k, None)
     if mode == 0:
@@ -96,6 +107,7 @@ for it in range(n_meshes):
         print(f"    candidate counts differ at {len(dn)} vertices: {dn[:10].tolist()}; bad {nc_b[dn[:10]].tolist()} good {nc_g[dn[:10]].tolist()}")
         for v in dn[:4]:
             print(f"      v {v}: bad rows {cd_b[v][:3 * max(1, min(8, int(nc_b[v])))].tolist()}  good rows {cd_g[v][:3 * max(1, min(8, int(nc_g[v])))].tolist()}")
-    print(f"{it:3d} kind {kind} {polys:5s} nv {a.nv:6d} q{q:<2d} sigma {sigma:.1e} seed {seed} mode {mode} faces {faces} slice {slice_}  {verdict}  ({time.time() - t0:.0f} s)", flush=True)
+    src = "compat" if from_compat else "chunk%d" % chunk
+    print(f"{it:3d} kind {kind} {polys:5s} nv {a.nv:6d} q{0 if lossless else q:<2d} {src} sigma {sigma:.1e} seed {seed} mode {mode} faces {faces} slice {slice_}  {verdict}  ({time.time() - t0:.0f} s)", flush=True)
 print("all equal" if not failed else f"{failed} MISMATCHES")
 sys.exit(1 if failed else 0)
