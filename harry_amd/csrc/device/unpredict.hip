@@ -827,6 +827,10 @@ constexpr uint32_t kRing3Near = kRing3 - 64;   // a source this close to its ver
 #define HRY_CHAIN_MAX_HEADS 8
 #endif
 constexpr uint32_t kMaxHeads = HRY_CHAIN_MAX_HEADS;   // heads per prepared tile
+#ifndef HRY_CHAIN_MAX_HEADS_LATE
+#define HRY_CHAIN_MAX_HEADS_LATE 12
+#endif
+constexpr uint32_t kMaxHeadsLate = HRY_CHAIN_MAX_HEADS_LATE;   // heads of a tile that is prepared when its turn has come
 constexpr uint32_t kHand0 = 2, kHand = 64;     // hand-over words of the chain's wavefront team behind its two control words
 enum { CR_NC = 3, CR_BIG = 3, CR_POS_SHIFT = 2, CR_POS_NONE = 7, CR_FAR = 1 << 5, CR_NEED_SHIFT = 6 };
 
@@ -1200,29 +1204,27 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			return rl(xh, e - 1u);
 		};
 		uint32_t x = 0;   // value of the vertex before the current position (uniform)
-		if (prepared) {
-			// ---- prepared tile: the maps of the vertices that are not heads (all their sources but the predecessor are final) and
-			// the scans of the runs between the heads, all of it before the tile before this one is finished
-			build_maps(valid && !head, tb + lo, 64u);
-			Map3 Fm = g;
-			if (!valid || head) { Fm.k = 0; Fm.A = 0; Fm.D = 0; }
-			// ONE segmented scan for all the runs of the tile: a run starts at the tile's first vertex and behind every head
-			if ((uint32_t)lane == lo || head || ((headmask << 1) >> lane) & 1ull) Fm.k |= kRunStart;
-			Fm = scan3_runs(Fm);
-			asm volatile("" : "+v"(Fm.k), "+v"(Fm.A), "+v"(Fm.D));   // the scan is computed before the wait below, not sunk behind it
-			auto run_end = [&](uint32_t s) -> uint32_t {   // the run that starts at s ends before the next head
-				const uint64_t above = headmask & ~((1ull << s) - 1ull);
-				return above ? (uint32_t)__builtin_ctzll(above) : hi;
-			};
-			HRY_CLK(++ck_early;)
-			wait_prev();
-			x = x_prev;   // the first vertex of a slice is never chained
+		// the maps of the vertices that are not heads and ONE segmented scan for all the runs between the heads (a run starts at
+		// the tile's first vertex and behind every head)
+		auto compose_runs = [&](uint64_t hm) -> Map3 {
+			const bool hd = (hm >> lane) & 1ull;
+			build_maps(valid && !hd, tb + lo, 64u);
+			Map3 F = g;
+			if (!valid || hd) { F.k = 0; F.A = 0; F.D = 0; }
+			if ((uint32_t)lane == lo || hd || ((hm << 1) >> lane) & 1ull) F.k |= kRunStart;
+			return scan3_runs(F);
+		};
+		// heads one by one (alone: from their candidate rows, fetched ahead for the first eight of pfm; else on their own lane from
+		// the record's slots, the predecessor included: LaneEvalSmall::eval), the runs between them from their composed maps
+		auto serial_part = [&](uint64_t hm, uint64_t alone, uint64_t pfm, const Map3 &Fm) {
 			for (uint32_t s = lo; s < hi;) {
-				if ((headmask >> s) & 1ull) {
+				if ((hm >> s) & 1ull) {
 					HRY_CLK(const unsigned long long h0t = __builtin_amdgcn_s_memtime();)
-					if ((rowmask >> s) & 1ull) { x = eval_alone(s, true, (uint32_t)__builtin_popcountll(rowmask & ((1ull << s) - 1ull))); HRY_CLK(asm volatile("" :: "s"(x)); ck_rowt += __builtin_amdgcn_s_memtime() - h0t; ++ck_rown;) }
-					else {
-						// on its own lane, every source from the ring (the predecessor included): LaneEvalSmall::eval
+					if ((alone >> s) & 1ull) {
+						const uint32_t bj = (uint32_t)__builtin_popcountll(pfm & ((1ull << s) - 1ull));
+						x = eval_alone(s, ((pfm >> s) & 1ull) != 0 && bj < 8u, bj);
+						HRY_CLK(asm volatile("" :: "s"(x)); ck_rowt += __builtin_amdgcn_s_memtime() - h0t; ++ck_rown;)
+					} else {
 						HRY_CLK(++ck_bigs; ck_is_clean = false;)
 						const uint32_t h0 = ring[slot0], h1 = ring[slot1], h2 = ring[slot2], h3 = ring[slot3], h4 = ring[slot4], h5 = ring[slot5];
 						const uint32_t q0 = med3_i32((int32_t)(h0 + h1 - h2), 0, (int32_t)top), q1 = med3_i32((int32_t)(h3 + h4 - h5), 0, (int32_t)top);
@@ -1234,32 +1236,52 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 					++s;
 					continue;
 				}
-				const uint32_t e = run_end(s);
+				const uint64_t above = hm & ~((1ull << s) - 1ull);   // the run that starts at s ends before the next head
+				const uint32_t e = above ? (uint32_t)__builtin_ctzll(above) : hi;
 				HRY_CLK(++ck_runs; if (s != lo) { ++ck_r2; ck_r2len += e - s; })
 				HRY_CLK(const unsigned long long r0t = __builtin_amdgcn_s_memtime();)
 				x = finish_run(s, e, Fm, x);
 				HRY_CLK(asm volatile("" :: "s"(x)); ck_runt += __builtin_amdgcn_s_memtime() - r0t;)
 				s = e;
 			}
+		};
+		if (prepared) {
+			// ---- prepared tile: everything but the heads before the tile before this one is finished
+			Map3 Fm = compose_runs(headmask);
+			asm volatile("" : "+v"(Fm.k), "+v"(Fm.A), "+v"(Fm.D));   // the scan is computed before the wait below, not sunk behind it
+			HRY_CLK(++ck_early;)
+			wait_prev();
+			x = x_prev;   // the first vertex of a slice is never chained
+			serial_part(headmask, rowheads, rowheads, Fm);
 		} else {
-			// ---- a tile with many recent sources (small or irregular meshes): runs are cut where a vertex needs a source inside
-			// the run, and prepared when the vertices before them are final
+			// ---- a tile with many recent sources (small or irregular meshes, the last rings of a closing border).  Most of them
+			// are recent but not of this tile: once the tiles before it are finished they are final, and the tile is prepared THEN,
+			// with heads only where a source lies inside the tile itself
 			wait_prev();
 			HRY_CLK(++ck_dense;)
-			for (uint32_t s = lo; s < hi;) {
-				if ((bigmask >> s) & 1ull) {
-					const uint32_t bj = (uint32_t)__builtin_popcountll(bigmask & ((1ull << s) - 1ull));
-					x = eval_alone(s, bj < 8u, bj);
-					++s;
-					continue;
+			const bool inner = valid && (nc == CR_BIG || (nc != 0u && gap <= (uint32_t)lane - lo && gap <= (uint32_t)lane));   // the source is a vertex of this tile
+			const uint64_t innermask = __ballot(inner);
+			if ((uint32_t)__builtin_popcountll(innermask) <= kMaxHeadsLate) {
+				x = x_prev;
+				const Map3 Fm = compose_runs(innermask);
+				serial_part(innermask, __ballot(inner && (nc == CR_BIG || far)), bigmask, Fm);
+			} else {
+				// runs are cut where a vertex needs a source inside the run, and prepared when the vertices before them are final
+				for (uint32_t s = lo; s < hi;) {
+					if ((bigmask >> s) & 1ull) {
+						const uint32_t bj = (uint32_t)__builtin_popcountll(bigmask & ((1ull << s) - 1ull));
+						x = eval_alone(s, bj < 8u, bj);
+						++s;
+						continue;
+					}
+					const uint64_t above = s >= 63u ? 0ull : ~((2ull << s) - 1ull);
+					const uint64_t cut = (__ballot(valid && need_rel > s) | bigmask) & above;
+					const uint32_t e = cut ? (uint32_t)__builtin_ctzll(cut) : hi;
+					HRY_CLK(++ck_runs; ck_is_clean = false;)
+					build_maps((uint32_t)lane >= s && (uint32_t)lane < e, tb + s, s);
+					x = finish_run(s, e, scan_run(s, e), 0u);
+					s = e;
 				}
-				const uint64_t above = s >= 63u ? 0ull : ~((2ull << s) - 1ull);
-				const uint64_t cut = (__ballot(valid && need_rel > s) | bigmask) & above;
-				const uint32_t e = cut ? (uint32_t)__builtin_ctzll(cut) : hi;
-				HRY_CLK(++ck_runs; ck_is_clean = false;)
-				build_maps((uint32_t)lane >= s && (uint32_t)lane < e, tb + s, s);
-				x = finish_run(s, e, scan_run(s, e), 0u);
-				s = e;
 			}
 		}
 		x_out = x;
