@@ -1151,10 +1151,14 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 					const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
 					pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
 				}
-				T pv[kCandMax];
-#pragma unroll
-				for (int k = 0; k < kCandMax; ++k) pv[k] = (T)rl(pk, l0 + k);
-				pred = chain_predict<T>(n0, pv);
+				// the candidates' sum: the lanes outside l0 .. l0 + 7 hold 0, three row shifts put the group's total on its last lane
+				// (transform.h:91 for unsigned values: (sum + n / 2) / n, as chain_predict)
+				uint32_t sum = pk & wrap;
+				sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x111, 0xf, 0xf, true);   // row_shr:1
+				sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x112, 0xf, 0xf, true);   // row_shr:2
+				sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x114, 0xf, 0xf, true);   // row_shr:4
+				const uint32_t tot = rl(sum, l0 + 7u) + (n0 >> 1);
+				pred = (T)(n0 == 1u ? tot : n0 == 2u ? tot >> 1 : n0 == 4u ? tot >> 2 : n0 == 8u ? tot >> 3 : div_small(tot, n0));
 			} else {
 				int64_t acc = 0;
 				uint32_t n = 0;
