@@ -231,7 +231,8 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	struct Landing { hipEvent_t ev; size_t off, len; };
 	std::deque<Landing> landing;
 	const int vstride = ldv.stride;
-	const void *node = callers_node_cpus();
+	const void *near = callers_neighbour_cpus();   // the consumer polls: near the replay's caches, but not on its core
+	const void *node = near ? near : callers_node_cpus();
 	std::thread consumer([&, node] {
 		try {
 			stay_on_node(node);

@@ -146,6 +146,43 @@ const void *callers_cache_cpus(unsigned *n_cpus)
 	return &it->second;
 }
 
+const void *callers_node_cpus();
+// the CPUs of the caller's last-level cache domain (else of its memory node) WITHOUT the caller's own core: for a helper that
+// polls while the caller runs a sequential loop -- on the caller's sibling hardware thread it would take issue slots from it
+const void *callers_neighbour_cpus()
+{
+	static std::mutex mu;
+	static std::unordered_map<int, cpu_set_t> *by_cpu = new std::unordered_map<int, cpu_set_t>();
+	if (getenv("HRY_NO_NUMA_BIND")) return nullptr;
+	const int cpu = sched_getcpu();
+	if (cpu < 0) return nullptr;
+	const void *base = callers_cache_cpus(nullptr);
+	if (!base) base = callers_node_cpus();
+	std::lock_guard<std::mutex> g(mu);
+	auto it = by_cpu->find(cpu);
+	if (it == by_cpu->end()) {
+		cpu_set_t cs;
+		if (base) cs = *(const cpu_set_t*)base;
+		else { CPU_ZERO(&cs); (void)sched_getaffinity(0, sizeof(cs), &cs); }
+		CPU_CLR(cpu, &cs);
+		char path[128];
+		snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+		if (FILE *f = fopen(path, "r")) {
+			int a, b;
+			while (fscanf(f, "%d", &a) == 1) {
+				b = a;
+				int c = fgetc(f);
+				if (c == '-') { if (fscanf(f, "%d", &b) != 1) break; c = fgetc(f); }
+				for (int k = a; k <= b && k < CPU_SETSIZE; ++k) CPU_CLR(k, &cs);
+				if (c != ',') break;
+			}
+			fclose(f);
+		}
+		it = by_cpu->emplace(cpu, cs).first;
+	}
+	return CPU_COUNT(&it->second) > 0 ? &it->second : nullptr;
+}
+
 const void *callers_node_cpus()
 {
 	static const NodeTable *tab = new NodeTable();

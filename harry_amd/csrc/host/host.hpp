@@ -136,6 +136,7 @@ uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
 // helper threads run on the CPUs of the memory node their creator is on (block_pool.cpp; HRY_NO_NUMA_BIND switches it off)
 const void *callers_node_cpus();       // nullptr: one node, or unknown
 void stay_on_node(const void *cpus);   // confines the calling thread
+const void *callers_neighbour_cpus();   // the caller's cache domain (else memory node) without the caller's own core (nullptr: unknown)
 const void *callers_cache_cpus(unsigned *n_cpus);   // CPUs sharing the caller's last-level cache (nullptr: unknown)
 template <typename F> inline void parallel_for(unsigned n_threads, F &&body, const void *cpus = nullptr)   // body(thread index), joins before returning
 {
