@@ -85,10 +85,9 @@ int hry_mesh_to_ply(const hry_mesh *m, int ascii, uint8_t **out, size_t *out_len
 {
 	if (!m || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
 	return guarded([&] {
-		std::vector<uint8_t> v;
+		ByteSink v;
 		mesh_to_ply(m->m, (ascii & HRY_PLY_ASCII) != 0, v, (ascii & HRY_PLY_PACKED) != 0);
-		*out = dup_bytes(v);
-		*out_len = v.size();
+		*out = v.release(out_len);
 	});
 }
 int hry_mesh_from_obj(const uint8_t *obj, size_t n, const char *dir, hry_mesh **out)
@@ -104,10 +103,9 @@ int hry_mesh_to_obj(const hry_mesh *m, int, uint8_t **out, size_t *out_len)
 {
 	if (!m || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
 	return guarded([&] {
-		std::vector<uint8_t> v;
+		ByteSink v;
 		mesh_to_obj(m->m, v);
-		*out = dup_bytes(v);
-		*out_len = v.size();
+		*out = v.release(out_len);
 	});
 }
 int hry_mesh_general(const hry_mesh *m) { return m && m->m.general ? 1 : 0; }

@@ -18,7 +18,7 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n);
 Mesh *mesh_from_arrays(uint32_t nv, const uint8_t *vrec, int v_ncomp, const uint8_t *v_types, const char *const *v_names,
                        uint32_t nf, const uint8_t *degrees, const uint32_t *indices,
                        const uint8_t *frec, int f_ncomp, const uint8_t *f_types, const char *const *f_names);
-void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed = false);
+void mesh_to_ply(const Mesh &m, bool ascii, ByteSink &out, bool packed = false);
 void build_twins(Mesh &m);
 // the readers leave the twin matching pending (Mesh::twins_pending); a context does it on the device when the mesh is first
 // uploaded (device/twins.hip), host-only entry points do it here
@@ -30,7 +30,7 @@ void print_component(std::string &o, const AttrList &L, const uint8_t *rec, int 
 
 // ---- obj_io.cpp (formats/obj/reader.rl:108-299, writer.cc:20-132): meshes with general bindings (mesh.hpp Bindings)
 Mesh *mesh_from_obj(const uint8_t *buf, size_t n, const char *directory);   // directory: where "mtllib" files are looked up
-void mesh_to_obj(const Mesh &m, std::vector<uint8_t> &out);
+void mesh_to_obj(const Mesh &m, ByteSink &out);
 
 // ---- context numbering of a .hry stream (formats/hry/models.h:183-237), shared with the device code
 enum {

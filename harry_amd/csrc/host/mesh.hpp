@@ -2,7 +2,9 @@
 // Reference counterparts: structs/mesh.h:19-40, structs/conn.h:72-170, structs/attr.h:24-189, structs/mixing.h:41-200.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -139,6 +141,40 @@ struct Bindings {
 		off_vtxlist.push_back(off_vtxlist.back() + n); reg_vtxlist.resize(off_vtxlist.back(), 0);
 		return nregs_vtx() - 1;
 	}
+};
+
+// Output bytes of the writers (PLY, OBJ): grows like a vector, but new bytes are not zero-filled (a 19 MB file is 4 600 fresh pages:
+// filling them once is enough) and the buffer can be handed to the C boundary as it is (malloc'ed: hry_free is free).
+class ByteSink {
+	uint8_t *p_ = nullptr;
+	size_t n_ = 0, cap_ = 0;
+	void grow(size_t want)
+	{
+		size_t c = cap_ ? cap_ : 4096;
+		while (c < want) c += c / 2 + 4096;
+		uint8_t *q = (uint8_t*)realloc(p_, c);
+		if (!q) throw std::bad_alloc();
+		p_ = q; cap_ = c;
+	}
+public:
+	ByteSink() = default;
+	ByteSink(const ByteSink&) = delete;
+	ByteSink &operator=(const ByteSink&) = delete;
+	~ByteSink() { free(p_); }
+	size_t size() const { return n_; }
+	bool empty() const { return n_ == 0; }
+	uint8_t *data() { return p_; }
+	const uint8_t *data() const { return p_; }
+	const uint8_t *begin() const { return p_; }
+	const uint8_t *end() const { return p_ + n_; }
+	uint8_t &operator[](size_t i) { return p_[i]; }
+	void clear() { n_ = 0; }
+	void reserve(size_t c) { if (c > cap_) grow(c); }
+	void resize(size_t n) { if (n > cap_) grow(n); n_ = n; }   // new bytes are NOT initialised
+	void push_back(uint8_t b) { if (n_ == cap_) grow(n_ + 1); p_[n_++] = b; }
+	template <typename It> void append(It b, It e) { const size_t k = (size_t)(e - b); if (n_ + k > cap_) grow(n_ + k); if (k) memcpy(p_ + n_, &*b, k); n_ += k; }
+	template <typename It> void assign(It b, It e) { n_ = 0; append(b, e); }
+	uint8_t *release(size_t *n) { uint8_t *q = p_ ? p_ : (uint8_t*)malloc(1); if (n) *n = n_; p_ = nullptr; n_ = cap_ = 0; return q; }   // the caller frees with free()
 };
 
 struct Mesh {

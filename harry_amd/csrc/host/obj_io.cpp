@@ -294,7 +294,7 @@ Mesh *mesh_from_obj(const uint8_t *buf, size_t n, const char *directory)
 // The writer keeps the reference's index arithmetic: normals are numbered after ALL texture coordinates (one running
 // offset for both tables, writer.cc:68-73,89-93), which is what the reference's files hold -- an OBJ reader that numbers
 // "vn" lines on their own sees indices that are too large by the number of "vt" lines.
-void mesh_to_obj(const Mesh &m, std::vector<uint8_t> &out)
+void mesh_to_obj(const Mesh &m, ByteSink &out)
 {
 	const size_t nl = m.lists.size();
 	auto has = [&](size_t l, int interp) { const AttrList &L = m.lists[l]; return interp < (int)L.interp_len.size() && L.interp_len[interp] != 0; };
@@ -318,7 +318,7 @@ void mesh_to_obj(const Mesh &m, std::vector<uint8_t> &out)
 	for (int r = 0; r < b->nregs_vtx(); ++r)
 		for (int a = 0; a < b->nvtxlists(r); ++a) if (has(b->vtxlist(r, a), I_POS)) is_pos[b->vtxlist(r, a)] = 1;
 	std::string o = "# decompressed using harry mesh compressor\n\n# vertex definitions and vertex attributes\n";
-	auto flush = [&]() { out.insert(out.end(), o.begin(), o.end()); o.clear(); };
+	auto flush = [&]() { out.append(o.begin(), o.end()); o.clear(); };
 	auto value = [&](size_t l, uint32_t idx, int c) { const AttrList &L = m.lists[l]; print_component(o, L, L.data.data() + (size_t)idx * L.stride(), c); };
 	for (uint32_t v = 0; v < m.nv; ++v) {
 		const int r = m.general ? m.bind.vtx_reg[v] : 0;

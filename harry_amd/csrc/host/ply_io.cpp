@@ -586,7 +586,7 @@ inline void print_comp(std::string &o, const AttrList &L, const uint8_t *rec, in
 // General bindings (formats/ply/writer.cc:106-192): the vertex element carries the lists that EVERY vertex region binds, the face
 // element those every face region binds as face lists (corner lists have no PLY form); each element writes the records its own
 // region binds, in slot order.
-void general_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed)
+void general_to_ply(const Mesh &m, bool ascii, ByteSink &out, bool packed)
 {
 	const Bindings &b = m.bind;
 	auto common = [&](int nregs, auto nlists, auto list_at) {   // writer.cc:141-156: running intersection over the regions that bind anything
@@ -626,7 +626,7 @@ void general_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool p
 		if (packed && q) for (int c = 0; c < L.ncomp(); ++c) o.append((const char*)rec + L.offset[c], (size_t)kTypeSize[L.stype(c)]);
 		else o.append((const char*)rec, (size_t)L.stride());
 	};
-	auto flush = [&]() { out.insert(out.end(), o.begin(), o.end()); o.clear(); };
+	auto flush = [&]() { out.append(o.begin(), o.end()); o.clear(); };
 	for (uint32_t v = 0; v < m.nv; ++v) {
 		const int r = b.vtx_reg[v];
 		for (int a = 0; a < b.nvtxlists(r); ++a) if (in_v[b.vtxlist(r, a)]) record(b.vtxlist(r, a), b.vtx_attr[(size_t)v * b.nb_vtx + a], a != 0);
@@ -646,7 +646,7 @@ void general_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool p
 }
 }   // namespace
 
-void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool packed)
+void mesh_to_ply(const Mesh &m, bool ascii, ByteSink &out, bool packed)
 {
 	if (m.general) { general_to_ply(m, ascii, out, packed); return; }
 	std::string h = std::string("ply\nformat ") + (ascii ? "ascii" : "binary_little_endian") + " 1.0\ncomment decompressed using harry mesh compressor\n";
@@ -667,20 +667,37 @@ void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool pack
 	// App. B-12), which no PLY reader can parse; without quantised components the two forms are the same bytes.
 	auto any_quant = [](const AttrList &L) { for (int c = 0; c < L.ncomp(); ++c) if (L.quant[c]) return true; return false; };
 	auto put_packed = [&](const AttrList &L, const uint8_t *rec) {
-		for (int c = 0; c < L.ncomp(); ++c) out.insert(out.end(), rec + L.offset[c], rec + L.offset[c] + kTypeSize[L.stype(c)]);
+		for (int c = 0; c < L.ncomp(); ++c) out.append(rec + L.offset[c], rec + L.offset[c] + kTypeSize[L.stype(c)]);
 	};
+	unsigned n_near = 0;
+	const void *near = callers_cache_cpus(&n_near);
+	const unsigned nt_fill = std::max(1u, std::min(near ? n_near : 8u, host_threads()));
 	if (!ascii) {
 		const bool pv = packed && any_quant(LV), pf = packed && any_quant(LF);
-		if (pv) { out.reserve(out.size() + LV.data.size()); for (uint32_t v = 0; v < m.nv; ++v) put_packed(LV, LV.data.data() + (size_t)v * LV.stride()); }
-		else out.insert(out.end(), LV.data.begin(), LV.data.end());   // whole original-width records (writer.cc:72-75)
+		if (pv) {
+			// the packed records of all vertices: one block, filled by a few threads
+			size_t ps = 0;
+			for (int c = 0; c < LV.ncomp(); ++c) ps += kTypeSize[LV.stype(c)];
+			const size_t at = out.size();
+			out.resize(at + ps * m.nv);
+			uint8_t *dst = out.data() + at;
+			const uint32_t nv = m.nv;
+			const unsigned nt = nv >= (1u << 16) ? nt_fill : 1u;
+			parallel_for(nt, [&](unsigned t) {
+				const uint32_t vb = (uint32_t)((uint64_t)nv * t / nt), ve = (uint32_t)((uint64_t)nv * (t + 1) / nt);
+				uint8_t *w = dst + ps * vb;
+				for (uint32_t v = vb; v < ve; ++v) {
+					const uint8_t *rec = LV.data.data() + (size_t)v * LV.stride();
+					for (int c = 0; c < LV.ncomp(); ++c) { const int k = kTypeSize[LV.stype(c)]; memcpy(w, rec + LV.offset[c], (size_t)k); w += k; }
+				}
+			}, near);
+		} else out.append(LV.data.begin(), LV.data.end());   // whole original-width records (writer.cc:72-75)
 		size_t fs = LF.stride();
 		int tri = 0;
 		if (!fs && m.uniform_degree(tri) && tri == 3 && m.nf >= (1u << 16)) {   // the usual file: 13-byte records, filled by a few threads
 			const size_t at = out.size();
 			out.resize(at + (size_t)m.nf * 13);
-			unsigned n_near = 0;
-			const void *near = callers_cache_cpus(&n_near);
-			const unsigned nt = std::max(1u, std::min(near ? n_near : 8u, host_threads()));
+			const unsigned nt = nt_fill;
 			uint8_t *dst = out.data() + at;
 			const uint32_t *org = m.org.data();
 			const uint32_t nf = m.nf;
@@ -694,9 +711,9 @@ void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool pack
 			uint32_t b = m.face_off[f], e = m.face_off[f + 1];
 			out.push_back((uint8_t)(e - b));
 			const uint8_t *p = (const uint8_t*)&m.org[b];
-			out.insert(out.end(), p, p + 4 * (size_t)(e - b));
+			out.append(p, p + 4 * (size_t)(e - b));
 			if (fs && pf) put_packed(LF, LF.data.data() + (size_t)f * fs);
-			else if (fs) out.insert(out.end(), LF.data.begin() + (size_t)f * fs, LF.data.begin() + (size_t)(f + 1) * fs);
+			else if (fs) out.append(LF.data.begin() + (size_t)f * fs, LF.data.begin() + (size_t)(f + 1) * fs);
 		}
 		return;
 	}
@@ -711,9 +728,9 @@ void mesh_to_ply(const Mesh &m, bool ascii, std::vector<uint8_t> &out, bool pack
 		for (uint32_t x = b; x < e; ++x) { o += '\t'; o += std::to_string(m.org[x]); }
 		for (int c = 0; c < LF.ncomp(); ++c) { o += '\t'; print_comp(o, LF, LF.data.data() + (size_t)f * LF.stride(), c); }
 		o += '\n';
-		if (o.size() > (1u << 20)) { out.insert(out.end(), o.begin(), o.end()); o.clear(); }
+		if (o.size() > (1u << 20)) { out.append(o.begin(), o.end()); o.clear(); }
 	}
-	out.insert(out.end(), o.begin(), o.end());
+	out.append(o.begin(), o.end());
 }
 
 }   // namespace hry

@@ -32,7 +32,7 @@ int main(int argc, char **argv)
 				const std::string dir = fn.substr(0, fn.find_last_of('/'));
 				std::unique_ptr<Mesh> m(ext == ".ply" ? mesh_from_ply(data.data(), data.size()) : mesh_from_obj(data.data(), data.size(), dir.c_str()));
 				ensure_twins(*m);
-				std::vector<uint8_t> out;
+				ByteSink out;
 				mesh_to_ply(*m, true, out);
 				mesh_to_ply(*m, false, out, true);
 				mesh_to_obj(*m, out);
