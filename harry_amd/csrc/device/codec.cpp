@@ -438,7 +438,7 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	write_hry_header(m, 1, out);
 	auto t_walk = Clock::now();
 	WalkResult w;
-	cut_border_walk(m, w);
+	cut_border_walk(m, w, false, true);   // one symbol sequence; the operation model is evaluated on the device (k_opmodel_*)
 	cx.timing.host_walk_ms = ms_since(t_walk);
 
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
@@ -465,7 +465,12 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	const size_t nop = w.op_sc.size();
 	cx.d_grp_val.ensure(std::max<size_t>(ngrp * 4, 16));
 	cx.d_grp_pos.ensure(std::max<size_t>(ngrp * 4, 16));
-	cx.d_op.ensure(std::max<size_t>(nop * 16, 16));
+	// operations as the walk wrote them (symbol | order class << 3) + where the connectivity groups sit between them: the
+	// device evaluates the operation model and places the records (k_opmodel_*)
+	std::vector<uint32_t> op_thr, op_cum;
+	op_position_table(w, op_thr, op_cum);
+	const size_t op_bytes = (nop + 15) & ~(size_t)15, ngr = op_thr.size();
+	cx.d_op.ensure(std::max<size_t>(op_bytes + ngr * 8 + dev::op_model_scratch_bytes((uint32_t)nop) + 64, 64));
 	size_t goff[G_COUNT + 1] = { 0 };
 	for (int g = 0; g < G_COUNT; ++g) {
 		size_t n = w.grp_val[g].size();
@@ -474,12 +479,13 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 		HIP_OK(hipMemcpyAsync(cx.d_grp_val.as<uint32_t>() + goff[g], w.grp_val[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
 		HIP_OK(hipMemcpyAsync(cx.d_grp_pos.as<uint32_t>() + goff[g], w.grp_pos[g].data(), n * 4, hipMemcpyHostToDevice, cx.stream));
 	}
-	uint32_t *d_opl = cx.d_op.as<uint32_t>(), *d_oph = d_opl + nop, *d_opt = d_oph + nop, *d_opp = d_opt + nop;
-	if (nop) {
-		HIP_OK(hipMemcpyAsync(d_opl, w.op_l.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
-		HIP_OK(hipMemcpyAsync(d_oph, w.op_h.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
-		HIP_OK(hipMemcpyAsync(d_opt, w.op_t.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
-		HIP_OK(hipMemcpyAsync(d_opp, w.op_pos.data(), nop * 4, hipMemcpyHostToDevice, cx.stream));
+	uint8_t *d_opsc = cx.d_op.as<uint8_t>();
+	uint32_t *d_opthr = (uint32_t*)(d_opsc + op_bytes), *d_opcum = d_opthr + ngr;
+	void *d_opscratch = d_opcum + ngr;
+	if (nop) HIP_OK(hipMemcpyAsync(d_opsc, w.op_sc.data(), nop, hipMemcpyHostToDevice, cx.stream));
+	if (ngr) {
+		HIP_OK(hipMemcpyAsync(d_opthr, op_thr.data(), ngr * 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipMemcpyAsync(d_opcum, op_cum.data(), ngr * 4, hipMemcpyHostToDevice, cx.stream));
 	}
 
 	// ---- model jobs: every byte plane with its initial counts (models.h:197-218, model.h:38-55)
@@ -526,7 +532,7 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	}
 	for (int p = 0; p < ldv.nplanes; ++p) add_job(cx.d_vplanes.as<uint8_t>() + (size_t)p * vc, vc, id_ones, nullptr, 0, base_v + 1 + p, sv);
 	for (int p = 0; p < ldf.nplanes; ++p) add_job(cx.d_fplanes.as<uint8_t>() + (size_t)p * fc, fc, id_ones, nullptr, 0, base_f + 1 + p, sf);
-	for (size_t i = 0; i < nop; ++i) max_total = std::max(max_total, w.op_t[i] + 1);
+	max_total = std::max<uint32_t>(max_total, (uint32_t)nop + 8);   // the operation model's total: 7 + the operations so far
 	cx.d_jobs.ensure(std::max<size_t>(jobs.size() * sizeof(PlaneJob), 16));
 	cx.d_chunks.ensure(std::max<size_t>(chunks.size() * sizeof(ChunkRef), 16));
 	cx.d_hist.ensure(std::max<size_t>(chunks.size() * 256 * 4, 16));
@@ -558,7 +564,7 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	const MagicEnt *magic = cx.d_magic.as<MagicEnt>();
 	SymRec *rec = cx.d_rec_sym.as<SymRec>();
 	uint32_t *sym_l = cx.d_sym_l.as<uint32_t>();
-	launch_op_records(cx.stream, d_opl, d_oph, d_opt, d_opp, (uint32_t)nop, magic, rec, sym_l);
+	launch_op_model(cx.stream, d_opsc, (uint32_t)nop, d_opthr, d_opcum, (uint32_t)ngr, d_opscratch, magic, rec, sym_l);
 	launch_type_records(cx.stream, vc, base_v, sv, magic, rec, sym_l);
 	launch_type_records(cx.stream, fc, base_f, sf, magic, rec, sym_l);
 	launch_model(cx.stream, cx.d_jobs.as<PlaneJob>(), (uint32_t)jobs.size(), cx.d_chunks.as<ChunkRef>(), (uint32_t)chunks.size(), cx.d_hist.as<uint32_t>(), magic, rec, sym_l);

@@ -361,6 +361,90 @@ __global__ __launch_bounds__(256) void k_op_records(const uint32_t *l, const uin
 	if (j < n) emit_symbol(rec, sym_l, magic, pos[j], l[j], h[j] - l[j], t[j]);
 }
 
+// The same model evaluated HERE, by counting (models.h:49-120): the state before operation i is a set of prefix counts over the
+// operation stream -- plain[s] = 1 + #(symbol s before i) for the five rare symbols, c_new[k] / c_fwd[k] = 1 + #(NEWVTX / CONNFWD of
+// order class k before i), c_all = 2 + #(NEWVTX or CONNFWD before i) -- and the mixed frequency of NEWVTX is c_new[k] c_all /
+// (c_new[k] + c_fwd[k]) in 64-bit integers.  Counters: 0..4 plain, 5..12 new, 13..20 fwd.  One wavefront per kOpChunk operations;
+// inside a batch of 64 the counts before a lane come from ballots (per symbol, and three for "same order class").
+constexpr uint32_t kOpChunk = 4096, kOpCounters = 21;
+__device__ __forceinline__ uint32_t op_counter(uint32_t s, uint32_t k) { return s < 5u ? s : s == 5u ? 5u + k : 13u + k; }
+__global__ __launch_bounds__(256) void k_opmodel_hist(const uint8_t *op, uint32_t n, uint32_t *hist)
+{
+	__shared__ uint32_t c[kOpCounters];
+	if (threadIdx.x < kOpCounters) c[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t b = blockIdx.x * kOpChunk, e = min(n, b + kOpChunk);
+	for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) { const uint32_t x = op[i]; atomicAdd(&c[op_counter(x & 7u, x >> 3)], 1u); }
+	__syncthreads();
+	if (threadIdx.x < kOpCounters) hist[(size_t)blockIdx.x * kOpCounters + threadIdx.x] = c[threadIdx.x];
+}
+// exclusive scan over the chunks, in place; one workgroup: thread t owns a contiguous range of chunks
+__global__ __launch_bounds__(256) void k_opmodel_scan(uint32_t *hist, uint32_t nchunks)
+{
+	__shared__ uint32_t part[256][kOpCounters];
+	const uint32_t per = (nchunks + 255u) / 256u, b = min(nchunks, threadIdx.x * per), e = min(nchunks, b + per);
+	uint32_t sum[kOpCounters];
+	for (uint32_t c = 0; c < kOpCounters; ++c) sum[c] = 0;
+	for (uint32_t k = b; k < e; ++k) for (uint32_t c = 0; c < kOpCounters; ++c) sum[c] += hist[(size_t)k * kOpCounters + c];
+	for (uint32_t c = 0; c < kOpCounters; ++c) part[threadIdx.x][c] = sum[c];
+	__syncthreads();
+	if (threadIdx.x < kOpCounters) { uint32_t run = 0; for (uint32_t t = 0; t < 256u; ++t) { const uint32_t v = part[t][threadIdx.x]; part[t][threadIdx.x] = run; run += v; } }
+	__syncthreads();
+	for (uint32_t c = 0; c < kOpCounters; ++c) sum[c] = part[threadIdx.x][c];
+	for (uint32_t k = b; k < e; ++k)
+		for (uint32_t c = 0; c < kOpCounters; ++c) { uint32_t *h = hist + (size_t)k * kOpCounters + c; const uint32_t v = *h; *h = sum[c]; sum[c] += v; }
+}
+// thr / cum: op_position_table (host.hpp) -- the connectivity groups between the operations
+__global__ __launch_bounds__(64) void k_opmodel_records(const uint8_t *op, uint32_t n, const uint32_t *hist, const uint32_t *thr, const uint32_t *cum, uint32_t ngroups,
+                                                         const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
+{
+	__shared__ uint32_t cnt[kOpCounters];
+	const uint32_t lane = threadIdx.x;
+	if (lane < kOpCounters) cnt[lane] = hist[(size_t)blockIdx.x * kOpCounters + lane];
+	__syncthreads();
+	uint32_t all = 0;   // NEWVTX + CONNFWD before the batch
+	for (uint32_t c = 5; c < kOpCounters; ++c) all += cnt[c];
+	const uint64_t earlier = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	const uint32_t b = blockIdx.x * kOpChunk, e = min(n, b + kOpChunk);
+	for (uint32_t base = b; base < e; base += 64) {
+		const uint32_t i = base + lane;
+		const bool valid = i < e;
+		const uint32_t x = valid ? op[i] : 0xffu, s = x & 7u, k = (x >> 3) & 7u;
+		uint64_t ms[7];
+#pragma unroll
+		for (uint32_t y = 0; y < 7; ++y) ms[y] = __ballot(valid && s == y);
+		uint64_t same = ~0ull;   // lanes of my order class
+#pragma unroll
+		for (int bit = 0; bit < 3; ++bit) { const bool mine = (k >> bit) & 1u; const uint64_t m = __ballot(mine); same &= mine ? m : ~m; }
+		if (valid) {
+			uint64_t f[7];
+#pragma unroll
+			for (uint32_t y = 0; y < 5; ++y) f[y] = 1u + cnt[y] + (uint32_t)__popcll(ms[y] & earlier);
+			const uint64_t c_new = 1u + cnt[5u + k] + (uint32_t)__popcll(ms[5] & same & earlier), c_fwd = 1u + cnt[13u + k] + (uint32_t)__popcll(ms[6] & same & earlier);
+			const uint64_t c_all = 2u + (uint64_t)all + (uint32_t)__popcll((ms[5] | ms[6]) & earlier);
+			const uint64_t nv = c_new * c_all / (c_new + c_fwd);
+			f[5] = nv; f[6] = c_all - nv;
+			uint64_t l = 0;
+#pragma unroll
+			for (uint32_t y = 0; y < 7; ++y) l += y < s ? f[y] : 0ull;
+			uint64_t fs = 0;
+#pragma unroll
+			for (uint32_t y = 0; y < 7; ++y) fs = y == s ? f[y] : fs;
+			const uint64_t t = f[0] + f[1] + f[2] + f[3] + f[4] + c_all;
+			// position in the symbol sequence: behind the groups that come before this operation
+			const uint32_t oi = i;
+			uint32_t lo = 0, hi = ngroups;   // first group with thr > oi
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (thr[mid] <= oi) lo = mid + 1; else hi = mid; }
+			const uint32_t pos = oi + (lo ? cum[lo - 1] : 0u);
+			emit_symbol(rec, sym_l, magic, pos, (uint32_t)l, (uint32_t)fs, (uint32_t)t);
+		}
+		__syncthreads();   // (one wavefront) the batch has read the counters
+		if (valid) atomicAdd(&cnt[op_counter(s, k)], 1u);
+		all += (uint32_t)__popcll(ms[5] | ms[6]);
+		__syncthreads();
+	}
+}
+
 // attr_type symbols of a list whose elements all carry private data: the j-th symbol is DATA with counts
 // {DATA: 1 + j, HIST: 1} (models.h:201-203) => l = 0, h = 1 + j, t = 2 + j
 __global__ __launch_bounds__(256) void k_type_records(uint32_t n, uint32_t pos_base, uint32_t pos_stride, const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
@@ -703,6 +787,16 @@ void launch_op_records(hipStream_t st, const uint32_t *l, const uint32_t *h, con
                        const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
 {
 	if (n) hipLaunchKernelGGL(k_op_records, dim3(blocks_for(n, 256)), dim3(256), 0, st, l, h, t, pos, n, magic, rec, sym_l);
+}
+size_t op_model_scratch_bytes(uint32_t n) { return (size_t)((n + kOpChunk - 1) / kOpChunk + 1) * kOpCounters * 4; }
+void launch_op_model(hipStream_t st, const uint8_t *op, uint32_t n, const uint32_t *thr, const uint32_t *cum, uint32_t ngroups, void *scratch,
+                     const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
+{
+	if (!n) return;
+	const uint32_t nchunks = (n + kOpChunk - 1) / kOpChunk;
+	hipLaunchKernelGGL(k_opmodel_hist, dim3(nchunks), dim3(256), 0, st, op, n, (uint32_t*)scratch);
+	hipLaunchKernelGGL(k_opmodel_scan, dim3(1), dim3(256), 0, st, (uint32_t*)scratch, nchunks);
+	hipLaunchKernelGGL(k_opmodel_records, dim3(nchunks), dim3(64), 0, st, op, n, (const uint32_t*)scratch, thr, cum, ngroups, magic, rec, sym_l);
 }
 void launch_type_records(hipStream_t st, uint32_t n, uint32_t pos_base, uint32_t pos_stride, const MagicEnt *magic, SymRec *rec, uint32_t *sym_l)
 {

@@ -21,6 +21,10 @@ void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *orde
 void launch_edge_faces(hipStream_t st, const uint32_t *foff, uint32_t nf, uint32_t *eface);
 void launch_magic_table(hipStream_t st, MagicEnt *tab, uint32_t from, uint32_t to);
 void launch_split_bytes(hipStream_t st, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes);
+// the order-conditioned operation model of the reference stream, by counting; op: symbol | class << 3 per operation, thr / cum: op_position_table
+size_t op_model_scratch_bytes(uint32_t n);
+void launch_op_model(hipStream_t st, const uint8_t *op, uint32_t n, const uint32_t *thr, const uint32_t *cum, uint32_t ngroups, void *scratch,
+                     const MagicEnt *magic, SymRec *rec, uint32_t *sym_l);
 void launch_op_records(hipStream_t st, const uint32_t *l, const uint32_t *h, const uint32_t *t, const uint32_t *pos, uint32_t n,
                        const MagicEnt *magic, SymRec *rec, uint32_t *sym_l);
 void launch_type_records(hipStream_t st, uint32_t n, uint32_t pos_base, uint32_t pos_stride, const MagicEnt *magic, SymRec *rec, uint32_t *sym_l);

@@ -999,7 +999,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 }
 
 template <int DEG>
-static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
+static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model, bool one_sequence)
 {
 	const uint32_t nv = m.nv, nf = m.nf;
 	if (nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
@@ -1016,7 +1016,7 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model)
 	for (uint8_t d : m.have_degree) ndeg += d ? 1 : 0;
 	w.numtri_coded = ndeg > 1;   // one degree => conn_numtri holds a single symbol of count == total: l = 0, h = t, coder state unchanged
 	if (eval_op_model) { w.op_l.reserve(m.ntri() + 16); w.op_h.reserve(m.ntri() + 16); w.op_t.reserve(m.ntri() + 16); w.op_pos.reserve(m.ntri() + 16); }
-	walk_sequential<DEG>(m, w, eface_tab.data(), eval_op_model, eval_op_model ? 1u : host_threads());
+	walk_sequential<DEG>(m, w, eface_tab.data(), eval_op_model, eval_op_model || one_sequence ? 1u : host_threads());
 }
 
 }   // namespace
@@ -1071,15 +1071,35 @@ void analyse_components(const Mesh &m, ComponentAnalysis &A)
 	analyse_impl<0>(m, eface_tab.data(), nullptr, nullptr, nt, A);
 }
 
-void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model)
+void op_position_table(const WalkResult &w, std::vector<uint32_t> &thr, std::vector<uint32_t> &cum)
+{
+	// merge of the (sorted) position lists of the group kinds; a group of b bytes at position p has p - (bytes of the groups
+	// before it) operations in front of it
+	size_t at[G_COUNT] = { 0 }, total = 0;
+	for (int g = 0; g < G_COUNT; ++g) total += w.grp_pos[g].size();
+	thr.clear(); cum.clear();
+	thr.reserve(total); cum.reserve(total);
+	uint32_t bytes = 0;
+	for (size_t k = 0; k < total; ++k) {
+		int best = -1;
+		for (int g = 0; g < G_COUNT; ++g)
+			if (at[g] < w.grp_pos[g].size() && (best < 0 || w.grp_pos[g][at[g]] < w.grp_pos[best][at[best]])) best = g;
+		const uint32_t p = w.grp_pos[best][at[best]++];
+		thr.push_back(p - bytes);
+		bytes += (uint32_t)kGroupBytes[best];
+		cum.push_back(bytes);
+	}
+}
+
+void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model, bool one_sequence)
 {
 	ensure_twins(m);
 	int udeg = 0;
 	if (!m.uniform_degree(udeg)) udeg = 0;
 	switch (udeg) {
-	case 3: walk_impl<3>(m, w, eval_op_model); break;
-	case 4: walk_impl<4>(m, w, eval_op_model); break;
-	default: walk_impl<0>(m, w, eval_op_model); break;   // mixed (or unusual uniform) degrees
+	case 3: walk_impl<3>(m, w, eval_op_model, one_sequence); break;
+	case 4: walk_impl<4>(m, w, eval_op_model, one_sequence); break;
+	default: walk_impl<0>(m, w, eval_op_model, one_sequence); break;   // mixed (or unusual uniform) degrees
 	}
 }
 

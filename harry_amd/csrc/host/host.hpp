@@ -95,7 +95,13 @@ struct WalkResult {
 };
 
 // ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
-void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true);
+// eval_op_model: the order-conditioned operation model of the reference stream evaluated per operation (op_l / op_h / op_t / op_pos);
+// the product evaluates it on the device (k_opmodel_*) and asks for one_sequence instead: positions of the connectivity groups in
+// ONE symbol sequence, i.e. the walk on one thread
+void cut_border_walk(Mesh &m, WalkResult &out, bool eval_op_model = true, bool one_sequence = false);
+// the connectivity groups of a walk in stream order, as the operations see them: operation i (0-based among the operations) sits at
+// position i + cum[j] of the symbol sequence, j = the last group with thr[j] <= i (none: i)
+void op_position_table(const WalkResult &w, std::vector<uint32_t> &thr, std::vector<uint32_t> &cum);
 
 // The connected components of a mesh as the walk will code them, without walking: which faces form a component, the coding
 // order (start-face sequence of the reference, writer.cc:40-46, or the seed list of a shard), how many vertices / faces /
