@@ -47,6 +47,9 @@ struct Decoder {
 		uint64_t q = value / r;
 		return q < t - 1 ? q : t - 1;
 	}
+	// the first half of target(): the symbol is then located by comparing cumulative counts scaled by r with the value
+	// (Table::locate), which spares the second division
+	void scale(uint64_t t) { r = range / t; }
 	void consume(uint64_t l, uint64_t h, uint64_t t)
 	{
 		value -= r * l;
@@ -76,6 +79,19 @@ struct Table {
 	void add(uint32_t s, uint64_t d) { cnt[s] += d; blk[s >> 4] += d; tot += d; }
 	void set(uint32_t s, uint64_t f) { uint64_t d = f - cnt[s]; cnt[s] += d; blk[s >> 4] += d; tot += d; }
 	void ones() { for (int i = 0; i < 256; ++i) cnt[i] = 1; for (int b = 0; b < 16; ++b) blk[b] = 16; tot = 256; }
+	// find(min(value / r, tot - 1)) without the division: "target >= c" for a cumulative count c is "c r <= value and c < tot"
+	// (c r <= range: no overflow).  Same symbol, same l and h as find() in every case, ties and the clamp included.
+	uint32_t locate(uint64_t value, uint64_t r, uint64_t &l, uint64_t &h) const
+	{
+		uint64_t cum = 0;
+		uint32_t b = 0;
+		for (; b < 15; ++b) { const uint64_t nx = cum + blk[b]; if (nx >= tot || nx * r > value) break; cum = nx; }
+		uint32_t s = b << 4;
+		for (; s < 255; ++s) { const uint64_t nx = cum + cnt[s]; if (nx >= tot || nx * r > value) break; cum = nx; }
+		l = cum;
+		h = cum + cnt[s];
+		return s;
+	}
 	uint32_t find(uint64_t target, uint64_t &l, uint64_t &h) const
 	{
 		uint64_t rem = target;
@@ -116,7 +132,9 @@ struct Live {
 	{
 		if (t.tot == 0) throw Error(HRY_E_FORMAT, "corrupt stream (symbol from an empty model)");
 		uint64_t l, h;
-		uint32_t s = t.find(dc.target(t.tot), l, h);
+		dc.scale(t.tot);
+		if (dc.r == 0) throw Error(HRY_E_FORMAT, "corrupt stream (coding interval smaller than the model's total)");
+		uint32_t s = t.locate(dc.value, dc.r, l, h);
 		if (h == l) throw Error(HRY_E_FORMAT, "corrupt stream (symbol with zero frequency)");
 		dc.consume(l, h, t.tot);
 		return s;
