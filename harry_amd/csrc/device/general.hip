@@ -19,6 +19,8 @@
 #include "fan.hpp"
 #include "kernels.hpp"
 
+#include <type_traits>
+
 namespace hry {
 namespace dev {
 
@@ -193,22 +195,31 @@ struct GenChainJob {
 	ListDesc ld;
 };
 
+// largest value of the wavefront, for small non-negative values (five ballots)
+__device__ __forceinline__ int wave_max_small(int v)
+{
+	int m = 0;
+#pragma unroll
+	for (int b = 4; b >= 0; --b) { const int t = m | (1 << b); if (__ballot(v >= t)) m = t; }
+	return m;
+}
 template <typename T> __device__ __forceinline__ uint32_t as_u32(T v) { typename cm::word<sizeof(T)>::u u = cm::bits<typename cm::word<sizeof(T)>::u>(v); return (uint32_t)u; }
 template <typename T> __device__ __forceinline__ T from_u32(uint32_t x) { return cm::bits<T>((typename cm::word<sizeof(T)>::u)x); }
 
 // val[k] = value of the k-th source
-template <int KIND, typename T, int CAP>
+// N <= CAP: only the first N slots can be in use (the batch's largest source count, rounded up: straight-line code per bucket)
+template <int KIND, typename T, int CAP, int N = CAP>
 __device__ __forceinline__ T predict_from(int ns, int q, const T (&val)[CAP])
 {
 	if constexpr (KIND == 0)
 		return combine_parts<T>([&](auto &&use) {
 #pragma unroll
-			for (int k = 0; k + 2 < CAP; k += 3) if (k + 2 < ns) use(cm::parallelogram<T>(val[k], val[k + 1], val[k + 2], q));
+			for (int k = 0; k + 2 < N; k += 3) if (k + 2 < ns) use(cm::parallelogram<T>(val[k], val[k + 1], val[k + 2], q));
 		});
 	else
 		return combine_parts<T>([&](auto &&use) {
 #pragma unroll
-			for (int k = 0; k < CAP; ++k) if (k < ns) use(val[k]);
+			for (int k = 0; k < N; ++k) if (k < ns) use(val[k]);
 		});
 }
 
@@ -255,28 +266,37 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 				}
 				bool final_ = !inside;
 				T out = T(0);
-				for (int round = 0; round < 65; ++round) {
-					if (inside) {
+				// the rounds, compiled for N source slots: a batch whose records read at most N sources runs the N-slot code
+				auto rounds = [&](auto n_slots) {
+					constexpr int N = decltype(n_slots)::value;
+					for (int round = 0; round < 65; ++round) {
+						if (inside) {
 #pragma unroll
-						for (int k = 0; k < CAP; ++k) {   // unconditional reads: issued back to back, one wait
-							const uint32_t x = s_val[slot[k] & 63u];
-							val[k] = slot[k] < 64u ? from_u32<T>(x) : val[k];
+							for (int k = 0; k < N; ++k) {   // unconditional reads: issued back to back, one wait
+								const uint32_t x = s_val[slot[k] & 63u];
+								val[k] = slot[k] < 64u ? from_u32<T>(x) : val[k];
+							}
+						}
+						if (in_run) out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q);
+						__syncthreads();   // (one wavefront: orders the LDS traffic of the rounds)
+						if (in_run) s_val[lane] = as_u32<T>(out);
+						__syncthreads();
+						// final: every source inside the run was final BEFORE this round
+						const unsigned long long fin = __ballot(final_ || !in_run);
+						if (fin == ~0ull) break;
+						if (!final_) {
+							bool now = true;
+#pragma unroll
+							for (int k = 0; k < N; ++k) if (slot[k] < 64u && !((fin >> slot[k]) & 1ull)) now = false;
+							final_ = now;
 						}
 					}
-					if (in_run) out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP>(ns, q, val), q);
-					__syncthreads();   // (one wavefront: orders the LDS traffic of the rounds)
-					if (in_run) s_val[lane] = as_u32<T>(out);
-					__syncthreads();
-					// final: every source inside the run was final BEFORE this round
-					const unsigned long long fin = __ballot(final_ || !in_run);
-					if (fin == ~0ull) break;
-					if (!final_) {
-						bool now = true;
-#pragma unroll
-						for (int k = 0; k < CAP; ++k) if (slot[k] < 64u && !((fin >> slot[k]) & 1ull)) now = false;
-						final_ = now;
-					}
-				}
+				};
+				const int most = (int)__builtin_amdgcn_readfirstlane(wave_max_small(in_run ? ns : 0));
+				constexpr int N1 = CAP / 4 >= 3 ? (CAP / 4 / 3) * 3 : CAP / 4, N2 = CAP / 2;   // multiples of three for the parallelograms of KIND 0
+				if (most <= N1) rounds(std::integral_constant<int, N1>());
+				else if (most <= N2) rounds(std::integral_constant<int, N2>());
+				else rounds(std::integral_constant<int, CAP>());
 				if (in_run) stg<T>(mine, out);
 			}
 			__threadfence();   // the run's records are in memory before anything later reads them
