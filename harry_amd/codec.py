@@ -206,7 +206,8 @@ class Mesh:
         try:
             out = {}
             names = [("order_v", np.uint32), ("order_f", np.uint32), ("op_sym", np.uint8), ("op_class", np.uint8), ("op_l", np.uint32),
-                     ("op_h", np.uint32), ("op_t", np.uint32), ("op_pos", np.uint32), ("info", np.uint32), ("marks", np.uint32)]
+                     ("op_h", np.uint32), ("op_t", np.uint32), ("op_pos", np.uint32), ("op_thr", np.uint32), ("op_cum", np.uint32), ("info", np.uint32),
+                     ("marks", np.uint32)]
             for g in range(5):
                 names += [(f"grp{g}_val", np.uint32), (f"grp{g}_pos", np.uint32)]
             for name, dt in names:

@@ -13,6 +13,9 @@ struct hry_plan { ShardPlan p; };
 struct hry_walk {
 	WalkResult w; uint32_t info[2]; std::vector<uint8_t> vplanes, fplanes; std::vector<uint32_t> seg_start, seg_level;
 	mutable std::vector<uint8_t> op_sym, op_class;   // unpacked from w.op_sc on first request
+	mutable std::vector<uint32_t> op_thr, op_cum;    // op_position_table, on first request
+	mutable bool have_table = false;
+	void table() const { if (!have_table) { op_position_table(w, op_thr, op_cum); have_table = true; } }
 	void unpack_ops() const
 	{
 		if (op_sym.size() == w.op_sc.size()) return;
@@ -356,6 +359,8 @@ size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 	if (n == "op_h") return ret(r.op_h);
 	if (n == "op_t") return ret(r.op_t);
 	if (n == "op_pos") return ret(r.op_pos);
+	if (n == "op_thr") { w->table(); return ret(w->op_thr); }   // where the connectivity groups sit between the operations (what the
+	if (n == "op_cum") { w->table(); return ret(w->op_cum); }   // device's operation model places its records with)
 	if (n == "info") { *ptr = w->info; return 2; }
 	if (n == "marks") { *ptr = r.marks.data(); return r.marks.size() * (sizeof(ComponentMark) / 4); }
 	if (n == "seg_start") return ret(w->seg_start);

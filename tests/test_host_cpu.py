@@ -110,6 +110,10 @@ def check_walk_against_oracle(ply: bytes):
     assert np.array_equal(w["op_sym"], ops["sym"].astype(np.uint8))
     assert np.array_equal(w["op_l"], ops["l"]) and np.array_equal(w["op_h"], ops["h"]) and np.array_equal(w["op_t"], ops["t"])
     assert np.array_equal(np.nonzero(conn["ctx"] == CTX_OP)[0], w["op_pos"])
+    # ... and the table the device's operation model places its records with (op_position_table): operation i sits at
+    # i + cum[j], j = the last group with thr[j] <= i
+    j = np.searchsorted(w["op_thr"], np.arange(len(w["op_pos"])), side="right")
+    assert np.array_equal(np.arange(len(w["op_pos"])) + np.concatenate([[0], w["op_cum"]])[j], w["op_pos"])
     # byte groups
     for g, (ctx, nb) in enumerate(GROUPS):
         val, pos = w[f"grp{g}_val"], w[f"grp{g}_pos"]
