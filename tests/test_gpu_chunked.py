@@ -287,7 +287,7 @@ def test_chunked_component_types_and_chain_variants(cx, case):
 def test_pipelined_decode_after_another_mesh(cx, monkeypatch):
     """The slices of the pipelined decode run on connectivity that is uploaded behind the replay.  A twin link made after the
     publication a slice rests on can point into the part of the device arrays that is not uploaded yet -- which holds whatever
-    the previous decode left there.  Found by scripts/chain_stress.py: the first decode after a different mesh saw extra
+    the previous decode left there.  Found by tests/tools/chain_stress.py: the first decode after a different mesh saw extra
     candidates (a fan walk that continued through the previous mesh's faces); the kernels now stop at the uploaded half-edges."""
     other = mg.torus(138, 156, polys="quad", seed=25, sigma=3.5e-2).to_ply()
     a0 = hc.Mesh.from_ply(other)

@@ -1,4 +1,4 @@
-"""A short run of scripts/chain_stress.py inside the GPU suite: random noisy meshes (few bits, heavy noise, short rings, non-manifold,
+"""A short run of tests/tools/chain_stress.py inside the GPU suite: random noisy meshes (few bits, heavy noise, short rings, non-manifold,
 multi-component, lossless, reference-format streams, forced small slices of the pipelined decode) through the product against the
 oracle.  The script is the development tool that found the uploaded-half-edge hole of the pipelined decode; two seeds of it run here
 so that the driver's GPU run meets meshes no fixed case describes."""
@@ -20,5 +20,5 @@ def test_random_meshes_against_the_oracle(seed, waves):
         env.pop(k, None)
     if waves:
         env["HRY_CHAIN_WAVES"] = waves
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "chain_stress.py"), "24", str(seed)], capture_output=True, text=True, env=env, timeout=550)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "chain_stress.py"), "24", str(seed)], capture_output=True, text=True, env=env, timeout=550)
     assert r.returncode == 0 and r.stdout.strip().endswith("all equal"), (r.stdout + r.stderr)[-3000:]

@@ -1,10 +1,10 @@
 """cfg3-like run (BASELINE configs[2] stand-in): closed torus 3742 x 3742 -> 28 005 128 triangles, float32 positions + analytic
 normals, positions 14 bits / normals 10 bits (`-l1 -a0 -q14 -a1 -q14 -a2 -q14 -a3 -q10 -a4 -q10 -a5 -q10`, SURVEY 8d flag
-caveat), chunked encode + decode on one GPU.  python scripts/cfg3_check.py [SIDE] [--oracle]
+caveat), chunked encode + decode on one GPU.  python tests/tools/cfg3_check.py [SIDE] [--oracle]
 Checks: order-independent invariants of the decoded mesh against the quantised input (per-component sums and xor-folds,
 face degree histogram); --oracle additionally decodes with the CPU oracle (slow at full size)."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from harry_amd import codec as hc, meshgen as mg
 

@@ -1,7 +1,7 @@
 """cfg4-like run: many mixed-polygon components with non-manifold edges/vertices, lossless, chunked encode + decode,
-verified against the CPU oracle (optional).  python scripts/cfg4_check.py NCOMP NU NV [--no-verify]"""
+verified against the CPU oracle (optional).  python tests/tools/cfg4_check.py NCOMP NU NV [--no-verify]"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from harry_amd import codec as hc, meshgen as mg
 nc, nu, nv = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

@@ -1,14 +1,14 @@
 """Random quantised meshes through the chunked profile on the GPU against the CPU oracle, aimed at the reconstruction chain:
 heavy noise and few bits (clamped parallelograms, far residual codes: the scan's speculation fails and is repaired), short rings
 (every vertex a head: the cut-and-scan path), non-manifold and multi-component meshes, forced small slices of the pipelined decode.
-Development aid; the committed tests hold the fixed cases.   python scripts/chain_stress.py [n_meshes] [seed]"""
+Development aid; the committed tests hold the fixed cases.   python tests/tools/chain_stress.py [n_meshes] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from harry_amd import codec as hc
 from harry_amd import meshgen as mg
 from oracle import oracle_py as op   # checker only

@@ -1,12 +1,12 @@
 """Random OBJ scenes through both profiles on the GPU against the CPU oracle (development aid; the committed tests hold the fixed cases).
-    python scripts/obj_stress.py [n_scenes] [seed]"""
+    python tests/tools/obj_stress.py [n_scenes] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from harry_amd import codec as hc
 from harry_amd import meshgen as mg
 from harry_amd import objgen as og
