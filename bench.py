@@ -244,7 +244,7 @@ def main():
         t_g = time.perf_counter()
         tm_d = {}
         if can_decode:
-            cx.read_hry(out)                             # every rank decodes its own segment
+            cx.read_hry(out, partial=world > 1)          # every rank decodes its own segment
             tm_d = cx.timing()
         t2 = time.perf_counter()
         merged = gather.finish() if gather else None     # rank 0: hry_merge -> ONE container

@@ -39,10 +39,20 @@ class Timing(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class ShardTiming(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("plan_ms", "extract_ms", "bounds_ms", "combine_ms", "quant_ms", "encode_ms", "merge_ms", "phase_a_ms",
+                                           "phase_b_ms", "host_walk_ms", "total_ms")] + \
+               [(k, C.c_uint32) for k in ("n_shards", "n_contexts", "n_segments", "n_components", "n_groups")]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 OK, E_ARG, E_FORMAT, E_UNSUPPORTED, E_NODEVICE, E_NOMEM, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PROFILE_COMPAT, PROFILE_CHUNKED = 0, 1
 FLAG_HOST_RECURRENCE = 1
 FLAG_DEVICE_RECURRENCE = 2
+FLAG_PARTIAL = 4
 
 _lib = None
 
@@ -118,8 +128,14 @@ def load():
     L.hry_mesh_region_lists.restype = C.c_int; L.hry_mesh_region_lists.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     L.hry_mesh_regions_of.restype = sz; L.hry_mesh_regions_of.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hry_mesh_bindings.restype = sz; L.hry_mesh_bindings.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]
-    if L.hry_abi_version() != 3:
-        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 3: rebuild it")
+    L.hry_mesh_partial.restype = C.c_int; L.hry_mesh_partial.argtypes = [vp]
+    L.hry_encode_sharded.restype = C.c_int
+    L.hry_encode_sharded.argtypes = [C.POINTER(vp), C.c_int, vp, C.POINTER(Quant), sz, C.c_int, C.POINTER(Opts), C.POINTER(vp), C.POINTER(sz), C.POINTER(ShardTiming)]
+    L.hry_decode_sharded.restype = C.c_int
+    L.hry_decode_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, sz, C.POINTER(Opts), C.POINTER(vp), C.POINTER(ShardTiming)]
+    L.hry_container_check.restype = C.c_int; L.hry_container_check.argtypes = [C.c_char_p, sz, C.POINTER(C.c_int)]
+    if L.hry_abi_version() != 4:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 4: rebuild it")
     _lib = L
     return L
 

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nat
-from ._native import FLAG_DEVICE_RECURRENCE, FLAG_HOST_RECURRENCE, HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
+from ._native import FLAG_DEVICE_RECURRENCE, FLAG_HOST_RECURRENCE, FLAG_PARTIAL, HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
 
 TYPE_NP = {0: "<f4", 1: "<f8", 2: "<u8", 3: "<i8", 4: "<u4", 5: "<i4", 6: "<u2", 7: "<i2", 8: "u1", 9: "i1"}
 TYPE_SIZE = {0: 4, 1: 8, 2: 8, 3: 8, 4: 4, 5: 4, 6: 2, 7: 2, 8: 1, 9: 1}
@@ -143,6 +143,8 @@ class Mesh:
         L = nat.load()
         n = L.hry_list_ncomp(self.h, l)
         return [(L.hry_list_min_at(self.h, l, c), L.hry_list_max_at(self.h, l, c)) for c in range(n)]
+
+    partial = property(lambda s: bool(nat.load().hry_mesh_partial(s.h)))
 
     def runs(self) -> np.ndarray:
         """(n, 6) u32: first_vertex, first_face, first_halfedge, n_vertices, n_faces, n_halfedges in the numbering of the whole mesh.
@@ -332,9 +334,10 @@ class Codec:
         nat.check(nat.load().hry_encode(self.h, mesh.h, C.byref(o), C.byref(p), C.byref(n)))
         return nat.take_bytes(p, n.value)
 
-    def read_hry(self, data: bytes, keep_stages: bool = False, shard=(0, 0)) -> Mesh:
-        """shard = (index, count): of a sharded container decode only the segments i with i % count == index"""
-        o = nat.Opts(0, 0, int(keep_stages), 0, int(shard[0]), int(shard[1]))
+    def read_hry(self, data: bytes, keep_stages: bool = False, shard=(0, 0), partial: bool = False) -> Mesh:
+        """shard = (index, count): of a sharded container decode only the segments i with i % count == index.
+        partial: accept a sharded container that does not hold the whole mesh (one rank's own part): the result is a partial mesh."""
+        o = nat.Opts(0, 0, int(keep_stages), FLAG_PARTIAL if partial else 0, int(shard[0]), int(shard[1]))
         h = C.c_void_p()
         nat.check(nat.load().hry_decode(self.h, data, len(data), C.byref(o), C.byref(h)))
         return Mesh(h)
@@ -357,6 +360,53 @@ class Codec:
         p, n = C.c_void_p(), C.c_size_t()
         nat.check(nat.load().hry_range_encode_lht(self.h, lht.ctypes.data, len(lht), C.byref(p), C.byref(n)))
         return nat.take_bytes(p, n.value)
+
+
+class MultiCodec:
+    """Several device contexts driven from this one process (include/harry_amd.h: hry_encode_sharded / hry_decode_sharded): the
+    reference's single entry with N devices behind it.  devices: one index per context; an index may repeat (contexts that share
+    a device run side by side on it)."""
+
+    def __init__(self, devices):
+        self.ctx = [Codec(int(d)) for d in devices]
+        self.last = {}
+
+    def close(self):
+        for c in getattr(self, "ctx", []):
+            c.close()
+        self.ctx = []
+
+    __del__ = close
+
+    def _handles(self):
+        return (C.c_void_p * len(self.ctx))(*[c.h for c in self.ctx])
+
+    def write_hry(self, mesh: Mesh, quants=(), clear: bool = False, n_shards: int = 0, chunk_syms: int = 0) -> bytes:
+        """plan + extract + bounds of the whole mesh + quantisation + encode of every shard on its context + merge: ONE .hry v0.3"""
+        qs = list(quants)
+        arr = (nat.Quant * max(len(qs), 1))(*[nat.Quant(int(l), int(c), int(b)) for l, c, b in qs])
+        o = nat.Opts(PROFILE_CHUNKED, chunk_syms, 0, 0, 0, int(n_shards))
+        p, n, t = C.c_void_p(), C.c_size_t(), nat.ShardTiming()
+        nat.check(nat.load().hry_encode_sharded(self._handles(), len(self.ctx), mesh.h, arr, len(qs), int(clear), C.byref(o), C.byref(p), C.byref(n), C.byref(t)))
+        self.last = t.asdict()
+        return nat.take_bytes(p, n.value)
+
+    def read_hry(self, data: bytes, shard=(0, 0), partial: bool = False) -> Mesh:
+        o = nat.Opts(0, 0, 0, FLAG_PARTIAL if partial else 0, int(shard[0]), int(shard[1]))
+        h, t = C.c_void_p(), nat.ShardTiming()
+        nat.check(nat.load().hry_decode_sharded(self._handles(), len(self.ctx), data, len(data), C.byref(o), C.byref(h), C.byref(t)))
+        self.last = t.asdict()
+        return Mesh(h)
+
+    def timings(self):
+        return [c.timing() for c in self.ctx]
+
+
+def container_check(data: bytes) -> bool:
+    """host-only validation of a sharded container's directory; returns whether its runs cover the whole mesh"""
+    c = C.c_int()
+    nat.check(nat.load().hry_container_check(data, len(data), C.byref(c)))
+    return bool(c.value)
 
 
 def parse_quant_flags(flags):

@@ -46,6 +46,11 @@ extern "C" {
 const char *hry_last_error(void) { return g_last_error.c_str(); }
 int hry_abi_version(void) { return HRY_ABI_VERSION; }
 
+int hry_device_count(void)
+{
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
 int hry_ctx_create(int device, hry_ctx **out)
 {
 	if (!out) { g_last_error = "null argument"; return HRY_E_ARG; }
@@ -215,10 +220,67 @@ int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts,
 		hry_opts o = opts ? *opts : hry_opts{};
 		ctx->cx.keep_stages = o.keep_stages != 0;
 		ctx->cx.stages.clear();
-		std::unique_ptr<Mesh> m(decode_any(ctx->cx, hry, n, o.shard_index, o.shard_count));
+		std::unique_ptr<Mesh> m(decode_any(ctx->cx, hry, n, o.shard_index, o.shard_count, (o.flags & HRY_FLAG_PARTIAL) != 0));
 		*out = new hry_mesh{ std::move(*m) };
 	});
 }
+int hry_encode_sharded(hry_ctx *const *ctx, int n_ctx, hry_mesh *m, const hry_quant *quant, size_t n_quant, int clear,
+                       const hry_opts *opts, uint8_t **out, size_t *out_len, hry_shard_timing *timing)
+{
+	if (!ctx || n_ctx <= 0 || !m || !out || !out_len || (n_quant && !quant)) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr; *out_len = 0;
+	return guarded([&] {
+		hry_opts o = opts ? *opts : hry_opts{};
+		o.profile = opts ? o.profile : HRY_PROFILE_CHUNKED;
+		if (o.profile != HRY_PROFILE_CHUNKED) throw Error(HRY_E_UNSUPPORTED, "the reference's single stream (compat) does not shard: one recurrence over the whole file");
+		std::vector<Context*> cxs;
+		for (int i = 0; i < n_ctx; ++i) { if (!ctx[i]) throw Error(HRY_E_ARG, "null context"); ctx[i]->cx.keep_stages = false; ctx[i]->cx.stages.clear(); cxs.push_back(&ctx[i]->cx); }
+		std::vector<uint8_t> v;
+		hry_shard_timing st{};
+		encode_sharded(cxs.data(), n_ctx, m->m, quant, n_quant, clear != 0, o.shard_count, o.chunk_syms, v, st);
+		if (timing) *timing = st;
+		*out = dup_bytes(v);
+		*out_len = v.size();
+	});
+}
+int hry_decode_sharded(hry_ctx *const *ctx, int n_ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out, hry_shard_timing *timing)
+{
+	if (!ctx || n_ctx <= 0 || !hry || !out) { g_last_error = "null argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		hry_opts o = opts ? *opts : hry_opts{};
+		std::vector<Context*> cxs;
+		for (int i = 0; i < n_ctx; ++i) { if (!ctx[i]) throw Error(HRY_E_ARG, "null context"); ctx[i]->cx.keep_stages = false; ctx[i]->cx.stages.clear(); cxs.push_back(&ctx[i]->cx); }
+		std::unique_ptr<Mesh> g(new Mesh());
+		int minor = 0;
+		const bool sharded = n >= 6 && hry[4] == 0 && hry[5] == 3;
+		if (!sharded) {   // an unsharded file: the first context decodes it
+			std::unique_ptr<Mesh> m(decode_any(*cxs[0], hry, n, 0, 0, false));
+			if (timing) { *timing = hry_shard_timing{}; timing->n_contexts = 1; timing->n_segments = 1; timing->total_ms = cxs[0]->timing.total_ms; }
+			*out = new hry_mesh{ std::move(*m) };
+			return;
+		}
+		const size_t hdr = read_hry_header(hry, n, *g, minor, false);
+		std::unique_ptr<Mesh> m(decode_sharded(cxs.data(), n_ctx, hry, n, hdr, std::move(g), o.shard_index, o.shard_count,
+		                                       (o.flags & HRY_FLAG_PARTIAL) != 0 || o.shard_count > 1, timing));
+		*out = new hry_mesh{ std::move(*m) };
+	});
+}
+int hry_container_check(const uint8_t *hry, size_t n, int *complete)
+{
+	if (!hry) { g_last_error = "null argument"; return HRY_E_ARG; }
+	if (complete) *complete = 0;
+	return guarded([&] {
+		Mesh m;
+		int minor = 0;
+		const size_t hdr = read_hry_header(hry, n, m, minor, false);
+		if (minor != 3) { if (complete) *complete = 1; return; }
+		ShardedDirectory dir;
+		parse_sharded_directory(hry, n, hdr, m.nv, m.nf, m.declared_ne, dir, true);
+		if (complete) *complete = dir.complete ? 1 : 0;
+	});
+}
+int hry_mesh_partial(const hry_mesh *m) { return m && m->m.partial ? 1 : 0; }
 void hry_free(void *p) { free(p); }
 int hry_container_info(const uint8_t *hry, size_t n, uint32_t info[8])
 {

@@ -6,10 +6,12 @@
 // (message of std::terminate on stderr, status 134).  Input kind by magic number, output kind by extension
 // (formats/unified_reader.h:33-56, unified_writer.h:31-47): .hry, .ply and .obj both ways.
 // Additive options (the reference rejects them as invalid): --profile compat|chunked (default compat = the reference's own
-// v0.1 stream), --chunk N, --device D, --shards N (chunked: code the mesh as N shards, one after the other on this GPU, and
-// merge them into one sharded container -- what N ranks do in parallel, see harry_amd/sharding.py), --ply-packed (binary PLY
-// of a quantised mesh with every value in the width its header declares; the reference's writer dumps the original-width
-// records, formats/ply/writer.cc:72-75).
+// v0.1 stream), --chunk N, --device D, --gpus N (N device contexts behind this one command, devices D, D+1, ... -- more
+// contexts than devices share them: the mesh shards by connected component, every context codes / decodes its shards on a
+// worker thread of its own, one sharded container comes out; hry_encode_sharded / hry_decode_sharded), --shards N (number of
+// shards, default one per context; both imply --profile chunked, the reference's single stream does not shard), --ply-packed
+// (binary PLY of a quantised mesh with every value in the width its header declares; the reference's writer dumps the
+// original-width records, formats/ply/writer.cc:72-75).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -27,10 +29,10 @@ namespace {
 
 struct QuantArg { int l, o, q; };
 struct Args {
-	std::string in, out, fmt, profile = "compat";
+	std::string in, out, fmt, profile;   // profile empty: compat, unless --gpus / --shards ask for the sharded container
 	std::vector<QuantArg> quant;
 	bool clearquant = false, ply_ascii = false, ply_packed = false;
-	int chunk = 0, device = 0, shards = 0;
+	int chunk = 0, device = 0, shards = 0, gpus = 0;
 };
 
 struct Opt { char s; const char *l; const char *descr; bool has_val; };
@@ -38,7 +40,8 @@ const Opt kOpts[] = {
 	{ 'h', "help", "Print this dialogue.", false }, { 'f', "format", "Enforce output format", true }, { 'l', "list", "Select attribute list", true },
 	{ 'a', "attr", "Select attribute", true }, { 'q', "quant", "Quantization bits", true }, { 'c', "clear-quant", "Clear all quantization first", false },
 	{ 0, "ply-ascii", "PLY writer: Use ASCII format", false }, { 0, "ply-packed", "PLY writer: quantised values in their declared width", false }, { 0, "profile", "compat (reference stream, default) or chunked", true },
-	{ 0, "chunk", "chunked: symbols per chunk", true }, { 0, "device", "GPU index", true }, { 0, "shards", "chunked: code as N shards and merge", true } };
+	{ 0, "chunk", "chunked: symbols per chunk", true }, { 0, "device", "GPU index (first one with --gpus)", true }, { 0, "gpus", "N device contexts, one worker thread each", true },
+	{ 0, "shards", "chunked: code as N shards (default: one per context)", true } };
 
 void usage(const char *argv0)
 {
@@ -109,7 +112,11 @@ Args parse(int argc, const char **argv)
 		else if (n == "chunk") a.chunk = to_int(argv[0], val);
 		else if (n == "device") a.device = to_int(argv[0], val);
 		else if (n == "shards") a.shards = to_int(argv[0], val);
+		else if (n == "gpus") a.gpus = to_int(argv[0], val);
 	}
+	if (a.gpus < 0 || a.shards < 0 || a.gpus > 64) arg_error(argv[0], "Invalid number of contexts / shards");
+	if ((a.gpus > 1 || a.shards > 1) && a.profile == "compat") arg_error(argv[0], "--gpus / --shards need --profile chunked: the reference's single stream does not shard");
+	if (a.profile.empty()) a.profile = a.gpus > 1 || a.shards > 1 ? "chunked" : "compat";
 	if (pos.size() < 2) arg_error(argv[0], "Too few non-optional arguments");
 	if (pos.size() > 2) arg_error(argv[0], "Too much non-optional arguments");
 	a.in = pos[0]; a.out = pos[1];
@@ -126,18 +133,14 @@ std::string ext_of(const std::string &fn)
 }
 
 struct Handles {   // released on every path
-	hry_ctx *cx = nullptr;
+	std::vector<hry_ctx*> cx;   // [0]: the context of every single-device step
 	hry_mesh *mesh = nullptr;
-	std::vector<hry_mesh*> shards;
-	hry_plan *plan = nullptr;
 	std::vector<uint8_t*> bufs;
 	~Handles()
 	{
 		for (uint8_t *b : bufs) hry_free(b);
-		for (hry_mesh *s : shards) hry_mesh_free(s);
-		if (plan) hry_plan_free(plan);
 		if (mesh) hry_mesh_free(mesh);
-		if (cx) hry_ctx_destroy(cx);
+		for (hry_ctx *c : cx) hry_ctx_destroy(c);
 	}
 };
 
@@ -146,19 +149,34 @@ int run(const Args &args)
 	typedef std::chrono::high_resolution_clock Clock;
 	auto ms = [](Clock::time_point a, Clock::time_point b) { return (long long)std::chrono::duration_cast<std::chrono::milliseconds>(b - a).count(); };
 	Handles h;
-	ok(hry_ctx_create(args.device, &h.cx));
+	const int n_ctx = std::max(1, args.gpus);
+	const int n_dev = hry_device_count();
+	for (int i = 0; i < n_ctx; ++i) {
+		hry_ctx *c = nullptr;
+		ok(hry_ctx_create(n_dev > 0 && i > 0 ? (args.device + i) % n_dev : args.device, &c));
+		h.cx.push_back(c);
+	}
+	const bool sharded = n_ctx > 1 || args.shards > 1;
 
 	std::cout << "Reading input..." << std::endl;
 	Clock::time_point t0 = Clock::now();
 	std::vector<uint8_t> in;
 	{
 		std::ifstream is(args.in, std::ifstream::binary);
+		if (!is) throw std::runtime_error("cannot open " + args.in);
 		is.seekg(0, std::ios::end);
 		std::streamoff size = is.tellg();
 		is.seekg(0, std::ios::beg);
 		if (size > 0) { in.resize((size_t)size); is.read((char*)in.data(), size); }
 	}
-	if (in.size() >= 4 && in[0] == 0xfa && in[1] == 0xff && in[2] == 0xaf && in[3] == 0xaf) ok(hry_decode(h.cx, in.data(), in.size(), nullptr, &h.mesh));
+	if (in.size() >= 4 && in[0] == 0xfa && in[1] == 0xff && in[2] == 0xaf && in[3] == 0xaf) {
+		if (n_ctx > 1) {
+			hry_shard_timing st{};
+			ok(hry_decode_sharded(h.cx.data(), n_ctx, in.data(), in.size(), nullptr, &h.mesh, &st));
+			std::cout << "  " << st.n_segments << " segment(s) on " << st.n_contexts << " context(s), " << std::min(n_ctx, std::max(1, n_dev)) << " device(s): decode "
+			          << (long long)st.encode_ms << " ms, placement " << (long long)st.extract_ms << " ms" << std::endl;
+		} else ok(hry_decode(h.cx[0], in.data(), in.size(), nullptr, &h.mesh));
+	}
 	else if (in.size() >= 3 && in[0] == 'p' && in[1] == 'l' && in[2] == 'y') ok(hry_mesh_from_ply(in.data(), in.size(), &h.mesh));
 	else if (ext_of(args.in) == ".obj") {
 		// material libraries are looked up in the input path up to its last separator -- the whole path when there is none, as
@@ -172,49 +190,41 @@ int run(const Args &args)
 	Clock::time_point t1 = Clock::now();
 	std::cout << "Reading input took " << ms(t0, t1) << " ms." << std::endl;
 
-	if (!args.quant.empty() || args.clearquant) {
-		std::cout << "Quantization..." << std::endl;
-		std::vector<hry_quant> q;
-		for (const QuantArg &x : args.quant) q.push_back(hry_quant{ x.l, x.o, x.q });
-		ok(hry_requant(h.cx, h.mesh, q.data(), q.size(), args.clearquant ? 1 : 0));   // validation and texts of main.cc:74-91 inside
-	}
-	Clock::time_point t2 = Clock::now();
-	if (!args.quant.empty() || args.clearquant) std::cout << "Quantization took " << ms(t1, t2) << " ms." << std::endl;
-
-	std::cout << "Writing output..." << std::endl;
 	std::string type = args.fmt;
 	if (type.empty()) {
 		const std::string e = ext_of(args.out);
 		type = e == ".hry" ? "hry" : e == ".ply" ? "ply" : e == ".obj" ? "obj" : "";
-		if (type.empty()) throw std::runtime_error("Unknown file extension");
 	}
+	std::vector<hry_quant> q;
+	for (const QuantArg &x : args.quant) q.push_back(hry_quant{ x.l, x.o, x.q });
+	// a sharded .hry quantises shard by shard on the workers (the bounds of the whole mesh are combined from the shards'): the
+	// whole mesh never sits on one device
+	const bool quant_in_encode = sharded && type == "hry";
+	const bool quant_phase = (!q.empty() || args.clearquant) && !quant_in_encode;
+	if (quant_phase) {
+		std::cout << "Quantization..." << std::endl;
+		ok(hry_requant(h.cx[0], h.mesh, q.data(), q.size(), args.clearquant ? 1 : 0));   // validation and texts of main.cc:74-91 inside
+	}
+	Clock::time_point t2 = Clock::now();
+	if (quant_phase) std::cout << "Quantization took " << ms(t1, t2) << " ms." << std::endl;
+
+	std::cout << "Writing output..." << std::endl;
+	if (type.empty()) throw std::runtime_error("Unknown file extension");
 	uint8_t *out = nullptr;
 	size_t out_len = 0;
 	if (type == "hry") {
 		hry_opts o{};
 		o.profile = args.profile == "chunked" ? HRY_PROFILE_CHUNKED : HRY_PROFILE_COMPAT;
 		o.chunk_syms = args.chunk;
-		if (args.shards > 1 && o.profile == HRY_PROFILE_CHUNKED) {
-			// the sharded path on one GPU: plan, extract, code every shard, merge.  The whole mesh's bounds come from the mesh itself
-			// here (hry_shard_extract copies them); N ranks combine their shards' bounds instead (harry_amd/sharding.py).
-			bool need_bounds = false;
-			for (int l = 0; l < hry_mesh_nlists(h.mesh); ++l) if (hry_list_ncomp(h.mesh, l) > 0 && !hry_list_min(h.mesh, l)) need_bounds = true;
-			if (need_bounds) ok(hry_bounds(h.cx, h.mesh));
-			ok(hry_shard_plan(h.mesh, args.shards, &h.plan));
-			std::vector<const uint8_t*> parts;
-			std::vector<size_t> sizes;
-			for (int s = 0; s < args.shards; ++s) {
-				hry_mesh *sh = nullptr;
-				ok(hry_shard_extract(h.mesh, h.plan, s, &sh));
-				h.shards.push_back(sh);
-				uint8_t *p = nullptr;
-				size_t n = 0;
-				ok(hry_encode(h.cx, sh, &o, &p, &n));
-				h.bufs.push_back(p);
-				parts.push_back(p); sizes.push_back(n);
-			}
-			ok(hry_merge(parts.data(), sizes.data(), parts.size(), &out, &out_len));
-		} else ok(hry_encode(h.cx, h.mesh, &o, &out, &out_len));
+		if (quant_in_encode) {
+			if (o.profile != HRY_PROFILE_CHUNKED) throw std::runtime_error("--gpus / --shards need --profile chunked");
+			o.shard_count = args.shards;
+			hry_shard_timing st{};
+			ok(hry_encode_sharded(h.cx.data(), n_ctx, h.mesh, q.data(), q.size(), args.clearquant ? 1 : 0, &o, &out, &out_len, &st));
+			std::cout << "  " << st.n_shards << " shard(s) of " << st.n_components << " component(s) on " << st.n_contexts << " context(s), " << std::min(n_ctx, std::max(1, n_dev))
+			          << " device(s): plan " << (long long)st.plan_ms << " ms, extract " << (long long)st.extract_ms << " ms, bounds " << (long long)(st.bounds_ms + st.combine_ms)
+			          << " ms, quantization " << (long long)st.quant_ms << " ms, encode " << (long long)st.encode_ms << " ms, merge " << (long long)st.merge_ms << " ms" << std::endl;
+		} else ok(hry_encode(h.cx[0], h.mesh, &o, &out, &out_len));
 	} else if (type == "ply") ok(hry_mesh_to_ply(h.mesh, (args.ply_ascii ? HRY_PLY_ASCII : 0) | (args.ply_packed ? HRY_PLY_PACKED : 0), &out, &out_len));
 	else ok(hry_mesh_to_obj(h.mesh, 0, &out, &out_len));
 	h.bufs.push_back(out);

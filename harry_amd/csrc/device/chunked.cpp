@@ -312,16 +312,14 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 
-Mesh *decode_sharded(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m, int shard_index, int shard_count);
-
-Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index, int shard_count)
+Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index, int shard_count, bool allow_partial)
 {
 	HIP_OK(hipSetDevice(cx.device));
 	std::unique_ptr<Mesh> m(new Mesh());
 	int minor = 0;
 	const bool sharded = n >= 6 && p[4] == 0 && p[5] == 3;   // the whole mesh's records are filled segment by segment: no zero fill first
 	size_t hdr = read_hry_header(p, n, *m, minor, !sharded);
-	if (minor == 3) return decode_sharded(cx, p, n, hdr, std::move(m), shard_index, shard_count);
+	if (minor == 3) { Context *one = &cx; return decode_sharded(&one, 1, p, n, hdr, std::move(m), shard_index, shard_count, allow_partial || shard_count > 1, nullptr); }
 	if (shard_count > 1) throw Error(HRY_E_ARG, "only a sharded container (.hry v0.3) decodes segment by segment");
 	if (minor == 2) return decode_chunked(cx, p, n, hdr, std::move(m));
 	if (m->general) return decode_general(cx, p, n, hdr, std::move(m));

@@ -86,6 +86,7 @@ void Context::ensure_magic(uint32_t n)
 }
 void Context::upload_mesh(Mesh &m)
 {
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
 	HIP_OK(hipSetDevice(device));
 	if (m.lists.size() > (size_t)kMaxLists) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
 	for (size_t l = 0; l < m.lists.size(); ++l) {
@@ -159,6 +160,7 @@ ListDesc make_list_desc(const AttrList &L)
 
 void check_codable(const Mesh &m)
 {
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
 	for (size_t l = 0; l < m.lists.size(); ++l)
 		for (int c = 0; c < m.lists[l].ncomp(); ++c) {
 			CompType st = m.lists[l].stype(c);

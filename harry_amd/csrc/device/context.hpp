@@ -151,7 +151,12 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out);   // general.cpp: regions, shared records, corner lists (reference stream only)
 Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload);
-Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index = 0, int shard_count = 0);
+Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index = 0, int shard_count = 0, bool allow_partial = false);
+// sharded.cpp: one mesh over several contexts (devices) from one process
+void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q, size_t nq, bool clear, int n_shards, int chunk_syms,
+                    std::vector<uint8_t> &out, hry_shard_timing &st);
+Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> g, int shard_index, int shard_count,
+                     bool allow_partial, hry_shard_timing *st);
 void range_encode_lht(Context &cx, const uint64_t *lht, size_t n, std::vector<uint8_t> &out);
 
 dev::ListDesc make_list_desc(const AttrList &L);

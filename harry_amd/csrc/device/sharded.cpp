@@ -1,0 +1,360 @@
+// One mesh over several GPUs from ONE process (north_star: "meshes shard by independent connected
+// component across the 8 GPUs of one node ... only for final stream concatenation").
+//
+// The reference has a single entry (main.cc:93-123 -> hry::writer::write, formats/hry/writer.cc:200-214) and one thread.  What
+// scales here is "host thread + device context": per million triangles an encode is ~7 ms of sequential cut-border walk on a
+// host core and ~1 ms of kernels, so the unit of parallelism is a worker thread that owns a context -- N of them in one
+// process over N devices (or several per device).  Nothing in the data path is exchanged between the workers:
+//
+//   encode   plan once (host/shard.cpp: components, coding order, groups, exclusive scans)
+//            workers: extract their shards, upload, k_bounds per shard                               (phase A)
+//            caller:  bounds of the whole mesh = the shards' bounds combined with the scan's own tie rule (combine_shard_bounds)
+//            workers: quantisation + chunked encode of their shards -> one-segment containers        (phase B)
+//            caller:  concatenation into ONE .hry v0.3 (merge_containers) -- the segments meet in host memory
+//   decode   directory parsed and validated once (parse_sharded_directory), whole-mesh arrays allocated once
+//            workers: decode their segments (ordinary v0.2 bodies) and place them run by run into the whole numbering
+//
+// A worker runs on the CPUs of the memory node its device hangs on and limits the helper threads of its host phases to its
+// share of the process's CPUs.
+#include <sched.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "context.hpp"
+
+namespace hry {
+
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
+
+namespace {
+
+// CPUs of the memory node the device's PCI function belongs to (nullptr: unknown or a single node)
+const void *device_cpus(int device)
+{
+	char bus[64] = {};
+	if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) != hipSuccess) return nullptr;
+	for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+	char path[160];
+	snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+	FILE *f = fopen(path, "r");
+	if (!f) return nullptr;
+	int node = -1;
+	if (fscanf(f, "%d", &node) != 1) node = -1;
+	fclose(f);
+	return node_cpus(node);
+}
+
+unsigned worker_thread_budget(int n_workers)
+{
+	cpu_set_t cs;
+	CPU_ZERO(&cs);
+	unsigned allowed = sched_getaffinity(0, sizeof cs, &cs) == 0 ? (unsigned)CPU_COUNT(&cs) : std::thread::hardware_concurrency();
+	if (!allowed) allowed = 1;
+	return std::max(1u, std::min(host_threads(), allowed / (unsigned)std::max(1, n_workers)));
+}
+
+// body(w) for every worker w on a thread of its own (one worker: the caller's thread); the first exception is rethrown here
+template <typename F> void run_workers(Context *const *cxs, int n, F &&body)
+{
+	if (n == 1) { body(0); return; }
+	const unsigned budget = worker_thread_budget(n);
+	std::vector<std::thread> th;
+	std::exception_ptr err;
+	std::mutex mu;
+	for (int w = 0; w < n; ++w)
+		th.emplace_back([&, w] {
+			try {
+				stay_on_node(device_cpus(cxs[w]->device));
+				set_thread_budget(budget);
+				body(w);
+			} catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+		});
+	for (auto &t : th) t.join();
+	if (err) std::rethrow_exception(err);
+}
+
+void check_contexts(Context *const *cxs, int n)
+{
+	if (!cxs || n <= 0) throw Error(HRY_E_ARG, "need at least one context");
+	for (int i = 0; i < n; ++i) {
+		if (!cxs[i]) throw Error(HRY_E_ARG, "null context");
+		for (int j = 0; j < i; ++j) if (cxs[j] == cxs[i]) throw Error(HRY_E_ARG, "a context may appear only once: its streams and buffers serve one worker");
+	}
+}
+
+}   // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q, size_t nq, bool clear, int n_shards, int chunk_syms,
+                    std::vector<uint8_t> &out, hry_shard_timing &st)
+{
+	const auto t_all = Clock::now();
+	st = hry_shard_timing{};
+	check_contexts(cxs, n_ctx);
+	if (n_shards <= 0) n_shards = n_ctx;
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh");
+	// ---- plan, once
+	auto t0 = Clock::now();
+	ensure_twins(m);
+	ShardPlan plan;
+	shard_plan(m, (uint32_t)n_shards, plan);
+	st.plan_ms = ms_since(t0);
+	st.n_shards = (uint32_t)n_shards; st.n_contexts = (uint32_t)n_ctx; st.n_components = plan.A.ncomp;
+	for (uint32_t k = 0; k < plan.A.ncomp; ++k) st.n_groups += plan.A.group[k] == k;
+	const int nl = (int)m.lists.size();
+	std::vector<char> had(nl, 0);
+	bool need_bounds = false;
+	for (int l = 0; l < nl; ++l) { had[l] = m.lists[l].have_bounds || m.lists[l].ncomp() == 0; need_bounds |= !had[l]; }
+
+	// ---- phase A: extract (+ bounds of the shard)
+	std::vector<std::unique_ptr<Mesh>> shards((size_t)n_shards);
+	std::vector<double> w_extract(n_ctx, 0.0), w_bounds(n_ctx, 0.0), w_quant(n_ctx, 0.0), w_encode(n_ctx, 0.0);
+	t0 = Clock::now();
+	run_workers(cxs, n_ctx, [&](int w) {
+		for (int s = w; s < n_shards; s += n_ctx) {
+			auto t = Clock::now();
+			shards[s].reset(shard_extract(m, plan, (uint32_t)s));
+			w_extract[w] += ms_since(t);
+			if (need_bounds) {
+				t = Clock::now();
+				device_bounds(*cxs[w], *shards[s]);   // uploads the shard: it stays resident for phase B when the worker has one shard
+				w_bounds[w] += ms_since(t);
+			}
+		}
+	});
+	st.phase_a_ms = ms_since(t0);
+	// ---- bounds of the whole mesh
+	t0 = Clock::now();
+	if (need_bounds) {
+		std::vector<const Mesh*> view;
+		for (auto &s : shards) view.push_back(s.get());
+		for (int l = 0; l < nl; ++l) {
+			std::vector<uint8_t> bmin, bmax;
+			if (had[l]) { bmin = m.lists[l].bmin; bmax = m.lists[l].bmax; }
+			else combine_shard_bounds(view, l, bmin, bmax);
+			for (auto &s : shards) {
+				AttrList &L = s->lists[l];
+				L.bmin = bmin; L.bmax = bmax; L.bmin_at.clear(); L.bmax_at.clear(); L.have_bounds = true;
+			}
+			if (!had[l]) {   // what the reference's reader leaves in the mesh (ply/reader.cc:428)
+				AttrList &L = m.lists[l];
+				L.bmin = bmin; L.bmax = bmax; L.bmin_at.clear(); L.bmax_at.clear(); L.have_bounds = true;
+			}
+		}
+	}
+	st.combine_ms = ms_since(t0);
+	// ---- phase B: quantisation + encode, one segment per shard
+	std::vector<std::vector<uint8_t>> parts((size_t)n_shards);
+	t0 = Clock::now();
+	run_workers(cxs, n_ctx, [&](int w) {
+		hry_timing acc{};
+		for (int s = w; s < n_shards; s += n_ctx) {
+			Context &cx = *cxs[w];
+			auto t = Clock::now();
+			if (nq || clear) device_requant(cx, *shards[s], q, nq, clear);
+			w_quant[w] += ms_since(t);
+			t = Clock::now();
+			encode_chunked(cx, *shards[s], chunk_syms, parts[s]);
+			w_encode[w] += ms_since(t);
+			const hry_timing &tm = cx.timing;
+			acc.host_walk_ms += tm.host_walk_ms; acc.h2d_ms += tm.h2d_ms; acc.device_ms += tm.device_ms; acc.d2h_ms += tm.d2h_ms;
+			acc.k_predict_ms += tm.k_predict_ms; acc.k_entropy_ms += tm.k_entropy_ms; acc.n_symbols += tm.n_symbols; acc.payload_bytes += tm.payload_bytes;
+			acc.total_ms += tm.total_ms;
+			shards[s].reset();
+		}
+		cxs[w]->timing = acc;
+	});
+	st.phase_b_ms = ms_since(t0);
+	// ---- one container
+	t0 = Clock::now();
+	std::vector<const uint8_t*> pp;
+	std::vector<size_t> ps;
+	for (auto &v : parts) { pp.push_back(v.data()); ps.push_back(v.size()); }
+	merge_containers(pp.data(), ps.data(), pp.size(), out);
+	st.merge_ms = ms_since(t0);
+	auto mx = [](const std::vector<double> &v) { double x = 0; for (double y : v) x = std::max(x, y); return x; };
+	st.extract_ms = mx(w_extract); st.bounds_ms = mx(w_bounds); st.quant_ms = mx(w_quant); st.encode_ms = mx(w_encode);
+	for (int w = 0; w < n_ctx; ++w) st.host_walk_ms = std::max(st.host_walk_ms, cxs[w]->timing.host_walk_ms);
+	st.n_segments = 0;
+	for (auto &v : parts) st.n_segments += v.size() > 0;
+	st.total_ms = ms_since(t_all);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// decode of a sharded container: the segments s with s % shard_count == shard_index (shard_count <= 1: all), spread over the
+// contexts.  allow_partial: the caller accepts a mesh that holds only a share (its own segments, or a container that is itself
+// one rank's part); otherwise every face and half-edge must end up decoded.
+Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> g, int shard_index, int shard_count,
+                     bool allow_partial, hry_shard_timing *st_out)
+{
+	const auto t_all = Clock::now();
+	hry_shard_timing st{};
+	check_contexts(cxs, n_ctx);
+	if (shard_count < 0 || shard_index < 0 || (shard_count > 0 && shard_index >= shard_count)) throw Error(HRY_E_ARG, "invalid shard selection");
+	if (g->general) throw Error(HRY_E_FORMAT, "sharded containers hold the PLY layout only");
+	const uint32_t gnv = g->nv, gnf = g->nf, gne = g->declared_ne;
+	auto t0 = Clock::now();
+	ShardedDirectory dir;
+	parse_sharded_directory(p, n, hdr, gnv, gnf, gne, dir, true);
+	const uint32_t nseg = (uint32_t)dir.segments.size();
+	std::vector<uint32_t> mine;
+	for (uint32_t si = 0; si < nseg; ++si) if (shard_count <= 1 || (int)(si % (uint32_t)shard_count) == shard_index) mine.push_back(si);
+	const bool everything = dir.complete && mine.size() == nseg;
+	if (!everything && !allow_partial)
+		throw Error(HRY_E_FORMAT, dir.complete ? "a share of the segments decodes into a partial mesh: ask for it (HRY_FLAG_PARTIAL)"
+		                                       : "sharded container does not cover the mesh (missing segments); HRY_FLAG_PARTIAL decodes what is there");
+	st.plan_ms = ms_since(t0);
+	st.n_segments = (uint32_t)mine.size(); st.n_contexts = (uint32_t)n_ctx; st.n_shards = nseg;
+	// ---- the whole mesh's arrays.  BigVec does not fill on resize: covered ranges are written by the placement below, the rest
+	// by the filler pass after it.
+	g->face_off.resize((size_t)gnf + 1);
+	g->org.resize(gne); g->twin.resize(gne);
+	for (int l = 0; l < 2; ++l) g->lists[l].data.resize((size_t)g->lists[l].count * g->lists[l].stride());
+	g->covered.clear();
+	const size_t vstride = (size_t)g->lists[1].stride(), fstride = (size_t)g->lists[0].stride();
+
+	std::vector<double> w_decode(n_ctx, 0.0), w_place(n_ctx, 0.0);
+	t0 = Clock::now();
+	run_workers(cxs, n_ctx, [&](int w) {
+		Context &cx = *cxs[w];
+		hry_timing acc{};
+		const unsigned nt = std::max(1u, host_threads());
+		for (size_t k = (size_t)w; k < mine.size(); k += (size_t)n_ctx) {
+			const ShardedDirectory::Segment &sg = dir.segments[mine[k]];
+			const std::vector<ShardRun> &runs = sg.runs;
+			const uint32_t nr = (uint32_t)runs.size();
+			const uint8_t *sp = p + sg.offset;
+			std::vector<uint32_t> cv(nr + 1, 0), cf(nr + 1, 0), ch(nr + 1, 0);
+			for (uint32_t j = 0; j < nr; ++j) { cv[j + 1] = cv[j] + runs[j].n_vertices; cf[j + 1] = cf[j] + runs[j].n_faces; ch[j + 1] = ch[j] + runs[j].n_halfedges; }
+			const uint32_t lnv = sg.nv, lnf = sg.nf, lne = sg.ne;
+			// the shard as a mesh of its own: formats and bounds of the whole, sizes of the runs
+			auto t = Clock::now();
+			std::unique_ptr<Mesh> lm(new Mesh());
+			lm->nv = lnv; lm->nf = lnf; lm->declared_ne = lne;
+			lm->have_degree = g->have_degree;
+			for (int l = 0; l < 2; ++l) {
+				const AttrList &L = g->lists[l];
+				AttrList &D = lm->lists[l];
+				D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
+				D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
+				D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = true;
+				D.count = l == 0 ? lm->nf : lm->nv;
+				D.data.assign((size_t)D.count * D.stride(), 0);
+			}
+			std::unique_ptr<Mesh> dm(decode_chunked(cx, sp + sg.body_at, sg.bytes - sg.body_at, 0, std::move(lm)));
+			w_decode[w] += ms_since(t);
+			const hry_timing &tm = cx.timing;
+			acc.host_walk_ms += tm.host_walk_ms; acc.h2d_ms += tm.h2d_ms; acc.device_ms += tm.device_ms; acc.d2h_ms += tm.d2h_ms;
+			acc.k_predict_ms += tm.k_predict_ms; acc.k_entropy_ms += tm.k_entropy_ms; acc.k_chain_ms += tm.k_chain_ms;
+			acc.n_symbols += tm.n_symbols; acc.payload_bytes += tm.payload_bytes;
+			if (dm->ne() != lne || dm->nf != lnf || dm->nv != lnv) throw Error(HRY_E_FORMAT, "corrupt segment (sizes do not match its runs)");
+			// ---- into the numbering of the whole mesh
+			t = Clock::now();
+			BigVec<uint32_t> l2g;
+			l2g.resize((size_t)lnv);
+			struct Task { uint32_t run, kind, b, e; };   // kind 0 vertices, 1 faces, 2 half-edges
+			std::vector<Task> tasks;
+			const uint32_t grain = 1u << 16;
+			for (uint32_t j = 0; j < nr; ++j) {
+				for (uint32_t b = 0; b < runs[j].n_vertices; b += grain) tasks.push_back(Task{ j, 0, b, std::min(runs[j].n_vertices, b + grain) });
+				for (uint32_t b = 0; b < runs[j].n_faces; b += grain) tasks.push_back(Task{ j, 1, b, std::min(runs[j].n_faces, b + grain) });
+			}
+			const size_t n_vf_tasks = tasks.size();
+			for (uint32_t j = 0; j < nr; ++j)
+				for (uint32_t b = 0; b < runs[j].n_halfedges; b += grain) tasks.push_back(Task{ j, 2, b, std::min(runs[j].n_halfedges, b + grain) });
+			std::atomic<bool> bad{ false };
+			auto run_tasks = [&](size_t from, size_t to) {
+				std::atomic<size_t> next{ from };
+				parallel_for((unsigned)std::max<size_t>(1, std::min<size_t>(nt, (to - from + 3) / 4)), [&](unsigned) {
+					for (;;) {
+						const size_t ti = next.fetch_add(1, std::memory_order_relaxed);
+						if (ti >= to) break;
+						const Task &tk = tasks[ti];
+						const ShardRun &r = runs[tk.run];
+						if (tk.kind == 0) {
+							for (uint32_t i = tk.b; i < tk.e; ++i) l2g[cv[tk.run] + i] = r.first_vertex + i;
+							if (vstride) memcpy(g->lists[1].data.data() + ((size_t)r.first_vertex + tk.b) * vstride, dm->lists[1].data.data() + ((size_t)cv[tk.run] + tk.b) * vstride, (size_t)(tk.e - tk.b) * vstride);
+						} else if (tk.kind == 1) {
+							const uint32_t shift = r.first_halfedge - ch[tk.run];   // modulo 2^32: local half-edge + shift = half-edge of the whole mesh
+							for (uint32_t i = tk.b; i < tk.e; ++i) {
+								const uint32_t lo = dm->face_off[(size_t)cf[tk.run] + i], hi = dm->face_off[(size_t)cf[tk.run] + i + 1];
+								if (lo > hi || hi > ch[tk.run + 1] || lo < ch[tk.run]) { bad.store(true, std::memory_order_relaxed); continue; }
+								g->face_off[(size_t)r.first_face + i + 1] = hi + shift;
+							}
+							if (tk.b == 0 && dm->face_off[cf[tk.run]] != ch[tk.run]) bad.store(true, std::memory_order_relaxed);
+							if (tk.e == r.n_faces && dm->face_off[(size_t)cf[tk.run] + r.n_faces] != ch[tk.run + 1]) bad.store(true, std::memory_order_relaxed);
+							if (fstride) memcpy(g->lists[0].data.data() + ((size_t)r.first_face + tk.b) * fstride, dm->lists[0].data.data() + ((size_t)cf[tk.run] + tk.b) * fstride, (size_t)(tk.e - tk.b) * fstride);
+						} else {
+							const uint32_t lo = ch[tk.run], hi = ch[tk.run + 1], shift = r.first_halfedge - lo;
+							for (uint32_t i = tk.b; i < tk.e; ++i) {
+								const uint32_t h = lo + i, tw = dm->twin[h], v = dm->org[h];
+								if (tw < lo || tw >= hi || v >= lnv) { bad.store(true, std::memory_order_relaxed); g->org[(size_t)r.first_halfedge + i] = 0; g->twin[(size_t)r.first_halfedge + i] = r.first_halfedge + i; continue; }
+								g->org[(size_t)r.first_halfedge + i] = l2g[v];
+								g->twin[(size_t)r.first_halfedge + i] = tw + shift;
+							}
+						}
+					}
+				});
+			};
+			run_tasks(0, n_vf_tasks);               // the vertex map first: half-edges of one run may name vertices of another
+			run_tasks(n_vf_tasks, tasks.size());
+			if (bad.load()) throw Error(HRY_E_FORMAT, "corrupt segment (runs do not match the connectivity)");
+			w_place[w] += ms_since(t);
+		}
+		cx.timing = acc;
+	});
+	st.phase_b_ms = ms_since(t0);
+	// ---- what no decoded run covers gets filler: faces without half-edges (the last face of a gap takes the gap's half-edges, so
+	// the offsets stay monotone and inside the arrays), half-edges that are borders at vertex 0, zero records.  In a complete decode
+	// that is exactly the vertices no face references (the reference never codes them: zero records).
+	t0 = Clock::now();
+	for (uint32_t si : mine) g->covered.insert(g->covered.end(), dir.segments[si].runs.begin(), dir.segments[si].runs.end());
+	std::vector<ShardRun> byf;
+	for (const ShardRun &r : g->covered) if (r.n_faces) byf.push_back(r);
+	std::sort(byf.begin(), byf.end(), [](const ShardRun &a, const ShardRun &b) { return a.first_face < b.first_face; });
+	{
+		uint64_t f_at = 0, h_at = 0;
+		auto gap = [&](uint64_t f_to, uint64_t h_to) {   // faces [f_at, f_to), half-edges [h_at, h_to) belong to nobody
+			for (uint64_t f = f_at; f < f_to; ++f) g->face_off[(size_t)f] = (uint32_t)h_at;
+			for (uint64_t h = h_at; h < h_to; ++h) { g->org[(size_t)h] = 0; g->twin[(size_t)h] = (uint32_t)h; }
+			if (fstride && f_to > f_at) memset(g->lists[0].data.data() + (size_t)f_at * fstride, 0, (size_t)(f_to - f_at) * fstride);
+		};
+		for (const ShardRun &r : byf) {
+			gap(r.first_face, r.first_halfedge);
+			g->face_off[r.first_face] = r.first_halfedge;
+			f_at = (uint64_t)r.first_face + r.n_faces; h_at = (uint64_t)r.first_halfedge + r.n_halfedges;
+		}
+		gap(gnf, gne);
+		g->face_off[gnf] = gne;
+		if (h_at < gne && f_at == gnf && gnf) {   // half-edges behind the last face: nothing may own them
+			throw Error(HRY_E_FORMAT, "corrupt sharded container (half-edges outside every face)");
+		}
+		std::vector<std::pair<uint32_t, uint32_t>> vr;
+		for (const ShardRun &r : g->covered) if (r.n_vertices) vr.push_back({ r.first_vertex, r.n_vertices });
+		std::sort(vr.begin(), vr.end());
+		uint64_t at = 0;
+		auto zero = [&](uint64_t b, uint64_t e) { if (e > b && vstride) memset(g->lists[1].data.data() + b * vstride, 0, (size_t)(e - b) * vstride); };
+		for (const auto &r : vr) { zero(at, r.first); at = (uint64_t)r.first + r.second; }
+		zero(at, gnv);
+	}
+	st.merge_ms = ms_since(t0);
+	g->partial = !everything;
+	auto mx = [](const std::vector<double> &v) { double x = 0; for (double y : v) x = std::max(x, y); return x; };
+	st.encode_ms = mx(w_decode); st.extract_ms = mx(w_place);
+	for (int w = 0; w < n_ctx; ++w) st.host_walk_ms = std::max(st.host_walk_ms, cxs[w]->timing.host_walk_ms);
+	st.total_ms = ms_since(t_all);
+	for (int w = 0; w < n_ctx; ++w) cxs[w]->timing.total_ms = st.total_ms;
+	if (st_out) *st_out = st;
+	g->device_token = 0;
+	return g.release();
+}
+
+}   // namespace hry

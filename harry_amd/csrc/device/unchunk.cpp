@@ -654,150 +654,6 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	return m.release();
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Sharded container (.hry v0.3, host/shard.cpp): every segment is the v0.2 body of one shard in the shard's own numbering
-// and decodes on its own; its runs give the place of its vertices, faces and half-edges in the numbering of the whole
-// mesh (the coding order across all components, cbm/decoder.h:48,75,145,162).  shard_count > 1: only the segments
-// i with i % shard_count == shard_index are decoded (one process per GPU, each takes its share); the rest of the
-// whole-mesh arrays stays unwritten and Mesh::covered lists what is valid.
-// ---------------------------------------------------------------------------------------------------------
-Mesh *decode_sharded(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> g, int shard_index, int shard_count)
-{
-	auto t_all = Clock::now();
-	if (shard_count < 0 || shard_index < 0 || (shard_count > 0 && shard_index >= shard_count)) throw Error(HRY_E_ARG, "invalid shard selection");
-	if (n < hdr + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
-	uint32_t nseg;
-	memcpy(&nseg, p + hdr, 4);
-	if ((uint64_t)nseg * 8 > n - hdr - 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
-	std::vector<uint64_t> seg_len(nseg);
-	if (nseg) memcpy(seg_len.data(), p + hdr + 4, 8ull * nseg);
-	size_t off = hdr + 4 + 8ull * nseg;
-	const uint32_t gnv = g->nv, gnf = g->nf, gne = g->declared_ne;
-	// the whole mesh's arrays; BigVec does not fill on resize, every covered element is written below
-	g->face_off.resize((size_t)gnf + 1); g->face_off[0] = 0; g->face_off[gnf] = gne;   // (the last entry is the half-edge count: Mesh::ne())
-	g->org.resize(gne); g->twin.resize(gne);
-	for (int l = 0; l < 2; ++l) g->lists[l].data.resize((size_t)g->lists[l].count * g->lists[l].stride());
-	g->covered.clear();
-	hry_timing acc{};
-	const unsigned nt = host_threads();
-	for (uint32_t si = 0; si < nseg; ++si) {
-		if (seg_len[si] > n - off) throw Error(HRY_E_FORMAT, "truncated sharded container");
-		const uint8_t *sp = p + off;
-		const size_t sn = (size_t)seg_len[si];
-		off += sn;
-		if (shard_count > 1 && (int)(si % (uint32_t)shard_count) != shard_index) continue;
-		if (sn < 4) throw Error(HRY_E_FORMAT, "truncated segment");
-		uint32_t nr;
-		memcpy(&nr, sp, 4);
-		if ((uint64_t)nr * sizeof(ShardRun) > sn - 4) throw Error(HRY_E_FORMAT, "truncated segment (runs)");
-		std::vector<ShardRun> runs(nr);
-		if (nr) memcpy(runs.data(), sp + 4, sizeof(ShardRun) * (size_t)nr);
-		const size_t body_at = 4 + sizeof(ShardRun) * (size_t)nr;
-		uint64_t lnv = 0, lnf = 0, lne = 0;
-		std::vector<uint32_t> cv(nr + 1, 0), cf(nr + 1, 0), ch(nr + 1, 0);
-		for (uint32_t j = 0; j < nr; ++j) {
-			const ShardRun &r = runs[j];
-			if ((uint64_t)r.first_vertex + r.n_vertices > gnv || (uint64_t)r.first_face + r.n_faces > gnf || (uint64_t)r.first_halfedge + r.n_halfedges > gne)
-				throw Error(HRY_E_FORMAT, "corrupt sharded container (run outside the mesh)");
-			lnv += r.n_vertices; lnf += r.n_faces; lne += r.n_halfedges;
-			if (lnv > gnv || lnf > gnf || lne > gne) throw Error(HRY_E_FORMAT, "corrupt sharded container (runs exceed the mesh)");
-			cv[j + 1] = (uint32_t)lnv; cf[j + 1] = (uint32_t)lnf; ch[j + 1] = (uint32_t)lne;
-		}
-		// the shard as a mesh of its own: formats and bounds of the whole, sizes of the runs
-		std::unique_ptr<Mesh> lm(new Mesh());
-		lm->nv = (uint32_t)lnv; lm->nf = (uint32_t)lnf; lm->declared_ne = (uint32_t)lne;
-		lm->have_degree = g->have_degree;
-		for (int l = 0; l < 2; ++l) {
-			const AttrList &L = g->lists[l];
-			AttrList &D = lm->lists[l];
-			D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
-			D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
-			D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = true;
-			D.count = l == 0 ? lm->nf : lm->nv;
-			D.data.assign((size_t)D.count * D.stride(), 0);
-		}
-		std::unique_ptr<Mesh> dm(decode_chunked(cx, sp + body_at, sn - body_at, 0, std::move(lm)));
-		const hry_timing &tm = cx.timing;
-		acc.host_walk_ms += tm.host_walk_ms; acc.h2d_ms += tm.h2d_ms; acc.device_ms += tm.device_ms; acc.d2h_ms += tm.d2h_ms;
-		acc.k_predict_ms += tm.k_predict_ms; acc.k_entropy_ms += tm.k_entropy_ms; acc.k_chain_ms += tm.k_chain_ms;
-		acc.n_symbols += tm.n_symbols; acc.payload_bytes += tm.payload_bytes;
-		if (dm->ne() != (uint32_t)lne) throw Error(HRY_E_FORMAT, "corrupt segment (polygon edge count)");
-		// ---- into the numbering of the whole mesh
-		BigVec<uint32_t> l2g;
-		l2g.resize((size_t)lnv);
-		struct Task { uint32_t run, kind, b, e; };   // kind 0 vertices, 1 faces, 2 half-edges
-		std::vector<Task> tasks;
-		const uint32_t grain = 1u << 16;
-		for (uint32_t j = 0; j < nr; ++j) {
-			for (uint32_t b = 0; b < runs[j].n_vertices; b += grain) tasks.push_back(Task{ j, 0, b, std::min(runs[j].n_vertices, b + grain) });
-			for (uint32_t b = 0; b < runs[j].n_faces; b += grain) tasks.push_back(Task{ j, 1, b, std::min(runs[j].n_faces, b + grain) });
-		}
-		const size_t n_vf_tasks = tasks.size();
-		for (uint32_t j = 0; j < nr; ++j)
-			for (uint32_t b = 0; b < runs[j].n_halfedges; b += grain) tasks.push_back(Task{ j, 2, b, std::min(runs[j].n_halfedges, b + grain) });
-		const size_t vstride = (size_t)g->lists[1].stride(), fstride = (size_t)g->lists[0].stride();
-		std::atomic<bool> bad{ false };
-		auto run_tasks = [&](size_t from, size_t to) {
-			std::atomic<size_t> next{ from };
-			parallel_for((unsigned)std::max<size_t>(1, std::min<size_t>(nt, (to - from + 3) / 4)), [&](unsigned) {
-				for (;;) {
-					const size_t ti = next.fetch_add(1, std::memory_order_relaxed);
-					if (ti >= to) break;
-					const Task &t = tasks[ti];
-					const ShardRun &r = runs[t.run];
-					if (t.kind == 0) {
-						for (uint32_t i = t.b; i < t.e; ++i) l2g[cv[t.run] + i] = r.first_vertex + i;
-						if (vstride) memcpy(g->lists[1].data.data() + ((size_t)r.first_vertex + t.b) * vstride, dm->lists[1].data.data() + ((size_t)cv[t.run] + t.b) * vstride, (size_t)(t.e - t.b) * vstride);
-					} else if (t.kind == 1) {
-						const uint32_t shift = r.first_halfedge - ch[t.run];   // modulo 2^32: local half-edge + shift = half-edge of the whole mesh
-						for (uint32_t i = t.b; i < t.e; ++i) g->face_off[(size_t)r.first_face + i + 1] = dm->face_off[(size_t)cf[t.run] + i + 1] + shift;
-						if (t.b == 0 && dm->face_off[cf[t.run]] != ch[t.run]) bad.store(true, std::memory_order_relaxed);
-						if (fstride) memcpy(g->lists[0].data.data() + ((size_t)r.first_face + t.b) * fstride, dm->lists[0].data.data() + ((size_t)cf[t.run] + t.b) * fstride, (size_t)(t.e - t.b) * fstride);
-					} else {
-						const uint32_t lo = ch[t.run], hi = ch[t.run + 1], shift = r.first_halfedge - lo;
-						for (uint32_t i = t.b; i < t.e; ++i) {
-							const uint32_t h = lo + i, tw = dm->twin[h], v = dm->org[h];
-							if (tw < lo || tw >= hi || v >= (uint32_t)lnv) { bad.store(true, std::memory_order_relaxed); continue; }
-							g->org[(size_t)r.first_halfedge + i] = l2g[v];
-							g->twin[(size_t)r.first_halfedge + i] = tw + shift;
-						}
-					}
-				}
-			});
-		};
-		run_tasks(0, n_vf_tasks);               // the vertex map first: half-edges of one run may name vertices of another
-		run_tasks(n_vf_tasks, tasks.size());
-		if (bad.load()) throw Error(HRY_E_FORMAT, "corrupt segment (runs do not match the connectivity)");
-		for (uint32_t j = 0; j < nr; ++j) if (runs[j].n_faces) g->face_off[runs[j].first_face] = runs[j].first_halfedge;
-		g->covered.insert(g->covered.end(), runs.begin(), runs.end());
-	}
-	// runs must not overlap; what no run covers (vertices that no face references: the reference never codes them) stays zero
-	std::vector<ShardRun> &cvd = g->covered;
-	std::sort(cvd.begin(), cvd.end(), [](const ShardRun &a, const ShardRun &b) { return a.first_face < b.first_face || (a.first_face == b.first_face && a.n_faces < b.n_faces); });
-	for (size_t i = 1; i < cvd.size(); ++i)
-		if ((uint64_t)cvd[i - 1].first_face + cvd[i - 1].n_faces > cvd[i].first_face || (uint64_t)cvd[i - 1].first_halfedge + cvd[i - 1].n_halfedges > cvd[i].first_halfedge)
-			throw Error(HRY_E_FORMAT, "corrupt sharded container (overlapping runs)");
-	{
-		std::vector<std::pair<uint32_t, uint32_t>> vr;
-		for (const ShardRun &r : cvd) if (r.n_vertices) vr.push_back({ r.first_vertex, r.n_vertices });
-		std::sort(vr.begin(), vr.end());
-		for (size_t i = 1; i < vr.size(); ++i) if ((uint64_t)vr[i - 1].first + vr[i - 1].second > vr[i].first) throw Error(HRY_E_FORMAT, "corrupt sharded container (overlapping runs)");
-		uint64_t nfc = 0, nhc = 0;
-		for (const ShardRun &r : cvd) { nfc += r.n_faces; nhc += r.n_halfedges; }
-		if (nfc == gnf && nhc == gne) {   // the whole mesh is here: vertices no run covers are the ones no face references
-			const size_t vstride = (size_t)g->lists[1].stride();
-			uint64_t at = 0;
-			auto zero = [&](uint64_t b, uint64_t e) { if (e > b && vstride) memset(g->lists[1].data.data() + b * vstride, 0, (size_t)(e - b) * vstride); };
-			for (const auto &r : vr) { zero(at, r.first); at = (uint64_t)r.first + r.second; }
-			zero(at, gnv);
-		}
-	}
-	cx.timing = acc;
-	cx.timing.total_ms = ms_since(t_all);
-	g->device_token = 0;
-	return g.release();
-}
-
 // General bindings (general.cpp) whose vertices all carry a private record of ONE list: that list is the vertex list of the PLY
 // layout in everything that matters to the reconstruction chains (record i belongs to the i-th coded vertex, candidates are the
 // parallelograms of the fan), so it takes them.  The mesh lends its connectivity and the list for the duration of the call.

@@ -183,9 +183,16 @@ const void *callers_neighbour_cpus()
 	return CPU_COUNT(&it->second) > 0 ? &it->second : nullptr;
 }
 
+static const NodeTable &node_table() { static const NodeTable *tab = new NodeTable(); return *tab; }
+const void *node_cpus(int node)
+{
+	const NodeTable &tab = node_table();
+	if (node < 0 || (size_t)node >= tab.nodes.size() || CPU_COUNT(&tab.nodes[node]) == 0) return nullptr;
+	return &tab.nodes[node];
+}
 const void *callers_node_cpus()
 {
-	static const NodeTable *tab = new NodeTable();
+	const NodeTable *tab = &node_table();
 	if (tab->nodes.empty()) return nullptr;
 	const int cpu = sched_getcpu();
 	if (cpu < 0) return nullptr;

@@ -664,8 +664,11 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 
 // ---- several host threads --------------------------------------------------------
 }   // namespace
+static thread_local unsigned t_thread_budget = 0;
+void set_thread_budget(unsigned n) { t_thread_budget = n; }
 unsigned host_threads()
 {
+	if (t_thread_budget) return t_thread_budget;
 	if (const char *e = getenv("HRY_HOST_THREADS")) { int v = atoi(e); return v > 0 ? (unsigned)v : 1u; }
 	// up to 32, and at most an eighth of a large node's cores: eight processes (one per GPU) share the node
 	unsigned hw = std::thread::hardware_concurrency();
@@ -1057,6 +1060,7 @@ std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark>
 
 void analyse_components(const Mesh &m, ComponentAnalysis &A)
 {
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
 	ensure_twins(m);
 	int udeg = 0;
 	if (!m.uniform_degree(udeg)) udeg = 0;
@@ -1093,6 +1097,7 @@ void op_position_table(const WalkResult &w, std::vector<uint32_t> &thr, std::vec
 
 void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model, bool one_sequence)
 {
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
 	ensure_twins(m);
 	int udeg = 0;
 	if (!m.uniform_degree(udeg)) udeg = 0;

@@ -130,6 +130,19 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan);
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard);
 // several single- or multi-segment sharded containers (.hry v0.3) of the same mesh -> one
 void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, std::vector<uint8_t> &out);
+// the directory of a sharded container, validated against the header's sizes (throws HRY_E_FORMAT on damage)
+struct ShardedDirectory {
+	struct Segment { size_t offset = 0, bytes = 0, body_at = 0; std::vector<ShardRun> runs; uint32_t nv = 0, nf = 0, ne = 0; };   // body_at: v0.2 body inside the segment
+	std::vector<Segment> segments;
+	bool complete = false;   // every face and half-edge of the mesh lies in some run
+};
+void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gnv, uint32_t gnf, uint32_t gne, ShardedDirectory &dir, bool allow_gaps = false);
+// bounds of list l of the whole mesh from device-computed bounds of its shards (the scan's own tie rule, see shard.cpp)
+void combine_shard_bounds(const std::vector<const Mesh*> &shards, int l, std::vector<uint8_t> &bmin, std::vector<uint8_t> &bmax);
+// a worker thread of the in-process multi-GPU executor limits the helper threads of the host phases it starts (0: no limit)
+void set_thread_budget(unsigned n);
+// the CPUs of memory node `node` (nullptr: unknown / single node); block_pool.cpp
+const void *node_cpus(int node);
 
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
 // seg_start: first decode rank of every connected component (+ end sentinel); seg_level[k]: 0 = the component touches no vertex

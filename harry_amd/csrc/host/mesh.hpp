@@ -192,6 +192,8 @@ struct Mesh {
 	uint32_t declared_ne = 0;            // half-edge count announced by a .hry header (the connectivity follows later)
 	ShardInfo shard;                     // set by shard_extract: this mesh is a shard of a larger one
 	std::vector<ShardRun> covered;       // set by the decoder of a sharded container: the runs of the whole numbering that were decoded
+	bool partial = false;                // a share of a sharded container's segments (shard_count > 1): everything outside `covered` is
+	                                     // filler (empty faces, zero records) -- readable through the accessors, refused by every consumer
 
 	uint32_t ne() const { return face_off.back(); }
 	uint64_t ntri() const { return (uint64_t)ne() - 2ull * nf; }

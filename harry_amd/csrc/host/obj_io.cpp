@@ -296,6 +296,7 @@ Mesh *mesh_from_obj(const uint8_t *buf, size_t n, const char *directory)
 // "vn" lines on their own sees indices that are too large by the number of "vt" lines.
 void mesh_to_obj(const Mesh &m, ByteSink &out)
 {
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
 	const size_t nl = m.lists.size();
 	auto has = [&](size_t l, int interp) { const AttrList &L = m.lists[l]; return interp < (int)L.interp_len.size() && L.interp_len[interp] != 0; };
 	auto len_of = [&](size_t l, int interp) { const AttrList &L = m.lists[l]; return interp < (int)L.interp_len.size() ? L.interp_len[interp] : 0; };

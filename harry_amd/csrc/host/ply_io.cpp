@@ -648,6 +648,7 @@ void general_to_ply(const Mesh &m, bool ascii, ByteSink &out, bool packed)
 
 void mesh_to_ply(const Mesh &m, bool ascii, ByteSink &out, bool packed)
 {
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
 	if (m.general) { general_to_ply(m, ascii, out, packed); return; }
 	std::string h = std::string("ply\nformat ") + (ascii ? "ascii" : "binary_little_endian") + " 1.0\ncomment decompressed using harry mesh compressor\n";
 	auto props = [&](const AttrList &L) {

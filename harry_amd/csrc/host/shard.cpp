@@ -111,7 +111,9 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 	const Ranges R(m.ne());
 	const unsigned nt = R.nt;
 	auto face_sel = [&](uint32_t f) { return plan.shard_of[A.rank_of[A.comp[f]]] == shard; };
-	auto vert_sel = [&](uint32_t v) { const uint32_t o = A.vertex_owner[v]; return o != NONE32 && plan.shard_of[o] == shard; };
+	// vertices that no face references are never coded (the reference's walk does not reach them) but its bounds scan reads every
+	// record (structs/quant.h:30-44): shard 0 carries them, so that the shards' bounds combine to the whole mesh's
+	auto vert_sel = [&](uint32_t v) { const uint32_t o = A.vertex_owner[v]; return o != NONE32 ? plan.shard_of[o] == shard : shard == 0; };
 	// compact numbering: ascending input index
 	std::vector<uint32_t> cf(nt + 1, 0), ch(nt + 1, 0), cv(nt + 1, 0);
 	parallel_for(nt, [&](unsigned t) {
@@ -221,14 +223,13 @@ PartView parse_part(const uint8_t *p, size_t n)
 	PartView v{};
 	v.hdr = read_hry_header(p, n, tmp, minor, false);
 	if (minor != 3) throw Error(HRY_E_ARG, "merge: not a sharded (.hry v0.3) container");
-	if (n < v.hdr + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
-	memcpy(&v.nseg, p + v.hdr, 4);
-	if ((uint64_t)v.nseg * 8 > n - v.hdr - 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
+	ShardedDirectory dir;   // every check a reader makes: a damaged part must not end up inside a merged container
+	parse_sharded_directory(p, n, v.hdr, tmp.nv, tmp.nf, tmp.declared_ne, dir, true);
+	v.nseg = (uint32_t)dir.segments.size();
 	v.lens = p + v.hdr + 4;
 	v.segs = v.lens + 8ull * v.nseg;
 	uint64_t tot = 0;
-	for (uint32_t i = 0; i < v.nseg; ++i) { uint64_t l; memcpy(&l, v.lens + 8ull * i, 8); if (l > n) throw Error(HRY_E_FORMAT, "truncated sharded container"); tot += l; }
-	if (tot != n - (size_t)(v.segs - p)) throw Error(HRY_E_FORMAT, "sharded container: segment sizes do not add up");
+	for (const auto &sg : dir.segments) tot += sg.bytes;
 	v.seg_bytes = (size_t)tot;
 	return v;
 }
@@ -253,6 +254,126 @@ void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n
 	out.insert(out.end(), (const uint8_t*)&ns32, (const uint8_t*)&ns32 + 4);
 	for (size_t i = 0; i < n; ++i) out.insert(out.end(), pv[i].lens, pv[i].lens + 8ull * pv[i].nseg);
 	for (size_t i = 0; i < n; ++i) out.insert(out.end(), pv[i].segs, pv[i].segs + pv[i].seg_bytes);
+}
+
+// ---- directory of a sharded container -------------------------------------------------------------------------------
+// Everything a reader needs before it touches a segment body, checked against the header's sizes: segment extents inside the
+// buffer, run tables inside their segments, runs inside the mesh, no two runs (of any segments) overlapping, and -- unless
+// allow_gaps -- every face and every half-edge covered (vertices need not be: the reference never codes a vertex no face
+// references).  Host-only, so the sanitizer build of tests/native reaches it.
+void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gnv, uint32_t gnf, uint32_t gne, ShardedDirectory &dir, bool allow_gaps)
+{
+	dir = ShardedDirectory();
+	if (n < hdr + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
+	uint32_t nseg;
+	memcpy(&nseg, p + hdr, 4);
+	if ((uint64_t)nseg * 8 > n - hdr - 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
+	size_t off = hdr + 4 + 8ull * nseg;
+	dir.segments.resize(nseg);
+	for (uint32_t si = 0; si < nseg; ++si) {
+		ShardedDirectory::Segment &sg = dir.segments[si];
+		uint64_t len;
+		memcpy(&len, p + hdr + 4 + 8ull * si, 8);
+		if (len > n - off) throw Error(HRY_E_FORMAT, "truncated sharded container");
+		sg.offset = off; sg.bytes = (size_t)len;
+		off += (size_t)len;
+		if (sg.bytes < 4) throw Error(HRY_E_FORMAT, "truncated segment");
+		uint32_t nr;
+		memcpy(&nr, p + sg.offset, 4);
+		if ((uint64_t)nr * sizeof(ShardRun) > sg.bytes - 4) throw Error(HRY_E_FORMAT, "truncated segment (runs)");
+		sg.runs.resize(nr);
+		if (nr) memcpy(sg.runs.data(), p + sg.offset + 4, sizeof(ShardRun) * (size_t)nr);
+		sg.body_at = 4 + sizeof(ShardRun) * (size_t)nr;
+		uint64_t lnv = 0, lnf = 0, lne = 0;
+		for (const ShardRun &r : sg.runs) {
+			if ((uint64_t)r.first_vertex + r.n_vertices > gnv || (uint64_t)r.first_face + r.n_faces > gnf || (uint64_t)r.first_halfedge + r.n_halfedges > gne)
+				throw Error(HRY_E_FORMAT, "corrupt sharded container (run outside the mesh)");
+			if (r.n_halfedges < r.n_faces) throw Error(HRY_E_FORMAT, "corrupt sharded container (run with fewer half-edges than faces)");
+			lnv += r.n_vertices; lnf += r.n_faces; lne += r.n_halfedges;
+		}
+		if (lnv > gnv || lnf > gnf || lne > gne) throw Error(HRY_E_FORMAT, "corrupt sharded container (runs exceed the mesh)");
+		sg.nv = (uint32_t)lnv; sg.nf = (uint32_t)lnf; sg.ne = (uint32_t)lne;
+	}
+	if (off != n) throw Error(HRY_E_FORMAT, "sharded container: segment sizes do not add up");
+	// overlap and coverage over the runs of ALL segments
+	struct Iv { uint64_t b, e; };
+	std::vector<Iv> fv, hv, vv;
+	for (const auto &sg : dir.segments)
+		for (const ShardRun &r : sg.runs) {
+			if (r.n_faces) fv.push_back(Iv{ r.first_face, (uint64_t)r.first_face + r.n_faces });
+			if (r.n_halfedges) hv.push_back(Iv{ r.first_halfedge, (uint64_t)r.first_halfedge + r.n_halfedges });
+			if (r.n_vertices) vv.push_back(Iv{ r.first_vertex, (uint64_t)r.first_vertex + r.n_vertices });
+		}
+	auto disjoint = [](std::vector<Iv> &v, uint64_t &covered) {
+		std::sort(v.begin(), v.end(), [](const Iv &a, const Iv &b) { return a.b < b.b; });
+		covered = 0;
+		for (size_t i = 0; i < v.size(); ++i) {
+			if (i && v[i - 1].e > v[i].b) return false;
+			covered += v[i].e - v[i].b;
+		}
+		return true;
+	};
+	uint64_t cf = 0, ch = 0, cvv = 0;
+	if (!disjoint(fv, cf) || !disjoint(hv, ch) || !disjoint(vv, cvv)) throw Error(HRY_E_FORMAT, "corrupt sharded container (overlapping runs)");
+	// faces and half-edges are numbered by the same order of the components (exclusive scans, cbm/decoder.h:48,75,145,162): a run
+	// that comes later in the faces comes later in the half-edges -- what keeps the merged face offsets monotone
+	{
+		std::vector<const ShardRun*> byf;
+		for (const auto &sg : dir.segments)
+			for (const ShardRun &r : sg.runs) {
+				if (r.n_faces) byf.push_back(&r);
+				else if (r.n_halfedges || r.n_vertices) throw Error(HRY_E_FORMAT, "corrupt sharded container (run without faces)");
+			}
+		std::sort(byf.begin(), byf.end(), [](const ShardRun *a, const ShardRun *b) { return a->first_face < b->first_face; });
+		for (size_t i = 1; i < byf.size(); ++i)
+			if ((uint64_t)byf[i - 1]->first_halfedge + byf[i - 1]->n_halfedges > byf[i]->first_halfedge)
+				throw Error(HRY_E_FORMAT, "corrupt sharded container (faces and half-edges of the runs are ordered differently)");
+	}
+	dir.complete = cf == gnf && ch == gne;
+	if (!dir.complete && !allow_gaps) throw Error(HRY_E_FORMAT, "sharded container does not cover the mesh (missing segments)");
+}
+
+// ---- bounds of the whole mesh from the bounds of its shards ---------------------------------------------------------
+// ONE sequential scan over the whole mesh (structs/quant.h:30-44: strict comparisons, the first element wins a tie, the
+// maximum starts at numeric_limits<T>::min()) restated as a combination of per-shard scans: every shard reports, per
+// component, its extreme value and 1 + the index IN THE WHOLE MESH of the first element that holds it (0: the scan's initial
+// value); the smaller key wins between equal values (+-0.0 compare equal and differ in their bits).
+namespace {
+template <typename F> void with_comp_type(CompType t, F &&f)
+{
+	switch (t) {
+	case C_FLOAT: f(float()); break; case C_DOUBLE: f(double()); break; case C_ULONG: f(uint64_t()); break; case C_LONG: f(int64_t()); break;
+	case C_UINT: f(uint32_t()); break; case C_INT: f(int32_t()); break; case C_USHORT: f(uint16_t()); break; case C_SHORT: f(int16_t()); break;
+	case C_UCHAR: f(uint8_t()); break; case C_CHAR: f(int8_t()); break; default: break;
+	}
+}
+}   // namespace
+
+void combine_shard_bounds(const std::vector<const Mesh*> &shards, int l, std::vector<uint8_t> &bmin, std::vector<uint8_t> &bmax)
+{
+	if (shards.empty()) throw Error(HRY_E_ARG, "no shards");
+	const AttrList &F = shards[0]->lists[l];
+	bmin.assign(F.stride(), 0); bmax.assign(F.stride(), 0);
+	for (int c = 0; c < F.ncomp(); ++c)
+		with_comp_type(F.type[c], [&](auto tag) {
+			typedef decltype(tag) T;
+			bool have = false;
+			T best_mn = T(), best_mx = T();
+			uint64_t key_mn = 0, key_mx = 0;
+			for (const Mesh *s : shards) {
+				const AttrList &L = s->lists[l];
+				if (!L.have_bounds || L.bmin_at.size() != (size_t)F.ncomp() || L.type != F.type) throw Error(HRY_E_ARG, "shard without device-computed bounds");
+				const std::vector<uint32_t> &whole = l == 0 ? s->shard.face_of : s->shard.vertex_of;
+				auto key = [&](uint32_t at) -> uint64_t { return at == 0 ? 0 : (at - 1 < whole.size() ? (uint64_t)whole[at - 1] + 1 : at); };
+				T mn, mx;
+				memcpy(&mn, L.bmin.data() + L.offset[c], sizeof(T)); memcpy(&mx, L.bmax.data() + L.offset[c], sizeof(T));
+				const uint64_t kmn = key(L.bmin_at[c]), kmx = key(L.bmax_at[c]);
+				if (!have || mn < best_mn || (!(best_mn < mn) && kmn < key_mn)) { best_mn = mn; key_mn = kmn; }
+				if (!have || mx > best_mx || (!(best_mx > mx) && kmx < key_mx)) { best_mx = mx; key_mx = kmx; }
+				have = true;
+			}
+			memcpy(bmin.data() + F.offset[c], &best_mn, sizeof(T)); memcpy(bmax.data() + F.offset[c], &best_mx, sizeof(T));
+		});
 }
 
 }   // namespace hry

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HRY_ABI_VERSION 3
+#define HRY_ABI_VERSION 4
 
 enum {
     HRY_OK = 0,
@@ -75,6 +75,11 @@ typedef struct hry_opts {
  * bytes).  HRY_FLAG_HOST_RECURRENCE is accepted for older callers and changes nothing. */
 #define HRY_FLAG_HOST_RECURRENCE 1
 #define HRY_FLAG_DEVICE_RECURRENCE 2
+/* hry_decode of a sharded container (.hry v0.3) that does not hold the whole mesh -- one rank's own part -- is an error unless this
+ * flag (or a share, shard_count > 1) asks for a PARTIAL mesh: only the runs hry_mesh_runs lists are decoded, everything else is
+ * filler (faces without half-edges, zero records).  The accessors read such a mesh; the writers, hry_encode, hry_mesh_upload,
+ * hry_walk_run and hry_shard_plan refuse it (HRY_E_ARG). */
+#define HRY_FLAG_PARTIAL 4
 
 /* timings of the last hry_encode / hry_decode on this context, milliseconds */
 typedef struct hry_timing {
@@ -87,7 +92,7 @@ typedef struct hry_timing {
     double k_model_ms;     /* adaptive-model evaluation kernels */
     double k_predict_ms;   /* prediction + residual + symbolisation kernels */
     double k_entropy_ms;   /* chunked: fused model+coder kernel */
-    double k_chain_ms;     /* decode: the reconstruction chain kernels alone (k_unpredict2), part of k_predict_ms */
+    double k_chain_ms;     /* decode: the reconstruction chain kernels alone (k_unpredict2 / k_unpredict3) */
     uint64_t n_symbols;    /* coder invocations represented in the stream */
     uint64_t payload_bytes;
 } hry_timing;
@@ -96,6 +101,7 @@ const char *hry_last_error(void);
 int hry_abi_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------ */
+int hry_device_count(void);   /* HIP devices this process sees (0: none) */
 int hry_ctx_create(int device, hry_ctx **out);
 void hry_ctx_destroy(hry_ctx *ctx);
 int hry_ctx_timing(const hry_ctx *ctx, hry_timing *out);
@@ -124,7 +130,8 @@ int hry_mesh_to_ply(const hry_mesh *m, int flags, uint8_t **out, size_t *out_len
  * elements (and, for face regions, their corners) carry, and every element holds one record index per list of its region.
  * The reader follows the reference's scanner where that differs from the OBJ specification (harry_amd/csrc/host/obj_io.cpp).
  * `dir`: where "mtllib" files are looked up (the reference passes the input path up to its last '/', formats/unified_reader.h:56).
- * hry_encode codes general bindings into the reference stream (HRY_PROFILE_COMPAT) only. */
+ * hry_encode codes general bindings into the reference stream (HRY_PROFILE_COMPAT) and into the chunked container
+ * (HRY_PROFILE_CHUNKED, .hry v0.2). */
 int hry_mesh_from_obj(const uint8_t *obj, size_t n, const char *dir, hry_mesh **out);
 int hry_mesh_to_obj(const hry_mesh *m, int flags, uint8_t **out, size_t *out_len);   /* flags: 0 */
 int hry_mesh_general(const hry_mesh *m);                   /* 0: the PLY layout (list 0 = face, list 1 = vertex attributes, record i of element i) */
@@ -211,6 +218,43 @@ int hry_list_set_bounds(hry_mesh *m, int l, const uint8_t *min_rec, const uint8_
  * the reference's scan (structs/quant.h:33) -- what a combination of per-shard bounds needs to break ties (+-0.0) like one scan */
 uint32_t hry_list_min_at(const hry_mesh *m, int l, int c);
 uint32_t hry_list_max_at(const hry_mesh *m, int l, int c);
+int hry_mesh_partial(const hry_mesh *m);   /* 1: decoded with HRY_FLAG_PARTIAL / as a share; only its runs are real */
+
+/* ---- the same from ONE process over several devices ---------------------------------------------------------------
+ * The reference's single entry (main.cc:93-123 -> quant::requant -> hry::writer::write, formats/hry/writer.cc:200-214) with
+ * N device contexts behind it: what scales is "host thread + context" (the sequential cut-border walk of a shard on a host
+ * core, the kernels of that shard on the context's device), so every context gets a worker thread of its own, confined to the
+ * memory node of its device.  Contexts may sit on different devices (one per GPU of a node) or share one.
+ *   hry_encode_sharded  plans once, extracts the shards on the workers, combines the shards' k_bounds results into the bounds of
+ *                       the whole mesh with the tie rule of ONE scan (structs/quant.h:30-44), quantises (quant / n_quant / clear
+ *                       as hry_requant; the shards are quantised, *m keeps its values and receives the bounds) and codes every
+ *                       shard (CHUNKED) on its worker, and concatenates the segments in host memory: ONE .hry v0.3, byte-identical
+ *                       to hry_shard_plan / hry_shard_extract / hry_encode / hry_merge run shard by shard.  opts->shard_count =
+ *                       number of shards (0: one per context); shard s is coded by context s % n_ctx.
+ *   hry_decode_sharded  decodes the segments of a sharded container on the contexts (segment i on context i % n_ctx) into ONE
+ *                       mesh in the numbering of the whole; opts->shard_index / shard_count select a share as in hry_decode.
+ * hry_ctx_timing of each context holds the sums over the shards / segments it processed. */
+typedef struct hry_shard_timing {
+    double plan_ms;      /* encode: twins + components + coding order + scans + distribution; decode: directory checks */
+    double extract_ms;   /* encode: hry_shard_extract (decode: placement into the whole numbering), max over the workers */
+    double bounds_ms;    /* upload + k_bounds per shard, max over the workers */
+    double combine_ms;   /* bounds of the whole mesh from the shards' */
+    double quant_ms;     /* hry_requant per shard, max over the workers */
+    double encode_ms;    /* hry_encode (decode: the segments' decode), max over the workers */
+    double merge_ms;     /* concatenation of the segments (decode: filler for what no decoded run covers) */
+    double phase_a_ms;   /* wall clock: extraction + bounds on all workers */
+    double phase_b_ms;   /* wall clock: quantisation + encode (decode: decode + placement) on all workers */
+    double host_walk_ms; /* the longest worker's cut-border walks / replays */
+    double total_ms;
+    uint32_t n_shards, n_contexts, n_segments, n_components, n_groups;
+} hry_shard_timing;
+int hry_encode_sharded(hry_ctx *const *ctx, int n_ctx, hry_mesh *m, const hry_quant *quant, size_t n_quant, int clear,
+                       const hry_opts *opts, uint8_t **out, size_t *out_len, hry_shard_timing *timing /* may be NULL */);
+int hry_decode_sharded(hry_ctx *const *ctx, int n_ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out,
+                       hry_shard_timing *timing /* may be NULL */);
+/* host-only: the directory of a sharded container checked against its header (segment extents, run tables, runs inside the mesh,
+ * no overlap, order of faces and half-edges consistent); *complete = every face and half-edge lies in some run */
+int hry_container_check(const uint8_t *hry, size_t n, int *complete);
 
 /* ---- stage-level access for parity tests (valid after hry_encode/hry_decode with keep_stages) ----- */
 /* names: "order_v","order_f","twin","vplanes","fplanes","rec","sym_l","r","S","payload", ... */

@@ -51,6 +51,32 @@ def test_cli_sharded_container(tmp_path):
     assert np.array_equal(dec.org(), ref.org())
 
 
+def test_cli_gpus_option_runs_contexts_in_one_process(tmp_path):
+    """`harry --gpus N`: N contexts behind the one command (on this box they share device 0), same bytes as --shards N on one"""
+    m = mg.with_nonmanifold(mg.multi_component(7, 10, 12, seed=6, polys="mixed"), 5, 3, seed=2)
+    src, a, b, c, back = tmp_path / "in.ply", tmp_path / "a.hry", tmp_path / "b.hry", tmp_path / "c.hry", tmp_path / "back.ply"
+    src.write_bytes(m.to_ply())
+    r = harry(src, a, "--gpus", "2", "-l1", "-q12")          # implies --profile chunked
+    assert r.returncode == 0, r.stderr
+    assert "2 shard(s)" in r.stdout and "on 2 context(s)" in r.stdout
+    assert harry(src, b, "--shards", "2", "-l1", "-q12").returncode == 0
+    assert a.read_bytes() == b.read_bytes() and hc.container_info(a.read_bytes())["minor"] == 3
+    assert harry(src, c, "--gpus", "3", "--shards", "5", "-l1", "-q12").returncode == 0
+    r = harry(c, back, "--gpus", "2", "--ply-packed")
+    assert r.returncode == 0 and "segment(s) on 2 context(s)" in r.stdout, r.stderr
+    o = op.Mesh.from_ply(m.to_ply())
+    o.requant([(1, -1, 12)])
+    ref = op.Mesh.from_hry(o.encode().data)
+    dec = hc.Mesh.from_ply(back.read_bytes())
+    assert np.array_equal(dec.org(), ref.org())
+    assert np.array_equal(dec.component(1, 0), ref.component(1, 0))
+    # the reference's single stream does not shard: said so instead of silently writing an unsharded file
+    r = harry(src, tmp_path / "x.hry", "--profile", "compat", "--shards", "2")
+    assert r.returncode == 1 and "does not shard" in r.stderr
+    r = harry(tmp_path / "missing.ply", tmp_path / "x.hry")
+    assert r.returncode == 134 and "cannot open" in r.stderr
+
+
 def test_cli_chunked_roundtrip_to_ply(tmp_path):
     m = mg.with_colors(mg.torus(20, 22, polys="mixed", normals=True))
     src = tmp_path / "in.ply"

@@ -96,6 +96,9 @@ def test_virtual_ranks_merge_decodes_like_the_reference(cx, kind, quant, n_shard
     seen_f = np.zeros(dec.nf, bool)
     for r in range(n_shards):
         part = cx.read_hry(merged, shard=(r, n_shards))
+        assert part.partial
+        with pytest.raises(hc.HryError):   # only its runs are real: no consumer takes it
+            part.to_ply()
         runs = part.runs()
         want = shards[r].runs()
         assert sorted(map(tuple, runs)) == sorted(map(tuple, want))
@@ -110,7 +113,9 @@ def test_virtual_ranks_merge_decodes_like_the_reference(cx, kind, quant, n_shard
             seen_f[ff:ff + nf] = True
         # a rank's own one-segment container decodes the same way
         if len(want):
-            own = cx.read_hry(parts[r]).list_data(1)
+            own = cx.read_hry(parts[r], partial=n_shards > 1 and sum(1 for q in shards if q.nf) > 1)
+            assert own.partial == (sum(1 for q in shards if q.nf) > 1)
+            own = own.list_data(1)
             for fv, ff, fh, nv, nf, nh in want:
                 assert np.array_equal(own[fv:fv + nv], rv[fv:fv + nv])
     assert seen_f.all()
@@ -150,3 +155,178 @@ def test_merge_checks_headers(cx):
         hc.merge([a[0], b[1]])
     with pytest.raises(hc.HryError):
         cx.read_hry(hc.merge(a)[:-7])
+
+
+# ---- one process, N contexts (include/harry_amd.h: hry_encode_sharded / hry_decode_sharded) ----------------------------------
+@pytest.mark.parametrize("kind,quant", [("mixed_nm", []), ("mixed_nm", [(1, -1, 12)]), ("tori_normals", [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)])])
+@pytest.mark.parametrize("n_ctx", [2, 8])
+def test_in_process_contexts_run_concurrently_and_match_the_virtual_ranks(cx, kind, quant, n_ctx):
+    """N contexts on device 0, one worker thread each, all at once: the merged container is byte for byte what the shards give
+    when they are coded one after the other on one context, and decodes (on the N contexts at once, and on one) to the
+    reference-format decode of the whole mesh."""
+    gen = _mesh(kind)
+    _, _, parts = _encode_sharded(cx, gen, n_ctx, quant, chunk_syms=1024)
+    want = hc.merge(parts)
+    mc = hc.MultiCodec([0] * n_ctx)
+    try:
+        whole = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props)
+        got = mc.write_hry(whole, quant, chunk_syms=1024)
+        assert got == want
+        assert mc.last["n_contexts"] == n_ctx and mc.last["n_shards"] == n_ctx and mc.last["plan_ms"] > 0
+        assert whole.list_min(1) is not None          # the whole mesh received its bounds (ply/reader.cc:428)
+        # more shards than contexts: every worker codes several, same bytes as that many virtual ranks
+        _, _, parts3 = _encode_sharded(cx, gen, n_ctx + 3, quant, chunk_syms=1024)
+        assert mc.write_hry(hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props), quant, n_shards=n_ctx + 3, chunk_syms=1024) == hc.merge(parts3)
+        o = op.Mesh.from_ply(gen.to_ply())
+        if quant:
+            o.requant(quant)
+        ref = op.Mesh.from_hry(o.encode().data)
+        for dec in (mc.read_hry(got), cx.read_hry(got)):
+            assert not dec.partial
+            assert np.array_equal(dec.face_offsets(), ref.face_offsets()) and np.array_equal(dec.org(), ref.org()) and np.array_equal(dec.twin(), ref.twin())
+            for l in (0, 1):
+                assert np.array_equal(dec.list_data(l), ref.list_data(l))
+        assert mc.last["n_segments"] >= 1
+        # an unsharded container through the same entry
+        one = cx.write_hry(hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props), profile=hc.PROFILE_CHUNKED)
+        assert np.array_equal(mc.read_hry(one).org(), cx.read_hry(one).org())
+    finally:
+        mc.close()
+
+
+def test_two_threads_two_contexts_independent_meshes():
+    """section 8b's threading contract: distinct contexts are independent -- two threads code and decode different meshes at once"""
+    import threading
+    gens = [_mesh("mixed_nm"), _mesh("tori_normals")]
+    want = []
+    c0 = hc.Codec(0)
+    for g in gens:
+        want.append(c0.write_hry(hc.Mesh.from_arrays(g.verts, g.degrees, g.indices), profile=hc.PROFILE_CHUNKED, chunk_syms=1024))
+    c0.close()
+    errs = []
+
+    def work(i):
+        try:
+            c = hc.Codec(0)
+            for _ in range(6):
+                out = c.write_hry(hc.Mesh.from_arrays(gens[i].verts, gens[i].degrees, gens[i].indices), profile=hc.PROFILE_CHUNKED, chunk_syms=1024)
+                assert out == want[i]
+                assert c.read_hry(out).nf == gens[i].nf
+                comp = c.write_hry(hc.Mesh.from_arrays(gens[i].verts, gens[i].degrees, gens[i].indices))
+                assert c.read_hry(comp).nf == gens[i].nf
+            c.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+def test_unreferenced_vertices_enter_the_bounds_of_the_whole_mesh(cx):
+    """vertices no face references are never coded, but the reference's bounds scan reads every record (structs/quant.h:30-44):
+    shard 0 carries them, so the combined bounds -- and with them the header and every quantised value -- are the whole mesh's"""
+    gen = mg.multi_component(5, 8, 9, seed=12, polys="tri")
+    v = np.zeros(gen.nv + 3, dtype=gen.verts.dtype)
+    v[:gen.nv] = gen.verts
+    v["x"][gen.nv:] = [1e3, -1e3, 0.0]
+    v["y"][gen.nv:] = [5.0, 5.0, -77.0]
+    gen = mg.Mesh(v, gen.degrees, gen.indices, None)
+    quant = [(1, -1, 12)]
+    one = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices)
+    cx.requant(one, quant)
+    ref = cx.read_hry(cx.write_hry(one, profile=hc.PROFILE_CHUNKED))
+    whole, shards, parts = _encode_sharded(cx, gen, 3, quant)
+    assert bytes(shards[1].list_min(1)) == bytes(one.list_min(1)) and bytes(shards[1].list_max(1)) == bytes(one.list_max(1))
+    dec = cx.read_hry(hc.merge(parts))
+    assert np.array_equal(dec.list_data(1), ref.list_data(1)) and np.array_equal(dec.org(), ref.org())
+    mc = hc.MultiCodec([0, 0, 0])
+    try:
+        assert mc.write_hry(hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices), quant) == hc.merge(parts)
+    finally:
+        mc.close()
+
+
+def _damage_cases(merged):
+    info = hc.container_info(merged)
+    hdr, nseg = info["header_bytes"], info["segments"]
+    lens = np.frombuffer(merged, "<u8", nseg, hdr + 4)
+    seg0 = hdr + 4 + 8 * nseg
+    b = bytearray(merged)
+    cases = {}
+    cases["truncated segment table"] = bytes(b[:hdr + 4 + 5])
+    cases["truncated body"] = bytes(b[:-9])
+    z = bytearray(b); z[hdr:hdr + 4] = (0).to_bytes(4, "little"); cases["no segments, trailing bytes"] = bytes(z)
+    cases["PARTIAL no segments"] = bytes(b[:hdr]) + (0).to_bytes(4, "little")
+    z = bytearray(b); z[hdr + 4:hdr + 12] = int(lens[0] + 1).to_bytes(8, "little"); cases["segment length off by one"] = bytes(z)
+    # the first run of segment 0 moved / grown
+    nr0 = int.from_bytes(b[seg0:seg0 + 4], "little")
+    assert nr0 >= 1
+    run0 = seg0 + 4
+    for name, word, val in (("run beyond the vertices", 0, info["nv"]), ("run beyond the faces", 1, info["nf"]), ("run beyond the half-edges", 2, info["ne"]),
+                            ("run larger than the mesh", 4, info["nf"] + 1)):
+        z = bytearray(b); z[run0 + 4 * word:run0 + 4 * word + 4] = int(val).to_bytes(4, "little"); cases[name] = bytes(z)
+    if nseg >= 2:
+        # two segments swapped with their lengths: still a valid container (segments are independent) -- must decode the same
+        s0, s1 = bytes(b[seg0:seg0 + int(lens[0])]), bytes(b[seg0 + int(lens[0]):seg0 + int(lens[0]) + int(lens[1])])
+        z = bytearray(b)
+        z[hdr + 4:hdr + 12] = int(lens[1]).to_bytes(8, "little"); z[hdr + 12:hdr + 20] = int(lens[0]).to_bytes(8, "little")
+        z[seg0:seg0 + len(s0) + len(s1)] = s1 + s0
+        cases["OK swapped segments"] = bytes(z)
+        # segment 1's first run claims segment 0's place
+        seg1 = seg0 + int(lens[0])
+        z = bytearray(b); z[seg1 + 4:seg1 + 4 + 12] = b[run0:run0 + 12]; cases["overlapping runs"] = bytes(z)
+        # a segment dropped: what is left does not cover the mesh
+        z = bytearray(b[:hdr]) + (nseg - 1).to_bytes(4, "little") + bytes(b[hdr + 12:seg0]) + bytes(b[seg0 + int(lens[0]):])
+        cases["PARTIAL missing segment"] = bytes(z)
+    return cases
+
+
+def test_damaged_sharded_containers_are_refused(cx):
+    gen = _mesh("mixed_nm")
+    _, _, parts = _encode_sharded(cx, gen, 3, [], chunk_syms=1024)
+    merged = hc.merge(parts)
+    good = cx.read_hry(merged)
+    assert hc.container_check(merged)
+    for name, data in _damage_cases(merged).items():
+        if name.startswith("OK"):
+            assert hc.container_check(data)
+            d = cx.read_hry(data)
+            assert np.array_equal(d.org(), good.org()) and np.array_equal(d.list_data(1), good.list_data(1)), name
+            continue
+        if name.startswith("PARTIAL"):
+            assert not hc.container_check(data)
+            with pytest.raises(hc.HryError):
+                cx.read_hry(data)
+            d = cx.read_hry(data, partial=True)
+            assert d.partial
+            fo = d.face_offsets()
+            assert (np.diff(fo.astype(np.int64)) >= 0).all() and fo[-1] == d.ne and (d.org() < d.nv).all() and (d.twin() < d.ne).all()
+            with pytest.raises(hc.HryError):
+                cx.write_hry(d, profile=hc.PROFILE_CHUNKED)
+            with pytest.raises(hc.HryError):
+                hc.ShardPlan(d, 2)
+            continue
+        with pytest.raises(hc.HryError):
+            hc.container_check(data)
+        for kw in ({}, {"partial": True}, {"shard": (0, 2)}):
+            with pytest.raises(hc.HryError):
+                cx.read_hry(data, **kw)
+        with pytest.raises(hc.HryError):
+            hc.merge([data, merged])
+    # bit flips inside a segment body must end in an error or a mesh, never in a crash (bounded number of cases)
+    info = hc.container_info(merged)
+    rng = np.random.default_rng(5)
+    body0 = info["header_bytes"] + 4 + 8 * info["segments"]
+    for _ in range(24):
+        z = bytearray(merged)
+        at = int(rng.integers(body0, len(z)))
+        z[at] ^= 1 << int(rng.integers(0, 8))
+        try:
+            d = cx.read_hry(bytes(z))
+            assert d.nf == good.nf
+        except hc.HryError:
+            pass
