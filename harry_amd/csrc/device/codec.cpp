@@ -41,6 +41,7 @@ Context::~Context()
 	(void)hipSetDevice(device);
 	if (stream) (void)hipStreamSynchronize(stream);
 	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+	for (auto &e : slice_ev) if (e) (void)hipEventDestroy(e);
 	if (stream) (void)hipStreamDestroy(stream);
 	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
 	if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }
@@ -334,35 +335,43 @@ void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload)
 		// The serial recurrence on a host core ("host or one-lane"; same arithmetic as k_rchain, 8 times
 		// faster than a lone wavefront's scalar unit).  It runs BEHIND the device: the records come down slice by slice into
 		// pinned memory while the core works on the slices before, and (r, S) of a finished slice go back up at once.
-		const uint32_t SL = 1u << 18;
+		// A ring of kRing slice buffers and events, reused: slot i % kRing receives slice i once (r, S) of slice i - kRing have
+		// gone up from it -- the stream runs its copies in order, so "download slice i" is simply enqueued behind "upload slice
+		// i - kRing" and the host waits for the download's event before it touches the slot.  Pinned memory stays at
+		// kRing x 7 MB whatever the stream's length (28 M triangles used to pin 4 GB for the life of the context).
+		const uint32_t SL = 1u << 18, kRing = 4;
 		const uint32_t nsl = (ns + SL - 1) / SL;
-		cx.h_rec.ensure((size_t)ns * sizeof(SymRec)); cx.h_r.ensure((size_t)ns * 8); cx.h_s.ensure((size_t)ns * 4);
-		while (cx.slice_ev.size() < nsl) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); cx.slice_ev.push_back(e); }
+		const size_t slot = std::min<size_t>(ns, SL);
+		cx.h_rec.ensure(slot * kRing * sizeof(SymRec)); cx.h_r.ensure(slot * kRing * 8); cx.h_s.ensure(slot * kRing * 4);
+		while (cx.slice_ev.size() < kRing) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); cx.slice_ev.push_back(e); }
 		SymRec *rec = cx.h_rec.as<SymRec>();
 		uint64_t *rr = cx.h_r.as<uint64_t>();
 		uint32_t *ss = cx.h_s.as<uint32_t>();
-		for (uint32_t i = 0; i < nsl; ++i) {
+		auto download = [&](uint32_t i) {
 			const uint32_t b0 = i * SL, n0 = std::min(SL, ns - b0);
-			HIP_OK(hipMemcpyAsync(rec + b0, cx.d_rec_sym.as<SymRec>() + b0, (size_t)n0 * sizeof(SymRec), hipMemcpyDeviceToHost, cx.stream));
-			HIP_OK(hipEventRecord(cx.slice_ev[i], cx.stream));
-		}
+			HIP_OK(hipMemcpyAsync(rec + (size_t)(i % kRing) * slot, cx.d_rec_sym.as<SymRec>() + b0, (size_t)n0 * sizeof(SymRec), hipMemcpyDeviceToHost, cx.stream));
+			HIP_OK(hipEventRecord(cx.slice_ev[i % kRing], cx.stream));
+		};
+		for (uint32_t i = 0; i < nsl && i < kRing; ++i) download(i);
 		uint64_t R = st[0], S = st[1];
 		for (uint32_t i = 0; i < nsl; ++i) {
-			const uint32_t b0 = i * SL, e0 = b0 + std::min(SL, ns - b0);
-			HIP_OK(hipEventSynchronize(cx.slice_ev[i]));
-			for (uint32_t k = b0; k < e0; ++k) {
-				const SymRec &q = rec[k];
+			const uint32_t b0 = i * SL, n0 = std::min(SL, ns - b0);
+			const size_t at = (size_t)(i % kRing) * slot;
+			HIP_OK(hipEventSynchronize(cx.slice_ev[i % kRing]));
+			for (uint32_t k = 0; k < n0; ++k) {
+				const SymRec &q = rec[at + k];
 				uint64_t r = cm::div_by_magic(R, q.magic, q.meta & 63u);
 				uint64_t prod = r * q.x;
 				uint64_t Rn = (q.meta & kMetaSub) ? R - prod : prod;
 				uint64_t y = Rn - 1;
 				uint32_t sh = (y ? (uint32_t)__builtin_clzll(y) : 64u) - 1u;
-				rr[k] = r; ss[k] = (uint32_t)S;
+				rr[at + k] = r; ss[at + k] = (uint32_t)S;
 				R = Rn << sh;
 				S += sh;
 			}
-			HIP_OK(hipMemcpyAsync(cx.d_r.as<uint64_t>() + b0, rr + b0, (size_t)(e0 - b0) * 8, hipMemcpyHostToDevice, cx.stream));
-			HIP_OK(hipMemcpyAsync(cx.d_s.as<uint32_t>() + b0, ss + b0, (size_t)(e0 - b0) * 4, hipMemcpyHostToDevice, cx.stream));
+			HIP_OK(hipMemcpyAsync(cx.d_r.as<uint64_t>() + b0, rr + at, (size_t)n0 * 8, hipMemcpyHostToDevice, cx.stream));
+			HIP_OK(hipMemcpyAsync(cx.d_s.as<uint32_t>() + b0, ss + at, (size_t)n0 * 4, hipMemcpyHostToDevice, cx.stream));
+			if (i + kRing < nsl) download(i + kRing);
 		}
 		st[0] = R; st[1] = S;
 		HIP_OK(hipEventRecord(cx.ev[4], cx.stream));

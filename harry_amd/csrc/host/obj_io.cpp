@@ -321,6 +321,7 @@ void mesh_to_obj(const Mesh &m, ByteSink &out)
 	std::string o = "# decompressed using harry mesh compressor\n\n# vertex definitions and vertex attributes\n";
 	auto flush = [&]() { out.append(o.begin(), o.end()); o.clear(); };
 	auto value = [&](size_t l, uint32_t idx, int c) { const AttrList &L = m.lists[l]; print_component(o, L, L.data.data() + (size_t)idx * L.stride(), c); };
+	for (size_t l = 0; l < nl; ++l) if ((size_t)m.lists[l].count * m.lists[l].stride() > m.lists[l].data.size()) throw Error(HRY_E_FORMAT, "attribute list shorter than its record count");
 	for (uint32_t v = 0; v < m.nv; ++v) {
 		const int r = m.general ? m.bind.vtx_reg[v] : 0;
 		o += 'v';
@@ -330,6 +331,8 @@ void mesh_to_obj(const Mesh &m, ByteSink &out)
 			if (!is_pos[l]) continue;
 			const uint32_t idx = m.general ? m.bind.vtx_attr[(size_t)v * m.bind.nb_vtx + a] : v;
 			const AttrList &L = m.lists[l];
+			// a header may announce vertices and an empty list (a decoded vertex no face reaches keeps record 0): nothing to print from
+			if (idx >= L.count || (size_t)(idx + 1) * L.stride() > L.data.size()) throw Error(HRY_E_FORMAT, "vertex names a record its list does not hold");
 			for (int k = 0; k < len_of(l, I_POS); ++k) { if (cnt++ >= 4) break; o += ' '; value(l, idx, L.interp_off[I_POS] + k); }
 			for (int k = 0; k < len_of(l, I_COLOR); ++k) { if (cnt++ >= 8) break; o += ' '; value(l, idx, L.interp_off[I_COLOR] + k); }
 			break;

@@ -45,7 +45,44 @@ int main(int argc, char **argv)
 				if (!m->general && m->nf) {
 					ShardPlan plan;
 					shard_plan(*m, 3, plan);
-					for (uint32_t s = 0; s < 3; ++s) { std::unique_ptr<Mesh> sh(shard_extract(*m, plan, s)); }
+					// a sharded container as three ranks would write it (host side: header of the whole mesh, run tables; the bodies
+					// are stand-ins), merged, then its directory under the checks every reader makes -- intact and damaged
+					std::vector<std::vector<uint8_t>> parts;
+					for (uint32_t s = 0; s < 3; ++s) {
+						std::unique_ptr<Mesh> sh(shard_extract(*m, plan, s));
+						std::vector<uint8_t> c;
+						write_hry_header(*sh, 3, c);
+						auto put = [&](const void *p, size_t n) { c.insert(c.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
+						const uint32_t one = sh->nf ? 1 : 0, nr = (uint32_t)sh->shard.runs.size();
+						put(&one, 4);
+						if (one) {
+							const uint64_t len = 4 + sizeof(ShardRun) * (uint64_t)nr + 7;
+							put(&len, 8); put(&nr, 4); put(sh->shard.runs.data(), sizeof(ShardRun) * nr); put("body...", 7);
+						}
+						parts.push_back(std::move(c));
+					}
+					std::vector<const uint8_t*> pp; std::vector<size_t> ps;
+					for (auto &c : parts) { pp.push_back(c.data()); ps.push_back(c.size()); }
+					std::vector<uint8_t> merged;
+					merge_containers(pp.data(), ps.data(), pp.size(), merged);
+					Mesh hm; int mn3 = 0;
+					const size_t h3 = read_hry_header(merged.data(), merged.size(), hm, mn3, false);
+					ShardedDirectory dir;
+					parse_sharded_directory(merged.data(), merged.size(), h3, hm.nv, hm.nf, hm.declared_ne, dir);
+					if (!dir.complete || mn3 != 3) throw Error(HRY_E_INTERNAL, "merged directory incomplete");
+					for (int k = 0; k < 64; ++k) {
+						std::vector<uint8_t> bad = merged;
+						if (k < 8) bad.resize(h3 + (size_t)k * (bad.size() - h3) / 8);
+						else for (int j = 0; j < 2; ++j) bad[h3 + (size_t)(1103515245u * (unsigned)(k * 2 + j + 1) + 12345u) % (bad.size() - h3)] ^= (uint8_t)(1u << ((k + j) & 7));
+						try {
+							ShardedDirectory d2;
+							parse_sharded_directory(bad.data(), bad.size(), h3, hm.nv, hm.nf, hm.declared_ne, d2, (k & 1) != 0);
+							const uint8_t *bp = bad.data(); const size_t bn = bad.size();
+							std::vector<uint8_t> again;
+							merge_containers(&bp, &bn, 1, again);
+						} catch (const Error &) {
+						}
+					}
 				}
 				if (m->nf) { WalkResult w; cut_border_walk(*m, w); }
 				// the same text, damaged: a clean error or a mesh

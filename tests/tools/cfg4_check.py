@@ -1,5 +1,8 @@
 """cfg4-like run: many mixed-polygon components with non-manifold edges/vertices, lossless, chunked encode + decode,
-verified against the CPU oracle (optional).  python tests/tools/cfg4_check.py NCOMP NU NV [--no-verify]"""
+verified against the CPU oracle (optional).  python tests/tools/cfg4_check.py NCOMP NU NV [--no-verify] [--contexts N] [--compat]
+--contexts N: additionally the in-process executor (hry_encode_sharded / hry_decode_sharded) with N contexts on device 0 -- the
+merged container must equal the shard-by-shard (virtual rank) result and decode to the same mesh.
+--compat: additionally the reference's single stream (.hry v0.1) of the whole mesh, compared with the oracle's bytes."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -20,11 +23,57 @@ for it in range(2):   # the first pass pays for module loading, stream creation 
     print(f"pass {it}: encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(out)} bpv {8*len(out)/mesh.nv:.2f} " + r(cx.timing()), flush=True)
     t = time.time(); dec = cx.read_hry(out); td = time.time() - t
     print(f"pass {it}: decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(cx.timing()), flush=True)
+def opt(name, default=0):
+    return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+nctx = opt("--contexts")
+if nctx:
+    mc = hc.MultiCodec([0] * nctx)
+    for it in range(2):
+        m = m0.clone()
+        t = time.time(); merged = mc.write_hry(m); te = time.time() - t
+        print(f"in-process x{nctx} pass {it}: encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(merged)} " + r(mc.last), flush=True)
+        t = time.time(); mdec = mc.read_hry(merged); td = time.time() - t
+        print(f"in-process x{nctx} pass {it}: decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(mc.last), flush=True)
+    same = np.array_equal(mdec.org(), dec.org()) and np.array_equal(mdec.list_data(1), dec.list_data(1)) and np.array_equal(mdec.face_offsets(), dec.face_offsets()) and np.array_equal(mdec.twin(), dec.twin())
+    print(f"in-process x{nctx}: merged container decodes to the single-context mesh: {'OK' if same else 'MISMATCH'}", flush=True)
+    assert same
+    # the same shards one after the other on ONE context (what N ranks would each do), merged: byte for byte the same container
+    from harry_amd import sharding
+    t = time.time()
+    whole = m0.clone()
+    plan = hc.ShardPlan(whole, nctx)
+    shards = [plan.extract(whole, s) for s in range(nctx)]
+    tabs = [sharding.shard_bounds(cx, sh) for sh in shards]
+    parts = []
+    for sh in shards:
+        sharding.combine_bounds(tabs, sh)
+        parts.append(cx.write_hry(sh, profile=hc.PROFILE_CHUNKED))
+    same = hc.merge(parts) == merged
+    print(f"in-process x{nctx}: container equals the {nctx} virtual ranks' merged container: {'OK' if same else 'MISMATCH'} ({time.time()-t:.1f}s)", flush=True)
+    assert same
+    del shards, parts, whole, plan, mdec
+    mc.close()
+compat = None
+if "--compat" in sys.argv:
+    for it in range(2):
+        m = m0.clone(); cx.upload(m)
+        t = time.time(); compat = cx.write_hry(m, profile=hc.PROFILE_COMPAT); te = time.time() - t
+        print(f"compat pass {it}: encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(compat)} ({8*len(compat)/1e9:.2f} Gbit of the 4.29 Gbit the 32-bit positions hold) " + r(cx.timing()), flush=True)
+    t = time.time(); cdec = cx.read_hry(compat); td = time.time() - t
+    print(f"compat decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(cx.timing()), flush=True)
+    same = np.array_equal(cdec.org(), dec.org()) and np.array_equal(cdec.list_data(1), dec.list_data(1))
+    print(f"compat decode equals the chunked decode: {'OK' if same else 'MISMATCH'}", flush=True)
+    assert same
+    del cdec
 if "--no-verify" not in sys.argv:
     from oracle import oracle_py as op
     t = time.time()
     o = op.Mesh.from_ply(mesh.to_ply())
-    ref = op.Mesh.from_hry(o.encode().data)
+    ob = o.encode().data
+    if compat is not None:
+        print(f"compat stream byte-identical to the oracle's: {'OK' if ob == compat else 'MISMATCH'}", flush=True)
+        assert ob == compat
+    ref = op.Mesh.from_hry(ob)
     ok = np.array_equal(dec.org(), ref.org()) and np.array_equal(dec.list_data(1), ref.list_data(1)) and np.array_equal(dec.face_offsets(), ref.face_offsets())
     print(f"oracle check {'OK' if ok else 'MISMATCH'} ({time.time()-t:.1f}s)")
     assert ok
