@@ -3,15 +3,23 @@
 
 One step = one pass of the hot path over one batch of synthetic input: encode the resident mesh to .hry
 (host cut-border walk + every HIP kernel + D2H of the stream) and, where the profile supports it, decode it back.
-Workload at N=1: BASELINE.json configs[1] -- 1 002 528-triangle closed torus, float32 xyz, `-l1 -q14`, one MI355X.
-With N>1 GPUs the workload is ONE mesh of N such components (weak scaling: per-GPU work fixed).  Every rank plans the split
-(hry_shard_plan: components, coding order, global vertex / face / half-edge bases), extracts its shard and keeps it resident;
-a step = all-gather of the shards' bounds (RCCL) + quantisation + encode of the shard (one segment, no data-path collective)
-+ gather of the segments on rank 0 and merge into ONE .hry v0.3 container + decode of the rank's own segment.  After the
-timed region rank 0 decodes the merged container and checks it against the single-GPU path on the whole mesh.
-
-`python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks (torch.distributed.run, 127.0.0.1)
-before anything touches a GPU.
+Workload at N=1: BASELINE.json configs[1] -- 1 002 528-triangle closed torus, float32 xyz, `-l1 -q14`, one MI355X; the
+larger configurations ride along as sub-records of the same line (`cfg3`: the 28 M-triangle torus with normals, positions 14 /
+normals 10 bits; `cfg4_share`: one GPU's share of configs[3], 128 mixed-polygon non-manifold components, lossless float).
+With N>1 GPUs the workload is ONE mesh shaped like configs[3]: N x 128 mixed-polygon components with non-manifold edges and
+vertices, float32 xyz, lossless (12.6 M triangles per GPU: weak scaling; N = 8 is configs[3] itself, 100.6 M triangles).  Two
+ways to run it:
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, what the driver does): one process
+    per GPU.  Every rank plans the split (hry_shard_plan: components, coding order, global vertex / face / half-edge bases) and
+    extracts its shard (timed once, reported as plan_ms / extract_ms); a step = k_bounds on the shard + all-gather of the
+    shards' bounds (RCCL) + encode of the shard (one segment, no data-path collective) + gather of the segments on rank 0 and
+    merge into ONE .hry v0.3 container + decode of the rank's own segment.  After the timed region rank 0 decodes the merged
+    container and checks it against the single-GPU path on the whole mesh, and -- with the other ranks idle -- runs the same job
+    through the in-process executor over all N devices (`inprocess` sub-record).
+  * `python bench.py --gpus N` with no launcher around it: ONE process, N device contexts (hry_encode_sharded /
+    hry_decode_sharded: plan once, a worker thread per device, segments merged in host memory; no torch.distributed).  A step =
+    the whole job from the host mesh: plan + extract + upload + bounds + encode + merge, then the decode of the merged container
+    on all devices into one mesh.  `--launcher` starts N ranks instead.
 
 Prints ONE JSON line on rank 0.
 """
@@ -115,12 +123,22 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def build_whole(n_side: int, world: int):
-    """ONE mesh of `world` torus components (seed 2 + k, side by side); world == 1 is BASELINE configs[1] itself"""
+CFG4_PER_GPU = (128, 221, 222)   # components per GPU, torus grid of each: 12.6 M triangles per GPU, x 8 = BASELINE configs[3]
+
+
+def build_cfg4(n_gpus: int, comps_per_gpu: int = CFG4_PER_GPU[0]):
+    """configs[3]-shaped: n_gpus x 128 components (40 % quads, 5 % pentagons, rest triangles), 0.1 % of the edges non-manifold,
+    0.05 % non-manifold vertices, float32 xyz; deterministic"""
     from harry_amd import meshgen as mg
+    m = mg.multi_component(comps_per_gpu * n_gpus, CFG4_PER_GPU[1], CFG4_PER_GPU[2], seed=4, polys="mixed")
+    return mg.with_nonmanifold(m, n_edges=max(1, m.ntri // 1000), n_vtx=max(1, m.ntri // 2000))
+
+
+def build_whole(n_side: int, world: int, comps_per_gpu: int = CFG4_PER_GPU[0]):
+    """world == 1: BASELINE configs[1] itself; world > 1: ONE configs[3]-shaped mesh, 128 components per GPU"""
     if world == 1:
         return build_workload(n_side, seed=2)
-    return mg.concat([mg.torus(n_side, n_side, seed=2 + k, sigma=1e-4, center=(3.0 * k, 0.0, 0.0)) for k in range(world)])
+    return build_cfg4(world, comps_per_gpu)
 
 
 def stay_on_memory_node():
@@ -155,10 +173,16 @@ def main():
     ap.add_argument("--side", type=int, default=708, help="torus grid side; 708 -> 1 002 528 triangles (configs[1])")
     ap.add_argument("--profile", default="auto", choices=["auto", "compat", "chunked"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the cfg3 / cfg4_share sub-records")
+    ap.add_argument("--launcher", action="store_true", help="--gpus N without a launcher: start N ranks instead of the in-process executor")
+    ap.add_argument("--comps-per-gpu", type=int, default=CFG4_PER_GPU[0], help="N > 1: components per GPU of the configs[3]-shaped mesh")
+    ap.add_argument("--share-device", action="store_true", help="in-process rehearsal on a box with fewer GPUs: contexts share devices")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)
+        if args.launcher:
+            self_launch(args)
+        return inprocess_main(args)
     stay_on_memory_node()
 
     import torch
@@ -189,15 +213,25 @@ def main():
     from harry_amd import codec as hc
     from harry_amd import sharding
 
-    quant = [(1, -1, 14)]
-    mesh = build_whole(args.side, world)                 # the WHOLE mesh, identical on every rank
+    quant = [(1, -1, 14)] if world == 1 else []          # configs[1]: -l1 -q14; configs[3]: lossless
+    mesh = build_whole(args.side, world, args.comps_per_gpu)   # the WHOLE mesh, identical on every rank
     whole = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)   # float32 positions, not yet quantised
     cx = hc.Codec(dev_index)
-    n_groups = 1
+    n_groups = n_comps = 1
+    plan_ms = extract_ms = 0.0
+    rccl_ranks = 1
     if world > 1:
+        # proof that the collective library saw every rank: a sum of ones over the backend that carries the data
+        ones = torch.ones(1, dtype=torch.int32, device=comm_dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        t0 = time.perf_counter()
         plan = hc.ShardPlan(whole, world)                # deterministic: the same plan on every rank
+        plan_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
         raw = plan.extract(whole, rank)                  # this rank's shard: whole groups of components, own numbering
-        n_groups = plan.ngroups
+        extract_ms = (time.perf_counter() - t0) * 1e3
+        n_groups, n_comps = plan.ngroups, plan.ncomponents
         shard_tris = [plan.triangles(r) for r in range(world)]
         if rank != 0:
             del whole
@@ -208,7 +242,8 @@ def main():
     if world > 1:
         cx.upload(base)
         sharding.exchange_bounds(cx, base, comm_dev)
-    cx.requant(base, quant)                              # used for the profile probe only; every timed step quantises itself
+    if quant:
+        cx.requant(base, quant)                          # used for the profile probe only; every timed step quantises itself
 
     profile = args.profile
     if profile == "auto":
@@ -222,7 +257,7 @@ def main():
     pid = hc.PROFILE_CHUNKED if profile == "chunked" else hc.PROFILE_COMPAT
     can_decode = True
     try:
-        cx.read_hry(cx.write_hry(base.clone(), profile=pid))
+        cx.read_hry(cx.write_hry(base.clone(), profile=pid), partial=world > 1)
     except hc.HryError:
         can_decode = False
 
@@ -234,7 +269,8 @@ def main():
         t0 = time.perf_counter()
         if world > 1:
             sharding.exchange_bounds(cx, m, comm_dev)    # k_bounds on the shard + all-gather (RCCL) -> bounds of the whole mesh
-        cx.requant(m, quant)                             # encode = quantisation (bounds, float -> uint14) + .hry production
+        if quant:
+            cx.requant(m, quant)                         # encode = quantisation (bounds, float -> uint14) + .hry production
         t_q = time.perf_counter()
         out = cx.write_hry(m, profile=pid)
         t1 = time.perf_counter()
@@ -283,7 +319,8 @@ def main():
         med = lambda k: float(np.median([t.get(k, 0.0) for t in timings]))
         # the dominant kernel of a step (HIP-event times taken inside the library on the codec stream)
         cands = {"k_rchain": med("k_rchain_ms"), "k_chunk_encode": med("k_entropy_ms") if profile == "chunked" else 0.0,
-                 "k_predict_vtx": med("k_predict_ms"), "k_chunk_decode": med("dec_k_entropy_ms"), "k_unpredict3": med("dec_k_chain_ms")}
+                 "k_predict_vtx": med("k_predict_ms"), "k_chunk_decode": med("dec_k_entropy_ms"),
+                 ("k_unpredict3" if world == 1 else "k_unpredict2<float>"): med("dec_k_chain_ms")}
         dom_name = max(cands, key=cands.get)
         dom_ms = cands[dom_name]
         # algorithmic bytes per launch: every input array once + the stream once =
@@ -310,19 +347,21 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         host_ms = med("host_walk_ms") + med("dec_host_walk_ms")
-        per_gpu = f"closed torus {args.side}x{args.side}, {mesh.ntri // world} triangles, float32 xyz, -l1 -q14 (BASELINE configs[1])"
+        per_gpu = (f"closed torus {args.side}x{args.side}, {mesh.ntri} triangles, float32 xyz, -l1 -q14 (BASELINE configs[1])" if world == 1 else
+                   f"{args.comps_per_gpu} mixed-polygon components with non-manifold edges / vertices, {mesh.ntri // world} triangles, float32 xyz, lossless")
+        k_chain_name = "k_unpredict3" if world == 1 else "k_unpredict2<float>"
         line = {
             "metric": "Mtriangles/s encode+decode", "value": round(value, 4), "unit": "Mtriangles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 residual bytes, u32 range-coder registers (compat profile: u64)", "data": "synthetic",
-            "config": {"workload": per_gpu if world == 1 else f"ONE mesh of {world} components ({ntri} triangles), each a {per_gpu}; sharded by connected component",
-                       "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}", "inputs_resident": True},
+            "config": {"workload": per_gpu if world == 1 else f"ONE mesh shaped like BASELINE configs[3] ({ntri} triangles, {n_comps} components, {n_groups} groups); per GPU: {per_gpu}; sharded by connected component",
+                       "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}, one process per GPU", "inputs_resident": True},
             "encode_mtri_s": round(ntri * args.steps / t_enc / 1e6, 4),
             "decode_mtri_s": round(ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
             "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / max(base.nv, 1), 4),
             "host_fraction": round(host_ms / step_ms, 4) if step_ms > 0 else None,
             "stage_ms": {k: round(med(k), 4) for k in ("requant_ms", "host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms",
-                                                        "gather_merge_ms", "dec_host_walk_ms", "dec_k_entropy_ms", "dec_k_predict_ms", "dec_k_chain_ms", "dec_total_ms")},
+                                                        "gather_merge_ms", "dec_host_walk_ms", "dec_k_entropy_ms", "dec_k_chain_ms", "dec_total_ms")},
             "kernel_ms": {k: round(v, 4) for k, v in cands.items()},
             "roofline": roof,
         }
@@ -340,13 +379,30 @@ def main():
             except Exception as exc:
                 sys.stderr.write(f"merged-container check failed: {exc}\n")
                 ok = False
-            line["sharded"] = {"rccl_ranks": world, "backend": "nccl (RCCL over xGMI)" if backend == "nccl" else "gloo (one-GPU rehearsal, not a measurement)",
-                               "components": world, "groups": n_groups, "triangles_per_rank": shard_tris,
+            line["sharded"] = {"rccl_ranks": rccl_ranks, "rccl_ranks_how": "all_reduce(ones) over the backend below", "plan_ms": round(plan_ms, 2), "extract_ms": round(extract_ms, 2),
+                               "plan_extract_note": "every rank plans the whole mesh and extracts its own shard, once, before the timed steps (the mesh is static input); "
+                                                    "the in-process executor's numbers include both",
+                               "backend": "nccl (RCCL over xGMI)" if backend == "nccl" else "gloo (one-GPU rehearsal, not a measurement)",
+                               "components": n_comps, "groups": n_groups, "triangles_per_rank": shard_tris,
                                "merged_container_bytes": len(merged), "segments": world,
                                "merged_decode_equals_single_gpu": ok, "comm_ms_per_step": round(t_comm / args.steps * 1e3, 3),
                                "collectives": "all_gather(bounds, 96 B/rank) + all_gather(sizes) + gather(segments, asynchronous: overlaps the decode) per step"}
             if ok is False:
                 line["error"] = "merged container does not decode to the single-GPU result"
+            # the same workload through ONE context, unsharded (rank 0's GPU): what the driver's per-N efficiency should be read against,
+            # since N = 1 of this benchmark is configs[1], another workload
+            try:
+                share = build_cfg4(1, args.comps_per_gpu)
+                sm = hc.Mesh.from_arrays(share.verts, share.degrees, share.indices)
+                ts = []
+                for _ in range(3):
+                    a = sm.clone(); cx.upload(a); torch.cuda.synchronize()
+                    t0 = time.perf_counter(); ob = cx.write_hry(a, profile=pid); cx.read_hry(ob); ts.append(time.perf_counter() - t0)
+                line["sharded"]["one_gpu_same_shape_mtri_s"] = round(share.ntri / min(ts[1:]) / 1e6, 3)
+                line["sharded"]["weak_scaling_efficiency_vs_same_shape"] = round(value / (world * line["sharded"]["one_gpu_same_shape_mtri_s"]), 4)
+                del sm, share
+            except Exception as exc:
+                sys.stderr.write(f"same-shape single-GPU leg failed: {exc}\n")
         # end to end, as the `harry in.ply out.hry -l1 -q14` / `harry out.hry back.ply` command lines see it: PLY bytes ->
         # parse + twin matching -> upload -> quantisation -> .hry bytes, and .hry bytes -> mesh -> binary PLY bytes.  Outside the timed
         # region; not part of `value`.
@@ -371,6 +427,26 @@ def main():
         except Exception as exc:
             if world == 1:
                 sys.stderr.write(f"end-to-end leg failed: {exc}\n")
+        if world == 1:
+            # the reference's "encode" starts from a host mesh (main.cc:104-117): the same step with the upload inside
+            try:
+                ts = []
+                for _ in range(4):
+                    m = raw.clone()
+                    t0 = time.perf_counter()
+                    cx.requant(m, quant)                 # uploads the records + connectivity first
+                    cx.write_hry(m, profile=pid)
+                    ts.append(time.perf_counter() - t0)
+                line["encode_from_host_mtri_s"] = round(ntri / float(np.median(ts[1:])) / 1e6, 4)
+                line["encode_from_host_ms"] = round(float(np.median(ts[1:])) * 1e3, 3)
+            except Exception as exc:
+                sys.stderr.write(f"encode-from-host leg failed: {exc}\n")
+        if world == 1 and not args.no_large and args.side == 708:
+            for name, leg in (("cfg3", cfg3_leg), ("cfg4_share", cfg4_share_leg)):
+                try:
+                    line[name] = leg(cx)
+                except Exception as exc:
+                    sys.stderr.write(f"{name} leg failed: {exc}\n")
         if not args.no_cpu_baseline and world == 1:
             cb, ref_hry = cpu_baseline(mesh, quant, budget_s=8.0)
             ref = cpu_baseline_reference(mesh, budget_s=12.0)
@@ -410,11 +486,223 @@ def main():
                 line["obj"] = obj_leg(cx)
             except Exception as exc:
                 sys.stderr.write(f"obj leg failed: {exc}\n")
+        if world > 1 and not share_gpu:
+            # with the other ranks idle (they wait on the host-side barrier below): the same mesh through the in-process executor
+            # over all N devices -- ONE process, plan + extract + upload inside the timed call
+            try:
+                line["inprocess"] = inprocess_leg(hc, whole, list(range(world)), quant, mesh.ntri, reps=3)
+            except Exception as exc:
+                sys.stderr.write(f"in-process leg failed: {exc}\n")
         print(json.dumps(line))
     cx.close()
     if world > 1:
-        dist.barrier()          # rank 0 checks the merged container after the timed region; leave together
+        # rank 0 works alone after the timed region; the others wait on the HOST (a gloo barrier: an RCCL barrier would spin on
+        # their GPUs, which the in-process leg uses)
+        try:
+            g = dist.new_group(backend="gloo")
+            dist.barrier(group=g)
+        except Exception:
+            dist.barrier()
         dist.destroy_process_group()
+
+
+def inprocess_leg(hc, whole, devices, quant, ntri, reps=3):
+    """ONE process, one context per entry of `devices`: the whole job from the host mesh (hry_encode_sharded: plan, extract,
+    upload, bounds, quantisation, encode, merge) and back (hry_decode_sharded: every segment on its device, one mesh out)"""
+    mc = hc.MultiCodec(devices)
+    try:
+        enc, dec, te_l, td_l, merged = [], [], [], [], b""
+        for _ in range(1 + reps):
+            t0 = time.perf_counter()
+            merged = mc.write_hry(whole, quant, keep_mesh=True)   # (the whole mesh stays as it is: every step computes the bounds again)
+            t1 = time.perf_counter()
+            te_l.append(dict(mc.last))
+            mc.read_hry(merged)
+            t2 = time.perf_counter()
+            td_l.append(dict(mc.last))
+            enc.append(t1 - t0); dec.append(t2 - t1)
+        e, d = float(np.median(enc[1:])), float(np.median(dec[1:]))
+        medk = lambda L, k: round(float(np.median([x[k] for x in L[1:]])), 2)
+        return {"contexts": len(devices), "devices": sorted(set(int(x) for x in devices)), "value": round(ntri / (e + d) / 1e6, 3), "unit": "Mtriangles/s encode+decode",
+                "encode_mtri_s": round(ntri / e / 1e6, 3), "decode_mtri_s": round(ntri / d / 1e6, 3), "encode_ms": round(e * 1e3, 2), "decode_ms": round(d * 1e3, 2),
+                "hry_bytes": len(merged), "inputs_resident": False,
+                "encode_stage_ms": {k: medk(te_l, k) for k in ("plan_ms", "extract_ms", "bounds_ms", "combine_ms", "quant_ms", "encode_ms", "merge_ms", "phase_a_ms", "phase_b_ms", "host_walk_ms", "total_ms")},
+                "decode_stage_ms": {"directory_ms": medk(td_l, "plan_ms"), "decode_ms": medk(td_l, "encode_ms"), "place_ms": medk(td_l, "extract_ms"), "filler_ms": medk(td_l, "merge_ms"),
+                                    "host_replay_ms": medk(td_l, "host_walk_ms"), "total_ms": medk(td_l, "total_ms")},
+                "shards": int(te_l[-1]["n_shards"]), "components": int(te_l[-1]["n_components"]), "groups": int(te_l[-1]["n_groups"]),
+                "what": "hry_encode_sharded + hry_decode_sharded from / to ONE host mesh: plan once, a worker thread per context, segments merged in host memory; no torch.distributed"}
+    finally:
+        mc.close()
+
+
+def inprocess_main(args):
+    """`python bench.py --gpus N` without a launcher: one process, N device contexts, no torch.distributed."""
+    from harry_amd import _native as nat
+    from harry_amd import codec as hc
+    n_dev = nat.load().hry_device_count()
+    if n_dev <= 0:
+        raise SystemExit("bench.py needs a GPU: harry_amd has no CPU path")
+    if n_dev < args.gpus and not args.share_device:
+        raise SystemExit(f"bench.py: {args.gpus} contexts need {args.gpus} GPUs, this node shows {n_dev} (--share-device rehearses on fewer)")
+    devices = [i % n_dev for i in range(args.gpus)]
+    world = args.gpus
+    quant = []
+    mesh = build_cfg4(world, args.comps_per_gpu)
+    whole = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    whole.twin()                                          # half-edge twins matched before the timed region (the reader's job)
+    mc = hc.MultiCodec(devices)
+    ntri = mesh.ntri
+    enc_s = dec_s = 0.0
+    te_l, td_l, merged = [], [], b""
+
+    def one_step():
+        t0 = time.perf_counter()
+        out = mc.write_hry(whole, quant, keep_mesh=True)   # (the whole mesh stays as it is: every step computes the bounds again)
+        t1 = time.perf_counter()
+        te = dict(mc.last)
+        tim_e = mc.timings()
+        dec = mc.read_hry(out)
+        t2 = time.perf_counter()
+        return out, dec, t1 - t0, t2 - t1, te, dict(mc.last), tim_e, mc.timings()
+
+    for _ in range(args.warmup):
+        one_step()
+    t_begin = time.perf_counter()
+    k_chain, k_entropy = [], []
+    dec = None
+    for _ in range(args.steps):
+        merged, dec, te, td, a, b, tim_e, tim_d = one_step()
+        enc_s += te; dec_s += td
+        te_l.append(a); td_l.append(b)
+        k_chain.append(max(t["k_chain_ms"] for t in tim_d)); k_entropy.append(max(t["k_entropy_ms"] for t in tim_e))
+    t_all = time.perf_counter() - t_begin
+    medk = lambda L, k: round(float(np.median([x[k] for x in L])), 2)
+    value = ntri * args.steps / t_all / 1e6
+    # dominant kernel: the float reconstruction chain of the slowest context; algorithmic bytes of one context's share
+    dom_ms = float(np.median(k_chain))
+    alg_bytes = (whole.nv * whole.list_stride(1) + 4 * whole.ne + len(merged)) // world
+    roof = {"bound": "hbm", "kernel": "k_unpredict2<float>", "achieved": round(alg_bytes / (dom_ms * 1e-3) / 1e9, 3) if dom_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(dom_ms, 4), "note": "per context: its share of the mesh, its own launches"}
+    roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 6) if roof["achieved"] else None
+    # check: the merged container decodes like the single-context path on the whole mesh
+    ok = None
+    try:
+        cx = hc.Codec(devices[0])
+        ref = cx.read_hry(cx.write_hry(whole.clone(), profile=hc.PROFILE_CHUNKED))
+        ok = bool(np.array_equal(dec.face_offsets(), ref.face_offsets()) and np.array_equal(dec.org(), ref.org()) and np.array_equal(dec.twin(), ref.twin())
+                  and np.array_equal(dec.list_data(1), ref.list_data(1)))
+        cx.close()
+    except Exception as exc:
+        sys.stderr.write(f"merged-container check failed: {exc}\n")
+        ok = False
+    line = {"metric": "Mtriangles/s encode+decode", "value": round(value, 4), "unit": "Mtriangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_all / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 residual bytes of f32 values, u32 range-coder registers", "data": "synthetic",
+            "config": {"workload": f"ONE mesh shaped like BASELINE configs[3] ({ntri} triangles, {int(te_l[-1]['n_components'])} components); per GPU: {args.comps_per_gpu} mixed-polygon "
+                                   f"components with non-manifold edges / vertices, {ntri // world} triangles, float32 xyz, lossless; sharded by connected component",
+                       "profile": "chunked", "decode_in_step": True, "parallelism": f"component-sharded x{world}, ONE process, one worker thread + context per device",
+                       "inputs_resident": False, "step_includes": "plan, extract, upload, bounds, encode, merge; decode of every segment, placement into one mesh",
+                       "devices": devices, "shared_devices": len(set(devices)) < len(devices)},
+            "encode_mtri_s": round(ntri * args.steps / enc_s / 1e6, 4), "decode_mtri_s": round(ntri * args.steps / dec_s / 1e6, 4),
+            "hry_bytes": len(merged), "bits_per_vertex": round(8 * len(merged) / max(whole.nv, 1), 4),
+            "stage_ms": {"encode": {k: medk(te_l, k) for k in ("plan_ms", "extract_ms", "bounds_ms", "combine_ms", "quant_ms", "encode_ms", "merge_ms", "phase_a_ms", "phase_b_ms", "host_walk_ms", "total_ms")},
+                         "decode": {"directory_ms": medk(td_l, "plan_ms"), "decode_ms": medk(td_l, "encode_ms"), "place_ms": medk(td_l, "extract_ms"), "filler_ms": medk(td_l, "merge_ms"),
+                                    "host_replay_ms": medk(td_l, "host_walk_ms"), "total_ms": medk(td_l, "total_ms")}},
+            "kernel_ms": {"k_unpredict2<float>": round(dom_ms, 4), "k_chunk_encode": round(float(np.median(k_entropy)), 4)},
+            "roofline": roof,
+            "sharded": {"executor": "in-process (hry_encode_sharded / hry_decode_sharded)", "contexts": world, "segments": int(td_l[-1]["n_segments"]),
+                        "groups": int(te_l[-1]["n_groups"]), "merged_decode_equals_single_gpu": ok, "collectives": "none: the segments meet in host memory"}}
+    if ok is False:
+        line["error"] = "merged container does not decode to the single-GPU result"
+    print(json.dumps(line))
+    mc.close()
+
+
+def cfg3_leg(cx):
+    """BASELINE configs[2] stand-in at full size: closed torus 3742 x 3742 = 28 005 128 triangles with analytic normals, positions
+    14 bits / normals 10 bits, chunked profile, one GPU.  Encode is timed from the HOST mesh (upload inside)."""
+    from harry_amd import codec as hc
+    from harry_amd import meshgen as mg
+    mesh = mg.torus(3742, 3742, seed=3, sigma=1e-4, normals=True)
+    m0 = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    m0.twin()
+    quant = [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)]
+    enc, dec, tms = [], [], []
+    out, qrec, d = b"", None, None
+    for _ in range(3):
+        m = m0.clone()
+        t0 = time.perf_counter()
+        cx.requant(m, quant)
+        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED)
+        t1 = time.perf_counter()
+        te = cx.timing()
+        d = cx.read_hry(out)
+        t2 = time.perf_counter()
+        td = cx.timing()
+        enc.append(t1 - t0); dec.append(t2 - t1); tms.append((te, td))
+        qrec = m
+    # size-independent check (the decoder renumbers vertices in coding order): the same multiset of quantised records
+    a = np.ascontiguousarray(qrec.list_data(1).reshape(m0.nv, -1).view(np.uint16)[:, ::2])
+    b = np.ascontiguousarray(d.list_data(1).reshape(m0.nv, -1).view(np.uint16)[:, ::2])
+    key = lambda x: np.sort((x[:, 0].astype(np.uint64) << 50) | (x[:, 1].astype(np.uint64) << 36) | (x[:, 2].astype(np.uint64) << 22) ^ (x[:, 3].astype(np.uint64) << 20)
+                            ^ (x[:, 4].astype(np.uint64) << 10) ^ x[:, 5].astype(np.uint64))
+    ok = bool((d.nv, d.nf, d.ne) == (m0.nv, m0.nf, m0.ne) and np.array_equal(key(a), key(b)))
+    e, dd = min(enc[1:]), min(dec[1:])
+    te, td = tms[-1]
+    ntri = mesh.ntri
+    alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
+    return {"workload": "closed torus 3742 x 3742, 28 005 128 triangles, float32 xyz + analytic normals, -l1 -a0 -q14 -a1 -q14 -a2 -q14 -a3 -q10 -a4 -q10 -a5 -q10 (BASELINE configs[2] stand-in)",
+            "triangles": int(ntri), "value": round(ntri / (e + dd) / 1e6, 3), "encode_from_host_mtri_s": round(ntri / e / 1e6, 3), "decode_mtri_s": round(ntri / dd / 1e6, 3),
+            "encode_from_host_ms": round(e * 1e3, 2), "decode_ms": round(dd * 1e3, 2), "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / m0.nv, 3),
+            "host_walk_ms": round(te["host_walk_ms"], 2), "host_replay_ms": round(td["host_walk_ms"], 2), "k_unpredict3_ms": round(td["k_chain_ms"], 2),
+            "k_chunk_encode_ms": round(te["k_entropy_ms"], 2), "k_chunk_decode_ms": round(td["k_entropy_ms"], 2), "k_predict_ms": round(te["k_predict_ms"], 2),
+            "roofline": {"bound": "hbm", "kernel": "k_unpredict3", "algorithmic_bytes_per_launch": alg, "kernel_ms": round(td["k_chain_ms"], 3),
+                         "achieved": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9, 3) if td["k_chain_ms"] > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if td["k_chain_ms"] > 0 else None},
+            "round_trip_invariants_ok": ok, "passes": 2}
+
+
+def cfg4_share_leg(cx):
+    """One GPU's share of BASELINE configs[3]: 128 mixed-polygon components, 0.1 % non-manifold edges, lossless float32 -- the
+    lossless-float reconstruction chain (k_unpredict2<float>), all components in one launch."""
+    from harry_amd import codec as hc
+    mesh = build_cfg4(1)
+    m0 = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    m0.twin()
+    enc, enc_res, dec, tms = [], [], [], []
+    out, d = b"", None
+    for _ in range(3):
+        m = m0.clone()
+        t0 = time.perf_counter()
+        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED)        # from the host mesh: the upload is inside
+        t1 = time.perf_counter()
+        te = cx.timing()
+        d = cx.read_hry(out)
+        t2 = time.perf_counter()
+        td = cx.timing()
+        m = m0.clone(); cx.upload(m)
+        t3 = time.perf_counter()
+        cx.write_hry(m, profile=hc.PROFILE_CHUNKED)              # resident inputs
+        t4 = time.perf_counter()
+        enc.append(t1 - t0); dec.append(t2 - t1); enc_res.append(t4 - t3); tms.append((te, td))
+    # size-independent check: the decoded vertex records are a permutation of the input's (lossless)
+    rec = lambda mm: np.sort(np.ascontiguousarray(mm.list_data(1)).view(np.dtype((np.void, 12))).reshape(-1))
+    nref = int(np.unique(m0.org()).size)                          # vertices no face references are not coded
+    ok = bool((d.nv, d.nf, d.ne) == (m0.nv, m0.nf, m0.ne) and (nref < m0.nv or np.array_equal(rec(d), rec(m0))))
+    e, er, dd = min(enc[1:]), min(enc_res[1:]), min(dec[1:])
+    te, td = tms[-1]
+    ntri = mesh.ntri
+    alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
+    return {"workload": "128 mixed-polygon components (40 % quads, 5 % pentagons) with 0.1 % non-manifold edges and 0.05 % non-manifold vertices, float32 xyz, lossless: one GPU's share of BASELINE configs[3]",
+            "triangles": int(ntri), "value": round(ntri / (er + dd) / 1e6, 3), "encode_mtri_s": round(ntri / er / 1e6, 3), "encode_from_host_mtri_s": round(ntri / e / 1e6, 3),
+            "decode_mtri_s": round(ntri / dd / 1e6, 3), "encode_ms": round(er * 1e3, 2), "encode_from_host_ms": round(e * 1e3, 2), "decode_ms": round(dd * 1e3, 2),
+            "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / m0.nv, 3),
+            "host_walk_ms": round(te["host_walk_ms"], 2), "host_replay_ms": round(td["host_walk_ms"], 2), "k_unpredict2_float_ms": round(td["k_chain_ms"], 2),
+            "k_chunk_encode_ms": round(te["k_entropy_ms"], 2), "k_chunk_decode_ms": round(td["k_entropy_ms"], 2), "k_predict_ms": round(te["k_predict_ms"], 2),
+            "roofline": {"bound": "hbm", "kernel": "k_unpredict2<float>", "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_triangle": round(alg / ntri, 2),
+                         "kernel_ms": round(td["k_chain_ms"], 3), "achieved": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9, 3) if td["k_chain_ms"] > 0 else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if td["k_chain_ms"] > 0 else None},
+            "round_trip_invariants_ok": ok, "passes": 2}
 
 
 def obj_leg(cx):

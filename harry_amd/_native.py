@@ -40,7 +40,7 @@ class Timing(C.Structure):
 
 
 class ShardTiming(C.Structure):
-    _fields_ = [(k, C.c_double) for k in ("plan_ms", "extract_ms", "bounds_ms", "combine_ms", "quant_ms", "encode_ms", "merge_ms", "phase_a_ms",
+    _fields_ = [(k, C.c_double) for k in ("twins_ms", "plan_ms", "extract_ms", "bounds_ms", "combine_ms", "quant_ms", "encode_ms", "merge_ms", "phase_a_ms",
                                            "phase_b_ms", "host_walk_ms", "total_ms")] + \
                [(k, C.c_uint32) for k in ("n_shards", "n_contexts", "n_segments", "n_components", "n_groups")]
 
@@ -53,6 +53,7 @@ PROFILE_COMPAT, PROFILE_CHUNKED = 0, 1
 FLAG_HOST_RECURRENCE = 1
 FLAG_DEVICE_RECURRENCE = 2
 FLAG_PARTIAL = 4
+FLAG_KEEP_MESH = 8
 
 _lib = None
 

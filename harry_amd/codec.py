@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nat
-from ._native import FLAG_DEVICE_RECURRENCE, FLAG_HOST_RECURRENCE, FLAG_PARTIAL, HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
+from ._native import FLAG_DEVICE_RECURRENCE, FLAG_HOST_RECURRENCE, FLAG_KEEP_MESH, FLAG_PARTIAL, HryError, PROFILE_CHUNKED, PROFILE_COMPAT  # noqa: F401
 
 TYPE_NP = {0: "<f4", 1: "<f8", 2: "<u8", 3: "<i8", 4: "<u4", 5: "<i4", 6: "<u2", 7: "<i2", 8: "u1", 9: "i1"}
 TYPE_SIZE = {0: 4, 1: 8, 2: 8, 3: 8, 4: 4, 5: 4, 6: 2, 7: 2, 8: 1, 9: 1}
@@ -381,11 +381,12 @@ class MultiCodec:
     def _handles(self):
         return (C.c_void_p * len(self.ctx))(*[c.h for c in self.ctx])
 
-    def write_hry(self, mesh: Mesh, quants=(), clear: bool = False, n_shards: int = 0, chunk_syms: int = 0) -> bytes:
-        """plan + extract + bounds of the whole mesh + quantisation + encode of every shard on its context + merge: ONE .hry v0.3"""
+    def write_hry(self, mesh: Mesh, quants=(), clear: bool = False, n_shards: int = 0, chunk_syms: int = 0, keep_mesh: bool = False) -> bytes:
+        """plan + extract + bounds of the whole mesh + quantisation + encode of every shard on its context + merge: ONE .hry v0.3.
+        keep_mesh: do not store the combined bounds in `mesh`"""
         qs = list(quants)
         arr = (nat.Quant * max(len(qs), 1))(*[nat.Quant(int(l), int(c), int(b)) for l, c, b in qs])
-        o = nat.Opts(PROFILE_CHUNKED, chunk_syms, 0, 0, 0, int(n_shards))
+        o = nat.Opts(PROFILE_CHUNKED, chunk_syms, 0, FLAG_KEEP_MESH if keep_mesh else 0, 0, int(n_shards))
         p, n, t = C.c_void_p(), C.c_size_t(), nat.ShardTiming()
         nat.check(nat.load().hry_encode_sharded(self._handles(), len(self.ctx), mesh.h, arr, len(qs), int(clear), C.byref(o), C.byref(p), C.byref(n), C.byref(t)))
         self.last = t.asdict()

@@ -235,12 +235,11 @@ int hry_encode_sharded(hry_ctx *const *ctx, int n_ctx, hry_mesh *m, const hry_qu
 		if (o.profile != HRY_PROFILE_CHUNKED) throw Error(HRY_E_UNSUPPORTED, "the reference's single stream (compat) does not shard: one recurrence over the whole file");
 		std::vector<Context*> cxs;
 		for (int i = 0; i < n_ctx; ++i) { if (!ctx[i]) throw Error(HRY_E_ARG, "null context"); ctx[i]->cx.keep_stages = false; ctx[i]->cx.stages.clear(); cxs.push_back(&ctx[i]->cx); }
-		std::vector<uint8_t> v;
+		ByteSink v;
 		hry_shard_timing st{};
-		encode_sharded(cxs.data(), n_ctx, m->m, quant, n_quant, clear != 0, o.shard_count, o.chunk_syms, v, st);
+		encode_sharded(cxs.data(), n_ctx, m->m, quant, n_quant, clear != 0, o.shard_count, o.chunk_syms, v, st, (o.flags & HRY_FLAG_KEEP_MESH) == 0);
 		if (timing) *timing = st;
-		*out = dup_bytes(v);
-		*out_len = v.size();
+		*out = v.release(out_len);
 	});
 }
 int hry_decode_sharded(hry_ctx *const *ctx, int n_ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out, hry_shard_timing *timing)
@@ -342,10 +341,9 @@ int hry_merge(const uint8_t *const *parts, const size_t *sizes, size_t n, uint8_
 	if (!parts || !sizes || !out || !out_len) { g_last_error = "null argument"; return HRY_E_ARG; }
 	*out = nullptr; *out_len = 0;
 	return guarded([&] {
-		std::vector<uint8_t> v;
+		ByteSink v;
 		merge_containers(parts, sizes, n, v);
-		*out = dup_bytes(v);
-		*out_len = v.size();
+		*out = v.release(out_len);
 	});
 }
 size_t hry_mesh_runs(const hry_mesh *m, const uint32_t **runs)

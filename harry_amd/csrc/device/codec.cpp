@@ -85,12 +85,12 @@ void Context::ensure_magic(uint32_t n)
 	std::swap(d_magic.cap, nb.cap);
 	magic_n = want;
 }
-void Context::upload_mesh(Mesh &m)
+void Context::upload_mesh(Mesh &m, bool with_records)
 {
 	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
 	HIP_OK(hipSetDevice(device));
 	if (m.lists.size() > (size_t)kMaxLists) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
-	for (size_t l = 0; l < m.lists.size(); ++l) {
+	for (size_t l = 0; l < m.lists.size() && with_records; ++l) {
 		d_rec[l].ensure(std::max<size_t>(m.lists[l].data.size(), 16));
 		if (!m.lists[l].data.empty()) HIP_OK(hipMemcpyAsync(d_rec[l].p, m.lists[l].data.data(), m.lists[l].data.size(), hipMemcpyHostToDevice, stream));
 	}
@@ -133,6 +133,7 @@ void Context::upload_mesh(Mesh &m)
 		m.twins_pending = false;
 	}
 	HIP_OK(hipStreamSynchronize(stream));
+	if (!with_records) { resident_token = 0; return; }   // connectivity only (twin matching for a caller that shards the mesh): nothing stays resident
 	m.device_token = next_token++;
 	resident_token = m.device_token;
 }

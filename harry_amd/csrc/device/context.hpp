@@ -103,7 +103,7 @@ struct Context {
 	void stage_put(const char *name, const void *dptr, size_t bytes);
 	void stage_put_host(const char *name, const void *hptr, size_t bytes);
 	void ensure_magic(uint32_t n);
-	void upload_mesh(Mesh &m);
+	void upload_mesh(Mesh &m, bool with_records = true);
 	dev::ConnView conn_view() const;
 	float elapsed(int a, int b);
 };
@@ -154,7 +154,7 @@ void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload);
 Mesh *decode_any(Context &cx, const uint8_t *p, size_t n, int shard_index = 0, int shard_count = 0, bool allow_partial = false);
 // sharded.cpp: one mesh over several contexts (devices) from one process
 void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q, size_t nq, bool clear, int n_shards, int chunk_syms,
-                    std::vector<uint8_t> &out, hry_shard_timing &st);
+                    ByteSink &out, hry_shard_timing &st, bool store_bounds = true);
 Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> g, int shard_index, int shard_count,
                      bool allow_partial, hry_shard_timing *st);
 void range_encode_lht(Context &cx, const uint64_t *lht, size_t n, std::vector<uint8_t> &out);

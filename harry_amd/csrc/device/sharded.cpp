@@ -52,28 +52,40 @@ const void *device_cpus(int device)
 	return node_cpus(node);
 }
 
-unsigned worker_thread_budget(int n_workers)
+// helper threads a worker may start in its host phases: its share of the CPUs it is confined to (the memory node of its device,
+// shared with the other workers on that node; the whole process's CPUs when the node is unknown)
+std::vector<unsigned> worker_thread_budgets(const std::vector<const void*> &cpus)
 {
 	cpu_set_t cs;
 	CPU_ZERO(&cs);
 	unsigned allowed = sched_getaffinity(0, sizeof cs, &cs) == 0 ? (unsigned)CPU_COUNT(&cs) : std::thread::hardware_concurrency();
 	if (!allowed) allowed = 1;
-	return std::max(1u, std::min(host_threads(), allowed / (unsigned)std::max(1, n_workers)));
+	const unsigned cap = host_threads();
+	std::vector<unsigned> out(cpus.size(), 1);
+	for (size_t w = 0; w < cpus.size(); ++w) {
+		unsigned sharing = 0;
+		for (size_t x = 0; x < cpus.size(); ++x) sharing += cpus[x] == cpus[w];
+		const unsigned avail = cpus[w] ? (unsigned)CPU_COUNT((const cpu_set_t*)cpus[w]) : allowed;
+		out[w] = std::max(1u, std::min(cap, avail / std::max(1u, sharing)));
+	}
+	return out;
 }
 
 // body(w) for every worker w on a thread of its own (one worker: the caller's thread); the first exception is rethrown here
 template <typename F> void run_workers(Context *const *cxs, int n, F &&body)
 {
 	if (n == 1) { body(0); return; }
-	const unsigned budget = worker_thread_budget(n);
+	std::vector<const void*> cpus((size_t)n);
+	for (int w = 0; w < n; ++w) cpus[w] = device_cpus(cxs[w]->device);
+	const std::vector<unsigned> budget = worker_thread_budgets(cpus);
 	std::vector<std::thread> th;
 	std::exception_ptr err;
 	std::mutex mu;
 	for (int w = 0; w < n; ++w)
 		th.emplace_back([&, w] {
 			try {
-				stay_on_node(device_cpus(cxs[w]->device));
-				set_thread_budget(budget);
+				stay_on_node(cpus[w]);
+				set_thread_budget(budget[w]);
 				body(w);
 			} catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
 		});
@@ -94,7 +106,7 @@ void check_contexts(Context *const *cxs, int n)
 
 // ---------------------------------------------------------------------------------------------------------------------
 void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q, size_t nq, bool clear, int n_shards, int chunk_syms,
-                    std::vector<uint8_t> &out, hry_shard_timing &st)
+                    ByteSink &out, hry_shard_timing &st, bool store_bounds)
 {
 	const auto t_all = Clock::now();
 	st = hry_shard_timing{};
@@ -103,7 +115,11 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh");
 	// ---- plan, once
 	auto t0 = Clock::now();
+	// a freshly read mesh: its half-edge twins are matched on the first context's device (twins.hip: 0.3 ms per million triangles
+	// + the connectivity's trip over PCIe) rather than by the host's hash buckets
+	if (m.twins_pending && !m.general) cxs[0]->upload_mesh(m, false);
 	ensure_twins(m);
+	st.twins_ms = ms_since(t0);
 	ShardPlan plan;
 	shard_plan(m, (uint32_t)n_shards, plan);
 	st.plan_ms = ms_since(t0);
@@ -144,7 +160,7 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 				AttrList &L = s->lists[l];
 				L.bmin = bmin; L.bmax = bmax; L.bmin_at.clear(); L.bmax_at.clear(); L.have_bounds = true;
 			}
-			if (!had[l]) {   // what the reference's reader leaves in the mesh (ply/reader.cc:428)
+			if (!had[l] && store_bounds) {   // what the reference's reader leaves in the mesh (ply/reader.cc:428)
 				AttrList &L = m.lists[l];
 				L.bmin = bmin; L.bmax = bmax; L.bmin_at.clear(); L.bmax_at.clear(); L.have_bounds = true;
 			}

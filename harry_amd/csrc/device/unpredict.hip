@@ -325,6 +325,11 @@ constexpr uint32_t kNoLane = 64;
 constexpr uint32_t kQueue = 256;        // vertices in the LDS input queue (4 tiles of 64)
 constexpr uint32_t kQueueCols = 26;     // 24 candidate ids, candidate count, residual code   // tag of a source that is already present
 
+#ifdef HRY_CHAIN_CLOCKS   // development: where the ticks of a chain go (wavefront 0 of every chain prints its sums)
+#define HRY_CLK(...) __VA_ARGS__
+#else
+#define HRY_CLK(...)
+#endif
 // Chains of different connected components run in ONE launch.  A component that names vertices of an earlier one (shared
 // non-manifold vertices, cbm/encoder.h:79-113,187) reads their reconstructed values from the records; it waits until the chain
 // of that component -- same attribute component -- has raised its flag.  Workgroups start in the order of their indices and
@@ -371,44 +376,33 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 	constexpr bool kSmallUnsigned = !cm::is_fp<T>::value && sizeof(T) <= 2 && !(T(-1) < T(0));
 	const int lane = threadIdx.x;
 	const uint32_t mask = ring_n - 1;
-	// Per-vertex inputs (candidate ids, candidate count, residual code) are staged through an LDS queue of kQueue
-	// vertices, filled in tiles of 64 that are requested from HBM up to four tiles ahead of the batch being reconstructed.
-	// A batch starts wherever the previous one ended (batches are cut at vertices that need special handling) and
-	// reads its 64 entries from the queue, so neither a cut nor the global-memory latency ever stalls the chain.
-	// Queue layout: column-major, column j of vertex slot s at queue[j * kQueue + s]; 24 id columns, count, code.
-	uint4 tid[6];
-	uint32_t tnc = 0, tbyte[sizeof(T)];   // raw loads only: anything computed from them here would wait for the memory
-	uint32_t tiles_committed = 0;             // tiles [0, tiles_committed) are in the queue (subject to its capacity)
+	// Per-vertex inputs (the ids of the first two candidates, candidate count, residual code) live in REGISTERS, one 64-vertex tile
+	// at a time (lane j <-> vertex tile_base + j), the next tile's loads in flight while this one is reconstructed.  A batch starts
+	// wherever the previous one ended (batches are cut at vertices that need special handling): the tile's registers are shifted
+	// down by the start lane through the LDS crossbar (ds_bpermute: no memory behind it), so the batch code always sees lane j <->
+	// vertex base + j; a batch ends at the tile's end at the latest.  Round 2 staged four tiles through a column-major LDS queue
+	// to let batches run across tiles: 52 LDS accesses per batch, 1 500 of the 8 400 cycles a batch cost once the float chain
+	// itself was down to 3 600.  The rows of vertices with more than two candidates (0.3 %) go to LDS when their tile starts.
+	uint32_t nx_id[6], nx_nc = 0, nx_byte[sizeof(T)];   // raw loads only: anything computed from them here would wait for the memory
 	const uint32_t n_tiles = (nvtx - seg_begin + 63) / 64;
 	auto tile_request = [&](uint32_t t) {     // loads of tile t into registers
 		const uint32_t v = seg_begin + 64 * t + lane;
-		tnc = 0;
+		nx_nc = 0;
 #pragma unroll
-		for (int b8 = 0; b8 < (int)sizeof(T); ++b8) tbyte[b8] = 0;
+		for (int b8 = 0; b8 < (int)sizeof(T); ++b8) nx_byte[b8] = 0;
 #pragma unroll
-		for (int k = 0; k < 6; ++k) tid[k] = make_uint4(0, 0, 0, 0);
+		for (int k = 0; k < 6; ++k) nx_id[k] = 0;
 		if (v < nvtx) {
-			const uint4 *src = (const uint4*)(cand + (size_t)v * (kCandMax * 3));
+			const uint32_t *src = cand + (size_t)v * (kCandMax * 3);
+			const uint4 a = *(const uint4*)src;
+			const uint2 b2 = *(const uint2*)(src + 4);
+			nx_id[0] = a.x; nx_id[1] = a.y; nx_id[2] = a.z; nx_id[3] = a.w; nx_id[4] = b2.x; nx_id[5] = b2.y;
+			nx_nc = ncand[v];
 #pragma unroll
-			for (int k = 0; k < 6; ++k) tid[k] = src[k];
-			tnc = ncand[v];
-#pragma unroll
-			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) tbyte[b8] = planes[(size_t)(plane0 + b8) * nvtx_total + v];
+			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) nx_byte[b8] = planes[(size_t)(plane0 + b8) * nvtx_total + v];
 		}
 	};
-	auto tile_commit = [&](uint32_t t) {      // registers -> queue
-		const uint32_t slot = (64 * t + lane) & (kQueue - 1);
-#pragma unroll
-		for (int k = 0; k < 6; ++k) {
-			queue[(4 * k) * kQueue + slot] = tid[k].x; queue[(4 * k + 1) * kQueue + slot] = tid[k].y;
-			queue[(4 * k + 2) * kQueue + slot] = tid[k].z; queue[(4 * k + 3) * kQueue + slot] = tid[k].w;
-		}
-		queue[24 * kQueue + slot] = tnc;
-		uint32_t tcode = 0;
-#pragma unroll
-		for (int b8 = 0; b8 < (int)sizeof(T); ++b8) tcode |= tbyte[b8] << (8 * b8);
-		queue[25 * kQueue + slot] = tcode;
-	};
+	uint32_t *bigrow = queue;                 // 24 ids per lane of the tile, written by the lanes with more than two candidates
 	// value of an already reconstructed vertex that lies before the current batch
 	auto old_value = [&](uint32_t id, uint32_t base) -> U {
 		if (base - id <= ring_n && id >= seg_begin) return ring[id & mask];
@@ -416,27 +410,46 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		return far_load<U>(rec + (size_t)id * stride + off);
 	};
 	tile_request(0);
-	uint32_t base = seg_begin;
-	while (base < nvtx) {
-		// the tiles covering [base, base + 64) must be in the queue; beyond that, commit ahead as far as the queue holds
-		// (tiles tile(base) .. tile(base) + kQueue/64 - 1) so that the request of the next tile is always in flight
-		{
-			const uint32_t t_base = (base - seg_begin) / 64;
-			while (tiles_committed < n_tiles && tiles_committed < t_base + kQueue / 64) {
-				tile_commit(tiles_committed);
-				++tiles_committed;
-				if (tiles_committed < n_tiles) tile_request(tiles_committed);
-				if (tiles_committed >= t_base + 2) break;   // enough for this batch; one more tile per batch keeps the queue ahead
-			}
-		}
-		const uint32_t slot = (base - seg_begin + lane) & (kQueue - 1);
-		const bool in_range = base + lane < nvtx;
-		uint32_t ids[6];
+	uint32_t fast_skip = 0, fast_backoff = 0;   // float chain: batches for which the speculative form is not tried after it failed
+	HRY_CLK(unsigned long long ck_p1 = 0, ck_p2 = 0, ck_p3 = 0, ck_prep = 0, ck_chain = 0, ck_verify = 0, ck_pub = 0, ck_exact = 0, ck_batches = 0, ck_nb = 0, ck_retry = 0, ck_exact_n = 0, ck_bigs = 0, ck_general = 0, ck_t = 0, ck_bigt = 0, ck_gen_n = 0, ck_gen_nb = 0;
+	        const unsigned long long ck_begin = __builtin_amdgcn_s_memtime();)
+	for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+	HRY_CLK(ck_t = __builtin_amdgcn_s_memtime();)
+	const uint32_t tile_base = seg_begin + 64 * tile, tile_n = min(64u, nvtx - tile_base);
+	uint32_t t_id[6], t_code = 0;
 #pragma unroll
-		for (int j = 0; j < 6; ++j) ids[j] = queue[j * kQueue + slot];
-		const uint32_t nc = in_range ? queue[24 * kQueue + slot] : 0u;
-		const uint32_t code = queue[25 * kQueue + slot];
-		uint32_t nb = min(64u, nvtx - base);
+	for (int j = 0; j < 6; ++j) t_id[j] = nx_id[j];
+	const uint32_t t_nc = nx_nc;
+#pragma unroll
+	for (int b8 = 0; b8 < (int)sizeof(T); ++b8) t_code |= nx_byte[b8] << (8 * b8);
+	if (tile + 1 < n_tiles) tile_request(tile + 1);   // in flight for the whole of this tile
+	if (__ballot(t_nc > 2 && t_nc != 0xff)) {
+		if (t_nc > 2 && t_nc != 0xff) {
+			const uint4 *src = (const uint4*)(cand + (size_t)(tile_base + lane) * (kCandMax * 3));
+#pragma unroll
+			for (int k = 0; k < 6; ++k) { const uint4 r = src[k]; bigrow[lane * 24 + 4 * k] = r.x; bigrow[lane * 24 + 4 * k + 1] = r.y; bigrow[lane * 24 + 4 * k + 2] = r.z; bigrow[lane * 24 + 4 * k + 3] = r.w; }
+		}
+	}
+	HRY_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_p1 += n - ck_t; })
+	uint32_t pos = 0;
+	while (pos < tile_n) {
+		HRY_CLK(ck_t = __builtin_amdgcn_s_memtime();)
+		const uint32_t base = tile_base + pos;
+		const bool in_range = (uint32_t)lane < tile_n - pos;
+		uint32_t ids[6], nc, code;
+		if (pos) {
+			const int from = (int)(((uint32_t)lane + pos) & 63u) * 4;
+#pragma unroll
+			for (int j = 0; j < 6; ++j) ids[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)t_id[j]);
+			nc = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)t_nc);
+			code = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)t_code);
+		} else {
+#pragma unroll
+			for (int j = 0; j < 6; ++j) ids[j] = t_id[j];
+			nc = t_nc; code = t_code;
+		}
+		nc = in_range ? nc : 0u;
+		uint32_t nb = tile_n - pos;
 		const uint64_t big = __ballot(nc > 2);
 		if (big & 1ull) {
 			// More than two candidates: this vertex is evaluated on its own; every source is older than it.  Up to
@@ -448,8 +461,8 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			if (n0 != 0xff) {
 				uint32_t pk = 0;
 				if ((uint32_t)lane < n0) {
-					const uint32_t s0 = (base - seg_begin) & (kQueue - 1);
-					const uint32_t c0i = queue[(3 * lane) * kQueue + s0], c1i = queue[(3 * lane + 1) * kQueue + s0], c2i = queue[(3 * lane + 2) * kQueue + s0];
+					const uint32_t *row = bigrow + pos * 24;
+					const uint32_t c0i = row[3 * lane], c1i = row[3 * lane + 1], c2i = row[3 * lane + 2];
 					pk = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(old_value(c0i, v)), cm::bits<T>(old_value(c1i, v)), cm::bits<T>(old_value(c2i, v)), q));
 				}
 				T pv[kCandMax];
@@ -484,7 +497,8 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 				stq<T>(rec + (size_t)v * stride + off, val);
 				ring[v & mask] = cm::bits<U>(val);
 			}
-			base += 1;
+			pos += 1;
+			HRY_CLK(++ck_bigs; ck_bigt += __builtin_amdgcn_s_memtime() - ck_t;)
 			continue;
 		}
 		if (big) nb = min(nb, (uint32_t)__builtin_ctzll(big));
@@ -516,7 +530,21 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			const bool chained = (npend == 0) | ((npend == 1) & (ngood == 1));
 			const uint64_t unchained = __ballot(!chained);   // never lane 0: all its sources are older; lanes >= nb count as chained
 			const uint32_t run = unchained ? min(nb, (uint32_t)__builtin_ctzll(unchained)) : nb;
-			if (run == nb || run >= 16) { run_mode = true; nb = run; }
+			// A run costs ~60 cycles per vertex, a step of the general form ~370, a batch start ~2 000.  An unchained vertex is
+			// chained again as the FIRST lane of a batch (every source is older then), so a run is cut in front of it; only where
+			// unchained vertices come thick (fewer than six chained ones in front) does the general form take them -- up to the
+			// first stretch of eight chained vertices, not to the end of the tile (round 2: 5 % of the batches of a regular mesh
+			// went through 64 general steps for one such vertex each, 16 % of the chain's time).
+			if (run == nb || run >= 6) { run_mode = true; nb = run; }
+			else {
+				uint32_t g = run + 1;
+				for (;;) {
+					const uint32_t w = g < 64 ? (uint32_t)(unchained >> g) & 0xffu : 0u;
+					if (!w) break;
+					g += 32u - (uint32_t)__builtin_clz(w);
+				}
+				nb = min(nb, g);
+			}
 		}
 		// Only a source older than the ring costs a global round trip, and only then is the vector-memory counter waited
 		// for: neither the stores of the previous batch nor the tile in flight are ever waited for here.
@@ -540,6 +568,7 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		}
 		LaneEval<T> ev;
 		ev.setup(nc, code, q);
+		HRY_CLK({ asm volatile("" :: "v"(src[0]), "v"(src[5]), "v"(tag[0])); const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_p2 += n - ck_t; })
 		// ---- chain
 		uint32_t val = 0;
 		bool done_run = false;
@@ -664,24 +693,123 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 #undef HRY_STEP
 			}
 		} else if (run_mode && cm::is_fp<T>::value) {
-			// Chain variant "run" for float components (lossless meshes), hand-scheduled like the 16-bit one.  Per lane:
+			// Chain variant "run" for float components (lossless meshes).  Per lane:
 			//   x  = value of the previous vertex (DPP wave shift)
 			//   pp = the parallelogram that waits for it: x + T (x is its first source, T = v1 - v2) or A + (x - O) (second source)
 			//   (p0, p1) = (pp, q) or (q, pp): q is the finished other parallelogram, the order of the candidates is kept because
-			//   the selection below is not symmetric (attrcode.h:182-208: mean in double, candidate nearest to it, strict <,
-			//   starting from FLT_MAX); a lone candidate is the prediction itself
+			//   the selection is not symmetric (attrcode.h:182-208: mean in double, candidate nearest to it, strict <, starting
+			//   from FLT_MAX); a lone candidate is the prediction itself
 			//   value = inverse residual code on the ordered-int images (transform.h:19-23, prediction.h:46-64, no sign flip)
-			// 33 instructions + 3 s_nop per vertex; LaneEval<float>::eval is the readable form of the same arithmetic.
+			// A lone wavefront pays ~4 cycles per instruction and ~6 per DEPENDENT instruction, so the chain is evaluated SPECULATIVELY
+			// in 11 - 12 instructions per vertex (8 on the dependency) and then VERIFIED exactly, all lanes at once (the scheme of k_unpredict3): every lane
+			// evaluates the reference arithmetic (LaneEval<float>::eval) on its predecessor's final value; lane 0 of a batch is exact
+			// by construction, so all values are right iff every lane agrees (induction).  What the short form assumes:
+			//   mean   fma(pp, 0.5, q/2) in float = the float of the double mean unless the sum leaves the float range or the two
+			//          exponents are > 29 bits apart;  the FLT_MAX start of the sweep never wins;
+			//   code   the "near" case of the residual code (prediction.h:58-63): value bits = prediction bits +- delta, the sign
+			//          taken from the prediction (no crossing of zero, prediction not 0).
+			// The first lane that disagrees is given its exact value (it becomes a lane without a source inside the batch) and the
+			// chain is run again from there, twice at most; after that -- and for the following batches of a chain that keeps
+			// failing (a coordinate plane z = 0: every prediction is 0) -- the exact chain below (33 instructions) takes over.
 			const uint32_t kp = pend_slot < 3 ? 0u : pend_slot < 6 ? 1u : 0u;
 			const float fa = cm::bits<float>(kp ? src[3] : src[0]), fb = cm::bits<float>(kp ? src[4] : src[1]), fo = cm::bits<float>(kp ? src[5] : src[2]);
 			const float ga = cm::bits<float>(kp ? src[0] : src[3]), gb = cm::bits<float>(kp ? src[1] : src[4]), go = cm::bits<float>(kp ? src[2] : src[5]);
 			const uint32_t cT = cm::bits<uint32_t>(fb - fo), cA = cm::bits<uint32_t>(fa), cO = cm::bits<uint32_t>(fo);
 			const uint32_t cq = cm::bits<uint32_t>(ga + (gb - go));
-			const uint32_t valc = ev.eval(src);                       // the finished value of a vertex without a source inside the batch
-			const uint64_t isB = __ballot(pend_slot == 1 || pend_slot == 4), isK1 = __ballot(kp == 1);
-			const uint64_t lone = __ballot(nc == 1), keep = __ballot(pend_slot == 6);
+			// the finished value of a vertex without a source inside the batch -- the exact chain needs it exactly; the speculative
+			// one takes the short form of the arithmetic for it too (it is verified like every other lane)
+			uint32_t valc = 0;
+			const bool isBl = pend_slot == 1 || pend_slot == 4;
+			const uint64_t isB = __ballot(isBl), isK1 = __ballot(kp == 1);
+			const uint64_t lone = __ballot(nc == 1);
+			const bool keepl0 = pend_slot == 6;
+			const uint64_t keep = __ballot(keepl0);
 			UnfoldPre uf;
 			uf.setup(code, 0xffffffffu, 0xffffffffu);
+			bool exact_chain = fast_skip != 0;
+			if (fast_skip) --fast_skip;
+			if (!exact_chain) {
+				// pp = P + (x + M): (M, P) = (T, -0.0) when x is the first source (-0.0 + y == y for every y), (-O, A) when it is the second.
+				// A lane without a source inside the batch holds a finished value: M = NaN makes its pp, mean and distances NaN, the
+				// difference of the |distances| a positive NaN -- never "pp is nearer" -- so the select yields q = that value, and
+				// delta = 0 leaves it alone: no instruction of the step is spent on such lanes.
+				const bool lonel = nc == 1;
+				{
+					const float p0 = cm::bits<float>(src[0]) + (cm::bits<float>(src[1]) - cm::bits<float>(src[2]));
+					const float p1 = cm::bits<float>(src[3]) + (cm::bits<float>(src[4]) - cm::bits<float>(src[5]));
+					const float avg = __builtin_fmaf(p0, 0.5f, 0.5f * p1);
+					const float e = __builtin_fabsf(avg - p0) - __builtin_fabsf(avg - p1);
+					const float two = e < 0.0f ? p0 : p1;                        // ties go to the later candidate
+					const uint32_t pb = cm::bits<uint32_t>(nc == 2 ? two : nc == 1 ? p0 : 0.0f);
+					valc = nc == 0 ? uf.code : (int32_t)pb < 0 ? pb - uf.delta : pb + uf.delta;
+				}
+				uint32_t cM = keepl0 ? 0x7fc00000u : isBl ? cm::bits<uint32_t>(-fo) : cT;
+				const uint32_t cP = isBl ? cA : 0x80000000u;
+				uint32_t q2 = keepl0 ? valc : lonel ? 0x7f7fffffu : cq;               // a lone candidate: the other one is out of reach
+				const uint32_t qh = lonel ? 0u : cm::bits<uint32_t>(0.5f * cm::bits<float>(cq));
+				const uint32_t kk = kp == 1 ? 1u : 0u;                                 // ties go to the later candidate (strict <)
+				uint32_t dlt = keepl0 ? 0u : uf.delta;
+				// the value either candidate would give: its bits +- delta by its own sign; the one for q is finished here, the one for
+				// pp runs beside the selection (the dependency is add, add, fma, sub, sub, sub, shift, select: eight deep)
+				uint32_t vq = (int32_t)q2 < 0 ? q2 - dlt : q2 + dlt;
+				const bool all_first = (isB & ((nb >= 64 ? ~0ull : (1ull << nb) - 1ull))) == 0;
+#define HRY_QSTEP_HEAD_A                                                                                                 \
+			    "v_add_f32_dpp v100, %[val], %[M] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define HRY_QSTEP_HEAD_B                                                                                                 \
+			    "v_add_f32_dpp v100, %[val], %[M] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                   \
+			    "v_add_f32 v100, %[P], v100\n\t"
+#define HRY_QSTEP_TAIL                                                                                                   \
+			    "v_fma_f32 v101, v100, 0.5, %[qh]\n\t"                                                                     \
+			    "v_ashrrev_i32 v105, 31, v100\n\t"                                                                         \
+			    "v_sub_f32 v102, v101, v100\n\t"                                                                           \
+			    "v_sub_f32 v103, v101, %[q]\n\t"                                                                           \
+			    "v_xad_u32 v106, %[dlt], v105, v100\n\t"                                                                   \
+			    "v_sub_f32_e64 v102, |v102|, |v103|\n\t"                                                                   \
+			    "v_sub_u32 v106, v106, v105\n\t"                                                                           \
+			    "v_sub_u32 v102, v102, %[kk]\n\t"                                                                          \
+			    "v_ashrrev_i32 v102, 31, v102\n\t"                                                                         \
+			    "v_bfi_b32 %[val], v102, v106, %[vq]\n\t"                                                                  \
+			    "s_nop 1\n\t"
+#define HRY_QRUN(HEAD)                                                                                                   \
+				for (uint32_t i = s0; i < nb; i += 8) {                                                                    \
+					asm(HEAD HRY_QSTEP_TAIL HEAD HRY_QSTEP_TAIL HEAD HRY_QSTEP_TAIL HEAD HRY_QSTEP_TAIL                         \
+					    HEAD HRY_QSTEP_TAIL HEAD HRY_QSTEP_TAIL HEAD HRY_QSTEP_TAIL HEAD HRY_QSTEP_TAIL                         \
+					    : [val] "+v"(val)                                                                                   \
+					    : [M] "v"(cM), [P] "v"(cP), [q] "v"(q2), [qh] "v"(qh), [kk] "v"(kk), [dlt] "v"(dlt), [vq] "v"(vq)             \
+					    : "v100", "v101", "v102", "v103", "v104", "v105", "v106");                                          \
+				}
+				uint32_t s0 = 0;
+				HRY_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_prep += n - ck_t; ck_t = n; })
+				for (uint32_t tries = 0;; ++tries) {
+					asm volatile("s_nop 1");   // the first DPP read of val, and the ballots above
+					if (all_first) { HRY_QRUN(HRY_QSTEP_HEAD_A) } else { HRY_QRUN(HRY_QSTEP_HEAD_B) }
+					HRY_CLK({ asm volatile("" :: "v"(val)); const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_chain += n - ck_t; ck_t = n; })
+					// exact check, all lanes at once: the reference arithmetic on the predecessor's final value
+					const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)val, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+					uint32_t sv[6];
+#pragma unroll
+					for (int j = 0; j < 6; ++j) sv[j] = pend_slot == (uint32_t)j ? prev : src[j];
+					const uint32_t ref = ev.eval(sv);
+					const uint64_t bad = __ballot(lane < (int)nb && ref != val);
+					HRY_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_verify += n - ck_t; ck_t = n; if (bad) ++ck_retry; })
+					if (!bad) break;
+					if (tries >= 2) { exact_chain = true; break; }
+					const uint32_t f = (uint32_t)__builtin_ctzll(bad);     // every lane before f is right, so ref of lane f is its exact value
+					const bool fix = (uint32_t)lane == f;                  // ... and the lane now holds a finished value
+					cM = fix ? 0x7fc00000u : cM; q2 = fix ? ref : q2; vq = fix ? ref : vq; dlt = fix ? 0u : dlt;
+					s0 = f & ~7u;
+				}
+#undef HRY_QRUN
+#undef HRY_QSTEP_TAIL
+#undef HRY_QSTEP_HEAD_B
+#undef HRY_QSTEP_HEAD_A
+				HRY_CLK(if (exact_chain) ++ck_exact_n;)
+				if (exact_chain) { fast_backoff = fast_backoff ? min(64u, 2u * fast_backoff) : 2u; fast_skip = fast_backoff; val = 0; }
+				else fast_backoff = 0;
+			}
+			if (exact_chain) {
+			valc = ev.eval(src);
+			// the exact chain, hand-scheduled: 33 instructions + 3 s_nop per vertex; LaneEval<float>::eval is the readable form
 			const uint32_t c_hp1 = uf.half + 1u, c_lim = 0xffffffffu - 2u * uf.half, fltmax = 0x7f7fffffu, htop = 0x7fffffffu;
 #define HRY_FSTEP                                                                                                       \
 			    "v_add_f32_dpp v100, %[val], %[T] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                   \
@@ -731,6 +859,8 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 				      "v116", "v117", "v118", "v119", "v120", "s80", "s81", "s82", "s83");
 			}
 #undef HRY_FSTEP
+			HRY_CLK({ asm volatile("" :: "v"(val)); const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_exact += n - ck_t; ck_t = n; })
+			}
 		} else if (run_mode) {
 			// Chain variant "run" for the other component types (32-bit and signed integers): the same wave shift, the
 			// arithmetic is LaneEval<T>::eval itself with the previous vertex substituted for the one source that waits for it.
@@ -751,13 +881,19 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			}
 		}
 		// ---- publish the batch
+		HRY_CLK({ asm volatile("" :: "v"(val)); const unsigned long long n = __builtin_amdgcn_s_memtime(); if (!run_mode) { ck_general += n - ck_t; ++ck_gen_n; ck_gen_nb += nb; } ck_t = n; })
 		if (lane < (int)nb) {
 			const uint32_t v = base + lane;
 			ring[v & mask] = (U)val;
 			stq<T>(rec + (size_t)v * stride + off, cm::bits<T>((U)val));
 		}
-		base += nb;
+		pos += nb;
+		HRY_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_pub += n - ck_t; ++ck_batches; ck_nb += nb; })
 	}
+	}
+	HRY_CLK(if (lane == 0 && ck_batches > 100) printf("chain2 comp %d: %llu vertices, %llu batches (mean %llu), bigs %llu, retries %llu, exact batches %llu | per batch: prep %llu (commit %llu, to sources %llu) chain %llu verify %llu exact %llu general %llu publish %llu | bigs at %llu, %llu general batches (mean %llu) | total %llu per vertex %llu\n",
+	        comp, (unsigned long long)(nvtx - seg_begin), ck_batches, ck_nb / ck_batches, ck_bigs, ck_retry, ck_exact_n, ck_prep / ck_batches, ck_p1 / ck_batches, ck_p2 / ck_batches, ck_chain / ck_batches, ck_verify / ck_batches, ck_exact / ck_batches,
+	        ck_general / ck_batches, ck_pub / ck_batches, ck_bigt / (ck_bigs ? ck_bigs : 1), ck_gen_n, ck_gen_nb / (ck_gen_n ? ck_gen_n : 1), __builtin_amdgcn_s_memtime() - ck_begin, (__builtin_amdgcn_s_memtime() - ck_begin) / (nvtx - seg_begin));)
 }
 
 struct CompSel { int32_t n; int32_t comp[kMaxComp]; };
@@ -817,11 +953,6 @@ constexpr uint32_t kRing3 = 16384;          // ring entries (32 KB of LDS for 16
 constexpr uint32_t kRing3Near = kRing3 - 64;   // a source this close to its vertex is still in the ring when the run is prepared
 #ifndef HRY_CHAIN_POLL_PAUSE_ASM
 #define HRY_CHAIN_POLL_PAUSE_ASM
-#endif
-#ifdef HRY_CHAIN_CLOCKS   // development: where the ticks of a chain go (wavefront 0 of every chain prints its sums)
-#define HRY_CLK(...) __VA_ARGS__
-#else
-#define HRY_CLK(...)
 #endif
 #ifndef HRY_CHAIN_MAX_HEADS
 #define HRY_CHAIN_MAX_HEADS 8

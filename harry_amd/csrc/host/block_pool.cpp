@@ -4,6 +4,8 @@
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <unistd.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <new>
@@ -20,9 +22,14 @@ struct Pool {
 	size_t free_bytes = 0, limit;
 	Pool()
 	{
-		// HRY_POOL_MB: how much freed memory the pool may keep (default 2048 MiB, 0 disables recycling)
+		// HRY_POOL_MB: how much freed memory the pool may keep (0 disables recycling).  Default: an eighth of the machine's memory,
+		// at least 2 GiB, at most 64 GiB -- a 100 M-triangle mesh frees 5 GB of per-call arrays per encode, and fresh ones cost
+		// a page fault per 4 KiB (or per 2 MiB) under the process-wide mmap lock, which is what N concurrent workers then queue on
 		const char *e = getenv("HRY_POOL_MB");
-		limit = (size_t)(e ? strtoull(e, nullptr, 10) : 2048ull) << 20;
+		size_t def = 2048;
+		const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+		if (pages > 0 && psz > 0) def = std::min<size_t>(65536, std::max<size_t>(2048, ((size_t)pages * (size_t)psz >> 20) / 8));
+		limit = (size_t)(e ? strtoull(e, nullptr, 10) : def) << 20;
 	}
 	~Pool() { for (auto &kv : free_blocks) free(kv.second); }
 };

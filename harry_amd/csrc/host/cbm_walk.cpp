@@ -1067,7 +1067,8 @@ void analyse_components(const Mesh &m, ComponentAnalysis &A)
 	const unsigned nt = m.nf >= (1u << 16) ? host_threads() : 1u;
 	if (udeg == 3) { analyse_impl<3>(m, nullptr, nullptr, nullptr, nt, A); return; }
 	if (udeg == 4) { analyse_impl<4>(m, nullptr, nullptr, nullptr, nt, A); return; }
-	std::vector<uint32_t> eface_tab(m.ne());
+	BigVec<uint32_t> &eface_tab = A.eface;   // (pooled, not value-initialised: every entry is written below)
+	eface_tab.resize(m.ne());
 	parallel_for(nt, [&](unsigned t) {
 		const uint32_t b = (uint32_t)((uint64_t)m.nf * t / nt), e = (uint32_t)((uint64_t)m.nf * (t + 1) / nt);
 		for (uint32_t f = b; f < e; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface_tab[h] = f;

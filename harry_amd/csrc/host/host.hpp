@@ -114,6 +114,7 @@ struct ComponentAnalysis {
 	std::vector<uint32_t> seed, n_faces, n_halfedges, fresh, group;   // per coding rank; group = smallest rank tied to it
 	bool want_vertex_owner = false;
 	BigVec<uint32_t> vertex_owner;               // per vertex: coding rank of the component that introduces it (0xffffffff: unused)
+	BigVec<uint32_t> eface;                      // mixed polygon degrees only: face of every half-edge (kept for the shard planner)
 };
 void analyse_components(const Mesh &m, ComponentAnalysis &A);
 
@@ -125,11 +126,17 @@ struct ShardPlan {
 	std::vector<uint32_t> base_v, base_f, base_he; // per coding rank (+ end): position in the numbering of the decoded mesh
 	std::vector<uint64_t> shard_triangles;        // per shard
 	std::vector<uint8_t> have_degree;
+	// where every element goes, built once for all shards (one pass over the mesh instead of one per shard)
+	BigVec<uint32_t> local_face, local_he;        // per face: its index in its shard, the first half-edge of it there
+	BigVec<uint32_t> local_vertex;                // per vertex: its index in the shard that owns it (unreferenced vertices: shard 0)
+	std::vector<BigVec<uint32_t>> shard_faces, shard_vertices;   // per shard: its faces / vertices, ascending input index
+	std::vector<uint32_t> shard_ne;               // per shard: half-edges
+	int udeg = 0;                                 // the one polygon degree of the mesh, 0 = mixed (then A.eface holds the face of every half-edge)
 };
 void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan);
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard);
 // several single- or multi-segment sharded containers (.hry v0.3) of the same mesh -> one
-void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, std::vector<uint8_t> &out);
+void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, ByteSink &out);
 // the directory of a sharded container, validated against the header's sizes (throws HRY_E_FORMAT on damage)
 struct ShardedDirectory {
 	struct Segment { size_t offset = 0, bytes = 0, body_at = 0; std::vector<ShardRun> runs; uint32_t nv = 0, nf = 0, ne = 0; };   // body_at: v0.2 body inside the segment

@@ -97,35 +97,65 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 		plan.shard_of[k] = shard_of_group[A.group[k]];
 		plan.shard_triangles[plan.shard_of[k]] += (uint64_t)A.n_halfedges[k] - 2ull * A.n_faces[k];
 	}
+	// ---- where every face / half-edge / vertex goes: compact numbering per shard, ascending input index.  One pass over the mesh
+	// for ALL shards (thread ranges count per shard, a prefix over the ranges places them).
+	if (!m.uniform_degree(plan.udeg)) plan.udeg = 0;
+	const uint32_t nf = m.nf, nv = m.nv;
+	const uint32_t *foff = m.face_off.data();
+	const Ranges R(m.ne());
+	const unsigned nt = R.nt;
+	const size_t S = n_shards;
+	// vertices that no face references are never coded (the reference's walk does not reach them) but its bounds scan reads every
+	// record (structs/quant.h:30-44): shard 0 carries them, so that the shards' bounds combine to the whole mesh's
+	auto shard_of_face = [&](uint32_t f) { return plan.shard_of[A.rank_of[A.comp[f]]]; };
+	auto shard_of_vertex = [&](uint32_t v) { const uint32_t o = A.vertex_owner[v]; return o != NONE32 ? plan.shard_of[o] : 0u; };
+	std::vector<uint32_t> cf((size_t)(nt + 1) * S, 0), ch((size_t)(nt + 1) * S, 0), cv((size_t)(nt + 1) * S, 0);
+	parallel_for(nt, [&](unsigned t) {
+		uint32_t b, e;
+		uint32_t *f_ = cf.data() + (size_t)(t + 1) * S, *h_ = ch.data() + (size_t)(t + 1) * S, *v_ = cv.data() + (size_t)(t + 1) * S;
+		R.of(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) { const uint32_t s = shard_of_face(f); ++f_[s]; h_[s] += foff[f + 1] - foff[f]; }
+		R.of(nv, t, b, e);
+		for (uint32_t v = b; v < e; ++v) ++v_[shard_of_vertex(v)];
+	});
+	for (unsigned t = 0; t < nt; ++t)
+		for (size_t s = 0; s < S; ++s) { cf[(t + 1) * S + s] += cf[t * S + s]; ch[(t + 1) * S + s] += ch[t * S + s]; cv[(t + 1) * S + s] += cv[t * S + s]; }
+	plan.shard_faces.resize(S); plan.shard_vertices.resize(S); plan.shard_ne.resize(S);
+	for (size_t s = 0; s < S; ++s) { plan.shard_faces[s].resize(cf[nt * S + s]); plan.shard_vertices[s].resize(cv[nt * S + s]); plan.shard_ne[s] = ch[nt * S + s]; }
+	plan.local_face.resize(nf); plan.local_he.resize(nf); plan.local_vertex.resize(nv);
+	parallel_for(nt, [&](unsigned t) {
+		uint32_t b, e;
+		std::vector<uint32_t> lf(cf.begin() + (size_t)t * S, cf.begin() + (size_t)(t + 1) * S), lh(ch.begin() + (size_t)t * S, ch.begin() + (size_t)(t + 1) * S),
+		                      lv(cv.begin() + (size_t)t * S, cv.begin() + (size_t)(t + 1) * S);
+		R.of(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) {
+			const uint32_t s = shard_of_face(f);
+			plan.local_face[f] = lf[s]; plan.local_he[f] = lh[s];
+			plan.shard_faces[s][lf[s]++] = f;
+			lh[s] += foff[f + 1] - foff[f];
+		}
+		R.of(nv, t, b, e);
+		for (uint32_t v = b; v < e; ++v) {
+			const uint32_t s = shard_of_vertex(v);
+			plan.local_vertex[v] = lv[s];
+			plan.shard_vertices[s][lv[s]++] = v;
+		}
+	});
 }
 
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 {
 	ensure_twins(m);
 	if (shard >= plan.n_shards) throw Error(HRY_E_ARG, "shard index out of range");
-	if (plan.g_nv != m.nv || plan.g_nf != m.nf || plan.g_ne != m.ne() || plan.A.comp.size() != m.nf || plan.A.vertex_owner.size() != m.nv)
+	if (plan.g_nv != m.nv || plan.g_nf != m.nf || plan.g_ne != m.ne() || plan.A.comp.size() != m.nf || plan.A.vertex_owner.size() != m.nv || plan.local_face.size() != m.nf)
 		throw Error(HRY_E_ARG, "the plan belongs to another mesh");
 	const ComponentAnalysis &A = plan.A;
 	const uint32_t nf = m.nf, nv = m.nv, nc = A.ncomp;
 	const uint32_t *foff = m.face_off.data();
-	const Ranges R(m.ne());
+	const BigVec<uint32_t> &faces = plan.shard_faces[shard], &verts = plan.shard_vertices[shard];
+	const uint32_t lnf = (uint32_t)faces.size(), lnv = (uint32_t)verts.size(), lne = plan.shard_ne[shard];
+	const Ranges R(lne);
 	const unsigned nt = R.nt;
-	auto face_sel = [&](uint32_t f) { return plan.shard_of[A.rank_of[A.comp[f]]] == shard; };
-	// vertices that no face references are never coded (the reference's walk does not reach them) but its bounds scan reads every
-	// record (structs/quant.h:30-44): shard 0 carries them, so that the shards' bounds combine to the whole mesh's
-	auto vert_sel = [&](uint32_t v) { const uint32_t o = A.vertex_owner[v]; return o != NONE32 ? plan.shard_of[o] == shard : shard == 0; };
-	// compact numbering: ascending input index
-	std::vector<uint32_t> cf(nt + 1, 0), ch(nt + 1, 0), cv(nt + 1, 0);
-	parallel_for(nt, [&](unsigned t) {
-		uint32_t b, e, nfc = 0, nhc = 0, nvc = 0;
-		R.of(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) if (face_sel(f)) { ++nfc; nhc += foff[f + 1] - foff[f]; }
-		R.of(nv, t, b, e);
-		for (uint32_t v = b; v < e; ++v) if (vert_sel(v)) ++nvc;
-		cf[t + 1] = nfc; ch[t + 1] = nhc; cv[t + 1] = nvc;
-	});
-	for (unsigned t = 0; t < nt; ++t) { cf[t + 1] += cf[t]; ch[t + 1] += ch[t]; cv[t + 1] += cv[t]; }
-	const uint32_t lnf = cf[nt], lne = ch[nt], lnv = cv[nt];
 	std::unique_ptr<Mesh> out(new Mesh());
 	Mesh &s = *out;
 	s.nv = lnv; s.nf = lnf;
@@ -133,52 +163,30 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 	s.face_off.resize((size_t)lnf + 1); s.face_off[0] = 0;
 	s.org.resize(lne); s.twin.resize(lne);
 	s.shard.g_nv = plan.g_nv; s.shard.g_nf = plan.g_nf; s.shard.g_ne = plan.g_ne;
-	s.shard.vertex_of.resize(lnv); s.shard.face_of.resize(lnf);
-	BigVec<uint32_t> g2l_f, g2l_v, l_off;   // input face -> (shard face, first half-edge of it in the shard); input vertex -> shard vertex
-	g2l_f.resize(nf); g2l_v.resize(nv); l_off.resize(nf);
-	parallel_for(nt, [&](unsigned t) {
-		uint32_t b, e;
-		R.of(nf, t, b, e);
-		uint32_t lf = cf[t], lh = ch[t];
-		for (uint32_t f = b; f < e; ++f) {
-			if (!face_sel(f)) { g2l_f[f] = NONE32; continue; }
-			g2l_f[f] = lf; l_off[f] = lh;
-			s.shard.face_of[lf] = f;
-			lh += foff[f + 1] - foff[f];
-			s.face_off[++lf] = lh;
-		}
-		R.of(nv, t, b, e);
-		uint32_t lv = cv[t];
-		for (uint32_t v = b; v < e; ++v) {
-			if (!vert_sel(v)) { g2l_v[v] = NONE32; continue; }
-			g2l_v[v] = lv;
-			s.shard.vertex_of[lv++] = v;
-		}
-	});
-	// face of a half-edge: uniform degree by division, else by bisection of the offsets
-	int udeg = 0;
-	if (!m.uniform_degree(udeg)) udeg = 0;
-	auto face_of = [&](uint32_t h) -> uint32_t {
-		if (udeg) return h / (uint32_t)udeg;
-		return (uint32_t)(std::upper_bound(foff, foff + nf + 1, h) - foff) - 1;
-	};
+	s.shard.vertex_of.assign(verts.begin(), verts.end()); s.shard.face_of.assign(faces.begin(), faces.end());
+	// face of a half-edge: uniform degree by division, else the table the analysis built
+	const int udeg = plan.udeg;
+	if (!udeg && A.eface.size() != m.ne()) throw Error(HRY_E_INTERNAL, "shard: plan without its half-edge table");
+	const uint32_t *eface = udeg ? nullptr : A.eface.data();
+	auto face_of = [&](uint32_t h) -> uint32_t { return udeg ? h / (uint32_t)udeg : eface[h]; };
 	std::atomic<bool> bad{ false };
 	parallel_for(nt, [&](unsigned t) {
 		uint32_t b, e;
-		R.of(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) {
-			if (g2l_f[f] == NONE32) continue;
-			const uint32_t lo = l_off[f];
-			for (uint32_t h = foff[f]; h < foff[f + 1]; ++h) {
-				const uint32_t lh = lo + (h - foff[f]);
-				const uint32_t lv = g2l_v[m.org[h]];
-				if (lv == NONE32) bad.store(true, std::memory_order_relaxed);
-				s.org[lh] = lv;
+		R.of(lnf, t, b, e);
+		for (uint32_t lf = b; lf < e; ++lf) {
+			const uint32_t f = faces[lf];
+			const uint32_t lo = plan.local_he[f], deg = foff[f + 1] - foff[f];
+			s.face_off[(size_t)lf + 1] = lo + deg;
+			for (uint32_t k = 0; k < deg; ++k) {
+				const uint32_t h = foff[f] + k, lh = lo + k;
+				const uint32_t v = m.org[h];
+				if (v >= nv || (A.vertex_owner[v] == NONE32 ? 0u : plan.shard_of[A.vertex_owner[v]]) != shard) { bad.store(true, std::memory_order_relaxed); s.org[lh] = 0; }
+				else s.org[lh] = plan.local_vertex[v];
 				const uint32_t o = m.twin[h];
 				if (o == h) { s.twin[lh] = lh; continue; }
 				const uint32_t fo = face_of(o);
-				if (g2l_f[fo] == NONE32) { bad.store(true, std::memory_order_relaxed); s.twin[lh] = lh; continue; }
-				s.twin[lh] = l_off[fo] + (o - foff[fo]);
+				if (fo >= nf || plan.shard_of[A.rank_of[A.comp[fo]]] != shard) { bad.store(true, std::memory_order_relaxed); s.twin[lh] = lh; continue; }
+				s.twin[lh] = plan.local_he[fo] + (o - foff[fo]);
 			}
 		}
 	});
@@ -190,7 +198,7 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 		D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
 		D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
 		D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = L.have_bounds;
-		const std::vector<uint32_t> &src = l == 0 ? s.shard.face_of : s.shard.vertex_of;
+		const BigVec<uint32_t> &src = l == 0 ? faces : verts;
 		D.count = (uint32_t)src.size();
 		const size_t st = (size_t)L.stride();
 		D.data.resize(src.size() * st);
@@ -198,14 +206,15 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 		if (st) parallel_for(nt, [&](unsigned t) {
 			uint32_t b, e;
 			R.of((uint32_t)src.size(), t, b, e);
-			for (uint32_t i = b; i < e; ++i) memcpy(D.data.data() + (size_t)i * st, L.data.data() + (size_t)src[i] * st, st);
+			if (st == 12) for (uint32_t i = b; i < e; ++i) memcpy(D.data.data() + (size_t)i * 12, L.data.data() + (size_t)src[i] * 12, 12);
+			else for (uint32_t i = b; i < e; ++i) memcpy(D.data.data() + (size_t)i * st, L.data.data() + (size_t)src[i] * st, st);
 		});
 	}
 	// components of the shard in coding order: seeds and runs
 	bool open = false;
 	for (uint32_t k = 0; k < nc; ++k) {
 		if (plan.shard_of[k] != shard) { open = false; continue; }
-		s.shard.seeds.push_back(g2l_f[A.seed[k]]);
+		s.shard.seeds.push_back(plan.local_face[A.seed[k]]);
 		if (!open) { s.shard.runs.push_back(ShardRun{ plan.base_v[k], plan.base_f[k], plan.base_he[k], 0, 0, 0 }); open = true; }
 		ShardRun &r = s.shard.runs.back();
 		r.n_vertices += A.fresh[k]; r.n_faces += A.n_faces[k]; r.n_halfedges += A.n_halfedges[k];
@@ -235,7 +244,7 @@ PartView parse_part(const uint8_t *p, size_t n)
 }
 }   // namespace
 
-void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, std::vector<uint8_t> &out)
+void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, ByteSink &out)
 {
 	if (n == 0) throw Error(HRY_E_ARG, "merge: nothing to merge");
 	std::vector<PartView> pv(n);
@@ -247,13 +256,24 @@ void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n
 		nseg += pv[i].nseg; bytes += pv[i].seg_bytes;
 	}
 	if (nseg > 0xffffffffull) throw Error(HRY_E_UNSUPPORTED, "too many segments");
+	const size_t hdr = pv[0].hdr;
 	out.clear();
-	out.reserve(pv[0].hdr + 4 + 8 * (size_t)nseg + (size_t)bytes);
-	out.insert(out.end(), parts[0], parts[0] + pv[0].hdr);
+	out.resize(hdr + 4 + 8 * (size_t)nseg + (size_t)bytes);   // (not zero-filled: every byte is written below)
+	uint8_t *o = out.data();
+	memcpy(o, parts[0], hdr);
 	const uint32_t ns32 = (uint32_t)nseg;
-	out.insert(out.end(), (const uint8_t*)&ns32, (const uint8_t*)&ns32 + 4);
-	for (size_t i = 0; i < n; ++i) out.insert(out.end(), pv[i].lens, pv[i].lens + 8ull * pv[i].nseg);
-	for (size_t i = 0; i < n; ++i) out.insert(out.end(), pv[i].segs, pv[i].segs + pv[i].seg_bytes);
+	memcpy(o + hdr, &ns32, 4);
+	std::vector<size_t> len_at(n), seg_at(n);
+	size_t la = hdr + 4, sa = hdr + 4 + 8 * (size_t)nseg;
+	for (size_t i = 0; i < n; ++i) { len_at[i] = la; seg_at[i] = sa; la += 8ull * pv[i].nseg; sa += pv[i].seg_bytes; }
+	// the segments are most of a container: copied by a few threads, each its parts (fresh pages of the output included)
+	const unsigned nt = bytes >= (16u << 20) ? (unsigned)std::min<size_t>(n, host_threads()) : 1u;
+	parallel_for(nt, [&](unsigned t) {
+		for (size_t i = t; i < n; i += nt) {
+			if (pv[i].nseg) memcpy(o + len_at[i], pv[i].lens, 8ull * pv[i].nseg);
+			if (pv[i].seg_bytes) memcpy(o + seg_at[i], pv[i].segs, pv[i].seg_bytes);
+		}
+	});
 }
 
 // ---- directory of a sharded container -------------------------------------------------------------------------------

@@ -80,6 +80,8 @@ typedef struct hry_opts {
  * filler (faces without half-edges, zero records).  The accessors read such a mesh; the writers, hry_encode, hry_mesh_upload,
  * hry_walk_run and hry_shard_plan refuse it (HRY_E_ARG). */
 #define HRY_FLAG_PARTIAL 4
+/* hry_encode_sharded: leave *m exactly as it is (do not store the combined bounds of the whole mesh in it) */
+#define HRY_FLAG_KEEP_MESH 8
 
 /* timings of the last hry_encode / hry_decode on this context, milliseconds */
 typedef struct hry_timing {
@@ -235,6 +237,7 @@ int hry_mesh_partial(const hry_mesh *m);   /* 1: decoded with HRY_FLAG_PARTIAL /
  *                       mesh in the numbering of the whole; opts->shard_index / shard_count select a share as in hry_decode.
  * hry_ctx_timing of each context holds the sums over the shards / segments it processed. */
 typedef struct hry_shard_timing {
+    double twins_ms;     /* encode: half-edge twin matching of a freshly read mesh (first context's device), part of plan_ms */
     double plan_ms;      /* encode: twins + components + coding order + scans + distribution; decode: directory checks */
     double extract_ms;   /* encode: hry_shard_extract (decode: placement into the whole numbering), max over the workers */
     double bounds_ms;    /* upload + k_bounds per shard, max over the workers */

@@ -63,7 +63,7 @@ int main(int argc, char **argv)
 					}
 					std::vector<const uint8_t*> pp; std::vector<size_t> ps;
 					for (auto &c : parts) { pp.push_back(c.data()); ps.push_back(c.size()); }
-					std::vector<uint8_t> merged;
+					ByteSink merged;
 					merge_containers(pp.data(), ps.data(), pp.size(), merged);
 					Mesh hm; int mn3 = 0;
 					const size_t h3 = read_hry_header(merged.data(), merged.size(), hm, mn3, false);
@@ -71,14 +71,14 @@ int main(int argc, char **argv)
 					parse_sharded_directory(merged.data(), merged.size(), h3, hm.nv, hm.nf, hm.declared_ne, dir);
 					if (!dir.complete || mn3 != 3) throw Error(HRY_E_INTERNAL, "merged directory incomplete");
 					for (int k = 0; k < 64; ++k) {
-						std::vector<uint8_t> bad = merged;
+						std::vector<uint8_t> bad(merged.begin(), merged.end());
 						if (k < 8) bad.resize(h3 + (size_t)k * (bad.size() - h3) / 8);
 						else for (int j = 0; j < 2; ++j) bad[h3 + (size_t)(1103515245u * (unsigned)(k * 2 + j + 1) + 12345u) % (bad.size() - h3)] ^= (uint8_t)(1u << ((k + j) & 7));
 						try {
 							ShardedDirectory d2;
 							parse_sharded_directory(bad.data(), bad.size(), h3, hm.nv, hm.nf, hm.declared_ne, d2, (k & 1) != 0);
 							const uint8_t *bp = bad.data(); const size_t bn = bad.size();
-							std::vector<uint8_t> again;
+							ByteSink again;
 							merge_containers(&bp, &bn, 1, again);
 						} catch (const Error &) {
 						}
