@@ -353,7 +353,8 @@ def main():
         line = {
             "metric": "Mtriangles/s encode+decode", "value": round(value, 4), "unit": "Mtriangles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 residual bytes, u32 range-coder registers (compat profile: u64)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u16 residual bytes, u32 range-coder registers (compat profile: u64)" if world == 1 else "u8 residual bytes of f32 values, u32 range-coder registers", "data": "synthetic",
             "config": {"workload": per_gpu if world == 1 else f"ONE mesh shaped like BASELINE configs[3] ({ntri} triangles, {n_comps} components, {n_groups} groups); per GPU: {per_gpu}; sharded by connected component",
                        "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}, one process per GPU", "inputs_resident": True},
             "encode_mtri_s": round(ntri * args.steps / t_enc / 1e6, 4),
@@ -496,11 +497,15 @@ def main():
         print(json.dumps(line))
     cx.close()
     if world > 1:
-        # rank 0 works alone after the timed region; the others wait on the HOST (a gloo barrier: an RCCL barrier would spin on
-        # their GPUs, which the in-process leg uses)
+        # rank 0 works alone after the timed region; the others wait on the HOST (a key in the rendezvous store: an RCCL barrier
+        # would spin on their GPUs, which the in-process leg uses; a gloo group would print to stdout)
         try:
-            g = dist.new_group(backend="gloo")
-            dist.barrier(group=g)
+            from torch.distributed import distributed_c10d as c10d
+            store = c10d._get_default_store()
+            if rank == 0:
+                store.set("hry_bench_done", "1")
+            else:
+                store.wait(["hry_bench_done"])
         except Exception:
             dist.barrier()
         dist.destroy_process_group()

@@ -1,7 +1,9 @@
-"""A short run of tests/tools/chain_stress.py inside the GPU suite: random noisy meshes (few bits, heavy noise, short rings, non-manifold,
-multi-component, lossless, reference-format streams, forced small slices of the pipelined decode) through the product against the
-oracle.  The script is the development tool that found the uploaded-half-edge hole of the pipelined decode; two seeds of it run here
-so that the driver's GPU run meets meshes no fixed case describes."""
+"""tests/tools/chain_stress.py and tests/tools/obj_stress.py inside the GPU suite: random noisy meshes (few bits, heavy noise, short
+rings, non-manifold, multi-component, lossless floats incl. magnitudes where float sums overflow or go denormal and coordinates that
+are 0 everywhere, reference-format streams, forced small slices of the pipelined decode, 1 - 8 wavefronts per chain) and random OBJ
+scenes (regions, shared records, corner lists, both profiles) through the product against the oracle.  chain_stress is the tool that
+found the uploaded-half-edge hole of the pipelined decode; sixteen seeds of it and eight of obj_stress run here so that the driver's
+GPU run meets meshes no fixed case describes.  Damaged sharded containers: tests/test_gpu_shard.py."""
 import os
 import subprocess
 import sys
@@ -9,16 +11,34 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WAVES = [None, "1", "2", "3", "4", "5", "6", "8"]
+
+
+def _run(tool, args, env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", tool), *args], capture_output=True, text=True, env=env, timeout=550)
+    return r
 
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("seed,waves", [(7, None), (8, "3")])
-def test_random_meshes_against_the_oracle(seed, waves):
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_random_meshes_against_the_oracle(seed):
     env = dict(os.environ)
-    for k in ("HRY_NO_PIPELINE", "HRY_PIPELINE_MIN_VERTICES", "HRY_PIPELINE_FACES", "HRY_PIPELINE_SLICE"):
+    for k in ("HRY_NO_PIPELINE", "HRY_PIPELINE_MIN_VERTICES", "HRY_PIPELINE_FACES", "HRY_PIPELINE_SLICE", "HRY_CHAIN_WAVES", "STRESS_LOSSLESS", "STRESS_BIG"):
         env.pop(k, None)
-    if waves:
-        env["HRY_CHAIN_WAVES"] = waves
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "chain_stress.py"), "24", str(seed)], capture_output=True, text=True, env=env, timeout=550)
+    if WAVES[seed % len(WAVES)]:
+        env["HRY_CHAIN_WAVES"] = WAVES[seed % len(WAVES)]
+    if seed % 4 == 0:
+        env["STRESS_LOSSLESS"] = "1"     # every mesh lossless: the float chain's speculation, its repairs and its exact fallback
+    if seed in (5, 11):
+        env["STRESS_BIG"] = "1"          # some meshes large enough for the pipelined decode with its production parameters
+    r = _run("chain_stress.py", ["40", str(100 + seed)], env)
     assert r.returncode == 0 and r.stdout.strip().endswith("all equal"), (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_random_obj_scenes_against_the_oracle(seed):
+    r = _run("obj_stress.py", ["20", str(200 + seed)], dict(os.environ))
+    assert r.returncode == 0 and r.stdout.strip().endswith("all ok"), (r.stdout + r.stderr)[-3000:]

@@ -35,7 +35,9 @@ for it in range(n_meshes):
     polys = ["tri", "quad", "mixed"][int(rng.integers(0, 3))]
     dims = [int(x) for x in rng.integers(0, 1 << 30, 4)]
     q = int(rng.integers(2, 17))
-    lossless = bool(rng.integers(0, 4) == 0)
+    lossless = bool(rng.integers(0, 4) == 0) or bool(os.environ.get("STRESS_LOSSLESS"))
+    scale_pow = float(rng.uniform(-43, 37)) if rng.integers(0, 3) == 0 else 0.0   # lossless: magnitudes where float sums overflow or go denormal
+    flat_axis = int(rng.integers(0, 6))                                            # lossless: 0 - 2: that coordinate is 0 everywhere (every prediction is 0)
     from_compat = bool(rng.integers(0, 4) == 0)     # decode the reference-format stream (host entropy decoder + device reconstruction)
     chunk = [0, 0, 1024, 4096, 20000][int(rng.integers(0, 5))]
     mode = int(rng.integers(0, 3))
@@ -58,6 +60,17 @@ for it in range(n_meshes):
     else:   # large enough for the pipelined decode with its production parameters (STRESS_BIG=1)
         base = mg.torus(r(0, 370, 520), r(1, 370, 520), polys="tri", seed=seed, sigma=sigma) if dims[2] & 1 else mg.grid(r(0, 370, 520), r(1, 370, 520), seed=seed, sigma=sigma)
         lossless, mode = False, 2
+    if lossless and kind != 5:
+        v = base.verts.copy()
+        with np.errstate(over="ignore", under="ignore"):
+            if scale_pow:
+                for k in "xyz":
+                    v[k] = (v[k].astype(np.float64) * 10.0 ** scale_pow).astype(np.float32)
+            if flat_axis < 3:
+                v["xyz"[flat_axis]][:] = np.float32(0.0) if seed & 1 else np.float32(-0.0)
+        v2 = np.nan_to_num(np.stack([v["x"], v["y"], v["z"]]), nan=0.0, posinf=3e38, neginf=-3e38)
+        v["x"], v["y"], v["z"] = v2[0], v2[1], v2[2]
+        base = mg.Mesh(v, base.degrees, base.indices, base.face_props)
     ply = base.to_ply()
     a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
     quant = [] if lossless else [(1, -1, q)] if kind != 5 else [(1, c, q) for c in range(6)]   # (the colours are bytes already)
