@@ -38,7 +38,9 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
                        const uint32_t *seg_start, uint32_t nseg, uint32_t *done);
 void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand);
 bool unpredict3_covers(const ListDesc &ld);
-void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t v_begin, uint32_t v_end, uint32_t *cand, uint8_t *ncand, void *crec);
+void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, uint32_t *cand, uint8_t *ncand, void *crec);
+size_t cand_table_words(uint32_t nvtx);
+void cand_table_reset(hipStream_t st, uint32_t *cand, uint32_t nvtx);
 void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,
                         const void *crec, const uint8_t *planes, const ListDesc &ld, uint8_t *rec);
 void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst);
@@ -65,9 +67,10 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
 	if (nvc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
 	const size_t ncand_bytes = ((size_t)nvc + 63) & ~(size_t)63;
-	cx.d_cscratch.ensure(std::max<size_t>((size_t)nvc * (8 * 3 * 4 + 16) + ncand_bytes + 64, 16));
+	const size_t cand_words = (cand_table_words(nvc) + 3) & ~(size_t)3;
+	cx.d_cscratch.ensure(std::max<size_t>(cand_words * 4 + (size_t)nvc * 16 + ncand_bytes + 64, 16));
 	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
-	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nvc * 24);
+	uint8_t *d_ncand = (uint8_t*)(d_cand + cand_words);
 	void *d_crec = d_ncand + ncand_bytes;   // 16-byte chain records (k_unpredict3), 16-byte aligned
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	if (ldv.nplanes) {
@@ -119,7 +122,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
 		cx.stage_put("ncand", d_ncand, nvc);
-		cx.stage_put("cand", d_cand, (size_t)nvc * 24 * 4);
+		cx.stage_put("cand", d_cand, (size_t)nvc * 6 * 4);
 	}
 }
 
@@ -189,9 +192,11 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	cx.d_foff.ensure(((size_t)nf + 1) * 4);
 	cx.d_order_v.ensure(std::max<size_t>((size_t)nv * 4, 16));
 	const size_t ncand_bytes = ((size_t)nv + 63) & ~(size_t)63;
-	cx.d_cscratch.ensure(std::max<size_t>((size_t)nv * (8 * 3 * 4 + 16) + ncand_bytes + 64, 16));
+	const size_t cand_words = (cand_table_words(nv) + 3) & ~(size_t)3;
+	cx.d_cscratch.ensure(std::max<size_t>(cand_words * 4 + (size_t)nv * 16 + ncand_bytes + 64, 16));
 	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
-	uint8_t *d_ncand = (uint8_t*)(d_cand + (size_t)nv * 24);
+	uint8_t *d_ncand = (uint8_t*)(d_cand + cand_words);
+	cand_table_reset(cx.stream2, d_cand, nv);
 	void *d_crec = d_ncand + ncand_bytes;
 	int ud = 0;
 	m->uniform_degree(ud);
@@ -304,7 +309,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 					// that is not -- made after the publication this slice rests on -- reads as a border, which is what it was then)
 					ConnView cvs = cv;
 					cvs.ne = he_up;
-					launch_slice_prepare(cx.stream2, cvs, cx.d_order_v.as<uint32_t>(), v_done, v_hi, d_cand, d_ncand, d_crec);
+					launch_slice_prepare(cx.stream2, cvs, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec);
 					HIP_OK(hipEventRecord(prepared, cx.stream2));
 					HIP_OK(hipStreamWaitEvent(cx.stream, prepared, 0));
 					// the residual codes of this slice: the groups of attribute streams that end inside it or before
@@ -397,7 +402,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
 		cx.stage_put("ncand", d_ncand, nv);
-		cx.stage_put("cand", d_cand, (size_t)nv * 24 * 4);
+		cx.stage_put("cand", d_cand, (size_t)nv * 6 * 4);
 	}
 }
 

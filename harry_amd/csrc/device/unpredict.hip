@@ -95,6 +95,22 @@ template <typename F> __device__ __forceinline__ void fan_ids(const TopoD &tp, u
 }
 
 constexpr int kCandMax = 8;
+// Candidate table of the decoder (k_candidates_ids): per vertex the ids of its FIRST TWO candidate triples (24 bytes -- a regular
+// mesh uses no more) and the candidate count; a vertex with three to eight candidates has its whole row (eight triples, 96
+// bytes) in an overflow area, its compact row holds the row's number there.  Round 2 wrote eight triples for every vertex: 96
+// bytes written and read back per vertex, ten times the algorithmic bytes of a decode.  Layout of the one allocation:
+// nvtx x 6 words | 16 words (word 0: rows handed out) | overflow rows of 24 words.
+constexpr int kCand2 = 6;
+__host__ __device__ __forceinline__ size_t cand_over_at(uint32_t nvtx_total) { return (size_t)nvtx_total * kCand2; }   // in words
+__device__ __forceinline__ const uint32_t *cand_full_row(const uint32_t *cand, uint32_t nvtx_total, uint32_t v)
+{
+	return cand + cand_over_at(nvtx_total) + 16 + (size_t)cand[(size_t)v * kCand2] * (kCandMax * 3);
+}
+// the row that holds candidate triples 0 .. n - 1 of vertex v
+__device__ __forceinline__ const uint32_t *cand_row(const uint32_t *cand, uint32_t nvtx_total, uint32_t v, uint32_t n)
+{
+	return n > 2 ? cand_full_row(cand, nvtx_total, v) : cand + (size_t)v * kCand2;
+}
 
 __global__ __launch_bounds__(256) void k_residuals_to_rec(const uint8_t *planes, uint32_t n, ListDesc ld, uint8_t *rec)
 {
@@ -393,10 +409,9 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 #pragma unroll
 		for (int k = 0; k < 6; ++k) nx_id[k] = 0;
 		if (v < nvtx) {
-			const uint32_t *src = cand + (size_t)v * (kCandMax * 3);
-			const uint4 a = *(const uint4*)src;
-			const uint2 b2 = *(const uint2*)(src + 4);
-			nx_id[0] = a.x; nx_id[1] = a.y; nx_id[2] = a.z; nx_id[3] = a.w; nx_id[4] = b2.x; nx_id[5] = b2.y;
+			const uint2 *src = (const uint2*)(cand + (size_t)v * kCand2);   // 24-byte rows: 8-byte aligned
+			const uint2 a = src[0], b2 = src[1], c2 = src[2];
+			nx_id[0] = a.x; nx_id[1] = a.y; nx_id[2] = b2.x; nx_id[3] = b2.y; nx_id[4] = c2.x; nx_id[5] = c2.y;
 			nx_nc = ncand[v];
 #pragma unroll
 			for (int b8 = 0; b8 < (int)sizeof(T); ++b8) nx_byte[b8] = planes[(size_t)(plane0 + b8) * nvtx_total + v];
@@ -425,7 +440,7 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 	if (tile + 1 < n_tiles) tile_request(tile + 1);   // in flight for the whole of this tile
 	if (__ballot(t_nc > 2 && t_nc != 0xff)) {
 		if (t_nc > 2 && t_nc != 0xff) {
-			const uint4 *src = (const uint4*)(cand + (size_t)(tile_base + lane) * (kCandMax * 3));
+			const uint4 *src = (const uint4*)cand_full_row(cand, nvtx_total, tile_base + lane);   // (96-byte rows behind a 64-byte header: 16-byte aligned)
 #pragma unroll
 			for (int k = 0; k < 6; ++k) { const uint4 r = src[k]; bigrow[lane * 24 + 4 * k] = r.x; bigrow[lane * 24 + 4 * k + 1] = r.y; bigrow[lane * 24 + 4 * k + 2] = r.z; bigrow[lane * 24 + 4 * k + 3] = r.w; }
 		}
@@ -975,7 +990,7 @@ __device__ __forceinline__ ChainRec make_chain_rec(const uint32_t *cand, const u
 	for (int j = 0; j < 6; ++j) r.slot[j] = 0;
 	r.pad = 0;
 	if (nc > 2) { r.flags = (uint16_t)(CR_BIG | (CR_POS_NONE << CR_POS_SHIFT)); return r; }
-	const uint32_t *row = cand + (size_t)v * (kCandMax * 3);
+	const uint32_t *row = cand + (size_t)v * kCand2;
 	uint32_t pos = CR_POS_NONE, need = 0, far = 0;
 	for (uint32_t j = 0; j < 3 * nc; ++j) {
 		const uint32_t id = row[j];
@@ -1211,9 +1226,9 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if (pf_pos < 64u) {
 				const uint32_t vb = tb + pf_pos;
 				pf_n = ncand[vb];
-				const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * (lane & 7);
-				pf_a = row[0]; pf_b = row[1]; pf_o = row[2];
 				if (pf_n != 0xffu && (uint32_t)(lane & 7) < pf_n) {
+					const uint32_t *row = cand_row(cand, nvtx_total, vb, pf_n) + 3 * (lane & 7);
+					pf_a = row[0]; pf_b = row[1]; pf_o = row[2];
 					auto is_far = [&](uint32_t id) { return id < vb && !(id >= ring_floor && vb - id <= kRing3Near); };
 					if (is_far(pf_a)) { pf_va = chain_far_value<T>(rec + (size_t)pf_a * stride + off, pf_a, seg_begin, sync, xs, comp); pf_far |= 1u; }
 					if (is_far(pf_b)) { pf_vb = chain_far_value<T>(rec + (size_t)pf_b * stride + off, pf_b, seg_begin, sync, xs, comp); pf_far |= 2u; }
@@ -1233,7 +1248,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			uint32_t sv0 = ring[slot0], sv1 = ring[slot1], sv2 = ring[slot2], sv3 = ring[slot3], sv4 = ring[slot4], sv5 = ring[slot5];
 			if (__ballot(sel && far)) {
 				if (sel && far) {   // some source is older than the ring or belongs to an earlier component: by vertex id
-					const uint32_t *row = cand + (size_t)v * (kCandMax * 3);
+					const uint32_t *row = cand + (size_t)v * kCand2;   // (at most two candidates here)
 					const uint32_t a0 = old_value(row[0], cur), a1 = old_value(row[1], cur), a2 = old_value(row[2], cur);
 					uint32_t a3 = a0, a4 = a1, a5 = a2;
 					if (nc == 2) { a3 = old_value(row[3], cur); a4 = old_value(row[4], cur); a5 = old_value(row[5], cur); }
@@ -1279,7 +1294,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 					const bool mine = (uint32_t)lane >> 3 == bj && (uint32_t)(lane & 7) < n0;
 					pk = mine ? med3_i32((int32_t)(a + b - o), 0, (int32_t)top) : 0u;
 				} else if ((uint32_t)lane < n0) {
-					const uint32_t *row = cand + (size_t)vb * (kCandMax * 3) + 3 * lane;
+					const uint32_t *row = cand_row(cand, nvtx_total, vb, n0) + 3 * lane;
 					pk = (uint32_t)cm::parallelogram<T>((T)old_value(row[0], vb), (T)old_value(row[1], vb), (T)old_value(row[2], vb), q);
 				}
 				// the candidates' sum: the lanes outside l0 .. l0 + 7 hold 0, three row shifts put the group's total on its last lane
@@ -1486,7 +1501,8 @@ bool unpredict2_applicable(const ListDesc &ld)
 }
 // candidate lists with plain vertex ids (k_unpredict2 resolves ring slots itself)
 // (virtual block (b % 8) * per + b / 8: one contiguous range of vertices per XCD and L2, see k_predict_vtx)
-__global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t v0, uint32_t n, uint32_t *cand, uint8_t *ncand, uint32_t blocks_per_xcd)
+__global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t v0, uint32_t n, uint32_t *cand, uint8_t *ncand, uint32_t blocks_per_xcd,
+                                                        uint32_t nvtx_total)
 {
 	uint32_t v = v0 + ((blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
 	if (v >= n) return;
@@ -1497,16 +1513,34 @@ __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint3
 		if (k < (uint32_t)kCandMax) { ids[3 * k] = a; ids[3 * k + 1] = b; ids[3 * k + 2] = o; }
 		++k;
 	});
-	uint32_t *out = cand + (size_t)v * (kCandMax * 3);
-	uint32_t m = k > (uint32_t)kCandMax ? 0 : k;
-	for (uint32_t j = 0; j < (uint32_t)(3 * kCandMax); ++j) out[j] = j < 3 * m ? ids[j] : 0u;
+	const uint32_t m = k > (uint32_t)kCandMax ? 0 : k;
+	for (uint32_t j = 3 * m; j < (uint32_t)(3 * kCandMax); ++j) ids[j] = 0u;
+	if (m > 2) {   // the whole row goes to the overflow area; the lanes of a wavefront that need one take their rows with ONE atomic
+		uint32_t *over = cand + cand_over_at(nvtx_total);
+		const uint64_t need = __ballot(true);
+		const uint32_t lane = threadIdx.x & 63u;
+		uint32_t base = 0;
+		if (lane == (uint32_t)__builtin_ctzll(need)) base = atomicAdd(over, (uint32_t)__builtin_popcountll(need));
+		base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(need));
+		const uint32_t slot = base + (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+		uint4 *row = (uint4*)(over + 16 + (size_t)slot * (kCandMax * 3));
+#pragma unroll
+		for (int j = 0; j < 6; ++j) row[j] = make_uint4(ids[4 * j], ids[4 * j + 1], ids[4 * j + 2], ids[4 * j + 3]);
+		ids[0] = slot;
+	}
+	uint2 *out = (uint2*)(cand + (size_t)v * kCand2);
+	out[0] = make_uint2(ids[0], ids[1]); out[1] = make_uint2(ids[2], ids[3]); out[2] = make_uint2(ids[4], ids[5]);
 	ncand[v] = k > (uint32_t)kCandMax ? 0xff : (uint8_t)k;
 }
+// words of the candidate table of nvtx vertices (compact rows, header, worst-case overflow)
+size_t cand_table_words(uint32_t nvtx) { return cand_over_at(nvtx) + 16 + (size_t)nvtx * (kCandMax * 3); }
+void cand_table_reset(hipStream_t st, uint32_t *cand, uint32_t nvtx) { (void)hipMemsetAsync(cand + cand_over_at(nvtx), 0, 64, st); }
 void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t *cand, uint8_t *ncand)
 {
 	if (!nvtx) return;
 	const uint32_t per = ((nvtx + 255) / 256 + 7) / 8;
-	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand, per);
+	cand_table_reset(st, cand, nvtx);
+	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand, per, nvtx);
 }
 // wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8; by default 5 for a large mesh (long rings: more
 // look-ahead for the preparation costs no heads), 4 otherwise
@@ -1530,12 +1564,12 @@ bool unpredict3_covers(const ListDesc &ld)
 	for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] != 6 && ld.stype[c] != 8) return false;
 	return ld.ncomp > 0;
 }
-void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t v_begin, uint32_t v_end, uint32_t *cand, uint8_t *ncand, void *crec)
+void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, uint32_t *cand, uint8_t *ncand, void *crec)
 {
 	if (v_end <= v_begin) return;
 	const uint32_t n = v_end - v_begin;
 	const uint32_t per = ((n + 255) / 256 + 7) / 8;
-	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, v_begin, v_end, cand, ncand, per);
+	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, v_begin, v_end, cand, ncand, per, nvtx);
 	hipLaunchKernelGGL(k_chain_records_range, dim3((n + 255) / 256), dim3(256), 0, st, (const uint32_t*)cand, (const uint8_t*)ncand, v_begin, v_end, chain_ring_floor(v_begin), (ChainRec*)crec);
 }
 void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,

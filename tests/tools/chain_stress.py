@@ -115,11 +115,11 @@ for it in range(n_meshes):
     if stages and any(b for b, _, _ in stages) and not all(b for b, _, _ in stages):
         bad = next(x for x in stages if x[0]); good = next(x for x in stages if not x[0])
         nc_b, nc_g = bad[1][:a.nv], good[1][:a.nv]
-        cd_b, cd_g = bad[2].reshape(-1, 24)[:a.nv], good[2].reshape(-1, 24)[:a.nv]
+        cd_b, cd_g = bad[2].reshape(-1, 6)[:a.nv], good[2].reshape(-1, 6)[:a.nv]
         dn = np.flatnonzero(nc_b != nc_g)
         print(f"    candidate counts differ at {len(dn)} vertices: {dn[:10].tolist()}; bad {nc_b[dn[:10]].tolist()} good {nc_g[dn[:10]].tolist()}")
         for v in dn[:4]:
-            print(f"      v {v}: bad rows {cd_b[v][:3 * max(1, min(8, int(nc_b[v])))].tolist()}  good rows {cd_g[v][:3 * max(1, min(8, int(nc_g[v])))].tolist()}")
+            print(f"      v {v}: bad rows {cd_b[v][:3 * max(1, min(2, int(nc_b[v])))].tolist()}  good rows {cd_g[v][:3 * max(1, min(2, int(nc_g[v])))].tolist()}")
     src = "compat" if from_compat else "chunk%d" % chunk
     print(f"{it:3d} kind {kind} {polys:5s} nv {a.nv:6d} q{0 if lossless else q:<2d} {src} sigma {sigma:.1e} seed {seed} mode {mode} faces {faces} slice {slice_}  {verdict}  ({time.time() - t0:.0f} s)", flush=True)
 print("all equal" if not failed else f"{failed} MISMATCHES")
