@@ -275,7 +275,9 @@ int hry_container_check(const uint8_t *hry, size_t n, int *complete)
 		const size_t hdr = read_hry_header(hry, n, m, minor, false);
 		if (minor != 3) { if (complete) *complete = 1; return; }
 		ShardedDirectory dir;
-		parse_sharded_directory(hry, n, hdr, m.nv, m.nf, m.declared_ne, dir, true);
+		std::vector<uint32_t> counts;
+		for (const AttrList &L : m.lists) counts.push_back(L.count);
+		parse_sharded_directory(hry, n, hdr, m.nv, m.nf, m.declared_ne, dir, true, m.general ? &counts : nullptr);
 		if (complete) *complete = dir.complete ? 1 : 0;
 	});
 }
@@ -356,6 +358,11 @@ size_t hry_mesh_runs(const hry_mesh *m, const uint32_t **runs)
 size_t hry_shard_elements(const hry_mesh *m, int which, const uint32_t **idx)
 {
 	if (!m || !idx) return 0;
+	if (which >= 16) {   // general bindings: input index in the whole mesh of every record of list which - 16
+		if ((size_t)(which - 16) >= m->m.shard.record_of.size()) return 0;
+		*idx = m->m.shard.record_of[which - 16].data();
+		return m->m.shard.record_of[which - 16].size();
+	}
 	const std::vector<uint32_t> &v = which == 2 ? m->m.shard.seeds : which ? m->m.shard.vertex_of : m->m.shard.face_of;
 	*idx = v.data();
 	return v.size();

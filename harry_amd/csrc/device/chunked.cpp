@@ -65,7 +65,6 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	HIP_OK(hipSetDevice(cx.device));
 	auto t_all = Clock::now();
 	cx.timing = hry_timing{};
-	if (m.general && m.shard.active()) throw Error(HRY_E_UNSUPPORTED, "only the PLY layout (one record per element) shards");
 	check_codable(m);
 	if (m.general) check_general(m);
 	uint32_t CH = chunk_syms > 0 ? std::min<uint32_t>((uint32_t)chunk_syms, kMaxChunk) : (uint32_t)kDefaultChunk;
@@ -94,8 +93,14 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 		seg_begin = out.size();
 		put32((uint32_t)m.shard.runs.size());
 		static_assert(sizeof(ShardRun) == 24, "runs are written as they lie in memory");
-		const uint8_t *rp = (const uint8_t*)m.shard.runs.data();
-		out.insert(out.end(), rp, rp + sizeof(ShardRun) * m.shard.runs.size());
+		// general bindings: every run is followed by its place in the record numbering of every list (first record, records)
+		const size_t nl2 = m.general ? 2 * m.lists.size() : 0;
+		if (m.shard.run_records.size() != nl2 * m.shard.runs.size()) throw Error(HRY_E_ARG, "shard without its record ranges");
+		for (size_t j = 0; j < m.shard.runs.size(); ++j) {
+			const uint8_t *rp = (const uint8_t*)&m.shard.runs[j];
+			out.insert(out.end(), rp, rp + sizeof(ShardRun));
+			if (nl2) { const uint8_t *qp = (const uint8_t*)(m.shard.run_records.data() + j * nl2); out.insert(out.end(), qp, qp + 4 * nl2); }
+		}
 	}
 	auto t_walk = Clock::now();
 	WalkResult w;

@@ -52,7 +52,6 @@ bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector
 void check_general(const Mesh &m)
 {
 	const Bindings &b = m.bind;
-	if (m.shard.active()) throw Error(HRY_E_UNSUPPORTED, "a shard holds the PLY layout only");
 	if (m.lists.size() > (size_t)kMaxLists) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
 	if (b.nregs_face() > 128 || b.nregs_vtx() > 128) throw Error(HRY_E_UNSUPPORTED, "more than 128 regions: the reference seeds its region models out of bounds (model.h:49-55)");
 	if (b.nb_face > 255 || b.nb_vtx > 255 || b.nb_corner > 255) throw Error(HRY_E_UNSUPPORTED, "more than 255 lists bound to one region");
@@ -70,6 +69,15 @@ void check_general(const Mesh &m)
 	for (int r = 0; r < b.nregs_vtx(); ++r) for (int a = 0; a < b.nvtxlists(r); ++a) bound(b.vtxlist(r, a), 1);
 	for (uint32_t f = 0; f < m.nf; ++f) if (b.face_reg[f] >= b.nregs_face()) throw Error(HRY_E_ARG, "face region out of range");
 	for (uint32_t v = 0; v < m.nv; ++v) if (b.vtx_reg[v] >= b.nregs_vtx()) throw Error(HRY_E_ARG, "vertex region out of range");
+	// every record an element names exists (a decoded header may announce elements and an empty list)
+	auto holds = [&](int l, uint32_t rec) { if (rec >= m.lists[l].count || (size_t)(rec + 1) * m.lists[l].stride() > m.lists[l].data.size()) throw Error(HRY_E_ARG, "an element names a record its list does not hold"); };
+	for (uint32_t f = 0; f < m.nf; ++f) {
+		const int r = b.face_reg[f];
+		for (int a = 0; a < b.nfacelists(r); ++a) holds(b.facelist(r, a), b.face_attr[(size_t)f * b.nb_face + a]);
+		for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h)
+			for (int a = 0; a < b.ncornerlists(r); ++a) holds(b.cornerlist(r, a), b.corner_attr[(size_t)h * b.nb_corner + a]);
+	}
+	for (uint32_t v = 0; v < m.nv; ++v) { const int r = b.vtx_reg[v]; for (int a = 0; a < b.nvtxlists(r); ++a) holds(b.vtxlist(r, a), b.vtx_attr[(size_t)v * b.nb_vtx + a]); }
 }
 
 // connectivity + every list + the binding tables -> HBM

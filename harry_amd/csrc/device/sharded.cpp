@@ -215,11 +215,14 @@ Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n,
 	hry_shard_timing st{};
 	check_contexts(cxs, n_ctx);
 	if (shard_count < 0 || shard_index < 0 || (shard_count > 0 && shard_index >= shard_count)) throw Error(HRY_E_ARG, "invalid shard selection");
-	if (g->general) throw Error(HRY_E_FORMAT, "sharded containers hold the PLY layout only");
 	const uint32_t gnv = g->nv, gnf = g->nf, gne = g->declared_ne;
 	auto t0 = Clock::now();
 	ShardedDirectory dir;
-	parse_sharded_directory(p, n, hdr, gnv, gnf, gne, dir, true);
+	const bool general = g->general;
+	const size_t nl = g->lists.size();
+	std::vector<uint32_t> list_counts;
+	for (const AttrList &L : g->lists) list_counts.push_back(L.count);
+	parse_sharded_directory(p, n, hdr, gnv, gnf, gne, dir, true, general ? &list_counts : nullptr);
 	const uint32_t nseg = (uint32_t)dir.segments.size();
 	std::vector<uint32_t> mine;
 	for (uint32_t si = 0; si < nseg; ++si) if (shard_count <= 1 || (int)(si % (uint32_t)shard_count) == shard_index) mine.push_back(si);
@@ -233,9 +236,18 @@ Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n,
 	// by the filler pass after it.
 	g->face_off.resize((size_t)gnf + 1);
 	g->org.resize(gne); g->twin.resize(gne);
-	for (int l = 0; l < 2; ++l) g->lists[l].data.resize((size_t)g->lists[l].count * g->lists[l].stride());
-	g->covered.clear();
-	const size_t vstride = (size_t)g->lists[1].stride(), fstride = (size_t)g->lists[0].stride();
+	for (size_t l = 0; l < nl; ++l) {
+		AttrList &L = g->lists[l];
+		if (general) L.data.assign((size_t)L.count * L.stride(), 0);   // (OBJ-sized; a record no run creates stays zero)
+		else L.data.resize((size_t)L.count * L.stride());
+	}
+	if (general) {   // element -> region and element x slot -> record, for the whole mesh (filler: region 0, record 0)
+		Bindings &b = g->bind;
+		b.face_reg.assign(gnf, 0); b.vtx_reg.assign(gnv, 0);
+		b.face_attr.assign((size_t)gnf * b.nb_face, 0); b.vtx_attr.assign((size_t)gnv * b.nb_vtx, 0); b.corner_attr.assign((size_t)gne * b.nb_corner, 0);
+	}
+	g->covered.clear(); g->covered_records.clear();
+	const size_t vstride = general ? 0 : (size_t)g->lists[1].stride(), fstride = general ? 0 : (size_t)g->lists[0].stride();
 
 	std::vector<double> w_decode(n_ctx, 0.0), w_place(n_ctx, 0.0);
 	t0 = Clock::now();
@@ -256,13 +268,24 @@ Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n,
 			std::unique_ptr<Mesh> lm(new Mesh());
 			lm->nv = lnv; lm->nf = lnf; lm->declared_ne = lne;
 			lm->have_degree = g->have_degree;
-			for (int l = 0; l < 2; ++l) {
+			if (general) {   // the regions of the whole mesh; every list with the records this segment creates
+				lm->general = true;
+				lm->lists.assign(nl, AttrList());
+				Bindings &lb = lm->bind;
+				const Bindings &b = g->bind;
+				lb.reg_facelist = b.reg_facelist; lb.reg_vtxlist = b.reg_vtxlist; lb.reg_cornerlist = b.reg_cornerlist;
+				lb.off_facelist = b.off_facelist; lb.off_vtxlist = b.off_vtxlist; lb.off_cornerlist = b.off_cornerlist;
+				lb.nb_face = b.nb_face; lb.nb_vtx = b.nb_vtx; lb.nb_corner = b.nb_corner;
+				lb.face_reg.assign(lnf, 0); lb.vtx_reg.assign(lnv, 0);   // (what the header reader allocates for an unsharded file)
+				lb.face_attr.assign((size_t)lnf * lb.nb_face, 0); lb.vtx_attr.assign((size_t)lnv * lb.nb_vtx, 0);
+			}
+			for (size_t l = 0; l < nl; ++l) {
 				const AttrList &L = g->lists[l];
 				AttrList &D = lm->lists[l];
 				D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
 				D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
 				D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = true;
-				D.count = l == 0 ? lm->nf : lm->nv;
+				D.count = general ? sg.nrec[l] : l == 0 ? lm->nf : lm->nv;
 				D.data.assign((size_t)D.count * D.stride(), 0);
 			}
 			std::unique_ptr<Mesh> dm(decode_chunked(cx, sp + sg.body_at, sg.bytes - sg.body_at, 0, std::move(lm)));
@@ -323,6 +346,52 @@ Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n,
 			run_tasks(0, n_vf_tasks);               // the vertex map first: half-edges of one run may name vertices of another
 			run_tasks(n_vf_tasks, tasks.size());
 			if (bad.load()) throw Error(HRY_E_FORMAT, "corrupt segment (runs do not match the connectivity)");
+			if (general) {
+				// the records of every list into the numbering of the whole (creation order over all components: run j's records
+				// of list l sit at its first_record), then every element's region and slots
+				const Bindings &db = dm->bind;
+				Bindings &b = g->bind;
+				if (db.face_reg.size() != lnf || db.vtx_reg.size() != lnv || db.face_attr.size() != (size_t)lnf * b.nb_face || db.vtx_attr.size() != (size_t)lnv * b.nb_vtx ||
+				    db.corner_attr.size() != (size_t)lne * b.nb_corner)
+					throw Error(HRY_E_FORMAT, "corrupt segment (binding tables)");
+				std::vector<std::vector<uint32_t>> rl2g(nl);
+				for (size_t l = 0; l < nl; ++l) {
+					const AttrList &S = dm->lists[l];
+					AttrList &D = g->lists[l];
+					if (S.count != sg.nrec[l]) throw Error(HRY_E_FORMAT, "corrupt segment (records of a list do not match its runs)");
+					rl2g[l].resize(S.count);
+					const size_t st = (size_t)D.stride();
+					uint32_t at = 0;
+					for (uint32_t j = 0; j < nr; ++j) {
+						const uint32_t first = sg.run_records[(size_t)j * 2 * nl + 2 * l], cnt = sg.run_records[(size_t)j * 2 * nl + 2 * l + 1];
+						for (uint32_t i = 0; i < cnt; ++i) rl2g[l][at + i] = first + i;
+						if (st && cnt) memcpy(D.data.data() + (size_t)first * st, S.data.data() + (size_t)at * st, (size_t)cnt * st);
+						at += cnt;
+					}
+				}
+				auto rec = [&](int l, uint32_t r) -> uint32_t { if ((size_t)l >= nl || r >= rl2g[l].size()) throw Error(HRY_E_FORMAT, "corrupt segment (record index)"); return rl2g[l][r]; };
+				for (uint32_t j = 0; j < nr; ++j) {
+					const ShardRun &r = runs[j];
+					for (uint32_t i = 0; i < r.n_vertices; ++i) {
+						const uint32_t lv = cv[j] + i, gv2 = r.first_vertex + i;
+						const int reg = db.vtx_reg[lv];
+						if (reg >= b.nregs_vtx()) throw Error(HRY_E_FORMAT, "corrupt segment (vertex region)");
+						b.vtx_reg[gv2] = (uint16_t)reg;
+						for (int a = 0; a < b.nvtxlists(reg); ++a) b.vtx_attr[(size_t)gv2 * b.nb_vtx + a] = rec(b.vtxlist(reg, a), db.vtx_attr[(size_t)lv * b.nb_vtx + a]);
+					}
+					for (uint32_t i = 0; i < r.n_faces; ++i) {
+						const uint32_t lf = cf[j] + i, gf = r.first_face + i;
+						const int reg = db.face_reg[lf];
+						if (reg >= b.nregs_face()) throw Error(HRY_E_FORMAT, "corrupt segment (face region)");
+						b.face_reg[gf] = (uint16_t)reg;
+						for (int a = 0; a < b.nfacelists(reg); ++a) b.face_attr[(size_t)gf * b.nb_face + a] = rec(b.facelist(reg, a), db.face_attr[(size_t)lf * b.nb_face + a]);
+						const uint32_t shift = r.first_halfedge - ch[j];
+						for (uint32_t h = dm->face_off[lf]; h < dm->face_off[(size_t)lf + 1]; ++h)
+							for (int a = 0; a < b.ncornerlists(reg); ++a)
+								b.corner_attr[(size_t)(h + shift) * b.nb_corner + a] = rec(b.cornerlist(reg, a), db.corner_attr[(size_t)h * b.nb_corner + a]);
+					}
+				}
+			}
 			w_place[w] += ms_since(t);
 		}
 		cx.timing = acc;
@@ -332,7 +401,10 @@ Mesh *decode_sharded(Context *const *cxs, int n_ctx, const uint8_t *p, size_t n,
 	// the offsets stay monotone and inside the arrays), half-edges that are borders at vertex 0, zero records.  In a complete decode
 	// that is exactly the vertices no face references (the reference never codes them: zero records).
 	t0 = Clock::now();
-	for (uint32_t si : mine) g->covered.insert(g->covered.end(), dir.segments[si].runs.begin(), dir.segments[si].runs.end());
+	for (uint32_t si : mine) {
+		g->covered.insert(g->covered.end(), dir.segments[si].runs.begin(), dir.segments[si].runs.end());
+		g->covered_records.insert(g->covered_records.end(), dir.segments[si].run_records.begin(), dir.segments[si].run_records.end());
+	}
 	std::vector<ShardRun> byf;
 	for (const ShardRun &r : g->covered) if (r.n_faces) byf.push_back(r);
 	std::sort(byf.begin(), byf.end(), [](const ShardRun &a, const ShardRun &b) { return a.first_face < b.first_face; });

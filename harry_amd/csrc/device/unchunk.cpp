@@ -135,7 +135,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 // When the replay ends only the last slice is left.  Results are those of the sequential pipeline: the candidates of a
 // complete vertex are final, and the chain is evaluated in the same order with the same arithmetic.
 // ---------------------------------------------------------------------------------------------------------
-struct SliceClock { hipEvent_t a, b; };
+struct SliceClock { hipEvent_t a, b, p0, p1; };   // chain on the main stream; candidates + chain records on the second one
 // host -> device through the context's pinned staging buffer (one stream; flush() = everything has left the buffer)
 struct Stager {
 	Context &cx;
@@ -309,13 +309,15 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 					// that is not -- made after the publication this slice rests on -- reads as a border, which is what it was then)
 					ConnView cvs = cv;
 					cvs.ne = he_up;
+					SliceClock ck;
+					HIP_OK(hipEventCreate(&ck.a)); HIP_OK(hipEventCreate(&ck.b)); HIP_OK(hipEventCreate(&ck.p0)); HIP_OK(hipEventCreate(&ck.p1));
+					HIP_OK(hipEventRecord(ck.p0, cx.stream2));
 					launch_slice_prepare(cx.stream2, cvs, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec);
+					HIP_OK(hipEventRecord(ck.p1, cx.stream2));
 					HIP_OK(hipEventRecord(prepared, cx.stream2));
 					HIP_OK(hipStreamWaitEvent(cx.stream, prepared, 0));
 					// the residual codes of this slice: the groups of attribute streams that end inside it or before
 					while (attr_waited < Context::kAttrGroups && (attr_waited == 0 || attr_upto[attr_waited - 1] < v_hi)) HIP_OK(hipStreamWaitEvent(cx.stream, cx.attr_ev[attr_waited++], 0));
-					SliceClock ck;
-					HIP_OK(hipEventCreate(&ck.a)); HIP_OK(hipEventCreate(&ck.b));
 					HIP_OK(hipEventRecord(ck.a, cx.stream));
 					launch_slice_chain(cx.stream, cvs, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>());
 					HIP_OK(hipEventRecord(ck.b, cx.stream));
@@ -378,7 +380,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	HRY_MARK(g_t0, "replay done");
 	if (trace_on()) fprintf(stderr, "[hry] %u publications, %.3f ms inside publish()\n", live.n_publish, live.t_publish_ms);
 	consumer.join();
-	auto drop_clocks = [&] { for (auto &c : clocks) { (void)hipEventDestroy(c.a); (void)hipEventDestroy(c.b); } };
+	auto drop_clocks = [&] { for (auto &c : clocks) { (void)hipEventDestroy(c.a); (void)hipEventDestroy(c.b); (void)hipEventDestroy(c.p0); (void)hipEventDestroy(c.p1); } };
 	if (replay_error || consumer_error) {
 		(void)hipStreamSynchronize(cx.stream); (void)hipStreamSynchronize(cx.stream2);
 		drop_clocks();
@@ -395,10 +397,16 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t>
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	HRY_MARK(g_t0, "records on the host");
 	if (uint32_t tf = chain_timeout_flags(cx.stream)) { drop_clocks(); throw Error(HRY_E_INTERNAL, "reconstruction chain: hand-over between wavefronts timed out (flags " + std::to_string(tf) + ")"); }
-	double chain_ms = 0;
-	for (auto &c : clocks) { float t = 0; if (hipEventElapsedTime(&t, c.a, c.b) == hipSuccess) chain_ms += t; }
+	double chain_ms = 0, prep_ms = 0;
+	(void)hipStreamSynchronize(cx.stream2);
+	for (auto &c : clocks) {
+		float t = 0;
+		if (hipEventElapsedTime(&t, c.a, c.b) == hipSuccess) chain_ms += t;
+		if (hipEventElapsedTime(&t, c.p0, c.p1) == hipSuccess) prep_ms += t;
+	}
 	drop_clocks();
 	cx.timing.k_chain_ms = chain_ms;
+	cx.timing.k_predict_ms = prep_ms + chain_ms;   // candidates, chain records (second stream, beside the chain of the slice before) + the chain
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
 		cx.stage_put("ncand", d_ncand, nv);
@@ -650,7 +658,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		cx.stage_put_host("dec_nsym", nsym.data(), nsym.size() * 4);
 	}
 	cx.timing.k_entropy_ms = cx.elapsed(1, 2) + cx.elapsed(5, 6);
-	cx.timing.k_predict_ms = pipelined ? cx.timing.k_chain_ms : cx.elapsed(3, 4);
+	if (!pipelined) cx.timing.k_predict_ms = cx.elapsed(3, 4);
 	cx.timing.device_ms = cx.timing.k_entropy_ms + cx.timing.k_predict_ms;
 	cx.timing.n_symbols = total_syms;
 	cx.timing.payload_bytes = payload_bytes;

@@ -1507,29 +1507,40 @@ __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint3
 	uint32_t v = v0 + ((blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
 	if (v >= n) return;
 	TopoD tp{ cv };
-	uint32_t k = 0;
-	uint32_t ids[kCandMax * 3];
+	// The first two triples stay in registers, the third to eighth go to LDS (one column per thread: no bank conflicts, nothing
+	// behind it).  A private array indexed by the running candidate count lives in scratch memory: round 2's version of this kernel
+	// wrote 122 bytes per vertex to HBM, 96 of them its own scratch.
+	__shared__ uint32_t s_more[(kCandMax - 2) * 3 * 256];
+	uint32_t k = 0, a0 = 0, b0 = 0, o0 = 0, a1 = 0, b1 = 0, o1 = 0;
 	fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-		if (k < (uint32_t)kCandMax) { ids[3 * k] = a; ids[3 * k + 1] = b; ids[3 * k + 2] = o; }
+		if (k == 0) { a0 = a; b0 = b; o0 = o; }
+		else if (k == 1) { a1 = a; b1 = b; o1 = o; }
+		else if (k < (uint32_t)kCandMax) { uint32_t *p = s_more + (size_t)(k - 2) * 3 * 256 + threadIdx.x; p[0] = a; p[256] = b; p[512] = o; }
 		++k;
 	});
 	const uint32_t m = k > (uint32_t)kCandMax ? 0 : k;
-	for (uint32_t j = 3 * m; j < (uint32_t)(3 * kCandMax); ++j) ids[j] = 0u;
-	if (m > 2) {   // the whole row goes to the overflow area; the lanes of a wavefront that need one take their rows with ONE atomic
+	if (m < 2) { a1 = b1 = o1 = 0; }
+	if (m < 1) { a0 = b0 = o0 = 0; }
+	const bool wide = m > 2;
+	const uint64_t need = __ballot(wide);
+	if (wide) {   // the whole row goes to the overflow area; the lanes of a wavefront that need one take their rows with ONE atomic
 		uint32_t *over = cand + cand_over_at(nvtx_total);
-		const uint64_t need = __ballot(true);
 		const uint32_t lane = threadIdx.x & 63u;
 		uint32_t base = 0;
 		if (lane == (uint32_t)__builtin_ctzll(need)) base = atomicAdd(over, (uint32_t)__builtin_popcountll(need));
 		base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(need));
 		const uint32_t slot = base + (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
-		uint4 *row = (uint4*)(over + 16 + (size_t)slot * (kCandMax * 3));
-#pragma unroll
-		for (int j = 0; j < 6; ++j) row[j] = make_uint4(ids[4 * j], ids[4 * j + 1], ids[4 * j + 2], ids[4 * j + 3]);
-		ids[0] = slot;
+		uint32_t *row = over + 16 + (size_t)slot * (kCandMax * 3);
+		row[0] = a0; row[1] = b0; row[2] = o0; row[3] = a1; row[4] = b1; row[5] = o1;
+		for (uint32_t j = 2; j < (uint32_t)kCandMax; ++j) {
+			const uint32_t *p = s_more + (size_t)(j - 2) * 3 * 256 + threadIdx.x;
+			const bool have = j < m;
+			row[3 * j] = have ? p[0] : 0u; row[3 * j + 1] = have ? p[256] : 0u; row[3 * j + 2] = have ? p[512] : 0u;
+		}
+		a0 = slot;
 	}
 	uint2 *out = (uint2*)(cand + (size_t)v * kCand2);
-	out[0] = make_uint2(ids[0], ids[1]); out[1] = make_uint2(ids[2], ids[3]); out[2] = make_uint2(ids[4], ids[5]);
+	out[0] = make_uint2(a0, b0); out[1] = make_uint2(o0, a1); out[2] = make_uint2(b1, o1);
 	ncand[v] = k > (uint32_t)kCandMax ? 0xff : (uint8_t)k;
 }
 // words of the candidate table of nvtx vertices (compact rows, header, worst-case overflow)

@@ -52,7 +52,7 @@ void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out)
 		const AttrList &L = m.lists[l];
 		if (!named[l]) continue;
 		if (!L.have_bounds && L.ncomp() > 0) throw Error(HRY_E_INTERNAL, "attribute bounds missing");
-		w.v<uint32_t>(sh ? (l == 0 ? m.shard.g_nf : m.shard.g_nv) : L.count);
+		w.v<uint32_t>(!sh ? L.count : m.general ? m.shard.g_list_count.at(l) : l == 0 ? m.shard.g_nf : m.shard.g_nv);
 		w.v<uint16_t>((uint16_t)L.ncomp());
 		for (int c = 0; c < L.ncomp(); ++c) { w.v<uint8_t>(L.type[c]); w.v<uint8_t>(L.quant[c]); }
 		w.v<uint16_t>((uint16_t)L.interp_off.size());
@@ -111,7 +111,6 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 	const bool ply_layout = nrf == 1 && nrv == 1 && b.nfacelists(0) == 1 && b.ncornerlists(0) == 0 && b.nvtxlists(0) == 1 &&
 	                        b.facelist(0, 0) == 0 && b.vtxlist(0, 0) == 1;
 	m.general = !ply_layout;
-	if (m.general && ver_minor == 3) throw Error(HRY_E_UNSUPPORTED, "the sharded container holds the PLY layout only (one face list, one vertex list)");
 	m.lists.assign(ply_layout ? 2 : target.size(), AttrList());
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		AttrList &L = m.lists[l];
@@ -149,7 +148,6 @@ size_t read_hry_header(const uint8_t *p, size_t n, Mesh &m, int &ver_minor, bool
 		L.have_bounds = true;
 	}
 	if (!m.general && (m.lists[0].count != m.nf || m.lists[1].count != m.nv)) m.general = true;   // shared records: the general decoder
-	if (m.general && ver_minor == 3) throw Error(HRY_E_UNSUPPORTED, "the sharded container holds the PLY layout only (one record per element)");
 	if (m.general) {
 		m.bind = std::move(b);
 		if (alloc_records) {

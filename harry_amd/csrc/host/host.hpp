@@ -132,6 +132,11 @@ struct ShardPlan {
 	std::vector<BigVec<uint32_t>> shard_faces, shard_vertices;   // per shard: its faces / vertices, ascending input index
 	std::vector<uint32_t> shard_ne;               // per shard: half-edges
 	int udeg = 0;                                 // the one polygon degree of the mesh, 0 = mixed (then A.eface holds the face of every half-edge)
+	// general bindings: every list's records belong to the component that first names them (coding order); components that name
+	// a common record are tied into one group like components that share a vertex
+	std::vector<BigVec<uint32_t>> record_owner, local_record;       // per list, per record: coding rank of its component (0xffffffff: unnamed), index in its shard
+	std::vector<std::vector<BigVec<uint32_t>>> shard_records;       // per list, per shard: its records, ascending input index
+	std::vector<std::vector<uint32_t>> base_rec, fresh_rec;         // per list, per coding rank (+ end for the bases): place in the decoder's record numbering
 };
 void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan);
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard);
@@ -139,11 +144,20 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard);
 void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, ByteSink &out);
 // the directory of a sharded container, validated against the header's sizes (throws HRY_E_FORMAT on damage)
 struct ShardedDirectory {
-	struct Segment { size_t offset = 0, bytes = 0, body_at = 0; std::vector<ShardRun> runs; uint32_t nv = 0, nf = 0, ne = 0; };   // body_at: v0.2 body inside the segment
+	struct Segment {
+		size_t offset = 0, bytes = 0, body_at = 0;   // body_at: v0.2 body inside the segment
+		std::vector<ShardRun> runs;
+		std::vector<uint32_t> run_records;           // general bindings: 2 x lists words per run (first record, records), else empty
+		std::vector<uint32_t> nrec;                  // ... records of every list in the segment
+		uint32_t nv = 0, nf = 0, ne = 0;
+	};
 	std::vector<Segment> segments;
 	bool complete = false;   // every face and half-edge of the mesh lies in some run
 };
-void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gnv, uint32_t gnf, uint32_t gne, ShardedDirectory &dir, bool allow_gaps = false);
+// list_counts: the record counts of the header's lists when the mesh has general bindings (then every run carries its record
+// ranges), nullptr for the PLY layout
+void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gnv, uint32_t gnf, uint32_t gne, ShardedDirectory &dir, bool allow_gaps = false,
+                             const std::vector<uint32_t> *list_counts = nullptr);
 // bounds of list l of the whole mesh from device-computed bounds of its shards (the scan's own tie rule, see shard.cpp)
 void combine_shard_bounds(const std::vector<const Mesh*> &shards, int l, std::vector<uint8_t> &bmin, std::vector<uint8_t> &bmax);
 // a worker thread of the in-process multi-GPU executor limits the helper threads of the host phases it starts (0: no limit)

@@ -108,6 +108,12 @@ struct ShardInfo {
 	                                         // reference's start-face rule, writer.cc:40-46, which depends on the full face count)
 	std::vector<ShardRun> runs;              // in coding order; the shard's own numbering lays them out back to back
 	std::vector<uint32_t> vertex_of, face_of; // input index in the full mesh of every vertex / face of the shard (bounds ties, tests)
+	// general bindings (regions, shared records, corner lists): the records of every list are numbered by the decoder in the order
+	// they are first coded (attrcode.h:443-531: cur_idx), across all components -- so every run also has its place in that
+	// numbering, per list: run_records[run * 2 * nlists + 2 * l] = first record, [... + 1] = records the run creates.
+	std::vector<uint32_t> g_list_count;      // records of every list of the full mesh (the merged container's header)
+	std::vector<uint32_t> run_records;
+	std::vector<std::vector<uint32_t>> record_of;   // per list: input index in the full mesh of every record of the shard (bounds ties)
 	bool active() const { return g_nf != 0; }
 };
 
@@ -192,6 +198,7 @@ struct Mesh {
 	uint32_t declared_ne = 0;            // half-edge count announced by a .hry header (the connectivity follows later)
 	ShardInfo shard;                     // set by shard_extract: this mesh is a shard of a larger one
 	std::vector<ShardRun> covered;       // set by the decoder of a sharded container: the runs of the whole numbering that were decoded
+	std::vector<uint32_t> covered_records;   // ... general bindings: their record ranges (2 x lists words per run, as ShardInfo::run_records)
 	bool partial = false;                // a share of a sharded container's segments (shard_count > 1): everything outside `covered` is
 	                                     // filler (empty faces, zero records) -- readable through the accessors, refused by every consumer
 

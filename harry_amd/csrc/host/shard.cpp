@@ -37,7 +37,6 @@ struct Ranges {
 
 void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 {
-	if (m.general) throw Error(HRY_E_UNSUPPORTED, "only the PLY layout (one record per element) shards");
 	if (n_shards == 0) throw Error(HRY_E_ARG, "need at least one shard");
 	if (m.nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
 	if (m.shard.active()) throw Error(HRY_E_ARG, "a shard cannot be sharded again");
@@ -56,6 +55,52 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 		plan.base_v[k + 1] = plan.base_v[k] + A.fresh[k];
 		plan.base_f[k + 1] = plan.base_f[k] + A.n_faces[k];
 		plan.base_he[k + 1] = plan.base_he[k] + A.n_halfedges[k];
+	}
+	// ---- general bindings (regions, shared records, corner lists; structs/attr.h:101-189).  A record of a list belongs to the
+	// component that names it first in coding order -- the decoder numbers the records of a list in the order they are first
+	// coded (attrcode.h:443-531), so that component "introduces" it like a vertex -- and components that name a common record (two
+	// parts of a scene using the same "vn" line) are tied into one group: the later one refers to it by its distance in the
+	// creation order (GlobalHistory, attrcode.h:23-53), which only exists inside one stream.  OBJ-sized inputs: plain loops.
+	if (m.general) {
+		const Bindings &b = m.bind;
+		const size_t nl = m.lists.size();
+		if (b.face_reg.size() != m.nf || b.vtx_reg.size() != m.nv || b.face_attr.size() != (size_t)m.nf * b.nb_face ||
+		    b.vtx_attr.size() != (size_t)m.nv * b.nb_vtx || b.corner_attr.size() != (size_t)m.ne() * b.nb_corner)
+			throw Error(HRY_E_ARG, "binding tables do not match the element counts");
+		plan.record_owner.resize(nl);
+		for (size_t l = 0; l < nl; ++l) plan.record_owner[l].assign(m.lists[l].count, NONE32);
+		std::vector<uint32_t> parent(A.group);   // union-find over coding ranks; a root is the smallest rank of its set (as in the analysis)
+		auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+		auto unite = [&](uint32_t x, uint32_t y) { x = find(x); y = find(y); if (x == y) return; if (x > y) std::swap(x, y); parent[y] = x; };
+		auto each_reference = [&](auto &&fn) {   // fn(list, record, coding rank of the naming component)
+			for (uint32_t f = 0; f < m.nf; ++f) {
+				const uint32_t k = A.rank_of[A.comp[f]];
+				const int r = b.face_reg[f];
+				if (r >= b.nregs_face()) throw Error(HRY_E_ARG, "face region out of range");
+				for (int a = 0; a < b.nfacelists(r); ++a) fn(b.facelist(r, a), b.face_attr[(size_t)f * b.nb_face + a], k);
+				for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h)
+					for (int a = 0; a < b.ncornerlists(r); ++a) fn(b.cornerlist(r, a), b.corner_attr[(size_t)h * b.nb_corner + a], k);
+			}
+			for (uint32_t v = 0; v < m.nv; ++v) {
+				const uint32_t k = A.vertex_owner[v];
+				if (k == NONE32) continue;
+				const int r = b.vtx_reg[v];
+				if (r >= b.nregs_vtx()) throw Error(HRY_E_ARG, "vertex region out of range");
+				for (int a = 0; a < b.nvtxlists(r); ++a) fn(b.vtxlist(r, a), b.vtx_attr[(size_t)v * b.nb_vtx + a], k);
+			}
+		};
+		each_reference([&](int l, uint32_t rec, uint32_t k) {
+			if ((size_t)l >= nl || rec >= m.lists[l].count) throw Error(HRY_E_ARG, "an element names a record its list does not hold");
+			uint32_t &o = plan.record_owner[l][rec];
+			o = std::min(o, k);
+		});
+		each_reference([&](int l, uint32_t rec, uint32_t k) { const uint32_t o = plan.record_owner[l][rec]; if (o != k) unite(o, k); });
+		for (uint32_t k = 0; k < nc; ++k) A.group[k] = find(k);
+		plan.fresh_rec.assign(nl, std::vector<uint32_t>(nc, 0)); plan.base_rec.assign(nl, std::vector<uint32_t>(nc + 1, 0));
+		for (size_t l = 0; l < nl; ++l) {
+			for (uint32_t o : plan.record_owner[l]) if (o != NONE32) ++plan.fresh_rec[l][o];
+			for (uint32_t k = 0; k < nc; ++k) plan.base_rec[l][k + 1] = plan.base_rec[l][k] + plan.fresh_rec[l][k];
+		}
 	}
 	// groups in the order of their first component, with their triangle counts
 	std::vector<uint32_t> groups;          // representative ranks, ascending
@@ -141,6 +186,19 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 			plan.shard_vertices[s][lv[s]++] = v;
 		}
 	});
+	if (m.general) {   // the records of every list, shard by shard (a record no element names goes with shard 0, like an unreferenced vertex)
+		const size_t nl = m.lists.size();
+		plan.local_record.resize(nl); plan.shard_records.assign(nl, std::vector<BigVec<uint32_t>>(S));
+		for (size_t l = 0; l < nl; ++l) {
+			const uint32_t cnt = m.lists[l].count;
+			plan.local_record[l].resize(cnt);
+			for (uint32_t r = 0; r < cnt; ++r) {
+				const uint32_t o = plan.record_owner[l][r], s = o != NONE32 ? plan.shard_of[o] : 0u;
+				plan.local_record[l][r] = (uint32_t)plan.shard_records[l][s].size();
+				plan.shard_records[l][s].push_back(r);
+			}
+		}
+	}
 }
 
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
@@ -191,8 +249,52 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 		}
 	});
 	if (bad.load()) throw Error(HRY_E_INTERNAL, "shard: a selected face reaches outside its group");
+	if (m.general) {
+		// regions and list formats of the whole mesh; every list with the records of this shard; every element's slots renumbered
+		const Bindings &b = m.bind;
+		const size_t nl = m.lists.size();
+		if (plan.local_record.size() != nl) throw Error(HRY_E_ARG, "the plan belongs to another mesh");
+		s.general = true;
+		s.lists.assign(nl, AttrList());
+		s.shard.g_list_count.resize(nl); s.shard.record_of.resize(nl);
+		for (size_t l = 0; l < nl; ++l) {
+			const AttrList &L = m.lists[l];
+			AttrList &D = s.lists[l];
+			D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
+			D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
+			D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = L.have_bounds;
+			const BigVec<uint32_t> &src = plan.shard_records[l][shard];
+			D.count = (uint32_t)src.size();
+			const size_t st = (size_t)L.stride();
+			D.data.resize(src.size() * st);
+			for (size_t i = 0; i < src.size() && st; ++i) memcpy(D.data.data() + i * st, L.data.data() + (size_t)src[i] * st, st);
+			s.shard.g_list_count[l] = L.count;
+			s.shard.record_of[l].assign(src.begin(), src.end());
+		}
+		Bindings &d = s.bind;
+		d.reg_facelist = b.reg_facelist; d.reg_vtxlist = b.reg_vtxlist; d.reg_cornerlist = b.reg_cornerlist;
+		d.off_facelist = b.off_facelist; d.off_vtxlist = b.off_vtxlist; d.off_cornerlist = b.off_cornerlist;
+		d.nb_face = b.nb_face; d.nb_vtx = b.nb_vtx; d.nb_corner = b.nb_corner;
+		d.face_reg.resize(lnf); d.vtx_reg.resize(lnv);
+		d.face_attr.assign((size_t)lnf * b.nb_face, 0); d.vtx_attr.assign((size_t)lnv * b.nb_vtx, 0); d.corner_attr.assign((size_t)lne * b.nb_corner, 0);
+		for (uint32_t lf = 0; lf < lnf; ++lf) {
+			const uint32_t f = faces[lf];
+			const int r = b.face_reg[f];
+			d.face_reg[lf] = (uint16_t)r;
+			for (int a = 0; a < b.nfacelists(r); ++a) d.face_attr[(size_t)lf * b.nb_face + a] = plan.local_record[b.facelist(r, a)][b.face_attr[(size_t)f * b.nb_face + a]];
+			for (uint32_t k = 0; k < foff[f + 1] - foff[f]; ++k)
+				for (int a = 0; a < b.ncornerlists(r); ++a)
+					d.corner_attr[(size_t)(plan.local_he[f] + k) * b.nb_corner + a] = plan.local_record[b.cornerlist(r, a)][b.corner_attr[(size_t)(foff[f] + k) * b.nb_corner + a]];
+		}
+		for (uint32_t lv = 0; lv < lnv; ++lv) {
+			const uint32_t v = verts[lv];
+			const int r = b.vtx_reg[v];
+			d.vtx_reg[lv] = (uint16_t)r;
+			for (int a = 0; a < b.nvtxlists(r); ++a) d.vtx_attr[(size_t)lv * b.nb_vtx + a] = plan.local_record[b.vtxlist(r, a)][b.vtx_attr[(size_t)v * b.nb_vtx + a]];
+		}
+	}
 	// attribute records and list formats
-	for (int l = 0; l < 2; ++l) {
+	for (int l = 0; l < 2 && !m.general; ++l) {
 		const AttrList &L = m.lists[l];
 		AttrList &D = s.lists[l];
 		D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
@@ -218,6 +320,14 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 		if (!open) { s.shard.runs.push_back(ShardRun{ plan.base_v[k], plan.base_f[k], plan.base_he[k], 0, 0, 0 }); open = true; }
 		ShardRun &r = s.shard.runs.back();
 		r.n_vertices += A.fresh[k]; r.n_faces += A.n_faces[k]; r.n_halfedges += A.n_halfedges[k];
+		if (m.general) {
+			const size_t nl = m.lists.size();
+			if (s.shard.run_records.size() < s.shard.runs.size() * 2 * nl) {
+				for (size_t l = 0; l < nl; ++l) { s.shard.run_records.push_back(plan.base_rec[l][k]); s.shard.run_records.push_back(0); }
+			}
+			uint32_t *rr = s.shard.run_records.data() + (s.shard.runs.size() - 1) * 2 * nl;
+			for (size_t l = 0; l < nl; ++l) rr[2 * l + 1] += plan.fresh_rec[l][k];
+		}
 	}
 	return out.release();
 }
@@ -233,7 +343,9 @@ PartView parse_part(const uint8_t *p, size_t n)
 	v.hdr = read_hry_header(p, n, tmp, minor, false);
 	if (minor != 3) throw Error(HRY_E_ARG, "merge: not a sharded (.hry v0.3) container");
 	ShardedDirectory dir;   // every check a reader makes: a damaged part must not end up inside a merged container
-	parse_sharded_directory(p, n, v.hdr, tmp.nv, tmp.nf, tmp.declared_ne, dir, true);
+	std::vector<uint32_t> counts;
+	for (const AttrList &L : tmp.lists) counts.push_back(L.count);
+	parse_sharded_directory(p, n, v.hdr, tmp.nv, tmp.nf, tmp.declared_ne, dir, true, tmp.general ? &counts : nullptr);
 	v.nseg = (uint32_t)dir.segments.size();
 	v.lens = p + v.hdr + 4;
 	v.segs = v.lens + 8ull * v.nseg;
@@ -281,7 +393,8 @@ void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n
 // buffer, run tables inside their segments, runs inside the mesh, no two runs (of any segments) overlapping, and -- unless
 // allow_gaps -- every face and every half-edge covered (vertices need not be: the reference never codes a vertex no face
 // references).  Host-only, so the sanitizer build of tests/native reaches it.
-void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gnv, uint32_t gnf, uint32_t gne, ShardedDirectory &dir, bool allow_gaps)
+void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gnv, uint32_t gnf, uint32_t gne, ShardedDirectory &dir, bool allow_gaps,
+                             const std::vector<uint32_t> *list_counts)
 {
 	dir = ShardedDirectory();
 	if (n < hdr + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
@@ -300,10 +413,23 @@ void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gn
 		if (sg.bytes < 4) throw Error(HRY_E_FORMAT, "truncated segment");
 		uint32_t nr;
 		memcpy(&nr, p + sg.offset, 4);
-		if ((uint64_t)nr * sizeof(ShardRun) > sg.bytes - 4) throw Error(HRY_E_FORMAT, "truncated segment (runs)");
+		const size_t nl2 = list_counts ? 2 * list_counts->size() : 0;
+		const size_t run_bytes = sizeof(ShardRun) + 4 * nl2;
+		if ((uint64_t)nr * run_bytes > sg.bytes - 4) throw Error(HRY_E_FORMAT, "truncated segment (runs)");
 		sg.runs.resize(nr);
-		if (nr) memcpy(sg.runs.data(), p + sg.offset + 4, sizeof(ShardRun) * (size_t)nr);
-		sg.body_at = 4 + sizeof(ShardRun) * (size_t)nr;
+		sg.run_records.resize((size_t)nr * nl2);
+		sg.nrec.assign(nl2 / 2, 0);
+		for (uint32_t j = 0; j < nr; ++j) {
+			const uint8_t *rp = p + sg.offset + 4 + (size_t)j * run_bytes;
+			memcpy(&sg.runs[j], rp, sizeof(ShardRun));
+			if (nl2) memcpy(sg.run_records.data() + (size_t)j * nl2, rp + sizeof(ShardRun), 4 * nl2);
+			for (size_t l = 0; l < nl2 / 2; ++l) {
+				const uint64_t first = sg.run_records[(size_t)j * nl2 + 2 * l], cnt = sg.run_records[(size_t)j * nl2 + 2 * l + 1];
+				if (first + cnt > (*list_counts)[l] || (uint64_t)sg.nrec[l] + cnt > (*list_counts)[l]) throw Error(HRY_E_FORMAT, "corrupt sharded container (records outside their list)");
+				sg.nrec[l] += (uint32_t)cnt;
+			}
+		}
+		sg.body_at = 4 + run_bytes * (size_t)nr;
 		uint64_t lnv = 0, lnf = 0, lne = 0;
 		for (const ShardRun &r : sg.runs) {
 			if ((uint64_t)r.first_vertex + r.n_vertices > gnv || (uint64_t)r.first_face + r.n_faces > gnf || (uint64_t)r.first_halfedge + r.n_halfedges > gne)
@@ -349,6 +475,17 @@ void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gn
 			if ((uint64_t)byf[i - 1]->first_halfedge + byf[i - 1]->n_halfedges > byf[i]->first_halfedge)
 				throw Error(HRY_E_FORMAT, "corrupt sharded container (faces and half-edges of the runs are ordered differently)");
 	}
+	if (list_counts)   // the record ranges of a list must not overlap either
+		for (size_t l = 0; l < list_counts->size(); ++l) {
+			std::vector<Iv> rv;
+			for (const auto &sg : dir.segments)
+				for (size_t j = 0; j < sg.runs.size(); ++j) {
+					const uint64_t first = sg.run_records[j * 2 * list_counts->size() + 2 * l], cnt = sg.run_records[j * 2 * list_counts->size() + 2 * l + 1];
+					if (cnt) rv.push_back(Iv{ first, first + cnt });
+				}
+			uint64_t c = 0;
+			if (!disjoint(rv, c)) throw Error(HRY_E_FORMAT, "corrupt sharded container (overlapping record ranges)");
+		}
 	dir.complete = cf == gnf && ch == gne;
 	if (!dir.complete && !allow_gaps) throw Error(HRY_E_FORMAT, "sharded container does not cover the mesh (missing segments)");
 }
@@ -383,7 +520,8 @@ void combine_shard_bounds(const std::vector<const Mesh*> &shards, int l, std::ve
 			for (const Mesh *s : shards) {
 				const AttrList &L = s->lists[l];
 				if (!L.have_bounds || L.bmin_at.size() != (size_t)F.ncomp() || L.type != F.type) throw Error(HRY_E_ARG, "shard without device-computed bounds");
-				const std::vector<uint32_t> &whole = l == 0 ? s->shard.face_of : s->shard.vertex_of;
+				static const std::vector<uint32_t> none;
+				const std::vector<uint32_t> &whole = s->general ? ((size_t)l < s->shard.record_of.size() ? s->shard.record_of[l] : none) : l == 0 ? s->shard.face_of : s->shard.vertex_of;
 				auto key = [&](uint32_t at) -> uint64_t { return at == 0 ? 0 : (at - 1 < whole.size() ? (uint64_t)whole[at - 1] + 1 : at); };
 				T mn, mx;
 				memcpy(&mn, L.bmin.data() + L.offset[c], sizeof(T)); memcpy(&mx, L.bmax.data() + L.offset[c], sizeof(T));

@@ -33,13 +33,13 @@ def shard_bounds(cx: "hc.Codec", shard: "hc.Mesh") -> np.ndarray:
     0 for the scan's initial value, else 1 + the element's index in the whole mesh."""
     cx.bounds(shard)
     rows = []
-    for l in (0, 1):
+    for l in range(shard.nlists):
         fmt = shard.list_fmt(l)
         if not fmt:
             continue
         mn, mx = shard.list_min(l), shard.list_max(l)
         at = shard.bounds_at(l)
-        whole_index = shard.shard_elements(1 if l == 1 else 0)
+        whole_index = shard.shard_elements(16 + l) if shard.general else shard.shard_elements(1 if l == 1 else 0)
         for c, (t, _q, off) in enumerate(fmt):
             sz = hc.TYPE_SIZE[t]
             bits = lambda rec: int.from_bytes(bytes(rec[off:off + sz]), "little")
@@ -52,7 +52,7 @@ def combine_bounds(per_shard, shard: "hc.Mesh"):
     """per_shard: the shard_bounds arrays of every shard (same list formats).  Sets the whole mesh's bounds on `shard`."""
     tabs = [np.asarray(p).view(np.uint64).reshape(-1, 4) for p in per_shard]
     row = 0
-    for l in (0, 1):
+    for l in range(shard.nlists):
         fmt = shard.list_fmt(l)
         if not fmt:
             continue

@@ -92,7 +92,7 @@ typedef struct hry_timing {
     double total_ms;
     double k_rchain_ms;    /* compat: serial range recurrence kernel */
     double k_model_ms;     /* adaptive-model evaluation kernels */
-    double k_predict_ms;   /* prediction + residual + symbolisation kernels */
+    double k_predict_ms;   /* prediction + residual + symbolisation kernels; decode: candidates + chain records + the chain */
     double k_entropy_ms;   /* chunked: fused model+coder kernel */
     double k_chain_ms;     /* decode: the reconstruction chain kernels alone (k_unpredict2 / k_unpredict3) */
     uint64_t n_symbols;    /* coder invocations represented in the stream */
@@ -212,7 +212,8 @@ int hry_merge(const uint8_t *const *parts, const size_t *sizes, size_t n, uint8_
  * mesh).  For a shard: where its components go; for a mesh decoded from a sharded container: what was decoded. */
 size_t hry_mesh_runs(const hry_mesh *m, const uint32_t **runs);
 /* for a shard: index in the whole mesh of every vertex (which = 1) / face (which = 0) of the shard; which = 2: the start face of
- * each of its components (shard numbering) in coding order */
+ * each of its components (shard numbering) in coding order; which = 16 + l (general bindings): index in the whole mesh of every
+ * record of list l */
 size_t hry_shard_elements(const hry_mesh *m, int which, const uint32_t **idx);
 /* bounds of a list as records in the original component types (what hry_list_min / hry_list_max return) */
 int hry_list_set_bounds(hry_mesh *m, int l, const uint8_t *min_rec, const uint8_t *max_rec);

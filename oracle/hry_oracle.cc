@@ -1013,7 +1013,6 @@ static void read_header(ByteReader &r, Mesh &m, int want_minor = 1, uint32_t *de
 	const bool ply_layout = nrf == 1 && nrv == 1 && b.nfacelists(0) == 1 && b.ncornerlists(0) == 0 && b.nvtxlists(0) == 1 &&
 	                        b.facelist(0, 0) == 0 && b.vtxlist(0, 0) == 1;
 	if (!ply_layout) {
-		if (want_minor == 3) throw std::runtime_error("oracle: the sharded container holds the PLY layout only");
 		if (nrf > 128 || nrv > 128) throw std::runtime_error("oracle: more than 128 regions overflow the reference's model seeding (model.h:49-55)");
 		b.on = true;
 		b.face_reg.assign(m.nf, 0); b.vtx_reg.assign(m.nv, 0);
@@ -2091,7 +2090,10 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 		uint32_t gne = 0;
 		read_header(br, *m, 3, &gne);
 		const uint32_t gnv = m->nv, gnf = m->nf;
+		const bool general = m->bind.on;
+		const size_t nl = m->lists.size();
 		m->foff.assign((size_t)gnf + 1, 0); m->org.assign(gne, 0); m->twin.assign(gne, 0); m->eface.assign(gne, 0);
+		if (general) m->bind.corner_attr.assign((size_t)gne * m->bind.nb_corner, 0);   // (the header sized the face / vertex tables)
 		std::vector<char> face_seen(gnf, 0);
 		const uint32_t nseg = br.get<uint32_t>();
 		std::vector<uint64_t> len(nseg);
@@ -2102,26 +2104,53 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 			ByteReader sr{ q, q + len[si] };
 			const uint32_t nr = sr.get<uint32_t>();
 			std::vector<std::array<uint32_t, 6>> runs(nr);
+			// general bindings: every run is followed by its place in the record numbering of every list (first record, records):
+			// the decoder numbers the records of a list in the order they are first coded (attrcode.h:443-531), over all components
+			std::vector<std::vector<std::array<uint32_t, 2>>> rrec(nr, std::vector<std::array<uint32_t, 2>>(general ? nl : 0));
 			Mesh lm;
 			uint32_t lne = 0;
-			for (auto &r : runs) {
+			std::vector<uint32_t> nrec(nl, 0);
+			for (uint32_t j = 0; j < nr; ++j) {
+				auto &r = runs[j];
 				for (auto &x : r) x = sr.get<uint32_t>();
 				if ((uint64_t)r[0] + r[3] > gnv || (uint64_t)r[1] + r[4] > gnf || (uint64_t)r[2] + r[5] > gne) throw std::runtime_error("oracle: run outside the mesh");
 				lm.nv += r[3]; lm.nf += r[4]; lne += r[5];
+				for (size_t l = 0; l < rrec[j].size(); ++l) {
+					rrec[j][l][0] = sr.get<uint32_t>(); rrec[j][l][1] = sr.get<uint32_t>();
+					if ((uint64_t)rrec[j][l][0] + rrec[j][l][1] > m->lists[l].count) throw std::runtime_error("oracle: records outside their list");
+					nrec[l] += rrec[j][l][1];
+				}
 			}
 			lm.have_deg = m->have_deg;
-			for (const List &L : m->lists) {
+			for (size_t l = 0; l < nl; ++l) {
+				const List &L = m->lists[l];
 				List D;
 				D.target = L.target; D.fmt = L.fmt; D.interps = L.interps; D.bmin = L.bmin; D.bmax = L.bmax;
-				D.count = L.target == TG_FACE ? lm.nf : lm.nv;
+				D.count = general ? nrec[l] : L.target == TG_FACE ? lm.nf : lm.nv;
 				D.data.assign((size_t)D.count * D.fmt.bytes(), 0);
 				lm.lists.push_back(std::move(D));
+			}
+			if (general) {
+				lm.bind = m->bind;   // the regions of the whole mesh; the element tables in the segment's sizes
+				lm.bind.face_reg.assign(lm.nf, 0); lm.bind.vtx_reg.assign(lm.nv, 0);
+				lm.bind.face_attr.assign((size_t)lm.nf * lm.bind.nb_face, 0); lm.bind.vtx_attr.assign((size_t)lm.nv * lm.bind.nb_vtx, 0);
+				lm.bind.corner_attr.clear();
 			}
 			decode_chunked_body(&lm, sr.p, (size_t)(sr.end - sr.p));
 			if (lm.num_edge() != lne) throw std::runtime_error("oracle: segment edge count mismatch");
 			std::vector<uint32_t> l2g(lm.nv);
 			uint32_t cv = 0, cf = 0, ch = 0;
 			for (const auto &r : runs) { for (uint32_t i = 0; i < r[3]; ++i) l2g[cv + i] = r[0] + i; cv += r[3]; }
+			std::vector<std::vector<uint32_t>> rl2g(general ? nl : 0);
+			for (size_t l = 0; l < rl2g.size(); ++l) {
+				const size_t st = (size_t)m->lists[l].fmt.bytes();
+				uint32_t at = 0;
+				for (uint32_t j = 0; j < nr; ++j) {
+					for (uint32_t i = 0; i < rrec[j][l][1]; ++i) rl2g[l].push_back(rrec[j][l][0] + i);
+					if (st && rrec[j][l][1]) memcpy(m->lists[l].data.data() + (size_t)rrec[j][l][0] * st, lm.lists[l].data.data() + (size_t)at * st, (size_t)rrec[j][l][1] * st);
+					at += rrec[j][l][1];
+				}
+			}
 			cv = 0;
 			for (const auto &r : runs) {
 				for (uint32_t i = 0; i < r[4]; ++i) {
@@ -2137,6 +2166,23 @@ static Mesh *decode_chunked(const uint8_t *p, size_t n)
 					m->twin[(size_t)r[2] + i] = tw - ch + r[2];
 					m->eface[(size_t)r[2] + i] = lm.eface[ch + i] - cf + r[1];
 				}
+				if (general) {
+					Mesh::Bind &b = m->bind;
+					const Mesh::Bind &d = lm.bind;
+					for (uint32_t i = 0; i < r[3]; ++i) {
+						const int reg = d.vtx_reg[cv + i];
+						b.vtx_reg[r[0] + i] = (uint16_t)reg;
+						for (int a = 0; a < b.nvtxlists(reg); ++a) b.vtx_attr[(size_t)(r[0] + i) * b.nb_vtx + a] = rl2g[b.vtxlist(reg, a)].at(d.vtx_attr[(size_t)(cv + i) * b.nb_vtx + a]);
+					}
+					for (uint32_t i = 0; i < r[4]; ++i) {
+						const int reg = d.face_reg[cf + i];
+						b.face_reg[r[1] + i] = (uint16_t)reg;
+						for (int a = 0; a < b.nfacelists(reg); ++a) b.face_attr[(size_t)(r[1] + i) * b.nb_face + a] = rl2g[b.facelist(reg, a)].at(d.face_attr[(size_t)(cf + i) * b.nb_face + a]);
+						for (uint32_t h = lm.foff[cf + i]; h < lm.foff[(size_t)cf + i + 1]; ++h)
+							for (int a = 0; a < b.ncornerlists(reg); ++a)
+								b.corner_attr[(size_t)(h - ch + r[2]) * b.nb_corner + a] = rl2g[b.cornerlist(reg, a)].at(d.corner_attr[(size_t)h * b.nb_corner + a]);
+					}
+				} else
 				for (const List &S : lm.lists) {
 					List &D = m->lists[&S - &lm.lists[0]];
 					const size_t st = (size_t)S.fmt.bytes();

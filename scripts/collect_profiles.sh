@@ -1,20 +1,42 @@
 #!/bin/bash
 # Collects the round's measurement artefacts on the GPU box (run through gpurun from the repository root):
-#   bench line, rocprofv3 kernel statistics of the same command, and PMC passes (own runs, no trace flags).
-# Results land in gpurun_out/prof_<tag>/; copy what should be judged into profiles/<round>/.
+#   bench lines, and per workload ("leg") the rocprofv3 kernel statistics + three PMC passes (own runs, no trace flags).
+# Results land in gpurun_out/prof_<tag>/<leg>/; copy what should be judged into profiles/<round>/.
+#   legs: configs1  scripts/quick_chunked.py 708            BASELINE configs[1], 3 encode + decode passes (k_unpredict3)
+#         float1m   scripts/float_chain_time.py 708          the same torus lossless: ONE component, k_unpredict2<float>
+#         cfg4share tests/tools/cfg4_check.py 128 221 222    one GPU's share of configs[3]: 128 components, lossless
+#         cfg0      scripts/cfg0_time.py                     bunny-class stand-in, lossless, both profiles
 set -u
-TAG=${1:-r1}
+TAG=${1:-r3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/chunked_bench.json 2> $OUT/chunked_bench.err
-python3 $ROOT/bench.py --profile compat --steps 2 --warmup 1 > $OUT/compat_bench.json 2> $OUT/compat_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/kstats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_compat -- python3 $ROOT/bench.py --profile compat --steps 2 --warmup 1 --no-cpu-baseline > $OUT/kstats_compat.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/scripts/quick_chunked.py 708 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/scripts/quick_chunked.py 708 > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/scripts/quick_chunked.py 708 > $OUT/pmc_sq.log 2>&1
+python3 $ROOT/bench.py --profile compat --steps 2 --warmup 1 --no-large > $OUT/compat_bench.json 2> $OUT/compat_bench.err
+mkdir -p $OUT/bench
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench/kstats -- python3 $ROOT/bench.py --no-cpu-baseline --no-large > $OUT/bench/kstats.log 2>&1
+leg() {
+	name=$1; shift
+	mkdir -p $OUT/$name
+	rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/kstats -- python3 "$@" > $OUT/$name/kstats.log 2>&1
+	rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$name/pmc_fetch -- python3 "$@" > $OUT/$name/pmc_fetch.log 2>&1
+	rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$name/pmc_write -- python3 "$@" > $OUT/$name/pmc_write.log 2>&1
+	rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/$name/pmc_sq -- python3 "$@" > $OUT/$name/pmc_sq.log 2>&1
+	echo "leg $name done" >> $OUT/progress.log
+}
+leg configs1 $ROOT/scripts/quick_chunked.py 708
+leg float1m $ROOT/scripts/float_chain_time.py 708
+leg cfg4share $ROOT/tests/tools/cfg4_check.py 128 221 222 --no-verify
+leg cfg0 $ROOT/scripts/cfg0_time.py
 cd $ROOT
-python3 scripts/summarise_profiles.py $OUT 3 > $OUT/summary.txt 2>&1
-tail -40 $OUT/summary.txt
+# passes of the workload per run (what traffic.json divides by): quick_chunked 3 encode + decode; float_chain_time 1 encode + 4
+# decodes (divide by the decodes: the decode kernels are the subject); cfg4_check 2; cfg0_time 3 per profile
+for lp in bench:1 configs1:3 float1m:4 cfg4share:2 cfg0:3; do
+	l=${lp%%:*}; n=${lp##*:}
+	echo "==== $l" >> $OUT/summary.txt
+	python3 scripts/summarise_profiles.py $OUT/$l $n >> $OUT/summary.txt 2>&1
+done
+# keep what is small: the condensed files, not the raw rocprofv3 trees
+find $OUT -type d \( -name kstats -o -name pmc_fetch -o -name pmc_write -o -name pmc_sq \) -prune -exec rm -rf {} +
+tail -60 $OUT/summary.txt

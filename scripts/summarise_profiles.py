@@ -18,7 +18,7 @@ def short(name):
     return name
 
 
-for tag in ("kstats", "kstats_compat"):
+for tag in ("kstats",):
     f = first(f"{tag}/**/*kernel_stats.csv")
     if not f:
         print(tag, ": no kernel stats")

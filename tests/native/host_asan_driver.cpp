@@ -42,7 +42,7 @@ int main(int argc, char **argv)
 				Mesh back;
 				int minor = 0;
 				read_hry_header(hdr.data(), hdr.size(), back, minor);
-				if (!m->general && m->nf) {
+				if (m->nf) {
 					ShardPlan plan;
 					shard_plan(*m, 3, plan);
 					// a sharded container as three ranks would write it (host side: header of the whole mesh, run tables; the bodies
@@ -56,8 +56,11 @@ int main(int argc, char **argv)
 						const uint32_t one = sh->nf ? 1 : 0, nr = (uint32_t)sh->shard.runs.size();
 						put(&one, 4);
 						if (one) {
-							const uint64_t len = 4 + sizeof(ShardRun) * (uint64_t)nr + 7;
-							put(&len, 8); put(&nr, 4); put(sh->shard.runs.data(), sizeof(ShardRun) * nr); put("body...", 7);
+							const size_t nl2 = sh->general ? 2 * sh->lists.size() : 0;   // general bindings: every run with its record ranges
+							const uint64_t len = 4 + (sizeof(ShardRun) + 4 * nl2) * (uint64_t)nr + 7;
+							put(&len, 8); put(&nr, 4);
+							for (uint32_t j = 0; j < nr; ++j) { put(&sh->shard.runs[j], sizeof(ShardRun)); if (nl2) put(sh->shard.run_records.data() + j * nl2, 4 * nl2); }
+							put("body...", 7);
 						}
 						parts.push_back(std::move(c));
 					}
@@ -68,7 +71,10 @@ int main(int argc, char **argv)
 					Mesh hm; int mn3 = 0;
 					const size_t h3 = read_hry_header(merged.data(), merged.size(), hm, mn3, false);
 					ShardedDirectory dir;
-					parse_sharded_directory(merged.data(), merged.size(), h3, hm.nv, hm.nf, hm.declared_ne, dir);
+					std::vector<uint32_t> counts;
+					for (const AttrList &L : hm.lists) counts.push_back(L.count);
+					const std::vector<uint32_t> *lc = hm.general ? &counts : nullptr;
+					parse_sharded_directory(merged.data(), merged.size(), h3, hm.nv, hm.nf, hm.declared_ne, dir, false, lc);
 					if (!dir.complete || mn3 != 3) throw Error(HRY_E_INTERNAL, "merged directory incomplete");
 					for (int k = 0; k < 64; ++k) {
 						std::vector<uint8_t> bad(merged.begin(), merged.end());
@@ -76,7 +82,7 @@ int main(int argc, char **argv)
 						else for (int j = 0; j < 2; ++j) bad[h3 + (size_t)(1103515245u * (unsigned)(k * 2 + j + 1) + 12345u) % (bad.size() - h3)] ^= (uint8_t)(1u << ((k + j) & 7));
 						try {
 							ShardedDirectory d2;
-							parse_sharded_directory(bad.data(), bad.size(), h3, hm.nv, hm.nf, hm.declared_ne, d2, (k & 1) != 0);
+							parse_sharded_directory(bad.data(), bad.size(), h3, hm.nv, hm.nf, hm.declared_ne, d2, (k & 1) != 0, lc);
 							const uint8_t *bp = bad.data(); const size_t bn = bad.size();
 							ByteSink again;
 							merge_containers(&bp, &bn, 1, again);

@@ -158,5 +158,7 @@ def test_cli_obj_both_ways(tmp_path):
     assert r.returncode == 0 and hc.container_info((tmp_path / "c.hry").read_bytes())["minor"] == 2
     assert harry(tmp_path / "c.hry", tmp_path / "c.obj").returncode == 0
     assert (tmp_path / "c.obj").read_bytes() == open(os.path.join(OBJ, "smooth.ll.dec.obj"), "rb").read()
-    r = harry(tmp_path / "smooth.obj", tmp_path / "d.hry", "--profile", "chunked", "--shards", "2")
-    assert r.returncode == 134 and "shards" in r.stderr
+    r = harry(tmp_path / "smooth.obj", tmp_path / "d.hry", "--gpus", "2", "--shards", "3")     # general bindings shard too (one component: one segment)
+    assert r.returncode == 0 and hc.container_info((tmp_path / "d.hry").read_bytes())["minor"] == 3, r.stderr
+    assert harry(tmp_path / "d.hry", tmp_path / "d.obj", "--gpus", "2").returncode == 0
+    assert (tmp_path / "d.obj").read_bytes() == open(os.path.join(OBJ, "smooth.ll.dec.obj"), "rb").read()

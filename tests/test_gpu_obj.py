@@ -147,11 +147,13 @@ def test_chunked_container_larger_scenes(cx):
         same_decoded(cx.read_hry(got), op.Mesh.from_hry(o.clone().encode().data))
 
 
-def test_general_bindings_do_not_shard(cx):
+def test_a_one_component_scene_shards_into_one_segment(cx):
+    """general bindings shard like the PLY layout (below: test_obj_scene_as_virtual_ranks_...); a scene of one component is one group"""
     m = hc.Mesh.from_obj(_read("smooth.obj"), OBJ)
-    with pytest.raises(hc.HryError) as e:
-        hc.ShardPlan(m, 2)
-    assert e.value.code == -3
+    plan = hc.ShardPlan(m, 2)
+    assert plan.ngroups == 1
+    shards = [plan.extract(m, s) for s in range(2)]
+    assert sorted(sh.nf for sh in shards) == [0, m.nf]
 
 
 def _disk_scene(n=28, colors_every=0):
@@ -245,3 +247,95 @@ def test_decode_survives_damaged_payload(cx):
     except hc.HryError:
         pass
     same_decoded(cx.read_hry(good), ref)
+
+
+# ---- one OBJ scene over N shards (general bindings in the sharded container, .hry v0.3) -------------------------------------------
+def _sharded_general(cx, obj, n_shards, quant, chunk=1024):
+    from harry_amd import sharding
+    whole = hc.Mesh.from_obj(obj, "")
+    plan = hc.ShardPlan(whole, n_shards)
+    shards = [plan.extract(whole, s) for s in range(n_shards)]
+    tabs = [sharding.shard_bounds(cx, sh) for sh in shards]
+    parts = []
+    for sh in shards:
+        sharding.combine_bounds(tabs, sh)
+        if quant:
+            cx.requant(sh, quant)
+        parts.append(cx.write_hry(sh, profile=hc.PROFILE_CHUNKED, chunk_syms=chunk))
+    return plan, shards, parts
+
+
+_SHARED_NORMAL_SCENE = b"""# three parts; the first two use the same vn line (they must stay in one group), the third has its own
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 3 0 0
+v 4 0 0
+v 4 1 0
+v 3 1 0.5
+v 6 0 0
+v 7 0 1
+v 7 1 0
+vn 0 0 1
+vn 0.6 0 0.8
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+f 1/1/1 2/2/1 3/3/1 4/4/1
+f 5/1/1 6/2/1 7/3/1
+f 5/1/1 7/3/1 8/4/1
+f 9/1/2 10/2/2 11/3/2
+"""
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+@pytest.mark.parametrize("kw,quant", [(dict(normals="smooth", tex="atlas", charts=3), []),
+                                      (dict(normals="flat", tex="corner", colors="some", materials=2, mtl_name="none.mtl"), [(0, -1, 12)]),
+                                      (dict(normals="smooth"), [(l, -1, 11) for l in range(2)])])
+def test_obj_scene_as_virtual_ranks_decodes_like_the_reference_format(cx, n_shards, kw, quant):
+    """plan (components tied by shared vertices AND shared records), extract (lists, regions, bindings of the shard), bounds of every
+    list combined from the shards', one segment per shard, merge; the merged container decodes -- on the GPU whole and on several
+    contexts, and by the oracle's independent CPU decoder -- to the reference-format decode of the whole scene: same connectivity,
+    same regions, same bindings, the records of every list in the same creation order (attrcode.h:443-531)"""
+    base = mg.with_nonmanifold(mg.multi_component(7, 8, 9, seed=5, polys="mixed"), 3, 2, seed=4)
+    sc = og.scene(base, **kw)
+    plan, shards, parts = _sharded_general(cx, sc.obj, n_shards, quant)
+    assert plan.ngroups >= 2
+    merged = hc.merge(parts)
+    assert hc.container_info(merged)["minor"] == 3 and hc.container_check(merged)
+    o = op.Mesh.from_obj(sc.obj, "")
+    if quant:
+        o.requant(quant)
+    ref = op.Mesh.from_hry(o.encode().data)                 # the reference stream of the whole scene, decoded
+    same_decoded(cx.read_hry(merged), ref)
+    same_decoded(cx.read_hry(merged), op.Mesh.from_hry_chunked(merged))
+    mc = hc.MultiCodec([0] * min(n_shards, 4))
+    try:
+        assert mc.write_hry(hc.Mesh.from_obj(sc.obj, ""), quant, n_shards=n_shards, chunk_syms=1024) == merged
+        same_decoded(mc.read_hry(merged), ref)
+    finally:
+        mc.close()
+    # a share of the segments: partial, its runs hold the reference's values
+    part = cx.read_hry(merged, shard=(0, 2))
+    assert part.partial and len(part.runs())
+    with pytest.raises(hc.HryError):
+        part.to_obj()
+    # text round trip of the merged container: what `harry merged.hry out.obj` writes is what the reference-format decode writes
+    assert cx.read_hry(merged).to_obj() == cx.read_hry(o.encode().data).to_obj()
+
+
+def test_components_that_share_a_record_stay_in_one_group(cx):
+    whole = hc.Mesh.from_obj(_SHARED_NORMAL_SCENE, "")
+    plan = hc.ShardPlan(whole, 3)
+    assert plan.ncomponents == 3 and plan.ngroups == 1          # the shared "vt" lines tie all three; ...
+    scene2 = _SHARED_NORMAL_SCENE.replace(b"f 9/1/2 10/2/2 11/3/2", b"vt 0.5 0.5\nvt 0.25 0.5\nvt 0.5 0.25\nf 9/5/2 10/6/2 11/7/2")
+    whole = hc.Mesh.from_obj(scene2, "")
+    plan = hc.ShardPlan(whole, 2)
+    assert plan.ncomponents == 3 and plan.ngroups == 2          # ... with its own texture coordinates the third part is free
+    _, shards, parts = _sharded_general(cx, scene2, 2, [])
+    merged = hc.merge(parts)
+    o = op.Mesh.from_obj(scene2, "")
+    same_decoded(cx.read_hry(merged), op.Mesh.from_hry(o.encode().data))
+    same_decoded(cx.read_hry(merged), op.Mesh.from_hry_chunked(merged))
