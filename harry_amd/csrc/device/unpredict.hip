@@ -550,7 +550,11 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 			// unchained vertices come thick (fewer than six chained ones in front) does the general form take them -- up to the
 			// first stretch of eight chained vertices, not to the end of the tile (round 2: 5 % of the batches of a regular mesh
 			// went through 64 general steps for one such vertex each, 16 % of the chain's time).
-			if (run == nb || run >= 6) { run_mode = true; nb = run; }
+			// ... unless they come thick all over the batch (quad and mixed-polygon meshes: a face brings two new vertices and the
+			// second one's parallelograms read both): cutting would leave batches of five with 4 000 cycles of overhead each
+			const uint32_t n_unchained = (uint32_t)__builtin_popcountll(unchained);
+			if (run == nb || (run >= 6 && n_unchained * 8u <= nb)) { run_mode = true; nb = run; }
+			else if (n_unchained * 8u > nb) { /* the general form for the whole batch */ }
 			else {
 				uint32_t g = run + 1;
 				for (;;) {
@@ -982,17 +986,17 @@ enum { CR_NC = 3, CR_BIG = 3, CR_POS_SHIFT = 2, CR_POS_NONE = 7, CR_FAR = 1 << 5
 
 // ring_floor: ids below it are not in the LDS ring when the vertex is reconstructed (they belong to an earlier component, or
 // to an earlier slice beyond the part of the ring that is reloaded): such sources are read by vertex id ("far")
-__device__ __forceinline__ ChainRec make_chain_rec(const uint32_t *cand, const uint8_t *ncand, uint32_t v, uint32_t seg_begin, uint32_t ring_floor)
+__device__ __forceinline__ ChainRec make_chain_rec_ids(uint32_t nc, const uint32_t (&row)[6], uint32_t v, uint32_t seg_begin, uint32_t ring_floor)
 {
-	const uint32_t nc = ncand[v];
 	ChainRec r;
 #pragma unroll
 	for (int j = 0; j < 6; ++j) r.slot[j] = 0;
 	r.pad = 0;
 	if (nc > 2) { r.flags = (uint16_t)(CR_BIG | (CR_POS_NONE << CR_POS_SHIFT)); return r; }
-	const uint32_t *row = cand + (size_t)v * kCand2;
 	uint32_t pos = CR_POS_NONE, need = 0, far = 0;
-	for (uint32_t j = 0; j < 3 * nc; ++j) {
+#pragma unroll
+	for (uint32_t j = 0; j < 6; ++j) {
+		if (j >= 3 * nc) continue;
 		const uint32_t id = row[j];
 		if (id + 1u == v && j % 3 != 2 && pos == CR_POS_NONE && v > seg_begin) pos = j;   // the chained source: predecessor, plus sign, once
 		else { need = max(need, id + 1u); }
@@ -1006,6 +1010,13 @@ __device__ __forceinline__ ChainRec make_chain_rec(const uint32_t *cand, const u
 	r.pad = (uint16_t)min(65535u, need ? v + 1u - need : 65535u);   // distance to the most recent source other than the chained one
 	return r;
 }
+__device__ __forceinline__ ChainRec make_chain_rec(const uint32_t *cand, const uint8_t *ncand, uint32_t v, uint32_t seg_begin, uint32_t ring_floor)
+{
+	const uint32_t nc = ncand[v];
+	uint32_t row[6] = { 0, 0, 0, 0, 0, 0 };
+	if (nc <= 2) { const uint32_t *p = cand + (size_t)v * kCand2; for (uint32_t j = 0; j < 3 * nc; ++j) row[j] = p[j]; }
+	return make_chain_rec_ids(nc, row, v, seg_begin, ring_floor);
+}
 // cand / ncand as written by k_candidates_ids; seg_start: first decode rank of every component + end sentinel
 __global__ __launch_bounds__(256) void k_chain_records(const uint32_t *cand, const uint8_t *ncand, uint32_t n, const uint32_t *seg_start, uint32_t nseg, ChainRec *out)
 {
@@ -1015,12 +1026,6 @@ __global__ __launch_bounds__(256) void k_chain_records(const uint32_t *cand, con
 	while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= v) lo = mid; else hi = mid; }
 	const uint32_t seg_begin = seg_start[lo];
 	out[v] = make_chain_rec(cand, ncand, v, seg_begin, seg_begin);
-}
-// one slice [v_begin, v_end) of a chain that continues an earlier slice (pipelined decode)
-__global__ __launch_bounds__(256) void k_chain_records_range(const uint32_t *cand, const uint8_t *ncand, uint32_t v_begin, uint32_t v_end, uint32_t ring_floor, ChainRec *out)
-{
-	const uint32_t v = v_begin + blockIdx.x * blockDim.x + threadIdx.x;
-	if (v < v_end) out[v] = make_chain_rec(cand, ncand, v, v_begin, ring_floor);
 }
 
 // g_chain_timeout (above) is set when a wavefront gave up waiting for another one (a hand-over that takes longer than ~a second
@@ -1501,8 +1506,10 @@ bool unpredict2_applicable(const ListDesc &ld)
 }
 // candidate lists with plain vertex ids (k_unpredict2 resolves ring slots itself)
 // (virtual block (b % 8) * per + b / 8: one contiguous range of vertices per XCD and L2, see k_predict_vtx)
+// crec != nullptr: the chain record of the vertex (k_unpredict3) from the same registers, for the slice [v0, n) of a chain that
+// continues an earlier slice -- one pass over the candidates instead of a second kernel that reads them back
 __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint32_t *order_v, uint32_t v0, uint32_t n, uint32_t *cand, uint8_t *ncand, uint32_t blocks_per_xcd,
-                                                        uint32_t nvtx_total)
+                                                        uint32_t nvtx_total, ChainRec *crec, uint32_t ring_floor)
 {
 	uint32_t v = v0 + ((blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
 	if (v >= n) return;
@@ -1521,6 +1528,7 @@ __global__ __launch_bounds__(256) void k_candidates_ids(ConnView cv, const uint3
 	const uint32_t m = k > (uint32_t)kCandMax ? 0 : k;
 	if (m < 2) { a1 = b1 = o1 = 0; }
 	if (m < 1) { a0 = b0 = o0 = 0; }
+	if (crec) { const uint32_t row[6] = { a0, b0, o0, a1, b1, o1 }; crec[v] = make_chain_rec_ids(k > 2 ? 3u : k, row, v, v0, ring_floor); }
 	const bool wide = m > 2;
 	const uint64_t need = __ballot(wide);
 	if (wide) {   // the whole row goes to the overflow area; the lanes of a wavefront that need one take their rows with ONE atomic
@@ -1551,7 +1559,7 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 	if (!nvtx) return;
 	const uint32_t per = ((nvtx + 255) / 256 + 7) / 8;
 	cand_table_reset(st, cand, nvtx);
-	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand, per, nvtx);
+	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand, per, nvtx, (ChainRec*)nullptr, 0u);
 }
 // wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8; by default 5 for a large mesh (long rings: more
 // look-ahead for the preparation costs no heads), 4 otherwise
@@ -1580,8 +1588,7 @@ void launch_slice_prepare(hipStream_t st, const ConnView &cv, const uint32_t *or
 	if (v_end <= v_begin) return;
 	const uint32_t n = v_end - v_begin;
 	const uint32_t per = ((n + 255) / 256 + 7) / 8;
-	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, v_begin, v_end, cand, ncand, per, nvtx);
-	hipLaunchKernelGGL(k_chain_records_range, dim3((n + 255) / 256), dim3(256), 0, st, (const uint32_t*)cand, (const uint8_t*)ncand, v_begin, v_end, chain_ring_floor(v_begin), (ChainRec*)crec);
+	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, v_begin, v_end, cand, ncand, per, nvtx, (ChainRec*)crec, chain_ring_floor(v_begin));
 }
 void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,
                         const void *crec, const uint8_t *planes, const ListDesc &ld, uint8_t *rec)

@@ -1,13 +1,13 @@
 """Lossless-float reconstruction chain (k_unpredict2<float>) on ONE component: ms per decode and ns per vertex.
 python scripts/float_chain_time.py [SIDE] [--flat] [--offset]   (--flat: z = 0 everywhere, the chain's fallback case;
---offset: all coordinates positive)"""
+--offset: all coordinates positive; --mixed: 40 % quads, 5 % pentagons, as BASELINE configs[3])"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from harry_amd import codec as hc, meshgen as mg
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 708
-mesh = mg.torus(side, side, seed=2, sigma=1e-4)
+mesh = mg.torus(side, side, seed=2, sigma=1e-4, polys="mixed" if "--mixed" in sys.argv else "tri")
 v = mesh.verts.copy()
 if "--flat" in sys.argv:
     v["z"][:] = 0
