@@ -264,33 +264,60 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 						else if (id[k] < i) { slot[k] = id[k] - base; inside = true; }   // (id >= i: damaged input, reads as 0)
 					}
 				}
-				bool final_ = !inside;
 				T out = T(0);
-				// the rounds, compiled for N source slots: a batch whose records read at most N sources runs the N-slot code
+				// the run, compiled for N source slots (a batch whose records read at most N sources runs the N-slot code).  Records read
+				// earlier records only, so the run is evaluated SYSTOLICALLY: at step i every lane evaluates its record from what it
+				// holds, lane i -- whose sources inside the run are all final by then -- broadcasts its value (v_readlane), and every
+				// lane that waits for record i picks it up.  Exactly hi - lo steps of one evaluation each, no LDS, no barrier; round 2
+				// relaxed the batch through LDS until nothing changed: up to 64 rounds of evaluate + two barriers + a ballot + a scan of
+				// the slots (0.7 us per record when every record reads its predecessor -- one normal per face).
 				auto rounds = [&](auto n_slots) {
 					constexpr int N = decltype(n_slots)::value;
-					for (int round = 0; round < 65; ++round) {
-						if (inside) {
-#pragma unroll
-							for (int k = 0; k < N; ++k) {   // unconditional reads: issued back to back, one wait
-								const uint32_t x = s_val[slot[k] & 63u];
-								val[k] = slot[k] < 64u ? from_u32<T>(x) : val[k];
-							}
-						}
+					if (!__ballot(inside)) {   // nothing reads inside the run (private texture coordinates): one evaluation
 						if (in_run) out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q);
-						__syncthreads();   // (one wavefront: orders the LDS traffic of the rounds)
-						if (in_run) s_val[lane] = as_u32<T>(out);
-						__syncthreads();
-						// final: every source inside the run was final BEFORE this round
-						const unsigned long long fin = __ballot(final_ || !in_run);
-						if (fin == ~0ull) break;
-						if (!final_) {
-							bool now = true;
-#pragma unroll
-							for (int k = 0; k < N; ++k) if (slot[k] < 64u && !((fin >> slot[k]) & 1ull)) now = false;
-							final_ = now;
-						}
+						return;
 					}
+					// how deep the dependencies inside the run go (connectivity only: a relaxation on small integers through the LDS
+					// crossbar, ~100 cycles a round): level = 1 + the deepest source inside the run
+					int level = 0, depth = 0;
+					bool settled = false;
+					for (int r = 0; r < 24 && !settled; ++r) {
+						int mx = 0;
+#pragma unroll
+						for (int k = 0; k < N; ++k) {
+							const int sl = __builtin_amdgcn_ds_bpermute((int)((slot[k] & 63u) * 4u), level);
+							mx = slot[k] < 64u ? max(mx, sl + 1) : mx;
+						}
+						settled = !__ballot(mx != level);
+						level = mx;
+						++depth;
+					}
+					// shallow (smooth normals, texture atlases: a handful of levels): that many rounds of "every lane evaluates from the
+					// current values of the run" through LDS; deep (one normal per face: every record reads the one before it): the
+					// systolic form, one evaluation per record
+					if (settled && depth * 3 < hi - lo) {
+						for (int round = 0; round < depth; ++round) {
+							if (round) {
+#pragma unroll
+								for (int k = 0; k < N; ++k) {   // unconditional reads: issued back to back, one wait
+									const uint32_t x = s_val[slot[k] & 63u];
+									val[k] = slot[k] < 64u ? from_u32<T>(x) : val[k];
+								}
+							}
+							if (in_run) out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q);
+							__syncthreads();   // (one wavefront: orders the LDS traffic of the rounds)
+							if (in_run) s_val[lane] = as_u32<T>(out);
+							__syncthreads();
+						}
+						return;
+					}
+					for (int i = lo; i < hi; ++i) {
+						out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q);
+						const T x = from_u32<T>((uint32_t)__builtin_amdgcn_readlane((int)as_u32<T>(out), i));
+#pragma unroll
+						for (int k = 0; k < N; ++k) val[k] = slot[k] == (uint32_t)i ? x : val[k];
+					}
+					// (lane j's `out` is final from step j on: its picks were complete then and nothing it holds changes afterwards)
 				};
 				const int most = (int)__builtin_amdgcn_readfirstlane(wave_max_small(in_run ? ns : 0));
 				constexpr int N1 = CAP / 4 >= 3 ? (CAP / 4 / 3) * 3 : CAP / 4, N2 = CAP / 2;   // multiples of three for the parallelograms of KIND 0
