@@ -281,7 +281,12 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 					// crossbar, ~100 cycles a round): level = 1 + the deepest source inside the run
 					int level = 0, depth = 0;
 					bool settled = false;
-					for (int r = 0; r < 24 && !settled; ++r) {
+					// (a run in which most records read the record right before them is deep without asking)
+					bool reads_prev = false;
+#pragma unroll
+					for (int k = 0; k < N; ++k) reads_prev |= slot[k] + 1u == (uint32_t)lane;
+					const bool chain_like = 2 * __builtin_popcountll(__ballot(reads_prev)) > hi - lo;
+					for (int r = 0; r < 24 && !settled && !chain_like; ++r) {
 						int mx = 0;
 #pragma unroll
 						for (int k = 0; k < N; ++k) {
@@ -310,6 +315,56 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 							__syncthreads();
 						}
 						return;
+					}
+					if constexpr (KIND == 1 && std::is_same<T, float>::value && N <= 6) {
+						// Float corner records (normals, texture coordinates), the deep case: the step in its SHORT form -- the mean by a
+						// multiplication with 1 / n instead of the division, the sweep for the nearest source without its FLT_MAX start,
+						// the residual code in its "near" form on the value's bits (attrcode.h:135-154,182-208, prediction.h:46-64) --
+						// and then VERIFIED exactly, all lanes at once: after the run every lane holds the final values of its sources,
+						// so it evaluates the reference arithmetic on them; the broadcast values were what `out` is now, hence all are
+						// right iff every lane agrees (induction over the lanes).  The first lane that disagrees gets its exact value and
+						// the run is repeated from there, three times at most; then the exact systolic form below takes the run.
+						const bool none = ns == 0;
+						const double rcp = none ? 0.0 : 1.0 / (double)ns;
+						float pen[N];
+#pragma unroll
+						for (int k = 0; k < N; ++k) pen[k] = k < ns ? 0.0f : 3.0e38f;
+						// prediction.h:46-64 on the ordered-int image of a float, near case: value bits = prediction bits +- delta by the
+						// prediction's own sign (delta = half the code, or -(half + 1) for an odd code)
+						const uint32_t c32 = (uint32_t)code, half = c32 >> 1, delta = (c32 & 1u) ? 0u - half - 1u : half;
+						auto near_value = [&](uint32_t pb) { const uint32_t m = (uint32_t)((int32_t)pb >> 31); return ((delta ^ m) + pb) - m; };
+						bool fixed = none;
+						uint32_t fixedval = as_u32<T>(cm::value_from_residual<T>(code, T(0), q));
+						int from = lo;
+						bool exact_form = false;
+						for (int tries = 0;; ++tries) {
+							for (int i = from; i < hi; ++i) {
+								double sd = 0.0;
+#pragma unroll
+								for (int k = 0; k < N; ++k) sd += (double)val[k];                     // (slots beyond ns hold 0)
+								const float avg = (float)(sd * rcp);
+								float best = val[0], dbest = __builtin_fabsf(avg - val[0]);
+#pragma unroll
+								for (int k = 1; k < N; ++k) {
+									const float dk = __builtin_fabsf(avg - val[k]) + pen[k];
+									const bool keep = dbest < dk;                                  // ties go to the later source
+									best = keep ? best : val[k]; dbest = keep ? dbest : dk;
+								}
+								const uint32_t cheap = near_value(cm::bits<uint32_t>(best));
+								out = from_u32<T>(fixed ? fixedval : cheap);
+								const T x = from_u32<T>((uint32_t)__builtin_amdgcn_readlane((int)as_u32<T>(out), i));
+#pragma unroll
+								for (int k = 0; k < N; ++k) val[k] = slot[k] == (uint32_t)i ? x : val[k];
+							}
+							const uint32_t ref = as_u32<T>(cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q));
+							const unsigned long long bad = __ballot(in_run && ref != as_u32<T>(out));
+							if (!bad) break;
+							if (tries >= 3) { exact_form = true; break; }
+							const int f = __builtin_ctzll(bad);
+							if (lane == f) { fixed = true; fixedval = ref; }
+							from = f;
+						}
+						if (!exact_form) return;
 					}
 					for (int i = lo; i < hi; ++i) {
 						out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q);
