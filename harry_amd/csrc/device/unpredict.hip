@@ -418,13 +418,57 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		}
 	};
 	uint32_t *bigrow = queue;                 // 24 ids per lane of the tile, written by the lanes with more than two candidates
-	// value of an already reconstructed vertex that lies before the current batch
+	// value of an already reconstructed vertex that lies before the current batch.  ring_floor: the dense form below writes a
+	// batch's values into the ring WHILE the batch runs and may run it again -- the ring slot of vertex base + j is the slot of vertex
+	// base + j - ring_n, so sources that far back are read from the records there
+	uint32_t ring_floor = 0;
 	auto old_value = [&](uint32_t id, uint32_t base) -> U {
-		if (base - id <= ring_n && id >= seg_begin) return ring[id & mask];
+		if (base - id <= ring_n && id >= seg_begin && id >= ring_floor) return ring[id & mask];
 		if (id < seg_begin) wait_owner(xs, comp, id);
 		return far_load<U>(rec + (size_t)id * stride + off);
 	};
+	// value of a vertex with more than two candidates, evaluated on its own from the ring (every source is older than it): up to
+	// kCandMax candidates sit in its row (lane k evaluates candidate k, the mean and the selection run over them in table order);
+	// beyond that the fan is walked right here.  Uniform: every lane returns the same value.  row_lane: its lane in the tile.
+	auto many_candidates_value = [&](uint32_t v, uint32_t row_lane, uint32_t n0, uint32_t c0) -> T {
+		T pred = T(0);
+		if (n0 != 0xff) {
+			uint32_t pk = 0;
+			if ((uint32_t)lane < n0) {
+				const uint32_t *row = bigrow + row_lane * 24;
+				const uint32_t c0i = row[3 * lane], c1i = row[3 * lane + 1], c2i = row[3 * lane + 2];
+				pk = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(old_value(c0i, v)), cm::bits<T>(old_value(c1i, v)), cm::bits<T>(old_value(c2i, v)), q));
+			}
+			T pv[kCandMax];
+#pragma unroll
+			for (int k = 0; k < kCandMax; ++k) pv[k] = cm::bits<T>((U)rl(pk, k));
+			pred = chain_predict<T>(n0, pv);
+		} else {
+			W acc = 0;
+			uint32_t n = 0;
+			fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
+				acc = acc + (W)cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
+				++n;
+			});
+			if (n) {
+				T avg = (T)cm::mean_of(acc, (W)n);
+				if constexpr (!cm::is_fp<T>::value) pred = avg;
+				else {
+					T best = 3.402823466e+38f;
+					fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
+						T p = cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
+						T db = avg > best ? avg - best : best - avg;
+						T dp = avg > p ? avg - p : p - avg;
+						best = db < dp ? best : p;
+					});
+					pred = best;
+				}
+			}
+		}
+		return cm::value_from_residual<T>((U)c0, pred, q);
+	};
 	tile_request(0);
+	uint32_t dense_skip = 0;                     // float chain, dense form: batches that take the exact step at once after the short one kept failing
 	uint32_t fast_skip = 0, fast_backoff = 0;   // float chain: batches for which the speculative form is not tried after it failed
 	HRY_CLK(unsigned long long ck_p1 = 0, ck_p2 = 0, ck_p3 = 0, ck_prep = 0, ck_chain = 0, ck_verify = 0, ck_pub = 0, ck_exact = 0, ck_batches = 0, ck_nb = 0, ck_retry = 0, ck_exact_n = 0, ck_bigs = 0, ck_general = 0, ck_t = 0, ck_bigt = 0, ck_gen_n = 0, ck_gen_nb = 0;
 	        const unsigned long long ck_begin = __builtin_amdgcn_s_memtime();)
@@ -466,48 +510,98 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		nc = in_range ? nc : 0u;
 		uint32_t nb = tile_n - pos;
 		const uint64_t big = __ballot(nc > 2);
-		if (big & 1ull) {
-			// More than two candidates: this vertex is evaluated on its own; every source is older than it.  Up to
-			// kCandMax candidates sit in the table (lane k evaluates candidate k, the mean and the selection run over
-			// them in table order); beyond that the fan is walked right here (uniform work).
-			const uint32_t v = base;
-			const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nc);
-			T pred = T(0);
-			if (n0 != 0xff) {
-				uint32_t pk = 0;
-				if ((uint32_t)lane < n0) {
-					const uint32_t *row = bigrow + pos * 24;
-					const uint32_t c0i = row[3 * lane], c1i = row[3 * lane + 1], c2i = row[3 * lane + 2];
-					pk = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(old_value(c0i, v)), cm::bits<T>(old_value(c1i, v)), cm::bits<T>(old_value(c2i, v)), q));
-				}
-				T pv[kCandMax];
+		if constexpr (std::is_same<T, float>::value) {
+			// ---- mixed-polygon meshes (BASELINE configs[3] / [4]): a quad brings two new vertices and the second one's parallelograms
+			// read both, one vertex in twelve has more than two candidates -- "chained" runs are eight long there and every cut
+			// costs a batch start.  Where such vertices come thick the rest of the tile is ONE batch in the general form: at step
+			// i lane i's value is final and is broadcast (every lane that waits for vertex i picks it up; it also goes into the
+			// ring), a vertex with many candidates is evaluated at its own step from the ring.  The step is the SHORT form of the
+			// arithmetic (as in the run form below), verified exactly after the batch: every lane holds the final values of its
+			// sources then and evaluates the reference arithmetic on them; the many-candidate values are exact functions of what was
+			// broadcast before them, so all are right iff every lane agrees.
+			const uint32_t nbf = tile_n - pos;
+			const uint64_t in_mask = nbf >= 64 ? ~0ull : (1ull << nbf) - 1ull;
+			const uint64_t bigm = big & in_mask;
+			if ((uint32_t)__builtin_popcountll(bigm) * 16u > nbf) {
+				ring_floor = base + 64u > ring_n ? base + 64u - ring_n : 0u;
+				const bool isbig = nc > 2;
+				const uint32_t nc2 = isbig ? 0u : nc;
+				uint32_t dsrc[6], dtag[6], far_any = 0;
 #pragma unroll
-				for (int k = 0; k < kCandMax; ++k) pv[k] = cm::bits<T>((U)rl(pk, k));
-				pred = chain_predict<T>(n0, pv);
-			} else {
-				W acc = 0;
-				uint32_t n = 0;
-				fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-					acc = acc + (W)cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
-					++n;
-				});
-				if (n) {
-					T avg = (T)cm::mean_of(acc, (W)n);
-					if constexpr (!cm::is_fp<T>::value) pred = avg;
-					else {
-						T best = 3.402823466e+38f;
-						fan_ids(tp, order_v[v], v, [&](uint32_t a, uint32_t b, uint32_t o) {
-							T p = cm::parallelogram<T>(cm::bits<T>(old_value(a, v)), cm::bits<T>(old_value(b, v)), cm::bits<T>(old_value(o, v)), q);
-							T db = avg > best ? avg - best : best - avg;
-							T dp = avg > p ? avg - p : p - avg;
-							best = db < dp ? best : p;
-						});
-						pred = best;
-					}
+				for (int s6 = 0; s6 < 6; ++s6) {
+					const uint32_t id = ids[s6];
+					const uint32_t ringv = (uint32_t)ring[id & mask];
+					const bool valid = (uint32_t)(s6 / 3) < nc2;
+					const bool inb = valid & (id >= base), old = valid & (id < base);
+					far_any |= (old & ((base - id > ring_n) | (id < seg_begin))) ? 1u : 0u;
+					dsrc[s6] = old ? ringv : 0u;
+					dtag[s6] = inb ? id - base : kNoLane;
 				}
+				if (__ballot(far_any != 0)) {
+#pragma unroll
+					for (int s6 = 0; s6 < 6; ++s6) {
+						const uint32_t id = ids[s6];
+						if ((uint32_t)(s6 / 3) < nc2 && id < base && ((base - id > ring_n) | (id < seg_begin))) {
+							if (id < seg_begin) wait_owner(xs, comp, id);
+							dsrc[s6] = (uint32_t)far_load<U>(rec + (size_t)id * stride + off);
+						}
+					}
+					__builtin_amdgcn_s_waitcnt(0);
+				}
+				LaneEval<T> dev;
+				dev.setup(nc2, code, q);
+				if (nc2 == 1) {   // a lone candidate is both candidates of the short form (the mean of p and p is p)
+#pragma unroll
+					for (int j = 0; j < 3; ++j) { dsrc[3 + j] = dsrc[j]; dtag[3 + j] = dtag[j]; }
+				}
+				const uint32_t half = code >> 1, delta = (code & 1u) ? 0u - half - 1u : half;
+				bool fixed = nc2 == 0;                           // no candidate: the residual code is the value (exact); many: its own step
+				uint32_t fixedval = dev.eval(dsrc), myval = 0;
+				uint32_t from = 0;
+				bool exact_steps = dense_skip != 0;      // the stretch keeps failing (a coordinate that is 0 everywhere): the exact step at once
+				for (uint32_t tries = 0;; ++tries) {
+					for (uint32_t i = from; i < nbf; ++i) {
+						uint32_t sv;
+						if ((bigm >> i) & 1ull) {
+							sv = cm::bits<uint32_t>(many_candidates_value(base + i, pos + i, rl(nc, i), rl(code, i)));
+						} else if (exact_steps) {
+							sv = rl(dev.eval(dsrc), i);
+						} else {
+							const float p0 = cm::bits<float>(dsrc[0]) + (cm::bits<float>(dsrc[1]) - cm::bits<float>(dsrc[2]));
+							const float p1 = cm::bits<float>(dsrc[3]) + (cm::bits<float>(dsrc[4]) - cm::bits<float>(dsrc[5]));
+							const float avg = __builtin_fmaf(p0, 0.5f, 0.5f * p1);
+							const float e = __builtin_fabsf(avg - p0) - __builtin_fabsf(avg - p1);
+							const uint32_t pb = (int32_t)cm::bits<uint32_t>(e) < 0 ? cm::bits<uint32_t>(p0) : cm::bits<uint32_t>(p1);   // ties go to the later candidate
+							const uint32_t m = (uint32_t)((int32_t)pb >> 31);
+							const uint32_t cheap = ((delta ^ m) + pb) - m;
+							sv = rl(fixed ? fixedval : cheap, i);
+						}
+						myval = (uint32_t)lane == i ? sv : myval;
+#pragma unroll
+						for (int j = 0; j < 6; ++j) dsrc[j] = dtag[j] == i ? sv : dsrc[j];
+						if (lane == 0) ring[(base + i) & mask] = (U)sv;
+					}
+					if (exact_steps) break;                                // (every value is the reference arithmetic on final sources)
+					const uint32_t ref = dev.eval(dsrc);
+					const uint64_t bad = __ballot((uint32_t)lane < nbf && !isbig && ref != myval);
+					if (!bad) break;
+					const uint32_t f = (uint32_t)__builtin_ctzll(bad);     // every lane before f is right, so ref of lane f is its exact value
+					if ((uint32_t)lane == f) { fixed = true; fixedval = ref; }
+					from = f;
+					if (tries >= 2) { exact_steps = true; dense_skip = 8; }   // the rest of the batch, and the next batches, in the exact step
+				}
+				if (dense_skip) --dense_skip;
+				ring_floor = 0;
+				if ((uint32_t)lane < nbf) stq<T>(rec + (size_t)(base + lane) * stride + off, cm::bits<T>((U)myval));
+				pos += nbf;
+				HRY_CLK(++ck_batches; ck_nb += nbf; ck_general += __builtin_amdgcn_s_memtime() - ck_t; ++ck_gen_n; ck_gen_nb += nbf;)
+				continue;
 			}
-			const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)code);
-			T val = cm::value_from_residual<T>((U)c0, pred, q);
+		}
+		if (big & 1ull) {
+			// More than two candidates: this vertex is evaluated on its own; every source is older than it.
+			const uint32_t v = base;
+			const T val = many_candidates_value(v, pos, (uint32_t)__builtin_amdgcn_readfirstlane((int)nc), (uint32_t)__builtin_amdgcn_readfirstlane((int)code));
 			if (lane == 0) {
 				stq<T>(rec + (size_t)v * stride + off, val);
 				ring[v & mask] = cm::bits<U>(val);

@@ -76,4 +76,12 @@ if "--no-verify" not in sys.argv:
     ref = op.Mesh.from_hry(ob)
     ok = np.array_equal(dec.org(), ref.org()) and np.array_equal(dec.list_data(1), ref.list_data(1)) and np.array_equal(dec.face_offsets(), ref.face_offsets())
     print(f"oracle check {'OK' if ok else 'MISMATCH'} ({time.time()-t:.1f}s)")
+    if not ok:
+        a, b = dec.list_data(1).view(np.uint32).reshape(-1, 3), ref.list_data(1).view(np.uint32).reshape(-1, 3)
+        bad = np.flatnonzero((a != b).any(axis=1))
+        print(f"  {len(bad)} vertex records differ; first {bad[:12].tolist()} last {bad[-4:].tolist()}; columns {np.flatnonzero((a != b).any(axis=0)).tolist()}")
+        for v in bad[:6]:
+            print(f"    v {v}: got {a[v].tolist()} want {b[v].tolist()}")
+        d = np.diff(bad)
+        print(f"  gaps between bad vertices: min {d.min() if len(d) else 0}, runs of consecutive: {int((d == 1).sum())}")
     assert ok
