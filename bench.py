@@ -332,7 +332,7 @@ def main():
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 6) if roof["achieved"] else None
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
         # timed program; scripts/collect_profiles.sh collects FETCH_SIZE and WRITE_SIZE in their own passes on this workload)
-        for rnd in ("r2", "r1"):
+        for rnd in ("r3", "r2", "r1"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
                     tr = json.load(f)["kernels"]

@@ -6,6 +6,7 @@
 #         float1m   scripts/float_chain_time.py 708          the same torus lossless: ONE component, k_unpredict2<float>
 #         cfg4share tests/tools/cfg4_check.py 128 221 222    one GPU's share of configs[3]: 128 components, lossless
 #         cfg0      scripts/cfg0_time.py                     bunny-class stand-in, lossless, both profiles
+#         floatmixed scripts/float_chain_time.py 708 --mixed  ONE mixed-polygon component (40 % quads, 5 % pentagons), lossless
 set -u
 TAG=${1:-r3}
 ROOT=$(pwd)
@@ -29,10 +30,18 @@ leg configs1 $ROOT/scripts/quick_chunked.py 708
 leg float1m $ROOT/scripts/float_chain_time.py 708
 leg cfg4share $ROOT/tests/tools/cfg4_check.py 128 221 222 --no-verify
 leg cfg0 $ROOT/scripts/cfg0_time.py
+leg floatmixed $ROOT/scripts/float_chain_time.py 708 --mixed
+# the OBJ / general-bindings path (row f-3): timing + kernel statistics
+python3 $ROOT/scripts/obj_time.py 300 > $OUT/obj_time.txt 2>&1
+mkdir -p $OUT/obj
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/obj/kstats -- python3 $ROOT/scripts/obj_time.py 300 > $OUT/obj/kstats.log 2>&1
+# both bench modes rehearsed with ranks / contexts sharing this box's one GPU (code paths, not measurements)
+python3 $ROOT/bench.py --gpus 2 --share-device --comps-per-gpu 16 --steps 3 --warmup 1 > $OUT/rehearsal_inprocess_2ctx_one_gpu.json 2> $OUT/rehearsal_inprocess.err
+HRY_BENCH_SHARE_GPU=1 python3 $ROOT/bench.py --gpus 2 --launcher --comps-per-gpu 16 --steps 2 --warmup 1 2> $OUT/rehearsal_ranks.err | grep '^{' > $OUT/rehearsal_2ranks_one_gpu.json
 cd $ROOT
 # passes of the workload per run (what traffic.json divides by): quick_chunked 3 encode + decode; float_chain_time 1 encode + 4
 # decodes (divide by the decodes: the decode kernels are the subject); cfg4_check 2; cfg0_time 3 per profile
-for lp in bench:1 configs1:3 float1m:4 cfg4share:2 cfg0:3; do
+for lp in bench:1 configs1:3 float1m:4 cfg4share:2 cfg0:3 floatmixed:4 obj:1; do
 	l=${lp%%:*}; n=${lp##*:}
 	echo "==== $l" >> $OUT/summary.txt
 	python3 scripts/summarise_profiles.py $OUT/$l $n >> $OUT/summary.txt 2>&1
