@@ -294,14 +294,13 @@ int hry_container_info(const uint8_t *hry, size_t n, uint32_t info[8])
 		info[0] = (uint32_t)minor; info[1] = (uint32_t)hdr; info[2] = m.nv; info[3] = m.nf; info[4] = m.declared_ne; info[7] = 1;
 		size_t body = hdr;
 		if (minor == 3) {
-			if (n < hdr + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
-			memcpy(&info[7], hry + hdr, 4);
-			if (info[7] == 0) return;
-			body = hdr + 4 + 8ull * info[7];
-			if (n < body + 4) throw Error(HRY_E_FORMAT, "truncated sharded container");
-			uint32_t nr;
-			memcpy(&nr, hry + body, 4);
-			body += 4 + 24ull * nr;
+			ShardedDirectory dir;
+			std::vector<uint32_t> counts;
+			for (const AttrList &L : m.lists) counts.push_back(L.count);
+			parse_sharded_directory(hry, n, hdr, m.nv, m.nf, m.declared_ne, dir, true, m.general ? &counts : nullptr);
+			info[7] = (uint32_t)dir.segments.size();
+			if (dir.segments.empty()) return;
+			body = dir.segments[0].offset + dir.segments[0].body_at;   // (general bindings: runs carry their record ranges)
 		}
 		if (minor >= 2) {
 			if (n < body + 8) throw Error(HRY_E_FORMAT, "truncated chunked directory");
