@@ -93,3 +93,58 @@ def test_single_group_cannot_be_split():
 def test_merge_rejects_foreign_input():
     with pytest.raises(hc.HryError):
         hc.merge([b"not a container"])
+
+
+# ---- general bindings (OBJ scenes): components tied by shared records, record ranges of the runs --------------------------------
+_TWO_PARTS_SHARING_A_NORMAL = b"""v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 3 0 0
+v 4 0 0
+v 4 1 0
+v 6 0 0
+v 7 0 1
+v 7 1 0
+vn 0 0 1
+vn 0.6 0 0.8
+f 1//1 2//1 3//1 4//1
+f 5//1 6//1 7//1
+f 8//2 9//2 10//2
+"""
+
+
+def test_general_plan_ties_components_that_share_a_record():
+    whole = hc.Mesh.from_obj(_TWO_PARTS_SHARING_A_NORMAL, "")
+    assert whole.general
+    plan = hc.ShardPlan(whole, 2)
+    assert plan.ncomponents == 3 and plan.ngroups == 2          # the two parts with "vn 1" are one group, the third is free
+    shards = [plan.extract(whole, s) for s in range(2)]
+    assert sorted(sh.nf for sh in shards) == [1, 2]
+    nl = whole.nlists
+    for sh in shards:
+        assert sh.general and sh.nlists == nl
+        # every element of a shard names records of the shard
+        for l in range(nl):
+            if sh.list_target(l) == 3:
+                continue
+            rec_of = sh.shard_elements(16 + l)
+            assert len(rec_of) == sh.list_count(l)
+            assert np.array_equal(sh.list_data(l), whole.list_data(l)[rec_of])
+        b = sh.bindings(2)
+        for l in range(nl):
+            if sh.list_target(l) == 2 and sh.list_count(l):
+                assert b.max() < max(sh.list_count(x) for x in range(nl))
+    # the two shards' records of every list partition the whole list
+    for l in range(nl):
+        if whole.list_target(l) == 3:
+            continue
+        both = np.concatenate([sh.shard_elements(16 + l) for sh in shards])
+        assert sorted(both.tolist()) == list(range(whole.list_count(l)))
+
+
+def test_container_check_is_host_only_and_rejects_garbage():
+    with pytest.raises(hc.HryError):
+        hc.container_check(b"\xfa\xff\xaf\xaf\x00\x03" + b"\x00" * 8)
+    with pytest.raises(hc.HryError):
+        hc.container_check(b"not a container")
