@@ -887,6 +887,25 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	ComponentAnalysis A;
+	const ShardInfo &sh = m.shard;
+	const uint32_t shc = (uint32_t)sh.comp_faces.size();
+	if (shc >= 2 && sh.seeds.size() == shc && sh.comp_halfedges.size() == shc && sh.comp_fresh.size() == shc && sh.comp_group.size() == shc) {
+		// a shard brings its components along (host/shard.cpp): labels, sizes, the vertices each one introduces, the ties -- the planner
+		// found them on the whole mesh.  The first one has just been walked; the others keep their order.
+		A.ncomp = shc - 1;   // (the walks below need the seeds, the sizes and the ties, not the per-face labels)
+		A.by_rank.resize(A.ncomp); A.rank_of.resize(A.ncomp);
+		A.seed.resize(A.ncomp); A.n_faces.resize(A.ncomp); A.n_halfedges.resize(A.ncomp); A.fresh.resize(A.ncomp); A.group.resize(A.ncomp);
+		uint32_t first_of_group0 = NONE32;   // the first component's group loses its root: the smallest rank left takes over
+		for (uint32_t k = 0; k < A.ncomp; ++k) {
+			A.by_rank[k] = A.rank_of[k] = k;
+			A.seed[k] = sh.seeds[k + 1]; A.n_faces[k] = sh.comp_faces[k + 1]; A.n_halfedges[k] = sh.comp_halfedges[k + 1]; A.fresh[k] = sh.comp_fresh[k + 1];
+			const uint32_t g = sh.comp_group[k + 1];
+			if (g > k + 1) throw Error(HRY_E_ARG, "shard: a group's root comes after its member");
+			if (g == 0) { if (first_of_group0 == NONE32) first_of_group0 = k; A.group[k] = first_of_group0; }
+			else A.group[k] = g - 1;
+		}
+		mark("components taken from the shard's plan");
+	} else
 	analyse_impl<DEG>(m, eface_tab, (const uint8_t*)st.gone.data(), st.sent.data(), n_threads, A);
 	const uint32_t ncomp = A.ncomp;
 	const std::vector<uint32_t> &group_of = A.group;

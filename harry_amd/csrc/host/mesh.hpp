@@ -108,6 +108,9 @@ struct ShardInfo {
 	                                         // reference's start-face rule, writer.cc:40-46, which depends on the full face count)
 	std::vector<ShardRun> runs;              // in coding order; the shard's own numbering lays them out back to back
 	std::vector<uint32_t> vertex_of, face_of; // input index in the full mesh of every vertex / face of the shard (bounds ties, tests)
+	// what the planner already knows about the shard's components, in their coding order (= the order of `seeds`): sizes, the
+	// vertices each one introduces, the ties -- the walk on several threads takes them instead of labelling the components again
+	std::vector<uint32_t> comp_faces, comp_halfedges, comp_fresh, comp_group;   // per component; group = smallest rank tied to it
 	// general bindings (regions, shared records, corner lists): the records of every list are numbered by the decoder in the order
 	// they are first coded (attrcode.h:443-531: cur_idx), across all components -- so every run also has its place in that
 	// numbering, per list: run_records[run * 2 * nlists + 2 * l] = first record, [... + 1] = records the run creates.

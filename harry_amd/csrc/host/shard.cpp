@@ -312,7 +312,18 @@ Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 			else for (uint32_t i = b; i < e; ++i) memcpy(D.data.data() + (size_t)i * st, L.data.data() + (size_t)src[i] * st, st);
 		});
 	}
-	// components of the shard in coding order: seeds and runs
+	// components of the shard in coding order: seeds and runs, and what the walk would otherwise find out again (labels, sizes, ties)
+	std::vector<uint32_t> local_rank(nc, NONE32);
+	{
+		uint32_t n = 0;
+		for (uint32_t k = 0; k < nc; ++k) if (plan.shard_of[k] == shard) local_rank[k] = n++;
+		s.shard.comp_faces.reserve(n); s.shard.comp_halfedges.reserve(n); s.shard.comp_fresh.reserve(n); s.shard.comp_group.reserve(n);
+		for (uint32_t k = 0; k < nc; ++k) {
+			if (plan.shard_of[k] != shard) continue;
+			s.shard.comp_faces.push_back(A.n_faces[k]); s.shard.comp_halfedges.push_back(A.n_halfedges[k]); s.shard.comp_fresh.push_back(A.fresh[k]);
+			s.shard.comp_group.push_back(local_rank[A.group[k]]);   // (a group lies in one shard: its root is here too, and comes first)
+		}
+	}
 	bool open = false;
 	for (uint32_t k = 0; k < nc; ++k) {
 		if (plan.shard_of[k] != shard) { open = false; continue; }
