@@ -488,7 +488,9 @@ int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_p
 		std::vector<RestartCounters> rcounters;
 		if (use_restart_points) restarts = select_restart_points(r.marks, r.named, rcounters);
 		std::vector<uint32_t> order_v;
-		cut_border_replay(m->m, planes, restarts, rcounters, order_v, w->seg_start, w->seg_level);
+		PlaneView views[21];
+		for (int k = 0; k < 21; ++k) views[k] = PlaneView(planes[k]);
+		cut_border_replay(m->m, views, restarts, rcounters, order_v, w->seg_start, w->seg_level);
 		w->w.order_v.assign(order_v.begin(), order_v.end());
 		w->info[0] = (uint32_t)restarts.size(); w->info[1] = 0;
 		*mesh = m.release();

@@ -94,6 +94,7 @@ struct Context {
 
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
+	PinBuf h_conn;                  // chunked decode: the connectivity planes, down for the host's replay
 	PinBuf h_rec, h_r, h_s;         // compat: symbol records down, (r, S) up, slice by slice (codec.cpp finish_stream)
 	std::vector<hipEvent_t> slice_ev;
 	std::map<std::string, std::vector<uint8_t>> stages;

@@ -164,7 +164,7 @@ struct Stager {
 		}
 	}
 };
-static bool pipelined_decode_applicable(const Mesh &m, const std::vector<RestartPoint> &restarts, const std::vector<uint8_t> *conn,
+static bool pipelined_decode_applicable(const Mesh &m, const std::vector<RestartPoint> &restarts, const PlaneView *conn,
                                         const ListDesc &ldv, uint32_t vc)
 {
 	if (getenv("HRY_NO_PIPELINE")) return false;
@@ -175,7 +175,7 @@ static bool pipelined_decode_applicable(const Mesh &m, const std::vector<Restart
 }
 
 // attr_upto[g]: the vertex planes are decoded up to this vertex once cx.attr_ev[g] has fired (the last entry covers everything)
-static void decode_pipelined(Context &cx, Mesh &mesh, const std::vector<uint8_t> *conn, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
+static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
                              const ListDesc &ldv, const ListDesc &ldf, std::vector<uint32_t> &order_v, const uint32_t (&attr_upto)[Context::kAttrGroups])
 {
 	Mesh *m = &mesh;
@@ -620,10 +620,18 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	HIP_OK(hipEventRecord(cx.ev[6], cx.stream3));
 	HIP_OK(hipEventRecord(cx.ev_x[1], cx.stream3));
 	if (trace_on()) { HIP_OK(hipEventSynchronize(cx.ev[2])); HRY_MARK(g_t0, "connectivity streams decoded"); }
-	std::vector<uint8_t> conn[kConnPlanes];
-	for (int k = 0; k < kConnPlanes; ++k) {
-		conn[k].resize(nsym[k]);
-		if (nsym[k]) HIP_OK(hipMemcpyAsync(conn[k].data(), cx.d_csyms.as<uint8_t>() + plane_off[k], nsym[k], hipMemcpyDeviceToHost, cx.stream));
+	// the connectivity planes come down into the context's pinned memory (one block, reused: fresh pageable vectors cost a zero
+	// fill, a page fault per 4 KiB and a staged copy -- 7 ms of a 51 ms decode on the configs[3] share)
+	PlaneView conn[kConnPlanes];
+	{
+		size_t at[kConnPlanes + 1] = { 0 };
+		for (int k = 0; k < kConnPlanes; ++k) at[k + 1] = at[k] + ((nsym[k] + 63) & ~(size_t)63);
+		cx.h_conn.ensure(std::max<size_t>(at[kConnPlanes], 64));
+		for (int k = 0; k < kConnPlanes; ++k) {
+			uint8_t *dst = cx.h_conn.as<uint8_t>() + at[k];
+			conn[k] = PlaneView(dst, nsym[k]);
+			if (nsym[k]) HIP_OK(hipMemcpyAsync(dst, cx.d_csyms.as<uint8_t>() + plane_off[k], nsym[k], hipMemcpyDeviceToHost, cx.stream));
+		}
 	}
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	const bool take_pipeline = !m->general && pipelined_decode_applicable(*m, restarts, conn, ldv, vc);

@@ -386,7 +386,7 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen_shared, uint32_t *order_v, Repl
 // replay_span, same results (the tests run both on the same inputs).
 // ---------------------------------------------------------------------------------------------------------
 template <bool LIVE>
-bool replay_triangles(Mesh &m, const std::vector<uint8_t> *conn, uint16_t *seen, uint32_t *order_v, ReplayCursor &cur,
+bool replay_triangles(Mesh &m, const PlaneView *conn, uint16_t *seen, uint32_t *order_v, ReplayCursor &cur,
                       std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs, ReplayLive *live)
 {
 	using namespace replay_detail;

@@ -9,12 +9,12 @@
 namespace hry {
 namespace {
 struct Planes {
-	const std::vector<uint8_t> *pl;   // container order: iop, elem[4], part[2], vertid[4], numtri[2], op[8]
+	const PlaneView *pl;   // container order: iop, elem[4], part[2], vertid[4], numtri[2], op[8]
 	size_t cur[21] = { 0 };
 	int fixed_numtri;
 	uint32_t byte(int plane)
 	{
-		const std::vector<uint8_t> &v = pl[plane];
+		const PlaneView &v = pl[plane];
 		if (cur[plane] >= v.size()) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)");
 		return v[cur[plane]++];
 	}
@@ -36,7 +36,7 @@ struct Planes {
 // state: plane cursors, next vertex id / face / half-edge, and the order counters of the older vertices the span names
 // (shared non-manifold vertices across the cut).  A span writes only the faces, half-edges and vertices it creates and counts
 // older vertices on its private copy of their counters, so every span runs on its own host thread.
-void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const std::vector<RestartPoint> &restarts,
+void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
                        std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
 {

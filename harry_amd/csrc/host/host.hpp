@@ -165,10 +165,24 @@ void set_thread_budget(unsigned n);
 // the CPUs of memory node `node` (nullptr: unknown / single node); block_pool.cpp
 const void *node_cpus(int node);
 
+// a byte plane of decoded connectivity symbols (the replay reads them where they landed: pinned memory of the context, or a vector)
+struct PlaneView {
+	const uint8_t *p = nullptr;
+	size_t n = 0;
+	PlaneView() = default;
+	PlaneView(const uint8_t *q, size_t c) : p(q), n(c) {}
+	PlaneView(const std::vector<uint8_t> &v) : p(v.data()), n(v.size()) {}
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	const uint8_t *data() const { return p; }
+	const uint8_t *begin() const { return p; }
+	const uint8_t *end() const { return p + n; }
+	uint8_t operator[](size_t i) const { return p[i]; }
+};
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
 // seg_start: first decode rank of every connected component (+ end sentinel); seg_level[k]: 0 = the component touches no vertex
 // coded before it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
-void cut_border_replay(Mesh &m, const std::vector<uint8_t> *conn_planes, const std::vector<RestartPoint> &restarts,
+void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
                        std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level);
 unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
