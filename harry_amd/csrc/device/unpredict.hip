@@ -338,8 +338,6 @@ template <> struct LaneEval<float> {
 
 template <typename T> __device__ __forceinline__ uint32_t ev_top(int q) { return (uint32_t)cm::ones<T>(q == 0 ? (int)sizeof(T) * 8 : q); }
 constexpr uint32_t kNoLane = 64;
-constexpr uint32_t kQueue = 256;        // vertices in the LDS input queue (4 tiles of 64)
-constexpr uint32_t kQueueCols = 26;     // 24 candidate ids, candidate count, residual code   // tag of a source that is already present
 
 #ifdef HRY_CHAIN_CLOCKS   // development: where the ticks of a chain go (wavefront 0 of every chain prints its sums)
 #define HRY_CLK(...) __VA_ARGS__
@@ -348,7 +346,9 @@ constexpr uint32_t kQueueCols = 26;     // 24 candidate ids, candidate count, re
 #endif
 // Chains of different connected components run in ONE launch.  A component that names vertices of an earlier one (shared
 // non-manifold vertices, cbm/encoder.h:79-113,187) reads their reconstructed values from the records; it waits until the chain
-// of that component -- same attribute component -- has raised its flag.  Workgroups start in the order of their indices and
+// of that component -- same attribute component -- has PROGRESSED past that vertex: done[] holds, per chain, the first vertex that
+// is not final yet (published every eighth tile and at the end; round 2: a flag at the end of the component, so a component glued
+// to the far end of another waited for all of it).  Workgroups start in the order of their indices and
 // a chain only ever waits for a component before it in coding order (= a lower workgroup index), which is therefore running
 // or finished: the waits cannot deadlock.  Bounded like every other wait of the chains (g_chain_timeout).
 struct CrossSync { const uint32_t *seg_start; uint32_t nseg; uint32_t *done; };   // done[attribute component * nseg + component of the mesh]
@@ -362,7 +362,7 @@ __device__ __attribute__((noinline)) void wait_owner(const CrossSync &xs, int c,
 	const uint32_t *flag = xs.done + (size_t)c * xs.nseg + lo;
 	uint32_t spins = 0;
 #pragma nounroll
-	while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+	while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= id) {
 		__builtin_amdgcn_s_sleep(8);
 		if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 4u); break; }
 	}
@@ -370,19 +370,20 @@ __device__ __attribute__((noinline)) void wait_owner(const CrossSync &xs, int c,
 // value of a vertex reconstructed by another chain or long ago by this one: past this compute unit's L1 (the line may have been
 // cached while a neighbouring attribute component of the same record was still unwritten)
 template <typename U> __device__ __forceinline__ U far_load(const uint8_t *addr) { return __hip_atomic_load((const U*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void raise_flag(const CrossSync &xs, int c, uint32_t seg_idx)
+// upto: every vertex of the chain below it is final in the records
+__device__ __forceinline__ void raise_flag(const CrossSync &xs, int c, uint32_t seg_idx, uint32_t upto)
 {
 	__syncthreads();
-	if (threadIdx.x == 0 && xs.done) {
-		__threadfence();   // the chain's stores into the records are visible device-wide before the flag
-		__hip_atomic_store(xs.done + (size_t)c * xs.nseg + seg_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (xs.done) {
+		__threadfence();   // every lane's stores into the records are visible device-wide before the progress word
+		if (threadIdx.x == 0) __hip_atomic_store(xs.done + (size_t)c * xs.nseg + seg_idx, upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
 template <typename T>
 __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                      const uint8_t *planes, uint8_t *rec, int stride, int off, int q, int plane0,
-                                     typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n, uint32_t *queue, const CrossSync &xs, int comp)
+                                     typename cm::word<sizeof(T)>::u *ring, uint32_t ring_n, uint32_t *queue, const CrossSync &xs, int comp, uint32_t seg_idx)
 {
 	// this call reconstructs the vertices [seg_begin, nvtx) of one component; the ring holds only vertices >= seg_begin.
 	// The workgroup is ONE wavefront: its LDS accesses execute in program order, no barrier is needed anywhere.
@@ -1003,6 +1004,12 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		pos += nb;
 		HRY_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_pub += n - ck_t; ++ck_batches; ck_nb += nb; })
 	}
+	// progress for the chains of later components that name vertices of this one (long components only: the fence costs a
+	// microsecond or two)
+	if (xs.done && (tile & 7u) == 7u && tile + 1 < n_tiles) {
+		__threadfence();
+		if (lane == 0) __hip_atomic_store(xs.done + (size_t)comp * xs.nseg + seg_idx, tile_base + tile_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 	}
 	HRY_CLK(if (lane == 0 && ck_batches > 100) printf("chain2 comp %d: %llu vertices, %llu batches (mean %llu), bigs %llu, retries %llu, exact batches %llu | per batch: prep %llu (commit %llu, to sources %llu) chain %llu verify %llu exact %llu general %llu publish %llu | bigs at %llu, %llu general batches (mean %llu) | total %llu per vertex %llu\n",
 	        comp, (unsigned long long)(nvtx - seg_begin), ck_batches, ck_nb / ck_batches, ck_bigs, ck_retry, ck_exact_n, ck_prep / ck_batches, ck_p1 / ck_batches, ck_p2 / ck_batches, ck_chain / ck_batches, ck_verify / ck_batches, ck_exact / ck_batches,
@@ -1027,8 +1034,8 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 		if (b < e)
 			unpredict2_component<T>(tp, order_v, nvtx, b, e, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
 			                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T),
-			                        (uint32_t*)((uint8_t*)ring_raw2 + ring_bytes), xs, c);
-		raise_flag(xs, c, segs[3 * k + 2]);
+			                        (uint32_t*)((uint8_t*)ring_raw2 + ring_bytes), xs, c, segs[3 * k + 2]);
+		raise_flag(xs, c, segs[3 * k + 2], e);
 	}
 }
 
@@ -1564,7 +1571,7 @@ __global__ __launch_bounds__(512) void k_unpredict3(ConnView cv, const uint32_t 
 	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
 		const uint32_t b = segs[3 * k], e = segs[3 * k + 1];
 		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, b, sync3, xs, c);
-		raise_flag(xs, c, segs[3 * k + 2]);
+		raise_flag(xs, c, segs[3 * k + 2], e);
 	}
 }
 template <typename T>
@@ -1723,7 +1730,9 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64 * chain_waves(nvtx)), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
 		                   segs, list_off, xs);
 	};
-	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + kQueue * kQueueCols * 4;
+	// the ring + the rows of a tile's many-candidate vertices (64 x 24 words): 38 KB, four chains per compute unit (round 2's input
+	// queue made it 58 KB and two)
+	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + 64 * kCandMax * 3 * 4;
 	auto go = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
