@@ -347,9 +347,9 @@ constexpr uint32_t kNoLane = 64;
 // Chains of different connected components run in ONE launch.  A component that names vertices of an earlier one (shared
 // non-manifold vertices, cbm/encoder.h:79-113,187) reads their reconstructed values from the records; it waits until the chain
 // of that component -- same attribute component -- has PROGRESSED past that vertex: done[] holds, per chain, the first vertex that
-// is not final yet (published every eighth tile and at the end; round 2: a flag at the end of the component, so a component glued
-// to the far end of another waited for all of it).  Workgroups start in the order of their indices and
-// a chain only ever waits for a component before it in coding order (= a lower workgroup index), which is therefore running
+// is not final yet, published when the component's chain ends (publishing every eighth tile as well was measured in round 3: the fence
+// it needs also waits for the next tile's prefetch, +4.5 % on a lone chain, and the configs[3] share gained nothing from it).
+// Workgroups start in the order of their indices and a chain only ever waits for a component before it in coding order (= a lower workgroup index), which is therefore running
 // or finished: the waits cannot deadlock.  Bounded like every other wait of the chains (g_chain_timeout).
 struct CrossSync { const uint32_t *seg_start; uint32_t nseg; uint32_t *done; };   // done[attribute component * nseg + component of the mesh]
 __device__ uint32_t g_chain_timeout;
@@ -1003,12 +1003,6 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		}
 		pos += nb;
 		HRY_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_pub += n - ck_t; ++ck_batches; ck_nb += nb; })
-	}
-	// progress for the chains of later components that name vertices of this one (long components only: the fence costs a
-	// microsecond or two)
-	if (xs.done && (tile & 7u) == 7u && tile + 1 < n_tiles) {
-		__threadfence();
-		if (lane == 0) __hip_atomic_store(xs.done + (size_t)comp * xs.nseg + seg_idx, tile_base + tile_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	}
 	HRY_CLK(if (lane == 0 && ck_batches > 100) printf("chain2 comp %d: %llu vertices, %llu batches (mean %llu), bigs %llu, retries %llu, exact batches %llu | per batch: prep %llu (commit %llu, to sources %llu) chain %llu verify %llu exact %llu general %llu publish %llu | bigs at %llu, %llu general batches (mean %llu) | total %llu per vertex %llu\n",
