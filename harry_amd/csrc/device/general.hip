@@ -223,6 +223,88 @@ __device__ __forceinline__ T predict_from(int ns, int q, const T (&val)[CAP])
 		});
 }
 
+// ---- one step of the short form of a float corner record (chain_component below), hand-scheduled -------------------------------
+// Every lane: mean of its NN sources (weights 1 / 0: slots past the record's own count hold 3e38 with weight 0), the LAST source
+// at the smallest distance from the mean (the reference's sweep keeps the later one on equal distances, attrcode.h:193-205), the
+// residual code on that source's bits (near: +- delta by its sign; constant lanes: one of two constants by its sign), then lane
+// `step` broadcasts its value and every lane takes it into the slots that wait for that record.  Written as one block so that no
+// wait state is spent: a VALU-written SGPR needs two other instructions before the VALU reads it (the compiler's version of this
+// loop carried nine s_nop and 68 issue slots at 6 sources; this one 49).  Temporaries: v236-v248, s86-s96, vcc.
+#define HRY_GS_SUM(k)   "v_fma_f32 v236, %[v" #k "], %[w" #k "], v236\n\t"
+#define HRY_GS_DIST(k)  "v_sub_f32 v24" #k ", v237, %[v" #k "]\n\t"
+#define HRY_GS_MIN(k)   "v_min_f32_e64 v238, v238, |v24" #k "|\n\t"
+#define HRY_GS_EQ(k, sp)   "v_cmp_eq_f32_e64 " sp ", |v24" #k "|, v238\n\t"
+#define HRY_GS_TAKE(k, sp) "v_cndmask_b32_e64 v239, v239, %[v" #k "], " sp "\n\t"
+#define HRY_GS_HIT(k, sp)  "v_cmp_eq_u32_e64 " sp ", %[step], %[s" #k "]\n\t"
+#define HRY_GS_PICK(k, sp) "v_cndmask_b32_e64 %[v" #k "], %[v" #k "], v246, " sp "\n\t"
+#define HRY_GS_HEAD     "v_mul_f32 v236, %[v0], %[w0]\n\t"
+#define HRY_GS_MEAN     "v_mul_f32 v237, v236, %[rcp]\n\t"
+#define HRY_GS_VALUE \
+	"v_ashrrev_i32 v247, 31, v239\n\t" \
+	"v_xad_u32 v248, %[delta], v247, v239\n\t" \
+	"v_bfi_b32 v236, v247, %[aneg], %[apos]\n\t" \
+	"v_sub_u32 v248, v248, v247\n\t" \
+	"v_bfi_b32 %[out], %[cmask], v236, v248\n\t"
+#define HRY_GS_CAST     "v_readlane_b32 s96, %[out], %[step]\n\t"
+#define HRY_GS_CLOBBER : "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", \
+	"s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "vcc"
+#define HRY_GS_IO(k) [v##k] "+v"(v[k])
+#define HRY_GS_IN(k) [w##k] "v"(w[k]), [s##k] "v"(slot[k])
+template <int NN, int CV, int CW>
+__device__ __forceinline__ uint32_t short_step(float (&v)[CV], const uint32_t (&slot)[CV], const float (&w)[CW], float rcp, uint32_t delta, uint32_t cmask,
+                                               uint32_t apos, uint32_t aneg, int step)
+{
+	static_assert(NN >= 2 && NN <= 6 && NN <= CV && NN <= CW, "sources");
+	uint32_t out;
+	if constexpr (NN == 2)
+		asm volatile(HRY_GS_HEAD HRY_GS_SUM(1) HRY_GS_MEAN HRY_GS_DIST(0) HRY_GS_DIST(1) "v_min_f32_e64 v238, |v240|, |v241|\n\t" "v_mov_b32 v239, %[v0]\n\t"
+		             HRY_GS_EQ(1, "vcc") "s_nop 1\n\t" HRY_GS_TAKE(1, "vcc") HRY_GS_VALUE
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") "s_nop 0\n\t" "v_mov_b32 v246, s96\n\t" HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1)
+		             : HRY_GS_IN(0), HRY_GS_IN(1), [rcp] "v"(rcp), [delta] "v"(delta), [cmask] "v"(cmask), [apos] "v"(apos), [aneg] "v"(aneg), [step] "s"(step) HRY_GS_CLOBBER);
+	else if constexpr (NN == 3)
+		asm volatile(HRY_GS_HEAD HRY_GS_SUM(1) HRY_GS_SUM(2) HRY_GS_MEAN HRY_GS_DIST(0) HRY_GS_DIST(1) HRY_GS_DIST(2) "v_min_f32_e64 v238, |v240|, |v241|\n\t" HRY_GS_MIN(2)
+		             "v_mov_b32 v239, %[v0]\n\t" HRY_GS_EQ(1, "vcc") HRY_GS_EQ(2, "s[88:89]") "s_nop 0\n\t" HRY_GS_TAKE(1, "vcc") HRY_GS_TAKE(2, "s[88:89]") HRY_GS_VALUE
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") "v_mov_b32 v246, s96\n\t"
+		             HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2)
+		             : HRY_GS_IN(0), HRY_GS_IN(1), HRY_GS_IN(2), [rcp] "v"(rcp), [delta] "v"(delta), [cmask] "v"(cmask), [apos] "v"(apos), [aneg] "v"(aneg), [step] "s"(step) HRY_GS_CLOBBER);
+	else if constexpr (NN == 4)
+		asm volatile(HRY_GS_HEAD HRY_GS_SUM(1) HRY_GS_SUM(2) HRY_GS_SUM(3) HRY_GS_MEAN HRY_GS_DIST(0) HRY_GS_DIST(1) HRY_GS_DIST(2) HRY_GS_DIST(3)
+		             "v_min_f32_e64 v238, |v240|, |v241|\n\t" HRY_GS_MIN(2) HRY_GS_MIN(3) "v_mov_b32 v239, %[v0]\n\t"
+		             HRY_GS_EQ(1, "vcc") HRY_GS_EQ(2, "s[88:89]") HRY_GS_EQ(3, "s[90:91]") HRY_GS_TAKE(1, "vcc") HRY_GS_TAKE(2, "s[88:89]") HRY_GS_TAKE(3, "s[90:91]") HRY_GS_VALUE
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") HRY_GS_HIT(3, "s[92:93]") "v_mov_b32 v246, s96\n\t"
+		             HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]") HRY_GS_PICK(3, "s[92:93]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2), HRY_GS_IO(3)
+		             : HRY_GS_IN(0), HRY_GS_IN(1), HRY_GS_IN(2), HRY_GS_IN(3), [rcp] "v"(rcp), [delta] "v"(delta), [cmask] "v"(cmask), [apos] "v"(apos), [aneg] "v"(aneg), [step] "s"(step) HRY_GS_CLOBBER);
+	else if constexpr (NN == 5)
+		asm volatile(HRY_GS_HEAD HRY_GS_SUM(1) HRY_GS_SUM(2) HRY_GS_SUM(3) HRY_GS_SUM(4) HRY_GS_MEAN HRY_GS_DIST(0) HRY_GS_DIST(1) HRY_GS_DIST(2) HRY_GS_DIST(3) HRY_GS_DIST(4)
+		             "v_min_f32_e64 v238, |v240|, |v241|\n\t" HRY_GS_MIN(2) HRY_GS_MIN(3) HRY_GS_MIN(4) "v_mov_b32 v239, %[v0]\n\t"
+		             HRY_GS_EQ(1, "vcc") HRY_GS_EQ(2, "s[88:89]") HRY_GS_EQ(3, "s[90:91]") HRY_GS_EQ(4, "s[92:93]")
+		             HRY_GS_TAKE(1, "vcc") HRY_GS_TAKE(2, "s[88:89]") HRY_GS_TAKE(3, "s[90:91]") HRY_GS_TAKE(4, "s[92:93]") HRY_GS_VALUE
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") HRY_GS_HIT(3, "s[92:93]") HRY_GS_HIT(4, "s[94:95]") "v_mov_b32 v246, s96\n\t"
+		             HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]") HRY_GS_PICK(3, "s[92:93]") HRY_GS_PICK(4, "s[94:95]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2), HRY_GS_IO(3), HRY_GS_IO(4)
+		             : HRY_GS_IN(0), HRY_GS_IN(1), HRY_GS_IN(2), HRY_GS_IN(3), HRY_GS_IN(4), [rcp] "v"(rcp), [delta] "v"(delta), [cmask] "v"(cmask), [apos] "v"(apos), [aneg] "v"(aneg), [step] "s"(step) HRY_GS_CLOBBER);
+	else
+		asm volatile(HRY_GS_HEAD HRY_GS_SUM(1) HRY_GS_SUM(2) HRY_GS_SUM(3) HRY_GS_SUM(4) HRY_GS_SUM(5) HRY_GS_MEAN
+		             HRY_GS_DIST(0) HRY_GS_DIST(1) HRY_GS_DIST(2) HRY_GS_DIST(3) HRY_GS_DIST(4) HRY_GS_DIST(5)
+		             "v_min_f32_e64 v238, |v240|, |v241|\n\t" HRY_GS_MIN(2) HRY_GS_MIN(3) HRY_GS_MIN(4) HRY_GS_MIN(5) "v_mov_b32 v239, %[v0]\n\t"
+		             HRY_GS_EQ(1, "vcc") HRY_GS_EQ(2, "s[88:89]") HRY_GS_EQ(3, "s[90:91]") HRY_GS_EQ(4, "s[92:93]") HRY_GS_EQ(5, "s[94:95]")
+		             HRY_GS_TAKE(1, "vcc") HRY_GS_TAKE(2, "s[88:89]") HRY_GS_TAKE(3, "s[90:91]") HRY_GS_TAKE(4, "s[92:93]") HRY_GS_TAKE(5, "s[94:95]") HRY_GS_VALUE
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") HRY_GS_HIT(3, "s[92:93]") HRY_GS_HIT(4, "s[94:95]") HRY_GS_HIT(5, "vcc")
+		             "v_mov_b32 v246, s96\n\t"
+		             HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]") HRY_GS_PICK(3, "s[92:93]") HRY_GS_PICK(4, "s[94:95]") HRY_GS_PICK(5, "vcc")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2), HRY_GS_IO(3), HRY_GS_IO(4), HRY_GS_IO(5)
+		             : HRY_GS_IN(0), HRY_GS_IN(1), HRY_GS_IN(2), HRY_GS_IN(3), HRY_GS_IN(4), HRY_GS_IN(5), [rcp] "v"(rcp), [delta] "v"(delta), [cmask] "v"(cmask), [apos] "v"(apos), [aneg] "v"(aneg), [step] "s"(step) HRY_GS_CLOBBER);
+	return out;
+}
+
+#ifdef HRY_GEN_CLOCKS
+#define GEN_CLK(...) __VA_ARGS__
+#else
+#define GEN_CLK(...)
+#endif
 template <int KIND, typename T>
 __device__ void chain_component(const ConnView &cv, const GenView &gv, const uint32_t *rank, const GenChainJob &jb, uint32_t *s_val)
 {
@@ -233,7 +315,9 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 	const int c = jb.comp, off = ld.off[c], q = ld.quant[c];
 	const bool aligned = (ld.stride % (int)sizeof(T)) == 0 && (off % (int)sizeof(T)) == 0;
 	Topo tp{ cv };
+	GEN_CLK(unsigned long long ck_load = 0, ck_depth = 0, ck_steps = 0, ck_verify = 0, ck_exact = 0, ck_shallow = 0, ck_store = 0, ck_runs = 0, ck_retry = 0, ck_exact_n = 0, ck_shallow_n = 0, ck_single = 0, ck_evals = 0, ck_t, ck_n[4] = {0, 0, 0, 0}; const unsigned long long ck_begin = __builtin_amdgcn_s_memtime();)
 	for (uint32_t base = 0; base < jb.n; base += 64) {
+		GEN_CLK(ck_t = __builtin_amdgcn_s_memtime();)
 		const uint32_t i = base + lane;
 		const bool live = i < jb.n;
 		const int ns_raw = live ? jb.nsrc[i] : 0;
@@ -265,18 +349,22 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 					}
 				}
 				T out = T(0);
+				GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); if (__ballot(val[0] == val[1] || true)) ck_load += n - ck_t; ck_t = n; ++ck_runs; })
 				// the run, compiled for N source slots (a batch whose records read at most N sources runs the N-slot code).  Records read
 				// earlier records only, so the run is evaluated SYSTOLICALLY: at step i every lane evaluates its record from what it
 				// holds, lane i -- whose sources inside the run are all final by then -- broadcasts its value (v_readlane), and every
 				// lane that waits for record i picks it up.  Exactly hi - lo steps of one evaluation each, no LDS, no barrier; round 2
 				// relaxed the batch through LDS until nothing changed: up to 64 rounds of evaluate + two barriers + a ballot + a scan of
 				// the slots (0.7 us per record when every record reads its predecessor -- one normal per face).
+				const int most = (int)__builtin_amdgcn_readfirstlane(wave_max_small(in_run ? ns : 0));
 				auto rounds = [&](auto n_slots) {
 					constexpr int N = decltype(n_slots)::value;
 					if (!__ballot(inside)) {   // nothing reads inside the run (private texture coordinates): one evaluation
 						if (in_run) out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q);
+						GEN_CLK(++ck_single;)
 						return;
 					}
+					GEN_CLK(++ck_n[N <= 3 ? 0 : N <= 6 ? 1 : N <= 12 ? 2 : 3];)
 					// how deep the dependencies inside the run go (connectivity only: a relaxation on small integers through the LDS
 					// crossbar, ~100 cycles a round): level = 1 + the deepest source inside the run
 					int level = 0, depth = 0;
@@ -300,7 +388,10 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 					// shallow (smooth normals, texture atlases: a handful of levels): that many rounds of "every lane evaluates from the
 					// current values of the run" through LDS; deep (one normal per face: every record reads the one before it): the
 					// systolic form, one evaluation per record
+					GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_depth += n - ck_t; ck_t = n; })
+					constexpr bool kShort = KIND == 1 && std::is_same<T, float>::value && N <= 6;
 					if (settled && depth * 3 < hi - lo) {
+						GEN_CLK(++ck_shallow_n;)
 						for (int round = 0; round < depth; ++round) {
 							if (round) {
 #pragma unroll
@@ -314,58 +405,64 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 							if (in_run) s_val[lane] = as_u32<T>(out);
 							__syncthreads();
 						}
+						GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_shallow += n - ck_t; ck_t = n; })
 						return;
 					}
-					if constexpr (KIND == 1 && std::is_same<T, float>::value && N <= 6) {
-						// Float corner records (normals, texture coordinates), the deep case: the step in its SHORT form -- the mean by a
-						// multiplication with 1 / n instead of the division, the sweep for the nearest source without its FLT_MAX start,
-						// the residual code in its "near" form on the value's bits (attrcode.h:135-154,182-208, prediction.h:46-64) --
-						// and then VERIFIED exactly, all lanes at once: after the run every lane holds the final values of its sources,
-						// so it evaluates the reference arithmetic on them; the broadcast values were what `out` is now, hence all are
-						// right iff every lane agrees (induction over the lanes).  The first lane that disagrees gets its exact value and
-						// the run is repeated from there, three times at most; then the exact systolic form below takes the run.
+					if constexpr (kShort) {
+						// Float corner records (normals, texture coordinates), the deep case -- one normal per face: every record reads the
+						// one before it, and which of two sources is nearer to their mean hangs on the last bit, so nothing but the
+						// record's final sources will do (a round-3 trial that solved the run from estimated values -- the picks as
+						// pointers, the residual codes as offsets, pointer jumping -- needed seven rounds a run for exactly that reason).
+						// So the step itself is SHORT: the mean in float (exact for one and two sources; a sum of three or more may round
+						// differently from the reference's double, which only matters when two sources are about equally near), the sweep
+						// for the nearest source without its FLT_MAX start, the residual code applied on the value's bits: "near" codes
+						// move the bits by +- delta by the prediction's own sign, codes from 2^31 are "far" for every prediction up to 2.0
+						// in magnitude -- a change of sign -- and give one of two constants by the prediction's sign
+						// (attrcode.h:135-154,182-208, prediction.h:46-64).  Then it is VERIFIED exactly, all lanes at once: after the
+						// run every lane holds the final values of its sources, so it evaluates the reference arithmetic on them; the
+						// broadcast values were what `out` is now, hence all are right iff every lane agrees (induction over the lanes).
+						// The first lane that disagrees gets its exact value and the run is repeated from there, six times at most; then
+						// the exact systolic form below takes the run.
 						const bool none = ns == 0;
-						const double rcp = none ? 0.0 : 1.0 / (double)ns;
-						float pen[N];
+						const float rcp = none ? 0.0f : 1.0f / (float)ns;
+						float w[N];
 #pragma unroll
-						for (int k = 0; k < N; ++k) pen[k] = k < ns ? 0.0f : 3.0e38f;
-						// prediction.h:46-64 on the ordered-int image of a float, near case: value bits = prediction bits +- delta by the
-						// prediction's own sign (delta = half the code, or -(half + 1) for an odd code)
+						for (int k = 0; k < N; ++k) { w[k] = k < ns ? 1.0f : 0.0f; val[k] = k < ns ? val[k] : 3.0e38f; }
 						const uint32_t c32 = (uint32_t)code, half = c32 >> 1, delta = (c32 & 1u) ? 0u - half - 1u : half;
-						auto near_value = [&](uint32_t pb) { const uint32_t m = (uint32_t)((int32_t)pb >> 31); return ((delta ^ m) + pb) - m; };
-						bool fixed = none;
-						uint32_t fixedval = as_u32<T>(cm::value_from_residual<T>(code, T(0), q));
+						// constant lanes: a far code (ordered value = the code after a prediction >= +0, its complement after a negative one),
+						// a record without sources, a lane that was put right
+						uint32_t const_mask = (c32 >> 31) ? ~0u : 0u;
+						uint32_t after_pos = as_u32<T>(cm::f32_from_ordered(c32)), after_neg = as_u32<T>(cm::f32_from_ordered(~c32));
+						if (none) { const_mask = ~0u; after_pos = after_neg = as_u32<T>(cm::value_from_residual<T>(code, T(0), q)); }
 						int from = lo;
 						bool exact_form = false;
+						uint32_t outb = 0;
 						for (int tries = 0;; ++tries) {
-							for (int i = from; i < hi; ++i) {
-								double sd = 0.0;
-#pragma unroll
-								for (int k = 0; k < N; ++k) sd += (double)val[k];                     // (slots beyond ns hold 0)
-								const float avg = (float)(sd * rcp);
-								float best = val[0], dbest = __builtin_fabsf(avg - val[0]);
-#pragma unroll
-								for (int k = 1; k < N; ++k) {
-									const float dk = __builtin_fabsf(avg - val[k]) + pen[k];
-									const bool keep = dbest < dk;                                  // ties go to the later source
-									best = keep ? best : val[k]; dbest = keep ? dbest : dk;
-								}
-								const uint32_t cheap = near_value(cm::bits<uint32_t>(best));
-								out = from_u32<T>(fixed ? fixedval : cheap);
-								const T x = from_u32<T>((uint32_t)__builtin_amdgcn_readlane((int)as_u32<T>(out), i));
-#pragma unroll
-								for (int k = 0; k < N; ++k) val[k] = slot[k] == (uint32_t)i ? x : val[k];
-							}
+							// (compiled per source count of the run: a step is 7 issue slots per source + 7)
+							auto steps = [&](auto nn) {
+								constexpr int NN = decltype(nn)::value;
+								if constexpr (NN <= N)
+									for (int i = from; i < hi; ++i) outb = short_step<NN>(val, slot, w, rcp, delta, const_mask, after_pos, after_neg, i);
+							};
+							if (most <= 2) steps(std::integral_constant<int, 2>());
+							else if (most == 3) steps(std::integral_constant<int, 3>());
+							else if (most == 4) steps(std::integral_constant<int, 4>());
+							else if (most == 5) steps(std::integral_constant<int, 5>());
+							else steps(std::integral_constant<int, 6>());
+							out = from_u32<T>(outb);
+							GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); if (__ballot(out == out)) ck_steps += n - ck_t; ck_t = n; })
 							const uint32_t ref = as_u32<T>(cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q));
 							const unsigned long long bad = __ballot(in_run && ref != as_u32<T>(out));
+							GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_verify += n - ck_t; ck_t = n; ++ck_evals; })
 							if (!bad) break;
-							if (tries >= 3) { exact_form = true; break; }
+							if (tries >= 6) { exact_form = true; break; }
 							const int f = __builtin_ctzll(bad);
-							if (lane == f) { fixed = true; fixedval = ref; }
+							if (lane == f) { const_mask = ~0u; after_pos = after_neg = ref; }
 							from = f;
 						}
 						if (!exact_form) return;
 					}
+					GEN_CLK(++ck_exact_n;)
 					for (int i = lo; i < hi; ++i) {
 						out = cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q);
 						const T x = from_u32<T>((uint32_t)__builtin_amdgcn_readlane((int)as_u32<T>(out), i));
@@ -373,15 +470,17 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 						for (int k = 0; k < N; ++k) val[k] = slot[k] == (uint32_t)i ? x : val[k];
 					}
 					// (lane j's `out` is final from step j on: its picks were complete then and nothing it holds changes afterwards)
+					GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); if (__ballot(out == out)) ck_exact += n - ck_t; ck_t = n; })
 				};
-				const int most = (int)__builtin_amdgcn_readfirstlane(wave_max_small(in_run ? ns : 0));
 				constexpr int N1 = CAP / 4 >= 3 ? (CAP / 4 / 3) * 3 : CAP / 4, N2 = CAP / 2;   // multiples of three for the parallelograms of KIND 0
 				if (most <= N1) rounds(std::integral_constant<int, N1>());
 				else if (most <= N2) rounds(std::integral_constant<int, N2>());
 				else rounds(std::integral_constant<int, CAP>());
+				GEN_CLK(ck_t = __builtin_amdgcn_s_memtime();)
 				if (in_run) stg<T>(mine, out);
 			}
 			__threadfence();   // the run's records are in memory before anything later reads them
+			GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_store += n - ck_t; ck_t = n; })
 			if (hi < 64) {
 				if (lane == hi && live) {   // a fan too large for the table: this lane alone, every source from memory
 					auto value = [&](uint32_t x) { return x < i ? far_value<T>(jb.rec + (size_t)x * ld.stride + off, aligned) : T(0); };
@@ -401,6 +500,9 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 			lo = hi + 1;
 		}
 	}
+	GEN_CLK(if (lane == 0 && jb.n > 10000) printf("gen chain kind %d comp %d: %u records, %llu runs (single %llu, shallow %llu, exact %llu, evaluations %llu; N<=3 %llu, <=6 %llu, <=12 %llu, more %llu) | per run: load %llu depth %llu steps %llu verify %llu exact %llu shallow %llu store %llu | total %llu per record %llu\n",
+	        KIND, c, jb.n, ck_runs, ck_single, ck_shallow_n, ck_exact_n, ck_evals, ck_n[0], ck_n[1], ck_n[2], ck_n[3], ck_load / ck_runs, ck_depth / ck_runs, ck_steps / ck_runs, ck_verify / ck_runs, ck_exact / ck_runs, ck_shallow / ck_runs, ck_store / ck_runs,
+	        __builtin_amdgcn_s_memtime() - ck_begin, (__builtin_amdgcn_s_memtime() - ck_begin) / jb.n);)
 }
 
 // one instantiation per kind and storage type: the jobs of a launch all have that kind and type (the host groups them)
