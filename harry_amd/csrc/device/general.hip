@@ -140,6 +140,40 @@ template <typename T> __device__ __forceinline__ T far_value(const uint8_t *p, b
 	return cm::bits<T>(u);
 }
 
+// The chain reads its job's tables through pointers it loaded from the job list, which the compiler can only take for generic
+// ("flat") ones; flat loads may return out of order, so every wait for one of them waits for ALL loads in flight -- including the
+// next batch's prefetch.  The chain therefore states the address space (global) itself.
+#define HRY_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ T far_value_g(const HRY_GLOBAL uint8_t *p, bool aligned)
+{
+	typedef typename cm::word<sizeof(T)>::u U;
+	U u;
+	if (aligned) u = __hip_atomic_load((const HRY_GLOBAL U*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else {
+		u = 0;
+		for (int b = 0; b < (int)sizeof(T); ++b) u |= (U)((U)__hip_atomic_load(p + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << (8 * b));
+	}
+	return cm::bits<T>(u);
+}
+template <typename T> __device__ __forceinline__ T load_g(const HRY_GLOBAL uint8_t *p, bool aligned)
+{
+	typedef typename cm::word<sizeof(T)>::u U;
+	U u;
+	if (aligned) u = *(const HRY_GLOBAL U*)p;
+	else {
+		u = 0;
+		for (int b = 0; b < (int)sizeof(T); ++b) u |= (U)((U)p[b] << (8 * b));
+	}
+	return cm::bits<T>(u);
+}
+template <typename T> __device__ __forceinline__ void store_g(HRY_GLOBAL uint8_t *p, T v, bool aligned)
+{
+	typedef typename cm::word<sizeof(T)>::u U;
+	const U u = cm::bits<U>(v);
+	if (aligned) *(HRY_GLOBAL U*)p = u;
+	else for (int b = 0; b < (int)sizeof(T); ++b) p[b] = (uint8_t)(u >> (8 * b));
+}
+
 // ---- sources: which earlier records the prediction of record i reads -----------------------------------------------
 // KIND 0: vertex records (the three records of every parallelogram, in fan order), 1: corner records (one record per already
 // decoded face of the region around the vertex).  Connectivity only, so every record at once: src[k * n + i] = k-th source id of
@@ -315,19 +349,38 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 	const int c = jb.comp, off = ld.off[c], q = ld.quant[c];
 	const bool aligned = (ld.stride % (int)sizeof(T)) == 0 && (off % (int)sizeof(T)) == 0;
 	Topo tp{ cv };
+	HRY_GLOBAL uint8_t *const g_rec = (HRY_GLOBAL uint8_t*)jb.rec;
+	const HRY_GLOBAL uint32_t *const g_src = (const HRY_GLOBAL uint32_t*)jb.src;
+	const HRY_GLOBAL uint8_t *const g_nsrc = (const HRY_GLOBAL uint8_t*)jb.nsrc;
 	GEN_CLK(unsigned long long ck_load = 0, ck_depth = 0, ck_steps = 0, ck_verify = 0, ck_exact = 0, ck_shallow = 0, ck_store = 0, ck_runs = 0, ck_retry = 0, ck_exact_n = 0, ck_shallow_n = 0, ck_single = 0, ck_evals = 0, ck_t, ck_n[4] = {0, 0, 0, 0}; const unsigned long long ck_begin = __builtin_amdgcn_s_memtime();)
+	// a batch's inputs (source count, the table's rows -- all of them, so that no load waits for the count --, the residual code
+	// that lies in the record's own slot) are loaded one batch ahead: three dependent trips to memory a batch became one
+	int nx_ns = 0;
+	uint32_t nx_id[CAP];
+	U nx_code = U(0);
+	auto fetch = [&](uint32_t at) {
+		const uint32_t j = at + lane;
+		const bool there = j < jb.n;
+		nx_ns = there ? g_nsrc[j] : 0;
+#pragma unroll
+		for (int k = 0; k < CAP; ++k) nx_id[k] = there ? g_src[(size_t)k * jb.n + j] : 0u;
+		nx_code = there ? cm::bits<U>(load_g<T>(g_rec + (size_t)j * ld.stride + off, aligned)) : U(0);
+	};
+	fetch(0);
 	for (uint32_t base = 0; base < jb.n; base += 64) {
 		GEN_CLK(ck_t = __builtin_amdgcn_s_memtime();)
 		const uint32_t i = base + lane;
 		const bool live = i < jb.n;
-		const int ns_raw = live ? jb.nsrc[i] : 0;
+		const int ns_raw = nx_ns;
 		const bool heavy = ns_raw == kSrcOverflow;
 		const int ns = heavy ? 0 : ns_raw;
 		uint32_t id[CAP];
 #pragma unroll
-		for (int k = 0; k < CAP; ++k) id[k] = k < ns ? jb.src[(size_t)k * jb.n + i] : 0u;
-		uint8_t *mine = jb.rec + (size_t)i * ld.stride + off;
-		const U code = live ? cm::bits<U>(ldg<T>(mine)) : U(0);
+		for (int k = 0; k < CAP; ++k) id[k] = k < ns ? nx_id[k] : 0u;
+		uint8_t *mine = jb.rec + (size_t)i * ld.stride + off;   // (the heavy lanes' path)
+		HRY_GLOBAL uint8_t *const g_mine = g_rec + (size_t)i * ld.stride + off;
+		const U code = nx_code;
+		bool fetched = false;
 		const unsigned long long heavy_mask = __ballot(heavy);
 		// the batch in runs of lanes between the heavy ones
 		int lo = 0;
@@ -340,14 +393,25 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 				T val[CAP];
 				uint32_t slot[CAP];          // LDS slot of a source inside the run, 64 = outside
 				bool inside = false;
+				const int most = (int)__builtin_amdgcn_readfirstlane(wave_max_small(in_run ? ns : 0));
+				// the sources before the run, from memory: every lane loads every slot the run uses (a lane without that source reads
+				// record 0 and drops it), so the loads go out back to back and are waited for once -- one trip to memory a run; with a
+				// branch per source and lane the compiler had serialised them
 #pragma unroll
 				for (int k = 0; k < CAP; ++k) {
 					val[k] = T(0); slot[k] = 64u;
-					if (in_run && k < ns) {
-						if (id[k] < first) val[k] = far_value<T>(jb.rec + (size_t)id[k] * ld.stride + off, aligned);
-						else if (id[k] < i) { slot[k] = id[k] - base; inside = true; }   // (id >= i: damaged input, reads as 0)
+					if (k < most) {
+						const bool used = in_run && k < ns;
+						const bool before = used && id[k] < first;
+						const T x = far_value_g<T>(g_rec + (size_t)(before ? id[k] : 0u) * ld.stride + off, aligned);
+						val[k] = before ? x : T(0);
+						if (used && !before && id[k] < i) { slot[k] = id[k] - base; inside = true; }   // (id >= i: damaged input, reads as 0)
 					}
 				}
+				// the next batch's inputs: asked for AFTER this run's far values (loads return in order: the wait for the far values
+				// then leaves these in flight), in every run so that the wait can be counted (harmless when a batch has two)
+				fetch(base + 64);
+				fetched = true;
 				T out = T(0);
 				GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); if (__ballot(val[0] == val[1] || true)) ck_load += n - ck_t; ck_t = n; ++ck_runs; })
 				// the run, compiled for N source slots (a batch whose records read at most N sources runs the N-slot code).  Records read
@@ -356,7 +420,6 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 				// lane that waits for record i picks it up.  Exactly hi - lo steps of one evaluation each, no LDS, no barrier; round 2
 				// relaxed the batch through LDS until nothing changed: up to 64 rounds of evaluate + two barriers + a ballot + a scan of
 				// the slots (0.7 us per record when every record reads its predecessor -- one normal per face).
-				const int most = (int)__builtin_amdgcn_readfirstlane(wave_max_small(in_run ? ns : 0));
 				auto rounds = [&](auto n_slots) {
 					constexpr int N = decltype(n_slots)::value;
 					if (!__ballot(inside)) {   // nothing reads inside the run (private texture coordinates): one evaluation
@@ -477,7 +540,7 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 				else if (most <= N2) rounds(std::integral_constant<int, N2>());
 				else rounds(std::integral_constant<int, CAP>());
 				GEN_CLK(ck_t = __builtin_amdgcn_s_memtime();)
-				if (in_run) stg<T>(mine, out);
+				if (in_run) store_g<T>(g_mine, out, aligned);
 			}
 			__threadfence();   // the run's records are in memory before anything later reads them
 			GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_store += n - ck_t; ck_t = n; })
@@ -499,6 +562,7 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 			}
 			lo = hi + 1;
 		}
+		if (!fetched) fetch(base + 64);
 	}
 	GEN_CLK(if (lane == 0 && jb.n > 10000) printf("gen chain kind %d comp %d: %u records, %llu runs (single %llu, shallow %llu, exact %llu, evaluations %llu; N<=3 %llu, <=6 %llu, <=12 %llu, more %llu) | per run: load %llu depth %llu steps %llu verify %llu exact %llu shallow %llu store %llu | total %llu per record %llu\n",
 	        KIND, c, jb.n, ck_runs, ck_single, ck_shallow_n, ck_exact_n, ck_evals, ck_n[0], ck_n[1], ck_n[2], ck_n[3], ck_load / ck_runs, ck_depth / ck_runs, ck_steps / ck_runs, ck_verify / ck_runs, ck_exact / ck_runs, ck_shallow / ck_runs, ck_store / ck_runs,
