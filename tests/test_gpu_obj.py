@@ -339,3 +339,49 @@ def test_components_that_share_a_record_stay_in_one_group(cx):
     o = op.Mesh.from_obj(scene2, "")
     same_decoded(cx.read_hry(merged), op.Mesh.from_hry(o.encode().data))
     same_decoded(cx.read_hry(merged), op.Mesh.from_hry_chunked(merged))
+
+
+def _with_normals(obj: bytes, values) -> bytes:
+    """the scene with the components of its `vn` lines replaced, in order, by values(k) -> three numbers as text"""
+    out, k = [], 0
+    for line in obj.split(b"\n"):
+        if line.startswith(b"vn "):
+            out.append(b"vn " + " ".join(values(k)).encode())
+            k += 1
+        else:
+            out.append(line)
+    return b"\n".join(out)
+
+
+_SPECIAL_NORMALS = {
+    # axis-aligned: zeros of both signs and +-1 (predictions of exactly 0, equal distances everywhere)
+    "axis": lambda rng: (lambda k: [["0", "-0", "1", "-1"][int(x)] for x in rng.integers(0, 4, 3)]),
+    # every record changes sign against the one before it (far residual codes in every step)
+    "signs": lambda rng: (lambda k: [("-" if (k + c) & 1 else "") + f"{1e-3 * (1 + (k % 7)):.6g}" for c in range(3)]),
+    # denormals and values whose float sum overflows while the reference's double does not (the exact form takes the run)
+    "range": lambda rng: (lambda k: [["1e-40", "-1e-40", "3e+38", "-3e+38", "0.5", "2.5e+38"][int(x)] for x in rng.integers(0, 6, 3)]),
+    # one value everywhere (every code 0, every distance equal)
+    "constant": lambda rng: (lambda k: ["0.25", "0.25", "0.25"]),
+    # two values only: the mean of two sources lies exactly between them (ties decided by the order of the sources)
+    "two": lambda rng: (lambda k: [["0.125", "0.375"][int(x)] for x in rng.integers(0, 2, 3)]),
+}
+
+
+@pytest.mark.parametrize("pattern", sorted(_SPECIAL_NORMALS))
+@pytest.mark.parametrize("shape", ["ico", "mixed"])
+def test_one_normal_per_face_with_special_values(cx, pattern, shape):
+    """the short form of the corner-record step (general.hip) against the oracle where its shortcuts do not hold: zeros of both
+    signs, a change of sign in every record, equal distances, float sums that overflow; runs of 2 to 6 sources"""
+    base = mg.icosphere(4) if shape == "ico" else mg.with_nonmanifold(mg.multi_component(3, 20, 22, polys="mixed"), 4, 3)
+    sc = og.scene(base, normals="flat", tex="corner" if shape == "ico" else None)
+    text = _with_normals(sc.obj, _SPECIAL_NORMALS[pattern](np.random.default_rng(11)))
+    m = hc.Mesh.from_obj(text, "")
+    o = op.Mesh.from_obj(text, "")
+    ref_bytes = o.clone().encode().data
+    got = cx.write_hry(m.clone(), profile=hc.PROFILE_COMPAT)
+    assert got == ref_bytes
+    ref = op.Mesh.from_hry(ref_bytes)
+    same_decoded(cx.read_hry(got), ref)
+    chunked = cx.write_hry(m.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=512)
+    assert chunked == o.clone().encode_chunked(512).data
+    same_decoded(cx.read_hry(chunked), ref)
