@@ -26,9 +26,12 @@ struct PerfCounters {
 		pe.disabled = group == -1 ? 1 : 0; pe.exclude_kernel = 1; pe.exclude_hv = 1;
 		return (int)syscall(SYS_perf_event_open, &pe, 0, -1, group, 0);
 	}
-	PerfCounters()
+	// nothing is opened before start(): the first perf_event_open of a process costs 100 - 200 ms on a 256-thread host, and the
+	// replay loops hold one of these whether or not HRY_PERF asks for the counters (round 3: that was the "cold first decode")
+	PerfCounters() { for (int i = 0; i < N; ++i) { fd[i] = -1; val[i] = 0; } }
+	void open()
 	{
-		for (int i = 0; i < N; ++i) { fd[i] = -1; val[i] = 0; }
+		if (ok || fd[0] >= 0) return;
 		fd[0] = open_one(PERF_TYPE_HARDWARE, PERF_COUNT_HW_CPU_CYCLES, -1);
 		if (fd[0] < 0) return;
 		fd[1] = open_one(PERF_TYPE_HARDWARE, PERF_COUNT_HW_INSTRUCTIONS, fd[0]);
@@ -38,7 +41,7 @@ struct PerfCounters {
 		ok = true;
 	}
 	~PerfCounters() { for (int i = 0; i < N; ++i) if (fd[i] >= 0) close(fd[i]); }
-	void start() { if (ok) { ioctl(fd[0], PERF_EVENT_IOC_RESET, PERF_IOC_FLAG_GROUP); ioctl(fd[0], PERF_EVENT_IOC_ENABLE, PERF_IOC_FLAG_GROUP); } }
+	void start() { open(); if (ok) { ioctl(fd[0], PERF_EVENT_IOC_RESET, PERF_IOC_FLAG_GROUP); ioctl(fd[0], PERF_EVENT_IOC_ENABLE, PERF_IOC_FLAG_GROUP); } }
 	void stop()
 	{
 		if (!ok) return;
