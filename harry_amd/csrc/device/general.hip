@@ -334,6 +334,60 @@ __device__ __forceinline__ uint32_t short_step(float (&v)[CV], const uint32_t (&
 	return out;
 }
 
+// ---- the same for unsigned integer records: rounded mean by a multiplication (see chain_component), residual code without branches --
+#define HRY_GI_UNFOLD \
+	"v_mul_hi_u32 v237, v236, %[magic]\n\t" \
+	"v_lshrrev_b32 v237, %[shift], v237\n\t" \
+	"v_sub_u32 v238, %[top], v237\n\t" \
+	"v_add_u32 v239, -1, v237\n\t" \
+	"v_min_u32 v239, v239, v238\n\t" \
+	"v_cmp_gt_u32_e64 vcc, %[half], v239\n\t" \
+	"v_cmp_ge_u32_e64 s[88:89], v238, v237\n\t" \
+	"v_cmp_eq_u32_e64 s[90:91], 0, v237\n\t" \
+	"v_sub_u32 v240, v237, v239\n\t" \
+	"v_add3_u32 v240, v240, %[c32], -1\n\t" \
+	"v_sub_u32 v241, v237, %[c32]\n\t" \
+	"v_add_u32 v241, v241, v239\n\t" \
+	"v_add_u32 v242, v237, %[dnear]\n\t" \
+	"v_cndmask_b32_e64 v240, v241, v240, s[88:89]\n\t" \
+	"v_cndmask_b32_e64 v240, v242, v240, vcc\n\t" \
+	"v_cndmask_b32_e64 v240, v240, %[c32], s[90:91]\n\t" \
+	"v_and_b32 %[out], v240, %[tmask]\n\t"
+#define HRY_GI_CONSTS [rnd] "v"(rnd), [magic] "v"(magic), [shift] "v"(shift), [top] "v"(top), [half] "v"(half), [c32] "v"(c32), [dnear] "v"(dnear), [tmask] "v"(tmask), [step] "s"(step)
+template <int NN, int CV>
+__device__ __forceinline__ uint32_t short_step_int(uint32_t (&v)[CV], const uint32_t (&slot)[CV], uint32_t rnd, uint32_t magic, uint32_t shift, uint32_t top, uint32_t half,
+                                                   uint32_t c32, uint32_t dnear, uint32_t tmask, int step)
+{
+	static_assert(NN >= 2 && NN <= 6 && NN <= CV, "sources");
+	uint32_t out;
+	if constexpr (NN == 2)
+		asm volatile("v_add3_u32 v236, %[rnd], %[v0], %[v1]\n\t" HRY_GI_UNFOLD
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") "s_nop 0\n\t" "v_mov_b32 v246, s96\n\t" HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1)
+		             : [s0] "v"(slot[0]), [s1] "v"(slot[1]), HRY_GI_CONSTS HRY_GS_CLOBBER);
+	else if constexpr (NN == 3)
+		asm volatile("v_add3_u32 v236, %[rnd], %[v0], %[v1]\n\t" "v_add_u32 v236, v236, %[v2]\n\t" HRY_GI_UNFOLD
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") "v_mov_b32 v246, s96\n\t" HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2)
+		             : [s0] "v"(slot[0]), [s1] "v"(slot[1]), [s2] "v"(slot[2]), HRY_GI_CONSTS HRY_GS_CLOBBER);
+	else if constexpr (NN == 4)
+		asm volatile("v_add3_u32 v236, %[rnd], %[v0], %[v1]\n\t" "v_add3_u32 v236, v236, %[v2], %[v3]\n\t" HRY_GI_UNFOLD
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") HRY_GS_HIT(3, "s[92:93]") "v_mov_b32 v246, s96\n\t" HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]") HRY_GS_PICK(3, "s[92:93]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2), HRY_GS_IO(3)
+		             : [s0] "v"(slot[0]), [s1] "v"(slot[1]), [s2] "v"(slot[2]), [s3] "v"(slot[3]), HRY_GI_CONSTS HRY_GS_CLOBBER);
+	else if constexpr (NN == 5)
+		asm volatile("v_add3_u32 v236, %[rnd], %[v0], %[v1]\n\t" "v_add3_u32 v236, v236, %[v2], %[v3]\n\t" "v_add_u32 v236, v236, %[v4]\n\t" HRY_GI_UNFOLD
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") HRY_GS_HIT(3, "s[92:93]") HRY_GS_HIT(4, "s[94:95]") "v_mov_b32 v246, s96\n\t" HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]") HRY_GS_PICK(3, "s[92:93]") HRY_GS_PICK(4, "s[94:95]")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2), HRY_GS_IO(3), HRY_GS_IO(4)
+		             : [s0] "v"(slot[0]), [s1] "v"(slot[1]), [s2] "v"(slot[2]), [s3] "v"(slot[3]), [s4] "v"(slot[4]), HRY_GI_CONSTS HRY_GS_CLOBBER);
+	else
+		asm volatile("v_add3_u32 v236, %[rnd], %[v0], %[v1]\n\t" "v_add3_u32 v236, v236, %[v2], %[v3]\n\t" "v_add3_u32 v236, v236, %[v4], %[v5]\n\t" HRY_GI_UNFOLD
+		             HRY_GS_HIT(0, "s[86:87]") HRY_GS_CAST HRY_GS_HIT(1, "s[88:89]") HRY_GS_HIT(2, "s[90:91]") HRY_GS_HIT(3, "s[92:93]") HRY_GS_HIT(4, "s[94:95]") HRY_GS_HIT(5, "vcc") "v_mov_b32 v246, s96\n\t" HRY_GS_PICK(0, "s[86:87]") HRY_GS_PICK(1, "s[88:89]") HRY_GS_PICK(2, "s[90:91]") HRY_GS_PICK(3, "s[92:93]") HRY_GS_PICK(4, "s[94:95]") HRY_GS_PICK(5, "vcc")
+		             : [out] "=&v"(out), HRY_GS_IO(0), HRY_GS_IO(1), HRY_GS_IO(2), HRY_GS_IO(3), HRY_GS_IO(4), HRY_GS_IO(5)
+		             : [s0] "v"(slot[0]), [s1] "v"(slot[1]), [s2] "v"(slot[2]), [s3] "v"(slot[3]), [s4] "v"(slot[4]), [s5] "v"(slot[5]), HRY_GI_CONSTS HRY_GS_CLOBBER);
+	return out;
+}
+
 #ifdef HRY_GEN_CLOCKS
 #define GEN_CLK(...) __VA_ARGS__
 #else
@@ -524,6 +578,64 @@ __device__ void chain_component(const ConnView &cv, const GenView &gv, const uin
 							from = f;
 						}
 						if (!exact_form) return;
+					}
+					if constexpr (KIND == 1 && std::is_unsigned<T>::value && sizeof(T) <= 4) {
+						// Integer corner records (quantised normals and texture coordinates), the deep case: the reference's step is the
+						// rounded mean of the sources in 64 bits and the residual code against it (attrcode.h:182-190, transform.h:91,
+						// prediction.h:46-64).  With at most 12 sources of at most 27 bits the sum fits 31 bits, and the division by the
+						// source count is a multiplication: q = (x M) >> (31 + s), s = ceil(log2 n), M = floor(2^(31+s) / n) + 1 is exact
+						// for x < 2^31 (M < 2^32 for n >= 2); the residual code without its branches.  Exact by construction; verified
+						// like the float form all the same (a damaged stream may wrap a narrow type where 32 bits do not).
+						const int nbits = cm::width_bits<T>(q);
+						if (sizeof(T) < 4 || nbits <= 27) {
+							const uint32_t tmask = sizeof(T) == 4 ? ~0u : (1u << (8 * (sizeof(T) & 3))) - 1u;
+							const uint32_t top = (uint32_t)cm::ones<T>(nbits);
+							const uint32_t c32 = (uint32_t)code, half = c32 >> 1, dnear = (c32 & 1u) ? ~half : half;
+							// (one source: x = mulhi(x + 1, 2^32 - 1); none: magic 0, prediction 0)
+							const uint32_t un = (uint32_t)ns, rnd = un == 1 ? 1u : un >> 1;
+							const int lg = un >= 2 ? 32 - __builtin_clz(un - 1) : 1;               // ceil(log2 n)
+							// (2^(31+s) / n in double: exact to the integer part -- the fraction is a multiple of 1/n, far from the rounding)
+							const uint32_t magic = un >= 2 ? (uint32_t)((double)(1ull << (31 + lg)) / (double)un) + 1u : un == 1 ? ~0u : 0u;
+							const uint32_t shift = (uint32_t)(lg - 1);
+							uint32_t vi[CAP];
+#pragma unroll
+							for (int k = 0; k < CAP; ++k) vi[k] = k < N && k < ns ? (uint32_t)val[k] : 0u;
+							uint32_t ob = 0;
+							auto steps = [&](auto nn) {
+								constexpr int NN = decltype(nn)::value;
+								if constexpr (NN <= N)
+									for (int i = lo; i < hi; ++i) ob = short_step_int<NN>(vi, slot, rnd, magic, shift, top, half, c32, dnear, tmask, i);
+							};
+							if (N > 6 && most > 6) {   // (more than six sources: the compiler's version of the step)
+								for (int i = lo; i < hi; ++i) {
+									uint32_t sum = rnd;
+#pragma unroll
+									for (int k = 0; k < N; ++k) sum += vi[k];
+									const uint32_t pr = __umulhi(sum, magic) >> shift;
+									const uint32_t room = top - pr, bal = min(pr - 1u, room);
+									const uint32_t farv = room >= pr ? pr + c32 - bal - 1u : pr - c32 + bal;
+									uint32_t v = half > bal ? farv : pr + dnear;
+									v = pr == 0u ? c32 : v;
+									ob = v & tmask;
+									const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)ob, i);
+#pragma unroll
+									for (int k = 0; k < N; ++k) vi[k] = slot[k] == (uint32_t)i ? x : vi[k];
+								}
+							}
+							else if (most <= 2) steps(std::integral_constant<int, 2>());
+							else if (most == 3) steps(std::integral_constant<int, 3>());
+							else if (most == 4) steps(std::integral_constant<int, 4>());
+							else if (most == 5) steps(std::integral_constant<int, 5>());
+							else steps(std::integral_constant<int, 6>());
+#pragma unroll
+							for (int k = 0; k < N; ++k) val[k] = k < ns ? (T)vi[k] : val[k];
+							out = (T)ob;
+							GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); if (__ballot(out == out)) ck_steps += n - ck_t; ck_t = n; })
+							const uint32_t ref = as_u32<T>(cm::value_from_residual<T>(code, predict_from<KIND, T, CAP, N>(ns, q, val), q));
+							const bool all_right = !__ballot(in_run && ref != as_u32<T>(out));
+							GEN_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_verify += n - ck_t; ck_t = n; ++ck_evals; })
+							if (all_right) return;
+						}
 					}
 					GEN_CLK(++ck_exact_n;)
 					for (int i = lo; i < hi; ++i) {

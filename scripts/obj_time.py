@@ -1,5 +1,6 @@
 """Timing of the OBJ / general-bindings path on one GPU: parse, encode (reference stream), decode.
-    python scripts/obj_time.py [n]        torus n x n (2 n^2 triangles), smooth normals + a 7-chart texture atlas, then flat normals"""
+    python scripts/obj_time.py [n] [bits]  torus n x n (2 n^2 triangles), smooth normals + a 7-chart texture atlas, then flat normals;
+                                           bits: quantise every list to that many bits first (integer records)"""
 import os
 import sys
 import time
@@ -10,6 +11,7 @@ from harry_amd import meshgen as mg
 from harry_amd import objgen as og
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+bits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 cx = hc.Codec(0)
 for label, kw in (("smooth normals + atlas", dict(normals="smooth", tex="atlas", charts=7)), ("flat normals", dict(normals="flat"))):
     t = time.time()
@@ -18,6 +20,8 @@ for label, kw in (("smooth normals + atlas", dict(normals="smooth", tex="atlas",
     t = time.time()
     m = hc.Mesh.from_obj(sc.obj, "")
     t_parse = time.time() - t
+    if bits:
+        cx.requant(m, [(l, -1, bits) for l in range(m.nlists) if m.list_target(l) != 3], False)
     ntri = m.ntri
     for rep in range(4):
         prof = hc.PROFILE_COMPAT if rep < 2 else hc.PROFILE_CHUNKED

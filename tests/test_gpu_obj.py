@@ -385,3 +385,15 @@ def test_one_normal_per_face_with_special_values(cx, pattern, shape):
     chunked = cx.write_hry(m.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=512)
     assert chunked == o.clone().encode_chunked(512).data
     same_decoded(cx.read_hry(chunked), ref)
+    # the same records as integers: 7 bits in a byte, 16 in a short, 20 and 27 in a word (sums below 2^31: the multiplication
+    # form of the mean), 30 (past it: the exact form)
+    for bits in (7, 16, 20, 27, 30):
+        quant = [(l, -1, bits) for l in range(m.nlists) if m.list_target(l) != 3]
+        mq, oq = m.clone(), o.clone()
+        cx.requant(mq, quant, False)
+        oq.requant(quant, False)
+        ref_bytes = oq.clone().encode().data
+        assert cx.write_hry(mq.clone(), profile=hc.PROFILE_COMPAT) == ref_bytes
+        ref = op.Mesh.from_hry(ref_bytes)
+        same_decoded(cx.read_hry(ref_bytes), ref)
+        same_decoded(cx.read_hry(cx.write_hry(mq.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=512)), ref)
