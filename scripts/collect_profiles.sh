@@ -33,6 +33,7 @@ leg cfg0 $ROOT/scripts/cfg0_time.py
 leg floatmixed $ROOT/scripts/float_chain_time.py 708 --mixed
 # the OBJ / general-bindings path (row f-3): timing + kernel statistics
 python3 $ROOT/scripts/obj_time.py 300 > $OUT/obj_time.txt 2>&1
+python3 $ROOT/scripts/obj_time.py 300 12 > $OUT/obj_time_12bits.txt 2>&1
 mkdir -p $OUT/obj
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/obj/kstats -- python3 $ROOT/scripts/obj_time.py 300 > $OUT/obj/kstats.log 2>&1
 # both bench modes rehearsed with ranks / contexts sharing this box's one GPU (code paths, not measurements)
