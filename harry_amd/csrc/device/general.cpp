@@ -19,6 +19,9 @@
 #include "context.hpp"
 #include "kernels.hpp"
 
+#include <exception>
+#include <thread>
+
 namespace hry {
 
 using namespace dev;
@@ -48,6 +51,9 @@ void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t
 }
 bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
                                   const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes, const uint8_t *d_vplanes = nullptr);   // unchunk.cpp
+bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order);                                                                             // unchunk.cpp
+void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+                                      const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes);                                            // unchunk.cpp
 
 void check_general(const Mesh &m)
 {
@@ -659,15 +665,38 @@ void general_planes_decode(Context &cx, Mesh &m, const std::vector<uint32_t> &or
 		}
 	}
 	std::vector<GenRecordEvents> ev;
-	read_general_planes(m, order_v, hp, ev);
-	// a list without coded bytes still creates records
-	// vertex lists in which every vertex owns a record take the PLY layout's chains, straight from the decoded planes
+	// A vertex list in which every vertex owns a record takes the PLY layout's chains, straight from the decoded planes -- and
+	// BESIDE the host's bookkeeping of the other lists (which record every corner / face names: 6 ms per 180 000 triangles, as
+	// long as the vertex chain): a helper thread drives the chain on copies of the connectivity and the list's records while this
+	// thread reads the planes.  Whether the list qualifies is known from the planes' lengths (one residual symbol in the list's first
+	// data plane per record coded as data).
+	int fast_l = -1;
 	if (m.bind.nregs_vtx() == 1 && m.bind.nvtxlists(0) == 1 && !getenv("HRY_GENERIC_VERTEX") && !order_v.empty()) {
 		const int l = m.bind.vtxlist(0, 0);
-		if (ev[l].he.size() == order_v.size() && m.lists[l].coded_bytes() > 0 &&
-		    reconstruct_vertex_list_fast(cx, m, l, order_v, seg_start, seg_level, std::vector<uint8_t>(), d_syms + plane_off[data_plane0[l]])) {
-			ev[l].he.clear(); ev[l].slot.clear();
+		if (hp.lists[l].n_data == order_v.size() && m.lists[l].coded_bytes() > 0 && vertex_list_fast_applicable(m, l, order_v.size())) fast_l = l;
+	}
+	if (fast_l < 0) read_general_planes(m, order_v, hp, ev);
+	else {
+		Mesh t;
+		t.nv = m.nv; t.nf = m.nf; t.declared_ne = m.declared_ne; t.have_degree = m.have_degree;
+		t.face_off = m.face_off; t.org = m.org; t.twin = m.twin;
+		{
+			BigVec<uint8_t> held;
+			held.swap(m.lists[fast_l].data);
+			t.lists[1] = m.lists[fast_l];      // the description; the records move
+			t.lists[1].data.swap(held);
 		}
+		std::exception_ptr chain_error, reader_error;
+		std::thread chain([&] {
+			try { reconstruct_vertex_list_detached(cx, t, order_v, seg_start, seg_level, d_syms + plane_off[data_plane0[fast_l]]); }
+			catch (...) { chain_error = std::current_exception(); }
+		});
+		try { read_general_planes(m, order_v, hp, ev); } catch (...) { reader_error = std::current_exception(); }
+		chain.join();
+		t.lists[1].data.swap(m.lists[fast_l].data);
+		if (reader_error) std::rethrow_exception(reader_error);
+		if (chain_error) std::rethrow_exception(chain_error);
+		ev[fast_l].he.clear(); ev[fast_l].slot.clear();
 	}
 	reconstruct_general(cx, m, order_v, ev, [&] {
 		for (size_t l = 0; l < m.lists.size(); ++l) {

@@ -701,6 +701,21 @@ bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector
 	return true;
 }
 
+// The same for a caller that keeps working on the mesh meanwhile (general_planes_decode: the host's bookkeeping of the other lists
+// runs beside the vertex chain): `t` holds COPIES of the connectivity and the vertex list's records (moved in by the caller, moved
+// back by it afterwards); nothing of `m` is touched.  Runs on the calling thread, which may be a helper.
+bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order)
+{
+	const ListDesc ldv = make_list_desc(m.lists[l]);
+	return ldv.nplanes && unpredict2_applicable(ldv) && m.lists[l].count >= n_order;
+}
+void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+                                      const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	reconstruct_attributes(cx, t, order_v, seg_start, seg_level, d_vplanes, nullptr, make_list_desc(t.lists[1]), make_list_desc(t.lists[0]));
+}
+
 // Reference format (.hry v0.1): the single adaptive stream is decoded and replayed on a host core (the format makes
 // both serial, compat_read.cpp); the residual planes then take the same device reconstruction as above.
 Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m)
