@@ -53,7 +53,8 @@ bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector
                                   const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes, const uint8_t *d_vplanes = nullptr);   // unchunk.cpp
 bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order);                                                                             // unchunk.cpp
 void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
-                                      const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes);                                            // unchunk.cpp
+                                      const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, long long trace_origin);                    // unchunk.cpp
+long long trace_origin_ns();                                                                                                                          // unchunk.cpp
 
 void check_general(const Mesh &m)
 {
@@ -687,8 +688,9 @@ void general_planes_decode(Context &cx, Mesh &m, const std::vector<uint32_t> &or
 			t.lists[1].data.swap(held);
 		}
 		std::exception_ptr chain_error, reader_error;
+		const long long origin = trace_origin_ns();
 		std::thread chain([&] {
-			try { reconstruct_vertex_list_detached(cx, t, order_v, seg_start, seg_level, d_syms + plane_off[data_plane0[fast_l]]); }
+			try { reconstruct_vertex_list_detached(cx, t, order_v, seg_start, seg_level, d_syms + plane_off[data_plane0[fast_l]], origin); }
 			catch (...) { chain_error = std::current_exception(); }
 		});
 		try { read_general_planes(m, order_v, hp, ev); } catch (...) { reader_error = std::current_exception(); }

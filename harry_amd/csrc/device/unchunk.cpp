@@ -704,15 +704,17 @@ bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector
 // The same for a caller that keeps working on the mesh meanwhile (general_planes_decode: the host's bookkeeping of the other lists
 // runs beside the vertex chain): `t` holds COPIES of the connectivity and the vertex list's records (moved in by the caller, moved
 // back by it afterwards); nothing of `m` is touched.  Runs on the calling thread, which may be a helper.
+long long trace_origin_ns() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(g_t0.time_since_epoch()).count(); }   // of the calling thread's decode
 bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order)
 {
 	const ListDesc ldv = make_list_desc(m.lists[l]);
 	return ldv.nplanes && unpredict2_applicable(ldv) && m.lists[l].count >= n_order;
 }
 void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
-                                      const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes)
+                                      const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, long long trace_origin)
 {
 	HIP_OK(hipSetDevice(cx.device));
+	g_t0 = Clock::time_point(std::chrono::duration_cast<Clock::duration>(std::chrono::nanoseconds(trace_origin)));   // (this thread's copy: HRY_TRACE's timeline)
 	reconstruct_attributes(cx, t, order_v, seg_start, seg_level, d_vplanes, nullptr, make_list_desc(t.lists[1]), make_list_desc(t.lists[0]));
 }
 
