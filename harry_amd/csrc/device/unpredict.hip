@@ -380,6 +380,46 @@ __device__ __forceinline__ void raise_flag(const CrossSync &xs, int c, uint32_t 
 	}
 }
 
+// ---- one ordinary step of the dense form of the float chain (unpredict2_component), hand-scheduled ----------------------------------
+// Every lane: the two parallelogram predictions of its vertex, the one nearer to their mean (the later one on equal distances:
+// sign of |mean - p0| - |mean - p1|), the residual code on its bits (+- delta by its sign; lanes with a fixed value take that);
+// then lane `step` broadcasts its value and every lane takes it into the sources that wait for that vertex.  One block, so that
+// no wait state is spent (a VALU-written SGPR needs two other instructions before the VALU reads it): 29 issue slots; the
+// compiler's version of the loop body had 83 with its branches, the ring write and the hazards' s_nop.
+// Temporaries: v236-v240, v246, s86-s96, vcc.
+#define HRY_DS_HIT(k, sp)  "v_cmp_eq_u32_e64 " sp ", %[step], %[t" #k "]\n\t"
+#define HRY_DS_PICK(k, sp) "v_cndmask_b32_e64 %[d" #k "], %[d" #k "], v246, " sp "\n\t"
+__device__ __forceinline__ uint32_t dense_step(uint32_t (&d)[6], const uint32_t (&tag)[6], uint32_t delta, uint32_t fixmask, uint32_t fixedval, uint32_t step)
+{
+	uint32_t out;
+	asm volatile(
+		"v_sub_f32 v236, %[d1], %[d2]\n\t"
+		"v_sub_f32 v237, %[d4], %[d5]\n\t"
+		"v_add_f32 v236, %[d0], v236\n\t"
+		"v_add_f32 v237, %[d3], v237\n\t"
+		"v_mul_f32 v238, 0.5, v237\n\t"
+		"v_fma_f32 v238, v236, 0.5, v238\n\t"
+		"v_sub_f32 v239, v238, v236\n\t"
+		"v_sub_f32 v240, v238, v237\n\t"
+		"v_sub_f32_e64 v239, |v239|, |v240|\n\t"
+		"v_ashrrev_i32 v239, 31, v239\n\t"
+		"v_bfi_b32 v236, v239, v236, v237\n\t"
+		"v_ashrrev_i32 v239, 31, v236\n\t"
+		"v_xad_u32 v240, %[delta], v239, v236\n\t"
+		"v_sub_u32 v240, v240, v239\n\t"
+		"v_bfi_b32 %[out], %[fixmask], %[fixedval], v240\n\t"
+		HRY_DS_HIT(0, "s[86:87]")
+		"v_readlane_b32 s96, %[out], %[step]\n\t"
+		HRY_DS_HIT(1, "s[88:89]") HRY_DS_HIT(2, "s[90:91]") HRY_DS_HIT(3, "s[92:93]") HRY_DS_HIT(4, "s[94:95]") HRY_DS_HIT(5, "vcc")
+		"v_mov_b32 v246, s96\n\t"
+		HRY_DS_PICK(0, "s[86:87]") HRY_DS_PICK(1, "s[88:89]") HRY_DS_PICK(2, "s[90:91]") HRY_DS_PICK(3, "s[92:93]") HRY_DS_PICK(4, "s[94:95]") HRY_DS_PICK(5, "vcc")
+		: [out] "=&v"(out), [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3]), [d4] "+v"(d[4]), [d5] "+v"(d[5])
+		: [t0] "v"(tag[0]), [t1] "v"(tag[1]), [t2] "v"(tag[2]), [t3] "v"(tag[3]), [t4] "v"(tag[4]), [t5] "v"(tag[5]),
+		  [delta] "v"(delta), [fixmask] "v"(fixmask), [fixedval] "v"(fixedval), [step] "s"(step)
+		: "v236", "v237", "v238", "v239", "v240", "v246", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "vcc");
+	return out;
+}
+
 template <typename T>
 __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                      const uint8_t *planes, uint8_t *rec, int stride, int off, int q, int plane0,
@@ -556,38 +596,55 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 					for (int j = 0; j < 3; ++j) { dsrc[3 + j] = dsrc[j]; dtag[3 + j] = dtag[j]; }
 				}
 				const uint32_t half = code >> 1, delta = (code & 1u) ? 0u - half - 1u : half;
-				bool fixed = nc2 == 0;                           // no candidate: the residual code is the value (exact); many: its own step
-				uint32_t fixedval = dev.eval(dsrc), myval = 0;
+				// fixed lanes (all-ones mask): no candidate -- the residual code is the value (exact) --, many candidates (its own step),
+				// a lane that was put right
+				uint32_t fixmask = nc2 == 0 ? ~0u : 0u;
+				uint32_t fixedval = dev.eval(dsrc), myval = 0, out = 0;
 				uint32_t from = 0;
 				bool exact_steps = dense_skip != 0;      // the stretch keeps failing (a coordinate that is 0 everywhere): the exact step at once
+				const uint32_t my_slot = (base + (uint32_t)lane) & mask;
 				for (uint32_t tries = 0;; ++tries) {
-					for (uint32_t i = from; i < nbf; ++i) {
-						uint32_t sv;
-						if ((bigm >> i) & 1ull) {
-							sv = cm::bits<uint32_t>(many_candidates_value(base + i, pos + i, rl(nc, i), rl(code, i)));
-						} else if (exact_steps) {
-							sv = rl(dev.eval(dsrc), i);
-						} else {
-							const float p0 = cm::bits<float>(dsrc[0]) + (cm::bits<float>(dsrc[1]) - cm::bits<float>(dsrc[2]));
-							const float p1 = cm::bits<float>(dsrc[3]) + (cm::bits<float>(dsrc[4]) - cm::bits<float>(dsrc[5]));
-							const float avg = __builtin_fmaf(p0, 0.5f, 0.5f * p1);
-							const float e = __builtin_fabsf(avg - p0) - __builtin_fabsf(avg - p1);
-							const uint32_t pb = (int32_t)cm::bits<uint32_t>(e) < 0 ? cm::bits<uint32_t>(p0) : cm::bits<uint32_t>(p1);   // ties go to the later candidate
-							const uint32_t m = (uint32_t)((int32_t)pb >> 31);
-							const uint32_t cheap = ((delta ^ m) + pb) - m;
-							sv = rl(fixed ? fixedval : cheap, i);
-						}
-						myval = (uint32_t)lane == i ? sv : myval;
+					// Stretches of ordinary vertices between the many-candidate ones.  A lane's value is final from its own step on (its
+					// sources are earlier lanes) and every later step computes it again, so nothing is kept per step; the ring -- which
+					// only the many-candidate evaluations read inside the batch -- gets the values of a stretch right before the next
+					// such vertex, all lanes at once (round 3 wrote it from lane 0 at every step).
+					uint32_t at = from, flushed = from;
+					while (at < nbf) {
+						const uint64_t ahead = bigm >> at;
+						const uint32_t stop = ahead ? at + (uint32_t)__builtin_ctzll(ahead) : nbf;
+						if (exact_steps) {
+							for (uint32_t i = at; i < stop; ++i) {
+								const uint32_t sv = rl(dev.eval(dsrc), i);
+								myval = (uint32_t)lane == i ? sv : myval;
 #pragma unroll
-						for (int j = 0; j < 6; ++j) dsrc[j] = dtag[j] == i ? sv : dsrc[j];
-						if (lane == 0) ring[(base + i) & mask] = (U)sv;
+								for (int j = 0; j < 6; ++j) dsrc[j] = dtag[j] == i ? sv : dsrc[j];
+							}
+						} else {
+							for (uint32_t i = at; i < stop; ++i) out = dense_step(dsrc, dtag, delta, fixmask, fixedval, i);
+						}
+						{   // the values of [flushed, stop) into the ring
+							const uint32_t mine = (isbig || exact_steps) ? myval : out;
+							if ((uint32_t)lane >= flushed && (uint32_t)lane < stop) ring[my_slot] = (U)mine;
+							flushed = stop;
+						}
+						if (stop < nbf) {
+							const uint32_t sv = cm::bits<uint32_t>(many_candidates_value(base + stop, pos + stop, rl(nc, stop), rl(code, stop)));
+							myval = (uint32_t)lane == stop ? sv : myval;
+#pragma unroll
+							for (int j = 0; j < 6; ++j) dsrc[j] = dtag[j] == stop ? sv : dsrc[j];
+						}
+						at = stop + 1;
 					}
+					if (flushed < nbf) {   // (the batch ended with a many-candidate vertex)
+						if ((uint32_t)lane >= flushed && (uint32_t)lane < nbf) ring[my_slot] = (U)myval;
+					}
+					if (!isbig && !exact_steps) myval = out;
 					if (exact_steps) break;                                // (every value is the reference arithmetic on final sources)
 					const uint32_t ref = dev.eval(dsrc);
 					const uint64_t bad = __ballot((uint32_t)lane < nbf && !isbig && ref != myval);
 					if (!bad) break;
 					const uint32_t f = (uint32_t)__builtin_ctzll(bad);     // every lane before f is right, so ref of lane f is its exact value
-					if ((uint32_t)lane == f) { fixed = true; fixedval = ref; }
+					if ((uint32_t)lane == f) { fixmask = ~0u; fixedval = ref; }
 					from = f;
 					if (tries >= 2) { exact_steps = true; dense_skip = 8; }   // the rest of the batch, and the next batches, in the exact step
 				}
@@ -985,13 +1042,35 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 				val = ev.eval(s);
 			}
 		} else {
+			bool settled = false;
+			if constexpr (std::is_same<T, float>::value) {
+				// the general form of a float batch (any lane may read any earlier lane): the short step of the dense form above,
+				// verified exactly after the batch; the exact loop below takes the batch when two repeats did not settle it
+				if (nc == 1) {   // a lone candidate is both candidates of the short form
 #pragma unroll
-			for (uint32_t i = 0; i < 64; ++i) {
-				if ((i & 7u) == 0 && i >= nb) break;   // steps past the end of a short batch only produce unused values
-				val = ev.eval(src);
-				const uint32_t s = rl(val, i);
+					for (int j = 0; j < 3; ++j) { src[3 + j] = src[j]; tag[3 + j] = tag[j]; }
+				}
+				const uint32_t half = code >> 1, delta = (code & 1u) ? 0u - half - 1u : half;
+				uint32_t fixmask = (nc == 0 || lane >= (int)nb) ? ~0u : 0u, fixedval = ev.eval(src), from = 0;
+				for (uint32_t tries = 0; tries < 3 && !settled; ++tries) {
+					for (uint32_t i = from; i < nb; ++i) val = dense_step(src, tag, delta, fixmask, fixedval, i);
+					const uint32_t ref = ev.eval(src);
+					const uint64_t bad = __ballot(lane < (int)nb && ref != val);
+					if (!bad) { settled = true; break; }
+					const uint32_t f = (uint32_t)__builtin_ctzll(bad);     // every lane before f is right, so ref of lane f is its exact value
+					if ((uint32_t)lane == f) { fixmask = ~0u; fixedval = ref; }
+					from = f;
+				}
+			}
+			if (!settled) {
 #pragma unroll
-				for (int j = 0; j < 6; ++j) src[j] = tag[j] == i ? s : src[j];
+				for (uint32_t i = 0; i < 64; ++i) {
+					if ((i & 7u) == 0 && i >= nb) break;   // steps past the end of a short batch only produce unused values
+					val = ev.eval(src);
+					const uint32_t s = rl(val, i);
+#pragma unroll
+					for (int j = 0; j < 6; ++j) src[j] = tag[j] == i ? s : src[j];
+				}
 			}
 		}
 		// ---- publish the batch
