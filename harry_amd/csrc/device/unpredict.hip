@@ -221,6 +221,40 @@ __device__ __forceinline__ T chain_predict(uint32_t ncu, const T *pv)
 	}
 }
 
+// the same for a number of candidates known at compile time; pk: lane k holds candidate k
+template <typename T, int N>
+__device__ __forceinline__ T chain_predict_n(uint32_t pk)
+{
+	typedef typename cm::word<sizeof(T)>::u U;
+	T pv[kCandMax];
+#pragma unroll
+	for (int k = 0; k < kCandMax; ++k) pv[k] = k < N ? cm::bits<T>((U)rl(pk, k)) : T(0);
+	if constexpr (!cm::is_fp<T>::value) return chain_predict<T>((uint32_t)N, pv);
+	else {
+		double acc = 0;
+#pragma unroll
+		for (int k = 0; k < N; ++k) acc = acc + (double)pv[k];
+		// acc / N, correctly rounded, without the division (20 issue slots): with y = RN(1 / N), q0 = RN(acc y), r = acc - N q0 (exact in
+		// an fma), RN(q0 + r y) is the correctly rounded quotient (Markstein); zeros, infinities and NaNs are q0 already
+		double mean;
+		if constexpr ((N & (N - 1)) == 0) mean = acc / (double)N;
+		else {
+			const double y = 1.0 / (double)N, q0 = acc * y;
+			const double r = __builtin_fma(-(double)N, q0, acc), q1 = __builtin_fma(r, y, q0);
+			mean = (__builtin_fabs(q0) > 0.0 && __builtin_fabs(q0) < __builtin_inf()) ? q1 : q0;
+		}
+		const T avg = (T)mean;
+		T best = 3.402823466e+38f;
+#pragma unroll
+		for (int k = 0; k < N; ++k) {
+			const T db = avg > best ? avg - best : best - avg;
+			const T dp = avg > pv[k] ? avg - pv[k] : pv[k] - avg;
+			best = db < dp ? best : pv[k];
+		}
+		return best;
+	}
+}
+
 // ---- per-lane evaluation of one vertex with at most two candidates: six source bit patterns -> value bit pattern.
 // Three tiers: unsigned components of at most 16 bits (quantised attributes, the headline case) in trimmed 32-bit
 // arithmetic, float / 32-bit unsigned branch-free, every other type through the generic functions of codec_math.hpp.
@@ -471,19 +505,36 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 	// value of a vertex with more than two candidates, evaluated on its own from the ring (every source is older than it): up to
 	// kCandMax candidates sit in its row (lane k evaluates candidate k, the mean and the selection run over them in table order);
 	// beyond that the fan is walked right here.  Uniform: every lane returns the same value.  row_lane: its lane in the tile.
+	HRY_CLK(unsigned long long ck_m1 = 0, ck_m2 = 0, ck_m3 = 0, ck_m4 = 0, ck_mn = 0;)
 	auto many_candidates_value = [&](uint32_t v, uint32_t row_lane, uint32_t n0, uint32_t c0) -> T {
+		HRY_CLK(const unsigned long long m_t0 = __builtin_amdgcn_s_memtime(); unsigned long long m_t1 = m_t0, m_t2 = m_t0, m_t3 = m_t0;)
 		T pred = T(0);
 		if (n0 != 0xff) {
-			uint32_t pk = 0;
-			if ((uint32_t)lane < n0) {
-				const uint32_t *row = bigrow + row_lane * 24;
-				const uint32_t c0i = row[3 * lane], c1i = row[3 * lane + 1], c2i = row[3 * lane + 2];
-				pk = (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(old_value(c0i, v)), cm::bits<T>(old_value(c1i, v)), cm::bits<T>(old_value(c2i, v)), q));
+			// lane k: candidate k.  Straight-line: the row and the ring are read unconditionally (addresses always inside) and the
+			// results selected -- a branch per source cost this lone wavefront an LDS round trip each; only a source older than the
+			// ring takes the branch to memory
+			const bool mine = (uint32_t)lane < n0;
+			const uint32_t *row = bigrow + row_lane * 24 + 3 * (mine ? lane : 0);
+			const uint32_t c0i = row[0], c1i = row[1], c2i = row[2];
+			U s0 = ring[c0i & mask], s1 = ring[c1i & mask], s2 = ring[c2i & mask];
+			auto in_ring = [&](uint32_t id) { return (v - id <= ring_n) & (id >= seg_begin) & (id >= ring_floor); };
+			if (__ballot(mine && !(in_ring(c0i) & in_ring(c1i) & in_ring(c2i)))) {
+				if (mine) { s0 = old_value(c0i, v); s1 = old_value(c1i, v); s2 = old_value(c2i, v); }
 			}
-			T pv[kCandMax];
+			const uint32_t pk = mine ? (uint32_t)cm::bits<U>(cm::parallelogram<T>(cm::bits<T>(s0), cm::bits<T>(s1), cm::bits<T>(s2), q)) : 0u;
+			HRY_CLK({ asm volatile("" :: "v"(pk)); m_t1 = __builtin_amdgcn_s_memtime(); })
+			// (compiled per number of candidates: the generic loop tests it eight times twice over)
+			if (n0 == 3) pred = chain_predict_n<T, 3>(pk);
+			else if (n0 == 4) pred = chain_predict_n<T, 4>(pk);
+			else if (n0 == 5) pred = chain_predict_n<T, 5>(pk);
+			else if (n0 == 6) pred = chain_predict_n<T, 6>(pk);
+			else {
+				T pv[kCandMax];
 #pragma unroll
-			for (int k = 0; k < kCandMax; ++k) pv[k] = cm::bits<T>((U)rl(pk, k));
-			pred = chain_predict<T>(n0, pv);
+				for (int k = 0; k < kCandMax; ++k) pv[k] = cm::bits<T>((U)rl(pk, k));
+				pred = chain_predict<T>(n0, pv);
+			}
+			HRY_CLK({ asm volatile("" :: "v"((uint32_t)cm::bits<U>(pred))); m_t2 = __builtin_amdgcn_s_memtime(); })
 		} else {
 			W acc = 0;
 			uint32_t n = 0;
@@ -506,7 +557,9 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 				}
 			}
 		}
-		return cm::value_from_residual<T>((U)c0, pred, q);
+		const T m_out = cm::value_from_residual<T>((U)c0, pred, q);
+		HRY_CLK({ asm volatile("" :: "v"((uint32_t)cm::bits<U>(m_out))); m_t3 = __builtin_amdgcn_s_memtime(); ck_m1 += m_t1 - m_t0; ck_m2 += m_t2 - m_t1; ck_m3 += m_t3 - m_t2; ++ck_mn; })
+		return m_out;
 	};
 	tile_request(0);
 	uint32_t dense_skip = 0;                     // float chain, dense form: batches that take the exact step at once after the short one kept failing
@@ -1084,9 +1137,9 @@ __device__ void unpredict2_component(const TopoD &tp, const uint32_t *order_v, u
 		HRY_CLK({ const unsigned long long n = __builtin_amdgcn_s_memtime(); ck_pub += n - ck_t; ++ck_batches; ck_nb += nb; })
 	}
 	}
-	HRY_CLK(if (lane == 0 && ck_batches > 100) printf("chain2 comp %d: %llu vertices, %llu batches (mean %llu), bigs %llu, retries %llu, exact batches %llu | per batch: prep %llu (commit %llu, to sources %llu) chain %llu verify %llu exact %llu general %llu publish %llu | bigs at %llu, %llu general batches (mean %llu) | total %llu per vertex %llu\n",
+	HRY_CLK(if (lane == 0 && ck_batches > 100) printf("chain2 comp %d: %llu vertices, %llu batches (mean %llu), bigs %llu, retries %llu, exact batches %llu | per batch: prep %llu (commit %llu, to sources %llu) chain %llu verify %llu exact %llu general %llu publish %llu | bigs at %llu, %llu general batches (mean %llu) | many-candidate: sources %llu predict %llu code %llu | total %llu per vertex %llu\n",
 	        comp, (unsigned long long)(nvtx - seg_begin), ck_batches, ck_nb / ck_batches, ck_bigs, ck_retry, ck_exact_n, ck_prep / ck_batches, ck_p1 / ck_batches, ck_p2 / ck_batches, ck_chain / ck_batches, ck_verify / ck_batches, ck_exact / ck_batches,
-	        ck_general / ck_batches, ck_pub / ck_batches, ck_bigt / (ck_bigs ? ck_bigs : 1), ck_gen_n, ck_gen_nb / (ck_gen_n ? ck_gen_n : 1), __builtin_amdgcn_s_memtime() - ck_begin, (__builtin_amdgcn_s_memtime() - ck_begin) / (nvtx - seg_begin));)
+	        ck_general / ck_batches, ck_pub / ck_batches, ck_bigt / (ck_bigs ? ck_bigs : 1), ck_gen_n, ck_gen_nb / (ck_gen_n ? ck_gen_n : 1), ck_m1 / (ck_mn ? ck_mn : 1), ck_m2 / (ck_mn ? ck_mn : 1), ck_m3 / (ck_mn ? ck_mn : 1), __builtin_amdgcn_s_memtime() - ck_begin, (__builtin_amdgcn_s_memtime() - ck_begin) / (nvtx - seg_begin));)
 }
 
 struct CompSel { int32_t n; int32_t comp[kMaxComp]; };
