@@ -61,7 +61,12 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	const uint32_t nvc = (uint32_t)order_v.size();
 	bool chain_timed = false;
 	HRY_MARK(g_t0, "reconstruct: begin");
-	cx.upload_mesh(*m);   // connectivity + (zeroed) records
+	// connectivity up; the records are born on the device (zeroed there: uploading the host's zeros was a fifth of this copy)
+	cx.upload_mesh(*m, false);
+	for (size_t l = 0; l < m->lists.size() && l < 2; ++l) {
+		cx.d_rec[l].ensure(std::max<size_t>(m->lists[l].data.size(), 16));
+		if (!m->lists[l].data.empty()) HIP_OK(hipMemsetAsync(cx.d_rec[l].p, 0, m->lists[l].data.size(), cx.stream));
+	}
 	HRY_MARK(g_t0, "connectivity uploaded");
 	ConnView cv = cx.conn_view();
 	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
