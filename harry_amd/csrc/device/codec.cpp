@@ -137,6 +137,29 @@ void Context::upload_mesh(Mesh &m, bool with_records)
 	m.device_token = next_token++;
 	resident_token = m.device_token;
 }
+void Context::ensure_second_stream()
+{
+	HIP_OK(hipSetDevice(device));
+	if (!stream2) HIP_OK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+}
+// what upload_mesh does besides the three copies
+void Context::adopt_conn(Mesh &m)
+{
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
+	HIP_OK(hipSetDevice(device));
+	const uint32_t ne = m.ne();
+	int ud = 0;
+	res_has_eface = !m.uniform_degree(ud);
+	res_udeg = (uint32_t)ud;
+	if (res_has_eface) {
+		d_eface.ensure(std::max<size_t>((size_t)ne * 4, 16));
+		dev::launch_edge_faces(stream, d_foff.as<uint32_t>(), m.nf, d_eface.as<uint32_t>());
+	}
+	res_nv = m.nv; res_nf = m.nf; res_ne = ne;
+	m.twins_pending = false;
+	HIP_OK(hipStreamSynchronize(stream));
+	resident_token = 0;
+}
 ConnView Context::conn_view() const
 {
 	ConnView cv;

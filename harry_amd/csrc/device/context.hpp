@@ -105,6 +105,8 @@ struct Context {
 	void stage_put_host(const char *name, const void *hptr, size_t bytes);
 	void ensure_magic(uint32_t n);
 	void upload_mesh(Mesh &m, bool with_records = true);
+	void adopt_conn(Mesh &m);        // the connectivity is in d_foff / d_org / d_twin already (unchunk.cpp: SpanUploader): the rest of upload_mesh
+	void ensure_second_stream();
 	dev::ConnView conn_view() const;
 	float elapsed(int a, int b);
 };

@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include <atomic>
+#include <condition_variable>
 #include <deque>
 #include <thread>
 
@@ -55,14 +56,16 @@ static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0
 // (already in HBM) -> attribute records.  Events 3/4 bracket the kernels.
 static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
                                    const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
-                                   const ListDesc &ldv, const ListDesc &ldf)
+                                   const ListDesc &ldv, const ListDesc &ldf, bool conn_resident = false)
 {
 	Mesh *m = &mesh;
 	const uint32_t nvc = (uint32_t)order_v.size();
 	bool chain_timed = false;
 	HRY_MARK(g_t0, "reconstruct: begin");
-	// connectivity up; the records are born on the device (zeroed there: uploading the host's zeros was a fifth of this copy)
-	cx.upload_mesh(*m, false);
+	// connectivity up (unless it went up beside the replay: SpanUploader); the records are born on the device (zeroed there:
+	// uploading the host's zeros was a fifth of this copy)
+	if (conn_resident) cx.adopt_conn(*m);
+	else cx.upload_mesh(*m, false);
 	for (size_t l = 0; l < m->lists.size() && l < 2; ++l) {
 		cx.d_rec[l].ensure(std::max<size_t>(m->lists[l].data.size(), 16));
 		if (!m->lists[l].data.empty()) HIP_OK(hipMemsetAsync(cx.d_rec[l].p, 0, m->lists[l].data.size(), cx.stream));
@@ -70,7 +73,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<ui
 	HRY_MARK(g_t0, "connectivity uploaded");
 	ConnView cv = cx.conn_view();
 	cx.d_order_v.ensure(std::max<size_t>((size_t)nvc * 4, 16));
-	if (nvc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
+	if (nvc && !conn_resident) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
 	const size_t ncand_bytes = ((size_t)nvc + 63) & ~(size_t)63;
 	const size_t cand_words = (cand_table_words(nvc) + 3) & ~(size_t)3;
 	cx.d_cscratch.ensure(std::max<size_t>(cand_words * 4 + (size_t)nvc * 16 + ncand_bytes + 64, 16));
@@ -169,6 +172,75 @@ struct Stager {
 		}
 	}
 };
+// Connectivity of a mesh of many components, uploaded BESIDE the parallel replay (cut_border_replay's spans): a thread of its own
+// copies every finished span's face offsets, origins, twins and decode order to the device while the other spans are still being
+// replayed -- after the replay nothing of the connectivity is left to copy (290 MB for the 12.6 M-triangle share of configs[3]:
+// 5.6 ms that used to follow the replay).  The copies come straight from the pageable arrays: one thread, a few large ranges.
+struct SpanUploader : SpanDone {
+	Context &cx;
+	Mesh &m;
+	const std::vector<uint32_t> &order_v;
+	struct Range { uint32_t f0, f1, h0, h1, v0, v1; };
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<Range> todo;
+	bool closing = false;
+	uint64_t faces_up = 0, he_up = 0, v_up = 0;
+	std::exception_ptr error;
+	std::thread worker;
+	SpanUploader(Context &c, Mesh &mesh, const std::vector<uint32_t> &ov) : cx(c), m(mesh), order_v(ov)
+	{
+		cx.ensure_second_stream();
+		cx.d_org.ensure(std::max<size_t>((size_t)m.declared_ne * 4, 16));
+		cx.d_twin.ensure(std::max<size_t>((size_t)m.declared_ne * 4, 16));
+		cx.d_foff.ensure(((size_t)m.nf + 1) * 4);
+		cx.d_order_v.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
+		const void *node = callers_node_cpus();
+		worker = std::thread([this, node] {
+			try {
+				stay_on_node(node);
+				HIP_OK(hipSetDevice(cx.device));
+				for (;;) {
+					Range r;
+					{
+						std::unique_lock<std::mutex> lk(mu);
+						cv.wait(lk, [&] { return closing || !todo.empty(); });
+						if (todo.empty()) break;
+						r = todo.front(); todo.pop_front();
+					}
+					if (r.f1 > r.f0) HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + r.f0 + 1, m.face_off.data() + r.f0 + 1, ((size_t)r.f1 - r.f0) * 4, hipMemcpyHostToDevice, cx.stream2));
+					if (r.h1 > r.h0) {
+						HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + r.h0, m.org.data() + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, cx.stream2));
+						HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + r.h0, m.twin.data() + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, cx.stream2));
+					}
+					if (r.v1 > r.v0) HIP_OK(hipMemcpyAsync(cx.d_order_v.as<uint32_t>() + r.v0, order_v.data() + r.v0, ((size_t)r.v1 - r.v0) * 4, hipMemcpyHostToDevice, cx.stream2));
+					faces_up += r.f1 - r.f0; he_up += r.h1 - r.h0; v_up += r.v1 - r.v0;
+				}
+				HIP_OK(hipStreamSynchronize(cx.stream2));
+			} catch (...) { error = std::current_exception(); }
+		});
+	}
+	void span(uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1) override
+	{
+		{ std::lock_guard<std::mutex> g(mu); todo.push_back(Range{ f0, f1, h0, h1, v0, v1 }); }
+		cv.notify_one();
+	}
+	// everything is on the device (true) or the caller uploads as usual (false: the replay ran as one sequence, or a copy failed)
+	bool finish()
+	{
+		{ std::lock_guard<std::mutex> g(mu); closing = true; }
+		cv.notify_one();
+		if (worker.joinable()) worker.join();
+		if (error) return false;
+		if (faces_up != m.nf || he_up != m.declared_ne || v_up != order_v.size() || order_v.size() != m.nv) return false;
+		const uint32_t zero = 0;
+		HIP_OK(hipMemcpyAsync(cx.d_foff.p, &zero, 4, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		return true;
+	}
+	~SpanUploader() { { std::lock_guard<std::mutex> g(mu); closing = true; todo.clear(); } cv.notify_one(); if (worker.joinable()) worker.join(); }
+};
+
 static bool pipelined_decode_applicable(const Mesh &m, const std::vector<RestartPoint> &restarts, const PlaneView *conn,
                                         const ListDesc &ldv, uint32_t vc)
 {
@@ -659,12 +731,17 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v, attr_upto);
 		cx.timing.host_walk_ms = cx.timing.host_walk_ms - std::chrono::duration<double, std::milli>(t_walk - g_t0).count();
 	} else {
-		cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
+		bool conn_resident = false;
+		if (!restarts.empty() && rcounters.size() == restarts.size() && m->nf >= (1u << 20) && !getenv("HRY_NO_SPAN_UPLOAD")) {
+			SpanUploader up(cx, *m, order_v);
+			cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level, &up);
+			conn_resident = up.finish();
+		} else cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
 		cx.timing.host_walk_ms = ms_since(t_walk);
 		HRY_MARK(g_t0, "replay done");
 		if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
 		reconstruct_attributes(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes],
-		                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf);
+		                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, conn_resident);
 	}
 	if (cx.keep_stages) {
 		cx.stage_put("dec_syms", cx.d_csyms.p, total_syms);

@@ -38,7 +38,7 @@ struct Planes {
 // older vertices on its private copy of their counters, so every span runs on its own host thread.
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
-                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
+                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span)
 {
 	using replay_detail::NONE32;
 	int ndeg = 0, onlydeg = 0;
@@ -125,8 +125,10 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 			size_t k = next.fetch_add(1, std::memory_order_relaxed);
 			if (k >= ns) break;
 			Span &sp = spans[k];
+			const uint32_t f0 = sp.cur.face, h0 = sp.cur.he, v0 = sp.cur.next_id;
 			sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
 			check_end(k);
+			if (on_span) on_span->span(f0, sp.cur.face, h0, sp.cur.he, v0, sp.cur.next_id);
 		}
 	});
 	mark("spans replayed");

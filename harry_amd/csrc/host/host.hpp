@@ -182,9 +182,13 @@ struct PlaneView {
 // ---- cbm_unwalk.cpp: cbm::decode restated over flat arrays (cbm/decoder.h:27-211)
 // seg_start: first decode rank of every connected component (+ end sentinel); seg_level[k]: 0 = the component touches no vertex
 // coded before it, else 1 + the level of the latest component it reads from (shared non-manifold vertices)
+// on_span (optional): called by the thread that finished a span of the parallel replay -- faces [f0, f1), half-edges [h0, h1) and
+// vertices [v0, v1) are final in m.face_off (entries f0 + 1 .. f1) / m.org / m.twin / order_v from then on (a span links half-edges
+// of its own components only).  Not called at all when the replay runs as one sequence.
+struct SpanDone { virtual void span(uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1) = 0; virtual ~SpanDone() {} };
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
-                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level);
+                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span = nullptr);
 unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
 uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
 // helper threads run on the CPUs of the memory node their creator is on (block_pool.cpp; HRY_NO_NUMA_BIND switches it off)
