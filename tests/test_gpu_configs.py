@@ -196,3 +196,34 @@ def test_cfg3_cfg4_sharded_as_8_virtual_ranks(cx, cfg4_share):
             covered += int(nf)
         assert np.array_equal(pv[mask_v], ref_v[mask_v]) and np.array_equal(porg[mask_h], ref_org[mask_h])
     assert covered == ref_dec.nf
+
+
+def test_damaged_large_container_while_spans_upload(cx, cfg4_share):
+    """the share's container with bytes flipped behind its directory: the parallel replay (spans on host threads, finished spans
+    going to the device beside it) ends in an error or some mesh -- never a crash or a hang -- and the context decodes the intact
+    container afterwards; the environment switch for the comparison gives the same mesh"""
+    _need_memory(24)
+    mesh, o, ref_dec = cfg4_share
+    a = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    good = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+    info = hc.container_info(good)
+    rng = np.random.default_rng(23)
+    outcomes = {"error": 0, "mesh": 0}
+    for trial in range(6):
+        bad = bytearray(good)
+        # the connectivity streams come first in the body: damage lands in the replay's input
+        for _ in range(1 + trial % 3):
+            k = int(rng.integers(info["header_bytes"] + 4096, info["header_bytes"] + (len(bad) - info["header_bytes"]) // 8))
+            bad[k] ^= int(rng.integers(1, 256))
+        try:
+            cx.read_hry(bytes(bad))
+            outcomes["mesh"] += 1
+        except hc.HryError:
+            outcomes["error"] += 1
+    assert outcomes["error"] + outcomes["mesh"] == 6 and outcomes["error"] > 0
+    same_mesh(cx.read_hry(good), ref_dec)
+    os.environ["HRY_NO_SPAN_UPLOAD"] = "1"
+    try:
+        same_mesh(cx.read_hry(good), ref_dec)
+    finally:
+        del os.environ["HRY_NO_SPAN_UPLOAD"]
