@@ -5,6 +5,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -196,17 +197,17 @@ const void *callers_node_cpus();       // nullptr: one node, or unknown
 void stay_on_node(const void *cpus);   // confines the calling thread
 const void *callers_neighbour_cpus();   // the caller's cache domain (else memory node) without the caller's own core (nullptr: unknown)
 const void *callers_cache_cpus(unsigned *n_cpus);   // CPUs sharing the caller's last-level cache (nullptr: unknown)
-template <typename F> inline void parallel_for(unsigned n_threads, F &&body, const void *cpus = nullptr)   // body(thread index), joins before returning
+void run_on_helpers(unsigned n, void (*fn)(void*, unsigned), void *arg, const void *cpus);   // thread_pool.cpp: helper threads kept between calls
+template <typename F> inline void parallel_for(unsigned n_threads, F &&body, const void *cpus = nullptr)   // body(thread index), returns when every index has
 {
-	std::vector<std::thread> th;
-	std::exception_ptr err;
-	std::mutex mu;
-	const void *node = n_threads > 1 ? (cpus ? cpus : callers_node_cpus()) : nullptr;
-	for (unsigned t = 1; t < n_threads; ++t)
-		th.emplace_back([&, t, node] { stay_on_node(node); try { body(t); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); } });
-	try { body(0); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
-	for (auto &x : th) x.join();
-	if (err) std::rethrow_exception(err);
+	if (n_threads <= 1) { body(0); return; }
+	typedef typename std::remove_reference<F>::type Body;
+	struct Job { Body *body; std::exception_ptr err; std::mutex mu; } job{ &body, nullptr, {} };
+	run_on_helpers(n_threads, [](void *a, unsigned t) {
+		Job &j = *(Job*)a;
+		try { (*j.body)(t); } catch (...) { std::lock_guard<std::mutex> g(j.mu); if (!j.err) j.err = std::current_exception(); }
+	}, &job, cpus);
+	if (job.err) std::rethrow_exception(job.err);
 }
 
 // ---- static priors of the chunked container's planes (header.cpp; the oracle restates the rule and the directory form)
