@@ -455,7 +455,7 @@ int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_wal
 		if (minor != 1) throw Error(HRY_E_ARG, "not a single-stream (v0.1) file");
 		if (m->m.general) throw Error(HRY_E_UNSUPPORTED, "hry_stream_read_host returns the planes of the PLY layout only");
 		std::vector<uint32_t> seg_start, seg_level;
-		std::vector<uint32_t> order_v;
+		OrderVec order_v;
 		read_compat_stream((const uint8_t*)hry + hdr, bytes - hdr, m->m, order_v, seg_start, seg_level, w->vplanes, w->fplanes);
 		w->w.order_v.assign(order_v.begin(), order_v.end());
 		w->info[0] = w->info[1] = 0;
@@ -487,7 +487,7 @@ int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_p
 		std::vector<RestartPoint> restarts;
 		std::vector<RestartCounters> rcounters;
 		if (use_restart_points) restarts = select_restart_points(r.marks, r.named, rcounters);
-		std::vector<uint32_t> order_v;
+		OrderVec order_v;
 		PlaneView views[21];
 		for (int k = 0; k < 21; ++k) views[k] = PlaneView(planes[k]);
 		cut_border_replay(m->m, views, restarts, rcounters, order_v, w->seg_start, w->seg_level);

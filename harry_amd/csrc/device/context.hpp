@@ -139,7 +139,7 @@ std::vector<GenPlane> general_plane_layout(const Mesh &m);
 void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vector<PlaneRef> &planes);
 // decode: the decoded planes (device, plane k at d_syms + plane_off[k], nsym[k] symbols; first = index of the first attribute
 // plane) -> bindings + records of m
-void general_planes_decode(Context &cx, Mesh &m, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+void general_planes_decode(Context &cx, Mesh &m, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                            const std::vector<uint32_t> &seg_level, const uint8_t *d_syms, const std::vector<uint64_t> &plane_off,
                            const std::vector<uint32_t> &nsym, uint32_t first);
 

@@ -49,10 +49,10 @@ void launch_gen_sources(hipStream_t st, int kind, const ConnView &cv, const GenV
 void launch_gen_chain(hipStream_t st, int kind, int stype, const ConnView &cv, const GenView &gv, const uint32_t *rank, const GenChainJob *jobs, uint32_t njobs);
 void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t *rec);
 }
-bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                   const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes, const uint8_t *d_vplanes = nullptr);   // unchunk.cpp
 bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order);                                                                             // unchunk.cpp
-void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                       const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, long long trace_origin);                    // unchunk.cpp
 long long trace_origin_ns();                                                                                                                          // unchunk.cpp
 
@@ -440,7 +440,7 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 // Device part of a decode with general bindings: connectivity, bindings and the lists (holding residual codes in record layout,
 // or -- chunked container -- zeros, the codes being scattered from the decoded planes by `fill`) go up; every list with records
 // to reconstruct gets its source table and its chains.  ev[l] empty: the list is final already (vertex fast path) or has no records.
-static void reconstruct_general(Context &cx, Mesh &m, const std::vector<uint32_t> &order_v, const std::vector<GenRecordEvents> &ev,
+static void reconstruct_general(Context &cx, Mesh &m, const OrderVec &order_v, const std::vector<GenRecordEvents> &ev,
                                 const std::function<void()> &fill)
 {
 	auto t_h2d = Clock::now();
@@ -525,7 +525,8 @@ Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 			if (L.stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
 		}
 	auto t_walk = Clock::now();
-	std::vector<uint32_t> order_v, seg_start, seg_level;
+	OrderVec order_v;
+	std::vector<uint32_t> seg_start, seg_level;
 	std::vector<GenRecordEvents> ev;
 	std::vector<uint8_t> vplanes;
 	// one vertex region with one list (every OBJ whose "v" lines have the same number of values): candidate for the vertex chains
@@ -630,7 +631,7 @@ void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vecto
 
 namespace dev { void launch_residuals_to_rec(hipStream_t st, const uint8_t *planes, uint32_t n, const ListDesc &ld, uint8_t *rec); }
 
-void general_planes_decode(Context &cx, Mesh &m, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+void general_planes_decode(Context &cx, Mesh &m, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                            const std::vector<uint32_t> &seg_level, const uint8_t *d_syms, const std::vector<uint64_t> &plane_off,
                            const std::vector<uint32_t> &nsym, uint32_t first)
 {

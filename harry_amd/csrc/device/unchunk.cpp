@@ -54,7 +54,7 @@ static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0
 
 // Attribute reconstruction on the device, shared by both formats: connectivity + decode order + residual byte planes
 // (already in HBM) -> attribute records.  Events 3/4 bracket the kernels.
-static void reconstruct_attributes(Context &cx, Mesh &mesh, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                    const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
                                    const ListDesc &ldv, const ListDesc &ldf, bool conn_resident = false)
 {
@@ -179,7 +179,7 @@ struct Stager {
 struct SpanUploader : SpanDone {
 	Context &cx;
 	Mesh &m;
-	const std::vector<uint32_t> &order_v;
+	const OrderVec &order_v;
 	struct Range { uint32_t f0, f1, h0, h1, v0, v1; };
 	std::mutex mu;
 	std::condition_variable cv;
@@ -188,7 +188,7 @@ struct SpanUploader : SpanDone {
 	uint64_t faces_up = 0, he_up = 0, v_up = 0;
 	std::exception_ptr error;
 	std::thread worker;
-	SpanUploader(Context &c, Mesh &mesh, const std::vector<uint32_t> &ov) : cx(c), m(mesh), order_v(ov)
+	SpanUploader(Context &c, Mesh &mesh, const OrderVec &ov) : cx(c), m(mesh), order_v(ov)
 	{
 		cx.ensure_second_stream();
 		cx.d_org.ensure(std::max<size_t>((size_t)m.declared_ne * 4, 16));
@@ -253,7 +253,7 @@ static bool pipelined_decode_applicable(const Mesh &m, const std::vector<Restart
 
 // attr_upto[g]: the vertex planes are decoded up to this vertex once cx.attr_ev[g] has fired (the last entry covers everything)
 static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
-                             const ListDesc &ldv, const ListDesc &ldf, std::vector<uint32_t> &order_v, const uint32_t (&attr_upto)[Context::kAttrGroups])
+                             const ListDesc &ldv, const ListDesc &ldf, OrderVec &order_v, const uint32_t (&attr_upto)[Context::kAttrGroups])
 {
 	Mesh *m = &mesh;
 	const uint32_t nv = m->nv, nf = m->nf, ne = m->declared_ne;
@@ -717,7 +717,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	HRY_MARK(g_t0, "connectivity planes on the host");
 	// ---- replay the cut-border machine on the host
 	auto t_walk = Clock::now();
-	std::vector<uint32_t> order_v, seg_start, seg_level;
+	OrderVec order_v;
+	std::vector<uint32_t> seg_start, seg_level;
 	bool pipelined = false;
 	if (m->general) {
 		cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
@@ -760,7 +761,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 // General bindings (general.cpp) whose vertices all carry a private record of ONE list: that list is the vertex list of the PLY
 // layout in everything that matters to the reconstruction chains (record i belongs to the i-th coded vertex, candidates are the
 // parallelograms of the fan), so it takes them.  The mesh lends its connectivity and the list for the duration of the call.
-bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                   const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes, const uint8_t *d_vplanes)
 {
 	const ListDesc ldv = make_list_desc(m.lists[l]);
@@ -792,7 +793,7 @@ bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order)
 	const ListDesc ldv = make_list_desc(m.lists[l]);
 	return ldv.nplanes && unpredict2_applicable(ldv) && m.lists[l].count >= n_order;
 }
-void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const std::vector<uint32_t> &order_v, const std::vector<uint32_t> &seg_start,
+void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                       const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, long long trace_origin)
 {
 	HIP_OK(hipSetDevice(cx.device));
@@ -812,7 +813,8 @@ Mesh *decode_compat(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::un
 		for (int c = 0; c < m->lists[l].ncomp(); ++c)
 			if (m->lists[l].stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
 	auto t_walk = Clock::now();
-	std::vector<uint32_t> order_v, seg_start, seg_level;
+	OrderVec order_v;
+	std::vector<uint32_t> seg_start, seg_level;
 	std::vector<uint8_t> vplanes, fplanes;
 	read_compat_stream(p + hdr, n - hdr, *m, order_v, seg_start, seg_level, vplanes, fplanes);
 	cx.timing.host_walk_ms = ms_since(t_walk);

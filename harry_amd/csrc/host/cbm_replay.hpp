@@ -665,7 +665,7 @@ inline void replay_levels(const std::vector<uint32_t> &seg_start, const std::vec
 
 // the whole connectivity as one span (reference v0.1 streams, and v0.2 containers without restart points)
 template <class RD>
-void cut_border_replay_with(Mesh &m, RD &rd, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
+void cut_border_replay_with(Mesh &m, RD &rd, OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level)
 {
 	m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
 	m.org.resize(m.declared_ne);

@@ -1,6 +1,8 @@
 // Cut-border replay from entropy-decoded symbol planes (chunked profile).  See cbm_replay.hpp.
 #include "cbm_replay.hpp"
 
+#include <cstring>
+
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -38,7 +40,7 @@ struct Planes {
 // older vertices on its private copy of their counters, so every span runs on its own host thread.
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
-                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span)
+                       OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span)
 {
 	using replay_detail::NONE32;
 	int ndeg = 0, onlydeg = 0;
@@ -99,8 +101,14 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 	m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
 	m.org.resize(m.declared_ne);
 	m.twin.resize(m.declared_ne);
-	order_v.assign(m.nv, 0);
-	BigVec<uint16_t> seen(m.nv, 0);
+	// (pooled arrays, zeroed by the helper threads: the two fills were 3 of the 4.3 ms in front of the spans on the 12.6 M-triangle share)
+	order_v.clear(); order_v.resize(m.nv);
+	BigVec<uint16_t> seen;
+	seen.resize(m.nv);
+	parallel_for(n_threads, [&](unsigned t) {
+		const size_t b = (size_t)m.nv * t / n_threads, e = (size_t)m.nv * (t + 1) / n_threads;
+		if (e > b) { memset(order_v.data() + b, 0, (e - b) * 4); memset(seen.data() + b, 0, (e - b) * 2); }
+	});
 	const RestartCounters none;
 	mark("allocated");
 	// a span must end exactly where the next one starts, in every counter

@@ -307,7 +307,7 @@ struct GeneralReader {
 		if (k == NONE) throw Error(HRY_E_FORMAT, "corrupt stream (per-vertex record history)");
 		return pool[k].idx;
 	}
-	void run(const std::vector<uint32_t> &order_v)
+	void run(const OrderVec &order_v)
 	{
 		if (b.nb_corner > 255 || b.nb_vtx > 255 || b.nb_face > 255) throw Error(HRY_E_UNSUPPORTED, "more than 255 lists bound to one region");
 		b.corner_attr.assign((size_t)m.ne() * b.nb_corner, 0);
@@ -359,7 +359,7 @@ struct GeneralReader {
 
 }   // namespace
 
-void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events,
+void read_general_stream(const uint8_t *p, size_t n, Mesh &m, OrderVec &order_v, std::vector<GenRecordEvents> &events,
                          std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, int plane_list, std::vector<uint8_t> &planes)
 {
 	Live lv(p, p + n, m);
@@ -373,7 +373,7 @@ void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32
 	gr.run(order_v);
 }
 
-void read_general_planes(Mesh &m, const std::vector<uint32_t> &order_v, const GenHostPlanes &hp, std::vector<GenRecordEvents> &events)
+void read_general_planes(Mesh &m, const OrderVec &order_v, const GenHostPlanes &hp, std::vector<GenRecordEvents> &events)
 {
 	if (hp.lists.size() != m.lists.size()) throw Error(HRY_E_INTERNAL, "plane table does not match the lists");
 	PlaneSource src(hp);
@@ -381,7 +381,7 @@ void read_general_planes(Mesh &m, const std::vector<uint32_t> &order_v, const Ge
 	gr.run(order_v);
 }
 
-void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
+void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, OrderVec &order_v, std::vector<uint32_t> &seg_start,
                         std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes)
 {
 	Live lv(p, p + n, m);

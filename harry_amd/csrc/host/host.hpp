@@ -189,7 +189,7 @@ struct PlaneView {
 struct SpanDone { virtual void span(uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1) = 0; virtual ~SpanDone() {} };
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
-                       std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span = nullptr);
+                       OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span = nullptr);
 unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
 uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
 // helper threads run on the CPUs of the memory node their creator is on (block_pool.cpp; HRY_NO_NUMA_BIND switches it off)
@@ -221,7 +221,7 @@ size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256]
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 // reference single-stream format (compat_read.cpp): serial entropy decode + replay on the host; residual byte planes
 // (plane-major, one plane per coded byte) are returned for the device reconstruction
-void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<uint32_t> &seg_start,
+void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, OrderVec &order_v, std::vector<uint32_t> &seg_start,
                         std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes);
 
 // the same for a stream whose header announces general bindings (regions, shared records, corner lists; mesh.hpp Bindings):
@@ -229,7 +229,7 @@ void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_
 // record was created: the half-edge of the vertex / the corner (the face index for face lists) and the slot of the list there
 struct GenRecordEvents { std::vector<uint32_t> he; std::vector<uint8_t> slot; };
 // plane_list >= 0: the residual bytes of that list additionally plane-major (one plane per coded byte, order_v.size() records each)
-void read_general_stream(const uint8_t *p, size_t n, Mesh &m, std::vector<uint32_t> &order_v, std::vector<GenRecordEvents> &events,
+void read_general_stream(const uint8_t *p, size_t n, Mesh &m, OrderVec &order_v, std::vector<GenRecordEvents> &events,
                          std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, int plane_list, std::vector<uint8_t> &planes);
 
 // the same bookkeeping over the decoded planes of a chunked container (host copies): region planes (absent with one region),
@@ -241,7 +241,7 @@ struct GenHostPlanes {
 	struct L { const uint8_t *type = nullptr, *gh[4] = { nullptr, nullptr, nullptr, nullptr }, *lh[2] = { nullptr, nullptr }; uint32_t n_type = 0, n_gh = 0, n_lh = 0, n_data = 0; };
 	std::vector<L> lists;
 };
-void read_general_planes(Mesh &m, const std::vector<uint32_t> &order_v, const GenHostPlanes &hp, std::vector<GenRecordEvents> &events);
+void read_general_planes(Mesh &m, const OrderVec &order_v, const GenHostPlanes &hp, std::vector<GenRecordEvents> &events);
 
 // a shard writes the sizes of the full mesh (m.shard.g_*): the header of a sharded container describes the whole
 void write_hry_header(const Mesh &m, int ver_minor, std::vector<uint8_t> &out);

@@ -43,6 +43,7 @@ template <typename T> struct PoolAlloc {
 	template <typename U> bool operator!=(const PoolAlloc<U>&) const noexcept { return false; }
 };
 template <typename T> using BigVec = std::vector<T, PoolAlloc<T>>;
+typedef BigVec<uint32_t> OrderVec;   // the decode order (one half-edge per coded vertex): 4 bytes per vertex, per call
 
 struct Error : std::runtime_error {
 	int code;

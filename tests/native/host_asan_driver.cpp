@@ -108,7 +108,8 @@ int main(int argc, char **argv)
 				int minor = 0;
 				const size_t h = read_hry_header(data.data(), data.size(), m, minor);
 				if (minor == 1) {
-					std::vector<uint32_t> order_v, seg_start, seg_level;
+					OrderVec order_v;
+					std::vector<uint32_t> seg_start, seg_level;
 					if (m.general) {
 						std::vector<GenRecordEvents> ev;
 						std::vector<uint8_t> planes;
@@ -136,7 +137,8 @@ int main(int argc, char **argv)
 						const size_t hb = read_hry_header(bad.data(), bad.size(), b, mn);
 						if (getenv("HRY_DRIVER_VERBOSE")) fprintf(stderr, "  minor %d nv %u nf %u general %d\n", mn, b.nv, b.nf, (int)b.general);
 						if (mn == 1 && (uint64_t)b.nv + b.nf < (1u << 22)) {
-							std::vector<uint32_t> ov, ss, sl;
+							OrderVec ov;
+							std::vector<uint32_t> ss, sl;
 							if (b.general) { std::vector<GenRecordEvents> ev; std::vector<uint8_t> pl; read_general_stream(bad.data() + hb, bad.size() - hb, b, ov, ev, ss, sl, -1, pl); }
 							else { std::vector<uint8_t> vp, fp; read_compat_stream(bad.data() + hb, bad.size() - hb, b, ov, ss, sl, vp, fp); }
 						}
