@@ -6,8 +6,10 @@
 // share of configs[3].  Now every CALLING thread owns a set of parked helpers (thread-local: the worker threads of the
 // in-process N-device executor each have theirs, sized by their own thread budget); a call publishes the job under the set's
 // mutex, runs index 0 itself and waits for the others.  Helpers are detached and hold the set's state alive; they leave when
-// their owner thread ends (or with the process).  A call made while the caller's set is busy (a body that calls parallel_for
+// their owner thread ends (or with the process); a forked child starts without any.  A call made while the caller's set is busy (a body that calls parallel_for
 // itself on the calling thread) falls back to threads of its own.
+#include <pthread.h>
+
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -40,6 +42,9 @@ struct Pool {
 	}
 };
 thread_local Pool t_pool;
+// a forked child has the forking thread only: its copy of the set names helpers that do not exist there
+void forget_helpers_in_child() { new (&t_pool.st) std::shared_ptr<PoolState>(); }   // (the old state is left alone: its mutex may be held)
+struct AtFork { AtFork() { (void)pthread_atfork(nullptr, nullptr, forget_helpers_in_child); } };
 
 void helper_main(std::shared_ptr<PoolState> st, unsigned index, uint64_t seen)
 {
@@ -80,6 +85,7 @@ void run_on_helpers(unsigned n, void (*fn)(void*, unsigned), void *arg, const vo
 {
 	if (n <= 1) { fn(arg, 0); return; }
 	const void *node = cpus ? cpus : callers_node_cpus();
+	static AtFork at_fork;
 	Pool &P = t_pool;
 	if (!P.st) P.st = std::make_shared<PoolState>();
 	PoolState &S = *P.st;
