@@ -343,3 +343,32 @@ def test_lean_triangle_walk_equals_generic_walk(case, threads, monkeypatch):
     for k in out[0][0]:
         assert np.array_equal(out[0][0][k], out[1][0][k]), k
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.timeout(120)
+def test_parallel_walk_in_a_forked_child(monkeypatch):
+    """the helper threads of parallel_for (host/thread_pool.cpp) are kept between calls; a forked child has none of them and must
+    start its own instead of waiting for the parent's"""
+    import ctypes as C
+    from harry_amd import _native as nat
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1000")
+    m0 = mg.multi_component(6, 60, 62, seed=4, polys="mixed")
+    m = hc.Mesh.from_ply(m0.to_ply())
+    L = nat.load()
+
+    def walk():
+        a, w = m.clone(), C.c_void_p()
+        nat.check(L.hry_walk_run_plain(a.h, C.byref(w)))
+        L.hry_walk_free(w)
+
+    walk()                      # the parent's helpers exist now
+    pid = os.fork()
+    if pid == 0:
+        try:
+            walk()
+            os._exit(0)
+        except BaseException:
+            os._exit(1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    walk()
