@@ -184,6 +184,10 @@ def main():
             self_launch(args)
         return inprocess_main(args)
     stay_on_memory_node()
+    # host threads of the multi-component walks / replays: the library's default (32 on these hosts) is an eighth of the node, for
+    # eight ranks side by side; a rank that has the node to itself takes the cores of its socket
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "HRY_HOST_THREADS" not in os.environ:
+        os.environ["HRY_HOST_THREADS"] = str(max(8, min(64, len(os.sched_getaffinity(0)) // 2)))
 
     import torch
     import torch.distributed as dist
@@ -356,7 +360,8 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u16 residual bytes, u32 range-coder registers (compat profile: u64)" if world == 1 else "u8 residual bytes of f32 values, u32 range-coder registers", "data": "synthetic",
             "config": {"workload": per_gpu if world == 1 else f"ONE mesh shaped like BASELINE configs[3] ({ntri} triangles, {n_comps} components, {n_groups} groups); per GPU: {per_gpu}; sharded by connected component",
-                       "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}, one process per GPU", "inputs_resident": True},
+                       "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}, one process per GPU", "inputs_resident": True,
+                       "host_threads": os.environ.get("HRY_HOST_THREADS", "library default (an eighth of the node, at most 32)")},
             "encode_mtri_s": round(ntri * args.steps / t_enc / 1e6, 4),
             "decode_mtri_s": round(ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
             "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / max(base.nv, 1), 4),
