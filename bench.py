@@ -703,6 +703,16 @@ def cfg4_share_leg(cx):
     te, td = tms[-1]
     ntri = mesh.ntri
     alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
+    traffic = traffic_raw = traffic_source = None
+    for rnd in ("r3",):   # the PMC passes of this very workload (scripts/collect_profiles.sh: leg cfg4share)
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "cfg4share", "traffic.json")) as f:
+                hit = json.load(f)["kernels"]["k_unpredict2<float>"]
+            traffic = 2 * hit["fetch_bytes"] + hit["write_bytes"]
+            traffic_raw = {"FETCH_SIZE_bytes": hit["fetch_bytes"], "WRITE_SIZE_bytes": hit["write_bytes"]}
+            traffic_source = f"profiles/{rnd}/cfg4share/traffic.json (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 per the gfx950 note; the three chains of a component write 4 bytes each into the same 12-byte records)"
+        except (OSError, KeyError, ValueError):
+            pass
     return {"workload": "128 mixed-polygon components (40 % quads, 5 % pentagons) with 0.1 % non-manifold edges and 0.05 % non-manifold vertices, float32 xyz, lossless: one GPU's share of BASELINE configs[3]",
             "triangles": int(ntri), "value": round(ntri / (er + dd) / 1e6, 3), "encode_mtri_s": round(ntri / er / 1e6, 3), "encode_from_host_mtri_s": round(ntri / e / 1e6, 3),
             "decode_mtri_s": round(ntri / dd / 1e6, 3), "encode_ms": round(er * 1e3, 2), "encode_from_host_ms": round(e * 1e3, 2), "decode_ms": round(dd * 1e3, 2),
@@ -711,7 +721,8 @@ def cfg4_share_leg(cx):
             "k_chunk_encode_ms": round(te["k_entropy_ms"], 2), "k_chunk_decode_ms": round(td["k_entropy_ms"], 2), "k_predict_ms": round(te["k_predict_ms"], 2),
             "roofline": {"bound": "hbm", "kernel": "k_unpredict2<float>", "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_triangle": round(alg / ntri, 2),
                          "kernel_ms": round(td["k_chain_ms"], 3), "achieved": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9, 3) if td["k_chain_ms"] > 0 else None,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if td["k_chain_ms"] > 0 else None},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if td["k_chain_ms"] > 0 else None,
+                         "traffic": traffic, "traffic_raw": traffic_raw, "traffic_source": traffic_source},
             "round_trip_invariants_ok": ok, "passes": 2}
 
 
