@@ -1149,13 +1149,21 @@ struct CompSel { int32_t n; int32_t comp[kMaxComp]; };
 template <typename T>
 __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand,
                                                    const uint8_t *planes, ListDesc ld, uint8_t *rec, uint32_t ring_bytes, CompSel sel,
-                                                   const uint32_t *segs, const uint32_t *list_off, CrossSync xs)
+                                                   const uint32_t *segs, const uint32_t *list_off, CrossSync xs, uint32_t n_lists)
 {
 	extern __shared__ unsigned long long ring_raw2[];
-	const int c = sel.comp[blockIdx.x];
+	// The chains of a mesh component's attribute components (x, y, z) write 4 bytes each into the same 12-byte records: they run on
+	// ONE XCD -- workgroups go round-robin over the eight, so a group of 8 sel.n consecutive workgroups holds eight lists, workgroup
+	// c * 8 + j of the group = attribute component c of list j -- and their stores meet in one L2 instead of three (the
+	// configs[3] share wrote 334 MB for 76 MB of records with (component, list) -> (blockIdx.x, blockIdx.y)).  A chain still
+	// only waits for the same attribute component of an EARLIER list, i.e. for a lower workgroup index.
+	const uint32_t per = 8u * (uint32_t)sel.n, grp = blockIdx.x / per, r = blockIdx.x % per;
+	const uint32_t list = grp * 8u + (r & 7u);
+	if (list >= n_lists) return;
+	const int c = sel.comp[r >> 3];
 	TopoD tp{ cv };
 	// segs: triples (first decode rank, end, component of the mesh)
-	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
+	for (uint32_t k = list_off[list]; k < list_off[list + 1]; ++k) {
 		const uint32_t b = segs[3 * k], e = segs[3 * k + 1];
 		if (b < e)
 			unpredict2_component<T>(tp, order_v, nvtx, b, e, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
@@ -1688,13 +1696,18 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 
 template <typename T>
 __global__ __launch_bounds__(512) void k_unpredict3(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
-                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, const uint32_t *segs, const uint32_t *list_off, CrossSync xs)
+                                                   const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, const uint32_t *segs, const uint32_t *list_off, CrossSync xs,
+                                                   uint32_t n_lists)
 {
 	__shared__ T ring3[kRing3];
 	__shared__ uint32_t sync3[kHand0 + kHand];
-	const int c = sel.comp[blockIdx.x];
+	// (the attribute components of a list on ONE XCD: see k_unpredict2)
+	const uint32_t per = 8u * (uint32_t)sel.n, grp = blockIdx.x / per, r = blockIdx.x % per;
+	const uint32_t list = grp * 8u + (r & 7u);
+	if (list >= n_lists) return;
+	const int c = sel.comp[r >> 3];
 	TopoD tp{ cv };
-	for (uint32_t k = list_off[blockIdx.y]; k < list_off[blockIdx.y + 1]; ++k) {
+	for (uint32_t k = list_off[list]; k < list_off[list + 1]; ++k) {
 		const uint32_t b = segs[3 * k], e = segs[3 * k + 1];
 		if (b < e) unpredict3_segment<T>(tp, order_v, nvtx, b, e, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, b, sync3, xs, c);
 		raise_flag(xs, c, segs[3 * k + 2], e);
@@ -1853,8 +1866,8 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64 * chain_waves(nvtx)), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
-		                   segs, list_off, xs);
+		hipLaunchKernelGGL(kern, dim3(((n_lists + 7) / 8) * 8 * (uint32_t)sel.n), dim3(64 * chain_waves(nvtx)), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
+		                   segs, list_off, xs, n_lists);
 	};
 	// the ring + the rows of a tile's many-candidate vertices (64 x 24 words): 38 KB, four chains per compute unit (round 2's input
 	// queue made it 58 KB and two)
@@ -1864,8 +1877,8 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
 		(void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-		hipLaunchKernelGGL(kern, dim3(sel.n, n_lists), dim3(64), lds_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel,
-		                   segs, list_off, xs);
+		hipLaunchKernelGGL(kern, dim3(((n_lists + 7) / 8) * 8 * (uint32_t)sel.n), dim3(64), lds_bytes, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, planes, ld, rec, ring_bytes, sel,
+		                   segs, list_off, xs, n_lists);
 	};
 	// components of different types are independent chains too: their kernels may overlap on the device
 	go(k_unpredict2<float>, 0); go(k_unpredict2<uint32_t>, 4); go(k_unpredict2<int32_t>, 5);
