@@ -686,7 +686,10 @@ template <int KIND, typename T>
 __global__ __launch_bounds__(64) void k_gen_chain(ConnView cv, GenView gv, const uint32_t *rank, const GenChainJob *jobs)
 {
 	__shared__ uint32_t s_val[64];
-	chain_component<KIND, T>(cv, gv, rank, jobs[blockIdx.x], s_val);
+	// the components of a list write into the same records: every chain of the launch on ONE XCD (workgroups go round-robin over the
+	// eight; only every eighth carries a chain), so that their stores meet in one L2 -- as the chains of the PLY layout do
+	if (blockIdx.x & 7u) return;
+	chain_component<KIND, T>(cv, gv, rank, jobs[blockIdx.x >> 3], s_val);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -721,13 +724,13 @@ template <int KIND>
 static void launch_chain_kind(hipStream_t st, int stype, const ConnView &cv, const GenView &gv, const uint32_t *rank, const GenChainJob *jobs, uint32_t njobs)
 {
 	switch (stype) {
-	case 0: hipLaunchKernelGGL((k_gen_chain<KIND, float>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
-	case 4: hipLaunchKernelGGL((k_gen_chain<KIND, uint32_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
-	case 5: hipLaunchKernelGGL((k_gen_chain<KIND, int32_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
-	case 6: hipLaunchKernelGGL((k_gen_chain<KIND, uint16_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
-	case 7: hipLaunchKernelGGL((k_gen_chain<KIND, int16_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
-	case 8: hipLaunchKernelGGL((k_gen_chain<KIND, uint8_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
-	case 9: hipLaunchKernelGGL((k_gen_chain<KIND, int8_t>), dim3(njobs), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 0: hipLaunchKernelGGL((k_gen_chain<KIND, float>), dim3((njobs - 1) * 8 + 1), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 4: hipLaunchKernelGGL((k_gen_chain<KIND, uint32_t>), dim3((njobs - 1) * 8 + 1), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 5: hipLaunchKernelGGL((k_gen_chain<KIND, int32_t>), dim3((njobs - 1) * 8 + 1), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 6: hipLaunchKernelGGL((k_gen_chain<KIND, uint16_t>), dim3((njobs - 1) * 8 + 1), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 7: hipLaunchKernelGGL((k_gen_chain<KIND, int16_t>), dim3((njobs - 1) * 8 + 1), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 8: hipLaunchKernelGGL((k_gen_chain<KIND, uint8_t>), dim3((njobs - 1) * 8 + 1), dim3(64), 0, st, cv, gv, rank, jobs); break;
+	case 9: hipLaunchKernelGGL((k_gen_chain<KIND, int8_t>), dim3((njobs - 1) * 8 + 1), dim3(64), 0, st, cv, gv, rank, jobs); break;
 	default: break;   // 8-byte storage types are rejected on the host
 	}
 }
