@@ -60,7 +60,7 @@ static uint32_t stream_words(uint32_t n, uint32_t t0)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &out)
+void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 {
 	HIP_OK(hipSetDevice(cx.device));
 	auto t_all = Clock::now();
@@ -77,16 +77,20 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 	// mesh, then its runs and an ordinary v0.2 body of the shard in its own numbering
 	const bool sharded = m.shard.active();
 	out.clear();
-	write_hry_header(m, sharded ? 3 : 2, out);
+	{
+		std::vector<uint8_t> hdr;
+		write_hry_header(m, sharded ? 3 : 2, hdr);
+		out.append(hdr.data(), hdr.data() + hdr.size());
+	}
 	size_t seg_len_at = 0, seg_begin = 0;
 	if (sharded && m.nf == 0) {   // a rank without a group to code contributes no segment
 		const uint32_t none = 0;
-		out.insert(out.end(), (const uint8_t*)&none, (const uint8_t*)&none + 4);
+		out.append((const uint8_t*)&none, (const uint8_t*)&none + 4);
 		cx.timing.total_ms = ms_since(t_all);
 		return;
 	}
 	if (sharded) {
-		auto put32 = [&](uint32_t v) { out.insert(out.end(), (const uint8_t*)&v, (const uint8_t*)&v + 4); };
+		auto put32 = [&](uint32_t v) { out.append((const uint8_t*)&v, (const uint8_t*)&v + 4); };
 		put32(1);
 		seg_len_at = out.size();
 		put32(0); put32(0);
@@ -98,8 +102,8 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &
 		if (m.shard.run_records.size() != nl2 * m.shard.runs.size()) throw Error(HRY_E_ARG, "shard without its record ranges");
 		for (size_t j = 0; j < m.shard.runs.size(); ++j) {
 			const uint8_t *rp = (const uint8_t*)&m.shard.runs[j];
-			out.insert(out.end(), rp, rp + sizeof(ShardRun));
-			if (nl2) { const uint8_t *qp = (const uint8_t*)(m.shard.run_records.data() + j * nl2); out.insert(out.end(), qp, qp + 4 * nl2); }
+			out.append(rp, rp + sizeof(ShardRun));
+			if (nl2) { const uint8_t *qp = (const uint8_t*)(m.shard.run_records.data() + j * nl2); out.append(qp, qp + 4 * nl2); }
 		}
 	}
 	auto t_walk = Clock::now();

@@ -150,7 +150,7 @@ void upload_general(Context &cx, Mesh &m);     // connectivity + every list + th
 void device_bounds(Context &cx, Mesh &m);
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);
 void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
-void encode_chunked(Context &cx, Mesh &m, int chunk_syms, std::vector<uint8_t> &out);
+void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out);   // (bytes that are not zero-filled first and go to the caller as they are)
 void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out);   // general.cpp: regions, shared records, corner lists (reference stream only)
 Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload);

@@ -168,7 +168,7 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 	}
 	st.combine_ms = ms_since(t0);
 	// ---- phase B: quantisation + encode, one segment per shard
-	std::vector<std::vector<uint8_t>> parts((size_t)n_shards);
+	std::unique_ptr<ByteSink[]> parts(new ByteSink[(size_t)n_shards]);
 	t0 = Clock::now();
 	run_workers(cxs, n_ctx, [&](int w) {
 		hry_timing acc{};
@@ -193,14 +193,14 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 	t0 = Clock::now();
 	std::vector<const uint8_t*> pp;
 	std::vector<size_t> ps;
-	for (auto &v : parts) { pp.push_back(v.data()); ps.push_back(v.size()); }
+	for (int s = 0; s < n_shards; ++s) { pp.push_back(parts[s].data()); ps.push_back(parts[s].size()); }
 	merge_containers(pp.data(), ps.data(), pp.size(), out);
 	st.merge_ms = ms_since(t0);
 	auto mx = [](const std::vector<double> &v) { double x = 0; for (double y : v) x = std::max(x, y); return x; };
 	st.extract_ms = mx(w_extract); st.bounds_ms = mx(w_bounds); st.quant_ms = mx(w_quant); st.encode_ms = mx(w_encode);
 	for (int w = 0; w < n_ctx; ++w) st.host_walk_ms = std::max(st.host_walk_ms, cxs[w]->timing.host_walk_ms);
 	st.n_segments = 0;
-	for (auto &v : parts) st.n_segments += v.size() > 0;
+	for (int s = 0; s < n_shards; ++s) st.n_segments += parts[s].size() > 0;
 	st.total_ms = ms_since(t_all);
 }
 
