@@ -165,6 +165,46 @@ def stay_on_memory_node():
     return None
 
 
+def _node_cpus(node: int):
+    cpus = set()
+    for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def stay_on_gpu_node(device: int, local_rank: int, local_world: int):
+    """A rank of an N-GPU run works on the memory node its GPU hangs on (what the in-process executor does for its worker threads,
+    device/sharded.cpp: device_cpus): the launcher starts the ranks wherever the scheduler puts them, six on one socket is as
+    likely as four.  Where the GPU's PCI address does not show in sysfs (virtualised pools) the ranks are spread over the nodes
+    in the order of their local ranks (GPUs 0 .. N/2 - 1 on the first socket is how these platforms are built).  Returns (node, how)."""
+    n_nodes = 0
+    while os.path.exists(f"/sys/devices/system/node/node{n_nodes}/cpulist"):
+        n_nodes += 1
+    if n_nodes < 2:
+        return None, "one memory node"
+    node, how = None, ""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device)
+        bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read())
+        how = f"numa_node of {bus}"
+    except Exception:
+        node = None
+    if node is None or node < 0 or node >= n_nodes:
+        node = min(n_nodes - 1, local_rank * n_nodes // max(local_world, 1))
+        how = "by local rank (the GPU's PCI address is not in sysfs)"
+    try:
+        cpus = _node_cpus(node)
+        if len(cpus) >= 8:
+            os.sched_setaffinity(0, cpus)
+            return node, how
+    except Exception:
+        pass
+    return None, "not bound"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,8 +246,10 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     dev_index = 0 if share_gpu else local_rank
     backend = "gloo" if share_gpu else "nccl"
+    gpu_node = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        gpu_node = stay_on_gpu_node(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # before the runtime and the codec start their threads
         torch.cuda.set_device(dev_index)
         dist.init_process_group(backend)
     torch.cuda.set_device(dev_index)
@@ -385,7 +427,7 @@ def main():
             except Exception as exc:
                 sys.stderr.write(f"merged-container check failed: {exc}\n")
                 ok = False
-            line["sharded"] = {"rccl_ranks": rccl_ranks, "rccl_ranks_how": "all_reduce(ones) over the backend below", "plan_ms": round(plan_ms, 2), "extract_ms": round(extract_ms, 2),
+            line["sharded"] = {"memory_node_of_rank0": list(gpu_node) if gpu_node else None, "rccl_ranks": rccl_ranks, "rccl_ranks_how": "all_reduce(ones) over the backend below", "plan_ms": round(plan_ms, 2), "extract_ms": round(extract_ms, 2),
                                "plan_extract_note": "every rank plans the whole mesh and extracts its own shard, once, before the timed steps (the mesh is static input); "
                                                     "the in-process executor's numbers include both",
                                "backend": "nccl (RCCL over xGMI)" if backend == "nccl" else "gloo (one-GPU rehearsal, not a measurement)",
