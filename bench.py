@@ -318,11 +318,11 @@ def main():
         if quant:
             cx.requant(m, quant)                         # encode = quantisation (bounds, float -> uint14) + .hry production
         t_q = time.perf_counter()
-        out = cx.write_hry(m, profile=pid)
+        out = cx.write_hry(m, profile=pid, as_buffer=True)   # the buffer hry_encode returns, as a C caller holds it (no copy into bytes)
         t1 = time.perf_counter()
         tm_e = cx.timing()
         tm_e["requant_ms"] = (t_q - t0) * 1e3
-        gather = sharding.SegmentGather(out, comm_dev) if world > 1 else None    # segments -> rank 0, overlapping the decode below
+        gather = sharding.SegmentGather(out, comm_dev, as_buffer=True) if world > 1 else None    # segments -> rank 0, overlapping the decode below
         t_g = time.perf_counter()
         tm_d = {}
         if can_decode:
@@ -566,7 +566,7 @@ def inprocess_leg(hc, whole, devices, quant, ntri, reps=3):
         enc, dec, te_l, td_l, merged = [], [], [], [], b""
         for _ in range(1 + reps):
             t0 = time.perf_counter()
-            merged = mc.write_hry(whole, quant, keep_mesh=True)   # (the whole mesh stays as it is: every step computes the bounds again)
+            merged = mc.write_hry(whole, quant, keep_mesh=True, as_buffer=True)   # (the whole mesh stays as it is: every step computes the bounds again)
             t1 = time.perf_counter()
             te_l.append(dict(mc.last))
             mc.read_hry(merged)
@@ -609,7 +609,7 @@ def inprocess_main(args):
 
     def one_step():
         t0 = time.perf_counter()
-        out = mc.write_hry(whole, quant, keep_mesh=True)   # (the whole mesh stays as it is: every step computes the bounds again)
+        out = mc.write_hry(whole, quant, keep_mesh=True, as_buffer=True)   # (the whole mesh stays as it is: every step computes the bounds again)
         t1 = time.perf_counter()
         te = dict(mc.last)
         tim_e = mc.timings()
@@ -685,7 +685,7 @@ def cfg3_leg(cx):
         m = m0.clone()
         t0 = time.perf_counter()
         cx.requant(m, quant)
-        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED)
+        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED, as_buffer=True)
         t1 = time.perf_counter()
         te = cx.timing()
         d = cx.read_hry(out)
@@ -726,7 +726,7 @@ def cfg4_share_leg(cx):
     for _ in range(3):
         m = m0.clone()
         t0 = time.perf_counter()
-        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED)        # from the host mesh: the upload is inside
+        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED, as_buffer=True)        # from the host mesh: the upload is inside
         t1 = time.perf_counter()
         te = cx.timing()
         d = cx.read_hry(out)
@@ -734,7 +734,7 @@ def cfg4_share_leg(cx):
         td = cx.timing()
         m = m0.clone(); cx.upload(m)
         t3 = time.perf_counter()
-        cx.write_hry(m, profile=hc.PROFILE_CHUNKED)              # resident inputs
+        cx.write_hry(m, profile=hc.PROFILE_CHUNKED, as_buffer=True)              # resident inputs
         t4 = time.perf_counter()
         enc.append(t1 - t0); dec.append(t2 - t1); enc_res.append(t4 - t3); tms.append((te, td))
     # size-independent check: the decoded vertex records are a permutation of the input's (lossless)

@@ -254,14 +254,15 @@ def container_info(data: bytes) -> dict:
     return dict(zip(keys, (int(x) for x in info)))
 
 
-def merge(parts) -> bytes:
-    """several sharded containers (.hry v0.3) of the same mesh -> one (hry_merge)"""
-    parts = [bytes(p) for p in parts]
-    arr = (C.c_char_p * len(parts))(*parts)
-    sizes = (C.c_size_t * len(parts))(*[len(p) for p in parts])
+def merge(parts, as_buffer: bool = False):
+    """several sharded containers (.hry v0.3) of the same mesh -> one (hry_merge).  The parts may be any buffers (bytes, numpy
+    arrays, NativeBuffer): none is copied on the way in; as_buffer: the result stays in the library's buffer too."""
+    where = [nat.buffer_address(p) for p in parts]
+    arr = (C.c_void_p * len(parts))(*[w[0] for w in where])
+    sizes = (C.c_size_t * len(parts))(*[w[1] for w in where])
     p, n = C.c_void_p(), C.c_size_t()
     nat.check(nat.load().hry_merge(arr, sizes, len(parts), C.byref(p), C.byref(n)))
-    return nat.take_bytes(p, n.value)
+    return nat.take(p, n.value, as_buffer)
 
 
 def walk_and_replay(mesh: "Mesh", use_restart_points: bool):
@@ -328,11 +329,12 @@ class Codec:
     def upload(self, mesh: Mesh):
         nat.check(nat.load().hry_mesh_upload(self.h, mesh.h))
 
-    def write_hry(self, mesh: Mesh, profile: int = PROFILE_COMPAT, chunk_syms: int = 0, keep_stages: bool = False, flags: int = 0) -> bytes:
+    def write_hry(self, mesh: Mesh, profile: int = PROFILE_COMPAT, chunk_syms: int = 0, keep_stages: bool = False, flags: int = 0, as_buffer: bool = False):
+        """as_buffer: return the library's buffer as it is (nat.NativeBuffer: what a C caller of hry_encode holds) instead of bytes"""
         o = nat.Opts(profile, chunk_syms, int(keep_stages), flags, 0, 0)
         p, n = C.c_void_p(), C.c_size_t()
         nat.check(nat.load().hry_encode(self.h, mesh.h, C.byref(o), C.byref(p), C.byref(n)))
-        return nat.take_bytes(p, n.value)
+        return nat.take(p, n.value, as_buffer)
 
     def read_hry(self, data: bytes, keep_stages: bool = False, shard=(0, 0), partial: bool = False) -> Mesh:
         """shard = (index, count): of a sharded container decode only the segments i with i % count == index.
@@ -381,7 +383,7 @@ class MultiCodec:
     def _handles(self):
         return (C.c_void_p * len(self.ctx))(*[c.h for c in self.ctx])
 
-    def write_hry(self, mesh: Mesh, quants=(), clear: bool = False, n_shards: int = 0, chunk_syms: int = 0, keep_mesh: bool = False) -> bytes:
+    def write_hry(self, mesh: Mesh, quants=(), clear: bool = False, n_shards: int = 0, chunk_syms: int = 0, keep_mesh: bool = False, as_buffer: bool = False):
         """plan + extract + bounds of the whole mesh + quantisation + encode of every shard on its context + merge: ONE .hry v0.3.
         keep_mesh: do not store the combined bounds in `mesh`"""
         qs = list(quants)
@@ -390,7 +392,7 @@ class MultiCodec:
         p, n, t = C.c_void_p(), C.c_size_t(), nat.ShardTiming()
         nat.check(nat.load().hry_encode_sharded(self._handles(), len(self.ctx), mesh.h, arr, len(qs), int(clear), C.byref(o), C.byref(p), C.byref(n), C.byref(t)))
         self.last = t.asdict()
-        return nat.take_bytes(p, n.value)
+        return nat.take(p, n.value, as_buffer)
 
     def read_hry(self, data: bytes, shard=(0, 0), partial: bool = False) -> Mesh:
         o = nat.Opts(0, 0, 0, FLAG_PARTIAL if partial else 0, int(shard[0]), int(shard[1]))
