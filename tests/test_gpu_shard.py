@@ -330,3 +330,32 @@ def test_damaged_sharded_containers_are_refused(cx):
             assert d.nf == good.nf
         except hc.HryError:
             pass
+
+
+@pytest.mark.gpu
+def test_the_librarys_buffers_pass_through_the_binding(cx):
+    """as_buffer=True: the binding returns what hry_encode / hry_merge allocated (no copy into bytes); such a buffer has the bytes'
+    length and content, decodes, merges (next to bytes and numpy arrays) and is freed with the object"""
+    from harry_amd import _native as nat
+    gen = _mesh("mixed_nm")
+    _, _, parts = _encode_sharded(cx, gen, 3, [])
+    merged = hc.merge(parts)
+    buf = hc.merge([parts[0], np.frombuffer(parts[1], dtype=np.uint8), parts[2]], as_buffer=True)
+    assert isinstance(buf, nat.NativeBuffer) and len(buf) == len(merged) and buf == merged and bytes(buf.view()) == merged
+    assert hc.container_info(buf)["minor"] == 3 and hc.container_check(buf)
+    a, b = cx.read_hry(merged), cx.read_hry(buf)
+    assert np.array_equal(a.list_data(1), b.list_data(1)) and np.array_equal(a.org(), b.org())
+    assert hc.merge([buf]) == merged                         # a NativeBuffer as a part
+    whole = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props)
+    one = cx.write_hry(whole.clone(), profile=hc.PROFILE_CHUNKED)
+    one_buf = cx.write_hry(whole.clone(), profile=hc.PROFILE_CHUNKED, as_buffer=True)
+    assert one_buf == one and len(one_buf) == len(one)
+    mc = hc.MultiCodec([0, 0])
+    try:
+        m_bytes = mc.write_hry(whole.clone(), (), n_shards=3)
+        m_buf = mc.write_hry(whole.clone(), (), n_shards=3, as_buffer=True)
+        assert m_buf == m_bytes
+        assert np.array_equal(mc.read_hry(m_buf).list_data(1), a.list_data(1))
+    finally:
+        mc.close()
+    del buf, one_buf, m_buf                                  # (freed here: hry_free)
