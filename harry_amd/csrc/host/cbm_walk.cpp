@@ -362,6 +362,7 @@ struct WalkState {
 template <int DEG>
 static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, uint32_t f, Border &cb, Emitter &em, uint32_t &next_id, uint32_t &consumed)
 {
+	static const bool kWalkPrefetch = [] { const char *e = getenv("HRY_WALK_PREFETCH"); return !e || atoi(e) != 0; }();
 	WalkResult &w = em.w;
 	const uint32_t *foff = m.face_off.data();
 	const uint32_t *org = m.org.data();
@@ -422,6 +423,16 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 			ntri = (int)(foff[f + 1] - foff[f]) - 2;
 			curtri = 0;
 			e1 = nxt(e0);
+			// the faces behind this polygon's other edges are the next gates' neighbours: their lines (twins, origins, the
+			// half-edge -> face table) are asked for now -- a component is walked once, every line of it is a miss the first time
+			// (hardware counters on the configs[3] share: 0.44 last-level misses per triangle, IPC 1.6)
+			if (kWalkPrefetch) {
+				for (uint32_t h = foff[f], he = foff[f + 1]; h < he; ++h) {
+					const uint32_t o = twin[h];
+					__builtin_prefetch(twin + o); __builtin_prefetch(org + o);
+					if (!DEG) __builtin_prefetch(eface_tab + o);
+				}
+			}
 		} else e1 = nxt(e1);
 		e2 = nxt(e1);
 		const uint32_t v2 = org[e2];
