@@ -108,6 +108,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	}
 	auto t_walk = Clock::now();
 	WalkResult w;
+	w.numtri_positions = false;     // (places in ONE symbol sequence: the chunked planes have none)
 	cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
 	cx.timing.host_walk_ms = ms_since(t_walk);
 

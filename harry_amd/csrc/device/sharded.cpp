@@ -56,17 +56,16 @@ const void *device_cpus(int device)
 // shared with the other workers on that node; the whole process's CPUs when the node is unknown)
 std::vector<unsigned> worker_thread_budgets(const std::vector<const void*> &cpus)
 {
-	cpu_set_t cs;
-	CPU_ZERO(&cs);
-	unsigned allowed = sched_getaffinity(0, sizeof cs, &cs) == 0 ? (unsigned)CPU_COUNT(&cs) : std::thread::hardware_concurrency();
-	if (!allowed) allowed = 1;
+	const unsigned allowed = cpu_allowance();   // affinity mask and control-group quota
 	const unsigned cap = host_threads();
+	const unsigned n = (unsigned)std::max<size_t>(1, cpus.size());
 	std::vector<unsigned> out(cpus.size(), 1);
 	for (size_t w = 0; w < cpus.size(); ++w) {
 		unsigned sharing = 0;
 		for (size_t x = 0; x < cpus.size(); ++x) sharing += cpus[x] == cpus[w];
 		const unsigned avail = cpus[w] ? (unsigned)CPU_COUNT((const cpu_set_t*)cpus[w]) : allowed;
-		out[w] = std::max(1u, std::min(cap, avail / std::max(1u, sharing)));
+		// a node's CPUs among the workers on it, and never more busy threads over all workers than the process may run
+		out[w] = std::max(1u, std::min(cap, std::min(avail / std::max(1u, sharing), (allowed + n - 1) / n)));
 	}
 	return out;
 }

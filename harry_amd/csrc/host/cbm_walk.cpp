@@ -241,6 +241,13 @@ struct StartFaces {
 		const Span &s = spans[a];
 		return s.first_pos + (s.asc ? f - s.lo : s.hi - f);
 	}
+	// the same for ascending faces: `a` is the caller's cursor into the spans (start it at 0; it only moves forward)
+	uint32_t position_from(uint32_t f, size_t &a) const
+	{
+		while (a + 1 < spans.size() && spans[a + 1].lo <= f) ++a;
+		const Span &s = spans[a];
+		return s.first_pos + (s.asc ? f - s.lo : s.hi - f);
+	}
 	uint32_t at_cursor() const
 	{
 		const Block &b = blocks[bi];
@@ -285,6 +292,9 @@ struct Emitter {
 	// operations (symbol | class << 3, one byte), coded vertices, coded faces.  detach() trims the arrays to what was written.
 	OpByte *op_cur = nullptr, *op_begin = nullptr;
 	uint32_t *ov_cur = nullptr, *ov_begin = nullptr, *of_cur = nullptr, *of_begin = nullptr;
+	// the triangle count of every coded polygon (only with more than one polygon degree): one per coded face, in the order of
+	// order_f -- the same kind of cursor; ntp_*: its position in the symbol sequence (nullptr: not wanted, WalkResult::numtri_positions)
+	uint32_t *nt_cur = nullptr, *nt_begin = nullptr, *ntp_cur = nullptr, *ntp_begin = nullptr;
 	explicit Emitter(WalkResult &r) : w(r) { for (int i = 0; i < 8; ++i) c_new[i] = c_fwd[i] = 1; }
 	// cap_*: upper bounds of what the walk can still emit on top of what the arrays hold
 	void attach(size_t cap_ops, size_t cap_v, size_t cap_f)
@@ -294,12 +304,23 @@ struct Emitter {
 		op_begin = w.op_sc.data(); op_cur = op_begin + no;
 		ov_begin = w.order_v.data(); ov_cur = ov_begin + nv;
 		of_begin = w.order_f.data(); of_cur = of_begin + nf;
+		if (w.numtri_coded) {
+			const size_t nn = w.grp_val[G_NUMTRI].size();
+			w.grp_val[G_NUMTRI].resize(nn + cap_f);
+			nt_begin = w.grp_val[G_NUMTRI].data(); nt_cur = nt_begin + nn;
+			if (w.numtri_positions) { w.grp_pos[G_NUMTRI].resize(nn + cap_f); ntp_begin = w.grp_pos[G_NUMTRI].data(); ntp_cur = ntp_begin + nn; }
+		}
 	}
 	void detach()
 	{
 		if (!op_begin) return;
 		w.op_sc.resize((size_t)(op_cur - op_begin)); w.order_v.resize((size_t)(ov_cur - ov_begin)); w.order_f.resize((size_t)(of_cur - of_begin));
 		op_begin = op_cur = nullptr;
+		if (nt_begin) {
+			w.grp_val[G_NUMTRI].resize((size_t)(nt_cur - nt_begin));
+			if (ntp_begin) w.grp_pos[G_NUMTRI].resize((size_t)(ntp_cur - ntp_begin));
+			nt_begin = nt_cur = ntp_begin = ntp_cur = nullptr;
+		}
 	}
 	uint32_t faces_coded() const { return (uint32_t)(of_cur - of_begin); }
 	void mark_component(uint32_t next_id)
@@ -307,6 +328,7 @@ struct Emitter {
 		if (!w.marks.empty()) w.marks.back().min_ref = min_ref;
 		ComponentMark k;
 		for (int g = 0; g < G_COUNT; ++g) k.n_grp[g] = (uint32_t)w.grp_val[g].size();
+		k.n_grp[G_NUMTRI] = (uint32_t)(nt_cur - nt_begin);
 		for (int i = 0; i < 8; ++i) k.n_op[i] = n_op[i];
 		k.first_vertex = next_id; k.first_face = faces_coded(); k.first_halfedge = halfedges;
 		k.min_ref = NONE32;
@@ -324,7 +346,13 @@ struct Emitter {
 	}
 	void elem(int i) { uint32_t c = (uint32_t)i; group(G_ELEM, (c << 1) ^ ((c >> 31) ? 0xffffffffu : 0u)); }   // transform.h:25-30
 	void part(int p) { group(G_PART, (uint32_t)(uint16_t)p); }
-	void numtri(int nt) { if (nt != 0 && w.numtri_coded) group(G_NUMTRI, (uint32_t)(uint16_t)nt); }          // io.h:162-165
+	void numtri(int nt)                                                                                          // io.h:162-165
+	{
+		if (nt == 0 || !w.numtri_coded) return;
+		*nt_cur++ = (uint32_t)(uint16_t)nt;
+		if (ntp_cur) *ntp_cur++ = n;
+		n += kGroupBytes[G_NUMTRI];
+	}
 	void op(uint32_t s, int order)
 	{
 		int k = order - 1;   // models.h:101-105; order >= 1 because the gate's front vertex lies on a coded triangle
@@ -616,6 +644,161 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 	next_id_io = next_id; consumed_io = consumed;
 }
 
+// The component walk for polygons, written like the triangle loop above (round 4; hardware counters of the generic loop on the
+// configs[3] share: 240 instructions and 108 cycles per triangle).  A polygon is a fan of triangles around the vertex its gate
+// starts at (encoder.h:133-166): the face's half-edge range stays in locals while its triangles are coded, so "next edge" is a
+// compare instead of two table lookups per step; cursors and counters are locals; the gate's neighbours are loaded only by the
+// operations that use them; the triangle count of a polygon goes through a bare cursor (one per coded face, Emitter::nt_cur).
+template <int DEG>
+static void walk_component_poly(Mesh &m, WalkState &st, const uint32_t *eface_tab, uint32_t f, Border &cb, Emitter &em, uint32_t &next_id_io, uint32_t &consumed_io)
+{
+	static const bool kWalkPrefetch = [] { const char *e = getenv("HRY_WALK_PREFETCH"); return !e || atoi(e) != 0; }();
+	WalkResult &w = em.w;
+	const uint32_t *foff = m.face_off.data();
+	const uint32_t *org = m.org.data();
+	uint32_t *twin = m.twin.data();
+	Gone *gone = st.gone.data();
+	uint32_t *sent = st.sent.data();
+	uint16_t *seen = st.seen.data();
+	OnCount *on = st.on.data();
+	uint32_t next_id = next_id_io, consumed = consumed_io, halfedges = em.halfedges;
+	OpByte *opc = em.op_cur;
+	uint32_t *ovc = em.ov_cur, *ofc = em.of_cur;
+	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, n_ops = 0;
+	bool changed = false;
+	const bool nt_coded = w.numtri_coded;
+	auto face_of = [&](uint32_t e) -> uint32_t { return DEG ? e / (uint32_t)(DEG ? DEG : 1) : eface_tab[e]; };
+	auto emit = [&](uint32_t s, uint32_t order) {
+		uint32_t k = order == 0 ? 0u : order > 8u ? 7u : order - 1u;   // models.h:101-105
+		++n_op[k]; ++n_ops;
+		*opc++ = (OpByte)(s | (k << 3));
+	};
+	// rare symbols go through the Emitter (its symbol counter is brought up to date first)
+	auto sync_n = [&] { em.n += n_ops; n_ops = 0; };
+
+	em.mark_component(next_id);
+	gone[f] = Gone::yes; ++consumed;
+	uint32_t fb = foff[f], fe = foff[f + 1];   // the half-edges of the polygon at hand
+	halfedges += fe - fb;
+	uint32_t ntri = fe - fb - 2, curtri = 1;
+	uint32_t e0 = fb, e1 = fb + 1, e2 = fb + 2;
+	{
+		const uint32_t a = org[e0], b = org[e1], c = org[e2];
+		auto rec = [&](uint32_t e) { *ovc++ = e; sent[org[e]] = next_id++; };
+		unsigned mask = (sent[a] != NONE32 ? 4u : 0u) | (sent[b] != NONE32 ? 2u : 0u) | (sent[c] != NONE32 ? 1u : 0u);
+		switch (mask) {   // encoder.h:68-131
+		case 7: em.iop(I_TRI111); em.vert(sent[a], seen[a]); em.vert(sent[b], seen[b]); em.vert(sent[c], seen[c]); em.numtri((int)ntri); break;
+		case 6: em.iop(I_TRI110); em.vert(sent[a], seen[a]); em.vert(sent[b], seen[b]); em.numtri((int)ntri); rec(e2); break;
+		case 3: em.iop(I_TRI011); em.vert(sent[b], seen[b]); em.vert(sent[c], seen[c]); em.numtri((int)ntri); rec(e0); break;
+		case 5: em.iop(I_TRI101); em.vert(sent[c], seen[c]); em.vert(sent[a], seen[a]); em.numtri((int)ntri); rec(e1); break;
+		case 4: em.iop(I_TRI100); em.vert(sent[a], seen[a]); em.numtri((int)ntri); rec(e1); rec(e2); break;
+		case 2: em.iop(I_TRI010); em.vert(sent[b], seen[b]); em.numtri((int)ntri); rec(e2); rec(e0); break;
+		case 1: em.iop(I_TRI001); em.vert(sent[c], seen[c]); em.numtri((int)ntri); rec(e0); rec(e1); break;
+		default: em.iop(I_INIT); em.numtri((int)ntri); rec(e0); rec(e1); rec(e2); break;
+		}
+		*ofc++ = e0;
+		++seen[a]; ++seen[b]; ++seen[c];
+		cb.start(a, e0, b, e1, c, e2);
+	}
+	uint32_t *ntc = em.nt_cur, *ntp = em.ntp_cur;
+	Border::Node *P = cb.P;
+	while (!cb.parts.empty()) {
+		Border::Part &pt = cb.parts.back();
+		const int32_t tn = pt.tail, hn = pt.head;
+		const uint32_t v0 = P[tn].v, gate = P[tn].a, v1 = P[hn].v;
+		const uint32_t order = seen[v1];
+		const bool first = curtri == ntri;   // the polygon before is finished: the gate leads into the next one
+		if (first) {
+			const uint32_t t = twin[gate];
+			const uint32_t fc = t == gate ? 0u : face_of(t);
+			if (t == gate || gone[fc] != Gone::no) {   // writer.cc:48-58: mesh border or neighbour already consumed
+				const Op bop = cb.border();
+				P = cb.P;
+				if (t != gate) { twin[gate] = gate; changed = true; }   // one-sided split (writer.cc:81-84)
+				emit(bop, order);
+				continue;
+			}
+			gone[fc] = Gone::yes; ++consumed;
+			fb = foff[fc]; fe = foff[fc + 1];
+			halfedges += fe - fb;
+			ntri = fe - fb - 2; curtri = 0;
+			e0 = t;
+			e1 = t + 1 == fe ? fb : t + 1;
+			// the faces behind this polygon's other edges are the next gates' neighbours: their lines (twins, origins, the
+			// half-edge -> face table) are asked for now -- a component is walked once, every line of it is a miss the first time
+			if (kWalkPrefetch) {
+				for (uint32_t h = fb; h < fe; ++h) {
+					const uint32_t o = twin[h];
+					__builtin_prefetch(twin + o); __builtin_prefetch(org + o);
+					if (!DEG) __builtin_prefetch(eface_tab + o);
+				}
+			}
+		} else e1 = e1 + 1 == fe ? fb : e1 + 1;
+		e2 = e1 + 1 == fe ? fb : e1 + 1;
+		const uint32_t v2 = org[e2];
+		const bool fresh = sent[v2] == NONE32;
+		if (fresh || on[v2] == 0) {
+			// NEWVTX, or a vertex that was coded before but left the border (non-manifold): encoder.h:167-181
+			P[tn].a = e1;
+			const int32_t nn = cb.make(v2, e2);
+			P = cb.P;
+			cb.append(cb.parts.back(), nn);
+			if (fresh) { emit(O_NEWVTX, order); *ovc++ = e2; sent[v2] = next_id++; }
+			else { emit(O_NM, order); sync_n(); em.vert(sent[v2], seen[v2]); }
+		} else if (pt.edge_begin && P[P[hn].next].v == v2) {
+			// connect forward (or close: the part is exactly this triangle)
+			const bool close = pt.size == 3;
+			if (curtri + 1 == ntri) {   // the polygon's last triangle: its last edge meets the next border edge
+				const uint32_t gatenext = P[hn].a;
+				if (twin[gatenext] != e2) { twin[gatenext] = e2; twin[e2] = gatenext; changed = true; }
+			}
+			if (close) {
+				const uint32_t gateprev = P[P[tn].prev].a;
+				if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; }
+				cb.discard_top();
+			} else { cb.drop(cb.unlink_head(pt)); P[pt.tail].a = e1; }
+			emit(O_CONNFWD, order);
+		} else if (P[P[tn].prev].v == v2) {
+			const uint32_t gateprev = P[P[tn].prev].a;
+			if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; }
+			cb.drop(cb.unlink_tail(pt));
+			P[pt.tail].a = e2;
+			emit(O_CONNBWD, order);
+		} else {
+			int i, p;
+			const int32_t hit = cb.locate(v2, i, p);
+			int32_t g, cp;
+			if (p > 0) {
+				cb.unite(hit, p, g, cp);
+				P = cb.P;
+				emit(O_UNION, order); sync_n(); em.elem(i); em.part(p);
+			} else {
+				cb.split(hit, i, g, cp);
+				P = cb.P;
+				emit(O_SPLIT, order); sync_n(); em.elem(i);
+			}
+			P[g].a = e1; P[cp].a = e2;
+		}
+		if (first) {
+			if (nt_coded) {   // io.h:162-165: the triangle count follows the first operation of the polygon and its operands
+				*ntc++ = (uint32_t)(uint16_t)ntri;
+				if (ntp) { sync_n(); *ntp++ = em.n; }
+				n_ops += kGroupBytes[G_NUMTRI];   // (two places in the symbol sequence)
+			}
+			*ofc++ = e0;
+		}
+		++seen[v0]; ++seen[v1]; ++seen[v2];
+		++curtri;
+	}
+	sync_n();
+	for (int i = 0; i < 8; ++i) em.n_op[i] += n_op[i];
+	em.halfedges = halfedges;
+	em.op_cur = opc; em.ov_cur = ovc; em.of_cur = ofc;
+	em.nt_cur = ntc; em.ntp_cur = ntp;
+	if (changed) w.twins_changed = true;
+	next_id_io = next_id; consumed_io = consumed;
+}
+
 template <int DEG>
 static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads);
 
@@ -642,11 +825,13 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	do {
 		uint32_t f = pool.next();
 		const bool lean = DEG == 3 && !getenv("HRY_GENERIC_WALK");
+		const bool lean_poly = DEG != 3 && !eval_op_model && !getenv("HRY_GENERIC_WALK");   // (the generic loop evaluates the operation model)
 		if (count && consumed == 0) {
 			PerfCounters pc;
 			pc.start();
 			if (lean && eval_op_model) walk_component_tri<true>(m, st, f, cb, em, next_id, consumed);
 			else if (lean) walk_component_tri<false>(m, st, f, cb, em, next_id, consumed);
+			else if (lean_poly) walk_component_poly<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 			else walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 			pc.stop();
 			pc.report(eval_op_model ? "cut-border walk (with the operation model)" : "cut-border walk", (double)(em.halfedges - 2.0 * consumed));
@@ -654,6 +839,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 		}
 		if (lean && eval_op_model) walk_component_tri<true>(m, st, f, cb, em, next_id, consumed);
 		else if (lean) walk_component_tri<false>(m, st, f, cb, em, next_id, consumed);
+		else if (lean_poly) walk_component_poly<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 		else walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 		// The operation model of the reference stream adapts across the whole file (models.h:49-120), so a walk that evaluates
 		// it is one sequence.  Without it (chunked profile: symbol + order class only) the remaining components are walked on
@@ -665,6 +851,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 			break;
 		}
 	} while (consumed != m.nf);
+	mark("(sequential part) back");
 	em.detach();
 	em.finish_marks();
 	em.iop(I_EOM);
@@ -681,9 +868,11 @@ unsigned host_threads()
 {
 	if (t_thread_budget) return t_thread_budget;
 	if (const char *e = getenv("HRY_HOST_THREADS")) { int v = atoi(e); return v > 0 ? (unsigned)v : 1u; }
-	// up to 32, and at most an eighth of a large node's cores: eight processes (one per GPU) share the node
-	unsigned hw = std::thread::hardware_concurrency();
-	if (!hw) hw = 1;
+	// what the process may keep busy (affinity mask, control-group quota: thread_pool.cpp), shared with the other ranks of a
+	// one-process-per-GPU launch on this node (LOCAL_WORLD_SIZE, torch.distributed.run); up to 32, and at most an eighth of a
+	// large unshared node's CPUs: eight processes (one per GPU) share the node
+	unsigned hw = cpu_allowance();
+	if (const char *e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) return std::max(1u, std::min(32u, hw / (unsigned)v)); }
 	return std::max(1u, std::min(32u, hw >= 128 ? hw / 8 : std::min(16u, hw)));
 }
 // below this many remaining faces the analysis passes cost more than they save (HRY_PARALLEL_MIN_FACES overrides, tests)
@@ -763,33 +952,78 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 	auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	// (a) components of the remaining faces
+	// Every thread first unites the faces of its own range among themselves, in order and without atomics: a face takes the
+	// root of its first smaller neighbour (the face itself needs no search -- it is new -- and a neighbour's root is one or two
+	// loads away, every path being compressed when it is walked), further smaller neighbours with another root link the two
+	// roots.  Edges that leave the range, and one-sided twins, are noted and united afterwards through the atomics, when every
+	// parent is initialised: the faces along the range boundaries on a mesh whose components are contiguous; a thread whose
+	// notes outgrow a quarter of its faces (faces in random order) goes over its edges again instead of keeping them.
+	// (Round 3 united every edge through two atomic searches: 81 of the 347 ms of the configs[3] host walk on the box's 16 CPUs.)
 	AtomicSets sets(nf);
-	parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nf, t, b, e); for (uint32_t f = b; f < e; ++f) sets.parent[f].store(f, std::memory_order_relaxed); });
-	parallel_for(n_threads, [&](unsigned t) {
-		uint32_t b, e; split(ne, t, b, e);
-		for (uint32_t h = b; h < e; ++h) {
-			uint32_t o = twin[h];
-			if (o != h && (o > h || twin[o] != h)) { uint32_t fa = face_of(h), fb = face_of(o); if (!is_gone(fa) && !is_gone(fb) && fa != fb) sets.unite(fa, fb); }
-		}
-	});
-	// dense component numbers (roots counted per thread range, then a prefix over the ranges)
+	{
+		std::vector<std::vector<std::pair<uint32_t, uint32_t>>> cross(n_threads);
+		std::vector<char> messy(n_threads, 0);
+		parallel_for(n_threads, [&](unsigned t) {
+			uint32_t b, e; split(nf, t, b, e);
+			std::vector<std::pair<uint32_t, uint32_t>> &notes = cross[t];
+			const size_t cap = (size_t)(e - b) / 4 + 4096;
+			bool over = false;
+			uint32_t *par = (uint32_t*)sets.parent.p;   // this thread's range only: plain words until the threads meet
+			for (uint32_t f = b; f < e; ++f) {
+				if (is_gone(f)) { par[f] = f; continue; }
+				uint32_t r = NONE32;
+				for (uint32_t h = foff[f], he = foff[f + 1]; h < he; ++h) {
+					const uint32_t o = twin[h];
+					if (o == h) continue;
+					const uint32_t fb = face_of(o);
+					if (fb == f || is_gone(fb)) continue;
+					if (fb > f) { if (twin[o] != h && !over) notes.push_back({ f, fb }); continue; }   // (a two-sided edge is seen from the larger face)
+					if (fb < b) { if (!over) notes.push_back({ f, fb }); continue; }
+					uint32_t rb = par[fb];
+					if (par[rb] != rb) { do rb = par[rb]; while (par[rb] != rb); par[fb] = rb; }
+					if (r == NONE32) r = rb;
+					else if (rb != r) { if (rb < r) std::swap(rb, r); par[rb] = r; }   // a root is the smallest face of its set
+				}
+				par[f] = r == NONE32 ? f : r;
+				if (notes.size() > cap) { over = true; messy[t] = 1; std::vector<std::pair<uint32_t, uint32_t>>().swap(notes); }
+			}
+		});
+		if (trace) { size_t nn = 0; unsigned nm = 0; for (unsigned t = 0; t < n_threads; ++t) { nn += cross[t].size(); nm += messy[t]; } fprintf(stderr, "[hry walk] %zu edges across the threads' ranges noted, %u of %u ranges go over their edges again\n", nn, nm, n_threads); }
+		parallel_for(n_threads, [&](unsigned t) {
+			if (!messy[t]) { for (const auto &pr : cross[t]) sets.unite(pr.first, pr.second); return; }
+			uint32_t b, e; split(nf, t, b, e);
+			for (uint32_t f = b; f < e; ++f) {
+				if (is_gone(f)) continue;
+				for (uint32_t h = foff[f], he = foff[f + 1]; h < he; ++h) {
+					const uint32_t o = twin[h];
+					if (o == h) continue;
+					const uint32_t fb = face_of(o);
+					if (fb != f && !is_gone(fb) && (fb < b || (fb > f && twin[o] != h))) sets.unite(f, fb);
+				}
+			}
+		});
+	}
+	mark("  faces united");
+	// dense component numbers: every face's root once (a thread keeps the roots it owns), the roots numbered in face order --
+	// the number goes where the root's parent word was, nobody searches any more -- and every face takes its root's number
 	BigVec<uint32_t> &comp = A.comp;
 	comp.resize(nf);
-	std::vector<uint32_t> range_roots(n_threads + 1, 0);
-	parallel_for(n_threads, [&](unsigned t) {
-		uint32_t b, e, c = 0; split(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) { comp[f] = NONE32; if (!is_gone(f) && sets.find(f) == f) ++c; }
-		range_roots[t + 1] = c;
-	});
-	for (unsigned t = 0; t < n_threads; ++t) range_roots[t + 1] += range_roots[t];
-	const uint32_t ncomp = A.ncomp = range_roots[n_threads];
-	parallel_for(n_threads, [&](unsigned t) {
-		uint32_t b, e, c = range_roots[t]; split(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) if (!is_gone(f) && sets.find(f) == f) comp[f] = c++;
-	});
+	std::vector<std::vector<uint32_t>> roots_of(n_threads);
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(nf, t, b, e);
-		for (uint32_t f = b; f < e; ++f) if (!is_gone(f)) { uint32_t r = sets.find(f); if (r != f) comp[f] = comp[r]; }
+		for (uint32_t f = b; f < e; ++f) {
+			if (is_gone(f)) { comp[f] = NONE32; continue; }
+			const uint32_t r = sets.find(f);
+			comp[f] = r;
+			if (r == f) roots_of[t].push_back(f);
+		}
+	});
+	uint32_t ncomp_count = 0;
+	for (unsigned t = 0; t < n_threads; ++t) { for (uint32_t f : roots_of[t]) sets.parent[f].store(ncomp_count++, std::memory_order_relaxed); }
+	const uint32_t ncomp = A.ncomp = ncomp_count;
+	parallel_for(n_threads, [&](unsigned t) {
+		uint32_t b, e; split(nf, t, b, e);
+		for (uint32_t f = b; f < e; ++f) if (comp[f] != NONE32) comp[f] = sets.parent[comp[f]].load(std::memory_order_relaxed);
 	});
 	mark("components labelled");
 	// (b) first face of every component in the start-face sequence, and the coding order
@@ -804,6 +1038,7 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 		uint32_t b, e; split(nf, t, b, e);
 		uint32_t run_c = NONE32, run_n = 0, run_he = 0;
 		uint64_t run_min = ~0ull;
+		size_t span_at = 0;
 		auto flush = [&] {
 			if (run_c == NONE32) return;
 			if (!seeded) atomic_min(first_key[run_c], run_min);
@@ -817,7 +1052,7 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 			++run_n;
 			run_he += foff[f + 1] - foff[f];
 			// the reference takes face 0 first whatever the set's order (writer.cc:40-46)
-			if (!seeded) run_min = std::min<uint64_t>(run_min, f == 0 ? 0ull : ((((uint64_t)seq.position(f) + 1) << 32) | f));
+			if (!seeded) run_min = std::min<uint64_t>(run_min, f == 0 ? 0ull : ((((uint64_t)seq.position_from(f, span_at) + 1) << 32) | f));
 		}
 		flush();
 	});
@@ -849,23 +1084,34 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 	// (c) the first remaining component (in coding order) that touches each vertex: it introduces the vertex unless the part
 	// walked before already transmitted it.  Components that touch a common vertex are tied together: the vertex's index,
 	// its triangle count (operation class) and its border count make the later one depend on the earlier one.
+	// One pass in face order (a face's rank is looked up once; no half-edge -> face table, no second sweep): every corner
+	// takes part in an atomic minimum on its vertex' word.  Whoever finds another component's rank there -- above its own (it
+	// replaces it) or below (it leaves it) -- notes the pair: every component at a vertex except the first to arrive notes
+	// one with a component that was there before it, so the notes connect all of them.
 	AtomicArray vfirst(nv);
 	parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nv, t, b, e); for (uint32_t v = b; v < e; ++v) vfirst[v].store(NONE32, std::memory_order_relaxed); });
+	std::vector<std::vector<std::pair<uint32_t, uint32_t>>> tie_notes(n_threads);
 	parallel_for(n_threads, [&](unsigned t) {
-		uint32_t b, e; split(ne, t, b, e);
-		for (uint32_t h = b; h < e; ++h) { uint32_t f = face_of(h); if (!is_gone(f)) atomic_min(vfirst[org[h]], rank_of[comp[f]]); }
+		uint32_t b, e; split(nf, t, b, e);
+		std::vector<std::pair<uint32_t, uint32_t>> &notes = tie_notes[t];
+		uint32_t last_c = NONE32, k = 0;
+		for (uint32_t f = b; f < e; ++f) {
+			if (is_gone(f)) continue;
+			const uint32_t c = comp[f];
+			if (c != last_c) { k = rank_of[c]; last_c = c; }
+			for (uint32_t h = foff[f], he = foff[f + 1]; h < he; ++h) {
+				std::atomic<uint32_t> &a = vfirst[org[h]];
+				uint32_t cur = a.load(std::memory_order_relaxed);
+				if (cur == k) continue;
+				while (k < cur && !a.compare_exchange_weak(cur, k, std::memory_order_relaxed)) {}
+				// cur: what was there when this corner settled (k < cur: replaced by k; k > cur: stays)
+				if (cur != NONE32 && cur != k && (notes.empty() || notes.back() != std::make_pair(cur, k))) notes.push_back({ cur, k });
+			}
+		}
 	});
 	AtomicSets ties(ncomp);
 	for (uint32_t k = 0; k < ncomp; ++k) ties.parent[k].store(k, std::memory_order_relaxed);
-	parallel_for(n_threads, [&](unsigned t) {
-		uint32_t b, e; split(ne, t, b, e);
-		for (uint32_t h = b; h < e; ++h) {
-			uint32_t f = face_of(h);
-			if (is_gone(f)) continue;
-			uint32_t k = rank_of[comp[f]], first = vfirst[org[h]].load(std::memory_order_relaxed);
-			if (first != k) ties.unite(first, k);
-		}
-	});
+	for (const auto &notes : tie_notes) for (const auto &pr : notes) ties.unite(pr.first, pr.second);
 	std::unique_ptr<std::atomic<uint32_t>[]> fresh(new std::atomic<uint32_t>[ncomp]);
 	for (uint32_t k = 0; k < ncomp; ++k) fresh[k].store(0, std::memory_order_relaxed);
 	parallel_for(n_threads, [&](unsigned t) {
@@ -897,6 +1143,7 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	const bool trace = getenv("HRY_TRACE") != nullptr;
 	auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
+	struct AtExit { decltype(mark) &mk; ~AtExit() { mk("temporaries released"); } } at_exit{ mark };
 	ComponentAnalysis A;
 	const ShardInfo &sh = m.shard;
 	const uint32_t shc = (uint32_t)sh.comp_faces.size();
@@ -938,103 +1185,153 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 	}
 	std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.faces > y.faces; });
 	if (trace) fprintf(stderr, "[hry walk] %u components in %zu groups, largest group %llu faces\n", ncomp, items.size(), items.empty() ? 0ull : (unsigned long long)items[0].faces);
-	// the walks
-	std::vector<WalkResult> frag(ncomp);
-	std::vector<uint32_t> frag_syms(ncomp, 0), frag_he(ncomp, 0), frag_op((size_t)ncomp * 8, 0);
+	// ---- the walks.  A component's place in the coded vertices, faces and half-edges is known before it is walked (the
+	// vertices it introduces, its faces: exclusive scans in coding order), so every walk writes its part of order_v / order_f
+	// where it belongs.  What is not known in advance -- how many operations a component takes (a triangle each + the border
+	// operations), the rare symbol groups, explicitly named vertices -- goes into the walking thread's own arrays, component
+	// after component, and is put in place afterwards.  (Until round 4 every component had a WalkResult of its own, copied and
+	// released afterwards: 150 000 of them on the configs[3] mesh, 140 of the 430 ms of its host walk.)
+	std::vector<uint64_t> off_v(ncomp + 1), off_f(ncomp + 1), off_he(ncomp + 1);
+	off_v[0] = w.order_v.size(); off_f[0] = w.order_f.size(); off_he[0] = em0.halfedges;
+	for (uint32_t k = 0; k < ncomp; ++k) { off_v[k + 1] = off_v[k] + A.fresh[k]; off_f[k + 1] = off_f[k] + A.n_faces[k]; off_he[k + 1] = off_he[k] + A.n_halfedges[k]; }
+	w.order_v.resize(off_v[ncomp]); w.order_f.resize(off_f[ncomp]);
+	// the polygons' triangle counts: one per coded face, so they have their place like order_f (positions: thread-local, moved below)
+	const bool generic = getenv("HRY_GENERIC_WALK") != nullptr;
+	const size_t nt0 = w.grp_val[G_NUMTRI].size();
+	const bool nt_pos = w.numtri_coded && w.numtri_positions;
+	if (w.numtri_coded) { w.grp_val[G_NUMTRI].resize(nt0 + (off_f[ncomp] - off_f[0])); if (nt_pos) w.grp_pos[G_NUMTRI].resize(nt0 + (off_f[ncomp] - off_f[0])); }
+	struct Piece {   // what component k left in its thread's arrays
+		const OpByte *ops; uint32_t n_ops, thread, mark, sym0, n_syms, named0, n_named;
+		uint32_t g0[G_COUNT], gn[G_COUNT], n_op[8];
+	};
+	std::vector<Piece> piece(ncomp);
+	struct PerThread {
+		WalkResult w;                               // rare groups, marks, named vertices of every component this thread walked
+		std::vector<BigVec<OpByte>> blocks;         // operation bytes, a component's in one piece
+		OpByte *cur = nullptr; size_t room = 0;
+	};
+	std::vector<PerThread> per_thread(n_threads);
 	std::atomic<size_t> next_item{ 0 };
-	parallel_for(n_threads, [&](unsigned) {
+	parallel_for(n_threads, [&](unsigned t) {
 		Border cb(st.on);
+		PerThread &T = per_thread[t];
+		T.w.numtri_coded = w.numtri_coded;
+		Emitter em(T.w);
+		em.eval_model = false;
+		em.ov_begin = w.order_v.data(); em.of_begin = w.order_f.data();
 		for (;;) {
 			size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
 			if (it >= items.size()) break;
 			for (uint32_t q = items[it].begin; q < items[it].end; ++q) {
 				const uint32_t k = order[q];
-				WalkResult &fw = frag[k];
-				fw.numtri_coded = w.numtri_coded;
 				const uint32_t nfc = A.n_faces[k];
-				Emitter em(fw);
-				em.eval_model = false;
-				em.attach((size_t)2 * A.n_halfedges[k] - 2 * (size_t)nfc + 16, A.fresh[k], nfc);
+				const size_t cap = (size_t)2 * A.n_halfedges[k] - 2 * (size_t)nfc + 16;
+				if (T.room < cap) {
+					T.blocks.emplace_back();
+					T.blocks.back().resize(std::max<size_t>(cap, (size_t)4 << 20));
+					T.cur = T.blocks.back().data(); T.room = T.blocks.back().size();
+				}
+				Piece &pc = piece[k];
+				pc.thread = t; pc.mark = (uint32_t)T.w.marks.size(); pc.sym0 = em.n; pc.named0 = (uint32_t)T.w.named.size(); pc.ops = T.cur;
+				for (int g = 0; g < G_COUNT; ++g) pc.g0[g] = (uint32_t)T.w.grp_val[g].size();
+				uint32_t nop0[8];
+				for (int i = 0; i < 8; ++i) nop0[i] = em.n_op[i];
+				em.op_begin = em.op_cur = T.cur;
+				em.ov_cur = em.ov_begin + off_v[k]; em.of_cur = em.of_begin + off_f[k];
+				if (w.numtri_coded) {
+					em.nt_begin = w.grp_val[G_NUMTRI].data(); em.nt_cur = em.nt_begin + nt0 + (off_f[k] - off_f[0]);
+					if (nt_pos) { em.ntp_begin = w.grp_pos[G_NUMTRI].data(); em.ntp_cur = em.ntp_begin + nt0 + (off_f[k] - off_f[0]); }
+				}
+				em.halfedges = (uint32_t)off_he[k];
 				uint32_t next_id = id_base[k], consumed = 0;
-				if (DEG == 3 && !getenv("HRY_GENERIC_WALK")) walk_component_tri<false>(m, st, A.seed[k], cb, em, next_id, consumed);
+				if (DEG == 3 && !generic) walk_component_tri<false>(m, st, A.seed[k], cb, em, next_id, consumed);
+				else if (!generic) walk_component_poly<DEG>(m, st, eface_tab, A.seed[k], cb, em, next_id, consumed);
 				else walk_component<DEG>(m, st, eface_tab, A.seed[k], cb, em, next_id, consumed);
-				em.detach();
-				if (next_id != id_base[k + 1] || consumed != nfc) throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
-				em.finish_marks();
-				frag_syms[k] = em.n;
-				frag_he[k] = em.halfedges;
-				for (int i = 0; i < 8; ++i) frag_op[k * 8 + i] = em.n_op[i];
+				if (next_id != id_base[k + 1] || consumed != nfc || em.ov_cur != em.ov_begin + off_v[k + 1] || em.of_cur != em.of_begin + off_f[k + 1] ||
+				    em.halfedges != (uint32_t)off_he[k + 1] || (size_t)(em.op_cur - T.cur) > cap ||
+				    (w.numtri_coded && em.nt_cur != em.nt_begin + nt0 + (off_f[k + 1] - off_f[0])))
+					throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
+				pc.n_ops = (uint32_t)(em.op_cur - T.cur);
+				T.room -= pc.n_ops; T.cur = em.op_cur;
+				pc.n_syms = em.n - pc.sym0; pc.n_named = (uint32_t)T.w.named.size() - pc.named0;
+				for (int g = 0; g < G_COUNT; ++g) pc.gn[g] = (uint32_t)T.w.grp_val[g].size() - pc.g0[g];
+				for (int i = 0; i < 8; ++i) pc.n_op[i] = em.n_op[i] - nop0[i];
 			}
 		}
+		em.op_begin = em.op_cur = nullptr;
+		em.nt_begin = em.nt_cur = em.ntp_begin = em.ntp_cur = nullptr;
+		em.finish_marks();
 	});
 	mark("walks");
-	// concatenation in coding order
-	std::vector<uint64_t> off_sym(ncomp + 1), off_v(ncomp + 1), off_f(ncomp + 1), off_op(ncomp + 1), off_g[G_COUNT];
+	// ---- the operations and the rare groups into coding order
+	std::vector<uint64_t> off_sym(ncomp + 1), off_op(ncomp + 1), off_g[G_COUNT];
 	for (int g = 0; g < G_COUNT; ++g) off_g[g].resize(ncomp + 1);
-	off_sym[0] = em0.n; off_v[0] = w.order_v.size(); off_f[0] = w.order_f.size(); off_op[0] = w.op_sc.size();
-	for (int g = 0; g < G_COUNT; ++g) off_g[g][0] = w.grp_val[g].size();
+	off_sym[0] = em0.n; off_op[0] = w.op_sc.size();
+	for (int g = 0; g < G_COUNT; ++g) off_g[g][0] = g == G_NUMTRI ? nt0 : w.grp_val[g].size();
 	for (uint32_t k = 0; k < ncomp; ++k) {
-		off_sym[k + 1] = off_sym[k] + frag_syms[k];
-		off_v[k + 1] = off_v[k] + frag[k].order_v.size();
-		off_f[k + 1] = off_f[k] + frag[k].order_f.size();
-		off_op[k + 1] = off_op[k] + frag[k].op_sc.size();
-		for (int g = 0; g < G_COUNT; ++g) off_g[g][k + 1] = off_g[g][k] + frag[k].grp_val[g].size();
+		off_sym[k + 1] = off_sym[k] + piece[k].n_syms;
+		off_op[k + 1] = off_op[k] + piece[k].n_ops;
+		for (int g = 0; g < G_COUNT; ++g) off_g[g][k + 1] = off_g[g][k] + piece[k].gn[g];
+		if (w.numtri_coded) off_g[G_NUMTRI][k + 1] = off_g[G_NUMTRI][k] + A.n_faces[k];   // (in place already)
 	}
 	if (off_sym[ncomp] + 1 >= (1ull << 32)) throw Error(HRY_E_UNSUPPORTED, "more than 2^32 connectivity symbols");
-	w.order_v.resize(off_v[ncomp]); w.order_f.resize(off_f[ncomp]);
 	w.op_sc.resize(off_op[ncomp]);
-	for (int g = 0; g < G_COUNT; ++g) { w.grp_val[g].resize(off_g[g][ncomp]); w.grp_pos[g].resize(off_g[g][ncomp]); }
-	std::atomic<uint32_t> next_frag{ 0 };
-	std::atomic<bool> changed_any{ false };
-	parallel_for(n_threads, [&](unsigned) {
-		for (;;) {
-			uint32_t k = next_frag.fetch_add(1, std::memory_order_relaxed);
-			if (k >= ncomp) break;
-			WalkResult &fw = frag[k];
-			std::copy(fw.order_v.begin(), fw.order_v.end(), w.order_v.begin() + (long)off_v[k]);
-			std::copy(fw.order_f.begin(), fw.order_f.end(), w.order_f.begin() + (long)off_f[k]);
-			std::copy(fw.op_sc.begin(), fw.op_sc.end(), w.op_sc.begin() + (long)off_op[k]);
+	for (int g = 0; g < G_COUNT; ++g) if (g != G_NUMTRI) { w.grp_val[g].resize(off_g[g][ncomp]); w.grp_pos[g].resize(off_g[g][ncomp]); }
+	parallel_for(n_threads, [&](unsigned t) {
+		// ranges of components with about the same number of operation bytes each
+		const uint64_t lo = off_op[0] + (off_op[ncomp] - off_op[0]) * t / n_threads, hi = off_op[0] + (off_op[ncomp] - off_op[0]) * (t + 1) / n_threads;
+		uint32_t kb = (uint32_t)(std::lower_bound(off_op.begin(), off_op.begin() + ncomp, lo) - off_op.begin());
+		uint32_t ke = t + 1 == n_threads ? ncomp : (uint32_t)(std::lower_bound(off_op.begin(), off_op.begin() + ncomp, hi) - off_op.begin());
+		for (uint32_t k = kb; k < ke; ++k) {
+			const Piece &pc = piece[k];
+			if (pc.n_ops) memcpy(w.op_sc.data() + off_op[k], pc.ops, pc.n_ops);
+			const WalkResult &tw = per_thread[pc.thread].w;
+			const uint32_t add = (uint32_t)off_sym[k] - pc.sym0;   // (modulo 2^32: thread-local position -> position in the sequence)
+			if (nt_pos) { uint32_t *q = w.grp_pos[G_NUMTRI].data() + off_g[G_NUMTRI][k]; for (uint32_t i = 0, nn = A.n_faces[k]; i < nn; ++i) q[i] += add; }
 			for (int g = 0; g < G_COUNT; ++g) {
-				std::copy(fw.grp_val[g].begin(), fw.grp_val[g].end(), w.grp_val[g].begin() + (long)off_g[g][k]);
+				if (!pc.gn[g]) continue;
+				memcpy(w.grp_val[g].data() + off_g[g][k], tw.grp_val[g].data() + pc.g0[g], (size_t)pc.gn[g] * 4);
 				uint32_t *dst = w.grp_pos[g].data() + off_g[g][k];
-				const uint32_t add = (uint32_t)off_sym[k];
-				for (size_t i = 0; i < fw.grp_pos[g].size(); ++i) dst[i] = fw.grp_pos[g][i] + add;
+				const uint32_t *src = tw.grp_pos[g].data() + pc.g0[g];
+				for (uint32_t i = 0; i < pc.gn[g]; ++i) dst[i] = src[i] + add;
 			}
-			// release here, on this thread: thousands of small fragments are otherwise freed one by one by the caller
-			BigVec<uint32_t>().swap(fw.order_v); BigVec<uint32_t>().swap(fw.order_f); BigVec<OpByte>().swap(fw.op_sc);
-			for (int g = 0; g < G_COUNT; ++g) { BigVec<uint32_t>().swap(fw.grp_val[g]); BigVec<uint32_t>().swap(fw.grp_pos[g]); }
-			if (fw.twins_changed) changed_any.store(true, std::memory_order_relaxed);
 		}
 	});
-	if (changed_any.load()) w.twins_changed = true;
-	// marks: every fragment holds exactly one (its component), relative to the fragment; make it absolute
+	mark("operations and rare groups in coding order");
+	for (const PerThread &T : per_thread) if (T.w.twins_changed) w.twins_changed = true;
+	// marks: one per component, with the counts of everything coded before it in the sequence
 	em0.finish_marks();
 	{
-		uint32_t he = em0.halfedges, nop[8];
+		uint32_t nop[8];
 		for (int i = 0; i < 8; ++i) nop[i] = em0.n_op[i];
-		w.marks.reserve(w.marks.size() + ncomp);
+		const size_t mark0 = w.marks.size();
+		w.marks.resize(mark0 + ncomp);
+		size_t n_named = w.named.size();
+		for (uint32_t k = 0; k < ncomp; ++k) n_named += piece[k].n_named;
+		w.named.reserve(n_named);
 		for (uint32_t k = 0; k < ncomp; ++k) {
-			for (NamedVertex ev : frag[k].named) { ev.mark = (uint32_t)w.marks.size(); w.named.push_back(ev); }   // fragment-local mark 0 -> its place in the sequence
-			ComponentMark mk = frag[k].marks.at(0);
+			const Piece &pc = piece[k];
+			const WalkResult &tw = per_thread[pc.thread].w;
+			for (uint32_t i = 0; i < pc.n_named; ++i) { NamedVertex ev = tw.named[pc.named0 + i]; ev.mark = (uint32_t)(mark0 + k); w.named.push_back(ev); }
+			ComponentMark mk = tw.marks.at(pc.mark);   // first_vertex and min_ref are the walk's
 			for (int g = 0; g < G_COUNT; ++g) mk.n_grp[g] = (uint32_t)off_g[g][k];
-			for (int i = 0; i < 8; ++i) { mk.n_op[i] = nop[i]; nop[i] += frag_op[(size_t)k * 8 + i]; }
+			for (int i = 0; i < 8; ++i) { mk.n_op[i] = nop[i]; nop[i] += pc.n_op[i]; }
 			mk.first_face = (uint32_t)off_f[k];
-			mk.first_halfedge = he;
-			he += frag_he[k];
-			w.marks.push_back(mk);
+			mk.first_halfedge = (uint32_t)off_he[k];
+			w.marks[mark0 + k] = mk;
 		}
-		em0.halfedges = he;
+		em0.halfedges = (uint32_t)off_he[ncomp];
 		for (int i = 0; i < 8; ++i) em0.n_op[i] = nop[i];
 	}
 	em0.n = (uint32_t)off_sym[ncomp];
 	em0.min_ref = w.marks.empty() ? NONE32 : w.marks.back().min_ref;   // the caller's finish_marks() writes it back into the last mark
-	mark("concatenated");
+	mark("marks in coding order");
 }
 
 template <int DEG>
 static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model, bool one_sequence)
 {
-	const uint32_t nv = m.nv, nf = m.nf;
+	const uint32_t nf = m.nf;
 	if (nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
 	BigVec<uint32_t> eface_tab;   // (pooled, not value-initialised: 4 bytes per half-edge, every entry written below)
 	if (DEG == 0) {

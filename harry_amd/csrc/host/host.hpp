@@ -92,6 +92,7 @@ struct WalkResult {
 	std::vector<NamedVertex> named;   // every explicit naming of a vertex, in coding order
 	uint32_t n_conn = 0;             // symbols in the connectivity part of the global sequence
 	bool numtri_coded = false;       // false when a single polygon degree makes every numtri symbol an exact no-op
+	bool numtri_positions = true;    // in: fill grp_pos[G_NUMTRI] (one entry per face; only a single symbol sequence needs it)
 	bool twins_changed = false;      // the walk repaired at least one twin (cbm/encoder.h:150,193-198): the device copy is stale
 };
 
@@ -190,7 +191,8 @@ struct SpanDone { virtual void span(uint32_t f0, uint32_t f1, uint32_t h0, uint3
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
                        OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span = nullptr);
-unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cores)
+unsigned cpu_allowance();           // CPUs this process may keep busy: affinity mask and control-group quota (HRY_CPUS overrides)
+unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cpu_allowance()) (large hosts: see cbm_walk.cpp)
 uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
 // helper threads run on the CPUs of the memory node their creator is on (block_pool.cpp; HRY_NO_NUMA_BIND switches it off)
 const void *callers_node_cpus();       // nullptr: one node, or unknown

@@ -222,7 +222,13 @@ def walk_plain(ply: bytes, threads: int, min_faces: int = 0):
         del os.environ["HRY_HOST_THREADS"], os.environ["HRY_PARALLEL_MIN_FACES"]
 
 
-@pytest.mark.parametrize("case", ["multi_tri", "multi_mixed_nm", "tied_by_vertices", "many_small", "single"])
+def shuffled_faces(m, seed=5):
+    """the same triangles in random file order (components no longer contiguous: the labelling's cross-range path)"""
+    perm = np.random.default_rng(seed).permutation(m.nf)
+    return mg.Mesh(m.verts, m.degrees[perm], m.indices.reshape(-1, 3)[perm].reshape(-1))
+
+
+@pytest.mark.parametrize("case", ["multi_tri", "multi_mixed_nm", "tied_by_vertices", "many_small", "single", "shuffled"])
 def test_threaded_walk_equals_sequential_walk(case):
     """The walk of the components after the first on several threads (component discovery, start-face order, vertex index
     bases computed up front) must reproduce the sequential walk array for array, including the repaired twins."""
@@ -230,7 +236,8 @@ def test_threaded_walk_equals_sequential_walk(case):
          "multi_mixed_nm": lambda: mg.with_nonmanifold(mg.multi_component(17, 12, 13, polys="mixed", seed=3), 40, 25),
          "tied_by_vertices": lambda: mg.with_nonmanifold(mg.concat([mg.torus(9, 10, center=(3.0 * i, 0, 0), seed=i) for i in range(12)]), 30, 60),
          "many_small": lambda: mg.multi_component(700, 3, 4, polys="tri"),
-         "single": lambda: mg.torus(40, 44)}[case]()
+         "single": lambda: mg.torus(40, 44),
+         "shuffled": lambda: shuffled_faces(mg.multi_component(12, 40, 42, polys="tri"))}[case]()
     ply = m.to_ply()
     seq, twin_seq = walk_plain(ply, 1)
     for threads in (2, 5):

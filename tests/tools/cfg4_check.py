@@ -19,7 +19,7 @@ cx = hc.Codec(0)
 r = lambda tm: json.dumps({k: round(v, 1) if isinstance(v, float) else v for k, v in tm.items() if v})
 for it in range(2):   # the first pass pays for module loading, stream creation and first-touch of the pools
     m = m0.clone(); cx.upload(m)
-    t = time.time(); out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED); te = time.time() - t
+    t = time.time(); out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED, as_buffer=True); te = time.time() - t
     print(f"pass {it}: encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(out)} bpv {8*len(out)/mesh.nv:.2f} " + r(cx.timing()), flush=True)
     t = time.time(); dec = cx.read_hry(out); td = time.time() - t
     print(f"pass {it}: decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(cx.timing()), flush=True)
@@ -30,7 +30,7 @@ if nctx:
     mc = hc.MultiCodec([0] * nctx)
     for it in range(2):
         m = m0.clone()
-        t = time.time(); merged = mc.write_hry(m); te = time.time() - t
+        t = time.time(); merged = mc.write_hry(m, as_buffer=True); te = time.time() - t
         print(f"in-process x{nctx} pass {it}: encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(merged)} " + r(mc.last), flush=True)
         t = time.time(); mdec = mc.read_hry(merged); td = time.time() - t
         print(f"in-process x{nctx} pass {it}: decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(mc.last), flush=True)
@@ -57,7 +57,7 @@ compat = None
 if "--compat" in sys.argv:
     for it in range(2):
         m = m0.clone(); cx.upload(m)
-        t = time.time(); compat = cx.write_hry(m, profile=hc.PROFILE_COMPAT); te = time.time() - t
+        t = time.time(); compat = cx.write_hry(m, profile=hc.PROFILE_COMPAT, as_buffer=True); te = time.time() - t
         print(f"compat pass {it}: encode {te*1e3:.0f} ms {mesh.ntri/te/1e6:.1f} Mtri/s bytes {len(compat)} ({8*len(compat)/1e9:.2f} Gbit of the 4.29 Gbit the 32-bit positions hold) " + r(cx.timing()), flush=True)
     t = time.time(); cdec = cx.read_hry(compat); td = time.time() - t
     print(f"compat decode {td*1e3:.0f} ms {mesh.ntri/td/1e6:.1f} Mtri/s " + r(cx.timing()), flush=True)
