@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include <atomic>
+#include <unordered_map>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,286 @@ struct Planes {
 	uint32_t op(int order) { int k = order - 1; if (k > 7) k = 7; if (k < 0) k = 0; return byte(13 + k); }
 };
 
+
+// One span of the replay for meshes with polygons, written like replay_triangles (cbm_replay.hpp) for few instructions -- the
+// generic replay_span measured 310 instructions per triangle on the configs[3] share (78 cycles at 4 per cycle; DESIGN.md
+// section 4b).  The operation planes and the two triangle-count planes are read through bare cursors with an end pointer, the
+// other planes (a few symbols per component) through the checked reader; nodes and the top part through bare pointers; the
+// gate's neighbours are loaded only by the operations that use them; a polygon's half-edges are initialised when its first
+// triangle arrives and its fan is continued by counting (cbm/decoder.h:133-197).  Same checks against a corrupt stream, same
+// results as replay_span (the tests run both).
+bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order_v, ReplayCursor &cur, uint32_t stop_face, uint32_t own_first,
+                     const RestartCounters &old_counts, std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs)
+{
+	using namespace replay_detail;
+	struct Node { uint32_t v, a; int32_t prev, next; };
+	struct Part { int32_t head, tail; uint32_t size, edge_begin; };
+	const uint32_t nv = m.nv, nf = m.nf;
+	const uint64_t ne_max = m.org.size();
+	uint32_t *const org = m.org.data(), *const twin = m.twin.data(), *const foff = m.face_off.data();
+	const uint8_t *opc[8], *ope[8];
+	for (int k = 0; k < 8; ++k) {
+		const PlaneView &v = rd.pl[13 + k];
+		if (rd.cur[13 + k] > v.size()) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart points)");
+		opc[k] = v.data() + rd.cur[13 + k]; ope[k] = v.data() + v.size();
+	}
+	const int fixed = rd.fixed_numtri;
+	const uint8_t *nt0 = nullptr, *nt1 = nullptr, *nt0e = nullptr, *nt1e = nullptr;
+	if (fixed < 0) {
+		if (rd.cur[11] > rd.pl[11].size() || rd.cur[12] > rd.pl[12].size()) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart points)");
+		nt0 = rd.pl[11].data() + rd.cur[11]; nt0e = rd.pl[11].data() + rd.pl[11].size();
+		nt1 = rd.pl[12].data() + rd.cur[12]; nt1e = rd.pl[12].data() + rd.pl[12].size();
+	}
+	auto numtri = [&]() -> uint32_t {   // io.h:228-231
+		if (fixed >= 0) return (uint32_t)fixed;
+		if (nt0 == nt0e || nt1 == nt1e) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)");
+		return (uint32_t)*nt0++ | (uint32_t)*nt1++ << 8;
+	};
+	// order counters: the span's own vertices in the shared array, older ones in a private map seeded by the restart point
+	std::unordered_map<uint32_t, uint16_t> old_seen;
+	for (const auto &c : old_counts) old_seen.emplace(c.first, (uint16_t)c.second);
+	auto seen = [&](uint32_t v) -> uint16_t& { return v >= own_first ? seen_shared[v] : old_seen.find(v)->second; };
+	auto chk = [&](uint32_t v) {
+		if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
+		if (v < own_first && !old_seen.count(v)) throw Error(HRY_E_FORMAT, "corrupt stream (restart point names an older vertex without its counter)");
+		return v;
+	};
+
+	std::vector<Node> pool;
+	pool.reserve(1 << 14);
+	Node *P = pool.data();
+	int32_t free_head = -1;
+	std::vector<Part> parts;
+	auto make = [&](uint32_t v, uint32_t a) -> int32_t {
+		int32_t i = free_head;
+		if (i >= 0) free_head = P[i].next;
+		else { i = (int32_t)pool.size(); pool.push_back(Node()); P = pool.data(); }
+		P[i].v = v; P[i].a = a; P[i].prev = -1; P[i].next = -1;
+		return i;
+	};
+	auto drop = [&](int32_t i) { P[i].next = free_head; free_head = i; };
+	auto append = [&](Part &p, int32_t i) { P[i].prev = p.tail; P[i].next = -1; if (p.tail >= 0) P[p.tail].next = i; else p.head = i; p.tail = i; ++p.size; };
+	auto prepend = [&](Part &p, int32_t i) { P[i].next = p.head; P[i].prev = -1; if (p.head >= 0) P[p.head].prev = i; else p.tail = i; p.head = i; ++p.size; };
+	auto unlink_tail = [&](Part &p) -> int32_t { int32_t i = p.tail; p.tail = P[i].prev; if (p.tail >= 0) P[p.tail].next = -1; else p.head = -1; --p.size; return i; };
+	auto unlink_head = [&](Part &p) -> int32_t { int32_t i = p.head; p.head = P[i].next; if (p.head >= 0) P[p.head].prev = -1; else p.tail = -1; --p.size; return i; };
+	auto discard_top = [&]() { for (int32_t i = parts.back().head; i >= 0;) { int32_t nx = P[i].next; drop(i); i = nx; } parts.pop_back(); };
+	auto border = [&]() {   // cutborder.h:217-248
+		Part &p = parts.back();
+		if (p.size - (p.edge_begin ? 0u : 1u) == 1u) { discard_top(); return; }
+		int32_t t = unlink_tail(p);
+		if (!p.edge_begin) drop(unlink_head(p));
+		prepend(p, t);
+		p.edge_begin = 0;
+	};
+	auto at = [&](int i, int pi, uint32_t &before) -> int32_t {   // cutborder.h:114-123
+		if ((size_t)pi >= parts.size()) throw Error(HRY_E_FORMAT, "corrupt stream (part index)");
+		Part &pt = parts[parts.size() - 1 - (size_t)pi];
+		int32_t n;
+		if (i > 0) {
+			if ((uint32_t)i > pt.size) throw Error(HRY_E_FORMAT, "corrupt stream (element offset)");
+			n = pt.head;
+			for (int k = 1; k < i; ++k) n = P[n].next;
+			before = (uint32_t)(i - 1);
+		} else {
+			if ((uint32_t)(-i) >= pt.size) throw Error(HRY_E_FORMAT, "corrupt stream (element offset)");
+			n = pt.tail;
+			for (int k = 0; k < -i; ++k) n = P[n].prev;
+			before = pt.size - 1 - (uint32_t)(-i);
+		}
+		return n;
+	};
+
+	uint32_t next_id = cur.next_id, face = cur.face, he = cur.he;
+	// a polygon of nt triangles: its half-edges, each its own twin until linked; origins beyond the first three are set as the
+	// fan reaches them (zero until then, like the generic replay)
+	auto new_face = [&](uint32_t nt) -> uint32_t {
+		const uint32_t ne = nt + 2;
+		if (ne < 3 || ne > 255) throw Error(HRY_E_FORMAT, "corrupt stream (polygon degree)");
+		if (face >= nf) throw Error(HRY_E_FORMAT, "corrupt stream (too many faces)");
+		if ((uint64_t)he + ne > ne_max) throw Error(HRY_E_FORMAT, "corrupt stream (too many polygon edges)");
+		const uint32_t o = he;
+		he += ne;
+		foff[++face] = he;
+		for (uint32_t i = 0; i < ne; ++i) twin[o + i] = o + i;
+		for (uint32_t i = 3; i < ne; ++i) org[o + i] = 0;
+		return o;
+	};
+	bool eom = false;
+	for (;;) {
+		if (stop_face != NONE32 && face >= stop_face) break;
+		const uint32_t iop = rd.iop();
+		if (iop == I_EOM) { eom = true; break; }
+		const uint32_t seg_first_id = next_id;
+		comp_first.push_back(seg_first_id);
+		const uint32_t comp_idx = (uint32_t)comp_first.size() - 1;
+		auto depends_on = [&](uint32_t vid) { if (vid < seg_first_id) refs.push_back({ comp_idx, vid }); };
+		auto fresh = [&]() { if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)"); return next_id++; };
+		uint32_t a = 0, b = 0, c = 0;
+		switch (iop) {   // decoder.h:46-77
+		case I_INIT: a = fresh(); b = fresh(); c = fresh(); break;
+		case I_TRI100: a = rd.vertid(); b = fresh(); c = fresh(); break;
+		case I_TRI010: c = fresh(); b = rd.vertid(); a = fresh(); break;
+		case I_TRI001: a = fresh(); b = fresh(); c = rd.vertid(); break;
+		case I_TRI110: a = rd.vertid(); b = rd.vertid(); c = fresh(); break;
+		case I_TRI101: c = rd.vertid(); b = fresh(); a = rd.vertid(); break;
+		case I_TRI011: a = fresh(); b = rd.vertid(); c = rd.vertid(); break;
+		case I_TRI111: a = rd.vertid(); b = rd.vertid(); c = rd.vertid(); break;
+		default: throw Error(HRY_E_FORMAT, "corrupt stream (init op)");
+		}
+		chk(a); chk(b); chk(c);
+		depends_on(a); depends_on(b); depends_on(c);
+		uint32_t ntri = numtri(), curtri = 1;
+		++seen(a); ++seen(b); ++seen(c);
+		uint32_t base = new_face(ntri);
+		{
+			const uint32_t e0 = base, e1 = base + 1, e2 = base + 2;
+			org[e0] = a; org[e1] = b; org[e2] = c;
+			switch (iop) {   // decoder.h:86-110: vertex ids are handed out in decode order, order_v is indexed by the id
+			case I_INIT: order_v[a] = e0; order_v[b] = e1; order_v[c] = e2; break;
+			case I_TRI100: order_v[b] = e1; order_v[c] = e2; break;
+			case I_TRI010: order_v[c] = e2; order_v[a] = e0; break;
+			case I_TRI001: order_v[a] = e0; order_v[b] = e1; break;
+			case I_TRI110: order_v[c] = e2; break;
+			case I_TRI101: order_v[b] = e1; break;
+			case I_TRI011: order_v[a] = e0; break;
+			default: break;
+			}
+			parts.push_back(Part{ -1, -1, 0, 1 });
+			append(parts.back(), make(a, e0));
+			append(parts.back(), make(b, e1));
+			append(parts.back(), make(c, e2));
+		}
+
+		while (!parts.empty()) {
+			Part *T = &parts.back();
+			if (T->size < 2) throw Error(HRY_E_FORMAT, "corrupt stream (border part)");
+			const int32_t tn = T->tail, hn = T->head;
+			const uint32_t v0 = P[tn].v, gate = P[tn].a, v1 = P[hn].v;
+			uint32_t k = seen(v1);
+			k = k == 0 ? 0u : k > 8u ? 7u : k - 1u;   // models.h:101-105
+			if (opc[k] == ope[k]) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)");
+			const uint32_t op = *opc[k]++;
+			uint32_t v2, realop = op, lk_next = NONE32, lk_prev = NONE32;   // lk_*: cut-border edges the new triangle may close (decoder.h:182-197)
+			int32_t first = -1, second = -1;
+			switch (op) {   // decoder.h:133-166
+			case O_NEWVTX: {
+				if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)");
+				v2 = next_id++;
+				first = tn;
+				second = make(v2, 0);
+				T = &parts.back();
+				P[second].prev = tn; P[tn].next = second; T->tail = second; ++T->size;   // append
+				break;
+			}
+			case O_CONNFWD: {
+				if (!T->edge_begin) { border(); continue; }   // renamed border (cutborder.h:177-179): no triangle
+				v2 = P[P[hn].next].v;
+				lk_next = P[hn].a;
+				if (T->size == 3) { lk_prev = P[P[tn].prev].a; discard_top(); realop = O_CLOSE; }
+				else { drop(unlink_head(*T)); first = T->tail; }
+				break;
+			}
+			case O_CONNBWD: {
+				lk_prev = P[P[tn].prev].a;
+				drop(unlink_tail(*T));
+				first = T->tail;
+				v2 = P[first].v;
+				break;
+			}
+			case O_NM: {
+				v2 = rd.vertid();
+				chk(v2);
+				depends_on(v2);
+				first = tn;
+				second = make(v2, 0);
+				T = &parts.back();
+				P[second].prev = tn; P[tn].next = second; T->tail = second; ++T->size;
+				break;
+			}
+			case O_SPLIT: {
+				const int i = rd.elem();
+				uint32_t before;
+				const int32_t hit = at(i, 0, before);
+				const size_t oi = parts.size() - 1;
+				const int32_t g = unlink_tail(parts[oi]);
+				if (hit == g) throw Error(HRY_E_FORMAT, "corrupt stream (split at the gate)");
+				Part np{ -1, -1, 0, 1 };
+				if (before > 0) {
+					Part &old = parts[oi];
+					const int32_t last = P[hit].prev;
+					np.head = old.head; np.tail = last; np.size = before;
+					P[last].next = -1; P[hit].prev = -1;
+					old.head = hit; old.size -= before;
+				}
+				append(parts[oi], g);
+				second = make(P[hit].v, P[hit].a);
+				append(np, second);
+				np.edge_begin = parts[oi].edge_begin;
+				parts[oi].edge_begin = 1;
+				parts.push_back(np);
+				first = g;
+				v2 = P[hit].v;
+				break;
+			}
+			case O_UNION: {
+				const int i = rd.elem();
+				const int pp = rd.part();
+				if (pp <= 0) throw Error(HRY_E_FORMAT, "corrupt stream (union with the current part)");
+				uint32_t before;
+				const int32_t hit = at(i, pp, before);
+				const size_t ci = parts.size() - 1, oi = ci - (size_t)pp;
+				Part other = parts[oi];
+				Part &cp = parts[ci];
+				first = cp.tail;
+				if (hit != other.head) {
+					P[other.tail].next = other.head; P[other.head].prev = other.tail;
+					const int32_t last = P[hit].prev;
+					P[last].next = -1; P[hit].prev = -1;
+					other.head = hit; other.tail = last;
+				}
+				P[cp.tail].next = other.head; P[other.head].prev = cp.tail;
+				cp.tail = other.tail; cp.size += other.size;
+				second = make(P[hit].v, P[hit].a);
+				append(parts[ci], second);
+				v2 = P[hit].v;
+				parts.erase(parts.begin() + (long)oi);
+				break;
+			}
+			case O_BORDER: border(); continue;
+			default: throw Error(HRY_E_FORMAT, "corrupt stream (op)");
+			}
+			// the new triangle: the first one of a polygon enters through the gate (v1 -> v0 -> v2), the others continue its fan
+			uint32_t e1, e2;
+			const bool first_tri = curtri == ntri;
+			if (first_tri) {
+				ntri = numtri();
+				curtri = 0;
+				base = new_face(ntri);
+				e1 = base + 1; e2 = base + 2;
+				org[base] = v1; org[e1] = v0; org[e2] = v2;
+				twin[base] = gate; twin[gate] = base;             // decoder.h:179 merge(gate, e0)
+			} else {
+				e1 = base + curtri + 1; e2 = e1 + 1;
+				org[e2] = v2;
+			}
+			switch (realop) {   // decoder.h:182-197
+			case O_CONNFWD: P[first].a = e1; break;
+			case O_CONNBWD: P[first].a = e2; break;
+			case O_CLOSE: break;
+			default: P[first].a = e1; P[second].a = e2; break;   // SPLIT, UNION, NEWVTX, NM
+			}
+			++seen(v0); ++seen(v1); ++seen(v2);
+			if (op == O_NEWVTX) order_v[v2] = e2;
+			++curtri;
+			if (lk_next != NONE32 && curtri == ntri) { twin[lk_next] = e2; twin[e2] = lk_next; }   // CONNFWD / CLOSE on the polygon's last triangle: its last edge meets the next cut-border edge
+			if (lk_prev != NONE32) { twin[lk_prev] = e1; twin[e1] = lk_prev; }                       // CONNBWD / CLOSE: its second edge meets the previous one
+		}
+	}
+	cur.next_id = next_id; cur.face = face; cur.he = he;
+	for (int k = 0; k < 8; ++k) rd.cur[13 + k] = (size_t)(opc[k] - rd.pl[13 + k].data());
+	if (fixed < 0) { rd.cur[11] = (size_t)(nt0 - rd.pl[11].data()); rd.cur[12] = (size_t)(nt1 - rd.pl[12].data()); }
+	return eom;
+}
 }   // namespace
 
 // planes: 21 connectivity planes in container order.  Fills m.face_off / org / twin and returns the decode order
@@ -71,6 +352,28 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 			return;
 		}
 		Planes rd{ conn_planes, { 0 }, fixed_numtri };
+		if (!getenv("HRY_GENERIC_REPLAY")) {   // polygons: the lean loop as one span from the start of the stream
+			m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;
+			m.org.resize(m.declared_ne);
+			m.twin.resize(m.declared_ne);
+			order_v.assign(m.nv, 0);
+			BigVec<uint16_t> seen(m.nv, 0);
+			ReplayCursor cur;
+			const RestartCounters none;
+			std::vector<std::pair<uint32_t, uint32_t>> refs;
+			seg_start.clear();
+			PerfCounters pc;
+			const bool count = getenv("HRY_PERF") != nullptr;
+			if (count) pc.start();
+			replay_polygons(m, rd, seen.data(), order_v.data(), cur, NONE32, 0, none, seg_start, refs);
+			if (count) { pc.stop(); pc.report("cut-border replay (polygons)", (double)cur.he - 2.0 * cur.face); }
+			if (cur.face != m.nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
+			if (cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (polygon edge count)");
+			order_v.resize(cur.next_id);
+			replay_levels(seg_start, refs, seg_level);
+			seg_start.push_back(cur.next_id);
+			return;
+		}
 		cut_border_replay_with(m, rd, order_v, seg_start, seg_level);
 		return;
 	}
@@ -128,13 +431,15 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 		if (!ok) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart point does not match the stream)");
 	};
 	std::atomic<size_t> next{ 0 };
+	const bool lean = !getenv("HRY_GENERIC_REPLAY");
 	parallel_for((unsigned)std::min<size_t>(n_threads, ns), [&](unsigned) {
 		for (;;) {
 			size_t k = next.fetch_add(1, std::memory_order_relaxed);
 			if (k >= ns) break;
 			Span &sp = spans[k];
 			const uint32_t f0 = sp.cur.face, h0 = sp.cur.he, v0 = sp.cur.next_id;
-			sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
+			if (lean) sp.eom = replay_polygons(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
+			else sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
 			check_end(k);
 			if (on_span) on_span->span(f0, sp.cur.face, h0, sp.cur.he, v0, sp.cur.next_id);
 		}

@@ -1090,6 +1090,7 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 	// one with a component that was there before it, so the notes connect all of them.
 	AtomicArray vfirst(nv);
 	parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nv, t, b, e); for (uint32_t v = b; v < e; ++v) vfirst[v].store(NONE32, std::memory_order_relaxed); });
+	mark("  vertex words initialised");
 	std::vector<std::vector<std::pair<uint32_t, uint32_t>>> tie_notes(n_threads);
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(nf, t, b, e);
@@ -1109,6 +1110,7 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 			}
 		}
 	});
+	mark("  corners");
 	AtomicSets ties(ncomp);
 	for (uint32_t k = 0; k < ncomp; ++k) ties.parent[k].store(k, std::memory_order_relaxed);
 	for (const auto &notes : tie_notes) for (const auto &pr : notes) ties.unite(pr.first, pr.second);
@@ -1125,6 +1127,7 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 		}
 		if (run_k != NONE32) fresh[run_k].fetch_add(run_n, std::memory_order_relaxed);
 	});
+	mark("  vertices counted");
 	A.fresh.resize(ncomp); A.group.resize(ncomp);
 	for (uint32_t k = 0; k < ncomp; ++k) { A.fresh[k] = fresh[k].load(std::memory_order_relaxed); A.group[k] = ties.find(k); }   // a root is the smallest rank of its group
 	if (A.want_vertex_owner) {

@@ -285,6 +285,14 @@ def test_replay_from_restart_points_equals_sequential_replay(case):
         assert np.array_equal(ref.org(), dec.org())
         assert np.array_equal(ref.twin(), dec.twin())
         assert np.array_equal(ov, ov2) and np.array_equal(ss, ss2) and np.array_equal(sl, sl2)
+    # the lean loops (replay_triangles, replay_polygons: the ones above) against the generic replay_span, span by span
+    os.environ["HRY_GENERIC_REPLAY"] = "1"
+    try:
+        _, dec, ov2, ss2, sl2, nrs = replay(ply, 3, True)
+    finally:
+        del os.environ["HRY_GENERIC_REPLAY"]
+    assert np.array_equal(ref.face_offsets(), dec.face_offsets()) and np.array_equal(ref.org(), dec.org()) and np.array_equal(ref.twin(), dec.twin())
+    assert np.array_equal(ov, ov2) and np.array_equal(ss, ss2) and np.array_equal(sl, sl2)
 
 
 # ---------------------------------------------------------------- half-edge twin matching on several threads
@@ -313,31 +321,39 @@ def test_threaded_twin_matching_equals_sequential(case):
         assert np.array_equal(ref, twins(t)), t
 
 
-@pytest.mark.parametrize("case", ["torus", "open_grid", "ico", "multi_nm", "tiny"])
-def test_lean_triangle_replay_equals_generic_replay(case, monkeypatch):
-    """cbm_replay.hpp: replay_triangles (few instructions per triangle, the headline decode's loop) against replay_span on the
-    same connectivity planes: borders, splits / unions (torus), several components, shared non-manifold vertices."""
+POLY_CASES = {"mixed_torus": lambda: mg.torus(40, 36, polys="mixed"), "quad_torus": lambda: mg.torus(17, 20, polys="quad"),
+              "mixed_multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(9, 12, 14, polys="mixed", seed=6), 30, 20),
+              "mixed_tiny": lambda: mg.torus(3, 4, polys="mixed")}
+
+
+@pytest.mark.parametrize("case", ["torus", "open_grid", "ico", "multi_nm", "tiny"] + list(POLY_CASES))
+@pytest.mark.parametrize("threads", [1, 3])
+def test_lean_triangle_replay_equals_generic_replay(case, threads, monkeypatch):
+    """cbm_replay.hpp: replay_triangles (few instructions per triangle, the headline decode's loop) and cbm_unwalk.cpp:
+    replay_polygons (the same for polygon meshes, one span or spans on several threads) against replay_span on the same
+    connectivity planes: borders, splits / unions (torus), several components, shared non-manifold vertices."""
     mesh = {"torus": lambda: mg.torus(40, 36), "open_grid": lambda: mg.grid(31, 17), "ico": lambda: mg.icosphere(4),
-            "multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 9, 10, polys="tri"), 7, 4), "tiny": lambda: mg.grid(2)}[case]()
-    monkeypatch.setenv("HRY_HOST_THREADS", "1")
+            "multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 9, 10, polys="tri"), 7, 4), "tiny": lambda: mg.grid(2), **POLY_CASES}[case]()
+    monkeypatch.setenv("HRY_HOST_THREADS", str(threads))
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
     out = []
     for generic in (False, True):
         if generic:
             monkeypatch.setenv("HRY_GENERIC_REPLAY", "1")
         m = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
-        dec, order_v, seg_start, seg_level, _ = hc.walk_and_replay(m, False)
+        dec, order_v, seg_start, seg_level, _ = hc.walk_and_replay(m, threads > 1)
         out.append((dec.face_offsets(), dec.org(), dec.twin(), order_v, seg_start, seg_level))
     for a, b in zip(*out):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("case", ["torus", "open_grid", "ico", "multi_nm", "tiny"])
+@pytest.mark.parametrize("case", ["torus", "open_grid", "ico", "multi_nm", "tiny"] + list(POLY_CASES))
 @pytest.mark.parametrize("threads", [1, 4])
 def test_lean_triangle_walk_equals_generic_walk(case, threads, monkeypatch):
     """cbm_walk.cpp: walk_component_tri (the headline encode's loop) against the generic walk_component: same order, same
     symbols, same repaired twins."""
     mesh = {"torus": lambda: mg.torus(40, 36), "open_grid": lambda: mg.grid(31, 17), "ico": lambda: mg.icosphere(4),
-            "multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 9, 10, polys="tri"), 7, 4), "tiny": lambda: mg.grid(2)}[case]()
+            "multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 9, 10, polys="tri"), 7, 4), "tiny": lambda: mg.grid(2), **POLY_CASES}[case]()
     monkeypatch.setenv("HRY_HOST_THREADS", str(threads))
     monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
     out = []
