@@ -111,6 +111,7 @@ def load():
     L.hry_range_encode_lht.restype = C.c_int; L.hry_range_encode_lht.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]
     L.hry_shard_plan.restype = C.c_int; L.hry_shard_plan.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hry_plan_free.argtypes = [vp]
+    L.hry_walk_run_shard.restype = C.c_int; L.hry_walk_run_shard.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     L.hry_plan_ncomponents.restype = C.c_uint32; L.hry_plan_ncomponents.argtypes = [vp]
     L.hry_plan_ngroups.restype = C.c_uint32; L.hry_plan_ngroups.argtypes = [vp]
     L.hry_plan_triangles.restype = C.c_uint64; L.hry_plan_triangles.argtypes = [vp, C.c_int]

@@ -205,20 +205,26 @@ class Mesh:
         L = nat.load()
         w = C.c_void_p()
         nat.check((L.hry_walk_run_plain if plain else L.hry_walk_run)(self.h, C.byref(w)))
-        try:
-            out = {}
-            names = [("order_v", np.uint32), ("order_f", np.uint32), ("op_sym", np.uint8), ("op_class", np.uint8), ("op_l", np.uint32),
-                     ("op_h", np.uint32), ("op_t", np.uint32), ("op_pos", np.uint32), ("op_thr", np.uint32), ("op_cum", np.uint32), ("info", np.uint32),
-                     ("marks", np.uint32)]
-            for g in range(5):
-                names += [(f"grp{g}_val", np.uint32), (f"grp{g}_pos", np.uint32)]
-            for name, dt in names:
-                p = C.c_void_p()
-                n = L.hry_walk_get(w, name.encode(), C.byref(p))
-                out[name] = (np.frombuffer(C.string_at(p, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt))
-            return out
-        finally:
-            L.hry_walk_free(w)
+        return _walk_arrays(w)
+
+
+def _walk_arrays(w) -> dict:
+    """every array of a recorded walk (hry_walk_get); frees the walk"""
+    L = nat.load()
+    try:
+        out = {}
+        names = [("order_v", np.uint32), ("order_f", np.uint32), ("op_sym", np.uint8), ("op_class", np.uint8), ("op_l", np.uint32),
+                 ("op_h", np.uint32), ("op_t", np.uint32), ("op_pos", np.uint32), ("op_thr", np.uint32), ("op_cum", np.uint32), ("info", np.uint32),
+                 ("marks", np.uint32)]
+        for g in range(5):
+            names += [(f"grp{g}_val", np.uint32), (f"grp{g}_pos", np.uint32)]
+        for name, dt in names:
+            p = C.c_void_p()
+            n = L.hry_walk_get(w, name.encode(), C.byref(p))
+            out[name] = (np.frombuffer(C.string_at(p, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt))
+        return out
+    finally:
+        L.hry_walk_free(w)
 
 
 class ShardPlan:
@@ -244,6 +250,12 @@ class ShardPlan:
         h = C.c_void_p()
         nat.check(nat.load().hry_shard_extract(mesh.h, self.h, shard, C.byref(h)))
         return Mesh(h)
+
+    def walk_in_place(self, mesh: Mesh, shard: int) -> dict:
+        """Host-only: the shard's components walked where they lie in `mesh` (hry_walk_run_shard; mutates its twins)."""
+        w = C.c_void_p()
+        nat.check(nat.load().hry_walk_run_shard(mesh.h, self.h, shard, C.byref(w)))
+        return _walk_arrays(w)
 
 
 def container_info(data: bytes) -> dict:

@@ -327,6 +327,31 @@ int hry_shard_plan(const hry_mesh *m, int n_shards, hry_plan **out)
 	});
 }
 void hry_plan_free(hry_plan *p) { delete p; }
+int hry_walk_run_shard(hry_mesh *m, const hry_plan *p, int shard, hry_walk **out)
+{
+	if (!m || !p || !out || shard < 0) { g_last_error = "invalid argument"; return HRY_E_ARG; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<hry_walk> w(new hry_walk());
+		check_codable(m->m);
+		ensure_twins(m->m);
+		if (p->p.g_nv != m->m.nv || p->p.g_nf != m->m.nf || p->p.g_ne != m->m.ne()) throw Error(HRY_E_ARG, "the plan belongs to another mesh");
+		ComponentAnalysis part;
+		ShardInfo info;
+		shard_components(p->p, (uint32_t)shard, part, info);
+		int ud = 0;
+		const bool uniform = m->m.uniform_degree(ud) && (ud == 3 || ud == 4);
+		BigVec<uint32_t> eface;
+		if (!uniform && p->p.A.eface.size() != m->m.ne()) {
+			eface.resize(m->m.ne());
+			for (uint32_t f = 0; f < m->m.nf; ++f) for (uint32_t h = m->m.face_off[f]; h < m->m.face_off[f + 1]; ++h) eface[h] = f;
+		}
+		WalkState marks(m->m.nv, m->m.nf);
+		cut_border_walk_in_place(m->m, part, uniform ? nullptr : eface.empty() ? p->p.A.eface.data() : eface.data(), marks, w->w);
+		w->info[0] = w->w.n_conn; w->info[1] = w->w.numtri_coded ? 1 : 0;
+		*out = w.release();
+	});
+}
 uint32_t hry_plan_ncomponents(const hry_plan *p) { return p ? p->p.A.ncomp : 0; }
 uint32_t hry_plan_ngroups(const hry_plan *p)
 {

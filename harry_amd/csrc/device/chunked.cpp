@@ -9,6 +9,8 @@
 // information are not stored (reg_face / reg_vtx with a single region, attr_type == DATA, numtri with one degree).
 // The symbols themselves are those of the compat stream, so the two profiles transcode losslessly.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "codec_math.hpp"
@@ -20,6 +22,9 @@ namespace hry {
 using namespace dev;
 typedef std::chrono::steady_clock Clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+// HRY_TRACE=1: wall-clock marks of the encode on stderr (development aid; the decode's are in unchunk.cpp)
+static bool trace_on() { static const bool on = getenv("HRY_TRACE") != nullptr; return on; }
+#define HRY_MARK(t0, what) do { if (trace_on()) fprintf(stderr, "[hry enc] %8.3f ms  %s\n", ms_since(t0), what); } while (0)
 
 void build_init_tables(const Mesh &m, std::vector<uint32_t> &tabs)
 {
@@ -60,7 +65,7 @@ static uint32_t stream_words(uint32_t n, uint32_t t0)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
+void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const InPlaceShard *in_place)
 {
 	HIP_OK(hipSetDevice(cx.device));
 	auto t_all = Clock::now();
@@ -70,8 +75,11 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	uint32_t CH = chunk_syms > 0 ? std::min<uint32_t>((uint32_t)chunk_syms, kMaxChunk) : (uint32_t)kDefaultChunk;
 	for (auto &L : m.lists) if (!L.have_bounds && L.ncomp()) { device_bounds(cx, m); break; }
 	for (auto &L : m.lists) if (!L.have_bounds) { L.bmin.assign(L.stride(), 0); L.bmax.assign(L.stride(), 0); L.have_bounds = true; }
+	if (in_place && (m.general || !m.shard.active())) throw Error(HRY_E_INTERNAL, "only a shard of a mesh in the PLY layout is coded in place");
 	if (m.general) upload_general(cx, m);
+	else if (in_place) {}   // (the caller filled the whole mesh's arrays over the shard's intervals)
 	else if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
+	const uint32_t dev_nv = in_place ? in_place->whole->nv : m.nv;   // vertex-indexed device arrays follow the numbering of the arrays in HBM
 
 	// a shard of a larger mesh writes one segment of a sharded container (.hry v0.3, host/shard.cpp): the header of the whole
 	// mesh, then its runs and an ordinary v0.2 body of the shard in its own numbering
@@ -106,11 +114,14 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 			if (nl2) { const uint8_t *qp = (const uint8_t*)(m.shard.run_records.data() + j * nl2); out.append(qp, qp + 4 * nl2); }
 		}
 	}
+	HRY_MARK(t_all, "mesh resident, header written");
 	auto t_walk = Clock::now();
 	WalkResult w;
 	w.numtri_positions = false;     // (places in ONE symbol sequence: the chunked planes have none)
-	cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
+	if (in_place) cut_border_walk_in_place(*in_place->whole, *in_place->part, in_place->eface, *in_place->marks, w);
+	else cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
 	cx.timing.host_walk_ms = ms_since(t_walk);
+	HRY_MARK(t_all, "walked");
 
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	const ListDesc ldv = m.general ? ListDesc{} : make_list_desc(m.lists[1]), ldf = m.general ? ListDesc{} : make_list_desc(m.lists[0]);   // (general bindings: general_planes_encode)
@@ -132,7 +143,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	for (int g = 0; g < G_COUNT; ++g) { ngrp += w.grp_val[g].size(); conn_plane_bytes += w.grp_val[g].size() * kGroupBytes[g]; }
 	cx.d_order_v.ensure(std::max<size_t>((size_t)vc * 4, 16));
 	cx.d_order_f.ensure(std::max<size_t>((size_t)fc * 4, 16));
-	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
+	cx.d_rank.ensure(std::max<size_t>((size_t)dev_nv * 4, 16));
 	cx.d_grp_val.ensure(std::max<size_t>(ngrp * 4, 16));
 	cx.d_connplanes.ensure(std::max<size_t>(conn_plane_bytes + 2 * nopb + 64, 16));   // ... + operation planes + the raw operation bytes
 	cx.d_vplanes.ensure(std::max<size_t>((size_t)vc * ldv.nplanes, 16));
@@ -140,7 +151,13 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
 	if (fc && (ldf.nplanes || m.general)) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));   // only the face planes read it
 	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
-	if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
+	if (w.twins_changed && in_place) {
+		const Mesh &g = *in_place->whole;
+		for (const auto &iv : *in_place->face_intervals) {
+			const size_t h0 = g.face_off[iv.first], h1 = g.face_off[iv.second];
+			if (h1 > h0) HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + h0, g.twin.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, cx.stream));
+		}
+	} else if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
 	size_t goff[G_COUNT + 1] = { 0 };
 	for (int g = 0; g < G_COUNT; ++g) {
 		size_t n = w.grp_val[g].size();
@@ -184,12 +201,13 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	HIP_OK(hipMemsetAsync(d_hist, 0, (size_t)npl * 1024, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	cx.timing.h2d_ms = ms_since(t_h2d);
+	HRY_MARK(t_all, "walk's outputs on the device");
 
 	// ---- device: prediction + residuals + planes, then the planes' histograms
 	ConnView cv = cx.conn_view();
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
 	if (!m.general) {
-		HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)m.nv * 4, cx.stream));
+		HIP_OK(hipMemsetAsync(cx.d_rank.p, 0xff, (size_t)dev_nv * 4, cx.stream));
 		launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, cx.d_rank.as<uint32_t>());
 		launch_predict_vtx(cx.stream, cv, cx.d_order_v.as<uint32_t>(), vc, cx.d_rank.as<uint32_t>(), cx.d_rec[1].as<uint8_t>(), ldv, cx.d_vplanes.as<uint8_t>());
 		launch_face_planes(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, cx.d_rec[0].as<uint8_t>(), ldf, cx.d_fplanes.as<uint8_t>());
@@ -213,6 +231,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	std::vector<uint32_t> hist((size_t)npl * 256);
 	if (npl) HIP_OK(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	HRY_MARK(t_all, "planes and their histograms");
 
 	// ---- initial table of every plane: its static prior, or the reference's initial counts for short planes
 	std::vector<uint32_t> inits((size_t)npl * 256);
@@ -267,6 +286,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	uint64_t total_bytes = 0;
 	HIP_OK(hipMemcpyAsync(&total_bytes, cx.d_coffs.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	HRY_MARK(t_all, "streams coded");
 	cx.d_cout.ensure(std::max<size_t>(total_bytes, 16));
 	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, cx.d_bytes.as<uint8_t>(), d_nbytes, cx.d_coffs.as<uint64_t>(), cx.d_cout.as<uint8_t>(), true);
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
@@ -300,6 +320,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out)
 	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
 	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	HRY_MARK(t_all, "container on the host");
 	if (sharded) { const uint64_t seg_len = out.size() - seg_begin; memcpy(out.data() + seg_len_at, &seg_len, 8); }
 
 	if (cx.keep_stages) {

@@ -200,10 +200,18 @@ void check_codable(const Mesh &m)
 // ---------------------------------------------------------------------------------------------------------
 // bounds (a1) and requantisation (a2 on the host, a3 on the device)
 // ---------------------------------------------------------------------------------------------------------
-void device_bounds(Context &cx, Mesh &m)
+void device_bounds(Context &cx, Mesh &m, const Mesh *records)
 {
 	HIP_OK(hipSetDevice(cx.device));
-	if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
+	if (records) {   // the scan reads nothing but the records: the caller has no use for the connectivity on this device
+		if (m.lists.size() > (size_t)kMaxLists || records->lists.size() != m.lists.size()) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
+		for (size_t l = 0; l < m.lists.size(); ++l) {
+			const BigVec<uint8_t> &src = records->lists[l].data;
+			cx.d_rec[l].ensure(std::max<size_t>(src.size(), 16));
+			if (!src.empty()) HIP_OK(hipMemcpyAsync(cx.d_rec[l].p, src.data(), src.size(), hipMemcpyHostToDevice, cx.stream));
+		}
+		cx.resident_token = 0;
+	} else if (m.device_token == 0 || m.device_token != cx.resident_token) cx.upload_mesh(m);
 	const int nparts = 256;   // one block per compute unit
 	cx.d_small.ensure((size_t)nparts * dev::kMaxComp * (8 + 8 + 8) + 24 * dev::kMaxComp + 64);
 	uint8_t *pmin = cx.d_small.as<uint8_t>(), *pmax = pmin + (size_t)nparts * dev::kMaxComp * 8;
@@ -285,10 +293,10 @@ std::vector<uint8_t> shared_extent(const AttrList &L)
 }
 }   // namespace
 
-void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear)
+// validation and expansion of a quantisation request as the reference CLI does it (main.cc:74-91): the quantisation of every
+// component afterwards
+std::vector<std::vector<uint8_t>> requant_targets(const Mesh &m, const hry_quant *q, size_t nq, bool clear)
 {
-	HIP_OK(hipSetDevice(cx.device));
-	// validation and expansion as the reference CLI does it (main.cc:74-91)
 	const int nl = (int)m.lists.size();
 	std::vector<std::vector<uint8_t>> nquant(nl);
 	for (int l = 0; l < nl; ++l) nquant[l] = m.lists[l].quant;
@@ -311,7 +319,34 @@ void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool cl
 	}
 	if (clear) for (int l = 0; l < nl; ++l) std::fill(nquant[l].begin(), nquant[l].end(), 0);
 	for (const One &r : reqs) nquant[r.l][r.c] = (uint8_t)r.q;
+	return nquant;
+}
+// what k_requant does to the records of list L (bounds known) to take its components to the quantisation `to`
+dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to)
+{
+	std::vector<uint8_t> scale = shared_extent(L);
+	RequantPlan plan{};
+	for (int c = 0; c < L.ncomp(); ++c) {
+		int sq = L.quant[c], dq = to[c];
+		if (sq == dq) continue;
+		if (dq > 30 || sq > 30) throw Error(HRY_E_UNSUPPORTED, "more than 30 quantisation bits: the reference evaluates 1 << bits in int (quant.h:135)");
+		RequantComp &rc = plan.c[plan.n++];
+		rc.off = L.offset[c];
+		rc.src_type = sq ? storage_type(L.type[c], sq) : L.type[c];
+		rc.src_bits = sq; rc.dst_bits = dq; rc.dst_type = L.type[c]; rc.pad = 0;
+		rc.mn = 0; rc.scale = 0;
+		memcpy(&rc.mn, L.bmin.data() + L.offset[c], kTypeSize[L.type[c]]);
+		memcpy(&rc.scale, scale.data() + L.offset[c], kTypeSize[L.type[c]]);
+		if (L.type[c] != C_FLOAT && L.type[c] != C_DOUBLE && rc.scale == 0) throw Error(HRY_E_UNSUPPORTED, "constant integer component: the reference divides by a zero extent (quant.h:106)");
+	}
+	return plan;
+}
 
+void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear)
+{
+	HIP_OK(hipSetDevice(cx.device));
+	const int nl = (int)m.lists.size();
+	const std::vector<std::vector<uint8_t>> nquant = requant_targets(m, q, nq, clear);
 	bool any = false;
 	for (int l = 0; l < nl; ++l) any |= nquant[l] != m.lists[l].quant;
 	if (!any) return;
@@ -321,21 +356,7 @@ void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool cl
 	for (int l = 0; l < nl; ++l) {
 		AttrList &L = m.lists[l];
 		if (nquant[l] == L.quant) continue;
-		std::vector<uint8_t> scale = shared_extent(L);
-		RequantPlan plan{};
-		for (int c = 0; c < L.ncomp(); ++c) {
-			int sq = L.quant[c], dq = nquant[l][c];
-			if (sq == dq) continue;
-			if (dq > 30 || sq > 30) throw Error(HRY_E_UNSUPPORTED, "more than 30 quantisation bits: the reference evaluates 1 << bits in int (quant.h:135)");
-			RequantComp &rc = plan.c[plan.n++];
-			rc.off = L.offset[c];
-			rc.src_type = sq ? storage_type(L.type[c], sq) : L.type[c];
-			rc.src_bits = sq; rc.dst_bits = dq; rc.dst_type = L.type[c]; rc.pad = 0;
-			rc.mn = 0; rc.scale = 0;
-			memcpy(&rc.mn, L.bmin.data() + L.offset[c], kTypeSize[L.type[c]]);
-			memcpy(&rc.scale, scale.data() + L.offset[c], kTypeSize[L.type[c]]);
-			if (L.type[c] != C_FLOAT && L.type[c] != C_DOUBLE && rc.scale == 0) throw Error(HRY_E_UNSUPPORTED, "constant integer component: the reference divides by a zero extent (quant.h:106)");
-		}
+		const RequantPlan plan = requant_plan(L, nquant[l]);
 		launch_requant(cx.stream, cx.d_rec[l].as<uint8_t>(), L.count, L.stride(), plan);
 		if (!L.data.empty()) HIP_OK(hipMemcpyAsync(L.data.data(), cx.d_rec[l].p, L.data.size(), hipMemcpyDeviceToHost, cx.stream));
 		HIP_OK(hipStreamSynchronize(cx.stream));

@@ -61,7 +61,7 @@ struct Context {
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;   // uploads and connectivity-only kernels of the pipelined decode (created on first use)
 	hipStream_t stream3 = nullptr;   // attribute streams' entropy decode, next to the connectivity streams' (created on first use)
-	hipEvent_t ev_x[2] = {};         // cross-stream ordering events (created with stream3)
+	hipEvent_t ev_x[3] = {};         // cross-stream ordering events (created with stream3)
 	// chunked decode: the attribute streams are launched in groups by how far into their plane they end (unchunk.cpp); group g
 	// runs on attr_stream[g] and raises attr_ev[g]
 	static constexpr int kAttrGroups = 3;   // (+ the codec's three streams: more streams than hardware queues serialise)
@@ -147,10 +147,24 @@ void check_general(const Mesh &m);             // general.cpp
 void upload_general(Context &cx, Mesh &m);     // connectivity + every list + the binding tables -> HBM
 
 // codec entry points (codec.cpp / chunked.cpp)
-void device_bounds(Context &cx, Mesh &m);
+// records: m holds the lists' formats and counts only, their records are those of *records and nothing else travels to the device
+void device_bounds(Context &cx, Mesh &m, const Mesh *records = nullptr);
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);
+std::vector<std::vector<uint8_t>> requant_targets(const Mesh &m, const hry_quant *q, size_t nq, bool clear);   // validated request -> quantisation of every component
+dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to);
 void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
-void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out);   // (bytes that are not zero-filled first and go to the caller as they are)
+// A shard coded where it lies in the whole mesh (sharded.cpp: the in-process executor): the mesh handed to encode_chunked is a
+// SKELETON -- the shard's sizes, the lists' formats and bounds, its runs, no arrays; the context's connectivity and record arrays
+// are those of the whole mesh in the whole mesh's numbering, filled over the shard's index intervals; the walk goes over the
+// whole mesh's host arrays with the shard's components.
+struct InPlaceShard {
+	Mesh *whole;
+	const ComponentAnalysis *part;                                   // the shard's components (shard_components)
+	const uint32_t *eface;                                           // face of every half-edge of the whole mesh (mixed degrees), else nullptr
+	WalkState *marks;                                                // of the whole mesh; shared by the workers
+	const std::vector<std::pair<uint32_t, uint32_t>> *face_intervals;   // the shard's faces, as uploaded (repaired twins go up over the same intervals)
+};
+void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const InPlaceShard *in_place = nullptr);   // (bytes that are not zero-filled first and go to the caller as they are)
 void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out);   // general.cpp: regions, shared records, corner lists (reference stream only)
 Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::unique_ptr<Mesh> m);
 void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload);

@@ -765,15 +765,16 @@ void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *orde
 	if (n && ld.ncomp) hipLaunchKernelGGL(k_face_planes, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, order_f, n, rec, ld, planes);
 }
 // face of every half-edge of a mixed-degree mesh, from the face offsets (the table the topology helpers read)
-__global__ __launch_bounds__(256) void k_edge_faces(const uint32_t *foff, uint32_t nf, uint32_t *eface)
+__global__ __launch_bounds__(256) void k_edge_faces(const uint32_t *foff, uint32_t first, uint32_t nf, uint32_t *eface)
 {
-	uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t f = first + blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= nf) return;
 	for (uint32_t e = foff[f]; e < foff[f + 1]; ++e) eface[e] = f;
 }
-void launch_edge_faces(hipStream_t st, const uint32_t *foff, uint32_t nf, uint32_t *eface)
+// faces [first, nf)
+void launch_edge_faces(hipStream_t st, const uint32_t *foff, uint32_t nf, uint32_t *eface, uint32_t first)
 {
-	if (nf) hipLaunchKernelGGL(k_edge_faces, dim3(blocks_for(nf, 256)), dim3(256), 0, st, foff, nf, eface);
+	if (nf > first) hipLaunchKernelGGL(k_edge_faces, dim3(blocks_for(nf - first, 256)), dim3(256), 0, st, foff, first, nf, eface);
 }
 void launch_magic_table(hipStream_t st, MagicEnt *tab, uint32_t from, uint32_t to)
 {

@@ -18,7 +18,7 @@ void launch_rank(hipStream_t st, const uint32_t *order_v, uint32_t n, const uint
 void launch_predict_vtx(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank, const uint8_t *rec,
                         const ListDesc &ld, uint8_t *planes);
 void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
-void launch_edge_faces(hipStream_t st, const uint32_t *foff, uint32_t nf, uint32_t *eface);
+void launch_edge_faces(hipStream_t st, const uint32_t *foff, uint32_t nf, uint32_t *eface, uint32_t first = 0);   // faces [first, nf)
 void launch_magic_table(hipStream_t st, MagicEnt *tab, uint32_t from, uint32_t to);
 void launch_split_bytes(hipStream_t st, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes);
 // the order-conditioned operation model of the reference stream, by counting; op: symbol | class << 3 per operation, thr / cum: op_position_table

@@ -26,6 +26,7 @@
 #include <thread>
 
 #include "context.hpp"
+#include "kernels.hpp"
 
 namespace hry {
 
@@ -92,6 +93,17 @@ template <typename F> void run_workers(Context *const *cxs, int n, F &&body)
 	if (err) std::rethrow_exception(err);
 }
 
+// segments of a merged container (a shard without a group contributes none: its part holds a zero count)
+uint32_t merged_segments(const ByteSink &out)
+{
+	Mesh tmp;
+	int minor = 0;
+	const size_t hdr = read_hry_header(out.data(), out.size(), tmp, minor, false);
+	uint32_t n = 0;
+	if (minor == 3 && hdr + 4 <= out.size()) memcpy(&n, out.data() + hdr, 4);
+	return n;
+}
+
 void check_contexts(Context *const *cxs, int n)
 {
 	if (!cxs || n <= 0) throw Error(HRY_E_ARG, "need at least one context");
@@ -104,6 +116,176 @@ void check_contexts(Context *const *cxs, int n)
 }   // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The shards coded WHERE THEY LIE (round 4).  Until then a shard was a sub-mesh of its own (shard_extract: every face, half-edge
+// and vertex renumbered and copied, 0.1 s per 100 M triangles on top of a plan that indexed every element, and the bounds of
+// the whole mesh met behind a barrier between two phases): 8 contexts took 1.08 s for what one context did in 1.0 s.  Now
+//   * the plan is the analysis alone (components, coding order, groups, scans; host/shard.cpp: light);
+//   * beside it the first context scans the records of the WHOLE mesh for the bounds (one k_bounds: no combination, no barrier);
+//   * a worker fills its context's arrays -- sized for the whole mesh, in the whole mesh's numbering -- over the index intervals
+//     its shard's components lie in (a few long copies; what lies between two nearby intervals travels along, unused), and
+//     walks its components over the whole mesh's host arrays, all workers on ONE set of marks (components of different
+//     groups touch different faces and vertices);
+//   * the kernels neither know nor care: half-edge and vertex numbers are names, the stream holds none of them (explicit
+//     vertex names are decode-order indices, counted from the shard's first component).
+// The segments are byte for byte what the virtual ranks write from extracted sub-meshes (tests/test_gpu_shard.py).
+static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q, size_t nq, bool clear, int n_shards, int chunk_syms,
+                                    ByteSink &out, hry_shard_timing &st, bool store_bounds)
+{
+	const auto t_all = Clock::now();
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry shards] %8.2f ms  %s\n", ms_since(t_all), what); };
+	auto t0 = Clock::now();
+	if (m.twins_pending) cxs[0]->upload_mesh(m, false);   // a freshly read mesh: its half-edge twins are matched on the first context's device
+	ensure_twins(m);
+	st.twins_ms = ms_since(t0);
+	const int nl = (int)m.lists.size();
+	std::vector<char> had(nl, 0);
+	bool need_bounds = false;
+	for (int l = 0; l < nl; ++l) { had[l] = m.lists[l].have_bounds || m.lists[l].ncomp() == 0; need_bounds |= !had[l]; }
+	// ---- the bounds of the whole mesh on the first context, beside the plan on the host threads
+	Mesh bm;   // formats of the lists + (after the scan) the bounds; the records stay where they are
+	std::exception_ptr bounds_err;
+	double bounds_ms = 0;
+	std::thread bounds_thread;
+	if (need_bounds) {
+		bounds_thread = std::thread([&] {
+			try {
+				const auto tb = Clock::now();
+				Context &cx = *cxs[0];
+				HIP_OK(hipSetDevice(cx.device));
+				bm.lists.resize((size_t)nl);
+				for (int l = 0; l < nl; ++l) {
+					AttrList &D = bm.lists[l];
+					const AttrList &L = m.lists[l];
+					D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset; D.count = L.count;
+					D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = L.have_bounds;
+				}
+				device_bounds(cx, bm, &m);
+				bounds_ms = ms_since(tb);
+			} catch (...) { bounds_err = std::current_exception(); }
+		});
+	}
+	ShardPlan plan;
+	std::exception_ptr plan_err;
+	try { shard_plan(m, (uint32_t)n_shards, plan, true); } catch (...) { plan_err = std::current_exception(); }
+	st.plan_ms = ms_since(t0);
+	if (bounds_thread.joinable()) bounds_thread.join();
+	if (plan_err) std::rethrow_exception(plan_err);
+	if (bounds_err) std::rethrow_exception(bounds_err);
+	st.bounds_ms = bounds_ms;
+	mark("plan, bounds of the whole mesh");
+	st.n_shards = (uint32_t)n_shards; st.n_contexts = (uint32_t)n_ctx; st.n_components = plan.A.ncomp;
+	for (uint32_t k = 0; k < plan.A.ncomp; ++k) st.n_groups += plan.A.group[k] == k;
+	if (need_bounds && store_bounds)   // what the reference's reader leaves in the mesh (ply/reader.cc:428)
+		for (int l = 0; l < nl; ++l) if (!had[l]) { AttrList &L = m.lists[l]; L.bmin = bm.lists[l].bmin; L.bmax = bm.lists[l].bmax; L.bmin_at.clear(); L.bmax_at.clear(); L.have_bounds = true; }
+	const uint32_t ne = m.ne();
+	const uint32_t *eface = plan.udeg == 3 || plan.udeg == 4 ? nullptr : plan.A.eface.data();
+	if (!(plan.udeg == 3 || plan.udeg == 4) && plan.A.eface.size() != ne) {
+		// (a uniform degree other than 3 or 4: the analysis divides, the walk wants the table)
+		plan.A.eface.resize(ne);
+		for (uint32_t f = 0; f < m.nf; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) plan.A.eface[h] = f;
+		eface = plan.A.eface.data();
+	}
+	WalkState marks(m.nv, m.nf, host_threads());
+	mark("marks");
+
+	std::unique_ptr<ByteSink[]> parts(new ByteSink[(size_t)n_shards]);
+	std::vector<double> w_upload(n_ctx, 0.0), w_quant(n_ctx, 0.0), w_encode(n_ctx, 0.0);
+	t0 = Clock::now();
+	run_workers(cxs, n_ctx, [&](int w) {
+		Context &cx = *cxs[w];
+		HIP_OK(hipSetDevice(cx.device));
+		hry_timing acc{};
+		bool arrays_ready = false;
+		for (int s = w; s < n_shards; s += n_ctx) {
+			// ---- the shard: its components, its runs, the intervals it lies in
+			ComponentAnalysis part;
+			Mesh sk;   // the skeleton encode_chunked describes the segment with
+			shard_components(plan, (uint32_t)s, part, sk.shard);
+			std::vector<std::pair<uint32_t, uint32_t>> fiv, viv;
+			shard_intervals(plan, (uint32_t)s, 4096, fiv, viv);
+			for (const ShardRun &r : sk.shard.runs) { sk.nf += r.n_faces; sk.nv += r.n_vertices; }
+			sk.have_degree = m.have_degree;
+			for (int l = 0; l < 2; ++l) {
+				const AttrList &L = m.lists[l];
+				AttrList &D = sk.lists[l];
+				D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
+				D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
+				D.count = l == 0 ? sk.nf : sk.nv;
+				const AttrList &B = had[l] ? L : bm.lists[l];
+				D.bmin = B.bmin; D.bmax = B.bmax; D.have_bounds = true;
+			}
+			// ---- the whole mesh's arrays on this device, filled over the shard's intervals
+			auto t = Clock::now();
+			if (!arrays_ready) {
+				cx.d_org.ensure(std::max<size_t>((size_t)ne * 4, 16)); cx.d_twin.ensure(std::max<size_t>((size_t)ne * 4, 16));
+				cx.d_foff.ensure(((size_t)m.nf + 1) * 4);
+				for (int l = 0; l < 2; ++l) cx.d_rec[l].ensure(std::max<size_t>(m.lists[l].data.size(), 16));
+				int ud = 0;
+				cx.res_has_eface = !m.uniform_degree(ud);
+				cx.res_udeg = (uint32_t)ud;
+				if (cx.res_has_eface) cx.d_eface.ensure(std::max<size_t>((size_t)ne * 4, 16));
+				cx.res_nv = m.nv; cx.res_nf = m.nf; cx.res_ne = ne;
+				cx.resident_token = 0;
+				arrays_ready = true;
+			}
+			const size_t st0 = (size_t)m.lists[0].stride(), st1 = (size_t)m.lists[1].stride();
+			for (const auto &iv : fiv) {
+				const size_t h0 = m.face_off[iv.first], h1 = m.face_off[iv.second];
+				HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + iv.first, m.face_off.data() + iv.first, ((size_t)iv.second - iv.first + 1) * 4, hipMemcpyHostToDevice, cx.stream));
+				if (h1 > h0) {
+					HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + h0, m.org.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, cx.stream));
+					HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + h0, m.twin.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, cx.stream));
+				}
+				if (st0) HIP_OK(hipMemcpyAsync(cx.d_rec[0].as<uint8_t>() + iv.first * st0, m.lists[0].data.data() + iv.first * st0, ((size_t)iv.second - iv.first) * st0, hipMemcpyHostToDevice, cx.stream));
+				if (cx.res_has_eface) dev::launch_edge_faces(cx.stream, cx.d_foff.as<uint32_t>(), iv.second, cx.d_eface.as<uint32_t>(), iv.first);
+			}
+			if (st1) for (const auto &iv : viv)
+				HIP_OK(hipMemcpyAsync(cx.d_rec[1].as<uint8_t>() + iv.first * st1, m.lists[1].data.data() + iv.first * st1, ((size_t)iv.second - iv.first) * st1, hipMemcpyHostToDevice, cx.stream));
+			HIP_OK(hipStreamSynchronize(cx.stream));
+			w_upload[w] += ms_since(t);
+			// ---- quantisation of the records on the device, over the same intervals
+			t = Clock::now();
+			if (nq || clear) {
+				const std::vector<std::vector<uint8_t>> to = requant_targets(sk, q, nq, clear);
+				for (int l = 0; l < 2; ++l) {
+					AttrList &L = sk.lists[l];
+					if (to[l] == L.quant) continue;
+					const dev::RequantPlan rp = requant_plan(L, to[l]);
+					const size_t stl = (size_t)L.stride();
+					for (const auto &iv : l == 0 ? fiv : viv)
+						dev::launch_requant(cx.stream, cx.d_rec[l].as<uint8_t>() + iv.first * stl, iv.second - iv.first, (int)stl, rp);
+					L.quant = to[l];
+				}
+			}
+			w_quant[w] += ms_since(t);
+			t = Clock::now();
+			const InPlaceShard ip{ &m, &part, eface, &marks, &fiv };
+			encode_chunked(cx, sk, chunk_syms, parts[s], &ip);
+			w_encode[w] += ms_since(t);
+			const hry_timing &tm = cx.timing;
+			acc.host_walk_ms += tm.host_walk_ms; acc.h2d_ms += tm.h2d_ms; acc.device_ms += tm.device_ms; acc.d2h_ms += tm.d2h_ms;
+			acc.k_predict_ms += tm.k_predict_ms; acc.k_entropy_ms += tm.k_entropy_ms; acc.n_symbols += tm.n_symbols; acc.payload_bytes += tm.payload_bytes;
+			acc.total_ms += tm.total_ms;
+		}
+		cx.timing = acc;
+	});
+	st.phase_b_ms = ms_since(t0);
+	mark("segments");
+	t0 = Clock::now();
+	std::vector<const uint8_t*> pp;
+	std::vector<size_t> ps;
+	for (int s = 0; s < n_shards; ++s) { pp.push_back(parts[s].data()); ps.push_back(parts[s].size()); }
+	merge_containers(pp.data(), ps.data(), pp.size(), out);
+	st.merge_ms = ms_since(t0);
+	auto mx = [](const std::vector<double> &v) { double x = 0; for (double y : v) x = std::max(x, y); return x; };
+	st.extract_ms = mx(w_upload); st.quant_ms = mx(w_quant); st.encode_ms = mx(w_encode);
+	for (int w = 0; w < n_ctx; ++w) st.host_walk_ms = std::max(st.host_walk_ms, cxs[w]->timing.host_walk_ms);
+	st.n_segments = merged_segments(out);
+	st.total_ms = ms_since(t_all);
+	mark("one container");
+}
+
 void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q, size_t nq, bool clear, int n_shards, int chunk_syms,
                     ByteSink &out, hry_shard_timing &st, bool store_bounds)
 {
@@ -112,6 +294,7 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 	check_contexts(cxs, n_ctx);
 	if (n_shards <= 0) n_shards = n_ctx;
 	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh");
+	if (!m.general && !getenv("HRY_SHARD_EXTRACT")) { encode_sharded_in_place(cxs, n_ctx, m, q, nq, clear, n_shards, chunk_syms, out, st, store_bounds); return; }
 	// ---- plan, once
 	auto t0 = Clock::now();
 	// a freshly read mesh: its half-edge twins are matched on the first context's device (twins.hip: 0.3 ms per million triangles
@@ -198,8 +381,7 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 	auto mx = [](const std::vector<double> &v) { double x = 0; for (double y : v) x = std::max(x, y); return x; };
 	st.extract_ms = mx(w_extract); st.bounds_ms = mx(w_bounds); st.quant_ms = mx(w_quant); st.encode_ms = mx(w_encode);
 	for (int w = 0; w < n_ctx; ++w) st.host_walk_ms = std::max(st.host_walk_ms, cxs[w]->timing.host_walk_ms);
-	st.n_segments = 0;
-	for (int s = 0; s < n_shards; ++s) st.n_segments += parts[s].size() > 0;
+	st.n_segments = merged_segments(out);
 	st.total_ms = ms_since(t_all);
 }
 

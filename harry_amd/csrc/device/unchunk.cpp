@@ -672,31 +672,6 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), n_conn_streams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
 	                    cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>(), cx.d_csizes.as<uint32_t>());
 	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
-	// the attribute streams wait for the connectivity streams' kernel: launched side by side, the long attribute waves took
-	// the SIMD slots the short connectivity waves needed (15 ms instead of 1 ms on a 12 M-triangle mesh), and the host replay
-	// -- the critical path -- waits for exactly those
-	// ... unless the mesh takes the pipelined decode (one large component, triangles replayed at ~6 ns each): there the device
-	// chain, not the replay, ends the decode, and it can start only when the attribute streams are done -- side by side then
-	const bool chain_bound = !m->general && restarts.empty() && nsym[7] == 0 && vc == m->nv && unpredict3_covers(ldv);
-	const bool side_by_side = getenv("HRY_ATTR_SIDE_BY_SIDE") ? atoi(getenv("HRY_ATTR_SIDE_BY_SIDE")) != 0 : chain_bound;
-	HIP_OK(hipStreamWaitEvent(cx.stream3, side_by_side ? cx.ev_x[0] : cx.ev[2], 0));
-	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
-	{
-		uint32_t first = n_conn_streams;
-		for (int g = 0; g < Context::kAttrGroups; ++g) {
-			hipStream_t st = cx.attr_stream[g];
-			if (g) HIP_OK(hipStreamWaitEvent(st, side_by_side ? cx.ev_x[0] : cx.ev[2], 0));
-			launch_chunk_decode(st, cx.d_cjobs.as<StreamJob>() + first, group_n[g], cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
-			                    cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first);
-			HIP_OK(hipEventRecord(cx.attr_ev[g], st));
-			first += group_n[g];
-		}
-		// everything joins on stream3: "all attribute planes decoded"
-		for (int g = 1; g < Context::kAttrGroups; ++g) HIP_OK(hipStreamWaitEvent(cx.stream3, cx.attr_ev[g], 0));
-	}
-	HIP_OK(hipEventRecord(cx.ev[6], cx.stream3));
-	HIP_OK(hipEventRecord(cx.ev_x[1], cx.stream3));
-	if (trace_on()) { HIP_OK(hipEventSynchronize(cx.ev[2])); HRY_MARK(g_t0, "connectivity streams decoded"); }
 	// the connectivity planes come down into the context's pinned memory (one block, reused: fresh pageable vectors cost a zero
 	// fill, a page fault per 4 KiB and a staged copy -- 7 ms of a 51 ms decode on the configs[3] share)
 	PlaneView conn[kConnPlanes];
@@ -710,6 +685,36 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 			if (nsym[k]) HIP_OK(hipMemcpyAsync(dst, cx.d_csyms.as<uint8_t>() + plane_off[k], nsym[k], hipMemcpyDeviceToHost, cx.stream));
 		}
 	}
+	HIP_OK(hipEventRecord(cx.ev_x[2], cx.stream));        // the connectivity planes are on their way to the host
+	// the attribute streams wait for the connectivity streams' kernel: launched side by side, the long attribute waves took
+	// the SIMD slots the short connectivity waves needed (15 ms instead of 1 ms on a 12 M-triangle mesh), and the host replay
+	// -- the critical path -- waits for exactly those
+	// ... unless the mesh takes the pipelined decode (one large component, triangles replayed at ~6 ns each): there the device
+	// chain, not the replay, ends the decode, and it can start only when the attribute streams are done -- side by side then
+	const bool chain_bound = !m->general && restarts.empty() && nsym[7] == 0 && vc == m->nv && unpredict3_covers(ldv);
+	const bool side_by_side = getenv("HRY_ATTR_SIDE_BY_SIDE") ? atoi(getenv("HRY_ATTR_SIDE_BY_SIDE")) != 0 : chain_bound;
+	// ... and for the planes' copy to the host: beside 10^5 attribute waves the copy of the configs[3] mesh's 110 MB of connectivity
+	// planes took 20 ms instead of 5, in front of the replay (HRY_CONN_COPY_FIRST=0: the old order)
+	static const bool copy_first = !getenv("HRY_CONN_COPY_FIRST") || atoi(getenv("HRY_CONN_COPY_FIRST")) != 0;
+	hipEvent_t attr_after = side_by_side ? cx.ev_x[0] : copy_first ? cx.ev_x[2] : cx.ev[2];
+	HIP_OK(hipStreamWaitEvent(cx.stream3, attr_after, 0));
+	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
+	{
+		uint32_t first = n_conn_streams;
+		for (int g = 0; g < Context::kAttrGroups; ++g) {
+			hipStream_t st = cx.attr_stream[g];
+			if (g) HIP_OK(hipStreamWaitEvent(st, attr_after, 0));
+			launch_chunk_decode(st, cx.d_cjobs.as<StreamJob>() + first, group_n[g], cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
+			                    cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first);
+			HIP_OK(hipEventRecord(cx.attr_ev[g], st));
+			first += group_n[g];
+		}
+		// everything joins on stream3: "all attribute planes decoded"
+		for (int g = 1; g < Context::kAttrGroups; ++g) HIP_OK(hipStreamWaitEvent(cx.stream3, cx.attr_ev[g], 0));
+	}
+	HIP_OK(hipEventRecord(cx.ev[6], cx.stream3));
+	HIP_OK(hipEventRecord(cx.ev_x[1], cx.stream3));
+	if (trace_on()) { HIP_OK(hipEventSynchronize(cx.ev[2])); HRY_MARK(g_t0, "connectivity streams decoded"); }
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	const bool take_pipeline = !m->general && pipelined_decode_applicable(*m, restarts, conn, ldv, vc);
 	if (!take_pipeline) HIP_OK(hipStreamWaitEvent(cx.stream, cx.ev_x[1], 0));   // attribute planes before anything that reads them (the pipelined decode waits group by group)

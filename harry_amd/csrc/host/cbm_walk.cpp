@@ -26,10 +26,6 @@ namespace hry {
 namespace {
 
 constexpr uint32_t NONE32 = 0xffffffffu;
-// per-face / per-vertex marks of the walk.  Not character types (see OpByte in host.hpp): a byte store in the hot loop would
-// force every cached pointer and counter back through memory
-enum class Gone : uint8_t { no = 0, yes = 1 };
-typedef uint16_t OnCount;
 enum InitOp { I_INIT, I_TRI100, I_TRI010, I_TRI001, I_TRI110, I_TRI101, I_TRI011, I_TRI111, I_EOM };
 enum Op { O_BORDER, O_CONNBWD, O_SPLIT, O_UNION, O_NM, O_NEWVTX, O_CONNFWD, O_CLOSE };
 
@@ -372,17 +368,6 @@ struct Emitter {
 		else if (s == O_CONNFWD) { ++c_all; ++c_fwd[k]; }
 		else ++plain[s];
 	}
-};
-
-// Shared state of a walk: per-vertex and per-face marks.  Connected components touch disjoint faces, and disjoint
-// vertices unless they share a (non-manifold) vertex, so several components can be walked at the same time on
-// these arrays as long as components that share a vertex are walked in coding order by one thread.
-struct WalkState {
-	BigVec<Gone> gone;         // face consumed
-	BigVec<OnCount> on;        // how many border elements reference a vertex (cutborder.h:69)
-	BigVec<uint32_t> sent;     // original vertex -> transmitted index (encoder.h:28-52)
-	BigVec<uint16_t> seen;     // triangles seen per vertex (selects the op model class)
-	WalkState(uint32_t nv, uint32_t nf) : gone(nf, Gone::no), on(nv, 0), sent(nv, NONE32), seen(nv, 0) {}
 };
 
 // One connected component, starting at face f (encoder.h:68-214).  DEG > 0: every polygon has DEG edges and the face of a
@@ -801,6 +786,8 @@ static void walk_component_poly(Mesh &m, WalkState &st, const uint32_t *eface_ta
 
 template <int DEG>
 static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads);
+template <int DEG>
+static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads, const ComponentAnalysis &A);
 
 template <int DEG>
 static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, bool eval_op_model, unsigned n_threads)
@@ -931,6 +918,11 @@ static void atomic_min(std::atomic<uint32_t> &a, uint32_t v)
 	uint32_t cur = a.load(std::memory_order_relaxed);
 	while (v < cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
 }
+static void atomic_max(std::atomic<uint32_t> &a, uint32_t v)
+{
+	uint32_t cur = a.load(std::memory_order_relaxed);
+	while (v > cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+}
 
 // Component analysis shared by the multi-threaded walk (below) and the shard planner (shard.cpp).  The stream a sequential
 // walk produces is a function of (a) which faces form a component, (b) the order of the components = the order of their
@@ -941,7 +933,7 @@ static void atomic_min(std::atomic<uint32_t> &a, uint32_t v)
 template <int DEG>
 static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t *gone, const uint32_t *sent, unsigned n_threads, ComponentAnalysis &A)
 {
-	const uint32_t nf = m.nf, nv = m.nv, ne = m.ne();
+	const uint32_t nf = m.nf, nv = m.nv;
 	const uint32_t *org = m.org.data();
 	const uint32_t *twin = m.twin.data();
 	const uint32_t *foff = m.face_off.data();
@@ -1033,10 +1025,14 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 	if (!seeded) { seq.derive_order(); seq.index_blocks(); }
 	std::unique_ptr<std::atomic<uint64_t>[]> first_key(new std::atomic<uint64_t>[ncomp]);
 	std::unique_ptr<std::atomic<uint32_t>[]> nfaces(new std::atomic<uint32_t>[ncomp]), nhe(new std::atomic<uint32_t>[ncomp]);
-	for (uint32_t c = 0; c < ncomp; ++c) { first_key[c].store(~0ull, std::memory_order_relaxed); nfaces[c].store(0, std::memory_order_relaxed); nhe[c].store(0, std::memory_order_relaxed); }
+	std::unique_ptr<std::atomic<uint32_t>[]> flo(new std::atomic<uint32_t>[ncomp]), fhi(new std::atomic<uint32_t>[ncomp]);   // the interval of face indices a component lies in
+	for (uint32_t c = 0; c < ncomp; ++c) {
+		first_key[c].store(~0ull, std::memory_order_relaxed); nfaces[c].store(0, std::memory_order_relaxed); nhe[c].store(0, std::memory_order_relaxed);
+		flo[c].store(NONE32, std::memory_order_relaxed); fhi[c].store(0, std::memory_order_relaxed);
+	}
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(nf, t, b, e);
-		uint32_t run_c = NONE32, run_n = 0, run_he = 0;
+		uint32_t run_c = NONE32, run_n = 0, run_he = 0, run_first = 0, run_last = 0;
 		uint64_t run_min = ~0ull;
 		size_t span_at = 0;
 		auto flush = [&] {
@@ -1044,11 +1040,13 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 			if (!seeded) atomic_min(first_key[run_c], run_min);
 			nfaces[run_c].fetch_add(run_n, std::memory_order_relaxed);
 			nhe[run_c].fetch_add(run_he, std::memory_order_relaxed);
+			atomic_min(flo[run_c], run_first); atomic_max(fhi[run_c], run_last + 1);
 		};
 		for (uint32_t f = b; f < e; ++f) {
 			if (is_gone(f)) continue;
 			uint32_t c = comp[f];
-			if (c != run_c) { flush(); run_c = c; run_n = 0; run_he = 0; run_min = ~0ull; }
+			if (c != run_c) { flush(); run_c = c; run_n = 0; run_he = 0; run_min = ~0ull; run_first = f; }
+			run_last = f;
 			++run_n;
 			run_he += foff[f + 1] - foff[f];
 			// the reference takes face 0 first whatever the set's order (writer.cc:40-46)
@@ -1080,6 +1078,8 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 		A.n_faces[k] = nfaces[c].load(std::memory_order_relaxed);
 		A.n_halfedges[k] = nhe[c].load(std::memory_order_relaxed);
 	}
+	A.face_lo.resize(ncomp); A.face_hi.resize(ncomp);
+	for (uint32_t k = 0; k < ncomp; ++k) { A.face_lo[k] = flo[by_rank[k]].load(std::memory_order_relaxed); A.face_hi[k] = fhi[by_rank[k]].load(std::memory_order_relaxed); }
 	mark("coding order");
 	// (c) the first remaining component (in coding order) that touches each vertex: it introduces the vertex unless the part
 	// walked before already transmitted it.  Components that touch a common vertex are tied together: the vertex's index,
@@ -1114,22 +1114,31 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 	AtomicSets ties(ncomp);
 	for (uint32_t k = 0; k < ncomp; ++k) ties.parent[k].store(k, std::memory_order_relaxed);
 	for (const auto &notes : tie_notes) for (const auto &pr : notes) ties.unite(pr.first, pr.second);
-	std::unique_ptr<std::atomic<uint32_t>[]> fresh(new std::atomic<uint32_t>[ncomp]);
-	for (uint32_t k = 0; k < ncomp; ++k) fresh[k].store(0, std::memory_order_relaxed);
+	std::unique_ptr<std::atomic<uint32_t>[]> fresh(new std::atomic<uint32_t>[ncomp]), vlo(new std::atomic<uint32_t>[ncomp]), vhi(new std::atomic<uint32_t>[ncomp]);
+	for (uint32_t k = 0; k < ncomp; ++k) { fresh[k].store(0, std::memory_order_relaxed); vlo[k].store(NONE32, std::memory_order_relaxed); vhi[k].store(0, std::memory_order_relaxed); }
 	parallel_for(n_threads, [&](unsigned t) {
 		uint32_t b, e; split(nv, t, b, e);
-		uint32_t run_k = NONE32, run_n = 0;
+		uint32_t run_k = NONE32, run_n = 0, run_first = 0, run_last = 0;
+		auto flush = [&] {
+			if (run_k == NONE32) return;
+			fresh[run_k].fetch_add(run_n, std::memory_order_relaxed);
+			atomic_min(vlo[run_k], run_first); atomic_max(vhi[run_k], run_last + 1);   // the interval of vertex indices the component introduces
+		};
 		for (uint32_t v = b; v < e; ++v) {
 			uint32_t first = vfirst[v].load(std::memory_order_relaxed);
 			if (first == NONE32 || (sent && sent[v] != NONE32)) continue;
-			if (first != run_k) { if (run_k != NONE32) fresh[run_k].fetch_add(run_n, std::memory_order_relaxed); run_k = first; run_n = 0; }
+			if (first != run_k) { flush(); run_k = first; run_n = 0; run_first = v; }
+			run_last = v;
 			++run_n;
 		}
-		if (run_k != NONE32) fresh[run_k].fetch_add(run_n, std::memory_order_relaxed);
+		flush();
 	});
 	mark("  vertices counted");
-	A.fresh.resize(ncomp); A.group.resize(ncomp);
-	for (uint32_t k = 0; k < ncomp; ++k) { A.fresh[k] = fresh[k].load(std::memory_order_relaxed); A.group[k] = ties.find(k); }   // a root is the smallest rank of its group
+	A.fresh.resize(ncomp); A.group.resize(ncomp); A.vtx_lo.resize(ncomp); A.vtx_hi.resize(ncomp);
+	for (uint32_t k = 0; k < ncomp; ++k) {
+		A.fresh[k] = fresh[k].load(std::memory_order_relaxed); A.group[k] = ties.find(k);   // a root is the smallest rank of its group
+		A.vtx_lo[k] = vlo[k].load(std::memory_order_relaxed); A.vtx_hi[k] = vhi[k].load(std::memory_order_relaxed);
+	}
 	if (A.want_vertex_owner) {
 		A.vertex_owner.resize(nv);
 		parallel_for(n_threads, [&](unsigned t) { uint32_t b, e; split(nv, t, b, e); for (uint32_t v = b; v < e; ++v) A.vertex_owner[v] = vfirst[v].load(std::memory_order_relaxed); });
@@ -1142,11 +1151,9 @@ static void analyse_impl(const Mesh &m, const uint32_t *eface_tab, const uint8_t
 template <int DEG>
 static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads)
 {
-	WalkResult &w = em0.w;
 	const bool trace = getenv("HRY_TRACE") != nullptr;
 	auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
-	struct AtExit { decltype(mark) &mk; ~AtExit() { mk("temporaries released"); } } at_exit{ mark };
 	ComponentAnalysis A;
 	const ShardInfo &sh = m.shard;
 	const uint32_t shc = (uint32_t)sh.comp_faces.size();
@@ -1168,6 +1175,18 @@ static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab
 		mark("components taken from the shard's plan");
 	} else
 	analyse_impl<DEG>(m, eface_tab, (const uint8_t*)st.gone.data(), st.sent.data(), n_threads, A);
+	walk_components_parallel<DEG>(m, st, eface_tab, em0, first_id, n_threads, A);
+}
+
+// The components A lists (coding order: seed face, faces, half-edges, new vertices, group of every one), walked on several
+// threads into em0's WalkResult behind what it holds already; components of one group stay in coding order on one thread.
+template <int DEG>
+static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads, const ComponentAnalysis &A)
+{
+	WalkResult &w = em0.w;
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	auto t0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry walk] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	const uint32_t ncomp = A.ncomp;
 	const std::vector<uint32_t> &group_of = A.group;
 	std::vector<uint32_t> id_base(ncomp + 1);
@@ -1404,6 +1423,45 @@ void analyse_components(const Mesh &m, ComponentAnalysis &A)
 		for (uint32_t f = b; f < e; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface_tab[h] = f;
 	});
 	analyse_impl<0>(m, eface_tab.data(), nullptr, nullptr, nt, A);
+}
+
+WalkState::WalkState(uint32_t nv, uint32_t nf, unsigned n_threads)
+{
+	gone.resize(nf); on.resize(nv); sent.resize(nv); seen.resize(nv);
+	parallel_for(std::max(1u, n_threads), [&](unsigned t) {
+		const unsigned nt = std::max(1u, n_threads);
+		const size_t fb = (size_t)nf * t / nt, fe = (size_t)nf * (t + 1) / nt, vb = (size_t)nv * t / nt, ve = (size_t)nv * (t + 1) / nt;
+		if (fe > fb) memset((void*)(gone.data() + fb), 0, fe - fb);
+		if (ve > vb) { memset(on.data() + vb, 0, (ve - vb) * sizeof(OnCount)); memset(sent.data() + vb, 0xff, (ve - vb) * 4); memset(seen.data() + vb, 0, (ve - vb) * 2); }
+	});
+}
+
+void cut_border_walk_in_place(Mesh &m, const ComponentAnalysis &part, const uint32_t *eface, WalkState &st, WalkResult &w)
+{
+	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");
+	if (m.twins_pending) throw Error(HRY_E_ARG, "walk in place: the twins must be matched");
+	if (st.gone.size() != m.nf || st.sent.size() != m.nv) throw Error(HRY_E_ARG, "walk in place: marks of another mesh");
+	const uint32_t nc = part.ncomp;
+	if (part.seed.size() != nc || part.n_faces.size() != nc || part.n_halfedges.size() != nc || part.fresh.size() != nc || part.group.size() != nc)
+		throw Error(HRY_E_ARG, "walk in place: incomplete component list");
+	for (uint32_t k = 0; k < nc; ++k) if (part.seed[k] >= m.nf || part.group[k] > k) throw Error(HRY_E_ARG, "walk in place: component list out of range");
+	int udeg = 0, ndeg = 0;
+	if (!m.uniform_degree(udeg)) udeg = 0;
+	if (udeg != 3 && udeg != 4) { udeg = 0; if (!eface) throw Error(HRY_E_ARG, "walk in place: mixed polygon degrees need the half-edge -> face table"); }
+	for (uint8_t d : m.have_degree) ndeg += d ? 1 : 0;
+	w.numtri_coded = ndeg > 1;
+	Emitter em(w);
+	em.eval_model = false;
+	const unsigned nt = host_threads();
+	switch (udeg) {
+	case 3: walk_components_parallel<3>(m, st, nullptr, em, 0, nt, part); break;
+	case 4: walk_components_parallel<4>(m, st, nullptr, em, 0, nt, part); break;
+	default: walk_components_parallel<0>(m, st, eface, em, 0, nt, part); break;
+	}
+	em.finish_marks();
+	em.iop(I_EOM);
+	w.n_conn = em.n;
+	for (int i = 0; i < 8; ++i) w.n_op_class[i] = em.n_op[i];
 }
 
 void op_position_table(const WalkResult &w, std::vector<uint32_t> &thr, std::vector<uint32_t> &cum)

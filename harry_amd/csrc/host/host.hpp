@@ -96,6 +96,23 @@ struct WalkResult {
 	bool twins_changed = false;      // the walk repaired at least one twin (cbm/encoder.h:150,193-198): the device copy is stale
 };
 
+// per-face / per-vertex marks of the walk.  Not character types (see OpByte above): a byte store in the hot loop would force every
+// cached pointer and counter back through memory
+enum class Gone : uint8_t { no = 0, yes = 1 };
+typedef uint16_t OnCount;
+// Shared state of a walk: per-vertex and per-face marks.  Connected components touch disjoint faces, and disjoint
+// vertices unless they share a (non-manifold) vertex, so several components can be walked at the same time on
+// these arrays as long as components that share a vertex are walked in coding order by one thread -- also the shards of one
+// mesh by the workers of the in-process executor (device/sharded.cpp), which is why the type is public.
+struct WalkState {
+	BigVec<Gone> gone;         // face consumed
+	BigVec<OnCount> on;        // how many border elements reference a vertex (cutborder.h:69)
+	BigVec<uint32_t> sent;     // original vertex -> transmitted index (encoder.h:28-52)
+	BigVec<uint16_t> seen;     // triangles seen per vertex (selects the op model class)
+	WalkState(uint32_t nv, uint32_t nf) : gone(nf, Gone::no), on(nv, 0), sent(nv, 0xffffffffu), seen(nv, 0) {}
+	WalkState(uint32_t nv, uint32_t nf, unsigned n_threads);   // the same, filled by several threads
+};
+
 // ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
 // eval_op_model: the order-conditioned operation model of the reference stream evaluated per operation (op_l / op_h / op_t / op_pos);
 // the product evaluates it on the device (k_opmodel_*) and asks for one_sequence instead: positions of the connectivity groups in
@@ -114,11 +131,17 @@ struct ComponentAnalysis {
 	BigVec<uint32_t> comp;                       // per face: component number (arbitrary, dense)
 	std::vector<uint32_t> by_rank, rank_of;      // coding rank <-> component number
 	std::vector<uint32_t> seed, n_faces, n_halfedges, fresh, group;   // per coding rank; group = smallest rank tied to it
+	std::vector<uint32_t> face_lo, face_hi, vtx_lo, vtx_hi;   // per coding rank: the index intervals [lo, hi) its faces / the vertices it introduces lie in
 	bool want_vertex_owner = false;
 	BigVec<uint32_t> vertex_owner;               // per vertex: coding rank of the component that introduces it (0xffffffff: unused)
 	BigVec<uint32_t> eface;                      // mixed polygon degrees only: face of every half-edge (kept for the shard planner)
 };
 void analyse_components(const Mesh &m, ComponentAnalysis &A);
+// Some components of `m`, walked where they lie (no sub-mesh): `part` lists them in coding order (seed faces of m, sizes, the
+// vertices each introduces, groups as ranks inside the list); vertex indices start at 0 with the list's first component -- what a
+// shard of m codes (shard.cpp: shard_components).  `st` may be shared with other calls walking OTHER groups of the same mesh at
+// the same time; eface: the face of every half-edge for mixed polygon degrees (ComponentAnalysis::eface), else nullptr.
+void cut_border_walk_in_place(Mesh &m, const ComponentAnalysis &part, const uint32_t *eface, WalkState &st, WalkResult &out);
 
 // ---- shard.cpp: a mesh shards by groups of connected components
 struct ShardPlan {
@@ -134,13 +157,18 @@ struct ShardPlan {
 	std::vector<BigVec<uint32_t>> shard_faces, shard_vertices;   // per shard: its faces / vertices, ascending input index
 	std::vector<uint32_t> shard_ne;               // per shard: half-edges
 	int udeg = 0;                                 // the one polygon degree of the mesh, 0 = mixed (then A.eface holds the face of every half-edge)
+	bool light = false;                           // made without the per-element index (local_* / shard_* below are empty)
 	// general bindings: every list's records belong to the component that first names them (coding order); components that name
 	// a common record are tied into one group like components that share a vertex
 	std::vector<BigVec<uint32_t>> record_owner, local_record;       // per list, per record: coding rank of its component (0xffffffff: unnamed), index in its shard
 	std::vector<std::vector<BigVec<uint32_t>>> shard_records;       // per list, per shard: its records, ascending input index
 	std::vector<std::vector<uint32_t>> base_rec, fresh_rec;         // per list, per coding rank (+ end for the bases): place in the decoder's record numbering
 };
-void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan);
+// light: for shards that are coded where they lie in the whole mesh (shard_components + cut_border_walk_in_place: the in-process
+// executor) -- no per-element index, shard_extract refuses such a plan
+void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan, bool light = false);
+void shard_components(const ShardPlan &plan, uint32_t shard, ComponentAnalysis &part, ShardInfo &info);
+void shard_intervals(const ShardPlan &plan, uint32_t shard, uint32_t gap, std::vector<std::pair<uint32_t, uint32_t>> &faces, std::vector<std::pair<uint32_t, uint32_t>> &vertices);
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard);
 // several single- or multi-segment sharded containers (.hry v0.3) of the same mesh -> one
 void merge_containers(const uint8_t *const *parts, const size_t *sizes, size_t n, ByteSink &out);

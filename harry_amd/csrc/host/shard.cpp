@@ -38,7 +38,7 @@ struct Ranges {
 };
 }   // namespace
 
-void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
+void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan, bool light)
 {
 	if (n_shards == 0) throw Error(HRY_E_ARG, "need at least one shard");
 	if (m.nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
@@ -48,7 +48,8 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 	plan.g_nv = m.nv; plan.g_nf = m.nf; plan.g_ne = m.ne();
 	plan.have_degree = m.have_degree;
 	ComponentAnalysis &A = plan.A;
-	A.want_vertex_owner = true;
+	plan.light = light && !m.general;
+	A.want_vertex_owner = !plan.light;
 	const bool trace = getenv("HRY_TRACE") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry plan] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
@@ -150,6 +151,8 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 		plan.shard_triangles[plan.shard_of[k]] += (uint64_t)A.n_halfedges[k] - 2ull * A.n_faces[k];
 	}
 	mark("groups onto shards");
+	if (!m.uniform_degree(plan.udeg)) plan.udeg = 0;
+	if (plan.light) return;   // shards coded where they lie (shard_components): nobody asks where an element goes
 	// ---- where every face / half-edge / vertex goes: compact numbering per shard, ascending input index.  One pass over the mesh
 	// for ALL shards (thread ranges count per shard, a prefix over the ranges places them).
 	if (!m.uniform_degree(plan.udeg)) plan.udeg = 0;
@@ -216,9 +219,56 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
 	}
 }
 
+// The components of one shard for a walk of the whole mesh where it lies (cut_border_walk_in_place): seeds as faces of the whole
+// mesh, groups as ranks inside the list; and what the shard's segment says about itself (runs in the whole mesh's numbering).
+void shard_components(const ShardPlan &plan, uint32_t shard, ComponentAnalysis &part, ShardInfo &info)
+{
+	if (shard >= plan.n_shards) throw Error(HRY_E_ARG, "shard index out of range");
+	const ComponentAnalysis &A = plan.A;
+	const uint32_t nc = A.ncomp;
+	part = ComponentAnalysis();
+	info = ShardInfo();
+	info.g_nv = plan.g_nv; info.g_nf = plan.g_nf; info.g_ne = plan.g_ne;
+	std::vector<uint32_t> local_rank(nc, NONE32);
+	bool open = false;
+	for (uint32_t k = 0; k < nc; ++k) {
+		if (plan.shard_of[k] != shard) { open = false; continue; }
+		local_rank[k] = part.ncomp++;
+		part.seed.push_back(A.seed[k]); part.n_faces.push_back(A.n_faces[k]); part.n_halfedges.push_back(A.n_halfedges[k]); part.fresh.push_back(A.fresh[k]);
+		part.group.push_back(local_rank[A.group[k]]);   // (a group lies in one shard: its root is here too, and comes first)
+		if (!open) { info.runs.push_back(ShardRun{ plan.base_v[k], plan.base_f[k], plan.base_he[k], 0, 0, 0 }); open = true; }
+		ShardRun &r = info.runs.back();
+		r.n_vertices += A.fresh[k]; r.n_faces += A.n_faces[k]; r.n_halfedges += A.n_halfedges[k];
+	}
+	part.by_rank.resize(part.ncomp); part.rank_of.resize(part.ncomp);
+	for (uint32_t k = 0; k < part.ncomp; ++k) part.by_rank[k] = part.rank_of[k] = k;
+}
+
+// The index intervals of the whole mesh a shard's faces and vertices lie in, merged where they are less than `gap` elements apart
+// (a little of the neighbours travels along: harmless, and a few long copies beat thousands of short ones).
+void shard_intervals(const ShardPlan &plan, uint32_t shard, uint32_t gap, std::vector<std::pair<uint32_t, uint32_t>> &faces, std::vector<std::pair<uint32_t, uint32_t>> &vertices)
+{
+	const ComponentAnalysis &A = plan.A;
+	auto collect = [&](const std::vector<uint32_t> &lo, const std::vector<uint32_t> &hi, std::vector<std::pair<uint32_t, uint32_t>> &out) {
+		out.clear();
+		for (uint32_t k = 0; k < A.ncomp; ++k) if (plan.shard_of[k] == shard && lo[k] < hi[k]) out.push_back({ lo[k], hi[k] });
+		std::sort(out.begin(), out.end());
+		size_t n = 0;
+		for (const auto &iv : out) {
+			if (n && iv.first <= out[n - 1].second + gap) out[n - 1].second = std::max(out[n - 1].second, iv.second);
+			else out[n++] = iv;
+		}
+		out.resize(n);
+	};
+	if (A.face_lo.size() != A.ncomp || A.vtx_lo.size() != A.ncomp) throw Error(HRY_E_INTERNAL, "shard: plan without its intervals");
+	collect(A.face_lo, A.face_hi, faces);
+	collect(A.vtx_lo, A.vtx_hi, vertices);
+}
+
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard)
 {
 	ensure_twins(m);
+	if (plan.light) throw Error(HRY_E_ARG, "the plan was made for coding the shards in place: it has no element index");
 	if (shard >= plan.n_shards) throw Error(HRY_E_ARG, "shard index out of range");
 	if (plan.g_nv != m.nv || plan.g_nf != m.nf || plan.g_ne != m.ne() || plan.A.comp.size() != m.nf || plan.A.vertex_owner.size() != m.nv || plan.local_face.size() != m.nf)
 		throw Error(HRY_E_ARG, "the plan belongs to another mesh");

@@ -273,6 +273,10 @@ int hry_walk_run(hry_mesh *m, hry_walk **out);
 /* same walk without evaluating the operation model (what the chunked profile uses; then "op_l/op_h/op_t/op_pos" are empty and
  * components after the first may be walked on several host threads: HRY_HOST_THREADS, default min(16, cores)) */
 int hry_walk_run_plain(hry_mesh *m, hry_walk **out);
+/* host-only: the components of shard `shard` of a plan (hry_shard_plan), walked where they lie in the whole mesh -- what a worker
+ * of hry_encode_sharded does instead of walking an extracted sub-mesh: same symbols as hry_walk_run_plain of hry_shard_extract's
+ * mesh, "order_v" / "order_f" as half-edges of the WHOLE mesh.  Mutates the mesh's twins like hry_encode. */
+int hry_walk_run_shard(hry_mesh *m, const hry_plan *plan, int shard, hry_walk **out);
 size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr);
 void hry_walk_free(hry_walk *w);
 

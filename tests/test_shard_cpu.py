@@ -148,3 +148,42 @@ def test_container_check_is_host_only_and_rejects_garbage():
         hc.container_check(b"\xfa\xff\xaf\xaf\x00\x03" + b"\x00" * 8)
     with pytest.raises(hc.HryError):
         hc.container_check(b"not a container")
+
+
+@pytest.mark.parametrize("kind", ["tori", "mixed_nm", "quads_nm"])
+@pytest.mark.parametrize("n_shards", [1, 3, 8])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_shard_walked_in_place_equals_the_walk_of_its_extracted_mesh(kind, n_shards, threads, monkeypatch):
+    """hry_walk_run_shard: the components of a shard walked where they lie in the whole mesh (what a worker of the in-process
+    executor does since round 4) -- every symbol, position, count and mark equal to the walk of the extracted sub-mesh, the
+    coded vertices and faces the same corners of the same elements, the repaired twins the same edges."""
+    monkeypatch.setenv("HRY_HOST_THREADS", str(threads))
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
+    gen = _mesh(kind)
+    whole = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices)
+    plan = hc.ShardPlan(whole, n_shards)
+    foff_w = whole.face_offsets()
+    shards = [plan.extract(whole, s) for s in range(n_shards)]      # before any walk mutates the whole mesh's twins
+    place = whole.clone()
+    for s, sh in enumerate(shards):
+        if sh.nf == 0:
+            continue
+        fof = sh.shard_elements(0)
+        foff_s = sh.face_offsets()
+        sw = sh.host_walk(plain=True)
+        pw = plan.walk_in_place(place, s)
+        for k in sw:
+            if k in ("order_v", "order_f"):
+                f_loc = _face_of_halfedge(foff_s, sw[k])
+                want = foff_w[fof[f_loc]] + (sw[k] - foff_s[f_loc])     # the same half-edge in the whole mesh's numbering
+                assert np.array_equal(pw[k], want), (k, s)
+            elif k == "marks":
+                assert np.array_equal(pw[k], sw[k]), (k, s)
+            else:
+                assert np.array_equal(pw[k], sw[k]), (k, s)
+        # repaired twins: the shard's half-edges of the whole mesh now point where the extracted mesh's do
+        tw_s, tw_p = sh.twin(), place.twin()
+        he_w = np.concatenate([np.arange(foff_w[f], foff_w[f + 1]) for f in fof]) if len(fof) else np.zeros(0, np.int64)
+        f_loc = _face_of_halfedge(foff_s, tw_s)
+        want = foff_w[fof[f_loc]] + (tw_s - foff_s[f_loc])
+        assert np.array_equal(tw_p[he_w], want), s
