@@ -289,7 +289,7 @@ int hry_container_check(const uint8_t *hry, size_t n, int *complete)
 	});
 }
 int hry_mesh_partial(const hry_mesh *m) { return m && m->m.partial ? 1 : 0; }
-void hry_free(void *p) { free(p); }
+void hry_free(void *p) { BlockPool::give(p); }   // (a block of the recycling pool goes back to it, anything else to the C library)
 int hry_container_info(const uint8_t *hry, size_t n, uint32_t info[8])
 {
 	if (!hry || !info) { g_last_error = "null argument"; return HRY_E_ARG; }

@@ -122,6 +122,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	else cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	HRY_MARK(t_all, "walked");
+	if (in_place && in_place->arrays_ready) in_place->arrays_ready();
 
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	const ListDesc ldv = m.general ? ListDesc{} : make_list_desc(m.lists[1]), ldf = m.general ? ListDesc{} : make_list_desc(m.lists[0]);   // (general bindings: general_planes_encode)
@@ -151,13 +152,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
 	if (fc && (ldf.nplanes || m.general)) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));   // only the face planes read it
 	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
-	if (w.twins_changed && in_place) {
-		const Mesh &g = *in_place->whole;
-		for (const auto &iv : *in_place->face_intervals) {
-			const size_t h0 = g.face_off[iv.first], h1 = g.face_off[iv.second];
-			if (h1 > h0) HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + h0, g.twin.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, cx.stream));
-		}
-	} else if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
+	upload_repaired_twins(cx, in_place ? *in_place->whole : m, w);
 	size_t goff[G_COUNT + 1] = { 0 };
 	for (int g = 0; g < G_COUNT; ++g) {
 		size_t n = w.grp_val[g].size();

@@ -342,6 +342,29 @@ dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to)
 	return plan;
 }
 
+namespace dev { void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst); }
+// A walk repairs a handful of twins (non-manifold edges, neighbours consumed from the other side) -- the whole array went up for
+// them: 1.2 GB for the configs[3] mesh.  Now the entries the walk names go up as (half-edge, twin) pairs and are scattered.
+void upload_repaired_twins(Context &cx, const Mesh &host, const WalkResult &w)
+{
+	if (!w.twins_changed) return;
+	const size_t ne = host.ne(), np = w.twin_patches.size();
+	if (np == 0 || np > ne / 16) {
+		HIP_OK(hipMemcpyAsync(cx.d_twin.p, host.twin.data(), ne * 4, hipMemcpyHostToDevice, cx.stream));
+		return;
+	}
+	std::vector<uint32_t> &pairs = cx.h_twin_patch;
+	pairs.resize(2 * np);
+	for (size_t i = 0; i < np; ++i) {
+		const uint32_t h = w.twin_patches[i];
+		if (h >= ne) throw Error(HRY_E_INTERNAL, "walk: repaired twin out of range");
+		pairs[2 * i] = h; pairs[2 * i + 1] = host.twin[h];
+	}
+	cx.d_patch.ensure(pairs.size() * 4);
+	HIP_OK(hipMemcpyAsync(cx.d_patch.p, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, cx.stream));
+	dev::launch_scatter_u32(cx.stream, cx.d_patch.as<uint32_t>(), (uint32_t)np, cx.d_twin.as<uint32_t>());
+}
+
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear)
 {
 	HIP_OK(hipSetDevice(cx.device));
@@ -514,7 +537,7 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
 	if (fc) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));
 	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
-	if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));   // repaired twins (encoder.h:150,193-198)
+	upload_repaired_twins(cx, m, w);   // (encoder.h:150,193-198)
 	// connectivity groups: values + positions, packed back to back
 	size_t ngrp = 0;
 	for (int g = 0; g < G_COUNT; ++g) ngrp += w.grp_val[g].size();

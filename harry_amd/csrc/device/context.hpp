@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -91,6 +92,7 @@ struct Context {
 	       d_rec_sym, d_sym_l, d_r, d_s, d_state, d_acc, d_v, d_summary, d_bytes, d_small;
 	// chunked profile
 	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms, d_patch;
+	std::vector<uint32_t> h_twin_patch;   // (half-edge, twin) pairs on their way to d_patch (upload_repaired_twins)
 
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
@@ -152,6 +154,8 @@ void device_bounds(Context &cx, Mesh &m, const Mesh *records = nullptr);
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);
 std::vector<std::vector<uint8_t>> requant_targets(const Mesh &m, const hry_quant *q, size_t nq, bool clear);   // validated request -> quantisation of every component
 dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to);
+// the twins the walk repaired (cbm/encoder.h:150,193-198) into the resident copy: the few entries it names, else the whole array
+void upload_repaired_twins(Context &cx, const Mesh &host, const WalkResult &w);
 void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
 // A shard coded where it lies in the whole mesh (sharded.cpp: the in-process executor): the mesh handed to encode_chunked is a
 // SKELETON -- the shard's sizes, the lists' formats and bounds, its runs, no arrays; the context's connectivity and record arrays
@@ -163,6 +167,8 @@ struct InPlaceShard {
 	const uint32_t *eface;                                           // face of every half-edge of the whole mesh (mixed degrees), else nullptr
 	WalkState *marks;                                                // of the whole mesh; shared by the workers
 	const std::vector<std::pair<uint32_t, uint32_t>> *face_intervals;   // the shard's faces, as uploaded (repaired twins go up over the same intervals)
+	std::function<void()> arrays_ready;                              // called after the walk, before anything touches the device: returns when the
+	                                                                 // shard's intervals are in HBM (and quantised, if the caller quantises)
 };
 void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const InPlaceShard *in_place = nullptr);   // (bytes that are not zero-filled first and go to the caller as they are)
 void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out);   // general.cpp: regions, shared records, corner lists (reference stream only)

@@ -263,7 +263,7 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	uint32_t *d_rank = cx.d_rank.as<uint32_t>(), *d_frank = d_rank + m.nv;
 	if (vc) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
 	if (fc) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));
-	if (w.twins_changed) HIP_OK(hipMemcpyAsync(cx.d_twin.p, m.twin.data(), (size_t)m.ne() * 4, hipMemcpyHostToDevice, cx.stream));
+	upload_repaired_twins(cx, m, w);
 	size_t ngrp = 0;
 	for (int g = 0; g < G_COUNT; ++g) ngrp += w.grp_val[g].size();
 	const size_t nop = w.op_sc.size();

@@ -229,38 +229,56 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 				cx.resident_token = 0;
 				arrays_ready = true;
 			}
+			// (the copies run on a thread of their own, on a stream of their own: from pageable memory every copy keeps its caller
+			// until it is staged -- 126 ms per shard of the configs[3] mesh with eight workers on one link -- and the walk does not
+			// need the device; the main stream waits for the event before the kernels of this shard, see encode_chunked)
 			const size_t st0 = (size_t)m.lists[0].stride(), st1 = (size_t)m.lists[1].stride();
-			for (const auto &iv : fiv) {
-				const size_t h0 = m.face_off[iv.first], h1 = m.face_off[iv.second];
-				HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + iv.first, m.face_off.data() + iv.first, ((size_t)iv.second - iv.first + 1) * 4, hipMemcpyHostToDevice, cx.stream));
-				if (h1 > h0) {
-					HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + h0, m.org.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, cx.stream));
-					HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + h0, m.twin.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, cx.stream));
-				}
-				if (st0) HIP_OK(hipMemcpyAsync(cx.d_rec[0].as<uint8_t>() + iv.first * st0, m.lists[0].data.data() + iv.first * st0, ((size_t)iv.second - iv.first) * st0, hipMemcpyHostToDevice, cx.stream));
-				if (cx.res_has_eface) dev::launch_edge_faces(cx.stream, cx.d_foff.as<uint32_t>(), iv.second, cx.d_eface.as<uint32_t>(), iv.first);
-			}
-			if (st1) for (const auto &iv : viv)
-				HIP_OK(hipMemcpyAsync(cx.d_rec[1].as<uint8_t>() + iv.first * st1, m.lists[1].data.data() + iv.first * st1, ((size_t)iv.second - iv.first) * st1, hipMemcpyHostToDevice, cx.stream));
-			HIP_OK(hipStreamSynchronize(cx.stream));
-			w_upload[w] += ms_since(t);
-			// ---- quantisation of the records on the device, over the same intervals
-			t = Clock::now();
+			cx.ensure_second_stream();
+			// quantisation of the records happens on the device, over the same intervals, behind the copies; the skeleton announces it
+			struct ListPlan { int l; size_t stride; dev::RequantPlan plan; };
+			std::vector<ListPlan> rplans;
 			if (nq || clear) {
 				const std::vector<std::vector<uint8_t>> to = requant_targets(sk, q, nq, clear);
 				for (int l = 0; l < 2; ++l) {
 					AttrList &L = sk.lists[l];
 					if (to[l] == L.quant) continue;
-					const dev::RequantPlan rp = requant_plan(L, to[l]);
-					const size_t stl = (size_t)L.stride();
-					for (const auto &iv : l == 0 ? fiv : viv)
-						dev::launch_requant(cx.stream, cx.d_rec[l].as<uint8_t>() + iv.first * stl, iv.second - iv.first, (int)stl, rp);
+					rplans.push_back(ListPlan{ l, (size_t)L.stride(), requant_plan(L, to[l]) });
 					L.quant = to[l];
 				}
 			}
-			w_quant[w] += ms_since(t);
+			std::exception_ptr up_err;
+			double up_ms = 0;
+			std::thread uploader([&] {
+				try {
+					const auto tu = Clock::now();
+					HIP_OK(hipSetDevice(cx.device));
+					hipStream_t us = cx.stream2;
+					for (const auto &iv : fiv) {
+						const size_t h0 = m.face_off[iv.first], h1 = m.face_off[iv.second];
+						HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + iv.first, m.face_off.data() + iv.first, ((size_t)iv.second - iv.first + 1) * 4, hipMemcpyHostToDevice, us));
+						if (h1 > h0) {
+							HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + h0, m.org.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, us));
+							HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + h0, m.twin.data() + h0, (h1 - h0) * 4, hipMemcpyHostToDevice, us));
+						}
+						if (st0) HIP_OK(hipMemcpyAsync(cx.d_rec[0].as<uint8_t>() + iv.first * st0, m.lists[0].data.data() + iv.first * st0, ((size_t)iv.second - iv.first) * st0, hipMemcpyHostToDevice, us));
+						if (cx.res_has_eface) dev::launch_edge_faces(us, cx.d_foff.as<uint32_t>(), iv.second, cx.d_eface.as<uint32_t>(), iv.first);
+					}
+					if (st1) for (const auto &iv : viv)
+						HIP_OK(hipMemcpyAsync(cx.d_rec[1].as<uint8_t>() + iv.first * st1, m.lists[1].data.data() + iv.first * st1, ((size_t)iv.second - iv.first) * st1, hipMemcpyHostToDevice, us));
+					for (const ListPlan &rp : rplans)
+						for (const auto &iv : rp.l == 0 ? fiv : viv)
+							dev::launch_requant(us, cx.d_rec[rp.l].as<uint8_t>() + iv.first * rp.stride, iv.second - iv.first, (int)rp.stride, rp.plan);
+					HIP_OK(hipStreamSynchronize(us));
+					up_ms = ms_since(tu);
+				} catch (...) { up_err = std::current_exception(); }
+			});
+			struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{ uploader };
 			t = Clock::now();
-			const InPlaceShard ip{ &m, &part, eface, &marks, &fiv };
+			const InPlaceShard ip{ &m, &part, eface, &marks, &fiv, [&] {
+				uploader.join();
+				if (up_err) std::rethrow_exception(up_err);
+				w_upload[w] += up_ms;
+			} };
 			encode_chunked(cx, sk, chunk_syms, parts[s], &ip);
 			w_encode[w] += ms_since(t);
 			const hry_timing &tm = cx.timing;
@@ -358,7 +376,6 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 			Context &cx = *cxs[w];
 			auto t = Clock::now();
 			if (nq || clear) device_requant(cx, *shards[s], q, nq, clear);
-			w_quant[w] += ms_since(t);
 			t = Clock::now();
 			encode_chunked(cx, *shards[s], chunk_syms, parts[s]);
 			w_encode[w] += ms_since(t);

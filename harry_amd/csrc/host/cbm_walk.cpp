@@ -389,7 +389,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 		uint32_t fe = eface_tab[e];
 		return e + 1 == foff[fe + 1] ? foff[fe] : e + 1;
 	};
-	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; w.twins_changed = true; };
+	auto link = [&](uint32_t a, uint32_t b) { twin[a] = b; twin[b] = a; w.twins_changed = true; w.twin_patches.push_back(a); w.twin_patches.push_back(b); };
 	auto record_vertex = [&](uint32_t e) { *em.ov_cur++ = e; sent[org[e]] = next_id++; };
 	auto take = [&](uint32_t face) { gone[face] = Gone::yes; ++consumed; em.halfedges += foff[face + 1] - foff[face]; };
 
@@ -426,7 +426,7 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 			uint32_t t = twin[gate];
 			if (t == gate || gone[face_of(t)] != Gone::no) {   // writer.cc:48-58: mesh border or neighbour already consumed
 				Op bop = cb.border();
-				if (t != gate) { twin[gate] = gate; w.twins_changed = true; }   // one-sided split (writer.cc:81-84)
+				if (t != gate) { twin[gate] = gate; w.twins_changed = true; w.twin_patches.push_back(gate); }   // one-sided split (writer.cc:81-84)
 				em.op(bop, order);
 				continue;
 			}
@@ -517,6 +517,7 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 	uint32_t *ovc = em.ov_cur, *ofc = em.of_cur;
 	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, n_ops = 0;
 	bool changed = false;
+	std::vector<uint32_t> &tp = w.twin_patches;   // half-edges whose twin this walk changes (rare: non-manifold edges, consumed neighbours)
 	// HRY_WALK_PREFETCH: 0 none, 1 the twins of the triangle's other edges, 2 (default) + the faces behind them, 3 + their marks
 	// (1 M triangles: 7.8 -> 7.4 ms; 28 M, beyond the caches: 293 -> 237 ms)
 	static const int pf_level = [] { const char *e = getenv("HRY_WALK_PREFETCH"); return e ? atoi(e) : 2; }();
@@ -561,7 +562,7 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 		if (t == gate || gone[fc] != Gone::no) {   // writer.cc:48-58: mesh border or neighbour already consumed
 			const Op bop = cb.border();
 			P = cb.P;
-			if (t != gate) { twin[gate] = gate; changed = true; }   // one-sided split (writer.cc:81-84)
+			if (t != gate) { twin[gate] = gate; changed = true; tp.push_back(gate); }   // one-sided split (writer.cc:81-84)
 			emit(bop, order);
 			continue;
 		}
@@ -589,16 +590,16 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 			// connect forward (or close: the part is exactly this triangle); the triangle's last edge meets the next border edge
 			const bool close = pt.size == 3;
 			const uint32_t gatenext = P[hn].a;
-			if (twin[gatenext] != e2) { twin[gatenext] = e2; twin[e2] = gatenext; changed = true; }
+			if (twin[gatenext] != e2) { twin[gatenext] = e2; twin[e2] = gatenext; changed = true; tp.push_back(gatenext); tp.push_back(e2); }
 			if (close) {
 				const uint32_t gateprev = P[P[tn].prev].a;
-				if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; }
+				if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; tp.push_back(gateprev); tp.push_back(e1); }
 				cb.discard_top();
 			} else { cb.drop(cb.unlink_head(pt)); P[pt.tail].a = e1; }
 			emit(O_CONNFWD, order);
 		} else if (P[P[tn].prev].v == v2) {
 			const uint32_t gateprev = P[P[tn].prev].a;
-			if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; }
+			if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; tp.push_back(gateprev); tp.push_back(e1); }
 			cb.drop(cb.unlink_tail(pt));
 			P[pt.tail].a = e2;
 			emit(O_CONNBWD, order);
@@ -651,6 +652,7 @@ static void walk_component_poly(Mesh &m, WalkState &st, const uint32_t *eface_ta
 	uint32_t *ovc = em.ov_cur, *ofc = em.of_cur;
 	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, n_ops = 0;
 	bool changed = false;
+	std::vector<uint32_t> &tp = w.twin_patches;   // half-edges whose twin this walk changes (rare: non-manifold edges, consumed neighbours)
 	const bool nt_coded = w.numtri_coded;
 	auto face_of = [&](uint32_t e) -> uint32_t { return DEG ? e / (uint32_t)(DEG ? DEG : 1) : eface_tab[e]; };
 	auto emit = [&](uint32_t s, uint32_t order) {
@@ -699,7 +701,7 @@ static void walk_component_poly(Mesh &m, WalkState &st, const uint32_t *eface_ta
 			if (t == gate || gone[fc] != Gone::no) {   // writer.cc:48-58: mesh border or neighbour already consumed
 				const Op bop = cb.border();
 				P = cb.P;
-				if (t != gate) { twin[gate] = gate; changed = true; }   // one-sided split (writer.cc:81-84)
+				if (t != gate) { twin[gate] = gate; changed = true; tp.push_back(gate); }   // one-sided split (writer.cc:81-84)
 				emit(bop, order);
 				continue;
 			}
@@ -735,17 +737,17 @@ static void walk_component_poly(Mesh &m, WalkState &st, const uint32_t *eface_ta
 			const bool close = pt.size == 3;
 			if (curtri + 1 == ntri) {   // the polygon's last triangle: its last edge meets the next border edge
 				const uint32_t gatenext = P[hn].a;
-				if (twin[gatenext] != e2) { twin[gatenext] = e2; twin[e2] = gatenext; changed = true; }
+				if (twin[gatenext] != e2) { twin[gatenext] = e2; twin[e2] = gatenext; changed = true; tp.push_back(gatenext); tp.push_back(e2); }
 			}
 			if (close) {
 				const uint32_t gateprev = P[P[tn].prev].a;
-				if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; }
+				if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; tp.push_back(gateprev); tp.push_back(e1); }
 				cb.discard_top();
 			} else { cb.drop(cb.unlink_head(pt)); P[pt.tail].a = e1; }
 			emit(O_CONNFWD, order);
 		} else if (P[P[tn].prev].v == v2) {
 			const uint32_t gateprev = P[P[tn].prev].a;
-			if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; }
+			if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; tp.push_back(gateprev); tp.push_back(e1); }
 			cb.drop(cb.unlink_tail(pt));
 			P[pt.tail].a = e2;
 			emit(O_CONNBWD, order);
@@ -1320,7 +1322,10 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 		}
 	});
 	mark("operations and rare groups in coding order");
-	for (const PerThread &T : per_thread) if (T.w.twins_changed) w.twins_changed = true;
+	for (const PerThread &T : per_thread) {
+		if (T.w.twins_changed) w.twins_changed = true;
+		w.twin_patches.insert(w.twin_patches.end(), T.w.twin_patches.begin(), T.w.twin_patches.end());
+	}
 	// marks: one per component, with the counts of everything coded before it in the sequence
 	em0.finish_marks();
 	{

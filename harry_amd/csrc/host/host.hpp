@@ -94,6 +94,7 @@ struct WalkResult {
 	bool numtri_coded = false;       // false when a single polygon degree makes every numtri symbol an exact no-op
 	bool numtri_positions = true;    // in: fill grp_pos[G_NUMTRI] (one entry per face; only a single symbol sequence needs it)
 	bool twins_changed = false;      // the walk repaired at least one twin (cbm/encoder.h:150,193-198): the device copy is stale
+	std::vector<uint32_t> twin_patches;   // ... at these half-edges (with repetitions); their twins are final when the walk returns
 };
 
 // per-face / per-vertex marks of the walk.  Not character types (see OpByte above): a byte store in the hot loop would force every

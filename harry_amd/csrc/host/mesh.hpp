@@ -153,24 +153,34 @@ struct Bindings {
 	}
 };
 
-// Output bytes of the writers (PLY, OBJ): grows like a vector, but new bytes are not zero-filled (a 19 MB file is 4 600 fresh pages:
-// filling them once is enough) and the buffer can be handed to the C boundary as it is (malloc'ed: hry_free is free).
+// Output bytes of the writers (PLY, OBJ, containers): grows like a vector, but new bytes are not zero-filled (a 19 MB file is 4 600
+// fresh pages: filling them once is enough) and the buffer can be handed to the C boundary as it is.  Large buffers come from the
+// recycling pool like every other big array (a 290 MB container from the C library is 71 000 fresh pages per encode, faulted in
+// under the device's copy, and as many returned to the kernel by free: 80 ms of a 490 ms sharded encode of the configs[3] mesh);
+// BlockPool::give takes both kinds back, and so does hry_free.
 class ByteSink {
 	uint8_t *p_ = nullptr;
 	size_t n_ = 0, cap_ = 0;
+	static uint8_t *get(size_t c)
+	{
+		uint8_t *q = (uint8_t*)(c >= BlockPool::kMinBytes ? BlockPool::take(c) : malloc(c));
+		if (!q) throw std::bad_alloc();
+		return q;
+	}
 	void grow(size_t want)
 	{
 		size_t c = cap_ ? cap_ : 4096;
 		while (c < want) c += c / 2 + 4096;
-		uint8_t *q = (uint8_t*)realloc(p_, c);
-		if (!q) throw std::bad_alloc();
+		uint8_t *q = get(c);
+		if (n_) memcpy(q, p_, n_);
+		BlockPool::give(p_);
 		p_ = q; cap_ = c;
 	}
 public:
 	ByteSink() = default;
 	ByteSink(const ByteSink&) = delete;
 	ByteSink &operator=(const ByteSink&) = delete;
-	~ByteSink() { free(p_); }
+	~ByteSink() { BlockPool::give(p_); }
 	size_t size() const { return n_; }
 	bool empty() const { return n_ == 0; }
 	uint8_t *data() { return p_; }
@@ -184,7 +194,7 @@ public:
 	void push_back(uint8_t b) { if (n_ == cap_) grow(n_ + 1); p_[n_++] = b; }
 	template <typename It> void append(It b, It e) { const size_t k = (size_t)(e - b); if (n_ + k > cap_) grow(n_ + k); if (k) memcpy(p_ + n_, &*b, k); n_ += k; }
 	template <typename It> void assign(It b, It e) { n_ = 0; append(b, e); }
-	uint8_t *release(size_t *n) { uint8_t *q = p_ ? p_ : (uint8_t*)malloc(1); if (n) *n = n_; p_ = nullptr; n_ = cap_ = 0; return q; }   // the caller frees with free()
+	uint8_t *release(size_t *n) { uint8_t *q = p_ ? p_ : (uint8_t*)malloc(1); if (n) *n = n_; p_ = nullptr; n_ = cap_ = 0; return q; }   // the caller frees with BlockPool::give (hry_free)
 };
 
 struct Mesh {
