@@ -274,6 +274,116 @@ __global__ __launch_bounds__(64) void k_chunk_decode(const StreamJob *jobs, cons
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same decoder for the many-streams regime: ONE LANE per stream, 64 streams per wavefront (round 4).
+// k_chunk_decode spends a wavefront on a stream: 48 scalar + 28 vector instructions per symbol, and once there are eight waves
+// per SIMD the scalar port is the bound (configs[3]: 7.9 G symbols/s, 111 ms for the attribute planes of 100 M triangles).
+// Here a lane runs the reference's loop on its own stream (arith::Decoder<uint32_t>::decode, coder.h:134-153, with
+// stat_adaptive.h:55-82), so a wave instruction serves 64 symbols:
+//   * the table is two levels of COUNTS in LDS, entry e of lane l at word e * 64 + l (bank = lane: no conflicts): 16 block
+//     sums and 256 counts; the target min(t - 1, D / r) is looked up by two running sums of 16 (first the block, then the
+//     symbol in it) -- the Fenwick descent of the reference (stat_adaptive.h:55-72) flattened to two levels -- and the update
+//     is one add to the count and one to its block;
+//   * D / r: r = floor(R / t) < 2^24 once t > 128 and the quotient stays below 2^23, so a float reciprocal lands within two
+//     of it and four compare-and-adjust steps make it exact; r l and r (h - l) are 24-bit multiplies (<= R < 2^32);
+//   * the stream's bits: a 64-bit buffer per lane, topped up by four bytes whenever fewer than 32 bits are left (a
+//     renormalisation takes at most 31); bytes past the end read 0xFF (bitstream.h:27).
+// Streams whose table starts with t0 <= 128 (planes under 1024 symbols keep the reference's initial counts) stay with
+// k_chunk_decode: the host sorts them behind the others.  About 2.5 vector instructions per symbol instead of 76.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs, uint32_t njobs, const uint32_t *inits, const MagicEnt *magic,
+                                                           const uint8_t *payload, const unsigned long long *offsets, const uint32_t *nbytes)
+{
+	extern __shared__ uint32_t lds_tab[];
+	uint32_t *const cnt = lds_tab;               // [256][64]
+	uint32_t *const blk = lds_tab + 256 * 64;    // [16][64]
+	const uint32_t lane = threadIdx.x;
+	const uint32_t j = blockIdx.x * 64 + lane;
+	const bool have = j < njobs;
+	StreamJob jb{ nullptr, 0, 0, 256, 0 };
+	if (have) jb = jobs[j];
+	{
+		const uint32_t *st = inits + (size_t)jb.init * 256;
+		for (int b = 0; b < 16; ++b) {
+			uint32_t sum = 0;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				const uint32_t c = have ? st[b * 16 + k] : 0u;
+				cnt[(b * 16 + k) * 64 + lane] = c;
+				sum += c;
+			}
+			blk[b * 64 + lane] = sum;
+		}
+	}
+	const uint8_t *src = payload + (have ? offsets[j] : 0ull);
+	const uint32_t nby = have ? nbytes[j] : 0u;
+	auto byte_at = [&](uint32_t k) -> uint32_t { return k < nby ? src[k] : 0xffu; };
+	auto word_at = [&](uint32_t k) -> uint32_t {
+		if (k + 4 <= nby) { uint32_t raw; __builtin_memcpy(&raw, src + k, 4); return __builtin_bswap32(raw); }
+		return (byte_at(k) << 24) | (byte_at(k + 1) << 16) | (byte_at(k + 2) << 8) | byte_at(k + 3);
+	};
+	uint32_t D = word_at(0);   // coder.h:124-129
+	uint32_t p = 4;            // next unread byte of the stream
+	uint64_t buf = 0;          // unread bits, left-aligned
+	uint32_t avail = 0;
+	uint32_t R = 1u << 31, t = jb.t0;
+	uint8_t *out = const_cast<uint8_t*>(jb.sym);
+	uint32_t nmax = jb.n;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+	nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+	for (uint32_t i = 0; i < nmax; ++i) {
+		if (i >= jb.n) continue;
+		const MagicEnt me = magic[t];
+		const uint32_t r = __umulhi(R, me.m32) >> ((me.shift >> kMagicSh32Shift) & 31u);   // floor(R / t)
+		// target = min(t - 1, D / r)
+		uint32_t q = (uint32_t)((float)D * __builtin_amdgcn_rcpf((float)r));
+		int32_t rem = (int32_t)(D - __umul24(q, r));
+		if (rem < 0) { --q; rem += (int32_t)r; }
+		if (rem < 0) { --q; rem += (int32_t)r; }
+		if (rem >= (int32_t)r) { ++q; rem -= (int32_t)r; }
+		if (rem >= (int32_t)r) { ++q; rem -= (int32_t)r; }
+		const uint32_t target = min(t - 1u, q);
+		// the block: how many block sums stay at or below the target, and the count below that block
+		uint32_t run = 0, b = 0, lo = 0;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			run += blk[k * 64 + lane];
+			const bool le = run <= target;
+			b += le ? 1u : 0u;
+			lo = le ? run : lo;
+		}
+		// the symbol inside the block (target < t = the sum of all counts, so the block exists)
+		const uint32_t *cb = cnt + (size_t)(b * 16u) * 64 + lane;
+		uint32_t sin = 0;
+		run = lo;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			run += cb[k * 64];
+			const bool le = run <= target;
+			sin += le ? 1u : 0u;
+			lo = le ? run : lo;
+		}
+		const uint32_t s = b * 16u + sin;
+		const uint32_t cs = cnt[s * 64 + lane];   // (one more trip to LDS beats carrying "the first count that did not fit" through the scan)
+		// coder.h:140-153 with l = lo, h = lo + cs
+		const uint32_t rl = __umul24(r, lo);
+		const uint32_t Rn = lo + cs < t ? __umul24(r, cs) : R - rl;
+		const uint32_t y = Rn - 1u;
+		const uint32_t sh = y ? (uint32_t)__builtin_clz(y) - 1u : 31u;
+		R = Rn << sh;
+		if (avail < 32u) { buf |= (uint64_t)word_at(p) << (32u - avail); avail += 32u; p += 4u; }
+		const uint32_t bits = (uint32_t)((buf >> 1) >> (63u - sh));
+		buf <<= sh; avail -= sh;
+		D = ((D - rl) << sh) | bits;
+		// stat_adaptive.h:77-82
+		cnt[s * 64 + lane] = cs + 1u;
+		blk[b * 64 + lane] += 1u;
+		++t;
+		out[i] = (uint8_t)s;
+	}
+}
+
 // (index, value) pairs -> dst[index] = value (late twin links of the pipelined decode; the pairs are applied in order of
 // appearance only across launches -- inside one list an index occurs at most once per link, later pairs repeat the final value)
 __global__ __launch_bounds__(256) void k_scatter_u32(const uint32_t *pairs, uint32_t n, uint32_t *dst)
@@ -389,6 +499,16 @@ void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstream
                          const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes)
 {
 	if (nstreams) hipLaunchKernelGGL(k_chunk_decode, dim3(nstreams), dim3(64), 0, st, jobs, inits, magic, payload, (const unsigned long long*)offsets, nbytes, (uint8_t*)nullptr);
+}
+// a lane per stream (every job: t0 > 128): 64 streams per workgroup, 68 KB of tables in LDS
+void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
+                               const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes)
+{
+	if (!nstreams) return;
+	constexpr uint32_t kLds = (256 + 16) * 64 * 4;
+	static const bool raised = [] { return hipFuncSetAttribute((const void*)k_chunk_decode_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) == hipSuccess; }();
+	(void)raised;
+	hipLaunchKernelGGL(k_chunk_decode_lanes, dim3((nstreams + 63) / 64), dim3(64), kLds, st, jobs, nstreams, inits, magic, payload, (const unsigned long long*)offsets, nbytes);
 }
 
 }   // namespace dev

@@ -52,6 +52,8 @@ void launch_plane_hist(hipStream_t st, const HistSlice *slices, uint32_t nslices
 void launch_scatter_u8(hipStream_t st, const uint8_t *src, const uint32_t *dst_index, uint32_t n, uint8_t *dst);
 void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
                          const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes);
+void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
+                               const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes);   // one lane per stream; every job with t0 > 128
 
 }   // namespace dev
 }   // namespace hry

@@ -625,18 +625,23 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		else if (ng == 2) { kGroupEnd[0] = 1u << 17; kGroupEnd[1] = ~0ull; }
 	}
 	uint32_t group_n[Context::kAttrGroups] = { 0, 0, 0 };
+	// ... and inside a launch the streams a lane can decode (k_chunk_decode_lanes: t0 > 128) come first; lanes_n: how many
+	uint32_t conn_lanes_n = 0, group_lanes_n[Context::kAttrGroups] = { 0, 0, 0 };
 	{
 		std::vector<uint32_t> perm(jobs.size());
-		std::vector<uint8_t> grp(jobs.size(), 0);
+		std::vector<uint8_t> grp(jobs.size(), 0);   // 2 * group + (not for a lane)
 		for (size_t j = 0; j < jobs.size(); ++j) {
 			perm[j] = (uint32_t)j;
-			if (j < n_conn_streams) continue;
+			const uint8_t slow = jobs[j].t0 > 128u ? 0 : 1;
+			if (j < n_conn_streams) { grp[j] = slow; conn_lanes_n += !slow; continue; }
 			const uint64_t end = (uint64_t)(jobs[j].sym - (cx.d_csyms.as<uint8_t>() + plane_off[jobs[j].init])) + jobs[j].n;   // (init holds the plane index)
 			int g = 0;
 			while (end > kGroupEnd[g]) ++g;
-			grp[j] = (uint8_t)g;
+			grp[j] = (uint8_t)(2 * g + slow);
 			++group_n[g];
+			group_lanes_n[g] += !slow;
 		}
+		std::stable_sort(perm.begin(), perm.begin() + n_conn_streams, [&](uint32_t a, uint32_t b) { return grp[a] < grp[b]; });
 		std::stable_sort(perm.begin() + n_conn_streams, perm.end(), [&](uint32_t a, uint32_t b) { return grp[a] < grp[b]; });
 		std::vector<StreamJob> pj(jobs.size());
 		std::vector<uint32_t> pn(nbytes.size());
@@ -669,8 +674,17 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	}
 	HIP_OK(hipEventRecord(cx.ev_x[0], cx.stream));          // payload, jobs and tables are on the device
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
-	launch_chunk_decode(cx.stream, cx.d_cjobs.as<StreamJob>(), n_conn_streams, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(),
-	                    cx.d_cout.as<uint8_t>(), cx.d_coffs.as<uint64_t>(), cx.d_csizes.as<uint32_t>());
+	// a launch with thousands of streams takes the lane-per-stream kernel for those it can (HRY_DECODE_LANES: 0 never, 1 always)
+	static const int lanes_mode = [] { const char *e = getenv("HRY_DECODE_LANES"); return e ? atoi(e) : -1; }();
+	auto decode_streams = [&](hipStream_t st, uint32_t first, uint32_t n, uint32_t n_for_lanes) {
+		const bool lanes = lanes_mode == 0 ? false : lanes_mode > 0 ? true : n >= 2048u;
+		const uint32_t nl = lanes ? n_for_lanes : 0u;
+		if (nl) launch_chunk_decode_lanes(st, cx.d_cjobs.as<StreamJob>() + first, nl, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
+		                                  cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first);
+		if (n > nl) launch_chunk_decode(st, cx.d_cjobs.as<StreamJob>() + first + nl, n - nl, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
+		                                cx.d_coffs.as<uint64_t>() + first + nl, cx.d_csizes.as<uint32_t>() + first + nl);
+	};
+	decode_streams(cx.stream, 0, n_conn_streams, conn_lanes_n);
 	HIP_OK(hipEventRecord(cx.ev[2], cx.stream));
 	// the connectivity planes come down into the context's pinned memory (one block, reused: fresh pageable vectors cost a zero
 	// fill, a page fault per 4 KiB and a staged copy -- 7 ms of a 51 ms decode on the configs[3] share)
@@ -704,8 +718,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		for (int g = 0; g < Context::kAttrGroups; ++g) {
 			hipStream_t st = cx.attr_stream[g];
 			if (g) HIP_OK(hipStreamWaitEvent(st, attr_after, 0));
-			launch_chunk_decode(st, cx.d_cjobs.as<StreamJob>() + first, group_n[g], cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
-			                    cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first);
+			decode_streams(st, first, group_n[g], group_lanes_n[g]);
 			HIP_OK(hipEventRecord(cx.attr_ev[g], st));
 			first += group_n[g];
 		}
