@@ -280,10 +280,10 @@ __global__ __launch_bounds__(64) void k_chunk_decode(const StreamJob *jobs, cons
 // per SIMD the scalar port is the bound (configs[3]: 7.9 G symbols/s, 111 ms for the attribute planes of 100 M triangles).
 // Here a lane runs the reference's loop on its own stream (arith::Decoder<uint32_t>::decode, coder.h:134-153, with
 // stat_adaptive.h:55-82), so a wave instruction serves 64 symbols:
-//   * the table is two levels of COUNTS in LDS, entry e of lane l at word e * 64 + l (bank = lane: no conflicts): 16 block
-//     sums and 256 counts; the target min(t - 1, D / r) is looked up by two running sums of 16 (first the block, then the
-//     symbol in it) -- the Fenwick descent of the reference (stat_adaptive.h:55-72) flattened to two levels -- and the update
-//     is one add to the count and one to its block;
+//   * the table has two levels: 16 inclusive block sums in registers and the 256 COUNTS in LDS, entry e of lane l at word
+//     e * 64 + l (bank = lane: no conflicts); the target min(t - 1, D / r) is looked up by two scans of 16 (first the block,
+//     then the symbol in it by a running sum) -- the Fenwick descent of the reference (stat_adaptive.h:55-72) flattened to
+//     two levels -- and the update is one add to the count and one to every block sum from its block on;
 //   * D / r: r = floor(R / t) < 2^24 once t > 128 and the quotient stays below 2^23, so a float reciprocal lands within two
 //     of it and four compare-and-adjust steps make it exact; r l and r (h - l) are 24-bit multiplies (<= R < 2^32);
 //   * the stream's bits: a 64-bit buffer per lane, topped up by four bytes whenever fewer than 32 bits are left (a
@@ -296,23 +296,26 @@ __global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs
 {
 	extern __shared__ uint32_t lds_tab[];
 	uint32_t *const cnt = lds_tab;               // [256][64]
-	uint32_t *const blk = lds_tab + 256 * 64;    // [16][64]
 	const uint32_t lane = threadIdx.x;
 	const uint32_t j = blockIdx.x * 64 + lane;
 	const bool have = j < njobs;
 	StreamJob jb{ nullptr, 0, 0, 256, 0 };
 	if (have) jb = jobs[j];
+	// the block level lives in registers as inclusive cumulative sums (no trip to LDS for it: with one wave per SIMD -- a few
+	// thousand streams are a hundred waves -- every trip is waited for in full)
+	uint32_t C[16];
 	{
 		const uint32_t *st = inits + (size_t)jb.init * 256;
+		uint32_t sum = 0;
+#pragma unroll
 		for (int b = 0; b < 16; ++b) {
-			uint32_t sum = 0;
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				const uint32_t c = have ? st[b * 16 + k] : 0u;
 				cnt[(b * 16 + k) * 64 + lane] = c;
 				sum += c;
 			}
-			blk[b * 64 + lane] = sum;
+			C[b] = sum;
 		}
 	}
 	const uint8_t *src = payload + (have ? offsets[j] : 0ull);
@@ -323,19 +326,32 @@ __global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs
 		return (byte_at(k) << 24) | (byte_at(k + 1) << 16) | (byte_at(k + 2) << 8) | byte_at(k + 3);
 	};
 	uint32_t D = word_at(0);   // coder.h:124-129
-	uint32_t p = 4;            // next unread byte of the stream
+	uint32_t p = 8;            // first byte behind the word that waits in `ahead`
+	uint32_t ahead = word_at(4);   // the stream's next four bytes, asked for a refill early: the load is not waited for when it is needed
 	uint64_t buf = 0;          // unread bits, left-aligned
 	uint32_t avail = 0;
 	uint32_t R = 1u << 31, t = jb.t0;
-	uint8_t *out = const_cast<uint8_t*>(jb.sym);
+	typedef __attribute__((address_space(1))) uint8_t gbyte;   // (global, not generic: a flat store also counts as an LDS operation)
+	gbyte *out = (gbyte*)const_cast<uint8_t*>(jb.sym);
 	uint32_t nmax = jb.n;
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
 	nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+	MagicEnt me = magic[t];    // reciprocal of t, fetched a symbol ahead (t is known: t0 + position)
+	// decoded symbols leave sixteen at a time: a store per symbol has every later wait for a load wait for the store as well (one
+	// counter for both, in order) -- a round trip to memory per symbol, 124 ms for the configs[3] mesh's attribute planes instead of 30
+	uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;   // the last sixteen symbols, oldest in the lowest byte of o0
 	for (uint32_t i = 0; i < nmax; ++i) {
+		if ((i & 15u) == 0u && i) {   // (uniform: every lane stores the sixteen symbols before i, if it has that many)
+			if (i < jb.n) {   // (a stream that ends exactly here has stored its last sixteen itself, below)
+				typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+				typedef __attribute__((address_space(1))) u32x4 __attribute__((aligned(1))) gvec;
+				*(gvec*)(out + i - 16) = u32x4{ o0, o1, o2, o3 };
+			}
+		}
 		if (i >= jb.n) continue;
-		const MagicEnt me = magic[t];
 		const uint32_t r = __umulhi(R, me.m32) >> ((me.shift >> kMagicSh32Shift) & 31u);   // floor(R / t)
+		me = magic[t + 1u];
 		// target = min(t - 1, D / r)
 		uint32_t q = (uint32_t)((float)D * __builtin_amdgcn_rcpf((float)r));
 		int32_t rem = (int32_t)(D - __umul24(q, r));
@@ -345,42 +361,50 @@ __global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs
 		if (rem >= (int32_t)r) { ++q; rem -= (int32_t)r; }
 		const uint32_t target = min(t - 1u, q);
 		// the block: how many block sums stay at or below the target, and the count below that block
-		uint32_t run = 0, b = 0, lo = 0;
+		uint32_t b = 0, lo = 0;
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
-			run += blk[k * 64 + lane];
-			const bool le = run <= target;
+			const bool le = C[k] <= target;
 			b += le ? 1u : 0u;
-			lo = le ? run : lo;
+			lo = le ? C[k] : lo;
 		}
-		// the symbol inside the block (target < t = the sum of all counts, so the block exists)
+		// the symbol inside the block (target < t = the sum of all counts, so the block exists): the counts before it that fit,
+		// and the first running sum that does not (its difference to the last one that does is the symbol's count)
 		const uint32_t *cb = cnt + (size_t)(b * 16u) * 64 + lane;
-		uint32_t sin = 0;
-		run = lo;
+		uint32_t sin = 0, run = lo, hi = 0xffffffffu;
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			run += cb[k * 64];
 			const bool le = run <= target;
 			sin += le ? 1u : 0u;
 			lo = le ? run : lo;
+			hi = min(hi, le ? 0xffffffffu : run);
 		}
 		const uint32_t s = b * 16u + sin;
-		const uint32_t cs = cnt[s * 64 + lane];   // (one more trip to LDS beats carrying "the first count that did not fit" through the scan)
-		// coder.h:140-153 with l = lo, h = lo + cs
+		const uint32_t cs = hi - lo;
+		// coder.h:140-153 with l = lo, h = hi
 		const uint32_t rl = __umul24(r, lo);
-		const uint32_t Rn = lo + cs < t ? __umul24(r, cs) : R - rl;
+		const uint32_t Rn = hi < t ? __umul24(r, cs) : R - rl;
 		const uint32_t y = Rn - 1u;
 		const uint32_t sh = y ? (uint32_t)__builtin_clz(y) - 1u : 31u;
 		R = Rn << sh;
-		if (avail < 32u) { buf |= (uint64_t)word_at(p) << (32u - avail); avail += 32u; p += 4u; }
+		if (avail < 32u) { buf |= (uint64_t)ahead << (32u - avail); avail += 32u; ahead = word_at(p); p += 4u; }
 		const uint32_t bits = (uint32_t)((buf >> 1) >> (63u - sh));
 		buf <<= sh; avail -= sh;
 		D = ((D - rl) << sh) | bits;
 		// stat_adaptive.h:77-82
 		cnt[s * 64 + lane] = cs + 1u;
-		blk[b * 64 + lane] += 1u;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) C[k] += (uint32_t)k >= b ? 1u : 0u;
 		++t;
-		out[i] = (uint8_t)s;
+		o0 = __builtin_amdgcn_alignbyte(o1, o0, 1); o1 = __builtin_amdgcn_alignbyte(o2, o1, 1); o2 = __builtin_amdgcn_alignbyte(o3, o2, 1);
+		o3 = (o3 >> 8) | (s << 24);
+		if (i + 1u == jb.n) {   // the stream's last symbols: the ones no store of sixteen will take
+			const uint32_t m = jb.n & 15u ? jb.n & 15u : 16u;
+			auto shift = [&] { o0 = __builtin_amdgcn_alignbyte(o1, o0, 1); o1 = __builtin_amdgcn_alignbyte(o2, o1, 1); o2 = __builtin_amdgcn_alignbyte(o3, o2, 1); o3 >>= 8; };
+			for (uint32_t k = m; k < 16u; ++k) shift();
+			for (uint32_t k = 0; k < m; ++k) { out[jb.n - m + k] = (uint8_t)o0; shift(); }
+		}
 	}
 }
 
@@ -500,12 +524,12 @@ void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstream
 {
 	if (nstreams) hipLaunchKernelGGL(k_chunk_decode, dim3(nstreams), dim3(64), 0, st, jobs, inits, magic, payload, (const unsigned long long*)offsets, nbytes, (uint8_t*)nullptr);
 }
-// a lane per stream (every job: t0 > 128): 64 streams per workgroup, 68 KB of tables in LDS
+// a lane per stream (every job: t0 > 128): 64 streams per workgroup, 64 KB of counts in LDS
 void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
                                const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes)
 {
 	if (!nstreams) return;
-	constexpr uint32_t kLds = (256 + 16) * 64 * 4;
+	constexpr uint32_t kLds = 256 * 64 * 4;
 	static const bool raised = [] { return hipFuncSetAttribute((const void*)k_chunk_decode_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) == hipSuccess; }();
 	(void)raised;
 	hipLaunchKernelGGL(k_chunk_decode_lanes, dim3((nstreams + 63) / 64), dim3(64), kLds, st, jobs, nstreams, inits, magic, payload, (const unsigned long long*)offsets, nbytes);

@@ -5,6 +5,7 @@
 // Reference: formats/hry/reader.cc:179-193, cbm/decoder.h:27-211, attrcode.h:533-550.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -674,10 +675,23 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	}
 	HIP_OK(hipEventRecord(cx.ev_x[0], cx.stream));          // payload, jobs and tables are on the device
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
-	// a launch with thousands of streams takes the lane-per-stream kernel for those it can (HRY_DECODE_LANES: 0 never, 1 always)
+	// A launch takes the lane-per-stream kernel for the streams it can where that is the faster of the two (HRY_DECODE_LANES: 0
+	// never, 1 always).  Measured on MI355X: a wavefront alone on its SIMD issues an instruction every ~5.5 cycles, so a lane-per-
+	// stream wave takes ~1 900 cycles per step of 64 symbols however many waves there are (up to one per SIMD), and the wave-per-
+	// stream kernel ~420 cycles per symbol of a stream, ~190 per symbol and SIMD once several waves share a SIMD (scalar port):
+	// many short streams (connectivity planes: 16 000 streams of 16 Ki symbols for configs[3]: 26 -> 14 ms) go to the lanes, a few
+	// thousand long ones (its attribute planes: 5 200 streams of 128 Ki symbols) stay with a wave each.
 	static const int lanes_mode = [] { const char *e = getenv("HRY_DECODE_LANES"); return e ? atoi(e) : -1; }();
 	auto decode_streams = [&](hipStream_t st, uint32_t first, uint32_t n, uint32_t n_for_lanes) {
-		const bool lanes = lanes_mode == 0 ? false : lanes_mode > 0 ? true : n >= 2048u;
+		bool lanes = lanes_mode > 0;
+		if (lanes_mode < 0 && n_for_lanes >= 256u) {
+			uint64_t total = 0, longest = 0;
+			for (uint32_t j = first; j < first + n_for_lanes; ++j) { total += jobs[j].n; longest = std::max<uint64_t>(longest, jobs[j].n); }
+			const double simds = 1024.0, lane_waves = (n_for_lanes + 63) / 64;
+			const double t_waves = std::max((double)longest * 420.0, (double)total * 190.0 / simds);
+			const double t_lanes = (double)longest * 1900.0 * std::ceil(lane_waves / simds);
+			lanes = t_lanes < t_waves;
+		}
 		const uint32_t nl = lanes ? n_for_lanes : 0u;
 		if (nl) launch_chunk_decode_lanes(st, cx.d_cjobs.as<StreamJob>() + first, nl, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
 		                                  cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first);

@@ -1871,7 +1871,11 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 	};
 	// the ring + the rows of a tile's many-candidate vertices (64 x 24 words): 38 KB, four chains per compute unit (round 2's input
 	// queue made it 58 KB and two)
-	const uint32_t ring_bytes = 32 * 1024, lds_bytes = ring_bytes + 64 * kCandMax * 3 * 4;
+	// ... when there are more chains than that gives places for (256 compute units x 4), a ring of half the size lets seven share a
+	// compute unit: a chain is a lone wavefront that issues an instruction every five or six cycles, two of them on a SIMD hardly
+	// slow each other, and a source older than the ring is simply read from the records (HRY_CHAIN_RING_KB: 8, 16 or 32)
+	static const uint32_t ring_kb_env = [] { const char *e = getenv("HRY_CHAIN_RING_KB"); const int v = e ? atoi(e) : 0; return v == 8 || v == 16 || v == 32 ? (uint32_t)v : 0u; }();
+	const uint32_t ring_bytes = (ring_kb_env ? ring_kb_env : (uint64_t)n_lists * (uint32_t)ld.ncomp > 1024u ? 16u : 32u) * 1024u, lds_bytes = ring_bytes + 64 * kCandMax * 3 * 4;
 	auto go = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
