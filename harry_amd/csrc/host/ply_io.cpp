@@ -368,7 +368,11 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 		L.target = k;
 		layout_attr_list(names, types, isl, L, slot[k]);
 		L.count = (uint32_t)el.count;
-		L.data.assign((size_t)L.count * L.stride(), 0);
+		// (binary little-endian records of scalars only are copied whole below: zeros first were 60 ms per 600 MB of them)
+		bool whole = mode == 1;
+		for (const Prop &p : el.props) whole &= p.len_type == C_NONE;
+		if (whole) L.data.resize((size_t)L.count * L.stride());
+		else L.data.assign((size_t)L.count * L.stride(), 0);
 	}
 	m->nf = (uint32_t)elems[fi].count;
 	m->nv = (uint32_t)elems[vi].count;
@@ -379,6 +383,7 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 	m->org.reserve((size_t)m->nf * 3);
 
 	uint8_t scratch[8];
+	bool index_range_checked = false;   // (the threaded face paths check the indices as they copy them)
 	for (size_t ei = 0; ei < elems.size(); ++ei) {
 		const Element &el = elems[ei];
 		bool is_attr = (int)ei == fi || (int)ei == vi;
@@ -394,13 +399,21 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 			c.need(rec * (size_t)el.count);
 			bool ident = (int)rec == L->stride();
 			for (size_t i = 0; ident && i < el.props.size(); ++i) ident = L->offset[slot[k][i]] == src_off[i];
-			if (ident) memcpy(L->data.data(), c.p, rec * (size_t)el.count);
-			else
-				for (long j = 0; j < el.count; ++j) {
-					const uint8_t *s = c.p + rec * (size_t)j;
-					uint8_t *d = L->data.data() + (size_t)j * L->stride();
-					for (size_t i = 0; i < el.props.size(); ++i) memcpy(d + L->offset[slot[k][i]], s + src_off[i], kTypeSize[el.props[i].type]);
-				}
+			{
+				const size_t n = (size_t)el.count, stride = (size_t)L->stride();
+				const unsigned nt = rec * n >= ((size_t)16 << 20) ? std::max(1u, host_threads()) : 1u;
+				const uint8_t *base = c.p;
+				// (every slot of a record is a property of the element, rec == stride: no byte stays unwritten)
+				parallel_for(nt, [&](unsigned t) {
+					const size_t j0 = n * t / nt, j1 = n * (t + 1) / nt;
+					if (ident) { if (j1 > j0) memcpy(L->data.data() + j0 * rec, base + j0 * rec, (j1 - j0) * rec); return; }
+					for (size_t j = j0; j < j1; ++j) {
+						const uint8_t *s = base + rec * j;
+						uint8_t *d = L->data.data() + j * stride;
+						for (size_t i = 0; i < el.props.size(); ++i) memcpy(d + L->offset[slot[k][i]], s + src_off[i], kTypeSize[el.props[i].type]);
+					}
+				});
+			}
 			c.p += rec * (size_t)el.count;
 			continue;
 		}
@@ -442,26 +455,68 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 					if (m->have_degree.size() < 4) m->have_degree.resize(4, 0);
 					m->have_degree[3] = 1;
 					c.p += (size_t)nf * 13;
+					index_range_checked = true;
 					continue;
 				}
 			}
+			// Polygons of several degrees: where a record starts depends on every count byte before it.  One thread follows the
+			// count bytes alone (a load and an add per face) and leaves a mark every 32 Ki faces -- byte offset and half-edge
+			// offset -- then the blocks between the marks are checked and copied by the host threads, like the triangles above
+			// (the serial loop did everything per face: 1.1 s for the 78 M faces of the configs[3] mesh; round 4).
 			m->org.clear();
-			m->org.reserve((size_t)nf * 3);
-			size_t pos = 0;
-			for (uint32_t f = 0; f < nf; ++f) {
-				if (p >= c.end) throw Error(HRY_E_FORMAT, "truncated PLY");
-				const uint32_t len = *p++;
-				if (len < 3) throw Error(HRY_E_UNSUPPORTED, "polygon degree outside 3..255");
-				if ((size_t)(c.end - p) < (size_t)len * 4) throw Error(HRY_E_FORMAT, "truncated PLY");
-				if (len >= m->have_degree.size()) m->have_degree.resize(len + 1, 0);
-				m->have_degree[len] = 1;
-				m->org.resize(pos + len);
-				memcpy(m->org.data() + pos, p, (size_t)len * 4);
-				p += (size_t)len * 4;
-				pos += len;
-				m->face_off[f + 1] = (uint32_t)pos;
+			const uint32_t kBlock = 1u << 15;
+			const uint32_t nblk = (nf + kBlock - 1) / kBlock;
+			std::vector<size_t> blk_byte(nblk + 1), blk_he(nblk + 1);
+			{
+				size_t at = 0, he = 0;
+				for (uint32_t f = 0; f < nf; ++f) {
+					if ((f & (kBlock - 1)) == 0) { blk_byte[f / kBlock] = at; blk_he[f / kBlock] = he; }
+					if (at >= avail) throw Error(HRY_E_FORMAT, "truncated PLY");
+					const size_t len = p[at];
+					at += 1 + 4 * len;
+					he += len;
+				}
+				if (at > avail) throw Error(HRY_E_FORMAT, "truncated PLY");
+				if (he > 0xfffffff0ull) throw Error(HRY_E_UNSUPPORTED, "more than 2^32 polygon corners");
+				blk_byte[nblk] = at; blk_he[nblk] = he;
 			}
-			c.p = p;
+			m->org.resize(blk_he[nblk]);
+			{
+				const unsigned nt = nf >= (1u << 16) ? std::max(1u, host_threads()) : 1u;
+				std::atomic<uint32_t> next{ 0 };
+				std::atomic<int> bad{ 0 };   // 1: degree below 3, 2: index out of range
+				std::vector<std::vector<uint8_t>> seen(nt, std::vector<uint8_t>(256, 0));
+				uint32_t *org = m->org.data(), *foff = m->face_off.data();
+				parallel_for(nt, [&](unsigned t) {
+					std::vector<uint8_t> &have = seen[t];
+					for (;;) {
+						const uint32_t b = next.fetch_add(1, std::memory_order_relaxed);
+						if (b >= nblk) break;
+						const uint32_t f0 = b * kBlock, f1 = std::min(nf, f0 + kBlock);
+						const uint8_t *q = p + blk_byte[b];
+						size_t he = blk_he[b];
+						bool small = false, inside = true;
+						for (uint32_t f = f0; f < f1; ++f) {
+							const uint32_t len = *q++;
+							small |= len < 3;
+							have[len] = 1;
+							memcpy(org + he, q, (size_t)len * 4);
+							for (uint32_t k = 0; k < len; ++k) inside &= org[he + k] < nv;
+							q += (size_t)len * 4;
+							he += len;
+							foff[f + 1] = (uint32_t)he;
+						}
+						if (small) bad.store(1, std::memory_order_relaxed);
+						else if (!inside && bad.load(std::memory_order_relaxed) == 0) bad.store(2, std::memory_order_relaxed);
+					}
+				});
+				if (bad.load() == 1) throw Error(HRY_E_UNSUPPORTED, "polygon degree outside 3..255");
+				if (bad.load() == 2) throw Error(HRY_E_FORMAT, "PLY vertex index out of range");
+				for (unsigned t = 0; t < nt; ++t)
+					for (size_t d = 0; d < 256; ++d) if (seen[t][d]) { if (d >= m->have_degree.size()) m->have_degree.resize(d + 1, 0); m->have_degree[d] = 1; }
+			}
+			c.p = p + blk_byte[nblk];
+			index_range_checked = true;
 			continue;
 		}
 		for (long j = 0; j < el.count; ++j) {
@@ -483,7 +538,7 @@ Mesh *mesh_from_ply(const uint8_t *buf, size_t n)
 		}
 	}
 	if (m->face_off.size() != (size_t)m->nf + 1) throw Error(HRY_E_FORMAT, "PLY face count mismatch");
-	for (uint32_t v : m->org) if (v >= m->nv) throw Error(HRY_E_FORMAT, "PLY vertex index out of range");
+	if (!index_range_checked) for (uint32_t v : m->org) if (v >= m->nv) throw Error(HRY_E_FORMAT, "PLY vertex index out of range");
 	m->twins_pending = true;   // matched on the device at the first upload, or by ensure_twins
 	return m.release();
 }
@@ -692,7 +747,13 @@ void mesh_to_ply(const Mesh &m, bool ascii, ByteSink &out, bool packed)
 					for (int c = 0; c < LV.ncomp(); ++c) { const int k = kTypeSize[LV.stype(c)]; memcpy(w, rec + LV.offset[c], (size_t)k); w += k; }
 				}
 			}, near);
-		} else out.append(LV.data.begin(), LV.data.end());   // whole original-width records (writer.cc:72-75)
+		} else if (LV.data.size() >= ((size_t)16 << 20)) {   // whole original-width records (writer.cc:72-75), copied by the host threads
+			const size_t at = out.size(), n = LV.data.size();
+			out.resize(at + n);
+			const unsigned nt = std::max(1u, host_threads());
+			uint8_t *dst = out.data() + at;
+			parallel_for(nt, [&](unsigned t) { const size_t b = n * t / nt, e = n * (t + 1) / nt; if (e > b) memcpy(dst + b, LV.data.data() + b, e - b); });
+		} else out.append(LV.data.begin(), LV.data.end());
 		size_t fs = LF.stride();
 		int tri = 0;
 		if (!fs && m.uniform_degree(tri) && tri == 3 && m.nf >= (1u << 16)) {   // the usual file: 13-byte records, filled by a few threads
@@ -706,6 +767,31 @@ void mesh_to_ply(const Mesh &m, bool ascii, ByteSink &out, bool packed)
 				const uint32_t fb = (uint32_t)((uint64_t)nf * t / nt), fe = (uint32_t)((uint64_t)nf * (t + 1) / nt);
 				for (uint32_t f = fb; f < fe; ++f) { uint8_t *r = dst + (size_t)f * 13; r[0] = 3; memcpy(r + 1, org + (size_t)f * 3, 12); }
 			}, near);
+			return;
+		}
+		if (m.nf >= (1u << 16)) {
+			// polygons of several degrees (and face records): face f starts f count bytes, 4 face_off[f] index bytes and f face
+			// records into the element, so every thread knows where its faces go
+			size_t frec = fs;
+			if (fs && pf) { frec = 0; for (int c = 0; c < LF.ncomp(); ++c) frec += (size_t)kTypeSize[LF.stype(c)]; }
+			const size_t at = out.size();
+			const uint32_t nf = m.nf;
+			out.resize(at + (size_t)nf * (1 + frec) + 4 * (size_t)m.face_off[nf]);
+			uint8_t *dst = out.data() + at;
+			const uint32_t *org = m.org.data(), *foff = m.face_off.data();
+			const unsigned nt = std::max(1u, host_threads());
+			parallel_for(nt, [&](unsigned t) {
+				const uint32_t fb = (uint32_t)((uint64_t)nf * t / nt), fe = (uint32_t)((uint64_t)nf * (t + 1) / nt);
+				uint8_t *w = dst + (size_t)fb * (1 + frec) + 4 * (size_t)foff[fb];
+				for (uint32_t f = fb; f < fe; ++f) {
+					const uint32_t b = foff[f], e = foff[f + 1];
+					*w++ = (uint8_t)(e - b);
+					memcpy(w, org + b, 4 * (size_t)(e - b));
+					w += 4 * (size_t)(e - b);
+					if (fs && pf) { const uint8_t *rec = LF.data.data() + (size_t)f * fs; for (int c = 0; c < LF.ncomp(); ++c) { const int k = kTypeSize[LF.stype(c)]; memcpy(w, rec + LF.offset[c], (size_t)k); w += k; } }
+					else if (fs) { memcpy(w, LF.data.data() + (size_t)f * fs, fs); w += fs; }
+				}
+			});
 			return;
 		}
 		for (uint32_t f = 0; f < m.nf; ++f) {

@@ -395,3 +395,35 @@ def test_parallel_walk_in_a_forked_child(monkeypatch):
     _, status = os.waitpid(pid, 0)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     walk()
+
+
+# ---------------------------------------------------------------- PLY reader / writer on several threads, polygons of several degrees
+@pytest.mark.parametrize("threads", [1, 5])
+@pytest.mark.parametrize("face_props", [False, True])
+def test_polygon_ply_reader_and_writer_on_threads(threads, face_props, monkeypatch):
+    """host/ply_io.cpp: a binary little-endian file with polygons of several degrees is read block by block behind one pass over
+    the count bytes, and written with every thread knowing where its faces go (formats/ply/reader.cc:323-429, writer.cc:60-104):
+    same arrays as the generator holds, same bytes behind the header as the generator's own writer."""
+    monkeypatch.setenv("HRY_HOST_THREADS", str(threads))
+    gen = mg.with_nonmanifold(mg.torus(260, 250, polys="mixed", seed=11), 30, 20)
+    assert gen.nf >= 1 << 16
+    if face_props:
+        fp = np.zeros(gen.nf, dtype=[("quality", "<f4"), ("flags", "u1")])
+        fp["quality"] = np.arange(gen.nf, dtype=np.float32) * 0.25
+        fp["flags"] = np.arange(gen.nf) % 251
+        gen = mg.Mesh(gen.verts, gen.degrees, gen.indices, fp)
+    ply = gen.to_ply()
+    m = hc.Mesh.from_ply(ply)
+    assert np.array_equal(m.org(), gen.indices)
+    assert np.array_equal(np.diff(m.face_offsets()), gen.degrees)
+    body = lambda b: b[b.index(b"end_header\n") + 11:]
+    assert body(m.to_ply()) == body(ply)
+    # damaged input: an index out of range, a degree below 3, a truncated face element
+    bad = bytearray(ply)
+    at = len(ply) - len(body(ply)) + gen.nv * gen.verts.dtype.itemsize
+    if not face_props:
+        bad[at + 1:at + 5] = (gen.nv + 7).to_bytes(4, "little")
+        with pytest.raises(hc.HryError):
+            hc.Mesh.from_ply(bytes(bad))
+        with pytest.raises(hc.HryError):
+            hc.Mesh.from_ply(ply[:-9])
