@@ -39,6 +39,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def cpu_allowance():
+    """CPUs this process may keep busy: affinity mask and control-group quota (what harry_amd/csrc/host/thread_pool.cpp reads)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()
+        if a != "max":
+            n = max(1, min(n, int(int(a) / int(b))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def build_workload(n_side: int, seed: int):
     from harry_amd import meshgen as mg
     return mg.torus(n_side, n_side, seed=seed, sigma=1e-4)
@@ -224,10 +236,9 @@ def main():
             self_launch(args)
         return inprocess_main(args)
     stay_on_memory_node()
-    # host threads of the multi-component walks / replays: the library's default (32 on these hosts) is an eighth of the node, for
-    # eight ranks side by side; a rank that has the node to itself takes the cores of its socket
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "HRY_HOST_THREADS" not in os.environ:
-        os.environ["HRY_HOST_THREADS"] = str(max(8, min(64, len(os.sched_getaffinity(0)) // 2)))
+    # host threads of the multi-component walks / replays: the library's own choice -- the CPUs the process may keep busy (affinity
+    # mask and the control group's CPU quota: the one-GPU boxes of this pool show 256 CPUs and grant 16), shared with the other
+    # ranks of a launcher run (LOCAL_WORLD_SIZE).  Round 3 forced 64 threads here and ran into the quota's throttling.
 
     import torch
     import torch.distributed as dist
@@ -378,7 +389,7 @@ def main():
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 6) if roof["achieved"] else None
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
         # timed program; scripts/collect_profiles.sh collects FETCH_SIZE and WRITE_SIZE in their own passes on this workload)
-        for rnd in ("r3", "r2", "r1"):
+        for rnd in ("r4", "r3", "r2", "r1"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
                     tr = json.load(f)["kernels"]
@@ -403,7 +414,7 @@ def main():
             "dtype": "u8/u16 residual bytes, u32 range-coder registers (compat profile: u64)" if world == 1 else "u8 residual bytes of f32 values, u32 range-coder registers", "data": "synthetic",
             "config": {"workload": per_gpu if world == 1 else f"ONE mesh shaped like BASELINE configs[3] ({ntri} triangles, {n_comps} components, {n_groups} groups); per GPU: {per_gpu}; sharded by connected component",
                        "profile": profile, "decode_in_step": can_decode, "parallelism": f"component-sharded x{world}, one process per GPU", "inputs_resident": True,
-                       "host_threads": os.environ.get("HRY_HOST_THREADS", "library default (an eighth of the node, at most 32)")},
+                       "host_threads": os.environ.get("HRY_HOST_THREADS", "library default"), "cpus_allowed": cpu_allowance()},
             "encode_mtri_s": round(ntri * args.steps / t_enc / 1e6, 4),
             "decode_mtri_s": round(ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
             "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / max(base.nv, 1), 4),
@@ -427,6 +438,10 @@ def main():
             except Exception as exc:
                 sys.stderr.write(f"merged-container check failed: {exc}\n")
                 ok = False
+            line["mode"] = "launcher: one process per GPU (torch.distributed, backend below)"
+            incl = t_all + args.steps * (plan_ms + extract_ms) * 1e-3
+            line["value_including_plan"] = round(ntri * args.steps / incl / 1e6, 4)
+            line["value_including_plan_note"] = "every step charged with rank 0's plan + extract of its shard (timed once before the steps: the mesh is static input)"
             line["sharded"] = {"memory_node_of_rank0": list(gpu_node) if gpu_node else None, "rccl_ranks": rccl_ranks, "rccl_ranks_how": "all_reduce(ones) over the backend below", "plan_ms": round(plan_ms, 2), "extract_ms": round(extract_ms, 2),
                                "plan_extract_note": "every rank plans the whole mesh and extracts its own shard, once, before the timed steps (the mesh is static input); "
                                                     "the in-process executor's numbers include both",
@@ -449,6 +464,14 @@ def main():
                 line["sharded"]["one_gpu_same_shape_mtri_s"] = round(share.ntri / min(ts[1:]) / 1e6, 3)
                 line["sharded"]["weak_scaling_efficiency_vs_same_shape"] = round(value / (world * line["sharded"]["one_gpu_same_shape_mtri_s"]), 4)
                 del sm, share
+                # ... and the SAME mesh (all N x 128 components) through this one context: what N devices are to be compared with
+                ts = []
+                for _ in range(2):
+                    a = whole.clone(); cx.upload(a); torch.cuda.synchronize()
+                    t0 = time.perf_counter(); ob = cx.write_hry(a, profile=pid, as_buffer=True); cx.read_hry(ob); ts.append(time.perf_counter() - t0)
+                line["sharded"]["one_context_same_mesh_mtri_s"] = round(ntri / ts[-1] / 1e6, 3)
+                line["sharded"]["efficiency_vs_one_context"] = round(value / (world * line["sharded"]["one_context_same_mesh_mtri_s"]), 4)
+                line["sharded"]["speedup_vs_one_context"] = round(value / line["sharded"]["one_context_same_mesh_mtri_s"], 3)
             except Exception as exc:
                 sys.stderr.write(f"same-shape single-GPU leg failed: {exc}\n")
         # end to end, as the `harry in.ply out.hry -l1 -q14` / `harry out.hry back.ply` command lines see it: PLY bytes ->
@@ -490,7 +513,7 @@ def main():
             except Exception as exc:
                 sys.stderr.write(f"encode-from-host leg failed: {exc}\n")
         if world == 1 and not args.no_large and args.side == 708:
-            for name, leg in (("cfg3", cfg3_leg), ("cfg4_share", cfg4_share_leg)):
+            for name, leg in (("cfg3", cfg3_leg), ("cfg4_share", cfg4_share_leg), ("cfg4_end_to_end", cfg4_end_to_end_leg), ("cfg4_full", cfg4_full_leg)):
                 try:
                     line[name] = leg(cx)
                 except Exception as exc:
@@ -601,7 +624,9 @@ def inprocess_main(args):
     quant = []
     mesh = build_cfg4(world, args.comps_per_gpu)
     whole = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
-    whole.twin()                                          # half-edge twins matched before the timed region (the reader's job)
+    t0 = time.perf_counter()
+    whole.twin()                                          # half-edge twins matched before the timed region (the reader's job; reported as twins_ms)
+    twins_ms = (time.perf_counter() - t0) * 1e3
     mc = hc.MultiCodec(devices)
     ntri = mesh.ntri
     enc_s = dec_s = 0.0
@@ -622,11 +647,13 @@ def inprocess_main(args):
     t_begin = time.perf_counter()
     k_chain, k_entropy = [], []
     dec = None
+    per_ctx = []
     for _ in range(args.steps):
         merged, dec, te, td, a, b, tim_e, tim_d = one_step()
         enc_s += te; dec_s += td
         te_l.append(a); td_l.append(b)
         k_chain.append(max(t["k_chain_ms"] for t in tim_d)); k_entropy.append(max(t["k_entropy_ms"] for t in tim_e))
+        per_ctx.append([(e["host_walk_ms"], e["k_entropy_ms"], d["host_walk_ms"], d["k_chain_ms"], d["k_entropy_ms"]) for e, d in zip(tim_e, tim_d)])
     t_all = time.perf_counter() - t_begin
     medk = lambda L, k: round(float(np.median([x[k] for x in L])), 2)
     value = ntri * args.steps / t_all / 1e6
@@ -647,8 +674,30 @@ def inprocess_main(args):
     except Exception as exc:
         sys.stderr.write(f"merged-container check failed: {exc}\n")
         ok = False
+    # every context's own numbers (medians over the steps): the record shows that N devices worked
+    pc = np.median(np.array(per_ctx, dtype=np.float64), axis=0)
+    contexts = [{"context": i, "device": int(devices[i]), "encode_host_walk_ms": round(float(pc[i][0]), 2), "k_chunk_encode_ms": round(float(pc[i][1]), 3),
+                 "decode_host_replay_ms": round(float(pc[i][2]), 2), "k_unpredict2_float_ms": round(float(pc[i][3]), 3), "k_chunk_decode_ms": round(float(pc[i][4]), 3)} for i in range(world)]
+    # the same mesh through ONE context on the first device: what the N contexts are to be compared with
+    one_ctx = None
+    try:
+        cx1 = hc.Codec(devices[0])
+        ts = []
+        for _ in range(2):
+            a = whole.clone()
+            t0 = time.perf_counter(); ob = cx1.write_hry(a, profile=hc.PROFILE_CHUNKED, as_buffer=True); t1 = time.perf_counter(); cx1.read_hry(ob); ts.append((t1 - t0, time.perf_counter() - t1))
+        cx1.close()
+        one_ctx = {"value": round(ntri / sum(ts[-1]) / 1e6, 3), "encode_from_host_mtri_s": round(ntri / ts[-1][0] / 1e6, 3), "decode_mtri_s": round(ntri / ts[-1][1] / 1e6, 3)}
+    except Exception as exc:
+        sys.stderr.write(f"one-context leg failed: {exc}\n")
     line = {"metric": "Mtriangles/s encode+decode", "value": round(value, 4), "unit": "Mtriangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_all / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "mode": "in-process: ONE process, one worker thread + device context per GPU (hry_encode_sharded / hry_decode_sharded); no torch.distributed, no collective",
+            "twins_ms": round(twins_ms, 1), "twins_note": "half-edge twin matching of the freshly built mesh, on the host, once, before the steps (a reader's job)",
+            "contexts": contexts, "one_context_same_mesh": one_ctx,
+            "efficiency_vs_one_context": round(value / (world * one_ctx["value"]), 4) if one_ctx else None,
+            "speedup_vs_one_context": round(value / one_ctx["value"], 3) if one_ctx else None,
+            "cpus_allowed": cpu_allowance(),
             "dtype": "u8 residual bytes of f32 values, u32 range-coder registers", "data": "synthetic",
             "config": {"workload": f"ONE mesh shaped like BASELINE configs[3] ({ntri} triangles, {int(te_l[-1]['n_components'])} components); per GPU: {args.comps_per_gpu} mixed-polygon "
                                    f"components with non-manifold edges / vertices, {ntri // world} triangles, float32 xyz, lossless; sharded by connected component",
@@ -746,7 +795,9 @@ def cfg4_share_leg(cx):
     ntri = mesh.ntri
     alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
     traffic = traffic_raw = traffic_source = None
-    for rnd in ("r3",):   # the PMC passes of this very workload (scripts/collect_profiles.sh: leg cfg4share)
+    for rnd in ("r4", "r3"):   # the PMC passes of this very workload (scripts/collect_profiles.sh: leg cfg4share)
+        if traffic is not None:
+            break
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "cfg4share", "traffic.json")) as f:
                 hit = json.load(f)["kernels"]["k_unpredict2<float>"]
@@ -766,6 +817,129 @@ def cfg4_share_leg(cx):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (td["k_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if td["k_chain_ms"] > 0 else None,
                          "traffic": traffic, "traffic_raw": traffic_raw, "traffic_source": traffic_source},
             "round_trip_invariants_ok": ok, "passes": 2}
+
+
+def cfg4_end_to_end_leg(cx):
+    """One GPU's share of BASELINE configs[3] from file bytes to file bytes: a binary PLY with polygons of several degrees -> mesh
+    (parse on the host threads, twin matching on the device) -> .hry (chunked) -> mesh -> binary PLY.  What `harry in.ply out.hry`
+    and `harry out.hry back.ply` do between reading and writing their files (the 100 M-triangle mesh through the command itself:
+    profiles/r4/cfg4_e2e_100M.txt)."""
+    from harry_amd import codec as hc
+    mesh = build_cfg4(1)
+    ply = mesh.to_ply()
+    parse, enc, dec, wr = [], [], [], []
+    out, back = b"", b""
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = hc.Mesh.from_ply(ply)
+        t1 = time.perf_counter()
+        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED, as_buffer=True)
+        t2 = time.perf_counter()
+        d = cx.read_hry(out)
+        t3 = time.perf_counter()
+        back = d.to_ply()
+        t4 = time.perf_counter()
+        parse.append(t1 - t0); enc.append(t2 - t1); dec.append(t3 - t2); wr.append(t4 - t3)
+    ntri = mesh.ntri
+    # size-independent check: the PLY that comes back holds the same multiset of vertex records and as many faces of every degree
+    m0 = hc.Mesh.from_ply(ply)
+    mb = hc.Mesh.from_ply(back)
+    rec = lambda mm: np.sort(np.ascontiguousarray(mm.list_data(1)).view(np.dtype((np.void, 12))).reshape(-1))
+    nref = int(np.unique(m0.org()).size)
+    ok = bool((mb.nv, mb.nf, mb.ne) == (m0.nv, m0.nf, m0.ne) and np.array_equal(np.sort(np.diff(mb.face_offsets())), np.sort(np.diff(m0.face_offsets())))
+              and (nref < m0.nv or np.array_equal(rec(mb), rec(m0))))
+    p, e, dd, w = min(parse[1:]), min(enc[1:]), min(dec[1:]), min(wr[1:])
+    return {"workload": "one GPU's share of BASELINE configs[3] (128 mixed-polygon components, 0.1 % non-manifold edges, float32 xyz, lossless), file bytes to file bytes",
+            "triangles": int(ntri), "ply_bytes": len(ply), "hry_bytes": len(out),
+            "encode_mtri_s": round(ntri / (p + e) / 1e6, 3), "decode_mtri_s": round(ntri / (dd + w) / 1e6, 3),
+            "parse_ms": round(p * 1e3, 2), "parse_ms_per_mtri": round(p * 1e3 / (ntri / 1e6), 3), "encode_ms": round(e * 1e3, 2), "decode_ms": round(dd * 1e3, 2),
+            "ply_write_ms": round(w * 1e3, 2), "encode_includes": "twin matching on the device, upload, walk, kernels, container", "round_trip_invariants_ok": ok, "passes": 2}
+
+
+def cfg4_full_leg(cx):
+    """BASELINE configs[3] / [4] at the named size on ONE MI355X: 1 024 mixed-polygon components + 150 000 non-manifold slivers,
+    100.6 M triangles, float32 xyz, lossless.  One context (resident inputs, and from the host mesh), then eight contexts on this
+    one device through the in-process executor (hry_encode_sharded / hry_decode_sharded: what `harry --gpus 8` runs) -- the code
+    path of an 8-GPU node with one GPU's worth of hardware.  Size-independent checks only (the oracle needs two minutes:
+    tests/test_gpu_configs.py holds that check)."""
+    import resource
+    from harry_amd import codec as hc
+    try:
+        avail_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
+    except (ValueError, OSError):
+        avail_gb = 0
+    if avail_gb < 48:
+        return {"skipped": f"needs about 40 GB of host memory, {avail_gb:.0f} GB are free"}
+    t0 = time.perf_counter()
+    mesh = build_cfg4(8)
+    m0 = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    cx.upload(m0)                                         # (twin matching on the device; every clone below has its twins)
+    build_s = time.perf_counter() - t0
+    ntri = mesh.ntri
+    enc, dec, host, tms = [], [], [], []
+    out, d = b"", None
+    for _ in range(2):
+        m = m0.clone(); cx.upload(m)
+        t0 = time.perf_counter()
+        out = cx.write_hry(m, profile=hc.PROFILE_CHUNKED, as_buffer=True)
+        t1 = time.perf_counter()
+        te = cx.timing()
+        d = cx.read_hry(out)
+        t2 = time.perf_counter()
+        td = cx.timing()
+        m = m0.clone()
+        t3 = time.perf_counter()
+        cx.write_hry(m, profile=hc.PROFILE_CHUNKED, as_buffer=True)   # from the host mesh: the upload inside
+        t4 = time.perf_counter()
+        enc.append(t1 - t0); dec.append(t2 - t1); host.append(t4 - t3); tms.append((te, td))
+    rec = lambda mm: np.sort(np.ascontiguousarray(mm.list_data(1)).view(np.dtype((np.void, 12))).reshape(-1))
+    ok = bool((d.nv, d.nf, d.ne) == (m0.nv, m0.nf, m0.ne) and np.array_equal(np.sort(np.diff(d.face_offsets())), np.sort(np.diff(m0.face_offsets()))))
+    nref = int(np.unique(m0.org()).size)
+    ok = ok and (nref < m0.nv or bool(np.array_equal(rec(d), rec(m0))))
+    one = d
+    e, dd, eh = enc[-1], dec[-1], host[-1]
+    te, td = tms[-1]
+    alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
+    kc = td["k_chain_ms"]
+    res = {"workload": "BASELINE configs[3] / [4] at the named size: 1 024 mixed-polygon components (40 % quads, 5 % pentagons) + 150 000 non-manifold slivers, float32 xyz, lossless, ONE MI355X",
+           "triangles": int(ntri), "components": None, "build_s": round(build_s, 1), "cpus_allowed": cpu_allowance(),
+           "one_context": {"value": round(ntri / (e + dd) / 1e6, 3), "encode_mtri_s": round(ntri / e / 1e6, 3), "decode_mtri_s": round(ntri / dd / 1e6, 3),
+                           "encode_from_host_mtri_s": round(ntri / eh / 1e6, 3), "encode_ms": round(e * 1e3, 1), "encode_from_host_ms": round(eh * 1e3, 1), "decode_ms": round(dd * 1e3, 1),
+                           "host_walk_ms": round(te["host_walk_ms"], 1), "host_replay_ms": round(td["host_walk_ms"], 1), "k_unpredict2_float_ms": round(kc, 2),
+                           "k_chunk_encode_ms": round(te["k_entropy_ms"], 2), "k_chunk_decode_ms": round(td["k_entropy_ms"], 2), "hry_bytes": len(out),
+                           "bits_per_vertex": round(8 * len(out) / m0.nv, 3)},
+           "roofline": {"bound": "hbm", "kernel": "k_unpredict2<float>", "algorithmic_bytes_per_launch": alg, "kernel_ms": round(kc, 3),
+                        "achieved": round(alg / (kc * 1e-3) / 1e9, 3) if kc > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if kc > 0 else None, "traffic": None},
+           "round_trip_invariants_ok": ok, "passes": 2}
+    # eight contexts on this one device: plan, walk in place, interval uploads, one container -- and back
+    try:
+        mc = hc.MultiCodec([cx.device] * 8)
+        try:
+            se, sd, last_e, last_d, merged, md = [], [], None, None, b"", None
+            for _ in range(2):
+                m = m0.clone()
+                t0 = time.perf_counter()
+                merged = mc.write_hry(m, as_buffer=True)
+                t1 = time.perf_counter()
+                last_e = dict(mc.last)
+                md = mc.read_hry(merged)
+                t2 = time.perf_counter()
+                last_d = dict(mc.last)
+                se.append(t1 - t0); sd.append(t2 - t1)
+            same = bool(np.array_equal(md.org(), one.org()) and np.array_equal(md.list_data(1), one.list_data(1)) and np.array_equal(md.face_offsets(), one.face_offsets()))
+            res["eight_contexts_one_device"] = {"value": round(ntri / (se[-1] + sd[-1]) / 1e6, 3), "encode_mtri_s": round(ntri / se[-1] / 1e6, 3), "decode_mtri_s": round(ntri / sd[-1] / 1e6, 3),
+                                                "encode_ms": round(se[-1] * 1e3, 1), "decode_ms": round(sd[-1] * 1e3, 1), "hry_bytes": len(merged),
+                                                "encode_stage_ms": {k: round(last_e[k], 1) for k in ("twins_ms", "plan_ms", "extract_ms", "bounds_ms", "encode_ms", "merge_ms", "host_walk_ms", "total_ms")},
+                                                "decode_stage_ms": {"decode_ms": round(last_d["encode_ms"], 1), "place_ms": round(last_d["extract_ms"], 1), "host_replay_ms": round(last_d["host_walk_ms"], 1), "total_ms": round(last_d["total_ms"], 1)},
+                                                "encode_faster_than_one_context_from_host": bool(se[-1] < eh), "decodes_to_the_one_context_mesh": same,
+                                                "what": "hry_encode_sharded / hry_decode_sharded, from / to ONE host mesh (inputs not resident); extract_ms = the interval uploads beside the walks"}
+        finally:
+            mc.close()
+    except Exception as exc:
+        sys.stderr.write(f"cfg4_full: in-process leg failed: {exc}\n")
+    res["peak_rss_gb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20, 1)
+    return res
 
 
 def obj_leg(cx):

@@ -320,6 +320,7 @@ class Codec:
 
     def __init__(self, device: int = 0):
         self.h = C.c_void_p()
+        self.device = int(device)
         nat.check(nat.load().hry_ctx_create(device, C.byref(self.h)))
 
     def close(self):

@@ -227,3 +227,48 @@ def test_damaged_large_container_while_spans_upload(cx, cfg4_share):
         same_mesh(cx.read_hry(good), ref_dec)
     finally:
         del os.environ["HRY_NO_SPAN_UPLOAD"]
+
+
+@pytest.mark.timeout(900)
+def test_cfg3_cfg4_named_size_100m_one_context_and_eight(cx):
+    """configs[3] / [4] at the size BASELINE names: 1 024 mixed-polygon components + 150 000 non-manifold slivers, 100.6 M triangles,
+    float32 xyz, lossless.  One context: the chunked container decodes to what the oracle decodes from ITS reference-format stream
+    of the same mesh (the oracle is byte-pinned to the reference binary on the committed fixtures).  Eight contexts on this one
+    device through the in-process executor (shards coded where they lie in the whole mesh): the merged container equals the eight
+    virtual ranks' (extracted sub-meshes, one after the other on one context) byte for byte and decodes -- whole, on eight
+    contexts -- to the same mesh.  About three minutes, two of them the oracle on one core."""
+    _need_memory(96)
+    gen = mg.multi_component(1024, 221, 222, seed=4, polys="mixed")
+    gen = mg.with_nonmanifold(gen, n_edges=max(1, gen.ntri // 1000), n_vtx=max(1, gen.ntri // 2000))
+    assert gen.ntri > 100_000_000
+    m0 = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices)
+    cx.upload(m0)                                                    # twin matching on the device; every clone has its twins
+    one = cx.write_hry(m0.clone(), profile=hc.PROFILE_CHUNKED, as_buffer=True)
+    dec = cx.read_hry(one)
+    mc = hc.MultiCodec([0] * 8)
+    try:
+        merged = mc.write_hry(m0.clone(), as_buffer=True)
+        assert mc.last["n_segments"] == 8 and mc.last["n_components"] > 150_000
+        mdec = mc.read_hry(merged)
+    finally:
+        mc.close()
+    same_mesh(mdec, dec)
+    del mdec
+    # the same shards as sub-meshes of their own, one after the other on ONE context (what eight ranks would each do)
+    whole = m0.clone()
+    plan = hc.ShardPlan(whole, 8)
+    parts = []
+    tabs = []
+    shards = [plan.extract(whole, s) for s in range(8)]
+    tabs = [sharding.shard_bounds(cx, sh) for sh in shards]
+    for sh in shards:
+        sharding.combine_bounds(tabs, sh)
+        parts.append(cx.write_hry(sh, profile=hc.PROFILE_CHUNKED))
+    assert hc.merge(parts) == merged
+    del shards, parts, whole, plan, merged
+    # the oracle: reference-format stream of the same PLY, decoded by the oracle
+    o = op.Mesh.from_ply(gen.to_ply())
+    ref = op.Mesh.from_hry(o.encode().data)
+    assert np.array_equal(dec.face_offsets(), ref.face_offsets())
+    assert np.array_equal(dec.org(), ref.org())
+    assert np.array_equal(dec.list_data(1), ref.list_data(1))
