@@ -170,7 +170,12 @@ class NativeBuffer:
         return self.n
 
     def view(self) -> memoryview:
-        return memoryview((C.c_ubyte * self.n).from_address(self.ptr)).cast("B") if self.n else memoryview(b"")
+        """zero-copy view; it keeps this object (and so the library's buffer) alive for as long as it exists"""
+        if not self.n:
+            return memoryview(b"")
+        arr = (C.c_ubyte * self.n).from_address(self.ptr)
+        arr._owner = self          # the view holds the array, the array holds the owner of the pointer
+        return memoryview(arr).cast("B")
 
     def tobytes(self) -> bytes:
         return C.string_at(self.ptr, self.n)

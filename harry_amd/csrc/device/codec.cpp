@@ -517,7 +517,7 @@ void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	write_hry_header(m, 1, out);
 	auto t_walk = Clock::now();
 	WalkResult w;
-	cut_border_walk(m, w, false, true);   // one symbol sequence; the operation model is evaluated on the device (k_opmodel_*)
+	cut_border_walk(m, w, false);   // the operation model is evaluated on the device (k_opmodel_*), the groups' places in the ONE symbol sequence come out of the walk -- also from its threads (cbm_walk.cpp: the components' pieces are put in coding order)
 	cx.timing.host_walk_ms = ms_since(t_walk);
 
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();

@@ -52,7 +52,7 @@ void launch_faces_unfold(hipStream_t st, uint32_t n, const ListDesc &ld, uint8_t
 bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                   const std::vector<uint32_t> &seg_level, const std::vector<uint8_t> &vplanes, const uint8_t *d_vplanes = nullptr);   // unchunk.cpp
 bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order);                                                                             // unchunk.cpp
-void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
+void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const Mesh &conn, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                       const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, long long trace_origin);                    // unchunk.cpp
 long long trace_origin_ns();                                                                                                                          // unchunk.cpp
 
@@ -246,7 +246,7 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	write_hry_header(m, 1, out);
 	auto t_walk = Clock::now();
 	WalkResult w;
-	cut_border_walk(m, w, false, true);   // one symbol sequence; the operation model is evaluated on the device (k_opmodel_*)
+	cut_border_walk(m, w, false);   // the operation model is evaluated on the device (k_opmodel_*), the groups' places in the ONE symbol sequence come out of the walk -- also from its threads (cbm_walk.cpp: the components' pieces are put in coding order)
 	Events E;
 	collect_events(m, w, w.n_conn, E);
 	cx.timing.host_walk_ms = ms_since(t_walk);
@@ -676,12 +676,19 @@ void general_planes_decode(Context &cx, Mesh &m, const OrderVec &order_v, const 
 	if (m.bind.nregs_vtx() == 1 && m.bind.nvtxlists(0) == 1 && !getenv("HRY_GENERIC_VERTEX") && !order_v.empty()) {
 		const int l = m.bind.vtxlist(0, 0);
 		if (hp.lists[l].n_data == order_v.size() && m.lists[l].coded_bytes() > 0 && vertex_list_fast_applicable(m, l, order_v.size())) fast_l = l;
+		// ... and from its reference kinds: every vertex must create its record (kind DATA).  A damaged stream whose data plane merely
+		// has the right length would otherwise get a whole device reconstruction before the reader refuses it.
+		if (fast_l >= 0) {
+			const GenHostPlanes::L &P = hp.lists[l];
+			bool all_data = P.n_type == order_v.size() && P.type != nullptr;
+			for (uint32_t i = 0; all_data && i < P.n_type; ++i) all_data = P.type[i] == 0;
+			if (!all_data) fast_l = -1;
+		}
 	}
 	if (fast_l < 0) read_general_planes(m, order_v, hp, ev);
 	else {
 		Mesh t;
-		t.nv = m.nv; t.nf = m.nf; t.declared_ne = m.declared_ne; t.have_degree = m.have_degree;
-		t.face_off = m.face_off; t.org = m.org; t.twin = m.twin;
+		t.nv = m.nv; t.nf = m.nf; t.declared_ne = m.declared_ne; t.have_degree = m.have_degree;   // (the connectivity itself is lent: both threads only read it)
 		{
 			BigVec<uint8_t> held;
 			held.swap(m.lists[fast_l].data);
@@ -691,7 +698,7 @@ void general_planes_decode(Context &cx, Mesh &m, const OrderVec &order_v, const 
 		std::exception_ptr chain_error, reader_error;
 		const long long origin = trace_origin_ns();
 		std::thread chain([&] {
-			try { reconstruct_vertex_list_detached(cx, t, order_v, seg_start, seg_level, d_syms + plane_off[data_plane0[fast_l]], origin); }
+			try { reconstruct_vertex_list_detached(cx, t, m, order_v, seg_start, seg_level, d_syms + plane_off[data_plane0[fast_l]], origin); }
 			catch (...) { chain_error = std::current_exception(); }
 		});
 		try { read_general_planes(m, order_v, hp, ev); } catch (...) { reader_error = std::current_exception(); }

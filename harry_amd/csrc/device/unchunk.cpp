@@ -55,9 +55,11 @@ static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0
 
 // Attribute reconstruction on the device, shared by both formats: connectivity + decode order + residual byte planes
 // (already in HBM) -> attribute records.  Events 3/4 bracket the kernels.
+// conn_from: the connectivity (face offsets, origins, twins) is read from that mesh instead -- one that another thread may be
+// READING at the same time (general_planes_decode: the host's bookkeeping runs beside the vertex chain)
 static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                    const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
-                                   const ListDesc &ldv, const ListDesc &ldf, bool conn_resident = false)
+                                   const ListDesc &ldv, const ListDesc &ldf, bool conn_resident = false, const Mesh *conn_from = nullptr)
 {
 	Mesh *m = &mesh;
 	const uint32_t nvc = (uint32_t)order_v.size();
@@ -66,7 +68,10 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 	// connectivity up (unless it went up beside the replay: SpanUploader); the records are born on the device (zeroed there:
 	// uploading the host's zeros was a fifth of this copy)
 	if (conn_resident) cx.adopt_conn(*m);
-	else cx.upload_mesh(*m, false);
+	else if (conn_from) {
+		if (conn_from->twins_pending || conn_from->partial) throw Error(HRY_E_INTERNAL, "lent connectivity must be complete");
+		cx.upload_mesh(const_cast<Mesh&>(*conn_from), false);   // (a mesh whose twins are matched is only read)
+	} else cx.upload_mesh(*m, false);
 	for (size_t l = 0; l < m->lists.size() && l < 2; ++l) {
 		cx.d_rec[l].ensure(std::max<size_t>(m->lists[l].data.size(), 16));
 		if (!m->lists[l].data.empty()) HIP_OK(hipMemsetAsync(cx.d_rec[l].p, 0, m->lists[l].data.size(), cx.stream));
@@ -817,20 +822,21 @@ bool reconstruct_vertex_list_fast(Context &cx, Mesh &m, int l, const OrderVec &o
 }
 
 // The same for a caller that keeps working on the mesh meanwhile (general_planes_decode: the host's bookkeeping of the other lists
-// runs beside the vertex chain): `t` holds COPIES of the connectivity and the vertex list's records (moved in by the caller, moved
-// back by it afterwards); nothing of `m` is touched.  Runs on the calling thread, which may be a helper.
+// runs beside the vertex chain): `t` holds the sizes and the vertex list's records (moved in by the caller, moved back by it
+// afterwards); the connectivity is read from `conn` -- lent, not copied: both threads only read it.  Runs on the calling thread,
+// which may be a helper.
 long long trace_origin_ns() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(g_t0.time_since_epoch()).count(); }   // of the calling thread's decode
 bool vertex_list_fast_applicable(const Mesh &m, int l, size_t n_order)
 {
 	const ListDesc ldv = make_list_desc(m.lists[l]);
 	return ldv.nplanes && unpredict2_applicable(ldv) && m.lists[l].count >= n_order;
 }
-void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
+void reconstruct_vertex_list_detached(Context &cx, Mesh &t, const Mesh &conn, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                       const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, long long trace_origin)
 {
 	HIP_OK(hipSetDevice(cx.device));
 	g_t0 = Clock::time_point(std::chrono::duration_cast<Clock::duration>(std::chrono::nanoseconds(trace_origin)));   // (this thread's copy: HRY_TRACE's timeline)
-	reconstruct_attributes(cx, t, order_v, seg_start, seg_level, d_vplanes, nullptr, make_list_desc(t.lists[1]), make_list_desc(t.lists[0]));
+	reconstruct_attributes(cx, t, order_v, seg_start, seg_level, d_vplanes, nullptr, make_list_desc(t.lists[1]), make_list_desc(t.lists[0]), false, &conn);
 }
 
 // Reference format (.hry v0.1): the single adaptive stream is decoded and replayed on a host core (the format makes

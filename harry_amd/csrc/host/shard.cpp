@@ -547,9 +547,20 @@ void parse_sharded_directory(const uint8_t *p, size_t n, size_t hdr, uint32_t gn
 				else if (r.n_halfedges || r.n_vertices) throw Error(HRY_E_FORMAT, "corrupt sharded container (run without faces)");
 			}
 		std::sort(byf.begin(), byf.end(), [](const ShardRun *a, const ShardRun *b) { return a->first_face < b->first_face; });
-		for (size_t i = 1; i < byf.size(); ++i)
-			if ((uint64_t)byf[i - 1]->first_halfedge + byf[i - 1]->n_halfedges > byf[i]->first_halfedge)
+		for (size_t i = 1; i < byf.size(); ++i) {
+			const uint64_t he_end = (uint64_t)byf[i - 1]->first_halfedge + byf[i - 1]->n_halfedges;
+			if (he_end > byf[i]->first_halfedge)
 				throw Error(HRY_E_FORMAT, "corrupt sharded container (faces and half-edges of the runs are ordered differently)");
+			// runs that follow each other without a face between them leave no half-edge between them either: a half-edge no
+			// face owns would end up inside the polygon in front of it when a partial mesh is filled up
+			if ((uint64_t)byf[i - 1]->first_face + byf[i - 1]->n_faces == byf[i]->first_face && he_end != byf[i]->first_halfedge)
+				throw Error(HRY_E_FORMAT, "corrupt sharded container (half-edges between two runs that no face owns)");
+		}
+		if (!byf.empty()) {   // the same at both ends of the mesh
+			if (byf.front()->first_face == 0 && byf.front()->first_halfedge != 0) throw Error(HRY_E_FORMAT, "corrupt sharded container (half-edges in front of the first face)");
+			if ((uint64_t)byf.back()->first_face + byf.back()->n_faces == gnf && (uint64_t)byf.back()->first_halfedge + byf.back()->n_halfedges != gne)
+				throw Error(HRY_E_FORMAT, "corrupt sharded container (half-edges behind the last face)");
+		}
 	}
 	if (list_counts)   // the record ranges of a list must not overlap either
 		for (size_t l = 0; l < list_counts->size(); ++l) {
