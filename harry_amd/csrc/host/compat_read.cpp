@@ -12,7 +12,6 @@
 #include "cbm_replay.hpp"
 
 #include <cstring>
-#include <immintrin.h>
 
 namespace hry {
 namespace {
@@ -70,75 +69,41 @@ struct Decoder {
 	}
 };
 
-// Adaptive frequency table over <= 256 symbols (same cumulative frequencies as the reference's Fenwick tree,
-// stat_adaptive.h:26-126; the halving above 2^62 total cannot trigger below 2^62 symbols), kept as INCLUSIVE cumulative counts
-// on two levels: cumblk[b] = everything up to the end of block b (16 symbols a block), cumin[16 b + e] = the counts of block b
-// up to its entry e.  A symbol is located by two compares of sixteen cumulative counts each -- no loop that ends where the data
-// says, which cost a mispredicted branch or two per symbol -- and an update adds to the entries from the symbol on.  With
-// AVX-512 (the hosts of the MI355X boxes: EPYC 9575F) a level is two vectors of eight 64-bit counts: multiply by r, compare,
-// count the mask (round 4: 22 -> 12 ns per symbol of a reference stream; the scalar form is the same arithmetic entry by entry).
-struct alignas(64) Table {
-	uint64_t cumblk[16];
-	uint64_t cumin[256];
+// Adaptive frequency table over <= 256 symbols: counts plus sums over blocks of 16 (same cumulative frequencies as
+// the reference's Fenwick tree, stat_adaptive.h:26-126; the halving above 2^62 total cannot trigger below 2^62 symbols).
+struct Table {
+	uint64_t cnt[256];
+	uint64_t blk[16];
 	uint64_t tot = 0;
-	Table() { memset(cumblk, 0, sizeof(cumblk)); memset(cumin, 0, sizeof(cumin)); }
-	uint64_t count(uint32_t s) const { return cumin[s] - ((s & 15u) ? cumin[s - 1] : 0u); }
-	void ones() { for (int i = 0; i < 256; ++i) cumin[i] = (uint64_t)(i & 15) + 1; for (int b = 0; b < 16; ++b) cumblk[b] = 16ull * (uint64_t)(b + 1); tot = 256; }
-	void add(uint32_t s, uint64_t d);   // (d may be "negative": the counts wrap like the reference's)
-	void set(uint32_t s, uint64_t f) { add(s, f - count(s)); }
+	Table() { memset(cnt, 0, sizeof(cnt)); memset(blk, 0, sizeof(blk)); }
+	void add(uint32_t s, uint64_t d) { cnt[s] += d; blk[s >> 4] += d; tot += d; }
+	void set(uint32_t s, uint64_t f) { uint64_t d = f - cnt[s]; cnt[s] += d; blk[s >> 4] += d; tot += d; }
+	void ones() { for (int i = 0; i < 256; ++i) cnt[i] = 1; for (int b = 0; b < 16; ++b) blk[b] = 16; tot = 256; }
 	// find(min(value / r, tot - 1)) without the division: "target >= c" for a cumulative count c is "c r <= value and c < tot"
-	// (c r <= range: no overflow).  Same symbol, same l and h as the reference's find() in every case, ties and the clamp included.
-	uint32_t locate(uint64_t value, uint64_t r, uint64_t &l, uint64_t &h) const;
+	// (c r <= range: no overflow).  Same symbol, same l and h as find() in every case, ties and the clamp included.
+	uint32_t locate(uint64_t value, uint64_t r, uint64_t &l, uint64_t &h) const
+	{
+		uint64_t cum = 0;
+		uint32_t b = 0;
+		for (; b < 15; ++b) { const uint64_t nx = cum + blk[b]; if (nx >= tot || nx * r > value) break; cum = nx; }
+		uint32_t s = b << 4;
+		for (; s < 255; ++s) { const uint64_t nx = cum + cnt[s]; if (nx >= tot || nx * r > value) break; cum = nx; }
+		l = cum;
+		h = cum + cnt[s];
+		return s;
+	}
+	uint32_t find(uint64_t target, uint64_t &l, uint64_t &h) const
+	{
+		uint64_t rem = target;
+		uint32_t b = 0;
+		while (b < 15 && rem >= blk[b]) rem -= blk[b++];
+		uint32_t s = b << 4;
+		while (s < 255 && rem >= cnt[s]) rem -= cnt[s++];
+		l = target - rem;
+		h = l + cnt[s];
+		return s;
+	}
 };
-
-static const bool g_avx512 = [] {
-	if (getenv("HRY_SCALAR_DECODER")) return false;
-	__builtin_cpu_init();
-	return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
-}();
-
-__attribute__((target("avx512f,avx512dq"))) static inline uint32_t below16(const uint64_t *c, uint64_t base, uint64_t value, uint64_t r, uint64_t tot)
-{
-	const __m512i vb = _mm512_set1_epi64((long long)base), vr = _mm512_set1_epi64((long long)r), vv = _mm512_set1_epi64((long long)value), vt = _mm512_set1_epi64((long long)tot);
-	const __m512i c0 = _mm512_add_epi64(_mm512_load_si512((const void*)c), vb), c1 = _mm512_add_epi64(_mm512_load_si512((const void*)(c + 8)), vb);
-	const __mmask8 m0 = _mm512_cmple_epu64_mask(_mm512_mullo_epi64(c0, vr), vv) & _mm512_cmplt_epu64_mask(c0, vt);
-	const __mmask8 m1 = _mm512_cmple_epu64_mask(_mm512_mullo_epi64(c1, vr), vv) & _mm512_cmplt_epu64_mask(c1, vt);
-	return (uint32_t)__builtin_popcount((unsigned)m0 | ((unsigned)m1 << 8));   // (the counts are increasing: the mask is a run of low bits)
-}
-__attribute__((target("avx512f,avx512dq"))) static inline void add_from16(uint64_t *c, uint32_t from, uint64_t d)
-{
-	// (whole-vector stores of "count + (d where the mask says)": a masked store does not forward to the whole-vector load of the next lookup)
-	const unsigned m = 0xffffu << from;
-	_mm512_store_si512((void*)c, _mm512_add_epi64(_mm512_load_si512((const void*)c), _mm512_maskz_set1_epi64((__mmask8)(m & 0xffu), (long long)d)));
-	_mm512_store_si512((void*)(c + 8), _mm512_add_epi64(_mm512_load_si512((const void*)(c + 8)), _mm512_maskz_set1_epi64((__mmask8)((m >> 8) & 0xffu), (long long)d)));
-}
-static inline uint32_t below16_scalar(const uint64_t *c, uint64_t base, uint64_t value, uint64_t r, uint64_t tot)
-{
-	uint32_t n = 0;
-	for (int i = 0; i < 16; ++i) { const uint64_t x = base + c[i]; n += (x * r <= value) & (x < tot); }   // (wrapping products of entries past the target lose to "x < tot" only where x >= tot; below it x r <= range)
-	return n;
-}
-inline void Table::add(uint32_t s, uint64_t d)
-{
-	const uint32_t b = s >> 4;
-	if (g_avx512) { add_from16(cumin + 16 * b, s & 15u, d); add_from16(cumblk, b, d); }
-	else { for (uint32_t e = s & 15u; e < 16; ++e) cumin[16 * b + e] += d; for (uint32_t k = b; k < 16; ++k) cumblk[k] += d; }
-	tot += d;
-}
-inline uint32_t Table::locate(uint64_t value, uint64_t r, uint64_t &l, uint64_t &h) const
-{
-	// (entries at or past the target: either their product exceeds the value, or -- the clamp to tot - 1 -- they reach tot; a
-	// product can wrap only for a count above range / r >= tot, which "x < tot" excludes... but the mask must stay a run of low
-	// bits: the scalar form and the vector form both AND the two tests entry by entry, and entries below the first failing one
-	// all pass both)
-	const uint32_t b = g_avx512 ? below16(cumblk, 0, value, r, tot) : below16_scalar(cumblk, 0, value, r, tot);
-	const uint64_t base = b ? cumblk[b - 1] : 0;
-	const uint64_t *c = cumin + 16 * b;
-	const uint32_t e = g_avx512 ? below16(c, base, value, r, tot) : below16_scalar(c, base, value, r, tot);
-	l = base + (e ? c[e - 1] : 0);
-	h = base + c[e];
-	return 16 * b + e;
-}
 
 enum { IOP_SYMS = 9, OP_SYMS = 7, OP_NEWVTX = 5, OP_CONNFWD = 6 };
 
