@@ -1472,21 +1472,38 @@ void cut_border_walk_in_place(Mesh &m, const ComponentAnalysis &part, const uint
 void op_position_table(const WalkResult &w, std::vector<uint32_t> &thr, std::vector<uint32_t> &cum)
 {
 	// merge of the (sorted) position lists of the group kinds; a group of b bytes at position p has p - (bytes of the groups
-	// before it) operations in front of it
-	size_t at[G_COUNT] = { 0 }, total = 0;
+	// before it) operations in front of it.  Large tables (one triangle count per polygon: 78 M entries for the configs[3] mesh,
+	// 0.3 s on one thread) are merged by the host threads, each the groups of its own range of positions.
+	size_t total = 0;
 	for (int g = 0; g < G_COUNT; ++g) total += w.grp_pos[g].size();
-	thr.clear(); cum.clear();
-	thr.reserve(total); cum.reserve(total);
-	uint32_t bytes = 0;
-	for (size_t k = 0; k < total; ++k) {
-		int best = -1;
-		for (int g = 0; g < G_COUNT; ++g)
-			if (at[g] < w.grp_pos[g].size() && (best < 0 || w.grp_pos[g][at[g]] < w.grp_pos[best][at[best]])) best = g;
-		const uint32_t p = w.grp_pos[best][at[best]++];
-		thr.push_back(p - bytes);
-		bytes += (uint32_t)kGroupBytes[best];
-		cum.push_back(bytes);
-	}
+	thr.resize(total); cum.resize(total);
+	const unsigned nt = total >= (getenv("HRY_PARALLEL_MIN_FACES") ? (size_t)parallel_min_faces() : (size_t)1 << 20) ? std::max(1u, host_threads()) : 1u;   // (the tests' switch for "small inputs on threads too")
+	uint32_t pmax = 0;
+	for (int g = 0; g < G_COUNT; ++g) if (!w.grp_pos[g].empty()) pmax = std::max(pmax, w.grp_pos[g].back());
+	parallel_for(nt, [&](unsigned t) {
+		// positions [lo, hi) (the last range takes everything that is left)
+		const uint64_t lo = ((uint64_t)pmax + 1) * t / nt, hi = t + 1 == nt ? (uint64_t)pmax + 1 : ((uint64_t)pmax + 1) * (t + 1) / nt;
+		size_t at[G_COUNT], end[G_COUNT], k = 0;
+		uint64_t bytes = 0;
+		for (int g = 0; g < G_COUNT; ++g) {
+			const BigVec<uint32_t> &p = w.grp_pos[g];
+			at[g] = (size_t)(std::lower_bound(p.begin(), p.end(), (uint32_t)lo) - p.begin());
+			end[g] = t + 1 == nt ? p.size() : (size_t)(std::lower_bound(p.begin(), p.end(), (uint32_t)hi) - p.begin());
+			k += at[g];
+			bytes += (uint64_t)at[g] * (uint64_t)kGroupBytes[g];
+		}
+		for (;;) {
+			int best = -1;
+			for (int g = 0; g < G_COUNT; ++g)
+				if (at[g] < end[g] && (best < 0 || w.grp_pos[g][at[g]] < w.grp_pos[best][at[best]])) best = g;
+			if (best < 0) break;
+			const uint32_t p = w.grp_pos[best][at[best]++];
+			thr[k] = p - (uint32_t)bytes;
+			bytes += (uint64_t)kGroupBytes[best];
+			cum[k] = (uint32_t)bytes;
+			++k;
+		}
+	});
 }
 
 void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model, bool one_sequence)
