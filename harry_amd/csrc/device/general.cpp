@@ -571,7 +571,10 @@ std::vector<GenPlane> general_plane_layout(const Mesh &m)
 void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vector<PlaneRef> &planes)
 {
 	Events E;
+	const auto t_events = Clock::now();
 	collect_events(m, w, 0, E);
+	cx.timing.host_walk_ms += ms_since(t_events);   // (host bookkeeping along the coding order, like the walk: it was missing from the record)
+	if (getenv("HRY_TRACE")) fprintf(stderr, "[hry enc] %8.3f ms  which record every element names (host)\n", ms_since(t_events));
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	Arena A;
 	struct At { size_t type_sym, gh, lh, d_idx, d_he, d_slot, planes; };
