@@ -53,26 +53,104 @@ static const int kConnPlanes = 21;
 
 static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0 : i == 12 ? INIT_NT1 : i >= 13 ? INIT_OP : INIT_ONES; }
 
+// The float / 32-bit reconstruction chains of a mesh of many components, launched in BATCHES of whole components (round 4): a
+// component's chain needs its connectivity on the device, the residual planes decoded, and the components before it launched --
+// not the end of the replay.  The tables the chains read (lists, every component's first vertex, the progress words) are laid out
+// for the most components the stream can hold and filled batch by batch; a component not yet known starts at 0xffffffff, which
+// the owner search of a waiting chain (wait_owner) simply never picks.
+struct ChainBatches {
+	Context &cx;
+	const ListDesc ldv;
+	const uint8_t *d_vplanes;
+	uint32_t nvc, ncomp_max;
+	uint32_t comps_done = 0, v_done = 0, lists_done = 0;
+	bool conn_adopted = false;             // the caller has set the context's view of the connectivity (no adopt_conn, which waits for the stream)
+	uint32_t v_first_batch = 0;            // vertices of the batches launched beside the replay
+	hipEvent_t first_done = nullptr;       // ... and the event behind them on their stream (nullptr: none)
+	uint32_t *d_lists = nullptr, *d_off = nullptr, *d_segstart = nullptr, *d_flags = nullptr, *d_cand = nullptr;
+	uint8_t *d_ncand = nullptr;
+	std::deque<std::vector<uint32_t>> held;   // host tables on their way to the device
+	ChainBatches(Context &c, const ListDesc &ld, const uint8_t *planes, uint32_t n_vertices, uint32_t max_components)
+	    : cx(c), ldv(ld), d_vplanes(planes), nvc(n_vertices), ncomp_max(std::max(1u, max_components)) {}
+	// everything that does not depend on the connectivity, on stream st (the first batch's stream)
+	void init(hipStream_t st, Mesh &m)
+	{
+		for (size_t l = 0; l < m.lists.size() && l < 2; ++l) {
+			cx.d_rec[l].ensure(std::max<size_t>(m.lists[l].data.size(), 16));
+			if (!m.lists[l].data.empty()) HIP_OK(hipMemsetAsync(cx.d_rec[l].p, 0, m.lists[l].data.size(), st));
+		}
+		const size_t ncand_bytes = ((size_t)nvc + 63) & ~(size_t)63;
+		const size_t cand_words = (cand_table_words(nvc) + 3) & ~(size_t)3;
+		cx.d_cscratch.ensure(std::max<size_t>(cand_words * 4 + ncand_bytes + 64, 16));
+		d_cand = cx.d_cscratch.as<uint32_t>();
+		d_ncand = (uint8_t*)(d_cand + cand_words);
+		cand_table_reset(st, d_cand, nvc);
+		const size_t words = (size_t)3 * ncomp_max + ((size_t)ncomp_max + 1) + ((size_t)ncomp_max + 1) + (size_t)ldv.ncomp * ncomp_max;
+		cx.d_small.ensure(words * 4 + 64);
+		d_lists = cx.d_small.as<uint32_t>();
+		d_off = d_lists + (size_t)3 * ncomp_max;
+		d_segstart = d_off + ncomp_max + 1;
+		d_flags = d_segstart + ncomp_max + 1;
+		HIP_OK(hipMemsetAsync(d_segstart, 0xff, ((size_t)ncomp_max + 1) * 4, st));
+		HIP_OK(hipMemsetAsync(d_flags, 0, (size_t)ldv.ncomp * ncomp_max * 4, st));
+	}
+	// components [comps_done, comps_done + n): first[i] = first vertex of component comps_done + i, v_end = first vertex behind them
+	void launch(hipStream_t st, const uint32_t *first, uint32_t n, uint32_t v_end)
+	{
+		if (!n) return;
+		if ((uint64_t)comps_done + n > ncomp_max || v_end > nvc || v_end < v_done) throw Error(HRY_E_FORMAT, "corrupt stream (more components than start symbols)");
+		held.emplace_back();
+		std::vector<uint32_t> &t = held.back();
+		// lists (first vertex, end, component) of the components that own vertices, then their offsets, then the first vertices
+		uint32_t nl = 0;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t b = first[i], e = i + 1 < n ? first[i + 1] : v_end;
+			if (b != e) { t.push_back(b); t.push_back(e); t.push_back(comps_done + i); ++nl; }
+		}
+		const size_t off_at = t.size();
+		for (uint32_t i = 0; i <= nl; ++i) t.push_back(lists_done + i);
+		const size_t seg_at = t.size();
+		t.insert(t.end(), first, first + n);
+		t.push_back(v_end);   // (the next batch overwrites it with its first component's start: the same number)
+		if (nl) HIP_OK(hipMemcpyAsync(d_lists + (size_t)3 * lists_done, t.data(), (size_t)3 * nl * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_off + lists_done, t.data() + off_at, ((size_t)nl + 1) * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_segstart + comps_done, t.data() + seg_at, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
+		const ConnView cv = cx.conn_view();
+		launch_slice_prepare(st, cv, cx.d_order_v.as<uint32_t>(), nvc, v_done, v_end, d_cand, d_ncand, nullptr);
+		for (uint32_t done = 0; done < nl; done += 65535)   // a launch holds at most 65535 x 8 lists' worth of workgroups
+			launch_unpredict2(st, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, nullptr, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
+			                  d_lists, d_off + lists_done + done, std::min(65535u, nl - done), d_segstart, ncomp_max, d_flags);
+		comps_done += n; lists_done += nl; v_done = v_end;
+	}
+};
+
 // Attribute reconstruction on the device, shared by both formats: connectivity + decode order + residual byte planes
 // (already in HBM) -> attribute records.  Events 3/4 bracket the kernels.
 // conn_from: the connectivity (face offsets, origins, twins) is read from that mesh instead -- one that another thread may be
 // READING at the same time (general_planes_decode: the host's bookkeeping runs beside the vertex chain)
 static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
                                    const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
-                                   const ListDesc &ldv, const ListDesc &ldf, bool conn_resident = false, const Mesh *conn_from = nullptr)
+                                   const ListDesc &ldv, const ListDesc &ldf, bool conn_resident = false, const Mesh *conn_from = nullptr, struct ChainBatches *batches = nullptr);
+
+static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &order_v, const std::vector<uint32_t> &seg_start,
+                                   const std::vector<uint32_t> &seg_level, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
+                                   const ListDesc &ldv, const ListDesc &ldf, bool conn_resident, const Mesh *conn_from, struct ChainBatches *batches)
 {
 	Mesh *m = &mesh;
 	const uint32_t nvc = (uint32_t)order_v.size();
 	bool chain_timed = false;
+	size_t early_bytes = 0;
 	HRY_MARK(g_t0, "reconstruct: begin");
 	// connectivity up (unless it went up beside the replay: SpanUploader); the records are born on the device (zeroed there:
 	// uploading the host's zeros was a fifth of this copy)
-	if (conn_resident) cx.adopt_conn(*m);
+	if (batches && !conn_resident) throw Error(HRY_E_INTERNAL, "chains were launched beside the replay, but its connectivity did not reach the device");
+	if (conn_resident && batches && batches->conn_adopted) {}   // (the uploader completed the device's view of the connectivity, without a wait)
+	else if (conn_resident) cx.adopt_conn(*m);
 	else if (conn_from) {
 		if (conn_from->twins_pending || conn_from->partial) throw Error(HRY_E_INTERNAL, "lent connectivity must be complete");
 		cx.upload_mesh(const_cast<Mesh&>(*conn_from), false);   // (a mesh whose twins are matched is only read)
 	} else cx.upload_mesh(*m, false);
-	for (size_t l = 0; l < m->lists.size() && l < 2; ++l) {
+	for (size_t l = 0; l < m->lists.size() && l < 2 && !batches; ++l) {   // (a run in batches zeroed them before its first batch)
 		cx.d_rec[l].ensure(std::max<size_t>(m->lists[l].data.size(), 16));
 		if (!m->lists[l].data.empty()) HIP_OK(hipMemsetAsync(cx.d_rec[l].p, 0, m->lists[l].data.size(), cx.stream));
 	}
@@ -82,12 +160,31 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 	if (nvc && !conn_resident) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, order_v.data(), (size_t)nvc * 4, hipMemcpyHostToDevice, cx.stream));
 	const size_t ncand_bytes = ((size_t)nvc + 63) & ~(size_t)63;
 	const size_t cand_words = (cand_table_words(nvc) + 3) & ~(size_t)3;
-	cx.d_cscratch.ensure(std::max<size_t>(cand_words * 4 + (size_t)nvc * 16 + ncand_bytes + 64, 16));
+	if (!batches) cx.d_cscratch.ensure(std::max<size_t>(cand_words * 4 + (size_t)nvc * 16 + ncand_bytes + 64, 16));
 	uint32_t *d_cand = cx.d_cscratch.as<uint32_t>();
 	uint8_t *d_ncand = (uint8_t*)(d_cand + cand_words);
 	void *d_crec = d_ncand + ncand_bytes;   // 16-byte chain records (k_unpredict3), 16-byte aligned
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
-	if (ldv.nplanes) {
+	if (ldv.nplanes && batches) {
+		// the components the batches beside the replay have not taken: one more batch, behind them
+		const uint32_t nseg = (uint32_t)seg_start.size() - 1;
+		if (batches->comps_done > nseg || nvc != batches->nvc) throw Error(HRY_E_FORMAT, "corrupt stream (components)");
+		HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
+		batches->launch(cx.stream, seg_start.data() + batches->comps_done, nseg - batches->comps_done, nvc);
+		HIP_OK(hipEventRecord(cx.ev[0], cx.stream));
+		chain_timed = true;
+		// the records of the batches that ran beside the replay come down while the last batch runs (their chains are done
+		// when the event behind them is reached; vertex v's record is record v: vertex ids are handed out in decode order)
+		if (batches->first_done && cx.stream3 && batches->v_first_batch && !m->lists[1].data.empty()) {
+			const size_t bytes = (size_t)batches->v_first_batch * m->lists[1].stride();
+			HIP_OK(hipStreamWaitEvent(cx.stream3, batches->first_done, 0));
+			HIP_OK(hipMemcpyAsync(m->lists[1].data.data(), cx.d_rec[1].p, bytes, hipMemcpyDeviceToHost, cx.stream3));
+			early_bytes = bytes;
+		}
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		d_cand = batches->d_cand; d_ncand = batches->d_ncand;
+		HRY_MARK(g_t0, "vertex chain done");
+	} else if (ldv.nplanes) {
 		if (unpredict2_applicable(ldv)) {
 			// One chain (a wavefront, or a team of them) per attribute component and per connected component of the mesh, all of
 			// them in ONE launch in coding order; residual codes come straight from the decoded byte planes.  A component that
@@ -127,9 +224,12 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 		launch_faces_unfold(cx.stream, m->nf, ldf, cx.d_rec[0].as<uint8_t>());
 	}
 	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
-	for (int l = 0; l < 2; ++l)
-		if (!m->lists[l].data.empty()) HIP_OK(hipMemcpyAsync(m->lists[l].data.data(), cx.d_rec[l].p, m->lists[l].data.size(), hipMemcpyDeviceToHost, cx.stream));
+	for (int l = 0; l < 2; ++l) {
+		const size_t skip = l == 1 ? early_bytes : 0;   // (already on their way down, on the other stream)
+		if (m->lists[l].data.size() > skip) HIP_OK(hipMemcpyAsync(m->lists[l].data.data() + skip, (const uint8_t*)cx.d_rec[l].p + skip, m->lists[l].data.size() - skip, hipMemcpyDeviceToHost, cx.stream));
+	}
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	if (early_bytes) HIP_OK(hipStreamSynchronize(cx.stream3));
 	HRY_MARK(g_t0, "records on the host");
 	if (uint32_t tf = chain_timeout_flags(cx.stream)) throw Error(HRY_E_INTERNAL, "reconstruction chain: hand-over between wavefronts timed out (flags " + std::to_string(tf) + ")");
 	cx.timing.k_chain_ms = chain_timed ? cx.elapsed(7, 0) : 0.0;
@@ -186,7 +286,15 @@ struct SpanUploader : SpanDone {
 	Context &cx;
 	Mesh &m;
 	const OrderVec &order_v;
-	struct Range { uint32_t f0, f1, h0, h1, v0, v1; };
+	ChainBatches *batches = nullptr;       // chains launched behind the copies, batch by batch (nullptr: after the replay, as one)
+	hipEvent_t planes_ready = nullptr;     // ... once the residual planes are decoded
+	struct Range { uint32_t index, n_spans, f0, f1, h0, h1, v0, v1; std::vector<uint32_t> comp_first; };
+	std::vector<Range> arrived;            // by span index, for the prefix of finished spans (uploader thread only)
+	std::vector<char> have;
+	uint32_t prefix = 0;                   // spans [0, prefix) are on the device
+	std::vector<uint32_t> pending_first;   // components of the prefix not launched yet
+	uint32_t pending_v_end = 0, batches_launched = 0;
+	bool planes_done = false;
 	std::mutex mu;
 	std::condition_variable cv;
 	std::deque<Range> todo;
@@ -194,13 +302,25 @@ struct SpanUploader : SpanDone {
 	uint64_t faces_up = 0, he_up = 0, v_up = 0;
 	std::exception_ptr error;
 	std::thread worker;
-	SpanUploader(Context &c, Mesh &mesh, const OrderVec &ov) : cx(c), m(mesh), order_v(ov)
+	Clock::time_point t_origin = g_t0;     // (the decode's clock: g_t0 is per thread)
+	uint32_t eface_upto = 0;               // faces whose half-edge -> face entries are computed on the device
+	SpanUploader(Context &c, Mesh &mesh, const OrderVec &ov, ChainBatches *cb = nullptr, hipEvent_t planes = nullptr) : cx(c), m(mesh), order_v(ov), batches(cb), planes_ready(planes)
 	{
 		cx.ensure_second_stream();
 		cx.d_org.ensure(std::max<size_t>((size_t)m.declared_ne * 4, 16));
 		cx.d_twin.ensure(std::max<size_t>((size_t)m.declared_ne * 4, 16));
 		cx.d_foff.ensure(((size_t)m.nf + 1) * 4);
 		cx.d_order_v.ensure(std::max<size_t>((size_t)m.nv * 4, 16));
+		if (batches) {
+			int ud = 0;
+			cx.res_has_eface = !m.uniform_degree(ud);
+			cx.res_udeg = (uint32_t)ud;
+			if (cx.res_has_eface) cx.d_eface.ensure(std::max<size_t>((size_t)m.declared_ne * 4, 16));
+			const uint32_t zero = 0;
+			HIP_OK(hipMemcpyAsync(cx.d_foff.p, &zero, 4, hipMemcpyHostToDevice, cx.stream2));
+			batches->init(cx.stream2, m);
+			HIP_OK(hipStreamSynchronize(cx.stream2));
+		}
 		const void *node = callers_node_cpus();
 		worker = std::thread([this, node] {
 			try {
@@ -214,35 +334,111 @@ struct SpanUploader : SpanDone {
 						if (todo.empty()) break;
 						r = todo.front(); todo.pop_front();
 					}
-					if (r.f1 > r.f0) HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + r.f0 + 1, m.face_off.data() + r.f0 + 1, ((size_t)r.f1 - r.f0) * 4, hipMemcpyHostToDevice, cx.stream2));
-					if (r.h1 > r.h0) {
-						HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + r.h0, m.org.data() + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, cx.stream2));
-						HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + r.h0, m.twin.data() + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, cx.stream2));
-					}
-					if (r.v1 > r.v0) HIP_OK(hipMemcpyAsync(cx.d_order_v.as<uint32_t>() + r.v0, order_v.data() + r.v0, ((size_t)r.v1 - r.v0) * 4, hipMemcpyHostToDevice, cx.stream2));
-					faces_up += r.f1 - r.f0; he_up += r.h1 - r.h0; v_up += r.v1 - r.v0;
+					copy_range(r, cx.stream2);
+					bool ending;
+					{ std::lock_guard<std::mutex> g(mu); faces_up += r.f1 - r.f0; he_up += r.h1 - r.h0; v_up += r.v1 - r.v0; ending = closing; }
+					if (batches && !ending) after_upload(std::move(r));   // (once the replay has ended the caller launches the rest)
 				}
 				HIP_OK(hipStreamSynchronize(cx.stream2));
 			} catch (...) { error = std::current_exception(); }
 		});
 	}
-	void span(uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1) override
+	void copy_range(const Range &r, hipStream_t st)
 	{
-		{ std::lock_guard<std::mutex> g(mu); todo.push_back(Range{ f0, f1, h0, h1, v0, v1 }); }
+		if (r.f1 > r.f0) HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + r.f0 + 1, m.face_off.data() + r.f0 + 1, ((size_t)r.f1 - r.f0) * 4, hipMemcpyHostToDevice, st));
+		if (r.h1 > r.h0) {
+			HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + r.h0, m.org.data() + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + r.h0, m.twin.data() + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, st));
+		}
+		if (r.v1 > r.v0) HIP_OK(hipMemcpyAsync(cx.d_order_v.as<uint32_t>() + r.v0, order_v.data() + r.v0, ((size_t)r.v1 - r.v0) * 4, hipMemcpyHostToDevice, st));
+	}
+	void span(uint32_t index, uint32_t n_spans, uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1, const uint32_t *comp_first, uint32_t n_comp) override
+	{
+		Range r{ index, n_spans, f0, f1, h0, h1, v0, v1, {} };
+		if (batches) r.comp_first.assign(comp_first, comp_first + n_comp);
+		{ std::lock_guard<std::mutex> g(mu); todo.push_back(std::move(r)); }
 		cv.notify_one();
+	}
+	// (uploader thread) a span's arrays are on their way: extend the prefix of finished spans, and once the residual planes are
+	// decoded launch the chains of the components the prefix has gained -- a quarter of the vertices at a time at least
+	void after_upload(Range &&r)
+	{
+		if (have.empty()) { have.assign(r.n_spans, 0); arrived.resize(r.n_spans); }
+		if (r.index >= have.size() || have[r.index]) throw Error(HRY_E_INTERNAL, "replay: span reported twice");
+		const uint32_t idx = r.index;
+		arrived[idx] = std::move(r);
+		have[idx] = 1;
+		while (prefix < have.size() && have[prefix]) {
+			Range &p = arrived[prefix];
+			pending_first.insert(pending_first.end(), p.comp_first.begin(), p.comp_first.end());
+			pending_v_end = p.v1;
+			std::vector<uint32_t>().swap(p.comp_first);
+			++prefix;
+		}
+		if (!planes_done) planes_done = hipEventQuery(planes_ready) == hipSuccess;
+		if (planes_done && prefix < have.size() && !pending_first.empty() && pending_v_end - batches->v_done >= std::max(1u, m.nv / 4)) launch_pending();
+	}
+	void launch_pending()
+	{
+		// the chains run on the MAIN stream (idle while the host replays), behind an event on the copies' stream: on that stream
+		// itself the copies of the later spans would queue behind tens of milliseconds of chains
+		cx.res_nv = m.nv; cx.res_nf = m.nf; cx.res_ne = m.declared_ne;   // (what conn_view reports: the arrays are that large from the start)
+		const uint32_t f_end = arrived[prefix - 1].f1;   // the faces of the prefix: their offsets are complete on the device
+		if (cx.res_has_eface && f_end > eface_upto) dev::launch_edge_faces(cx.stream2, cx.d_foff.as<uint32_t>(), f_end, cx.d_eface.as<uint32_t>(), eface_upto);
+		eface_upto = f_end;
+		HIP_OK(hipEventRecord(cx.ev_x[2], cx.stream2));
+		HIP_OK(hipStreamWaitEvent(cx.stream, cx.ev_x[2], 0));
+		batches->launch(cx.stream, pending_first.data(), (uint32_t)pending_first.size(), pending_v_end);
+		HIP_OK(hipEventRecord(cx.attr_ev[0], cx.stream));   // (the attribute groups' events are free by now: the planes are decoded)
+		batches->first_done = cx.attr_ev[0]; batches->v_first_batch = pending_v_end;
+		pending_first.clear();
+		++batches_launched;
+		if (getenv("HRY_TRACE")) fprintf(stderr, "[hry] %8.3f ms  chains of the components up to vertex %u launched beside the replay\n", ms_since(t_origin), pending_v_end);
 	}
 	// everything is on the device (true) or the caller uploads as usual (false: the replay ran as one sequence, or a copy failed)
 	bool finish()
 	{
-		{ std::lock_guard<std::mutex> g(mu); closing = true; }
+		size_t left = 0;
+		{ std::lock_guard<std::mutex> g(mu); closing = true; left = todo.size(); }
 		cv.notify_one();
+		if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  replay returned: %zu finished span(s) still to be copied\n", ms_since(t_origin), left);
+		// The replay is over and its thread has nothing to do: it takes spans off the list too, on the stream the attribute planes
+		// were decoded on (idle by now) -- the one uploader used to be 25 - 30 ms behind at this point on the configs[3] mesh.
+		// (No more batches from here on: the caller launches what is left.)
+		if (!error) {
+			try {
+				for (;;) {
+					Range r;
+					{
+						std::lock_guard<std::mutex> g(mu);
+						if (todo.empty()) break;
+						r = std::move(todo.back()); todo.pop_back();
+					}
+					copy_range(r, cx.stream3 ? cx.stream3 : cx.stream2);
+					std::lock_guard<std::mutex> g(mu);
+					faces_up += r.f1 - r.f0; he_up += r.h1 - r.h0; v_up += r.v1 - r.v0;
+				}
+				if (cx.stream3) HIP_OK(hipStreamSynchronize(cx.stream3));
+			} catch (...) { if (worker.joinable()) worker.join(); throw; }
+		}
 		if (worker.joinable()) worker.join();
+		if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  every span is on the device\n", ms_since(t_origin));
 		if (error) return false;
 		if (faces_up != m.nf || he_up != m.declared_ne || v_up != order_v.size() || order_v.size() != m.nv) return false;
+		if (batches) return true;   // (the first offset went up before the first span; the main stream may still be running a batch of chains: no wait)
 		const uint32_t zero = 0;
 		HIP_OK(hipMemcpyAsync(cx.d_foff.p, &zero, 4, hipMemcpyHostToDevice, cx.stream));
 		HIP_OK(hipStreamSynchronize(cx.stream));
 		return true;
+	}
+	// the half-edge -> face entries of the faces behind the last batch, on stream st (the caller's last batch follows on it)
+	void finish_edge_faces(hipStream_t st)
+	{
+		if (cx.res_has_eface && m.nf > eface_upto) dev::launch_edge_faces(st, cx.d_foff.as<uint32_t>(), m.nf, cx.d_eface.as<uint32_t>(), eface_upto);
+		eface_upto = m.nf;
+		cx.res_nv = m.nv; cx.res_nf = m.nf; cx.res_ne = m.declared_ne;
+		m.twins_pending = false;
+		cx.resident_token = 0;
 	}
 	~SpanUploader() { { std::lock_guard<std::mutex> g(mu); closing = true; todo.clear(); } cv.notify_one(); if (worker.joinable()) worker.join(); }
 };
@@ -770,16 +966,29 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		cx.timing.host_walk_ms = cx.timing.host_walk_ms - std::chrono::duration<double, std::milli>(t_walk - g_t0).count();
 	} else {
 		bool conn_resident = false;
+		std::unique_ptr<ChainBatches> batches;
 		if (!restarts.empty() && rcounters.size() == restarts.size() && m->nf >= (1u << 20) && !getenv("HRY_NO_SPAN_UPLOAD")) {
-			SpanUploader up(cx, *m, order_v);
+			// float / 32-bit vertex components: their chains start beside the replay, batch by batch (ChainBatches)
+			// ... where that pays: a batch is a launch of its own on the main stream, and a launch takes as long as its longest
+			// chain (one wavefront, one component: 7 - 14 ms for the 49 000 vertices of a configs[3] component), so three batches of a
+			// mesh whose chains all fit on the device at once (the 12.6 M-triangle share: 384 chains) took 36 ms where one launch takes 15;
+			// the 100 M-triangle mesh's 3 072 chains need two rounds anyway and finish 25 ms earlier in batches.
+			// HRY_CHAIN_BATCH_MIN_VERTICES: the threshold (tests run small meshes in batches).
+			const char *bm = getenv("HRY_CHAIN_BATCH_MIN_VERTICES");
+			const uint32_t batch_min = bm ? (uint32_t)strtoul(bm, nullptr, 10) : 20000000u;
+			const bool in_batches = ldv.nplanes && unpredict2_applicable(ldv) && !unpredict3_wanted(ldv) && vc == m->nv && vc >= batch_min && !getenv("HRY_NO_CHAIN_BATCHES");
+			if (in_batches) batches.reset(new ChainBatches(cx, ldv, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], vc, nsym[0]));
+			SpanUploader up(cx, *m, order_v, batches.get(), cx.ev_x[1]);
 			cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level, &up);
 			conn_resident = up.finish();
+			if (up.error) std::rethrow_exception(up.error);
+			if (batches && conn_resident) { up.finish_edge_faces(cx.stream); batches->conn_adopted = true; }
 		} else cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
 		cx.timing.host_walk_ms = ms_since(t_walk);
 		HRY_MARK(g_t0, "replay done");
 		if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");
 		reconstruct_attributes(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes],
-		                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, conn_resident);
+		                       cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, conn_resident, nullptr, batches.get());
 	}
 	if (cx.keep_stages) {
 		cx.stage_put("dec_syms", cx.d_csyms.p, total_syms);

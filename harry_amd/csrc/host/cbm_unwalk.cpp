@@ -441,7 +441,7 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 			if (lean) sp.eom = replay_polygons(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
 			else sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
 			check_end(k);
-			if (on_span) on_span->span(f0, sp.cur.face, h0, sp.cur.he, v0, sp.cur.next_id);
+			if (on_span) on_span->span((uint32_t)k, (uint32_t)ns, f0, sp.cur.face, h0, sp.cur.he, v0, sp.cur.next_id, sp.first.data(), (uint32_t)sp.first.size());
 		}
 	});
 	mark("spans replayed");

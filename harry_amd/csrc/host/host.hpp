@@ -216,7 +216,12 @@ struct PlaneView {
 // on_span (optional): called by the thread that finished a span of the parallel replay -- faces [f0, f1), half-edges [h0, h1) and
 // vertices [v0, v1) are final in m.face_off (entries f0 + 1 .. f1) / m.org / m.twin / order_v from then on (a span links half-edges
 // of its own components only).  Not called at all when the replay runs as one sequence.
-struct SpanDone { virtual void span(uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1) = 0; virtual ~SpanDone() {} };
+// index / n_spans: which span of how many; comp_first[0 .. n_comp): the first vertex of every component the span holds (valid until
+// cut_border_replay returns)
+struct SpanDone {
+	virtual void span(uint32_t index, uint32_t n_spans, uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1, const uint32_t *comp_first, uint32_t n_comp) = 0;
+	virtual ~SpanDone() {}
+};
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
                        OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span = nullptr);

@@ -165,6 +165,20 @@ def test_cfg3_share_one_gpu_lossless(cx, cfg4_share):
     same_mesh(cx.read_hry(got), ref_dec)
 
 
+def test_cfg3_share_chains_in_batches_beside_the_replay(cx, cfg4_share, monkeypatch):
+    """The float chains of a mesh of many components start beside the replay, batch by batch, once the mesh is large enough for
+    that to pay (unchunk.cpp: ChainBatches; 20 M vertices by default).  Forced onto the 12.6 M-triangle share: every batch's
+    components wait for owners in earlier batches through the same progress words, the last batch follows the replay, the
+    first batches' records come down early -- the decoded mesh is the reference-format decode's, twice in a row on one context."""
+    _need_memory(24)
+    mesh, o, ref_dec = cfg4_share
+    a = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+    got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+    monkeypatch.setenv("HRY_CHAIN_BATCH_MIN_VERTICES", "1")
+    for _ in range(2):
+        same_mesh(cx.read_hry(got), ref_dec)
+
+
 def test_cfg3_cfg4_sharded_as_8_virtual_ranks(cx, cfg4_share):
     """The same mesh through the sharded path: plan -> 8 shards -> per-shard bounds + combination -> 8 segments -> ONE
     container; decode-only (configs[4]) of that container whole and segment by segment == reference-format decode."""
