@@ -8,7 +8,7 @@
 #         cfg0      scripts/cfg0_time.py                     bunny-class stand-in, lossless, both profiles
 #         floatmixed scripts/float_chain_time.py 708 --mixed  ONE mixed-polygon component (40 % quads, 5 % pentagons), lossless
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -26,6 +26,28 @@ leg() {
 	rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/$name/pmc_sq -- python3 "$@" > $OUT/$name/pmc_sq.log 2>&1
 	echo "leg $name done" >> $OUT/progress.log
 }
+# PART=2: only the 100 M-triangle collections (configs[3] / [4] at the named size; a call of their own: they take minutes)
+if [ "${PART:-1}" = "2" ]; then
+	cd $ROOT
+	HRY_TRACE=1 python3 tests/tools/cfg4_check.py 1024 221 222 --contexts 8 > $OUT/cfg4_full_100M_trace.txt 2>&1
+	echo "100M trace + oracle done" >> $OUT/progress.log
+	python3 tests/tools/cfg4_check.py 1024 221 222 --no-verify --compat > $OUT/cfg4_full_100M_compat.txt 2>&1
+	echo "100M compat done" >> $OUT/progress.log
+	HRY_TRACE=1 python3 tests/tools/cfg4_e2e.py 1024 221 222 --gpus 8 > $OUT/cfg4_e2e_100M.txt 2>&1
+	python3 tests/tools/cfg4_e2e.py 1024 221 222 > $OUT/cfg4_e2e_100M_one_context.txt 2>&1
+	echo "100M end to end done" >> $OUT/progress.log
+	cd /tmp
+	mkdir -p $OUT/cfg4full
+	rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg4full/kstats -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify > $OUT/cfg4full/kstats.log 2>&1
+	rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/cfg4full/pmc_sq -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify > $OUT/cfg4full/pmc_sq.log 2>&1
+	echo "100M profiles done" >> $OUT/progress.log
+	cd $ROOT
+	echo "==== cfg4full" >> $OUT/summary.txt
+	python3 scripts/summarise_profiles.py $OUT/cfg4full 4 >> $OUT/summary.txt 2>&1
+	find $OUT -type d \( -name kstats -o -name pmc_fetch -o -name pmc_write -o -name pmc_sq \) -prune -exec rm -rf {} +
+	tail -30 $OUT/summary.txt
+	exit 0
+fi
 leg configs1 $ROOT/scripts/quick_chunked.py 708
 leg float1m $ROOT/scripts/float_chain_time.py 708
 leg cfg4share $ROOT/tests/tools/cfg4_check.py 128 221 222 --no-verify
