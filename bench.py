@@ -942,14 +942,13 @@ def cfg4_full_leg(cx):
     return res
 
 
-def obj_leg(cx):
+def _obj_scene_record(cx, sc, workload, with_reference_binary=True):
+    """One OBJ scene through both profiles: reference stream (bytes against the CPU port) and the parallel container (bytes against the
+    port's restatement, decode against the reference-format decode); best of the passes after the first."""
     import subprocess
     import tempfile
     from harry_amd import codec as hc
-    from harry_amd import meshgen as mg
-    from harry_amd import objgen as og
     from oracle import oracle_py as op   # checker only
-    sc = og.scene(mg.torus(200, 200, seed=2), normals="smooth", tex="atlas", charts=7)
     t0 = time.perf_counter()
     m = hc.Mesh.from_obj(sc.obj, "")
     t_parse = time.perf_counter() - t0
@@ -965,26 +964,30 @@ def obj_leg(cx):
         enc.append(t1 - t0); dec.append(t2 - t1)
     want = op.Mesh.from_obj(sc.obj, "").encode().data
     # the same scene in the parallel container (.hry v0.2 holds general bindings too)
-    cenc, cdec, cdata = [], [], b""
+    cenc, cdec, cdata, ctm_e, ctm_d = [], [], b"", {}, {}
     for _ in range(3):
         a = m.clone()
         t0 = time.perf_counter()
         cdata = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
         t1 = time.perf_counter()
+        ctm_e = cx.timing()
+        t1b = time.perf_counter()
         cd = cx.read_hry(cdata)
         t2 = time.perf_counter()
-        cenc.append(t1 - t0); cdec.append(t2 - t1)
+        ctm_d = cx.timing()
+        cenc.append(t1 - t0); cdec.append(t2 - t1b)
     chunked = {"encode_ms": round(min(cenc[1:]) * 1e3, 2), "decode_ms": round(min(cdec[1:]) * 1e3, 2),
                "encode_mtri_s": round(ntri / min(cenc[1:]) / 1e6, 3), "decode_mtri_s": round(ntri / min(cdec[1:]) / 1e6, 3), "hry_bytes": len(cdata),
+               "encode_host_ms": round(ctm_e.get("host_walk_ms", 0.0), 2), "decode_chain_ms": round(ctm_d.get("k_chain_ms", 0.0), 2),
                "container_equals_cpu_port": bool(cdata == op.Mesh.from_obj(sc.obj, "").encode_chunked(hc.container_info(cdata)["chunk_syms"]).data),
                "decode_equals_reference_format_decode": bool(all(np.array_equal(cd.list_data(l), x) for l, x in enumerate(_oracle_lists(op, want))))}
-    rec = {"workload": "torus 200 x 200 as OBJ: smooth normals + 7-chart texture atlas (v / vt / vn, f v/t/n)", "triangles": int(ntri), "obj_bytes": len(sc.obj), "chunked": chunked,
+    rec = {"workload": workload, "triangles": int(ntri), "obj_bytes": len(sc.obj), "chunked": chunked,
            "parse_ms": round(t_parse * 1e3, 2), "encode_ms": round(min(enc[1:]) * 1e3, 2), "decode_ms": round(min(dec[1:]) * 1e3, 2),
            "encode_mtri_s": round(ntri / min(enc[1:]) / 1e6, 3), "decode_mtri_s": round(ntri / min(dec[1:]) / 1e6, 3),
            "hry_bytes": len(data), "byte_identical_to_cpu_ref": bool(data == want),
            "decode_equals_cpu_ref": bool(d.to_obj() is not None and all(np.array_equal(d.list_data(l), x) for l, x in enumerate(_oracle_lists(op, want))))}
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "harry_ref")
-    if os.path.exists(ref_bin):
+    if with_reference_binary and os.path.exists(ref_bin):
         with tempfile.TemporaryDirectory() as tmp:
             src, hry, back = os.path.join(tmp, "s.obj"), os.path.join(tmp, "s.hry"), os.path.join(tmp, "b.obj")
             with open(src, "wb") as f:
@@ -996,6 +999,50 @@ def obj_leg(cx):
             t2 = time.perf_counter()
             rec["reference_binary"] = {"obj_to_hry_ms": round((t1 - t0) * 1e3, 1), "hry_to_obj_ms": round((t2 - t1) * 1e3, 1),
                                        "bytes_equal": bool(open(hry, "rb").read() == data), "what": "whole process, file to file, one core"}
+    return rec
+
+
+def obj_leg(cx):
+    """OBJ scenes: smooth normals + atlas (shared records, short chains), one normal per face (every record
+    depends on the one before it: k_gen_chain<1, float>), and a many-part scene over two device contexts of this process."""
+    from harry_amd import codec as hc
+    from harry_amd import meshgen as mg
+    from harry_amd import objgen as og
+    from oracle import oracle_py as op   # checker only
+    rec = _obj_scene_record(cx, og.scene(mg.torus(200, 200, seed=2), normals="smooth", tex="atlas", charts=7),
+                            "torus 200 x 200 as OBJ: smooth normals + 7-chart texture atlas (v / vt / vn, f v/t/n)")
+    try:
+        rec["flat_normals"] = _obj_scene_record(cx, og.scene(mg.torus(200, 200, seed=2), normals="flat", tex="atlas", charts=7),
+                                                "the same torus with ONE normal per face (f v/t/n, 80 000 vn lines): the serial record chain")
+    except Exception as exc:   # noqa: BLE001
+        rec["flat_normals"] = {"error": str(exc)}
+    try:
+        # a scene of many parts in the sharded container (.hry v0.3 with general bindings): two contexts of this process on this device
+        base = mg.with_nonmanifold(mg.multi_component(32, 40, 41, seed=5, polys="mixed"), 30, 20, seed=4)
+        sc = og.scene(base, normals="flat", tex="corner")
+        whole = hc.Mesh.from_obj(sc.obj, "")
+        one = cx.read_hry(cx.write_hry(whole.clone(), profile=hc.PROFILE_CHUNKED))
+        mc = hc.MultiCodec([cx.device, cx.device])
+        try:
+            te, td, merged = [], [], b""
+            for _ in range(3):
+                w = hc.Mesh.from_obj(sc.obj, "")
+                t0 = time.perf_counter()
+                merged = mc.write_hry(w, [])
+                t1 = time.perf_counter()
+                got = mc.read_hry(merged)
+                t2 = time.perf_counter()
+                te.append(t1 - t0); td.append(t2 - t1)
+            info = hc.container_info(merged)
+            rec["sharded"] = {"workload": "32 mixed-polygon parts with non-manifold edges as OBJ (one normal per face, texture coordinates per corner), 2 contexts on one device",
+                              "triangles": int(whole.ntri), "segments": int(info.get("segments", 0)), "hry_bytes": len(merged),
+                              "encode_ms": round(min(te[1:]) * 1e3, 2), "decode_ms": round(min(td[1:]) * 1e3, 2),
+                              "encode_mtri_s": round(whole.ntri / min(te[1:]) / 1e6, 3), "decode_mtri_s": round(whole.ntri / min(td[1:]) / 1e6, 3),
+                              "text_equals_single_context": bool(got.to_obj() == one.to_obj())}
+        finally:
+            mc.close()
+    except Exception as exc:   # noqa: BLE001
+        rec["sharded"] = {"error": str(exc)}
     return rec
 
 

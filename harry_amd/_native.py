@@ -136,8 +136,8 @@ def load():
     L.hry_decode_sharded.restype = C.c_int
     L.hry_decode_sharded.argtypes = [C.POINTER(vp), C.c_int, vp, sz, C.POINTER(Opts), C.POINTER(vp), C.POINTER(ShardTiming)]
     L.hry_container_check.restype = C.c_int; L.hry_container_check.argtypes = [vp, sz, C.POINTER(C.c_int)]
-    if L.hry_abi_version() != 4:
-        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 4: rebuild it")
+    if L.hry_abi_version() != 5:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 5: rebuild it")
     _lib = L
     return L
 

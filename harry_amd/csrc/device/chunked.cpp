@@ -127,11 +127,13 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	const ListDesc ldv = m.general ? ListDesc{} : make_list_desc(m.lists[1]), ldf = m.general ? ListDesc{} : make_list_desc(m.lists[0]);   // (general bindings: general_planes_encode)
 	if (chunk_syms <= 0) {
-		// default policy: 32 Ki symbols per chunk (about +5 % size on a 1 M-triangle mesh); larger meshes get larger chunks
-		// as long as some thousands of streams remain to fill the 1024 SIMDs
+		// default policy: 8 Ki symbols per chunk; larger meshes get larger chunks as long as a lane's worth of streams remains for
+		// every SIMD (64 x 1024: the decoder runs a stream per LANE once there are that many, k_chunk_decode_lanes, and its time is
+		// the longest stream's).  The 100 M-triangle configs[3] mesh: 16 Ki (53 000 streams; 128 Ki until round 4, when a stream
+		// took a wavefront: attribute streams' decode 99.6 -> 36.0 ms, encode 37.4 -> 26.7, container + 0.33 %)
 		uint64_t total = (uint64_t)w.n_conn + (uint64_t)vc * ldv.nplanes + (uint64_t)fc * ldf.nplanes;
 		if (m.general) for (const AttrList &L : m.lists) total += (uint64_t)L.count * L.coded_bytes();
-		while (CH < (1u << 18) && total / CH > 8192) CH <<= 1;
+		while (CH < (1u << 18) && total / CH > 65536) CH <<= 1;
 	}
 
 	// ---- connectivity planes on the host side: 5 groups (split into bytes on the device) + 8 operation planes

@@ -45,6 +45,8 @@ Context::~Context()
 	if (stream) (void)hipStreamDestroy(stream);
 	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
 	if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }
+	for (auto &u : up_stream) if (u) { (void)hipStreamSynchronize(u); (void)hipStreamDestroy(u); }
+	for (auto &e : up_ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ev_x) if (e) (void)hipEventDestroy(e);
 	for (auto &e : attr_ev) if (e) (void)hipEventDestroy(e);
 	for (int g = 1; g < kAttrGroups; ++g) if (attr_stream[g]) { (void)hipStreamSynchronize(attr_stream[g]); (void)hipStreamDestroy(attr_stream[g]); }   // [0] is stream3

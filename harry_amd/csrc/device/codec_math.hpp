@@ -134,7 +134,12 @@ HRY_HD uint64_t quantise_f32(float v, float mn, float scale, int q)
 }
 
 // ---- exact division by a context total through a precomputed reciprocal ---------------------------------
-// r = floor(n / t) for any 64-bit n: q = mulhi(magic, n); r = (((n - q) >> 1) + q) >> shift  (round-up method)
+// r = floor(n / t) for every n <= 2^63 (the coder's range register never exceeds HALF, coder.h:47,92-101) and 2 <= t < 2^32:
+//   t not a power of two: s = floor(log2 t), magic = floor(2^(64+s) / t) + 1 = 2^(64+s)/t + e with 0 < e <= 1; mulhi(magic, n)
+//   >> s overshoots n / t by n e / 2^(64+s) <= 2^63 / 2^(64+s) = 1 / 2^(s+1) < 1 / t, so the floor is unchanged;
+//   t = 2^s: magic = 2^63 is the exact reciprocal at shift s - 1.
+// (One multiplication and one shift in the serial chain; the 65-bit reciprocal that is exact for every 64-bit n costs three
+// more dependent operations per symbol.)
 HRY_HD uint64_t mulhi64(uint64_t a, uint64_t b)
 {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -145,21 +150,19 @@ HRY_HD uint64_t mulhi64(uint64_t a, uint64_t b)
 }
 HRY_HD uint64_t div_by_magic(uint64_t n, uint64_t magic, uint32_t shift)
 {
-	uint64_t q = mulhi64(magic, n);
-	return (((n - q) >> 1) + q) >> shift;
+	return mulhi64(magic, n) >> shift;
 }
 // reciprocal of t (2 <= t < 2^32)
 HRY_HD void make_magic(uint32_t t, uint64_t &magic, uint32_t &shift)
 {
 	uint32_t k = 31u - (uint32_t)__builtin_clz(t);
-	if ((t & (t - 1)) == 0) { magic = 0; shift = k - 1; return; }
+	if ((t & (t - 1)) == 0) { magic = 1ull << 63; shift = k - 1; return; }
+	// floor(2^(64+k) / t) in two 64-bit steps (2^(32+k) / t < 2^32)
 	uint64_t n1 = (uint64_t)(1u << k) << 32;
 	uint64_t q1 = n1 / t, r1 = n1 % t;
 	uint64_t n0 = r1 << 32;
-	uint64_t q0 = n0 / t, r0 = n0 % t;
-	uint64_t q = (q1 << 32) | q0;
-	uint64_t m = q + q + ((r0 + r0 >= t) ? 1 : 0);
-	magic = m + 1;
+	uint64_t q0 = n0 / t;
+	magic = ((q1 << 32) | q0) + 1;
 	shift = k;
 }
 

@@ -62,6 +62,9 @@ struct Context {
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;   // uploads and connectivity-only kernels of the pipelined decode (created on first use)
 	hipStream_t stream3 = nullptr;   // attribute streams' entropy decode, next to the connectivity streams' (created on first use)
+	static constexpr int kUploadStreams = 3;
+	hipStream_t up_stream[kUploadStreams] = {};   // further uploaders of finished spans beside stream2 (unchunk.cpp: SpanUploader; created on first use)
+	hipEvent_t up_ev[kUploadStreams] = {};
 	hipEvent_t ev_x[3] = {};         // cross-stream ordering events (created with stream3)
 	// chunked decode: the attribute streams are launched in groups by how far into their plane they end (unchunk.cpp); group g
 	// runs on attr_stream[g] and raises attr_ev[g]

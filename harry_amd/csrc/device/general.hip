@@ -177,8 +177,7 @@ template <typename T> __device__ __forceinline__ void store_g(HRY_GLOBAL uint8_t
 // ---- sources: which earlier records the prediction of record i reads -----------------------------------------------
 // KIND 0: vertex records (the three records of every parallelogram, in fan order), 1: corner records (one record per already
 // decoded face of the region around the vertex).  Connectivity only, so every record at once: src[k * n + i] = k-th source id of
-// record i, nsrc[i] = their number, kSrcOverflow when the fan has more than kSrcCap (the chain walks that fan itself).
-constexpr int kSrcCap = 24;                                                 // rows of the table
+// record i, nsrc[i] = their number, kSrcOverflow when the fan has more than SrcCap<KIND> rows (the chain walks that fan itself).
 template <int KIND> struct SrcCap { static constexpr int value = KIND == 0 ? 24 : 12; };   // 8 parallelograms / 12 faces around a vertex
 constexpr uint8_t kSrcOverflow = 255;
 

@@ -301,7 +301,15 @@ struct SpanUploader : SpanDone {
 	bool closing = false;
 	uint64_t faces_up = 0, he_up = 0, v_up = 0;
 	std::exception_ptr error;
-	std::thread worker;
+	// Three threads take spans off the list, each with a stream of its own: a copy from pageable memory holds its thread until the
+	// runtime has staged it (10 GB/s a thread), and one thread was 16 - 20 ms behind the replay of the configs[3] mesh at its end
+	// (2.7 GB in 125 ms; 249 spans still queued), two 13 ms (165 spans), three none: decode 175 -> 163 -> 149 ms; a fourth thread, or
+	// replay threads given up for them, gain nothing (16 CPUs of quota: `profiles/r4/decode_uploaders.txt`)
+	static constexpr int kWorkers = Context::kUploadStreams + 1;
+	std::thread worker[kWorkers];
+	hipStream_t up_stream[kWorkers] = {};
+	int n_workers = 3;
+	std::mutex mu_prefix;                  // after_upload / launch_pending: one worker at a time
 	Clock::time_point t_origin = g_t0;     // (the decode's clock: g_t0 is per thread)
 	uint32_t eface_upto = 0;               // faces whose half-edge -> face entries are computed on the device
 	SpanUploader(Context &c, Mesh &mesh, const OrderVec &ov, ChainBatches *cb = nullptr, hipEvent_t planes = nullptr) : cx(c), m(mesh), order_v(ov), batches(cb), planes_ready(planes)
@@ -321,8 +329,16 @@ struct SpanUploader : SpanDone {
 			batches->init(cx.stream2, m);
 			HIP_OK(hipStreamSynchronize(cx.stream2));
 		}
+		static const int wanted = [] { const char *e = getenv("HRY_SPAN_UPLOADERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > kWorkers ? kWorkers : v; }();
+		n_workers = wanted;
+		up_stream[0] = cx.stream2;
+		for (int k = 1; k < n_workers; ++k) {
+			if (!cx.up_stream[k - 1]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[k - 1], hipStreamNonBlocking));
+			if (!cx.up_ev[k - 1]) HIP_OK(hipEventCreateWithFlags(&cx.up_ev[k - 1], hipEventDisableTiming));
+			up_stream[k] = cx.up_stream[k - 1];
+		}
 		const void *node = callers_node_cpus();
-		worker = std::thread([this, node] {
+		for (int k = 0; k < n_workers; ++k) worker[k] = std::thread([this, node, k] {
 			try {
 				stay_on_node(node);
 				HIP_OK(hipSetDevice(cx.device));
@@ -334,13 +350,13 @@ struct SpanUploader : SpanDone {
 						if (todo.empty()) break;
 						r = todo.front(); todo.pop_front();
 					}
-					copy_range(r, cx.stream2);
+					copy_range(r, up_stream[k]);
 					bool ending;
 					{ std::lock_guard<std::mutex> g(mu); faces_up += r.f1 - r.f0; he_up += r.h1 - r.h0; v_up += r.v1 - r.v0; ending = closing; }
-					if (batches && !ending) after_upload(std::move(r));   // (once the replay has ended the caller launches the rest)
+					if (batches && !ending) { std::lock_guard<std::mutex> g(mu_prefix); after_upload(std::move(r)); }   // (once the replay has ended the caller launches the rest)
 				}
-				HIP_OK(hipStreamSynchronize(cx.stream2));
-			} catch (...) { error = std::current_exception(); }
+				HIP_OK(hipStreamSynchronize(up_stream[k]));
+			} catch (...) { std::lock_guard<std::mutex> g(mu); if (!error) error = std::current_exception(); }
 		});
 	}
 	void copy_range(const Range &r, hipStream_t st)
@@ -359,7 +375,7 @@ struct SpanUploader : SpanDone {
 		{ std::lock_guard<std::mutex> g(mu); todo.push_back(std::move(r)); }
 		cv.notify_one();
 	}
-	// (uploader thread) a span's arrays are on their way: extend the prefix of finished spans, and once the residual planes are
+	// (an uploader thread, under mu_prefix) a span's arrays are on their way: extend the prefix of finished spans, and once the residual planes are
 	// decoded launch the chains of the components the prefix has gained -- a quarter of the vertices at a time at least
 	void after_upload(Range &&r)
 	{
@@ -376,7 +392,8 @@ struct SpanUploader : SpanDone {
 			++prefix;
 		}
 		if (!planes_done) planes_done = hipEventQuery(planes_ready) == hipSuccess;
-		if (planes_done && prefix < have.size() && !pending_first.empty() && pending_v_end - batches->v_done >= std::max(1u, m.nv / 4)) launch_pending();
+		static const uint32_t parts = [] { const char *e = getenv("HRY_CHAIN_BATCH_PARTS"); const int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : v); }();
+		if (planes_done && prefix < have.size() && !pending_first.empty() && pending_v_end - batches->v_done >= std::max(1u, m.nv / parts)) launch_pending();
 	}
 	void launch_pending()
 	{
@@ -384,6 +401,10 @@ struct SpanUploader : SpanDone {
 		// itself the copies of the later spans would queue behind tens of milliseconds of chains
 		cx.res_nv = m.nv; cx.res_nf = m.nf; cx.res_ne = m.declared_ne;   // (what conn_view reports: the arrays are that large from the start)
 		const uint32_t f_end = arrived[prefix - 1].f1;   // the faces of the prefix: their offsets are complete on the device
+		for (int k = 1; k < n_workers; ++k) {   // (the prefix' spans went up on any of the streams: the first waits for the others)
+			HIP_OK(hipEventRecord(cx.up_ev[k - 1], up_stream[k]));
+			HIP_OK(hipStreamWaitEvent(cx.stream2, cx.up_ev[k - 1], 0));
+		}
 		if (cx.res_has_eface && f_end > eface_upto) dev::launch_edge_faces(cx.stream2, cx.d_foff.as<uint32_t>(), f_end, cx.d_eface.as<uint32_t>(), eface_upto);
 		eface_upto = f_end;
 		HIP_OK(hipEventRecord(cx.ev_x[2], cx.stream2));
@@ -400,7 +421,7 @@ struct SpanUploader : SpanDone {
 	{
 		size_t left = 0;
 		{ std::lock_guard<std::mutex> g(mu); closing = true; left = todo.size(); }
-		cv.notify_one();
+		cv.notify_all();
 		if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  replay returned: %zu finished span(s) still to be copied\n", ms_since(t_origin), left);
 		// The replay is over and its thread has nothing to do: it takes spans off the list too, on the stream the attribute planes
 		// were decoded on (idle by now) -- the one uploader used to be 25 - 30 ms behind at this point on the configs[3] mesh.
@@ -419,9 +440,9 @@ struct SpanUploader : SpanDone {
 					faces_up += r.f1 - r.f0; he_up += r.h1 - r.h0; v_up += r.v1 - r.v0;
 				}
 				if (cx.stream3) HIP_OK(hipStreamSynchronize(cx.stream3));
-			} catch (...) { if (worker.joinable()) worker.join(); throw; }
+			} catch (...) { for (auto &w : worker) if (w.joinable()) w.join(); throw; }
 		}
-		if (worker.joinable()) worker.join();
+		for (auto &w : worker) if (w.joinable()) w.join();
 		if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  every span is on the device\n", ms_since(t_origin));
 		if (error) return false;
 		if (faces_up != m.nf || he_up != m.declared_ne || v_up != order_v.size() || order_v.size() != m.nv) return false;
@@ -440,7 +461,7 @@ struct SpanUploader : SpanDone {
 		m.twins_pending = false;
 		cx.resident_token = 0;
 	}
-	~SpanUploader() { { std::lock_guard<std::mutex> g(mu); closing = true; todo.clear(); } cv.notify_one(); if (worker.joinable()) worker.join(); }
+	~SpanUploader() { { std::lock_guard<std::mutex> g(mu); closing = true; todo.clear(); } cv.notify_all(); for (auto &w : worker) if (w.joinable()) w.join(); }
 };
 
 static bool pipelined_decode_applicable(const Mesh &m, const std::vector<RestartPoint> &restarts, const PlaneView *conn,
@@ -880,8 +901,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// never, 1 always).  Measured on MI355X: a wavefront alone on its SIMD issues an instruction every ~5.5 cycles, so a lane-per-
 	// stream wave takes ~1 900 cycles per step of 64 symbols however many waves there are (up to one per SIMD), and the wave-per-
 	// stream kernel ~420 cycles per symbol of a stream, ~190 per symbol and SIMD once several waves share a SIMD (scalar port):
-	// many short streams (connectivity planes: 16 000 streams of 16 Ki symbols for configs[3]: 26 -> 14 ms) go to the lanes, a few
-	// thousand long ones (its attribute planes: 5 200 streams of 128 Ki symbols) stay with a wave each.
+	// many short streams (the 53 000 streams of 16 Ki symbols of configs[3] under the default chunk policy, chunked.cpp) go to the
+	// lanes, a few thousand long ones (a container written with 128 Ki-symbol chunks: 5 200 attribute streams) stay with a wave each.
 	static const int lanes_mode = [] { const char *e = getenv("HRY_DECODE_LANES"); return e ? atoi(e) : -1; }();
 	auto decode_streams = [&](hipStream_t st, uint32_t first, uint32_t n, uint32_t n_for_lanes) {
 		bool lanes = lanes_mode > 0;
@@ -889,8 +910,9 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 			uint64_t total = 0, longest = 0;
 			for (uint32_t j = first; j < first + n_for_lanes; ++j) { total += jobs[j].n; longest = std::max<uint64_t>(longest, jobs[j].n); }
 			const double simds = 1024.0, lane_waves = (n_for_lanes + 63) / 64;
+			const double lane_slots = 512.0;   // 64 KB of counts per lane-wave: two of them in a compute unit's 160 KB of LDS
 			const double t_waves = std::max((double)longest * 420.0, (double)total * 190.0 / simds);
-			const double t_lanes = (double)longest * 1900.0 * std::ceil(lane_waves / simds);
+			const double t_lanes = (double)longest * 1900.0 * std::ceil(lane_waves / lane_slots);
 			lanes = t_lanes < t_waves;
 		}
 		const uint32_t nl = lanes ? n_for_lanes : 0u;

@@ -327,7 +327,8 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 	int ndeg = 0, onlydeg = 0;
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++ndeg; onlydeg = (int)d; }
 	const int fixed_numtri = ndeg <= 1 ? onlydeg - 2 : -1;
-	const unsigned n_threads = host_threads();
+	unsigned n_threads = host_threads();
+	if (const char *e = getenv("HRY_REPLAY_THREADS")) { const int v = atoi(e); if (v > 0) n_threads = (unsigned)v; }   // (development: the spans' threads beside the uploaders')
 	if (restarts.empty() || n_threads < 2 || m.nf < parallel_min_faces() || counters.size() != restarts.size()) {
 		if (fixed_numtri == 1 && !getenv("HRY_GENERIC_REPLAY")) {
 			// triangles only: the lean loop (cbm_replay.hpp: replay_triangles), same results

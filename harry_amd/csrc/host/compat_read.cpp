@@ -10,7 +10,11 @@
 // formats/hry/models.h:27-237 (context inventory, order-conditioned operation model), formats/hry/io.h:168-231,
 // formats/hry/attrcode.h:443-501 (attribute symbol order), bitstream.h:14-40 (MSB-first bits, ones past the end).
 #include "cbm_replay.hpp"
+#include "perf_counters.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace hry {
@@ -384,10 +388,22 @@ void read_general_planes(Mesh &m, const OrderVec &order_v, const GenHostPlanes &
 void read_compat_stream(const uint8_t *p, size_t n, Mesh &m, OrderVec &order_v, std::vector<uint32_t> &seg_start,
                         std::vector<uint32_t> &seg_level, std::vector<uint8_t> &vplanes, std::vector<uint8_t> &fplanes)
 {
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) {
+		if (trace) fprintf(stderr, "[hry v0.1] %9.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+	};
 	Live lv(p, p + n, m);
 	cut_border_replay_with(m, lv, order_v, seg_start, seg_level);
+	mark("connectivity decoded and replayed");
+	PerfCounters pc;
+	const bool perf = getenv("HRY_PERF") != nullptr;
+	if (perf) pc.start();
 	read_list(lv, m.lists[1], false, (uint32_t)order_v.size(), vplanes);
+	if (perf) { pc.stop(); pc.report("v0.1 vertex records (per symbol)", (double)order_v.size() * (1 + (vplanes.size() / std::max<size_t>(1, order_v.size())))); }
+	mark("vertex records' symbols decoded");
 	read_list(lv, m.lists[0], false, m.nf, fplanes);
+	mark("face records' symbols decoded");
 }
 
 }   // namespace hry

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HRY_ABI_VERSION 4
+#define HRY_ABI_VERSION 5
 
 enum {
     HRY_OK = 0,
@@ -177,6 +177,8 @@ int hry_mesh_upload(hry_ctx *ctx, hry_mesh *m);
  * exactly as the reference's encoder mutates it (cbm/encoder.h:150,193-198). */
 int hry_encode(hry_ctx *ctx, hry_mesh *m, const hry_opts *opts, uint8_t **out, size_t *out_len);
 int hry_decode(hry_ctx *ctx, const uint8_t *hry, size_t n, const hry_opts *opts, hry_mesh **out);
+/* every buffer the library hands out (*out of the encoders, writers and hry_merge) goes back through hry_free and nothing else:
+ * large ones belong to the library's recycling pool (their pages serve the next call), not to the C library's heap */
 void hry_free(void *p);
 /* host-only: what a .hry file is, without decoding it.  info[0] minor version (1 reference stream, 2 chunked, 3 sharded chunked),
  * [1] header bytes, [2] vertices, [3] faces, [4] half-edges, [5] symbols per chunk and plane (first segment; 0 for v0.1),

@@ -29,15 +29,22 @@ def cx():
 
 
 def magic_of(t: int):
-    """Reference implementation (Python ints) of the reciprocal the device precomputes for a context total."""
+    """Reference implementation (Python ints) of the reciprocal the device precomputes for a context total: floor(R / t) ==
+    (R * magic) >> (64 + shift) for every R <= 2^63 (codec_math.hpp: make_magic)."""
     if t < 2:
         return 0, 0
     k = t.bit_length() - 1
     if t & (t - 1) == 0:
-        return 0, k - 1
-    q, r = divmod(1 << (64 + k), t)
-    m = 2 * q + (1 if 2 * r >= t else 0)
-    return (m + 1) & (2 ** 64 - 1), k
+        return 1 << 63, k - 1
+    return ((1 << (64 + k)) // t + 1) & (2 ** 64 - 1), k
+
+
+def test_reciprocal_reference_is_exact_on_the_coders_range():
+    rng = np.random.default_rng(3)
+    for t in [2, 3, 5, 7, 255, 256, 257, 65535, 65537, 2 ** 31 - 1, 2 ** 31 + 1, 2 ** 32 - 1] + [int(x) for x in rng.integers(2, 2 ** 32, 200)]:
+        m, sh = magic_of(t)
+        for R in [1 << 63, (1 << 63) - 1, (1 << 62) + 1, t * ((1 << 63) // t), t * ((1 << 63) // t) - 1] + [int(x) for x in rng.integers(1 << 62, 1 << 63, 20)]:
+            assert (R * m) >> (64 + sh) == R // t, (t, R)
 
 
 # ---------------------------------------------------------------- end to end vs the reference's bytes

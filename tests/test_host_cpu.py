@@ -28,7 +28,7 @@ def test_abi_exports_every_declared_symbol():
     L = nat.load()
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.hry_abi_version() == 4
+    assert L.hry_abi_version() == 5
 
 
 def test_no_device_fails_loudly():
@@ -427,3 +427,17 @@ def test_polygon_ply_reader_and_writer_on_threads(threads, face_props, monkeypat
             hc.Mesh.from_ply(bytes(bad))
         with pytest.raises(hc.HryError):
             hc.Mesh.from_ply(ply[:-9])
+
+
+def test_range_reciprocal_equals_division(tmp_path):
+    """r = floor(range / total) of the compat recurrence (coder.h:69-70) through the precomputed reciprocal: exact for every range <= 2^63."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "magic_check")
+    subprocess.run([cxx, "-O2", "-std=c++17", "-I", os.path.join(root, "harry_amd", "csrc", "device"), os.path.join(root, "tests", "tools", "magic_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 bad" in r.stdout, r.stdout + r.stderr
