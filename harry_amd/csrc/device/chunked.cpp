@@ -282,13 +282,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, nullptr, d_nbytes, cx.d_coffs.as<uint64_t>(), nullptr, false);
 	uint64_t total_bytes = 0;
 	HIP_OK(hipMemcpyAsync(&total_bytes, cx.d_coffs.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, cx.stream));
-	HIP_OK(hipStreamSynchronize(cx.stream));
-	HRY_MARK(t_all, "streams coded");
-	cx.d_cout.ensure(std::max<size_t>(total_bytes, 16));
-	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, cx.d_bytes.as<uint8_t>(), d_nbytes, cx.d_coffs.as<uint64_t>(), cx.d_cout.as<uint8_t>(), true);
-	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
-
-	// ---- container
+	// (while the device codes the streams: 17 ms of host work for the 151 741 components of the configs[3] mesh)
 	// directory: chunk sizes, plane lengths, restart points of the connectivity replay, stream lengths
 	std::vector<RestartCounters> rcounters;
 	const std::vector<RestartPoint> restarts = select_restart_points(w.marks, w.named, rcounters);
@@ -298,6 +292,14 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 		counter_dir.push_back((uint32_t)cs.size());
 		for (const auto &c : cs) { counter_dir.push_back(c.first); counter_dir.push_back(c.second); }
 	}
+	HRY_MARK(t_all, "  restart points selected");
+	HIP_OK(hipStreamSynchronize(cx.stream));
+	HRY_MARK(t_all, "streams coded");
+	cx.d_cout.ensure(std::max<size_t>(total_bytes, 16));
+	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, cx.d_bytes.as<uint8_t>(), d_nbytes, cx.d_coffs.as<uint64_t>(), cx.d_cout.as<uint8_t>(), true);
+	HIP_OK(hipEventRecord(cx.ev[5], cx.stream));
+
+	// ---- container
 	static_assert(sizeof(RestartPoint) == kRestartWords * 4, "restart points are written as they lie in memory");
 	const size_t dir_prior = 12 + 4 * planes.size();
 	const size_t dir_restart = dir_prior + prior_dir.size();
@@ -315,7 +317,26 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	if (nrs) memcpy(o + dir_restart + 4, restarts.data(), sizeof(RestartPoint) * (size_t)nrs);
 	if (!counter_dir.empty()) memcpy(o + dir_counters, counter_dir.data(), 4 * counter_dir.size());
 	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
-	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
+	// the streams' bytes: a copy into pageable memory holds its thread while the runtime stages it (13 GB/s: 22 ms for the 292 MB
+	// of the configs[3] mesh), so a large payload comes down in three parts on three threads and streams
+	constexpr int kDownParts = Context::kUploadStreams;
+	if (total_bytes >= ((uint64_t)32 << 20) && !getenv("HRY_ONE_DOWNLOAD")) {
+		HIP_OK(hipEventRecord(cx.ev[6], cx.stream));   // packed
+		for (int k = 0; k < kDownParts; ++k) {
+			if (!cx.up_stream[k]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[k], hipStreamNonBlocking));
+			HIP_OK(hipStreamWaitEvent(cx.up_stream[k], cx.ev[6], 0));
+		}
+		std::exception_ptr failed[kDownParts];
+		parallel_for((unsigned)kDownParts, [&](unsigned k) {
+			try {
+				HIP_OK(hipSetDevice(cx.device));
+				const uint64_t b = (total_bytes * k / kDownParts) & ~(uint64_t)4095, e = k + 1 == (unsigned)kDownParts ? total_bytes : (total_bytes * (k + 1) / kDownParts) & ~(uint64_t)4095;
+				if (e > b) HIP_OK(hipMemcpyAsync(o + dir + b, cx.d_cout.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, cx.up_stream[k]));
+				HIP_OK(hipStreamSynchronize(cx.up_stream[k]));
+			} catch (...) { failed[k] = std::current_exception(); }
+		});
+		for (auto &f : failed) if (f) std::rethrow_exception(f);
+	} else if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	HRY_MARK(t_all, "container on the host");
 	if (sharded) { const uint64_t seg_len = out.size() - seg_begin; memcpy(out.data() + seg_len_at, &seg_len, 8); }
