@@ -53,6 +53,25 @@ static const int kConnPlanes = 21;
 
 static int conn_init_kind(int i) { return i == 0 ? INIT_IOP : i == 11 ? INIT_NT0 : i == 12 ? INIT_NT1 : i >= 13 ? INIT_OP : INIT_ONES; }
 
+// Work lists of the chain kernel (k_unpredict2: one wavefront per list and attribute component walks the list's components one
+// after the other).  A component is a list of its own -- unless it is tiny: the slivers that non-manifold edges and vertices
+// split off are components of a triangle or two, 19 000 of them in one GPU's share of configs[3] beside its 128 real ones, and
+// a workgroup each made 57 000 workgroups of 384 chains' work: 13.7 ms of chains against 12.2 with consecutive tiny components
+// sharing a list, up to kTinyRun of them, and 10.7 with the owners a chain has waited for remembered (unpredict.hip: wait_owner;
+// 8.5 ms without any slivers -- scripts/chain_slivers.py).  triples: (first vertex, end, component) per component that owns vertices; starts: index of every list's first triple.
+static void group_chain_lists(const uint32_t *triples, uint32_t n, uint32_t first_index, std::vector<uint32_t> &starts)
+{
+	constexpr uint32_t kTiny = 64, kTinyRun = 64;
+	static const bool merge = getenv("HRY_CHAIN_NO_LIST_MERGE") == nullptr;
+	uint32_t run = 0;   // tiny components in the list at hand (0: the next component starts a list)
+	for (uint32_t i = 0; i < n; ++i) {
+		const bool tiny = merge && triples[3 * i + 1] - triples[3 * i] < kTiny;
+		if (!tiny || run == 0 || run >= kTinyRun) { starts.push_back(first_index + i); run = 0; }
+		run = tiny ? run + 1 : 0;
+	}
+	starts.push_back(first_index + n);
+}
+
 // The float / 32-bit reconstruction chains of a mesh of many components, launched in BATCHES of whole components (round 4): a
 // component's chain needs its connectivity on the device, the residual planes decoded, and the components before it launched --
 // not the end of the replay.  The tables the chains read (lists, every component's first vertex, the progress words) are laid out
@@ -63,7 +82,7 @@ struct ChainBatches {
 	const ListDesc ldv;
 	const uint8_t *d_vplanes;
 	uint32_t nvc, ncomp_max;
-	uint32_t comps_done = 0, v_done = 0, lists_done = 0;
+	uint32_t comps_done = 0, v_done = 0, lists_done = 0, triples_done = 0;
 	bool conn_adopted = false;             // the caller has set the context's view of the connectivity (no adopt_conn, which waits for the stream)
 	uint32_t v_first_batch = 0;            // vertices of the batches launched beside the replay
 	hipEvent_t first_done = nullptr;       // ... and the event behind them on their stream (nullptr: none)
@@ -107,20 +126,23 @@ struct ChainBatches {
 			const uint32_t b = first[i], e = i + 1 < n ? first[i + 1] : v_end;
 			if (b != e) { t.push_back(b); t.push_back(e); t.push_back(comps_done + i); ++nl; }
 		}
+		std::vector<uint32_t> starts;
+		group_chain_lists(t.data(), nl, triples_done, starts);
+		const uint32_t n_lists = (uint32_t)starts.size() - 1;
 		const size_t off_at = t.size();
-		for (uint32_t i = 0; i <= nl; ++i) t.push_back(lists_done + i);
+		t.insert(t.end(), starts.begin(), starts.end());
 		const size_t seg_at = t.size();
 		t.insert(t.end(), first, first + n);
 		t.push_back(v_end);   // (the next batch overwrites it with its first component's start: the same number)
-		if (nl) HIP_OK(hipMemcpyAsync(d_lists + (size_t)3 * lists_done, t.data(), (size_t)3 * nl * 4, hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(d_off + lists_done, t.data() + off_at, ((size_t)nl + 1) * 4, hipMemcpyHostToDevice, st));
+		if (nl) HIP_OK(hipMemcpyAsync(d_lists + (size_t)3 * triples_done, t.data(), (size_t)3 * nl * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_off + lists_done, t.data() + off_at, ((size_t)n_lists + 1) * 4, hipMemcpyHostToDevice, st));
 		HIP_OK(hipMemcpyAsync(d_segstart + comps_done, t.data() + seg_at, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
 		const ConnView cv = cx.conn_view();
 		launch_slice_prepare(st, cv, cx.d_order_v.as<uint32_t>(), nvc, v_done, v_end, d_cand, d_ncand, nullptr);
-		for (uint32_t done = 0; done < nl; done += 65535)   // a launch holds at most 65535 x 8 lists' worth of workgroups
+		for (uint32_t done = 0; done < n_lists; done += 65535)   // a launch holds at most 65535 x 8 lists' worth of workgroups
 			launch_unpredict2(st, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, nullptr, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
-			                  d_lists, d_off + lists_done + done, std::min(65535u, nl - done), d_segstart, ncomp_max, d_flags);
-		comps_done += n; lists_done += nl; v_done = v_end;
+			                  d_lists, d_off + lists_done + done, std::min(65535u, n_lists - done), d_segstart, ncomp_max, d_flags);
+		comps_done += n; lists_done += n_lists; triples_done += nl; v_done = v_end;
 	}
 };
 
@@ -196,8 +218,13 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 			uint32_t n_lists = 0;
 			for (uint32_t k = 0; k < nseg; ++k)
 				if (seg_start[k] != seg_start[k + 1]) { table.push_back(seg_start[k]); table.push_back(seg_start[k + 1]); table.push_back(k); ++n_lists; }
-			const size_t off_at = table.size();
-			for (uint32_t i = 0; i <= n_lists; ++i) table.push_back(i);
+			{
+				std::vector<uint32_t> starts;
+				group_chain_lists(table.data(), n_lists, 0, starts);
+				n_lists = (uint32_t)starts.size() - 1;
+				table.insert(table.end(), starts.begin(), starts.end());
+			}
+			const size_t off_at = table.size() - ((size_t)n_lists + 1);
 			const size_t segstart_at = table.size();
 			table.insert(table.end(), seg_start.begin(), seg_start.end());
 			const size_t done_at = table.size();

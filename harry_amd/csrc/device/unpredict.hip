@@ -385,21 +385,28 @@ constexpr uint32_t kNoLane = 64;
 // it needs also waits for the next tile's prefetch, +4.5 % on a lone chain, and the configs[3] share gained nothing from it).
 // Workgroups start in the order of their indices and a chain only ever waits for a component before it in coding order (= a lower workgroup index), which is therefore running
 // or finished: the waits cannot deadlock.  Bounded like every other wait of the chains (g_chain_timeout).
-struct CrossSync { const uint32_t *seg_start; uint32_t nseg; uint32_t *done; };   // done[attribute component * nseg + component of the mesh]
+// cache: eight 64-bit words of the chain's LDS, or nullptr -- owners it waited for, as (first vertex, progress seen) in ONE word each
+// (whichever lane writes one, every lane reads a pair that belongs together): a vertex inside a remembered owner's finished part
+// needs neither the owner search (fourteen dependent loads in a table of 19 000 components) nor a look at the progress word.
+struct CrossSync { const uint32_t *seg_start; uint32_t nseg; uint32_t *done; unsigned long long *cache; };   // done[attribute component * nseg + component of the mesh]
 __device__ uint32_t g_chain_timeout;
 constexpr uint32_t kSpinLimit = 1u << 22;
 __device__ __attribute__((noinline)) void wait_owner(const CrossSync &xs, int c, uint32_t id)
 {
 	if (!xs.done) return;
-	uint32_t lo = 0, hi = xs.nseg;   // owner: the last component that starts at or before the vertex
-	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (xs.seg_start[mid] <= id) lo = mid; else hi = mid; }
+	if (xs.cache) { const unsigned long long e = xs.cache[(id >> 2) & 7u]; if (id >= (uint32_t)e && id < (uint32_t)(e >> 32)) return; }
+	uint32_t lo = 0, hi = xs.nseg, first = 0;   // owner: the last component that starts at or before the vertex
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, at = xs.seg_start[mid]; if (at <= id) { lo = mid; first = at; } else hi = mid; }
 	const uint32_t *flag = xs.done + (size_t)c * xs.nseg + lo;
-	uint32_t spins = 0;
+	uint32_t spins = 0, seen;
 #pragma nounroll
-	while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= id) {
-		__builtin_amdgcn_s_sleep(8);
-		if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 4u); break; }
+	while ((seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= id) {
+		// (a few quick looks, then one every 3 us: thousands of slivers wait for the END of the component they hang on, each
+		// look is a load past the caches, and the chains that do the work share that path)
+		if (spins < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(127);
+		if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 4u); return; }
 	}
+	if (xs.cache && lo) xs.cache[(id >> 2) & 7u] = ((unsigned long long)seen << 32) | first;
 }
 // value of a vertex reconstructed by another chain or long ago by this one: past this compute unit's L1 (the line may have been
 // cached while a neighbouring attribute component of the same record was still unwritten)
@@ -1162,13 +1169,16 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 	if (list >= n_lists) return;
 	const int c = sel.comp[r >> 3];
 	TopoD tp{ cv };
+	CrossSync xl = xs;   // ... with the chain's remembered owners behind the ring and the rows (wait_owner)
+	xl.cache = (unsigned long long*)((uint8_t*)ring_raw2 + ring_bytes + 64 * kCandMax * 3 * 4);
+	if (threadIdx.x < 8) xl.cache[threadIdx.x] = 0xffffffffull;   // (first vertex 2^32 - 1, nothing seen: no vertex is inside)
 	// segs: triples (first decode rank, end, component of the mesh)
 	for (uint32_t k = list_off[list]; k < list_off[list + 1]; ++k) {
 		const uint32_t b = segs[3 * k], e = segs[3 * k + 1];
 		if (b < e)
 			unpredict2_component<T>(tp, order_v, nvtx, b, e, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
 			                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T),
-			                        (uint32_t*)((uint8_t*)ring_raw2 + ring_bytes), xs, c, segs[3 * k + 2]);
+			                        (uint32_t*)((uint8_t*)ring_raw2 + ring_bytes), xl, c, segs[3 * k + 2]);
 		raise_flag(xs, c, segs[3 * k + 2], e);
 	}
 }
@@ -1726,7 +1736,7 @@ __global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uin
 	if (blockIdx.x & 7u) return;
 	const int c = sel.comp[blockIdx.x >> 3];
 	TopoD tp{ cv };
-	const CrossSync none{ nullptr, 0, nullptr };   // one component: no other chain to wait for
+	const CrossSync none{ nullptr, 0, nullptr, nullptr };   // one component: no other chain to wait for
 	unpredict3_segment<T>(tp, order_v, nvtx, v_begin, v_end, cand, ncand, crec, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c], ring3, ring_floor, sync3, none, c);
 }
 
@@ -1861,7 +1871,7 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
                        const uint32_t *seg_start, uint32_t nseg, uint32_t *done)
 {
 	if (!nvtx || !ld.ncomp || !n_lists) return;
-	const CrossSync xs{ seg_start, nseg, done };
+	const CrossSync xs{ seg_start, nseg, done, nullptr };
 	auto go3 = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
@@ -1875,7 +1885,7 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 	// compute unit: a chain is a lone wavefront that issues an instruction every five or six cycles, two of them on a SIMD hardly
 	// slow each other, and a source older than the ring is simply read from the records (HRY_CHAIN_RING_KB: 8, 16 or 32)
 	static const uint32_t ring_kb_env = [] { const char *e = getenv("HRY_CHAIN_RING_KB"); const int v = e ? atoi(e) : 0; return v == 8 || v == 16 || v == 32 ? (uint32_t)v : 0u; }();
-	const uint32_t ring_bytes = (ring_kb_env ? ring_kb_env : (uint64_t)n_lists * (uint32_t)ld.ncomp > 1024u ? 16u : 32u) * 1024u, lds_bytes = ring_bytes + 64 * kCandMax * 3 * 4;
+	const uint32_t ring_bytes = (ring_kb_env ? ring_kb_env : (uint64_t)n_lists * (uint32_t)ld.ncomp > 1024u ? 16u : 32u) * 1024u, lds_bytes = ring_bytes + 64 * kCandMax * 3 * 4 + 64;   // ring, rows, remembered owners
 	auto go = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
