@@ -127,13 +127,14 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	const ListDesc ldv = m.general ? ListDesc{} : make_list_desc(m.lists[1]), ldf = m.general ? ListDesc{} : make_list_desc(m.lists[0]);   // (general bindings: general_planes_encode)
 	if (chunk_syms <= 0) {
-		// default policy: 8 Ki symbols per chunk; larger meshes get larger chunks as long as a lane's worth of streams remains for
-		// every SIMD (64 x 1024: the decoder runs a stream per LANE once there are that many, k_chunk_decode_lanes, and its time is
-		// the longest stream's).  The 100 M-triangle configs[3] mesh: 16 Ki (53 000 streams; 128 Ki until round 4, when a stream
-		// took a wavefront: attribute streams' decode 99.6 -> 36.0 ms, encode 37.4 -> 26.7, container + 0.33 %)
+		// default policy: 8 Ki symbols per chunk; larger meshes get larger chunks as long as some thousands of streams remain to
+		// fill the 1024 SIMDs -- up to 32 Ki symbols: beyond a few thousand streams the decoder runs a stream per LANE
+		// (k_chunk_decode_lanes), 512 wavefronts of them at a time, and its time is the longest stream's (32 Ki symbols: 26 ms).
+		// The 100 M-triangle configs[3] mesh in one piece had 128 Ki-symbol chunks until round 4 (5 200 attribute streams of a
+		// wavefront each, 100 ms); every smaller mesh keeps the size it had
 		uint64_t total = (uint64_t)w.n_conn + (uint64_t)vc * ldv.nplanes + (uint64_t)fc * ldf.nplanes;
 		if (m.general) for (const AttrList &L : m.lists) total += (uint64_t)L.count * L.coded_bytes();
-		while (CH < (1u << 18) && total / CH > 65536) CH <<= 1;
+		while (CH < (1u << 15) && total / CH > 8192) CH <<= 1;
 	}
 
 	// ---- connectivity planes on the host side: 5 groups (split into bytes on the device) + 8 operation planes
@@ -317,26 +318,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	if (nrs) memcpy(o + dir_restart + 4, restarts.data(), sizeof(RestartPoint) * (size_t)nrs);
 	if (!counter_dir.empty()) memcpy(o + dir_counters, counter_dir.data(), 4 * counter_dir.size());
 	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
-	// the streams' bytes: a copy into pageable memory holds its thread while the runtime stages it (13 GB/s: 22 ms for the 292 MB
-	// of the configs[3] mesh), so a large payload comes down in three parts on three threads and streams
-	constexpr int kDownParts = Context::kUploadStreams;
-	if (total_bytes >= ((uint64_t)32 << 20) && !getenv("HRY_ONE_DOWNLOAD")) {
-		HIP_OK(hipEventRecord(cx.ev[6], cx.stream));   // packed
-		for (int k = 0; k < kDownParts; ++k) {
-			if (!cx.up_stream[k]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[k], hipStreamNonBlocking));
-			HIP_OK(hipStreamWaitEvent(cx.up_stream[k], cx.ev[6], 0));
-		}
-		std::exception_ptr failed[kDownParts];
-		parallel_for((unsigned)kDownParts, [&](unsigned k) {
-			try {
-				HIP_OK(hipSetDevice(cx.device));
-				const uint64_t b = (total_bytes * k / kDownParts) & ~(uint64_t)4095, e = k + 1 == (unsigned)kDownParts ? total_bytes : (total_bytes * (k + 1) / kDownParts) & ~(uint64_t)4095;
-				if (e > b) HIP_OK(hipMemcpyAsync(o + dir + b, cx.d_cout.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, cx.up_stream[k]));
-				HIP_OK(hipStreamSynchronize(cx.up_stream[k]));
-			} catch (...) { failed[k] = std::current_exception(); }
-		});
-		for (auto &f : failed) if (f) std::rethrow_exception(f);
-	} else if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
+	if (total_bytes) HIP_OK(hipMemcpyAsync(o + dir, cx.d_cout.p, total_bytes, hipMemcpyDeviceToHost, cx.stream));
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	HRY_MARK(t_all, "container on the host");
 	if (sharded) { const uint64_t seg_len = out.size() - seg_begin; memcpy(out.data() + seg_len_at, &seg_len, 8); }
