@@ -453,7 +453,9 @@ struct SpanUploader : SpanDone {
 		// The replay is over and its thread has nothing to do: it takes spans off the list too, on the stream the attribute planes
 		// were decoded on (idle by now) -- the one uploader used to be 25 - 30 ms behind at this point on the configs[3] mesh.
 		// (No more batches from here on: the caller launches what is left.)
-		if (!error) {
+		bool failed;
+		{ std::lock_guard<std::mutex> g(mu); failed = (bool)error; }   // (the uploaders set it under the same lock)
+		if (!failed) {
 			try {
 				for (;;) {
 					Range r;

@@ -91,6 +91,36 @@ int main(int argc, char **argv)
 					}
 				}
 				if (m->nf) { WalkResult w; cut_border_walk(*m, w); }
+				if (m->nf && !m->general) {
+					// the walk of the chunked profile (no operation model): on the host threads where the mesh has several components
+					// (the test sets HRY_PARALLEL_MIN_FACES=1), its components found by the threads' union-find, coded where they belong
+					std::unique_ptr<Mesh> m2(ext == ".ply" ? mesh_from_ply(data.data(), data.size()) : mesh_from_obj(data.data(), data.size(), dir.c_str()));
+					ensure_twins(*m2);
+					WalkResult w2;
+					cut_border_walk(*m2, w2, false);
+					if (w2.order_f.size() != m2->nf) throw Error(HRY_E_INTERNAL, "plain walk: a face was not coded");
+					// ... and a shard of it walked in place on the whole mesh's arrays (the in-process executor's walk)
+					std::unique_ptr<Mesh> m3(ext == ".ply" ? mesh_from_ply(data.data(), data.size()) : mesh_from_obj(data.data(), data.size(), dir.c_str()));
+					ensure_twins(*m3);
+					ShardPlan light;
+					shard_plan(*m3, 2, light, true);
+					int ud = 0;
+					const bool uniform = m3->uniform_degree(ud) && (ud == 3 || ud == 4);
+					BigVec<uint32_t> eface;
+					if (!uniform && light.A.eface.size() != m3->ne()) {
+						eface.resize(m3->ne());
+						for (uint32_t f = 0; f < m3->nf; ++f) for (uint32_t h = m3->face_off[f]; h < m3->face_off[f + 1]; ++h) eface[h] = f;
+					}
+					WalkState marks(m3->nv, m3->nf);
+					for (uint32_t sidx = 0; sidx < 2; ++sidx) {
+						ComponentAnalysis part;
+						ShardInfo info;
+						shard_components(light, sidx, part, info);
+						if (!part.ncomp) continue;
+						WalkResult w3;
+						cut_border_walk_in_place(*m3, part, uniform ? nullptr : eface.empty() ? light.A.eface.data() : eface.data(), marks, w3);
+					}
+				}
 				// the same text, damaged: a clean error or a mesh
 				for (int k = 0; k < 16; ++k) {
 					std::vector<uint8_t> bad = data;

@@ -35,8 +35,46 @@ def test_host_code_under_sanitizers(tmp_path):
     g = os.path.join(ROOT, "tests", "golden")
     files = [f for f in sorted(glob.glob(g + "/*.ply") + glob.glob(g + "/obj/*.obj")) if ".dec." not in f]   # the reference's own
     files += sorted(glob.glob(g + "/*.hry") + glob.glob(g + "/obj/*.hry"))                                   # outputs do not all re-read
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    # (the walks of the chunked profile and of a shard in place run on four host threads whatever the mesh's size)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", HRY_PARALLEL_MIN_FACES="1", HRY_HOST_THREADS="4")
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe, *files], capture_output=True, text=True, env=env, timeout=800)
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (r.stdout + r.stderr)[-4000:]
+    assert r.stdout.strip() == "ok %d files" % len(files)
+
+
+@pytest.mark.timeout(900)
+def test_threaded_host_code_under_thread_sanitizer(tmp_path):
+    """The walks that run on several host threads (components found by the threads' union-find, coded where they belong; a shard
+    walked in place), the threaded readers and the pool under gcc's ThreadSanitizer, on the multi-component goldens and two generated
+    meshes with non-manifold slivers."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    flags = ["-O1", "-g1", "-std=c++17", "-fsanitize=thread", "-pthread"]
+    probe = subprocess.run(["g++", *flags, "-x", "c++", "-", "-o", str(tmp_path / "probe")], input="int main(){return 0;}", capture_output=True, text=True)
+    if probe.returncode != 0 or subprocess.run([str(tmp_path / "probe")], capture_output=True).returncode != 0:
+        pytest.skip("ThreadSanitizer is not usable here")
+    units = [(os.path.join(HOST, s + ".cpp"), str(tmp_path / (s + ".o"))) for s in SOURCES]
+    units.append((os.path.join(ROOT, "tests", "native", "host_asan_driver.cpp"), str(tmp_path / "driver.o")))
+
+    def compile_one(u):
+        return subprocess.run(["g++", *flags, "-c", u[0], "-o", u[1]], capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        for r in ex.map(compile_one, units):
+            assert r.returncode == 0, r.stderr[-3000:]
+    exe = str(tmp_path / "host_tsan")
+    r = subprocess.run(["g++", *flags, *[u[1] for u in units], "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    from harry_amd import meshgen as mg
+    files = [os.path.join(ROOT, "tests", "golden", n) for n in ("multi5.ply", "nonmanifold.ply", "torus_mixed.ply")]
+    for i, m in enumerate((mg.with_nonmanifold(mg.multi_component(12, 30, 31, seed=5, polys="mixed"), 40, 20, seed=4),
+                           mg.with_nonmanifold(mg.multi_component(6, 30, 31, seed=6), 10, 5, seed=2))):
+        files.append(str(tmp_path / f"generated{i}.ply"))
+        with open(files[-1], "wb") as f:
+            f.write(m.to_ply())
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 history_size=4", HRY_PARALLEL_MIN_FACES="1", HRY_HOST_THREADS="6")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe, *files], capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-4000:]
     assert r.stdout.strip() == "ok %d files" % len(files)
