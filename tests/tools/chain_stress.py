@@ -30,6 +30,8 @@ only = os.environ.get("STRESS_ONLY")
 failed = 0
 for it in range(n_meshes):
     kind = int(rng.integers(0, 7 if os.environ.get("STRESS_BIG") else 6))
+    if os.environ.get("STRESS_SLIVERS") and rng.integers(0, 2):
+        kind = 7   # many components with slivers coded before and after the components they hang on (work lists of several tiny components, owners remembered by the chains)
     sigma = float(10.0 ** rng.uniform(-5, -0.5))
     seed = int(rng.integers(1, 99))
     polys = ["tri", "quad", "mixed"][int(rng.integers(0, 3))]
@@ -57,6 +59,8 @@ for it in range(n_meshes):
         base = mg.with_nonmanifold(mg.torus(r(0, 30, 120), r(1, 30, 120), polys=polys, seed=seed, sigma=sigma), r(2, 1, 40), r(3, 1, 20), seed=seed)
     elif kind == 5:
         base = mg.with_colors(mg.torus(r(0, 30, 160), r(1, 30, 160), normals=True, seed=seed, sigma=sigma))
+    elif kind == 7:
+        base = mg.with_nonmanifold(mg.multi_component(r(0, 2, 40), r(1, 6, 40), r(2, 6, 40), polys=polys, seed=seed), r(2, 20, 400), r(3, 10, 200), seed=seed)
     else:   # large enough for the pipelined decode with its production parameters (STRESS_BIG=1)
         base = mg.torus(r(0, 370, 520), r(1, 370, 520), polys="tri", seed=seed, sigma=sigma) if dims[2] & 1 else mg.grid(r(0, 370, 520), r(1, 370, 520), seed=seed, sigma=sigma)
         lossless, mode = False, 2
