@@ -112,6 +112,7 @@ def load():
     L.hry_shard_plan.restype = C.c_int; L.hry_shard_plan.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hry_plan_free.argtypes = [vp]
     L.hry_walk_run_shard.restype = C.c_int; L.hry_walk_run_shard.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.hry_analysis_check.restype = C.c_int; L.hry_analysis_check.argtypes = [vp, vp]
     L.hry_plan_ncomponents.restype = C.c_uint32; L.hry_plan_ncomponents.argtypes = [vp]
     L.hry_plan_ngroups.restype = C.c_uint32; L.hry_plan_ngroups.argtypes = [vp]
     L.hry_plan_triangles.restype = C.c_uint64; L.hry_plan_triangles.argtypes = [vp, C.c_int]
@@ -136,8 +137,8 @@ def load():
     L.hry_decode_sharded.restype = C.c_int
     L.hry_decode_sharded.argtypes = [C.POINTER(vp), C.c_int, vp, sz, C.POINTER(Opts), C.POINTER(vp), C.POINTER(ShardTiming)]
     L.hry_container_check.restype = C.c_int; L.hry_container_check.argtypes = [vp, sz, C.POINTER(C.c_int)]
-    if L.hry_abi_version() != 5:
-        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 5: rebuild it")
+    if L.hry_abi_version() != 6:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.hry_abi_version()}, this binding expects 6: rebuild it")
     _lib = L
     return L
 

@@ -328,6 +328,10 @@ class Codec:
             nat.load().hry_ctx_destroy(self.h)
             self.h = None
 
+    def analysis_check(self, mesh: "Mesh") -> None:
+        """Development / tests: the component analysis of `mesh` on the device against the host's, table by table (hry_analysis_check)."""
+        nat.check(nat.load().hry_analysis_check(self.h, mesh.h))
+
     __del__ = close
 
     def bounds(self, mesh: Mesh):

@@ -352,6 +352,30 @@ int hry_walk_run_shard(hry_mesh *m, const hry_plan *p, int shard, hry_walk **out
 		*out = w.release();
 	});
 }
+int hry_analysis_check(hry_ctx *ctx, hry_mesh *m)
+{
+	if (!ctx || !m) { g_last_error = "invalid argument"; return HRY_E_ARG; }
+	return guarded([&] {
+		check_codable(m->m);
+		if (m->m.general || !m->m.shard.seeds.empty()) throw Error(HRY_E_ARG, "analysis check: a mesh in the PLY layout that is not a shard");
+		if (m->m.device_token == 0 || m->m.device_token != ctx->cx.resident_token) ctx->cx.upload_mesh(m->m);
+		ComponentAnalysis D, H;
+		device_component_analysis(ctx->cx, m->m, D);
+		analyse_components(m->m, H);
+		if (D.ncomp != H.ncomp) throw Error(HRY_E_INTERNAL, "analysis: " + std::to_string(D.ncomp) + " components on the device, " + std::to_string(H.ncomp) + " on the host");
+		if (D.ncomp < 2) return;
+		auto same = [&](const char *what, const std::vector<uint32_t> &d, const std::vector<uint32_t> &h) {
+			if (d.size() != h.size()) throw Error(HRY_E_INTERNAL, std::string("analysis: size of ") + what);
+			for (size_t i = 0; i < d.size(); ++i)
+				if (d[i] != h[i]) throw Error(HRY_E_INTERNAL, std::string("analysis: ") + what + "[" + std::to_string(i) + "] = " + std::to_string(d[i]) + " on the device, " + std::to_string(h[i]) + " on the host");
+		};
+		same("seed", D.seed, H.seed); same("n_faces", D.n_faces, H.n_faces); same("n_halfedges", D.n_halfedges, H.n_halfedges);
+		same("fresh", D.fresh, H.fresh); same("group", D.group, H.group);
+		same("face_lo", D.face_lo, H.face_lo); same("face_hi", D.face_hi, H.face_hi); same("vtx_lo", D.vtx_lo, H.vtx_lo); same("vtx_hi", D.vtx_hi, H.vtx_hi);
+		// (component NUMBERS are the roots' order in both: by_rank / rank_of agree too)
+		same("by_rank", D.by_rank, H.by_rank);
+	});
+}
 uint32_t hry_plan_ncomponents(const hry_plan *p) { return p ? p->p.A.ncomp : 0; }
 uint32_t hry_plan_ngroups(const hry_plan *p)
 {

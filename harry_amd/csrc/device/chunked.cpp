@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <thread>
 
 #include "codec_math.hpp"
 #include "context.hpp"
@@ -62,6 +64,14 @@ static uint32_t stream_words(uint32_t n, uint32_t t0)
 	while ((2u << lg) <= tmax) ++lg;   // floor(log2(tmax))
 	uint64_t bits = (uint64_t)n * (lg + 2) + 64;
 	return (uint32_t)(bits / 32 + 4);
+}
+
+// faces from which the components are analysed on the device (HRY_DEVICE_ANALYSIS_MIN_FACES; 0xffffffff = never): below, the
+// sequential walk of the first component and the host's passes over the rest cost less than the launches and round trips
+static uint32_t device_analysis_min_faces()
+{
+	const char *e = getenv("HRY_DEVICE_ANALYSIS_MIN_FACES");   // (read per call: the tests change it)
+	return e ? (uint32_t)strtoul(e, nullptr, 10) : (4u << 20);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -118,8 +128,39 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	auto t_walk = Clock::now();
 	WalkResult w;
 	w.numtri_positions = false;     // (places in ONE symbol sequence: the chunked planes have none)
-	if (in_place) cut_border_walk_in_place(*in_place->whole, *in_place->part, in_place->eface, *in_place->marks, w);
-	else cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
+	bool walked = false;
+	if (in_place) { cut_border_walk_in_place(*in_place->whole, *in_place->part, in_place->eface, *in_place->marks, w); walked = true; }
+	else if (!m.general && m.shard.seeds.empty() && m.nf >= device_analysis_min_faces() && host_threads() > 1) {
+		// A large mesh: its components -- labels, coding order, sizes, new vertices, ties -- are found on the device, where the
+		// connectivity is resident (analysis.cpp: 1.9 CPU-seconds of host passes at 100 M triangles), and all of them are walked on
+		// the host threads where they lie, from the first one on; a mesh of ONE component takes the sequential loop as before
+		ComponentAnalysis A;
+		std::exception_ptr failed;
+		std::thread analysis([&] { try { device_component_analysis(cx, m, A); } catch (...) { failed = std::current_exception(); } });
+		// (beside it, on the host: what the walk loops need whatever the analysis says)
+		int ud = 0;
+		const bool uniform = m.uniform_degree(ud) && (ud == 3 || ud == 4);
+		BigVec<uint32_t> eface;   // mixed degrees: the face of every half-edge
+		std::unique_ptr<WalkState> marks;
+		try {
+			if (!uniform) {
+				eface.resize(m.ne());
+				const unsigned nt = host_threads();
+				parallel_for(nt, [&](unsigned t) {
+					const uint32_t b = (uint32_t)((uint64_t)m.nf * t / nt), e = (uint32_t)((uint64_t)m.nf * (t + 1) / nt);
+					for (uint32_t f = b; f < e; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface[h] = f;
+				});
+			}
+			marks.reset(new WalkState(m.nv, m.nf, host_threads()));
+		} catch (...) { analysis.join(); throw; }
+		analysis.join();
+		if (failed) std::rethrow_exception(failed);
+		if (A.ncomp > 1) {
+			cut_border_walk_in_place(m, A, uniform ? nullptr : eface.data(), *marks, w);
+			walked = true;
+		}
+	}
+	if (!walked) cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	HRY_MARK(t_all, "walked");
 	if (in_place && in_place->arrays_ready) in_place->arrays_ready();

@@ -154,6 +154,8 @@ void upload_general(Context &cx, Mesh &m);     // connectivity + every list + th
 // codec entry points (codec.cpp / chunked.cpp)
 // records: m holds the lists' formats and counts only, their records are those of *records and nothing else travels to the device
 void device_bounds(Context &cx, Mesh &m, const Mesh *records = nullptr);
+// analysis.cpp: host/cbm_walk.cpp's analyse_components on the device, for a mesh resident on cx (every table but the per-face labels)
+void device_component_analysis(Context &cx, const Mesh &m, ComponentAnalysis &A);
 void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool clear);
 std::vector<std::vector<uint8_t>> requant_targets(const Mesh &m, const hry_quant *q, size_t nq, bool clear);   // validated request -> quantisation of every component
 dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to);

@@ -155,5 +155,196 @@ void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twi
 	hipLaunchKernelGGL(k_twin_match, dim3(blocks_for(nv, 256)), dim3(256), 0, st, cv, nv, start, ent, twin, over);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The connected components of the faces and what the walk on several host threads needs to know of them before it starts
+// (host/cbm_walk.cpp: analyse_impl -- which faces form a component, the coding order, how many faces / half-edges / new vertices
+// each component brings, which components share a vertex), on the device where the connectivity is resident anyway: on the
+// host these passes are 1.9 CPU-seconds for the 100 M-triangle configs[3] mesh -- 117 ms on the 16 CPUs a box grants, as much
+// as the walks themselves.  Data-parallel integer work over 300 M half-edges and 50 M vertices with random access into tables
+// of a few hundred megabytes: atomics on label / vertex words, per-component sums aggregated per wavefront first (faces and
+// vertices of one component are neighbours in memory: a wavefront holds one or two components).
+//   k_cc_init / k_cc_hook / k_cc_flatten   lock-free union-find, the root of a set is its smallest face (what the host's is)
+//   k_cc_roots + k_scan_*                  dense component numbers in face order of the roots
+//   k_cc_face_stats                        faces, half-edges, face interval, smallest key of the start-face sequence per component
+//   k_cc_vertex_first / _ties / _stats     the first component (coding order) at every vertex, components tied by a shared
+//                                          vertex (a second union-find over components), new vertices and vertex interval
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uf_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t uf_find(uint32_t *par, uint32_t x)
+{
+	// parents only ever decrease and a face that has got a parent never becomes a root again: a stale read is a valid (higher)
+	// ancestor, and the halving store -- a plain one -- can only replace an ancestor by another ancestor
+	uint32_t p = uf_load(par + x);
+	while (p != x) {
+		const uint32_t g = uf_load(par + p);
+		if (g != p) __hip_atomic_store(par + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		x = p; p = g;
+	}
+	return x;
+}
+__device__ __forceinline__ void uf_unite(uint32_t *par, uint32_t a, uint32_t b)
+{
+	for (;;) {
+		a = uf_find(par, a); b = uf_find(par, b);
+		if (a == b) return;
+		if (a > b) { const uint32_t t = a; a = b; b = t; }
+		const uint32_t old = atomicCAS(par + b, b, a);   // b is a root still: it hangs under the smaller root
+		if (old == b) return;
+		b = old;
+	}
+}
+__global__ __launch_bounds__(256) void k_cc_init(uint32_t *label, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) label[i] = i;
+}
+// one thread per face: an edge with a twin on both sides is taken from its larger face (whose root is looked up once for all its
+// edges), a one-sided twin from the side that has it
+__global__ __launch_bounds__(256) void k_cc_hook(ConnView cv, uint32_t *label)
+{
+	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= cv.nf) return;
+	Topo tp{ cv };
+	const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
+	for (uint32_t h = h0; h < h1; ++h) {
+		const uint32_t o = cv.twin[h];
+		if (o == h || o >= cv.ne) continue;
+		const uint32_t b = tp.face(o);
+		if (b == f || (b > f && cv.twin[o] == h)) continue;
+		uf_unite(label, f, b);
+	}
+}
+// every label becomes its root.  No halving here: a halving store into an element another thread has already set to its root would
+// leave an ancestor there; an element's own store is the only one it gets, and a root read is final (the unions are over)
+__global__ __launch_bounds__(256) void k_cc_flatten(uint32_t *label, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t x = i, p = uf_load(label + x);
+	while (p != x) { x = p; p = uf_load(label + x); }
+	if (x != i) __hip_atomic_store(label + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void k_cc_roots(const uint32_t *label, uint32_t n, uint32_t *flag)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) flag[i] = label[i] == i ? 1u : 0u;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
+__device__ __forceinline__ unsigned long long wave_min64(unsigned long long v)
+{
+	for (int d = 32; d; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+	return v;
+}
+// spans: the start-face sequence as (lowest face, highest face, position of the span's first face, ascending?) sorted by the
+// lowest face (host/cbm_walk.cpp: StartFaces::index_blocks); label[] holds a face's root on entry, its component number on exit
+__global__ __launch_bounds__(256) void k_cc_face_stats(ConnView cv, uint32_t *label, const uint32_t *num, const uint32_t *spans, uint32_t nspans,
+                                                       uint32_t *nfaces, uint32_t *nhe, uint32_t *flo, uint32_t *fhi, unsigned long long *first_key)
+{
+	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool valid = f < cv.nf;
+	uint32_t c = 0xffffffffu, deg = 0;
+	unsigned long long key = ~0ull;
+	if (valid) {
+		c = num[label[f]];
+		label[f] = c;
+		deg = cv.eface ? cv.foff[f + 1] - cv.foff[f] : cv.udeg;
+		uint32_t a = 0, b = nspans;
+		while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (spans[4 * mid] <= f) a = mid; else b = mid; }
+		const uint32_t lo = spans[4 * a], hi = spans[4 * a + 1], pos0 = spans[4 * a + 2], asc = spans[4 * a + 3];
+		const uint32_t pos = pos0 + (asc ? f - lo : hi - f);
+		key = f == 0 ? 0ull : (((unsigned long long)pos + 1ull) << 32) | f;   // the reference takes face 0 first whatever the set's order (writer.cc:40-46)
+	}
+	const int lane = threadIdx.x & 63;
+	unsigned long long todo = __ballot(valid);
+	while (todo) {
+		const int leader = __ffsll((long long)todo) - 1;
+		const uint32_t c0 = (uint32_t)__shfl((int)c, leader, 64);
+		const bool mine = valid && c == c0;
+		const unsigned long long mask = __ballot(mine);
+		const uint32_t n = (uint32_t)__popcll(mask), sdeg = wave_sum(mine ? deg : 0u);
+		const unsigned long long kmin = wave_min64(mine ? key : ~0ull);
+		const int last = 63 - __clzll((long long)mask);
+		const uint32_t f_first = (uint32_t)__shfl((int)f, leader, 64), f_last = (uint32_t)__shfl((int)f, last, 64);
+		if (lane == leader) {
+			atomicAdd(nfaces + c0, n); atomicAdd(nhe + c0, sdeg);
+			atomicMin(flo + c0, f_first); atomicMax(fhi + c0, f_last + 1u);
+			atomicMin(first_key + c0, kmin);
+		}
+		todo &= ~mask;
+	}
+}
+// comp[] = component number of every face (k_cc_face_stats), rank_of[] = its place in the coding order; one thread per face
+__global__ __launch_bounds__(256) void k_cc_vertex_first(ConnView cv, const uint32_t *comp, const uint32_t *rank_of, uint32_t *vfirst)
+{
+	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= cv.nf) return;
+	const uint32_t k = rank_of[comp[f]];
+	const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
+	for (uint32_t h = h0; h < h1; ++h) atomicMin(vfirst + cv.org[h], k);
+}
+__global__ __launch_bounds__(256) void k_cc_vertex_ties(ConnView cv, const uint32_t *comp, const uint32_t *rank_of, const uint32_t *vfirst, uint32_t *tie)
+{
+	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= cv.nf) return;
+	const uint32_t k = rank_of[comp[f]];
+	const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
+	for (uint32_t h = h0; h < h1; ++h) {
+		const uint32_t first = vfirst[cv.org[h]];
+		if (first != k) uf_unite(tie, first, k);
+	}
+}
+__global__ __launch_bounds__(256) void k_cc_vertex_stats(const uint32_t *vfirst, uint32_t nv, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t k = v < nv ? vfirst[v] : 0xffffffffu;
+	const bool valid = k != 0xffffffffu;
+	const int lane = threadIdx.x & 63;
+	unsigned long long todo = __ballot(valid);
+	while (todo) {
+		const int leader = __ffsll((long long)todo) - 1;
+		const uint32_t k0 = (uint32_t)__shfl((int)k, leader, 64);
+		const unsigned long long mask = __ballot(valid && k == k0);
+		const int last = 63 - __clzll((long long)mask);
+		const uint32_t v_first = (uint32_t)__shfl((int)v, leader, 64), v_last = (uint32_t)__shfl((int)v, last, 64);
+		if (lane == leader) { atomicAdd(fresh + k0, (uint32_t)__popcll(mask)); atomicMin(vlo + k0, v_first); atomicMax(vhi + k0, v_last + 1u); }
+		todo &= ~mask;
+	}
+}
+
+size_t components_workspace_bytes(uint32_t nv, uint32_t nf) { return ((size_t)3 * nf + nv + blocks_for(nf, kScanBlock) + 16) * 4; }
+// stage 1: label[f] = root of f's component, num = exclusive scan of the root flags (num[nf] = number of components)
+void launch_components_label(hipStream_t st, const ConnView &cv, void *ws, uint32_t **label_out, uint32_t **num_out)
+{
+	uint32_t *label = (uint32_t*)ws, *flag = label + cv.nf, *num = flag + cv.nf, *sums = num + cv.nf + 1;
+	*label_out = label; *num_out = num;
+	if (!cv.nf) return;
+	const unsigned nb = blocks_for(cv.nf, kScanBlock);
+	hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
+	if (cv.ne) hipLaunchKernelGGL(k_cc_hook, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, label);
+	hipLaunchKernelGGL(k_cc_flatten, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
+	hipLaunchKernelGGL(k_cc_roots, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf, flag);
+	hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kScanBlock), 0, st, flag, cv.nf, sums);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, sums, nb);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanBlock), 0, st, flag, cv.nf, sums, num);
+}
+// stage 2: per component (numbered in face order of the roots; tables zeroed / set to their neutral values by the caller)
+void launch_components_faces(hipStream_t st, const ConnView &cv, uint32_t *label, const uint32_t *num, const uint32_t *spans, uint32_t nspans,
+                             uint32_t *nfaces, uint32_t *nhe, uint32_t *flo, uint32_t *fhi, uint64_t *first_key)
+{
+	if (cv.nf) hipLaunchKernelGGL(k_cc_face_stats, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, label, num, spans, nspans, nfaces, nhe, flo, fhi, (unsigned long long*)first_key);
+}
+// stage 3: per component in coding order (rank_of: component number -> rank; vfirst 0xff-filled, tie[k] = k, fresh 0, vlo 0xff, vhi 0 by the caller)
+void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t ncomp, const uint32_t *comp, const uint32_t *rank_of,
+                                uint32_t *vfirst, uint32_t *tie, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi)
+{
+	if (!cv.ne || !nv) return;
+	hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(ncomp, 256)), dim3(256), 0, st, tie, ncomp);
+	hipLaunchKernelGGL(k_cc_vertex_first, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, vfirst);
+	hipLaunchKernelGGL(k_cc_vertex_ties, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, (const uint32_t*)vfirst, tie);
+	hipLaunchKernelGGL(k_cc_flatten, dim3(blocks_for(ncomp, 256)), dim3(256), 0, st, tie, ncomp);
+	hipLaunchKernelGGL(k_cc_vertex_stats, dim3(blocks_for(nv, 256)), dim3(256), 0, st, (const uint32_t*)vfirst, nv, fresh, vlo, vhi);
+}
+
 }   // namespace dev
 }   // namespace hry

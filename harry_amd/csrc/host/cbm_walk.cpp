@@ -1412,6 +1412,17 @@ std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark>
 	return out;
 }
 
+// the start-face sequence of a mesh of nf faces as spans sorted by their lowest face: (lowest, highest, position of the span's first
+// face in the sequence, 1 = ascending) -- what a face's place in the coding order is computed from (StartFaces::position)
+void start_face_spans(uint32_t nf, std::vector<uint32_t> &spans)
+{
+	BigVec<Gone> no_gone;
+	StartFaces seq(nf, no_gone);
+	seq.derive_order(); seq.index_blocks();
+	spans.clear();
+	for (const StartFaces::Span &sp : seq.spans) { spans.push_back(sp.lo); spans.push_back(sp.hi); spans.push_back(sp.first_pos); spans.push_back(sp.asc ? 1u : 0u); }
+}
+
 void analyse_components(const Mesh &m, ComponentAnalysis &A)
 {
 	if (m.partial) throw Error(HRY_E_ARG, "partially decoded mesh (a share of a sharded container): only its runs are real");

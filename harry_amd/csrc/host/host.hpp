@@ -138,6 +138,7 @@ struct ComponentAnalysis {
 	BigVec<uint32_t> eface;                      // mixed polygon degrees only: face of every half-edge (kept for the shard planner)
 };
 void analyse_components(const Mesh &m, ComponentAnalysis &A);
+void start_face_spans(uint32_t nf, std::vector<uint32_t> &spans);   // (lowest face, highest face, position of the first, ascending) per span, sorted by the lowest face
 // Some components of `m`, walked where they lie (no sub-mesh): `part` lists them in coding order (seed faces of m, sizes, the
 // vertices each introduces, groups as ranks inside the list); vertex indices start at 0 with the list's first component -- what a
 // shard of m codes (shard.cpp: shard_components).  `st` may be shared with other calls walking OTHER groups of the same mesh at

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HRY_ABI_VERSION 5
+#define HRY_ABI_VERSION 6
 
 enum {
     HRY_OK = 0,
@@ -279,6 +279,10 @@ int hry_walk_run_plain(hry_mesh *m, hry_walk **out);
  * of hry_encode_sharded does instead of walking an extracted sub-mesh: same symbols as hry_walk_run_plain of hry_shard_extract's
  * mesh, "order_v" / "order_f" as half-edges of the WHOLE mesh.  Mutates the mesh's twins like hry_encode. */
 int hry_walk_run_shard(hry_mesh *m, const hry_plan *plan, int shard, hry_walk **out);
+/* development / tests: the component analysis of the mesh (connected components, coding order, sizes, new vertices, ties -- what
+ * hry_encode of a large mesh computes on the device before its walk, analysis.cpp) by the device AND by the host, compared table by
+ * table; 0 = equal (or fewer than two components), HRY_E_INTERNAL with the first difference otherwise.  Uploads the mesh. */
+int hry_analysis_check(hry_ctx *ctx, hry_mesh *m);
 size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr);
 void hry_walk_free(hry_walk *w);
 

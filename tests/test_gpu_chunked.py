@@ -307,3 +307,51 @@ def test_pipelined_decode_after_another_mesh(cx, monkeypatch):
         monkeypatch.setenv("HRY_PIPELINE_FACES", str(faces))
         monkeypatch.setenv("HRY_PIPELINE_SLICE", str(slice_))
         same_mesh(cx.read_hry(got), ref_dec)
+
+
+# ---- the component analysis on the device (analysis.cpp) against the host's (cbm_walk.cpp: analyse_components) ----------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["multi", "multi_tri", "slivers", "slivers_quad", "shuffled", "one", "hub"])
+def test_device_component_analysis_equals_the_hosts(cx, case):
+    """connected components (one-sided twins and non-manifold slivers included), coding order by the reference's start-face sequence,
+    faces / half-edges / new vertices per component, face and vertex intervals, groups of components that share a vertex"""
+    rng = np.random.default_rng(11)
+    if case == "multi":
+        g = mg.multi_component(40, 9, 11, seed=3, polys="mixed")
+    elif case == "multi_tri":
+        g = mg.multi_component(25, 12, 7, seed=4)
+    elif case == "slivers":
+        g = mg.with_nonmanifold(mg.multi_component(30, 10, 12, seed=5, polys="mixed"), 120, 60, seed=4)
+    elif case == "slivers_quad":
+        g = mg.with_nonmanifold(mg.multi_component(12, 14, 9, seed=6, polys="quad"), 50, 25, seed=2)
+    elif case == "shuffled":   # faces in random order: components are not contiguous in memory
+        b = mg.with_nonmanifold(mg.multi_component(20, 8, 9, seed=7, polys="mixed"), 40, 20, seed=3)
+        deg = b.degrees.astype(np.int64); offs = np.concatenate(([0], np.cumsum(deg)))
+        perm = rng.permutation(b.nf)
+        idx = np.concatenate([b.indices[offs[f]:offs[f + 1]] for f in perm])
+        g = mg.Mesh(b.verts, b.degrees[perm], idx.astype(np.uint32), None)
+    elif case == "one":
+        g = mg.torus(30, 40, polys="mixed")
+    else:   # many components that all touch ONE vertex (a hub): one group
+        parts = [mg.grid(4, 5, seed=s) for s in range(12)]
+        b = mg.concat(parts)
+        idx = b.indices.copy()
+        nvp = parts[0].nv
+        for k in range(1, 12):
+            idx[idx == k * nvp] = 0        # the first vertex of every part becomes vertex 0
+        g = mg.Mesh(b.verts, b.degrees, idx, None)
+    m = hc.Mesh.from_arrays(g.verts, g.degrees, g.indices)
+    cx.analysis_check(m)
+
+
+@pytest.mark.gpu
+def test_encode_with_the_device_analysis_equals_the_oracle(cx, monkeypatch):
+    """the walk from the device's tables (every component in place on the host threads) gives the container the oracle writes"""
+    monkeypatch.setenv("HRY_DEVICE_ANALYSIS_MIN_FACES", "1")
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
+    for seed, polys in ((3, "mixed"), (4, "tri"), (5, "quad")):
+        g = mg.with_nonmanifold(mg.multi_component(20, 10, 12, seed=seed, polys=polys), 60, 30, seed=seed)
+        ply = g.to_ply()
+        a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+        got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+        assert got == o.encode_chunked(hc.container_info(got)["chunk_syms"]).data

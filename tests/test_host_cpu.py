@@ -28,7 +28,7 @@ def test_abi_exports_every_declared_symbol():
     L = nat.load()
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.hry_abi_version() == 5
+    assert L.hry_abi_version() == 6
 
 
 def test_no_device_fails_loudly():
