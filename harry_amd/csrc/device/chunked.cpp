@@ -135,25 +135,29 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 		// connectivity is resident (analysis.cpp: 1.9 CPU-seconds of host passes at 100 M triangles), and all of them are walked on
 		// the host threads where they lie, from the first one on; a mesh of ONE component takes the sequential loop as before
 		ComponentAnalysis A;
-		std::exception_ptr failed;
-		std::thread analysis([&] { try { device_component_analysis(cx, m, A); } catch (...) { failed = std::current_exception(); } });
-		// (beside it, on the host: what the walk loops need whatever the analysis says)
+		// (beside it, on a host thread of its own: what the walk loops need whatever the analysis says.  The device calls stay on
+		// this thread: a short-lived thread that has used the runtime leaves the next pageable copy of this one 25 ms slower)
 		int ud = 0;
 		const bool uniform = m.uniform_degree(ud) && (ud == 3 || ud == 4);
 		BigVec<uint32_t> eface;   // mixed degrees: the face of every half-edge
 		std::unique_ptr<WalkState> marks;
-		try {
-			if (!uniform) {
-				eface.resize(m.ne());
-				const unsigned nt = host_threads();
-				parallel_for(nt, [&](unsigned t) {
-					const uint32_t b = (uint32_t)((uint64_t)m.nf * t / nt), e = (uint32_t)((uint64_t)m.nf * (t + 1) / nt);
-					for (uint32_t f = b; f < e; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface[h] = f;
-				});
-			}
-			marks.reset(new WalkState(m.nv, m.nf, host_threads()));
-		} catch (...) { analysis.join(); throw; }
-		analysis.join();
+		std::exception_ptr failed;
+		const unsigned nt = host_threads();
+		std::thread tables([&] {
+			try {
+				set_thread_budget(nt);
+				if (!uniform) {
+					eface.resize(m.ne());
+					parallel_for(nt, [&](unsigned t) {
+						const uint32_t b = (uint32_t)((uint64_t)m.nf * t / nt), e = (uint32_t)((uint64_t)m.nf * (t + 1) / nt);
+						for (uint32_t f = b; f < e; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface[h] = f;
+					});
+				}
+				marks.reset(new WalkState(m.nv, m.nf, nt));
+			} catch (...) { failed = std::current_exception(); }
+		});
+		try { device_component_analysis(cx, m, A); } catch (...) { tables.join(); throw; }
+		tables.join();
 		if (failed) std::rethrow_exception(failed);
 		if (A.ncomp > 1) {
 			cut_border_walk_in_place(m, A, uniform ? nullptr : eface.data(), *marks, w);
