@@ -283,16 +283,42 @@ __global__ __launch_bounds__(256) void k_cc_vertex_first(ConnView cv, const uint
 	const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
 	for (uint32_t h = h0; h < h1; ++h) atomicMin(vfirst + cv.org[h], k);
 }
-__global__ __launch_bounds__(256) void k_cc_vertex_ties(ConnView cv, const uint32_t *comp, const uint32_t *rank_of, const uint32_t *vfirst, uint32_t *tie)
+// A corner whose vertex another component reached first ties the two.  Such corners are rare (three in a thousand on the configs[3]
+// mesh) but every wavefront of 64 faces holds one, and a union inline -- searches, a compare-and-swap, retries -- kept all 64 lanes
+// waiting for it: 13 ms at 100 M triangles against 2.7 ms for the pass before it, which touches the same words.  The pairs are
+// appended to a list instead (one atomic per wavefront and corner round) and united by a kernel of their own; what does not fit
+// in the list is united on the spot.
+__global__ __launch_bounds__(256) void k_cc_vertex_ties(ConnView cv, const uint32_t *comp, const uint32_t *rank_of, const uint32_t *vfirst, uint32_t *tie,
+                                                        uint2 *pairs, uint32_t cap, uint32_t *count)
 {
 	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= cv.nf) return;
-	const uint32_t k = rank_of[comp[f]];
-	const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
-	for (uint32_t h = h0; h < h1; ++h) {
-		const uint32_t first = vfirst[cv.org[h]];
-		if (first != k) uf_unite(tie, first, k);
+	const bool live = f < cv.nf;
+	const uint32_t k = live ? rank_of[comp[f]] : 0u;
+	const uint32_t h0 = !live ? 0u : cv.eface ? cv.foff[f] : f * cv.udeg, h1 = !live ? 0u : cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
+	const int lane = threadIdx.x & 63;
+	uint32_t rounds = h1 - h0;
+	for (int d = 32; d; d >>= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, d, 64));
+	for (uint32_t i = 0; i < rounds; ++i) {
+		const uint32_t h = h0 + i;
+		const uint32_t first = h < h1 ? vfirst[cv.org[h]] : k;
+		const bool hit = first != k;
+		const unsigned long long mask = __ballot(hit);
+		if (!mask) continue;
+		uint32_t base = 0;
+		const int leader = __ffsll((long long)mask) - 1;
+		if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+		base = (uint32_t)__shfl((int)base, leader, 64);
+		if (hit) {
+			const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+			if (at < cap) pairs[at] = make_uint2(first, k);
+			else uf_unite(tie, first, k);
+		}
 	}
+}
+__global__ __launch_bounds__(256) void k_cc_tie_pairs(const uint2 *pairs, uint32_t cap, const uint32_t *count, uint32_t *tie)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < min(*count, cap)) uf_unite(tie, pairs[i].x, pairs[i].y);
 }
 __global__ __launch_bounds__(256) void k_cc_vertex_stats(const uint32_t *vfirst, uint32_t nv, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi)
 {
@@ -312,7 +338,8 @@ __global__ __launch_bounds__(256) void k_cc_vertex_stats(const uint32_t *vfirst,
 	}
 }
 
-size_t components_workspace_bytes(uint32_t nv, uint32_t nf) { return ((size_t)3 * nf + nv + blocks_for(nf, kScanBlock) + 16) * 4; }
+constexpr uint32_t kTiePairs = 1u << 22;   // capacity of the tie list (8 bytes each; the configs[3] mesh at 100 M triangles notes 0.9 M)
+size_t components_workspace_bytes(uint32_t nv, uint32_t nf) { return ((size_t)3 * nf + nv + blocks_for(nf, kScanBlock) + 16) * 4 + (size_t)kTiePairs * 8 + 64; }
 // stage 1: label[f] = root of f's component, num = exclusive scan of the root flags (num[nf] = number of components)
 void launch_components_label(hipStream_t st, const ConnView &cv, void *ws, uint32_t **label_out, uint32_t **num_out)
 {
@@ -339,9 +366,14 @@ void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv,
                                 uint32_t *vfirst, uint32_t *tie, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi)
 {
 	if (!cv.ne || !nv) return;
+	// the tie list behind the vertex words (components_workspace_bytes), 8-byte aligned; its counter in front of it
+	uint32_t *count = (uint32_t*)(((uintptr_t)(vfirst + nv) + 7) & ~(uintptr_t)7);
+	uint2 *pairs = (uint2*)(count + 2);
+	(void)hipMemsetAsync(count, 0, 8, st);
 	hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(ncomp, 256)), dim3(256), 0, st, tie, ncomp);
 	hipLaunchKernelGGL(k_cc_vertex_first, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, vfirst);
-	hipLaunchKernelGGL(k_cc_vertex_ties, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, (const uint32_t*)vfirst, tie);
+	hipLaunchKernelGGL(k_cc_vertex_ties, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, (const uint32_t*)vfirst, tie, pairs, kTiePairs, count);
+	hipLaunchKernelGGL(k_cc_tie_pairs, dim3(blocks_for(kTiePairs, 256)), dim3(256), 0, st, (const uint2*)pairs, kTiePairs, (const uint32_t*)count, tie);
 	hipLaunchKernelGGL(k_cc_flatten, dim3(blocks_for(ncomp, 256)), dim3(256), 0, st, tie, ncomp);
 	hipLaunchKernelGGL(k_cc_vertex_stats, dim3(blocks_for(nv, 256)), dim3(256), 0, st, (const uint32_t*)vfirst, nv, fresh, vlo, vhi);
 }
