@@ -167,8 +167,9 @@ void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twi
 //   k_cc_init / k_cc_hook / k_cc_flatten   lock-free union-find, the root of a set is its smallest face (what the host's is)
 //   k_cc_roots + k_scan_*                  dense component numbers in face order of the roots
 //   k_cc_face_stats                        faces, half-edges, face interval, smallest key of the start-face sequence per component
-//   k_cc_vertex_first / _ties / _stats     the first component (coding order) at every vertex, components tied by a shared
-//                                          vertex (a second union-find over components), new vertices and vertex interval
+//   k_cc_vertex_first / _ties / _tie_pairs / _stats   the first component (coding order) at every vertex, components tied by a
+//                                          shared vertex (noted as pairs, then a second union-find over components), new
+//                                          vertices and vertex interval
 // ---------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t uf_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t uf_find(uint32_t *par, uint32_t x)
