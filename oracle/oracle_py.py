@@ -197,7 +197,7 @@ class Mesh:
         return Mesh(lib().ho_mesh_clone(self.h))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:   # (at interpreter shutdown the module's globals may be gone already)
             lib().ho_mesh_free(self.h)
             self.h = None
 
