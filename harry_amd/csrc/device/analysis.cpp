@@ -73,6 +73,7 @@ void device_component_analysis(Context &cx, const Mesh &m, ComponentAnalysis &A)
 	std::iota(by_rank.begin(), by_rank.end(), 0u);
 	std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
 	for (uint32_t k = 0; k < ncomp; ++k) rank_of[by_rank[k]] = k;
+	mark("  keys sorted (host)");
 	HIP_OK(hipMemcpyAsync(d_rank, rank_of.data(), (size_t)ncomp * 4, hipMemcpyHostToDevice, st));
 	dev::launch_components_vertices(st, cv, nv, ncomp, d_label, d_rank, d_vfirst, d_tie, d_fresh, d_vlo, d_vhi);
 	std::vector<uint32_t> by_rank_tab((size_t)4 * ncomp);   // group, new vertices, lowest vertex, highest + 1, by rank
