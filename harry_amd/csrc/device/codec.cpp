@@ -42,6 +42,7 @@ Context::~Context()
 	if (stream) (void)hipStreamSynchronize(stream);
 	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : slice_ev) if (e) (void)hipEventDestroy(e);
+	for (auto &e : chain_ev) if (e) (void)hipEventDestroy(e);
 	if (stream) (void)hipStreamDestroy(stream);
 	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
 	if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }

@@ -76,6 +76,10 @@ struct Context {
 	void *h_stage = nullptr;         // pinned staging memory for uploads that run next to a busy host thread (copies from
 	size_t h_stage_cap = 0;          // pageable memory make the runtime pin and unpin pages: TLB shootdowns for every thread)
 	hipEvent_t ev[8] = {};
+	// the float chains of a large mesh run in batches (unchunk.cpp: ChainBatches): a pair of timing events around every batch's
+	// launches, so that hry_timing.k_chain_ms is the sum over the batches of a decode (created on first use)
+	static constexpr int kChainBatchEvents = 16;
+	hipEvent_t chain_ev[2 * kChainBatchEvents] = {};
 	hry_timing timing{};
 
 	// resident mesh (hry_mesh_upload): attribute records and connectivity stay in HBM across encodes

@@ -46,7 +46,7 @@ void cand_table_reset(hipStream_t st, uint32_t *cand, uint32_t nvtx);
 void launch_slice_chain(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t nvtx, uint32_t v_begin, uint32_t v_end, const uint32_t *cand, const uint8_t *ncand,
                         const void *crec, const uint8_t *planes, const ListDesc &ld, uint8_t *rec);
 void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst);
-uint32_t chain_timeout_flags(hipStream_t st);
+uint32_t chain_timeout_flags(hipStream_t st, const uint32_t *gave_up = nullptr);
 }
 
 static const int kConnPlanes = 21;
@@ -85,6 +85,7 @@ struct ChainBatches {
 	uint32_t comps_done = 0, v_done = 0, lists_done = 0, triples_done = 0;
 	bool conn_adopted = false;             // the caller has set the context's view of the connectivity (no adopt_conn, which waits for the stream)
 	uint32_t v_first_batch = 0;            // vertices of the batches launched beside the replay
+	int n_timed = 0;                       // batches bracketed by cx.chain_ev pairs (elapsed_ms after the streams have drained)
 	hipEvent_t first_done = nullptr;       // ... and the event behind them on their stream (nullptr: none)
 	uint32_t *d_lists = nullptr, *d_off = nullptr, *d_segstart = nullptr, *d_flags = nullptr, *d_cand = nullptr;
 	uint8_t *d_ncand = nullptr;
@@ -104,14 +105,14 @@ struct ChainBatches {
 		d_cand = cx.d_cscratch.as<uint32_t>();
 		d_ncand = (uint8_t*)(d_cand + cand_words);
 		cand_table_reset(st, d_cand, nvc);
-		const size_t words = (size_t)3 * ncomp_max + ((size_t)ncomp_max + 1) + ((size_t)ncomp_max + 1) + (size_t)ldv.ncomp * ncomp_max;
+		const size_t words = (size_t)3 * ncomp_max + ((size_t)ncomp_max + 1) + ((size_t)ncomp_max + 1) + (size_t)ldv.ncomp * ncomp_max + 1;   // (+ the give-up word behind the flags)
 		cx.d_small.ensure(words * 4 + 64);
 		d_lists = cx.d_small.as<uint32_t>();
 		d_off = d_lists + (size_t)3 * ncomp_max;
 		d_segstart = d_off + ncomp_max + 1;
 		d_flags = d_segstart + ncomp_max + 1;
 		HIP_OK(hipMemsetAsync(d_segstart, 0xff, ((size_t)ncomp_max + 1) * 4, st));
-		HIP_OK(hipMemsetAsync(d_flags, 0, (size_t)ldv.ncomp * ncomp_max * 4, st));
+		HIP_OK(hipMemsetAsync(d_flags, 0, ((size_t)ldv.ncomp * ncomp_max + 1) * 4, st));
 	}
 	// components [comps_done, comps_done + n): first[i] = first vertex of component comps_done + i, v_end = first vertex behind them
 	void launch(hipStream_t st, const uint32_t *first, uint32_t n, uint32_t v_end)
@@ -139,10 +140,26 @@ struct ChainBatches {
 		HIP_OK(hipMemcpyAsync(d_segstart + comps_done, t.data() + seg_at, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
 		const ConnView cv = cx.conn_view();
 		launch_slice_prepare(st, cv, cx.d_order_v.as<uint32_t>(), nvc, v_done, v_end, d_cand, d_ncand, nullptr);
+		const bool timed = n_timed < Context::kChainBatchEvents;
+		if (timed) {
+			for (int k = 0; k < 2; ++k) if (!cx.chain_ev[2 * n_timed + k]) HIP_OK(hipEventCreate(&cx.chain_ev[2 * n_timed + k]));
+			HIP_OK(hipEventRecord(cx.chain_ev[2 * n_timed], st));
+		}
 		for (uint32_t done = 0; done < n_lists; done += 65535)   // a launch holds at most 65535 x 8 lists' worth of workgroups
 			launch_unpredict2(st, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand, nullptr, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>(),
 			                  d_lists, d_off + lists_done + done, std::min(65535u, n_lists - done), d_segstart, ncomp_max, d_flags);
+		if (timed) { HIP_OK(hipEventRecord(cx.chain_ev[2 * n_timed + 1], st)); ++n_timed; }
 		comps_done += n; lists_done += n_lists; triples_done += nl; v_done = v_end;
+	}
+	// the chain kernels' time over every batch of the decode (the batches' streams have drained)
+	double elapsed_ms() const
+	{
+		double sum = 0;
+		for (int i = 0; i < n_timed; ++i) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, cx.chain_ev[2 * i], cx.chain_ev[2 * i + 1]) == hipSuccess) sum += ms;
+		}
+		return sum;
 	}
 };
 
@@ -162,6 +179,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 	const uint32_t nvc = (uint32_t)order_v.size();
 	bool chain_timed = false;
 	size_t early_bytes = 0;
+	const uint32_t *d_gave_up = nullptr;   // the chains' give-up word of this decode (behind their flag table)
 	HRY_MARK(g_t0, "reconstruct: begin");
 	// connectivity up (unless it went up beside the replay: SpanUploader); the records are born on the device (zeroed there:
 	// uploading the host's zeros was a fifth of this copy)
@@ -205,6 +223,7 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 		}
 		HIP_OK(hipStreamSynchronize(cx.stream));
 		d_cand = batches->d_cand; d_ncand = batches->d_ncand;
+		d_gave_up = batches->d_flags + (size_t)batches->ldv.ncomp * batches->ncomp_max;
 		HRY_MARK(g_t0, "vertex chain done");
 	} else if (ldv.nplanes) {
 		if (unpredict2_applicable(ldv)) {
@@ -229,10 +248,11 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 			table.insert(table.end(), seg_start.begin(), seg_start.end());
 			const size_t done_at = table.size();
 			const bool scan_chain = unpredict3_wanted(ldv) && seg_start.size() >= 2;
-			cx.d_small.ensure((table.size() + (size_t)ldv.ncomp * nseg) * 4 + 64);
+			cx.d_small.ensure((table.size() + (size_t)ldv.ncomp * nseg + 1) * 4 + 64);   // (+ the give-up word behind the flags)
 			HIP_OK(hipMemcpyAsync(cx.d_small.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, cx.stream));
 			uint32_t *d_tab = cx.d_small.as<uint32_t>();
-			HIP_OK(hipMemsetAsync(d_tab + done_at, 0, (size_t)ldv.ncomp * nseg * 4, cx.stream));
+			HIP_OK(hipMemsetAsync(d_tab + done_at, 0, ((size_t)ldv.ncomp * nseg + 1) * 4, cx.stream));
+			d_gave_up = d_tab + done_at + (size_t)ldv.ncomp * nseg;
 			launch_candidates_ids(cx.stream, cv, cx.d_order_v.as<uint32_t>(), nvc, d_cand, d_ncand);
 			if (scan_chain) launch_chain_records(cx.stream, d_cand, d_ncand, nvc, d_tab + segstart_at, nseg, d_crec);
 			HIP_OK(hipEventRecord(cx.ev[7], cx.stream));
@@ -258,8 +278,9 @@ static void reconstruct_attributes(Context &cx, Mesh &mesh, const OrderVec &orde
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	if (early_bytes) HIP_OK(hipStreamSynchronize(cx.stream3));
 	HRY_MARK(g_t0, "records on the host");
-	if (uint32_t tf = chain_timeout_flags(cx.stream)) throw Error(HRY_E_INTERNAL, "reconstruction chain: hand-over between wavefronts timed out (flags " + std::to_string(tf) + ")");
-	cx.timing.k_chain_ms = chain_timed ? cx.elapsed(7, 0) : 0.0;
+	if (uint32_t tf = chain_timeout_flags(cx.stream, d_gave_up)) throw Error(HRY_E_INTERNAL, "reconstruction chain: hand-over between wavefronts timed out (flags " + std::to_string(tf) + ")");
+	// (in batches: the sum over every batch of this decode, the ones launched beside the replay included)
+	cx.timing.k_chain_ms = batches && batches->n_timed ? batches->elapsed_ms() : chain_timed ? cx.elapsed(7, 0) : 0.0;
 	if (cx.keep_stages) {
 		cx.stage_put_host("order_v", order_v.data(), order_v.size() * 4);
 		cx.stage_put("ncand", d_ncand, nvc);

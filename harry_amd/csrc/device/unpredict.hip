@@ -388,9 +388,16 @@ constexpr uint32_t kNoLane = 64;
 // cache: eight 64-bit words of the chain's LDS, or nullptr -- owners it waited for, as (first vertex, progress seen) in ONE word each
 // (whichever lane writes one, every lane reads a pair that belongs together): a vertex inside a remembered owner's finished part
 // needs neither the owner search (fourteen dependent loads in a table of 19 000 components) nor a look at the progress word.
-struct CrossSync { const uint32_t *seg_start; uint32_t nseg; uint32_t *done; unsigned long long *cache; };   // done[attribute component * nseg + component of the mesh]
+struct CrossSync { const uint32_t *seg_start; uint32_t nseg; uint32_t *done; unsigned long long *cache; uint32_t *gave_up; };   // done[attribute component * nseg + component of the mesh]; gave_up: the launch's own word behind that table
 __device__ uint32_t g_chain_timeout;
 constexpr uint32_t kSpinLimit = 1u << 22;
+// A wait for another component's chain is bounded in WALL-CLOCK time (the 100 MHz counter of s_memrealtime, looked at every 256
+// slow polls = every millisecond or so): two seconds -- the longest chain of the largest mesh this was built for takes 20 ms; a
+// context that shares a busy device (eight contexts on one GPU is a tested mode) is slowed down, not stopped.  Once a chain of
+// THIS decode has given up (the word behind its flag table: contexts that share a device do not see each other's) every other
+// wait ends at its next look and k_unpredict2 starts no further component: the grid drains in the time of the components under
+// way, and the host turns the word (and g_chain_timeout) into an error instead of returning a wrong mesh.
+constexpr unsigned long long kOwnerWaitTicks = 200000000ull;
 __device__ __attribute__((noinline)) void wait_owner(const CrossSync &xs, int c, uint32_t id)
 {
 	if (!xs.done) return;
@@ -399,12 +406,22 @@ __device__ __attribute__((noinline)) void wait_owner(const CrossSync &xs, int c,
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1, at = xs.seg_start[mid]; if (at <= id) { lo = mid; first = at; } else hi = mid; }
 	const uint32_t *flag = xs.done + (size_t)c * xs.nseg + lo;
 	uint32_t spins = 0, seen;
+	unsigned long long t_begin = 0;
 #pragma nounroll
 	while ((seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= id) {
 		// (a few quick looks, then one every 3 us: thousands of slivers wait for the END of the component they hang on, each
 		// look is a load past the caches, and the chains that do the work share that path)
 		if (spins < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(127);
-		if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 4u); return; }
+		if ((++spins & 255u) == 0u) {
+			if (xs.gave_up && __hip_atomic_load(xs.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // given up elsewhere in this decode: drain
+			const unsigned long long now = wall_clock64();
+			if (!t_begin) t_begin = now;
+			else if (now - t_begin > kOwnerWaitTicks || spins > kSpinLimit) {
+				atomicOr(&g_chain_timeout, 4u);
+				if (xs.gave_up) __hip_atomic_store(xs.gave_up, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+		}
 	}
 	if (xs.cache && lo) xs.cache[(id >> 2) & 7u] = ((unsigned long long)seen << 32) | first;
 }
@@ -1175,6 +1192,8 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 	// segs: triples (first decode rank, end, component of the mesh)
 	for (uint32_t k = list_off[list]; k < list_off[list + 1]; ++k) {
 		const uint32_t b = segs[3 * k], e = segs[3 * k + 1];
+		// a chain of this device gave up a wait: no further component is started (the result is an error on the host either way)
+		if (xs.gave_up && __builtin_amdgcn_readfirstlane(__hip_atomic_load(xs.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
 		if (b < e)
 			unpredict2_component<T>(tp, order_v, nvtx, b, e, cand, ncand, planes, rec, ld.stride, ld.off[c], ld.quant[c], ld.plane[c],
 			                        (typename cm::word<sizeof(T)>::u*)ring_raw2, ring_bytes / (uint32_t)sizeof(T),
@@ -1819,13 +1838,16 @@ static uint32_t chain_waves(uint32_t nvtx)
 	return forced ? forced : nvtx >= (1u << 18) ? 5u : 4u;
 }
 // ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
-uint32_t chain_timeout_flags(hipStream_t st)
+// gave_up: the decode's own give-up word (behind its flag table), or nullptr -- a context that shares its device with others may find
+// g_chain_timeout read and reset by one of them, its own word not
+uint32_t chain_timeout_flags(hipStream_t st, const uint32_t *gave_up)
 {
-	uint32_t f = 0, zero = 0;
+	uint32_t f = 0, own = 0, zero = 0;
 	if (hipMemcpyFromSymbolAsync(&f, HIP_SYMBOL(g_chain_timeout), 4, 0, hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
+	if (gave_up && hipMemcpyAsync(&own, gave_up, 4, hipMemcpyDeviceToHost, st) != hipSuccess) own = 0;
 	(void)hipStreamSynchronize(st);
 	if (f) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chain_timeout), &zero, 4, 0, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
-	return f;
+	return f | own;
 }
 uint32_t chain_ring_floor(uint32_t v_begin) { return v_begin > kRing3Near ? v_begin - kRing3Near : 0u; }
 bool unpredict3_covers(const ListDesc &ld)
@@ -1871,7 +1893,8 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
                        const uint32_t *seg_start, uint32_t nseg, uint32_t *done)
 {
 	if (!nvtx || !ld.ncomp || !n_lists) return;
-	const CrossSync xs{ seg_start, nseg, done, nullptr };
+	// (the callers' flag tables hold ld.ncomp x nseg progress words and one more behind them, zeroed with them: the give-up word)
+	const CrossSync xs{ seg_start, nseg, done, nullptr, done ? done + (size_t)ld.ncomp * nseg : nullptr };
 	auto go3 = [&](auto kern, int stype) {
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;

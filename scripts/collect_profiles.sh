@@ -8,7 +8,7 @@
 #         cfg0      scripts/cfg0_time.py                     bunny-class stand-in, lossless, both profiles
 #         floatmixed scripts/float_chain_time.py 708 --mixed  ONE mixed-polygon component (40 % quads, 5 % pentagons), lossless
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -38,12 +38,18 @@ if [ "${PART:-1}" = "2" ]; then
 	echo "100M end to end done" >> $OUT/progress.log
 	cd /tmp
 	mkdir -p $OUT/cfg4full
-	rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg4full/kstats -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify > $OUT/cfg4full/kstats.log 2>&1
-	rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/cfg4full/pmc_sq -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify > $OUT/cfg4full/pmc_sq.log 2>&1
+	# (--profile-run: exactly two encodes from resident inputs and two decodes, so that "per pass" means the same for every kernel)
+	rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg4full/kstats -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify --profile-run > $OUT/cfg4full/kstats.log 2>&1
+	echo "100M kernel stats done" >> $OUT/progress.log
+	rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cfg4full/pmc_fetch -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify --profile-run > $OUT/cfg4full/pmc_fetch.log 2>&1
+	echo "100M FETCH_SIZE done" >> $OUT/progress.log
+	rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cfg4full/pmc_write -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify --profile-run > $OUT/cfg4full/pmc_write.log 2>&1
+	echo "100M WRITE_SIZE done" >> $OUT/progress.log
+	rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/cfg4full/pmc_sq -- python3 $ROOT/tests/tools/cfg4_check.py 1024 221 222 --no-verify --profile-run > $OUT/cfg4full/pmc_sq.log 2>&1
 	echo "100M profiles done" >> $OUT/progress.log
 	cd $ROOT
 	echo "==== cfg4full" >> $OUT/summary.txt
-	python3 scripts/summarise_profiles.py $OUT/cfg4full 4 >> $OUT/summary.txt 2>&1
+	python3 scripts/summarise_profiles.py $OUT/cfg4full 2 >> $OUT/summary.txt 2>&1
 	find $OUT -type d \( -name kstats -o -name pmc_fetch -o -name pmc_write -o -name pmc_sq \) -prune -exec rm -rf {} +
 	tail -30 $OUT/summary.txt
 	exit 0
@@ -59,8 +65,8 @@ python3 $ROOT/scripts/obj_time.py 300 12 > $OUT/obj_time_12bits.txt 2>&1
 mkdir -p $OUT/obj
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/obj/kstats -- python3 $ROOT/scripts/obj_time.py 300 > $OUT/obj/kstats.log 2>&1
 # both bench modes rehearsed with ranks / contexts sharing this box's one GPU (code paths, not measurements)
-python3 $ROOT/bench.py --gpus 2 --share-device --comps-per-gpu 16 --steps 3 --warmup 1 > $OUT/rehearsal_inprocess_2ctx_one_gpu.json 2> $OUT/rehearsal_inprocess.err
-HRY_BENCH_SHARE_GPU=1 python3 $ROOT/bench.py --gpus 2 --launcher --comps-per-gpu 16 --steps 2 --warmup 1 2> $OUT/rehearsal_ranks.err | grep '^{' > $OUT/rehearsal_2ranks_one_gpu.json
+python3 $ROOT/bench.py --gpus 2 --inprocess --share-device --comps-per-gpu 16 --steps 3 --warmup 1 > $OUT/rehearsal_inprocess_2ctx_one_gpu.json 2> $OUT/rehearsal_inprocess.err
+python3 $ROOT/bench.py --gpus 2 --share-device --comps-per-gpu 16 --steps 2 --warmup 1 2> $OUT/rehearsal_ranks.err | grep '^{' > $OUT/rehearsal_2ranks_one_gpu.json
 cd $ROOT
 # passes of the workload per run (what traffic.json divides by): quick_chunked 3 encode + decode; float_chain_time 1 encode + 4
 # decodes (divide by the decodes: the decode kernels are the subject); cfg4_check 2; cfg0_time 3 per profile
