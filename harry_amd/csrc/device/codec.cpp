@@ -43,6 +43,9 @@ Context::~Context()
 	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : slice_ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : chain_ev) if (e) (void)hipEventDestroy(e);
+	if (pipe_stream) { (void)hipStreamSynchronize(pipe_stream); (void)hipStreamDestroy(pipe_stream); }
+	if (pipe_ev) (void)hipEventDestroy(pipe_ev);
+	for (auto &e : pipe_slot_ev) if (e) (void)hipEventDestroy(e);
 	if (stream) (void)hipStreamDestroy(stream);
 	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
 	if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }

@@ -75,6 +75,10 @@ struct Context {
 	size_t h_down_cap = 0;
 	void *h_stage = nullptr;         // pinned staging memory for uploads that run next to a busy host thread (copies from
 	size_t h_stage_cap = 0;          // pageable memory make the runtime pin and unpin pages: TLB shootdowns for every thread)
+	hipStream_t pipe_stream = nullptr;   // chunked encode: what finished groups of a walk on several threads have coded goes to the planes beside the walk (chunked.cpp: EncodePipeline; created on first use)
+	hipEvent_t pipe_ev = nullptr;
+	static constexpr int kPipeSlots = 3;
+	hipEvent_t pipe_slot_ev[kPipeSlots] = {};   // a slot of h_pipe / d_pipe is free again
 	hipEvent_t ev[8] = {};
 	// the float chains of a large mesh run in batches (unchunk.cpp: ChainBatches): a pair of timing events around every batch's
 	// launches, so that hry_timing.k_chain_ms is the sum over the batches of a decode (created on first use)
@@ -99,10 +103,12 @@ struct Context {
 	       d_rec_sym, d_sym_l, d_r, d_s, d_state, d_acc, d_v, d_summary, d_bytes, d_small;
 	// chunked profile
 	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms, d_patch;
+	DevBuf d_pipe, d_nt_val, d_nt_planes;   // EncodePipeline: run tables and twin pairs of the batches; the polygons' triangle counts and their two byte planes
 	std::vector<uint32_t> h_twin_patch;   // (half-edge, twin) pairs on their way to d_patch (upload_repaired_twins)
 
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
+	PinBuf h_pipe;                  // chunked encode: the pipeline's staging slots (run tables + the runs' entries, gathered)
 	PinBuf h_conn;                  // chunked decode: the connectivity planes, down for the host's replay
 	PinBuf h_rec, h_r, h_s;         // compat: symbol records down, (r, S) up, slice by slice (codec.cpp finish_stream)
 	std::vector<hipEvent_t> slice_ev;

@@ -232,6 +232,29 @@ __global__ __launch_bounds__(256) void k_rank(const uint32_t *order_v, uint32_t 
 	if (k < n) rank[org[order_v[k]]] = k;
 }
 
+// ---- the same kernels over RUNS of the coding order (chunked.cpp: EncodePipeline).  The groups of a multi-component mesh finish
+// their walks one by one, in no particular order; what a finished group has coded is a handful of runs [first, first + n) of the
+// coded vertices / faces, final from then on.  A batch of such runs is one launch: position p of the batch lies in run r =
+// the last one with start[r] <= p (start: exclusive scan of the runs' lengths, start[nruns] = the batch's size).
+struct RunTable { const uint32_t *start, *first; uint32_t nruns, total; };
+__device__ __forceinline__ uint32_t run_lookup(const RunTable &rt, uint32_t p)
+{
+	uint32_t lo = 0, hi = rt.nruns;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rt.start[mid] <= p) lo = mid; else hi = mid; }
+	return rt.first[lo] + (p - rt.start[lo]);
+}
+// packed: the runs' entries of order_v back to back, as they came up (position p of the batch); they take their places in order_v here
+// (packed == nullptr: the runs' entries are in their places already, copied there run by run)
+__global__ __launch_bounds__(256) void k_rank_runs(RunTable rt, const uint32_t *packed, uint32_t *order_v, const uint32_t *org, uint32_t *rank)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= rt.total) return;
+	const uint32_t k = run_lookup(rt, p);
+	uint32_t e;
+	if (packed) { e = packed[p]; order_v[k] = e; } else e = order_v[k];
+	rank[org[e]] = k;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_predict_vtx: prediction + residual folding + byte symbolisation of vertex attributes, one thread per coded
 // vertex (attrcode.h:209-225 vtx, :321-344 vtx_post; io.h:90-94; models.h:168-173).  Output: SoA byte planes,
@@ -245,13 +268,10 @@ __global__ __launch_bounds__(256) void k_rank(const uint32_t *order_v, uint32_t 
 // XCD one contiguous range of the coding order, so the connectivity / rank / record lines its wavefronts gather are shared
 // inside one L2 instead of being fetched by all eight.
 constexpr int kEncCand = 8;
-__global__ __launch_bounds__(256) void k_predict_vtx(ConnView cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank,
-                                                     const uint8_t *rec, ListDesc ld, uint8_t *planes, uint32_t blocks_per_xcd)
+// coded vertex k of n (n = the stride of the byte planes)
+__device__ __forceinline__ void predict_vertex(const ConnView &cv, const uint32_t *order_v, uint32_t k, uint32_t n, const uint32_t *rank,
+                                               const uint8_t *rec, const ListDesc &ld, uint8_t *planes, uint32_t (*s_cand)[256])
 {
-	const uint32_t vb = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
-	const uint32_t k = vb * blockDim.x + threadIdx.x;
-	__shared__ uint32_t s_cand[kEncCand * 3][256];
-	if (k >= n) return;
 	Topo tp{ cv };
 	const uint32_t e = order_v[k];
 	const uint32_t v = cv.org[e];
@@ -298,12 +318,55 @@ __global__ __launch_bounds__(256) void k_predict_vtx(ConnView cv, const uint32_t
 		});
 	}
 }
+__global__ __launch_bounds__(256) void k_predict_vtx(ConnView cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank,
+                                                     const uint8_t *rec, ListDesc ld, uint8_t *planes, uint32_t blocks_per_xcd)
+{
+	const uint32_t vb = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
+	const uint32_t k = vb * blockDim.x + threadIdx.x;
+	__shared__ uint32_t s_cand[kEncCand * 3][256];
+	if (k >= n) return;
+	predict_vertex(cv, order_v, k, n, rank, rec, ld, planes, s_cand);
+}
+// a batch of runs of the coding order (RunTable above); n: all coded vertices of the mesh = the planes' stride
+__global__ __launch_bounds__(256) void k_predict_vtx_runs(ConnView cv, RunTable rt, const uint32_t *order_v, uint32_t n, const uint32_t *rank,
+                                                          const uint8_t *rec, ListDesc ld, uint8_t *planes, uint32_t blocks_per_xcd)
+{
+	const uint32_t vb = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
+	const uint32_t p = vb * blockDim.x + threadIdx.x;
+	__shared__ uint32_t s_cand[kEncCand * 3][256];
+	if (p >= rt.total) return;
+	predict_vertex(cv, order_v, run_lookup(rt, p), n, rank, rec, ld, planes, s_cand);
+}
 
 // faces: prediction is always "no candidate" (attrcode.h:227-254) => residual against 0
+__device__ __forceinline__ void face_planes_of(const ConnView &cv, const uint32_t *order_f, uint32_t j, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
 __global__ __launch_bounds__(256) void k_face_planes(ConnView cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, ListDesc ld, uint8_t *planes)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= n) return;
+	face_planes_of(cv, order_f, j, n, rec, ld, planes);
+}
+// packed: the runs' entries of order_f back to back (position p of the batch)
+__global__ __launch_bounds__(256) void k_face_planes_runs(ConnView cv, RunTable rt, const uint32_t *packed, uint32_t *order_f, uint32_t n, const uint8_t *rec, ListDesc ld, uint8_t *planes)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= rt.total) return;
+	const uint32_t j = run_lookup(rt, p);
+	if (packed) order_f[j] = packed[p];
+	face_planes_of(cv, order_f, j, n, rec, ld, planes);
+}
+// one 32-bit value per symbol -> byte planes, over runs (the polygons' triangle counts, one per coded face; n = all of them);
+// packed: the runs' values back to back
+// (packed == nullptr: the values are in their places in val)
+__global__ __launch_bounds__(256) void k_split_bytes_runs(RunTable rt, const uint32_t *packed, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= rt.total) return;
+	const uint32_t j = run_lookup(rt, p), v = packed ? packed[p] : val[j];
+	for (int b = 0; b < nbytes; ++b) planes[(size_t)b * n + j] = (uint8_t)(v >> (8 * b));
+}
+__device__ __forceinline__ void face_planes_of(const ConnView &cv, const uint32_t *order_f, uint32_t j, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes)
+{
 	Topo tp{ cv };
 	uint32_t f = tp.face(order_f[j]);
 	for (int c = 0; c < ld.ncomp; ++c) {
@@ -763,6 +826,27 @@ void launch_predict_vtx(hipStream_t st, const ConnView &cv, const uint32_t *orde
 void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes)
 {
 	if (n && ld.ncomp) hipLaunchKernelGGL(k_face_planes, dim3(blocks_for(n, 256)), dim3(256), 0, st, cv, order_f, n, rec, ld, planes);
+}
+// ---- over a batch of runs of the coding order: start / first = device arrays of nruns + 1 / nruns entries, total = start[nruns]
+void launch_rank_runs(hipStream_t st, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *packed, uint32_t *order_v, const uint32_t *org, uint32_t *rank)
+{
+	if (total) hipLaunchKernelGGL(k_rank_runs, dim3(blocks_for(total, 256)), dim3(256), 0, st, RunTable{ start, first, nruns, total }, packed, order_v, org, rank);
+}
+void launch_predict_vtx_runs(hipStream_t st, const ConnView &cv, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *order_v, uint32_t n,
+                             const uint32_t *rank, const uint8_t *rec, const ListDesc &ld, uint8_t *planes)
+{
+	if (!total) return;
+	const unsigned per = (blocks_for(total, 256) + 7) / 8;
+	hipLaunchKernelGGL(k_predict_vtx_runs, dim3(per * 8), dim3(256), 0, st, cv, RunTable{ start, first, nruns, total }, order_v, n, rank, rec, ld, planes, per);
+}
+void launch_face_planes_runs(hipStream_t st, const ConnView &cv, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *packed, uint32_t *order_f, uint32_t n,
+                             const uint8_t *rec, const ListDesc &ld, uint8_t *planes)
+{
+	if (total && ld.ncomp) hipLaunchKernelGGL(k_face_planes_runs, dim3(blocks_for(total, 256)), dim3(256), 0, st, cv, RunTable{ start, first, nruns, total }, packed, order_f, n, rec, ld, planes);
+}
+void launch_split_bytes_runs(hipStream_t st, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *packed, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes)
+{
+	if (total) hipLaunchKernelGGL(k_split_bytes_runs, dim3(blocks_for(total, 256)), dim3(256), 0, st, RunTable{ start, first, nruns, total }, packed, val, n, nbytes, planes);
 }
 // face of every half-edge of a mixed-degree mesh, from the face offsets (the table the topology helpers read)
 __global__ __launch_bounds__(256) void k_edge_faces(const uint32_t *foff, uint32_t first, uint32_t nf, uint32_t *eface)

@@ -18,6 +18,16 @@ void launch_rank(hipStream_t st, const uint32_t *order_v, uint32_t n, const uint
 void launch_predict_vtx(hipStream_t st, const ConnView &cv, const uint32_t *order_v, uint32_t n, const uint32_t *rank, const uint8_t *rec,
                         const ListDesc &ld, uint8_t *planes);
 void launch_face_planes(hipStream_t st, const ConnView &cv, const uint32_t *order_f, uint32_t n, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
+// the same over a batch of runs of the coding order (chunked.cpp: EncodePipeline): start = exclusive scan of the runs' lengths
+// (nruns + 1 entries, device), first = where each run begins in the coding order, total = start[nruns]; n = all coded elements;
+// packed = the runs' entries of the host array back to back (they take their places in order_v / order_f on the way)
+void launch_rank_runs(hipStream_t st, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *packed, uint32_t *order_v, const uint32_t *org, uint32_t *rank);
+void launch_predict_vtx_runs(hipStream_t st, const ConnView &cv, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *order_v, uint32_t n,
+                             const uint32_t *rank, const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
+void launch_face_planes_runs(hipStream_t st, const ConnView &cv, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *packed, uint32_t *order_f, uint32_t n,
+                             const uint8_t *rec, const ListDesc &ld, uint8_t *planes);
+void launch_split_bytes_runs(hipStream_t st, const uint32_t *start, const uint32_t *first, uint32_t nruns, uint32_t total, const uint32_t *packed, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes);
+// (packed == nullptr in any of them: the runs' entries were copied to their places in order_v / order_f / val run by run)
 void launch_edge_faces(hipStream_t st, const uint32_t *foff, uint32_t nf, uint32_t *eface, uint32_t first = 0);   // faces [first, nf)
 void launch_magic_table(hipStream_t st, MagicEnt *tab, uint32_t from, uint32_t to);
 void launch_split_bytes(hipStream_t st, const uint32_t *val, uint32_t n, int nbytes, uint8_t *planes);

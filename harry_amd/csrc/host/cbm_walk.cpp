@@ -1236,6 +1236,9 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 	};
 	std::vector<PerThread> per_thread(n_threads);
 	std::atomic<size_t> next_item{ 0 };
+	WalkProgress *const progress = off_v[0] == 0 && off_f[0] == 0 && nt0 == 0 ? w.progress : nullptr;   // (positions = indices of the arrays)
+	if (progress) progress->begin(w.order_v.data(), w.order_v.size(), w.order_f.data(), w.order_f.size(), w.numtri_coded ? w.grp_val[G_NUMTRI].data() : nullptr);
+	const uint32_t *const twin_now = m.twin.data();
 	parallel_for(n_threads, [&](unsigned t) {
 		Border cb(st.on);
 		PerThread &T = per_thread[t];
@@ -1243,9 +1246,11 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 		Emitter em(T.w);
 		em.eval_model = false;
 		em.ov_begin = w.order_v.data(); em.of_begin = w.order_f.data();
+		std::vector<uint32_t> runs_v, runs_f, pairs;   // (progress) what the finished group has coded
 		for (;;) {
 			size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
 			if (it >= items.size()) break;
+			const size_t patches0 = T.w.twin_patches.size();
 			for (uint32_t q = items[it].begin; q < items[it].end; ++q) {
 				const uint32_t k = order[q];
 				const uint32_t nfc = A.n_faces[k];
@@ -1280,6 +1285,18 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 				pc.n_syms = em.n - pc.sym0; pc.n_named = (uint32_t)T.w.named.size() - pc.named0;
 				for (int g = 0; g < G_COUNT; ++g) pc.gn[g] = (uint32_t)T.w.grp_val[g].size() - pc.g0[g];
 				for (int i = 0; i < 8; ++i) pc.n_op[i] = em.n_op[i] - nop0[i];
+			}
+			if (progress) {
+				// the group's components in ascending rank: consecutive ranks lie next to each other in order_v / order_f
+				runs_v.clear(); runs_f.clear(); pairs.clear();
+				auto add = [](std::vector<uint32_t> &r, uint64_t b, uint64_t e) {
+					if (b == e) return;
+					if (!r.empty() && (uint64_t)r[r.size() - 2] + r.back() == b) r.back() += (uint32_t)(e - b);
+					else { r.push_back((uint32_t)b); r.push_back((uint32_t)(e - b)); }
+				};
+				for (uint32_t q = items[it].begin; q < items[it].end; ++q) { const uint32_t k = order[q]; add(runs_v, off_v[k], off_v[k + 1]); add(runs_f, off_f[k], off_f[k + 1]); }
+				for (size_t i = patches0; i < T.w.twin_patches.size(); ++i) { const uint32_t h = T.w.twin_patches[i]; pairs.push_back(h); pairs.push_back(twin_now[h]); }
+				progress->group_done(runs_v.data(), (uint32_t)(runs_v.size() / 2), runs_f.data(), (uint32_t)(runs_f.size() / 2), pairs.data(), (uint32_t)(pairs.size() / 2));
 			}
 		}
 		em.op_begin = em.op_cur = nullptr;

@@ -77,7 +77,21 @@ std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark>
 enum class OpByte : uint8_t {};
 inline uint8_t op_u8(OpByte b) { return (uint8_t)b; }
 
+// Progress of a walk on several threads (walk_components_parallel): what a finished GROUP of tied components has coded is final
+// from then on -- runs of the coded vertices / faces (positions in order_v / order_f; the polygons' triangle counts lie like
+// order_f) and the twins it repaired.  The encoder's device side takes them while the other groups are still being walked
+// (device/chunked.cpp: EncodePipeline).  Called by the walking threads, several at a time.
+struct WalkProgress {
+	virtual ~WalkProgress() {}
+	// before the first walk: the arrays the runs refer to (they do not move until the walk returns); numtri = nullptr when the
+	// mesh has one polygon degree
+	virtual void begin(const uint32_t *order_v, size_t n_v, const uint32_t *order_f, size_t n_f, const uint32_t *numtri) = 0;
+	// runs: (first, length) pairs; twin_pairs: (half-edge, its final twin) pairs
+	virtual void group_done(const uint32_t *v_runs, uint32_t n_v_runs, const uint32_t *f_runs, uint32_t n_f_runs, const uint32_t *twin_pairs, uint32_t n_pairs) = 0;
+};
+
 struct WalkResult {
+	WalkProgress *progress = nullptr;   // in: told about every finished group of a walk on several threads (nullptr: nobody listens)
 	BigVec<uint32_t> order_v;   // one half-edge per coded vertex, in coding order (attrcode.h:297,310-314)
 	BigVec<uint32_t> order_f;   // one half-edge per face, in coding order (attrcode.h:298,315-319)
 	// connectivity symbols: values (low byte first, one entry per symbol) + position in the global symbol sequence

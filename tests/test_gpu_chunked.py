@@ -355,3 +355,45 @@ def test_encode_with_the_device_analysis_equals_the_oracle(cx, monkeypatch):
         a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
         got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
         assert got == o.encode_chunked(hc.container_info(got)["chunk_syms"]).data
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", ["1", "300", "small-slots", "direct-1", "direct-0", "direct-8-small-slots", None, "off"])
+def test_encode_beside_the_walk_equals_the_oracle(cx, monkeypatch, batch):
+    """EncodePipeline (round 5): the finished groups' runs of the coding order go to the planes while the other groups are still
+    walked -- in batches of one group, of a few, with slots so small that groups are sent in pieces, in the production size (here: one
+    batch behind the walk), and not at all; vertex
+    planes of quantised positions + normals, face planes of face properties, the polygons' triangle counts, repaired twins"""
+    monkeypatch.setenv("HRY_DEVICE_ANALYSIS_MIN_FACES", "1")
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
+    monkeypatch.setenv("HRY_HOST_THREADS", "6")
+    if batch == "off":
+        monkeypatch.setenv("HRY_NO_ENCODE_PIPELINE", "1")
+    elif batch == "small-slots":   # slots of 64 entries: most groups outgrow them and go through the sending thread in pieces
+        monkeypatch.setenv("HRY_ENCODE_PIPELINE_SLOT", "64")
+        monkeypatch.setenv("HRY_ENCODE_PIPELINE_BATCH", "40")
+    elif batch and batch.startswith("direct-"):   # runs of at least so many entries are copied from the walk's (registered) arrays; 0: none
+        monkeypatch.setenv("HRY_ENCODE_PIPELINE_DIRECT", batch.split("-")[1])
+        monkeypatch.setenv("HRY_ENCODE_PIPELINE_BATCH", "200")
+        if batch.endswith("small-slots"):
+            monkeypatch.setenv("HRY_ENCODE_PIPELINE_SLOT", "64")
+    elif batch:
+        monkeypatch.setenv("HRY_ENCODE_PIPELINE_BATCH", batch)
+    cases = [(mg.with_nonmanifold(mg.multi_component(24, 10, 12, seed=7, polys="mixed"), 80, 40, seed=7), []),
+             (mg.with_nonmanifold(mg.multi_component(17, 9, 11, seed=8, polys="tri"), 30, 30, seed=8), [(1, -1, 12)]),
+             (mg.with_face_props(mg.multi_component(12, 9, 11, seed=9, polys="quad")), []),
+             (mg.concat([mg.torus(14 + 2 * i, 12 + i, seed=20 + i, normals=True, center=(3.0 * i, 0, 0), polys="mixed") for i in range(9)]),
+              [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)])]
+    for g, quant in cases:
+        ply = g.to_ply()
+        a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+        if quant:
+            cx.requant(a, quant)
+            o.requant(quant)
+        got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED)
+        assert got == o.encode_chunked(hc.container_info(got)["chunk_syms"]).data
+        # ... and a second encode on the same context (recycled device arrays, a rank table of another mesh)
+        b = hc.Mesh.from_ply(ply)
+        if quant:
+            cx.requant(b, quant)
+        assert cx.write_hry(b, profile=hc.PROFILE_CHUNKED) == got
