@@ -31,8 +31,9 @@ void device_component_analysis(Context &cx, const Mesh &m, ComponentAnalysis &A)
 	if (cv.nf != nf || cv.ne != m.ne()) throw Error(HRY_E_INTERNAL, "device analysis: resident connectivity of another mesh");
 	hipStream_t st = cx.stream;
 	cx.d_cscratch.ensure(dev::components_workspace_bytes(nv, nf));
-	uint32_t *d_label = nullptr, *d_num = nullptr;
-	dev::launch_components_label(st, cv, cx.d_cscratch.p, &d_label, &d_num);
+	const dev::ComponentsWorkspace ws = dev::components_workspace(cx.d_cscratch.p, nv, nf);
+	uint32_t *d_label = ws.label, *d_num = ws.num;
+	dev::launch_components_label(st, cv, ws);
 	uint32_t ncomp = 0;
 	HIP_OK(hipMemcpyAsync(&ncomp, d_num + nf, 4, hipMemcpyDeviceToHost, st));
 	std::vector<uint32_t> spans;
@@ -60,8 +61,7 @@ void device_component_analysis(Context &cx, const Mesh &m, ComponentAnalysis &A)
 	HIP_OK(hipMemcpyAsync(key.data(), d_key, (size_t)ncomp * 8, hipMemcpyDeviceToHost, st));
 	HIP_OK(hipMemcpyAsync(by_num.data(), d_nfaces, (size_t)4 * ncomp * 4, hipMemcpyDeviceToHost, st));
 	// (the vertex words go to their neutral value meanwhile)
-	uint32_t *d_vfirst = d_num + nf + 1 + ((nf + 1023) / 1024) + 8;   // behind the scan's block sums (components_workspace_bytes)
-	HIP_OK(hipMemsetAsync(d_vfirst, 0xff, (size_t)nv * 4, st));
+	HIP_OK(hipMemsetAsync(ws.vfirst, 0xff, (size_t)nv * 4, st));
 	HIP_OK(hipMemsetAsync(d_fresh, 0, (size_t)ncomp * 4, st));
 	HIP_OK(hipMemsetAsync(d_vlo, 0xff, (size_t)ncomp * 4, st));
 	HIP_OK(hipMemsetAsync(d_vhi, 0, (size_t)ncomp * 4, st));
@@ -75,7 +75,7 @@ void device_component_analysis(Context &cx, const Mesh &m, ComponentAnalysis &A)
 	for (uint32_t k = 0; k < ncomp; ++k) rank_of[by_rank[k]] = k;
 	mark("  keys sorted (host)");
 	HIP_OK(hipMemcpyAsync(d_rank, rank_of.data(), (size_t)ncomp * 4, hipMemcpyHostToDevice, st));
-	dev::launch_components_vertices(st, cv, nv, ncomp, d_label, d_rank, d_vfirst, d_tie, d_fresh, d_vlo, d_vhi);
+	dev::launch_components_vertices(st, cv, nv, ncomp, ws, d_rank, d_tie, d_fresh, d_vlo, d_vhi);
 	std::vector<uint32_t> by_rank_tab((size_t)4 * ncomp);   // group, new vertices, lowest vertex, highest + 1, by rank
 	HIP_OK(hipMemcpyAsync(by_rank_tab.data(), d_tie, (size_t)4 * ncomp * 4, hipMemcpyDeviceToHost, st));
 	A.seed.resize(ncomp); A.n_faces.resize(ncomp); A.n_halfedges.resize(ncomp); A.face_lo.resize(ncomp); A.face_hi.resize(ncomp);

@@ -608,6 +608,8 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 		if (arrays_err) std::rethrow_exception(arrays_err);
 	};
 	if (in_place) {
+		if (in_place->before_walk) in_place->before_walk();   // (its turn among the executor's workers, and the turn's thread budget)
+		struct After { const std::function<void()> &f; ~After() { if (f) f(); } } after{ in_place->after_walk };
 		start_pipeline(*in_place->part, shard_arrays_ready);
 		cut_border_walk_in_place(*in_place->whole, *in_place->part, in_place->eface, *in_place->marks, w);
 		walked = true;
@@ -688,7 +690,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	if (vc && !piped) HIP_OK(hipMemcpyAsync(cx.d_order_v.p, w.order_v.data(), (size_t)vc * 4, hipMemcpyHostToDevice, cx.stream));
 	if (fc && (ldf.nplanes || m.general) && !piped) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));   // only the face planes read it
 	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
-	if (!piped) upload_repaired_twins(cx, in_place ? *in_place->whole : m, w);
+	if (!piped) upload_repaired_twins(cx, in_place ? *in_place->whole : m, w, in_place != nullptr);
 	size_t goff[G_COUNT + 1] = { 0 };
 	for (int g = 0; g < G_COUNT; ++g) {
 		size_t n = w.grp_val[g].size();

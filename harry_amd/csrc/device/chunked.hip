@@ -12,6 +12,8 @@
 //                    symbol search by wave-wide compare + ballot (no division by the data-dependent r)
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <stdexcept>
 #include <type_traits>
 
 #include "codec_math.hpp"
@@ -530,9 +532,24 @@ void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t n
 {
 	if (!nstreams) return;
 	constexpr uint32_t kLds = 256 * 64 * 4;
-	static const bool raised = [] { return hipFuncSetAttribute((const void*)k_chunk_decode_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) == hipSuccess; }();
-	(void)raised;
+	// the dynamic LDS limit is a property of the function ON A DEVICE: raised once for every device a launch goes to (N contexts
+	// on N devices in one process: hry_decode_sharded), on the device that is current -- the stream's
+	static std::mutex mu;
+	static bool raised[64] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+	{
+		std::lock_guard<std::mutex> g(mu);
+		if (!raised[dev]) {
+			if (hipFuncSetAttribute((const void*)k_chunk_decode_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess) {
+				(void)hipGetLastError();
+				throw std::runtime_error("k_chunk_decode_lanes: the device refuses 64 KB of dynamic LDS");
+			}
+			raised[dev] = true;
+		}
+	}
 	hipLaunchKernelGGL(k_chunk_decode_lanes, dim3((nstreams + 63) / 64), dim3(64), kLds, st, jobs, nstreams, inits, magic, payload, (const unsigned long long*)offsets, nbytes);
+	if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_chunk_decode_lanes: launch failed");
 }
 
 }   // namespace dev

@@ -209,7 +209,9 @@ void check_codable(const Mesh &m)
 void device_bounds(Context &cx, Mesh &m, const Mesh *records)
 {
 	HIP_OK(hipSetDevice(cx.device));
-	if (records) {   // the scan reads nothing but the records: the caller has no use for the connectivity on this device
+	if (records && records->device_token != 0 && records->device_token == cx.resident_token) {
+		if (records->lists.size() != m.lists.size()) throw Error(HRY_E_INTERNAL, "bounds: list count");   // (the records are resident: nothing to bring up)
+	} else if (records) {   // the scan reads nothing but the records: the caller has no use for the connectivity on this device
 		if (m.lists.size() > (size_t)kMaxLists || records->lists.size() != m.lists.size()) throw Error(HRY_E_UNSUPPORTED, "more than 16 attribute lists");
 		for (size_t l = 0; l < m.lists.size(); ++l) {
 			const BigVec<uint8_t> &src = records->lists[l].data;
@@ -351,14 +353,17 @@ dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to)
 namespace dev { void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint32_t *dst); }
 // A walk repairs a handful of twins (non-manifold edges, neighbours consumed from the other side) -- the whole array went up for
 // them: 1.2 GB for the configs[3] mesh.  Now the entries the walk names go up as (half-edge, twin) pairs and are scattered.
-void upload_repaired_twins(Context &cx, const Mesh &host, const WalkResult &w)
+// patches_only: `host` is a mesh other threads are walking other parts of (a shard coded in place) -- never the whole array,
+// whose other entries are theirs to change and, where contexts share a device's arrays, theirs to bring up
+void upload_repaired_twins(Context &cx, const Mesh &host, const WalkResult &w, bool patches_only)
 {
 	if (!w.twins_changed) return;
 	const size_t ne = host.ne(), np = w.twin_patches.size();
-	if (np == 0 || np > ne / 16) {
+	if (!patches_only && (np == 0 || np > ne / 16)) {
 		HIP_OK(hipMemcpyAsync(cx.d_twin.p, host.twin.data(), ne * 4, hipMemcpyHostToDevice, cx.stream));
 		return;
 	}
+	if (np == 0) return;
 	std::vector<uint32_t> &pairs = cx.h_twin_patch;
 	pairs.resize(2 * np);
 	for (size_t i = 0; i < np; ++i) {

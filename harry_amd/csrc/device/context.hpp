@@ -170,7 +170,7 @@ void device_requant(Context &cx, Mesh &m, const hry_quant *q, size_t nq, bool cl
 std::vector<std::vector<uint8_t>> requant_targets(const Mesh &m, const hry_quant *q, size_t nq, bool clear);   // validated request -> quantisation of every component
 dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to);
 // the twins the walk repaired (cbm/encoder.h:150,193-198) into the resident copy: the few entries it names, else the whole array
-void upload_repaired_twins(Context &cx, const Mesh &host, const WalkResult &w);
+void upload_repaired_twins(Context &cx, const Mesh &host, const WalkResult &w, bool patches_only = false);
 void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
 // A shard coded where it lies in the whole mesh (sharded.cpp: the in-process executor): the mesh handed to encode_chunked is a
 // SKELETON -- the shard's sizes, the lists' formats and bounds, its runs, no arrays; the context's connectivity and record arrays
@@ -184,6 +184,7 @@ struct InPlaceShard {
 	const std::vector<std::pair<uint32_t, uint32_t>> *face_intervals;   // the shard's faces, as uploaded (repaired twins go up over the same intervals)
 	std::function<void()> arrays_ready;                              // called after the walk, before anything touches the device: returns when the
 	                                                                 // shard's intervals are in HBM (and quantised, if the caller quantises)
+	std::function<void()> before_walk, after_walk;                   // around the walk on the host threads (the executor takes the workers' walks in turn)
 };
 void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const InPlaceShard *in_place = nullptr);   // (bytes that are not zero-filled first and go to the caller as they are)
 void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out);   // general.cpp: regions, shared records, corner lists (reference stream only)

@@ -51,11 +51,16 @@ uint32_t twin_overflow_capacity();
 void launch_twins(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t *twin, void *ws, const uint32_t **over);
 // connected components of the faces and their tables for the walk on several host threads (twins.hip; driver: analysis.cpp)
 size_t components_workspace_bytes(uint32_t nv, uint32_t nf);
-void launch_components_label(hipStream_t st, const ConnView &cv, void *ws, uint32_t **label, uint32_t **num);
+// where the workspace's parts lie (twins.hip decides; nobody else computes an offset into it): per face the component label (a
+// root face after stage 1), the root flags, their exclusive scan (num[nf] = components) and the scan's block sums; per vertex the
+// first component in coding order (stage 3); the list of (component, component) ties with its counter
+struct ComponentsWorkspace { uint32_t *label, *flag, *num, *sums, *vfirst, *tie_count, *tie_pairs; };
+ComponentsWorkspace components_workspace(void *ws, uint32_t nv, uint32_t nf);
+void launch_components_label(hipStream_t st, const ConnView &cv, const ComponentsWorkspace &w);
 void launch_components_faces(hipStream_t st, const ConnView &cv, uint32_t *label, const uint32_t *num, const uint32_t *spans, uint32_t nspans,
                              uint32_t *nfaces, uint32_t *nhe, uint32_t *flo, uint32_t *fhi, uint64_t *first_key);
-void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t ncomp, const uint32_t *comp, const uint32_t *rank_of,
-                                uint32_t *vfirst, uint32_t *tie, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi);
+void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t ncomp, const ComponentsWorkspace &w, const uint32_t *rank_of,
+                                uint32_t *tie, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi);
 
 // chunked profile (chunked.hip)
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits);

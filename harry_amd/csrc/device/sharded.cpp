@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -93,6 +95,30 @@ template <typename F> void run_workers(Context *const *cxs, int n, F &&body)
 	if (err) std::rethrow_exception(err);
 }
 
+// Workers that share something take turns at it, in the order of their shards: the CPUs of a memory node (the walks) and the
+// link to a device (the interval copies).  A walk is bound by the CPUs it gets and a copy by its link, so sharing them evenly
+// makes every worker finish at the same time -- and the device phases that follow (planes, streams, container) pile up behind
+// the last walk.  One after the other, each with all of the shared resource, the total is the same and the first shard's
+// device phase starts after an eighth of it: the workers' device phases hide behind each other's walks.
+struct Turnstile {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<int> order;   // the shards that pass here, ascending
+	size_t next = 0;
+	bool open = false;        // a worker failed: nobody waits any more
+	void enter(int s)
+	{
+		std::unique_lock<std::mutex> g(mu);
+		cv.wait(g, [&] { return open || (next < order.size() && order[next] == s); });
+	}
+	void leave(int s)
+	{
+		{ std::lock_guard<std::mutex> g(mu); if (next < order.size() && order[next] == s) ++next; }
+		cv.notify_all();
+	}
+	void abort() { { std::lock_guard<std::mutex> g(mu); open = true; } cv.notify_all(); }
+};
+
 // segments of a merged container (a shard without a group contributes none: its part holds a zero count)
 uint32_t merged_segments(const ByteSink &out)
 {
@@ -135,45 +161,109 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 	const bool trace = getenv("HRY_TRACE") != nullptr;
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry shards] %8.2f ms  %s\n", ms_since(t_all), what); };
 	auto t0 = Clock::now();
-	if (m.twins_pending) cxs[0]->upload_mesh(m, false);   // a freshly read mesh: its half-edge twins are matched on the first context's device
-	ensure_twins(m);
-	st.twins_ms = ms_since(t0);
 	const int nl = (int)m.lists.size();
 	std::vector<char> had(nl, 0);
 	bool need_bounds = false;
 	for (int l = 0; l < nl; ++l) { had[l] = m.lists[l].have_bounds || m.lists[l].ncomp() == 0; need_bounds |= !had[l]; }
-	// ---- the bounds of the whole mesh on the first context, beside the plan on the host threads
 	Mesh bm;   // formats of the lists + (after the scan) the bounds; the records stay where they are
-	std::exception_ptr bounds_err;
+	auto bounds_formats = [&] {
+		bm.lists.resize((size_t)nl);
+		for (int l = 0; l < nl; ++l) {
+			AttrList &D = bm.lists[l];
+			const AttrList &L = m.lists[l];
+			D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset; D.count = L.count;
+			D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = L.have_bounds;
+		}
+	};
+	ShardPlan plan;
+	std::unique_ptr<WalkState> marks_p;
+	// ---- Round 5: THE PLAN ON THE FIRST CONTEXT'S DEVICE for a large mesh.  The whole mesh goes up there once (four long copies at
+	// the link's rate: 54 ms for the 2.9 GB of configs[3]; a freshly read mesh went there anyway, for its twins), its bounds are
+	// one k_bounds, its components -- labels, coding order, sizes, new vertices, ties, index intervals -- one device analysis
+	// (analysis.cpp: 43 ms), while the host threads build what the walks need whatever the analysis says (the half-edge -> face
+	// table, the marks).  About what the host's analysis takes on 16 CPUs, but it leaves the mesh resident: the contexts of
+	// THAT device read the first context's arrays (an allocation belongs to the device, not to a stream) instead of bringing their
+	// intervals up again -- eight contexts rehearsing on one device had 2.9 GB of interval copies from pageable memory beside
+	// their walks (140 - 170 ms, every pin a round of TLB shootdowns for sixteen walking threads).  Contexts on other devices
+	// bring their intervals up as before, over their own links.  HRY_SHARD_HOST_PLAN=1: the host's analysis (round 4).
+	bool device_plan = false;
+	{
+		const char *e = getenv("HRY_DEVICE_ANALYSIS_MIN_FACES");
+		const uint32_t min_faces = e ? (uint32_t)strtoul(e, nullptr, 10) : (4u << 20);
+		device_plan = m.nf >= min_faces && getenv("HRY_SHARD_HOST_PLAN") == nullptr && host_threads() > 1;
+	}
 	double bounds_ms = 0;
+	bool bounds_done = false;
+	if (device_plan) {
+		Context &cx0 = *cxs[0];
+		HIP_OK(hipSetDevice(cx0.device));
+		if (m.twins_pending || m.device_token == 0 || m.device_token != cx0.resident_token) cx0.upload_mesh(m);   // (matches the twins of a freshly read mesh)
+		st.twins_ms = ms_since(t0);
+		mark("the whole mesh on the first context's device");
+		BigVec<uint32_t> eface_tab;
+		std::exception_ptr failed;
+		const unsigned nt = host_threads();
+		int ud0 = 0;
+		const bool uniform = m.uniform_degree(ud0) && (ud0 == 3 || ud0 == 4);
+		std::thread tables([&] {
+			try {
+				set_thread_budget(nt);
+				if (!uniform) {
+					eface_tab.resize(m.ne());
+					parallel_for(nt, [&](unsigned t) {
+						const uint32_t fb = (uint32_t)((uint64_t)m.nf * t / nt), fe = (uint32_t)((uint64_t)m.nf * (t + 1) / nt);
+						for (uint32_t f = fb; f < fe; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) eface_tab[h] = f;
+					});
+				}
+				marks_p.reset(new WalkState(m.nv, m.nf, nt));
+			} catch (...) { failed = std::current_exception(); }
+		});
+		ComponentAnalysis A;
+		try {
+			if (need_bounds) {
+				const auto tb = Clock::now();
+				bounds_formats();
+				device_bounds(cx0, bm, &m);   // (the records are resident: the scan alone)
+				bounds_ms = ms_since(tb);
+				bounds_done = true;
+			}
+			device_component_analysis(cx0, m, A);
+		} catch (...) { tables.join(); throw; }
+		tables.join();
+		if (failed) std::rethrow_exception(failed);
+		if (A.ncomp >= 2) {
+			shard_plan_from_analysis(m, (uint32_t)n_shards, std::move(A), plan);
+			plan.A.eface = std::move(eface_tab);
+		} else device_plan = false;   // (one component: nothing to split; the host's plan says so in its own words)
+	}
+	if (!device_plan) {
+	if (m.twins_pending) cxs[0]->upload_mesh(m, false);   // a freshly read mesh: its half-edge twins are matched on the first context's device
+	ensure_twins(m);
+	st.twins_ms = ms_since(t0);
+	// ---- the bounds of the whole mesh on the first context, beside the plan on the host threads
+	std::exception_ptr bounds_err;
 	std::thread bounds_thread;
-	if (need_bounds) {
+	if (need_bounds && !bounds_done) {
 		bounds_thread = std::thread([&] {
 			try {
 				const auto tb = Clock::now();
 				Context &cx = *cxs[0];
 				HIP_OK(hipSetDevice(cx.device));
-				bm.lists.resize((size_t)nl);
-				for (int l = 0; l < nl; ++l) {
-					AttrList &D = bm.lists[l];
-					const AttrList &L = m.lists[l];
-					D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset; D.count = L.count;
-					D.bmin = L.bmin; D.bmax = L.bmax; D.have_bounds = L.have_bounds;
-				}
+				bounds_formats();
 				device_bounds(cx, bm, &m);
 				bounds_ms = ms_since(tb);
 			} catch (...) { bounds_err = std::current_exception(); }
 		});
 	}
-	ShardPlan plan;
 	std::exception_ptr plan_err;
 	try { shard_plan(m, (uint32_t)n_shards, plan, true); } catch (...) { plan_err = std::current_exception(); }
-	st.plan_ms = ms_since(t0);
 	if (bounds_thread.joinable()) bounds_thread.join();
 	if (plan_err) std::rethrow_exception(plan_err);
 	if (bounds_err) std::rethrow_exception(bounds_err);
+	}
+	st.plan_ms = ms_since(t0);
 	st.bounds_ms = bounds_ms;
-	mark("plan, bounds of the whole mesh");
+	mark(device_plan ? "plan (device analysis), bounds of the whole mesh" : "plan, bounds of the whole mesh");
 	st.n_shards = (uint32_t)n_shards; st.n_contexts = (uint32_t)n_ctx; st.n_components = plan.A.ncomp;
 	for (uint32_t k = 0; k < plan.A.ncomp; ++k) st.n_groups += plan.A.group[k] == k;
 	if (need_bounds && store_bounds)   // what the reference's reader leaves in the mesh (ply/reader.cc:428)
@@ -186,17 +276,88 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 		for (uint32_t f = 0; f < m.nf; ++f) for (uint32_t h = m.face_off[f]; h < m.face_off[f + 1]; ++h) plan.A.eface[h] = f;
 		eface = plan.A.eface.data();
 	}
-	WalkState marks(m.nv, m.nf, host_threads());
+	if (!marks_p) marks_p.reset(new WalkState(m.nv, m.nf, host_threads()));
+	WalkState &marks = *marks_p;
 	mark("marks");
 
 	std::unique_ptr<ByteSink[]> parts(new ByteSink[(size_t)n_shards]);
-	std::vector<double> w_upload(n_ctx, 0.0), w_quant(n_ctx, 0.0), w_encode(n_ctx, 0.0);
+	std::vector<double> w_upload(n_ctx, 0.0), w_encode(n_ctx, 0.0);
+	// ---- turns (Turnstile above): the walks of the workers on one memory node, the copies to one device.  Measured on the
+	// configs[3] mesh, eight contexts on one device and 16 CPUs, and NOT the default: a shard's walk with all sixteen threads takes
+	// 20 - 25 ms where an eighth of the parallel walks would be 17 (128 groups over sixteen threads leave some idle at the end, and
+	// every walk has its sequential ends), the eight of them 194 ms against 133 side by side -- more than the device phases that hide
+	// behind them (encode 317 against 262 ms).  HRY_SHARD_TURNS=1 takes turns.
+	const bool turns = n_ctx > 1 && getenv("HRY_SHARD_TURNS") != nullptr;
+	// (the copies in turn were measured on one device: each shard's 360 MB of intervals took 30 ms alone -- pageable memory that
+	// sixteen walking threads are reading, every pin a round of TLB shootdowns -- 240 ms one after the other against 150 ms for
+	// eight staging threads at once; HRY_SHARD_COPY_TURNS=1 for the comparison)
+	const bool copy_turns = turns && getenv("HRY_SHARD_COPY_TURNS") != nullptr;
+	std::vector<int> walk_group(n_ctx, 0), copy_group(n_ctx, 0);
+	std::vector<unsigned> walk_budget(n_ctx, 0);
+	std::vector<std::unique_ptr<Turnstile>> walk_turn, copy_turn;
+	if (turns) {
+		std::vector<const void*> cpus((size_t)n_ctx);
+		for (int w = 0; w < n_ctx; ++w) cpus[w] = device_cpus(cxs[w]->device);
+		const unsigned allowed = cpu_allowance(), cap = host_threads();
+		std::vector<const void*> wkeys;
+		std::vector<int> ckeys;
+		for (int w = 0; w < n_ctx; ++w) {
+			size_t g = std::find(wkeys.begin(), wkeys.end(), cpus[w]) - wkeys.begin();
+			if (g == wkeys.size()) { wkeys.push_back(cpus[w]); walk_turn.emplace_back(new Turnstile()); }
+			walk_group[w] = (int)g;
+			size_t c = std::find(ckeys.begin(), ckeys.end(), cxs[w]->device) - ckeys.begin();
+			if (c == ckeys.size()) { ckeys.push_back(cxs[w]->device); copy_turn.emplace_back(new Turnstile()); }
+			copy_group[w] = (int)c;
+		}
+		for (int w = 0; w < n_ctx; ++w) {
+			unsigned members = 0;
+			for (int x = 0; x < n_ctx; ++x) members += walk_group[x] == walk_group[w];
+			const unsigned avail = cpus[w] ? (unsigned)CPU_COUNT((const cpu_set_t*)cpus[w]) : allowed;
+			// the node's CPUs, and the group's share of what the process may keep busy
+			walk_budget[w] = std::max(1u, std::min(cap, std::min(avail, std::max(1u, allowed * members / (unsigned)n_ctx))));
+		}
+		for (int sh = 0; sh < n_shards; ++sh) { walk_turn[walk_group[sh % n_ctx]]->order.push_back(sh); copy_turn[copy_group[sh % n_ctx]]->order.push_back(sh); }
+	}
+	auto abort_turns = [&] { for (auto &t : walk_turn) t->abort(); for (auto &t : copy_turn) t->abort(); };
+	// ---- (device plan) the whole mesh is resident on the first context: quantisation happens there once, over whole lists -- the
+	// intervals of different shards overlap where they were merged, and a record must be quantised exactly once
+	if (device_plan && (nq || clear)) {
+		Context &cx0 = *cxs[0];
+		Mesh whole_sk;
+		for (int l = 0; l < 2; ++l) {
+			const AttrList &L = m.lists[l];
+			AttrList &D = whole_sk.lists[l];
+			D.target = L.target; D.type = L.type; D.quant = L.quant; D.offset = L.offset;
+			D.interp_off = L.interp_off; D.interp_len = L.interp_len; D.interp_name = L.interp_name;
+			D.count = L.count;
+			const AttrList &B = had[l] ? L : bm.lists[l];
+			D.bmin = B.bmin; D.bmax = B.bmax; D.have_bounds = true;
+		}
+		const std::vector<std::vector<uint8_t>> to = requant_targets(whole_sk, q, nq, clear);
+		const auto tq = Clock::now();
+		HIP_OK(hipSetDevice(cx0.device));
+		for (int l = 0; l < 2; ++l) {
+			AttrList &L = whole_sk.lists[l];
+			if (to[l] == L.quant || !L.count) continue;
+			dev::launch_requant(cx0.stream, cx0.d_rec[l].as<uint8_t>(), L.count, L.stride(), requant_plan(L, to[l]));
+		}
+		HIP_OK(hipStreamSynchronize(cx0.stream));
+		st.quant_ms = ms_since(tq);   // (contexts on other devices quantise their intervals behind their copies: part of extract_ms)
+		cx0.resident_token = 0;   // (the resident records are no longer the host mesh's)
+	}
 	t0 = Clock::now();
 	run_workers(cxs, n_ctx, [&](int w) {
+	  // (device plan) a context on the first context's device reads that context's arrays: lent for the length of this call
+	  const bool shares0 = device_plan && cxs[w]->device == cxs[0]->device;
+	  struct Lent { DevBuf *b; void *p; size_t cap; };
+	  std::vector<Lent> lent;
+	  struct GiveBack { std::vector<Lent> &l; ~GiveBack() { for (const Lent &x : l) { x.b->p = x.p; x.b->cap = x.cap; } } } give_back{ lent };
+	  try {
 		Context &cx = *cxs[w];
 		HIP_OK(hipSetDevice(cx.device));
 		hry_timing acc{};
 		bool arrays_ready = false;
+		const unsigned own_budget = host_threads();   // (run_workers: this worker's share)
 		for (int s = w; s < n_shards; s += n_ctx) {
 			// ---- the shard: its components, its runs, the intervals it lies in
 			ComponentAnalysis part;
@@ -217,6 +378,18 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 			}
 			// ---- the whole mesh's arrays on this device, filled over the shard's intervals
 			auto t = Clock::now();
+			if (!arrays_ready && shares0) {
+				if (w != 0) {
+					Context &c0 = *cxs[0];
+					auto lend = [&](DevBuf &dst, DevBuf &src) { lent.push_back(Lent{ &dst, dst.p, dst.cap }); dst.p = src.p; dst.cap = src.cap; };
+					lend(cx.d_org, c0.d_org); lend(cx.d_twin, c0.d_twin); lend(cx.d_foff, c0.d_foff); lend(cx.d_eface, c0.d_eface);
+					for (int l = 0; l < 2; ++l) lend(cx.d_rec[l], c0.d_rec[l]);
+					cx.res_has_eface = c0.res_has_eface; cx.res_udeg = c0.res_udeg;
+					cx.res_nv = m.nv; cx.res_nf = m.nf; cx.res_ne = ne;
+					cx.resident_token = 0;
+				}
+				arrays_ready = true;
+			}
 			if (!arrays_ready) {
 				cx.d_org.ensure(std::max<size_t>((size_t)ne * 4, 16)); cx.d_twin.ensure(std::max<size_t>((size_t)ne * 4, 16));
 				cx.d_foff.ensure(((size_t)m.nf + 1) * 4);
@@ -246,13 +419,20 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 					L.quant = to[l];
 				}
 			}
+			if (shares0) rplans.clear();   // (quantised above, once for the whole lists)
 			std::exception_ptr up_err;
 			double up_ms = 0;
-			std::thread uploader([&] {
+			std::thread uploader;
+			if (!shares0) uploader = std::thread([&] {
+				struct Turn { Turnstile *t; int s; ~Turn() { if (t) t->leave(s); } } turn{ copy_turns ? copy_turn[copy_group[w]].get() : nullptr, s };
 				try {
+					if (turn.t) turn.t->enter(s);   // (the link to this device: one shard's intervals after the other)
 					const auto tu = Clock::now();
 					HIP_OK(hipSetDevice(cx.device));
 					hipStream_t us = cx.stream2;
+					// (the twins go up while this worker's and the others' walks repair some of them in the host array: whichever value
+					// a repaired entry arrives with, every repaired entry is sent again as a (half-edge, twin) pair once its group is
+					// walked -- by the encode's pipeline, or by upload_repaired_twins(patches_only) -- and both wait for these copies)
 					for (const auto &iv : fiv) {
 						const size_t h0 = m.face_off[iv.first], h1 = m.face_off[iv.second];
 						HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + iv.first, m.face_off.data() + iv.first, ((size_t)iv.second - iv.first + 1) * 4, hipMemcpyHostToDevice, us));
@@ -268,18 +448,31 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 					for (const ListPlan &rp : rplans)
 						for (const auto &iv : rp.l == 0 ? fiv : viv)
 							dev::launch_requant(us, cx.d_rec[rp.l].as<uint8_t>() + iv.first * rp.stride, iv.second - iv.first, (int)rp.stride, rp.plan);
+					if (turn.t) { turn.t->leave(s); turn.t = nullptr; }   // (every copy is staged: the next shard's may start while the last of these land)
 					HIP_OK(hipStreamSynchronize(us));
 					up_ms = ms_since(tu);
 				} catch (...) { up_err = std::current_exception(); }
 			});
 			struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{ uploader };
 			t = Clock::now();
+			bool walk_entered = false, walk_left = false;
+			Turnstile *wt = turns ? walk_turn[walk_group[w]].get() : nullptr;
 			const InPlaceShard ip{ &m, &part, eface, &marks, &fiv, [&] {
-				uploader.join();
+				if (uploader.joinable()) uploader.join();
 				if (up_err) std::rethrow_exception(up_err);
 				w_upload[w] += up_ms;
+			}, [&] {   // before the walk: this shard's turn at the node's CPUs, all of them
+				if (!wt) return;
+				wt->enter(s); walk_entered = true;
+				set_thread_budget(walk_budget[w]);
+			}, [&] {   // after it
+				if (!wt) return;
+				set_thread_budget(own_budget);
+				wt->leave(s); walk_left = true;
 			} };
+			struct Pass { Turnstile *t; int s; bool &left; ~Pass() { if (t && !left) { t->enter(s); t->leave(s); } } } pass{ wt, s, walk_left };   // (a shard that never walked passes its turn on)
 			encode_chunked(cx, sk, chunk_syms, parts[s], &ip);
+			(void)walk_entered;
 			w_encode[w] += ms_since(t);
 			const hry_timing &tm = cx.timing;
 			acc.host_walk_ms += tm.host_walk_ms; acc.h2d_ms += tm.h2d_ms; acc.device_ms += tm.device_ms; acc.d2h_ms += tm.d2h_ms;
@@ -287,6 +480,7 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 			acc.total_ms += tm.total_ms;
 		}
 		cx.timing = acc;
+	  } catch (...) { abort_turns(); throw; }
 	});
 	st.phase_b_ms = ms_since(t0);
 	mark("segments");
@@ -297,7 +491,7 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 	merge_containers(pp.data(), ps.data(), pp.size(), out);
 	st.merge_ms = ms_since(t0);
 	auto mx = [](const std::vector<double> &v) { double x = 0; for (double y : v) x = std::max(x, y); return x; };
-	st.extract_ms = mx(w_upload); st.quant_ms = mx(w_quant); st.encode_ms = mx(w_encode);
+	st.extract_ms = mx(w_upload); st.encode_ms = mx(w_encode);   // (quant_ms: set where the whole lists were quantised on the first context)
 	for (int w = 0; w < n_ctx; ++w) st.host_walk_ms = std::max(st.host_walk_ms, cxs[w]->timing.host_walk_ms);
 	st.n_segments = merged_segments(out);
 	st.total_ms = ms_since(t_all);
@@ -376,6 +570,7 @@ void encode_sharded(Context *const *cxs, int n_ctx, Mesh &m, const hry_quant *q,
 			Context &cx = *cxs[w];
 			auto t = Clock::now();
 			if (nq || clear) device_requant(cx, *shards[s], q, nq, clear);
+			w_quant[w] += ms_since(t);
 			t = Clock::now();
 			encode_chunked(cx, *shards[s], chunk_syms, parts[s]);
 			w_encode[w] += ms_since(t);

@@ -12,6 +12,7 @@
 
 #include "dev_types.hpp"
 #include "fan.hpp"
+#include "kernels.hpp"
 
 namespace hry {
 namespace dev {
@@ -341,11 +342,21 @@ __global__ __launch_bounds__(256) void k_cc_vertex_stats(const uint32_t *vfirst,
 
 constexpr uint32_t kTiePairs = 1u << 22;   // capacity of the tie list (8 bytes each; the configs[3] mesh at 100 M triangles notes 0.9 M)
 size_t components_workspace_bytes(uint32_t nv, uint32_t nf) { return ((size_t)3 * nf + nv + blocks_for(nf, kScanBlock) + 16) * 4 + (size_t)kTiePairs * 8 + 64; }
-// stage 1: label[f] = root of f's component, num = exclusive scan of the root flags (num[nf] = number of components)
-void launch_components_label(hipStream_t st, const ConnView &cv, void *ws, uint32_t **label_out, uint32_t **num_out)
+// where everything lies in that workspace -- the ONE place that knows (the driver, analysis.cpp, asks here)
+ComponentsWorkspace components_workspace(void *ws, uint32_t nv, uint32_t nf)
 {
-	uint32_t *label = (uint32_t*)ws, *flag = label + cv.nf, *num = flag + cv.nf, *sums = num + cv.nf + 1;
-	*label_out = label; *num_out = num;
+	ComponentsWorkspace w;
+	w.label = (uint32_t*)ws; w.flag = w.label + nf; w.num = w.flag + nf; w.sums = w.num + nf + 1;
+	w.vfirst = w.sums + blocks_for(nf, kScanBlock) + 8;
+	// the tie list behind the vertex words, 8-byte aligned; its counter (two words) in front of it
+	w.tie_count = (uint32_t*)(((uintptr_t)(w.vfirst + nv) + 7) & ~(uintptr_t)7);
+	w.tie_pairs = w.tie_count + 2;
+	return w;
+}
+// stage 1: label[f] = root of f's component, num = exclusive scan of the root flags (num[nf] = number of components)
+void launch_components_label(hipStream_t st, const ConnView &cv, const ComponentsWorkspace &w)
+{
+	uint32_t *label = w.label, *flag = w.flag, *num = w.num, *sums = w.sums;
 	if (!cv.nf) return;
 	const unsigned nb = blocks_for(cv.nf, kScanBlock);
 	hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
@@ -363,13 +374,13 @@ void launch_components_faces(hipStream_t st, const ConnView &cv, uint32_t *label
 	if (cv.nf) hipLaunchKernelGGL(k_cc_face_stats, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, label, num, spans, nspans, nfaces, nhe, flo, fhi, (unsigned long long*)first_key);
 }
 // stage 3: per component in coding order (rank_of: component number -> rank; vfirst 0xff-filled, tie[k] = k, fresh 0, vlo 0xff, vhi 0 by the caller)
-void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t ncomp, const uint32_t *comp, const uint32_t *rank_of,
-                                uint32_t *vfirst, uint32_t *tie, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi)
+void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv, uint32_t ncomp, const ComponentsWorkspace &w, const uint32_t *rank_of,
+                                uint32_t *tie, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi)
 {
 	if (!cv.ne || !nv) return;
-	// the tie list behind the vertex words (components_workspace_bytes), 8-byte aligned; its counter in front of it
-	uint32_t *count = (uint32_t*)(((uintptr_t)(vfirst + nv) + 7) & ~(uintptr_t)7);
-	uint2 *pairs = (uint2*)(count + 2);
+	const uint32_t *comp = w.label;
+	uint32_t *vfirst = w.vfirst, *count = w.tie_count;
+	uint2 *pairs = (uint2*)w.tie_pairs;
 	(void)hipMemsetAsync(count, 0, 8, st);
 	hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(ncomp, 256)), dim3(256), 0, st, tie, ncomp);
 	hipLaunchKernelGGL(k_cc_vertex_first, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, vfirst);

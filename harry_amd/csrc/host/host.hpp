@@ -183,6 +183,8 @@ struct ShardPlan {
 // light: for shards that are coded where they lie in the whole mesh (shard_components + cut_border_walk_in_place: the in-process
 // executor) -- no per-element index, shard_extract refuses such a plan
 void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan, bool light = false);
+void shard_plan_from_analysis(const Mesh &m, uint32_t n_shards, ComponentAnalysis &&A, ShardPlan &plan);   // light; A: the tables per coding rank + intervals
+void shard_plan_finish(const Mesh &m, uint32_t n_shards, ShardPlan &plan);   // (internal: plan.A is complete)
 void shard_components(const ShardPlan &plan, uint32_t shard, ComponentAnalysis &part, ShardInfo &info);
 void shard_intervals(const ShardPlan &plan, uint32_t shard, uint32_t gap, std::vector<std::pair<uint32_t, uint32_t>> &faces, std::vector<std::pair<uint32_t, uint32_t>> &vertices);
 Mesh *shard_extract(const Mesh &m, const ShardPlan &plan, uint32_t shard);
@@ -249,6 +251,9 @@ void stay_on_node(const void *cpus);   // confines the calling thread
 const void *callers_neighbour_cpus();   // the caller's cache domain (else memory node) without the caller's own core (nullptr: unknown)
 const void *callers_cache_cpus(unsigned *n_cpus);   // CPUs sharing the caller's last-level cache (nullptr: unknown)
 void run_on_helpers(unsigned n, void (*fn)(void*, unsigned), void *arg, const void *cpus);   // thread_pool.cpp: helper threads kept between calls
+// CONTRACT: the indices may run ONE AFTER THE OTHER on the calling thread (a helper thread that cannot be created leaves its index
+// to the caller, after index 0).  A body must therefore never wait for another index (no barriers, no hand-overs between indices);
+// every body here takes work off a shared counter or owns a range computed from (index, n_threads), which stays what was asked for.
 template <typename F> inline void parallel_for(unsigned n_threads, F &&body, const void *cpus = nullptr)   // body(thread index), returns when every index has
 {
 	if (n_threads <= 1) { body(0); return; }

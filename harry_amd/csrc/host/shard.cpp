@@ -55,6 +55,37 @@ void shard_plan(const Mesh &m, uint32_t n_shards, ShardPlan &plan, bool light)
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry plan] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	analyse_components(m, A);
 	mark("components analysed");
+	shard_plan_finish(m, n_shards, plan);
+}
+
+// the plan of a mesh whose components somebody else has analysed (device/analysis.cpp: the tables per coding rank, the index
+// intervals; no per-face labels): a light plan, for shards that are coded where they lie
+void shard_plan_from_analysis(const Mesh &m, uint32_t n_shards, ComponentAnalysis &&A, ShardPlan &plan)
+{
+	if (n_shards == 0) throw Error(HRY_E_ARG, "need at least one shard");
+	if (m.nf == 0) throw Error(HRY_E_UNSUPPORTED, "mesh without faces");
+	if (m.shard.active()) throw Error(HRY_E_ARG, "a shard cannot be sharded again");
+	if (m.general) throw Error(HRY_E_INTERNAL, "shard plan: general bindings need the per-face labels");
+	const uint32_t nc = A.ncomp;
+	if (nc == 0 || A.seed.size() != nc || A.n_faces.size() != nc || A.n_halfedges.size() != nc || A.fresh.size() != nc || A.group.size() != nc || A.face_lo.size() != nc ||
+	    A.face_hi.size() != nc || A.vtx_lo.size() != nc || A.vtx_hi.size() != nc)
+		throw Error(HRY_E_INTERNAL, "shard plan: incomplete analysis");
+	plan = ShardPlan();
+	plan.n_shards = n_shards;
+	plan.g_nv = m.nv; plan.g_nf = m.nf; plan.g_ne = m.ne();
+	plan.have_degree = m.have_degree;
+	plan.light = true;
+	plan.A = std::move(A);
+	shard_plan_finish(m, n_shards, plan);
+}
+
+// scans, groups onto shards, and (unless the plan is light) where every element goes: plan.A is complete
+void shard_plan_finish(const Mesh &m, uint32_t n_shards, ShardPlan &plan)
+{
+	ComponentAnalysis &A = plan.A;
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry plan] %8.2f ms  (finish) %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	const uint32_t nc = A.ncomp;
 	// numbering of the decoded mesh: exclusive scans in coding order
 	plan.base_v.resize(nc + 1); plan.base_f.resize(nc + 1); plan.base_he.resize(nc + 1);

@@ -84,6 +84,7 @@ void helper_main(std::shared_ptr<PoolState> st, unsigned index, uint64_t seen)
 void run_on_fresh_threads(unsigned n, void (*fn)(void*, unsigned), void *arg, const void *node)
 {
 	std::vector<std::thread> th;
+	th.reserve(n);   // (before the first thread exists: growing the vector must not be what throws while joinable threads sit in it)
 	unsigned started = 1;
 	try {
 		for (; started < n; ++started) th.emplace_back([=] { stay_on_node(node); fn(arg, started); });

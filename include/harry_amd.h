@@ -245,7 +245,7 @@ typedef struct hry_shard_timing {
     double extract_ms;   /* encode: hry_shard_extract (decode: placement into the whole numbering), max over the workers */
     double bounds_ms;    /* upload + k_bounds per shard, max over the workers */
     double combine_ms;   /* bounds of the whole mesh from the shards' */
-    double quant_ms;     /* hry_requant per shard, max over the workers */
+    double quant_ms;     /* quantisation: of the whole lists on the first context (device plan), of the extracted shards (max over the workers); coded in place on other devices it is part of extract_ms */
     double encode_ms;    /* hry_encode (decode: the segments' decode), max over the workers */
     double merge_ms;     /* concatenation of the segments (decode: filler for what no decoded run covers) */
     double phase_a_ms;   /* wall clock: extraction + bounds on all workers */

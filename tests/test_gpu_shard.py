@@ -160,10 +160,21 @@ def test_merge_checks_headers(cx):
 # ---- one process, N contexts (include/harry_amd.h: hry_encode_sharded / hry_decode_sharded) ----------------------------------
 @pytest.mark.parametrize("kind,quant", [("mixed_nm", []), ("mixed_nm", [(1, -1, 12)]), ("tori_normals", [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)])])
 @pytest.mark.parametrize("n_ctx", [2, 8])
-def test_in_process_contexts_run_concurrently_and_match_the_virtual_ranks(cx, kind, quant, n_ctx):
+@pytest.mark.parametrize("how", ["host-plan", "host-plan-turns", "device-plan", "device-plan-turns", "device-plan-small-batches"])
+def test_in_process_contexts_run_concurrently_and_match_the_virtual_ranks(cx, kind, quant, n_ctx, how, monkeypatch):
     """N contexts on device 0, one worker thread each, all at once: the merged container is byte for byte what the shards give
     when they are coded one after the other on one context, and decodes (on the N contexts at once, and on one) to the
-    reference-format decode of the whole mesh."""
+    reference-format decode of the whole mesh.  device-plan (round 5; what a large mesh takes): the whole mesh resident on the
+    first context, its components analysed there, the other contexts of that device reading the first one's arrays; the walks of
+    the workers all at once (or in turn), the encode's device side beside them."""
+    if how.startswith("device-plan"):
+        monkeypatch.setenv("HRY_DEVICE_ANALYSIS_MIN_FACES", "1")
+        monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
+        monkeypatch.setenv("HRY_HOST_THREADS", "6")
+    if how.endswith("-turns"):
+        monkeypatch.setenv("HRY_SHARD_TURNS", "1")
+    if how == "device-plan-small-batches":
+        monkeypatch.setenv("HRY_ENCODE_PIPELINE_BATCH", "1")
     gen = _mesh(kind)
     _, _, parts = _encode_sharded(cx, gen, n_ctx, quant, chunk_syms=1024)
     want = hc.merge(parts)
