@@ -630,6 +630,226 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 	next_id_io = next_id; consumed_io = consumed;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The triangle walk on TWO cores (round 5).  The loop above is bound by its instructions (132 per triangle at 3.5 per cycle, no
+// misses to speak of), and a quarter of them decide nothing: the triangle counts per vertex (three read-modify-writes per
+// triangle: they only select an operation's model class, models.h:101-105), the operation byte, the coded-vertex and coded-face
+// entries, the per-class counters.  So the walking thread (A) keeps what the automaton needs -- the border, the face marks, which
+// vertices are coded, the twins -- and writes ONE 8-byte record per operation into a trace: (half-edge the triangle was entered
+// through | operation) or (head vertex | border operation), plus the rare operands (the split / union position).  A second thread
+// (B) on a core next to it (same last-level cache, not the sibling hardware thread) follows the trace and expands it: the vertices
+// of a triangle are the origins of the entered half-edge's face, in order (the entered half-edge runs against the gate: from its
+// head to its tail), the model class from its own count table, then the operation byte, order_v / order_f, and everything that
+// goes through the Emitter (component marks, initial operations, explicitly named vertices).  The output is what the one-thread
+// loop writes, entry for entry (tests/test_host_cpu.py compares them); A alone measured 7.9 -> 6.0 - 6.4 ms per million
+// triangles on the boxes' EPYC 9575F before B existed (a ring that stays in its cache; 6.9 with one that does not).
+// HRY_WALK_SPLIT=0: the one-thread loop.
+struct WalkTrace {
+	enum { T_TRI = 0, T_BORDER = 1, T_START = 2, T_NEXTID = 3, T_ELEM = 4, T_PART = 5 };   // code in bits 8..15 of the high word, operation in bits 0..7
+	BigVec<uint64_t> rec;
+	alignas(64) std::atomic<size_t> head{ 0 };
+	alignas(64) std::atomic<int> done{ 0 };
+	static uint64_t make(uint32_t a, uint32_t code, uint32_t op, uint32_t payload = 0) { return (uint64_t)a | ((uint64_t)(op | (code << 8) | (payload << 16)) << 32); }
+};
+
+// A: the automaton (the loop of walk_component_tri<false> without what B does)
+static void walk_component_tri_a(Mesh &m, WalkState &st, uint32_t f, Border &cb, WalkResult &w, WalkTrace &tr, size_t &at_io, uint32_t &next_id_io, uint32_t &consumed_io)
+{
+	const uint32_t *org = m.org.data();
+	uint32_t *twin = m.twin.data();
+	Gone *gone = st.gone.data();
+	uint32_t *sent = st.sent.data();
+	OnCount *on = st.on.data();
+	uint32_t next_id = next_id_io, consumed = consumed_io;
+	bool changed = false;
+	std::vector<uint32_t> &tp = w.twin_patches;
+	static const int pf_level = [] { const char *e = getenv("HRY_WALK_PREFETCH"); return e ? atoi(e) : 2; }();
+	uint64_t *rec = tr.rec.data();
+	size_t at = at_io, published = at_io;
+	auto put = [&](uint64_t r) {
+		rec[at++] = r;
+		if (at - published >= 256) { tr.head.store(at, std::memory_order_release); published = at; }
+	};
+	gone[f] = Gone::yes; ++consumed;
+	{
+		const uint32_t e0 = 3 * f, e1 = e0 + 1, e2 = e0 + 2;
+		const uint32_t a = org[e0], b = org[e1], c = org[e2];
+		const unsigned mask = (sent[a] != NONE32 ? 4u : 0u) | (sent[b] != NONE32 ? 2u : 0u) | (sent[c] != NONE32 ? 1u : 0u);
+		put(WalkTrace::make(f, WalkTrace::T_START, 0, mask));
+		put(WalkTrace::make(next_id, WalkTrace::T_NEXTID, 0));
+		auto fresh = [&](uint32_t v) { sent[v] = next_id++; };
+		switch (mask) {   // the order in which the one-thread loop numbers the new vertices (encoder.h:68-131)
+		case 7: break;
+		case 6: fresh(c); break;
+		case 3: fresh(a); break;
+		case 5: fresh(b); break;
+		case 4: fresh(b); fresh(c); break;
+		case 2: fresh(c); fresh(a); break;
+		case 1: fresh(a); fresh(b); break;
+		default: fresh(a); fresh(b); fresh(c); break;
+		}
+		cb.start(a, e0, b, e1, c, e2);
+	}
+	Border::Node *P = cb.P;
+	while (!cb.parts.empty()) {
+		Border::Part &pt = cb.parts.back();
+		const int32_t tn = pt.tail, hn = pt.head;
+		const uint32_t gate = P[tn].a;
+		const uint32_t t = twin[gate];
+		uint32_t fc = t / 3u;
+		if (t == gate || gone[fc] != Gone::no) {   // writer.cc:48-58: mesh border or neighbour already consumed
+			const uint32_t v1 = P[hn].v;
+			const Op bop = cb.border();
+			P = cb.P;
+			if (t != gate) { twin[gate] = gate; changed = true; tp.push_back(gate); }   // one-sided split (writer.cc:81-84)
+			put(WalkTrace::make(v1, WalkTrace::T_BORDER, (uint32_t)bop));
+			continue;
+		}
+		gone[fc] = Gone::yes; ++consumed;
+		const uint32_t base = 3u * fc, kk = t - base;
+		const uint32_t e1 = base + (kk == 2u ? 0u : kk + 1u), e2 = base + (kk == 0u ? 2u : kk - 1u);
+		const uint32_t v2 = org[e2];
+		if (pf_level >= 1) {
+			const uint32_t t1 = twin[e1], t2 = twin[e2];
+			if (pf_level >= 2) { __builtin_prefetch(org + t1); __builtin_prefetch(org + t2); }
+			if (pf_level >= 3) { __builtin_prefetch(gone + t1 / 3u); __builtin_prefetch(gone + t2 / 3u); }
+		}
+		const bool fresh = sent[v2] == NONE32;
+		if (fresh || on[v2] == 0) {
+			P[tn].a = e1;
+			const int32_t nn = cb.make(v2, e2);
+			P = cb.P;
+			cb.append(cb.parts.back(), nn);
+			if (fresh) { sent[v2] = next_id++; put(WalkTrace::make(t, WalkTrace::T_TRI, O_NEWVTX)); }
+			else put(WalkTrace::make(t, WalkTrace::T_TRI, O_NM));
+		} else if (pt.edge_begin && P[P[hn].next].v == v2) {
+			const bool close = pt.size == 3;
+			const uint32_t gatenext = P[hn].a;
+			if (twin[gatenext] != e2) { twin[gatenext] = e2; twin[e2] = gatenext; changed = true; tp.push_back(gatenext); tp.push_back(e2); }
+			if (close) {
+				const uint32_t gateprev = P[P[tn].prev].a;
+				if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; tp.push_back(gateprev); tp.push_back(e1); }
+				cb.discard_top();
+			} else { cb.drop(cb.unlink_head(pt)); P[pt.tail].a = e1; }
+			put(WalkTrace::make(t, WalkTrace::T_TRI, O_CONNFWD));
+		} else if (P[P[tn].prev].v == v2) {
+			const uint32_t gateprev = P[P[tn].prev].a;
+			if (twin[gateprev] != e1) { twin[gateprev] = e1; twin[e1] = gateprev; changed = true; tp.push_back(gateprev); tp.push_back(e1); }
+			cb.drop(cb.unlink_tail(pt));
+			P[pt.tail].a = e2;
+			put(WalkTrace::make(t, WalkTrace::T_TRI, O_CONNBWD));
+		} else {
+			int i, p;
+			const int32_t hit = cb.locate(v2, i, p);
+			int32_t g, cp;
+			if (p > 0) {
+				cb.unite(hit, p, g, cp);
+				P = cb.P;
+				put(WalkTrace::make(t, WalkTrace::T_TRI, O_UNION));
+				put(WalkTrace::make((uint32_t)i, WalkTrace::T_ELEM, 0));
+				put(WalkTrace::make((uint32_t)p, WalkTrace::T_PART, 0));
+			} else {
+				cb.split(hit, i, g, cp);
+				P = cb.P;
+				put(WalkTrace::make(t, WalkTrace::T_TRI, O_SPLIT));
+				put(WalkTrace::make((uint32_t)i, WalkTrace::T_ELEM, 0));
+			}
+			P[g].a = e1; P[cp].a = e2;
+		}
+	}
+	tr.head.store(at, std::memory_order_release);
+	at_io = at;
+	if (changed) w.twins_changed = true;
+	next_id_io = next_id; consumed_io = consumed;
+}
+
+// B: follows the trace until A says it is complete; owns the Emitter and the per-vertex triangle counts meanwhile
+static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTrace &tr)
+{
+	const uint32_t *org = m.org.data();
+	const uint32_t *sent = st.sent.data();   // (read for vertices that were coded before the record was written: final by then)
+	uint16_t *seen = st.seen.data();
+	const uint64_t *rec = tr.rec.data();
+	OpByte *opc = em.op_cur;
+	uint32_t *ovc = em.ov_cur, *ofc = em.of_cur;
+	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, n_ops = 0, faces = 0;
+	auto emit = [&](uint32_t s, uint32_t order) {
+		const uint32_t k = order == 0 ? 0u : order > 8u ? 7u : order - 1u;   // models.h:101-105
+		++n_op[k]; ++n_ops;
+		*opc++ = (OpByte)(s | (k << 3));
+	};
+	auto sync_n = [&] { em.n += n_ops; n_ops = 0; };
+	size_t pos = 0;
+	for (;;) {
+		size_t h = tr.head.load(std::memory_order_acquire);
+		if (h == pos) {
+			if (tr.done.load(std::memory_order_acquire)) { h = tr.head.load(std::memory_order_acquire); if (h == pos) break; }
+			else { __builtin_ia32_pause(); continue; }
+		}
+		// (a split / union / start record is followed by its operands: A publishes whole groups only at the end of a component or
+		// in blocks of 256, so an operand may still be on its way -- wait for it)
+		auto need = [&](size_t k) { while (h < k) { __builtin_ia32_pause(); h = tr.head.load(std::memory_order_acquire); } };
+		while (pos < h) {
+			if (pos + 8 < h) { const uint64_t ahead = rec[pos + 8]; if (((ahead >> 40) & 0xffu) == WalkTrace::T_TRI) __builtin_prefetch(org + 3u * ((uint32_t)ahead / 3u)); }
+			const uint64_t r = rec[pos++];
+			const uint32_t a = (uint32_t)r, hi = (uint32_t)(r >> 32), op = hi & 0xffu, code = (hi >> 8) & 0xffu;
+			if (code == WalkTrace::T_TRI) {
+				const uint32_t base = 3u * (a / 3u), kk = a - base;
+				const uint32_t e1 = base + (kk == 2u ? 0u : kk + 1u), e2 = base + (kk == 0u ? 2u : kk - 1u);
+				const uint32_t v1 = org[a], v0 = org[e1], v2 = org[e2];
+				const uint32_t order = seen[v1];
+				emit(op, order);
+				if (op == O_NEWVTX) *ovc++ = e2;
+				else if (op == O_NM) { sync_n(); em.vert(sent[v2], seen[v2]); }
+				else if (op == O_UNION) {
+					need(pos + 2);
+					sync_n(); em.elem((int)(int32_t)(uint32_t)rec[pos]); em.part((int)(uint32_t)rec[pos + 1]);
+					pos += 2;
+				} else if (op == O_SPLIT) {
+					need(pos + 1);
+					sync_n(); em.elem((int)(int32_t)(uint32_t)rec[pos]);
+					pos += 1;
+				}
+				++seen[v0]; ++seen[v1]; ++seen[v2];
+				*ofc++ = a;
+				++faces;
+			} else if (code == WalkTrace::T_BORDER) {
+				emit(op, seen[a]);
+			} else if (code == WalkTrace::T_START) {
+				need(pos + 1);
+				const uint32_t next_id = (uint32_t)rec[pos++];
+				const unsigned mask = (hi >> 16) & 0xffu;
+				// the Emitter's own view of the cursors and counters (its mark of the new component reads them)
+				sync_n();
+				for (int i = 0; i < 8; ++i) { em.n_op[i] += n_op[i]; n_op[i] = 0; }
+				em.halfedges += 3 * faces; faces = 0;
+				em.op_cur = opc; em.ov_cur = ovc; em.of_cur = ofc;
+				em.mark_component(next_id);
+				const uint32_t e0 = 3 * a, e1 = e0 + 1, e2 = e0 + 2;
+				const uint32_t va = org[e0], vb = org[e1], vc = org[e2];
+				auto recv = [&](uint32_t e) { *ovc++ = e; };
+				switch (mask) {   // encoder.h:68-131 (numtri is not coded: one polygon degree)
+				case 7: em.iop(I_TRI111); em.vert(sent[va], seen[va]); em.vert(sent[vb], seen[vb]); em.vert(sent[vc], seen[vc]); break;
+				case 6: em.iop(I_TRI110); em.vert(sent[va], seen[va]); em.vert(sent[vb], seen[vb]); recv(e2); break;
+				case 3: em.iop(I_TRI011); em.vert(sent[vb], seen[vb]); em.vert(sent[vc], seen[vc]); recv(e0); break;
+				case 5: em.iop(I_TRI101); em.vert(sent[vc], seen[vc]); em.vert(sent[va], seen[va]); recv(e1); break;
+				case 4: em.iop(I_TRI100); em.vert(sent[va], seen[va]); recv(e1); recv(e2); break;
+				case 2: em.iop(I_TRI010); em.vert(sent[vb], seen[vb]); recv(e2); recv(e0); break;
+				case 1: em.iop(I_TRI001); em.vert(sent[vc], seen[vc]); recv(e0); recv(e1); break;
+				default: em.iop(I_INIT); recv(e0); recv(e1); recv(e2); break;
+				}
+				*ofc++ = e0;
+				++seen[va]; ++seen[vb]; ++seen[vc];
+				++faces;
+			} else throw Error(HRY_E_INTERNAL, "walk trace: stray record");
+		}
+	}
+	sync_n();
+	for (int i = 0; i < 8; ++i) em.n_op[i] += n_op[i];
+	em.halfedges += 3 * faces;
+	em.op_cur = opc; em.ov_cur = ovc; em.of_cur = ofc;
+}
+
 // The component walk for polygons, written like the triangle loop above (round 4; hardware counters of the generic loop on the
 // configs[3] share: 240 instructions and 108 cycles per triangle).  A polygon is a fan of triangles around the vertex its gate
 // starts at (encoder.h:133-166): the face's half-edge range stays in locals while its triangles are coded, so "next edge" is a
@@ -811,6 +1031,22 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	mark("(sequential part) start faces and output planes");
 	uint32_t next_id = 0, consumed = 0;
 	const bool count = getenv("HRY_PERF") != nullptr;   // hardware counters of this thread around the first component's walk
+	// the triangle walk on two cores (walk_component_tri_a / walk_trace_expand above): large triangle meshes of the chunked profile
+	struct Split {
+		std::unique_ptr<WalkTrace> trace;
+		std::thread expander;
+		std::exception_ptr err;
+		size_t at = 0;
+		void stop()
+		{
+			if (!expander.joinable()) return;
+			trace->done.store(1, std::memory_order_release);
+			expander.join();
+		}
+		~Split() { stop(); }
+	} split;
+	const uint32_t split_min_faces = [] { const char *e = getenv("HRY_WALK_SPLIT"); return e ? (atoi(e) > 0 ? (uint32_t)atoi(e) : 0xffffffffu) : (1u << 17); }();   // 0: never; n: from n faces (read per call: the tests change it)
+	const bool want_split = DEG == 3 && !eval_op_model && !getenv("HRY_GENERIC_WALK") && !count && n_threads > 1 && m.nf >= split_min_faces;
 	do {
 		uint32_t f = pool.next();
 		const bool lean = DEG == 3 && !getenv("HRY_GENERIC_WALK");
@@ -826,7 +1062,21 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 			pc.report(eval_op_model ? "cut-border walk (with the operation model)" : "cut-border walk", (double)(em.halfedges - 2.0 * consumed));
 			continue;
 		}
-		if (lean && eval_op_model) walk_component_tri<true>(m, st, f, cb, em, next_id, consumed);
+		if (want_split) {
+			if (!split.trace) {
+				split.trace.reset(new WalkTrace());
+				// a record per triangle and per border operation, at most two operands per triangle, two records per component start
+				split.trace->rec.resize((size_t)3 * m.ntri() + m.ne() + (size_t)2 * m.nf + 64);
+				const void *near_cpus = callers_neighbour_cpus();   // (this thread's cache domain without its own core)
+				WalkTrace *trp = split.trace.get();
+				std::exception_ptr *errp = &split.err;
+				split.expander = std::thread([&m, &st, &em, trp, errp, near_cpus] {
+					try { stay_on_node(near_cpus); walk_trace_expand(m, st, em, *trp); } catch (...) { *errp = std::current_exception(); }
+				});
+			}
+			walk_component_tri_a(m, st, f, cb, w, *split.trace, split.at, next_id, consumed);
+		}
+		else if (lean && eval_op_model) walk_component_tri<true>(m, st, f, cb, em, next_id, consumed);
 		else if (lean) walk_component_tri<false>(m, st, f, cb, em, next_id, consumed);
 		else if (lean_poly) walk_component_poly<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
 		else walk_component<DEG>(m, st, eface_tab, f, cb, em, next_id, consumed);
@@ -834,12 +1084,16 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 		// it is one sequence.  Without it (chunked profile: symbol + order class only) the remaining components are walked on
 		// several threads once the first one shows that the mesh has more than one.
 		if (n_threads > 1 && !eval_op_model && m.nf - consumed >= parallel_min_faces()) {
+			split.stop();   // (the expander owns the Emitter until the trace is complete)
+			if (split.err) std::rethrow_exception(split.err);
 			em.detach();
 			mark("(sequential part) first component walked");
 			walk_rest_parallel<DEG>(m, st, eface_tab, em, next_id, n_threads);
 			break;
 		}
 	} while (consumed != m.nf);
+	split.stop();
+	if (split.err) std::rethrow_exception(split.err);
 	mark("(sequential part) back");
 	em.detach();
 	em.finish_marks();

@@ -368,6 +368,37 @@ def test_lean_triangle_walk_equals_generic_walk(case, threads, monkeypatch):
     assert np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("case", ["torus", "open_grid", "ico", "multi_nm", "multi_shared", "tiny", "torus_big"])
+def test_triangle_walk_on_two_cores_equals_the_one_thread_loop(case, monkeypatch):
+    """cbm_walk.cpp, round 5: the walking thread writes a trace of its decisions, a second thread expands it into the operation
+    bytes, order_v / order_f, the marks and the explicitly named vertices -- entry for entry what the one-thread loop writes
+    (meshes with borders, non-manifold edges and vertices, several components one after the other, components that name each
+    other's vertices, splits and unions of the cut-border)."""
+    def shared():
+        parts = [mg.grid(5, 6, seed=s) for s in range(7)]
+        b = mg.concat(parts)
+        idx = b.indices.copy()
+        nvp = parts[0].nv
+        for k in range(1, 7):
+            idx[idx == k * nvp + 3] = 3          # one vertex of every part becomes vertex 3 of the first
+        return mg.Mesh(b.verts, b.degrees, idx, None)
+    mesh = {"torus": lambda: mg.torus(40, 36), "open_grid": lambda: mg.grid(31, 17), "ico": lambda: mg.icosphere(4),
+            "multi_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 9, 10, polys="tri"), 7, 4), "multi_shared": shared, "tiny": lambda: mg.grid(2),
+            "torus_big": lambda: mg.torus(300, 280)}[case]()
+    monkeypatch.setenv("HRY_HOST_THREADS", "2")
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "4000000000")   # (every component in the sequential loop)
+    out = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("HRY_WALK_SPLIT", split)
+        m = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
+        w = m.host_walk(plain=True)
+        out.append((w, m.twin()))
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
+    assert np.array_equal(out[0][1], out[1][1])
+    assert len(out[0][0]["order_f"]) == mesh.nf
+
+
 @pytest.mark.timeout(120)
 def test_parallel_walk_in_a_forked_child(monkeypatch):
     """the helper threads of parallel_for (host/thread_pool.cpp) are kept between calls; a forked child has none of them and must
