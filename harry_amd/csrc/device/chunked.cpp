@@ -812,9 +812,39 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	// ---- device: one wavefront per stream
 	HIP_OK(hipMemsetAsync(cx.d_acc.p, 0, (size_t)nw * 8, cx.stream));
 	uint32_t *d_bits = cx.d_csizes.as<uint32_t>(), *d_nbytes = d_bits + ns;
+	// thousands of streams: the model a wavefront per stream, the range registers a lane per stream (chunked.hip: k_chunk_model,
+	// k_chunk_ranges; the one kernel is bound by the compute units' scalar units: 0.04 ns a symbol over all streams, and by its
+	// longest stream at 0.09 us a symbol; the two take 0.0057 ns a symbol for the model and 0.21 us a symbol of the longest stream
+	// for the ranges -- 100 M triangles: 28 -> 11.8 ms, the 12.6 M-triangle share 4.7 -> 3.9, the 1 M-triangle torus 0.76 -> 1.64).
+	// HRY_ENCODE_SPLIT_MIN_STREAMS: from how many streams instead of by that estimate (0 = never)
+	bool split_kernels;
+	{
+		uint32_t longest = 0;
+		for (uint32_t i = 0; i < ns; ++i) longest = std::max(longest, jobs[i].n);
+		const double one = std::max(longest * 0.09e-3, (double)nsym_total * 0.04e-6), two = longest * 0.207e-3 + (double)nsym_total * 0.0057e-6;   // ms
+		const char *e = getenv("HRY_ENCODE_SPLIT_MIN_STREAMS");
+		split_kernels = e ? (strtoul(e, nullptr, 10) != 0 && ns >= strtoul(e, nullptr, 10)) : (ns >= 64 && two < 0.9 * one);
+	}
+	for (uint32_t i = 0; i < ns && split_kernels; ++i) split_kernels = (uint64_t)jobs[i].t0 + jobs[i].n <= 65535u;   // (its records hold 16-bit counts)
+	std::vector<uint64_t> tab;   // (lives until the stream is waited for below)
+	if (split_kernels) {
+		tab.resize((size_t)ns + ((size_t)ns + 1) / 2);   // rec_off (u64 each), then the order (u32 each)
+		uint32_t *order = (uint32_t*)(tab.data() + ns);
+		uint64_t off = 0;
+		for (uint32_t i = 0; i < ns; ++i) { tab[i] = off; off += jobs[i].n; order[i] = i; }
+		std::stable_sort(order, order + ns, [&](uint32_t a, uint32_t b) { return jobs[a].n > jobs[b].n; });
+		cx.d_rec_sym.ensure(std::max<size_t>((size_t)off * 8, 16));
+		cx.d_split.ensure(tab.size() * 8);
+		HIP_OK(hipMemcpyAsync(cx.d_split.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, cx.stream));
+		HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
+		launch_chunk_encode_split(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_acc.as<uint64_t>(), d_bits,
+		                          cx.d_split.as<uint64_t>(), cx.d_rec_sym.p, (const uint32_t*)(cx.d_split.as<uint64_t>() + ns));
+		HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	} else {
 	HIP_OK(hipEventRecord(cx.ev[3], cx.stream));
 	launch_chunk_encode(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_acc.as<uint64_t>(), d_bits);
 	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
+	}
 	launch_carry(cx.stream, cx.d_acc.as<uint64_t>(), nw, cx.d_v.as<uint64_t>(), cx.d_summary.as<uint32_t>(), cx.d_bytes.as<uint8_t>());
 	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, nullptr, d_nbytes, cx.d_coffs.as<uint64_t>(), nullptr, false);
 	uint64_t total_bytes = 0;

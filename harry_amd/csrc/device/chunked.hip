@@ -136,6 +136,155 @@ __global__ __launch_bounds__(64) void k_chunk_encode(const StreamJob *jobs, cons
 	if (lane == 0) stream_bits[blockIdx.x] = S + 32;   // flush: the 32 bits of the low register (coder.h:58-67)
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The encoder in TWO kernels, for containers of thousands of streams (round 5).  k_chunk_encode above is bound by the ONE scalar
+// unit of a compute unit: every symbol's range step is a dozen scalar instructions on a serial chain, and the chains of all the
+// wavefronts of a compute unit share that unit (879 M symbols x ~18 / (256 units x 2.4 GHz) = 26 of the 28 ms the configs[3] mesh
+// takes at the named size).  The model does not need the range register, and the range register does not need the wavefront:
+//   k_chunk_model   a wavefront per stream, as above, but only the adaptive model by counting: per symbol (l, count) and floor(2^32 / t),
+//                   8 bytes, stream after stream -- vector work, 64 symbols a step;
+//   k_chunk_ranges  a LANE per stream, 64 streams per wavefront: arith::Encoder<uint32_t>::operator() (arith/coder.h:69-91) over
+//                   the records -- r = floor(R / t) by the reciprocal of t (t = t0 + position), the interval, one count-leading-
+//                   zeros for the renormalisation -- on the vector unit, sixty-four chains an instruction; the low register as
+//                   before is a sum of terms r l 2^-S: a lane keeps the two 32-bit output words under its position as 64-bit
+//                   counters and stores a word when its position has left it (k_carry_* folds and carries, unchanged).
+// Same bits as k_chunk_encode, stream for stream (tests: the container against the oracle's at both sizes of the switch).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_chunk_model(const StreamJob *jobs, const uint32_t *inits, const MagicEnt *magic, const unsigned long long *rec_off, uint2 *rec)
+{
+	const StreamJob jb = jobs[blockIdx.x];
+	const int lane = threadIdx.x;
+	__shared__ uint32_t cnt[257], cum[257], bh[256];
+	{
+		const uint32_t *st = inits + (size_t)jb.init * 256 + 4 * lane;
+		uint32_t a = st[0], b = st[1], c = st[2], d = st[3], tot;
+		uint32_t ex = wscan_excl(a + b + c + d, tot);
+		cnt[4 * lane] = a; cnt[4 * lane + 1] = b; cnt[4 * lane + 2] = c; cnt[4 * lane + 3] = d;
+		cum[4 * lane] = ex; cum[4 * lane + 1] = ex + a; cum[4 * lane + 2] = ex + a + b; cum[4 * lane + 3] = ex + a + b + c;
+		if (lane == 0) { cnt[256] = 0; cum[256] = 0; }
+	}
+	__syncthreads();
+	uint2 *out = rec + rec_off[blockIdx.x];
+	const uint64_t earlier = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	for (uint32_t base = 0; base < jb.n; base += 64) {
+		const uint32_t j = base + lane;
+		const bool valid = j < jb.n;
+		const uint32_t s = valid ? jb.sym[j] : 0x100u;
+		uint64_t eq = ~0ull, lt = 0;
+#pragma unroll
+		for (int b = 8; b >= 0; --b) {
+			const bool mine = (s >> b) & 1u;
+			const uint64_t m = __ballot(mine);
+			lt |= mine ? (eq & ~m) : 0ull;
+			eq &= mine ? m : ~m;
+		}
+		const uint32_t l = cum[s] + (uint32_t)__popcll(lt & earlier), c = cnt[s] + (uint32_t)__popcll(eq & earlier);
+		if (valid) {
+			// ... and floor(2^32 / t) for the range step (t = t0 + j; from the table's reciprocal floor(2^(32+s) / t) + 1 at shift s;
+			// a power of two has 2^31 at shift s - 1)
+			const MagicEnt me = magic[jb.t0 + j];
+			const uint32_t msh = (me.shift >> kMagicSh32Shift) & 31u;
+			const uint32_t q = me.m32 == 0x80000000u ? me.m32 >> msh : (me.m32 - 1u) >> msh;   // (2^31 >> (s - 1) = 2^(32 - s))
+			out[j] = make_uint2(l | (c << 16), q);   // (l and c below t0 + n <= 65535: the launcher checks)
+		}
+		bh[4 * lane] = 0; bh[4 * lane + 1] = 0; bh[4 * lane + 2] = 0; bh[4 * lane + 3] = 0;
+		__syncthreads();
+		if (valid) atomicAdd(&bh[s], 1u);
+		__syncthreads();
+		uint32_t a0 = bh[4 * lane], a1 = bh[4 * lane + 1], a2 = bh[4 * lane + 2], a3 = bh[4 * lane + 3], tot;
+		uint32_t ex = wscan_excl(a0 + a1 + a2 + a3, tot);
+		cnt[4 * lane] += a0; cnt[4 * lane + 1] += a1; cnt[4 * lane + 2] += a2; cnt[4 * lane + 3] += a3;
+		cum[4 * lane] += ex; cum[4 * lane + 1] += ex + a0; cum[4 * lane + 2] += ex + a0 + a1; cum[4 * lane + 3] += ex + a0 + a1 + a2;
+		__syncthreads();
+	}
+}
+
+// order: the streams longest first (waves of equally long chains); lane k of workgroup g runs stream order[64 g + k].
+// A lane's records lie one after the other in memory -- a load per lane would be 64 cache lines a wavefront -- so the wavefront
+// brings them in TOGETHER, a stream at a time: lane k loads record step0 + k of stream s (512 contiguous bytes), 64 such loads
+// fill two 64 x 64 tiles in LDS, transposed on the way (row s, 65 words apart: both the write of a row and a lane's walk along
+// its own row touch every bank once); the next tiles' loads are in flight while these tiles' 64 steps run.
+// A lone wavefront issues an instruction every five or six cycles whatever it is, so a step is written for FEW instructions and
+// no branches: floor(R / t) = umulhi(R, floor(2^32 / t)) or one more (the estimate is short by less than R / 2^32 <= 1/2: one
+// compare of the remainder), both interval candidates computed and selected, the term's two words by one 64-bit shift.  What is
+// left data-dependent is the store of an output word when a lane's position has left it.
+// (Versions on the way: record and table reciprocal loaded per lane a step ahead: 580 cycles a step; eight steps ahead: the same
+// -- the wavefront is bound by what it issues, not by what it waits for; the compiler's branches around the float-reciprocal
+// division and the two products: 640.)
+__global__ __launch_bounds__(64) void k_chunk_ranges(const StreamJob *jobs, uint32_t njobs, const uint32_t *order, const unsigned long long *rec_off,
+                                                     const uint2 *rec, unsigned long long *acc, uint32_t *stream_bits)
+{
+	__shared__ uint32_t tile_lc[64 * 65], tile_q[64 * 65];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t slot = blockIdx.x * 64 + lane;
+	const bool have = slot < njobs;
+	const uint32_t job = have ? order[slot] : 0u;
+	StreamJob jb{ nullptr, 0, 0, 256, 0 };
+	if (have) jb = jobs[job];
+	const uint32_t n = have ? jb.n : 0u;
+	const uint2 *in = rec + (have ? rec_off[job] : 0ull);
+	unsigned long long *dst = acc + jb.word_base;
+	uint32_t nmax = n;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+	nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+	const uint32_t in_lo = (uint32_t)(uintptr_t)in, in_hi = (uint32_t)((uintptr_t)in >> 32);
+	uint2 nxt[64];
+	// the records step0 .. step0 + 63 of every stream of the wavefront, one coalesced load a stream
+	auto fetch = [&](uint32_t step0) {
+#pragma unroll
+		for (int s = 0; s < 64; ++s) {
+			const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)n, s);
+			const uint2 *ps = (const uint2*)(((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)in_hi, s) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)in_lo, s));
+			const uint32_t j = step0 + lane;
+			nxt[s] = j < ns ? ps[j] : make_uint2(0u, 0u);
+		}
+	};
+	auto stash = [&]() {
+#pragma unroll
+		for (int s = 0; s < 64; ++s) { tile_lc[s * 65 + lane] = nxt[s].x; tile_q[s * 65 + lane] = nxt[s].y; }
+	};
+	uint32_t R = 1u << 31, S = 0, t = jb.t0;   // coder.h:47 with b = 32
+	uint32_t cur_w = 0;
+	unsigned long long a0 = 0, a1 = 0;   // the output words cur_w and cur_w + 1 as counters
+	fetch(0);
+	stash();
+	for (uint32_t step0 = 0; step0 < nmax; step0 += 64) {
+		const bool more = step0 + 64 < nmax;
+		if (more) fetch(step0 + 64);
+		const uint32_t *row_lc = tile_lc + lane * 65, *row_q = tile_q + lane * 65;
+		const uint32_t left = nmax - step0 < 64u ? nmax - step0 : 64u;   // (uniform)
+		for (uint32_t k = 0; k < left; ++k) {
+			const uint32_t lc = row_lc[k], q = row_q[k];
+			const bool live = step0 + k < n;   // (a lane past its stream's end goes through the motions on zeros and keeps its state)
+			const uint32_t l = lc & 0xffffu, c = lc >> 16;
+			uint32_t r = __umulhi(R, q);
+			r += R - r * t >= t ? 1u : 0u;      // floor(R / t)
+			uint32_t rl, rc;
+			asm("v_mul_lo_u32 %0, %1, %2" : "=v"(rl) : "v"(r), "v"(l));   // (both products, unconditionally: the compiler branches around one of them)
+			asm("v_mul_lo_u32 %0, %1, %2" : "=v"(rc) : "v"(r), "v"(c));
+			const uint32_t Rn = l + c == t ? R - rl : rc;   // the last symbol with a count: R' = R - r l (coder.h:74-77)
+			// low register: L += r l at bit position S (coder.h:71); r l <= R fits 32 bits: its two words by one 64-bit shift
+			const uint32_t w = S >> 5;
+			const unsigned long long two = ((unsigned long long)(live ? rl : 0u) << 32) >> (S & 31u);
+			if (w != cur_w) { dst[cur_w] = a0; a0 = a1; a1 = 0; cur_w = w; }   // (a step moves the position by at most 31 bits: one word)
+			a0 += two >> 32;
+			a1 += two & 0xffffffffull;
+			const uint32_t y = Rn - 1u;
+			const uint32_t sh = y ? (uint32_t)__builtin_clz(y) - 1u : 31u;
+			R = live ? Rn << sh : R;
+			S += live ? sh : 0u;
+			t += live ? 1u : 0u;
+		}
+		if (more) stash();
+	}
+	if (have) {
+		dst[cur_w] = a0;
+		dst[cur_w + 1u] = a1;
+		stream_bits[job] = S + 32u;   // flush: the 32 bits of the low register (coder.h:58-67)
+	}
+}
+
 // byte length of every stream and exclusive prefix (one workgroup; wave scans + LDS for the wave totals)
 __global__ __launch_bounds__(1024) void k_stream_offsets(const uint32_t *stream_bits, uint32_t n, uint32_t *nbytes, unsigned long long *offsets)
 {
@@ -510,6 +659,16 @@ void launch_scatter_u32(hipStream_t st, const uint32_t *pairs, uint32_t n, uint3
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits)
 {
 	if (nstreams) hipLaunchKernelGGL(k_chunk_encode, dim3(nstreams), dim3(64), 0, st, jobs, inits, magic, (unsigned long long*)acc, stream_bits);
+}
+// the same streams by k_chunk_model + k_chunk_ranges: rec_off[j] = records of the streams before j, rec = 8 bytes per symbol of all
+// streams (the caller has checked t0 + n <= 65535 for every stream), order = the streams longest first
+void launch_chunk_encode_split(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits,
+                               const uint64_t *rec_off, void *rec, const uint32_t *order)
+{
+	if (!nstreams) return;
+	hipLaunchKernelGGL(k_chunk_model, dim3(nstreams), dim3(64), 0, st, jobs, inits, magic, (const unsigned long long*)rec_off, (uint2*)rec);
+	hipLaunchKernelGGL(k_chunk_ranges, dim3((nstreams + 63) / 64), dim3(64), 0, st, jobs, nstreams, order, (const unsigned long long*)rec_off, (const uint2*)rec,
+	                   (unsigned long long*)acc, stream_bits);
 }
 void launch_stream_pack(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *stream_bits, const uint8_t *bytes,
                         uint32_t *nbytes, uint64_t *offsets, uint8_t *out, bool pack)

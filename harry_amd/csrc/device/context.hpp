@@ -103,6 +103,7 @@ struct Context {
 	       d_rec_sym, d_sym_l, d_r, d_s, d_state, d_acc, d_v, d_summary, d_bytes, d_small;
 	// chunked profile
 	DevBuf d_cjobs, d_cscratch, d_csizes, d_coffs, d_cout, d_csyms, d_patch;
+	DevBuf d_split;   // chunked encode in two kernels: per stream the place of its records and the streams' order, longest first (the records: d_rec_sym)
 	DevBuf d_pipe, d_nt_val, d_nt_planes;   // EncodePipeline: run tables and twin pairs of the batches; the polygons' triangle counts and their two byte planes
 	std::vector<uint32_t> h_twin_patch;   // (half-edge, twin) pairs on their way to d_patch (upload_repaired_twins)
 

@@ -64,6 +64,11 @@ void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv,
 
 // chunked profile (chunked.hip)
 void launch_chunk_encode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits);
+// the same streams in two kernels (thousands of streams: the model a wavefront per stream, the range registers a lane per stream):
+// rec = 8 bytes per symbol of all streams (every stream: t0 + n <= 65535), rec_off[j] = symbols of the streams before j,
+// order = stream indices, longest first
+void launch_chunk_encode_split(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic, uint64_t *acc, uint32_t *stream_bits,
+                               const uint64_t *rec_off, void *rec, const uint32_t *order);
 void launch_stream_pack(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *stream_bits, const uint8_t *bytes,
                         uint32_t *nbytes, uint64_t *offsets, uint8_t *out, bool pack);
 // stable partition of the operation bytes (symbol | class << 3) into one plane of symbols per class; base[c] = first byte of

@@ -397,3 +397,30 @@ def test_encode_beside_the_walk_equals_the_oracle(cx, monkeypatch, batch):
         if quant:
             cx.requant(b, quant)
         assert cx.write_hry(b, profile=hc.PROFILE_CHUNKED) == got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_streams", ["1", "0"])
+def test_encoder_in_two_kernels_writes_the_same_streams(cx, monkeypatch, min_streams):
+    """k_chunk_model + k_chunk_ranges (round 5: the model a wavefront per stream, the range registers a lane per stream; what a
+    container of thousands of streams takes) against the oracle's container, like the one kernel: streams of every length (the
+    growing chunk schedule, plane ends, 512-symbol connectivity chunks), lossless floats and quantised values, planes that keep the
+    reference's initial counts, more streams than a wavefront has lanes and fewer"""
+    monkeypatch.setenv("HRY_ENCODE_SPLIT_MIN_STREAMS", min_streams)
+    cases = [(mg.torus(60, 50, seed=5), [], 1024), (mg.torus(33, 21, seed=6, polys="mixed", normals=True), [(1, -1, 11)], 512),
+             (mg.with_nonmanifold(mg.multi_component(9, 13, 15, seed=4, polys="mixed"), 9, 5, seed=3), [], 0), (mg.grid(3), [], 0),
+             (mg.with_face_props(mg.multi_component(6, 9, 11, seed=9, polys="tri")), [(1, -1, 14)], 2048)]
+    for g, quant, chunk in cases:
+        ply = g.to_ply()
+        a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+        if quant:
+            cx.requant(a, quant)
+            o.requant(quant)
+        got = cx.write_hry(a, profile=hc.PROFILE_CHUNKED, chunk_syms=chunk)
+        assert got == o.encode_chunked(hc.container_info(got)["chunk_syms"]).data
+        dec = cx.read_hry(got)
+        o2 = op.Mesh.from_ply(ply)
+        if quant:
+            o2.requant(quant)
+        ref = op.Mesh.from_hry(o2.encode().data)
+        assert np.array_equal(dec.org(), ref.org()) and np.array_equal(dec.list_data(1), ref.list_data(1))
