@@ -113,107 +113,6 @@ static GenView gen_view(const Context &cx, const Mesh &m)
 
 namespace {
 
-// everything the stream says about one list, as byte planes with the position of every symbol in the stream
-struct ListStream {
-	std::vector<uint8_t> type_sym;
-	std::vector<uint32_t> type_pos;
-	std::vector<uint32_t> gh_val, gh_pos;   // distance in creation order (4 bytes each, io.h:99-103)
-	std::vector<uint32_t> lh_val, lh_pos;   // distance in the vertex' own names (2 bytes each, io.h:104-108)
-	std::vector<uint32_t> d_pos, d_idx, d_he;   // records coded as data: position of the first residual byte, the record, where
-	std::vector<uint8_t> d_slot;
-	uint32_t nbytes = 0;                    // residual bytes per record
-	std::vector<uint32_t> first_at;         // record -> its rank among the records created so far (GlobalHistory::tidxlist)
-	uint32_t created = 0;
-};
-
-struct Events {
-	std::vector<ListStream> ls;
-	std::vector<uint8_t> rv_sym, rf_sym;    // region of every vertex / face (low byte; the high byte never carries information)
-	std::vector<uint32_t> rv_pos, rf_pos;
-	uint32_t end_pos = 0;
-};
-
-// attrcode.h:321-393,395-416 without the values
-void collect_events(const Mesh &m, const WalkResult &w, uint32_t pos0, Events &E)
-{
-	const Bindings &b = m.bind;
-	static constexpr uint32_t NONE = 0xffffffffu;
-	E.ls.assign(m.lists.size(), ListStream());
-	for (size_t l = 0; l < m.lists.size(); ++l) {
-		E.ls[l].nbytes = (uint32_t)m.lists[l].coded_bytes();
-		E.ls[l].first_at.assign(m.lists[l].count, NONE);
-	}
-	const bool code_rv = b.nregs_vtx() > 1, code_rf = b.nregs_face() > 1;
-	uint32_t pos = pos0;
-	auto reference = [&](int l, uint32_t idx) -> bool {   // true: already created (HIST written)
-		ListStream &S = E.ls[l];
-		if (idx >= S.first_at.size()) throw Error(HRY_E_ARG, "an element names a record outside its list");
-		if (S.first_at[idx] == NONE) { S.first_at[idx] = S.created++; return false; }
-		S.type_sym.push_back(1); S.type_pos.push_back(pos++);
-		S.gh_val.push_back(S.created - 1 - S.first_at[idx]); S.gh_pos.push_back(pos);
-		pos += 4;
-		return true;
-	};
-	auto data = [&](int l, uint32_t idx, uint32_t he, int slot) {
-		ListStream &S = E.ls[l];
-		S.type_sym.push_back(0); S.type_pos.push_back(pos++);
-		S.d_pos.push_back(pos); S.d_idx.push_back(idx); S.d_he.push_back(he); S.d_slot.push_back((uint8_t)slot);
-		pos += S.nbytes;
-	};
-	for (uint32_t e : w.order_v) {
-		const uint32_t v = m.org[e];
-		const int r = b.vtx_reg[v];
-		if (code_rv) { E.rv_sym.push_back((uint8_t)r); E.rv_pos.push_back(pos++); }
-		for (int a = 0; a < b.nvtxlists(r); ++a) {
-			const int l = b.vtxlist(r, a);
-			const uint32_t idx = b.vtx_attr[(size_t)v * b.nb_vtx + a];
-			if (!reference(l, idx)) data(l, idx, e, a);
-		}
-	}
-	// per corner slot and vertex: the records named there so far, newest first (LocalHistory, attrcode.h:54-80)
-	struct Node { uint32_t idx, next; };
-	std::vector<Node> pool;
-	std::vector<std::vector<uint32_t>> head(b.nb_corner);
-	for (auto &h : head) h.assign(m.nv, NONE);
-	// face of a half-edge
-	std::vector<uint32_t> eface(m.ne());
-	for (uint32_t f = 0; f < m.nf; ++f) for (uint32_t e = m.face_off[f]; e < m.face_off[f + 1]; ++e) eface[e] = f;
-	for (uint32_t e0 : w.order_f) {
-		const uint32_t f = eface[e0];
-		const int r = b.face_reg[f];
-		if (code_rf) { E.rf_sym.push_back((uint8_t)r); E.rf_pos.push_back(pos++); }
-		for (int a = 0; a < b.nfacelists(r); ++a) {
-			const int l = b.facelist(r, a);
-			const uint32_t idx = b.face_attr[(size_t)f * b.nb_face + a];
-			if (!reference(l, idx)) data(l, idx, f, a);
-		}
-		const uint32_t fb = m.face_off[f], fe = m.face_off[f + 1];
-		uint32_t c = e0;
-		do {
-			const uint32_t v = m.org[c];
-			for (int a = 0; a < b.ncornerlists(r); ++a) {
-				const int l = b.cornerlist(r, a);
-				const uint32_t idx = b.corner_attr[(size_t)c * b.nb_corner + a];
-				uint32_t back = 0, k = head[a][v];
-				while (k != NONE && pool[k].idx != idx) { k = pool[k].next; ++back; }
-				if (k != NONE) {
-					if (back > 0xffffu) throw Error(HRY_E_UNSUPPORTED, "more than 65536 different records of one list at one vertex (io.h:104 codes 16 bits)");
-					ListStream &S = E.ls[l];
-					S.type_sym.push_back(2); S.type_pos.push_back(pos++);
-					S.lh_val.push_back(back); S.lh_pos.push_back(pos);
-					pos += 2;
-					continue;
-				}
-				pool.push_back(Node{ idx, head[a][v] });
-				head[a][v] = (uint32_t)pool.size() - 1;
-				if (!reference(l, idx)) data(l, idx, c, a);
-			}
-			c = c + 1 == fe ? fb : c + 1;
-		} while (c != e0);
-	}
-	E.end_pos = pos;
-}
-
 // a device arena filled from host vectors in one go
 struct Arena {
 	std::vector<uint8_t> host;
@@ -224,7 +123,7 @@ struct Arena {
 		if (bytes) memcpy(host.data() + at, p, bytes);
 		return at;
 	}
-	template <typename T> size_t add(const std::vector<T> &v) { return add(v.data(), v.size() * sizeof(T)); }
+	template <typename V> size_t add(const V &v) { return add(v.data(), v.size() * sizeof(typename V::value_type)); }
 };
 
 }   // namespace
@@ -248,7 +147,7 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	WalkResult w;
 	cut_border_walk(m, w, false);   // the operation model is evaluated on the device (k_opmodel_*), the groups' places in the ONE symbol sequence come out of the walk -- also from its threads (cbm_walk.cpp: the components' pieces are put in coding order)
 	Events E;
-	collect_events(m, w, w.n_conn, E);
+	collect_events(m, w, w.n_conn, true, E);
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	if ((uint64_t)E.end_pos >= (1ull << 31)) throw Error(HRY_E_UNSUPPORTED, "more than 2^31 symbols in one compat stream");
 	const uint32_t ns = E.end_pos;
@@ -309,26 +208,32 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 
 	// the arena: symbol planes the host made, position tables, event tables; then room for the residual planes the kernels make
 	Arena A;
-	struct ListAt { size_t type_sym, type_pos, gh_planes, gh_pos, lh_planes, lh_pos, d_pos, d_idx, d_he, d_slot, planes; };
+	struct ListAt { size_t type_sym, type_pos, gh_vals, gh_planes, gh_pos, lh_vals, lh_planes, lh_pos, d_pos, d_idx, d_he, d_slot, planes; };
 	std::vector<ListAt> at(m.lists.size());
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		const ListStream &S = E.ls[l];
 		ListAt &T = at[l];
 		T.type_sym = A.add(S.type_sym); T.type_pos = A.add(S.type_pos);
-		std::vector<uint8_t> pl(S.gh_val.size() * 4);
-		for (size_t i = 0; i < S.gh_val.size(); ++i) for (int k = 0; k < 4; ++k) pl[(size_t)k * S.gh_val.size() + i] = (uint8_t)(S.gh_val[i] >> (8 * k));
-		T.gh_planes = A.add(pl); T.gh_pos = A.add(S.gh_pos);
-		pl.assign(S.lh_val.size() * 2, 0);
-		for (size_t i = 0; i < S.lh_val.size(); ++i) for (int k = 0; k < 2; ++k) pl[(size_t)k * S.lh_val.size() + i] = (uint8_t)(S.lh_val[i] >> (8 * k));
-		T.lh_planes = A.add(pl); T.lh_pos = A.add(S.lh_pos);
+		// (the distances go up as 32-bit values and are split into their byte planes on the device, like the connectivity groups:
+		// the host's byte loops were a millisecond of an 80 000-triangle scene)
+		T.gh_vals = A.add(S.gh_val); T.gh_pos = A.add(S.gh_pos);
+		T.lh_vals = A.add(S.lh_val); T.lh_pos = A.add(S.lh_pos);
 		T.d_pos = A.add(S.d_pos); T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
 	}
 	const size_t rv_sym = A.add(E.rv_sym), rv_pos = A.add(E.rv_pos), rf_sym = A.add(E.rf_sym), rf_pos = A.add(E.rf_pos);
 	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
-	for (size_t l = 0; l < m.lists.size(); ++l) { at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_pos.size() * E.ls[l].nbytes + 15) & ~(size_t)15; }
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_pos.size() * E.ls[l].nbytes + 15) & ~(size_t)15;
+		at[l].gh_planes = arena_bytes; arena_bytes += (E.ls[l].gh_val.size() * 4 + 15) & ~(size_t)15;
+		at[l].lh_planes = arena_bytes; arena_bytes += (E.ls[l].lh_val.size() * 2 + 15) & ~(size_t)15;
+	}
 	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
 	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
 	uint8_t *arena = cx.d_gen.as<uint8_t>();
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].gh_vals), (uint32_t)E.ls[l].gh_val.size(), 4, arena + at[l].gh_planes);
+		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].lh_vals), (uint32_t)E.ls[l].lh_val.size(), 2, arena + at[l].lh_planes);
+	}
 
 	size_t conn_plane_bytes = 0;
 	for (int g = 0; g < G_COUNT; ++g) conn_plane_bytes += w.grp_val[g].size() * kGroupBytes[g];
@@ -572,32 +477,35 @@ void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vecto
 {
 	Events E;
 	const auto t_events = Clock::now();
-	collect_events(m, w, 0, E);
+	collect_events(m, w, 0, false, E);
 	cx.timing.host_walk_ms += ms_since(t_events);   // (host bookkeeping along the coding order, like the walk: it was missing from the record)
 	if (getenv("HRY_TRACE")) fprintf(stderr, "[hry enc] %8.3f ms  which record every element names (host)\n", ms_since(t_events));
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	Arena A;
-	struct At { size_t type_sym, gh, lh, d_idx, d_he, d_slot, planes; };
+	struct At { size_t type_sym, gh_vals, gh, lh_vals, lh, d_idx, d_he, d_slot, planes; };
 	std::vector<At> at(m.lists.size());
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		const ListStream &S = E.ls[l];
 		At &T = at[l];
 		T.type_sym = A.add(S.type_sym);
-		std::vector<uint8_t> pl(S.gh_val.size() * 4);
-		for (size_t i = 0; i < S.gh_val.size(); ++i) for (int k = 0; k < 4; ++k) pl[(size_t)k * S.gh_val.size() + i] = (uint8_t)(S.gh_val[i] >> (8 * k));
-		T.gh = A.add(pl);
-		pl.assign(S.lh_val.size() * 2, 0);
-		for (size_t i = 0; i < S.lh_val.size(); ++i) for (int k = 0; k < 2; ++k) pl[(size_t)k * S.lh_val.size() + i] = (uint8_t)(S.lh_val[i] >> (8 * k));
-		T.lh = A.add(pl);
+		T.gh_vals = A.add(S.gh_val); T.lh_vals = A.add(S.lh_val);   // (32-bit values: split into byte planes on the device)
 		T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
 	}
 	const size_t rv = A.add(E.rv_sym), rf = A.add(E.rf_sym);
 	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
-	for (size_t l = 0; l < m.lists.size(); ++l) { at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_idx.size() * E.ls[l].nbytes + 15) & ~(size_t)15; }
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_idx.size() * E.ls[l].nbytes + 15) & ~(size_t)15;
+		at[l].gh = arena_bytes; arena_bytes += (E.ls[l].gh_val.size() * 4 + 15) & ~(size_t)15;
+		at[l].lh = arena_bytes; arena_bytes += (E.ls[l].lh_val.size() * 2 + 15) & ~(size_t)15;
+	}
 	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
 	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
-	HIP_OK(hipStreamSynchronize(cx.stream));   // (the arena's host copy goes out of scope)
 	uint8_t *arena = cx.d_gen.as<uint8_t>();
+	for (size_t l = 0; l < m.lists.size(); ++l) {
+		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].gh_vals), (uint32_t)E.ls[l].gh_val.size(), 4, arena + at[l].gh);
+		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].lh_vals), (uint32_t)E.ls[l].lh_val.size(), 2, arena + at[l].lh);
+	}
+	HIP_OK(hipStreamSynchronize(cx.stream));   // (the arena's host copy goes out of scope)
 	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4 + (size_t)m.nf * 4, 16));
 	uint32_t *d_rank = cx.d_rank.as<uint32_t>(), *d_frank = d_rank + m.nv;
 	ConnView cv = cx.conn_view();

@@ -159,6 +159,32 @@ void start_face_spans(uint32_t nf, std::vector<uint32_t> &spans);   // (lowest f
 // the same time; eface: the face of every half-edge for mixed polygon degrees (ComponentAnalysis::eface), else nullptr.
 void cut_border_walk_in_place(Mesh &m, const ComponentAnalysis &part, const uint32_t *eface, WalkState &st, WalkResult &out);
 
+// ---- general_events.cpp: which record every element of a mesh with general bindings names, along the coding order
+// (attrcode.h:321-393).  Kinds and slots are enumerations of a byte's width, not character types (see OpByte)
+enum class RefKind : uint8_t { data = 0, hist = 1, lhist = 2 };   // io.h:95-98 (also: a region number where regions are coded)
+enum class RefSlot : uint8_t {};
+// everything the stream says about one list, as symbols with (for the reference stream) the position of every symbol in it
+struct ListStream {   // (BigVec: sized once for the most a list can get, not filled first)
+	BigVec<RefKind> type_sym;
+	BigVec<uint32_t> type_pos;
+	BigVec<uint32_t> gh_val, gh_pos;   // distance in creation order (4 bytes each, io.h:99-103)
+	BigVec<uint32_t> lh_val, lh_pos;   // distance in the vertex' own names (2 bytes each, io.h:104-108)
+	BigVec<uint32_t> d_pos, d_idx, d_he;   // records coded as data: position of the first residual byte, the record, where
+	BigVec<RefSlot> d_slot;
+	uint32_t nbytes = 0;                    // residual bytes per record
+	BigVec<uint32_t> first_at;              // record -> its rank among the records created so far (GlobalHistory::tidxlist)
+	uint32_t created = 0;
+};
+struct Events {
+	std::vector<ListStream> ls;
+	BigVec<RefKind> rv_sym, rf_sym;    // region of every vertex / face (low byte; the high byte never carries information)
+	BigVec<uint32_t> rv_pos, rf_pos;
+	uint32_t end_pos = 0;
+};
+// pos0: the position of the first symbol (behind the connectivity); want_positions: fill the *_pos arrays (the ONE symbol sequence
+// of the reference stream; the parallel container asks for none)
+void collect_events(const Mesh &m, const WalkResult &w, uint32_t pos0, bool want_positions, Events &E);
+
 // ---- shard.cpp: a mesh shards by groups of connected components
 struct ShardPlan {
 	uint32_t n_shards = 0, g_nv = 0, g_nf = 0, g_ne = 0;

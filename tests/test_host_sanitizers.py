@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "harry_amd", "csrc", "host")
-SOURCES = ["block_pool", "thread_pool", "ply_io", "obj_io", "header", "cbm_walk", "cbm_unwalk", "compat_read", "shard"]
+SOURCES = ["block_pool", "thread_pool", "ply_io", "obj_io", "header", "cbm_walk", "cbm_unwalk", "compat_read", "shard", "general_events"]
 FLAGS = ["-O0", "-g1", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread"]
 
 

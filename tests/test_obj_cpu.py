@@ -81,3 +81,38 @@ def test_obj_writer_roundtrips_what_the_reader_built():
         x, y = a.list_data(l).view("<f4"), b.list_data(l).view("<f4")
         plain = np.abs(x) >= 1e-4     # "%g" prints smaller values as 8.2e-05, which the scanner reads as 8.2e+05 (reader.rl:36-37,44)
         assert np.allclose(x[plain], y[plain], rtol=1e-5, atol=1e-6) and plain.mean() > 0.9
+
+
+@pytest.mark.timeout(600)
+def test_fast_event_collection_equals_the_plain_one(tmp_path):
+    """host/general_events.cpp (round 5: sized once, bare cursors, no character-typed stores, positions only on request) against a
+    plain restatement of the same bookkeeping (tests/native/events_check.cpp): every array of every list equal, with and without
+    positions, on the reference's OBJ fixtures and on generated scenes (shared records, one normal per face, per-corner texture
+    coordinates, several materials, mixed polygons, non-manifold parts)."""
+    import glob
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = util.ROOT
+    host = os.path.join(root, "harry_amd", "csrc", "host")
+    units = [(os.path.join(host, s + ".cpp"), str(tmp_path / (s + ".o"))) for s in
+             ("block_pool", "thread_pool", "ply_io", "obj_io", "header", "cbm_walk", "cbm_unwalk", "compat_read", "shard", "general_events")]
+    units.append((os.path.join(root, "tests", "native", "events_check.cpp"), str(tmp_path / "driver.o")))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        for r in ex.map(lambda u: subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-c", u[0], "-o", u[1]], capture_output=True, text=True), units):
+            assert r.returncode == 0, r.stderr[-3000:]
+    exe = str(tmp_path / "events_check")
+    r = subprocess.run(["g++", "-pthread", *[u[1] for u in units], "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    files = [f for f in sorted(glob.glob(os.path.join(root, "tests", "golden", "obj", "*.obj"))) if ".dec." not in f and ".ll." not in f and ".q" not in os.path.basename(f)]
+    scenes = [og.scene(mg.torus(24, 20, seed=3, polys="mixed"), normals="smooth", tex="atlas", charts=5, colors="some"),
+              og.scene(mg.torus(22, 18, seed=4), normals="flat", tex="corner"),
+              og.scene(mg.with_nonmanifold(mg.multi_component(6, 9, 10, seed=5, polys="mixed"), 7, 4, seed=2), normals="flat", tex="corner")]
+    for i, sc in enumerate(scenes):
+        files.append(str(tmp_path / f"scene{i}.obj"))
+        with open(files[-1], "wb") as f:
+            f.write(sc.obj)
+    r = subprocess.run([exe, *files], capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok %d files" % len(files)), (r.stdout + r.stderr)[-3000:]
