@@ -798,6 +798,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	}
 	const uint32_t ns = (uint32_t)jobs.size();
 	const uint32_t nw = (uint32_t)words + 2;
+	HRY_MARK(t_all, "  priors and stream jobs (host)");
 	cx.d_init.ensure(std::max<size_t>(inits.size() * 4, 16));
 	if (!inits.empty()) HIP_OK(hipMemcpyAsync(cx.d_init.p, inits.data(), inits.size() * 4, hipMemcpyHostToDevice, cx.stream));
 	cx.d_cjobs.ensure(std::max<size_t>((size_t)ns * sizeof(StreamJob), 16));
@@ -847,8 +848,13 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	}
 	launch_carry(cx.stream, cx.d_acc.as<uint64_t>(), nw, cx.d_v.as<uint64_t>(), cx.d_summary.as<uint32_t>(), cx.d_bytes.as<uint8_t>());
 	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, nullptr, d_nbytes, cx.d_coffs.as<uint64_t>(), nullptr, false);
-	uint64_t total_bytes = 0;
-	HIP_OK(hipMemcpyAsync(&total_bytes, cx.d_coffs.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, cx.stream));
+	// (into pinned memory: a copy into a pageable variable returned only when the streams were coded, and the restart points below
+	// -- 17 ms of host work at 100 M triangles -- were selected after the kernels instead of beside them)
+	cx.h_small.ensure(64);
+	volatile uint64_t *total_bytes_p = cx.h_small.as<uint64_t>();
+	*total_bytes_p = 0;
+	HIP_OK(hipMemcpyAsync((void*)total_bytes_p, cx.d_coffs.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, cx.stream));
+	HRY_MARK(t_all, "  stream kernels launched");
 	// (while the device codes the streams: 17 ms of host work for the 151 741 components of the configs[3] mesh)
 	// directory: chunk sizes, plane lengths, restart points of the connectivity replay, stream lengths
 	std::vector<RestartCounters> rcounters;
@@ -861,6 +867,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	}
 	HRY_MARK(t_all, "  restart points selected");
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	const uint64_t total_bytes = *total_bytes_p;
 	HRY_MARK(t_all, "streams coded");
 	cx.d_cout.ensure(std::max<size_t>(total_bytes, 16));
 	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, cx.d_bytes.as<uint8_t>(), d_nbytes, cx.d_coffs.as<uint64_t>(), cx.d_cout.as<uint8_t>(), true);

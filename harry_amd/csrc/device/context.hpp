@@ -110,6 +110,7 @@ struct Context {
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
 	PinBuf h_pipe;                  // chunked encode: the pipeline's staging slots (run tables + the runs' entries, gathered)
+	PinBuf h_small;                 // a few words that come down asynchronously (a copy into pageable memory keeps its caller until it has happened)
 	PinBuf h_conn;                  // chunked decode: the connectivity planes, down for the host's replay
 	PinBuf h_rec, h_r, h_s;         // compat: symbol records down, (r, S) up, slice by slice (codec.cpp finish_stream)
 	std::vector<hipEvent_t> slice_ev;

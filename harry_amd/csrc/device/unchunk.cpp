@@ -372,10 +372,11 @@ struct SpanUploader : SpanDone {
 			cx.res_has_eface = !m.uniform_degree(ud);
 			cx.res_udeg = (uint32_t)ud;
 			if (cx.res_has_eface) cx.d_eface.ensure(std::max<size_t>((size_t)m.declared_ne * 4, 16));
-			const uint32_t zero = 0;
-			HIP_OK(hipMemcpyAsync(cx.d_foff.p, &zero, 4, hipMemcpyHostToDevice, cx.stream2));
+			// (no wait for these: the first batch's launch follows them through an event of this stream, launch_pending -- and a wait
+			// here lasted as long as the attribute streams' kernel, 40 ms of the named size's decode in front of the replay: with more
+			// streams than hardware queues this stream shares a queue with one of theirs)
+			HIP_OK(hipMemsetAsync(cx.d_foff.p, 0, 4, cx.stream2));
 			batches->init(cx.stream2, m);
-			HIP_OK(hipStreamSynchronize(cx.stream2));
 		}
 		static const int wanted = [] { const char *e = getenv("HRY_SPAN_UPLOADERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > kWorkers ? kWorkers : v; }();
 		n_workers = wanted;
@@ -386,6 +387,7 @@ struct SpanUploader : SpanDone {
 			up_stream[k] = cx.up_stream[k - 1];
 		}
 		const void *node = callers_node_cpus();
+		HRY_MARK(t_origin, "span uploaders' arrays and streams ready");
 		for (int k = 0; k < n_workers; ++k) worker[k] = std::thread([this, node, k] {
 			try {
 				stay_on_node(node);
