@@ -193,7 +193,7 @@ int hry_requant(hry_ctx *ctx, hry_mesh *m, const hry_quant *q, size_t nq, int cl
 int hry_mesh_upload(hry_ctx *ctx, hry_mesh *m)
 {
 	if (!ctx || !m) { g_last_error = "null argument"; return HRY_E_ARG; }
-	return guarded([&] { ctx->cx.upload_mesh(m->m); });
+	return guarded([&] { if (m->m.general) upload_general(ctx->cx, m->m); else ctx->cx.upload_mesh(m->m); });
 }
 int hry_encode(hry_ctx *ctx, hry_mesh *m, const hry_opts *opts, uint8_t **out, size_t *out_len)
 {

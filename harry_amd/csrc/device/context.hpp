@@ -88,6 +88,7 @@ struct Context {
 
 	// resident mesh (hry_mesh_upload): attribute records and connectivity stay in HBM across encodes
 	uint64_t resident_token = 0;
+	uint64_t gen_token = 0;          // the mesh whose binding tables (d_vreg .. d_cattr) are in HBM (general.cpp: upload_general)
 	uint64_t next_token = 1;
 	DevBuf d_rec[kMaxLists], d_org, d_twin, d_foff, d_eface;
 	DevBuf d_vreg, d_freg, d_vattr, d_cattr, d_gen;   // general bindings (general.cpp): region and record tables, event arena
@@ -110,6 +111,7 @@ struct Context {
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
 	PinBuf h_pipe;                  // chunked encode: the pipeline's staging slots (run tables + the runs' entries, gathered)
+	PinBuf h_gen;                   // general bindings: the events' arena on its way up (general.cpp)
 	PinBuf h_small;                 // a few words that come down asynchronously (a copy into pageable memory keeps its caller until it has happened)
 	PinBuf h_conn;                  // chunked decode: the connectivity planes, down for the host's replay
 	PinBuf h_rec, h_r, h_s;         // compat: symbol records down, (r, S) up, slice by slice (codec.cpp finish_stream)

@@ -88,9 +88,12 @@ void check_general(const Mesh &m)
 }
 
 // connectivity + every list + the binding tables -> HBM
+// (a mesh that hry_mesh_upload has made resident stays so, tables included, like a mesh in the PLY layout)
 void upload_general(Context &cx, Mesh &m)
 {
-	cx.upload_mesh(m);
+	const bool mesh_there = m.device_token != 0 && m.device_token == cx.resident_token && !m.twins_pending;
+	if (mesh_there && cx.gen_token == m.device_token) return;
+	if (!mesh_there) cx.upload_mesh(m);
 	const Bindings &b = m.bind;
 	auto put = [&](DevBuf &d, const void *src, size_t bytes) {
 		d.ensure(std::max<size_t>(bytes, 16));
@@ -101,6 +104,7 @@ void upload_general(Context &cx, Mesh &m)
 	put(cx.d_vattr, b.vtx_attr.data(), b.vtx_attr.size() * 4);
 	put(cx.d_cattr, b.corner_attr.data(), b.corner_attr.size() * 4);
 	HIP_OK(hipStreamSynchronize(cx.stream));
+	cx.gen_token = m.device_token;
 }
 static GenView gen_view(const Context &cx, const Mesh &m)
 {
@@ -115,15 +119,28 @@ namespace {
 
 // a device arena filled from host vectors in one go
 struct Arena {
-	std::vector<uint8_t> host;
-	size_t add(const void *p, size_t bytes)
+	struct Piece { const void *p; size_t bytes, at; };
+	std::vector<Piece> pieces;
+	size_t bytes = 0;
+	size_t add(const void *p, size_t n)
 	{
-		size_t at = (host.size() + 15) & ~(size_t)15;
-		host.resize(at + bytes);
-		if (bytes) memcpy(host.data() + at, p, bytes);
+		const size_t at = (bytes + 15) & ~(size_t)15;
+		pieces.push_back(Piece{ p, n, at });
+		bytes = at + n;
 		return at;
 	}
 	template <typename V> size_t add(const V &v) { return add(v.data(), v.size() * sizeof(typename V::value_type)); }
+	// the pieces -> the context's pinned block -> HBM, behind everything on the stream; no wait: the block is the context's, and the
+	// context's next call finds the stream drained.  (Until round 5 a pageable vector that grew piece by piece, its copy, and a wait
+	// for it because the vector went out of scope: 4 of the 11 ms of a 180 000-triangle scene's encode.)
+	void send(Context &cx, void *dst)
+	{
+		if (!bytes) return;
+		cx.h_gen.ensure(bytes);
+		uint8_t *h = cx.h_gen.as<uint8_t>();
+		for (const Piece &q : pieces) if (q.bytes) memcpy(h + q.at, q.p, q.bytes);
+		HIP_OK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, cx.stream));
+	}
 };
 
 }   // namespace
@@ -221,14 +238,14 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 		T.d_pos = A.add(S.d_pos); T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
 	}
 	const size_t rv_sym = A.add(E.rv_sym), rv_pos = A.add(E.rv_pos), rf_sym = A.add(E.rf_sym), rf_pos = A.add(E.rf_pos);
-	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
+	size_t arena_bytes = (A.bytes + 15) & ~(size_t)15;
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_pos.size() * E.ls[l].nbytes + 15) & ~(size_t)15;
 		at[l].gh_planes = arena_bytes; arena_bytes += (E.ls[l].gh_val.size() * 4 + 15) & ~(size_t)15;
 		at[l].lh_planes = arena_bytes; arena_bytes += (E.ls[l].lh_val.size() * 2 + 15) & ~(size_t)15;
 	}
 	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
-	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
+	A.send(cx, cx.d_gen.p);
 	uint8_t *arena = cx.d_gen.as<uint8_t>();
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].gh_vals), (uint32_t)E.ls[l].gh_val.size(), 4, arena + at[l].gh_planes);
@@ -359,7 +376,7 @@ static void reconstruct_general(Context &cx, Mesh &m, const OrderVec &order_v, c
 	const size_t nl = m.lists.size();
 	std::vector<size_t> he_at(nl), slot_at(nl), src_at(nl), nsrc_at(nl);
 	for (size_t l = 0; l < nl; ++l) { he_at[l] = A.add(ev[l].he); slot_at[l] = A.add(ev[l].slot); }
-	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
+	size_t arena_bytes = (A.bytes + 15) & ~(size_t)15;
 	for (size_t l = 0; l < nl; ++l) {
 		if (m.lists[l].target != 1 && m.lists[l].target != 2) continue;
 		const size_t nd = ev[l].he.size();
@@ -371,7 +388,7 @@ static void reconstruct_general(Context &cx, Mesh &m, const OrderVec &order_v, c
 	for (const AttrList &L : m.lists) max_jobs += (size_t)L.ncomp();
 	arena_bytes += (max_jobs + 1) * sizeof(GenChainJob);
 	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
-	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
+	A.send(cx, cx.d_gen.p);
 	uint8_t *arena = cx.d_gen.as<uint8_t>();
 	std::vector<GenChainJob> jobs, lead;   // lead: one per list (the source table is per record)
 	for (size_t l = 0; l < nl; ++l) {
@@ -492,20 +509,19 @@ void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vecto
 		T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
 	}
 	const size_t rv = A.add(E.rv_sym), rf = A.add(E.rf_sym);
-	size_t arena_bytes = (A.host.size() + 15) & ~(size_t)15;
+	size_t arena_bytes = (A.bytes + 15) & ~(size_t)15;
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_idx.size() * E.ls[l].nbytes + 15) & ~(size_t)15;
 		at[l].gh = arena_bytes; arena_bytes += (E.ls[l].gh_val.size() * 4 + 15) & ~(size_t)15;
 		at[l].lh = arena_bytes; arena_bytes += (E.ls[l].lh_val.size() * 2 + 15) & ~(size_t)15;
 	}
 	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
-	if (!A.host.empty()) HIP_OK(hipMemcpyAsync(cx.d_gen.p, A.host.data(), A.host.size(), hipMemcpyHostToDevice, cx.stream));
+	A.send(cx, cx.d_gen.p);
 	uint8_t *arena = cx.d_gen.as<uint8_t>();
 	for (size_t l = 0; l < m.lists.size(); ++l) {
 		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].gh_vals), (uint32_t)E.ls[l].gh_val.size(), 4, arena + at[l].gh);
 		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].lh_vals), (uint32_t)E.ls[l].lh_val.size(), 2, arena + at[l].lh);
 	}
-	HIP_OK(hipStreamSynchronize(cx.stream));   // (the arena's host copy goes out of scope)
 	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4 + (size_t)m.nf * 4, 16));
 	uint32_t *d_rank = cx.d_rank.as<uint32_t>(), *d_frank = d_rank + m.nv;
 	ConnView cv = cx.conn_view();

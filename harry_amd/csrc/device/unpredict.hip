@@ -1352,6 +1352,13 @@ __device__ __forceinline__ Map3 scan3(Map3 m)
 	return m;
 }
 
+// (max of the lower bounds, min of the upper bounds of the lanes a scan step combines; lanes without a partner keep theirs)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void fold_bounds(int32_t &lower, int32_t &upper)
+{
+	lower = max(lower, __builtin_amdgcn_update_dpp(0, lower, CTRL, ROWMASK, 0xf, false));              // (every lower bound is >= 0)
+	upper = min(upper, __builtin_amdgcn_update_dpp(0x7fffffff, upper, CTRL, ROWMASK, 0xf, false));
+}
+
 // segmented: bit 8 of k marks a lane that starts a run; lane l gets m_l o ... o m_s, s = the last start at or below l
 constexpr int32_t kRunStart = 256;
 __device__ __forceinline__ Map3 scan3_runs(Map3 m)
@@ -1419,7 +1426,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	if (threadIdx.x < kHand) sync[kHand0 + threadIdx.x] = 0;
 	__syncthreads();
 	bool given_up = false;
-	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_r2 = 0, ck_r2len = 0, ck_r2_8 = 0, ck_r2_16 = 0, ck_r2_32 = 0, ck_r2_afterbig = 0, ck_rowt = 0, ck_rown = 0, ck_slott = 0, ck_slotn = 0, ck_runt = 0, ck_dense = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
+	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_r2 = 0, ck_r2len = 0, ck_r2_8 = 0, ck_r2_16 = 0, ck_r2_32 = 0, ck_r2_afterbig = 0, ck_rowt = 0, ck_rown = 0, ck_fast = 0, ck_slott = 0, ck_slotn = 0, ck_runt = 0, ck_dense = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
 	request(t_first + 64 * wv);
 	for (uint32_t tb = t_first + 64 * wv; tb < seg_end && !given_up; tb += 64 * W) {
 		if (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // another wavefront's wait ran into its bound
@@ -1669,9 +1676,58 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			Map3 Fm = compose_runs(headmask);
 			asm volatile("" : "+v"(Fm.k), "+v"(Fm.A), "+v"(Fm.D));   // the scan is computed before the wait below, not sunk behind it
 			HRY_CLK(++ck_early;)
+#ifndef HRY_CHAIN_NO_FAST_TILES
+			// A tile without heads is ONE run, and whether its speculation holds is a question about the predecessor's value alone:
+			// lane l's form (parallelogram inside [0, top], residual code near: prediction.h:58-63) holds iff the value before it
+			// lies in an interval [a, b]; that value is the composed map of the lanes before it -- monotone in x, the value handed
+			// over -- so the condition pulls back to an interval of x, and the lanes' intervals intersect to ONE: [x_lo, x_lo +
+			// x_width].  All of that is computed HERE, before the wait; behind it are a scalar range test, three instructions for
+			// the tile's values, three scalar ones for the value handed on.  (x outside: the verified path below, as before.)
+			bool fast = false;
+			int32_t x_lo = 0;
+			uint32_t x_width = 0;
+			int32_t end_k = 0, end_A = 0, end_D = 0;
+			if (headmask == 0ull) {
+				const int32_t hf = (int32_t)uf.half, tp_ = (int32_t)top;
+				int32_t a = two ? max(0, 2 * hf + 1 - (int32_t)p1c) - bo0 : hf + 1 - bo0;
+				int32_t b = two ? min(tp_, 2 * (tp_ - hf) - (int32_t)p1c) - bo0 : tp_ - hf - bo0;
+				if (keepl || !valid) { a = -(1 << 29); b = 1 << 29; }
+				// the map in front of the lane (the tile's first vertex: x itself)
+				Map3 P;
+				P.k = __builtin_amdgcn_update_dpp(0, Fm.k, 0x138, 0xf, 0xf, false);   // wave_shr:1
+				P.A = __builtin_amdgcn_update_dpp(0, Fm.A, 0x138, 0xf, 0xf, false);
+				P.D = __builtin_amdgcn_update_dpp(0, Fm.D, 0x138, 0xf, 0xf, false);
+				if ((uint32_t)lane <= lo) { P.k = 0; P.A = 0; P.D = 0; }
+				// floor((x + A) / 2^k) + D >= a  <=>  x >= (a - D) 2^k - A;   <= b  <=>  x <= (b - D + 1) 2^k - A - 1   (x + A < 2^17)
+				const int32_t room = 0x20000 >> P.k;
+				const int32_t t = a - P.D, u = b - P.D + 1;
+				int32_t lower = t <= 0 ? 0 : t > room ? 0x7fffffff : (t << P.k) - P.A;
+				int32_t upper = u <= 0 ? -1 : u > room ? 0x7fffffff : (u << P.k) - P.A - 1;
+				fold_bounds<0x111, 0xf>(lower, upper);   // (the scan's six steps: lane 63 ends up with every lane's bounds)
+				fold_bounds<0x112, 0xf>(lower, upper);
+				fold_bounds<0x114, 0xf>(lower, upper);
+				fold_bounds<0x118, 0xf>(lower, upper);
+				fold_bounds<0x142, 0xa>(lower, upper);
+				fold_bounds<0x143, 0xc>(lower, upper);
+				const int32_t L = (int32_t)rl((uint32_t)lower, 63u), U = (int32_t)rl((uint32_t)upper, 63u);
+				fast = U >= L;
+				x_lo = L;
+				x_width = (uint32_t)(U - L);
+				end_k = (int32_t)rl((uint32_t)Fm.k, hi - 1u); end_A = (int32_t)rl((uint32_t)Fm.A, hi - 1u); end_D = (int32_t)rl((uint32_t)Fm.D, hi - 1u);
+			}
+			wait_prev();
+			x = x_prev;   // the first vertex of a slice is never chained
+			if (fast && (uint32_t)((int32_t)x - x_lo) <= x_width) {
+				const uint32_t xh = (uint32_t)((((int32_t)x + Fm.A) >> Fm.k) + Fm.D);
+				if (valid) ring[v & mask] = (T)xh;
+				x = (uint32_t)((((int32_t)x + end_A) >> end_k) + end_D);
+				HRY_CLK(++ck_runs; ++ck_fast;)
+			} else serial_part(headmask, rowheads, rowheads, Fm);
+#else
 			wait_prev();
 			x = x_prev;   // the first vertex of a slice is never chained
 			serial_part(headmask, rowheads, rowheads, Fm);
+#endif
 		} else {
 			// ---- a tile with many recent sources (small or irregular meshes, the last rings of a closing border).  Most of them
 			// are recent but not of this tile: once the tiles before it are finished they are final, and the tile is prepared THEN,
@@ -1719,7 +1775,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			if (lane == 0) __hip_atomic_fetch_max(&sync[1], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // flushes of different wavefronts may finish out of order
 		}
 	}
-	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu (dense %llu) runs %llu at %llu (later runs %llu, mean length %llu), heads from rows %llu at %llu, from slots %llu at %llu, retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_dense, ck_runs, ck_runt / (ck_runs ? ck_runs : 1), ck_r2, ck_r2len / (ck_r2 ? ck_r2 : 1), ck_rown, ck_rowt / (ck_rown ? ck_rown : 1), ck_slotn, ck_slott / (ck_slotn ? ck_slotn : 1), ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
+	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu (dense %llu, fast %llu) runs %llu at %llu (later runs %llu, mean length %llu), heads from rows %llu at %llu, from slots %llu at %llu, retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_dense, ck_fast, ck_runs, ck_runt / (ck_runs ? ck_runs : 1), ck_r2, ck_r2len / (ck_r2 ? ck_r2 : 1), ck_rown, ck_rowt / (ck_rown ? ck_rown : 1), ck_slotn, ck_slott / (ck_slotn ? ck_slotn : 1), ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
 	                                    ck_prep / ck_tiles, ck_wait / ck_tiles, ck_serial / ck_tiles, (unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin, ((unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin) / (ck_tiles * W));)
 }
 
@@ -1830,12 +1886,14 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 	cand_table_reset(st, cand, nvtx);
 	hipLaunchKernelGGL(k_candidates_ids, dim3(per * 8), dim3(256), 0, st, cv, order_v, 0u, nvtx, cand, ncand, per, nvtx, (ChainRec*)nullptr, 0u);
 }
-// wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8; by default 5 for a large mesh (long rings: more
-// look-ahead for the preparation costs no heads), 4 otherwise
+// wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8; by default 6 for a large mesh (long rings: more
+// look-ahead for the preparation costs no heads; 5 until a tile without heads got its short serial part, round 5: the preparation
+// grew by the tile's interval, the chain's turn shrank -- 1 M-triangle torus, one launch: 5.20 ms before, 4.86 with five, 4.69 with
+// six, 4.89 with eight), 4 otherwise
 static uint32_t chain_waves(uint32_t nvtx)
 {
 	static const uint32_t forced = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }();
-	return forced ? forced : nvtx >= (1u << 18) ? 5u : 4u;
+	return forced ? forced : nvtx >= (1u << 18) ? 6u : 4u;
 }
 // ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
 // gave_up: the decode's own give-up word (behind its flag table), or nullptr -- a context that shares its device with others may find

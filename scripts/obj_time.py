@@ -25,7 +25,7 @@ for label, kw in (("smooth normals + atlas", dict(normals="smooth", tex="atlas",
     ntri = m.ntri
     for rep in range(4):
         prof = hc.PROFILE_COMPAT if rep < 2 else hc.PROFILE_CHUNKED
-        a = m.clone()
+        a = m.clone(); cx.upload(a)   # (resident inputs, as bench.py measures)
         t = time.time()
         data = cx.write_hry(a, profile=prof)
         t_enc = time.time() - t

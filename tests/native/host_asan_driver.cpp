@@ -90,7 +90,16 @@ int main(int argc, char **argv)
 						}
 					}
 				}
-				if (m->nf) { WalkResult w; cut_border_walk(*m, w); }
+				if (m->nf) {
+					WalkResult w; cut_border_walk(*m, w);
+					if (m->general) {   // which record every element names: with the symbols' positions, and without them
+						Events E1, E2;
+						collect_events(*m, w, w.n_conn, true, E1);
+						collect_events(*m, w, 0, false, E2);
+						for (size_t l = 0; l < m->lists.size(); ++l)
+							if (E1.ls[l].created != E2.ls[l].created || E1.ls[l].type_sym.size() != E2.ls[l].type_sym.size()) throw Error(HRY_E_INTERNAL, "events: the two collections differ");
+					}
+				}
 				if (m->nf && !m->general) {
 					// the walk of the chunked profile (no operation model): on the host threads where the mesh has several components
 					// (the test sets HRY_PARALLEL_MIN_FACES=1), its components found by the threads' union-find, coded where they belong

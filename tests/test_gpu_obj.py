@@ -397,3 +397,33 @@ def test_one_normal_per_face_with_special_values(cx, pattern, shape):
         ref = op.Mesh.from_hry(ref_bytes)
         same_decoded(cx.read_hry(ref_bytes), ref)
         same_decoded(cx.read_hry(cx.write_hry(mq.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=512)), ref)
+
+
+def test_a_resident_scene_writes_the_bytes_of_an_uploaded_one(cx):
+    """hry_mesh_upload keeps a mesh with general bindings resident like one in the PLY layout (connectivity, every list, the region
+    and record tables: general.cpp upload_general): encodes from the resident copy, repeated, in both profiles, after another mesh has
+    taken the context, and after a decode has, all write the bytes an unprepared clone writes (which equal the oracle's)."""
+    sc = og.scene(mg.with_nonmanifold(mg.multi_component(5, 14, 15, seed=21, polys="mixed"), 6, 3, seed=3), normals="flat", tex="corner", colors="some")
+    other = og.scene(mg.torus(17, 13, seed=4), normals="smooth", tex="atlas", charts=3)
+    m = hc.Mesh.from_obj(sc.obj, "")
+    m2 = hc.Mesh.from_obj(other.obj, "")
+    want_compat = cx.write_hry(m.clone(), profile=hc.PROFILE_COMPAT)
+    want_chunked = cx.write_hry(m.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=512)
+    assert want_compat == op.Mesh.from_obj(sc.obj, "").encode().data
+    a = m.clone()
+    cx.upload(a)
+    assert cx.write_hry(a, profile=hc.PROFILE_CHUNKED, chunk_syms=512) == want_chunked
+    assert cx.write_hry(a, profile=hc.PROFILE_COMPAT) == want_compat
+    assert cx.write_hry(a, profile=hc.PROFILE_CHUNKED, chunk_syms=512) == want_chunked
+    other_bytes = cx.write_hry(m2.clone(), profile=hc.PROFILE_CHUNKED)      # another mesh takes the context's arrays
+    assert cx.write_hry(a, profile=hc.PROFILE_CHUNKED, chunk_syms=512) == want_chunked
+    b = m2.clone()
+    cx.upload(b)
+    assert cx.write_hry(b, profile=hc.PROFILE_CHUNKED) == other_bytes
+    d = cx.read_hry(want_chunked)                                            # a decode takes them
+    assert cx.write_hry(b, profile=hc.PROFILE_CHUNKED) == other_bytes
+    again = cx.write_hry(d.clone(), profile=hc.PROFILE_COMPAT)              # (the decoded scene, in its own numbering)
+    assert cx.write_hry(d, profile=hc.PROFILE_COMPAT) == again              # straight from the decode's arrays
+    cx.upload(d)
+    assert cx.write_hry(d, profile=hc.PROFILE_COMPAT) == again
+    assert cx.write_hry(a, profile=hc.PROFILE_COMPAT) == want_compat

@@ -68,6 +68,7 @@ def test_threaded_host_code_under_thread_sanitizer(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     from harry_amd import meshgen as mg
     files = [os.path.join(ROOT, "tests", "golden", n) for n in ("multi5.ply", "nonmanifold.ply", "torus_mixed.ply")]
+    files += [f for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "obj", "*.obj"))) if ".dec." not in f][:4]   # general bindings: walk and references beside the threaded paths
     for i, m in enumerate((mg.with_nonmanifold(mg.multi_component(12, 30, 31, seed=5, polys="mixed"), 40, 20, seed=4),
                            mg.with_nonmanifold(mg.multi_component(6, 30, 31, seed=6), 10, 5, seed=2))):
         files.append(str(tmp_path / f"generated{i}.ply"))
