@@ -647,6 +647,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 			start_pipeline(A, nullptr);
 			cut_border_walk_in_place(m, A, uniform ? nullptr : eface.data(), *marks, w);
 			walked = true;
+			HRY_MARK(t_all, "  walk returned");
 		}
 	}
 	if (!walked) cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed

@@ -201,19 +201,70 @@ __global__ __launch_bounds__(256) void k_cc_init(uint32_t *label, uint32_t n)
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) label[i] = i;
 }
-// one thread per face: an edge with a twin on both sides is taken from its larger face (whose root is looked up once for all its
-// edges), a one-sided twin from the side that has it
+// An edge with a twin on both sides is taken from its larger face, a one-sided twin from the side that has it.
+//
+// Round 5, in two passes.  Faces that lie near each other in the arrays mostly ARE neighbours (a file is written patch by patch), so a
+// workgroup first unites its own kHookFaces faces in LDS -- the same lock-free union-find on 16-bit-distance parents, no traffic --
+// and writes every face's local root as its label; the second pass takes only the edges that leave a workgroup's faces to the
+// union-find in HBM, where a set now arrives as one root per workgroup instead of face by face.  (One pass over HBM: 19.0 ms for
+// the 78.5 M faces of the configs[3] mesh, its searches and compare-and-swaps all in the L2.)
+constexpr uint32_t kHookFaces = 1024;
+__device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
+{
+	uint32_t p = __hip_atomic_load(par + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	while (p != x) {
+		const uint32_t g = __hip_atomic_load(par + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (g != p) __hip_atomic_store(par + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		x = p; p = g;
+	}
+	return x;
+}
+__global__ __launch_bounds__(kHookFaces) void k_cc_hook_local(ConnView cv, uint32_t *label)
+{
+	__shared__ uint32_t par[kHookFaces];
+	const uint32_t base = blockIdx.x * kHookFaces, t = threadIdx.x, f = base + t;
+	par[t] = t;
+	__syncthreads();
+	if (f < cv.nf) {
+		Topo tp{ cv };
+		const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
+		for (uint32_t h = h0; h < h1; ++h) {
+			const uint32_t o = cv.twin[h];
+			if (o == h || o >= cv.ne) continue;
+			const uint32_t b = tp.face(o);
+			if (b == f || (b > f && cv.twin[o] == h)) continue;
+			if (b - base >= kHookFaces) continue;   // leaves the workgroup's faces: the second pass
+			uint32_t x = t, y = b - base;
+			for (;;) {
+				x = lds_find(par, x); y = lds_find(par, y);
+				if (x == y) break;
+				if (x > y) { const uint32_t s = x; x = y; y = s; }
+				const uint32_t old = atomicCAS(par + y, y, x);
+				if (old == y) break;
+				y = old;
+			}
+		}
+	}
+	__syncthreads();
+	if (f < cv.nf) {   // (the unions are over: a root read is final)
+		uint32_t x = t, q = par[x];
+		while (q != x) { x = q; q = par[x]; }
+		label[f] = base + x;
+	}
+}
 __global__ __launch_bounds__(256) void k_cc_hook(ConnView cv, uint32_t *label)
 {
 	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= cv.nf) return;
 	Topo tp{ cv };
+	const uint32_t base = f & ~(kHookFaces - 1u);
 	const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
 	for (uint32_t h = h0; h < h1; ++h) {
 		const uint32_t o = cv.twin[h];
 		if (o == h || o >= cv.ne) continue;
 		const uint32_t b = tp.face(o);
 		if (b == f || (b > f && cv.twin[o] == h)) continue;
+		if (b - base < kHookFaces) continue;   // united in LDS by the first pass
 		uf_unite(label, f, b);
 	}
 }
@@ -290,6 +341,7 @@ __global__ __launch_bounds__(256) void k_cc_vertex_first(ConnView cv, const uint
 // waiting for it: 13 ms at 100 M triangles against 2.7 ms for the pass before it, which touches the same words.  The pairs are
 // appended to a list instead (one atomic per wavefront and corner round) and united by a kernel of their own; what does not fit
 // in the list is united on the spot.
+constexpr uint32_t kTieLists = 64;   // (a power of two that divides kTiePairs)
 __global__ __launch_bounds__(256) void k_cc_vertex_ties(ConnView cv, const uint32_t *comp, const uint32_t *rank_of, const uint32_t *vfirst, uint32_t *tie,
                                                         uint2 *pairs, uint32_t cap, uint32_t *count)
 {
@@ -306,13 +358,16 @@ __global__ __launch_bounds__(256) void k_cc_vertex_ties(ConnView cv, const uint3
 		const bool hit = first != k;
 		const unsigned long long mask = __ballot(hit);
 		if (!mask) continue;
+		// (kTieLists lists with a counter each, a workgroup appends to the one of its index: every wavefront of the configs[3] mesh
+		// notes a pair or two, and 2.5 M additions to ONE word were most of this kernel's 8.1 ms)
 		uint32_t base = 0;
 		const int leader = __ffsll((long long)mask) - 1;
-		if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+		const uint32_t sub = blockIdx.x & (kTieLists - 1u), sub_cap = cap / kTieLists;
+		if (lane == leader) base = atomicAdd(count + sub, (uint32_t)__popcll(mask));
 		base = (uint32_t)__shfl((int)base, leader, 64);
 		if (hit) {
 			const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-			if (at < cap) pairs[at] = make_uint2(first, k);
+			if (at < sub_cap) pairs[(size_t)sub * sub_cap + at] = make_uint2(first, k);
 			else uf_unite(tie, first, k);
 		}
 	}
@@ -320,7 +375,8 @@ __global__ __launch_bounds__(256) void k_cc_vertex_ties(ConnView cv, const uint3
 __global__ __launch_bounds__(256) void k_cc_tie_pairs(const uint2 *pairs, uint32_t cap, const uint32_t *count, uint32_t *tie)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < min(*count, cap)) uf_unite(tie, pairs[i].x, pairs[i].y);
+	const uint32_t sub_cap = cap / kTieLists, sub = i / sub_cap, at = i - sub * sub_cap;
+	if (sub < kTieLists && at < min(count[sub], sub_cap)) uf_unite(tie, pairs[i].x, pairs[i].y);
 }
 __global__ __launch_bounds__(256) void k_cc_vertex_stats(const uint32_t *vfirst, uint32_t nv, uint32_t *fresh, uint32_t *vlo, uint32_t *vhi)
 {
@@ -341,16 +397,16 @@ __global__ __launch_bounds__(256) void k_cc_vertex_stats(const uint32_t *vfirst,
 }
 
 constexpr uint32_t kTiePairs = 1u << 22;   // capacity of the tie list (8 bytes each; the configs[3] mesh at 100 M triangles notes 0.9 M)
-size_t components_workspace_bytes(uint32_t nv, uint32_t nf) { return ((size_t)3 * nf + nv + blocks_for(nf, kScanBlock) + 16) * 4 + (size_t)kTiePairs * 8 + 64; }
+size_t components_workspace_bytes(uint32_t nv, uint32_t nf) { return ((size_t)3 * nf + nv + blocks_for(nf, kScanBlock) + 16) * 4 + (size_t)kTiePairs * 8 + kTieLists * 4 + 64; }
 // where everything lies in that workspace -- the ONE place that knows (the driver, analysis.cpp, asks here)
 ComponentsWorkspace components_workspace(void *ws, uint32_t nv, uint32_t nf)
 {
 	ComponentsWorkspace w;
 	w.label = (uint32_t*)ws; w.flag = w.label + nf; w.num = w.flag + nf; w.sums = w.num + nf + 1;
 	w.vfirst = w.sums + blocks_for(nf, kScanBlock) + 8;
-	// the tie list behind the vertex words, 8-byte aligned; its counter (two words) in front of it
+	// the tie lists behind the vertex words, 8-byte aligned; their counters (kTieLists words) in front of them
 	w.tie_count = (uint32_t*)(((uintptr_t)(w.vfirst + nv) + 7) & ~(uintptr_t)7);
-	w.tie_pairs = w.tie_count + 2;
+	w.tie_pairs = w.tie_count + kTieLists;
 	return w;
 }
 // stage 1: label[f] = root of f's component, num = exclusive scan of the root flags (num[nf] = number of components)
@@ -359,8 +415,10 @@ void launch_components_label(hipStream_t st, const ConnView &cv, const Component
 	uint32_t *label = w.label, *flag = w.flag, *num = w.num, *sums = w.sums;
 	if (!cv.nf) return;
 	const unsigned nb = blocks_for(cv.nf, kScanBlock);
-	hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
-	if (cv.ne) hipLaunchKernelGGL(k_cc_hook, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, label);
+	if (cv.ne) {
+		hipLaunchKernelGGL(k_cc_hook_local, dim3(blocks_for(cv.nf, kHookFaces)), dim3(kHookFaces), 0, st, cv, label);
+		hipLaunchKernelGGL(k_cc_hook, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, label);
+	} else hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
 	hipLaunchKernelGGL(k_cc_flatten, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
 	hipLaunchKernelGGL(k_cc_roots, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf, flag);
 	hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kScanBlock), 0, st, flag, cv.nf, sums);
@@ -381,7 +439,7 @@ void launch_components_vertices(hipStream_t st, const ConnView &cv, uint32_t nv,
 	const uint32_t *comp = w.label;
 	uint32_t *vfirst = w.vfirst, *count = w.tie_count;
 	uint2 *pairs = (uint2*)w.tie_pairs;
-	(void)hipMemsetAsync(count, 0, 8, st);
+	(void)hipMemsetAsync(count, 0, kTieLists * 4, st);
 	hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(ncomp, 256)), dim3(256), 0, st, tie, ncomp);
 	hipLaunchKernelGGL(k_cc_vertex_first, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, vfirst);
 	hipLaunchKernelGGL(k_cc_vertex_ties, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, comp, rank_of, (const uint32_t*)vfirst, tie, pairs, kTiePairs, count);
