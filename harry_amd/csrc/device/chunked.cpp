@@ -657,6 +657,26 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	const bool piped = pipe && pipe->began;
 	if (pipe) { pipe->finish(); w.progress = nullptr; }
 	if (piped) HRY_MARK(t_all, "  pipeline drained");
+	// directory, part one: the restart points of the connectivity replay come from the walk's marks alone -- for a mesh of many
+	// components on a thread of its own from here on (17 ms for the 151 741 components of the configs[3] mesh: beside the stream
+	// kernels until round 5, which the carry kernels' rewrite left shorter than that)
+	std::vector<RestartCounters> rcounters;
+	std::vector<RestartPoint> restarts;
+	std::vector<uint32_t> counter_dir;   // per restart point: n, then n x (vertex, counter)
+	auto select_restarts = [&] {
+		restarts = select_restart_points(w.marks, w.named, rcounters);
+		for (const RestartCounters &cs : rcounters) {
+			counter_dir.push_back((uint32_t)cs.size());
+			for (const auto &c : cs) { counter_dir.push_back(c.first); counter_dir.push_back(c.second); }
+		}
+	};
+	struct Helper {   // (joined on every way out)
+		std::thread th; std::exception_ptr failed;
+		void wait() { if (th.joinable()) th.join(); if (failed) { std::exception_ptr e = failed; failed = nullptr; std::rethrow_exception(e); } }
+		~Helper() { if (th.joinable()) th.join(); }
+	} dir_helper;
+	const bool dir_beside = w.marks.size() >= 4096 && host_threads() > 1;
+	if (dir_beside) dir_helper.th = std::thread([&] { try { select_restarts(); } catch (...) { dir_helper.failed = std::current_exception(); } });
 
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 	if (piped && (vc != pipe->vc || fc != pipe->fc)) throw Error(HRY_E_INTERNAL, "encode pipeline: sizes changed under the walk");
@@ -806,7 +826,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	if (ns) HIP_OK(hipMemcpyAsync(cx.d_cjobs.p, jobs.data(), (size_t)ns * sizeof(StreamJob), hipMemcpyHostToDevice, cx.stream));
 	cx.ensure_magic(max_t0 + CH + 16);
 	cx.d_acc.ensure((size_t)nw * 8);
-	cx.d_v.ensure((size_t)nw * 8);
+	// (no folded copy of the accumulators: the carry kernels fold where they read, kernels.hip)
 	cx.d_summary.ensure(((size_t)nw / 1024 + 2) * 4);
 	cx.d_bytes.ensure((size_t)nw * 4);
 	cx.d_csizes.ensure(std::max<size_t>((size_t)ns * 8, 16));   // bits | nbytes
@@ -856,16 +876,10 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	*total_bytes_p = 0;
 	HIP_OK(hipMemcpyAsync((void*)total_bytes_p, cx.d_coffs.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, cx.stream));
 	HRY_MARK(t_all, "  stream kernels launched");
-	// (while the device codes the streams: 17 ms of host work for the 151 741 components of the configs[3] mesh)
-	// directory: chunk sizes, plane lengths, restart points of the connectivity replay, stream lengths
-	std::vector<RestartCounters> rcounters;
-	const std::vector<RestartPoint> restarts = select_restart_points(w.marks, w.named, rcounters);
+	// directory: chunk sizes, plane lengths, restart points of the connectivity replay (while the device codes the streams, unless
+	// a thread has been at them since the walk), stream lengths
+	if (dir_beside) dir_helper.wait(); else select_restarts();
 	const uint32_t nrs = (uint32_t)restarts.size();
-	std::vector<uint32_t> counter_dir;   // per restart point: n, then n x (vertex, counter)
-	for (const RestartCounters &cs : rcounters) {
-		counter_dir.push_back((uint32_t)cs.size());
-		for (const auto &c : cs) { counter_dir.push_back(c.first); counter_dir.push_back(c.second); }
-	}
 	HRY_MARK(t_all, "  restart points selected");
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	const uint64_t total_bytes = *total_bytes_p;

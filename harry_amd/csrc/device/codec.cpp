@@ -478,7 +478,7 @@ void finish_stream(Context &cx, uint32_t ns, std::vector<uint8_t> &payload)
 	size_t nbytes = (size_t)((nbits + 7) / 8);
 	uint32_t nw = (uint32_t)((nbits + 31) / 32) + 2;
 	cx.d_acc.ensure((size_t)nw * 8);
-	cx.d_v.ensure((size_t)nw * 8);
+	// (no folded copy of the accumulators: the carry kernels fold where they read, kernels.hip)
 	cx.d_summary.ensure(((size_t)nw / 1024 + 2) * 4);
 	cx.d_bytes.ensure((size_t)nw * 4);
 	HIP_OK(hipMemsetAsync(cx.d_acc.p, 0, (size_t)nw * 8, cx.stream));

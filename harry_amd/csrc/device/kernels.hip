@@ -689,51 +689,62 @@ __global__ __launch_bounds__(256) void k_low_accumulate(const uint64_t *r, const
 	}
 }
 
-// first normalisation: v[k] = low32(acc[k]) + high32(acc[k+1]) < 2^33, after which carries are single bits
-__global__ __launch_bounds__(256) void k_carry_fold(const unsigned long long *acc, uint32_t nw, unsigned long long *v)
+// first normalisation: v[k] = low32(acc[k]) + high32(acc[k+1]) < 2^33, after which carries are single bits (formed where it is
+// needed: until round 5 a kernel of its own wrote the v[] -- 8 bytes per output word -- for the two below to read)
+__device__ __forceinline__ unsigned long long carry_folded(const unsigned long long *acc, uint32_t nw, uint32_t k)
 {
-	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= nw) return;
-	unsigned long long up = k + 1 < nw ? acc[k + 1] >> 32 : 0ull;
-	v[k] = (acc[k] & 0xffffffffull) + up;
+	const unsigned long long up = k + 1 < nw ? acc[k + 1] >> 32 : 0ull;
+	return (acc[k] & 0xffffffffull) + up;
 }
 
 // carry-lookahead over words, processed from the least significant word (index nw-1) upwards.
 // pair (g, p): g = the segment generates a carry, p = it propagates an incoming carry.
-__device__ __forceinline__ uint32_t gp_combine(uint32_t hi, uint32_t lo)   // hi = more significant segment
-{
-	uint32_t g = (hi & 1u) | (((hi >> 1) & 1u) & (lo & 1u));
-	uint32_t p = ((hi >> 1) & 1u) & ((lo >> 1) & 1u);
-	return g | (p << 1);
-}
 __device__ __forceinline__ uint32_t gp_of(unsigned long long v) { return (v >> 32 ? 1u : 0u) | ((v == 0xffffffffull) ? 2u : 0u); }
-
-constexpr int kCarryBlock = 1024;   // words per block
-__global__ __launch_bounds__(256) void k_carry_block_summary(const unsigned long long *v, uint32_t nw, uint32_t *summary)
-{
-	// block b covers reversed indices [b*1024, (b+1)*1024): reversed index i <-> word nw-1-i
-	__shared__ uint32_t sm[256];
-	uint32_t i0 = blockIdx.x * kCarryBlock + threadIdx.x * 4;
-	uint32_t acc = 2u;   // identity: no generate, propagate
-	for (int q = 0; q < 4; ++q) {
-		uint32_t i = i0 + q;
-		uint32_t e = i < nw ? gp_of(v[nw - 1 - i]) : 2u;
-		acc = gp_combine(e, acc);
-	}
-	sm[threadIdx.x] = acc;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t a = 2u;
-		for (int t = 0; t < 256; ++t) a = gp_combine(sm[t], a);
-		summary[blockIdx.x] = a;
-	}
-}
 // (generate, propagate) of a lower part followed by a higher part
 __device__ __forceinline__ uint32_t gp_then(uint32_t lo, uint32_t hi)
 {
 	const uint32_t g = (hi & 1u) | (((hi >> 1) & 1u) & (lo & 1u));
 	const uint32_t p = ((hi >> 1) & 1u) & ((lo >> 1) & 1u);
 	return g | (p << 1);
+}
+
+constexpr int kCarryRows = 16;                        // rows of 64 words per wavefront
+constexpr int kCarryBlock = 4 * 64 * kCarryRows;      // words per block (four wavefronts)
+// A block covers reversed indices [b * kCarryBlock, ...): reversed index i <-> word nw-1-i; wavefront w of the block its kCarryRows
+// rows of 64 from b * kCarryBlock + w * 64 * kCarryRows, lane l of a row the word at l: one coalesced load per row.  A row's 64
+// look-ahead pairs are two ballots, G (generates) and P (propagates; never both), and carry look-ahead over them is ONE 64-bit
+// addition on the scalar unit: (G | P) + G + c has, XORed with its operands, the carry INTO every position, and overflows iff the
+// row hands one on.  (Until round 5: four words per thread in a row, thread 0 folding the block's 256 pairs one by one and every
+// thread of k_carry_apply the pairs of all threads below it -- 6 ms of carry kernels for the 292 MB of streams of the
+// 100 M-triangle mesh, at 3 % of what HBM delivers; the folded words v[] came from a kernel of their own.)
+struct CarryRow { unsigned long long G, P; };
+__device__ __forceinline__ unsigned long long carry_row_load(const unsigned long long *acc, uint32_t nw, uint32_t i, CarryRow &row)
+{
+	const unsigned long long v = i < nw ? carry_folded(acc, nw, nw - 1 - i) : 0xffffffffull;   // (behind the end: propagates, never stored)
+	row.G = __ballot((v >> 32) != 0ull);
+	row.P = __ballot(v == 0xffffffffull);
+	return v;
+}
+// the row as one pair: bit 0 = hands a carry on by itself, bit 1 = hands an incoming one on
+__device__ __forceinline__ uint32_t carry_row_pair(const CarryRow &row)
+{
+	const unsigned long long X = row.G | row.P, sum = X + row.G;
+	return (sum < X ? 1u : 0u) | (row.P == ~0ull ? 2u : 0u);
+}
+__global__ __launch_bounds__(256) void k_carry_block_summary(const unsigned long long *acc, uint32_t nw, uint32_t *summary)
+{
+	__shared__ uint32_t sm[4];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t base = blockIdx.x * kCarryBlock + wave * 64u * kCarryRows;
+	uint32_t a = 2u;   // identity: generates nothing, propagates
+	for (int r = 0; r < kCarryRows; ++r) {
+		CarryRow row;
+		(void)carry_row_load(acc, nw, base + (uint32_t)r * 64u + lane, row);
+		a = gp_then(a, carry_row_pair(row));
+	}
+	if (lane == 0) sm[wave] = a;
+	__syncthreads();
+	if (threadIdx.x == 0) summary[blockIdx.x] = gp_then(gp_then(gp_then(sm[0], sm[1]), sm[2]), sm[3]);
 }
 // summary[b] becomes the carry INTO block b.  One workgroup: every thread folds a contiguous run of blocks, the 1024 run
 // aggregates are scanned in LDS (carry look-ahead is associative), then every thread pushes its carry through its run.
@@ -762,35 +773,33 @@ __global__ __launch_bounds__(1024) void k_carry_scan_blocks(uint32_t *summary, u
 		carry = (gp & 1u) | (((gp >> 1) & 1u) & carry);
 	}
 }
-__global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *v, uint32_t nw, const uint32_t *block_carry, uint8_t *bytes)
+__global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *acc, uint32_t nw, const uint32_t *block_carry, uint8_t *bytes)
 {
-	__shared__ uint32_t sm[256];
-	uint32_t i0 = blockIdx.x * kCarryBlock + threadIdx.x * 4;
-	uint32_t e[4];
-	uint32_t acc = 2u;
-	for (int q = 0; q < 4; ++q) {
-		uint32_t i = i0 + q;
-		e[q] = i < nw ? gp_of(v[nw - 1 - i]) : 2u;
-		acc = gp_combine(e[q], acc);
+	__shared__ uint32_t sm[4];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t base = blockIdx.x * kCarryBlock + wave * 64u * kCarryRows;
+	unsigned long long v[kCarryRows];
+	CarryRow row[kCarryRows];
+	uint32_t a = 2u;
+#pragma unroll
+	for (int r = 0; r < kCarryRows; ++r) {
+		v[r] = carry_row_load(acc, nw, base + (uint32_t)r * 64u + lane, row[r]);
+		a = gp_then(a, carry_row_pair(row[r]));
 	}
-	sm[threadIdx.x] = acc;
+	if (lane == 0) sm[wave] = a;
 	__syncthreads();
-	// carry into this thread's 4 words = block carry pushed through all lower threads
-	uint32_t carry = block_carry[blockIdx.x];
-	for (uint32_t t = 0; t < threadIdx.x; ++t) {
-		uint32_t gp = sm[t];
-		carry = (gp & 1u) | (((gp >> 1) & 1u) & carry);
-	}
-	for (int q = 0; q < 4; ++q) {
-		uint32_t i = i0 + q;
-		if (i >= nw) break;
-		uint32_t k = nw - 1 - i;
-		uint32_t word = (uint32_t)(v[k] + carry);
-		carry = (e[q] & 1u) | (((e[q] >> 1) & 1u) & carry);
-		bytes[(size_t)4 * k] = (uint8_t)(word >> 24);
-		bytes[(size_t)4 * k + 1] = (uint8_t)(word >> 16);
-		bytes[(size_t)4 * k + 2] = (uint8_t)(word >> 8);
-		bytes[(size_t)4 * k + 3] = (uint8_t)word;
+	uint32_t before = 2u;
+	for (uint32_t w = 0; w < wave; ++w) before = gp_then(before, sm[w]);
+	// the carry into this wavefront's first row: the block's, pushed through the wavefronts below
+	unsigned long long c = (before & 1u) | (((before >> 1) & 1u) & block_carry[blockIdx.x]);
+	uint32_t *words = (uint32_t*)bytes;   // (big-endian bytes of word k at 4 k: one swapped store)
+#pragma unroll
+	for (int r = 0; r < kCarryRows; ++r) {
+		const unsigned long long X = row[r].G | row[r].P, s1 = X + row[r].G, s2 = s1 + c;
+		const unsigned long long into = s2 ^ X ^ row[r].G;   // bit l: the carry into the word at lane l
+		const uint32_t i = base + (uint32_t)r * 64u + lane;
+		if (i < nw) words[nw - 1 - i] = __builtin_bswap32((uint32_t)(v[r] + ((into >> lane) & 1ull)));
+		c = (s1 < X || s2 < s1) ? 1ull : 0ull;
 	}
 }
 
@@ -906,10 +915,10 @@ void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s,
 void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes)
 {
 	unsigned nb = blocks_for(nw, kCarryBlock);
-	hipLaunchKernelGGL(k_carry_fold, dim3(blocks_for(nw, 256)), dim3(256), 0, st, (const unsigned long long*)acc, nw, (unsigned long long*)v);
-	hipLaunchKernelGGL(k_carry_block_summary, dim3(nb), dim3(256), 0, st, (const unsigned long long*)v, nw, summary);
+	(void)v;   // (the folded words are formed inside the kernels)
+	hipLaunchKernelGGL(k_carry_block_summary, dim3(nb), dim3(256), 0, st, (const unsigned long long*)acc, nw, summary);
 	hipLaunchKernelGGL(k_carry_scan_blocks, dim3(1), dim3(1024), 0, st, summary, nb);
-	hipLaunchKernelGGL(k_carry_apply, dim3(nb), dim3(256), 0, st, (const unsigned long long*)v, nw, summary, bytes);
+	hipLaunchKernelGGL(k_carry_apply, dim3(nb), dim3(256), 0, st, (const unsigned long long*)acc, nw, summary, bytes);
 }
 
 }   // namespace dev

@@ -1572,55 +1572,66 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 	if (off_sym[ncomp] + 1 >= (1ull << 32)) throw Error(HRY_E_UNSUPPORTED, "more than 2^32 connectivity symbols");
 	w.op_sc.resize(off_op[ncomp]);
 	for (int g = 0; g < G_COUNT; ++g) if (g != G_NUMTRI) { w.grp_val[g].resize(off_g[g][ncomp]); w.grp_pos[g].resize(off_g[g][ncomp]); }
-	parallel_for(n_threads, [&](unsigned t) {
-		// ranges of components with about the same number of operation bytes each
-		const uint64_t lo = off_op[0] + (off_op[ncomp] - off_op[0]) * t / n_threads, hi = off_op[0] + (off_op[ncomp] - off_op[0]) * (t + 1) / n_threads;
-		uint32_t kb = (uint32_t)(std::lower_bound(off_op.begin(), off_op.begin() + ncomp, lo) - off_op.begin());
-		uint32_t ke = t + 1 == n_threads ? ncomp : (uint32_t)(std::lower_bound(off_op.begin(), off_op.begin() + ncomp, hi) - off_op.begin());
-		for (uint32_t k = kb; k < ke; ++k) {
-			const Piece &pc = piece[k];
-			if (pc.n_ops) memcpy(w.op_sc.data() + off_op[k], pc.ops, pc.n_ops);
-			const WalkResult &tw = per_thread[pc.thread].w;
-			const uint32_t add = (uint32_t)off_sym[k] - pc.sym0;   // (modulo 2^32: thread-local position -> position in the sequence)
-			if (nt_pos) { uint32_t *q = w.grp_pos[G_NUMTRI].data() + off_g[G_NUMTRI][k]; for (uint32_t i = 0, nn = A.n_faces[k]; i < nn; ++i) q[i] += add; }
-			for (int g = 0; g < G_COUNT; ++g) {
-				if (!pc.gn[g]) continue;
-				memcpy(w.grp_val[g].data() + off_g[g][k], tw.grp_val[g].data() + pc.g0[g], (size_t)pc.gn[g] * 4);
-				uint32_t *dst = w.grp_pos[g].data() + off_g[g][k];
-				const uint32_t *src = tw.grp_pos[g].data() + pc.g0[g];
-				for (uint32_t i = 0; i < pc.gn[g]; ++i) dst[i] = src[i] + add;
+	// (the marks -- one thread's loop over the components, 4 ms for the 151 741 of the configs[3] mesh -- beside the copies)
+	std::exception_ptr marks_failed;
+	auto marks_in_order = [&] {
+		for (const PerThread &T : per_thread) {
+			if (T.w.twins_changed) w.twins_changed = true;
+			w.twin_patches.insert(w.twin_patches.end(), T.w.twin_patches.begin(), T.w.twin_patches.end());
+		}
+		// marks: one per component, with the counts of everything coded before it in the sequence
+		em0.finish_marks();
+		{
+			uint32_t nop[8];
+			for (int i = 0; i < 8; ++i) nop[i] = em0.n_op[i];
+			const size_t mark0 = w.marks.size();
+			w.marks.resize(mark0 + ncomp);
+			size_t n_named = w.named.size();
+			for (uint32_t k = 0; k < ncomp; ++k) n_named += piece[k].n_named;
+			w.named.reserve(n_named);
+			for (uint32_t k = 0; k < ncomp; ++k) {
+				const Piece &pc = piece[k];
+				const WalkResult &tw = per_thread[pc.thread].w;
+				for (uint32_t i = 0; i < pc.n_named; ++i) { NamedVertex ev = tw.named[pc.named0 + i]; ev.mark = (uint32_t)(mark0 + k); w.named.push_back(ev); }
+				ComponentMark mk = tw.marks.at(pc.mark);   // first_vertex and min_ref are the walk's
+				for (int g = 0; g < G_COUNT; ++g) mk.n_grp[g] = (uint32_t)off_g[g][k];
+				for (int i = 0; i < 8; ++i) { mk.n_op[i] = nop[i]; nop[i] += pc.n_op[i]; }
+				mk.first_face = (uint32_t)off_f[k];
+				mk.first_halfedge = (uint32_t)off_he[k];
+				w.marks[mark0 + k] = mk;
 			}
+			em0.halfedges = (uint32_t)off_he[ncomp];
+			for (int i = 0; i < 8; ++i) em0.n_op[i] = nop[i];
 		}
-	});
+	};
+	std::thread marks_thread;
+	if (ncomp >= (getenv("HRY_PARALLEL_MIN_FACES") ? 1u : 4096u) && n_threads > 1) marks_thread =   // (the tests' switch for "small inputs on threads too")
+		 std::thread([&] { try { marks_in_order(); } catch (...) { marks_failed = std::current_exception(); } });
+	try {
+		parallel_for(n_threads, [&](unsigned t) {
+			// ranges of components with about the same number of operation bytes each
+			const uint64_t lo = off_op[0] + (off_op[ncomp] - off_op[0]) * t / n_threads, hi = off_op[0] + (off_op[ncomp] - off_op[0]) * (t + 1) / n_threads;
+			uint32_t kb = (uint32_t)(std::lower_bound(off_op.begin(), off_op.begin() + ncomp, lo) - off_op.begin());
+			uint32_t ke = t + 1 == n_threads ? ncomp : (uint32_t)(std::lower_bound(off_op.begin(), off_op.begin() + ncomp, hi) - off_op.begin());
+			for (uint32_t k = kb; k < ke; ++k) {
+				const Piece &pc = piece[k];
+				if (pc.n_ops) memcpy(w.op_sc.data() + off_op[k], pc.ops, pc.n_ops);
+				const WalkResult &tw = per_thread[pc.thread].w;
+				const uint32_t add = (uint32_t)off_sym[k] - pc.sym0;   // (modulo 2^32: thread-local position -> position in the sequence)
+				if (nt_pos) { uint32_t *q = w.grp_pos[G_NUMTRI].data() + off_g[G_NUMTRI][k]; for (uint32_t i = 0, nn = A.n_faces[k]; i < nn; ++i) q[i] += add; }
+				for (int g = 0; g < G_COUNT; ++g) {
+					if (!pc.gn[g]) continue;
+					memcpy(w.grp_val[g].data() + off_g[g][k], tw.grp_val[g].data() + pc.g0[g], (size_t)pc.gn[g] * 4);
+					uint32_t *dst = w.grp_pos[g].data() + off_g[g][k];
+					const uint32_t *src = tw.grp_pos[g].data() + pc.g0[g];
+					for (uint32_t i = 0; i < pc.gn[g]; ++i) dst[i] = src[i] + add;
+				}
+			}
+		});
+	} catch (...) { if (marks_thread.joinable()) marks_thread.join(); throw; }
 	mark("operations and rare groups in coding order");
-	for (const PerThread &T : per_thread) {
-		if (T.w.twins_changed) w.twins_changed = true;
-		w.twin_patches.insert(w.twin_patches.end(), T.w.twin_patches.begin(), T.w.twin_patches.end());
-	}
-	// marks: one per component, with the counts of everything coded before it in the sequence
-	em0.finish_marks();
-	{
-		uint32_t nop[8];
-		for (int i = 0; i < 8; ++i) nop[i] = em0.n_op[i];
-		const size_t mark0 = w.marks.size();
-		w.marks.resize(mark0 + ncomp);
-		size_t n_named = w.named.size();
-		for (uint32_t k = 0; k < ncomp; ++k) n_named += piece[k].n_named;
-		w.named.reserve(n_named);
-		for (uint32_t k = 0; k < ncomp; ++k) {
-			const Piece &pc = piece[k];
-			const WalkResult &tw = per_thread[pc.thread].w;
-			for (uint32_t i = 0; i < pc.n_named; ++i) { NamedVertex ev = tw.named[pc.named0 + i]; ev.mark = (uint32_t)(mark0 + k); w.named.push_back(ev); }
-			ComponentMark mk = tw.marks.at(pc.mark);   // first_vertex and min_ref are the walk's
-			for (int g = 0; g < G_COUNT; ++g) mk.n_grp[g] = (uint32_t)off_g[g][k];
-			for (int i = 0; i < 8; ++i) { mk.n_op[i] = nop[i]; nop[i] += pc.n_op[i]; }
-			mk.first_face = (uint32_t)off_f[k];
-			mk.first_halfedge = (uint32_t)off_he[k];
-			w.marks[mark0 + k] = mk;
-		}
-		em0.halfedges = (uint32_t)off_he[ncomp];
-		for (int i = 0; i < 8; ++i) em0.n_op[i] = nop[i];
-	}
+	if (marks_thread.joinable()) marks_thread.join(); else marks_in_order();
+	if (marks_failed) std::rethrow_exception(marks_failed);
 	em0.n = (uint32_t)off_sym[ncomp];
 	em0.min_ref = w.marks.empty() ? NONE32 : w.marks.back().min_ref;   // the caller's finish_marks() writes it back into the last mark
 	mark("marks in coding order");
