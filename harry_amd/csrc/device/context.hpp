@@ -111,6 +111,8 @@ struct Context {
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core
 	PinBuf h_pipe;                  // chunked encode: the pipeline's staging slots (run tables + the runs' entries, gathered)
+	PinBuf h_fetch;                 // large results on their way down: a ring of pinned slots (fetch_to_host, codec.cpp)
+	hipEvent_t stage_ev[8] = {};    // ... and an event per slot
 	PinBuf h_gen;                   // general bindings: the events' arena on its way up (general.cpp)
 	PinBuf h_small;                 // a few words that come down asynchronously (a copy into pageable memory keeps its caller until it has happened)
 	PinBuf h_conn;                  // chunked decode: the connectivity planes, down for the host's replay
@@ -163,6 +165,8 @@ void general_planes_decode(Context &cx, Mesh &m, const OrderVec &order_v, const 
                            const std::vector<uint32_t> &nsym, uint32_t first);
 
 void check_general(const Mesh &m);             // general.cpp
+// device -> pageable host memory, behind everything on cx.stream; returns when the bytes are there (codec.cpp)
+void fetch_to_host(Context &cx, void *dst, const void *d_src, size_t bytes);
 void upload_general(Context &cx, Mesh &m);     // connectivity + every list + the binding tables -> HBM
 
 // codec entry points (codec.cpp / chunked.cpp)
