@@ -898,7 +898,7 @@ def cfg3_leg(cx):
                             ^ (x[:, 4].astype(np.uint64) << 10) ^ x[:, 5].astype(np.uint64))
     ok = bool((d.nv, d.nf, d.ne) == (m0.nv, m0.nf, m0.ne) and np.array_equal(key(a), key(b)))
     e, dd = min(enc[1:]), min(dec[1:])
-    te, td = tms[-1]
+    te, td = tms[enc.index(e)][0], tms[dec.index(dd)][1]   # (the stage times of the passes the record quotes)
     ntri = mesh.ntri
     alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
     return {"workload": "closed torus 3742 x 3742, 28 005 128 triangles, float32 xyz + analytic normals, -l1 -a0 -q14 -a1 -q14 -a2 -q14 -a3 -q10 -a4 -q10 -a5 -q10 (BASELINE configs[2] stand-in)",
@@ -940,7 +940,7 @@ def cfg4_share_leg(cx):
     nref = int(np.unique(m0.org()).size)                          # vertices no face references are not coded
     ok = bool((d.nv, d.nf, d.ne) == (m0.nv, m0.nf, m0.ne) and (nref < m0.nv or np.array_equal(rec(d), rec(m0))))
     e, er, dd = min(enc[1:]), min(enc_res[1:]), min(dec[1:])
-    te, td = tms[-1]
+    te, td = tms[enc.index(e)][0], tms[dec.index(dd)][1]   # (the stage times of the passes the record quotes)
     ntri = mesh.ntri
     alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
     traffic = traffic_raw = traffic_source = None
