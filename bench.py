@@ -418,6 +418,7 @@ def main():
         enc_s += te
         dec_s += td
         comm_s += tg
+        tm["step_ms"] = (te + td + tg) * 1e3
         timings.append(tm)
     barrier()
     total = torch.tensor([enc_s + dec_s + comm_s, enc_s, dec_s, comm_s], dtype=torch.float64, device=comm_dev)
@@ -475,6 +476,7 @@ def main():
             "decode_mtri_s": round(ntri * args.steps / t_dec / 1e6, 4) if can_decode and t_dec > 0 else None,
             "hry_bytes": len(out), "bits_per_vertex": round(8 * len(out) / max(base.nv, 1), 4),
             "host_fraction": round(host_ms / step_ms, 4) if step_ms > 0 else None,
+            "step_ms_each": [round(t["step_ms"], 2) for t in timings],      # (rank 0's steps: value is their mean, outliers included)
             "stage_ms": {k: round(med(k), 4) for k in ("requant_ms", "host_walk_ms", "h2d_ms", "device_ms", "k_predict_ms", "k_model_ms", "k_rchain_ms", "k_entropy_ms", "total_ms",
                                                         "gather_merge_ms", "dec_host_walk_ms", "dec_k_entropy_ms", "dec_k_chain_ms", "dec_total_ms")},
             "kernel_ms": {k: round(v, 4) for k, v in cands.items()},

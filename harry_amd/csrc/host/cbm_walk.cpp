@@ -646,11 +646,38 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 // HRY_WALK_SPLIT=0: the one-thread loop.
 struct WalkTrace {
 	enum { T_TRI = 0, T_BORDER = 1, T_START = 2, T_NEXTID = 3, T_ELEM = 4, T_PART = 5 };   // code in bits 8..15 of the high word, operation in bits 0..7
+	// a RING of kRing records (8 MB: stays in the two cores' shared cache; until late in round 5 one array for the whole walk,
+	// 64 MB per million triangles from the block pool -- whose blocks the decode between two encodes may have taken, and then the
+	// walk paid the page faults of a fresh one: one step in twenty took 10 - 18 ms instead of 6).  The walking thread waits when it
+	// is a ring ahead (never seen: the expanding thread stays within 10^4 - 10^5 records).
+	static constexpr size_t kRing = (size_t)1 << 20;
+	size_t ring = kRing, mask = kRing - 1;   // (HRY_WALK_RING: a smaller ring, so that small test meshes go round it many times)
 	BigVec<uint64_t> rec;
 	alignas(64) std::atomic<size_t> head{ 0 };
 	alignas(64) std::atomic<int> done{ 0 };
+	alignas(64) std::atomic<size_t> tail{ 0 };   // how far the expanding thread has come (published once per batch it takes: traces, tests)
 	static uint64_t make(uint32_t a, uint32_t code, uint32_t op, uint32_t payload = 0) { return (uint64_t)a | ((uint64_t)(op | (code << 8) | (payload << 16)) << 32); }
 };
+
+// one ring is kept between calls (its pages stay where they are)
+static std::mutex g_trace_mu;
+static std::unique_ptr<WalkTrace> g_trace_spare;
+static std::unique_ptr<WalkTrace> take_walk_trace()
+{
+	std::unique_ptr<WalkTrace> t;
+	{ std::lock_guard<std::mutex> g(g_trace_mu); t = std::move(g_trace_spare); }
+	size_t want = WalkTrace::kRing;
+	if (const char *e = getenv("HRY_WALK_RING")) { const size_t v = (size_t)strtoull(e, nullptr, 10); want = 1024; while (want < v && want < WalkTrace::kRing) want <<= 1; }
+	if (t && t->ring != want) t.reset();
+	if (!t) { t.reset(new WalkTrace()); t->ring = want; t->mask = want - 1; t->rec.resize(want); }
+	t->head.store(0, std::memory_order_relaxed); t->tail.store(0, std::memory_order_relaxed); t->done.store(0, std::memory_order_relaxed);
+	return t;
+}
+static void keep_walk_trace(std::unique_ptr<WalkTrace> t)
+{
+	std::lock_guard<std::mutex> g(g_trace_mu);
+	if (!g_trace_spare) g_trace_spare = std::move(t);
+}
 
 // A: the automaton (the loop of walk_component_tri<false> without what B does)
 static void walk_component_tri_a(Mesh &m, WalkState &st, uint32_t f, Border &cb, WalkResult &w, WalkTrace &tr, size_t &at_io, uint32_t &next_id_io, uint32_t &consumed_io)
@@ -666,8 +693,14 @@ static void walk_component_tri_a(Mesh &m, WalkState &st, uint32_t f, Border &cb,
 	static const int pf_level = [] { const char *e = getenv("HRY_WALK_PREFETCH"); return e ? atoi(e) : 2; }();
 	uint64_t *rec = tr.rec.data();
 	size_t at = at_io, published = at_io;
+	const size_t ring = tr.ring, rmask = tr.mask;
+	size_t room_upto = tr.tail.load(std::memory_order_acquire) + ring;   // records below it may be written
 	auto put = [&](uint64_t r) {
-		rec[at++] = r;
+		if (at >= room_upto) {   // (a ring ahead of the expanding thread)
+			tr.head.store(at, std::memory_order_release); published = at;
+			while (at >= (room_upto = tr.tail.load(std::memory_order_acquire) + ring)) __builtin_ia32_pause();
+		}
+		rec[at++ & rmask] = r;
 		if (at - published >= 256) { tr.head.store(at, std::memory_order_release); published = at; }
 	};
 	gone[f] = Gone::yes; ++consumed;
@@ -770,6 +803,7 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 	const uint32_t *sent = st.sent.data();   // (read for vertices that were coded before the record was written: final by then)
 	uint16_t *seen = st.seen.data();
 	const uint64_t *rec = tr.rec.data();
+	const size_t rmask = tr.mask;
 	OpByte *opc = em.op_cur;
 	uint32_t *ovc = em.ov_cur, *ofc = em.of_cur;
 	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, n_ops = 0, faces = 0;
@@ -779,7 +813,7 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 		*opc++ = (OpByte)(s | (k << 3));
 	};
 	auto sync_n = [&] { em.n += n_ops; n_ops = 0; };
-	size_t pos = 0;
+	size_t pos = 0, tail_said = 0;
 	for (;;) {
 		size_t h = tr.head.load(std::memory_order_acquire);
 		if (h == pos) {
@@ -788,10 +822,14 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 		}
 		// (a split / union / start record is followed by its operands: A publishes whole groups only at the end of a component or
 		// in blocks of 256, so an operand may still be on its way -- wait for it)
-		auto need = [&](size_t k) { while (h < k) { __builtin_ia32_pause(); h = tr.head.load(std::memory_order_acquire); } };
+		auto need = [&](size_t k) {
+			if (h < k) { tr.tail.store(pos, std::memory_order_release); tail_said = pos; }   // (the record in hand has been read: the walking thread is not kept waiting for room by this wait)
+			while (h < k) { __builtin_ia32_pause(); h = tr.head.load(std::memory_order_acquire); }
+		};
 		while (pos < h) {
-			if (pos + 8 < h) { const uint64_t ahead = rec[pos + 8]; if (((ahead >> 40) & 0xffu) == WalkTrace::T_TRI) __builtin_prefetch(org + 3u * ((uint32_t)ahead / 3u)); }
-			const uint64_t r = rec[pos++];
+			if (pos - tail_said >= 4096) { tr.tail.store(pos, std::memory_order_release); tail_said = pos; }
+			if (pos + 8 < h) { const uint64_t ahead = rec[(pos + 8) & rmask]; if (((ahead >> 40) & 0xffu) == WalkTrace::T_TRI) __builtin_prefetch(org + 3u * ((uint32_t)ahead / 3u)); }
+			const uint64_t r = rec[pos++ & rmask];
 			const uint32_t a = (uint32_t)r, hi = (uint32_t)(r >> 32), op = hi & 0xffu, code = (hi >> 8) & 0xffu;
 			if (code == WalkTrace::T_TRI) {
 				const uint32_t base = 3u * (a / 3u), kk = a - base;
@@ -803,11 +841,11 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 				else if (op == O_NM) { sync_n(); em.vert(sent[v2], seen[v2]); }
 				else if (op == O_UNION) {
 					need(pos + 2);
-					sync_n(); em.elem((int)(int32_t)(uint32_t)rec[pos]); em.part((int)(uint32_t)rec[pos + 1]);
+					sync_n(); em.elem((int)(int32_t)(uint32_t)rec[pos & rmask]); em.part((int)(uint32_t)rec[(pos + 1) & rmask]);
 					pos += 2;
 				} else if (op == O_SPLIT) {
 					need(pos + 1);
-					sync_n(); em.elem((int)(int32_t)(uint32_t)rec[pos]);
+					sync_n(); em.elem((int)(int32_t)(uint32_t)rec[pos & rmask]);
 					pos += 1;
 				}
 				++seen[v0]; ++seen[v1]; ++seen[v2];
@@ -817,7 +855,7 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 				emit(op, seen[a]);
 			} else if (code == WalkTrace::T_START) {
 				need(pos + 1);
-				const uint32_t next_id = (uint32_t)rec[pos++];
+				const uint32_t next_id = (uint32_t)rec[pos++ & rmask];
 				const unsigned mask = (hi >> 16) & 0xffu;
 				// the Emitter's own view of the cursors and counters (its mark of the new component reads them)
 				sync_n();
@@ -843,6 +881,8 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 				++faces;
 			} else throw Error(HRY_E_INTERNAL, "walk trace: stray record");
 		}
+		tr.tail.store(pos, std::memory_order_release);   // (everything below pos has been read: the walking thread may write over it)
+		tail_said = pos;
 	}
 	sync_n();
 	for (int i = 0; i < 8; ++i) em.n_op[i] += n_op[i];
@@ -1040,10 +1080,14 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 		void stop()
 		{
 			if (!expander.joinable()) return;
+			const size_t behind = trace->head.load(std::memory_order_relaxed) - trace->tail.load(std::memory_order_relaxed);
+			const auto t_stop = std::chrono::steady_clock::now();
 			trace->done.store(1, std::memory_order_release);
 			expander.join();
+			if (getenv("HRY_TRACE")) fprintf(stderr, "[hry walk] the expanding thread was %zu records behind the walk's %zu, joined after %.2f ms\n", behind,
+			                                 trace->head.load(std::memory_order_relaxed), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_stop).count());
 		}
-		~Split() { stop(); }
+		~Split() { stop(); if (trace) keep_walk_trace(std::move(trace)); }
 	} split;
 	const uint32_t split_min_faces = [] { const char *e = getenv("HRY_WALK_SPLIT"); return e ? (atoi(e) > 0 ? (uint32_t)atoi(e) : 0xffffffffu) : (1u << 17); }();   // 0: never; n: from n faces (read per call: the tests change it)
 	const bool want_split = DEG == 3 && !eval_op_model && !getenv("HRY_GENERIC_WALK") && !count && n_threads > 1 && m.nf >= split_min_faces;
@@ -1064,9 +1108,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 		}
 		if (want_split) {
 			if (!split.trace) {
-				split.trace.reset(new WalkTrace());
-				// a record per triangle and per border operation, at most two operands per triangle, two records per component start
-				split.trace->rec.resize((size_t)3 * m.ntri() + m.ne() + (size_t)2 * m.nf + 64);
+				split.trace = take_walk_trace();   // (the ring of the call before, where there was one)
 				const void *near_cpus = callers_neighbour_cpus();   // (this thread's cache domain without its own core)
 				WalkTrace *trp = split.trace.get();
 				std::exception_ptr *errp = &split.err;

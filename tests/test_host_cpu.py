@@ -388,14 +388,17 @@ def test_triangle_walk_on_two_cores_equals_the_one_thread_loop(case, monkeypatch
     monkeypatch.setenv("HRY_HOST_THREADS", "2")
     monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "4000000000")   # (every component in the sequential loop)
     out = []
-    for split in ("0", "1"):
+    for split, ring in (("0", None), ("1", None), ("1", "1024")):   # (the trace is a ring: the last round goes round a small one many times)
         monkeypatch.setenv("HRY_WALK_SPLIT", split)
+        if ring:
+            monkeypatch.setenv("HRY_WALK_RING", ring)
         m = hc.Mesh.from_arrays(mesh.verts, mesh.degrees, mesh.indices)
         w = m.host_walk(plain=True)
         out.append((w, m.twin()))
-    for k in out[0][0]:
-        assert np.array_equal(out[0][0][k], out[1][0][k]), k
-    assert np.array_equal(out[0][1], out[1][1])
+    for other in out[1:]:
+        for k in out[0][0]:
+            assert np.array_equal(out[0][0][k], other[0][k]), k
+        assert np.array_equal(out[0][1], other[1])
     assert len(out[0][0]["order_f"]) == mesh.nf
 
 

@@ -36,7 +36,7 @@ def test_host_code_under_sanitizers(tmp_path):
     files = [f for f in sorted(glob.glob(g + "/*.ply") + glob.glob(g + "/obj/*.obj")) if ".dec." not in f]   # the reference's own
     files += sorted(glob.glob(g + "/*.hry") + glob.glob(g + "/obj/*.hry"))                                   # outputs do not all re-read
     # (the walks of the chunked profile and of a shard in place run on four host threads whatever the mesh's size)
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", HRY_PARALLEL_MIN_FACES="1", HRY_HOST_THREADS="4", HRY_WALK_SPLIT="1")   # (... and a triangle mesh's first component on two cores)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", HRY_PARALLEL_MIN_FACES="1", HRY_HOST_THREADS="4", HRY_WALK_SPLIT="1", HRY_WALK_RING="1024")   # (... and a triangle mesh's first component on two cores)
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe, *files], capture_output=True, text=True, env=env, timeout=800)
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (r.stdout + r.stderr)[-4000:]
@@ -74,7 +74,7 @@ def test_threaded_host_code_under_thread_sanitizer(tmp_path):
         files.append(str(tmp_path / f"generated{i}.ply"))
         with open(files[-1], "wb") as f:
             f.write(m.to_ply())
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 history_size=4", HRY_PARALLEL_MIN_FACES="1", HRY_HOST_THREADS="6", HRY_WALK_SPLIT="1")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 history_size=4", HRY_PARALLEL_MIN_FACES="1", HRY_HOST_THREADS="6", HRY_WALK_SPLIT="1", HRY_WALK_RING="1024")
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe, *files], capture_output=True, text=True, env=env, timeout=800)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-4000:]
