@@ -275,8 +275,8 @@ def stay_on_gpu_node(device: int, local_rank: int, local_world: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)    # a step is ~20 ms of two sequential host loops: ten of them average the host's noise
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)    # a step is ~17 ms of two sequential host loops, and on a shared host one step in twenty takes 23 - 28 (step_ms_each): thirty of them average that
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--side", type=int, default=708, help="torus grid side; 708 -> 1 002 528 triangles (configs[1])")
     ap.add_argument("--profile", default="auto", choices=["auto", "compat", "chunked"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
