@@ -718,12 +718,16 @@ constexpr int kCarryBlock = 4 * 64 * kCarryRows;      // words per block (four w
 // thread of k_carry_apply the pairs of all threads below it -- 6 ms of carry kernels for the 292 MB of streams of the
 // 100 M-triangle mesh, at 3 % of what HBM delivers; the folded words v[] came from a kernel of their own.)
 struct CarryRow { unsigned long long G, P; };
-__device__ __forceinline__ unsigned long long carry_row_load(const unsigned long long *acc, uint32_t nw, uint32_t i, CarryRow &row)
+__device__ __forceinline__ unsigned long long carry_word(const unsigned long long *acc, uint32_t nw, uint32_t i)
 {
-	const unsigned long long v = i < nw ? carry_folded(acc, nw, nw - 1 - i) : 0xffffffffull;   // (behind the end: propagates, never stored)
-	row.G = __ballot((v >> 32) != 0ull);
-	row.P = __ballot(v == 0xffffffffull);
-	return v;
+	return i < nw ? carry_folded(acc, nw, nw - 1 - i) : 0xffffffffull;   // (behind the end: propagates, never stored)
+}
+__device__ __forceinline__ void carry_row_masks(unsigned long long v, CarryRow &row)
+{
+	// (the callers give lane l the row's position 63 - l, so that the lanes' addresses ascend -- descending ones were fetched and
+	// written sector by sector: 1.8 GB each way for 292 MB of words, profiles/r5 -- and the ballots are turned round to match)
+	row.G = __builtin_bitreverse64(__ballot((v >> 32) != 0ull));
+	row.P = __builtin_bitreverse64(__ballot(v == 0xffffffffull));
 }
 // the row as one pair: bit 0 = hands a carry on by itself, bit 1 = hands an incoming one on
 __device__ __forceinline__ uint32_t carry_row_pair(const CarryRow &row)
@@ -737,9 +741,13 @@ __global__ __launch_bounds__(256) void k_carry_block_summary(const unsigned long
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t base = blockIdx.x * kCarryBlock + wave * 64u * kCarryRows;
 	uint32_t a = 2u;   // identity: generates nothing, propagates
+	unsigned long long v[kCarryRows];
+#pragma unroll
+	for (int r = 0; r < kCarryRows; ++r) v[r] = carry_word(acc, nw, base + (uint32_t)r * 64u + (63u - lane));   // (every load in flight before the first ballot waits for one)
+#pragma unroll
 	for (int r = 0; r < kCarryRows; ++r) {
 		CarryRow row;
-		(void)carry_row_load(acc, nw, base + (uint32_t)r * 64u + lane, row);
+		carry_row_masks(v[r], row);
 		a = gp_then(a, carry_row_pair(row));
 	}
 	if (lane == 0) sm[wave] = a;
@@ -782,8 +790,10 @@ __global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *a
 	CarryRow row[kCarryRows];
 	uint32_t a = 2u;
 #pragma unroll
+	for (int r = 0; r < kCarryRows; ++r) v[r] = carry_word(acc, nw, base + (uint32_t)r * 64u + (63u - lane));   // (every load in flight before the first ballot waits for one)
+#pragma unroll
 	for (int r = 0; r < kCarryRows; ++r) {
-		v[r] = carry_row_load(acc, nw, base + (uint32_t)r * 64u + lane, row[r]);
+		carry_row_masks(v[r], row[r]);
 		a = gp_then(a, carry_row_pair(row[r]));
 	}
 	if (lane == 0) sm[wave] = a;
@@ -796,9 +806,9 @@ __global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *a
 #pragma unroll
 	for (int r = 0; r < kCarryRows; ++r) {
 		const unsigned long long X = row[r].G | row[r].P, s1 = X + row[r].G, s2 = s1 + c;
-		const unsigned long long into = s2 ^ X ^ row[r].G;   // bit l: the carry into the word at lane l
-		const uint32_t i = base + (uint32_t)r * 64u + lane;
-		if (i < nw) words[nw - 1 - i] = __builtin_bswap32((uint32_t)(v[r] + ((into >> lane) & 1ull)));
+		const unsigned long long into = s2 ^ X ^ row[r].G;   // bit j: the carry into the word at position j of the row
+		const uint32_t i = base + (uint32_t)r * 64u + (63u - lane);
+		if (i < nw) words[nw - 1 - i] = __builtin_bswap32((uint32_t)(v[r] + ((into >> (63u - lane)) & 1ull)));
 		c = (s1 < X || s2 < s1) ? 1ull : 0ull;
 	}
 }
