@@ -171,7 +171,8 @@ const uint8_t *hry_list_max(const hry_mesh *m, int l);
 /* min/max per component on the GPU (k_bounds); hry_mesh_from_ply leaves bounds unset until first needed */
 int hry_bounds(hry_ctx *ctx, hry_mesh *m);
 int hry_requant(hry_ctx *ctx, hry_mesh *m, const hry_quant *q, size_t nq, int clear);
-/* Keep the mesh's attribute records and connectivity resident in HBM for subsequent hry_encode calls. */
+/* Keep the mesh's attribute records and connectivity resident in HBM for subsequent hry_encode calls -- for a mesh with general
+ * bindings (OBJ) its region and record tables too. */
 int hry_mesh_upload(hry_ctx *ctx, hry_mesh *m);
 /* mesh -> .hry.  *out is allocated by the library, release with hry_free.  The mesh's twin array is updated
  * exactly as the reference's encoder mutates it (cbm/encoder.h:150,193-198). */

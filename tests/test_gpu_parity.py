@@ -202,6 +202,24 @@ def test_range_coder_long_carry_chains(cx):
     assert cx.range_encode_lht(lht) == op.range_encode_lht(lht)
 
 
+@pytest.mark.parametrize("period", [97, 4099, 70001, 0])
+def test_range_coder_carries_across_rows_wavefronts_and_blocks(cx, period):
+    """The same over 160 000 output words: the carry kernels take a row of 64 words per ballot pair, sixteen rows per wavefront,
+    4 096 words per block and the blocks' pairs through a scan of their own (kernels.hip: k_carry_*) -- runs of all-ones words of
+    every length up to the whole stream, ended by a word that generates."""
+    n = 320000
+    t = np.full(n, 1 << 16, np.uint64)
+    lht = np.stack([t - 1, t.copy(), t], 1)
+    if period:
+        lht[::period] = [0, 1, 1 << 16]
+    lht[-1] = [(1 << 16) - 1, 1 << 16, 1 << 16]
+    assert cx.range_encode_lht(lht) == op.range_encode_lht(lht)
+    rng = np.random.default_rng(period + 1)
+    k = rng.integers(0, n, 200)
+    lht[k] = np.stack([rng.integers(0, 1 << 15, 200), rng.integers(1 << 15, 1 << 16, 200), np.full(200, 1 << 16)], 1).astype(np.uint64)
+    assert cx.range_encode_lht(lht) == op.range_encode_lht(lht)
+
+
 # ---------------------------------------------------------------- larger seeded meshes vs the oracle
 @pytest.mark.parametrize("case", ["torus150_q14", "ico5", "multi40", "nm_big", "grid_quads"])
 def test_encode_compat_matches_oracle_on_larger_meshes(cx, case):
