@@ -58,6 +58,7 @@ Context::~Context()
 	for (auto &u : up_stream) if (u) { (void)hipStreamSynchronize(u); (void)hipStreamDestroy(u); }
 	for (auto &e : up_ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ev_x) if (e) (void)hipEventDestroy(e);
+	if (ev_payload) (void)hipEventDestroy(ev_payload);
 	for (auto &e : attr_ev) if (e) (void)hipEventDestroy(e);
 	for (int g = 1; g < kAttrGroups; ++g) if (attr_stream[g]) { (void)hipStreamSynchronize(attr_stream[g]); (void)hipStreamDestroy(attr_stream[g]); }   // [0] is stream3
 	if (h_stage) (void)hipHostFree(h_stage);

@@ -66,6 +66,7 @@ struct Context {
 	hipStream_t up_stream[kUploadStreams] = {};   // further uploaders of finished spans beside stream2 (unchunk.cpp: SpanUploader; created on first use)
 	hipEvent_t up_ev[kUploadStreams] = {};
 	hipEvent_t ev_x[3] = {};         // cross-stream ordering events (created with stream3)
+	hipEvent_t ev_payload = nullptr; // chunked decode: the attribute streams' part of a large payload is on the device (created with stream3)
 	// chunked decode: the attribute streams are launched in groups by how far into their plane they end (unchunk.cpp); group g
 	// runs on attr_stream[g] and raises attr_ev[g]
 	static constexpr int kAttrGroups = 3;   // (+ the codec's three streams: more streams than hardware queues serialise)

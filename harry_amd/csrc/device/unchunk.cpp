@@ -899,6 +899,13 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		if (ng == 1) kGroupEnd[0] = kGroupEnd[1] = ~0ull;
 		else if (ng == 2) { kGroupEnd[0] = 1u << 17; kGroupEnd[1] = ~0ull; }
 	}
+	// A large payload goes up in two parts: the connectivity streams (the container's first streams) in front of their kernel, the
+	// attribute streams -- nine tenths of it -- while that kernel runs (the copy is from the caller's pageable buffer and keeps this
+	// thread, which has nothing else to do until the connectivity planes are back): 289 MB of the 100 M-triangle mesh were 7.4 ms
+	// in front of everything.  HRY_NO_SPLIT_UPLOAD: one copy as before; HRY_SPLIT_UPLOAD_MIN: from how many bytes (32 MB).
+	const uint64_t conn_bytes = offs[std::min<size_t>(n_conn_streams, nstreams)];
+	static const uint64_t split_min = [] { const char *e = getenv("HRY_SPLIT_UPLOAD_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)32 << 20; }();   // (tests: 1)
+	const bool split_upload = payload_bytes >= split_min && conn_bytes < payload_bytes && !getenv("HRY_NO_SPLIT_UPLOAD");
 	uint32_t group_n[Context::kAttrGroups] = { 0, 0, 0 };
 	// ... and inside a launch the streams a lane can decode (k_chunk_decode_lanes: t0 > 128) come first; lanes_n: how many
 	uint32_t conn_lanes_n = 0, group_lanes_n[Context::kAttrGroups] = { 0, 0, 0 };
@@ -926,7 +933,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		jobs.swap(pj); nbytes.swap(pn); offs.swap(po);
 	}
 	HIP_OK(hipMemcpyAsync(cx.d_init.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice, cx.stream));
-	if (payload_bytes) HIP_OK(hipMemcpyAsync(cx.d_cout.p, payload, payload_bytes, hipMemcpyHostToDevice, cx.stream));
+	if (payload_bytes) HIP_OK(hipMemcpyAsync(cx.d_cout.p, payload, split_upload ? conn_bytes : payload_bytes, hipMemcpyHostToDevice, cx.stream));
 	if (nstreams) {
 		HIP_OK(hipMemcpyAsync(cx.d_cjobs.p, jobs.data(), jobs.size() * sizeof(StreamJob), hipMemcpyHostToDevice, cx.stream));
 		HIP_OK(hipMemcpyAsync(cx.d_csizes.p, nbytes.data(), nbytes.size() * 4, hipMemcpyHostToDevice, cx.stream));
@@ -946,8 +953,9 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		cx.attr_stream[0] = cx.stream3;
 		for (int g = 1; g < Context::kAttrGroups; ++g) HIP_OK(hipStreamCreateWithFlags(&cx.attr_stream[g], hipStreamNonBlocking));
 		for (auto &e : cx.attr_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		HIP_OK(hipEventCreateWithFlags(&cx.ev_payload, hipEventDisableTiming));
 	}
-	HIP_OK(hipEventRecord(cx.ev_x[0], cx.stream));          // payload, jobs and tables are on the device
+	HIP_OK(hipEventRecord(cx.ev_x[0], cx.stream));          // payload (its connectivity part at least), jobs and tables are on the device
 	HIP_OK(hipEventRecord(cx.ev[1], cx.stream));
 	// A launch takes the lane-per-stream kernel for the streams it can where that is the faster of the two (HRY_DECODE_LANES: 0
 	// never, 1 always).  Measured on MI355X: a wavefront alone on its SIMD issues an instruction every ~5.5 cycles, so a lane-per-
@@ -1000,6 +1008,13 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// planes took 20 ms instead of 5, in front of the replay (HRY_CONN_COPY_FIRST=0: the old order)
 	static const bool copy_first = !getenv("HRY_CONN_COPY_FIRST") || atoi(getenv("HRY_CONN_COPY_FIRST")) != 0;
 	hipEvent_t attr_after = side_by_side ? cx.ev_x[0] : copy_first ? cx.ev_x[2] : cx.ev[2];
+	if (split_upload) {   // the rest of the payload, beside the connectivity streams' kernel (on the uploads' stream)
+		cx.ensure_second_stream();
+		HIP_OK(hipMemcpyAsync(cx.d_cout.as<uint8_t>() + conn_bytes, payload + conn_bytes, payload_bytes - conn_bytes, hipMemcpyHostToDevice, cx.stream2));
+		HIP_OK(hipEventRecord(cx.ev_payload, cx.stream2));
+		for (int g = 0; g < Context::kAttrGroups; ++g) HIP_OK(hipStreamWaitEvent(cx.attr_stream[g], cx.ev_payload, 0));
+		HRY_MARK(g_t0, "attribute streams on the device");
+	}
 	HIP_OK(hipStreamWaitEvent(cx.stream3, attr_after, 0));
 	HIP_OK(hipEventRecord(cx.ev[5], cx.stream3));
 	{
