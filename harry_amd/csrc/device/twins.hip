@@ -204,11 +204,11 @@ __global__ __launch_bounds__(256) void k_cc_init(uint32_t *label, uint32_t n)
 // An edge with a twin on both sides is taken from its larger face, a one-sided twin from the side that has it.
 //
 // Round 5, in two passes.  Faces that lie near each other in the arrays mostly ARE neighbours (a file is written patch by patch), so a
-// workgroup first unites its own kHookFaces faces in LDS -- the same lock-free union-find on 16-bit-distance parents, no traffic --
+// workgroup first unites its own kHookFaces faces in LDS -- the same lock-free union-find, no traffic --
 // and writes every face's local root as its label; the second pass takes only the edges that leave a workgroup's faces to the
 // union-find in HBM, where a set now arrives as one root per workgroup instead of face by face.  (One pass over HBM: 19.0 ms for
 // the 78.5 M faces of the configs[3] mesh, its searches and compare-and-swaps all in the L2.)
-constexpr uint32_t kHookFaces = 1024;
+constexpr uint32_t kHookFaces = 16384, kHookThreads = 1024;   // 64 KB of parents in LDS: two workgroups a compute unit
 __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 {
 	uint32_t p = __hip_atomic_load(par + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -219,14 +219,16 @@ __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 	}
 	return x;
 }
-__global__ __launch_bounds__(kHookFaces) void k_cc_hook_local(ConnView cv, uint32_t *label)
+__global__ __launch_bounds__(kHookThreads) void k_cc_hook_local(ConnView cv, uint32_t *label)
 {
 	__shared__ uint32_t par[kHookFaces];
-	const uint32_t base = blockIdx.x * kHookFaces, t = threadIdx.x, f = base + t;
-	par[t] = t;
+	const uint32_t base = blockIdx.x * kHookFaces;
+	for (uint32_t t = threadIdx.x; t < kHookFaces; t += kHookThreads) par[t] = t;
 	__syncthreads();
-	if (f < cv.nf) {
-		Topo tp{ cv };
+	Topo tp{ cv };
+	for (uint32_t t = threadIdx.x; t < kHookFaces; t += kHookThreads) {
+		const uint32_t f = base + t;
+		if (f >= cv.nf) break;
 		const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
 		for (uint32_t h = h0; h < h1; ++h) {
 			const uint32_t o = cv.twin[h];
@@ -246,7 +248,9 @@ __global__ __launch_bounds__(kHookFaces) void k_cc_hook_local(ConnView cv, uint3
 		}
 	}
 	__syncthreads();
-	if (f < cv.nf) {   // (the unions are over: a root read is final)
+	for (uint32_t t = threadIdx.x; t < kHookFaces; t += kHookThreads) {   // (the unions are over: a root read is final)
+		const uint32_t f = base + t;
+		if (f >= cv.nf) break;
 		uint32_t x = t, q = par[x];
 		while (q != x) { x = q; q = par[x]; }
 		label[f] = base + x;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void k_cc_hook(ConnView cv, uint32_t *label)
 	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= cv.nf) return;
 	Topo tp{ cv };
-	const uint32_t base = f & ~(kHookFaces - 1u);
+	const uint32_t base = f - f % kHookFaces;
 	const uint32_t h0 = cv.eface ? cv.foff[f] : f * cv.udeg, h1 = cv.eface ? cv.foff[f + 1] : h0 + cv.udeg;
 	for (uint32_t h = h0; h < h1; ++h) {
 		const uint32_t o = cv.twin[h];
@@ -459,7 +463,7 @@ void launch_components_label(hipStream_t st, const ConnView &cv, const Component
 	if (!cv.nf) return;
 	const unsigned nb = blocks_for(cv.nf, kScanBlock);
 	if (cv.ne) {
-		hipLaunchKernelGGL(k_cc_hook_local, dim3(blocks_for(cv.nf, kHookFaces)), dim3(kHookFaces), 0, st, cv, label);
+		hipLaunchKernelGGL(k_cc_hook_local, dim3(blocks_for(cv.nf, kHookFaces)), dim3(kHookThreads), 0, st, cv, label);
 		hipLaunchKernelGGL(k_cc_hook, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, cv, label);
 	} else hipLaunchKernelGGL(k_cc_init, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
 	hipLaunchKernelGGL(k_cc_flatten, dim3(blocks_for(cv.nf, 256)), dim3(256), 0, st, label, cv.nf);
