@@ -442,11 +442,16 @@ __global__ __launch_bounds__(64) void k_chunk_decode(const StreamJob *jobs, cons
 // Streams whose table starts with t0 <= 128 (planes under 1024 symbols keep the reference's initial counts) stay with
 // k_chunk_decode: the host sorts them behind the others.  About 2.5 vector instructions per symbol instead of 76.
 // ---------------------------------------------------------------------------------------------------------
+// CT: the counts' type in LDS.  uint16_t where every stream of the launch has t0 + n <= 65535 (a count never exceeds the total): 32 KB
+// a wavefront instead of 64, five wavefronts a compute unit instead of two -- the 840 lane-wavefronts of the 100 M-triangle mesh's
+// connectivity streams (and the 830 of its attribute streams) in ONE round instead of two (round 5).  Entry e of lane l at element
+// e * 64 + l either way: two lanes' 16-bit counts share a bank's word, which is a broadcast, not a conflict.
+template <typename CT>
 __global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs, uint32_t njobs, const uint32_t *inits, const MagicEnt *magic,
                                                            const uint8_t *payload, const unsigned long long *offsets, const uint32_t *nbytes)
 {
 	extern __shared__ uint32_t lds_tab[];
-	uint32_t *const cnt = lds_tab;               // [256][64]
+	CT *const cnt = (CT*)lds_tab;                // [256][64]
 	const uint32_t lane = threadIdx.x;
 	const uint32_t j = blockIdx.x * 64 + lane;
 	const bool have = j < njobs;
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				const uint32_t c = have ? st[b * 16 + k] : 0u;
-				cnt[(b * 16 + k) * 64 + lane] = c;
+				cnt[(b * 16 + k) * 64 + lane] = (CT)c;
 				sum += c;
 			}
 			C[b] = sum;
@@ -521,11 +526,11 @@ __global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs
 		}
 		// the symbol inside the block (target < t = the sum of all counts, so the block exists): the counts before it that fit,
 		// and the first running sum that does not (its difference to the last one that does is the symbol's count)
-		const uint32_t *cb = cnt + (size_t)(b * 16u) * 64 + lane;
+		const CT *cb = cnt + (size_t)(b * 16u) * 64 + lane;
 		uint32_t sin = 0, run = lo, hi = 0xffffffffu;
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
-			run += cb[k * 64];
+			run += (uint32_t)cb[k * 64];
 			const bool le = run <= target;
 			sin += le ? 1u : 0u;
 			lo = le ? run : lo;
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(64) void k_chunk_decode_lanes(const StreamJob *jobs
 		buf <<= sh; avail -= sh;
 		D = ((D - rl) << sh) | bits;
 		// stat_adaptive.h:77-82
-		cnt[s * 64 + lane] = cs + 1u;
+		cnt[s * 64 + lane] = (CT)(cs + 1u);
 #pragma unroll
 		for (int k = 0; k < 16; ++k) C[k] += (uint32_t)k >= b ? 1u : 0u;
 		++t;
@@ -685,12 +690,13 @@ void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstream
 {
 	if (nstreams) hipLaunchKernelGGL(k_chunk_decode, dim3(nstreams), dim3(64), 0, st, jobs, inits, magic, payload, (const unsigned long long*)offsets, nbytes, (uint8_t*)nullptr);
 }
-// a lane per stream (every job: t0 > 128): 64 streams per workgroup, 64 KB of counts in LDS
-void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
-                               const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes)
+// a lane per stream (every job: t0 > 128): 64 streams per workgroup, 64 KB of counts in LDS -- 32 KB with 16-bit counts
+// (counts16: the caller has checked t0 + n <= 65535 for every stream of the launch)
+template <typename CT>
+static void launch_chunk_decode_lanes_as(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
+                                         const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes)
 {
-	if (!nstreams) return;
-	constexpr uint32_t kLds = 256 * 64 * 4;
+	constexpr uint32_t kLds = 256 * 64 * sizeof(CT);
 	// the dynamic LDS limit is a property of the function ON A DEVICE: raised once for every device a launch goes to (N contexts
 	// on N devices in one process: hry_decode_sharded), on the device that is current -- the stream's
 	static std::mutex mu;
@@ -700,15 +706,22 @@ void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t n
 	{
 		std::lock_guard<std::mutex> g(mu);
 		if (!raised[dev]) {
-			if (hipFuncSetAttribute((const void*)k_chunk_decode_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess) {
+			if (hipFuncSetAttribute((const void*)k_chunk_decode_lanes<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess) {
 				(void)hipGetLastError();
-				throw std::runtime_error("k_chunk_decode_lanes: the device refuses 64 KB of dynamic LDS");
+				throw std::runtime_error("k_chunk_decode_lanes: the device refuses its dynamic LDS");
 			}
 			raised[dev] = true;
 		}
 	}
-	hipLaunchKernelGGL(k_chunk_decode_lanes, dim3((nstreams + 63) / 64), dim3(64), kLds, st, jobs, nstreams, inits, magic, payload, (const unsigned long long*)offsets, nbytes);
+	hipLaunchKernelGGL(k_chunk_decode_lanes<CT>, dim3((nstreams + 63) / 64), dim3(64), kLds, st, jobs, nstreams, inits, magic, payload, (const unsigned long long*)offsets, nbytes);
 	if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_chunk_decode_lanes: launch failed");
+}
+void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
+                               const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes, bool counts16)
+{
+	if (!nstreams) return;
+	if (counts16) launch_chunk_decode_lanes_as<uint16_t>(st, jobs, nstreams, inits, magic, payload, offsets, nbytes);
+	else launch_chunk_decode_lanes_as<uint32_t>(st, jobs, nstreams, inits, magic, payload, offsets, nbytes);
 }
 
 }   // namespace dev

@@ -80,7 +80,7 @@ void launch_scatter_u8(hipStream_t st, const uint8_t *src, const uint32_t *dst_i
 void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
                          const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes);
 void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
-                               const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes);   // one lane per stream; every job with t0 > 128
+                               const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes, bool counts16);   // one lane per stream; every job with t0 > 128 (counts16: and t0 + n <= 65535)
 
 }   // namespace dev
 }   // namespace hry

@@ -966,18 +966,22 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	static const int lanes_mode = [] { const char *e = getenv("HRY_DECODE_LANES"); return e ? atoi(e) : -1; }();
 	auto decode_streams = [&](hipStream_t st, uint32_t first, uint32_t n, uint32_t n_for_lanes) {
 		bool lanes = lanes_mode > 0;
+		// (16-bit counts where no stream's total passes 65535: 32 KB a lane-wave, five of them a compute unit; HRY_DECODE_COUNTS32: never)
+		static const bool wide_only = getenv("HRY_DECODE_COUNTS32") != nullptr;
+		bool counts16 = !wide_only;
+		for (uint32_t j = first; j < first + n_for_lanes && counts16; ++j) counts16 = (uint64_t)jobs[j].t0 + jobs[j].n <= 65535u;
 		if (lanes_mode < 0 && n_for_lanes >= 256u) {
 			uint64_t total = 0, longest = 0;
 			for (uint32_t j = first; j < first + n_for_lanes; ++j) { total += jobs[j].n; longest = std::max<uint64_t>(longest, jobs[j].n); }
 			const double simds = 1024.0, lane_waves = (n_for_lanes + 63) / 64;
-			const double lane_slots = 512.0;   // 64 KB of counts per lane-wave: two of them in a compute unit's 160 KB of LDS
+			const double lane_slots = counts16 ? 1280.0 : 512.0;   // 64 KB of counts per lane-wave: two of them in a compute unit's 160 KB of LDS (32 KB: five)
 			const double t_waves = std::max((double)longest * 420.0, (double)total * 190.0 / simds);
 			const double t_lanes = (double)longest * 1900.0 * std::ceil(lane_waves / lane_slots);
 			lanes = t_lanes < t_waves;
 		}
 		const uint32_t nl = lanes ? n_for_lanes : 0u;
 		if (nl) launch_chunk_decode_lanes(st, cx.d_cjobs.as<StreamJob>() + first, nl, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
-		                                  cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first);
+		                                  cx.d_coffs.as<uint64_t>() + first, cx.d_csizes.as<uint32_t>() + first, counts16);
 		if (n > nl) launch_chunk_decode(st, cx.d_cjobs.as<StreamJob>() + first + nl, n - nl, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_cout.as<uint8_t>(),
 		                                cx.d_coffs.as<uint64_t>() + first + nl, cx.d_csizes.as<uint32_t>() + first + nl);
 	};

@@ -24,7 +24,7 @@ def _run(tool, args, env):
 @pytest.mark.parametrize("seed", list(range(1, 17)))
 def test_random_meshes_against_the_oracle(seed):
     env = dict(os.environ)
-    for k in ("HRY_NO_PIPELINE", "HRY_PIPELINE_MIN_VERTICES", "HRY_PIPELINE_FACES", "HRY_PIPELINE_SLICE", "HRY_CHAIN_WAVES", "STRESS_LOSSLESS", "STRESS_BIG", "STRESS_SLIVERS", "HRY_DEVICE_ANALYSIS_MIN_FACES", "HRY_PARALLEL_MIN_FACES", "HRY_ENCODE_PIPELINE_BATCH", "HRY_NO_ENCODE_PIPELINE", "HRY_STAGED_FETCH_MIN", "HRY_STAGED_FETCH_SLOT", "HRY_SPLIT_UPLOAD_MIN"):
+    for k in ("HRY_NO_PIPELINE", "HRY_PIPELINE_MIN_VERTICES", "HRY_PIPELINE_FACES", "HRY_PIPELINE_SLICE", "HRY_CHAIN_WAVES", "STRESS_LOSSLESS", "STRESS_BIG", "STRESS_SLIVERS", "HRY_DEVICE_ANALYSIS_MIN_FACES", "HRY_PARALLEL_MIN_FACES", "HRY_ENCODE_PIPELINE_BATCH", "HRY_NO_ENCODE_PIPELINE", "HRY_STAGED_FETCH_MIN", "HRY_STAGED_FETCH_SLOT", "HRY_SPLIT_UPLOAD_MIN", "HRY_DECODE_LANES", "HRY_DECODE_COUNTS32"):
         env.pop(k, None)
     if WAVES[seed % len(WAVES)]:
         env["HRY_CHAIN_WAVES"] = WAVES[seed % len(WAVES)]
@@ -40,6 +40,10 @@ def test_random_meshes_against_the_oracle(seed):
             env["HRY_STAGED_FETCH_MIN"] = "1"        # ... and every container fetched through the ring of pinned slots (8 KiB each: many rounds)
             env["HRY_STAGED_FETCH_SLOT"] = "8192"
             env["HRY_SPLIT_UPLOAD_MIN"] = "1"        # ... and every payload up in two parts, the attribute streams' beside the connectivity kernel
+    if seed in (2, 9, 11):
+        env["HRY_DECODE_LANES"] = "1"    # every stream a lane can decode goes to k_chunk_decode_lanes (16-bit counts in LDS) ...
+        if seed == 9:
+            env["HRY_DECODE_COUNTS32"] = "1"   # ... or its 32-bit form
     if seed in (5, 11):
         env["STRESS_BIG"] = "1"          # some meshes large enough for the pipelined decode with its production parameters
     r = _run("chain_stress.py", ["40", str(100 + seed)], env)
