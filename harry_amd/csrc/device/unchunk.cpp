@@ -1007,7 +1007,11 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	// ... unless the mesh takes the pipelined decode (one large component, triangles replayed at ~6 ns each): there the device
 	// chain, not the replay, ends the decode, and it can start only when the attribute streams are done -- side by side then
 	const bool chain_bound = !m->general && restarts.empty() && nsym[7] == 0 && vc == m->nv && unpredict3_covers(ldv);
-	const bool side_by_side = getenv("HRY_ATTR_SIDE_BY_SIDE") ? atoi(getenv("HRY_ATTR_SIDE_BY_SIDE")) != 0 : chain_bound;
+	// (round 5: not by default there either -- beside the attribute waves the 28 M-triangle torus' 30 MB of connectivity planes came
+	// down in 7.4 ms instead of 1.5, in front of the replay, and its chain waits for the replay most of the time: decode 213 -> 206 ms,
+	// the 1 M-triangle torus the same either way; HRY_ATTR_SIDE_BY_SIDE=1: the old order)
+	(void)chain_bound;
+	const bool side_by_side = getenv("HRY_ATTR_SIDE_BY_SIDE") ? atoi(getenv("HRY_ATTR_SIDE_BY_SIDE")) != 0 : false;
 	// ... and for the planes' copy to the host: beside 10^5 attribute waves the copy of the configs[3] mesh's 110 MB of connectivity
 	// planes took 20 ms instead of 5, in front of the replay (HRY_CONN_COPY_FIRST=0: the old order)
 	static const bool copy_first = !getenv("HRY_CONN_COPY_FIRST") || atoi(getenv("HRY_CONN_COPY_FIRST")) != 0;
