@@ -311,7 +311,7 @@ def test_pipelined_decode_after_another_mesh(cx, monkeypatch):
 
 # ---- the component analysis on the device (analysis.cpp) against the host's (cbm_walk.cpp: analyse_components) ----------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["multi", "multi_tri", "slivers", "slivers_quad", "shuffled", "one", "hub"])
+@pytest.mark.parametrize("case", ["multi", "multi_tri", "slivers", "slivers_quad", "shuffled", "one", "hub", "big", "big_shuffled", "big_one"])
 def test_device_component_analysis_equals_the_hosts(cx, case):
     """connected components (one-sided twins and non-manifold slivers included), coding order by the reference's start-face sequence,
     faces / half-edges / new vertices per component, face and vertex intervals, groups of components that share a vertex"""
@@ -330,6 +330,17 @@ def test_device_component_analysis_equals_the_hosts(cx, case):
         perm = rng.permutation(b.nf)
         idx = np.concatenate([b.indices[offs[f]:offs[f + 1]] for f in perm])
         g = mg.Mesh(b.verts, b.degrees[perm], idx.astype(np.uint32), None)
+    elif case in ("big", "big_shuffled"):   # more faces than a workgroup labels in LDS (16 384): edges that leave a workgroup's faces go to the union-find in HBM
+        b = mg.with_nonmanifold(mg.multi_component(28, 44, 41, seed=9, polys="mixed"), 200, 90, seed=5)
+        if case == "big":
+            g = b
+        else:               # ... nearly all of them, with the faces in random order
+            deg = b.degrees.astype(np.int64); offs = np.concatenate(([0], np.cumsum(deg)))
+            perm = rng.permutation(b.nf)
+            idx = np.concatenate([b.indices[offs[f]:offs[f + 1]] for f in perm])
+            g = mg.Mesh(b.verts, b.degrees[perm], idx.astype(np.uint32), None)
+    elif case == "big_one":
+        g = mg.torus(210, 190, polys="mixed")
     elif case == "one":
         g = mg.torus(30, 40, polys="mixed")
     else:   # many components that all touch ONE vertex (a hub): one group
