@@ -92,7 +92,7 @@ struct Context {
 	uint64_t gen_token = 0;          // the mesh whose binding tables (d_vreg .. d_cattr) are in HBM (general.cpp: upload_general)
 	uint64_t next_token = 1;
 	DevBuf d_rec[kMaxLists], d_org, d_twin, d_foff, d_eface;
-	DevBuf d_vreg, d_freg, d_vattr, d_cattr, d_gen;   // general bindings (general.cpp): region and record tables, event arena
+	DevBuf d_vreg, d_freg, d_vattr, d_cattr, d_fattr, d_gen;   // general bindings (general.cpp): region and record tables, event arena
 	uint32_t res_nv = 0, res_nf = 0, res_ne = 0, res_udeg = 0;
 	bool res_has_eface = false;
 

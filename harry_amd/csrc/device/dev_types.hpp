@@ -30,6 +30,14 @@ struct GenView {
 	const uint32_t *vtx_attr, *corner_attr;
 	int32_t nb_vtx, nb_corner;
 };
+// which lists a region binds at its slots (Bindings: off_* / reg_*: region r's slots are [off[r], off[r + 1])), and the faces' own
+// records -- what the device needs beside GenView to say which record every element names (events.hip)
+struct EvRegions {
+	const int32_t *off_face, *off_vtx, *off_corner;
+	const uint16_t *face_lists, *vtx_lists, *corner_lists;
+	const uint32_t *face_attr;
+	int32_t nb_face;
+};
 
 // per-symbol record consumed by the serial range recurrence (16 bytes, one dwordx4 per lane)
 struct alignas(16) SymRec {

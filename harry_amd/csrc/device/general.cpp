@@ -103,6 +103,7 @@ void upload_general(Context &cx, Mesh &m)
 	put(cx.d_freg, b.face_reg.data(), b.face_reg.size() * 2);
 	put(cx.d_vattr, b.vtx_attr.data(), b.vtx_attr.size() * 4);
 	put(cx.d_cattr, b.corner_attr.data(), b.corner_attr.size() * 4);
+	put(cx.d_fattr, b.face_attr.data(), b.face_attr.size() * 4);
 	HIP_OK(hipStreamSynchronize(cx.stream));
 	cx.gen_token = m.device_token;
 }
@@ -490,68 +491,169 @@ std::vector<GenPlane> general_plane_layout(const Mesh &m)
 	return p;
 }
 
+// The planes of a mesh with general bindings in the parallel container: which record every element names -- on the device
+// (events.hip; HRY_HOST_EVENTS: the host's loop and an arena of its arrays, as until round 5) -- and the residuals of the records
+// coded as data (general.hip).  Per list: kinds (one byte a reference), four planes of creation-order distances, two of per-vertex
+// distances at corner lists, the data planes.
 void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vector<PlaneRef> &planes)
 {
-	Events E;
-	const auto t_events = Clock::now();
-	collect_events(m, w, 0, false, E);
-	cx.timing.host_walk_ms += ms_since(t_events);   // (host bookkeeping along the coding order, like the walk: it was missing from the record)
-	if (getenv("HRY_TRACE")) fprintf(stderr, "[hry enc] %8.3f ms  which record every element names (host)\n", ms_since(t_events));
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
-	Arena A;
-	struct At { size_t type_sym, gh_vals, gh, lh_vals, lh, d_idx, d_he, d_slot, planes; };
-	std::vector<At> at(m.lists.size());
-	for (size_t l = 0; l < m.lists.size(); ++l) {
-		const ListStream &S = E.ls[l];
-		At &T = at[l];
-		T.type_sym = A.add(S.type_sym);
-		T.gh_vals = A.add(S.gh_val); T.lh_vals = A.add(S.lh_val);   // (32-bit values: split into byte planes on the device)
-		T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
+	const size_t nl = m.lists.size();
+	struct Lst { uint32_t nt = 0, ng = 0, nlh = 0, nd = 0, nbytes = 0; const uint8_t *type_sym = nullptr, *d_slot = nullptr; const uint32_t *gh_vals = nullptr, *lh_vals = nullptr, *d_idx = nullptr, *d_he = nullptr;
+	             uint8_t *gh = nullptr, *lh = nullptr, *data = nullptr; };
+	std::vector<Lst> ls(nl);
+	const uint8_t *rv = nullptr, *rf = nullptr;
+	uint32_t n_rv = 0, n_rf = 0;
+	ConnView cv = cx.conn_view();
+	const GenView gv = gen_view(cx, m);
+	const Bindings &b = m.bind;
+	static const bool host_events = getenv("HRY_HOST_EVENTS") != nullptr;
+	Events E;   // (the host's arrays live until the arena has been copied into pinned memory: Arena::send)
+	if (host_events) {
+		const auto t_events = Clock::now();
+		collect_events(m, w, 0, false, E);
+		cx.timing.host_walk_ms += ms_since(t_events);   // (host bookkeeping along the coding order, like the walk: it was missing from the record)
+		if (getenv("HRY_TRACE")) fprintf(stderr, "[hry enc] %8.3f ms  which record every element names (host)\n", ms_since(t_events));
+		Arena A;
+		struct At { size_t type_sym, gh_vals, gh, lh_vals, lh, d_idx, d_he, d_slot, planes; };
+		std::vector<At> at(nl);
+		for (size_t l = 0; l < nl; ++l) {
+			const ListStream &S = E.ls[l];
+			At &T = at[l];
+			T.type_sym = A.add(S.type_sym);
+			T.gh_vals = A.add(S.gh_val); T.lh_vals = A.add(S.lh_val);   // (32-bit values: split into byte planes on the device)
+			T.d_idx = A.add(S.d_idx); T.d_he = A.add(S.d_he); T.d_slot = A.add(S.d_slot);
+		}
+		const size_t rv_at = A.add(E.rv_sym), rf_at = A.add(E.rf_sym);
+		size_t arena_bytes = (A.bytes + 15) & ~(size_t)15;
+		for (size_t l = 0; l < nl; ++l) {
+			at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_idx.size() * E.ls[l].nbytes + 15) & ~(size_t)15;
+			at[l].gh = arena_bytes; arena_bytes += (E.ls[l].gh_val.size() * 4 + 15) & ~(size_t)15;
+			at[l].lh = arena_bytes; arena_bytes += (E.ls[l].lh_val.size() * 2 + 15) & ~(size_t)15;
+		}
+		cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
+		A.send(cx, cx.d_gen.p);
+		uint8_t *arena = cx.d_gen.as<uint8_t>();
+		for (size_t l = 0; l < nl; ++l) {
+			const ListStream &S = E.ls[l];
+			Lst &L = ls[l];
+			L.nt = (uint32_t)S.type_sym.size(); L.ng = (uint32_t)S.gh_val.size(); L.nlh = (uint32_t)S.lh_val.size(); L.nd = (uint32_t)S.d_idx.size(); L.nbytes = S.nbytes;
+			L.type_sym = arena + at[l].type_sym; L.gh_vals = (const uint32_t*)(arena + at[l].gh_vals); L.lh_vals = (const uint32_t*)(arena + at[l].lh_vals);
+			L.d_idx = (const uint32_t*)(arena + at[l].d_idx); L.d_he = (const uint32_t*)(arena + at[l].d_he); L.d_slot = arena + at[l].d_slot;
+			L.gh = arena + at[l].gh; L.lh = arena + at[l].lh; L.data = arena + at[l].planes;
+		}
+		rv = arena + rv_at; rf = arena + rf_at; n_rv = (uint32_t)E.rv_sym.size(); n_rf = (uint32_t)E.rf_sym.size();
+	} else {
+		// ---- on the device.  Most references a list can get, without a pass over the orders: every coded element at every slot
+		// of the region with the most slots for it (corner lists: every half-edge)
+		std::vector<uint32_t> max_refs(nl, 0);
+		for (size_t l = 0; l < nl; ++l) {
+			const int tg = m.lists[l].target;
+			if (tg == 3) continue;
+			const int nreg = tg == 1 ? b.nregs_vtx() : b.nregs_face();
+			uint32_t most = 0;
+			for (int r = 0; r < nreg; ++r) {
+				uint32_t c = 0;
+				const int na = tg == 1 ? b.nvtxlists(r) : tg == 0 ? b.nfacelists(r) : b.ncornerlists(r);
+				for (int a = 0; a < na; ++a) c += (uint32_t)(tg == 1 ? b.vtxlist(r, a) : tg == 0 ? b.facelist(r, a) : b.cornerlist(r, a)) == (uint32_t)l;
+				most = std::max(most, c);
+			}
+			const uint64_t elems = tg == 1 ? vc : tg == 0 ? fc : m.ne();
+			if (elems * most >= (1ull << 31)) throw Error(HRY_E_UNSUPPORTED, "more than 2^31 references to one list");
+			max_refs[l] = (uint32_t)(elems * most);
+		}
+		// the regions' tables (a few words) through the context's pinned block
+		Arena A;
+		std::vector<int32_t> off_f(b.off_facelist.begin(), b.off_facelist.end()), off_v(b.off_vtxlist.begin(), b.off_vtxlist.end()), off_c(b.off_cornerlist.begin(), b.off_cornerlist.end());
+		const size_t a_off_f = A.add(off_f), a_off_v = A.add(off_v), a_off_c = A.add(off_c);
+		const size_t a_lf = A.add(b.reg_facelist), a_lv = A.add(b.reg_vtxlist), a_lc = A.add(b.reg_cornerlist);
+		size_t bytes = (A.bytes + 15) & ~(size_t)15;
+		auto take = [&](size_t n) { const size_t at = bytes; bytes += (n + 15) & ~(size_t)15; return at; };
+		struct At { size_t type_sym, gh_vals, lh_vals, d_idx, d_he, d_slot, gh, lh, planes, ws; };
+		std::vector<At> at(nl);
+		// (the vertices' names at the corner slots are shared by the corner lists: at most every half-edge at every corner slot)
+		uint32_t most_corner_slots = 0;
+		bool any_corner = false;
+		for (int r = 0; r < b.nregs_face(); ++r) most_corner_slots = std::max(most_corner_slots, (uint32_t)b.ncornerlists(r));
+		for (size_t l = 0; l < nl; ++l) any_corner |= m.lists[l].target == 2 && max_refs[l] != 0;
+		if ((uint64_t)m.ne() * most_corner_slots >= (1ull << 31) || (uint64_t)b.nb_corner * m.nv >= (1ull << 31)) throw Error(HRY_E_UNSUPPORTED, "more than 2^31 corner references");
+		const uint32_t corner_refs_max = any_corner ? m.ne() * most_corner_slots : 0u, head_words = any_corner ? (uint32_t)b.nb_corner * m.nv : 0u;
+		for (size_t l = 0; l < nl; ++l) {
+			const size_t r = max_refs[l];
+			const uint32_t n_order = m.lists[l].target == 1 ? vc : fc;
+			ls[l].nbytes = (uint32_t)m.lists[l].coded_bytes();
+			at[l].type_sym = take(r); at[l].gh_vals = take(r * 4); at[l].lh_vals = take(m.lists[l].target == 2 ? r * 4 : 0);
+			at[l].d_idx = take(r * 4); at[l].d_he = take(r * 4); at[l].d_slot = take(r);
+			at[l].gh = take(r * 4); at[l].lh = take(m.lists[l].target == 2 ? r * 2 : 0); at[l].planes = take(r * ls[l].nbytes);
+			at[l].ws = take(r ? dev::events_list_workspace_bytes(n_order, (uint32_t)r, m.lists[l].count) : 0);
+		}
+		const size_t a_counts = take((nl * 4 + 4) * 4), a_rv = take(vc), a_rf = take(fc), a_names = take(dev::events_names_workspace_bytes(fc, corner_refs_max, head_words));
+		cx.d_gen.ensure(std::max<size_t>(bytes, 16));
+		A.send(cx, cx.d_gen.p);
+		uint8_t *arena = cx.d_gen.as<uint8_t>();
+		EvRegions rg{ (const int32_t*)(arena + a_off_f), (const int32_t*)(arena + a_off_v), (const int32_t*)(arena + a_off_c),
+		              (const uint16_t*)(arena + a_lf), (const uint16_t*)(arena + a_lv), (const uint16_t*)(arena + a_lc), cx.d_fattr.as<uint32_t>(), b.nb_face };
+		uint32_t *d_counts = (uint32_t*)(arena + a_counts), *d_err = d_counts + nl * 4;
+		HIP_OK(hipMemsetAsync(d_err, 0, 16, cx.stream));
+		if (any_corner) dev::launch_corner_places(cx.stream, cv, gv, rg, cx.d_order_f.as<uint32_t>(), fc, corner_refs_max, head_words, m.nv, arena + a_names);
+		for (int phase = 0; phase < 2; ++phase)
+			for (size_t l = 0; l < nl; ++l) {
+				const int tg = m.lists[l].target;
+				if (tg == 3) { if (!phase) HIP_OK(hipMemsetAsync(d_counts + 4 * l, 0, 16, cx.stream)); continue; }
+				const uint32_t *order = tg == 1 ? cx.d_order_v.as<uint32_t>() : cx.d_order_f.as<uint32_t>();
+				const uint32_t n_order = tg == 1 ? vc : fc;
+				if (!phase) dev::launch_list_refs(cx.stream, tg, (uint32_t)l, m.lists[l].count, cv, gv, rg, order, n_order, max_refs[l], m.nv, fc, corner_refs_max, head_words, arena + a_names,
+				                                  arena + at[l].ws, d_counts + 4 * l, d_err);
+				else dev::launch_list_kinds(cx.stream, tg, m.lists[l].count, cv, n_order, max_refs[l], m.nv, fc, corner_refs_max, head_words, arena + a_names, arena + at[l].ws, arena + at[l].type_sym,
+				                            (uint32_t*)(arena + at[l].gh_vals), (uint32_t*)(arena + at[l].lh_vals), (uint32_t*)(arena + at[l].d_idx), (uint32_t*)(arena + at[l].d_he),
+				                            arena + at[l].d_slot, d_counts + 4 * l, d_err);
+			}
+		if (b.nregs_vtx() > 1) { dev::launch_region_symbols(cx.stream, 1, cv, gv, cx.d_order_v.as<uint32_t>(), vc, arena + a_rv); rv = arena + a_rv; n_rv = vc; }
+		if (b.nregs_face() > 1) { dev::launch_region_symbols(cx.stream, 0, cv, gv, cx.d_order_f.as<uint32_t>(), fc, arena + a_rf); rf = arena + a_rf; n_rf = fc; }
+		// how many of every kind: the one thing the host needs (the planes' lengths)
+		cx.h_small.ensure(std::max<size_t>((nl * 4 + 4) * 4, 4096));
+		uint32_t *h_counts = cx.h_small.as<uint32_t>();
+		HIP_OK(hipMemcpyAsync(h_counts, d_counts, (nl * 4 + 4) * 4, hipMemcpyDeviceToHost, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		const uint32_t err = h_counts[nl * 4];
+		if (err & 1u) throw Error(HRY_E_ARG, "an element names a record outside its list");
+		if (err & 2u) throw Error(HRY_E_UNSUPPORTED, "more than 65536 different records of one list at one vertex (io.h:104 codes 16 bits)");
+		for (size_t l = 0; l < nl; ++l) {
+			Lst &L = ls[l];
+			L.nt = h_counts[4 * l]; L.ng = h_counts[4 * l + 1]; L.nlh = h_counts[4 * l + 2]; L.nd = h_counts[4 * l + 3];
+			if (L.nt > max_refs[l] || (uint64_t)L.ng + L.nlh + L.nd != L.nt) throw Error(HRY_E_INTERNAL, "references on the device: the kinds do not add up");
+			L.type_sym = arena + at[l].type_sym; L.gh_vals = (const uint32_t*)(arena + at[l].gh_vals); L.lh_vals = (const uint32_t*)(arena + at[l].lh_vals);
+			L.d_idx = (const uint32_t*)(arena + at[l].d_idx); L.d_he = (const uint32_t*)(arena + at[l].d_he); L.d_slot = arena + at[l].d_slot;
+			L.gh = arena + at[l].gh; L.lh = arena + at[l].lh; L.data = arena + at[l].planes;
+		}
 	}
-	const size_t rv = A.add(E.rv_sym), rf = A.add(E.rf_sym);
-	size_t arena_bytes = (A.bytes + 15) & ~(size_t)15;
-	for (size_t l = 0; l < m.lists.size(); ++l) {
-		at[l].planes = arena_bytes; arena_bytes += ((size_t)E.ls[l].d_idx.size() * E.ls[l].nbytes + 15) & ~(size_t)15;
-		at[l].gh = arena_bytes; arena_bytes += (E.ls[l].gh_val.size() * 4 + 15) & ~(size_t)15;
-		at[l].lh = arena_bytes; arena_bytes += (E.ls[l].lh_val.size() * 2 + 15) & ~(size_t)15;
-	}
-	cx.d_gen.ensure(std::max<size_t>(arena_bytes, 16));
-	A.send(cx, cx.d_gen.p);
-	uint8_t *arena = cx.d_gen.as<uint8_t>();
-	for (size_t l = 0; l < m.lists.size(); ++l) {
-		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].gh_vals), (uint32_t)E.ls[l].gh_val.size(), 4, arena + at[l].gh);
-		launch_split_bytes(cx.stream, (const uint32_t*)(arena + at[l].lh_vals), (uint32_t)E.ls[l].lh_val.size(), 2, arena + at[l].lh);
+	for (size_t l = 0; l < nl; ++l) {
+		launch_split_bytes(cx.stream, ls[l].gh_vals, ls[l].ng, 4, ls[l].gh);
+		launch_split_bytes(cx.stream, ls[l].lh_vals, ls[l].nlh, 2, ls[l].lh);
 	}
 	cx.d_rank.ensure(std::max<size_t>((size_t)m.nv * 4 + (size_t)m.nf * 4, 16));
 	uint32_t *d_rank = cx.d_rank.as<uint32_t>(), *d_frank = d_rank + m.nv;
-	ConnView cv = cx.conn_view();
-	const GenView gv = gen_view(cx, m);
 	HIP_OK(hipMemsetAsync(d_rank, 0xff, (size_t)m.nv * 4, cx.stream));
 	launch_rank(cx.stream, cx.d_order_v.as<uint32_t>(), vc, cv.org, d_rank);
 	launch_face_rank(cx.stream, cv, cx.d_order_f.as<uint32_t>(), fc, d_frank);
-	for (size_t l = 0; l < m.lists.size(); ++l) {
-		const ListStream &S = E.ls[l];
-		const At &T = at[l];
-		const uint32_t nd = (uint32_t)S.d_idx.size();
-		if (!nd || !S.nbytes) continue;
+	for (size_t l = 0; l < nl; ++l) {
+		const Lst &L = ls[l];
+		if (!L.nd || !L.nbytes) continue;
 		const ListDesc ld = make_list_desc(m.lists[l]);
-		const uint32_t *he = (const uint32_t*)(arena + T.d_he), *idx = (const uint32_t*)(arena + T.d_idx);
-		const uint8_t *slot = arena + T.d_slot;
 		const uint8_t *rec = cx.d_rec[l].as<uint8_t>();
-		if (m.lists[l].target == 1) launch_gen_vtx_resid(cx.stream, cv, gv, d_rank, he, slot, idx, nd, rec, ld, arena + T.planes);
-		else if (m.lists[l].target == 2) launch_gen_corner_resid(cx.stream, cv, gv, d_frank, he, slot, idx, nd, rec, ld, arena + T.planes);
-		else launch_gen_face_resid(cx.stream, idx, nd, rec, ld, arena + T.planes);
+		if (m.lists[l].target == 1) launch_gen_vtx_resid(cx.stream, cv, gv, d_rank, L.d_he, L.d_slot, L.d_idx, L.nd, rec, ld, L.data);
+		else if (m.lists[l].target == 2) launch_gen_corner_resid(cx.stream, cv, gv, d_frank, L.d_he, L.d_slot, L.d_idx, L.nd, rec, ld, L.data);
+		else launch_gen_face_resid(cx.stream, L.d_idx, L.nd, rec, ld, L.data);
 	}
 	for (const GenPlane &g : general_plane_layout(m)) {
-		const ListStream *S = g.list >= 0 ? &E.ls[g.list] : nullptr;
-		const At *T = g.list >= 0 ? &at[g.list] : nullptr;
+		const Lst *L = g.list >= 0 ? &ls[g.list] : nullptr;
 		switch (g.what) {
-		case GP_REGV: planes.push_back(PlaneRef{ arena + rv, (uint32_t)E.rv_sym.size(), g.init }); break;
-		case GP_REGF: planes.push_back(PlaneRef{ arena + rf, (uint32_t)E.rf_sym.size(), g.init }); break;
-		case GP_TYPE: planes.push_back(PlaneRef{ arena + T->type_sym, (uint32_t)S->type_sym.size(), g.init }); break;
-		case GP_GHIST: planes.push_back(PlaneRef{ arena + T->gh + (size_t)g.byte * S->gh_val.size(), (uint32_t)S->gh_val.size(), g.init }); break;
-		case GP_LHIST: planes.push_back(PlaneRef{ arena + T->lh + (size_t)g.byte * S->lh_val.size(), (uint32_t)S->lh_val.size(), g.init }); break;
-		default: planes.push_back(PlaneRef{ arena + T->planes + (size_t)g.byte * S->d_idx.size(), (uint32_t)S->d_idx.size(), g.init }); break;
+		case GP_REGV: planes.push_back(PlaneRef{ rv, n_rv, g.init }); break;
+		case GP_REGF: planes.push_back(PlaneRef{ rf, n_rf, g.init }); break;
+		case GP_TYPE: planes.push_back(PlaneRef{ L->type_sym, L->nt, g.init }); break;
+		case GP_GHIST: planes.push_back(PlaneRef{ L->gh + (size_t)g.byte * L->ng, L->ng, g.init }); break;
+		case GP_LHIST: planes.push_back(PlaneRef{ L->lh + (size_t)g.byte * L->nlh, L->nlh, g.init }); break;
+		default: planes.push_back(PlaneRef{ L->data + (size_t)g.byte * L->nd, L->nd, g.init }); break;
 		}
 	}
 }

@@ -82,5 +82,18 @@ void launch_chunk_decode(hipStream_t st, const StreamJob *jobs, uint32_t nstream
 void launch_chunk_decode_lanes(hipStream_t st, const StreamJob *jobs, uint32_t nstreams, const uint32_t *inits, const MagicEnt *magic,
                                const uint8_t *payload, const uint64_t *offsets, const uint32_t *nbytes, bool counts16);   // one lane per stream; every job with t0 > 128 (counts16: and t0 + n <= 65535)
 
+// events.hip: which record every element names, per list, on the device (the host's loop: host/general_events.cpp)
+size_t events_list_workspace_bytes(uint32_t n_order, uint32_t max_refs, uint32_t list_count);
+size_t events_names_workspace_bytes(uint32_t fc, uint32_t corner_refs_max, uint32_t head_words);
+void launch_corner_places(hipStream_t st, const ConnView &cv, const GenView &gv, const EvRegions &rg, const uint32_t *order_f, uint32_t fc, uint32_t corner_refs_max,
+                          uint32_t head_words, uint32_t nv, void *names_ws);
+void launch_list_refs(hipStream_t st, int kind, uint32_t list, uint32_t list_count, const ConnView &cv, const GenView &gv, const EvRegions &rg,
+                      const uint32_t *order, uint32_t n_order, uint32_t max_refs, uint32_t nv, uint32_t fc, uint32_t corner_refs_max, uint32_t head_words, void *names_ws, void *list_ws,
+                      uint32_t *counts, uint32_t *err);
+void launch_list_kinds(hipStream_t st, int kind, uint32_t list_count, const ConnView &cv, uint32_t n_order, uint32_t max_refs, uint32_t nv, uint32_t fc, uint32_t corner_refs_max,
+                       uint32_t head_words, void *names_ws, void *list_ws, uint8_t *type_sym, uint32_t *gh_val, uint32_t *lh_val, uint32_t *d_idx, uint32_t *d_he, uint8_t *d_slot,
+                       uint32_t *counts, uint32_t *err);
+void launch_region_symbols(hipStream_t st, int kind, const ConnView &cv, const GenView &gv, const uint32_t *order, uint32_t n, uint8_t *out);
+
 }   // namespace dev
 }   // namespace hry

@@ -54,5 +54,9 @@ def test_random_meshes_against_the_oracle(seed):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("seed", list(range(1, 9)))
 def test_random_obj_scenes_against_the_oracle(seed):
-    r = _run("obj_stress.py", ["20", str(200 + seed)], dict(os.environ))
+    env = dict(os.environ)
+    env.pop("HRY_HOST_EVENTS", None)
+    if seed == 3:
+        env["HRY_HOST_EVENTS"] = "1"     # the parallel container's references collected by the host's loop (the device's: events.hip, every other seed)
+    r = _run("obj_stress.py", ["20", str(200 + seed)], env)
     assert r.returncode == 0 and r.stdout.strip().endswith("all ok"), (r.stdout + r.stderr)[-3000:]
