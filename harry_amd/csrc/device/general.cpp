@@ -9,6 +9,7 @@
 //   device  prediction + residuals of every record coded as DATA (general.hip), the adaptive models of every byte plane by
 //           counting, the range coder (kernels.hip: the same kernels as the PLY layout; planes carry explicit positions)
 // and for the decoder: host = serial entropy decode + replay + the same bookkeeping (compat_read.cpp), device = un-prediction.
+// (The parallel container has no single sequence: there the bookkeeping is the device's too -- events.hip, general_planes_encode.)
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
