@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void k_ev_expand(int kind, uint32_t list, uint
 }
 
 // ---- the names a vertex has got in a corner slot: head[slot * nv + v] -> nodes (record, smallest naming position, next) ------------
-struct Names { uint32_t *head, *n_idx, *n_pos, *n_next, *n_nodes; uint32_t nv; };
+constexpr uint32_t kMaxNames = 1u << 14;   // names of one vertex at one slot that a reference may walk past on the device
+struct Names { uint32_t *head, *n_idx, *n_pos, *n_next, *n_nodes, *err; uint32_t nv; };
 __global__ __launch_bounds__(256) void k_ev_names(ConnView cv, const uint32_t *r_elem, const uint8_t *r_slot, const uint32_t *r_idx, const uint32_t *r_q, const uint32_t *n_ptr, Names nm)
 {
 	const uint32_t ref = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,11 +185,16 @@ __global__ __launch_bounds__(256) void k_ev_names(ConnView cv, const uint32_t *r
 	const uint32_t idx = r_idx[ref];
 	uint32_t *hd = nm.head + (size_t)r_slot[ref] * nm.nv + cv.org[r_elem[ref]];
 	uint32_t mine = NONE, seen_upto = NONE;   // mine: the node this thread has filled but not linked; seen_upto: the head whose list has been searched
+	uint32_t steps = 0;
 	for (;;) {
 		const uint32_t first = ld_u32(hd);
 		// search the nodes in front of what has been searched already
-		for (uint32_t k = first; k != seen_upto && k != NONE; k = ld_u32(nm.n_next + k))
+		for (uint32_t k = first; k != seen_upto && k != NONE; k = ld_u32(nm.n_next + k)) {
 			if (ld_u32(nm.n_idx + k) == idx) { atomicMin(nm.n_pos + k, p); return; }   // (a node this thread filled in vain stays out of every list)
+			// a vertex with tens of thousands of different records at one slot (a hub): every reference walks its whole list, here as
+			// on the host -- but a host thread is not a wavefront that the others of its kernel wait for.  The host takes such a mesh
+			if (++steps > kMaxNames) { atomicOr(nm.err, 4u); return; }
+		}
 		seen_upto = first;
 		if (mine == NONE) {
 			mine = atomicAdd(nm.n_nodes, 1u);
@@ -332,6 +338,7 @@ void launch_list_refs(hipStream_t st, int kind, uint32_t list, uint32_t list_cou
 	const ListWs L = carve(list_ws, n_order, max_refs, list_count);
 	uint32_t *corner_base, *corner_cnt, *sums;
 	Names nm = names_of(names_ws, fc, corner_refs_max, head_words, nv, &corner_base, &corner_cnt, &sums);
+	nm.err = err;
 	hipLaunchKernelGGL(k_ev_count, dim3(blocks(n_order)), dim3(256), 0, st, kind, list, cv, gv, rg, order, n_order, L.cnt);
 	exclusive_scan(st, L.cnt, n_order, L.sums, L.base, counts + 0);
 	hipLaunchKernelGGL(k_ev_expand, dim3(blocks(n_order)), dim3(256), 0, st, kind, list, list_count, cv, gv, rg, order, n_order, (const uint32_t*)L.base, (const uint32_t*)corner_base,
@@ -353,6 +360,7 @@ void launch_list_kinds(hipStream_t st, int kind, uint32_t list_count, const Conn
 	const ListWs L = carve(list_ws, n_order, max_refs, list_count);
 	uint32_t *corner_base, *corner_cnt, *sums;
 	Names nm = names_of(names_ws, fc, corner_refs_max, head_words, nv, &corner_base, &corner_cnt, &sums);
+	nm.err = err;
 	const uint32_t *n_refs = counts + 0;
 	const uint32_t nr = max_refs;
 	hipLaunchKernelGGL(k_ev_first, dim3(blocks(nr)), dim3(256), 0, st, kind, cv, (const uint32_t*)L.r_elem, (const uint8_t*)L.r_slot, (const uint32_t*)L.r_idx, (const uint32_t*)L.r_q, n_refs, nm,

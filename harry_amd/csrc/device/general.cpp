@@ -508,8 +508,10 @@ void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vecto
 	ConnView cv = cx.conn_view();
 	const GenView gv = gen_view(cx, m);
 	const Bindings &b = m.bind;
-	static const bool host_events = getenv("HRY_HOST_EVENTS") != nullptr;
+	static const bool host_events_env = getenv("HRY_HOST_EVENTS") != nullptr;
+	bool host_events = host_events_env;
 	Events E;   // (the host's arrays live until the arena has been copied into pinned memory: Arena::send)
+again:
 	if (host_events) {
 		const auto t_events = Clock::now();
 		collect_events(m, w, 0, false, E);
@@ -617,6 +619,7 @@ void general_planes_encode(Context &cx, Mesh &m, const WalkResult &w, std::vecto
 		HIP_OK(hipMemcpyAsync(h_counts, d_counts, (nl * 4 + 4) * 4, hipMemcpyDeviceToHost, cx.stream));
 		HIP_OK(hipStreamSynchronize(cx.stream));
 		const uint32_t err = h_counts[nl * 4];
+		if (err & 4u) { host_events = true; goto again; }   // a hub: a vertex with more names at a slot than a device thread walks (events.hip: kMaxNames) -- the host's loop
 		if (err & 1u) throw Error(HRY_E_ARG, "an element names a record outside its list");
 		if (err & 2u) throw Error(HRY_E_UNSUPPORTED, "more than 65536 different records of one list at one vertex (io.h:104 codes 16 bits)");
 		for (size_t l = 0; l < nl; ++l) {

@@ -427,3 +427,32 @@ def test_a_resident_scene_writes_the_bytes_of_an_uploaded_one(cx):
     cx.upload(d)
     assert cx.write_hry(d, profile=hc.PROFILE_COMPAT) == again
     assert cx.write_hry(a, profile=hc.PROFILE_COMPAT) == want_compat
+
+
+def _cone_scene(n):
+    import math
+    lines = ["v 0 0 1"]
+    for i in range(n):
+        a = 2 * math.pi * i / n
+        lines.append(f"v {math.cos(a):.6f} {math.sin(a):.6f} 0")
+    for i in range(n):
+        a = 2 * math.pi * (i + 0.5) / n
+        lines.append(f"vn {math.cos(a) * 0.7:.6f} {math.sin(a) * 0.7:.6f} 0.7")
+    for i in range(n):
+        lines.append(f"f 1//{i + 1} {2 + i}//{i + 1} {2 + (i + 1) % n}//{i + 1}")
+    return ("\n".join(lines) + "\n").encode()
+
+
+def test_a_hub_with_more_names_than_a_device_thread_walks(cx):
+    """a cone: n faces round one apex, a normal of its own for every face -- the apex gets n different records at the normals'
+    corner slot.  On the device every reference walks the vertex' list of names (events.hip: k_ev_names), and a thread that passes
+    16 384 of them gives the mesh to the host's loop: the container equals the oracle's either way (600 faces: the device's lists;
+    20 000: the host's).  The round trip is checked on the small cone only: the decoder's chain walks such a fan record by record."""
+    for n in (600, 20000):
+        data = _cone_scene(n)
+        m = hc.Mesh.from_obj(data, "")
+        o = op.Mesh.from_obj(data, "")
+        got = cx.write_hry(m, profile=hc.PROFILE_CHUNKED)
+        assert got == o.clone().encode_chunked(hc.container_info(got)["chunk_syms"]).data
+        if n == 600:
+            same_decoded(cx.read_hry(got), op.Mesh.from_hry(o.clone().encode().data))
