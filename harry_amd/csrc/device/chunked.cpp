@@ -712,6 +712,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	if (fc && (ldf.nplanes || m.general) && !piped) HIP_OK(hipMemcpyAsync(cx.d_order_f.p, w.order_f.data(), (size_t)fc * 4, hipMemcpyHostToDevice, cx.stream));   // only the face planes read it
 	// the resident copy of the twins is current unless the walk repaired some (non-manifold edges, consumed neighbours)
 	if (!piped) upload_repaired_twins(cx, in_place ? *in_place->whole : m, w, in_place != nullptr);
+	if (in_place) cx.inplace_twin_patches.insert(cx.inplace_twin_patches.end(), w.twin_patches.begin(), w.twin_patches.end());
 	size_t goff[G_COUNT + 1] = { 0 };
 	for (int g = 0; g < G_COUNT; ++g) {
 		size_t n = w.grp_val[g].size();
@@ -915,6 +916,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 		cx.stage_put_host("order_f", w.order_f.data(), (size_t)fc * 4);
 		cx.stage_put("vplanes", cx.d_vplanes.p, (size_t)vc * ldv.nplanes);
 		cx.stage_put("fplanes", cx.d_fplanes.p, (size_t)fc * ldf.nplanes);
+		cx.stage_put("d_twin", cx.d_twin.p, (size_t)(in_place ? in_place->whole->ne() : m.ne()) * 4);   // the twins the prediction's fan walks followed
 	}
 	cx.timing.k_predict_ms = cx.elapsed(1, 2);
 	cx.timing.k_entropy_ms = cx.elapsed(3, 4);

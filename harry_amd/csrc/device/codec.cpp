@@ -15,6 +15,7 @@
 #include <limits>
 #include <mutex>
 #include <thread>
+#include <system_error>
 #include <vector>
 
 #include "codec_math.hpp"
@@ -241,6 +242,9 @@ void fetch_to_host(Context &cx, void *dst, const void *d_src, size_t bytes)
 	bool stop = false;
 	std::vector<std::thread> helpers;
 	const void *node = callers_node_cpus();
+	helpers.reserve(n_helpers);   // (no growth -- and so no destruction of a joinable thread -- between two creations)
+	auto finish = [&] { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (auto &h : helpers) h.join(); };
+	try {
 	for (unsigned t = 0; t < n_helpers; ++t) helpers.emplace_back([&, node] {
 		stay_on_node(node);
 		for (;;) {
@@ -257,7 +261,12 @@ void fetch_to_host(Context &cx, void *dst, const void *d_src, size_t bytes)
 			cv.notify_all();
 		}
 	});
-	auto finish = [&] { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (auto &h : helpers) h.join(); };
+	} catch (const std::system_error &) {   // no thread to be had: the helpers that did start go home, the runtime's own path brings the bytes down
+		finish();
+		HIP_OK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, cx.stream));
+		HIP_OK(hipStreamSynchronize(cx.stream));
+		return;
+	}
 	try {
 		size_t issued = 0, waited = 0;
 		while (waited < n_chunks) {

@@ -108,6 +108,7 @@ struct Context {
 	DevBuf d_split;   // chunked encode in two kernels: per stream the place of its records and the streams' order, longest first (the records: d_rec_sym)
 	DevBuf d_pipe, d_nt_val, d_nt_planes;   // EncodePipeline: run tables and twin pairs of the batches; the polygons' triangle counts and their two byte planes
 	std::vector<uint32_t> h_twin_patch;   // (half-edge, twin) pairs on their way to d_patch (upload_repaired_twins)
+	std::vector<uint32_t> inplace_twin_patches;   // a shard coded in place: the half-edges whose twins its walks repaired in the WHOLE mesh's host array (sharded.cpp brings them to the resident copy on another device)
 
 	bool keep_stages = false;
 	bool device_recurrence = false; // HRY_FLAG_DEVICE_RECURRENCE: k_rchain instead of the host core

@@ -36,6 +36,8 @@ namespace dev {
 namespace {
 constexpr uint32_t NONE = 0xffffffffu;
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a link (a list's head, a node's next): what it shows was written before it was published
+__device__ __forceinline__ uint32_t ld_link(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // slots of region r that lead to list l: visit(a) for each, in slot order
 template <typename F> __device__ __forceinline__ void slots_of(const EvRegions &rg, int kind, int r, uint32_t l, F &&visit)
@@ -187,9 +189,9 @@ __global__ __launch_bounds__(256) void k_ev_names(ConnView cv, const uint32_t *r
 	uint32_t mine = NONE, seen_upto = NONE;   // mine: the node this thread has filled but not linked; seen_upto: the head whose list has been searched
 	uint32_t steps = 0;
 	for (;;) {
-		const uint32_t first = ld_u32(hd);
+		const uint32_t first = ld_link(hd);
 		// search the nodes in front of what has been searched already
-		for (uint32_t k = first; k != seen_upto && k != NONE; k = ld_u32(nm.n_next + k)) {
+		for (uint32_t k = first; k != seen_upto && k != NONE; k = ld_link(nm.n_next + k)) {
 			if (ld_u32(nm.n_idx + k) == idx) { atomicMin(nm.n_pos + k, p); return; }   // (a node this thread filled in vain stays out of every list)
 			// a vertex with tens of thousands of different records at one slot (a hub): every reference walks its whole list, here as
 			// on the host -- but a host thread is not a wavefront that the others of its kernel wait for.  The host takes such a mesh
@@ -198,10 +200,12 @@ __global__ __launch_bounds__(256) void k_ev_names(ConnView cv, const uint32_t *r
 		seen_upto = first;
 		if (mine == NONE) {
 			mine = atomicAdd(nm.n_nodes, 1u);
-			nm.n_idx[mine] = idx; nm.n_pos[mine] = p;
+			// (atomic stores: another thread's atomicMin may meet n_pos as soon as the link below shows the node)
+			__hip_atomic_store(nm.n_idx + mine, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(nm.n_pos + mine, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		__hip_atomic_store(nm.n_next + mine, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__threadfence();   // the node's fields before the link that shows it
+		__threadfence();   // the node's fields before the link that shows it (release; the readers' ld_link is the acquire)
 		if (atomicCAS(hd, first, mine) == first) return;
 	}
 }
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void k_ev_first(int kind, ConnView cv, const u
 	if (p >= *n_ptr) return;
 	const uint32_t idx = r_idx[p];
 	bool first = true;
+	if (kind == 2 && (ld_u32(nm.err) & 4u)) return;   // (a hub was met: the host's loop takes the mesh, nobody walks the hub's list again)
 	if (kind == 2) {
 		uint32_t k = nm.head[(size_t)r_slot[p] * nm.nv + cv.org[r_elem[p]]];
 		while (k != NONE && nm.n_idx[k] != idx) k = nm.n_next[k];
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(256) void k_ev_hist(ConnView cv, const uint8_t *kin
 	if (p >= *n_ptr || kind[p] == 0) return;
 	const uint32_t idx = r_idx[p];
 	if (kind[p] == 1) { gh_val[at_hist[p]] = at_data[p] - 1u - rank_of[idx]; return; }   // records created so far - 1 - the record's rank
+	if (ld_u32(nm.err) & 4u) return;   // (a hub: see k_ev_first)
 	// the vertex' names are kept newest first: the distance is the number of names it got after this record's and before now
 	uint32_t before_now = 0, mine_pos = NONE;
 	const uint32_t h0 = nm.head[(size_t)r_slot[p] * nm.nv + cv.org[r_elem[p]]], q = r_q[p];

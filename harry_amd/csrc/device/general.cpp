@@ -591,7 +591,11 @@ again:
 			at[l].ws = take(r ? dev::events_list_workspace_bytes(n_order, (uint32_t)r, m.lists[l].count) : 0);
 		}
 		const size_t a_counts = take((nl * 4 + 4) * 4), a_rv = take(vc), a_rf = take(fc), a_names = take(dev::events_names_workspace_bytes(fc, corner_refs_max, head_words));
-		cx.d_gen.ensure(std::max<size_t>(bytes, 16));
+		// (the arena is sized from upper bounds -- every half-edge times the most slots a region binds to the list -- where the
+		// host's loop needs the actual counts: a scene whose bounds do not fit the device's memory takes the host's loop)
+		bool no_room = false;
+		try { cx.d_gen.ensure(std::max<size_t>(bytes, 16)); } catch (const Error &) { (void)hipGetLastError(); no_room = true; }
+		if (no_room) { host_events = true; goto again; }
 		A.send(cx, cx.d_gen.p);
 		uint8_t *arena = cx.d_gen.as<uint8_t>();
 		EvRegions rg{ (const int32_t*)(arena + a_off_f), (const int32_t*)(arena + a_off_v), (const int32_t*)(arena + a_off_c),

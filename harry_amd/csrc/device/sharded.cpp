@@ -346,9 +346,14 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 		cx0.resident_token = 0;   // (the resident records are no longer the host mesh's)
 	}
 	t0 = Clock::now();
+	for (int w = 0; w < n_ctx; ++w) cxs[w]->inplace_twin_patches.clear();
+	// (HRY_SHARD_FOREIGN_CONTEXTS=1, for tests on a one-GPU box: every context but the first behaves as one on another device --
+	// it brings its own intervals up and repairs its own copy of the twins)
+	const bool foreign_ctx = getenv("HRY_SHARD_FOREIGN_CONTEXTS") != nullptr;
+	auto on_first_device = [&](int w) { return w == 0 || (!foreign_ctx && cxs[w]->device == cxs[0]->device); };
 	run_workers(cxs, n_ctx, [&](int w) {
 	  // (device plan) a context on the first context's device reads that context's arrays: lent for the length of this call
-	  const bool shares0 = device_plan && cxs[w]->device == cxs[0]->device;
+	  const bool shares0 = device_plan && on_first_device(w);
 	  struct Lent { DevBuf *b; void *p; size_t cap; };
 	  std::vector<Lent> lent;
 	  struct GiveBack { std::vector<Lent> &l; ~GiveBack() { for (const Lent &x : l) { x.b->p = x.p; x.b->cap = x.cap; } } } give_back{ lent };
@@ -482,6 +487,24 @@ static void encode_sharded_in_place(Context *const *cxs, int n_ctx, Mesh &m, con
 		cx.timing = acc;
 	  } catch (...) { abort_turns(); throw; }
 	});
+	// (device plan) the whole mesh stays resident on the first context.  Workers on its device repaired their twins in its arrays;
+	// workers on OTHER devices repaired the host array and their own copies only -- their (half-edge, twin) pairs go to the resident
+	// copy now, or a later hry_encode of the resident mesh would predict from stale twins (its walk finds nothing left to repair)
+	if (device_plan && cxs[0]->resident_token != 0 && cxs[0]->resident_token == m.device_token) {
+		Context &cx0 = *cxs[0];
+		WalkResult foreign;
+		for (int w = 1; w < n_ctx; ++w) if (!on_first_device(w)) {
+			const std::vector<uint32_t> &tp = cxs[w]->inplace_twin_patches;
+			foreign.twin_patches.insert(foreign.twin_patches.end(), tp.begin(), tp.end());
+		}
+		if (!foreign.twin_patches.empty()) {
+			foreign.twins_changed = true;
+			HIP_OK(hipSetDevice(cx0.device));
+			upload_repaired_twins(cx0, m, foreign, true);
+			HIP_OK(hipStreamSynchronize(cx0.stream));
+		}
+	}
+	for (int w = 0; w < n_ctx; ++w) { cxs[w]->inplace_twin_patches.clear(); cxs[w]->inplace_twin_patches.shrink_to_fit(); }
 	st.phase_b_ms = ms_since(t0);
 	mark("segments");
 	t0 = Clock::now();

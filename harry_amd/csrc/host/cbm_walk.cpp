@@ -656,6 +656,7 @@ struct WalkTrace {
 	alignas(64) std::atomic<size_t> head{ 0 };
 	alignas(64) std::atomic<int> done{ 0 };
 	alignas(64) std::atomic<size_t> tail{ 0 };   // how far the expanding thread has come (published once per batch it takes: traces, tests)
+	std::atomic<int> failed{ 0 };                // the expanding thread has left with an exception: the walking thread must not wait for room any more
 	static uint64_t make(uint32_t a, uint32_t code, uint32_t op, uint32_t payload = 0) { return (uint64_t)a | ((uint64_t)(op | (code << 8) | (payload << 16)) << 32); }
 };
 
@@ -670,7 +671,7 @@ static std::unique_ptr<WalkTrace> take_walk_trace()
 	if (const char *e = getenv("HRY_WALK_RING")) { const size_t v = (size_t)strtoull(e, nullptr, 10); want = 1024; while (want < v && want < WalkTrace::kRing) want <<= 1; }
 	if (t && t->ring != want) t.reset();
 	if (!t) { t.reset(new WalkTrace()); t->ring = want; t->mask = want - 1; t->rec.resize(want); }
-	t->head.store(0, std::memory_order_relaxed); t->tail.store(0, std::memory_order_relaxed); t->done.store(0, std::memory_order_relaxed);
+	t->head.store(0, std::memory_order_relaxed); t->tail.store(0, std::memory_order_relaxed); t->done.store(0, std::memory_order_relaxed); t->failed.store(0, std::memory_order_relaxed);
 	return t;
 }
 static void keep_walk_trace(std::unique_ptr<WalkTrace> t)
@@ -698,7 +699,10 @@ static void walk_component_tri_a(Mesh &m, WalkState &st, uint32_t f, Border &cb,
 	auto put = [&](uint64_t r) {
 		if (at >= room_upto) {   // (a ring ahead of the expanding thread)
 			tr.head.store(at, std::memory_order_release); published = at;
-			while (at >= (room_upto = tr.tail.load(std::memory_order_acquire) + ring)) __builtin_ia32_pause();
+			while (at >= (room_upto = tr.tail.load(std::memory_order_acquire) + ring)) {
+				if (tr.failed.load(std::memory_order_acquire)) throw Error(HRY_E_INTERNAL, "walk: the expanding thread has failed");   // (its own exception is reported in front of this one)
+				__builtin_ia32_pause();
+			}
 		}
 		rec[at++ & rmask] = r;
 		if (at - published >= 256) { tr.head.store(at, std::memory_order_release); published = at; }
@@ -824,7 +828,11 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 		// in blocks of 256, so an operand may still be on its way -- wait for it)
 		auto need = [&](size_t k) {
 			if (h < k) { tr.tail.store(pos, std::memory_order_release); tail_said = pos; }   // (the record in hand has been read: the walking thread is not kept waiting for room by this wait)
-			while (h < k) { __builtin_ia32_pause(); h = tr.head.load(std::memory_order_acquire); }
+			while (h < k) {
+				// (the walking thread has stopped -- with an exception between a record and its operands -- and nothing more will come)
+				if (tr.done.load(std::memory_order_acquire) && (h = tr.head.load(std::memory_order_acquire)) < k) throw Error(HRY_E_INTERNAL, "walk: truncated trace");
+				__builtin_ia32_pause(); h = tr.head.load(std::memory_order_acquire);
+			}
 		};
 		while (pos < h) {
 			if (pos - tail_said >= 4096) { tr.tail.store(pos, std::memory_order_release); tail_said = pos; }
@@ -1113,10 +1121,11 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 				WalkTrace *trp = split.trace.get();
 				std::exception_ptr *errp = &split.err;
 				split.expander = std::thread([&m, &st, &em, trp, errp, near_cpus] {
-					try { stay_on_node(near_cpus); walk_trace_expand(m, st, em, *trp); } catch (...) { *errp = std::current_exception(); }
+					try { stay_on_node(near_cpus); walk_trace_expand(m, st, em, *trp); } catch (...) { *errp = std::current_exception(); trp->failed.store(1, std::memory_order_release); }
 				});
 			}
-			walk_component_tri_a(m, st, f, cb, w, *split.trace, split.at, next_id, consumed);
+			try { walk_component_tri_a(m, st, f, cb, w, *split.trace, split.at, next_id, consumed); }
+			catch (...) { split.stop(); if (split.err) std::rethrow_exception(split.err); throw; }   // (the expanding thread's failure is the cause, where there is one)
 		}
 		else if (lean && eval_op_model) walk_component_tri<true>(m, st, f, cb, em, next_id, consumed);
 		else if (lean) walk_component_tri<false>(m, st, f, cb, em, next_id, consumed);

@@ -205,6 +205,40 @@ def test_in_process_contexts_run_concurrently_and_match_the_virtual_ranks(cx, ki
         mc.close()
 
 
+def test_resident_mesh_keeps_the_twins_that_contexts_of_other_devices_repaired(monkeypatch):
+    """Round 6: with the plan on the first context's device the whole mesh stays resident there.  A worker on ANOTHER
+    device repairs non-manifold twins in the host array and in its own copy only; the first context receives those (half-edge,
+    twin) pairs after the workers, so that a later hry_encode of the resident mesh -- whose walk finds nothing left to repair --
+    predicts from the twins the decoder will have.  HRY_SHARD_FOREIGN_CONTEXTS makes the contexts of this one-GPU box behave as
+    contexts of other devices (own interval copies, own twins)."""
+    monkeypatch.setenv("HRY_DEVICE_ANALYSIS_MIN_FACES", "1")
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
+    monkeypatch.setenv("HRY_HOST_THREADS", "6")
+    monkeypatch.setenv("HRY_SHARD_FOREIGN_CONTEXTS", "1")
+    gen = _mesh("mixed_nm")
+    one = hc.Codec(0)
+    try:
+        want_one = one.write_hry(hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props), profile=hc.PROFILE_CHUNKED, chunk_syms=1024)
+        _, _, parts = _encode_sharded(one, gen, 3, [], chunk_syms=1024)
+    finally:
+        one.close()
+    mc = hc.MultiCodec([0, 0, 0])
+    try:
+        whole = hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props)
+        assert mc.write_hry(whole, [], chunk_syms=1024) == hc.merge(parts)
+        # the same host mesh again through the first context alone: resident there, its twins repaired by the other contexts' walks
+        again = mc.ctx[0].write_hry(whole, profile=hc.PROFILE_CHUNKED, chunk_syms=1024, keep_stages=True)
+        assert again == want_one
+        repaired = whole.twin()
+        assert not np.array_equal(repaired, hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props).twin())   # (the walks did repair some)
+        assert np.array_equal(mc.ctx[0].stage("d_twin", np.uint32), repaired)   # the fan walks followed the repaired twins, every one of them
+        ref = op.Mesh.from_hry(op.Mesh.from_ply(gen.to_ply()).encode().data)
+        dec = mc.ctx[0].read_hry(again)
+        assert np.array_equal(dec.twin(), ref.twin()) and np.array_equal(dec.list_data(1), ref.list_data(1))
+    finally:
+        mc.close()
+
+
 def test_two_threads_two_contexts_independent_meshes():
     """section 8b's threading contract: distinct contexts are independent -- two threads code and decode different meshes at once"""
     import threading
