@@ -215,7 +215,7 @@ def _walk_arrays(w) -> dict:
         out = {}
         names = [("order_v", np.uint32), ("order_f", np.uint32), ("op_sym", np.uint8), ("op_class", np.uint8), ("op_l", np.uint32),
                  ("op_h", np.uint32), ("op_t", np.uint32), ("op_pos", np.uint32), ("op_thr", np.uint32), ("op_cum", np.uint32), ("info", np.uint32),
-                 ("marks", np.uint32)]
+                 ("marks", np.uint32), ("snap_section", np.uint8)]
         for g in range(5):
             names += [(f"grp{g}_val", np.uint32), (f"grp{g}_pos", np.uint32)]
         for name, dt in names:
@@ -285,14 +285,15 @@ def walk_and_replay(mesh: "Mesh", use_restart_points: bool):
     nat.check(L.hry_walk_run_plain(mesh.h, C.byref(w)))
     try:
         mh, r = C.c_void_p(), C.c_void_p()
-        nat.check(L.hry_walk_replay(mesh.h, w, 1 if use_restart_points else 0, C.byref(mh), C.byref(r)))
+        nat.check(L.hry_walk_replay(mesh.h, w, int(use_restart_points), C.byref(mh), C.byref(r)))
         try:
             out = []
             for name in ("order_v", "seg_start", "seg_level", "info"):
                 p = C.c_void_p()
                 n = L.hry_walk_get(r, name.encode(), C.byref(p))
                 out.append(np.frombuffer(C.string_at(p, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32))
-            return (Mesh(mh), out[0], out[1], out[2], int(out[3][0]))
+            # use_restart_points: False / True (the restart points at component starts), or 2 / 3: + the border snapshots inside components
+            return (Mesh(mh), out[0], out[1], out[2], int(out[3][0]) if int(use_restart_points) < 2 else (int(out[3][0]), int(out[3][1])))
         finally:
             L.hry_walk_free(r)
     finally:

@@ -15,7 +15,15 @@ struct hry_walk {
 	mutable std::vector<uint8_t> op_sym, op_class;   // unpacked from w.op_sc on first request
 	mutable std::vector<uint32_t> op_thr, op_cum;    // op_position_table, on first request
 	mutable bool have_table = false;
+	mutable std::vector<uint8_t> snap_section;       // the border snapshots as the chunked container's directory holds them, on first request
 	void table() const { if (!have_table) { op_position_table(w, op_thr, op_cum); have_table = true; } }
+	void snapshots() const
+	{
+		if (!snap_section.empty() || w.snapshots.empty()) return;
+		std::vector<RestartCounters> rc, sc;
+		(void)select_restart_points(w.marks, w.named, rc, &w.snapshots, &sc);
+		write_snapshot_section(w.snapshot_faces, w.snapshots, sc, snap_section);
+	}
 	void unpack_ops() const
 	{
 		if (op_sym.size() == w.op_sc.size()) return;
@@ -347,6 +355,7 @@ int hry_walk_run_shard(hry_mesh *m, const hry_plan *p, int shard, hry_walk **out
 			for (uint32_t f = 0; f < m->m.nf; ++f) for (uint32_t h = m->m.face_off[f]; h < m->m.face_off[f + 1]; ++h) eface[h] = f;
 		}
 		WalkState marks(m->m.nv, m->m.nf);
+		{ uint64_t nfs = 0; for (uint32_t k = 0; k < part.ncomp; ++k) nfs += part.n_faces[k]; w->w.snapshot_faces = snapshot_spacing((uint32_t)nfs); }   // (what an encode of the shard asks for)
 		cut_border_walk_in_place(m->m, part, uniform ? nullptr : eface.empty() ? p->p.A.eface.data() : eface.data(), marks, w->w);
 		w->info[0] = w->w.n_conn; w->info[1] = w->w.numtri_coded ? 1 : 0;
 		*out = w.release();
@@ -462,6 +471,7 @@ int hry_walk_run_plain(hry_mesh *m, hry_walk **out)
 	return guarded([&] {
 		std::unique_ptr<hry_walk> w(new hry_walk());
 		check_codable(m->m);
+		w->w.snapshot_faces = snapshot_spacing(m->m.nf);   // (what a chunked encode asks for)
 		cut_border_walk(m->m, w->w, false);
 		w->info[0] = w->w.n_conn; w->info[1] = w->w.numtri_coded ? 1 : 0;
 		*out = w.release();
@@ -484,6 +494,7 @@ size_t hry_walk_get(const hry_walk *w, const char *name, const void **ptr)
 	if (n == "op_thr") { w->table(); return ret(w->op_thr); }   // where the connectivity groups sit between the operations (what the
 	if (n == "op_cum") { w->table(); return ret(w->op_cum); }   // device's operation model places its records with)
 	if (n == "info") { *ptr = w->info; return 2; }
+	if (n == "snap_section") { w->snapshots(); return ret(w->snap_section); }
 	if (n == "marks") { *ptr = r.marks.data(); return r.marks.size() * (sizeof(ComponentMark) / 4); }
 	if (n == "seg_start") return ret(w->seg_start);
 	if (n == "seg_level") return ret(w->seg_level);
@@ -540,15 +551,26 @@ int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_p
 		std::unique_ptr<hry_mesh> m(new hry_mesh());
 		std::unique_ptr<hry_walk> w(new hry_walk());
 		m->m.nv = src->m.nv; m->m.nf = src->m.nf; m->m.declared_ne = src->m.ne(); m->m.have_degree = src->m.have_degree;
+		// use_restart_points: 1 the restart points at component starts, 3 also the border snapshots inside components -- through the
+		// directory's form and back, as a decoder receives them (the counters of a span depend on which points exist: never the snapshots alone)
 		std::vector<RestartPoint> restarts;
-		std::vector<RestartCounters> rcounters;
-		if (use_restart_points) restarts = select_restart_points(r.marks, r.named, rcounters);
+		std::vector<RestartCounters> rcounters, scounters;
+		std::vector<SnapshotPoint> snaps;
+		const bool with_snaps = (use_restart_points & 2) != 0 && !r.snapshots.empty();
+		if (use_restart_points & 3) restarts = select_restart_points(r.marks, r.named, rcounters, with_snaps ? &r.snapshots : nullptr, with_snaps ? &scounters : nullptr);
+		if (use_restart_points == 2) throw Error(HRY_E_ARG, "replay: border snapshots go with the restart points");
+		if (with_snaps) {
+			std::vector<uint8_t> sec;
+			write_snapshot_section(r.snapshot_faces, r.snapshots, scounters, sec);
+			uint32_t spacing = 0;
+			if (read_snapshot_section(sec.data(), sec.size(), m->m.nv, spacing, snaps) != sec.size() || spacing != r.snapshot_faces) throw Error(HRY_E_INTERNAL, "border snapshots: the section does not read back");
+		}
 		OrderVec order_v;
 		PlaneView views[21];
 		for (int k = 0; k < 21; ++k) views[k] = PlaneView(planes[k]);
-		cut_border_replay(m->m, views, restarts, rcounters, order_v, w->seg_start, w->seg_level);
+		cut_border_replay(m->m, views, restarts, rcounters, order_v, w->seg_start, w->seg_level, nullptr, with_snaps ? &snaps : nullptr);
 		w->w.order_v.assign(order_v.begin(), order_v.end());
-		w->info[0] = (uint32_t)restarts.size(); w->info[1] = 0;
+		w->info[0] = (uint32_t)restarts.size(); w->info[1] = (uint32_t)snaps.size();
 		*mesh = m.release();
 		*out = w.release();
 	});

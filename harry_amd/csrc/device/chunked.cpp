@@ -576,6 +576,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	const ListDesc ldv = m.general ? ListDesc{} : make_list_desc(m.lists[1]), ldf = m.general ? ListDesc{} : make_list_desc(m.lists[0]);   // (general bindings: general_planes_encode)
 	WalkResult w;
 	w.numtri_positions = false;     // (places in ONE symbol sequence: the chunked planes have none)
+	w.snapshot_faces = snapshot_spacing(m.nf);   // restart points inside large components (host.hpp BorderSnapshot; a shard: its own faces)
 	bool walked = false;
 	// the device side beside the walk (EncodePipeline above): for walks on several threads whose sizes are known before they start
 	std::unique_ptr<EncodePipeline> pipe;
@@ -663,12 +664,15 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	std::vector<RestartCounters> rcounters;
 	std::vector<RestartPoint> restarts;
 	std::vector<uint32_t> counter_dir;   // per restart point: n, then n x (vertex, counter)
+	std::vector<uint8_t> snap_dir;       // the border snapshots' section (host/header.cpp: write_snapshot_section), empty without any
 	auto select_restarts = [&] {
-		restarts = select_restart_points(w.marks, w.named, rcounters);
+		std::vector<RestartCounters> scounters;
+		restarts = select_restart_points(w.marks, w.named, rcounters, &w.snapshots, &scounters);
 		for (const RestartCounters &cs : rcounters) {
 			counter_dir.push_back((uint32_t)cs.size());
 			for (const auto &c : cs) { counter_dir.push_back(c.first); counter_dir.push_back(c.second); }
 		}
+		if (!w.snapshots.empty()) write_snapshot_section(w.snapshot_faces, w.snapshots, scounters, snap_dir);
 	};
 	struct Helper {   // (joined on every way out)
 		std::thread th; std::exception_ptr failed;
@@ -894,7 +898,8 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	const size_t dir_prior = 12 + 4 * planes.size();
 	const size_t dir_restart = dir_prior + prior_dir.size();
 	const size_t dir_counters = dir_restart + 4 + sizeof(RestartPoint) * (size_t)nrs;
-	const size_t dir_streams = dir_counters + 4 * counter_dir.size();
+	const size_t dir_snaps = dir_counters + 4 * counter_dir.size();   // (round 6: the border snapshots, announced by the top bit of the restart points' count)
+	const size_t dir_streams = dir_snaps + snap_dir.size();
 	size_t dir = dir_streams + 4 * (size_t)ns;
 	size_t base = out.size();
 	out.resize(base + dir + total_bytes);
@@ -903,9 +908,10 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	memcpy(o, &CH, 4); memcpy(o + 4, &CHC, 4); memcpy(o + 8, &np, 4);
 	for (size_t i = 0; i < planes.size(); ++i) memcpy(o + 12 + 4 * i, &planes[i].n, 4);
 	if (!prior_dir.empty()) memcpy(o + dir_prior, prior_dir.data(), prior_dir.size());
-	memcpy(o + dir_restart, &nrs, 4);
+	{ const uint32_t nrs_word = nrs | (snap_dir.empty() ? 0u : 0x80000000u); memcpy(o + dir_restart, &nrs_word, 4); }
 	if (nrs) memcpy(o + dir_restart + 4, restarts.data(), sizeof(RestartPoint) * (size_t)nrs);
 	if (!counter_dir.empty()) memcpy(o + dir_counters, counter_dir.data(), 4 * counter_dir.size());
+	if (!snap_dir.empty()) memcpy(o + dir_snaps, snap_dir.data(), snap_dir.size());
 	if (ns) HIP_OK(hipMemcpyAsync(o + dir_streams, d_nbytes, (size_t)ns * 4, hipMemcpyDeviceToHost, cx.stream));
 	fetch_to_host(cx, o + dir, cx.d_cout.p, total_bytes);   // (returns when everything on the stream has happened)
 	HRY_MARK(t_all, "container on the host");

@@ -336,7 +336,7 @@ struct SpanUploader : SpanDone {
 	const OrderVec &order_v;
 	ChainBatches *batches = nullptr;       // chains launched behind the copies, batch by batch (nullptr: after the replay, as one)
 	hipEvent_t planes_ready = nullptr;     // ... once the residual planes are decoded
-	struct Range { uint32_t index, n_spans, f0, f1, h0, h1, v0, v1; std::vector<uint32_t> comp_first; };
+	struct Range { uint32_t index, n_spans, f0, f1, h0, h1, v0, v1; std::vector<uint32_t> comp_first; bool ends_inside = false; };
 	std::vector<Range> arrived;            // by span index, for the prefix of finished spans (uploader thread only)
 	std::vector<char> have;
 	uint32_t prefix = 0;                   // spans [0, prefix) are on the device
@@ -418,9 +418,9 @@ struct SpanUploader : SpanDone {
 		}
 		if (r.v1 > r.v0) HIP_OK(hipMemcpyAsync(cx.d_order_v.as<uint32_t>() + r.v0, order_v.data() + r.v0, ((size_t)r.v1 - r.v0) * 4, hipMemcpyHostToDevice, st));
 	}
-	void span(uint32_t index, uint32_t n_spans, uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1, const uint32_t *comp_first, uint32_t n_comp) override
+	void span(uint32_t index, uint32_t n_spans, uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1, const uint32_t *comp_first, uint32_t n_comp, bool ends_inside) override
 	{
-		Range r{ index, n_spans, f0, f1, h0, h1, v0, v1, {} };
+		Range r{ index, n_spans, f0, f1, h0, h1, v0, v1, {}, ends_inside };
 		if (batches) r.comp_first.assign(comp_first, comp_first + n_comp);
 		{ std::lock_guard<std::mutex> g(mu); todo.push_back(std::move(r)); }
 		cv.notify_one();
@@ -435,11 +435,16 @@ struct SpanUploader : SpanDone {
 		arrived[idx] = std::move(r);
 		have[idx] = 1;
 		while (prefix < have.size() && have[prefix]) {
-			Range &p = arrived[prefix];
-			pending_first.insert(pending_first.end(), p.comp_first.begin(), p.comp_first.end());
-			pending_v_end = p.v1;
-			std::vector<uint32_t>().swap(p.comp_first);
-			++prefix;
+			// (a component that goes on in the next span -- the span stops at a border snapshot -- joins the prefix with its last span)
+			size_t q = prefix;
+			while (q < have.size() && have[q] && arrived[q].ends_inside) ++q;
+			if (q == have.size() || !have[q]) break;
+			for (; prefix <= q; ++prefix) {
+				Range &p = arrived[prefix];
+				pending_first.insert(pending_first.end(), p.comp_first.begin(), p.comp_first.end());
+				pending_v_end = p.v1;
+				std::vector<uint32_t>().swap(p.comp_first);
+			}
 		}
 		if (!planes_done) planes_done = hipEventQuery(planes_ready) == hipSuccess;
 		static const uint32_t parts = [] { const char *e = getenv("HRY_CHAIN_BATCH_PARTS"); const int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : v); }();
@@ -528,7 +533,8 @@ static bool pipelined_decode_applicable(const Mesh &m, const std::vector<Restart
 
 // attr_upto[g]: the vertex planes are decoded up to this vertex once cx.attr_ev[g] has fired (the last entry covers everything)
 static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, const uint8_t *d_vplanes, const uint8_t *d_fplanes,
-                             const ListDesc &ldv, const ListDesc &ldf, OrderVec &order_v, const uint32_t (&attr_upto)[Context::kAttrGroups])
+                             const ListDesc &ldv, const ListDesc &ldf, OrderVec &order_v, const uint32_t (&attr_upto)[Context::kAttrGroups],
+                             const std::vector<SnapshotPoint> &snaps_in)
 {
 	Mesh *m = &mesh;
 	const uint32_t nv = m->nv, nf = m->nf, ne = m->declared_ne;
@@ -557,8 +563,13 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 
 	m->face_off.resize((size_t)nf + 1); m->face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
 	m->org.resize(ne);
-	m->twin.resize(ne);
 	order_v.assign(nv, 0);
+	// Round 6: border snapshots in the directory (restart points inside the component): this thread replays the stretch up to the
+	// first one and publishes as before, the stretches behind the snapshots run on helper threads meanwhile and are joined when
+	// all have finished (cbm_replay.hpp SnapshotSpans) -- the replay of ONE component on several cores
+	std::unique_ptr<SnapshotSpans> spans;
+	if (ud == 3 && !snaps_in.empty() && host_threads() > 1 && !getenv("HRY_NO_SNAPSHOT_REPLAY") && !getenv("HRY_GENERIC_REPLAY")) spans.reset(new SnapshotSpans(*m, conn, snaps_in, order_v.data()));   // (sizes m->twin)
+	else m->twin.resize(ne);
 	BigVec<uint16_t> seen(nv, 0);
 	ReplayLive live;
 	live.on_border.assign(nv, 0);
@@ -717,7 +728,16 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 		const bool count = getenv("HRY_PERF") != nullptr;
 		PerfCounters pc;
 		if (count) pc.start();
-		if (onlydeg == 3 && !getenv("HRY_GENERIC_REPLAY")) replay_triangles<true>(*m, conn, seen.data(), order_v.data(), cur, comp_first, refs, &live);   // the lean loop
+		if (spans) {
+			spans->start(host_threads() - 1);
+			BorderEnd end0;
+			size_t cur_end0[21];
+			const bool eom0 = replay_triangles<true>(*m, conn, seen.data(), order_v.data(), cur, comp_first, refs, &live, nullptr, spans->spans[0].cur1, spans->spans[0].stop_face, true, nullptr, &end0, cur_end0);
+			if (!eom0) live.publish(cur.face, cur.he, cur.next_id, false);   // (what this stretch has finished: the consumer goes on while the others are waited for)
+			HRY_MARK(g_t0, "replay: the first stretch has reached its snapshot");
+			spans->finish(cur, cur_end0, std::move(end0), eom0, &live);
+		}
+		else if (onlydeg == 3 && !getenv("HRY_GENERIC_REPLAY")) replay_triangles<true>(*m, conn, seen.data(), order_v.data(), cur, comp_first, refs, &live);   // the lean loop
 		else replay_span(*m, rd, seen.data(), order_v.data(), cur, replay_detail::NONE32, 0, none, comp_first, refs, &live);
 		if (count) { pc.stop(); pc.report("cut-border replay (pipelined decode, publishing)", (double)cur.he - 2.0 * cur.face); }
 		if (cur.face != nf) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
@@ -811,6 +831,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	uint32_t nrs;
 	memcpy(&nrs, p + off, 4);
 	off += 4;
+	const bool has_snapshots = (nrs & 0x80000000u) != 0;   // (round 6: a section of border snapshots follows the restart points' counters)
+	nrs &= 0x7fffffffu;
 	if ((uint64_t)nrs * sizeof(RestartPoint) > n) throw Error(HRY_E_FORMAT, "truncated chunked directory");
 	need(off, sizeof(RestartPoint) * (size_t)nrs);
 	std::vector<RestartPoint> restarts(nrs);
@@ -828,6 +850,8 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		for (uint32_t j = 0; j < nc; ++j) { uint32_t v[2]; memcpy(v, p + off + 8ull * j, 8); rcounters[k][j] = { v[0], v[1] }; }
 		off += 8ull * nc;
 	}
+	std::vector<SnapshotPoint> snaps;   // restart points inside components (host.hpp BorderSnapshot)
+	if (has_snapshots) { uint32_t spacing = 0; off += read_snapshot_section(p + off, n - off, m->nv, spacing, snaps); }
 	need(off, 4 * nstreams);
 	std::vector<uint32_t> nbytes((size_t)nstreams);
 	if (nstreams) memcpy(nbytes.data(), p + off, 4 * (size_t)nstreams);
@@ -1051,7 +1075,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	std::vector<uint32_t> seg_start, seg_level;
 	bool pipelined = false;
 	if (m->general) {
-		cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
+		cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level, nullptr, &snaps);
 		cx.timing.host_walk_ms = ms_since(t_walk);
 		HRY_MARK(g_t0, "replay done");
 		general_planes_decode(cx, *m, order_v, seg_start, seg_level, cx.d_csyms.as<uint8_t>(), plane_off, nsym, (uint32_t)kConnPlanes);
@@ -1059,7 +1083,7 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 		pipelined = true;
 		uint32_t attr_upto[Context::kAttrGroups];
 		for (int g = 0; g < Context::kAttrGroups; ++g) attr_upto[g] = (uint32_t)std::min<uint64_t>(kGroupEnd[g], 0xffffffffull);
-		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v, attr_upto);
+		decode_pipelined(cx, *m, conn, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes + ldv.nplanes], ldv, ldf, order_v, attr_upto, snaps);
 		cx.timing.host_walk_ms = cx.timing.host_walk_ms - std::chrono::duration<double, std::milli>(t_walk - g_t0).count();
 	} else {
 		bool conn_resident = false;
@@ -1076,11 +1100,11 @@ Mesh *decode_chunked(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 			const bool in_batches = ldv.nplanes && unpredict2_applicable(ldv) && !unpredict3_wanted(ldv) && vc == m->nv && vc >= batch_min && !getenv("HRY_NO_CHAIN_BATCHES");
 			if (in_batches) batches.reset(new ChainBatches(cx, ldv, cx.d_csyms.as<uint8_t>() + plane_off[kConnPlanes], vc, nsym[0]));
 			SpanUploader up(cx, *m, order_v, batches.get(), cx.ev_x[1]);
-			cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level, &up);
+			cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level, &up, &snaps);
 			conn_resident = up.finish();
 			if (up.error) std::rethrow_exception(up.error);
 			if (batches && conn_resident) { up.finish_edge_faces(cx.stream); batches->conn_adopted = true; }
-		} else cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level);
+		} else cut_border_replay(*m, conn, restarts, rcounters, order_v, seg_start, seg_level, nullptr, &snaps);
 		cx.timing.host_walk_ms = ms_since(t_walk);
 		HRY_MARK(g_t0, "replay done");
 		if (order_v.size() != vc && ldv.nplanes) throw Error(HRY_E_FORMAT, "vertex plane length does not match the connectivity");

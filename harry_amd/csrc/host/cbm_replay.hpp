@@ -11,6 +11,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <unordered_map>
+#include <mutex>
+#include <thread>
 
 namespace hry {
 namespace replay_detail {
@@ -116,6 +118,58 @@ struct Ring {
 //                   the reconstruction from them (replay_levels) once every span is known
 // RD provides: iop(), vertid(), elem(), part(), numtri(), op(order)
 struct ReplayCursor { uint32_t next_id = 0, face = 0, he = 0; };
+
+// A span of the replay that starts INSIDE a component (round 6): the border comes from a snapshot of the container's directory
+// (host.hpp SnapshotPoint).  The snapshot has no half-edges: element j (parts from the bottom of the stack, head -> tail) carries the
+// placeholder sym_base + j -- a number above every half-edge of the mesh -- and the twin array has room up there: whatever the span
+// links such an edge to is noted at the placeholder's own entry, and when the span BEFORE this one has finished, its last border
+// says which half-edges the placeholders were (join_spans in cbm_unwalk.cpp).  A border edge only ever becomes the twin of an edge
+// the span creates (decoder.h:179-197), so nothing else of the replay looks at these numbers.
+struct BorderSeed { const SnapshotPoint *snap = nullptr; uint32_t sym_base = 0; };
+// the border a span stopped with inside a component, in the snapshot's order (a: half-edges, or placeholders of the span's own seed
+// for elements it never touched; seen: the triangle counts, clamped like the snapshot's)
+struct BorderEnd { std::vector<uint32_t> parts, vtx, a; std::vector<uint8_t> seen; };
+// the triangle counts of ONE span that starts inside a component (cbm_unwalk.cpp)
+struct SeenOfSpan {
+	uint16_t *p = nullptr; size_t bytes = 0;
+	explicit SeenOfSpan(uint32_t nv);
+	~SeenOfSpan();
+	SeenOfSpan(const SeenOfSpan&) = delete;
+	SeenOfSpan &operator=(const SeenOfSpan&) = delete;
+};
+struct ReplayLive;
+void join_spans(Mesh &m, const std::vector<const SnapshotPoint*> &seeds, const std::vector<uint32_t> &sym_base, const std::vector<BorderEnd> &ends, ReplayLive *live);
+// A triangle mesh whose replay publishes its progress (unchunk.cpp: the pipelined decode) and whose directory holds border
+// snapshots: the caller replays the stretch up to the first snapshot itself, publishing as it goes; the stretches behind the
+// snapshots run on helper threads meanwhile (cbm_unwalk.cpp).  No restart points, no explicitly named vertices (the pipelined
+// decode's own conditions).
+struct SnapshotSpans {
+	Mesh &m;
+	const PlaneView *conn;
+	const std::vector<SnapshotPoint> &snaps;
+	uint32_t *order_v;
+	size_t n_spans = 0;
+	uint64_t n_sym = 0;
+	struct Span { ReplayCursor cur; size_t cur0[21], cur1[21], cur_end[21]; uint32_t stop_face = 0xffffffffu; bool stop_mid = false, eom = false; BorderSeed seed; std::vector<uint32_t> first; std::vector<std::pair<uint32_t, uint32_t>> refs; };
+	std::vector<Span> spans;
+	std::vector<const SnapshotPoint*> seeds;
+	std::vector<uint32_t> sym_base;
+	std::vector<BorderEnd> ends;
+	std::vector<std::thread> helpers;
+	std::atomic<size_t> next{ 1 };
+	std::mutex mu;
+	std::exception_ptr failed;
+	// checks the snapshots against the header's sizes, sizes m.twin for the placeholders (m.org / m.twin / m.face_off are
+	// allocated by the caller before) -- start() then sets the helpers off
+	SnapshotSpans(Mesh &mesh, const PlaneView *planes, const std::vector<SnapshotPoint> &points, uint32_t *ov);
+	~SnapshotSpans();
+	void start(unsigned n_threads);
+	// the caller's stretch has stopped at the first snapshot with border `end0` and cursors `cur` / plane cursors `cur_end0`: waits
+	// for the helpers, checks every stretch's end against the next snapshot, joins them (twin links into published half-edges become
+	// patches of `live`) and leaves the last stretch's cursor in `cur`
+	void finish(ReplayCursor &cur, const size_t *cur_end0, BorderEnd &&end0, bool eom0, ReplayLive *live);
+};
+constexpr uint32_t kContinues = 0xffffffffu;   // refs of a span that starts inside a component: "the component the span before me ended in"
 
 // Progress of a running replay, published for a consumer thread that uploads the finished part of the connectivity and
 // starts the attribute reconstruction of the vertices that can no longer change (unchunk.cpp, pipelined decode).
@@ -385,9 +439,15 @@ bool replay_span(Mesh &m, RD &rd, uint16_t *seen_shared, uint32_t *order_v, Repl
 // part through bare pointers, the order counters in the shared array only.  Same checks against a corrupt stream as
 // replay_span, same results (the tests run both on the same inputs).
 // ---------------------------------------------------------------------------------------------------------
+// A span of it (round 6): cur0 / cur1 = where the 21 planes' cursors stand at its start and (at most) at its end (nullptr: the planes'
+// own ends); stop_face / stop_mid: it ends in front of the component that would start at face stop_face, or -- stop_mid -- inside a
+// component, between two operations, as soon as stop_face faces exist (`end` receives the border); seed: it starts inside a
+// component (`seen` then is the span's own array: the counts at the border's vertices are entered here).
 template <bool LIVE>
 bool replay_triangles(Mesh &m, const PlaneView *conn, uint16_t *seen, uint32_t *order_v, ReplayCursor &cur,
-                      std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs, ReplayLive *live)
+                      std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs, ReplayLive *live,
+                      const size_t *cur0 = nullptr, const size_t *cur1 = nullptr, uint32_t stop_face = replay_detail::NONE32, bool stop_mid = false,
+                      const BorderSeed *seed = nullptr, BorderEnd *end = nullptr, size_t *cur_out = nullptr)
 {
 	using namespace replay_detail;
 	struct Node { uint32_t v, a; int32_t prev, next; };
@@ -397,20 +457,23 @@ bool replay_triangles(Mesh &m, const PlaneView *conn, uint16_t *seen, uint32_t *
 	uint32_t *const org = m.org.data(), *const twin = m.twin.data();
 	{   // a triangle mesh: face f owns the half-edges 3 f .. 3 f + 2 (the counts are checked against the header at the end)
 		uint32_t *fo = m.face_off.data();
-		const size_t n = std::min<uint64_t>((uint64_t)nf, ne_max / 3) + 1;
-		for (size_t i = 0; i < n; ++i) fo[i] = (uint32_t)(3 * i);
+		const size_t last = std::min<uint64_t>(stop_face != NONE32 ? (uint64_t)stop_face : (uint64_t)nf, std::min<uint64_t>((uint64_t)nf, ne_max / 3));
+		for (size_t i = cur.face; i <= last; ++i) fo[i] = (uint32_t)(3 * i);
 	}
-	// operation planes with a sentinel behind the last symbol
+	// operation planes with a sentinel behind the last symbol (of the span)
 	std::vector<uint8_t> opl[8];
 	const uint8_t *opc[8];
 	for (int k = 0; k < 8; ++k) {
-		opl[k].reserve(conn[13 + k].size() + 1);
-		opl[k].assign(conn[13 + k].begin(), conn[13 + k].end());
+		const size_t b = cur0 ? cur0[13 + k] : 0, e = cur1 ? cur1[13 + k] : conn[13 + k].size();
+		if (b > e || e > conn[13 + k].size()) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart points)");
+		opl[k].reserve(e - b + 1);
+		opl[k].assign(conn[13 + k].begin() + b, conn[13 + k].begin() + e);
 		opl[k].push_back(0xff);
 		opc[k] = opl[k].data();
 	}
 	// the other connectivity planes are read a few times per mesh: checked cursors
 	size_t rc[13] = { 0 };
+	if (cur0) for (int k = 0; k < 13; ++k) rc[k] = cur0[k];
 	auto rbyte = [&](int p) -> uint32_t { if (rc[p] >= conn[p].size()) throw Error(HRY_E_FORMAT, "corrupt stream (connectivity plane exhausted)"); return conn[p][rc[p]++]; };
 	auto ru32 = [&](int first) -> uint32_t { uint32_t v = rbyte(first); v |= rbyte(first + 1) << 8; v |= rbyte(first + 2) << 16; v |= rbyte(first + 3) << 24; return v; };
 	auto r_elem = [&]() -> int { uint32_t z = ru32(1); return (int)((z >> 1) ^ ((z & 1) ? 0xffffffffu : 0u)); };
@@ -468,16 +531,49 @@ bool replay_triangles(Mesh &m, const PlaneView *conn, uint16_t *seen, uint32_t *
 	uint32_t next_id = cur.next_id, face = cur.face, he = cur.he;
 	uint32_t he_pub = LIVE ? live->he_pub : 0u, face_pub = LIVE ? live->face_pub : 0u;
 	const uint32_t interval = LIVE ? live->interval : 0u;
-	bool eom = false;
+	const uint32_t stop_at = stop_mid ? stop_face : NONE32;   // (NONE32: `face` never gets there)
+	const uint32_t own_first = cur.next_id;                   // a span names older vertices only with their counters (chk below)
+	bool eom = false, resume = false, older_known = false;
+	std::vector<uint32_t> older;   // vertices older than the span that it may name (chk below)
+	if (seed) {
+		// the border of the snapshot: nodes in its order, placeholders for the half-edges, the counts at its vertices
+		const SnapshotPoint &S = *seed->snap;
+		size_t j = 0;
+		for (const uint32_t pt : S.parts) {
+			parts.push_back(Part{ -1, -1, 0, pt & 1u });
+			for (uint32_t q = 0, nq = pt >> 1; q < nq; ++q, ++j) {
+				const int32_t n = make(S.vtx[j], seed->sym_base + (uint32_t)j);
+				append(parts.back(), n);
+				seen[S.vtx[j]] = S.seen[j];
+				twin[seed->sym_base + j] = seed->sym_base + (uint32_t)j;   // (nothing linked yet)
+			}
+		}
+		for (const auto &c : S.counters) seen[c.first] = (uint16_t)c.second;
+		resume = true;
+	}
 	for (;;) {
+		uint32_t seg_first_id = next_id, comp_idx = kContinues;
+		auto depends_on = [&](uint32_t vid) { if (vid < seg_first_id) refs.push_back({ comp_idx, vid }); };
+		auto chk = [&](uint32_t v) {
+			if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
+			if (v < own_first) {   // (rare: a vertex named explicitly) older than the span: only with its counter -- on the snapshot's border, or listed with it
+				if (!older_known) {
+					older_known = true;
+					if (seed) { older.assign(seed->snap->vtx.begin(), seed->snap->vtx.end()); for (const auto &c : seed->snap->counters) older.push_back(c.first); }
+					std::sort(older.begin(), older.end());
+				}
+				if (!std::binary_search(older.begin(), older.end(), v)) throw Error(HRY_E_FORMAT, "corrupt stream (restart point names an older vertex without its counter)");
+			}
+			return v;
+		};
+		auto fresh = [&]() { if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)"); return next_id++; };
+		if (resume) resume = false;   // (inside the component the span before this one ended in)
+		else {
+		if (!stop_mid && stop_face != NONE32 && face >= stop_face) break;
 		const uint32_t iop = rbyte(0);
 		if (iop == I_EOM) { eom = true; break; }
-		const uint32_t seg_first_id = next_id;
 		comp_first.push_back(seg_first_id);
-		const uint32_t comp_idx = (uint32_t)comp_first.size() - 1;
-		auto depends_on = [&](uint32_t vid) { if (vid < seg_first_id) refs.push_back({ comp_idx, vid }); };
-		auto chk = [&](uint32_t v) { if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)"); return v; };
-		auto fresh = [&]() { if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)"); return next_id++; };
+		comp_idx = (uint32_t)comp_first.size() - 1;
 		uint32_t a = 0, b = 0, c = 0;
 		switch (iop) {   // decoder.h:46-77
 		case I_INIT: a = fresh(); b = fresh(); c = fresh(); break;
@@ -515,8 +611,19 @@ bool replay_triangles(Mesh &m, const PlaneView *conn, uint16_t *seen, uint32_t *
 			append(parts.back(), make(b, e1));
 			append(parts.back(), make(c, e2));
 		}
+		}
 
 		while (!parts.empty()) {
+			if (face >= stop_at) {   // the span ends here, inside the component: its border goes to whoever joins the spans
+				if (end) {
+					end->parts.clear(); end->vtx.clear(); end->a.clear(); end->seen.clear();
+					for (const Part &q : parts) {
+						end->parts.push_back(q.size << 1 | (q.edge_begin ? 1u : 0u));
+						for (int32_t i = q.head; i >= 0; i = P[i].next) { end->vtx.push_back(P[i].v); end->a.push_back(P[i].a); end->seen.push_back((uint8_t)std::min<uint32_t>(seen[P[i].v], 9u)); }
+					}
+				}
+				goto stopped;
+			}
 			if (LIVE && face - face_pub >= interval) { live->publish(face, he, next_id, false); he_pub = live->he_pub; face_pub = live->face_pub; }
 			Part *T = &parts.back();
 			if (T->size < 2) throw Error(HRY_E_FORMAT, "corrupt stream (border part)");
@@ -642,7 +749,12 @@ bool replay_triangles(Mesh &m, const PlaneView *conn, uint16_t *seen, uint32_t *
 			}
 		}
 	}
+stopped:
 	cur.next_id = next_id; cur.face = face; cur.he = he;
+	if (cur_out) {
+		for (int k = 0; k < 13; ++k) cur_out[k] = rc[k];
+		for (int k = 0; k < 8; ++k) cur_out[13 + k] = (cur0 ? cur0[13 + k] : 0) + (size_t)(opc[k] - opl[k].data());
+	}
 	return eom;
 }
 

@@ -2,6 +2,7 @@
 #include "cbm_replay.hpp"
 
 #include <cstring>
+#include <sys/mman.h>
 
 #include <atomic>
 #include <unordered_map>
@@ -38,8 +39,12 @@ struct Planes {
 // gate's neighbours are loaded only by the operations that use them; a polygon's half-edges are initialised when its first
 // triangle arrives and its fan is continued by counting (cbm/decoder.h:133-197).  Same checks against a corrupt stream, same
 // results as replay_span (the tests run both).
+// Round 6: stop_mid -- the span ends inside a component, between two operations with the polygon in hand complete, as soon as
+// stop_face faces exist (`end` receives the border); seed -- it starts inside one, from a border snapshot of the directory
+// (cbm_replay.hpp BorderSeed; seen_shared then is the span's OWN array, for every vertex it touches).
 bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order_v, ReplayCursor &cur, uint32_t stop_face, uint32_t own_first,
-                     const RestartCounters &old_counts, std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs)
+                     const RestartCounters &old_counts, std::vector<uint32_t> &comp_first, std::vector<std::pair<uint32_t, uint32_t>> &refs,
+                     bool stop_mid = false, const BorderSeed *seed = nullptr, BorderEnd *end = nullptr)
 {
 	using namespace replay_detail;
 	struct Node { uint32_t v, a; int32_t prev, next; };
@@ -68,7 +73,12 @@ bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order
 	// order counters: the span's own vertices in the shared array, older ones in a private map seeded by the restart point
 	std::unordered_map<uint32_t, uint16_t> old_seen;
 	for (const auto &c : old_counts) old_seen.emplace(c.first, (uint16_t)c.second);
-	auto seen = [&](uint32_t v) -> uint16_t& { return v >= own_first ? seen_shared[v] : old_seen.find(v)->second; };
+	const bool own_array = seed != nullptr;   // (a span that starts inside a component counts in an array of its own; old_seen: which older vertices it may name)
+	if (seed) {
+		for (size_t j = 0; j < seed->snap->vtx.size(); ++j) { old_seen.emplace(seed->snap->vtx[j], 0); seen_shared[seed->snap->vtx[j]] = seed->snap->seen[j]; }
+		for (const auto &c : seed->snap->counters) { old_seen.emplace(c.first, 0); seen_shared[c.first] = (uint16_t)c.second; }
+	}
+	auto seen = [&](uint32_t v) -> uint16_t& { return own_array || v >= own_first ? seen_shared[v] : old_seen.find(v)->second; };
 	auto chk = [&](uint32_t v) {
 		if (v >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex id)");
 		if (v < own_first && !old_seen.count(v)) throw Error(HRY_E_FORMAT, "corrupt stream (restart point names an older vertex without its counter)");
@@ -134,16 +144,32 @@ bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order
 		for (uint32_t i = 3; i < ne; ++i) org[o + i] = 0;
 		return o;
 	};
-	bool eom = false;
+	bool eom = false, resume = false;
+	const uint32_t stop_at = stop_mid ? stop_face : NONE32;
+	uint32_t ntri = 0, curtri = 0, base = 0;
+	if (seed) {   // the border of the snapshot, placeholders for its half-edges
+		size_t j = 0;
+		for (const uint32_t pt : seed->snap->parts) {
+			parts.push_back(Part{ -1, -1, 0, pt & 1u });
+			for (uint32_t q = 0, nq = pt >> 1; q < nq; ++q, ++j) {
+				append(parts.back(), make(seed->snap->vtx[j], seed->sym_base + (uint32_t)j));
+				twin[seed->sym_base + j] = seed->sym_base + (uint32_t)j;
+			}
+		}
+		resume = true;   // (between two polygons: curtri == ntri)
+	}
 	for (;;) {
-		if (stop_face != NONE32 && face >= stop_face) break;
-		const uint32_t iop = rd.iop();
-		if (iop == I_EOM) { eom = true; break; }
 		const uint32_t seg_first_id = next_id;
-		comp_first.push_back(seg_first_id);
-		const uint32_t comp_idx = (uint32_t)comp_first.size() - 1;
+		uint32_t comp_idx = kContinues;
 		auto depends_on = [&](uint32_t vid) { if (vid < seg_first_id) refs.push_back({ comp_idx, vid }); };
 		auto fresh = [&]() { if (next_id >= nv) throw Error(HRY_E_FORMAT, "corrupt stream (vertex count)"); return next_id++; };
+		if (resume) resume = false;
+		else {
+		if (!stop_mid && stop_face != NONE32 && face >= stop_face) break;
+		const uint32_t iop = rd.iop();
+		if (iop == I_EOM) { eom = true; break; }
+		comp_first.push_back(seg_first_id);
+		comp_idx = (uint32_t)comp_first.size() - 1;
 		uint32_t a = 0, b = 0, c = 0;
 		switch (iop) {   // decoder.h:46-77
 		case I_INIT: a = fresh(); b = fresh(); c = fresh(); break;
@@ -158,9 +184,9 @@ bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order
 		}
 		chk(a); chk(b); chk(c);
 		depends_on(a); depends_on(b); depends_on(c);
-		uint32_t ntri = numtri(), curtri = 1;
+		ntri = numtri(); curtri = 1;
 		++seen(a); ++seen(b); ++seen(c);
-		uint32_t base = new_face(ntri);
+		base = new_face(ntri);
 		{
 			const uint32_t e0 = base, e1 = base + 1, e2 = base + 2;
 			org[e0] = a; org[e1] = b; org[e2] = c;
@@ -179,8 +205,19 @@ bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order
 			append(parts.back(), make(b, e1));
 			append(parts.back(), make(c, e2));
 		}
+		}
 
 		while (!parts.empty()) {
+			if (face >= stop_at && curtri == ntri) {   // the span ends here, inside the component
+				if (end) {
+					end->parts.clear(); end->vtx.clear(); end->a.clear(); end->seen.clear();
+					for (const Part &q : parts) {
+						end->parts.push_back(q.size << 1 | (q.edge_begin ? 1u : 0u));
+						for (int32_t i = q.head; i >= 0; i = P[i].next) { end->vtx.push_back(P[i].v); end->a.push_back(P[i].a); end->seen.push_back((uint8_t)std::min<uint32_t>(seen(P[i].v), 9u)); }
+					}
+				}
+				goto stopped;
+			}
 			Part *T = &parts.back();
 			if (T->size < 2) throw Error(HRY_E_FORMAT, "corrupt stream (border part)");
 			const int32_t tn = T->tail, hn = T->head;
@@ -305,12 +342,142 @@ bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order
 			if (lk_prev != NONE32) { twin[lk_prev] = e1; twin[e1] = lk_prev; }                       // CONNBWD / CLOSE: its second edge meets the previous one
 		}
 	}
+stopped:
 	cur.next_id = next_id; cur.face = face; cur.he = he;
 	for (int k = 0; k < 8; ++k) rd.cur[13 + k] = (size_t)(opc[k] - rd.pl[13 + k].data());
 	if (fixed < 0) { rd.cur[11] = (size_t)(nt0 - rd.pl[11].data()); rd.cur[12] = (size_t)(nt1 - rd.pl[12].data()); }
 	return eom;
 }
 }   // namespace
+
+// ---- spans that start inside a component (round 6: border snapshots of the directory) --------------------------------------------
+// An array of triangle counts for ONE such span: it counts at the vertices of the snapshot's border (older than the span, and
+// still being counted at by the spans before it, which run at the same time) and at its own.  The whole index range is mapped,
+// pages come into being where the span touches them -- its own vertices and the border's, which mostly follow each other.
+SeenOfSpan::SeenOfSpan(uint32_t nv)
+{
+	bytes = ((size_t)nv * 2 + 4095) & ~(size_t)4095;
+	if (bytes == 0) bytes = 4096;
+	void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+	if (q == MAP_FAILED) throw Error(HRY_E_INTERNAL, "replay: no address space for a span's counters");
+	(void)madvise(q, bytes, MADV_NOHUGEPAGE);   // (a touched page is a page, not two megabytes of zeros)
+	p = (uint16_t*)q;
+}
+SeenOfSpan::~SeenOfSpan() { if (p) munmap(p, bytes); }
+
+// Every span has run: span k + 1 started from snapshot k + 1 with placeholders for the half-edges of the border's elements, span k
+// stopped there with the border it had -- the same border (checked: parts, vertices, counts), whose half-edges are what the
+// placeholders stood for (possibly placeholders of span k's own start, resolved a step earlier).  What span k + 1 linked a
+// placeholder to sits in the twin array at the placeholder's index: the link goes to the real half-edge, both ways.
+// sym_base[k], n_sym[k]: the placeholders of span k (n_sym 0: it did not start inside a component); ends[k]: its last border
+// (empty: it ended between components).  live: links into the part of the arrays a consumer may have copied are noted as patches.
+void join_spans(Mesh &m, const std::vector<const SnapshotPoint*> &seeds, const std::vector<uint32_t> &sym_base, const std::vector<BorderEnd> &ends, ReplayLive *live)
+{
+	const uint32_t ne = m.declared_ne;
+	uint32_t *twin = m.twin.data();
+	std::vector<uint32_t> real_prev, real;   // what the placeholders of the span before / of this span were
+	for (size_t k = 0; k < seeds.size(); ++k) {
+		real.clear();
+		if (seeds[k]) {
+			if (k == 0) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+			const SnapshotPoint &S = *seeds[k];
+			const BorderEnd &E = ends[k - 1];
+			if (E.parts != S.parts || E.vtx != S.vtx || E.seen != S.seen) throw Error(HRY_E_FORMAT, "corrupt chunked directory (a border snapshot does not match the stream)");
+			real.resize(S.vtx.size());
+			for (size_t j = 0; j < real.size(); ++j) {
+				uint32_t a = E.a[j];
+				if (a >= ne) {   // an element the span before never touched: what it was at ITS start
+					const uint32_t i = a - sym_base[k - 1];
+					if (!seeds[k - 1] || a < sym_base[k - 1] || i >= real_prev.size()) throw Error(HRY_E_INTERNAL, "replay: stray placeholder");
+					a = real_prev[i];
+				}
+				real[j] = a;
+			}
+			for (size_t j = 0; j < real.size(); ++j) {
+				const uint32_t sym = sym_base[k] + (uint32_t)j, t = twin[sym];
+				if (t == sym) continue;   // still on the border when the span ended (or closed onto itself: never -- a border edge meets an edge of a new face)
+				if (t >= ne) throw Error(HRY_E_INTERNAL, "replay: a placeholder linked to a placeholder");
+				twin[real[j]] = t; twin[t] = real[j];
+				if (live) live->link(real[j], t);
+			}
+		}
+		real_prev.swap(real);
+	}
+}
+
+SnapshotSpans::SnapshotSpans(Mesh &mesh, const PlaneView *planes, const std::vector<SnapshotPoint> &points, uint32_t *ov) : m(mesh), conn(planes), snaps(points), order_v(ov)
+{
+	n_spans = snaps.size() + 1;
+	spans.resize(n_spans); seeds.assign(n_spans, nullptr); sym_base.assign(n_spans, 0); ends.resize(n_spans);
+	static const int first_plane[G_COUNT] = { 0, 1, 5, 7, 11 };
+	auto cursors_of = [&](const RestartPoint &r, size_t *cur) {
+		for (int g = 0; g < G_COUNT; ++g) for (int b = 0; b < kGroupBytes[g]; ++b) cur[first_plane[g] + b] = r.n_grp[g];
+		for (int i = 0; i < 8; ++i) cur[13 + i] = r.n_op[i];
+	};
+	for (size_t k = 0; k < n_spans; ++k) {
+		Span &sp = spans[k];
+		for (int p = 0; p < 21; ++p) { sp.cur0[p] = 0; sp.cur1[p] = conn[p].size(); sp.cur_end[p] = 0; }
+		if (k > 0) {
+			const SnapshotPoint &S = snaps[k - 1];
+			const RestartPoint &r = S.at;
+			const uint32_t prev_face = k > 1 ? snaps[k - 2].at.first_face : 0u;
+			if (r.first_face <= prev_face || r.first_face > m.nf || r.first_vertex > m.nv || r.first_halfedge > m.declared_ne || !S.counters.empty())
+				throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshots)");
+			sp.cur.next_id = r.first_vertex; sp.cur.face = r.first_face; sp.cur.he = r.first_halfedge;
+			cursors_of(r, sp.cur0);
+			for (int p = 0; p < 21; ++p) if (sp.cur0[p] > conn[p].size() && !((p == 11 || p == 12) && conn[p].empty())) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshots)");
+			seeds[k] = &S;
+			sym_base[k] = (uint32_t)(m.declared_ne + n_sym);
+			n_sym += S.vtx.size();
+			sp.seed = BorderSeed{ &S, sym_base[k] };
+		}
+		if (k + 1 < n_spans) { sp.stop_face = snaps[k].at.first_face; sp.stop_mid = true; cursors_of(snaps[k].at, sp.cur1); }
+	}
+	if ((uint64_t)m.declared_ne + n_sym >= 0xffffffffull) throw Error(HRY_E_UNSUPPORTED, "border snapshots: the placeholders do not fit behind the half-edges");
+	m.twin.resize((size_t)m.declared_ne + n_sym);
+}
+void SnapshotSpans::start(unsigned n_threads)
+{
+	const void *node = callers_node_cpus();
+	const size_t nt = std::min<size_t>(std::max(1u, n_threads), n_spans - 1);
+	helpers.reserve(nt);
+	for (size_t t = 0; t < nt; ++t) helpers.emplace_back([this, node] {
+		try {
+			stay_on_node(node);
+			for (;;) {
+				{ std::lock_guard<std::mutex> g(mu); if (failed) return; }
+				const size_t k = next.fetch_add(1, std::memory_order_relaxed);
+				if (k >= n_spans) return;
+				Span &sp = spans[k];
+				SeenOfSpan own(m.nv);
+				sp.eom = replay_triangles<false>(m, conn, own.p, order_v, sp.cur, sp.first, sp.refs, nullptr, sp.cur0, sp.cur1, sp.stop_face, sp.stop_mid, &sp.seed, &ends[k], sp.cur_end);
+			}
+		} catch (...) { std::lock_guard<std::mutex> g(mu); if (!failed) failed = std::current_exception(); }
+	});
+}
+SnapshotSpans::~SnapshotSpans() { next.store(n_spans, std::memory_order_relaxed); for (auto &h : helpers) if (h.joinable()) h.join(); }
+void SnapshotSpans::finish(ReplayCursor &cur, const size_t *cur_end0, BorderEnd &&end0, bool eom0, ReplayLive *live)
+{
+	for (auto &h : helpers) if (h.joinable()) h.join();
+	if (failed) std::rethrow_exception(failed);
+	spans[0].cur = cur; spans[0].eom = eom0;
+	for (int p = 0; p < 21; ++p) spans[0].cur_end[p] = cur_end0[p];
+	ends[0] = std::move(end0);
+	for (size_t k = 0; k < n_spans; ++k) {   // a stretch ends exactly where the next one starts, in every counter
+		const Span &sp = spans[k];
+		if (k + 1 == n_spans) {
+			if (!sp.eom || sp.cur.face != m.nf || sp.cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
+			break;
+		}
+		const RestartPoint &r = snaps[k].at;
+		bool ok = !sp.eom && sp.cur.face == r.first_face && sp.cur.next_id == r.first_vertex && sp.cur.he == r.first_halfedge && !ends[k].parts.empty();
+		for (int p = 0; p < 21 && ok; ++p) if (p != 11 && p != 12) ok = sp.cur_end[p] == spans[k + 1].cur0[p];   // (triangles: no counts of triangles per polygon)
+		if (!ok) throw Error(HRY_E_FORMAT, "corrupt chunked directory (a border snapshot does not match the stream)");
+	}
+	join_spans(m, seeds, sym_base, ends, live);
+	m.twin.resize(m.declared_ne);
+	cur = spans.back().cur;
+}
 
 // planes: 21 connectivity planes in container order.  Fills m.face_off / org / twin and returns the decode order
 // (one half-edge per vertex; vertex ids are assigned in this order, cbm/decoder.h:48-75,145).
@@ -321,15 +488,18 @@ bool replay_polygons(Mesh &m, Planes &rd, uint16_t *seen_shared, uint32_t *order
 // older vertices on its private copy of their counters, so every span runs on its own host thread.
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
-                       OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span)
+                       OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span,
+                       const std::vector<SnapshotPoint> *snaps_in)
 {
 	using replay_detail::NONE32;
+	static const std::vector<SnapshotPoint> no_snaps;
+	const std::vector<SnapshotPoint> &snaps = snaps_in && !getenv("HRY_NO_SNAPSHOT_REPLAY") && !getenv("HRY_GENERIC_REPLAY") ? *snaps_in : no_snaps;
 	int ndeg = 0, onlydeg = 0;
 	for (size_t d = 0; d < m.have_degree.size(); ++d) if (m.have_degree[d]) { ++ndeg; onlydeg = (int)d; }
 	const int fixed_numtri = ndeg <= 1 ? onlydeg - 2 : -1;
 	unsigned n_threads = host_threads();
 	if (const char *e = getenv("HRY_REPLAY_THREADS")) { const int v = atoi(e); if (v > 0) n_threads = (unsigned)v; }   // (development: the spans' threads beside the uploaders')
-	if (restarts.empty() || n_threads < 2 || m.nf < parallel_min_faces() || counters.size() != restarts.size()) {
+	if ((restarts.empty() && snaps.empty()) || n_threads < 2 || m.nf < parallel_min_faces() || counters.size() != restarts.size()) {
 		if (fixed_numtri == 1 && !getenv("HRY_GENERIC_REPLAY")) {
 			// triangles only: the lean loop (cbm_replay.hpp: replay_triangles), same results
 			m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;
@@ -378,33 +548,67 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 		cut_border_replay_with(m, rd, order_v, seg_start, seg_level);
 		return;
 	}
-	// spans: [start state, stop face); the directory must be strictly increasing in faces and consistent in every counter
-	const size_t ns = restarts.size() + 1;
-	struct Span { ReplayCursor cur; uint32_t stop_face; Planes rd; std::vector<uint32_t> first; std::vector<std::pair<uint32_t, uint32_t>> refs; bool eom = false; };
+	// spans: [start state, stop face); the points of both kinds in stream order -- faces ascending, and of a snapshot and a restart
+	// point at the same face the snapshot comes first (it lies inside the component whose last operations make no face)
+	struct Point { const RestartPoint *r; const RestartCounters *c; const SnapshotPoint *s; };
+	std::vector<Point> pts;
+	{
+		size_t i = 0, j = 0;
+		while (i < restarts.size() || j < snaps.size()) {
+			const bool take_snap = j < snaps.size() && (i == restarts.size() || snaps[j].at.first_face <= restarts[i].first_face);
+			if (take_snap) { pts.push_back(Point{ &snaps[j].at, &snaps[j].counters, &snaps[j] }); ++j; }
+			else { pts.push_back(Point{ &restarts[i], &counters[i], nullptr }); ++i; }
+		}
+	}
+	const size_t ns = pts.size() + 1;
+	struct Span {
+		ReplayCursor cur; uint32_t stop_face; bool stop_mid = false; Planes rd; size_t cur1[21]; std::vector<uint32_t> first; std::vector<std::pair<uint32_t, uint32_t>> refs; bool eom = false;
+		BorderSeed seed; uint32_t own_first = 0, f0 = 0, h0 = 0, v0 = 0;
+	};
 	std::vector<Span> spans(ns);
+	std::vector<const SnapshotPoint*> seeds(ns, nullptr);
+	std::vector<uint32_t> sym_base(ns, 0);
+	std::vector<BorderEnd> ends(ns);
+	uint64_t n_sym = 0;
+	static const int first_plane[G_COUNT] = { 0, 1, 5, 7, 11 };
+	auto cursors_of = [&](const RestartPoint &r, size_t *cur) {
+		for (int g = 0; g < G_COUNT; ++g) for (int b = 0; b < kGroupBytes[g]; ++b) cur[first_plane[g] + b] = r.n_grp[g];
+		for (int i = 0; i < 8; ++i) cur[13 + i] = r.n_op[i];
+	};
 	for (size_t k = 0; k < ns; ++k) {
 		Span &sp = spans[k];
 		sp.rd = Planes{ conn_planes, { 0 }, fixed_numtri };
 		if (k > 0) {
-			const RestartPoint &r = restarts[k - 1];
-			const uint32_t prev_face = k > 1 ? restarts[k - 2].first_face : 0u;
-			if (r.first_face <= prev_face || r.first_face >= m.nf || r.first_vertex > m.nv || r.first_halfedge > m.declared_ne)
+			const RestartPoint &r = *pts[k - 1].r;
+			const uint32_t prev_face = k > 1 ? pts[k - 2].r->first_face : 0u;
+			// (a snapshot may share its face count with the restart point behind it, never with another snapshot or the point before it)
+			const bool ordered = pts[k - 1].s ? r.first_face > prev_face : (r.first_face > prev_face || (k > 1 && pts[k - 2].s && r.first_face == prev_face));
+			if (!ordered || r.first_face == 0 || r.first_face > m.nf || (r.first_face == m.nf && !pts[k - 1].s) || r.first_vertex > m.nv || r.first_halfedge > m.declared_ne)
 				throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart points)");
-			for (const auto &c : counters[k - 1]) if (c.first >= r.first_vertex) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart counters)");
+			for (const auto &c : *pts[k - 1].c) if (c.first >= r.first_vertex) throw Error(HRY_E_FORMAT, "corrupt chunked directory (restart counters)");
 			sp.cur.next_id = r.first_vertex; sp.cur.face = r.first_face; sp.cur.he = r.first_halfedge;
-			static const int first_plane[G_COUNT] = { 0, 1, 5, 7, 11 };
-			for (int g = 0; g < G_COUNT; ++g) for (int b = 0; b < kGroupBytes[g]; ++b) sp.rd.cur[first_plane[g] + b] = r.n_grp[g];
-			for (int i = 0; i < 8; ++i) sp.rd.cur[13 + i] = r.n_op[i];
+			sp.own_first = r.first_vertex;
+			cursors_of(r, sp.rd.cur);
+			if (pts[k - 1].s) {
+				seeds[k] = pts[k - 1].s;
+				sym_base[k] = (uint32_t)(m.declared_ne + n_sym);
+				n_sym += pts[k - 1].s->vtx.size();
+				sp.seed = BorderSeed{ pts[k - 1].s, sym_base[k] };
+			}
 		}
-		sp.stop_face = k + 1 < ns ? restarts[k].first_face : NONE32;
+		sp.stop_face = k + 1 < ns ? pts[k].r->first_face : NONE32;
+		sp.stop_mid = k + 1 < ns && pts[k].s != nullptr;
+		if (k + 1 < ns) cursors_of(*pts[k].r, sp.cur1);
+		else for (int p = 0; p < 21; ++p) sp.cur1[p] = conn_planes[p].size();
 	}
+	if ((uint64_t)m.declared_ne + n_sym >= 0xffffffffull) throw Error(HRY_E_UNSUPPORTED, "border snapshots: the placeholders do not fit behind the half-edges");
 	const bool trace = getenv("HRY_TRACE") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[hry replay] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	if (trace) fprintf(stderr, "[hry replay] %zu spans\n", ns);
 	m.face_off.resize((size_t)m.nf + 1); m.face_off[0] = 0;   // every entry is written before it is read (BigVec: no fill)
 	m.org.resize(m.declared_ne);
-	m.twin.resize(m.declared_ne);
+	m.twin.resize((size_t)m.declared_ne + n_sym);   // (behind the half-edges: the placeholders of the spans that start inside a component)
 	// (pooled arrays, zeroed by the helper threads: the two fills were 3 of the 4.3 ms in front of the spans on the 12.6 M-triangle share)
 	order_v.clear(); order_v.resize(m.nv);
 	BigVec<uint16_t> seen;
@@ -422,8 +626,9 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 			if (!sp.eom || sp.cur.face != m.nf || sp.cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
 			return;
 		}
-		const RestartPoint &r = restarts[k];
+		const RestartPoint &r = *pts[k].r;
 		bool ok = !sp.eom && sp.cur.face == r.first_face && sp.cur.next_id == r.first_vertex && sp.cur.he == r.first_halfedge;
+		ok = ok && (ends[k].parts.empty() == (pts[k].s == nullptr));   // (it stopped inside a component exactly where a snapshot says so)
 		for (int p = 0; p < 21 && ok; ++p) {
 			size_t want = p == 0 ? r.n_grp[0] : p < 5 ? r.n_grp[1] : p < 7 ? r.n_grp[2] : p < 11 ? r.n_grp[3] : p < 13 ? r.n_grp[4] : r.n_op[p - 13];
 			if (fixed_numtri >= 0 && (p == 11 || p == 12)) continue;   // numtri is not stored for a single polygon degree
@@ -439,20 +644,49 @@ void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<
 			if (k >= ns) break;
 			Span &sp = spans[k];
 			const uint32_t f0 = sp.cur.face, h0 = sp.cur.he, v0 = sp.cur.next_id;
-			if (lean) sp.eom = replay_polygons(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
-			else sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, k ? sp.cur.next_id : 0u, k ? counters[k - 1] : none, sp.first, sp.refs);
+			sp.f0 = f0; sp.h0 = h0; sp.v0 = v0;
+			const RestartCounters &old_counts = k && !seeds[k] ? *pts[k - 1].c : none;
+			std::unique_ptr<SeenOfSpan> own;   // (a span that starts inside a component counts in an array of its own)
+			if (seeds[k]) own.reset(new SeenOfSpan(m.nv));
+			uint16_t *sn = own ? own->p : seen.data();
+			// triangles: the lean loop where the span needs no counters of older vertices from a table (none named, or all of them in its own array)
+			if (lean && fixed_numtri == 1 && old_counts.empty()) {
+				size_t cur_end[21];
+				sp.eom = replay_triangles<false>(m, conn_planes, sn, order_v.data(), sp.cur, sp.first, sp.refs, nullptr, sp.rd.cur, sp.cur1, sp.stop_face, sp.stop_mid,
+				                                 seeds[k] ? &sp.seed : nullptr, &ends[k], cur_end);
+				for (int p = 0; p < 21; ++p) sp.rd.cur[p] = cur_end[p];
+			}
+			else if (lean) sp.eom = replay_polygons(m, sp.rd, sn, order_v.data(), sp.cur, sp.stop_face, sp.own_first, old_counts, sp.first, sp.refs, sp.stop_mid, seeds[k] ? &sp.seed : nullptr, &ends[k]);
+			else sp.eom = replay_span(m, sp.rd, seen.data(), order_v.data(), sp.cur, sp.stop_face, sp.own_first, old_counts, sp.first, sp.refs);
 			check_end(k);
-			if (on_span) on_span->span((uint32_t)k, (uint32_t)ns, f0, sp.cur.face, h0, sp.cur.he, v0, sp.cur.next_id, sp.first.data(), (uint32_t)sp.first.size());
+			if (trace) fprintf(stderr, "[hry replay] %8.2f ms    span %zu done (faces %u .. %u%s)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), k, f0, sp.cur.face, seeds[k] ? ", from a border snapshot" : "");
+			// (a span next to a snapshot is not final before the spans are joined: nobody is told)
+			if (on_span && !seeds[k] && !sp.stop_mid) on_span->span((uint32_t)k, (uint32_t)ns, f0, sp.cur.face, h0, sp.cur.he, v0, sp.cur.next_id, sp.first.data(), (uint32_t)sp.first.size(), false);
 		}
 	});
 	mark("spans replayed");
+	if (n_sym) {
+		join_spans(m, seeds, sym_base, ends, nullptr);
+		m.twin.resize(m.declared_ne);
+		mark("spans joined");
+		// ... and now the spans next to a snapshot are final too
+		if (on_span) for (size_t k = 0; k < ns; ++k) {
+			const Span &sp = spans[k];
+			if (seeds[k] || sp.stop_mid) on_span->span((uint32_t)k, (uint32_t)ns, sp.f0, sp.cur.face, sp.h0, sp.cur.he, sp.v0, sp.cur.next_id, sp.first.data(), (uint32_t)sp.first.size(), sp.stop_mid);
+		}
+	}
 	// the component table and the dependency levels of the reconstruction
 	seg_start.clear();
 	std::vector<std::pair<uint32_t, uint32_t>> refs;
 	for (size_t k = 0; k < ns; ++k) {
 		const uint32_t base = (uint32_t)seg_start.size();
 		seg_start.insert(seg_start.end(), spans[k].first.begin(), spans[k].first.end());
-		for (const auto &r : spans[k].refs) refs.push_back({ base + r.first, r.second });
+		for (const auto &r : spans[k].refs) {
+			if (r.first != kContinues) { refs.push_back({ base + r.first, r.second }); continue; }
+			// named inside the component the span before ended in: a dependency only if the vertex is older than that component
+			if (base == 0) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+			if (r.second < seg_start[base - 1]) refs.push_back({ base - 1, r.second });
+		}
 	}
 	replay_levels(seg_start, refs, seg_level);
 	const uint32_t n_ids = spans.back().cur.next_id;

@@ -319,8 +319,43 @@ struct Emitter {
 		}
 	}
 	uint32_t faces_coded() const { return (uint32_t)(of_cur - of_begin); }
+	// ---- border snapshots (host.hpp BorderSnapshot): restart points inside a component
+	uint32_t snaps_in_component = 0;
+	// the border as it stands between two operations: parts from the bottom of the stack, elements head -> tail; vertices in the
+	// decoder's numbering (sent), triangle counts clamped at 9 (seen == nullptr: the mesh's own vertex numbers into s.orig instead,
+	// for the thread that holds the counts)
+	static void snapshot_border(const Border &cb, const uint32_t *sent, const uint16_t *seen, BorderSnapshot &s)
+	{
+		size_t n = 0;
+		for (const Border::Part &q : cb.parts) n += q.size;
+		s.parts.clear(); s.vtx.clear(); s.seen.clear(); s.orig.clear();
+		s.parts.reserve(cb.parts.size()); s.vtx.reserve(n);
+		if (seen) s.seen.reserve(n); else s.orig.reserve(n);
+		for (const Border::Part &q : cb.parts) {
+			s.parts.push_back(q.size << 1 | (q.edge_begin ? 1u : 0u));
+			for (int32_t i = q.head; i >= 0; i = cb.P[i].next) {
+				const uint32_t v = cb.P[i].v;
+				s.vtx.push_back(sent[v]);
+				if (seen) s.seen.push_back((uint8_t)std::min<uint32_t>(seen[v], 9u)); else s.orig.push_back(v);
+			}
+		}
+	}
+	// the cursors of a snapshot, RELATIVE to the mark of the component in hand (finish_snapshots makes them absolute when the marks
+	// are final: a walk on several threads numbers them afterwards).  ops_in_component: operations per class since that mark;
+	// nt_now: the triangle counts' cursor where the caller keeps it in a local
+	void snapshot_cursors(BorderSnapshot &s, uint32_t next_id, uint32_t faces_in_component, uint32_t halfedges_in_component, const uint32_t *ops_in_component, const uint32_t *nt_now)
+	{
+		const ComponentMark &mk = w.marks.back();
+		s.mark = (uint32_t)w.marks.size() - 1;
+		for (int g = 0; g < G_COUNT; ++g) s.n_grp[g] = (uint32_t)w.grp_val[g].size() - mk.n_grp[g];
+		s.n_grp[G_NUMTRI] = (uint32_t)(nt_now - nt_begin) - mk.n_grp[G_NUMTRI];
+		for (int i = 0; i < 8; ++i) s.n_op[i] = ops_in_component[i];
+		s.first_vertex = next_id - mk.first_vertex; s.first_face = faces_in_component; s.first_halfedge = halfedges_in_component;
+		++snaps_in_component;
+	}
 	void mark_component(uint32_t next_id)
 	{
+		snaps_in_component = 0;
 		if (!w.marks.empty()) w.marks.back().min_ref = min_ref;
 		ComponentMark k;
 		for (int g = 0; g < G_COUNT; ++g) k.n_grp[g] = (uint32_t)w.grp_val[g].size();
@@ -338,7 +373,7 @@ struct Emitter {
 	{
 		group(G_VERT, v);
 		if (v < min_ref) min_ref = v;
-		if (!w.marks.empty()) w.named.push_back(NamedVertex{ (uint32_t)w.marks.size() - 1, v, count });
+		if (!w.marks.empty()) w.named.push_back(NamedVertex{ (uint32_t)w.marks.size() - 1, v, count, snaps_in_component });
 	}
 	void elem(int i) { uint32_t c = (uint32_t)i; group(G_ELEM, (c << 1) ^ ((c >> 31) ? 0xffffffffu : 0u)); }   // transform.h:25-30
 	void part(int p) { group(G_PART, (uint32_t)(uint16_t)p); }
@@ -394,6 +429,9 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 	auto take = [&](uint32_t face) { gone[face] = Gone::yes; ++consumed; em.halfedges += foff[face + 1] - foff[face]; };
 
 	em.mark_component(next_id);
+	const uint32_t consumed0 = consumed, halfedges0 = em.halfedges;
+	const uint32_t snap_every = w.snapshot_faces;
+	uint64_t next_snap = snap_every ? snap_every : ~0ull;   // (faces of this component at which the border is noted: host.hpp BorderSnapshot)
 	take(f);
 	uint32_t e0 = foff[f], e1 = nxt(e0), e2 = nxt(e1);
 	uint32_t a = org[e0], b = org[e1], c = org[e2];
@@ -415,6 +453,14 @@ static void walk_component(Mesh &m, WalkState &st, const uint32_t *eface_tab, ui
 
 	// ---- grow until the border of this component is exhausted (encoder.h:133-214)
 	while (!cb.parts.empty()) {
+		if (consumed - consumed0 >= next_snap && curtri == ntri) {
+			next_snap += snap_every;
+			uint32_t ops[8];
+			for (int i = 0; i < 8; ++i) ops[i] = em.n_op[i] - w.marks.back().n_op[i];
+			w.snapshots.emplace_back();
+			Emitter::snapshot_border(cb, sent, seen, w.snapshots.back());
+			em.snapshot_cursors(w.snapshots.back(), next_id, consumed - consumed0, em.halfedges - halfedges0, ops, em.nt_cur);
+		}
 		Border::Part &pt = cb.top();
 		const uint32_t v0 = cb.N(pt.tail).v, v1 = cb.N(pt.head).v;
 		const uint32_t gate = cb.N(pt.tail).a;
@@ -552,7 +598,15 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 		cb.start(a, e0, b, e1, c, e2);
 	}
 	Border::Node *P = cb.P;
+	const uint32_t snap_every = MODEL ? 0u : w.snapshot_faces;
+	uint64_t next_snap = snap_every ? (uint64_t)consumed_io + snap_every : ~0ull;   // (host.hpp BorderSnapshot)
 	while (!cb.parts.empty()) {
+		if (consumed >= next_snap) {
+			next_snap += snap_every;
+			w.snapshots.emplace_back();
+			Emitter::snapshot_border(cb, sent, seen, w.snapshots.back());
+			em.snapshot_cursors(w.snapshots.back(), next_id, consumed - consumed_io, 3u * (consumed - consumed_io), n_op, em.nt_cur);
+		}
 		Border::Part &pt = cb.parts.back();
 		const int32_t tn = pt.tail, hn = pt.head;
 		const uint32_t v0 = P[tn].v, gate = P[tn].a, v1 = P[hn].v;
@@ -645,7 +699,7 @@ static void walk_component_tri(Mesh &m, WalkState &st, uint32_t f, Border &cb, E
 // triangles on the boxes' EPYC 9575F before B existed (a ring that stays in its cache; 6.9 with one that does not).
 // HRY_WALK_SPLIT=0: the one-thread loop.
 struct WalkTrace {
-	enum { T_TRI = 0, T_BORDER = 1, T_START = 2, T_NEXTID = 3, T_ELEM = 4, T_PART = 5 };   // code in bits 8..15 of the high word, operation in bits 0..7
+	enum { T_TRI = 0, T_BORDER = 1, T_START = 2, T_NEXTID = 3, T_ELEM = 4, T_PART = 5, T_SNAP = 6 };   // code in bits 8..15 of the high word, operation in bits 0..7
 	// a RING of kRing records (8 MB: stays in the two cores' shared cache; until late in round 5 one array for the whole walk,
 	// 64 MB per million triangles from the block pool -- whose blocks the decode between two encodes may have taken, and then the
 	// walk paid the page faults of a fresh one: one step in twenty took 10 - 18 ms instead of 6).  The walking thread waits when it
@@ -728,7 +782,21 @@ static void walk_component_tri_a(Mesh &m, WalkState &st, uint32_t f, Border &cb,
 		cb.start(a, e0, b, e1, c, e2);
 	}
 	Border::Node *P = cb.P;
+	const uint32_t snap_every = w.snapshot_faces;
+	uint64_t next_snap = snap_every ? (uint64_t)consumed_io + snap_every : ~0ull;   // (host.hpp BorderSnapshot)
 	while (!cb.parts.empty()) {
+		if (consumed >= next_snap) {
+			// the border is this thread's, the triangle counts and the cursors are the expanding thread's: it completes the
+			// snapshot when it gets to the record (the array does not move: walk_sequential reserved it)
+			next_snap += snap_every;
+			if (w.snapshots.size() == w.snapshots.capacity()) throw Error(HRY_E_INTERNAL, "walk: more border snapshots than faces allow");
+			const uint32_t idx = (uint32_t)w.snapshots.size();
+			w.snapshots.emplace_back();
+			BorderSnapshot &sn = w.snapshots.back();
+			Emitter::snapshot_border(cb, sent, nullptr, sn);
+			sn.first_vertex = next_id - next_id_io; sn.first_face = consumed - consumed_io; sn.first_halfedge = 3u * (consumed - consumed_io);
+			put(WalkTrace::make(idx, WalkTrace::T_SNAP, 0));
+		}
 		Border::Part &pt = cb.parts.back();
 		const int32_t tn = pt.tail, hn = pt.head;
 		const uint32_t gate = P[tn].a;
@@ -808,6 +876,7 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 	uint16_t *seen = st.seen.data();
 	const uint64_t *rec = tr.rec.data();
 	const size_t rmask = tr.mask;
+	BorderSnapshot *const snaps = em.w.snapshots.data();   // (reserved before the walk: the walking thread appends, the array stays where it is)
 	OpByte *opc = em.op_cur;
 	uint32_t *ovc = em.ov_cur, *ofc = em.of_cur;
 	uint32_t n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, n_ops = 0, faces = 0;
@@ -887,6 +956,14 @@ static void walk_trace_expand(const Mesh &m, WalkState &st, Emitter &em, WalkTra
 				*ofc++ = e0;
 				++seen[va]; ++seen[vb]; ++seen[vc];
 				++faces;
+			} else if (code == WalkTrace::T_SNAP) {
+				// a border snapshot of the walking thread: the counts at its vertices and the cursors are this thread's
+				BorderSnapshot &sn = snaps[a];
+				sn.seen.reserve(sn.orig.size());
+				for (const uint32_t v : sn.orig) sn.seen.push_back((uint8_t)std::min<uint32_t>(seen[v], 9u));
+				std::vector<uint32_t>().swap(sn.orig);
+				if (sn.first_face != faces) throw Error(HRY_E_INTERNAL, "walk trace: a snapshot out of step");
+				em.snapshot_cursors(sn, em.w.marks.back().first_vertex + sn.first_vertex, sn.first_face, sn.first_halfedge, n_op, em.nt_cur);
 			} else throw Error(HRY_E_INTERNAL, "walk trace: stray record");
 		}
 		tr.tail.store(pos, std::memory_order_release);   // (everything below pos has been read: the walking thread may write over it)
@@ -957,7 +1034,15 @@ static void walk_component_poly(Mesh &m, WalkState &st, const uint32_t *eface_ta
 	}
 	uint32_t *ntc = em.nt_cur, *ntp = em.ntp_cur;
 	Border::Node *P = cb.P;
+	const uint32_t snap_every = w.snapshot_faces, halfedges0 = em.halfedges;
+	uint64_t next_snap = snap_every ? (uint64_t)consumed_io + snap_every : ~0ull;   // (host.hpp BorderSnapshot)
 	while (!cb.parts.empty()) {
+		if (consumed >= next_snap && curtri == ntri) {
+			next_snap += snap_every;
+			w.snapshots.emplace_back();
+			Emitter::snapshot_border(cb, sent, seen, w.snapshots.back());
+			em.snapshot_cursors(w.snapshots.back(), next_id, consumed - consumed_io, halfedges - halfedges0, n_op, ntc);
+		}
 		Border::Part &pt = cb.parts.back();
 		const int32_t tn = pt.tail, hn = pt.head;
 		const uint32_t v0 = P[tn].v, gate = P[tn].a, v1 = P[hn].v;
@@ -1054,6 +1139,18 @@ static void walk_component_poly(Mesh &m, WalkState &st, const uint32_t *eface_ta
 	next_id_io = next_id; consumed_io = consumed;
 }
 
+// the walk is over, every mark has its final counts: the snapshots' cursors from "since my component's mark" to absolute
+static void finish_snapshots(WalkResult &w)
+{
+	for (BorderSnapshot &s : w.snapshots) {
+		const ComponentMark &mk = w.marks.at(s.mark);
+		for (int g = 0; g < G_COUNT; ++g) s.n_grp[g] += mk.n_grp[g];
+		for (int i = 0; i < 8; ++i) s.n_op[i] += mk.n_op[i];
+		s.first_vertex += mk.first_vertex; s.first_face += mk.first_face; s.first_halfedge += mk.first_halfedge;
+		if (!s.orig.empty() || s.seen.size() != s.vtx.size()) throw Error(HRY_E_INTERNAL, "walk: a border snapshot was left incomplete");
+	}
+}
+
 template <int DEG>
 static void walk_rest_parallel(Mesh &m, WalkState &st, const uint32_t *eface_tab, Emitter &em0, uint32_t first_id, unsigned n_threads);
 template <int DEG>
@@ -1076,6 +1173,8 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	Emitter em(w);
 	em.eval_model = eval_op_model;
 	em.attach((size_t)m.ne() + m.ntri() + 16, m.nv, m.nf);   // every half-edge ends at most one border operation, every triangle one other
+	if (eval_op_model) w.snapshot_faces = 0;   // (the reference stream has no directory to put them in)
+	if (w.snapshot_faces) w.snapshots.reserve(w.snapshots.size() + (size_t)m.nf / w.snapshot_faces + 2);   // (the two-core walk appends while its second thread reads: no growth)
 	mark("(sequential part) start faces and output planes");
 	uint32_t next_id = 0, consumed = 0;
 	const bool count = getenv("HRY_PERF") != nullptr;   // hardware counters of this thread around the first component's walk
@@ -1152,6 +1251,7 @@ static void walk_sequential(Mesh &m, WalkResult &w, const uint32_t *eface_tab, b
 	mark("(sequential part) done");
 	w.n_conn = em.n;
 	for (int i = 0; i < 8; ++i) w.n_op_class[i] = em.n_op[i];
+	finish_snapshots(w);
 }
 
 // ---- several host threads --------------------------------------------------------
@@ -1530,7 +1630,7 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 	const bool nt_pos = w.numtri_coded && w.numtri_positions;
 	if (w.numtri_coded) { w.grp_val[G_NUMTRI].resize(nt0 + (off_f[ncomp] - off_f[0])); if (nt_pos) w.grp_pos[G_NUMTRI].resize(nt0 + (off_f[ncomp] - off_f[0])); }
 	struct Piece {   // what component k left in its thread's arrays
-		const OpByte *ops; uint32_t n_ops, thread, mark, sym0, n_syms, named0, n_named;
+		const OpByte *ops; uint32_t n_ops, thread, mark, sym0, n_syms, named0, n_named, snap0, n_snap;
 		uint32_t g0[G_COUNT], gn[G_COUNT], n_op[8];
 	};
 	std::vector<Piece> piece(ncomp);
@@ -1548,6 +1648,7 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 		Border cb(st.on);
 		PerThread &T = per_thread[t];
 		T.w.numtri_coded = w.numtri_coded;
+		T.w.snapshot_faces = w.snapshot_faces;
 		Emitter em(T.w);
 		em.eval_model = false;
 		em.ov_begin = w.order_v.data(); em.of_begin = w.order_f.data();
@@ -1567,6 +1668,7 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 				}
 				Piece &pc = piece[k];
 				pc.thread = t; pc.mark = (uint32_t)T.w.marks.size(); pc.sym0 = em.n; pc.named0 = (uint32_t)T.w.named.size(); pc.ops = T.cur;
+				pc.snap0 = (uint32_t)T.w.snapshots.size();
 				for (int g = 0; g < G_COUNT; ++g) pc.g0[g] = (uint32_t)T.w.grp_val[g].size();
 				uint32_t nop0[8];
 				for (int i = 0; i < 8; ++i) nop0[i] = em.n_op[i];
@@ -1587,7 +1689,7 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 					throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
 				pc.n_ops = (uint32_t)(em.op_cur - T.cur);
 				T.room -= pc.n_ops; T.cur = em.op_cur;
-				pc.n_syms = em.n - pc.sym0; pc.n_named = (uint32_t)T.w.named.size() - pc.named0;
+				pc.n_syms = em.n - pc.sym0; pc.n_named = (uint32_t)T.w.named.size() - pc.named0; pc.n_snap = (uint32_t)T.w.snapshots.size() - pc.snap0;
 				for (int g = 0; g < G_COUNT; ++g) pc.gn[g] = (uint32_t)T.w.grp_val[g].size() - pc.g0[g];
 				for (int i = 0; i < 8; ++i) pc.n_op[i] = em.n_op[i] - nop0[i];
 			}
@@ -1644,6 +1746,8 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 				const Piece &pc = piece[k];
 				const WalkResult &tw = per_thread[pc.thread].w;
 				for (uint32_t i = 0; i < pc.n_named; ++i) { NamedVertex ev = tw.named[pc.named0 + i]; ev.mark = (uint32_t)(mark0 + k); w.named.push_back(ev); }
+				// (border snapshots: relative to their component's mark until finish_snapshots; this loop is the only writer of both)
+				for (uint32_t i = 0; i < pc.n_snap; ++i) { w.snapshots.push_back(std::move(per_thread[pc.thread].w.snapshots[pc.snap0 + i])); w.snapshots.back().mark = (uint32_t)(mark0 + k); }
 				ComponentMark mk = tw.marks.at(pc.mark);   // first_vertex and min_ref are the walk's
 				for (int g = 0; g < G_COUNT; ++g) mk.n_grp[g] = (uint32_t)off_g[g][k];
 				for (int i = 0; i < 8; ++i) { mk.n_op[i] = nop[i]; nop[i] += pc.n_op[i]; }
@@ -1711,8 +1815,18 @@ static void walk_impl(Mesh &m, WalkResult &w, bool eval_op_model, bool one_seque
 
 }   // namespace
 
+uint32_t snapshot_spacing(uint32_t nf)
+{
+	if (getenv("HRY_NO_SNAPSHOTS")) return 0;
+	if (const char *e = getenv("HRY_SNAPSHOT_FACES")) return (uint32_t)strtoul(e, nullptr, 10);
+	uint32_t sp = kSnapshotMinFaces;
+	while ((uint64_t)sp * 32u < nf) sp <<= 1;
+	return sp;
+}
+
 std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks, const std::vector<NamedVertex> &named,
-                                                std::vector<RestartCounters> &counters)
+                                                std::vector<RestartCounters> &counters, const std::vector<BorderSnapshot> *snaps,
+                                                std::vector<RestartCounters> *snap_counters)
 {
 	std::vector<RestartPoint> out;
 	std::vector<uint32_t> span_of_mark(marks.size(), NONE32);   // restart span of every component (none: before the first point)
@@ -1733,12 +1847,34 @@ std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark>
 		last_face = marks[k].first_face;
 	}
 	// the older vertices a span names, with their counters at the first naming inside the span = at the start of the span (a
-	// vertex is touched only after the component at hand has named it)
+	// vertex is touched only after the component at hand has named it).  A span ends where the next point lies, of either kind:
+	// a naming behind a border snapshot belongs to the span that starts THERE -- which brings the counters of the vertices on its
+	// border along already (they have been counted on since: the naming's counter is not the span's start), so only the others
+	// are listed with it.  Points and namings are in stream order; a snapshot's place is (component, how many the component
+	// had taken before), a restart point's (component, 0), a naming's (component, snapshots its component had taken).
 	counters.assign(out.size(), RestartCounters());
-	std::unordered_set<uint64_t> taken;
+	const size_t n_snaps = snaps ? snaps->size() : 0;
+	if (snap_counters) snap_counters->assign(n_snaps, RestartCounters());
+	std::vector<uint32_t> nth(n_snaps, 0);   // a snapshot's number inside its component, from 1
+	for (size_t i = 0; i < n_snaps; ++i) nth[i] = i && (*snaps)[i - 1].mark == (*snaps)[i].mark ? nth[i - 1] + 1 : 1u;
+	std::vector<std::unordered_set<uint32_t>> on_border(n_snaps);   // (filled when a snapshot's span names its first older vertex)
+	std::unordered_set<uint64_t> taken, taken_snap;
+	size_t si = 0;   // snapshots at or before the naming in hand
 	for (const NamedVertex &ev : named) {
 		if (ev.mark >= marks.size()) continue;
+		while (si < n_snaps && ((*snaps)[si].mark < ev.mark || ((*snaps)[si].mark == ev.mark && nth[si] <= ev.snap))) ++si;
 		const uint32_t sp = span_of_mark[ev.mark];
+		// the restart point's component: the first component of its span
+		const bool snap_later = si > 0 && (sp == NONE32 || (*snaps)[si - 1].first_face > out[sp].first_face);
+		if (snap_later) {
+			const size_t q = si - 1;
+			const BorderSnapshot &S = (*snaps)[q];
+			if (!snap_counters || ev.id >= S.first_vertex) continue;
+			if (on_border[q].empty()) on_border[q].insert(S.vtx.begin(), S.vtx.end());
+			if (on_border[q].count(ev.id)) continue;
+			if (taken_snap.insert(((uint64_t)q << 32) | ev.id).second) (*snap_counters)[q].push_back({ ev.id, ev.count });
+			continue;
+		}
 		if (sp == NONE32 || ev.id >= out[sp].first_vertex) continue;
 		if (taken.insert(((uint64_t)sp << 32) | ev.id).second) counters[sp].push_back({ ev.id, ev.count });
 	}
@@ -1811,6 +1947,7 @@ void cut_border_walk_in_place(Mesh &m, const ComponentAnalysis &part, const uint
 	em.iop(I_EOM);
 	w.n_conn = em.n;
 	for (int i = 0; i < 8; ++i) w.n_op_class[i] = em.n_op[i];
+	finish_snapshots(w);
 }
 
 void op_position_table(const WalkResult &w, std::vector<uint32_t> &thr, std::vector<uint32_t> &cum)

@@ -5,6 +5,7 @@
 #include "host.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 namespace hry {
 namespace {
@@ -210,6 +211,124 @@ size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256]
 		if (v == 255) { need(2); v = (uint32_t)p[k] | ((uint32_t)p[k + 1] << 8); k += 2; }
 		if (v == 0) throw Error(HRY_E_FORMAT, "corrupt chunked directory (prior count)");
 		table[s] = v;
+	}
+	return k;
+}
+
+// ---- border snapshots in the chunked container's directory (host.hpp BorderSnapshot; the oracle restates the form)
+//   u32 spacing, u32 n; per snapshot: 17 u32 like a restart point (flags = 0), u32 n_counters, n_counters x (u32 vertex, u32 counter),
+//   u32 n_parts, u32 n_elements, u32 blob_bytes, blob, zero bytes up to a multiple of four.
+// blob, all numbers as LEB128 varints: per part `size << 1 | edge_begin`; then the elements' vertices as differences from "the
+// vertex before + 1" (before the first element: the snapshot's next vertex), zigzag-folded, in runs -- `length of a run of zeros`,
+// then the non-zero value that ends it (nothing behind the last element); then the triangle counts (0 .. 9) the same way, as
+// differences from the count before (before the first: 3).  Along a border the vertices mostly follow each other and have seen
+// three triangles: a part of a thousand elements is a handful of bytes.
+namespace {
+void put_varint(std::vector<uint8_t> &o, uint64_t v) { while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; } o.push_back((uint8_t)v); }
+uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+int64_t unzigzag(uint64_t z) { return (int64_t)(z >> 1) ^ -(int64_t)(z & 1); }
+template <typename F> void put_runs(std::vector<uint8_t> &o, size_t n, F &&diff)   // diff(i): the i-th value's difference from its prediction
+{
+	for (size_t i = 0; i < n;) {
+		uint64_t run = 0;
+		while (i < n && diff(i) == 0) { ++run; ++i; }
+		put_varint(o, run);
+		if (i < n) { put_varint(o, zigzag(diff(i))); ++i; }
+	}
+}
+struct VarintReader {
+	const uint8_t *p, *end;
+	uint64_t get()
+	{
+		uint64_t v = 0;
+		for (int sh = 0; sh < 64; sh += 7) {
+			if (p == end) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+			const uint8_t b = *p++;
+			v |= (uint64_t)(b & 0x7f) << sh;
+			if (!(b & 0x80)) return v;
+		}
+		throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+	}
+};
+}   // namespace
+
+void write_snapshot_section(uint32_t spacing, const std::vector<BorderSnapshot> &snaps, const std::vector<RestartCounters> &counters, std::vector<uint8_t> &out)
+{
+	auto put32 = [&](uint32_t v) { const uint8_t *q = (const uint8_t*)&v; out.insert(out.end(), q, q + 4); };
+	put32(spacing); put32((uint32_t)snaps.size());
+	std::vector<uint8_t> blob;
+	for (size_t k = 0; k < snaps.size(); ++k) {
+		const BorderSnapshot &S = snaps[k];
+		for (int g = 0; g < G_COUNT; ++g) put32(S.n_grp[g]);
+		for (int i = 0; i < 8; ++i) put32(S.n_op[i]);
+		put32(S.first_vertex); put32(S.first_face); put32(S.first_halfedge); put32(0);
+		const RestartCounters none, &cs = k < counters.size() ? counters[k] : none;
+		put32((uint32_t)cs.size());
+		for (const auto &c : cs) { put32(c.first); put32(c.second); }
+		put32((uint32_t)S.parts.size()); put32((uint32_t)S.vtx.size());
+		blob.clear();
+		for (uint32_t pt : S.parts) put_varint(blob, pt);
+		put_runs(blob, S.vtx.size(), [&](size_t i) { return (int64_t)S.vtx[i] - ((int64_t)(i ? S.vtx[i - 1] : S.first_vertex - 1u) + 1); });
+		put_runs(blob, S.seen.size(), [&](size_t i) { return (int64_t)S.seen[i] - (int64_t)(i ? S.seen[i - 1] : 3); });
+		put32((uint32_t)blob.size());
+		out.insert(out.end(), blob.begin(), blob.end());
+		while (out.size() & 3) out.push_back(0);
+	}
+}
+
+size_t read_snapshot_section(const uint8_t *p, size_t avail, uint32_t nv, uint32_t &spacing, std::vector<SnapshotPoint> &out)
+{
+	size_t k = 0;
+	auto need = [&](size_t n) { if (n > avail - k) throw Error(HRY_E_FORMAT, "truncated chunked directory"); };
+	auto get32 = [&]() { need(4); uint32_t v; memcpy(&v, p + k, 4); k += 4; return v; };
+	spacing = get32();
+	const uint32_t n = get32();
+	if ((uint64_t)n * (kRestartWords * 4 + 16) > avail) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+	out.clear(); out.resize(n);
+	for (uint32_t q = 0; q < n; ++q) {
+		SnapshotPoint &S = out[q];
+		need(sizeof(RestartPoint));
+		memcpy(&S.at, p + k, sizeof(RestartPoint));
+		k += sizeof(RestartPoint);
+		const uint32_t nc = get32();
+		if ((uint64_t)nc * 8 > avail - k) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+		S.counters.resize(nc);
+		for (uint32_t j = 0; j < nc; ++j) { const uint32_t a = get32(), b = get32(); S.counters[j] = { a, b }; }
+		const uint32_t n_parts = get32(), n_elems = get32(), nb = get32();
+		need(nb);
+		// (every element costs at least ... nothing: a run covers any number of them; the bounds are the mesh's)
+		if (n_parts == 0 || n_parts > n_elems || n_elems > (uint64_t)2 * nv + 4) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+		VarintReader rd{ p + k, p + k + nb };
+		S.parts.resize(n_parts);
+		uint64_t total = 0;
+		for (uint32_t i = 0; i < n_parts; ++i) {
+			const uint64_t v = rd.get();
+			if (v >> 1 < 1 || v >> 1 > n_elems) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+			S.parts[i] = (uint32_t)v;
+			total += v >> 1;
+		}
+		if (total != n_elems) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+		S.vtx.resize(n_elems); S.seen.resize(n_elems);
+		for (uint32_t i = 0; i < n_elems;) {
+			const uint64_t run = rd.get();
+			if (run > n_elems - i) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+			for (uint64_t r = 0; r < run; ++r, ++i) S.vtx[i] = (i ? S.vtx[i - 1] : S.at.first_vertex - 1u) + 1u;
+			if (i < n_elems) { S.vtx[i] = (uint32_t)((int64_t)(i ? S.vtx[i - 1] : S.at.first_vertex - 1u) + 1 + unzigzag(rd.get())); ++i; }
+		}
+		for (uint32_t i = 0; i < n_elems; ++i) if (S.vtx[i] >= S.at.first_vertex || S.vtx[i] >= nv) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+		for (uint32_t i = 0; i < n_elems;) {
+			const uint64_t run = rd.get();
+			if (run > n_elems - i) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+			for (uint64_t r = 0; r < run; ++r, ++i) S.seen[i] = i ? S.seen[i - 1] : 3;
+			if (i < n_elems) {
+				const int64_t v = (int64_t)(i ? S.seen[i - 1] : 3) + unzigzag(rd.get());
+				if (v < 0 || v > 9) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+				S.seen[i] = (uint8_t)v; ++i;
+			}
+		}
+		if (rd.p != rd.end) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+		k += nb;
+		while (k & 3) { need(1); ++k; }
 	}
 	return k;
 }

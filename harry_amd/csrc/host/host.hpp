@@ -62,14 +62,38 @@ struct RestartPoint {
 };
 // An explicit naming of a vertex (TRIxxx start, NM operation) with the number of triangles seen at it so far (the "order"
 // the operation planes are split by, models.h:69-72) and the component (index into marks) that names it.
-struct NamedVertex { uint32_t mark, id, count; };
+// snap: how many border snapshots (below) its component had taken when the vertex was named -- 0 = before the first
+struct NamedVertex { uint32_t mark, id, count, snap; };
 // counters a restart point carries: (vertex, order counter at the start of the span) for every older vertex its span names
 typedef std::vector<std::pair<uint32_t, uint32_t>> RestartCounters;
 constexpr uint32_t kRestartFaces = 8192;   // a restart point at the first component start >= this many faces after the previous one
 constexpr uint32_t kRestartWords = G_COUNT + 8 + 4;
+// A restart point INSIDE a connected component (round 6; chunked container, directory extension): the cut-border at the first
+// moment between two operations -- the polygon in hand complete -- at which the component has coded j * snapshot_faces faces,
+// j = 1, 2, ...  What a decoder needs to start replaying there (cbm/decoder.h:27-211, cbm/cutborder.h:49-333): the plane cursors and
+// the next vertex / face / half-edge like any restart point; the parts of the border with their edge_begin flags; of every
+// element the vertex (the decoder's numbering) and how many triangles have been seen at it (it selects the plane the next
+// operation is read from, models.h:101-105; counts from 9 on are one class).  The elements' half-edges are NOT stored: they
+// only ever become twins of edges the span creates, so a decoder replays with placeholders and joins the spans afterwards.
+struct BorderSnapshot {
+	uint32_t mark = 0;                        // the component it lies in (index into WalkResult::marks)
+	uint32_t n_grp[G_COUNT] = { 0, 0, 0, 0, 0 }, n_op[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // symbols consumed: since the component's mark while the
+	uint32_t first_vertex = 0, first_face = 0, first_halfedge = 0;                      // walk runs, absolute once finish_snapshots() has run
+	std::vector<uint32_t> parts;              // bottom of the stack first: size << 1 | edge_begin
+	std::vector<uint32_t> vtx;                // per element, part by part, head -> tail
+	std::vector<uint8_t> seen;                // min(triangles seen at the vertex, 9)
+	std::vector<uint32_t> orig;               // (walk on two cores only: the elements' vertices in the mesh's numbering, until the counts are filled in)
+};
+constexpr uint32_t kSnapshotMinFaces = 1u << 18;
+// spacing of the snapshots for a container that describes nf faces: at least 2^18 faces, and at most some thirty snapshots a mesh
+// (a power of two; 0 = none: HRY_NO_SNAPSHOTS).  HRY_SNAPSHOT_FACES overrides (tests: small meshes)
+uint32_t snapshot_spacing(uint32_t nf);
 // canonical selection, shared by every writer of the container (the oracle restates it)
+// snaps (finished: absolute cursors) / snap_counters: the border snapshots of the walk and, out, per snapshot the older vertices
+// its span names that are not on its border, with their counters
 std::vector<RestartPoint> select_restart_points(const std::vector<ComponentMark> &marks, const std::vector<NamedVertex> &named,
-                                                std::vector<RestartCounters> &counters);
+                                                std::vector<RestartCounters> &counters, const std::vector<BorderSnapshot> *snaps = nullptr,
+                                                std::vector<RestartCounters> *snap_counters = nullptr);
 
 // One byte per cut-border operation: symbol | order class << 3.  A distinct type on purpose: stores through a character
 // type may alias anything, so a plain uint8_t stream makes the compiler reload every pointer of the walk's hot loop after each
@@ -109,6 +133,8 @@ struct WalkResult {
 	bool numtri_positions = true;    // in: fill grp_pos[G_NUMTRI] (one entry per face; only a single symbol sequence needs it)
 	bool twins_changed = false;      // the walk repaired at least one twin (cbm/encoder.h:150,193-198): the device copy is stale
 	std::vector<uint32_t> twin_patches;   // ... at these half-edges (with repetitions); their twins are final when the walk returns
+	uint32_t snapshot_faces = 0;     // in: a border snapshot every so many faces of a component (0: none)
+	std::vector<BorderSnapshot> snapshots;   // in stream order
 };
 
 // per-face / per-vertex marks of the walk.  Not character types (see OpByte above): a byte store in the hot loop would force every
@@ -262,12 +288,16 @@ struct PlaneView {
 // index / n_spans: which span of how many; comp_first[0 .. n_comp): the first vertex of every component the span holds (valid until
 // cut_border_replay returns)
 struct SpanDone {
-	virtual void span(uint32_t index, uint32_t n_spans, uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1, const uint32_t *comp_first, uint32_t n_comp) = 0;
+	// ends_inside: the span stops inside a component (at a border snapshot): the component's last listed here goes on in the next span
+	virtual void span(uint32_t index, uint32_t n_spans, uint32_t f0, uint32_t f1, uint32_t h0, uint32_t h1, uint32_t v0, uint32_t v1, const uint32_t *comp_first, uint32_t n_comp, bool ends_inside) = 0;
 	virtual ~SpanDone() {}
 };
+struct SnapshotPoint;
+// snaps: the border snapshots of the directory (restart points inside components; nullptr / HRY_NO_SNAPSHOT_REPLAY: not used)
 void cut_border_replay(Mesh &m, const PlaneView *conn_planes, const std::vector<RestartPoint> &restarts,
                        const std::vector<RestartCounters> &counters,
-                       OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span = nullptr);
+                       OrderVec &order_v, std::vector<uint32_t> &seg_start, std::vector<uint32_t> &seg_level, SpanDone *on_span = nullptr,
+                       const std::vector<SnapshotPoint> *snaps = nullptr);
 unsigned cpu_allowance();           // CPUs this process may keep busy: affinity mask and control-group quota (HRY_CPUS overrides)
 unsigned host_threads();            // HRY_HOST_THREADS, default min(16, cpu_allowance()) (large hosts: see cbm_walk.cpp)
 uint32_t parallel_min_faces();      // HRY_PARALLEL_MIN_FACES, default 65536
@@ -299,6 +329,18 @@ constexpr uint32_t kPriorK = 1024, kPriorMinSyms = 1024;
 bool plane_prior_from_hist(const uint32_t hist[256], uint64_t n, uint32_t table[256]);
 void write_prior(std::vector<uint8_t> &out, bool use, const uint32_t table[256]);
 size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256]);   // returns bytes consumed; throws on damage
+
+// ---- border snapshots in the chunked container's directory (header.cpp)
+// a snapshot as a decoder holds it: where it lies (the cursors of a restart point), the counters of the older vertices its span
+// names that are not on the border, the border itself
+struct SnapshotPoint {
+	RestartPoint at;
+	RestartCounters counters;
+	std::vector<uint32_t> parts, vtx;   // parts: size << 1 | edge_begin, bottom of the stack first; vtx per element, head -> tail
+	std::vector<uint8_t> seen;
+};
+void write_snapshot_section(uint32_t spacing, const std::vector<BorderSnapshot> &snaps, const std::vector<RestartCounters> &counters, std::vector<uint8_t> &out);
+size_t read_snapshot_section(const uint8_t *p, size_t avail, uint32_t nv, uint32_t &spacing, std::vector<SnapshotPoint> &out);   // returns bytes consumed; throws on damage
 
 // ---- header.cpp (formats/hry/writer.cc:104-198 / reader.cc:60-177)
 // reference single-stream format (compat_read.cpp): serial entropy decode + replay on the host; residual byte planes

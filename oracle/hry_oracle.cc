@@ -570,6 +570,7 @@ struct SymWriter {
 	uint32_t min_ref = 0xffffffffu;
 	void mark_component(uint32_t next_id, uint32_t nfaces)
 	{
+		snaps_in_component = 0;
 		if (!record) return;
 		if (!marks.empty()) marks.back().min_ref = min_ref;
 		Mark k;
@@ -613,9 +614,16 @@ struct SymWriter {
 	// chunked profile: every explicit naming of a vertex with the number of triangles seen at it so far (the "order" the
 	// operation model conditions on, models.h:69-72), per component -- restart points carry the counters of the older
 	// vertices their span names, so that a decoder can start there without the components before it
-	struct Named { uint32_t mark, id, count; };
+	struct Named { uint32_t mark, id, count, snap; };   // snap: border snapshots its component had taken before the naming
 	std::vector<Named> named;
-	void name(uint32_t v, uint32_t count) { if (record && !marks.empty()) named.push_back(Named{ (uint32_t)marks.size() - 1, v, count }); vertid(v); }
+	void name(uint32_t v, uint32_t count) { if (record && !marks.empty()) named.push_back(Named{ (uint32_t)marks.size() - 1, v, count, snaps_in_component }); vertid(v); }
+	// chunked profile, round 6: restart points INSIDE a component -- the cut-border at the first moment between two operations, the
+	// polygon in hand complete, at which the component has coded j * snapshot_faces faces (j = 1, 2, ...): the cursors of a restart
+	// point, the parts with their edge_begin flags, per element the vertex (the decoder's number) and min(triangles seen at it, 9).
+	// The elements' half-edges are not part of it (cbm/decoder.h:179-197: a border edge only ever becomes the twin of a new edge).
+	struct Snap { uint32_t mark, n_grp[5], n_op[8], first_vertex, first_face; std::vector<uint32_t> parts, vtx; std::vector<uint8_t> seen; };
+	std::vector<Snap> snaps;
+	uint32_t snapshot_faces = 0, snaps_in_component = 0;
 	void numtri(int n) { if (n != 0) { uint16_t v = (uint16_t)n; bytes(CTX_NUMTRI, (const uint8_t*)&v, 2); } }   // io.h:162-165
 	void reg_face(uint16_t r) { bytes(CTX_REGFACE, (const uint8_t*)&r, 2); }
 	void reg_vtx(uint16_t r) { bytes(CTX_REGVTX, (const uint8_t*)&r, 2); }
@@ -630,6 +638,11 @@ struct SymReader {
 	std::vector<std::vector<uint8_t>> *planes = nullptr;
 	std::vector<size_t> cursor;
 	int fixed_numtri = -1;   // >= 0: numtri is not transmitted (single polygon degree)
+	// chunked container, round 6: the border snapshots of the directory, checked by cbm_decode against its own state
+	struct Snap { uint32_t n_grp[5], n_op[8], first_vertex, first_face, first_halfedge; std::vector<std::pair<uint32_t, uint32_t>> counters; std::vector<uint32_t> parts, vtx; std::vector<uint8_t> seen; };
+	const std::vector<Snap> *snaps = nullptr;
+	size_t snaps_checked = 0;
+	size_t cursor_of(int slot) const { return (size_t)slot < cursor.size() ? cursor[slot] : 0; }
 	SymReader(Models &m, RangeDecoder &r) : md(m), rc(r) {}
 	uint32_t pop(int slot)
 	{
@@ -1127,8 +1140,26 @@ static void cbm_encode(Mesh &m, SymWriter &wr, std::vector<uint32_t> &order_v, s
 		++seen[a]; ++seen[b]; ++seen[c];
 		cb.start(Elem{ a, e0 }, Elem{ b, e1 }, Elem{ c, e2 });
 		++curtri;
+		const size_t comp_face0 = order_f.size() - 1;
+		uint64_t next_snap = wr.record && wr.snapshot_faces ? wr.snapshot_faces : ~0ull;
 
 		while (!cb.empty()) {
+			if (curtri == ntri && order_f.size() - comp_face0 >= next_snap) {   // a border snapshot (SymWriter::Snap)
+				next_snap += wr.snapshot_faces;
+				SymWriter::Snap sn;
+				sn.mark = (uint32_t)wr.marks.size() - 1;
+				const auto &rec = *wr.record;
+				sn.n_grp[0] = (uint32_t)rec[CTX_IOP].size(); sn.n_grp[1] = (uint32_t)rec[CTX_ELEM].size(); sn.n_grp[2] = (uint32_t)rec[CTX_PART].size();
+				sn.n_grp[3] = (uint32_t)rec[CTX_VERT].size(); sn.n_grp[4] = (uint32_t)rec[CTX_NUMTRI].size();
+				for (int i = 0; i < 8; ++i) sn.n_op[i] = (uint32_t)rec[REC_OP0 + i].size();
+				sn.first_vertex = next_id; sn.first_face = (uint32_t)order_f.size();
+				for (const Part &q : cb.parts) {   // bottom of the stack first; elements front (the gate's head side) to back (the gate)
+					sn.parts.push_back((uint32_t)q.el.size() << 1 | (q.edge_begin ? 1u : 0u));
+					for (const Elem &el : q.el) { sn.vtx.push_back(perm[el.v]); sn.seen.push_back((uint8_t)std::min<uint32_t>(seen[el.v], 9u)); }
+				}
+				wr.snaps.push_back(std::move(sn));
+				++wr.snaps_in_component;
+			}
 			Part &pt = cb.top();
 			Elem g0 = pt.el.back(), g1 = pt.el.front();
 			he_t gate = g0.a;
@@ -1326,6 +1357,24 @@ static void cbm_decode(Mesh &m, SymReader &rd, std::vector<uint32_t> &order_v)
 		cb.start(Elem{ a, e0 }, Elem{ b, e1 }, Elem{ c, e2 });
 
 		while (!cb.empty()) {
+			// a border snapshot of the directory that claims this moment -- between two operations, the polygon in hand complete, this
+			// many faces made (the first such moment) -- must describe exactly the state this replay is in: cursors, next vertex / face /
+			// half-edge, parts, vertices, triangle counts; and the counters listed with it must be those of vertices off the border
+			if (rd.snaps && rd.snaps_checked < rd.snaps->size() && curtri == ntri && m.num_face() >= (*rd.snaps)[rd.snaps_checked].first_face) {
+				const SymReader::Snap &S = (*rd.snaps)[rd.snaps_checked++];
+				bool ok = m.num_face() == S.first_face && next_id == S.first_vertex && m.num_edge() == S.first_halfedge;
+				ok = ok && rd.cursor_of(CTX_IOP) == S.n_grp[0] && rd.cursor_of(CTX_ELEM) == S.n_grp[1] && rd.cursor_of(CTX_PART) == S.n_grp[2] && rd.cursor_of(CTX_VERT) == S.n_grp[3];
+				if (rd.fixed_numtri < 0) ok = ok && rd.cursor_of(CTX_NUMTRI) == S.n_grp[4];
+				for (int i = 0; i < 8; ++i) ok = ok && rd.cursor_of(REC_OP0 + i) == S.n_op[i];
+				std::vector<uint32_t> parts, vtx; std::vector<uint8_t> sn;
+				for (const Part &q : cb.parts) {
+					parts.push_back((uint32_t)q.el.size() << 1 | (q.edge_begin ? 1u : 0u));
+					for (const Elem &el : q.el) { vtx.push_back(el.v); sn.push_back((uint8_t)std::min<uint32_t>(seen[el.v], 9u)); }
+				}
+				ok = ok && parts == S.parts && vtx == S.vtx && sn == S.seen;
+				for (const auto &c : S.counters) ok = ok && c.first < S.first_vertex && seen[c.first] == c.second && std::find(vtx.begin(), vtx.end(), c.first) == vtx.end();
+				if (!ok) throw std::runtime_error("oracle: a border snapshot of the directory does not match the replay");
+			}
 			Part &pt = cb.top();
 			Elem g0 = pt.el.back(), g1 = pt.el.front();
 			he_t gate = g0.a;
@@ -1880,7 +1929,46 @@ static size_t attr_chunk_len(size_t pos, size_t chunk_syms)
 	return std::min(len, chunk_syms);
 }
 
-static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
+// border snapshots in the directory (round 6): LEB128 varints, zigzag-folded differences in runs (see encode_chunked)
+static void put_varint(std::vector<uint8_t> &o, uint64_t v) { while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; } o.push_back((uint8_t)v); }
+static uint64_t zigzag64(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+static int64_t unzigzag64(uint64_t z) { return (int64_t)(z >> 1) ^ -(int64_t)(z & 1); }
+static void put_runs(std::vector<uint8_t> &o, const std::vector<int64_t> &d)   // `length of a run of zeros`, then the non-zero value that ends it (nothing behind the last one)
+{
+	for (size_t i = 0; i < d.size();) {
+		uint64_t run = 0;
+		while (i < d.size() && d[i] == 0) { ++run; ++i; }
+		put_varint(o, run);
+		if (i < d.size()) { put_varint(o, zigzag64(d[i])); ++i; }
+	}
+}
+static uint64_t get_varint(const uint8_t *&p, const uint8_t *end)
+{
+	uint64_t v = 0;
+	for (int sh = 0; sh < 64; sh += 7) {
+		if (p == end) throw std::runtime_error("oracle: truncated border snapshot");
+		const uint8_t b = *p++;
+		v |= (uint64_t)(b & 0x7f) << sh;
+		if (!(b & 0x80)) return v;
+	}
+	throw std::runtime_error("oracle: bad varint");
+}
+static std::vector<int64_t> get_runs(const uint8_t *&p, const uint8_t *end, size_t n)
+{
+	std::vector<int64_t> d;
+	while (d.size() < n) {
+		uint64_t run = get_varint(p, end);
+		if (run > n - d.size()) throw std::runtime_error("oracle: bad run in a border snapshot");
+		d.insert(d.end(), (size_t)run, 0);
+		if (d.size() < n) d.push_back(unzigzag64(get_varint(p, end)));
+	}
+	return d;
+}
+// spacing of the border snapshots for a container that describes nf faces: at least 2^18 faces, at most some thirty snapshots
+static uint32_t default_snapshot_faces(uint32_t nf) { uint32_t sp = 1u << 18; while ((uint64_t)sp * 32u < nf) sp <<= 1; return sp; }
+enum : uint32_t { SNAPSHOT_DEFAULT = 0xffffffffu };
+
+static Result *encode_chunked(Mesh &m, uint32_t chunk_syms, uint32_t snapshot_faces = SNAPSHOT_DEFAULT)
 {
 	if (m.bind.on) check_general(m); else check_supported(m);
 	if (chunk_syms == 0) chunk_syms = 8192;
@@ -1909,6 +1997,7 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 		SymWriter wr(md, rc, nullptr);
 		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
 		wr.record = &rec;
+		wr.snapshot_faces = snapshot_faces == SNAPSHOT_DEFAULT ? default_snapshot_faces((uint32_t)m.num_face()) : snapshot_faces;
 		cbm_encode(m, wr, res->order_v, res->order_f);
 		if (m.bind.on) encode_attrs_general(m, wr, res->order_v, res->order_f);
 		else encode_attrs(m, wr, res->order_v, res->order_f);
@@ -1952,7 +2041,7 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 				pts.push_back(r);
 				last_face = mk.first_face;
 			}
-			w.put<uint32_t>((uint32_t)pts.size());
+			w.put<uint32_t>((uint32_t)pts.size() | (wr.snaps.empty() ? 0u : 0x80000000u));   // (top bit: a section of border snapshots follows the counters)
 			for (auto &r : pts) for (uint32_t x : r) w.put<uint32_t>(x);
 			// per restart point: the older vertices its span names (first naming in the span) with their counters at that moment
 			// = at the start of the span (a vertex is only touched after it has been named in the component at hand)
@@ -1965,9 +2054,25 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 					span_of_mark[k] = (uint32_t)q;
 				}
 			}
-			std::vector<std::vector<std::pair<uint32_t, uint32_t>>> counters(pts.size());
+			// A span ends where the next point lies, of either kind: a naming behind a border snapshot belongs to the span that starts
+			// at the snapshot (the last one at or before it in the stream), which brings the counters of the vertices ON its border
+			// along; of the older vertices it names only the others are listed with it.
+			std::vector<std::vector<std::pair<uint32_t, uint32_t>>> counters(pts.size()), snap_counters(wr.snaps.size());
+			std::vector<uint32_t> nth(wr.snaps.size(), 0);   // a snapshot's number inside its component, from 1
+			for (size_t i = 0; i < wr.snaps.size(); ++i) nth[i] = i && wr.snaps[i - 1].mark == wr.snaps[i].mark ? nth[i - 1] + 1 : 1u;
 			for (const SymWriter::Named &ev : wr.named) {
 				const uint32_t sp = span_of_mark[ev.mark];
+				long q = -1;   // the last snapshot at or before the naming
+				for (size_t i = 0; i < wr.snaps.size(); ++i)
+					if (wr.snaps[i].mark < ev.mark || (wr.snaps[i].mark == ev.mark && nth[i] <= ev.snap)) q = (long)i;
+				if (q >= 0 && (sp == 0xffffffffu || wr.snaps[q].first_face > pts[sp][14])) {
+					const SymWriter::Snap &S = wr.snaps[q];
+					if (ev.id >= S.first_vertex || std::find(S.vtx.begin(), S.vtx.end(), ev.id) != S.vtx.end()) continue;
+					bool dup = false;
+					for (auto &c : snap_counters[q]) if (c.first == ev.id) { dup = true; break; }
+					if (!dup) snap_counters[q].push_back({ ev.id, ev.count });
+					continue;
+				}
 				if (sp == 0xffffffffu || ev.id >= pts[sp][13]) continue;
 				bool dup = false;
 				for (auto &c : counters[sp]) if (c.first == ev.id) { dup = true; break; }
@@ -1976,6 +2081,33 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms)
 			for (auto &cs : counters) {
 				w.put<uint32_t>((uint32_t)cs.size());
 				for (auto &c : cs) { w.put<uint32_t>(c.first); w.put<uint32_t>(c.second); }
+			}
+			// the border snapshots: u32 spacing, u32 n; per snapshot 17 u32 like a restart point (flags = 0), u32 n_counters + the
+			// counters, u32 n_parts, u32 n_elements, u32 blob_bytes, the blob, zero bytes up to a multiple of four.  Blob (varints):
+			// per part size << 1 | edge_begin; the vertices as differences from "the vertex before + 1" (before the first: the
+			// snapshot's next vertex) in runs; the triangle counts as differences from the count before (before the first: 3) in runs
+			if (!wr.snaps.empty()) {
+				const size_t sec0 = res->bytes.size();   // (the padding counts from the section's first byte)
+				w.put<uint32_t>(wr.snapshot_faces); w.put<uint32_t>((uint32_t)wr.snaps.size());
+				for (size_t k = 0; k < wr.snaps.size(); ++k) {
+					const SymWriter::Snap &S = wr.snaps[k];
+					for (int g = 0; g < 5; ++g) w.put<uint32_t>(g == 4 && !numtri_coded ? 0u : S.n_grp[g]);
+					for (int i = 0; i < 8; ++i) w.put<uint32_t>(S.n_op[i]);
+					w.put<uint32_t>(S.first_vertex); w.put<uint32_t>(S.first_face); w.put<uint32_t>(he_before[S.first_face]); w.put<uint32_t>(0);
+					w.put<uint32_t>((uint32_t)snap_counters[k].size());
+					for (auto &c : snap_counters[k]) { w.put<uint32_t>(c.first); w.put<uint32_t>(c.second); }
+					w.put<uint32_t>((uint32_t)S.parts.size()); w.put<uint32_t>((uint32_t)S.vtx.size());
+					std::vector<uint8_t> blob;
+					for (uint32_t pt : S.parts) put_varint(blob, pt);
+					std::vector<int64_t> d(S.vtx.size());
+					for (size_t i = 0; i < d.size(); ++i) d[i] = (int64_t)S.vtx[i] - ((i ? (int64_t)S.vtx[i - 1] : (int64_t)S.first_vertex - 1) + 1);
+					put_runs(blob, d);
+					for (size_t i = 0; i < d.size(); ++i) d[i] = (int64_t)S.seen[i] - (i ? (int64_t)S.seen[i - 1] : 3);
+					put_runs(blob, d);
+					w.put<uint32_t>((uint32_t)blob.size());
+					w.raw(blob.data(), blob.size());
+					while ((res->bytes.size() - sec0) & 3) w.put<uint8_t>(0);
+				}
 			}
 		}
 		std::vector<std::vector<uint8_t>> streams;
@@ -2027,8 +2159,38 @@ static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 		std::vector<char> has_prior(np, 0);
 		for (size_t k = 0; k < np; ++k) has_prior[k] = read_prior(br, prior[k].data()) ? 1 : 0;
 		uint32_t n_restart = br.get<uint32_t>();   // restart points: an aid for parallel decoders, not needed here
+		const bool has_snaps = (n_restart & 0x80000000u) != 0;
+		n_restart &= 0x7fffffffu;
 		for (uint64_t i = 0; i < (uint64_t)n_restart * 17; ++i) (void)br.get<uint32_t>();
 		for (uint32_t i = 0; i < n_restart; ++i) { uint32_t nc = br.get<uint32_t>(); for (uint64_t j = 0; j < 2ull * nc; ++j) (void)br.get<uint32_t>(); }
+		// border snapshots (round 6): not needed for this sequential decode either -- but it CHECKS every one of them against the
+		// state its own replay is in at that moment (SymReader::snaps, cbm_decode): what a parallel decoder would start from
+		std::vector<SymReader::Snap> snaps;
+		if (has_snaps) {
+			const uint8_t *sec0 = br.p;
+			(void)br.get<uint32_t>();   // spacing
+			const uint32_t ns = br.get<uint32_t>();
+			for (uint32_t k = 0; k < ns; ++k) {
+				SymReader::Snap S;
+				for (int g = 0; g < 5; ++g) S.n_grp[g] = br.get<uint32_t>();
+				for (int i = 0; i < 8; ++i) S.n_op[i] = br.get<uint32_t>();
+				S.first_vertex = br.get<uint32_t>(); S.first_face = br.get<uint32_t>(); S.first_halfedge = br.get<uint32_t>(); (void)br.get<uint32_t>();
+				const uint32_t nc = br.get<uint32_t>();
+				for (uint32_t j = 0; j < nc; ++j) { uint32_t v = br.get<uint32_t>(), c = br.get<uint32_t>(); S.counters.push_back({ v, c }); }
+				const uint32_t n_parts = br.get<uint32_t>(), n_elems = br.get<uint32_t>(), nb = br.get<uint32_t>();
+				br.need(nb);
+				const uint8_t *q = br.p, *qe = br.p + nb;
+				for (uint32_t i = 0; i < n_parts; ++i) S.parts.push_back((uint32_t)get_varint(q, qe));
+				std::vector<int64_t> d = get_runs(q, qe, n_elems);
+				for (size_t i = 0; i < d.size(); ++i) S.vtx.push_back((uint32_t)((i ? (int64_t)S.vtx[i - 1] : (int64_t)S.first_vertex - 1) + 1 + d[i]));
+				d = get_runs(q, qe, n_elems);
+				for (size_t i = 0; i < d.size(); ++i) S.seen.push_back((uint8_t)((i ? (int64_t)S.seen[i - 1] : 3) + d[i]));
+				if (q != qe) throw std::runtime_error("oracle: bytes left in a border snapshot");
+				br.p += nb;
+				while ((br.p - sec0) & 3) (void)br.get<uint8_t>();
+				snaps.push_back(std::move(S));
+			}
+		}
 		std::vector<uint32_t> nbytes(nstreams);
 		for (auto &x : nbytes) x = br.get<uint32_t>();
 		std::vector<std::vector<uint8_t>> rec(std::max<size_t>(REC_SLOTS, md.tab.size()));
@@ -2059,6 +2221,7 @@ static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 		RangeDecoder rc(none.data(), none.data());
 		SymReader rd(md, rc);
 		rd.planes = &rec;
+		rd.snaps = &snaps;
 		if (count_degrees(*m) <= 1) {
 			int d = 0;
 			for (size_t i = 0; i < m->have_deg.size(); ++i) if (m->have_deg[i]) d = (int)i;
@@ -2068,6 +2231,7 @@ static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 		std::vector<char> hdr_deg = m->have_deg;
 		cbm_decode(*m, rd, order_v);
 		m->have_deg = hdr_deg;
+		if (rd.snaps_checked != snaps.size()) throw std::runtime_error("oracle: a border snapshot of the directory lies where the replay never stood");
 		if (m->num_face() != m->nf) throw std::runtime_error("oracle: face count mismatch");
 		if (m->bind.on) decode_attrs_general(*m, rd, order_v);
 		else decode_attrs(*m, rd, order_v);
@@ -2950,10 +3114,11 @@ ho_result *ho_encode(ho_mesh *m, int trace)
 	return h;
 	HO_CATCH(nullptr)
 }
-ho_result *ho_encode_chunked(ho_mesh *m, uint32_t chunk_syms)
+ho_result *ho_encode_chunked(ho_mesh *m, uint32_t chunk_syms) { return ho_encode_chunked2(m, chunk_syms, 0xffffffffu); }
+ho_result *ho_encode_chunked2(ho_mesh *m, uint32_t chunk_syms, uint32_t snapshot_faces)
 {
 	HO_TRY
-	ho::Result *r = ho::encode_chunked(m->m, chunk_syms);
+	ho::Result *r = ho::encode_chunked(m->m, chunk_syms, snapshot_faces);
 	ho_result *h = new ho_result{ std::move(*r) };
 	delete r;
 	return h;

@@ -58,6 +58,7 @@ def lib():
     L.ho_encode.restype = vp; L.ho_encode.argtypes = [vp, C.c_int]
     L.ho_result_free.argtypes = [vp]
     L.ho_encode_chunked.restype = vp; L.ho_encode_chunked.argtypes = [vp, C.c_uint32]
+    L.ho_encode_chunked2.restype = vp; L.ho_encode_chunked2.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.ho_mesh_from_hry_chunked.restype = vp; L.ho_mesh_from_hry_chunked.argtypes = [C.c_char_p, sz]
     L.ho_result_size.restype = sz; L.ho_result_size.argtypes = [vp]
     L.ho_result_data.restype = u8p; L.ho_result_data.argtypes = [vp]
@@ -170,8 +171,10 @@ class Mesh:
     def from_hry_chunked(cls, data: bytes) -> "Mesh":
         return cls(lib().ho_mesh_from_hry_chunked(data, len(data)))
 
-    def encode_chunked(self, chunk_syms: int = 0) -> "Result":
-        r = lib().ho_encode_chunked(self.h, chunk_syms)
+    def encode_chunked(self, chunk_syms: int = 0, snapshot_faces=None) -> "Result":
+        """snapshot_faces: faces of a component between two border snapshots of the directory (restart points inside components);
+        None = the default rule, 0 = none"""
+        r = lib().ho_encode_chunked2(self.h, chunk_syms, 0xffffffff if snapshot_faces is None else int(snapshot_faces))
         if not r:
             raise _err()
         return Result(r)

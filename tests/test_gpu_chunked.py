@@ -133,6 +133,89 @@ def test_chunked_pipelined_decode(cx, case, faces, slice_, monkeypatch):
     assert np.array_equal(piped.twin(), plain.twin())
 
 
+@pytest.mark.parametrize("case", ["torus150_q14", "colors_normals", "torus_lossless", "quads_q12", "mixed_nm_multi", "open_grid_q8"])
+@pytest.mark.parametrize("spacing", [97, 1500])
+def test_border_snapshots_container_and_decodes(cx, case, spacing, monkeypatch):
+    """Round 6, restart points INSIDE a component: the walk notes the cut-border every `spacing` faces of a component in the
+    container's directory (parts, vertices, triangle counts), a decoder starts a span of the replay at every snapshot on a host
+    thread of its own and joins the spans.  The container equals the oracle's restatement byte for byte (whose sequential
+    decode checks every snapshot against its own replay); the decode -- one sequence ignoring the snapshots, spans beside each
+    other, spans beside the publishing first stretch of the pipelined decode -- equals the reference-format decode."""
+    mesh, quant = {
+        "torus150_q14": (lambda: mg.torus(150, 150, seed=2), [(1, -1, 14)]),
+        "colors_normals": (lambda: mg.with_colors(mg.torus(90, 80, normals=True)), [(1, 0, 14), (1, 1, 14), (1, 2, 14), (1, 3, 10), (1, 4, 10), (1, 5, 10)]),
+        "torus_lossless": (lambda: mg.torus(100, 90, seed=5), []),
+        "quads_q12": (lambda: mg.torus(70, 64, polys="quad"), [(1, -1, 12)]),
+        "mixed_nm_multi": (lambda: mg.with_nonmanifold(mg.multi_component(5, 30, 34, polys="mixed", seed=3), 40, 25), []),
+        "open_grid_q8": (lambda: mg.grid(200, 150), [(1, -1, 8)]),
+    }[case]
+    monkeypatch.setenv("HRY_SNAPSHOT_FACES", str(spacing))
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "0")
+    monkeypatch.setenv("HRY_HOST_THREADS", "5")
+    ply = mesh().to_ply()
+    a, o = hc.Mesh.from_ply(ply), op.Mesh.from_ply(ply)
+    if quant:
+        cx.requant(a, quant)
+        o.requant(quant)
+    ref_dec = op.Mesh.from_hry(o.clone().encode().data)
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=1000)
+    want = o.clone().encode_chunked(1000, spacing).data
+    assert got == want
+    assert len(got) > len(o.clone().encode_chunked(1000, 0).data)          # (the section is there)
+    same_mesh(op.Mesh.from_hry_chunked(got), ref_dec)                      # the oracle's own decode, which checks the snapshots
+    monkeypatch.setenv("HRY_NO_PIPELINE", "1")
+    monkeypatch.setenv("HRY_NO_SNAPSHOT_REPLAY", "1")
+    plain = cx.read_hry(got)                                               # one sequence: the snapshots are skipped
+    same_mesh(plain, ref_dec)
+    monkeypatch.delenv("HRY_NO_SNAPSHOT_REPLAY")
+    spans = cx.read_hry(got)                                               # spans beside each other (cut_border_replay)
+    same_mesh(spans, ref_dec)
+    assert np.array_equal(spans.twin(), plain.twin())
+    monkeypatch.delenv("HRY_NO_PIPELINE")
+    monkeypatch.setenv("HRY_PIPELINE_MIN_VERTICES", "0")
+    for faces, slice_ in ((64, 64), (1000, 4096)):
+        monkeypatch.setenv("HRY_PIPELINE_FACES", str(faces))
+        monkeypatch.setenv("HRY_PIPELINE_SLICE", str(slice_))
+        piped = cx.read_hry(got)                                           # (where the pipelined decode applies: its first stretch publishes, the others run beside it)
+        same_mesh(piped, ref_dec)
+        assert np.array_equal(piped.twin(), plain.twin())
+    # a container without snapshots is what it was before this round
+    monkeypatch.setenv("HRY_NO_SNAPSHOTS", "1")
+    assert cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=1000) == o.clone().encode_chunked(1000, 0).data
+
+
+def test_damaged_border_snapshots_are_refused(cx, monkeypatch):
+    """every word and byte of the snapshots' section: a changed one either decodes to the same mesh (padding) or is refused"""
+    monkeypatch.setenv("HRY_SNAPSHOT_FACES", "400")
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "0")
+    monkeypatch.setenv("HRY_HOST_THREADS", "4")
+    monkeypatch.setenv("HRY_NO_PIPELINE", "1")
+    m = mg.torus(40, 36, seed=3)
+    a = hc.Mesh.from_ply(m.to_ply())
+    got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=1000)
+    ref = cx.read_hry(got)
+    monkeypatch.setenv("HRY_NO_SNAPSHOTS", "1")
+    without = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=1000)
+    monkeypatch.delenv("HRY_NO_SNAPSHOTS")
+    assert len(got) > len(without)
+    # the section: where the two containers part company (behind the restart points' count), as long as their difference
+    first = next(i for i in range(len(without)) if got[i] != without[i])
+    sec0, sec1 = first + 1, first + 1 + (len(got) - len(without))   # (the count's top byte differs; the section follows the counters: none here)
+    rng = np.random.default_rng(1)
+    refused = same = 0
+    for at in list(range(sec0 - 4, sec0 + 80)) + list(rng.integers(sec0, sec1, 120)):
+        bad = bytearray(got)
+        bad[at] ^= 1 << int(rng.integers(0, 8))
+        try:
+            dec = cx.read_hry(bytes(bad))
+        except hc.HryError:
+            refused += 1
+            continue
+        same += 1
+        assert np.array_equal(dec.org(), ref.org()) and np.array_equal(dec.twin(), ref.twin()) and np.array_equal(dec.list_data(1), ref.list_data(1))
+    assert refused > 100
+
+
 def test_headline_workload_full_size(cx):
     """BASELINE configs[1] at its full size (closed torus 708 x 708 = 1 002 528 triangles, -l1 -q14), every default of the
     product path: threaded walk, pipelined decode, wavefront team on the reconstruction chain.

@@ -295,6 +295,94 @@ def test_replay_from_restart_points_equals_sequential_replay(case):
     assert np.array_equal(ov, ov2) and np.array_equal(ss, ss2) and np.array_equal(sl, sl2)
 
 
+# ---------------------------------------------------------------- restart points INSIDE a component (round 6: border snapshots)
+def _snapshot_case(case):
+    return {"torus_tri": lambda: mg.torus(80, 84),
+            "torus_quads": lambda: mg.torus(40, 44, polys="quad"),
+            "torus_mixed": lambda: mg.torus(50, 52, polys="mixed"),
+            "multi_mixed_nm": lambda: mg.with_nonmanifold(mg.multi_component(6, 24, 26, polys="mixed", seed=3), 40, 25),
+            "shared_vertices": lambda: mg.with_nonmanifold(mg.concat([mg.torus(40, 41, center=(3.0 * i, 0, 0), seed=i) for i in range(12)]), 30, 200),
+            "open_grid": lambda: mg.grid(60, 70)}[case]()
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("case", ["torus_tri", "torus_quads", "torus_mixed", "multi_mixed_nm", "shared_vertices", "open_grid"])
+@pytest.mark.parametrize("spacing", [64, 257, 1000])
+def test_replay_from_border_snapshots_equals_sequential_replay(case, spacing):
+    """The walk notes the cut-border every `spacing` faces of a component (parts, vertices, triangle counts: no half-edges); the
+    replay starts a span at every snapshot -- placeholders for the border's half-edges, counters of its own -- on several host
+    threads and joins the spans afterwards.  Same arrays as ONE sequential replay (cbm/decoder.h:27-211): face offsets, origins,
+    twins, decode order, component table and levels -- with and without the restart points at component starts, with the
+    snapshots written by the one-thread walk, the two-core walk and the walk of the components on several threads."""
+    gen = _snapshot_case(case)
+    ply = gen.to_ply()
+    src, ref, ov, ss, sl, _ = replay(ply, 1, False)
+    seen_points = 0
+    for threads, mode, split in ((2, 3, 0), (5, 3, 1), (3, 3, 0)):
+        env = {"HRY_SNAPSHOT_FACES": spacing, "HRY_WALK_SPLIT": split, "HRY_WALK_RING": 1024}
+        _, dec, ov2, ss2, sl2, (nrs, nsn) = _with_env(env, lambda: replay(ply, threads, mode))
+        seen_points += nsn
+        assert np.array_equal(ref.face_offsets(), dec.face_offsets())
+        assert np.array_equal(ref.org(), dec.org())
+        assert np.array_equal(ref.twin(), dec.twin())
+        assert np.array_equal(ov, ov2) and np.array_equal(ss, ss2) and np.array_equal(sl, sl2)
+    if not (case == "multi_mixed_nm" and spacing == 1000):
+        assert seen_points > 0, "the case must exercise border snapshots"
+
+
+@pytest.mark.parametrize("case", ["torus_tri", "torus_mixed", "multi_mixed_nm", "shared_vertices"])
+def test_border_snapshots_are_the_same_whichever_loop_walks(case):
+    """one-thread triangle / polygon loops, the generic loop, the two-core walk, components on several threads: one directory section"""
+    gen = _snapshot_case(case)
+    ply = gen.to_ply()
+    want = _with_env({"HRY_SNAPSHOT_FACES": 100, "HRY_WALK_SPLIT": 0}, lambda: walk_plain(ply, 1))[0]["snap_section"]
+    assert len(want) > 8
+    for env, threads in (({"HRY_WALK_SPLIT": 1, "HRY_WALK_RING": 1024}, 2), ({"HRY_GENERIC_WALK": 1}, 1), ({"HRY_WALK_SPLIT": 0}, 5), ({"HRY_GENERIC_WALK": 1}, 4)):
+        env = dict(env, HRY_SNAPSHOT_FACES=100)
+        got = _with_env(env, lambda: walk_plain(ply, threads))[0]["snap_section"]
+        assert np.array_equal(got, want), env
+    # no snapshots asked for: no section
+    assert len(_with_env({"HRY_SNAPSHOT_FACES": 0}, lambda: walk_plain(ply, 2))[0]["snap_section"]) == 0
+    assert len(_with_env({"HRY_NO_SNAPSHOTS": 1, "HRY_SNAPSHOT_FACES": 100}, lambda: walk_plain(ply, 2))[0]["snap_section"]) == 0
+
+
+@pytest.mark.parametrize("case", ["torus_tri", "torus_quads", "torus_mixed", "multi_mixed_nm", "shared_vertices", "open_grid"])
+def test_border_snapshot_section_equals_the_oracles(case):
+    """The directory section the product's walk writes is, byte for byte, the one in the oracle's restatement of the container --
+    whose own sequential decode checks every snapshot against the state its replay is in at that moment."""
+    gen = _snapshot_case(case)
+    ply = gen.to_ply()
+    for spacing in (90, 700):
+        got = _with_env({"HRY_SNAPSHOT_FACES": spacing}, lambda: walk_plain(ply, 3))[0]["snap_section"].tobytes()
+        o = op.Mesh.from_ply(ply)
+        ref = o.encode_chunked(1024, spacing).data
+        if not got:
+            assert case == "multi_mixed_nm" and spacing == 700
+            continue
+        assert got in ref
+        back = op.Mesh.from_hry_chunked(ref)      # (raises if a snapshot does not describe the replay's state)
+        plain = op.Mesh.from_hry(op.Mesh.from_ply(ply).encode().data)
+        assert np.array_equal(back.org(), plain.org()) and np.array_equal(back.twin(), plain.twin())
+    # a damaged snapshot is refused by the oracle's decode (it is looked at, not skipped)
+    bad = bytearray(ref)
+    at = ref.index(got) + 8 + 4 * 13          # the first snapshot's next vertex
+    bad[at] ^= 1
+    with pytest.raises(Exception):
+        op.Mesh.from_hry_chunked(bytes(bad))
+
+
 # ---------------------------------------------------------------- half-edge twin matching on several threads
 @pytest.mark.parametrize("case", ["torus_tri", "mixed_nonmanifold", "open_grid", "duplicates"])
 def test_threaded_twin_matching_equals_sequential(case):
