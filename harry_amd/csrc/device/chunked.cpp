@@ -577,7 +577,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	WalkResult w;
 	w.numtri_positions = false;     // (places in ONE symbol sequence: the chunked planes have none)
 	w.snapshot_faces = snapshot_spacing(m.nf);   // restart points inside large components (host.hpp BorderSnapshot; a shard: its own faces)
-	bool walked = false;
+	bool walked = false, walk_again = false;
 	// the device side beside the walk (EncodePipeline above): for walks on several threads whose sizes are known before they start
 	std::unique_ptr<EncodePipeline> pipe;
 	auto start_pipeline = [&](const ComponentAnalysis &A, std::function<void()> ready) {
@@ -645,13 +645,26 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 		tables.join();
 		if (failed) std::rethrow_exception(failed);
 		if (A.ncomp > 1) {
-			start_pipeline(A, nullptr);
-			cut_border_walk_in_place(m, A, uniform ? nullptr : eface.data(), *marks, w);
-			walked = true;
-			HRY_MARK(t_all, "  walk returned");
+			try {
+				start_pipeline(A, nullptr);
+				cut_border_walk_in_place(m, A, uniform ? nullptr : eface.data(), *marks, w);
+				walked = true;
+				HRY_MARK(t_all, "  walk returned");
+			} catch (const WalkMismatch &) {
+				// (host.hpp WalkMismatch: a repaired twin cut a component in two) everything of the attempt is dropped -- what the pipeline
+				// has sent, the result, the twins as the attempt left them -- and the mesh takes the walk below, which ends on one thread
+				if (pipe) { try { pipe->finish(); } catch (...) {} pipe.reset(); }
+				WalkResult fresh;
+				fresh.numtri_positions = false; fresh.snapshot_faces = w.snapshot_faces;
+				w = std::move(fresh);
+				build_twins(m);
+				walk_again = true;
+				HRY_MARK(t_all, "  a repaired twin split a component: walked again");
+			}
 		}
 	}
 	if (!walked) cut_border_walk(m, w, false);   // operation planes carry symbol + order class; no model evaluation needed
+	if (walk_again) { w.twins_changed = true; w.twin_patches.clear(); }   // (the device's twins are those of the dropped attempt: the whole array goes up again)
 	cx.timing.host_walk_ms = ms_since(t_walk);
 	HRY_MARK(t_all, "walked");
 	shard_arrays_ready();

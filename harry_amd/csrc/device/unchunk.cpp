@@ -586,6 +586,8 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 	uint32_t first_slice = 1u << 13;
 	if (const char *e = getenv("HRY_PIPELINE_FIRST_SLICE")) first_slice = std::max(64u, (uint32_t)strtoul(e, nullptr, 10));
 	first_slice = std::min(first_slice, min_slice);
+	uint32_t last_piece = 1u << 16;   // pieces of what is left when the replay is done (HRY_PIPELINE_LAST_PIECE; tests: small)
+	if (const char *e = getenv("HRY_PIPELINE_LAST_PIECE")) last_piece = std::max(64u, (uint32_t)strtoul(e, nullptr, 10) & ~63u);
 	int attr_waited = 0;   // groups of attribute streams the chain's stream has been told to wait for
 	const Clock::time_point t_begin = g_t0;
 	// vertex records come back slice by slice into pinned memory and are copied into the mesh by the consumer as they land
@@ -605,9 +607,10 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 		try {
 			stay_on_node(node);
 			HIP_OK(hipSetDevice(cx.device));
-			uint32_t f_up = 0, he_up = 0, v_done = 0;
-			uint64_t seen_seq = 0;
+			uint32_t f_up = 0, he_up = 0, v_done = 0, v_up = 0;   // v_up: decode order on the device up to this vertex
+			uint64_t seen_seq = 0, seen_pub = 0;
 			std::vector<uint32_t> patches;
+			std::vector<ReplayLive::Range> ranges, ranges_up;   // stretches of helper threads: announced / on the device (round 6)
 			DevBuf &d_patch = cx.d_patch;   // persistent and sized before the pipeline starts: growing it here would synchronise the device (hipFree / hipMalloc) in mid-flight
 			Stager up(cx, cx.stream2);
 			hipEvent_t prepared;
@@ -641,19 +644,46 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 					newest = live.pub;
 					patches.insert(patches.end(), live.patches.begin(), live.patches.end());
 					live.patches.clear();
+					ranges.insert(ranges.end(), live.ranges.begin(), live.ranges.end());
+					live.ranges.clear();
 					seen_seq = newest.seq;
 				}
 				if (newest.failed) break;
+				// a helper thread's finished stretch goes up at once (nobody is writing there any more)
+				for (const ReplayLive::Range &r : ranges) {
+					if (r.f1 > r.f0) up.put(cx.d_foff.as<uint32_t>() + r.f0 + 1, m->face_off.data() + r.f0 + 1, ((size_t)r.f1 - r.f0) * 4);
+					if (r.h1 > r.h0) {
+						up.put(cx.d_org.as<uint32_t>() + r.h0, m->org.data() + r.h0, ((size_t)r.h1 - r.h0) * 4);
+						up.put(cx.d_twin.as<uint32_t>() + r.h0, m->twin.data() + r.h0, ((size_t)r.h1 - r.h0) * 4);
+					}
+					if (r.v1 > r.v0) up.put(cx.d_order_v.as<uint32_t>() + r.v0, order_v.data() + r.v0, ((size_t)r.v1 - r.v0) * 4);
+					if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  a helper's stretch (faces %u .. %u) is on its way up\n", ms_since(t_begin), r.f0, r.f1);
+					ranges_up.push_back(r);
+				}
+				ranges.clear();
+				if (newest.n_pub == seen_pub) continue;   // (a helper's announcement only: no new publication of the replaying thread)
+				seen_pub = newest.n_pub;
 				if (trace_on() && getenv("HRY_TRACE_CONSUMER")) fprintf(stderr, "[hry] %8.3f ms    consumer: publication %llu (faces %u, vertices final up to %u)\n", ms_since(t_begin), (unsigned long long)newest.seq, newest.faces, newest.upto);
 				hist.push_back(newest);
 				if (!newest.done && hist.size() <= lag) continue;
 				const ReplayLive::Pub P = newest.done ? newest : hist.front();
-				while (!hist.empty() && hist.front().seq <= P.seq) hist.pop_front();
-				// finished part of the connectivity
+				while (!hist.empty() && hist.front().n_pub <= P.n_pub) hist.pop_front();
+				// finished part of the connectivity -- but for what the helpers' stretches have brought up already
 				if (P.faces > f_up) {
-					up.put(cx.d_foff.as<uint32_t>() + f_up, m->face_off.data() + f_up, ((size_t)P.faces - f_up + 1) * 4);
-					up.put(cx.d_org.as<uint32_t>() + he_up, m->org.data() + he_up, ((size_t)P.he - he_up) * 4);
-					up.put(cx.d_twin.as<uint32_t>() + he_up, m->twin.data() + he_up, ((size_t)P.he - he_up) * 4);
+					std::sort(ranges_up.begin(), ranges_up.end(), [](const ReplayLive::Range &a, const ReplayLive::Range &b) { return a.f0 < b.f0; });
+					uint32_t f = f_up, h = he_up;
+					auto copy_upto = [&](uint32_t f_to, uint32_t he_to) {
+						if (f_to <= f) return;
+						up.put(cx.d_foff.as<uint32_t>() + f, m->face_off.data() + f, ((size_t)f_to - f + 1) * 4);
+						up.put(cx.d_org.as<uint32_t>() + h, m->org.data() + h, ((size_t)he_to - h) * 4);
+						up.put(cx.d_twin.as<uint32_t>() + h, m->twin.data() + h, ((size_t)he_to - h) * 4);
+					};
+					for (const ReplayLive::Range &r : ranges_up) {
+						if (r.f1 <= f || r.f0 >= P.faces) continue;
+						copy_upto(std::min(r.f0, P.faces), std::min(r.h0, P.he));
+						f = std::max(f, r.f1); h = std::max(h, r.h1);
+					}
+					copy_upto(P.faces, P.he);
 					f_up = P.faces; he_up = P.he;
 				}
 				// vertices that can no longer change: whole tiles, slices of a useful size
@@ -667,33 +697,52 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 						launch_scatter_u32(cx.stream2, d_patch.as<uint32_t>(), (uint32_t)(patches.size() / 2), cx.d_twin.as<uint32_t>());
 						patches.clear();
 					}
-					up.put(cx.d_order_v.as<uint32_t>() + v_done, order_v.data() + v_done, ((size_t)v_hi - v_done) * 4);
+					{   // the decode order of the slice's vertices (the helpers' stretches brought theirs)
+						std::sort(ranges_up.begin(), ranges_up.end(), [](const ReplayLive::Range &a, const ReplayLive::Range &b) { return a.f0 < b.f0; });
+						uint32_t v = std::max(v_done, v_up);
+						for (const ReplayLive::Range &r : ranges_up) {
+							if (r.v1 <= v || r.v0 >= v_hi) continue;
+							if (r.v0 > v) up.put(cx.d_order_v.as<uint32_t>() + v, order_v.data() + v, ((size_t)std::min(r.v0, v_hi) - v) * 4);
+							v = std::max(v, r.v1);
+						}
+						if (v_hi > v) up.put(cx.d_order_v.as<uint32_t>() + v, order_v.data() + v, ((size_t)v_hi - v) * 4);
+						v_up = std::max(v_up, v_hi);
+					}
 					// what the kernels of this slice may follow: the half-edges that are on the device now (a link into the part
 					// that is not -- made after the publication this slice rests on -- reads as a border, which is what it was then)
 					ConnView cvs = cv;
 					cvs.ne = he_up;
-					SliceClock ck;
-					HIP_OK(hipEventCreate(&ck.a)); HIP_OK(hipEventCreate(&ck.b)); HIP_OK(hipEventCreate(&ck.p0)); HIP_OK(hipEventCreate(&ck.p1));
-					HIP_OK(hipEventRecord(ck.p0, cx.stream2));
-					launch_slice_prepare(cx.stream2, cvs, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec);
-					HIP_OK(hipEventRecord(ck.p1, cx.stream2));
-					HIP_OK(hipEventRecord(prepared, cx.stream2));
-					HIP_OK(hipStreamWaitEvent(cx.stream, prepared, 0));
-					// the residual codes of this slice: the groups of attribute streams that end inside it or before
-					while (attr_waited < Context::kAttrGroups && (attr_waited == 0 || attr_upto[attr_waited - 1] < v_hi)) HIP_OK(hipStreamWaitEvent(cx.stream, cx.attr_ev[attr_waited++], 0));
-					HIP_OK(hipEventRecord(ck.a, cx.stream));
-					launch_slice_chain(cx.stream, cvs, cx.d_order_v.as<uint32_t>(), nv, v_done, v_hi, d_cand, d_ncand, d_crec, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>());
-					HIP_OK(hipEventRecord(ck.b, cx.stream));
-					clocks.push_back(ck);
-					{
-						Landing L;
-						L.off = (size_t)v_done * vstride; L.len = ((size_t)v_hi - v_done) * vstride;
-						HIP_OK(hipMemcpyAsync((uint8_t*)cx.h_down + L.off, cx.d_rec[1].as<uint8_t>() + L.off, L.len, hipMemcpyDeviceToHost, cx.stream));
-						HIP_OK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
-						HIP_OK(hipEventRecord(L.ev, cx.stream));
-						landing.push_back(L);
+					// (round 6: what is left when the replay is done -- since its stretches run side by side, most of the mesh -- goes in
+					// pieces: a piece's records come down while the next piece's chain runs, and its candidates are found beside the chain
+					// of the piece before)
+					const uint32_t piece = P.done && v_hi - v_done > 3 * last_piece ? last_piece : v_hi - v_done;
+					for (uint32_t v_lo = v_done; v_lo < v_hi;) {
+						const uint32_t v_to = v_hi - v_lo <= piece + piece / 2 ? v_hi : v_lo + piece;
+						SliceClock ck;
+						HIP_OK(hipEventCreate(&ck.a)); HIP_OK(hipEventCreate(&ck.b)); HIP_OK(hipEventCreate(&ck.p0)); HIP_OK(hipEventCreate(&ck.p1));
+						HIP_OK(hipEventRecord(ck.p0, cx.stream2));
+						launch_slice_prepare(cx.stream2, cvs, cx.d_order_v.as<uint32_t>(), nv, v_lo, v_to, d_cand, d_ncand, d_crec);
+						HIP_OK(hipEventRecord(ck.p1, cx.stream2));
+						HIP_OK(hipEventRecord(prepared, cx.stream2));
+						HIP_OK(hipStreamWaitEvent(cx.stream, prepared, 0));
+						// the residual codes of this slice: the groups of attribute streams that end inside it or before
+						while (attr_waited < Context::kAttrGroups && (attr_waited == 0 || attr_upto[attr_waited - 1] < v_to)) HIP_OK(hipStreamWaitEvent(cx.stream, cx.attr_ev[attr_waited++], 0));
+						HIP_OK(hipEventRecord(ck.a, cx.stream));
+						launch_slice_chain(cx.stream, cvs, cx.d_order_v.as<uint32_t>(), nv, v_lo, v_to, d_cand, d_ncand, d_crec, d_vplanes, ldv, cx.d_rec[1].as<uint8_t>());
+						HIP_OK(hipEventRecord(ck.b, cx.stream));
+						clocks.push_back(ck);
+						{
+							Landing L;
+							L.off = (size_t)v_lo * vstride; L.len = ((size_t)v_to - v_lo) * vstride;
+							HIP_OK(hipMemcpyAsync((uint8_t*)cx.h_down + L.off, cx.d_rec[1].as<uint8_t>() + L.off, L.len, hipMemcpyDeviceToHost, cx.stream));
+							HIP_OK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+							HIP_OK(hipEventRecord(L.ev, cx.stream));
+							landing.push_back(L);
+						}
+						if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  slice [%u, %u) enqueued (replay at face %u)\n", ms_since(t_begin), v_lo, v_to, newest.faces);
+						v_lo = v_to;
+						drain(false);
 					}
-					if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  slice [%u, %u) enqueued (replay at face %u)\n", ms_since(t_begin), v_done, v_hi, newest.faces);
 					v_done = v_hi;
 				}
 				if (P.done) break;
@@ -729,6 +778,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 		PerfCounters pc;
 		if (count) pc.start();
 		if (spans) {
+			spans->announce_to = &live;   // (the consumer copies a helper's stretch as soon as it is finished)
 			spans->start(host_threads() - 1);
 			BorderEnd end0;
 			size_t cur_end0[21];

@@ -168,6 +168,7 @@ struct SnapshotSpans {
 	// for the helpers, checks every stretch's end against the next snapshot, joins them (twin links into published half-edges become
 	// patches of `live`) and leaves the last stretch's cursor in `cur`
 	void finish(ReplayCursor &cur, const size_t *cur_end0, BorderEnd &&end0, bool eom0, ReplayLive *live);
+	ReplayLive *announce_to = nullptr;   // (set before start(): finished stretches are announced there)
 };
 constexpr uint32_t kContinues = 0xffffffffu;   // refs of a span that starts inside a component: "the component the span before me ended in"
 
@@ -179,12 +180,24 @@ constexpr uint32_t kContinues = 0xffffffffu;   // refs of a span that starts ins
 // smallest id still on the border.  Twins of edges that lie below the last published half-edge count may already have been
 // copied by the consumer: later links of such edges are recorded as patches (idempotent index/value pairs).
 struct ReplayLive {
-	struct Pub { uint64_t seq = 0; uint32_t faces = 0, he = 0, upto = 0; bool done = false, failed = false; };
+	struct Pub { uint64_t seq = 0, n_pub = 0; uint32_t faces = 0, he = 0, upto = 0; bool done = false, failed = false; };   // seq: announcements of any kind; n_pub: publications of the replaying thread
 	std::mutex mu;
 	std::atomic<uint64_t> announced{ 0 };      // pub.seq, readable without the lock: the consumer polls it (a condition variable
 	                                           // costs the replay a futex wake per publication, 3 us each, 7 % of its time)
 	Pub pub;                                   // guarded by mu
 	std::vector<uint32_t> patches;             // guarded by mu: (half-edge, twin) pairs since the consumer last took them
+	// Round 6 (SnapshotSpans): a stretch of the replay that ran on a helper thread, finished -- its faces' offsets, its half-edges'
+	// origins and twins (placeholders of border edges included: patched when the stretches are joined) and its vertices' decode
+	// order are where they will stay, the consumer may copy them while the other stretches are still running
+	struct Range { uint32_t f0, f1, h0, h1, v0, v1; };
+	std::vector<Range> ranges;                 // guarded by mu: since the consumer last took them
+	void range_done(const Range &r)
+	{
+		std::lock_guard<std::mutex> g(mu);
+		ranges.push_back(r);
+		++pub.seq;
+		announced.store(pub.seq, std::memory_order_release);
+	}
 	// producer side
 	BigVec<uint16_t> on_border;
 	std::vector<uint32_t> pending;             // patches since the last publication
@@ -207,10 +220,10 @@ struct ReplayLive {
 		}
 		{
 			std::lock_guard<std::mutex> g(mu);
-			++pub.seq; pub.faces = face; pub.he = he; pub.upto = done ? next_id : min_open; pub.done = done; pub.failed = failed;
+			++pub.seq; ++pub.n_pub; pub.faces = face; pub.he = he; pub.upto = done ? next_id : min_open; pub.done = done; pub.failed = failed;
 			patches.insert(patches.end(), pending.begin(), pending.end());
+			announced.store(pub.seq, std::memory_order_release);   // (inside the lock since round 6: helper threads announce their stretches too)
 		}
-		announced.store(pub.seq, std::memory_order_release);   // only this thread writes pub
 		pending.clear();
 		face_pub = face; he_pub = he;
 	}

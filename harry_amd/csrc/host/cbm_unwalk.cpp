@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <sys/mman.h>
+#include <sched.h>
 
 #include <atomic>
 #include <unordered_map>
@@ -398,7 +399,9 @@ void join_spans(Mesh &m, const std::vector<const SnapshotPoint*> &seeds, const s
 				if (t == sym) continue;   // still on the border when the span ended (or closed onto itself: never -- a border edge meets an edge of a new face)
 				if (t >= ne) throw Error(HRY_E_INTERNAL, "replay: a placeholder linked to a placeholder");
 				twin[real[j]] = t; twin[t] = real[j];
-				if (live) live->link(real[j], t);
+				// (both entries may be on the device already -- the first stretch's published half-edges, a helper's finished stretch:
+				// a patch of an entry that is copied later is harmless, the copy carries the final value too)
+				if (live) { live->pending.push_back(real[j]); live->pending.push_back(t); live->pending.push_back(t); live->pending.push_back(real[j]); }
 			}
 		}
 		real_prev.swap(real);
@@ -439,21 +442,33 @@ SnapshotSpans::SnapshotSpans(Mesh &mesh, const PlaneView *planes, const std::vec
 void SnapshotSpans::start(unsigned n_threads)
 {
 	const void *node = callers_node_cpus();
-	const size_t nt = std::min<size_t>(std::max(1u, n_threads), n_spans - 1);
-	helpers.reserve(nt);
-	for (size_t t = 0; t < nt; ++t) helpers.emplace_back([this, node] {
+	const bool trace = getenv("HRY_TRACE") != nullptr;
+	const auto t_start = std::chrono::steady_clock::now();
+	if (trace) fprintf(stderr, "[hry replay]   the caller sets the helpers off on cpu %d\n", sched_getcpu());
+	auto work = [this, trace, t_start] {
 		try {
-			stay_on_node(node);
 			for (;;) {
 				{ std::lock_guard<std::mutex> g(mu); if (failed) return; }
 				const size_t k = next.fetch_add(1, std::memory_order_relaxed);
 				if (k >= n_spans) return;
 				Span &sp = spans[k];
+				const auto t_a = std::chrono::steady_clock::now();
 				SeenOfSpan own(m.nv);
+				const ReplayCursor c0 = sp.cur;
+				PerfCounters pc;
+				const bool count = getenv("HRY_PERF") != nullptr;
+				if (count) pc.start();
 				sp.eom = replay_triangles<false>(m, conn, own.p, order_v, sp.cur, sp.first, sp.refs, nullptr, sp.cur0, sp.cur1, sp.stop_face, sp.stop_mid, &sp.seed, &ends[k], sp.cur_end);
+				if (count) { pc.stop(); char what[64]; snprintf(what, sizeof what, "replay, stretch %zu on a helper thread", k); pc.report(what, (double)(sp.cur.face - c0.face)); }
+				if (announce_to) announce_to->range_done(ReplayLive::Range{ c0.face, sp.cur.face, c0.he, sp.cur.he, c0.next_id, sp.cur.next_id });
+				if (trace) fprintf(stderr, "[hry replay]   stretch %zu: %.3f .. %.3f ms after the helpers were set off, on cpu %d\n", k, std::chrono::duration<double, std::milli>(t_a - t_start).count(),
+				                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), sched_getcpu());
 			}
 		} catch (...) { std::lock_guard<std::mutex> g(mu); if (!failed) failed = std::current_exception(); }
-	});
+	};
+	const size_t nt = std::min<size_t>(std::max(1u, n_threads), n_spans - 1);
+	helpers.reserve(nt);
+	for (size_t t = 0; t < nt; ++t) helpers.emplace_back([work, node] { stay_on_node(node); work(); });
 }
 SnapshotSpans::~SnapshotSpans() { next.store(n_spans, std::memory_order_relaxed); for (auto &h : helpers) if (h.joinable()) h.join(); }
 void SnapshotSpans::finish(ReplayCursor &cur, const size_t *cur_end0, BorderEnd &&end0, bool eom0, ReplayLive *live)

@@ -1686,7 +1686,7 @@ static void walk_components_parallel(Mesh &m, WalkState &st, const uint32_t *efa
 				if (next_id != id_base[k + 1] || consumed != nfc || em.ov_cur != em.ov_begin + off_v[k + 1] || em.of_cur != em.of_begin + off_f[k + 1] ||
 				    em.halfedges != (uint32_t)off_he[k + 1] || (size_t)(em.op_cur - T.cur) > cap ||
 				    (w.numtri_coded && em.nt_cur != em.nt_begin + nt0 + (off_f[k + 1] - off_f[0])))
-					throw Error(HRY_E_INTERNAL, "parallel walk: component bookkeeping mismatch");
+					throw WalkMismatch();
 				pc.n_ops = (uint32_t)(em.op_cur - T.cur);
 				T.room -= pc.n_ops; T.cur = em.op_cur;
 				pc.n_syms = em.n - pc.sym0; pc.n_named = (uint32_t)T.w.named.size() - pc.named0; pc.n_snap = (uint32_t)T.w.snapshots.size() - pc.snap0;
@@ -1993,10 +1993,26 @@ void cut_border_walk(Mesh &m, WalkResult &w, bool eval_op_model, bool one_sequen
 	ensure_twins(m);
 	int udeg = 0;
 	if (!m.uniform_degree(udeg)) udeg = 0;
-	switch (udeg) {
-	case 3: walk_impl<3>(m, w, eval_op_model, one_sequence); break;
-	case 4: walk_impl<4>(m, w, eval_op_model, one_sequence); break;
-	default: walk_impl<0>(m, w, eval_op_model, one_sequence); break;   // mixed (or unusual uniform) degrees
+	auto run = [&](bool one) {
+		switch (udeg) {
+		case 3: walk_impl<3>(m, w, eval_op_model, one); break;
+		case 4: walk_impl<4>(m, w, eval_op_model, one); break;
+		default: walk_impl<0>(m, w, eval_op_model, one); break;   // mixed (or unusual uniform) degrees
+		}
+	};
+	try { run(one_sequence); }
+	catch (const WalkMismatch &) {
+		// (host.hpp WalkMismatch) the twins as the matching leaves them, a fresh result, one thread: the reference's own order
+		if (getenv("HRY_TRACE")) fprintf(stderr, "[hry walk] a repaired twin split a component: the mesh is walked again on one thread\n");
+		build_twins(m);
+		WalkResult fresh;
+		fresh.progress = nullptr;   // (whoever listened to the groups of the first attempt has to start over: see chunked.cpp)
+		fresh.numtri_positions = w.numtri_positions; fresh.snapshot_faces = w.snapshot_faces;
+		w = std::move(fresh);
+		w.twins_changed = true;     // (the caller's copy of the twins, if it has one, is that of the first attempt)
+		run(true);
+		w.twins_changed = true;
+		w.twin_patches.clear();     // (... every entry of it: no list of patches)
 	}
 }
 

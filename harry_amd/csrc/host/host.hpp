@@ -154,6 +154,15 @@ struct WalkState {
 	WalkState(uint32_t nv, uint32_t nf, unsigned n_threads);   // the same, filled by several threads
 };
 
+// A walk of the components on several threads rests on knowing the components before it starts -- from the half-edge twins as the
+// matching left them.  The walk REPAIRS twins where more than two faces meet in an edge (cbm/encoder.h:150,193-198), and a repair
+// can cut a component in two (the faces behind the old pairing are reached later, as a component of their own): the walk of that
+// component then consumes fewer faces than the analysis promised.  Thrown at that point, with the mesh's twins partly repaired:
+// cut_border_walk catches it, matches the twins afresh (the matching is a function of the connectivity) and walks on one thread, as
+// the reference does; callers that walk shards in place (cut_border_walk_in_place) see it as the error it is.
+struct WalkMismatch : Error {
+	WalkMismatch() : Error(HRY_E_INTERNAL, "walk on several threads: a repaired half-edge twin split a connected component (cbm/encoder.h:150,193-198); such a mesh is walked on one thread (HRY_HOST_THREADS=1)") {}
+};
 // ---- cbm_walk.cpp: cbm::encode restated over flat arrays (cbm/encoder.h:54-217, cutborder.h:49-333)
 // eval_op_model: the order-conditioned operation model of the reference stream evaluated per operation (op_l / op_h / op_t / op_pos);
 // the product evaluates it on the device (k_opmodel_*) and asks for one_sequence instead: positions of the connectivity groups in

@@ -258,6 +258,22 @@ def icosphere(level: int, seed: int = 1, sigma: float = 1e-3, extra_props: bool 
     return _tri_mesh(cols, f)
 
 
+def soup(nv: int = 40, nf: int = 120, seed: int = 5) -> Mesh:
+    """Random triangles over a few vertices: edges shared by any number of faces, in either direction.  The half-edge matching
+    pairs them first come, first served (structs/conn.h:201-214) and the cut-border walk re-pairs some of them as it meets the
+    faces (cbm/encoder.h:150,193-198): the meshes whose twins an encode repairs (seeds 5, 6, 13, 14, 16, 22 at the default size)."""
+    rng = np.random.default_rng(seed)
+    tris = set()
+    while len(tris) < nf:
+        a, b, c = rng.choice(nv, 3, replace=False)
+        tris.add((int(a), int(b), int(c)))
+    idx = np.array(sorted(tris), np.uint32).reshape(-1)
+    v = np.zeros(nv, torus(4, 4).verts.dtype)
+    for k in "xyz":
+        v[k] = rng.normal(size=nv).astype(np.float32)
+    return Mesh(v, np.full(nf, 3, np.uint8), idx)
+
+
 def concat(meshes) -> Mesh:
     """Disjoint union (multi-component mesh); vertex layouts must agree."""
     verts = np.concatenate([m.verts for m in meshes])

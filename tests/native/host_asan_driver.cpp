@@ -106,8 +106,60 @@ int main(int argc, char **argv)
 					std::unique_ptr<Mesh> m2(ext == ".ply" ? mesh_from_ply(data.data(), data.size()) : mesh_from_obj(data.data(), data.size(), dir.c_str()));
 					ensure_twins(*m2);
 					WalkResult w2;
+					w2.snapshot_faces = 50;   // (border snapshots inside the components: restart points for the replay below)
 					cut_border_walk(*m2, w2, false);
 					if (w2.order_f.size() != m2->nf) throw Error(HRY_E_INTERNAL, "plain walk: a face was not coded");
+					{
+						// the decoder's replay of what the walk wrote: as one sequence, and from the restart points and border snapshots of the
+						// directory on the host threads (spans joined afterwards) -- the same arrays; then the snapshots' section damaged
+						std::vector<uint8_t> planes[21];
+						static const int first_plane[G_COUNT] = { 0, 1, 5, 7, 11 };
+						for (int g = 0; g < G_COUNT; ++g)
+							for (int b = 0; b < kGroupBytes[g]; ++b) {
+								std::vector<uint8_t> &pl = planes[first_plane[g] + b];
+								pl.resize(w2.grp_val[g].size());
+								for (size_t q = 0; q < pl.size(); ++q) pl[q] = (uint8_t)(w2.grp_val[g][q] >> (8 * b));
+							}
+						for (size_t q = 0; q < w2.op_sc.size(); ++q) planes[13 + (op_u8(w2.op_sc[q]) >> 3)].push_back(op_u8(w2.op_sc[q]) & 7);
+						PlaneView views[21];
+						for (int k = 0; k < 21; ++k) views[k] = PlaneView(planes[k]);
+						auto skeleton = [&](Mesh &d) { d.nv = m2->nv; d.nf = m2->nf; d.declared_ne = m2->ne(); d.have_degree = m2->have_degree; };
+						Mesh seq, par;
+						skeleton(seq); skeleton(par);
+						OrderVec ov_seq, ov_par;
+						std::vector<uint32_t> ss0, sl0, ss1, sl1;
+						const std::vector<RestartPoint> no_points;
+						const std::vector<RestartCounters> no_counters;
+						cut_border_replay(seq, views, no_points, no_counters, ov_seq, ss0, sl0);
+						std::vector<RestartCounters> rc, sc;
+						const std::vector<RestartPoint> rs = select_restart_points(w2.marks, w2.named, rc, &w2.snapshots, &sc);
+						std::vector<uint8_t> sec;
+						std::vector<SnapshotPoint> snaps;
+						if (!w2.snapshots.empty()) {
+							write_snapshot_section(w2.snapshot_faces, w2.snapshots, sc, sec);
+							uint32_t spacing = 0;
+							if (read_snapshot_section(sec.data(), sec.size(), m2->nv, spacing, snaps) != sec.size()) throw Error(HRY_E_INTERNAL, "snapshots: the section does not read back");
+						}
+						cut_border_replay(par, views, rs, rc, ov_par, ss1, sl1, nullptr, &snaps);
+						if (seq.org != par.org || seq.twin != par.twin || seq.face_off != par.face_off || ov_seq != ov_par || ss0 != ss1 || sl0 != sl1) throw Error(HRY_E_INTERNAL, "replay from the directory's points differs from the sequential replay");
+#if !defined(__SANITIZE_THREAD__)   // (spans started from a damaged directory may overlap: every index is checked against the header's sizes, the result is an error -- but two threads may have written the same word)
+						for (size_t k = 0; k < sec.size() && k < 4000; ++k) {
+							std::vector<uint8_t> bad = sec;
+							bad[k] ^= (uint8_t)(1u << (k % 8));
+							try {
+								std::vector<SnapshotPoint> sn2;
+								uint32_t spacing = 0;
+								read_snapshot_section(bad.data(), bad.size(), m2->nv, spacing, sn2);
+								Mesh d;
+								skeleton(d);
+								OrderVec ov;
+								std::vector<uint32_t> a, b;
+								cut_border_replay(d, views, rs, rc, ov, a, b, nullptr, &sn2);
+							} catch (const Error &) {
+							}
+						}
+#endif
+					}
 					// ... and a shard of it walked in place on the whole mesh's arrays (the in-process executor's walk)
 					std::unique_ptr<Mesh> m3(ext == ".ply" ? mesh_from_ply(data.data(), data.size()) : mesh_from_obj(data.data(), data.size(), dir.c_str()));
 					ensure_twins(*m3);

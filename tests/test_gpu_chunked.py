@@ -173,15 +173,42 @@ def test_border_snapshots_container_and_decodes(cx, case, spacing, monkeypatch):
     assert np.array_equal(spans.twin(), plain.twin())
     monkeypatch.delenv("HRY_NO_PIPELINE")
     monkeypatch.setenv("HRY_PIPELINE_MIN_VERTICES", "0")
-    for faces, slice_ in ((64, 64), (1000, 4096)):
+    for faces, slice_, piece in ((64, 64, 128), (1000, 4096, 1024)):
         monkeypatch.setenv("HRY_PIPELINE_FACES", str(faces))
         monkeypatch.setenv("HRY_PIPELINE_SLICE", str(slice_))
+        monkeypatch.setenv("HRY_PIPELINE_LAST_PIECE", str(piece))          # (what is left behind the replay goes in pieces)
         piped = cx.read_hry(got)                                           # (where the pipelined decode applies: its first stretch publishes, the others run beside it)
         same_mesh(piped, ref_dec)
         assert np.array_equal(piped.twin(), plain.twin())
     # a container without snapshots is what it was before this round
     monkeypatch.setenv("HRY_NO_SNAPSHOTS", "1")
     assert cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=1000) == o.clone().encode_chunked(1000, 0).data
+
+
+@pytest.mark.parametrize("how", ["host-threads", "device-analysis"])
+def test_repaired_twins_that_split_a_component_take_one_thread(cx, how, monkeypatch):
+    """Triangle soups: edges shared by any number of faces.  The walk re-pairs such half-edges as it meets the faces
+    (cbm/encoder.h:150,193-198), and a repair can cut a component -- as the analysis in front of a walk on several threads saw it --
+    in two.  The encode notices (the component consumes fewer faces than promised), drops the attempt, matches the twins afresh
+    and walks on one thread: the reference's stream byte for byte, the oracle's container, the reference-format decode."""
+    monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
+    monkeypatch.setenv("HRY_HOST_THREADS", "6")
+    if how == "device-analysis":
+        monkeypatch.setenv("HRY_DEVICE_ANALYSIS_MIN_FACES", "1")
+    gen = mg.concat([mg.torus(12, 13, seed=1)] + [mg.soup(seed=s) for s in (5, 6, 13, 14, 16, 22)] + [mg.torus(10, 11, seed=2)])
+    ply = gen.to_ply()
+    o = op.Mesh.from_ply(ply)
+    compat = o.clone().encode().data
+    ref_dec = op.Mesh.from_hry(compat)
+    for _ in range(2):   # (twice: what the first encode leaves on the device must not matter)
+        a = hc.Mesh.from_ply(ply)
+        assert cx.write_hry(a.clone(), profile=hc.PROFILE_COMPAT) == compat
+        got = cx.write_hry(a.clone(), profile=hc.PROFILE_CHUNKED, chunk_syms=1000)
+        assert got == o.clone().encode_chunked(1000).data
+        same_mesh(cx.read_hry(got), ref_dec)
+        # a resident mesh: its device copy of the twins is the dropped attempt's until the whole array has gone up again
+        cx.upload(a)
+        assert cx.write_hry(a, profile=hc.PROFILE_CHUNKED, chunk_syms=1000) == got
 
 
 def test_damaged_border_snapshots_are_refused(cx, monkeypatch):

@@ -26,6 +26,10 @@ def _mesh(kind):
         return mg.with_nonmanifold(mg.multi_component(9, 13, 15, seed=4, polys="mixed"), 9, 5, seed=3)
     if kind == "tori_normals":
         return mg.concat([mg.torus(14 + 2 * i, 12 + i, seed=20 + i, normals=True, center=(3.0 * i, 0, 0)) for i in range(7)])
+    if kind == "soup_between_tori":   # edges shared by several faces: the walk REPAIRS twins (cbm/encoder.h:150,193-198) -- in the second of three shards
+        return mg.concat([mg.torus(12, 12, seed=2), mg.soup(20, 200, 28), mg.torus(9, 11, seed=7), mg.torus(6, 9, seed=1)])
+    if kind == "soups":   # ... and repairs that cut components in two: such a mesh ends up on ONE walking thread (host.hpp WalkMismatch)
+        return mg.concat([mg.torus(12, 13, seed=1)] + [mg.soup(seed=s) for s in (5, 6, 13, 14, 16, 22)] + [mg.torus(10, 11, seed=2)])
     if kind == "faceprops":
         return mg.with_face_props(mg.multi_component(6, 9, 11, seed=9, polys="tri"))
     raise ValueError(kind)
@@ -215,7 +219,7 @@ def test_resident_mesh_keeps_the_twins_that_contexts_of_other_devices_repaired(m
     monkeypatch.setenv("HRY_PARALLEL_MIN_FACES", "1")
     monkeypatch.setenv("HRY_HOST_THREADS", "6")
     monkeypatch.setenv("HRY_SHARD_FOREIGN_CONTEXTS", "1")
-    gen = _mesh("mixed_nm")
+    gen = _mesh("soup_between_tori")
     one = hc.Codec(0)
     try:
         want_one = one.write_hry(hc.Mesh.from_arrays(gen.verts, gen.degrees, gen.indices, gen.face_props), profile=hc.PROFILE_CHUNKED, chunk_syms=1024)
