@@ -471,7 +471,7 @@ bool replay_triangles(Mesh &m, const PlaneView *conn, uint16_t *seen, uint32_t *
 	{   // a triangle mesh: face f owns the half-edges 3 f .. 3 f + 2 (the counts are checked against the header at the end)
 		uint32_t *fo = m.face_off.data();
 		const size_t last = std::min<uint64_t>(stop_face != NONE32 ? (uint64_t)stop_face : (uint64_t)nf, std::min<uint64_t>((uint64_t)nf, ne_max / 3));
-		for (size_t i = cur.face; i <= last; ++i) fo[i] = (uint32_t)(3 * i);
+		for (size_t i = (size_t)cur.face + 1; i <= last; ++i) fo[i] = (uint32_t)(3 * i);   // (entry cur.face: the caller's 0, or the span's before this one)
 	}
 	// operation planes with a sentinel behind the last symbol (of the span)
 	std::vector<uint8_t> opl[8];
