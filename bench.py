@@ -664,6 +664,13 @@ def build_summary(line):
     encode / decode times, the host loops and the roofline fraction of every larger configuration."""
     sm = {"n_gpus": line.get("n_gpus"), "value": line.get("value"), "enc_mtri_s": line.get("encode_mtri_s"), "dec_mtri_s": line.get("decode_mtri_s"),
           "frac": (line.get("roofline") or {}).get("frac"), "kernel": (line.get("roofline") or {}).get("kernel")}
+    steps = line.get("step_ms_each")
+    if steps:   # (the mean is `ms_per_step`; on shared hosts one step in ten or twenty is an outlier of the two host loops)
+        sm["step_ms_median"] = round(float(np.median(steps)), 2)
+        sm["value_at_median_step"] = round(float(line["value"]) * float(line["ms_per_step"]) / float(np.median(steps)), 2) if line.get("ms_per_step") else None
+    st = line.get("stage_ms") or {}
+    if st.get("dec_host_walk_ms") is not None:
+        sm["host_walk_ms"] = st.get("host_walk_ms"); sm["host_replay_ms"] = st.get("dec_host_walk_ms"); sm["dec_ms"] = st.get("dec_total_ms"); sm["enc_ms"] = st.get("total_ms")
     if line.get("n_gpus", 1) > 1:
         sm.update(_pick(line, ("rccl_ranks", "n1_same_workload_value")))
         sm["cpu_ref"] = (line.get("cpu_baseline") or {}).get("value")
