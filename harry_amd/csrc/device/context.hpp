@@ -74,6 +74,7 @@ struct Context {
 	hipEvent_t attr_ev[kAttrGroups] = {};
 	void *h_down = nullptr;          // pinned landing buffer for the vertex records of the pipelined decode (device -> host per slice)
 	size_t h_down_cap = 0;
+	PinBuf h_mirror;                 // pipelined decode with border snapshots: pinned copies of the helper threads' stretches (face offsets, origins, twins, decode order), made by the helpers themselves
 	void *h_stage = nullptr;         // pinned staging memory for uploads that run next to a busy host thread (copies from
 	size_t h_stage_cap = 0;          // pageable memory make the runtime pin and unpin pages: TLB shootdowns for every thread)
 	hipStream_t pipe_stream = nullptr;   // chunked encode: what finished groups of a walk on several threads have coded goes to the planes beside the walk (chunked.cpp: EncodePipeline; created on first use)

@@ -611,6 +611,14 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 			uint64_t seen_seq = 0, seen_pub = 0;
 			std::vector<uint32_t> patches;
 			std::vector<ReplayLive::Range> ranges, ranges_up;   // stretches of helper threads: announced / on the device (round 6)
+			// the helpers' pinned copies go up on a stream of their own -- on the uploads' stream (stream2) the candidates of the next
+			// slice of the FIRST stretch sat behind a millisecond of the other stretches' transfers -- with an event each, which
+			// stream2 waits for when a publication reaches into them
+			std::vector<hipEvent_t> mir_ev;        // per entry of ranges_up (nullptr: came through stream2)
+			size_t mir_waited = 0;
+			if (!cx.up_stream[0]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[0], hipStreamNonBlocking));
+			const hipStream_t mir_stream = cx.up_stream[0];
+			struct DropEvents { std::vector<hipEvent_t> &v; ~DropEvents() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } drop_events{ mir_ev };
 			DevBuf &d_patch = cx.d_patch;   // persistent and sized before the pipeline starts: growing it here would synchronise the device (hipFree / hipMalloc) in mid-flight
 			Stager up(cx, cx.stream2);
 			hipEvent_t prepared;
@@ -651,26 +659,43 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 				if (newest.failed) break;
 				// a helper thread's finished stretch goes up at once (nobody is writing there any more)
 				for (const ReplayLive::Range &r : ranges) {
+					hipEvent_t rev = nullptr;
+					if (r.mirrored) {   // (the helper left a pinned copy: four transfers, no copy on this thread)
+						const uint32_t *mf = cx.h_mirror.as<uint32_t>(), *mo = mf + (size_t)nf + 1, *mt = mo + ne, *mv = mt + ne;
+						if (r.f1 > r.f0) HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + r.f0 + 1, mf + r.f0 + 1, ((size_t)r.f1 - r.f0) * 4, hipMemcpyHostToDevice, mir_stream));
+						if (r.h1 > r.h0) {
+							HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + r.h0, mo + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, mir_stream));
+							HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + r.h0, mt + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, mir_stream));
+						}
+						if (r.v1 > r.v0) HIP_OK(hipMemcpyAsync(cx.d_order_v.as<uint32_t>() + r.v0, mv + r.v0, ((size_t)r.v1 - r.v0) * 4, hipMemcpyHostToDevice, mir_stream));
+						HIP_OK(hipEventCreateWithFlags(&rev, hipEventDisableTiming));
+						HIP_OK(hipEventRecord(rev, mir_stream));
+					} else {
 					if (r.f1 > r.f0) up.put(cx.d_foff.as<uint32_t>() + r.f0 + 1, m->face_off.data() + r.f0 + 1, ((size_t)r.f1 - r.f0) * 4);
 					if (r.h1 > r.h0) {
 						up.put(cx.d_org.as<uint32_t>() + r.h0, m->org.data() + r.h0, ((size_t)r.h1 - r.h0) * 4);
 						up.put(cx.d_twin.as<uint32_t>() + r.h0, m->twin.data() + r.h0, ((size_t)r.h1 - r.h0) * 4);
 					}
 					if (r.v1 > r.v0) up.put(cx.d_order_v.as<uint32_t>() + r.v0, order_v.data() + r.v0, ((size_t)r.v1 - r.v0) * 4);
+					}
 					if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  a helper's stretch (faces %u .. %u) is on its way up\n", ms_since(t_begin), r.f0, r.f1);
 					ranges_up.push_back(r);
+					mir_ev.push_back(rev);
 				}
 				ranges.clear();
 				if (newest.n_pub == seen_pub) continue;   // (a helper's announcement only: no new publication of the replaying thread)
 				seen_pub = newest.n_pub;
 				if (trace_on() && getenv("HRY_TRACE_CONSUMER")) fprintf(stderr, "[hry] %8.3f ms    consumer: publication %llu (faces %u, vertices final up to %u)\n", ms_since(t_begin), (unsigned long long)newest.seq, newest.faces, newest.upto);
 				hist.push_back(newest);
-				if (!newest.done && hist.size() <= lag) continue;
-				const ReplayLive::Pub P = newest.done ? newest : hist.front();
+				if (!newest.done && !newest.joined && hist.size() <= lag) continue;
+				const ReplayLive::Pub P = newest.done || newest.joined ? newest : hist.front();
 				while (!hist.empty() && hist.front().n_pub <= P.n_pub) hist.pop_front();
+				// (a publication behind the replaying thread's own stretch rests on the helpers' stretches: their transfers first)
+				if (P.joined || P.done) for (; mir_waited < mir_ev.size(); ++mir_waited) if (mir_ev[mir_waited]) HIP_OK(hipStreamWaitEvent(cx.stream2, mir_ev[mir_waited], 0));
 				// finished part of the connectivity -- but for what the helpers' stretches have brought up already
 				if (P.faces > f_up) {
-					std::sort(ranges_up.begin(), ranges_up.end(), [](const ReplayLive::Range &a, const ReplayLive::Range &b) { return a.f0 < b.f0; });
+					std::vector<ReplayLive::Range> by_face(ranges_up);
+					std::sort(by_face.begin(), by_face.end(), [](const ReplayLive::Range &a, const ReplayLive::Range &b) { return a.f0 < b.f0; });
 					uint32_t f = f_up, h = he_up;
 					auto copy_upto = [&](uint32_t f_to, uint32_t he_to) {
 						if (f_to <= f) return;
@@ -678,7 +703,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 						up.put(cx.d_org.as<uint32_t>() + h, m->org.data() + h, ((size_t)he_to - h) * 4);
 						up.put(cx.d_twin.as<uint32_t>() + h, m->twin.data() + h, ((size_t)he_to - h) * 4);
 					};
-					for (const ReplayLive::Range &r : ranges_up) {
+					for (const ReplayLive::Range &r : by_face) {
 						if (r.f1 <= f || r.f0 >= P.faces) continue;
 						copy_upto(std::min(r.f0, P.faces), std::min(r.h0, P.he));
 						f = std::max(f, r.f1); h = std::max(h, r.h1);
@@ -688,7 +713,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 				}
 				// vertices that can no longer change: whole tiles, slices of a useful size
 				const uint32_t v_hi = P.done ? nv : (P.upto & ~63u);
-				if (v_hi > v_done && (P.done || v_hi - v_done >= std::min(min_slice, std::max(first_slice, v_done)))) {
+				if (v_hi > v_done && (P.done || P.joined || v_hi - v_done >= std::min(min_slice, std::max(first_slice, v_done)))) {
 					// late links of edges that were copied before (a patch of an edge that is copied later is harmless: the copy
 					// carries the final value too)
 					if (!patches.empty()) {
@@ -698,9 +723,10 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 						patches.clear();
 					}
 					{   // the decode order of the slice's vertices (the helpers' stretches brought theirs)
-						std::sort(ranges_up.begin(), ranges_up.end(), [](const ReplayLive::Range &a, const ReplayLive::Range &b) { return a.f0 < b.f0; });
+						std::vector<ReplayLive::Range> by_face(ranges_up);
+						std::sort(by_face.begin(), by_face.end(), [](const ReplayLive::Range &a, const ReplayLive::Range &b) { return a.f0 < b.f0; });
 						uint32_t v = std::max(v_done, v_up);
-						for (const ReplayLive::Range &r : ranges_up) {
+						for (const ReplayLive::Range &r : by_face) {
 							if (r.v1 <= v || r.v0 >= v_hi) continue;
 							if (r.v0 > v) up.put(cx.d_order_v.as<uint32_t>() + v, order_v.data() + v, ((size_t)std::min(r.v0, v_hi) - v) * 4);
 							v = std::max(v, r.v1);
@@ -715,7 +741,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 					// (round 6: what is left when the replay is done -- since its stretches run side by side, most of the mesh -- goes in
 					// pieces: a piece's records come down while the next piece's chain runs, and its candidates are found beside the chain
 					// of the piece before)
-					const uint32_t piece = P.done && v_hi - v_done > 3 * last_piece ? last_piece : v_hi - v_done;
+					const uint32_t piece = (P.done || P.joined) && v_hi - v_done > 3 * last_piece ? last_piece : v_hi - v_done;
 					for (uint32_t v_lo = v_done; v_lo < v_hi;) {
 						const uint32_t v_to = v_hi - v_lo <= piece + piece / 2 ? v_hi : v_lo + piece;
 						SliceClock ck;
@@ -779,6 +805,14 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 		if (count) pc.start();
 		if (spans) {
 			spans->announce_to = &live;   // (the consumer copies a helper's stretch as soon as it is finished)
+			{   // ... from pinned mirrors the helpers fill themselves, where the mesh is small enough for them (128 MB)
+				const size_t words = (size_t)nf + 1 + 2 * (size_t)ne + nv;
+				if (words * 4 <= ((size_t)128 << 20) && !getenv("HRY_NO_MIRRORS")) {
+					cx.h_mirror.ensure(words * 4);
+					uint32_t *p0 = cx.h_mirror.as<uint32_t>();
+					spans->mirror_foff = p0; spans->mirror_org = p0 + (size_t)nf + 1; spans->mirror_twin = spans->mirror_org + ne; spans->mirror_order = spans->mirror_twin + ne;
+				}
+			}
 			spans->start(host_threads() - 1);
 			BorderEnd end0;
 			size_t cur_end0[21];

@@ -138,6 +138,12 @@ struct SeenOfSpan {
 	SeenOfSpan &operator=(const SeenOfSpan&) = delete;
 };
 struct ReplayLive;
+struct SpanJoiner {   // (cbm_unwalk.cpp) the spans' placeholders resolved one span after the other, in stream order
+	Mesh &m;
+	std::vector<uint32_t> real_prev;   // what the placeholders of the span before were
+	explicit SpanJoiner(Mesh &mesh) : m(mesh) {}
+	void step(size_t k, const SnapshotPoint *seed, const SnapshotPoint *seed_before, uint32_t sym_base, uint32_t sym_base_before, const BorderEnd &end_before, ReplayLive *live);
+};
 void join_spans(Mesh &m, const std::vector<const SnapshotPoint*> &seeds, const std::vector<uint32_t> &sym_base, const std::vector<BorderEnd> &ends, ReplayLive *live);
 // A triangle mesh whose replay publishes its progress (unchunk.cpp: the pipelined decode) and whose directory holds border
 // snapshots: the caller replays the stretch up to the first snapshot itself, publishing as it goes; the stretches behind the
@@ -150,7 +156,7 @@ struct SnapshotSpans {
 	uint32_t *order_v;
 	size_t n_spans = 0;
 	uint64_t n_sym = 0;
-	struct Span { ReplayCursor cur; size_t cur0[21], cur1[21], cur_end[21]; uint32_t stop_face = 0xffffffffu; bool stop_mid = false, eom = false; BorderSeed seed; std::vector<uint32_t> first; std::vector<std::pair<uint32_t, uint32_t>> refs; };
+	struct Span { ReplayCursor cur; size_t cur0[21], cur1[21], cur_end[21]; uint32_t stop_face = 0xffffffffu; bool stop_mid = false, eom = false, done = false; BorderSeed seed; std::vector<uint32_t> first; std::vector<std::pair<uint32_t, uint32_t>> refs; };
 	std::vector<Span> spans;
 	std::vector<const SnapshotPoint*> seeds;
 	std::vector<uint32_t> sym_base;
@@ -158,6 +164,7 @@ struct SnapshotSpans {
 	std::vector<std::thread> helpers;
 	std::atomic<size_t> next{ 1 };
 	std::mutex mu;
+	std::condition_variable cv;
 	std::exception_ptr failed;
 	// checks the snapshots against the header's sizes, sizes m.twin for the placeholders (m.org / m.twin / m.face_off are
 	// allocated by the caller before) -- start() then sets the helpers off
@@ -169,6 +176,9 @@ struct SnapshotSpans {
 	// patches of `live`) and leaves the last stretch's cursor in `cur`
 	void finish(ReplayCursor &cur, const size_t *cur_end0, BorderEnd &&end0, bool eom0, ReplayLive *live);
 	ReplayLive *announce_to = nullptr;   // (set before start(): finished stretches are announced there)
+	// (set before start(), or nullptr) pinned mirrors of face offsets (nf + 1 words), origins, twins (declared_ne words each) and the
+	// decode order (nv words): a helper copies its finished stretch there itself -- the consumer then only starts the transfers
+	uint32_t *mirror_foff = nullptr, *mirror_org = nullptr, *mirror_twin = nullptr, *mirror_order = nullptr;
 };
 constexpr uint32_t kContinues = 0xffffffffu;   // refs of a span that starts inside a component: "the component the span before me ended in"
 
@@ -180,7 +190,7 @@ constexpr uint32_t kContinues = 0xffffffffu;   // refs of a span that starts ins
 // smallest id still on the border.  Twins of edges that lie below the last published half-edge count may already have been
 // copied by the consumer: later links of such edges are recorded as patches (idempotent index/value pairs).
 struct ReplayLive {
-	struct Pub { uint64_t seq = 0, n_pub = 0; uint32_t faces = 0, he = 0, upto = 0; bool done = false, failed = false; };   // seq: announcements of any kind; n_pub: publications of the replaying thread
+	struct Pub { uint64_t seq = 0, n_pub = 0; uint32_t faces = 0, he = 0, upto = 0; bool done = false, failed = false, joined = false; };   // seq: announcements of any kind; n_pub: publications of the replaying thread; joined: behind the replaying thread's own stretch (nothing of it is in that thread's cache: no lag)
 	std::mutex mu;
 	std::atomic<uint64_t> announced{ 0 };      // pub.seq, readable without the lock: the consumer polls it (a condition variable
 	                                           // costs the replay a futex wake per publication, 3 us each, 7 % of its time)
@@ -189,7 +199,7 @@ struct ReplayLive {
 	// Round 6 (SnapshotSpans): a stretch of the replay that ran on a helper thread, finished -- its faces' offsets, its half-edges'
 	// origins and twins (placeholders of border edges included: patched when the stretches are joined) and its vertices' decode
 	// order are where they will stay, the consumer may copy them while the other stretches are still running
-	struct Range { uint32_t f0, f1, h0, h1, v0, v1; };
+	struct Range { uint32_t f0, f1, h0, h1, v0, v1; bool mirrored; };   // mirrored: the stretch lies in the pinned mirrors too (SnapshotSpans)
 	std::vector<Range> ranges;                 // guarded by mu: since the consumer last took them
 	void range_done(const Range &r)
 	{
@@ -208,6 +218,17 @@ struct ReplayLive {
 		if (b < he_pub) { pending.push_back(b); pending.push_back(a); }
 	}
 	double t_publish_ms = 0, t_lock_ms = 0; uint32_t n_publish = 0;
+	// (round 6) a stretch of a helper thread has been joined with the ones before it: faces / half-edges up to its end are final
+	// (patches pending), vertices below `upto` have every face
+	void publish_at(uint32_t face, uint32_t he, uint32_t upto)
+	{
+		std::lock_guard<std::mutex> g(mu);
+		++pub.seq; ++pub.n_pub; pub.faces = face; pub.he = he; pub.upto = upto; pub.done = false; pub.failed = false; pub.joined = true;
+		patches.insert(patches.end(), pending.begin(), pending.end());
+		pending.clear();
+		face_pub = face; he_pub = he;
+		announced.store(pub.seq, std::memory_order_release);
+	}
 	void publish(uint32_t face, uint32_t he, uint32_t next_id, bool done, bool failed = false)
 	{
 		auto t0 = std::chrono::steady_clock::now();
@@ -220,7 +241,7 @@ struct ReplayLive {
 		}
 		{
 			std::lock_guard<std::mutex> g(mu);
-			++pub.seq; ++pub.n_pub; pub.faces = face; pub.he = he; pub.upto = done ? next_id : min_open; pub.done = done; pub.failed = failed;
+			++pub.seq; ++pub.n_pub; pub.faces = face; pub.he = he; pub.upto = done ? next_id : min_open; pub.done = done; pub.failed = failed; pub.joined = false;
 			patches.insert(patches.end(), pending.begin(), pending.end());
 			announced.store(pub.seq, std::memory_order_release);   // (inside the lock since round 6: helper threads announce their stretches too)
 		}

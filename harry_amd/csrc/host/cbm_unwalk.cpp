@@ -366,46 +366,47 @@ SeenOfSpan::SeenOfSpan(uint32_t nv)
 }
 SeenOfSpan::~SeenOfSpan() { if (p) munmap(p, bytes); }
 
-// Every span has run: span k + 1 started from snapshot k + 1 with placeholders for the half-edges of the border's elements, span k
-// stopped there with the border it had -- the same border (checked: parts, vertices, counts), whose half-edges are what the
-// placeholders stood for (possibly placeholders of span k's own start, resolved a step earlier).  What span k + 1 linked a
-// placeholder to sits in the twin array at the placeholder's index: the link goes to the real half-edge, both ways.
-// sym_base[k], n_sym[k]: the placeholders of span k (n_sym 0: it did not start inside a component); ends[k]: its last border
-// (empty: it ended between components).  live: links into the part of the arrays a consumer may have copied are noted as patches.
-void join_spans(Mesh &m, const std::vector<const SnapshotPoint*> &seeds, const std::vector<uint32_t> &sym_base, const std::vector<BorderEnd> &ends, ReplayLive *live)
+// Span k started from snapshot k with placeholders for the half-edges of the border's elements, span k - 1 stopped there with the
+// border it had -- the same border (checked: parts, vertices, counts), whose half-edges are what the placeholders stood for
+// (possibly placeholders of span k - 1's own start, resolved a step earlier).  What span k linked a placeholder to sits in the twin
+// array at the placeholder's index: the link goes to the real half-edge, both ways.  One span after the other, in stream order:
+// step(k) when spans k - 1 and k have finished.  live: links into the part of the arrays a consumer may have copied are noted as
+// patches (a patch of an entry that is copied later is harmless: the copy carries the final value too).
+void SpanJoiner::step(size_t k, const SnapshotPoint *seed, const SnapshotPoint *seed_before, uint32_t sym_base, uint32_t sym_base_before, const BorderEnd &end_before, ReplayLive *live)
 {
 	const uint32_t ne = m.declared_ne;
 	uint32_t *twin = m.twin.data();
-	std::vector<uint32_t> real_prev, real;   // what the placeholders of the span before / of this span were
-	for (size_t k = 0; k < seeds.size(); ++k) {
-		real.clear();
-		if (seeds[k]) {
-			if (k == 0) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
-			const SnapshotPoint &S = *seeds[k];
-			const BorderEnd &E = ends[k - 1];
-			if (E.parts != S.parts || E.vtx != S.vtx || E.seen != S.seen) throw Error(HRY_E_FORMAT, "corrupt chunked directory (a border snapshot does not match the stream)");
-			real.resize(S.vtx.size());
-			for (size_t j = 0; j < real.size(); ++j) {
-				uint32_t a = E.a[j];
-				if (a >= ne) {   // an element the span before never touched: what it was at ITS start
-					const uint32_t i = a - sym_base[k - 1];
-					if (!seeds[k - 1] || a < sym_base[k - 1] || i >= real_prev.size()) throw Error(HRY_E_INTERNAL, "replay: stray placeholder");
-					a = real_prev[i];
-				}
-				real[j] = a;
+	std::vector<uint32_t> real;
+	if (seed) {
+		if (k == 0) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+		const SnapshotPoint &S = *seed;
+		const BorderEnd &E = end_before;
+		if (E.parts != S.parts || E.vtx != S.vtx || E.seen != S.seen) throw Error(HRY_E_FORMAT, "corrupt chunked directory (a border snapshot does not match the stream)");
+		real.resize(S.vtx.size());
+		for (size_t j = 0; j < real.size(); ++j) {
+			uint32_t a = E.a[j];
+			if (a >= ne) {   // an element the span before never touched: what it was at ITS start
+				const uint32_t i = a - sym_base_before;
+				if (!seed_before || a < sym_base_before || i >= real_prev.size()) throw Error(HRY_E_INTERNAL, "replay: stray placeholder");
+				a = real_prev[i];
 			}
-			for (size_t j = 0; j < real.size(); ++j) {
-				const uint32_t sym = sym_base[k] + (uint32_t)j, t = twin[sym];
-				if (t == sym) continue;   // still on the border when the span ended (or closed onto itself: never -- a border edge meets an edge of a new face)
-				if (t >= ne) throw Error(HRY_E_INTERNAL, "replay: a placeholder linked to a placeholder");
-				twin[real[j]] = t; twin[t] = real[j];
-				// (both entries may be on the device already -- the first stretch's published half-edges, a helper's finished stretch:
-				// a patch of an entry that is copied later is harmless, the copy carries the final value too)
-				if (live) { live->pending.push_back(real[j]); live->pending.push_back(t); live->pending.push_back(t); live->pending.push_back(real[j]); }
-			}
+			real[j] = a;
 		}
-		real_prev.swap(real);
+		for (size_t j = 0; j < real.size(); ++j) {
+			const uint32_t sym = sym_base + (uint32_t)j, t = twin[sym];
+			if (t == sym) continue;   // still on the border when the span ended (or closed onto itself: never -- a border edge meets an edge of a new face)
+			if (t >= ne) throw Error(HRY_E_INTERNAL, "replay: a placeholder linked to a placeholder");
+			twin[real[j]] = t; twin[t] = real[j];
+			if (live) { live->pending.push_back(real[j]); live->pending.push_back(t); live->pending.push_back(t); live->pending.push_back(real[j]); }
+		}
 	}
+	real_prev.swap(real);
+}
+void join_spans(Mesh &m, const std::vector<const SnapshotPoint*> &seeds, const std::vector<uint32_t> &sym_base, const std::vector<BorderEnd> &ends, ReplayLive *live)
+{
+	SpanJoiner J(m);
+	static const BorderEnd none;
+	for (size_t k = 0; k < seeds.size(); ++k) J.step(k, seeds[k], k ? seeds[k - 1] : nullptr, sym_base[k], k ? sym_base[k - 1] : 0u, k ? ends[k - 1] : none, live);
 }
 
 SnapshotSpans::SnapshotSpans(Mesh &mesh, const PlaneView *planes, const std::vector<SnapshotPoint> &points, uint32_t *ov) : m(mesh), conn(planes), snaps(points), order_v(ov)
@@ -460,11 +461,21 @@ void SnapshotSpans::start(unsigned n_threads)
 				if (count) pc.start();
 				sp.eom = replay_triangles<false>(m, conn, own.p, order_v, sp.cur, sp.first, sp.refs, nullptr, sp.cur0, sp.cur1, sp.stop_face, sp.stop_mid, &sp.seed, &ends[k], sp.cur_end);
 				if (count) { pc.stop(); char what[64]; snprintf(what, sizeof what, "replay, stretch %zu on a helper thread", k); pc.report(what, (double)(sp.cur.face - c0.face)); }
-				if (announce_to) announce_to->range_done(ReplayLive::Range{ c0.face, sp.cur.face, c0.he, sp.cur.he, c0.next_id, sp.cur.next_id });
+				if (announce_to) {
+					const bool mir = mirror_org != nullptr;
+					if (mir) {   // (placeholders in the twins included: the join's patches follow)
+						if (sp.cur.face > c0.face) memcpy(mirror_foff + c0.face + 1, m.face_off.data() + c0.face + 1, ((size_t)sp.cur.face - c0.face) * 4);
+						if (sp.cur.he > c0.he) { memcpy(mirror_org + c0.he, m.org.data() + c0.he, ((size_t)sp.cur.he - c0.he) * 4); memcpy(mirror_twin + c0.he, m.twin.data() + c0.he, ((size_t)sp.cur.he - c0.he) * 4); }
+						if (sp.cur.next_id > c0.next_id) memcpy(mirror_order + c0.next_id, order_v + c0.next_id, ((size_t)sp.cur.next_id - c0.next_id) * 4);
+					}
+					announce_to->range_done(ReplayLive::Range{ c0.face, sp.cur.face, c0.he, sp.cur.he, c0.next_id, sp.cur.next_id, mir });
+				}
+				{ std::lock_guard<std::mutex> g(mu); sp.done = true; }
+				cv.notify_all();
 				if (trace) fprintf(stderr, "[hry replay]   stretch %zu: %.3f .. %.3f ms after the helpers were set off, on cpu %d\n", k, std::chrono::duration<double, std::milli>(t_a - t_start).count(),
 				                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), sched_getcpu());
 			}
-		} catch (...) { std::lock_guard<std::mutex> g(mu); if (!failed) failed = std::current_exception(); }
+		} catch (...) { { std::lock_guard<std::mutex> g(mu); if (!failed) failed = std::current_exception(); } cv.notify_all(); }
 	};
 	const size_t nt = std::min<size_t>(std::max(1u, n_threads), n_spans - 1);
 	helpers.reserve(nt);
@@ -473,23 +484,39 @@ void SnapshotSpans::start(unsigned n_threads)
 SnapshotSpans::~SnapshotSpans() { next.store(n_spans, std::memory_order_relaxed); for (auto &h : helpers) if (h.joinable()) h.join(); }
 void SnapshotSpans::finish(ReplayCursor &cur, const size_t *cur_end0, BorderEnd &&end0, bool eom0, ReplayLive *live)
 {
-	for (auto &h : helpers) if (h.joinable()) h.join();
-	if (failed) std::rethrow_exception(failed);
 	spans[0].cur = cur; spans[0].eom = eom0;
 	for (int p = 0; p < 21; ++p) spans[0].cur_end[p] = cur_end0[p];
 	ends[0] = std::move(end0);
-	for (size_t k = 0; k < n_spans; ++k) {   // a stretch ends exactly where the next one starts, in every counter
+	SpanJoiner J(m);
+	static const BorderEnd none;
+	J.step(0, nullptr, nullptr, 0, 0, none, live);
+	// one stretch after the other, as they finish: a stretch ends exactly where the next one starts, in every counter; joined with
+	// the stretches before it, its vertices below the smallest one on its last border have every face (no vertex is named twice
+	// here: none returns to a border) -- published at once, the consumer goes on while the later stretches are waited for
+	for (size_t k = 0; k < n_spans; ++k) {
+		if (k > 0) {
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return spans[k].done || failed; });
+			if (failed) { lk.unlock(); for (auto &h : helpers) if (h.joinable()) h.join(); std::rethrow_exception(failed); }
+		}
 		const Span &sp = spans[k];
+		if (k > 0) {
+			const Span &sb = spans[k - 1];
+			const RestartPoint &r = snaps[k - 1].at;
+			bool ok = !sb.eom && sb.cur.face == r.first_face && sb.cur.next_id == r.first_vertex && sb.cur.he == r.first_halfedge && !ends[k - 1].parts.empty();
+			for (int p = 0; p < 21 && ok; ++p) if (p != 11 && p != 12) ok = sb.cur_end[p] == sp.cur0[p];   // (triangles: no counts of triangles per polygon)
+			if (!ok) throw Error(HRY_E_FORMAT, "corrupt chunked directory (a border snapshot does not match the stream)");
+			J.step(k, seeds[k], seeds[k - 1], sym_base[k], sym_base[k - 1], ends[k - 1], live);
+		}
 		if (k + 1 == n_spans) {
 			if (!sp.eom || sp.cur.face != m.nf || sp.cur.he != m.declared_ne) throw Error(HRY_E_FORMAT, "corrupt stream (face count)");
-			break;
+		} else if (live && k > 0) {
+			uint32_t upto = sp.cur.next_id;
+			for (const uint32_t v : ends[k].vtx) upto = std::min(upto, v);
+			live->publish_at(sp.cur.face, sp.cur.he, upto);
 		}
-		const RestartPoint &r = snaps[k].at;
-		bool ok = !sp.eom && sp.cur.face == r.first_face && sp.cur.next_id == r.first_vertex && sp.cur.he == r.first_halfedge && !ends[k].parts.empty();
-		for (int p = 0; p < 21 && ok; ++p) if (p != 11 && p != 12) ok = sp.cur_end[p] == spans[k + 1].cur0[p];   // (triangles: no counts of triangles per polygon)
-		if (!ok) throw Error(HRY_E_FORMAT, "corrupt chunked directory (a border snapshot does not match the stream)");
 	}
-	join_spans(m, seeds, sym_base, ends, live);
+	for (auto &h : helpers) if (h.joinable()) h.join();
 	m.twin.resize(m.declared_ne);
 	cur = spans.back().cur;
 }

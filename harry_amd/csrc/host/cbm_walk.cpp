@@ -1820,7 +1820,7 @@ uint32_t snapshot_spacing(uint32_t nf)
 	if (getenv("HRY_NO_SNAPSHOTS")) return 0;
 	if (const char *e = getenv("HRY_SNAPSHOT_FACES")) return (uint32_t)strtoul(e, nullptr, 10);
 	uint32_t sp = kSnapshotMinFaces;
-	while ((uint64_t)sp * 32u < nf) sp <<= 1;
+	while ((uint64_t)sp * 64u < nf) sp <<= 1;
 	return sp;
 }
 

@@ -216,13 +216,14 @@ size_t read_prior(const uint8_t *p, size_t avail, bool &use, uint32_t table[256]
 }
 
 // ---- border snapshots in the chunked container's directory (host.hpp BorderSnapshot; the oracle restates the form)
-//   u32 spacing, u32 n; per snapshot: 17 u32 like a restart point (flags = 0), u32 n_counters, n_counters x (u32 vertex, u32 counter),
-//   u32 n_parts, u32 n_elements, u32 blob_bytes, blob, zero bytes up to a multiple of four.
-// blob, all numbers as LEB128 varints: per part `size << 1 | edge_begin`; then the elements' vertices as differences from "the
-// vertex before + 1" (before the first element: the snapshot's next vertex), zigzag-folded, in runs -- `length of a run of zeros`,
-// then the non-zero value that ends it (nothing behind the last element); then the triangle counts (0 .. 9) the same way, as
-// differences from the count before (before the first: 3).  Along a border the vertices mostly follow each other and have seen
-// three triangles: a part of a thousand elements is a handful of bytes.
+//   u32 spacing, u32 n, u32 bytes, then `bytes` bytes of LEB128 varints, then zero bytes up to a multiple of four (from the section's
+//   first byte).  Per snapshot: the cursors of a restart point -- symbols consumed per plane group (5) and operation class (8), next
+//   vertex, face, half-edge --, the number of counters and the (vertex, counter) pairs, the number of parts and of elements; per part
+//   `size << 1 | edge_begin`; then the elements' vertices as differences from "the vertex before + 1" (before the first element: the
+//   snapshot's next vertex), zigzag-folded, in runs -- `length of a run of zeros`, then the non-zero value that ends it (nothing
+//   behind the last element); then the triangle counts (0 .. 9) the same way, as differences from the count before (before the
+//   first: 3).  Along a border the vertices mostly follow each other and have seen three triangles: a snapshot of a thousand
+//   elements is some eighty bytes, half of them its cursors.
 namespace {
 void put_varint(std::vector<uint8_t> &o, uint64_t v) { while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; } o.push_back((uint8_t)v); }
 uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
@@ -254,60 +255,59 @@ struct VarintReader {
 
 void write_snapshot_section(uint32_t spacing, const std::vector<BorderSnapshot> &snaps, const std::vector<RestartCounters> &counters, std::vector<uint8_t> &out)
 {
+	const size_t sec0 = out.size();
 	auto put32 = [&](uint32_t v) { const uint8_t *q = (const uint8_t*)&v; out.insert(out.end(), q, q + 4); };
-	put32(spacing); put32((uint32_t)snaps.size());
-	std::vector<uint8_t> blob;
+	std::vector<uint8_t> body;
 	for (size_t k = 0; k < snaps.size(); ++k) {
 		const BorderSnapshot &S = snaps[k];
-		for (int g = 0; g < G_COUNT; ++g) put32(S.n_grp[g]);
-		for (int i = 0; i < 8; ++i) put32(S.n_op[i]);
-		put32(S.first_vertex); put32(S.first_face); put32(S.first_halfedge); put32(0);
+		for (int g = 0; g < G_COUNT; ++g) put_varint(body, S.n_grp[g]);
+		for (int i = 0; i < 8; ++i) put_varint(body, S.n_op[i]);
+		put_varint(body, S.first_vertex); put_varint(body, S.first_face); put_varint(body, S.first_halfedge);
 		const RestartCounters none, &cs = k < counters.size() ? counters[k] : none;
-		put32((uint32_t)cs.size());
-		for (const auto &c : cs) { put32(c.first); put32(c.second); }
-		put32((uint32_t)S.parts.size()); put32((uint32_t)S.vtx.size());
-		blob.clear();
-		for (uint32_t pt : S.parts) put_varint(blob, pt);
-		put_runs(blob, S.vtx.size(), [&](size_t i) { return (int64_t)S.vtx[i] - ((int64_t)(i ? S.vtx[i - 1] : S.first_vertex - 1u) + 1); });
-		put_runs(blob, S.seen.size(), [&](size_t i) { return (int64_t)S.seen[i] - (int64_t)(i ? S.seen[i - 1] : 3); });
-		put32((uint32_t)blob.size());
-		out.insert(out.end(), blob.begin(), blob.end());
-		while (out.size() & 3) out.push_back(0);
+		put_varint(body, cs.size());
+		for (const auto &c : cs) { put_varint(body, c.first); put_varint(body, c.second); }
+		put_varint(body, S.parts.size()); put_varint(body, S.vtx.size());
+		for (uint32_t pt : S.parts) put_varint(body, pt);
+		put_runs(body, S.vtx.size(), [&](size_t i) { return (int64_t)S.vtx[i] - ((int64_t)(i ? S.vtx[i - 1] : S.first_vertex - 1u) + 1); });
+		put_runs(body, S.seen.size(), [&](size_t i) { return (int64_t)S.seen[i] - (int64_t)(i ? S.seen[i - 1] : 3); });
 	}
+	put32(spacing); put32((uint32_t)snaps.size()); put32((uint32_t)body.size());
+	out.insert(out.end(), body.begin(), body.end());
+	while ((out.size() - sec0) & 3) out.push_back(0);
 }
 
 size_t read_snapshot_section(const uint8_t *p, size_t avail, uint32_t nv, uint32_t &spacing, std::vector<SnapshotPoint> &out)
 {
-	size_t k = 0;
-	auto need = [&](size_t n) { if (n > avail - k) throw Error(HRY_E_FORMAT, "truncated chunked directory"); };
-	auto get32 = [&]() { need(4); uint32_t v; memcpy(&v, p + k, 4); k += 4; return v; };
-	spacing = get32();
-	const uint32_t n = get32();
-	if ((uint64_t)n * (kRestartWords * 4 + 16) > avail) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+	if (avail < 12) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+	uint32_t n, nb;
+	memcpy(&spacing, p, 4); memcpy(&n, p + 4, 4); memcpy(&nb, p + 8, 4);
+	const size_t total = (12 + (size_t)nb + 3) & ~(size_t)3;
+	if (nb > avail - 12 || total > avail || (uint64_t)n * 20 > nb) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+	for (size_t k = 12 + nb; k < total; ++k) if (p[k]) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+	VarintReader rd{ p + 12, p + 12 + nb };
+	auto get32 = [&]() -> uint32_t { const uint64_t v = rd.get(); if (v > 0xffffffffull) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)"); return (uint32_t)v; };
 	out.clear(); out.resize(n);
 	for (uint32_t q = 0; q < n; ++q) {
 		SnapshotPoint &S = out[q];
-		need(sizeof(RestartPoint));
-		memcpy(&S.at, p + k, sizeof(RestartPoint));
-		k += sizeof(RestartPoint);
+		for (int g = 0; g < G_COUNT; ++g) S.at.n_grp[g] = get32();
+		for (int i = 0; i < 8; ++i) S.at.n_op[i] = get32();
+		S.at.first_vertex = get32(); S.at.first_face = get32(); S.at.first_halfedge = get32(); S.at.flags = 0;
 		const uint32_t nc = get32();
-		if ((uint64_t)nc * 8 > avail - k) throw Error(HRY_E_FORMAT, "truncated chunked directory");
+		if ((uint64_t)nc * 2 > nb) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
 		S.counters.resize(nc);
 		for (uint32_t j = 0; j < nc; ++j) { const uint32_t a = get32(), b = get32(); S.counters[j] = { a, b }; }
-		const uint32_t n_parts = get32(), n_elems = get32(), nb = get32();
-		need(nb);
-		// (every element costs at least ... nothing: a run covers any number of them; the bounds are the mesh's)
+		const uint32_t n_parts = get32(), n_elems = get32();
+		// (a run covers any number of elements in a byte or two: the bounds are the mesh's)
 		if (n_parts == 0 || n_parts > n_elems || n_elems > (uint64_t)2 * nv + 4) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
-		VarintReader rd{ p + k, p + k + nb };
 		S.parts.resize(n_parts);
-		uint64_t total = 0;
+		uint64_t sum = 0;
 		for (uint32_t i = 0; i < n_parts; ++i) {
 			const uint64_t v = rd.get();
 			if (v >> 1 < 1 || v >> 1 > n_elems) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
 			S.parts[i] = (uint32_t)v;
-			total += v >> 1;
+			sum += v >> 1;
 		}
-		if (total != n_elems) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+		if (sum != n_elems) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
 		S.vtx.resize(n_elems); S.seen.resize(n_elems);
 		for (uint32_t i = 0; i < n_elems;) {
 			const uint64_t run = rd.get();
@@ -326,11 +326,9 @@ size_t read_snapshot_section(const uint8_t *p, size_t avail, uint32_t nv, uint32
 				S.seen[i] = (uint8_t)v; ++i;
 			}
 		}
-		if (rd.p != rd.end) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
-		k += nb;
-		while (k & 3) { need(1); ++k; }
 	}
-	return k;
+	if (rd.p != rd.end) throw Error(HRY_E_FORMAT, "corrupt chunked directory (border snapshot)");
+	return total;
 }
 
 }   // namespace hry

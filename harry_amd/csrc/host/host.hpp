@@ -84,9 +84,10 @@ struct BorderSnapshot {
 	std::vector<uint8_t> seen;                // min(triangles seen at the vertex, 9)
 	std::vector<uint32_t> orig;               // (walk on two cores only: the elements' vertices in the mesh's numbering, until the counts are filled in)
 };
-constexpr uint32_t kSnapshotMinFaces = 1u << 18;
-// spacing of the snapshots for a container that describes nf faces: at least 2^18 faces, and at most some thirty snapshots a mesh
-// (a power of two; 0 = none: HRY_NO_SNAPSHOTS).  HRY_SNAPSHOT_FACES overrides (tests: small meshes)
+constexpr uint32_t kSnapshotMinFaces = 1u << 17;
+// spacing of the snapshots for a container that describes nf faces: at least 2^17 faces (0.9 ms of replay on a core of the test
+// boxes: eight stretches for the million triangles of BASELINE configs[1]), and at most some sixty snapshots a mesh (a power of two;
+// 0 = none: HRY_NO_SNAPSHOTS).  HRY_SNAPSHOT_FACES overrides (tests: small meshes)
 uint32_t snapshot_spacing(uint32_t nf);
 // canonical selection, shared by every writer of the container (the oracle restates it)
 // snaps (finished: absolute cursors) / snap_counters: the border snapshots of the walk and, out, per snapshot the older vertices

@@ -1964,8 +1964,8 @@ static std::vector<int64_t> get_runs(const uint8_t *&p, const uint8_t *end, size
 	}
 	return d;
 }
-// spacing of the border snapshots for a container that describes nf faces: at least 2^18 faces, at most some thirty snapshots
-static uint32_t default_snapshot_faces(uint32_t nf) { uint32_t sp = 1u << 18; while ((uint64_t)sp * 32u < nf) sp <<= 1; return sp; }
+// spacing of the border snapshots for a container that describes nf faces: at least 2^17 faces, at most some sixty snapshots
+static uint32_t default_snapshot_faces(uint32_t nf) { uint32_t sp = 1u << 17; while ((uint64_t)sp * 64u < nf) sp <<= 1; return sp; }
 enum : uint32_t { SNAPSHOT_DEFAULT = 0xffffffffu };
 
 static Result *encode_chunked(Mesh &m, uint32_t chunk_syms, uint32_t snapshot_faces = SNAPSHOT_DEFAULT)
@@ -2082,32 +2082,32 @@ static Result *encode_chunked(Mesh &m, uint32_t chunk_syms, uint32_t snapshot_fa
 				w.put<uint32_t>((uint32_t)cs.size());
 				for (auto &c : cs) { w.put<uint32_t>(c.first); w.put<uint32_t>(c.second); }
 			}
-			// the border snapshots: u32 spacing, u32 n; per snapshot 17 u32 like a restart point (flags = 0), u32 n_counters + the
-			// counters, u32 n_parts, u32 n_elements, u32 blob_bytes, the blob, zero bytes up to a multiple of four.  Blob (varints):
-			// per part size << 1 | edge_begin; the vertices as differences from "the vertex before + 1" (before the first: the
-			// snapshot's next vertex) in runs; the triangle counts as differences from the count before (before the first: 3) in runs
+			// the border snapshots: u32 spacing, u32 n, u32 bytes, then `bytes` bytes of varints, then zero bytes up to a multiple of
+			// four counted from the section's first byte.  Per snapshot: symbols consumed per plane group (5) and operation class (8),
+			// next vertex / face / half-edge, the number of counters + the counters, the number of parts and of elements, per part
+			// size << 1 | edge_begin; the vertices as differences from "the vertex before + 1" (before the first: the snapshot's
+			// next vertex) in runs; the triangle counts as differences from the count before (before the first: 3) in runs
 			if (!wr.snaps.empty()) {
-				const size_t sec0 = res->bytes.size();   // (the padding counts from the section's first byte)
-				w.put<uint32_t>(wr.snapshot_faces); w.put<uint32_t>((uint32_t)wr.snaps.size());
+				const size_t sec0 = res->bytes.size();
+				std::vector<uint8_t> body;
 				for (size_t k = 0; k < wr.snaps.size(); ++k) {
 					const SymWriter::Snap &S = wr.snaps[k];
-					for (int g = 0; g < 5; ++g) w.put<uint32_t>(g == 4 && !numtri_coded ? 0u : S.n_grp[g]);
-					for (int i = 0; i < 8; ++i) w.put<uint32_t>(S.n_op[i]);
-					w.put<uint32_t>(S.first_vertex); w.put<uint32_t>(S.first_face); w.put<uint32_t>(he_before[S.first_face]); w.put<uint32_t>(0);
-					w.put<uint32_t>((uint32_t)snap_counters[k].size());
-					for (auto &c : snap_counters[k]) { w.put<uint32_t>(c.first); w.put<uint32_t>(c.second); }
-					w.put<uint32_t>((uint32_t)S.parts.size()); w.put<uint32_t>((uint32_t)S.vtx.size());
-					std::vector<uint8_t> blob;
-					for (uint32_t pt : S.parts) put_varint(blob, pt);
+					for (int g = 0; g < 5; ++g) put_varint(body, g == 4 && !numtri_coded ? 0u : S.n_grp[g]);
+					for (int i = 0; i < 8; ++i) put_varint(body, S.n_op[i]);
+					put_varint(body, S.first_vertex); put_varint(body, S.first_face); put_varint(body, he_before[S.first_face]);
+					put_varint(body, snap_counters[k].size());
+					for (auto &c : snap_counters[k]) { put_varint(body, c.first); put_varint(body, c.second); }
+					put_varint(body, S.parts.size()); put_varint(body, S.vtx.size());
+					for (uint32_t pt : S.parts) put_varint(body, pt);
 					std::vector<int64_t> d(S.vtx.size());
 					for (size_t i = 0; i < d.size(); ++i) d[i] = (int64_t)S.vtx[i] - ((i ? (int64_t)S.vtx[i - 1] : (int64_t)S.first_vertex - 1) + 1);
-					put_runs(blob, d);
+					put_runs(body, d);
 					for (size_t i = 0; i < d.size(); ++i) d[i] = (int64_t)S.seen[i] - (i ? (int64_t)S.seen[i - 1] : 3);
-					put_runs(blob, d);
-					w.put<uint32_t>((uint32_t)blob.size());
-					w.raw(blob.data(), blob.size());
-					while ((res->bytes.size() - sec0) & 3) w.put<uint8_t>(0);
+					put_runs(body, d);
 				}
+				w.put<uint32_t>(wr.snapshot_faces); w.put<uint32_t>((uint32_t)wr.snaps.size()); w.put<uint32_t>((uint32_t)body.size());
+				w.raw(body.data(), body.size());
+				while ((res->bytes.size() - sec0) & 3) w.put<uint8_t>(0);
 			}
 		}
 		std::vector<std::vector<uint8_t>> streams;
@@ -2169,27 +2169,28 @@ static void decode_chunked_body(Mesh *m, const uint8_t *p, size_t n)
 		if (has_snaps) {
 			const uint8_t *sec0 = br.p;
 			(void)br.get<uint32_t>();   // spacing
-			const uint32_t ns = br.get<uint32_t>();
+			const uint32_t ns = br.get<uint32_t>(), nb = br.get<uint32_t>();
+			br.need(nb);
+			const uint8_t *q = br.p, *qe = br.p + nb;
+			auto get32 = [&]() { return (uint32_t)get_varint(q, qe); };
 			for (uint32_t k = 0; k < ns; ++k) {
 				SymReader::Snap S;
-				for (int g = 0; g < 5; ++g) S.n_grp[g] = br.get<uint32_t>();
-				for (int i = 0; i < 8; ++i) S.n_op[i] = br.get<uint32_t>();
-				S.first_vertex = br.get<uint32_t>(); S.first_face = br.get<uint32_t>(); S.first_halfedge = br.get<uint32_t>(); (void)br.get<uint32_t>();
-				const uint32_t nc = br.get<uint32_t>();
-				for (uint32_t j = 0; j < nc; ++j) { uint32_t v = br.get<uint32_t>(), c = br.get<uint32_t>(); S.counters.push_back({ v, c }); }
-				const uint32_t n_parts = br.get<uint32_t>(), n_elems = br.get<uint32_t>(), nb = br.get<uint32_t>();
-				br.need(nb);
-				const uint8_t *q = br.p, *qe = br.p + nb;
-				for (uint32_t i = 0; i < n_parts; ++i) S.parts.push_back((uint32_t)get_varint(q, qe));
+				for (int g = 0; g < 5; ++g) S.n_grp[g] = get32();
+				for (int i = 0; i < 8; ++i) S.n_op[i] = get32();
+				S.first_vertex = get32(); S.first_face = get32(); S.first_halfedge = get32();
+				const uint32_t nc = get32();
+				for (uint32_t j = 0; j < nc; ++j) { uint32_t v = get32(), c = get32(); S.counters.push_back({ v, c }); }
+				const uint32_t n_parts = get32(), n_elems = get32();
+				for (uint32_t i = 0; i < n_parts; ++i) S.parts.push_back(get32());
 				std::vector<int64_t> d = get_runs(q, qe, n_elems);
 				for (size_t i = 0; i < d.size(); ++i) S.vtx.push_back((uint32_t)((i ? (int64_t)S.vtx[i - 1] : (int64_t)S.first_vertex - 1) + 1 + d[i]));
 				d = get_runs(q, qe, n_elems);
 				for (size_t i = 0; i < d.size(); ++i) S.seen.push_back((uint8_t)((i ? (int64_t)S.seen[i - 1] : 3) + d[i]));
-				if (q != qe) throw std::runtime_error("oracle: bytes left in a border snapshot");
-				br.p += nb;
-				while ((br.p - sec0) & 3) (void)br.get<uint8_t>();
 				snaps.push_back(std::move(S));
 			}
+			if (q != qe) throw std::runtime_error("oracle: bytes left in the border snapshots' section");
+			br.p += nb;
+			while ((br.p - sec0) & 3) (void)br.get<uint8_t>();
 		}
 		std::vector<uint32_t> nbytes(nstreams);
 		for (auto &x : nbytes) x = br.get<uint32_t>();

@@ -380,7 +380,7 @@ def test_border_snapshot_section_equals_the_oracles(case):
         assert np.array_equal(back.org(), plain.org()) and np.array_equal(back.twin(), plain.twin())
     # a damaged snapshot is refused by the oracle's decode (it is looked at, not skipped)
     bad = bytearray(ref)
-    at = ref.index(got) + 8 + 4 * 13          # the first snapshot's next vertex
+    at = ref.index(got) + 12 + 13             # the first snapshot's next vertex (behind the section's three words and thirteen one-byte cursors)
     bad[at] ^= 1
     with pytest.raises(Exception):
         op.Mesh.from_hry_chunked(bytes(bad))
