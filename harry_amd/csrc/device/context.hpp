@@ -182,6 +182,7 @@ std::vector<std::vector<uint8_t>> requant_targets(const Mesh &m, const hry_quant
 dev::RequantPlan requant_plan(const AttrList &L, const std::vector<uint8_t> &to);
 // the twins the walk repaired (cbm/encoder.h:150,193-198) into the resident copy: the few entries it names, else the whole array
 void upload_repaired_twins(Context &cx, const Mesh &host, const WalkResult &w, bool patches_only = false);
+uint64_t test_extra(const char *name);   // HRY_TEST_EXTRA_SYMBOLS / _BITS: counted on top of a reference stream's own (tests of the format's limits)
 void encode_compat(Context &cx, Mesh &m, std::vector<uint8_t> &out);
 // A shard coded where it lies in the whole mesh (sharded.cpp: the in-process executor): the mesh handed to encode_chunked is a
 // SKELETON -- the shard's sizes, the lists' formats and bounds, its runs, no arrays; the context's connectivity and record arrays

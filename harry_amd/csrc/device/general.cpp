@@ -168,7 +168,7 @@ void encode_general(Context &cx, Mesh &m, std::vector<uint8_t> &out)
 	Events E;
 	collect_events(m, w, w.n_conn, true, E);
 	cx.timing.host_walk_ms = ms_since(t_walk);
-	if ((uint64_t)E.end_pos >= (1ull << 31)) throw Error(HRY_E_UNSUPPORTED, "more than 2^31 symbols in one compat stream");
+	if ((uint64_t)E.end_pos + test_extra("HRY_TEST_EXTRA_SYMBOLS") >= (1ull << 31)) throw Error(HRY_E_UNSUPPORTED, "more than 2^31 symbols in one compat stream");
 	const uint32_t ns = E.end_pos;
 	const uint32_t vc = (uint32_t)w.order_v.size(), fc = (uint32_t)w.order_f.size();
 
@@ -447,6 +447,7 @@ Mesh *decode_general(Context &cx, const uint8_t *p, size_t n, size_t hdr, std::u
 	for (const AttrList &L : m->lists)
 		for (int c = 0; c < L.ncomp(); ++c) {
 			if (L.stype(c) == C_DOUBLE) throw Error(HRY_E_UNSUPPORTED, "lossless double components are outside the supported subset");
+			if (kTypeSize[L.stype(c)] == 8) throw Error(HRY_E_UNSUPPORTED, "8-byte storage types (more than 32 quantisation bits, lossless 64-bit integers) are outside the supported subset");   // (before the stream is read: the record chains have no such form)
 		}
 	auto t_walk = Clock::now();
 	OrderVec order_v;

@@ -61,3 +61,17 @@ def test_bench_inprocess_mode_two_contexts_on_one_gpu():
     check_common(line, text, 2)
     assert line["rccl_ranks"] == 0 and "in-process" in line["mode"]
     assert line["sharded"]["merged_decode_equals_single_gpu"] is True and len(line["contexts"]) == 2
+
+
+def test_bench_launcher_mode_four_ranks_share_one_generated_mesh():
+    """Round 6: the whole mesh is generated ONCE -- rank 0 builds it and leaves its arrays in shared memory, the other ranks map
+    them -- instead of once per rank (eight generations of 100 M triangles on one node's CPU share never fitted a driver's time
+    limit); four ranks on this box's one device, the same record, nothing left behind in shared memory."""
+    import glob
+    before = set(glob.glob("/dev/shm/hry_bench_*"))
+    line, text = run_bench("--gpus", 4, "--share-device", "--comps-per-gpu", 3, "--steps", 1, "--warmup", 0)
+    check_common(line, text, 4)
+    assert line["rccl_ranks"] == 4 and line["sharded"]["rccl_ranks"] == 4
+    assert line["sharded"]["merged_decode_equals_single_gpu"] is True and line["sharded"]["segments"] == 4
+    assert line["mesh_generated_on"] == "rank 0 (the other ranks map its arrays: shared memory)"
+    assert set(glob.glob("/dev/shm/hry_bench_*")) == before

@@ -116,3 +116,13 @@ def test_fast_event_collection_equals_the_plain_one(tmp_path):
             f.write(sc.obj)
     r = subprocess.run([exe, *files], capture_output=True, text=True, timeout=500)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok %d files" % len(files)), (r.stdout + r.stderr)[-3000:]
+
+
+def test_faces_with_mixed_index_kinds_are_refused():
+    """`f 1/1 2 3`: the reference reads past its index arrays there (formats/obj/reader.rl:212-277); refused with the reason"""
+    head = b"v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvn 0 0 1\nvn 0 1 0\n"
+    for face in (b"f 1/1/1 2 3\n", b"f 1/1/1 2/2/2 3\n", b"f 1//1 2 3//2\n"):
+        with pytest.raises(hc.HryError, match="same kinds of index"):
+            hc.Mesh.from_obj(head + face, "")
+    ok = hc.Mesh.from_obj(head + b"f 1/1/1 2/2/2 3/1/1\n", "")
+    assert ok.nf == 1
