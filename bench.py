@@ -488,7 +488,7 @@ def main():
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 6) if roof["achieved"] else None
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
         # timed program; scripts/collect_profiles.sh collects FETCH_SIZE and WRITE_SIZE in their own passes on this workload)
-        for rnd in ("r5", "r4", "r3", "r2", "r1"):
+        for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
                     tr = json.load(f)["kernels"]
@@ -996,7 +996,7 @@ def cfg4_share_leg(cx):
     ntri = mesh.ntri
     alg = m0.nv * m0.list_stride(1) + 4 * m0.ne + len(out)
     traffic = traffic_raw = traffic_source = None
-    for rnd in ("r5", "r4", "r3"):   # the PMC passes of this very workload (scripts/collect_profiles.sh: leg cfg4share)
+    for rnd in ("r6", "r5", "r4", "r3"):   # the PMC passes of this very workload (scripts/collect_profiles.sh: leg cfg4share)
         if traffic is not None:
             break
         try:
@@ -1108,14 +1108,16 @@ def cfg4_full_leg(cx):
     dom = max(cands, key=cands.get)
     dom_ms = cands[dom]
     traffic = traffic_raw = traffic_source = None
-    try:   # the PMC passes of this very workload (scripts/collect_profiles.sh PART=2: leg cfg4full)
-        with open(os.path.join(ROOT, "profiles", "r5", "cfg4full", "traffic.json")) as f:
-            hit = json.load(f)["kernels"][dom]
-        traffic = 2 * hit["fetch_bytes"] + hit["write_bytes"]
-        traffic_raw = {"FETCH_SIZE_bytes": hit["fetch_bytes"], "WRITE_SIZE_bytes": hit["write_bytes"]}
-        traffic_source = "profiles/r5/cfg4full/traffic.json (rocprofv3 --pmc, separate passes, per pass of the workload; FETCH_SIZE x2 per the gfx950 note)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for rnd in ("r6", "r5"):   # the PMC passes of this very workload (scripts/collect_profiles.sh PART=2: leg cfg4full)
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "cfg4full", "traffic.json")) as f:
+                hit = json.load(f)["kernels"][dom]
+            traffic = 2 * hit["fetch_bytes"] + hit["write_bytes"]
+            traffic_raw = {"FETCH_SIZE_bytes": hit["fetch_bytes"], "WRITE_SIZE_bytes": hit["write_bytes"]}
+            traffic_source = f"profiles/{rnd}/cfg4full/traffic.json (rocprofv3 --pmc, separate passes, per pass of the workload; FETCH_SIZE x2 per the gfx950 note)"
+            break
+        except (OSError, KeyError, ValueError):
+            pass
     res = {"workload": "BASELINE configs[3] / [4] at the named size: 1 024 mixed-polygon components (40 % quads, 5 % pentagons) + 150 000 non-manifold slivers, float32 xyz, lossless, ONE MI355X",
            "triangles": int(ntri), "components": None, "build_s": round(build_s, 1), "cpus_allowed": cpu_allowance(),
            "one_context": {"value": round(ntri / (e + dd) / 1e6, 3), "encode_mtri_s": round(ntri / e / 1e6, 3), "decode_mtri_s": round(ntri / dd / 1e6, 3),
