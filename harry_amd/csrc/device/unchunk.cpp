@@ -618,6 +618,8 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 			size_t mir_waited = 0;
 			if (!cx.up_stream[0]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[0], hipStreamNonBlocking));
 			const hipStream_t mir_stream = cx.up_stream[0];
+			if (!cx.up_stream[1]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[1], hipStreamNonBlocking));
+			const hipStream_t down_stream = cx.up_stream[1];   // the slices' records on their way down
 			struct DropEvents { std::vector<hipEvent_t> &v; ~DropEvents() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } drop_events{ mir_ev };
 			DevBuf &d_patch = cx.d_patch;   // persistent and sized before the pipeline starts: growing it here would synchronise the device (hipFree / hipMalloc) in mid-flight
 			Stager up(cx, cx.stream2);
@@ -758,11 +760,14 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 						HIP_OK(hipEventRecord(ck.b, cx.stream));
 						clocks.push_back(ck);
 						{
+							// (the records come down on a stream of their own, behind the slice's chain: on the chain's stream the next
+							// slice's chain waited for the copy -- 0.1 ms a slice, 30 ms of the 28 M-triangle mesh's 214 slices)
 							Landing L;
 							L.off = (size_t)v_lo * vstride; L.len = ((size_t)v_to - v_lo) * vstride;
-							HIP_OK(hipMemcpyAsync((uint8_t*)cx.h_down + L.off, cx.d_rec[1].as<uint8_t>() + L.off, L.len, hipMemcpyDeviceToHost, cx.stream));
+							HIP_OK(hipStreamWaitEvent(down_stream, ck.b, 0));
+							HIP_OK(hipMemcpyAsync((uint8_t*)cx.h_down + L.off, cx.d_rec[1].as<uint8_t>() + L.off, L.len, hipMemcpyDeviceToHost, down_stream));
 							HIP_OK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
-							HIP_OK(hipEventRecord(L.ev, cx.stream));
+							HIP_OK(hipEventRecord(L.ev, down_stream));
 							landing.push_back(L);
 						}
 						if (trace_on()) fprintf(stderr, "[hry] %8.3f ms  slice [%u, %u) enqueued (replay at face %u)\n", ms_since(t_begin), v_lo, v_to, newest.faces);
@@ -805,9 +810,12 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 		if (count) pc.start();
 		if (spans) {
 			spans->announce_to = &live;   // (the consumer copies a helper's stretch as soon as it is finished)
-			{   // ... from pinned mirrors the helpers fill themselves, where the mesh is small enough for them (128 MB)
+			{   // ... from pinned mirrors the helpers fill themselves, where the mesh is small enough for them: 1 GB (HRY_MIRROR_MAX_MB) --
+				// 30 bytes a triangle, 840 MB for the 28 M triangles of configs[2], kept by the context.  Without them the consumer
+				// thread stages every byte itself: 10 GB/s, 80 ms for that mesh, in front of a chain that the replay no longer holds up
 				const size_t words = (size_t)nf + 1 + 2 * (size_t)ne + nv;
-				if (words * 4 <= ((size_t)128 << 20) && !getenv("HRY_NO_MIRRORS")) {
+				static const size_t max_mb = [] { const char *e = getenv("HRY_MIRROR_MAX_MB"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
+				if (words * 4 <= (max_mb << 20) && !getenv("HRY_NO_MIRRORS")) {
 					cx.h_mirror.ensure(words * 4);
 					uint32_t *p0 = cx.h_mirror.as<uint32_t>();
 					spans->mirror_foff = p0; spans->mirror_org = p0 + (size_t)nf + 1; spans->mirror_twin = spans->mirror_org + ne; spans->mirror_order = spans->mirror_twin + ne;
@@ -839,6 +847,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 	auto drop_clocks = [&] { for (auto &c : clocks) { (void)hipEventDestroy(c.a); (void)hipEventDestroy(c.b); (void)hipEventDestroy(c.p0); (void)hipEventDestroy(c.p1); } };
 	if (replay_error || consumer_error) {
 		(void)hipStreamSynchronize(cx.stream); (void)hipStreamSynchronize(cx.stream2);
+		for (auto &u : cx.up_stream) if (u) (void)hipStreamSynchronize(u);
 		drop_clocks();
 		for (auto &L : landing) (void)hipEventDestroy(L.ev);
 		std::rethrow_exception(replay_error ? replay_error : consumer_error);
