@@ -1809,6 +1809,9 @@ __global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uin
 	// that all of them share ONE L2 -- the records are fetched from memory once, and the components' 2-byte stores into a
 	// 12-byte record meet in one cache instead of three.
 	if (blockIdx.x & 7u) return;
+	// (the chain is a handful of wavefronts on a serial dependency; beside it run hundreds of entropy-decoding wavefronts of the same
+	// decode, and where one of them shares a SIMD with a chain wavefront the arbiter should know which of the two everybody waits for)
+	__builtin_amdgcn_s_setprio(3);
 	const int c = sel.comp[blockIdx.x >> 3];
 	TopoD tp{ cv };
 	const CrossSync none{ nullptr, 0, nullptr, nullptr };   // one component: no other chain to wait for
