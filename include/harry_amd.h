@@ -295,10 +295,13 @@ void hry_walk_free(hry_walk *w);
 int hry_stream_read_host(const void *hry, size_t bytes, hry_mesh **mesh, hry_walk **out);
 
 /* host-only: the decoder-side cut-border replay (cbm::decode, cbm/decoder.h:27-211) of the connectivity symbols a plain
- * walk recorded, as the chunked container carries them (21 byte planes).  use_restart_points != 0: cut the replay at the
+ * walk recorded, as the chunked container carries them (21 byte planes).  use_restart_points 1: cut the replay at the
  * restart points the container directory would hold and replay the spans on several host threads (HRY_HOST_THREADS,
- * HRY_PARALLEL_MIN_FACES).  *mesh gets nv/nf and the rebuilt connectivity; the result holds "order_v", "seg_start",
- * "seg_level" (u32) and "info" = { number of restart points, 0 }. */
+ * HRY_PARALLEL_MIN_FACES); 3: also at the border snapshots INSIDE the components (what hry_walk_run_plain noted every
+ * HRY_SNAPSHOT_FACES faces of a component; through the directory's form and back): spans with placeholders for the border's
+ * half-edges, joined afterwards.  *mesh gets nv/nf and the rebuilt connectivity; the result holds "order_v", "seg_start",
+ * "seg_level" (u32) and "info" = { number of restart points, number of border snapshots }; hry_walk_get(walk, "snap_section")
+ * is the directory section of a walk's snapshots. */
 int hry_walk_replay(const hry_mesh *src, const hry_walk *walk, int use_restart_points, hry_mesh **mesh, hry_walk **out);
 
 /* raw range-coder back end on explicit (l,h,t) triples (arith/coder.h:69-91 + flush :58-67), compat form */
