@@ -11,6 +11,9 @@
 #include <vector>
 
 #include "../../harry_amd/csrc/host/host.hpp"
+#include "../../harry_amd/csrc/host/cbm_replay.hpp"
+#include <atomic>
+#include <thread>
 
 using namespace hry;
 
@@ -142,6 +145,55 @@ int main(int argc, char **argv)
 						}
 						cut_border_replay(par, views, rs, rc, ov_par, ss1, sl1, nullptr, &snaps);
 						if (seq.org != par.org || seq.twin != par.twin || seq.face_off != par.face_off || ov_seq != ov_par || ss0 != ss1 || sl0 != sl1) throw Error(HRY_E_INTERNAL, "replay from the directory's points differs from the sequential replay");
+						// ... and the way the pipelined decode of a triangle mesh takes (device/unchunk.cpp): the calling thread replays the
+						// stretch up to the first snapshot and publishes its progress, helper threads the stretches behind the snapshots
+						// (SnapshotSpans), joined one after the other as they finish; a reader thread plays the consumer
+						int udeg = 0;
+						if (!snaps.empty() && rs.empty() && planes[7].empty() && m2->uniform_degree(udeg) && udeg == 3) {
+							Mesh live_m;
+							skeleton(live_m);
+							live_m.face_off.resize((size_t)live_m.nf + 1); live_m.face_off[0] = 0;
+							live_m.org.resize(live_m.declared_ne);
+							OrderVec ov_live;
+							ov_live.assign(live_m.nv, 0);
+							SnapshotSpans spans(live_m, views, snaps, ov_live.data());   // (sizes the twins)
+							BigVec<uint16_t> seen(live_m.nv, 0);
+							ReplayLive live;
+							live.on_border.assign(live_m.nv, 0);
+							live.interval = 64;
+							std::atomic<bool> stop{ false };
+							uint64_t n_ranges = 0, n_pubs = 0;
+							std::thread consumer([&] {
+								uint64_t seen_seq = 0;
+								for (;;) {
+									while (live.announced.load(std::memory_order_acquire) == seen_seq && !stop.load()) std::this_thread::yield();
+									std::unique_lock<std::mutex> lk(live.mu);
+									const ReplayLive::Pub P = live.pub;
+									n_ranges += live.ranges.size(); live.ranges.clear();
+									live.patches.clear();
+									seen_seq = P.seq;
+									++n_pubs;
+									if (P.done || P.failed || stop.load()) break;
+								}
+							});
+							ReplayCursor cur;
+							std::vector<uint32_t> cf;
+							std::vector<std::pair<uint32_t, uint32_t>> refs;
+							try {
+								spans.announce_to = &live;
+								spans.start(3);
+								BorderEnd end0;
+								size_t cur_end0[21];
+								const bool eom0 = replay_triangles<true>(live_m, views, seen.data(), ov_live.data(), cur, cf, refs, &live, nullptr, spans.spans[0].cur1, spans.spans[0].stop_face, true, nullptr, &end0, cur_end0);
+								if (!eom0) live.publish(cur.face, cur.he, cur.next_id, false);
+								spans.finish(cur, cur_end0, std::move(end0), eom0, &live);
+								live.publish(cur.face, cur.he, cur.next_id, true);
+							} catch (...) { stop.store(true); live.publish(cur.face, cur.he, cur.next_id, true, true); consumer.join(); throw; }
+							consumer.join();
+							ov_live.resize(cur.next_id);
+							if (live_m.org != seq.org || live_m.twin != seq.twin || live_m.face_off != seq.face_off || ov_live != ov_seq || n_ranges != snaps.size())
+								throw Error(HRY_E_INTERNAL, "publishing replay with stretches on helper threads differs from the sequential replay");
+						}
 #if !defined(__SANITIZE_THREAD__)   // (spans started from a damaged directory may overlap: every index is checked against the header's sizes, the result is an error -- but two threads may have written the same word)
 						for (size_t k = 0; k < sec.size() && k < 4000; ++k) {
 							std::vector<uint8_t> bad = sec;
