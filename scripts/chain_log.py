@@ -1,0 +1,53 @@
+"""Development: the hand-over times of every 64-vertex tile of the reconstruction chain (component 0) of the headline mesh,
+from a library built with -DHRY_CHAIN_LOG (scripts/build_variant.sh chainlog -DHRY_CHAIN_LOG; run with
+HRY_LIB=harry_amd/variants/libharry_amd_chainlog.so python scripts/chain_log.py [side]): ticks per tile by the tile's kind."""
+import sys, os, ctypes
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+bench.stay_on_memory_node()
+from harry_amd import codec as hc
+from harry_amd import meshgen as mg
+side = int(sys.argv[1]) if len(sys.argv) > 1 else 708
+g = mg.torus(side, side, seed=2, sigma=1e-4)
+cx = hc.Codec(0)
+m = hc.Mesh.from_arrays(g.verts, g.degrees, g.indices)
+cx.requant(m, [(1, -1, 14)])
+cx.upload(m)
+data = cx.write_hry(m, profile=hc.PROFILE_CHUNKED)
+for it in range(4):
+    d = cx.read_hry(data); del d
+lib = ctypes.CDLL(os.environ["HRY_LIB"])
+nv = side * side
+nt = (nv + 63) // 64
+buf = np.zeros(nt, dtype=np.uint64)
+assert lib.hry_debug_chain_log(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(nt)) == 0
+t = (buf >> np.uint64(16)).astype(np.int64)
+kind = (buf & np.uint64(0xf)).astype(np.int64)
+nh = ((buf >> np.uint64(4)) & np.uint64(0x3f)).astype(np.int64)
+nrow = ((buf >> np.uint64(10)) & np.uint64(0x3f)).astype(np.int64)
+dt = np.diff(t)
+k1 = kind[1:]
+print(f"tiles {nt}; ticks first -> last {t[-1] - t[0]} (with the gaps between launches)")
+gap = dt > 20000          # between launches (pieces)
+print(f"launch gaps: {gap.sum()} of {dt[gap].sum()} ticks; inside launches {dt[~gap].sum()} ticks, {dt[~gap].mean():.0f} per tile")
+names = {0: "unset", 1: "fast", 2: "prepared, heads / out of range", 3: "prepared late", 4: "dense"}
+for k in sorted(set(k1.tolist())):
+    sel = (k1 == k) & ~gap
+    if sel.any():
+        print(f"  {names.get(k, k):32s} n {sel.sum():6d}  mean {dt[sel].mean():8.0f}  median {np.median(dt[sel]):8.0f}  p90 {np.percentile(dt[sel], 90):8.0f}  sum {dt[sel].sum():9d} ({100.0 * dt[sel].sum() / dt[~gap].sum():.1f} %)")
+# fast tiles by what came before them
+for prev in (1, 2):
+    sel = (k1[1:] == 1) & (k1[:-1] == prev) & ~gap[1:]
+    if sel.any(): print(f"  fast after kind {prev}: n {sel.sum()} mean {dt[1:][sel].mean():.0f}")
+sel2 = (k1 == 2) & ~gap
+for h in range(0, 9):
+    s = sel2 & (nh[1:] == h)
+    if s.any(): print(f"  prepared with {h} heads ({nrow[1:][s].mean():.2f} from rows): n {s.sum():6d} mean {dt[s].mean():8.0f}")
+# along the chain: per 1/16 of the mesh
+step = max(1, (nt - 1) // 16)
+for i in range(0, nt - 1, step):
+    s = slice(i, min(nt - 1, i + step))
+    g_ = ~gap[s]
+    kk = k1[s]
+    print(f"  tiles {i:6d}..: {dt[s][g_].mean():7.0f} per tile; fast {np.mean(kk == 1):.2f} heads {np.mean(kk == 2):.2f} late {np.mean(kk == 3):.2f} dense {np.mean(kk == 4):.2f}")
