@@ -378,6 +378,29 @@ constexpr uint32_t kNoLane = 64;
 #else
 #define HRY_CLK(...)
 #endif
+#ifdef HRY_CHAIN_LOG   // development: when every tile of component 0's chain was handed on, and what kind of tile it was (scripts/chain_log.py)
+__device__ unsigned long long g_chain_log[1u << 18];
+__device__ unsigned long long g_chain_marks[1u << 18];   // (-DHRY_CHAIN_MARKS: ticks from the value's arrival to the end of the first run, of the first head, of the tile)
+extern "C" int hry_debug_chain_log(unsigned long long *dst, unsigned n)
+{
+	if (hipDeviceSynchronize() != hipSuccess) return -1;
+	return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_chain_log), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int hry_debug_chain_marks(unsigned long long *dst, unsigned n)
+{
+	if (hipDeviceSynchronize() != hipSuccess) return -1;
+	return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_chain_marks), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#ifdef HRY_CHAIN_MARKS
+#define HRY_MARK(...) __VA_ARGS__
+#else
+#define HRY_MARK(...)
+#endif
+#define HRY_LOG(...) __VA_ARGS__
+#else
+#define HRY_LOG(...)
+#define HRY_MARK(...)
+#endif
 // Chains of different connected components run in ONE launch.  A component that names vertices of an earlier one (shared
 // non-manifold vertices, cbm/encoder.h:79-113,187) reads their reconstructed values from the records; it waits until the chain
 // of that component -- same attribute component -- has PROGRESSED past that vertex: done[] holds, per chain, the first vertex that
@@ -1436,6 +1459,8 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		if (tb + 64 * W < seg_end) request(tb + 64 * W);
 		const uint32_t tile_idx = (tb - t_first) >> 6;
 		bool waited = false;
+		HRY_LOG(uint32_t log_kind = 0;)
+		HRY_MARK(unsigned long long mk0 = 0, mk1 = 0, mk2 = 0;)
 		uint32_t x_prev = 0;    // the value of vertex tb - 1, as handed over by its tile
 		uint32_t x_out = 0;     // the value of this tile's last finished vertex (uniform)
 		auto wait_prev = [&]() {
@@ -1466,6 +1491,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			             : "memory", "scc");
 			if (left == 0u) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); given_up = true; }
 			asm volatile("" ::: "memory");   // ring reads stay behind the wait
+			HRY_MARK(mk0 = __builtin_amdgcn_s_memtime();)
 			x_prev = w & 0xffffu;
 		};
 		const uint32_t v = tb + lane;
@@ -1659,6 +1685,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 						x = rl(val, s);
 						HRY_CLK(asm volatile("" :: "s"(x)); ck_slott += __builtin_amdgcn_s_memtime() - h0t; ++ck_slotn;)
 					}
+					HRY_MARK(if (!mk2) { asm volatile("" :: "s"(x)); mk2 = __builtin_amdgcn_s_memtime(); })
 					++s;
 					continue;
 				}
@@ -1667,13 +1694,49 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				HRY_CLK(++ck_runs; if (s != lo) { ++ck_r2; ck_r2len += e - s; })
 				HRY_CLK(const unsigned long long r0t = __builtin_amdgcn_s_memtime();)
 				x = finish_run(s, e, Fm, x);
+				HRY_MARK(if (!mk1) { asm volatile("" :: "s"(x)); mk1 = __builtin_amdgcn_s_memtime(); })
 				HRY_CLK(asm volatile("" :: "s"(x)); ck_runt += __builtin_amdgcn_s_memtime() - r0t;)
 				s = e;
 			}
 		};
-		if (prepared) {
+		// the hand-over word of an earlier tile: that tile and every one before it are finished
+		auto wait_tile = [&](uint32_t u) {
+			uint32_t spins = 0;
+#pragma nounroll
+			while ((__hip_atomic_load(&sync[kHand0 + (u & (kHand - 1u))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) != ((u + 1u) & 0xffffu)) {
+				if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); given_up = true; break; }
+				if ((spins & 1023u) == 0u && __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { given_up = true; break; }
+			}
+			asm volatile("" ::: "memory");   // ring reads stay behind the wait
+		};
+		uint64_t hm = headmask, alone = rowheads, pfm = rowheads;
+		bool composed = prepared;
+		if (!prepared) {
+			// ---- a tile with many recent sources (small or irregular meshes, the first and the last rings of a closing border).  Most
+			// of them are recent but not of this tile: once the tiles that hold them are finished they are final, and the tile is
+			// prepared THEN, with heads only where a source lies inside the tile itself.  The latest source of the tile's other
+			// vertices lies d tiles back (d = 0: in the tile before this one): the preparation waits for tile t - 1 - d and runs
+			// beside the serial parts of the d tiles between
+			const bool inner = valid && (nc == CR_BIG || (nc != 0u && gap <= (uint32_t)lane - lo && gap <= (uint32_t)lane));   // the source is a vertex of this tile
+			const uint64_t innermask = __ballot(inner);
+			if ((uint32_t)__builtin_popcountll(innermask) <= kMaxHeadsLate) {
+				composed = true;
+				hm = innermask; alone = __ballot(inner && (nc == CR_BIG || far)); pfm = bigmask;
+				const uint32_t back = valid && nc != 0u && !inner ? (gap - (uint32_t)lane - 1u) >> 6 : 0xffffu;   // whole tiles between this one and the vertex's latest source
+				uint32_t d = 0;
+#pragma nounroll
+				for (uint32_t dd = W - 1u; dd >= 1u; --dd) if (!__ballot(back < dd)) { d = dd; break; }
+#ifdef HRY_CHAIN_NO_LATE_OVERLAP
+				d = 0;
+#endif
+				if (d == 0u) wait_prev();
+				else if (tile_idx > d) wait_tile(tile_idx - 1u - d);
+				HRY_LOG(log_kind = 3u | ((uint32_t)__builtin_popcountll(innermask) << 4) | (d << 10);)
+			}
+		}
+		if (composed) {
 			// ---- prepared tile: everything but the heads before the tile before this one is finished
-			Map3 Fm = compose_runs(headmask);
+			Map3 Fm = compose_runs(hm);
 			asm volatile("" : "+v"(Fm.k), "+v"(Fm.A), "+v"(Fm.D));   // the scan is computed before the wait below, not sunk behind it
 			HRY_CLK(++ck_early;)
 #ifndef HRY_CHAIN_NO_FAST_TILES
@@ -1683,16 +1746,25 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			// over -- so the condition pulls back to an interval of x, and the lanes' intervals intersect to ONE: [x_lo, x_lo +
 			// x_width].  All of that is computed HERE, before the wait; behind it are a scalar range test, three instructions for
 			// the tile's values, three scalar ones for the value handed on.  (x outside: the verified path below, as before.)
-			bool fast = false;
-			int32_t x_lo = 0;
-			uint32_t x_width = 0;
+			// (round 6) A tile with ONE head that is evaluated from its record's slots -- a corner of the walk's spiral, one tile in four
+			// of a regular mesh -- is two runs with the head between them: the same test per run (run 2's is about the head's value)
+			// leaves "values of run 1, the head from the ring, values of run 2" behind the wait, without the verified path's scans.
+			bool fast = false, one = false;
+			int32_t x_lo = 0, x2_lo = 0;
+			uint32_t x_width = 0, x2_width = 0, hs = 0;
 			int32_t end_k = 0, end_A = 0, end_D = 0;
-			if (headmask == 0ull) {
+#ifndef HRY_CHAIN_NO_ONE_HEAD
+			const bool one_cand = (hm & (hm - 1ull)) == 0ull && (hm & alone) == 0ull;
+#else
+			const bool one_cand = false;
+#endif
+			if (hm == 0ull || one_cand) {
 				const int32_t hf = (int32_t)uf.half, tp_ = (int32_t)top;
 				int32_t a = two ? max(0, 2 * hf + 1 - (int32_t)p1c) - bo0 : hf + 1 - bo0;
 				int32_t b = two ? min(tp_, 2 * (tp_ - hf) - (int32_t)p1c) - bo0 : tp_ - hf - bo0;
-				if (keepl || !valid) { a = -(1 << 29); b = 1 << 29; }
-				// the map in front of the lane (the tile's first vertex: x itself)
+				if (keepl || !valid || ((hm >> lane) & 1ull)) { a = -(1 << 29); b = 1 << 29; }
+				// the map in front of the lane (the first vertex of the tile, and of the run behind a head: the value itself -- a head's
+				// own map in the scan is the identity)
 				Map3 P;
 				P.k = __builtin_amdgcn_update_dpp(0, Fm.k, 0x138, 0xf, 0xf, false);   // wave_shr:1
 				P.A = __builtin_amdgcn_update_dpp(0, Fm.A, 0x138, 0xf, 0xf, false);
@@ -1703,17 +1775,34 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				const int32_t t = a - P.D, u = b - P.D + 1;
 				int32_t lower = t <= 0 ? 0 : t > room ? 0x7fffffff : (t << P.k) - P.A;
 				int32_t upper = u <= 0 ? -1 : u > room ? 0x7fffffff : (u << P.k) - P.A - 1;
-				fold_bounds<0x111, 0xf>(lower, upper);   // (the scan's six steps: lane 63 ends up with every lane's bounds)
-				fold_bounds<0x112, 0xf>(lower, upper);
-				fold_bounds<0x114, 0xf>(lower, upper);
-				fold_bounds<0x118, 0xf>(lower, upper);
-				fold_bounds<0x142, 0xa>(lower, upper);
-				fold_bounds<0x143, 0xc>(lower, upper);
-				const int32_t L = (int32_t)rl((uint32_t)lower, 63u), U = (int32_t)rl((uint32_t)upper, 63u);
-				fast = U >= L;
-				x_lo = L;
-				x_width = (uint32_t)(U - L);
-				end_k = (int32_t)rl((uint32_t)Fm.k, hi - 1u); end_A = (int32_t)rl((uint32_t)Fm.A, hi - 1u); end_D = (int32_t)rl((uint32_t)Fm.D, hi - 1u);
+				if (hm == 0ull) {
+					fold_bounds<0x111, 0xf>(lower, upper);   // (the scan's six steps: lane 63 ends up with every lane's bounds)
+					fold_bounds<0x112, 0xf>(lower, upper);
+					fold_bounds<0x114, 0xf>(lower, upper);
+					fold_bounds<0x118, 0xf>(lower, upper);
+					fold_bounds<0x142, 0xa>(lower, upper);
+					fold_bounds<0x143, 0xc>(lower, upper);
+					const int32_t L = (int32_t)rl((uint32_t)lower, 63u), U = (int32_t)rl((uint32_t)upper, 63u);
+					fast = U >= L;
+					x_lo = L;
+					x_width = (uint32_t)(U - L);
+					end_k = (int32_t)rl((uint32_t)Fm.k, hi - 1u); end_A = (int32_t)rl((uint32_t)Fm.A, hi - 1u); end_D = (int32_t)rl((uint32_t)Fm.D, hi - 1u);
+				} else if (one_cand) {
+					hs = (uint32_t)__builtin_ctzll(hm);
+					int32_t l1 = (uint32_t)lane < hs ? lower : 0, u1 = (uint32_t)lane < hs ? upper : 0x7fffffff;   // run 1: the lanes below the head
+					int32_t l2 = (uint32_t)lane > hs ? lower : 0, u2 = (uint32_t)lane > hs ? upper : 0x7fffffff;   // run 2: the lanes above it
+					fold_bounds<0x111, 0xf>(l1, u1); fold_bounds<0x111, 0xf>(l2, u2);
+					fold_bounds<0x112, 0xf>(l1, u1); fold_bounds<0x112, 0xf>(l2, u2);
+					fold_bounds<0x114, 0xf>(l1, u1); fold_bounds<0x114, 0xf>(l2, u2);
+					fold_bounds<0x118, 0xf>(l1, u1); fold_bounds<0x118, 0xf>(l2, u2);
+					fold_bounds<0x142, 0xa>(l1, u1); fold_bounds<0x142, 0xa>(l2, u2);
+					fold_bounds<0x143, 0xc>(l1, u1); fold_bounds<0x143, 0xc>(l2, u2);
+					const int32_t L1 = (int32_t)rl((uint32_t)l1, 63u), U1 = (int32_t)rl((uint32_t)u1, 63u), L2 = (int32_t)rl((uint32_t)l2, 63u), U2 = (int32_t)rl((uint32_t)u2, 63u);
+					one = U1 >= L1 && U2 >= L2;
+					x_lo = L1; x_width = (uint32_t)(U1 - L1);
+					x2_lo = L2; x2_width = (uint32_t)(U2 - L2);
+					end_k = (int32_t)rl((uint32_t)Fm.k, hi - 1u); end_A = (int32_t)rl((uint32_t)Fm.A, hi - 1u); end_D = (int32_t)rl((uint32_t)Fm.D, hi - 1u);   // (a head in the last lane: the identity)
+				}
 			}
 			wait_prev();
 			x = x_prev;   // the first vertex of a slice is never chained
@@ -1722,26 +1811,37 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				if (valid) ring[v & mask] = (T)xh;
 				x = (uint32_t)((((int32_t)x + end_A) >> end_k) + end_D);
 				HRY_CLK(++ck_runs; ++ck_fast;)
-			} else serial_part(headmask, rowheads, rowheads, Fm);
+				HRY_LOG(log_kind = prepared ? 1u : 5u | (log_kind & ~0xfu);)
+			} else if (one && (uint32_t)((int32_t)x - x_lo) <= x_width) {
+				const uint32_t xh1 = (uint32_t)((((int32_t)x + Fm.A) >> Fm.k) + Fm.D);
+				if (valid && (uint32_t)lane < hs) ring[v & mask] = (T)xh1;
+				// the head, on its own lane from its record's slots (the vertex before it is in the ring now)
+				const uint32_t h0 = ring[slot0], h1 = ring[slot1], h2 = ring[slot2], h3 = ring[slot3], h4 = ring[slot4], h5 = ring[slot5];
+				const uint32_t q0 = med3_i32((int32_t)(h0 + h1 - h2), 0, (int32_t)top), q1 = med3_i32((int32_t)(h3 + h4 - h5), 0, (int32_t)top);
+				const uint32_t val = uf.apply((q0 + q1 + 1u) >> 1, top) & wrap;
+				const uint32_t xm = rl(val, hs);
+				if ((uint32_t)((int32_t)xm - x2_lo) <= x2_width) {
+					const uint32_t xh2 = (uint32_t)((((int32_t)xm + Fm.A) >> Fm.k) + Fm.D);
+					if (valid && (uint32_t)lane >= hs) ring[v & mask] = (T)((uint32_t)lane == hs ? val : xh2);
+					x = (uint32_t)((((int32_t)xm + end_A) >> end_k) + end_D);
+				} else {
+					if ((uint32_t)lane == hs) ring[v & mask] = (T)val;
+					x = hs + 1u < hi ? finish_run(hs + 1u, hi, Fm, xm) : xm;
+				}
+				HRY_LOG(log_kind = 6u | (log_kind & ~0xfu);)
+			} else { HRY_LOG(if (prepared) log_kind = 2u | (nheads << 4) | ((uint32_t)__builtin_popcountll(rowheads) << 10);) serial_part(hm, alone, pfm, Fm); }
 #else
 			wait_prev();
 			x = x_prev;   // the first vertex of a slice is never chained
-			serial_part(headmask, rowheads, rowheads, Fm);
+			serial_part(hm, alone, pfm, Fm);
 #endif
 		} else {
-			// ---- a tile with many recent sources (small or irregular meshes, the last rings of a closing border).  Most of them
-			// are recent but not of this tile: once the tiles before it are finished they are final, and the tile is prepared THEN,
-			// with heads only where a source lies inside the tile itself
+			// ---- a tile whose vertices need each other: runs are cut where a vertex needs a source inside the run, and prepared
+			// when the vertices before them are final
 			wait_prev();
 			HRY_CLK(++ck_dense;)
-			const bool inner = valid && (nc == CR_BIG || (nc != 0u && gap <= (uint32_t)lane - lo && gap <= (uint32_t)lane));   // the source is a vertex of this tile
-			const uint64_t innermask = __ballot(inner);
-			if ((uint32_t)__builtin_popcountll(innermask) <= kMaxHeadsLate) {
-				x = x_prev;
-				const Map3 Fm = compose_runs(innermask);
-				serial_part(innermask, __ballot(inner && (nc == CR_BIG || far)), bigmask, Fm);
-			} else {
-				// runs are cut where a vertex needs a source inside the run, and prepared when the vertices before them are final
+			{
+				HRY_LOG(log_kind = 4u | ((uint32_t)__builtin_popcountll(bigmask) << 10);)
 				for (uint32_t s = lo; s < hi;) {
 					if ((bigmask >> s) & 1ull) {
 						const uint32_t bj = (uint32_t)__builtin_popcountll(bigmask & ((1ull << s) - 1ull));
@@ -1764,6 +1864,9 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		wait_prev();
 		asm volatile("" ::: "memory");   // the ring writes of this tile are issued before the word that announces them (LDS runs a wavefront's accesses in order)
 		__hip_atomic_store(&sync[kHand0 + (tile_idx & (kHand - 1u))], ((tile_idx + 1u) << 16) | (x_out & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // every lane, the same word: no exec juggling
+		HRY_MARK(if (comp == 0 && lane == 0) { const unsigned long long mk3 = __builtin_amdgcn_s_memtime(); auto d = [&](unsigned long long a, unsigned long long b) { return a && b && b > a ? (b - a > 0xffffull ? 0xffffull : b - a) : 0ull; };
+			g_chain_marks[(tb >> 6) & ((1u << 18) - 1u)] = d(mk0, mk1) | (d(mk0, mk2) << 16) | (d(mk0, mk3) << 32); })
+		HRY_LOG(if (comp == 0 && lane == 0) g_chain_log[(tb >> 6) & ((1u << 18) - 1u)] = ((unsigned long long)__builtin_amdgcn_s_memtime() << 16) | log_kind;)
 		HRY_CLK(const unsigned long long ck_d = __builtin_amdgcn_s_memtime() - ck_t1; ck_serial += ck_d; if (ck_is_clean && ck_runs - ck_runs0 == 1) { ck_clean += ck_d; ++ck_clean_n; })
 		// every 64 tiles, and at the end, the owner of the tile sends the finished values to the records
 		const bool last_tile = tb + 64 >= seg_end;
@@ -1892,11 +1995,12 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 // wavefronts per reconstruction chain (k_unpredict3): HRY_CHAIN_WAVES = 1..8; by default 6 for a large mesh (long rings: more
 // look-ahead for the preparation costs no heads; 5 until a tile without heads got its short serial part, round 5: the preparation
 // grew by the tile's interval, the chain's turn shrank -- 1 M-triangle torus, one launch: 5.20 ms before, 4.86 with five, 4.69 with
-// six, 4.89 with eight), 4 otherwise
+// six, 4.89 with eight; round 6, with the late tiles' preparation beside the tiles before them: 4.85 with six, 4.65 with seven,
+// 4.75 with eight), 4 otherwise
 static uint32_t chain_waves(uint32_t nvtx)
 {
 	static const uint32_t forced = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }();
-	return forced ? forced : nvtx >= (1u << 18) ? 6u : 4u;
+	return forced ? forced : nvtx >= (1u << 18) ? 7u : 4u;
 }
 // ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
 // gave_up: the decode's own give-up word (behind its flag table), or nullptr -- a context that shares its device with others may find

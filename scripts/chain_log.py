@@ -29,9 +29,9 @@ nrow = ((buf >> np.uint64(10)) & np.uint64(0x3f)).astype(np.int64)
 dt = np.diff(t)
 k1 = kind[1:]
 print(f"tiles {nt}; ticks first -> last {t[-1] - t[0]} (with the gaps between launches)")
-gap = dt > 20000          # between launches (pieces)
+gap = (dt > 20000) | (dt < 0)          # between launches (pieces)
 print(f"launch gaps: {gap.sum()} of {dt[gap].sum()} ticks; inside launches {dt[~gap].sum()} ticks, {dt[~gap].mean():.0f} per tile")
-names = {0: "unset", 1: "fast", 2: "prepared, heads / out of range", 3: "prepared late", 4: "dense"}
+names = {0: "unset", 1: "fast", 2: "prepared, heads / out of range", 3: "prepared late", 4: "dense", 5: "prepared late, fast", 6: "one head between two runs"}
 for k in sorted(set(k1.tolist())):
     sel = (k1 == k) & ~gap
     if sel.any():
@@ -50,4 +50,23 @@ for i in range(0, nt - 1, step):
     s = slice(i, min(nt - 1, i + step))
     g_ = ~gap[s]
     kk = k1[s]
-    print(f"  tiles {i:6d}..: {dt[s][g_].mean():7.0f} per tile; fast {np.mean(kk == 1):.2f} heads {np.mean(kk == 2):.2f} late {np.mean(kk == 3):.2f} dense {np.mean(kk == 4):.2f}")
+    print(f"  tiles {i:6d}..: {dt[s][g_].mean():7.0f} per tile; fast {np.mean(kk == 1):.2f} heads {np.mean(kk == 2):.2f} late {np.mean(kk == 3):.2f} late-fast {np.mean(kk == 5):.2f} dense {np.mean(kk == 4):.2f}")
+sel3 = ((k1 == 3) | (k1 == 5)) & ~gap
+for d in range(0, 8):
+    s = sel3 & (nrow[1:] == d)
+    if s.any(): print(f"  prepared late, {d} tiles of overlap: n {s.sum():6d} median {np.median(dt[s]):8.0f}")
+
+if hasattr(lib, "hry_debug_chain_marks") and os.environ.get("MARKS"):
+    mk = np.zeros(nt, dtype=np.uint64)
+    assert lib.hry_debug_chain_marks(mk.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(nt)) == 0
+    a = (mk & np.uint64(0xffff)).astype(np.int64); b = ((mk >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64); c = ((mk >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)
+    print("ticks from the arrival of the value to: the end of the first run | of the first head | of the tile (medians)")
+    for k in (1, 2, 3, 5):
+        for h in range(0, 4):
+            sel = (kind == k) & ((nh == h) if k in (2, 3) else True) & (c > 0)
+            if sel.any() and (h == 0 or k in (2, 3)):
+                print(f"  kind {k} heads {h if k in (2, 3) else '-'}: n {sel.sum():6d}  run {np.median(a[sel]):6.0f}  head {np.median(b[sel]):6.0f}  end {np.median(c[sel]):6.0f}   (tile-to-tile median {np.median(dt[sel[1:] & ~gap]) if (sel[1:] & ~gap).any() else 0:.0f})")
+
+sel = (kind == 1)
+if sel.any() and nh[sel].max() > 0:
+    print("fast tiles by the chain's polls for the descriptor:", {int(k): int((nh[sel] == k).sum()) for k in sorted(set(nh[sel].tolist()))})
