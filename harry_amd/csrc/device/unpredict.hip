@@ -1318,12 +1318,30 @@ __global__ __launch_bounds__(256) void k_chain_records(const uint32_t *cand, con
 // g_chain_timeout (above) is set when a wavefront gave up waiting for another one (a hand-over that takes longer than ~a second
 // is a bug, not load): the grid still drains, and the host turns the flag into an error instead of returning a wrong mesh.
 
+// What the chain's rare paths need, kept in LDS behind the team's words (written once per segment): the out-of-line functions
+// below take a vertex id and the team's words, nothing else.  With their operands as arguments -- the records' base, stride and
+// offset, ring, bounds, the other components' progress table: eleven scalars that have to be live at every call site -- the chain's
+// loop had 36 more of its own values in spill lanes, every one of them a v_readlane on the serial path (- 4 % of the kernel).
+struct ChainCold {
+	const uint8_t *rec;      // records, already at the component's offset
+	const void *ring;
+	CrossSync xs;
+	int32_t stride, q, comp;
+	uint32_t ring_floor, seg_begin;
+	ConnView cv;             // (for the fan walk of a vertex with more candidates than a table row holds)
+	const uint32_t *order_v;
+};
+constexpr uint32_t kCold0 = kHand0 + kHand;                          // (8-byte aligned: 66 words)
+constexpr uint32_t kSync3Words = kCold0 + (sizeof(ChainCold) + 3) / 4;
+__device__ __forceinline__ const ChainCold &chain_cold(const uint32_t *sync) { return *(const ChainCold*)(sync + kCold0); }
+
 // rare: a source older than the LDS ring (or of an earlier launch), read from the records by vertex id.  Out of line on purpose:
 // the chain's hot loop has to stay small enough for the instruction cache.
 template <typename T>
-__device__ __attribute__((noinline)) uint32_t chain_far_value(const uint8_t *addr, uint32_t id, uint32_t seg_begin, uint32_t *sync, const CrossSync &xs, int comp)
+__device__ __attribute__((noinline)) uint32_t chain_far_value(uint32_t id, uint32_t *sync)
 {
-	if (id < seg_begin) wait_owner(xs, comp, id);   // another component's chain (or an earlier slice: no flags, already final)
+	const ChainCold &c = chain_cold(sync);
+	if (id < c.seg_begin) wait_owner(c.xs, c.comp, id);   // another component's chain (or an earlier slice: no flags, already final)
 	else {   // this chain's own output: wait for its flush
 		uint32_t spins = 0;
 #pragma nounroll
@@ -1333,7 +1351,28 @@ __device__ __attribute__((noinline)) uint32_t chain_far_value(const uint8_t *add
 			if (spins > kSpinLimit) { atomicOr(&g_chain_timeout, 2u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
 		}
 	}
-	return (uint32_t)__hip_atomic_load((const T*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return (uint32_t)__hip_atomic_load((const T*)(c.rec + (size_t)id * c.stride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// rare: a vertex with more candidates than a table row holds, predicted by walking its fan
+template <typename T>
+__device__ __attribute__((noinline)) uint32_t chain_fan_pred(uint32_t vb, uint32_t *sync)
+{
+	const ChainCold &c = chain_cold(sync);
+	const TopoD tp{ c.cv };
+	const T *ring = (const T*)c.ring;
+	auto old_value = [&](uint32_t id) -> uint32_t {   // (every source of a vertex that is evaluated on its own is final)
+		if (id >= vb) return 0u;
+		if (id >= c.ring_floor && vb - id <= kRing3 - 64u) return (uint32_t)ring[id & (kRing3 - 1)];
+		return chain_far_value<T>(id, sync);
+	};
+	int64_t acc = 0;
+	uint32_t n = 0;
+	fan_ids(tp, c.order_v[vb], vb, [&](uint32_t a, uint32_t b, uint32_t o) {
+		acc += (int64_t)cm::parallelogram<T>((T)old_value(a), (T)old_value(b), (T)old_value(o), c.q);
+		++n;
+	});
+	return n ? (uint32_t)(T)cm::mean_of(acc, (int64_t)n) : 0u;
 }
 
 struct Map3 { int32_t k, A, D; };   // x -> floor((x + A) / 2^k) + D, 0 <= A < 2^k, k <= 16
@@ -1412,6 +1451,11 @@ __device__ __forceinline__ Map3 scan3_runs(Map3 m)
 // tile's owner has its input with the load that ends its wait (no second LDS round trip, no counter, no s_waitcnt on the
 // serial path).  sync[0] = the chain was given up (a wait ran into its bound), sync[1] = vertices below it have reached global
 // memory.  Every wait is for an earlier tile, whose owner never waits for a later one, so the chain always advances.
+// What is behind the wait, by the tile's kind (ticks per tile on the headline mesh, scripts/chain_log.py): no heads -- a range
+// test and the values (~ 500, the LDS round trip of the hand-over included); one head from its record's slots -- the same per
+// run with the head between them (~ 900); more heads, or a value outside its interval -- runs verified against their true
+// arithmetic, heads one by one (2 000 - 3 500); tiles whose sources are too recent to be prepared ahead -- prepared beside
+// the d tiles that separate them from their latest source (1 700 - 3 300), or run by run when the vertices name each other.
 template <typename T>
 __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uint32_t nvtx_total, uint32_t seg_begin, uint32_t seg_end,
                                    const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec, const uint8_t *planes, uint8_t *rec,
@@ -1430,7 +1474,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	auto old_value = [&](uint32_t id, uint32_t cur) -> uint32_t {
 		if (id >= cur) return 0u;   // the chained source of a vertex inside the run: not final yet, and never used from here
 		if (id >= ring_floor && cur - id <= kRing3Near) return (uint32_t)ring[id & mask];
-		return chain_far_value<T>(rec + (size_t)id * stride + off, id, seg_begin, sync, xs, comp);
+		return chain_far_value<T>(id, sync);
 	};
 	uint4 nx_rec = make_uint4(0, 0, 0, 0);
 	uint32_t nx_b0 = 0, nx_b1 = 0;
@@ -1445,13 +1489,17 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 	};
 	// a slice that continues a chain finds the end of the previous slice in the ring again
 	for (uint32_t b = ring_floor + 64 * wv; b < seg_begin; b += 64 * W) { const uint32_t v = b + lane; if (v < seg_begin) ring[v & mask] = ldq<T>(rec + (size_t)v * stride + off); }
-	if (threadIdx.x == 0) { sync[0] = 0; sync[1] = seg_begin; }
+	if (threadIdx.x == 0) {
+		sync[0] = 0; sync[1] = seg_begin;
+		ChainCold c;
+		c.cv = tp.c; c.order_v = order_v; c.rec = rec + off; c.ring = ring; c.xs = xs; c.stride = stride; c.q = q; c.comp = comp; c.ring_floor = ring_floor; c.seg_begin = seg_begin;
+		*(ChainCold*)(sync + kCold0) = c;
+	}
 	if (threadIdx.x < kHand) sync[kHand0 + threadIdx.x] = 0;
 	__syncthreads();
-	bool given_up = false;
 	HRY_CLK(unsigned long long ck_wait = 0, ck_serial = 0, ck_prep = 0, ck_t0 = 0, ck_t1 = 0, ck_tiles = 0, ck_early = 0, ck_retry = 0, ck_runs = 0, ck_bigs = 0, ck_clean = 0, ck_clean_n = 0, ck_r2 = 0, ck_r2len = 0, ck_r2_8 = 0, ck_r2_16 = 0, ck_r2_32 = 0, ck_r2_afterbig = 0, ck_rowt = 0, ck_rown = 0, ck_fast = 0, ck_slott = 0, ck_slotn = 0, ck_runt = 0, ck_dense = 0, ck_begin = __builtin_amdgcn_s_memtime(); bool ck_is_clean = true;)
 	request(t_first + 64 * wv);
-	for (uint32_t tb = t_first + 64 * wv; tb < seg_end && !given_up; tb += 64 * W) {
+	for (uint32_t tb = t_first + 64 * wv; tb < seg_end; tb += 64 * W) {
 		if (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // another wavefront's wait ran into its bound
 		HRY_CLK(ck_t0 = __builtin_amdgcn_s_memtime(); ++ck_tiles; ck_is_clean = true; const unsigned long long ck_runs0 = ck_runs;)
 		const uint4 cr = nx_rec;
@@ -1485,14 +1533,15 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			             "s_sub_u32 %[left], %[left], 1\n\t"
 			             "s_cmp_lg_u32 %[left], 0\n\t"
 			             "s_cbranch_scc1 1b\n\t"
-			             "2:"
+			             "2:\n\t"
+			             "s_and_b32 %[t], %[w], 0xffff"
 			             : [w] "=&s"(w), [t] "=&s"(tmp_s), [v] "=&v"(tmp_v), [left] "+s"(left)
 			             : [addr] "v"(slot_addr), [want] "s"(want)
 			             : "memory", "scc");
-			if (left == 0u) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); given_up = true; }
+			if (left == 0u) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (the loop ends at its next turn: sync[0])
 			asm volatile("" ::: "memory");   // ring reads stay behind the wait
 			HRY_MARK(mk0 = __builtin_amdgcn_s_memtime();)
-			x_prev = w & 0xffffu;
+			x_prev = tmp_s;
 		};
 		const uint32_t v = tb + lane;
 		const uint32_t lo = seg_begin > tb ? seg_begin - tb : 0u, hi = min(64u, seg_end - tb);
@@ -1532,9 +1581,9 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 					const uint32_t *row = cand_row(cand, nvtx_total, vb, pf_n) + 3 * (lane & 7);
 					pf_a = row[0]; pf_b = row[1]; pf_o = row[2];
 					auto is_far = [&](uint32_t id) { return id < vb && !(id >= ring_floor && vb - id <= kRing3Near); };
-					if (is_far(pf_a)) { pf_va = chain_far_value<T>(rec + (size_t)pf_a * stride + off, pf_a, seg_begin, sync, xs, comp); pf_far |= 1u; }
-					if (is_far(pf_b)) { pf_vb = chain_far_value<T>(rec + (size_t)pf_b * stride + off, pf_b, seg_begin, sync, xs, comp); pf_far |= 2u; }
-					if (is_far(pf_o)) { pf_vo = chain_far_value<T>(rec + (size_t)pf_o * stride + off, pf_o, seg_begin, sync, xs, comp); pf_far |= 4u; }
+					if (is_far(pf_a)) { pf_va = chain_far_value<T>(pf_a, sync); pf_far |= 1u; }
+					if (is_far(pf_b)) { pf_vb = chain_far_value<T>(pf_b, sync); pf_far |= 2u; }
+					if (is_far(pf_o)) { pf_vo = chain_far_value<T>(pf_o, sync); pf_far |= 4u; }
 				}
 			}
 		}
@@ -1608,13 +1657,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 				const uint32_t tot = rl(sum, l0 + 7u) + (n0 >> 1);
 				pred = (T)(n0 == 1u ? tot : n0 == 2u ? tot >> 1 : n0 == 4u ? tot >> 2 : n0 == 8u ? tot >> 3 : div_small(tot, n0));
 			} else {
-				int64_t acc = 0;
-				uint32_t n = 0;
-				fan_ids(tp, order_v[vb], vb, [&](uint32_t a, uint32_t b, uint32_t o) {
-					acc += (int64_t)cm::parallelogram<T>((T)old_value(a, vb), (T)old_value(b, vb), (T)old_value(o, vb), q);
-					++n;
-				});
-				if (n) pred = (T)cm::mean_of(acc, (int64_t)n);
+				pred = (T)chain_fan_pred<T>(vb, sync);
 			}
 			// prediction.h:46-64 through the vertex's own lane (uf holds its residual code)
 			const uint32_t val = uf.apply((uint32_t)pred, top) & wrap;
@@ -1704,8 +1747,8 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			uint32_t spins = 0;
 #pragma nounroll
 			while ((__hip_atomic_load(&sync[kHand0 + (u & (kHand - 1u))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) != ((u + 1u) & 0xffffu)) {
-				if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); given_up = true; break; }
-				if ((spins & 1023u) == 0u && __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { given_up = true; break; }
+				if (++spins > kSpinLimit) { atomicOr(&g_chain_timeout, 1u); __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+				if ((spins & 1023u) == 0u && __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
 			}
 			asm volatile("" ::: "memory");   // ring reads stay behind the wait
 		};
@@ -1750,8 +1793,8 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			// of a regular mesh -- is two runs with the head between them: the same test per run (run 2's is about the head's value)
 			// leaves "values of run 1, the head from the ring, values of run 2" behind the wait, without the verified path's scans.
 			bool fast = false, one = false;
-			int32_t x_lo = 0, x2_lo = 0;
-			uint32_t x_width = 0, x2_width = 0, hs = 0;
+			int32_t x_lo = 0x7fffffff, x1_lo = 0, x2_lo = 0;   // (x_lo: no interval yet -- no 16-bit value passes the test behind the wait)
+			uint32_t x_width = 0, x1_width = 0, x2_width = 0, hs = 0;
 			int32_t end_k = 0, end_A = 0, end_D = 0;
 #ifndef HRY_CHAIN_NO_ONE_HEAD
 			const bool one_cand = (hm & (hm - 1ull)) == 0ull && (hm & alone) == 0ull;
@@ -1784,8 +1827,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 					fold_bounds<0x143, 0xc>(lower, upper);
 					const int32_t L = (int32_t)rl((uint32_t)lower, 63u), U = (int32_t)rl((uint32_t)upper, 63u);
 					fast = U >= L;
-					x_lo = L;
-					x_width = (uint32_t)(U - L);
+					if (fast) { x_lo = L; x_width = (uint32_t)(U - L); }
 					end_k = (int32_t)rl((uint32_t)Fm.k, hi - 1u); end_A = (int32_t)rl((uint32_t)Fm.A, hi - 1u); end_D = (int32_t)rl((uint32_t)Fm.D, hi - 1u);
 				} else if (one_cand) {
 					hs = (uint32_t)__builtin_ctzll(hm);
@@ -1799,20 +1841,20 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 					fold_bounds<0x143, 0xc>(l1, u1); fold_bounds<0x143, 0xc>(l2, u2);
 					const int32_t L1 = (int32_t)rl((uint32_t)l1, 63u), U1 = (int32_t)rl((uint32_t)u1, 63u), L2 = (int32_t)rl((uint32_t)l2, 63u), U2 = (int32_t)rl((uint32_t)u2, 63u);
 					one = U1 >= L1 && U2 >= L2;
-					x_lo = L1; x_width = (uint32_t)(U1 - L1);
+					x1_lo = L1; x1_width = (uint32_t)(U1 - L1);
 					x2_lo = L2; x2_width = (uint32_t)(U2 - L2);
 					end_k = (int32_t)rl((uint32_t)Fm.k, hi - 1u); end_A = (int32_t)rl((uint32_t)Fm.A, hi - 1u); end_D = (int32_t)rl((uint32_t)Fm.D, hi - 1u);   // (a head in the last lane: the identity)
 				}
 			}
 			wait_prev();
 			x = x_prev;   // the first vertex of a slice is never chained
-			if (fast && (uint32_t)((int32_t)x - x_lo) <= x_width) {
+			if ((uint32_t)((int32_t)x - x_lo) <= x_width) {
 				const uint32_t xh = (uint32_t)((((int32_t)x + Fm.A) >> Fm.k) + Fm.D);
 				if (valid) ring[v & mask] = (T)xh;
 				x = (uint32_t)((((int32_t)x + end_A) >> end_k) + end_D);
 				HRY_CLK(++ck_runs; ++ck_fast;)
 				HRY_LOG(log_kind = prepared ? 1u : 5u | (log_kind & ~0xfu);)
-			} else if (one && (uint32_t)((int32_t)x - x_lo) <= x_width) {
+			} else if (one && (uint32_t)((int32_t)x - x1_lo) <= x1_width) {
 				const uint32_t xh1 = (uint32_t)((((int32_t)x + Fm.A) >> Fm.k) + Fm.D);
 				if (valid && (uint32_t)lane < hs) ring[v & mask] = (T)xh1;
 				// the head, on its own lane from its record's slots (the vertex before it is in the ring now)
@@ -1888,7 +1930,7 @@ __global__ __launch_bounds__(512) void k_unpredict3(ConnView cv, const uint32_t 
                                                    uint32_t n_lists)
 {
 	__shared__ T ring3[kRing3];
-	__shared__ uint32_t sync3[kHand0 + kHand];
+	__shared__ __attribute__((aligned(16))) uint32_t sync3[kSync3Words];
 	// (the attribute components of a list on ONE XCD: see k_unpredict2)
 	const uint32_t per = 8u * (uint32_t)sel.n, grp = blockIdx.x / per, r = blockIdx.x % per;
 	const uint32_t list = grp * 8u + (r & 7u);
@@ -1906,7 +1948,7 @@ __global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uin
                                                          const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, uint32_t v_begin, uint32_t v_end, uint32_t ring_floor)
 {
 	__shared__ T ring3[kRing3];
-	__shared__ uint32_t sync3[kHand0 + kHand];
+	__shared__ __attribute__((aligned(16))) uint32_t sync3[kSync3Words];
 	// The chains of the attribute components read the same chain records and write into the same vertex records.  Workgroups
 	// go round-robin over the 8 XCDs (each with its own L2): only every eighth workgroup of the launch carries a chain, so
 	// that all of them share ONE L2 -- the records are fetched from memory once, and the components' 2-byte stores into a
