@@ -885,7 +885,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	launch_chunk_encode(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, cx.d_init.as<uint32_t>(), cx.d_magic.as<MagicEnt>(), cx.d_acc.as<uint64_t>(), d_bits);
 	HIP_OK(hipEventRecord(cx.ev[4], cx.stream));
 	}
-	launch_carry(cx.stream, cx.d_acc.as<uint64_t>(), nw, cx.d_v.as<uint64_t>(), cx.d_summary.as<uint32_t>(), cx.d_bytes.as<uint8_t>());
+	launch_carry(cx.stream, cx.d_acc.as<uint64_t>(), nw, cx.d_v.as<uint64_t>(), cx.d_summary.as<uint32_t>(), cx.d_bytes.as<uint8_t>(), cx.d_cjobs.as<StreamJob>(), d_bits, ns);
 	launch_stream_pack(cx.stream, cx.d_cjobs.as<StreamJob>(), ns, d_bits, nullptr, d_nbytes, cx.d_coffs.as<uint64_t>(), nullptr, false);
 	// (into pinned memory: a copy into a pageable variable returned only when the streams were coded, and the restart points below
 	// -- 17 ms of host work at 100 M triangles -- were selected after the kernels instead of beside them)

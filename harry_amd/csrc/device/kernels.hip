@@ -735,9 +735,23 @@ __device__ __forceinline__ uint32_t carry_row_pair(const CarryRow &row)
 	const unsigned long long X = row.G | row.P, sum = X + row.G;
 	return (sum < X ? 1u : 0u) | (row.P == ~0ull ? 2u : 0u);
 }
-__global__ __launch_bounds__(256) void k_carry_block_summary(const unsigned long long *acc, uint32_t nw, uint32_t *summary)
+// (round 6) The chunked container's streams are numbers of their own, laid out at their CAPACITY: 443 M words of accumulators
+// for 73 M used at 100 M triangles, and the three kernels swept all of it (3.6 GB each way, 2 ms).  A stream's words beyond its
+// bit count are zero -- a block of them generates nothing, propagates nothing and its bytes are never packed -- so the blocks
+// that hold no used word are marked beforehand and leave at once.
+__global__ __launch_bounds__(256) void k_carry_mark_used(const StreamJob *jobs, const uint32_t *stream_bits, uint32_t ns, uint32_t nw, uint8_t *used)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= ns) return;
+	const uint32_t w0 = jobs[i].word_base, n = (stream_bits[i] + 31u) >> 5;   // (the low register's last word included: stream_bits = shifts + 32)
+	if (!n || w0 >= nw) return;
+	const uint32_t w1 = min(nw, w0 + n);
+	for (uint32_t b = (nw - w1) / (uint32_t)kCarryBlock; b <= (nw - 1u - w0) / (uint32_t)kCarryBlock; ++b) used[b] = 1;   // (reversed index nw - 1 - word)
+}
+__global__ __launch_bounds__(256) void k_carry_block_summary(const unsigned long long *acc, uint32_t nw, uint32_t *summary, const uint8_t *used)
 {
 	__shared__ uint32_t sm[4];
+	if (used && !used[blockIdx.x]) { if (threadIdx.x == 0) summary[blockIdx.x] = 0u; return; }   // zeros: no carry out of them, none through them
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t base = blockIdx.x * kCarryBlock + wave * 64u * kCarryRows;
 	uint32_t a = 2u;   // identity: generates nothing, propagates
@@ -781,9 +795,10 @@ __global__ __launch_bounds__(1024) void k_carry_scan_blocks(uint32_t *summary, u
 		carry = (gp & 1u) | (((gp >> 1) & 1u) & carry);
 	}
 }
-__global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *acc, uint32_t nw, const uint32_t *block_carry, uint8_t *bytes)
+__global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *acc, uint32_t nw, const uint32_t *block_carry, uint8_t *bytes, const uint8_t *used)
 {
 	__shared__ uint32_t sm[4];
+	if (used && !used[blockIdx.x]) return;   // (nobody reads the bytes of words no stream uses)
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t base = blockIdx.x * kCarryBlock + wave * 64u * kCarryRows;
 	unsigned long long v[kCarryRows];
@@ -922,13 +937,22 @@ void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s,
 {
 	if (n) hipLaunchKernelGGL(k_low_accumulate, dim3(blocks_for(n, 256)), dim3(256), 0, st, r, s, sym_l, n, (unsigned long long*)acc);
 }
-void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes)
+// jobs / stream_bits (ns streams, device): the streams' places and lengths, for a container of many streams (nullptr: ONE number
+// of nw words).  summary: nw / 1024 + 2 words (the blocks' pairs, behind them the blocks' marks)
+void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes, const StreamJob *jobs, const uint32_t *stream_bits, uint32_t ns)
 {
 	unsigned nb = blocks_for(nw, kCarryBlock);
 	(void)v;   // (the folded words are formed inside the kernels)
-	hipLaunchKernelGGL(k_carry_block_summary, dim3(nb), dim3(256), 0, st, (const unsigned long long*)acc, nw, summary);
+	uint8_t *used = nullptr;
+	static const bool sweep_all = [] { const char *e = getenv("HRY_CARRY_SWEEP_ALL"); return e && *e && *e != '0'; }();
+	if (jobs && stream_bits && ns > 1 && !sweep_all) {
+		used = (uint8_t*)(summary + nb + 1);
+		(void)hipMemsetAsync(used, 0, nb, st);
+		hipLaunchKernelGGL(k_carry_mark_used, dim3(blocks_for(ns, 256)), dim3(256), 0, st, jobs, stream_bits, ns, nw, used);
+	}
+	hipLaunchKernelGGL(k_carry_block_summary, dim3(nb), dim3(256), 0, st, (const unsigned long long*)acc, nw, summary, (const uint8_t*)used);
 	hipLaunchKernelGGL(k_carry_scan_blocks, dim3(1), dim3(1024), 0, st, summary, nb);
-	hipLaunchKernelGGL(k_carry_apply, dim3(nb), dim3(256), 0, st, (const unsigned long long*)acc, nw, summary, bytes);
+	hipLaunchKernelGGL(k_carry_apply, dim3(nb), dim3(256), 0, st, (const unsigned long long*)acc, nw, summary, bytes, (const uint8_t*)used);
 }
 
 }   // namespace dev
