@@ -845,7 +845,7 @@ void encode_chunked(Context &cx, Mesh &m, int chunk_syms, ByteSink &out, const I
 	cx.ensure_magic(max_t0 + CH + 16);
 	cx.d_acc.ensure((size_t)nw * 8);
 	// (no folded copy of the accumulators: the carry kernels fold where they read, kernels.hip)
-	cx.d_summary.ensure(((size_t)nw / 1024 + 2) * 4);
+	cx.d_summary.ensure(((size_t)nw / 1024 + 8) * 4);   // the carry kernels' block pairs and, behind them, their marks of used ranges
 	cx.d_bytes.ensure((size_t)nw * 4);
 	cx.d_csizes.ensure(std::max<size_t>((size_t)ns * 8, 16));   // bits | nbytes
 	cx.d_coffs.ensure(((size_t)ns + 1) * 8);

@@ -737,8 +737,8 @@ __device__ __forceinline__ uint32_t carry_row_pair(const CarryRow &row)
 }
 // (round 6) The chunked container's streams are numbers of their own, laid out at their CAPACITY: 443 M words of accumulators
 // for 73 M used at 100 M triangles, and the three kernels swept all of it (3.6 GB each way, 2 ms).  A stream's words beyond its
-// bit count are zero -- a block of them generates nothing, propagates nothing and its bytes are never packed -- so the blocks
-// that hold no used word are marked beforehand and leave at once.
+// bit count are zero -- a wavefront's 1 024 of them generate nothing, propagate nothing and their bytes are never packed -- so the
+// wavefronts' ranges that hold a used word are marked beforehand and the others load and store nothing.
 __global__ __launch_bounds__(256) void k_carry_mark_used(const StreamJob *jobs, const uint32_t *stream_bits, uint32_t ns, uint32_t nw, uint8_t *used)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -746,23 +746,26 @@ __global__ __launch_bounds__(256) void k_carry_mark_used(const StreamJob *jobs, 
 	const uint32_t w0 = jobs[i].word_base, n = (stream_bits[i] + 31u) >> 5;   // (the low register's last word included: stream_bits = shifts + 32)
 	if (!n || w0 >= nw) return;
 	const uint32_t w1 = min(nw, w0 + n);
-	for (uint32_t b = (nw - w1) / (uint32_t)kCarryBlock; b <= (nw - 1u - w0) / (uint32_t)kCarryBlock; ++b) used[b] = 1;   // (reversed index nw - 1 - word)
+	constexpr uint32_t per = 64u * kCarryRows;   // words of one wavefront
+	for (uint32_t g = (nw - w1) / per; g <= (nw - 1u - w0) / per; ++g) used[g] = 1;   // (reversed index nw - 1 - word)
 }
 __global__ __launch_bounds__(256) void k_carry_block_summary(const unsigned long long *acc, uint32_t nw, uint32_t *summary, const uint8_t *used)
 {
 	__shared__ uint32_t sm[4];
-	if (used && !used[blockIdx.x]) { if (threadIdx.x == 0) summary[blockIdx.x] = 0u; return; }   // zeros: no carry out of them, none through them
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t base = blockIdx.x * kCarryBlock + wave * 64u * kCarryRows;
 	uint32_t a = 2u;   // identity: generates nothing, propagates
-	unsigned long long v[kCarryRows];
+	if (used && !used[blockIdx.x * 4u + wave]) a = 0u;   // zeros: no carry out of them, none through them
+	else {
+		unsigned long long v[kCarryRows];
 #pragma unroll
-	for (int r = 0; r < kCarryRows; ++r) v[r] = carry_word(acc, nw, base + (uint32_t)r * 64u + (63u - lane));   // (every load in flight before the first ballot waits for one)
+		for (int r = 0; r < kCarryRows; ++r) v[r] = carry_word(acc, nw, base + (uint32_t)r * 64u + (63u - lane));   // (every load in flight before the first ballot waits for one)
 #pragma unroll
-	for (int r = 0; r < kCarryRows; ++r) {
-		CarryRow row;
-		carry_row_masks(v[r], row);
-		a = gp_then(a, carry_row_pair(row));
+		for (int r = 0; r < kCarryRows; ++r) {
+			CarryRow row;
+			carry_row_masks(v[r], row);
+			a = gp_then(a, carry_row_pair(row));
+		}
 	}
 	if (lane == 0) sm[wave] = a;
 	__syncthreads();
@@ -798,21 +801,24 @@ __global__ __launch_bounds__(1024) void k_carry_scan_blocks(uint32_t *summary, u
 __global__ __launch_bounds__(256) void k_carry_apply(const unsigned long long *acc, uint32_t nw, const uint32_t *block_carry, uint8_t *bytes, const uint8_t *used)
 {
 	__shared__ uint32_t sm[4];
-	if (used && !used[blockIdx.x]) return;   // (nobody reads the bytes of words no stream uses)
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t base = blockIdx.x * kCarryBlock + wave * 64u * kCarryRows;
+	const bool mine = !used || used[blockIdx.x * 4u + wave];   // (nobody reads the bytes of words no stream uses; zeros hand nothing on)
 	unsigned long long v[kCarryRows];
 	CarryRow row[kCarryRows];
-	uint32_t a = 2u;
+	uint32_t a = mine ? 2u : 0u;
+	if (mine) {
 #pragma unroll
-	for (int r = 0; r < kCarryRows; ++r) v[r] = carry_word(acc, nw, base + (uint32_t)r * 64u + (63u - lane));   // (every load in flight before the first ballot waits for one)
+		for (int r = 0; r < kCarryRows; ++r) v[r] = carry_word(acc, nw, base + (uint32_t)r * 64u + (63u - lane));   // (every load in flight before the first ballot waits for one)
 #pragma unroll
-	for (int r = 0; r < kCarryRows; ++r) {
-		carry_row_masks(v[r], row[r]);
-		a = gp_then(a, carry_row_pair(row[r]));
+		for (int r = 0; r < kCarryRows; ++r) {
+			carry_row_masks(v[r], row[r]);
+			a = gp_then(a, carry_row_pair(row[r]));
+		}
 	}
 	if (lane == 0) sm[wave] = a;
 	__syncthreads();
+	if (!mine) return;
 	uint32_t before = 2u;
 	for (uint32_t w = 0; w < wave; ++w) before = gp_then(before, sm[w]);
 	// the carry into this wavefront's first row: the block's, pushed through the wavefronts below
@@ -946,8 +952,8 @@ void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v,
 	uint8_t *used = nullptr;
 	static const bool sweep_all = [] { const char *e = getenv("HRY_CARRY_SWEEP_ALL"); return e && *e && *e != '0'; }();
 	if (jobs && stream_bits && ns > 1 && !sweep_all) {
-		used = (uint8_t*)(summary + nb + 1);
-		(void)hipMemsetAsync(used, 0, nb, st);
+		used = (uint8_t*)(summary + nb + 1);   // (a mark per wavefront: 4 nb bytes behind the nb words of the pairs; summary has nw / 1024 + 2 words)
+		(void)hipMemsetAsync(used, 0, (size_t)nb * 4, st);
 		hipLaunchKernelGGL(k_carry_mark_used, dim3(blocks_for(ns, 256)), dim3(256), 0, st, jobs, stream_bits, ns, nw, used);
 	}
 	hipLaunchKernelGGL(k_carry_block_summary, dim3(nb), dim3(256), 0, st, (const unsigned long long*)acc, nw, summary, (const uint8_t*)used);
