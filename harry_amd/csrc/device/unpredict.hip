@@ -1633,6 +1633,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			const uint32_t vb = tb + s;
 			const uint32_t l0 = fetched ? 8u * bj : 0u;   // lanes l0 .. l0 + 7 hold its candidates
 			const uint32_t n0 = fetched ? rl(pf_n, l0) : (uint32_t)ncand[vb];
+			HRY_LOG(if (comp == 0 && lane == 0 && !HRY_MARK(1 +) 0) { unsigned long long &mk = g_chain_marks[(tb >> 6) & ((1u << 18) - 1u)]; mk = (mk << 8) | (n0 & 0xffu); })
 			T pred = T(0);
 			if (n0 != 0xff) {
 				uint32_t pk = 0;

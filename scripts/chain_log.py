@@ -70,3 +70,13 @@ if hasattr(lib, "hry_debug_chain_marks") and os.environ.get("MARKS"):
 sel = (kind == 1)
 if sel.any() and nh[sel].max() > 0:
     print("fast tiles by the chain's polls for the descriptor:", {int(k): int((nh[sel] == k).sum()) for k in sorted(set(nh[sel].tolist()))})
+
+if hasattr(lib, "hry_debug_chain_marks") and os.environ.get("ROWHEADS"):
+    mk = np.zeros(nt, dtype=np.uint64)
+    assert lib.hry_debug_chain_marks(mk.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(nt)) == 0
+    from collections import Counter
+    c = Counter()
+    for w in mk[mk != 0].tolist():
+        while w:
+            c[w & 0xff] += 1; w >>= 8
+    print("heads evaluated from candidate rows, by their number of candidates (accumulated over the decodes of this run):", dict(sorted(c.items())))
