@@ -1907,6 +1907,9 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 		wait_prev();
 		asm volatile("" ::: "memory");   // the ring writes of this tile are issued before the word that announces them (LDS runs a wavefront's accesses in order)
 		__hip_atomic_store(&sync[kHand0 + (tile_idx & (kHand - 1u))], ((tile_idx + 1u) << 16) | (x_out & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // every lane, the same word: no exec juggling
+#ifndef HRY_CHAIN_NO_SCHED_BARRIER
+		__builtin_amdgcn_sched_barrier(0);   // (the loop's bookkeeping and the flush's test stay behind the store that everybody waits for: the scheduler had put nine of their instructions in front of it)
+#endif
 		HRY_MARK(if (comp == 0 && lane == 0) { const unsigned long long mk3 = __builtin_amdgcn_s_memtime(); auto d = [&](unsigned long long a, unsigned long long b) { return a && b && b > a ? (b - a > 0xffffull ? 0xffffull : b - a) : 0ull; };
 			g_chain_marks[(tb >> 6) & ((1u << 18) - 1u)] = d(mk0, mk1) | (d(mk0, mk2) << 16) | (d(mk0, mk3) << 32); })
 		HRY_LOG(if (comp == 0 && lane == 0) g_chain_log[(tb >> 6) & ((1u << 18) - 1u)] = ((unsigned long long)__builtin_amdgcn_s_memtime() << 16) | log_kind;)
