@@ -1914,7 +1914,17 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			g_chain_marks[(tb >> 6) & ((1u << 18) - 1u)] = d(mk0, mk1) | (d(mk0, mk2) << 16) | (d(mk0, mk3) << 32); })
 		HRY_LOG(if (comp == 0 && lane == 0) g_chain_log[(tb >> 6) & ((1u << 18) - 1u)] = ((unsigned long long)__builtin_amdgcn_s_memtime() << 16) | log_kind;)
 		HRY_CLK(const unsigned long long ck_d = __builtin_amdgcn_s_memtime() - ck_t1; ck_serial += ck_d; if (ck_is_clean && ck_runs - ck_runs0 == 1) { ck_clean += ck_d; ++ck_clean_n; })
-		// every 64 tiles, and at the end, the owner of the tile sends the finished values to the records
+		// The tile's values go to the records, from the ring, by its owner (round 6: until then the owner of every 64th tile sent 4 096
+		// values and fenced -- 8 000 ticks in which it did not prepare its next tile: one tile in 64 arrived 4 000 - 10 000 ticks late, 8 %
+		// of the kernel).  No fence here: the store is complete when this wavefront takes the record it requests at its NEXT turn
+		// (vector memory returns in order: that record's wait covers everything issued before the request), i.e. before it can finish
+		// the tile 2 W behind this one; so when a tile is handed over, every tile 3 W or more before it is in memory, and sync[1] says
+		// so every 64 tiles -- readers of old values are 255 tiles behind.  The last tiles: the kernel's end, or raise_flag()'s fence.
+#ifndef HRY_CHAIN_FLUSH_BLOCKS
+		if (valid) stq<T>(rec + (size_t)v * stride + off, ring[v & mask]);
+		if (((tile_idx + 1u) & 63u) == 0u && tile_idx + 1u > 3u * W && lane == 0)
+			__hip_atomic_fetch_max(&sync[1], t_first + 64u * (tile_idx + 1u - 3u * W), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
 		const bool last_tile = tb + 64 >= seg_end;
 		if (((tile_idx + 1u) & 63u) == 0u || last_tile) {
 			const uint32_t upto = min(tb + 64u, seg_end);
@@ -1923,6 +1933,7 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			__threadfence();   // the stores have reached the device's coherence point (far readers load past their L1)
 			if (lane == 0) __hip_atomic_fetch_max(&sync[1], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // flushes of different wavefronts may finish out of order
 		}
+#endif
 	}
 	HRY_CLK(if (threadIdx.x == 0 && ck_tiles > 100) printf("chain comp %d: tiles %llu (dense %llu, fast %llu) runs %llu at %llu (later runs %llu, mean length %llu), heads from rows %llu at %llu, from slots %llu at %llu, retries %llu clean %llu at %llu | per tile: prep %llu wait %llu serial %llu | total %llu per tile of the team %llu\n", comp, ck_tiles, ck_dense, ck_fast, ck_runs, ck_runt / (ck_runs ? ck_runs : 1), ck_r2, ck_r2len / (ck_r2 ? ck_r2 : 1), ck_rown, ck_rowt / (ck_rown ? ck_rown : 1), ck_slotn, ck_slott / (ck_slotn ? ck_slotn : 1), ck_retry, ck_clean_n, ck_clean / (ck_clean_n ? ck_clean_n : 1),
 	                                    ck_prep / ck_tiles, ck_wait / ck_tiles, ck_serial / ck_tiles, (unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin, ((unsigned long long)__builtin_amdgcn_s_memtime() - ck_begin) / (ck_tiles * W));)
@@ -2042,11 +2053,12 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 // look-ahead for the preparation costs no heads; 5 until a tile without heads got its short serial part, round 5: the preparation
 // grew by the tile's interval, the chain's turn shrank -- 1 M-triangle torus, one launch: 5.20 ms before, 4.86 with five, 4.69 with
 // six, 4.89 with eight; round 6, with the late tiles' preparation beside the tiles before them: 4.85 with six, 4.65 with seven,
-// 4.75 with eight), 4 otherwise
+// 4.75 with eight; with every tile sent to the records by its owner instead of 64 at a time by one: 4.00 with six, 3.64 with
+// seven, 3.47 with eight; 3.44 with ten or twelve, 3.64 with sixteen in a build that allowed them), 4 otherwise
 static uint32_t chain_waves(uint32_t nvtx)
 {
 	static const uint32_t forced = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }();
-	return forced ? forced : nvtx >= (1u << 18) ? 7u : 4u;
+	return forced ? forced : nvtx >= (1u << 18) ? 8u : 4u;
 }
 // ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
 // gave_up: the decode's own give-up word (behind its flag table), or nullptr -- a context that shares its device with others may find

@@ -80,3 +80,27 @@ if hasattr(lib, "hry_debug_chain_marks") and os.environ.get("ROWHEADS"):
         while w:
             c[w & 0xff] += 1; w >>= 8
     print("heads evaluated from candidate rows, by their number of candidates (accumulated over the decodes of this run):", dict(sorted(c.items())))
+
+if os.environ.get("FAST_TAIL"):
+    W = int(os.environ.get("HRY_CHAIN_WAVES", "7"))
+    f = (k1 == 1) & ~gap
+    d = dt[f]
+    print("fast tiles: ticks to the tile before, percentiles 10/25/50/75/90/95/99:", [int(np.percentile(d, p)) for p in (10, 25, 50, 75, 90, 95, 99)])
+    idx = np.nonzero(f)[0] + 1
+    # by the length of the run of fast tiles that ends here
+    runlen = np.zeros(nt, dtype=np.int64)
+    for i in range(1, nt):
+        runlen[i] = runlen[i - 1] + 1 if kind[i] == 1 else 0
+    for r in (1, 2, 3, 4, 5, 6, 7, 8, 10, 14, 20):
+        s = f & (runlen[1:] == r)
+        if s.any(): print(f"  {r:3d}th fast tile in a row: n {s.sum():5d} mean {dt[s].mean():7.0f} median {np.median(dt[s]):7.0f}")
+    s = f & (runlen[1:] > 20)
+    if s.any(): print(f"  beyond the 20th: n {s.sum():5d} mean {dt[s].mean():7.0f} median {np.median(dt[s]):7.0f}")
+    # by what the same wavefront did W tiles earlier (it prepared this tile right after that one)
+    for kk in (1, 2, 6, 3):
+        s = f.copy(); s[:W] = False
+        s[W:] &= (kind[1:][:-W] == kk) if W < nt - 1 else False
+        if s.any(): print(f"  fast tiles whose owner's previous tile was of kind {kk}: n {s.sum():5d} mean {dt[s].mean():7.0f} median {np.median(dt[s]):7.0f}")
+    big = np.nonzero((dt > 4000) & ~gap & (k1 == 1))[0] + 1
+    from collections import Counter
+    print("fast tiles above 4000 ticks:", len(big), "their index mod 64:", dict(sorted(Counter((big % 64).tolist()).items())))
