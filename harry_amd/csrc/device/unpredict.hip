@@ -1251,8 +1251,8 @@ __global__ __launch_bounds__(64) void k_unpredict2(ConnView cv, const uint32_t *
 // are right iff every lane agrees.  The first disagreeing lane is replaced by its true value (a constant map) and the
 // scan is repeated once; a second disagreement finishes the run vertex by vertex.  Results are bit-identical to the
 // sequential evaluation in every case; only the speed depends on the data.
-// Reconstructed values live in an LDS ring of kRing3 entries and are flushed to the records every 4096 vertices, so the
-// chain never waits for a store.
+// Reconstructed values live in an LDS ring of kRing3 entries and go to the records tile by tile, by the tile's owner and behind
+// its hand-over, so the chain never waits for a store.
 // ---------------------------------------------------------------------------------------------------------
 struct alignas(16) ChainRec { uint16_t slot[6]; uint16_t flags; uint16_t pad; };
 constexpr uint32_t kRing3 = 16384;          // ring entries (32 KB of LDS for 16-bit values)
