@@ -945,6 +945,28 @@ void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s,
 }
 // jobs / stream_bits (ns streams, device): the streams' places and lengths, for a container of many streams (nullptr: ONE number
 // of nw words).  summary: nw / 1024 + 2 words (the blocks' pairs, behind them the blocks' marks)
+// Up to four ranges of 32-bit words from PINNED HOST memory into device arrays, by ONE kernel (round 6: the decoder's helper threads
+// leave their stretches of the connectivity in pinned mirrors; as four hipMemcpyAsync per stretch those 24 MB of the headline
+// mesh went up as ~ 45 serialized transfers of 20 - 45 us each, 2 ms in front of the chains of everything behind the first
+// stretch; a kernel reads the host memory over the link with thousands of requests in flight)
+__global__ __launch_bounds__(256) void k_pull_ranges(PullRanges r)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const uint32_t n = r.words[k];
+		const uint32_t *src = r.src[k];
+		uint32_t *dst = r.dst[k];
+		for (uint32_t i = t; i < n; i += step) dst[i] = __builtin_nontemporal_load(src + i);
+	}
+}
+void launch_pull_ranges(hipStream_t st, const PullRanges &r)
+{
+	const uint64_t total = (uint64_t)r.words[0] + r.words[1] + r.words[2] + r.words[3];
+	if (!total) return;
+	const unsigned nb = (unsigned)std::min<uint64_t>(1024, (total + 1023) / 1024);   // four words a thread at least
+	hipLaunchKernelGGL(k_pull_ranges, dim3(nb), dim3(256), 0, st, r);
+}
 void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes, const StreamJob *jobs, const uint32_t *stream_bits, uint32_t ns)
 {
 	unsigned nb = blocks_for(nw, kCarryBlock);

@@ -42,6 +42,8 @@ void launch_model(hipStream_t st, const PlaneJob *jobs, uint32_t njobs, const Ch
                   const MagicEnt *magic, SymRec *rec, uint32_t *sym_l);
 void launch_rchain(hipStream_t st, const SymRec *rec, uint32_t n, uint64_t *r_out, uint32_t *s_out, uint64_t *state);
 void launch_low_accumulate(hipStream_t st, const uint64_t *r, const uint32_t *s, const uint32_t *sym_l, uint32_t n, uint64_t *acc);
+struct PullRanges { uint32_t *dst[4]; const uint32_t *src[4]; uint32_t words[4]; };   // device destinations, pinned host sources (device-visible), 32-bit words each
+void launch_pull_ranges(hipStream_t st, const PullRanges &r);
 void launch_carry(hipStream_t st, const uint64_t *acc, uint32_t nw, uint64_t *v, uint32_t *summary, uint8_t *bytes, const StreamJob *jobs = nullptr, const uint32_t *stream_bits = nullptr, uint32_t ns = 0);
 
 // half-edge twin matching (twins.hip): conn.org / foff (/ eface) resident, twin = output; ws: twin_workspace_bytes

@@ -615,7 +615,7 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 			// slice of the FIRST stretch sat behind a millisecond of the other stretches' transfers -- with an event each, which
 			// stream2 waits for when a publication reaches into them
 			std::vector<hipEvent_t> mir_ev;        // per entry of ranges_up (nullptr: came through stream2)
-			size_t mir_waited = 0;
+			std::vector<char> mir_waited;          // per entry of mir_ev: the second stream waits for it already
 			if (!cx.up_stream[0]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[0], hipStreamNonBlocking));
 			const hipStream_t mir_stream = cx.up_stream[0];
 			if (!cx.up_stream[1]) HIP_OK(hipStreamCreateWithFlags(&cx.up_stream[1], hipStreamNonBlocking));
@@ -664,12 +664,22 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 					hipEvent_t rev = nullptr;
 					if (r.mirrored) {   // (the helper left a pinned copy: four transfers, no copy on this thread)
 						const uint32_t *mf = cx.h_mirror.as<uint32_t>(), *mo = mf + (size_t)nf + 1, *mt = mo + ne, *mv = mt + ne;
+						static const bool pull = !getenv("HRY_NO_PULL");
+						if (pull) {   // one kernel reads the four ranges from the pinned mirrors (HRY_NO_PULL=1: four transfers, as until round 6)
+							PullRanges pr{};
+							pr.dst[0] = cx.d_foff.as<uint32_t>() + r.f0 + 1; pr.src[0] = mf + r.f0 + 1; pr.words[0] = r.f1 - r.f0;
+							pr.dst[1] = cx.d_org.as<uint32_t>() + r.h0; pr.src[1] = mo + r.h0; pr.words[1] = r.h1 - r.h0;
+							pr.dst[2] = cx.d_twin.as<uint32_t>() + r.h0; pr.src[2] = mt + r.h0; pr.words[2] = r.h1 - r.h0;
+							pr.dst[3] = cx.d_order_v.as<uint32_t>() + r.v0; pr.src[3] = mv + r.v0; pr.words[3] = r.v1 - r.v0;
+							launch_pull_ranges(mir_stream, pr);
+						} else {
 						if (r.f1 > r.f0) HIP_OK(hipMemcpyAsync(cx.d_foff.as<uint32_t>() + r.f0 + 1, mf + r.f0 + 1, ((size_t)r.f1 - r.f0) * 4, hipMemcpyHostToDevice, mir_stream));
 						if (r.h1 > r.h0) {
 							HIP_OK(hipMemcpyAsync(cx.d_org.as<uint32_t>() + r.h0, mo + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, mir_stream));
 							HIP_OK(hipMemcpyAsync(cx.d_twin.as<uint32_t>() + r.h0, mt + r.h0, ((size_t)r.h1 - r.h0) * 4, hipMemcpyHostToDevice, mir_stream));
 						}
 						if (r.v1 > r.v0) HIP_OK(hipMemcpyAsync(cx.d_order_v.as<uint32_t>() + r.v0, mv + r.v0, ((size_t)r.v1 - r.v0) * 4, hipMemcpyHostToDevice, mir_stream));
+						}
 						HIP_OK(hipEventCreateWithFlags(&rev, hipEventDisableTiming));
 						HIP_OK(hipEventRecord(rev, mir_stream));
 					} else {
@@ -693,7 +703,15 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 				const ReplayLive::Pub P = newest.done || newest.joined ? newest : hist.front();
 				while (!hist.empty() && hist.front().n_pub <= P.n_pub) hist.pop_front();
 				// (a publication behind the replaying thread's own stretch rests on the helpers' stretches: their transfers first)
-				if (P.joined || P.done) for (; mir_waited < mir_ev.size(); ++mir_waited) if (mir_ev[mir_waited]) HIP_OK(hipStreamWaitEvent(cx.stream2, mir_ev[mir_waited], 0));
+				// (only those that lie below the publication's faces: the fans of its final vertices end there.  Waiting for every
+				// transfer under way -- they arrive in the order the helpers finish, 24 MB within 0.3 ms of each other, a millisecond
+				// on the link -- kept the chain idle until the LAST stretch was up: HRY_MIRROR_WAIT_ALL=1)
+				if (P.joined || P.done) {
+					static const bool wait_all = getenv("HRY_MIRROR_WAIT_ALL") != nullptr;
+					mir_waited.resize(mir_ev.size(), 0);
+					for (size_t i = 0; i < mir_ev.size(); ++i)
+						if (!mir_waited[i] && mir_ev[i] && (wait_all || P.done || ranges_up[i].f0 < P.faces)) { HIP_OK(hipStreamWaitEvent(cx.stream2, mir_ev[i], 0)); mir_waited[i] = 1; }
+				}
 				// finished part of the connectivity -- but for what the helpers' stretches have brought up already
 				if (P.faces > f_up) {
 					std::vector<ReplayLive::Range> by_face(ranges_up);
@@ -868,6 +886,13 @@ static void decode_pipelined(Context &cx, Mesh &mesh, const PlaneView *conn, con
 		float t = 0;
 		if (hipEventElapsedTime(&t, c.a, c.b) == hipSuccess) chain_ms += t;
 		if (hipEventElapsedTime(&t, c.p0, c.p1) == hipSuccess) prep_ms += t;
+		static const bool slices_only = getenv("HRY_TRACE_SLICES") != nullptr;   // (these lines alone: nothing of the trace's own waits inside the decode)
+		if (trace_on() || slices_only) {   // where the slices' kernels lay on the device's clock, from the decode's first event (the payload's upload)
+			float a = 0, b = 0, p0 = 0, p1 = 0;
+			(void)hipEventElapsedTime(&a, cx.ev[1], c.a); (void)hipEventElapsedTime(&b, cx.ev[1], c.b);
+			(void)hipEventElapsedTime(&p0, cx.ev[1], c.p0); (void)hipEventElapsedTime(&p1, cx.ev[1], c.p1);
+			fprintf(stderr, "[hry]   on the device: a slice's candidates %.3f .. %.3f ms, its chain %.3f .. %.3f ms after the connectivity kernel's start\n", p0, p1, a, b);
+		}
 	}
 	drop_clocks();
 	cx.timing.k_chain_ms = chain_ms;
