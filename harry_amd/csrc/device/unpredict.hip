@@ -1402,17 +1402,39 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ Map3 dpp3(const Map3
 	r.D = __builtin_amdgcn_update_dpp(0, m.D, CTRL, ROWMASK, 0xf, false);
 	return r;
 }
-// inclusive scan over the wavefront: lane l gets m_l o m_(l-1) o ... o m_0
-__device__ __forceinline__ Map3 scan3(Map3 m)
+// g after f where f.k + g.k <= 16 is known: no step function to fold (8 instructions instead of 20)
+__device__ __forceinline__ Map3 compose3_small(const Map3 &f, const Map3 &g)
 {
-	m = compose3(dpp3<0x111, 0xf>(m), m);   // row_shr:1
-	m = compose3(dpp3<0x112, 0xf>(m), m);   // row_shr:2
-	m = compose3(dpp3<0x114, 0xf>(m), m);   // row_shr:4
-	m = compose3(dpp3<0x118, 0xf>(m), m);   // row_shr:8
+	const int32_t T = f.D + g.A;
+	Map3 h;
+	h.k = f.k + g.k;
+	h.A = f.A + ((T & ((1 << g.k) - 1)) << f.k);
+	h.D = g.D + (T >> g.k);
+	return h;
+}
+// inclusive scan over the wavefront: lane l gets m_l o m_(l-1) o ... o m_0.  SMALL: every lane's k is 0 or 1 (the caller has
+// looked), so the spans of the first four steps -- 2, 4, 8, 16 lanes -- stay at k <= 16 and take the short composition: a tile
+// of a long regular stretch is prepared in ~ 400 instructions, half of them this scan, and eight wavefronts that prepare
+// one tile each are what bounds such a stretch (round 6: every eighth tile of a long row of tiles without heads waited
+// 2 000 ticks for its preparation on the 28 M-triangle torus)
+template <bool SMALL> __device__ __forceinline__ Map3 scan3_t(Map3 m)
+{
+	if (SMALL) {
+		m = compose3_small(dpp3<0x111, 0xf>(m), m);
+		m = compose3_small(dpp3<0x112, 0xf>(m), m);
+		m = compose3_small(dpp3<0x114, 0xf>(m), m);
+		m = compose3_small(dpp3<0x118, 0xf>(m), m);
+	} else {
+		m = compose3(dpp3<0x111, 0xf>(m), m);   // row_shr:1
+		m = compose3(dpp3<0x112, 0xf>(m), m);   // row_shr:2
+		m = compose3(dpp3<0x114, 0xf>(m), m);   // row_shr:4
+		m = compose3(dpp3<0x118, 0xf>(m), m);   // row_shr:8
+	}
 	m = compose3(dpp3<0x142, 0xa>(m), m);   // row_bcast:15 into rows 1 and 3
 	m = compose3(dpp3<0x143, 0xc>(m), m);   // row_bcast:31 into rows 2 and 3
 	return m;
 }
+__device__ __forceinline__ Map3 scan3(Map3 m) { return scan3_t<false>(m); }
 
 // (max of the lower bounds, min of the upper bounds of the lanes a scan step combines; lanes without a partner keep theirs)
 template <int CTRL, int ROWMASK> __device__ __forceinline__ void fold_bounds(int32_t &lower, int32_t &upper)
@@ -1423,25 +1445,26 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ void fold_bounds(int
 
 // segmented: bit 8 of k marks a lane that starts a run; lane l gets m_l o ... o m_s, s = the last start at or below l
 constexpr int32_t kRunStart = 256;
-__device__ __forceinline__ Map3 scan3_runs(Map3 m)
+template <bool SMALL> __device__ __forceinline__ Map3 scan3_runs_t(Map3 m)
 {
-	auto step = [&](const Map3 &p) {
+	auto step = [&](const Map3 &p, bool small) {
 		const bool start = (m.k & kRunStart) != 0;
 		Map3 pm = p, mm = m;
 		pm.k &= kRunStart - 1; mm.k &= kRunStart - 1;
-		Map3 c = compose3(pm, mm);
+		Map3 c = small ? compose3_small(pm, mm) : compose3(pm, mm);
 		c.k |= p.k & kRunStart;   // a start anywhere in the span
 		m.k = start ? m.k : c.k; m.A = start ? m.A : c.A; m.D = start ? m.D : c.D;
 	};
-	step(dpp3<0x111, 0xf>(m));
-	step(dpp3<0x112, 0xf>(m));
-	step(dpp3<0x114, 0xf>(m));
-	step(dpp3<0x118, 0xf>(m));
-	step(dpp3<0x142, 0xa>(m));
-	step(dpp3<0x143, 0xc>(m));
+	step(dpp3<0x111, 0xf>(m), SMALL);
+	step(dpp3<0x112, 0xf>(m), SMALL);
+	step(dpp3<0x114, 0xf>(m), SMALL);
+	step(dpp3<0x118, 0xf>(m), SMALL);
+	step(dpp3<0x142, 0xa>(m), false);
+	step(dpp3<0x143, 0xc>(m), false);
 	m.k &= kRunStart - 1;
 	return m;
 }
+__device__ __forceinline__ Map3 scan3_runs(Map3 m) { return scan3_runs_t<false>(m); }
 
 // Several wavefronts share one chain (blockDim.x / 64 of them): wavefront w owns the tiles t = w (mod W).  A tile whose
 // first run depends on the tiles before it only through its predecessor's value is PREPARED (gathers, maps, scan) while
@@ -1707,6 +1730,14 @@ __device__ void unpredict3_segment(const TopoD &tp, const uint32_t *order_v, uin
 			build_maps(valid && !hd, tb + lo, 64u);
 			Map3 F = g;
 			if (!valid || hd) { F.k = 0; F.A = 0; F.D = 0; }
+#ifndef HRY_CHAIN_FULL_SCANS
+			// (the usual tile: every map is of a lone candidate or of the mean of two -- k = 0 or 1 -- and mostly there is no head)
+			if (!__ballot(F.k > 1)) {
+				if (hm == 0ull) return scan3_t<true>(F);   // one run (the lanes before it hold the identity): no runs' flags either
+				if ((uint32_t)lane == lo || hd || ((hm << 1) >> lane) & 1ull) F.k |= kRunStart;
+				return scan3_runs_t<true>(F);
+			}
+#endif
 			if ((uint32_t)lane == lo || hd || ((hm << 1) >> lane) & 1ull) F.k |= kRunStart;
 			return scan3_runs(F);
 		};
@@ -1959,7 +1990,7 @@ __global__ __launch_bounds__(512) void k_unpredict3(ConnView cv, const uint32_t 
 	}
 }
 template <typename T>
-__global__ __launch_bounds__(512) void k_unpredict3_range(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
+__global__ __launch_bounds__(1024) void k_unpredict3_range(ConnView cv, const uint32_t *order_v, uint32_t nvtx, const uint32_t *cand, const uint8_t *ncand, const ChainRec *crec,
                                                          const uint8_t *planes, ListDesc ld, uint8_t *rec, CompSel sel, uint32_t v_begin, uint32_t v_end, uint32_t ring_floor)
 {
 	__shared__ T ring3[kRing3];
@@ -2054,11 +2085,13 @@ void launch_candidates_ids(hipStream_t st, const ConnView &cv, const uint32_t *o
 // grew by the tile's interval, the chain's turn shrank -- 1 M-triangle torus, one launch: 5.20 ms before, 4.86 with five, 4.69 with
 // six, 4.89 with eight; round 6, with the late tiles' preparation beside the tiles before them: 4.85 with six, 4.65 with seven,
 // 4.75 with eight; with every tile sent to the records by its owner instead of 64 at a time by one: 4.00 with six, 3.64 with
-// seven, 3.47 with eight; 3.44 with ten or twelve, 3.64 with sixteen in a build that allowed them), 4 otherwise
+// seven, 3.47 with eight, 3.44 with ten or twelve, 3.64 with sixteen.  Long regular stretches are bound by the preparation -- a
+// tile takes ~ 5 000 ticks to prepare where two wavefronts share a SIMD, and every W-th tile of a row of tiles without heads
+// waits for it --: the 28 M-triangle torus 98.7 ms with eight, 81.4 with twelve, 80.6 with sixteen: twelve), 4 otherwise
 static uint32_t chain_waves(uint32_t nvtx)
 {
-	static const uint32_t forced = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }();
-	return forced ? forced : nvtx >= (1u << 18) ? 8u : 4u;
+	static const uint32_t forced = [] { const char *e = getenv("HRY_CHAIN_WAVES"); int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : v > 16 ? 16 : v); }();
+	return forced ? forced : nvtx >= (1u << 18) ? 12u : 4u;
 }
 // ---- pipelined decode: one slice [v_begin, v_end) of the vertex chain
 // gave_up: the decode's own give-up word (behind its flag table), or nullptr -- a context that shares its device with others may find
@@ -2122,7 +2155,7 @@ void launch_unpredict2(hipStream_t st, const ConnView &cv, const uint32_t *order
 		CompSel sel{};
 		for (int c = 0; c < ld.ncomp; ++c) if (ld.stype[c] == stype) sel.comp[sel.n++] = c;
 		if (!sel.n) return;
-		hipLaunchKernelGGL(kern, dim3(((n_lists + 7) / 8) * 8 * (uint32_t)sel.n), dim3(64 * chain_waves(nvtx)), 0, st, cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
+		hipLaunchKernelGGL(kern, dim3(((n_lists + 7) / 8) * 8 * (uint32_t)sel.n), dim3(64 * std::min(8u, chain_waves(nvtx))), 0, st,   /* (the kernel of many chains keeps its 512 threads: with 1 024 it would not fit its registers) */ cv, order_v, nvtx, (const uint32_t*)cand, (const uint8_t*)ncand, (const ChainRec*)crec, planes, ld, rec, sel,
 		                   segs, list_off, xs, n_lists);
 	};
 	// the ring + the rows of a tile's many-candidate vertices (64 x 24 words): 38 KB, four chains per compute unit (round 2's input

@@ -11,7 +11,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WAVES = [None, "1", "2", "3", "4", "5", "6", "7", "8"]
+WAVES = [None, "1", "2", "3", "4", "5", "6", "7", "8", "12", "16"]
 
 
 def _run(tool, args, env):
