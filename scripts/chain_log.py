@@ -1,6 +1,10 @@
 """Development: the hand-over times of every 64-vertex tile of the reconstruction chain (component 0) of the headline mesh,
 from a library built with -DHRY_CHAIN_LOG (scripts/build_variant.sh chainlog -DHRY_CHAIN_LOG; run with
-HRY_LIB=harry_amd/variants/libharry_amd_chainlog.so python scripts/chain_log.py [side]): ticks per tile by the tile's kind."""
+HRY_LIB=harry_amd/variants/libharry_amd_chainlog.so python scripts/chain_log.py [side]): ticks per tile by the tile's kind, along
+the chain, by the late tiles' overlap.  FAST_TAIL=1: the slow tail of the tiles without heads (percentiles, by their place in a row of
+such tiles, by what their owner did before, the late ones' indices mod 64 -- how the 64-tile flush and the preparation rate were
+found); ROWHEADS=1: the candidate counts of the heads evaluated from rows; MARKS=1 with a -DHRY_CHAIN_MARKS build: ticks from the
+value's arrival to the end of the first run, of the first head, of the tile."""
 import sys, os, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
