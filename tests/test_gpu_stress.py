@@ -60,3 +60,18 @@ def test_random_obj_scenes_against_the_oracle(seed):
         env["HRY_HOST_EVENTS"] = "1"     # the parallel container's references collected by the host's loop (the device's: events.hip, every other seed)
     r = _run("obj_stress.py", ["20", str(200 + seed)], env)
     assert r.returncode == 0 and r.stdout.strip().endswith("all ok"), (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("waves,whole", [("12", False), ("16", False), ("5", False), ("1", True), ("8", True)])
+def test_headline_mesh_with_every_team_size(waves, whole):
+    """Round 6: the chain's team got late tiles prepared beside their neighbours, a one-head path, tile-by-tile stores and up to
+    sixteen wavefronts -- the full-size mesh (every kind of tile) with several team sizes, in slices beside the replay and as one
+    launch, against the reference-format decode."""
+    env = dict(os.environ, HRY_CHAIN_WAVES=waves)
+    env.pop("HRY_NO_PIPELINE", None)
+    if whole:
+        env["HRY_NO_PIPELINE"] = "1"
+    r = _run("team_sizes.py", ["708"], env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("all equal"), (r.stdout + r.stderr)[-3000:]
